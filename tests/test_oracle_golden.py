@@ -1,0 +1,118 @@
+"""Oracle vs golden vectors captured from the reference (tests/golden/make_golden.py).
+CPU only.  Pins oracle/{metrics,predict,slicer}_ref.py to the reference's own outputs."""
+import os
+import numpy as np
+import pytest
+
+from oracle import metrics_ref, predict_ref, slicer_ref
+
+
+@pytest.fixture(scope='module')
+def G(golden_dir):
+    return {k: np.load(os.path.join(golden_dir, k + '.npz')) for k in ('losses', 'predict', 'slicer')}
+
+
+def test_losses_and_grads_match_reference(G):
+    g = G['losses']
+    for c in range(int(g['n_cases'])):
+        key = f'c{c}'
+        p, y, axes = g[key + '_p'], g[key + '_y'], list(g[key + '_axes'])
+        w = g[key + '_w'] if key + '_w' in g else None
+        for kind in metrics_ref.KINDS:
+            want = float(g[f'{key}_{kind}'])
+            got = metrics_ref.loss(kind, p, y, w, axes)
+            assert abs(got - want) <= 1e-10 * max(1, abs(want)), (c, kind, got, want)
+            gw = g[f'{key}_{kind}_grad']
+            gg = metrics_ref.loss_grad(kind, p, y, w, axes)
+            assert np.allclose(gg, gw, rtol=1e-8, atol=1e-12), (c, kind, np.abs(gg - gw).max())
+        r = metrics_ref.rounded_metrics(p, y, w, axes)
+        assert np.allclose(r, g[key + '_rounded'], rtol=1e-10, atol=1e-12)
+
+
+def test_block_coordinates_bit_exact(G):
+    g = G['predict']
+    for k in range(int(g['n_bc'])):
+        a = g[f'bc{k}_args']
+        b, pb, lb = predict_ref.get_block_coordinates(a[:3], int(a[3]), a[4] / 100.0)
+        assert np.array_equal(b, g[f'bc{k}_b']) and np.array_equal(pb, g[f'bc{k}_pb']) \
+            and np.array_equal(lb, g[f'bc{k}_lb']), a
+
+
+def test_c4_block_grid():
+    b, pb, lb = predict_ref.get_block_coordinates((1024,) * 3, 128, 0.25)
+    assert len(pb) == 1331 and tuple(pb[0][:3]) == (-32,) * 3 and tuple(pb[-1][3:]) == (1056,) * 3
+
+
+def test_padded_block_and_reflect(G):
+    g = G['predict']
+    vol = g['pad_vol']
+    for i, c in enumerate(g['pad_coords']):
+        assert np.array_equal(predict_ref.get_padded_block(vol, *c), g[f'pad{i}'])
+    for n in (1, 2, 7, 16):
+        assert np.array_equal(predict_ref.reflect_index(g['reflect_idx'], n), g[f'reflect_{n}'])
+
+
+def test_windows(G):
+    g = G['predict']
+    for S in (8, 16, 32):
+        assert np.array_equal(predict_ref.gaussian_3d(S), g[f'gauss{S}'])
+        assert np.allclose(predict_ref.hanning_3d(S), g[f'hann{S}'], rtol=0, atol=0)
+    w = predict_ref.gaussian_3d(128)
+    assert np.array_equal(np.array([w[i, i, i] for i in range(128)]), g['gauss128_diag'])
+    assert np.array_equal(w[64, 64, :], g['gauss128_line'])
+    assert np.array_equal(predict_ref.get_shard_coordinates([300, 260, 129], 128), g['shards_300_260_129_128'])
+    assert np.array_equal(predict_ref.get_shard_coordinates([512] * 3, 256), g['shards_512_256'])
+
+
+def _stub(kind):
+    def softmax(l):
+        e = np.exp(l - l.max(1, keepdims=True))
+        return e / e.sum(1, keepdims=True)
+
+    def f(x):
+        x = x.astype(np.float32)
+        B, _, H, W = x.shape
+        if kind == 0:
+            return softmax(np.concatenate([x, 1 - x], 1))
+        r = (np.arange(H, dtype=np.float32) / H).reshape(1, 1, H, 1)
+        c = (np.arange(W, dtype=np.float32) / W).reshape(1, 1, 1, W)
+        return softmax(np.concatenate([x * (1 + r), x * (0.5 + 2 * c) - 0.3 * r, 0.2 + 0 * x], 1))
+    return f
+
+
+def test_predict_block_2p5d(G):
+    g = G['predict']
+    for k in range(int(g['n_pb'])):
+        S, bs, kind, ncls = [int(v) for v in g[f'pb{k}_args']]
+        out = predict_ref.predict_block(_stub(kind), g[f'pb{k}_block'], ncls, bs, list(g[f'pb{k}_axes']))
+        assert np.allclose(out, g[f'pb{k}_out'], rtol=0, atol=2e-6), np.abs(out - g[f'pb{k}_out']).max()
+
+
+def test_blend_normalise_quantise(G):
+    g = G['predict']
+    fn = lambda blk: predict_ref.predict_block(_stub(1), blk, 3, 8, (0, 1, 2))
+    final, pred, weight = predict_ref.blend_volume(g['blend_volume'], fn, 32, 3, 0.25)
+    assert np.allclose(weight, g['blend_weight'], rtol=1e-6, atol=0)
+    assert np.allclose(pred[::7, ::5, ::3], g['blend_pred_sample'], rtol=0, atol=5e-6)
+    diff = np.abs(final.astype(int) - g['blend_final'].astype(int))
+    # truncating cast: a 1e-6 float wobble in the stub softmax may flip a value sitting on an integer
+    assert diff.max() <= 1 and (diff > 0).mean() < 1e-3
+
+
+def test_slicer_geometry(G):
+    g = G['slicer']
+    ramp, vol = g['ramp'], g['vol']
+    for i in range(int(g['n'])):
+        rot_vec, R, u, v, w = slicer_ref.orientation_vectors(g[f's{i}_rv'])
+        for name, val in (('rotvec', rot_vec), ('rotmat', R), ('u', u), ('v', v), ('w', w)):
+            assert np.array_equal(val, g[f's{i}_{name}']), (i, name)
+        origin = g[f's{i}_origin']
+        assert np.array_equal(slicer_ref.interpolation_coords(u, v, w, origin, 8), g[f's{i}_coords8'])
+        for axis in (0, 1, 2):
+            for order in (0, 1):
+                s = slicer_ref.get_slice(ramp, u, v, w, origin, axis, 24, order)
+                assert np.array_equal(s, g[f's{i}_slice_a{axis}_o{order}']), (i, axis, order)
+        upd = slicer_ref.update_volume(g[f's{i}_upd_data'], vol.copy(), u, v, w, origin, axis=1)
+        assert np.array_equal(upd, g[f's{i}_upd_vol'])
+        # to_dict/from_dict re-derives the vectors from the *normalised* rotation vector (slicer.py:84-92)
+        assert np.array_equal(slicer_ref.orientation_vectors(rot_vec)[2], g[f's{i}_rt_u'])
