@@ -1,0 +1,18 @@
+#!/bin/bash
+# Build libiunet.so for gfx950 (cross-compiles without a GPU).
+set -e
+HERE="$(cd "$(dirname "$0")" && pwd)"
+OUT="$HERE/../lib"
+mkdir -p "$OUT" "$HERE/obj"
+FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-result"
+pids=()
+for f in "$HERE"/*.hip; do
+  o="$HERE/obj/$(basename "${f%.hip}").o"
+  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ "$HERE/common.h" -nt "$o" ]; then
+    hipcc $FLAGS -c "$f" -o "$o" &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]}"; do wait "$p"; done
+hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libiunet.so" "$HERE"/obj/*.o
+echo "built $OUT/libiunet.so"

@@ -1,0 +1,141 @@
+// extern "C" surface of libiunet.so (see include/iunet.h).  Plain pointers and sizes
+// only; the caller (PyTorch-ROCm tensors on the host side) owns every buffer and passes
+// the stream it wants the work ordered on.  No allocation, no synchronisation here.
+#include "common.h"
+#include <cstdarg>
+#include <cstdio>
+
+static thread_local char g_err[512] = "";
+
+void iunet_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+// internal launchers (conv3_mfma.hip, pointwise.hip)
+int iunet_conv3_launch(int dtype, int nd, const void* x, long long x_sstride, void* y, long long y_sstride,
+                       const void* wpk, const float* bias, float* stats, int N, int D, int H, int W, int Cin,
+                       int Cout, int epi, hipStream_t stream);
+int iunet_conv3_tiles(int nd, int N, int D, int H, int W);
+int iunet_pack_conv3_launch(int dtype, const float* w, const float* scale, void* dst, int Cout, int Cin, int taps,
+                            int mode, hipStream_t stream);
+int iunet_first_conv_launch(int dtype, int nd, const void* x, int in_dtype, long long sN, long long sC, long long sD,
+                            long long sH, long long sW, void* y, long long y_sstride, const float* w,
+                            const float* bias, float* stats, int N, int D, int H, int W, int Cin, int Cout, int relu,
+                            hipStream_t stream);
+int iunet_first_conv_blocks(int N, int D, int H, int W);
+int iunet_maxpool_launch(int dtype, int nd, const void* x, long long x_ss, void* y, long long y_ss, int planes, int N,
+                         int Do, int Ho, int Wo, hipStream_t stream);
+int iunet_convT_launch(int dtype, int nd, const void* x, long long x_ss, void* y, long long y_ss, const void* wpk,
+                       const float* bias, int N, int D, int H, int W, int Cin, int Cout, hipStream_t stream);
+int iunet_pack_convT_launch(int dtype, const float* w, void* dst, int Cin, int Cout, int npos, hipStream_t stream);
+int iunet_head_launch(int dtype, const void* x, long long x_ss, int C0, const float* w, const float* bias, int ncls,
+                      float* logits, float* probs, unsigned char* cls, long long oN, long long oC, long long oD,
+                      long long oH, long long oW, float divisor, int accumulate, int N, int D, int H, int W,
+                      hipStream_t stream);
+
+namespace {
+template <typename T>
+__global__ void pack_first_kernel(const float* __restrict__ w, const float* __restrict__ scale, float* __restrict__ dst,
+                                  int Cout, int Cin, int taps) {
+  const int total = Cout * Cin * taps;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int co = i % Cout, r = i / Cout;
+    const int ci = r % Cin, t = r / Cin;
+    float v = w[(co * Cin + ci) * taps + t];
+    if (scale) v *= scale[co];
+    dst[i] = to_f32<T>(from_f32<T>(v));
+  }
+}
+}  // namespace
+
+#define DT_OK(dt) IUNET_REQUIRE((dt) == 0 || (dt) == 1, "dtype must be 0 (f16) or 1 (bf16), got %d", (dt))
+
+extern "C" {
+
+const char* iunet_last_error(void) { return g_err; }
+int iunet_abi_version(void) { return 1; }
+
+int iunet_conv3_num_tiles(int nd, int N, int D, int H, int W) { return iunet_conv3_tiles(nd, N, D, H, W); }
+int iunet_first_conv_num_blocks(int N, int D, int H, int W) { return iunet_first_conv_blocks(N, D, H, W); }
+
+int iunet_pack_conv3(int dtype, const void* w, const void* scale, void* dst, int Cout, int Cin, int taps, int mode,
+                     void* stream) {
+  DT_OK(dtype);
+  IUNET_REQUIRE(w && dst, "pack_conv3: null pointer");
+  IUNET_REQUIRE(taps == 9 || taps == 27, "pack_conv3: taps must be 9 or 27 (got %d)", taps);
+  return iunet_pack_conv3_launch(dtype, (const float*)w, (const float*)scale, dst, Cout, Cin, taps, mode, (hipStream_t)stream);
+}
+
+int iunet_pack_first_conv(int dtype, const void* w, const void* scale, void* dst, int Cout, int Cin, int taps,
+                          void* stream) {
+  DT_OK(dtype);
+  IUNET_REQUIRE(w && dst, "pack_first_conv: null pointer");
+  const int total = Cout * Cin * taps;
+  if (dtype == 0) hipLaunchKernelGGL(pack_first_kernel<f16>, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)w, (const float*)scale, (float*)dst, Cout, Cin, taps);
+  else hipLaunchKernelGGL(pack_first_kernel<bf16>, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)w, (const float*)scale, (float*)dst, Cout, Cin, taps);
+  IUNET_CHECK_HIP(hipGetLastError());
+  return IUNET_OK;
+}
+
+int iunet_pack_convT(int dtype, const void* w, void* dst, int Cin, int Cout, int npos, void* stream) {
+  DT_OK(dtype);
+  IUNET_REQUIRE(w && dst, "pack_convT: null pointer");
+  IUNET_REQUIRE(npos == 4 || npos == 8, "pack_convT: npos must be 4 or 8");
+  IUNET_REQUIRE(Cin % 32 == 0 && Cout % 32 == 0, "pack_convT: channels must be multiples of 32");
+  return iunet_pack_convT_launch(dtype, (const float*)w, dst, Cin, Cout, npos, (hipStream_t)stream);
+}
+
+int iunet_conv3_fwd(int dtype, int nd, const void* x, long long x_sstride, void* y, long long y_sstride,
+                    const void* wpk, const void* bias, void* stats, int N, int D, int H, int W, int Cin, int Cout,
+                    int epi, void* stream) {
+  DT_OK(dtype);
+  IUNET_REQUIRE(x && y && wpk, "conv3: null pointer");
+  IUNET_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0, "conv3: bad shape %d %d %d %d", N, D, H, W);
+  IUNET_REQUIRE(epi >= 0 && epi <= 2, "conv3: bad epilogue %d", epi);
+  return iunet_conv3_launch(dtype, nd, x, x_sstride, y, y_sstride, wpk, (const float*)bias, (float*)stats, N, D, H, W,
+                            Cin, Cout, epi, (hipStream_t)stream);
+}
+
+int iunet_first_conv_fwd(int dtype, int nd, const void* x, int in_dtype, const long long* in_strides, void* y,
+                         long long y_sstride, const void* w, const void* bias, void* stats, int N, int D, int H, int W,
+                         int Cin, int Cout, int relu, void* stream) {
+  DT_OK(dtype);
+  IUNET_REQUIRE(x && y && w && in_strides, "first_conv: null pointer");
+  IUNET_REQUIRE(in_dtype >= 0 && in_dtype <= 3, "first_conv: bad input dtype %d", in_dtype);
+  IUNET_REQUIRE(nd == 2 || nd == 3, "first_conv: nd must be 2 or 3");
+  IUNET_REQUIRE(nd == 3 || D == 1, "first_conv: 2-D needs D == 1");
+  return iunet_first_conv_launch(dtype, nd, x, in_dtype, in_strides[0], in_strides[1], in_strides[2], in_strides[3],
+                                 in_strides[4], y, y_sstride, (const float*)w, (const float*)bias, (float*)stats, N, D,
+                                 H, W, Cin, Cout, relu, (hipStream_t)stream);
+}
+
+int iunet_maxpool_fwd(int dtype, int nd, const void* x, long long x_ss, void* y, long long y_ss, int C, int N, int Do,
+                      int Ho, int Wo, void* stream) {
+  DT_OK(dtype);
+  IUNET_REQUIRE(x && y, "maxpool: null pointer");
+  IUNET_REQUIRE(C % 8 == 0, "maxpool: C must be a multiple of 8");
+  return iunet_maxpool_launch(dtype, nd, x, x_ss, y, y_ss, C / 8, N, Do, Ho, Wo, (hipStream_t)stream);
+}
+
+int iunet_convT_fwd(int dtype, int nd, const void* x, long long x_ss, void* y, long long y_ss, const void* wpk,
+                    const void* bias, int N, int D, int H, int W, int Cin, int Cout, void* stream) {
+  DT_OK(dtype);
+  IUNET_REQUIRE(x && y && wpk, "convT: null pointer");
+  return iunet_convT_launch(dtype, nd, x, x_ss, y, y_ss, wpk, (const float*)bias, N, D, H, W, Cin, Cout, (hipStream_t)stream);
+}
+
+int iunet_head_fwd(int dtype, const void* x, long long x_ss, int C0, const void* w, const void* bias, int ncls,
+                   void* logits, void* probs, void* cls, const long long* out_strides, float divisor, int accumulate,
+                   int N, int D, int H, int W, void* stream) {
+  DT_OK(dtype);
+  IUNET_REQUIRE(x && w && bias && out_strides, "head: null pointer");
+  IUNET_REQUIRE(C0 % 8 == 0, "head: C0 must be a multiple of 8");
+  return iunet_head_launch(dtype, x, x_ss, C0, (const float*)w, (const float*)bias, ncls, (float*)logits, (float*)probs,
+                           (unsigned char*)cls, out_strides[0], out_strides[1], out_strides[2], out_strides[3],
+                           out_strides[4], divisor, accumulate, N, D, H, W, (hipStream_t)stream);
+}
+
+}  // extern "C"

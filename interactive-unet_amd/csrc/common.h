@@ -1,0 +1,82 @@
+// Common device/host helpers for libiunet (gfx950 only).
+//
+// Activation layout in HBM ("NHWC8c", channel-blocked NHWC): a tensor with C channels
+// (C % 8 == 0) over a D x H x W grid is stored as C/8 planes, each plane
+// [D][H][W][8] with the 8 channels of a block innermost (16 bytes per voxel per
+// plane).  One MFMA operand fragment (16 consecutive x voxels x 8 channels) is then
+// 256 contiguous bytes, LDS images are lane-linear (bank-conflict free for
+// ds_read_b128) and a channel concat is a concatenation of planes (no copy).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef _Float16 f16;
+typedef __bf16 bf16;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// A tensor view: `planes` channel planes of [D][H][W][8] elements starting at `ptr`;
+// consecutive samples are `sample_stride` elements apart (lets a conv read or write a
+// slice of a wider concat buffer).
+struct TView {
+  void* ptr;
+  long long sample_stride;   // elements
+  int planes;                // C/8 of this view
+};
+
+template <typename T> struct Vec8;
+template <> struct Vec8<f16> { typedef f16x8 type; };
+template <> struct Vec8<bf16> { typedef bf16x8 type; };
+
+template <typename T> __device__ __forceinline__ float to_f32(T v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v) { return (T)v; }
+
+template <typename T>
+__device__ __forceinline__ f32x4 mfma16(typename Vec8<T>::type a, typename Vec8<T>::type b, f32x4 c);
+template <>
+__device__ __forceinline__ f32x4 mfma16<f16>(f16x8 a, f16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ f32x4 mfma16<bf16>(bf16x8 a, bf16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+// XCD-aware block remap (cdna_hip_programming.md T1, bijective form): blocks b and b+8
+// share an XCD/L2, so give each XCD a contiguous run of tiles (neighbouring tiles share
+// halo voxels).  Speed only.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + (bid >> 3);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+#define IUNET_OK 0
+#define IUNET_ERR_ARG (-1)
+#define IUNET_ERR_HIP (-2)
+#define IUNET_ERR_UNSUPPORTED (-3)
+#define IUNET_ERR_WORKSPACE (-4)
+
+void iunet_set_error(const char* fmt, ...);
+#define IUNET_CHECK_HIP(expr)                                                        \
+  do {                                                                               \
+    hipError_t _e = (expr);                                                          \
+    if (_e != hipSuccess) {                                                          \
+      iunet_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return IUNET_ERR_HIP;                                                          \
+    }                                                                                \
+  } while (0)
+#define IUNET_REQUIRE(cond, ...)                                                     \
+  do {                                                                               \
+    if (!(cond)) { iunet_set_error(__VA_ARGS__); return IUNET_ERR_ARG; }             \
+  } while (0)

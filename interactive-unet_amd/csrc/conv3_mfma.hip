@@ -1,0 +1,328 @@
+// 3^d convolution (d = 2, 3), stride 1, pad 1, as an im2col-free implicit GEMM on the
+// gfx950 matrix cores.  Used for the forward stage convs and (with repacked weights)
+// for their data gradients.
+//
+// GEMM view (swapped so that the epilogue owns 8 consecutive channels of one voxel):
+//     D[cout][voxel] = sum_{tap, cin} W[cout][tap, cin] * X[tap-shifted voxel][cin]
+//   A operand = packed weights  (rows = 16 couts,  k = 32 cin of one tap)   <- global/L1
+//   B operand = activations     (cols = 16 consecutive x voxels, k = 32 cin) <- LDS
+// One workgroup (4 waves, 256 threads) owns a TZ x TY x TX voxel tile and 16*MI output
+// channels.  Per 32-channel chunk of Cin the input tile plus its 1-voxel halo is staged
+// once into LDS as 4 planes of [pixel][8 ch] (16 B per pixel, the HBM layout itself), and
+// every tap reads its B fragments from that single image at a shifted pixel offset: the
+// 27 (9) taps re-use the LDS bytes, nothing is materialised.  A fragment read is 64 lanes
+// x 16 B = four contiguous 256-B runs, one per plane, planes 0 mod 256 B apart:
+// conflict-free for ds_read_b128 at any pixel shift.
+//
+// Each wave owns 8 voxel fragments (NI = 8) x MI cout tiles: 8*MI MFMA 16x16x32 per tap
+// and chunk against 8 LDS fragment reads and MI weight-fragment loads.
+#include "common.h"
+
+namespace {
+
+template <int ND> struct Tile;
+template <> struct Tile<3> { static constexpr int TZ = 4, TY = 8, TX = 16, PADZ = 1, TAPS = 27; };
+template <> struct Tile<2> { static constexpr int TZ = 1, TY = 16, TX = 32, PADZ = 0, TAPS = 9; };
+
+struct Conv3Params {
+  const void* x;  long long x_sstride;        // input view (Cin/8 planes)
+  void* y;        long long y_sstride;        // output view (Cout/8 planes)
+  const void* wpk;                            // packed weights [cob][chunk][tap][MI][64][8]
+  const float* bias;                          // [Cout] or null
+  float* stats;                               // [ntiles][Cout][2] partial sum / sumsq, or null
+  int N, D, H, W, Cin, Cout;
+  int tilesZ, tilesY, tilesX;                 // tiles per sample along each axis
+  int epi;                                    // 0 none, 1 +bias, 2 +bias,relu
+};
+
+enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_RELU = 2 };
+
+template <typename T, int ND, int MI>
+__global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(Conv3Params p) {
+  using TL = Tile<ND>;
+  using V8 = typename Vec8<T>::type;
+  constexpr int TZ = TL::TZ, TY = TL::TY, TX = TL::TX, PADZ = TL::PADZ;
+  constexpr int PZ = TZ + 2 * PADZ, PY = TY + 2, PX = TX + 2;
+  constexpr int NPIX = PZ * PY * PX;
+  constexpr int PLANE = ((NPIX * 16 + 255) / 256) * 256;   // bytes, 0 mod 256
+  constexpr int FX = TX / 16;                               // x fragments per row
+  constexpr int NI = 8;
+  static_assert(TZ * TY * FX == 32, "tile must hold 32 fragments (4 waves x 8)");
+  constexpr int KD = (ND == 3) ? 3 : 1;
+
+  extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int l15 = lane & 15, q = lane >> 4;
+
+  // ---- which tile ----
+  const int tiles_per_sample = p.tilesZ * p.tilesY * p.tilesX;
+  const int ntiles = tiles_per_sample * p.N;
+  const int tile = xcd_remap(blockIdx.x, ntiles);
+  const int n_img = tile / tiles_per_sample;
+  int trem = tile - n_img * tiles_per_sample;
+  const int tz_i = trem / (p.tilesY * p.tilesX);
+  trem -= tz_i * p.tilesY * p.tilesX;
+  const int ty_i = trem / p.tilesX;
+  const int tx_i = trem - ty_i * p.tilesX;
+  const int z0 = tz_i * TZ, y0 = ty_i * TY, x0 = tx_i * TX;
+  const int cob = blockIdx.y;
+
+  const long long plane_stride = (long long)p.D * p.H * p.W * 8;   // elements
+  const T* xin = (const T*)p.x + (long long)n_img * p.x_sstride;
+  const int nchunk = p.Cin >> 5;
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int m = 0; m < MI; ++m)
+#pragma unroll
+    for (int n = 0; n < NI; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // per-lane LDS byte address of fragment n at tap (0,0,0)
+  int frag_addr[NI];
+#pragma unroll
+  for (int n = 0; n < NI; ++n) {
+    const int f = wave * NI + n;
+    const int xh = f % FX, row = f / FX;
+    const int fy = row % TY, fz = row / TY;
+    frag_addr[n] = q * PLANE + (((fz * PY + fy) * PX) + xh * 16 + l15) * 16;
+  }
+
+  const V8* wbase = (const V8*)p.wpk + ((long long)cob * nchunk * TL::TAPS * MI) * 64 + lane;
+
+  for (int chunk = 0; chunk < nchunk; ++chunk) {
+    __syncthreads();   // previous chunk's fragment reads are done
+    // ---- stage the halo tile of 32 channels: global -> registers -> LDS ----
+    {
+      const T* xc = xin + (long long)chunk * 4 * plane_stride;
+      constexpr int ITERS = (NPIX + 255) / 256;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        u32x4 v[ITERS][2];
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+          const int pix = tid + it * 256;
+          const int px = pix % PX, t2 = pix / PX;
+          const int py = t2 % PY, pz = t2 / PY;
+          const int gz = z0 + pz - PADZ, gy = y0 + py - 1, gx = x0 + px - 1;
+          const bool ok = (pix < NPIX) && (unsigned)gz < (unsigned)p.D && (unsigned)gy < (unsigned)p.H &&
+                          (unsigned)gx < (unsigned)p.W;
+          const long long goff = (((long long)gz * p.H + gy) * p.W + gx) * 8;
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            u32x4 val = u32x4{0u, 0u, 0u, 0u};
+            if (ok) val = *(const u32x4*)(xc + (half * 2 + k) * plane_stride + goff);
+            v[it][k] = val;
+          }
+        }
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+          const int pix = tid + it * 256;
+          if (pix < NPIX) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+              *(u32x4*)(smem + (half * 2 + k) * PLANE + pix * 16) = v[it][k];
+          }
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- all taps of this chunk ----
+    const V8* wc = wbase + (long long)chunk * TL::TAPS * MI * 64;
+    V8 a_cur[MI];
+#pragma unroll
+    for (int m = 0; m < MI; ++m) a_cur[m] = wc[m * 64];
+#pragma unroll
+    for (int tap = 0; tap < TL::TAPS; ++tap) {
+      V8 a_nxt[MI];
+      if (tap + 1 < TL::TAPS) {
+#pragma unroll
+        for (int m = 0; m < MI; ++m) a_nxt[m] = wc[((tap + 1) * MI + m) * 64];
+      }
+      const int dz = (ND == 3) ? tap / 9 : 0;
+      const int dy = (tap / 3) % 3, dx = tap % 3;
+      const int tapoff = ((dz * PY + dy) * PX + dx) * 16;
+      (void)KD;
+#pragma unroll
+      for (int n = 0; n < NI; ++n) {
+        const V8 b = *(const V8*)(smem + frag_addr[n] + tapoff);
+#pragma unroll
+        for (int m = 0; m < MI; ++m) acc[m][n] = mfma16<T>(a_cur[m], b, acc[m][n]);
+      }
+      if (tap + 1 < TL::TAPS) {
+#pragma unroll
+        for (int m = 0; m < MI; ++m) a_cur[m] = a_nxt[m];
+      }
+    }
+  }
+
+  // ---- epilogue: lane (g = q, x = l15) holds couts 32u+8g+{0..7} of MI/2 plane groups ----
+  T* yout = (T*)p.y + (long long)n_img * p.y_sstride;
+  float s_sum[MI / 2][8], s_sq[MI / 2][8];
+#pragma unroll
+  for (int u = 0; u < MI / 2; ++u)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s_sum[u][j] = 0.f; s_sq[u][j] = 0.f; }
+
+#pragma unroll
+  for (int n = 0; n < NI; ++n) {
+    const int f = wave * NI + n;
+    const int xh = f % FX, row = f / FX;
+    const int fy = row % TY, fz = row / TY;
+    const int gz = z0 + fz, gy = y0 + fy, gx = x0 + xh * 16 + l15;
+    const bool ok = gz < p.D && gy < p.H && gx < p.W;
+    const long long voff = (((long long)gz * p.H + gy) * p.W + gx) * 8;
+#pragma unroll
+    for (int u = 0; u < MI / 2; ++u) {
+      const int cbase = cob * 16 * MI + 32 * u + 8 * q;
+      float vals[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { vals[j] = acc[2 * u][n][j]; vals[4 + j] = acc[2 * u + 1][n][j]; }
+      if (p.stats != nullptr && ok) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s_sum[u][j] += vals[j]; s_sq[u][j] += vals[j] * vals[j]; }
+      }
+      if (p.epi != EPI_NONE) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          vals[j] += p.bias[cbase + j];
+          if (p.epi == EPI_BIAS_RELU) vals[j] = fmaxf(vals[j], 0.f);
+        }
+      }
+      V8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = from_f32<T>(vals[j]);
+      if (ok) {
+        const int plane = (cbase >> 3);
+        *(V8*)(yout + (long long)plane * plane_stride + voff) = o;
+      }
+    }
+  }
+
+  if (p.stats != nullptr) {
+    // reduce over the 16 x-lanes of each q group, then over the 4 waves through LDS
+    __syncthreads();
+    float* red = (float*)smem;   // [4 waves][MI/2][4 q][8][2]
+#pragma unroll
+    for (int u = 0; u < MI / 2; ++u)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float a = s_sum[u][j], b = s_sq[u][j];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+        if (l15 == 0) {
+          const int idx = (((wave * (MI / 2) + u) * 4 + q) * 8 + j) * 2;
+          red[idx] = a; red[idx + 1] = b;
+        }
+      }
+    __syncthreads();
+    constexpr int NCH = 16 * MI;
+    if (tid < NCH * 2) {
+      const int c = tid >> 1, which = tid & 1;          // c = 32u + 8g + j
+      const int u = c >> 5, g = (c >> 3) & 3, j = c & 7;
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) s += red[(((w * (MI / 2) + u) * 4 + g) * 8 + j) * 2 + which];
+      p.stats[((long long)tile * p.Cout + cob * NCH + c) * 2 + which] = s;
+    }
+  }
+}
+
+// ---- weight packing: fp32 [Cout][Cin][taps] -> fragment order, optional per-cout scale ----
+// mode 0: forward weights.  mode 1: data-gradient weights: out channel = original Cin,
+// in channel = original Cout, taps flipped (correlation with the transposed, mirrored filter).
+template <typename T>
+__global__ void pack_conv3_kernel(const float* __restrict__ w, const float* __restrict__ scale, T* __restrict__ dst,
+                                  int CoutP, int CinP, int taps, int MI, int mode, int CoutO, int CinO) {
+  // CoutP / CinP: channels of the packed (possibly transposed) operator; CoutO / CinO: original dims
+  const long long total = (long long)CoutP * CinP * taps;
+  const int nchunk = CinP >> 5;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    long long r = i;
+    const int j = r & 7; r >>= 3;
+    const int lane = r & 63; r >>= 6;
+    const int m = r % MI; r /= MI;
+    const int tap = r % taps; r /= taps;
+    const int chunk = r % nchunk;
+    const int cob = r / nchunk;
+    const int row = lane & 15, qq = lane >> 4;
+    const int co = cob * 16 * MI + 32 * (m >> 1) + 8 * (row >> 2) + 4 * (m & 1) + (row & 3);
+    const int ci = chunk * 32 + 8 * qq + j;
+    float v;
+    if (mode == 0) {
+      v = w[((long long)co * CinO + ci) * taps + tap];
+      if (scale) v *= scale[co];
+    } else {
+      v = w[((long long)ci * CinO + co) * taps + (taps - 1 - tap)];
+    }
+    dst[i] = from_f32<T>(v);
+  }
+}
+
+template <typename T, int ND, int MI>
+int launch_conv3(const Conv3Params& p, hipStream_t stream) {
+  using TL = Tile<ND>;
+  constexpr int PZ = TL::TZ + 2 * TL::PADZ, PY = TL::TY + 2, PX = TL::TX + 2;
+  constexpr int PLANE = ((PZ * PY * PX * 16 + 255) / 256) * 256;
+  constexpr int LDS = 4 * PLANE;
+  static bool attr_set = false;
+  if (!attr_set) {
+    IUNET_CHECK_HIP(hipFuncSetAttribute((const void*)conv3_mfma_kernel<T, ND, MI>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    attr_set = true;
+  }
+  dim3 grid(p.tilesZ * p.tilesY * p.tilesX * p.N, p.Cout / (16 * MI));
+  hipLaunchKernelGGL((conv3_mfma_kernel<T, ND, MI>), grid, dim3(256), LDS, stream, p);
+  IUNET_CHECK_HIP(hipGetLastError());
+  return IUNET_OK;
+}
+
+}  // namespace
+
+// Host entry used by the net runtime and the per-kernel C ABI.
+int iunet_conv3_launch(int dtype, int nd, const void* x, long long x_sstride, void* y, long long y_sstride,
+                       const void* wpk, const float* bias, float* stats, int N, int D, int H, int W, int Cin,
+                       int Cout, int epi, hipStream_t stream) {
+  IUNET_REQUIRE(nd == 2 || nd == 3, "conv3: nd must be 2 or 3 (got %d)", nd);
+  IUNET_REQUIRE(Cin % 32 == 0 && Cout % 32 == 0, "conv3: Cin (%d) and Cout (%d) must be multiples of 32", Cin, Cout);
+  IUNET_REQUIRE(nd == 3 || D == 1, "conv3: 2-D conv needs D == 1");
+  IUNET_REQUIRE(epi == 0 || bias != nullptr, "conv3: epilogue %d needs a bias", epi);
+  Conv3Params p;
+  p.x = x; p.x_sstride = x_sstride; p.y = y; p.y_sstride = y_sstride; p.wpk = wpk; p.bias = bias; p.stats = stats;
+  p.N = N; p.D = D; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.epi = epi;
+  const int TZ = nd == 3 ? 4 : 1, TY = nd == 3 ? 8 : 16, TX = nd == 3 ? 16 : 32;
+  p.tilesZ = (D + TZ - 1) / TZ; p.tilesY = (H + TY - 1) / TY; p.tilesX = (W + TX - 1) / TX;
+  const bool wide = (Cout % 64 == 0);
+#define IUNET_DISPATCH(TT)                                                                   \
+  if (nd == 3) return wide ? launch_conv3<TT, 3, 4>(p, stream) : launch_conv3<TT, 3, 2>(p, stream); \
+  else         return wide ? launch_conv3<TT, 2, 4>(p, stream) : launch_conv3<TT, 2, 2>(p, stream);
+  if (dtype == 0) { IUNET_DISPATCH(f16) } else { IUNET_DISPATCH(bf16) }
+#undef IUNET_DISPATCH
+}
+
+int iunet_conv3_tiles(int nd, int N, int D, int H, int W) {
+  const int TZ = nd == 3 ? 4 : 1, TY = nd == 3 ? 8 : 16, TX = nd == 3 ? 16 : 32;
+  return N * ((D + TZ - 1) / TZ) * ((H + TY - 1) / TY) * ((W + TX - 1) / TX);
+}
+
+int iunet_conv3_mi(int Cout) { return (Cout % 64 == 0) ? 4 : 2; }
+
+int iunet_pack_conv3_launch(int dtype, const float* w, const float* scale, void* dst, int Cout, int Cin, int taps,
+                            int mode, hipStream_t stream) {
+  // mode 0: packed operator is Cout x Cin; mode 1 (dgrad): packed operator is Cin x Cout
+  const int CoutP = mode == 0 ? Cout : Cin, CinP = mode == 0 ? Cin : Cout;
+  IUNET_REQUIRE(CoutP % 32 == 0 && CinP % 32 == 0, "pack_conv3: channel counts must be multiples of 32 (%d, %d)", CoutP, CinP);
+  const int MI = iunet_conv3_mi(CoutP);
+  const long long total = (long long)CoutP * CinP * taps;
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  if (dtype == 0)
+    hipLaunchKernelGGL(pack_conv3_kernel<f16>, dim3(blocks), dim3(256), 0, stream, w, scale, (f16*)dst, CoutP, CinP, taps, MI, mode, Cout, Cin);
+  else
+    hipLaunchKernelGGL(pack_conv3_kernel<bf16>, dim3(blocks), dim3(256), 0, stream, w, scale, (bf16*)dst, CoutP, CinP, taps, MI, mode, Cout, Cin);
+  IUNET_CHECK_HIP(hipGetLastError());
+  return IUNET_OK;
+}

@@ -1,0 +1,372 @@
+// HBM-bound forward kernels around the MFMA convolutions: the first convolution
+// (tiny Cin, reads the caller's NCHW / uint8 / strided block directly), 2x max-pool,
+// the k2 s2 transposed convolution (MFMA, operands straight from global: it is bound by
+// its 8x larger output, not by the matrix cores) and the 1x1 head fused with
+// softmax / argmax (writes the caller's NCHW fp32 / uint8 / strided accumulator).
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------ first conv
+struct FirstConvParams {
+  const void* x;       // input, generic strides (elements)
+  long long sN, sC, sD, sH, sW;
+  int in_dtype;        // 0 f32, 1 f16, 2 u8 (scaled by 1/255), 3 bf16
+  void* y; long long y_sstride;
+  const float* w;      // [taps][Cin][Cout] fp32 (already rounded to the activation dtype)
+  const float* bias;   // [Cout] or null
+  float* stats;        // [nblocks][Cout][2] or null
+  int N, D, H, W, Cin, Cout, nd, relu;
+};
+
+__device__ __forceinline__ float load_in(const void* p, long long off, int dt) {
+  switch (dt) {
+    case 0: return ((const float*)p)[off];
+    case 1: return (float)((const f16*)p)[off];
+    case 2: return (float)((const unsigned char*)p)[off] / 255.0f;
+    default: return (float)((const bf16*)p)[off];
+  }
+}
+
+template <typename T, int ND, int CIN>
+__global__ __launch_bounds__(256) void first_conv_kernel(FirstConvParams p) {
+  constexpr int KD = ND == 3 ? 3 : 1;
+  constexpr int TAPS = KD * 9;
+  using V8 = typename Vec8<T>::type;
+  const long long vox = (long long)p.D * p.H * p.W;
+  const long long v = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int n = blockIdx.y;
+  const bool ok = v < vox;
+  const long long vv = ok ? v : vox - 1;
+  const int gx = (int)(vv % p.W);
+  const int gy = (int)((vv / p.W) % p.H);
+  const int gz = (int)(vv / ((long long)p.W * p.H));
+
+  float win[TAPS * CIN];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t) {
+    const int dz = ND == 3 ? t / 9 - 1 : 0, dy = (t / 3) % 3 - 1, dx = t % 3 - 1;
+    const int z = gz + dz, y = gy + dy, x = gx + dx;
+    const bool in = (unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) {
+      float val = 0.f;
+      if (in) val = load_in(p.x, n * p.sN + c * p.sC + z * p.sD + y * p.sH + x * p.sW, p.in_dtype);
+      win[t * CIN + c] = to_f32<T>(from_f32<T>(val));   // activations live in T
+    }
+  }
+  T* yout = (T*)p.y + (long long)n * p.y_sstride;
+  const long long plane_stride = vox * 8;
+  __shared__ float red[4][2];
+  for (int cb = 0; cb < p.Cout / 8; ++cb) {
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int k = 0; k < TAPS * CIN; ++k) {
+      const float* wk = p.w + (long long)k * p.Cout + cb * 8;   // wave-uniform -> scalar loads
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = fmaf(win[k], wk[j], acc[j]);
+    }
+    if (p.stats) {
+      // per-channel partial sums of the raw conv output over this block's voxels
+      for (int j = 0; j < 8; ++j) {
+        float s = ok ? acc[j] : 0.f, s2 = ok ? acc[j] * acc[j] : 0.f;
+        s = wave_sum(s); s2 = wave_sum(s2);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = s; red[threadIdx.x >> 6][1] = s2; }
+        __syncthreads();
+        if (threadIdx.x < 2) {
+          const float tot = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+          p.stats[(((long long)n * gridDim.x + blockIdx.x) * p.Cout + cb * 8 + j) * 2 + threadIdx.x] = tot;
+        }
+      }
+    }
+    V8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float r = acc[j];
+      if (p.bias) r += p.bias[cb * 8 + j];
+      if (p.relu) r = fmaxf(r, 0.f);
+      o[j] = from_f32<T>(r);
+    }
+    if (ok) *(V8*)(yout + cb * plane_stride + v * 8) = o;
+  }
+}
+
+// ------------------------------------------------------------------ max-pool 2^d
+template <typename T, int ND>
+__global__ __launch_bounds__(256) void maxpool_kernel(const T* __restrict__ x, long long x_ss, T* __restrict__ y,
+                                                      long long y_ss, int planes, int Do, int Ho, int Wo) {
+  using V8 = typename Vec8<T>::type;
+  const long long ovox = (long long)Do * Ho * Wo;
+  const long long total = ovox * planes;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int n = blockIdx.y;
+  const int pl = (int)(i / ovox);
+  const long long r = i - (long long)pl * ovox;
+  const int ox = (int)(r % Wo), oy = (int)((r / Wo) % Ho), oz = (int)(r / ((long long)Wo * Ho));
+  const int Di = ND == 3 ? Do * 2 : 1, Hi = Ho * 2, Wi = Wo * 2;
+  const T* xp = x + n * x_ss + (long long)pl * Di * Hi * Wi * 8;
+  float m[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) m[j] = -INFINITY;
+#pragma unroll
+  for (int a = 0; a < (ND == 3 ? 2 : 1); ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int z = ND == 3 ? oz * 2 + a : 0;
+        const V8 v = *(const V8*)(xp + (((long long)z * Hi + oy * 2 + b) * Wi + ox * 2 + c) * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m[j] = fmaxf(m[j], to_f32<T>(v[j]));
+      }
+  V8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = from_f32<T>(m[j]);
+  *(V8*)(y + n * y_ss + (long long)pl * ovox * 8 + r * 8) = o;
+}
+
+// ------------------------------------------------------------------ transposed conv k2 s2
+// One wave = 16 consecutive input x voxels x 32 output channels x all 2^d output
+// positions.  A = packed weights [cob32][kstep][pos][t][64][8], B = activations.
+struct ConvTParams {
+  const void* x; long long x_sstride;
+  void* y; long long y_sstride;
+  const void* wpk; const float* bias;
+  int N, D, H, W, Cin, Cout;   // input grid
+};
+
+template <typename T, int ND>
+__global__ __launch_bounds__(256) void convT_kernel(ConvTParams p) {
+  using V8 = typename Vec8<T>::type;
+  constexpr int NPOS = ND == 3 ? 8 : 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l15 = lane & 15, q = lane >> 4;
+  const int xg = (p.W + 15) / 16;
+  const long long rows = (long long)p.D * p.H * xg;
+  const long long wid = (long long)blockIdx.x * 4 + wave;
+  if (wid >= rows * p.N) return;
+  const int n = (int)(wid / rows);
+  const long long r = wid - n * rows;
+  const int xb = (int)(r % xg), y = (int)((r / xg) % p.H), z = (int)(r / ((long long)xg * p.H));
+  const int cob = blockIdx.y;
+  const int x = xb * 16 + l15;
+  const bool ok = x < p.W;
+  const int xc = ok ? x : p.W - 1;
+  const long long in_plane = (long long)p.D * p.H * p.W * 8;
+  const T* xin = (const T*)p.x + n * p.x_sstride + (((long long)z * p.H + y) * p.W + xc) * 8;
+  const int nk = p.Cin >> 5;
+  const V8* wp = (const V8*)p.wpk + (long long)cob * nk * NPOS * 2 * 64 + lane;
+
+  f32x4 acc[NPOS][2];
+#pragma unroll
+  for (int s = 0; s < NPOS; ++s) { acc[s][0] = f32x4{0, 0, 0, 0}; acc[s][1] = f32x4{0, 0, 0, 0}; }
+  for (int ks = 0; ks < nk; ++ks) {
+    const V8 b = *(const V8*)(xin + (long long)(ks * 4 + q) * in_plane);
+#pragma unroll
+    for (int s = 0; s < NPOS; ++s) {
+      const V8 a0 = wp[((ks * NPOS + s) * 2 + 0) * 64];
+      const V8 a1 = wp[((ks * NPOS + s) * 2 + 1) * 64];
+      acc[s][0] = mfma16<T>(a0, b, acc[s][0]);
+      acc[s][1] = mfma16<T>(a1, b, acc[s][1]);
+    }
+  }
+  const int Do = ND == 3 ? p.D * 2 : 1, Ho = p.H * 2, Wo = p.W * 2;
+  const long long out_plane = (long long)Do * Ho * Wo * 8;
+  T* yout = (T*)p.y + n * p.y_sstride + (long long)(cob * 4 + q) * out_plane;
+  float bias[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) bias[j] = p.bias ? p.bias[cob * 32 + q * 8 + j] : 0.f;
+#pragma unroll
+  for (int s = 0; s < NPOS; ++s) {
+    const int a = ND == 3 ? (s >> 2) : 0, b = (s >> 1) & 1, c = s & 1;
+    V8 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      o[j] = from_f32<T>(acc[s][0][j] + bias[j]);
+      o[4 + j] = from_f32<T>(acc[s][1][j] + bias[4 + j]);
+    }
+    const int oz = ND == 3 ? z * 2 + a : 0;
+    if (ok) *(V8*)(yout + (((long long)oz * Ho + y * 2 + b) * Wo + x * 2 + c) * 8) = o;
+  }
+}
+
+// pack ConvTranspose weights fp32 [Cin][Cout][2^d] -> [cob32][kstep][pos][t][64][8]
+template <typename T>
+__global__ void pack_convT_kernel(const float* __restrict__ w, T* __restrict__ dst, int Cin, int Cout, int npos) {
+  const long long total = (long long)Cin * Cout * npos;
+  const int nk = Cin >> 5;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    long long r = i;
+    const int j = r & 7; r >>= 3;
+    const int lane = r & 63; r >>= 6;
+    const int t = r & 1; r >>= 1;
+    const int s = r % npos; r /= npos;
+    const int ks = r % nk;
+    const int cob = r / nk;
+    const int row = lane & 15, qq = lane >> 4;
+    const int co = cob * 32 + 8 * (row >> 2) + 4 * t + (row & 3);
+    const int ci = ks * 32 + 8 * qq + j;
+    dst[i] = from_f32<T>(w[((long long)ci * Cout + co) * npos + s]);
+  }
+}
+
+// ------------------------------------------------------------------ 1x1 head + softmax / argmax
+struct HeadParams {
+  const void* x; long long x_sstride; int planes;     // C0/8
+  const float* w;      // [ncls][C0] fp32
+  const float* bias;   // [ncls]
+  float* logits;       // optional, generic strides
+  float* probs;        // optional, generic strides
+  unsigned char* cls;  // optional, [N][vox]
+  long long oN, oC, oD, oH, oW;   // output strides (elements) for logits / probs
+  float divisor; int accumulate;  // probs: out = ((accumulate ? out : 0) + p) / divisor  (predict.py:101-110)
+  int N, D, H, W;
+};
+
+template <typename T, int NCLS>
+__global__ __launch_bounds__(256) void head_kernel(HeadParams p) {
+  using V8 = typename Vec8<T>::type;
+  const long long vox = (long long)p.D * p.H * p.W;
+  const long long v = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (v >= vox) return;
+  const int n = blockIdx.y;
+  const T* xin = (const T*)p.x + n * p.x_sstride + v * 8;
+  float l[NCLS];
+#pragma unroll
+  for (int c = 0; c < NCLS; ++c) l[c] = p.bias[c];
+  for (int pl = 0; pl < p.planes; ++pl) {
+    const V8 xv = *(const V8*)(xin + (long long)pl * vox * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float a = to_f32<T>(xv[j]);
+#pragma unroll
+      for (int c = 0; c < NCLS; ++c) l[c] = fmaf(a, p.w[c * p.planes * 8 + pl * 8 + j], l[c]);
+    }
+  }
+  const int gx = (int)(v % p.W), gy = (int)((v / p.W) % p.H), gz = (int)(v / ((long long)p.W * p.H));
+  const long long obase = n * p.oN + gz * p.oD + gy * p.oH + gx * p.oW;
+  float mx = l[0];
+#pragma unroll
+  for (int c = 1; c < NCLS; ++c) mx = fmaxf(mx, l[c]);
+  if (p.logits) {
+#pragma unroll
+    for (int c = 0; c < NCLS; ++c) p.logits[obase + c * p.oC] = l[c];
+  }
+  float e[NCLS], s = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCLS; ++c) { e[c] = __expf(l[c] - mx); s += e[c]; }
+  const float inv = 1.0f / s;
+  // class map = first maximum of the probabilities, exactly what np.argmax over the
+  // returned softmax gives (predict.py:38)
+  float pm = e[0] * inv; int am = 0;
+#pragma unroll
+  for (int c = 1; c < NCLS; ++c) { const float pc = e[c] * inv; if (pc > pm) { pm = pc; am = c; } }
+  if (p.cls) p.cls[n * vox + v] = (unsigned char)am;
+  if (p.probs) {
+#pragma unroll
+    for (int c = 0; c < NCLS; ++c) {
+      const float pr = e[c] * inv;
+      float* o = p.probs + obase + c * p.oC;
+      float r = p.accumulate ? __fadd_rn(*o, pr) : pr;
+      if (p.divisor != 1.0f) r = __fdiv_rn(r, p.divisor);
+      *o = r;
+    }
+  }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ host launchers
+int iunet_first_conv_launch(int dtype, int nd, const void* x, int in_dtype, long long sN, long long sC, long long sD,
+                            long long sH, long long sW, void* y, long long y_sstride, const float* w,
+                            const float* bias, float* stats, int N, int D, int H, int W, int Cin, int Cout, int relu,
+                            hipStream_t stream) {
+  IUNET_REQUIRE(Cin >= 1 && Cin <= 4, "first_conv: Cin must be 1..4 (got %d)", Cin);
+  IUNET_REQUIRE(Cout % 8 == 0, "first_conv: Cout must be a multiple of 8 (got %d)", Cout);
+  FirstConvParams p;
+  p.x = x; p.sN = sN; p.sC = sC; p.sD = sD; p.sH = sH; p.sW = sW; p.in_dtype = in_dtype;
+  p.y = y; p.y_sstride = y_sstride; p.w = w; p.bias = bias; p.stats = stats;
+  p.N = N; p.D = D; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.nd = nd; p.relu = relu;
+  const long long vox = (long long)D * H * W;
+  dim3 grid((unsigned)((vox + 255) / 256), N);
+#define IUNET_FC(TT, NDV, CI) hipLaunchKernelGGL((first_conv_kernel<TT, NDV, CI>), grid, dim3(256), 0, stream, p)
+#define IUNET_FC_CIN(TT, NDV)                                              \
+  switch (Cin) { case 1: IUNET_FC(TT, NDV, 1); break; case 2: IUNET_FC(TT, NDV, 2); break; \
+                 case 3: IUNET_FC(TT, NDV, 3); break; default: IUNET_FC(TT, NDV, 4); break; }
+  if (dtype == 0) { if (nd == 3) { IUNET_FC_CIN(f16, 3) } else { IUNET_FC_CIN(f16, 2) } }
+  else            { if (nd == 3) { IUNET_FC_CIN(bf16, 3) } else { IUNET_FC_CIN(bf16, 2) } }
+#undef IUNET_FC_CIN
+#undef IUNET_FC
+  IUNET_CHECK_HIP(hipGetLastError());
+  return IUNET_OK;
+}
+
+int iunet_first_conv_blocks(int N, int D, int H, int W) { return N * (int)(((long long)D * H * W + 255) / 256); }
+
+int iunet_maxpool_launch(int dtype, int nd, const void* x, long long x_ss, void* y, long long y_ss, int planes, int N,
+                         int Do, int Ho, int Wo, hipStream_t stream) {
+  const long long total = (long long)Do * Ho * Wo * planes;
+  dim3 grid((unsigned)((total + 255) / 256), N);
+  if (dtype == 0) {
+    if (nd == 3) hipLaunchKernelGGL((maxpool_kernel<f16, 3>), grid, dim3(256), 0, stream, (const f16*)x, x_ss, (f16*)y, y_ss, planes, Do, Ho, Wo);
+    else hipLaunchKernelGGL((maxpool_kernel<f16, 2>), grid, dim3(256), 0, stream, (const f16*)x, x_ss, (f16*)y, y_ss, planes, Do, Ho, Wo);
+  } else {
+    if (nd == 3) hipLaunchKernelGGL((maxpool_kernel<bf16, 3>), grid, dim3(256), 0, stream, (const bf16*)x, x_ss, (bf16*)y, y_ss, planes, Do, Ho, Wo);
+    else hipLaunchKernelGGL((maxpool_kernel<bf16, 2>), grid, dim3(256), 0, stream, (const bf16*)x, x_ss, (bf16*)y, y_ss, planes, Do, Ho, Wo);
+  }
+  IUNET_CHECK_HIP(hipGetLastError());
+  return IUNET_OK;
+}
+
+int iunet_convT_launch(int dtype, int nd, const void* x, long long x_ss, void* y, long long y_ss, const void* wpk,
+                       const float* bias, int N, int D, int H, int W, int Cin, int Cout, hipStream_t stream) {
+  IUNET_REQUIRE(Cin % 32 == 0 && Cout % 32 == 0, "convT: Cin (%d) and Cout (%d) must be multiples of 32", Cin, Cout);
+  ConvTParams p;
+  p.x = x; p.x_sstride = x_ss; p.y = y; p.y_sstride = y_ss; p.wpk = wpk; p.bias = bias;
+  p.N = N; p.D = D; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
+  const long long waves = (long long)N * D * H * ((W + 15) / 16);
+  dim3 grid((unsigned)((waves + 3) / 4), Cout / 32);
+  if (dtype == 0) {
+    if (nd == 3) hipLaunchKernelGGL((convT_kernel<f16, 3>), grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((convT_kernel<f16, 2>), grid, dim3(256), 0, stream, p);
+  } else {
+    if (nd == 3) hipLaunchKernelGGL((convT_kernel<bf16, 3>), grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((convT_kernel<bf16, 2>), grid, dim3(256), 0, stream, p);
+  }
+  IUNET_CHECK_HIP(hipGetLastError());
+  return IUNET_OK;
+}
+
+int iunet_pack_convT_launch(int dtype, const float* w, void* dst, int Cin, int Cout, int npos, hipStream_t stream) {
+  const long long total = (long long)Cin * Cout * npos;
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  if (dtype == 0) hipLaunchKernelGGL(pack_convT_kernel<f16>, dim3(blocks), dim3(256), 0, stream, w, (f16*)dst, Cin, Cout, npos);
+  else hipLaunchKernelGGL(pack_convT_kernel<bf16>, dim3(blocks), dim3(256), 0, stream, w, (bf16*)dst, Cin, Cout, npos);
+  IUNET_CHECK_HIP(hipGetLastError());
+  return IUNET_OK;
+}
+
+int iunet_head_launch(int dtype, const void* x, long long x_ss, int C0, const float* w, const float* bias, int ncls,
+                      float* logits, float* probs, unsigned char* cls, long long oN, long long oC, long long oD,
+                      long long oH, long long oW, float divisor, int accumulate, int N, int D, int H, int W,
+                      hipStream_t stream) {
+  IUNET_REQUIRE(ncls >= 2 && ncls <= 10, "head: num_classes must be 2..10 (got %d)", ncls);
+  HeadParams p;
+  p.x = x; p.x_sstride = x_ss; p.planes = C0 / 8; p.w = w; p.bias = bias; p.logits = logits; p.probs = probs; p.cls = cls;
+  p.oN = oN; p.oC = oC; p.oD = oD; p.oH = oH; p.oW = oW; p.divisor = divisor; p.accumulate = accumulate;
+  p.N = N; p.D = D; p.H = H; p.W = W;
+  const long long vox = (long long)D * H * W;
+  dim3 grid((unsigned)((vox + 255) / 256), N);
+#define IUNET_HEAD(TT, NC) case NC: hipLaunchKernelGGL((head_kernel<TT, NC>), grid, dim3(256), 0, stream, p); break;
+#define IUNET_HEAD_ALL(TT) switch (ncls) { IUNET_HEAD(TT, 2) IUNET_HEAD(TT, 3) IUNET_HEAD(TT, 4) IUNET_HEAD(TT, 5) \
+  IUNET_HEAD(TT, 6) IUNET_HEAD(TT, 7) IUNET_HEAD(TT, 8) IUNET_HEAD(TT, 9) IUNET_HEAD(TT, 10) }
+  if (dtype == 0) { IUNET_HEAD_ALL(f16) } else { IUNET_HEAD_ALL(bf16) }
+#undef IUNET_HEAD_ALL
+#undef IUNET_HEAD
+  IUNET_CHECK_HIP(hipGetLastError());
+  return IUNET_OK;
+}

@@ -1,0 +1,96 @@
+"""ctypes binding of libiunet.so (the C ABI declared in include/iunet.h).
+
+The library is pure HIP (no torch types in its signatures): tensors cross the boundary
+as raw device pointers + sizes + the HIP stream to order the work on.  There is NO CPU
+fallback: if the shared library is missing or a call fails, this module raises.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), 'lib', 'libiunet.so')
+
+_lib = None
+
+c_void_p, c_int, c_ll, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_float
+
+# name -> argtypes (all functions return int status except where noted)
+_SIGS = {
+    'iunet_abi_version': [],
+    'iunet_conv3_num_tiles': [c_int] * 5,
+    'iunet_first_conv_num_blocks': [c_int] * 4,
+    'iunet_pack_conv3': [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
+    'iunet_pack_first_conv': [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    'iunet_pack_convT': [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    'iunet_conv3_fwd': [c_int, c_int, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_void_p, c_void_p,
+                        c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    'iunet_first_conv_fwd': [c_int, c_int, c_void_p, c_int, ctypes.POINTER(c_ll), c_void_p, c_ll, c_void_p, c_void_p,
+                             c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    'iunet_maxpool_fwd': [c_int, c_int, c_void_p, c_ll, c_void_p, c_ll, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    'iunet_convT_fwd': [c_int, c_int, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_void_p,
+                        c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    'iunet_head_fwd': [c_int, c_void_p, c_ll, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                       ctypes.POINTER(c_ll), c_float, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    'iunet_gather_block': [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
+    'iunet_blend_accumulate': [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                               ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_void_p],
+    'iunet_normalize_quantize': [c_void_p, c_void_p, c_void_p, c_ll, c_int, c_float, c_void_p],
+    'iunet_div_f32': [c_void_p, c_ll, c_float, c_void_p],
+}
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libiunet.so once; raise (never fall back) if it is not there."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise NativeError(f'{LIB_PATH} is missing: build it with __graft_entry__.build() '
+                              f'(interactive-unet_amd/csrc/build.sh); there is no CPU fallback')
+        l = ctypes.CDLL(LIB_PATH)
+        l.iunet_last_error.restype = ctypes.c_char_p
+        l.iunet_last_error.argtypes = []
+        for name, args in _SIGS.items():
+            fn = getattr(l, name)          # AttributeError here = header/library mismatch
+            fn.argtypes = args
+            fn.restype = c_int
+        _lib = l
+    return _lib
+
+
+def exported_symbols():
+    return ['iunet_last_error'] + list(_SIGS)
+
+
+def check(status):
+    if status != 0:
+        raise NativeError(f'libiunet error {status}: {lib().iunet_last_error().decode()}')
+
+
+def call(name, *args):
+    check(getattr(lib(), name)(*args))
+
+
+def ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ll_array(vals):
+    return (c_ll * len(vals))(*[int(v) for v in vals])
+
+
+def int_array(vals):
+    return (c_int * len(vals))(*[int(v) for v in vals])
+
+
+DTYPE_CODE = {torch.float16: 0, torch.bfloat16: 1}
+IN_DTYPE_CODE = {torch.float32: 0, torch.float16: 1, torch.uint8: 2, torch.bfloat16: 3}

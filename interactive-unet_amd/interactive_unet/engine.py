@@ -1,0 +1,201 @@
+"""Host-side plan of the native U-Net: owns packed weights and activation workspaces
+(PyTorch-ROCm tensors = device memory + streams) and sequences the libiunet kernels.
+
+Canonical network (replaces smp.Unet behind unet.py:33-61):
+levels L, channels base*2^l, stage = 2 x [conv 3^d -> BatchNorm -> ReLU], max-pool 2,
+decoder = ConvTranspose k2 s2 -> concat(skip, up) -> stage, head 1x1 -> softmax.
+
+Activations live in HBM as channel-blocked NHWC ("NHWC8c": C/8 planes of [D][H][W][8]);
+the skip concat is free (encoder conv2 and the transposed conv write into the two halves
+of one buffer).  External tensors stay NCHW / uint8 / strided: the first conv and the head
+read / write them directly.
+"""
+import ctypes
+import math
+
+import torch
+
+from . import _native as nv
+
+BN_EPS = 1e-5
+
+
+def _vox(dims):
+    return dims[0] * dims[1] * dims[2]
+
+
+class Engine:
+    def __init__(self, dim=2, levels=4, base=32, cin=1, ncls=2, act_dtype=torch.float16, device='cuda'):
+        if dim not in (2, 3):
+            raise ValueError('dim must be 2 or 3')
+        if base % 32 != 0:
+            raise NotImplementedError('native U-Net needs base channels to be a multiple of 32')
+        if not (1 <= cin <= 4):
+            raise NotImplementedError('native U-Net supports 1..4 input channels')
+        if not (2 <= ncls <= 10):
+            raise NotImplementedError('native U-Net supports 2..10 classes (app.py:162)')
+        self.dim, self.levels, self.base, self.cin, self.ncls = dim, levels, base, cin, ncls
+        self.act_dtype = act_dtype
+        self.dt = nv.DTYPE_CODE[act_dtype]
+        self.device = torch.device(device)
+        self.ch = [base * 2 ** l for l in range(levels)]
+        self.taps = 3 ** dim
+        self.npos = 2 ** dim
+        self.packed = None
+        self._ws_cache = {}
+        nv.lib()   # fail loudly now if the HIP library is missing
+
+    # ------------------------------------------------------------------ weights
+    def stage_names(self):
+        names = [f'enc{l}' for l in range(self.levels)] + [f'dec{l}' for l in range(self.levels - 2, -1, -1)]
+        return names
+
+    def stage_io(self, prefix):
+        l = int(prefix[3:])
+        if prefix.startswith('enc'):
+            ci = self.cin if l == 0 else self.ch[l - 1]
+        else:
+            ci = 2 * self.ch[l]
+        return ci, self.ch[l]
+
+    def load_eval(self, params):
+        """Fold eval-mode BatchNorm into the stage convs and pack everything into MFMA
+        fragment order.  `params`: {name: fp32 tensor on the device}."""
+        s = nv.stream()
+        P = {}
+        keep = []
+        for prefix in self.stage_names():
+            ci, co = self.stage_io(prefix)
+            for j, (a, b) in enumerate(((ci, co), (co, co)), 1):
+                w = params[f'{prefix}.conv{j}.weight'].detach().to(self.device, torch.float32).contiguous()
+                g = params[f'{prefix}.bn{j}.weight'].detach().to(self.device, torch.float32)
+                be = params[f'{prefix}.bn{j}.bias'].detach().to(self.device, torch.float32)
+                mu = params[f'{prefix}.bn{j}.running_mean'].detach().to(self.device, torch.float32)
+                var = params[f'{prefix}.bn{j}.running_var'].detach().to(self.device, torch.float32)
+                scale = (g / torch.sqrt(var + BN_EPS)).contiguous()
+                bias = (be - mu * scale).contiguous()
+                keep += [w, scale]
+                if prefix == 'enc0' and j == 1:
+                    dst = torch.empty(self.taps * a * b, dtype=torch.float32, device=self.device)
+                    nv.call('iunet_pack_first_conv', self.dt, nv.ptr(w), nv.ptr(scale), nv.ptr(dst), b, a, self.taps, s)
+                else:
+                    dst = torch.empty(self.taps * a * b, dtype=self.act_dtype, device=self.device)
+                    nv.call('iunet_pack_conv3', self.dt, nv.ptr(w), nv.ptr(scale), nv.ptr(dst), b, a, self.taps, 0, s)
+                P[f'{prefix}.conv{j}'] = (dst, bias)
+        for l in range(self.levels - 2, -1, -1):
+            w = params[f'dec{l}.up.weight'].detach().to(self.device, torch.float32).contiguous()
+            bias = params[f'dec{l}.up.bias'].detach().to(self.device, torch.float32).contiguous()
+            dst = torch.empty(w.numel(), dtype=self.act_dtype, device=self.device)
+            nv.call('iunet_pack_convT', self.dt, nv.ptr(w), nv.ptr(dst), self.ch[l + 1], self.ch[l], self.npos, s)
+            keep.append(w)
+            P[f'dec{l}.up'] = (dst, bias)
+        hw = params['head.weight'].detach().to(self.device, torch.float32).reshape(self.ncls, self.ch[0]).contiguous()
+        hb = params['head.bias'].detach().to(self.device, torch.float32).contiguous()
+        P['head'] = (hw, hb)
+        torch.cuda.current_stream().synchronize()   # sources in `keep` may be freed after this
+        self.packed = P
+
+    # ------------------------------------------------------------------ workspace
+    def level_dims(self, D, H, W):
+        out = []
+        for l in range(self.levels):
+            f = 2 ** l
+            out.append((D // f if self.dim == 3 else 1, H // f, W // f))
+        return out
+
+    def check_shape(self, D, H, W):
+        f = 2 ** (self.levels - 1)
+        if H % f or W % f or (self.dim == 3 and D % f) or (self.dim == 2 and D != 1):
+            raise ValueError(f'spatial size {(D, H, W)} must be divisible by {f} (and D == 1 in 2-D)')
+
+    def workspace(self, N, D, H, W):
+        key = (N, D, H, W)
+        ws = self._ws_cache.get(key)
+        if ws is None:
+            self.check_shape(D, H, W)
+            dims = self.level_dims(D, H, W)
+            mk = lambda c, v: torch.empty(N * c * v, dtype=self.act_dtype, device=self.device)
+            ws = {'dims': dims}
+            for l in range(self.levels):
+                v = _vox(dims[l])
+                ws[f'a{l}'] = mk(self.ch[l], v)
+                ws[f'b{l}'] = mk(self.ch[l], v)
+                if l < self.levels - 1:
+                    ws[f'cat{l}'] = mk(2 * self.ch[l], v)
+                if l > 0:
+                    ws[f'pin{l}'] = mk(self.ch[l - 1], v)
+            if len(self._ws_cache) > 4:
+                self._ws_cache.clear()
+            self._ws_cache[key] = ws
+        return ws
+
+    # ------------------------------------------------------------------ forward (inference)
+    def _conv3(self, x_ptr, x_ss, y_ptr, y_ss, name, N, dims, ci, co, s):
+        wpk, bias = self.packed[name]
+        nv.call('iunet_conv3_fwd', self.dt, self.dim, x_ptr, x_ss, y_ptr, y_ss, nv.ptr(wpk), nv.ptr(bias), None,
+                N, dims[0], dims[1], dims[2], ci, co, 2, s)
+
+    def infer(self, x, x_strides, N, D, H, W, logits=None, probs=None, cls=None, out_strides=None,
+              divisor=1.0, accumulate=False):
+        """Run the folded network.  `x`: any torch tensor on the device (f32/f16/bf16/u8; u8 is
+        scaled by 1/255 as predict.py:30 does); `x_strides` = element strides (n, c, d, h, w).
+        Outputs (all optional): logits / probs fp32 written with `out_strides` (n, c, d, h, w),
+        cls uint8 [N, D*H*W]."""
+        if self.packed is None:
+            raise RuntimeError('Engine.load_eval() has not been called')
+        ws = self.workspace(N, D, H, W)
+        dims = ws['dims']
+        es = torch.tensor([], dtype=self.act_dtype).element_size()
+        s = nv.stream()
+        L, ch = self.levels, self.ch
+        P = lambda t, off_elems=0: ctypes.c_void_p(t.data_ptr() + off_elems * es)
+        for l in range(L):
+            v = _vox(dims[l])
+            if l == 0:
+                w, b = self.packed['enc0.conv1']
+                nv.call('iunet_first_conv_fwd', self.dt, self.dim, nv.ptr(x), nv.IN_DTYPE_CODE[x.dtype],
+                        nv.ll_array(x_strides), P(ws['a0']), ch[0] * v, nv.ptr(w), nv.ptr(b), None,
+                        N, dims[0][0], dims[0][1], dims[0][2], self.cin, ch[0], 1, s)
+            else:
+                self._conv3(P(ws[f'pin{l}']), ch[l - 1] * v, P(ws[f'a{l}']), ch[l] * v, f'enc{l}.conv1', N, dims[l],
+                            ch[l - 1], ch[l], s)
+            if l < L - 1:
+                self._conv3(P(ws[f'a{l}']), ch[l] * v, P(ws[f'cat{l}']), 2 * ch[l] * v, f'enc{l}.conv2', N, dims[l],
+                            ch[l], ch[l], s)
+                vo = _vox(dims[l + 1])
+                nv.call('iunet_maxpool_fwd', self.dt, self.dim, P(ws[f'cat{l}']), 2 * ch[l] * v, P(ws[f'pin{l + 1}']),
+                        ch[l] * vo, ch[l], N, dims[l + 1][0], dims[l + 1][1], dims[l + 1][2], s)
+            else:
+                self._conv3(P(ws[f'a{l}']), ch[l] * v, P(ws[f'b{l}']), ch[l] * v, f'enc{l}.conv2', N, dims[l],
+                            ch[l], ch[l], s)
+        for l in range(L - 2, -1, -1):
+            v, vi = _vox(dims[l]), _vox(dims[l + 1])
+            wpk, bias = self.packed[f'dec{l}.up']
+            nv.call('iunet_convT_fwd', self.dt, self.dim, P(ws[f'b{l + 1}']), ch[l + 1] * vi,
+                    P(ws[f'cat{l}'], ch[l] * v), 2 * ch[l] * v, nv.ptr(wpk), nv.ptr(bias),
+                    N, dims[l + 1][0], dims[l + 1][1], dims[l + 1][2], ch[l + 1], ch[l], s)
+            self._conv3(P(ws[f'cat{l}']), 2 * ch[l] * v, P(ws[f'a{l}']), ch[l] * v, f'dec{l}.conv1', N, dims[l],
+                        2 * ch[l], ch[l], s)
+            self._conv3(P(ws[f'a{l}']), ch[l] * v, P(ws[f'b{l}']), ch[l] * v, f'dec{l}.conv2', N, dims[l],
+                        ch[l], ch[l], s)
+        hw, hb = self.packed['head']
+        if out_strides is None:
+            v = _vox(dims[0])
+            out_strides = (self.ncls * v, v, H * W, W, 1)          # contiguous NC(D)HW
+        nv.call('iunet_head_fwd', self.dt, P(ws['b0']), ch[0] * _vox(dims[0]), ch[0], nv.ptr(hw), nv.ptr(hb),
+                self.ncls, nv.ptr(logits), nv.ptr(probs), nv.ptr(cls), nv.ll_array(out_strides),
+                float(divisor), int(bool(accumulate)), N, D, H, W, s)
+
+    # ------------------------------------------------------------------ layout helpers (tests / debugging)
+    def to_blocked(self, t):
+        """[N, C, *spatial] -> flat NHWC8c tensor in the activation dtype."""
+        N, C = t.shape[:2]
+        sp = t.shape[2:]
+        t = t.reshape(N, C // 8, 8, *sp)
+        perm = [0, 1] + list(range(3, 3 + len(sp))) + [2]
+        return t.permute(*perm).contiguous().to(self.act_dtype).reshape(-1)
+
+    def from_blocked(self, flat, N, C, sp):
+        t = flat.reshape(N, C // 8, *sp, 8)
+        perm = [0, 1, 2 + len(sp)] + list(range(2, 2 + len(sp)))
+        return t.permute(*perm).reshape(N, C, *sp)

@@ -1,0 +1,230 @@
+"""Per-kernel parity of the HIP path (through the C ABI) against plain torch fp32 ops on
+the CPU and the oracle.  Needs an MI355X: run with -m gpu."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DT = {'f16': torch.float16, 'bf16': torch.bfloat16}
+
+
+@pytest.fixture(scope='module')
+def nv():
+    assert torch.cuda.is_available(), 'gpu tests need a GPU'
+    from interactive_unet import _native
+    _native.lib()
+    return _native
+
+
+def blocked(t, dtype):
+    N, C = t.shape[:2]
+    sp = t.shape[2:]
+    t = t.reshape(N, C // 8, 8, *sp)
+    perm = [0, 1] + list(range(3, 3 + len(sp))) + [2]
+    return t.permute(*perm).contiguous().to(dtype).reshape(-1)
+
+
+def unblocked(flat, N, C, sp):
+    t = flat.reshape(N, C // 8, *sp, 8)
+    perm = [0, 1, 2 + len(sp)] + list(range(2, 2 + len(sp)))
+    return t.permute(*perm).reshape(N, C, *sp)
+
+
+def run_conv3(nv, x, w, dtype, nd, scale=None, bias=None, epi=0, stats=False, mode=0):
+    """x [N,Cin,D,H,W] fp32 cpu, w [Cout,Cin,k..] fp32 cpu -> y [N,Cout',D,H,W] fp32 cpu."""
+    dev = 'cuda'
+    N, Cin = x.shape[:2]
+    sp = tuple(x.shape[2:])
+    D, H, W = sp if nd == 3 else (1,) + sp
+    taps = 3 ** nd
+    Co_p, Ci_p = (w.shape[0], w.shape[1]) if mode == 0 else (w.shape[1], w.shape[0])
+    xb = blocked(x, dtype).to(dev)
+    wd = w.contiguous().to(dev)
+    wpk = torch.empty(Co_p * Ci_p * taps, dtype=dtype, device=dev)
+    sc = None if scale is None else scale.to(dev)
+    nv.call('iunet_pack_conv3', nv.DTYPE_CODE[dtype], nv.ptr(wd), nv.ptr(sc), nv.ptr(wpk), w.shape[0], w.shape[1],
+            taps, mode, nv.stream())
+    vox = D * H * W
+    y = torch.full((N * Co_p * vox,), float('nan'), dtype=dtype, device=dev)
+    bd = None if bias is None else bias.to(dev)
+    st = None
+    if stats:
+        nt = nv.lib().iunet_conv3_num_tiles(nd, N, D, H, W)
+        st = torch.zeros(nt * Co_p * 2, dtype=torch.float32, device=dev)
+    nv.call('iunet_conv3_fwd', nv.DTYPE_CODE[dtype], nd, nv.ptr(xb), Ci_p * vox, nv.ptr(y), Co_p * vox, nv.ptr(wpk),
+            nv.ptr(bd), nv.ptr(st), N, D, H, W, Ci_p, Co_p, epi, nv.stream())
+    torch.cuda.synchronize()
+    out = unblocked(y.float().cpu(), N, Co_p, sp)
+    if stats:
+        return out, st.cpu().reshape(-1, Co_p, 2).sum(0)
+    return out
+
+
+@pytest.mark.parametrize('nd,shape,cin,cout', [
+    (2, (16, 32), 32, 32), (2, (48, 40), 64, 64), (2, (20, 70), 64, 32), (2, (16, 16), 32, 128),
+    (3, (4, 8, 16), 32, 32), (3, (6, 12, 20), 64, 64), (3, (8, 8, 8), 32, 64)])
+def test_conv3_exact_integers(nv, nd, shape, cin, cout):
+    """Small-integer data: every product and sum is exact in f16 x f16 -> f32, so the MFMA
+    path must equal the fp32 reference bit for bit (catches any fragment-map / tap / halo
+    error; weights are asymmetric in every axis)."""
+    g = torch.Generator().manual_seed(1)
+    N = 2
+    x = torch.randint(-2, 3, (N, cin) + shape, generator=g).float()
+    w = torch.randint(-1, 2, (cout, cin) + (3,) * nd, generator=g).float()
+    ref = (F.conv2d if nd == 2 else F.conv3d)(x, w, padding=1)
+    for dt in (torch.float16, torch.bfloat16):
+        got = run_conv3(nv, x, w, dt, nd)
+        ok = ref.abs() <= (2048 if dt == torch.float16 else 256)       # exactly representable outputs
+        assert torch.equal(got[ok], ref[ok]), (dt, (got - ref)[ok].abs().max())
+
+
+@pytest.mark.parametrize('nd', [2, 3])
+def test_conv3_random_bias_relu_stats(nv, nd):
+    g = torch.Generator().manual_seed(2)
+    shape = (40, 48) if nd == 2 else (8, 16, 24)
+    cin, cout, N = 64, 64, 2
+    x = torch.randn((N, cin) + shape, generator=g).half().float()
+    w = torch.randn((cout, cin) + (3,) * nd, generator=g) * (2.0 / (cin * 3 ** nd)) ** 0.5
+    scale = 0.5 + torch.rand(cout, generator=g)
+    bias = torch.randn(cout, generator=g) * 0.1
+    wf = (w * scale.view(-1, *([1] * (nd + 1)))).half().float()
+    conv = F.conv2d if nd == 2 else F.conv3d
+    ref = F.relu(conv(x, wf, bias=bias, padding=1))
+    got = run_conv3(nv, x, w, torch.float16, nd, scale=scale, bias=bias, epi=2)
+    assert (got - ref).abs().max() <= 2e-3 * max(1.0, ref.abs().max().item())
+    raw, st = run_conv3(nv, x, w, torch.float16, nd, stats=True)
+    rr = conv(x, w.half().float(), padding=1)
+    dims = [0] + list(range(2, 2 + nd))
+    assert torch.allclose(st[:, 0], rr.sum(dims), rtol=1e-3, atol=1e-1)
+    assert torch.allclose(st[:, 1], (rr * rr).sum(dims), rtol=1e-3, atol=1e-1)
+    assert (raw - rr).abs().max() <= 2e-3 * rr.abs().max().item()
+
+
+@pytest.mark.parametrize('nd', [2, 3])
+def test_conv3_dgrad_mode(nv, nd):
+    """mode-1 packing turns the same kernel into the data gradient."""
+    g = torch.Generator().manual_seed(3)
+    shape = (24, 40) if nd == 2 else (4, 8, 24)
+    cin, cout = 64, 32
+    w = torch.randint(-1, 2, (cout, cin) + (3,) * nd, generator=g).float()
+    dy = torch.randint(-2, 3, (1, cout) + shape, generator=g).float()
+    convT = F.conv_transpose2d if nd == 2 else F.conv_transpose3d
+    ref = convT(dy, w, padding=1)                     # = d/dx of conv(x, w, padding=1) . dy
+    got = run_conv3(nv, dy, w, torch.float16, nd, mode=1)
+    ok = ref.abs() <= 2048
+    assert torch.equal(got[ok], ref[ok])
+
+
+@pytest.mark.parametrize('nd,in_dtype', [(2, torch.uint8), (2, torch.float32), (3, torch.uint8), (3, torch.float16)])
+def test_first_conv(nv, nd, in_dtype):
+    g = torch.Generator().manual_seed(4)
+    shape = (24, 36) if nd == 2 else (6, 10, 12)
+    N, cin, cout = 2, 1, 32
+    taps = 3 ** nd
+    if in_dtype == torch.uint8:
+        xi = torch.randint(0, 256, (N, cin) + shape, generator=g, dtype=torch.uint8)
+        xf = (xi.float() / 255.0).half().float()
+    else:
+        xi = torch.rand((N, cin) + shape, generator=g).to(in_dtype)
+        xf = xi.float().half().float()
+    w = torch.randn((cout, cin) + (3,) * nd, generator=g) * 0.3
+    scale = 0.5 + torch.rand(cout, generator=g)
+    bias = torch.randn(cout, generator=g) * 0.1
+    wf = (w * scale.view(-1, *([1] * (nd + 1)))).half().float()
+    ref = F.relu((F.conv2d if nd == 2 else F.conv3d)(xf, wf, bias=bias, padding=1))
+    dev = 'cuda'
+    xd = xi.to(dev)
+    wd, sd, bd = w.to(dev), scale.to(dev), bias.to(dev)
+    wp = torch.empty(taps * cin * cout, dtype=torch.float32, device=dev)
+    nv.call('iunet_pack_first_conv', 0, nv.ptr(wd), nv.ptr(sd), nv.ptr(wp), cout, cin, taps, nv.stream())
+    D, H, W = shape if nd == 3 else (1,) + shape
+    vox = D * H * W
+    y = torch.empty(N * cout * vox, dtype=torch.float16, device=dev)
+    nb = nv.lib().iunet_first_conv_num_blocks(N, D, H, W)
+    st = torch.zeros(nb * cout * 2, dtype=torch.float32, device=dev)
+    strides = (cin * vox, vox, H * W, W, 1)
+    nv.call('iunet_first_conv_fwd', 0, nd, nv.ptr(xd), nv.IN_DTYPE_CODE[in_dtype], nv.ll_array(strides), nv.ptr(y),
+            cout * vox, nv.ptr(wp), nv.ptr(bd), nv.ptr(st), N, D, H, W, cin, cout, 1, nv.stream())
+    torch.cuda.synchronize()
+    got = unblocked(y.float().cpu(), N, cout, shape)
+    assert (got - ref).abs().max() <= 2e-3 * max(1.0, ref.abs().max().item())
+    raw = (F.conv2d if nd == 2 else F.conv3d)(xf, wf, padding=1)
+    s = st.cpu().reshape(-1, cout, 2).sum(0)
+    dims = [0] + list(range(2, 2 + nd))
+    assert torch.allclose(s[:, 0], raw.sum(dims), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(s[:, 1], (raw * raw).sum(dims), rtol=1e-4, atol=1e-2)
+
+
+@pytest.mark.parametrize('nd', [2, 3])
+@pytest.mark.parametrize('dt', ['f16', 'bf16'])
+def test_maxpool(nv, nd, dt):
+    dtype = DT[dt]
+    g = torch.Generator().manual_seed(5)
+    shape = (12, 20) if nd == 2 else (4, 6, 10)
+    N, C = 2, 32
+    x = torch.randn((N, C) + shape, generator=g).to(dtype).float()
+    ref = (F.max_pool2d if nd == 2 else F.max_pool3d)(x, 2)
+    xb = blocked(x, dtype).cuda()
+    osp = tuple(s // 2 for s in shape)
+    Do, Ho, Wo = osp if nd == 3 else (1,) + osp
+    y = torch.empty(N * C * Do * Ho * Wo, dtype=dtype, device='cuda')
+    vin = int(np.prod(shape))
+    nv.call('iunet_maxpool_fwd', nv.DTYPE_CODE[dtype], nd, nv.ptr(xb), C * vin, nv.ptr(y), C * Do * Ho * Wo, C, N,
+            Do, Ho, Wo, nv.stream())
+    torch.cuda.synchronize()
+    assert torch.equal(unblocked(y.float().cpu(), N, C, osp), ref)
+
+
+@pytest.mark.parametrize('nd,shape,cin,cout', [(2, (8, 16), 64, 32), (2, (6, 20), 256, 128), (3, (4, 4, 16), 64, 32),
+                                               (3, (2, 3, 8), 128, 64)])
+def test_convT_exact_integers(nv, nd, shape, cin, cout):
+    g = torch.Generator().manual_seed(6)
+    N = 2
+    x = torch.randint(-2, 3, (N, cin) + shape, generator=g).float()
+    w = torch.randint(-1, 2, (cin, cout) + (2,) * nd, generator=g).float()
+    bias = torch.randint(-3, 4, (cout,), generator=g).float()
+    ref = (F.conv_transpose2d if nd == 2 else F.conv_transpose3d)(x, w, bias=bias, stride=2)
+    D, H, W = shape if nd == 3 else (1,) + shape
+    osp = tuple(2 * s for s in shape)
+    xb = blocked(x, torch.float16).cuda()
+    wd, bd = w.cuda(), bias.cuda()
+    wpk = torch.empty(w.numel(), dtype=torch.float16, device='cuda')
+    nv.call('iunet_pack_convT', 0, nv.ptr(wd), nv.ptr(wpk), cin, cout, 2 ** nd, nv.stream())
+    vin, vout = int(np.prod(shape)), int(np.prod(osp))
+    y = torch.full((N * cout * vout,), float('nan'), dtype=torch.float16, device='cuda')
+    nv.call('iunet_convT_fwd', 0, nd, nv.ptr(xb), cin * vin, nv.ptr(y), cout * vout, nv.ptr(wpk), nv.ptr(bd),
+            N, D, H, W, cin, cout, nv.stream())
+    torch.cuda.synchronize()
+    got = unblocked(y.float().cpu(), N, cout, osp)
+    ok = ref.abs() <= 2048
+    assert torch.equal(got[ok], ref[ok])
+
+
+@pytest.mark.parametrize('ncls', [2, 3, 10])
+def test_head_softmax_argmax(nv, ncls):
+    g = torch.Generator().manual_seed(7)
+    N, C0, shape = 2, 32, (3, 10, 12)
+    x = torch.randn((N, C0) + shape, generator=g).half().float()
+    w = torch.randn(ncls, C0, generator=g) * 0.3
+    b = torch.randn(ncls, generator=g) * 0.1
+    ref_l = F.conv3d(x, w.view(ncls, C0, 1, 1, 1), bias=b)
+    ref_p = torch.softmax(ref_l, 1)
+    D, H, W = shape
+    vox = D * H * W
+    xb = blocked(x, torch.float16).cuda()
+    logits = torch.empty(N, ncls, D, H, W, device='cuda')
+    probs = torch.empty(N, ncls, D, H, W, device='cuda')
+    cls = torch.empty(N, vox, dtype=torch.uint8, device='cuda')
+    nv.call('iunet_head_fwd', 0, nv.ptr(xb), C0 * vox, C0, nv.ptr(w.cuda()), nv.ptr(b.cuda()), ncls, nv.ptr(logits),
+            nv.ptr(probs), nv.ptr(cls), nv.ll_array((ncls * vox, vox, H * W, W, 1)), 1.0, 0, N, D, H, W, nv.stream())
+    torch.cuda.synchronize()
+    assert (logits.cpu() - ref_l).abs().max() < 1e-5
+    assert (probs.cpu() - ref_p).abs().max() < 1e-6
+    # class map must be exactly np.argmax of the probabilities we returned (predict.py:38)
+    want = np.argmax(probs.cpu().numpy(), axis=1).reshape(N, vox)
+    assert np.array_equal(cls.cpu().numpy(), want)
