@@ -220,7 +220,8 @@ def test_head_softmax_argmax(nv, ncls):
     logits = torch.empty(N, ncls, D, H, W, device='cuda')
     probs = torch.empty(N, ncls, D, H, W, device='cuda')
     cls = torch.empty(N, vox, dtype=torch.uint8, device='cuda')
-    nv.call('iunet_head_fwd', 0, nv.ptr(xb), C0 * vox, C0, nv.ptr(w.cuda()), nv.ptr(b.cuda()), ncls, nv.ptr(logits),
+    wd, bd = w.cuda(), b.cuda()          # keep the device copies alive across the async launch
+    nv.call('iunet_head_fwd', 0, nv.ptr(xb), C0 * vox, C0, nv.ptr(wd), nv.ptr(bd), ncls, nv.ptr(logits),
             nv.ptr(probs), nv.ptr(cls), nv.ll_array((ncls * vox, vox, H * W, W, 1)), 1.0, 0, N, D, H, W, nv.stream())
     torch.cuda.synchronize()
     assert (logits.cpu() - ref_l).abs().max() < 1e-5
