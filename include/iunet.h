@@ -80,6 +80,60 @@ int iunet_normalize_quantize(const void* pred, const void* weight, void* out_u8,
                              void* stream);
 int iunet_div_f32(void* p, long long n, float d, void* stream);
 
+/* ---- training step (replaces autograd + AMP + AdamW under unet.py:71-102, trainer.py:56-63) -- */
+/* BatchNorm batch statistics: slab = partial (sum, sumsq) [nparts][C][2] written by the conv
+ * epilogues -> per-channel scale/shift (gamma*invstd, beta-mean*scale), mean, invstd; updates
+ * running_mean / running_var (momentum, unbiased variance) when they are not NULL. */
+int iunet_bn_finalize(const void* slab, int nparts, int C, double count, const void* gamma, const void* beta,
+                      void* running_mean, void* running_var, float momentum, float eps, void* scale, void* shift,
+                      void* mean, void* invstd, void* stream);
+int iunet_bn_relu_fwd(int dtype, const void* y, long long y_ss, void* z, long long z_ss, const void* scale,
+                      const void* shift, int C, int N, long long vox, void* stream);
+/* backward of z = relu(bn(y)): dy, dgamma, dbeta from dz, z, y.  slab: iunet_bn_bwd_num_parts*C*2 floats,
+ * coef: 3*C floats of scratch. */
+int iunet_bn_bwd_num_parts(int N, long long vox);
+int iunet_bn_relu_bwd(int dtype, const void* dz, long long dz_ss, const void* z, long long z_ss, const void* y,
+                      long long y_ss, void* dy, long long dy_ss, const void* mean, const void* invstd, const void* gamma,
+                      void* dgamma, void* dbeta, void* slab, void* coef, int C, int N, long long vox, void* stream);
+/* dz = (add_skip ? dz : 0) + max-pool backward of dpool (first maximum gets the gradient), in place. */
+int iunet_maxpool_bwd(int dtype, int nd, const void* z, long long z_ss, const void* dpool, long long dp_ss, void* dz,
+                      long long dz_ss, int add_skip, int C, int N, int Do, int Ho, int Wo, void* stream);
+/* fused 1x1 head + softmax + weighted soft-confusion loss of metrics.py:3-187 with axes = batch + spatial
+ * (unet.py:98).  kind: 0 CE, 1 Dice, 2 IoU, 3 MCC, 4 Dice+CE, 5 IoU+CE, 6 MCC+CE (utils.py:458-475).
+ * target / weight: [N][ncls][vox], tdtype 0 f32 / 1 f16; weight may be NULL.
+ * out4 = {loss, Dice, IoU, MCC on rounded tensors (unet.py:75-86)}; coef = [ncls][3] gradient coefficients
+ * consumed by iunet_head_loss_bwd.  slab: iunet_head_loss_num_parts*ncls*8 floats. */
+int iunet_head_loss_num_parts(int N, long long vox);
+int iunet_head_loss_fwd(int dtype, const void* x, long long x_ss, int C0, const void* w, const void* bias, int ncls,
+                        const void* target, const void* weight, int tdtype, int kind, void* slab, void* out4, void* coef,
+                        int N, long long vox, void* stream);
+/* backward through loss, softmax and head: dx (NHWC8c), dW/db partial slab [num_parts][ncls*(C0+1)]. */
+int iunet_head_loss_bwd(int dtype, const void* x, long long x_ss, int C0, const void* w, const void* bias, int ncls,
+                        const void* target, const void* weight, int tdtype, const void* coef, float loss_scale, void* dx,
+                        long long dx_ss, void* dwslab, int N, long long vox, void* stream);
+/* out[i] = alpha * sum_p slab[p][i] (+ out[i]); fixed summation order. */
+int iunet_reduce_slab(const void* slab, int nparts, long long n, void* out, float alpha, int accumulate, void* stream);
+/* weight gradient of the 3^d conv on MFMA (transposing LDS reads): dW fp32 [Cout][Cin][taps]. */
+int iunet_conv3_wgrad_blocks(int nd, int N, int D, int H, int W, int Cin, int Cout);
+long long iunet_conv3_wgrad_slab_floats(int nd, int N, int D, int H, int W, int Cin, int Cout);
+int iunet_conv3_wgrad(int dtype, int nd, const void* x, long long x_ss, const void* dy, long long dy_ss, void* slab,
+                      void* dW, float alpha, int N, int D, int H, int W, int Cin, int Cout, void* stream);
+/* transposed conv backward (N, D, H, W, Cin, Cout describe the forward op). */
+int iunet_pack_convT_dgrad(int dtype, const void* w, void* dst, int Cin, int Cout, int npos, void* stream);
+int iunet_convT_dgrad(int dtype, int nd, const void* dy, long long dy_ss, void* dx, long long dx_ss, const void* wpk,
+                      int N, int D, int H, int W, int Cin, int Cout, void* stream);
+int iunet_convT_wgrad_blocks(int N, int D, int H, int W);
+int iunet_convT_wgrad(int dtype, int nd, const void* x, long long x_ss, const void* dy, long long dy_ss, void* wslab,
+                      void* bslab, int N, int D, int H, int W, int Cin, int Cout, void* stream);
+int iunet_first_conv_wgrad_tiles(int nd, int N, int D, int H, int W);
+int iunet_first_conv_wgrad(int dtype, int nd, const void* x, int in_dtype, const long long* in_strides, const void* dy,
+                           long long dy_ss, void* slab, int N, int D, int H, int W, int Cin, int Cout, void* stream);
+/* AdamW with torch defaults (unet.py:71-73); grads are multiplied by grad_scale_inv (loss scaling, 1/world);
+ * if *skip_flag != 0 (set by iunet_check_finite) the step is skipped. */
+int iunet_check_finite(const void* g, long long n, void* flag, void* stream);
+int iunet_adamw_step(void* p, const void* g, void* m, void* v, long long n, float lr, float b1, float b2, float eps,
+                     float wd, int step, float grad_scale_inv, const void* skip_flag, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

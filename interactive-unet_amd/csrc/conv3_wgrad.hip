@@ -1,0 +1,285 @@
+// Weight gradient of the 3^d convolution on the matrix cores:
+//     dW[co][ci][tap] = sum_{n, v} dy[n][co][v] * x[n][ci][v + tap - 1]
+// GEMM per tap with the VOXELS as the reduction (k) dimension: A[co][k = voxel] = dy^T,
+// B[k = voxel][ci] = x shifted by the tap.  Both operands need "8 consecutive voxels of one
+// channel" per lane while the HBM/LDS layout (NHWC8c) has the channels innermost, so the
+// fragments are read with gfx950's transposing LDS read ds_read_b64_tr_b16 straight from
+// the channel-innermost tile images (no transposed copy of the activations anywhere).
+//
+// One workgroup (4 waves) walks voxel tiles for one (32 co) x (32 ci) block of the filter
+// and keeps all TAPS x 32 x 32 partial sums in registers (split over the waves by
+// (tap, ci half)); at the end it stores one fp32 slab; a second kernel sums the slabs in a
+// fixed order into dW (deterministic, no float atomics).
+//
+// LDS plane strides are 64 mod 256 bytes: a 32-lane half of the tr-read touches planes
+// p, p+1 and pixels P..P+3, P+8..P+11 -> 32 distinct 8-byte slots of the 256-B bank row.
+#include "common.h"
+
+namespace {
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) s16x4* lds_s4_ptr;
+
+template <int ND> struct WTile;
+template <> struct WTile<3> { static constexpr int TZ = 2, TY = 8, TX = 16, PADZ = 1, TAPS = 27; };
+template <> struct WTile<2> { static constexpr int TZ = 1, TY = 16, TX = 32, PADZ = 0, TAPS = 9; };
+
+struct WgradParams {
+  const void* x;  long long x_ss;     // conv input  (Cin/8 planes)
+  const void* dy; long long dy_ss;    // output grad (Cout/8 planes)
+  float* slab;                        // [gridDim.x][Cout/32][Cin/32][TAPS][32][32]
+  int N, D, H, W, Cin, Cout;
+  int tilesZ, tilesY, tilesX;
+};
+
+template <typename T>
+__device__ __forceinline__ typename Vec8<T>::type tr_frag(unsigned addr) {
+  // two transposing reads: k = 0..3 and k = 4..7 (4 voxels = 64 bytes further) of this lane's k-quad
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)addr);
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(addr + 64));
+  const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(typename Vec8<T>::type, v);
+}
+
+template <typename T, int ND>
+__global__ __launch_bounds__(256, 2) void conv3_wgrad_kernel(WgradParams p) {
+  using TL = WTile<ND>;
+  constexpr int TZ = TL::TZ, TY = TL::TY, TX = TL::TX, PADZ = TL::PADZ, TAPS = TL::TAPS;
+  constexpr int PZ = TZ + 2 * PADZ, PY = TY + 2, PX = TX + 2;
+  constexpr int NPIX = PZ * PY * PX;
+  constexpr int NVOX = TZ * TY * TX;
+  constexpr int FX = TX / 16;
+  constexpr int NFRAG = NVOX / 16;
+  constexpr int NKS = NFRAG / 2;                                   // k-steps of 32 voxels
+  constexpr int PLANE_X = ((NPIX * 16 + 255) / 256) * 256 + 64;    // 64 mod 256
+  constexpr int PLANE_Y = ((NVOX * 16 + 255) / 256) * 256 + 64;
+  constexpr int OFF_Y = 4 * PLANE_X;
+  constexpr int NU = TAPS * 2;                                     // units = (tap, ci half)
+  constexpr int MAXU = (NU + 3) / 4;
+
+  extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform -> scalar registers
+  const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3;
+  const int gh = g >> 1, gl = g & 1;
+
+  // lane part of the tr-read addresses (bytes): voxel (gl*8 + q) of fragment gh, channels 4pp..4pp+3
+  const unsigned laneY = lds0 + OFF_Y + (pp >> 1) * PLANE_Y + (pp & 1) * 8 + (gh * 16 + gl * 8 + q) * 16;
+  // x image: fragment gh is the next y row (3-D, FX = 1) or the next 16 x voxels (2-D, FX = 2)
+  const int ghpix = (FX == 1) ? gh * PX : gh * 16;
+  const unsigned laneX = lds0 + (pp >> 1) * PLANE_X + (pp & 1) * 8 + (ghpix + gl * 8 + q) * 16;
+
+  // units of this wave: u = wave + 4 i  ->  tap = u >> 1, ci half = u & 1
+  unsigned unit_off[MAXU];
+#pragma unroll
+  for (int i = 0; i < MAXU; ++i) {
+    const int u = wave + 4 * i;
+    const int tap = (u < NU ? u : 0) >> 1, cih = u & 1;
+    const int dz = ND == 3 ? tap / 9 : 0, dy_ = (tap / 3) % 3, dx = tap % 3;
+    unit_off[i] = (unsigned)(((dz * PY + dy_) * PX + dx) * 16 + cih * 2 * PLANE_X);
+  }
+
+  f32x4 acc[MAXU][2];
+#pragma unroll
+  for (int i = 0; i < MAXU; ++i) { acc[i][0] = f32x4{0, 0, 0, 0}; acc[i][1] = f32x4{0, 0, 0, 0}; }
+
+  const int tiles_per_sample = p.tilesZ * p.tilesY * p.tilesX;
+  const int ntiles = tiles_per_sample * p.N;
+  const int cob = blockIdx.y, cib = blockIdx.z;
+  const long long plane_stride = (long long)p.D * p.H * p.W * 8;
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int n_img = tile / tiles_per_sample;
+    int trem = tile - n_img * tiles_per_sample;
+    const int tz_i = trem / (p.tilesY * p.tilesX);
+    trem -= tz_i * p.tilesY * p.tilesX;
+    const int ty_i = trem / p.tilesX, tx_i = trem - ty_i * p.tilesX;
+    const int z0 = tz_i * TZ, y0 = ty_i * TY, x0 = tx_i * TX;
+    const T* xin = (const T*)p.x + (long long)n_img * p.x_ss + (long long)cib * 4 * plane_stride;
+    const T* dyin = (const T*)p.dy + (long long)n_img * p.dy_ss + (long long)cob * 4 * plane_stride;
+
+    __syncthreads();    // previous tile's reads are done
+    // ---- stage x halo tile (4 planes) ----
+    {
+      constexpr int ITERS = (NPIX + 255) / 256;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        u32x4 v[ITERS][2];
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+          const int pix = tid + it * 256;
+          const int px = pix % PX, t2 = pix / PX;
+          const int py = t2 % PY, pz = t2 / PY;
+          const int gz = z0 + pz - PADZ, gy = y0 + py - 1, gx = x0 + px - 1;
+          const bool ok = (pix < NPIX) && (unsigned)gz < (unsigned)p.D && (unsigned)gy < (unsigned)p.H &&
+                          (unsigned)gx < (unsigned)p.W;
+          const long long goff = (((long long)gz * p.H + gy) * p.W + gx) * 8;
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            u32x4 val = u32x4{0u, 0u, 0u, 0u};
+            if (ok) val = *(const u32x4*)(xin + (half * 2 + k) * plane_stride + goff);
+            v[it][k] = val;
+          }
+        }
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+          const int pix = tid + it * 256;
+          if (pix < NPIX) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) *(u32x4*)(smem + (half * 2 + k) * PLANE_X + pix * 16) = v[it][k];
+          }
+        }
+      }
+    }
+    // ---- stage dy tile (4 planes, no halo), zero outside the image ----
+    {
+      constexpr int ITERS = NVOX / 256;
+      static_assert(NVOX % 256 == 0, "tile voxels must be a multiple of 256");
+      u32x4 v[ITERS][4];
+#pragma unroll
+      for (int it = 0; it < ITERS; ++it) {
+        const int pix = tid + it * 256;
+        const int px = pix % TX, t2 = pix / TX;
+        const int py = t2 % TY, pz = t2 / TY;
+        const int gz = z0 + pz, gy = y0 + py, gx = x0 + px;
+        const bool ok = gz < p.D && gy < p.H && gx < p.W;
+        const long long goff = (((long long)gz * p.H + gy) * p.W + gx) * 8;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          u32x4 val = u32x4{0u, 0u, 0u, 0u};
+          if (ok) val = *(const u32x4*)(dyin + k * plane_stride + goff);
+          v[it][k] = val;
+        }
+      }
+#pragma unroll
+      for (int it = 0; it < ITERS; ++it) {
+        const int pix = tid + it * 256;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) *(u32x4*)(smem + OFF_Y + k * PLANE_Y + pix * 16) = v[it][k];
+      }
+    }
+    __syncthreads();
+
+    // ---- k loop over 32-voxel steps (fragments 2ks, 2ks+1) ----
+#pragma unroll 2
+    for (int ks = 0; ks < NKS; ++ks) {
+      // fragment 2ks -> (fz, fy, xh); the lane's own fragment adds gh (folded into laneX / laneY)
+      const int f = 2 * ks;
+      const int xh = f % FX, row = f / FX;
+      const int fy = row % TY, fz = row / TY;
+      const unsigned offY = (unsigned)(f * 16 * 16);
+      const unsigned offX = (unsigned)((((fz * PY + fy) * PX) + xh * 16) * 16);
+      const typename Vec8<T>::type a0 = tr_frag<T>(laneY + offY);                    // co 0..15
+      const typename Vec8<T>::type a1 = tr_frag<T>(laneY + offY + 2 * PLANE_Y);      // co 16..31
+#pragma unroll
+      for (int i = 0; i < MAXU; ++i) {
+        if (wave + 4 * i < NU) {        // wave-uniform
+          const typename Vec8<T>::type b = tr_frag<T>(laneX + offX + unit_off[i]);
+          acc[i][0] = mfma16<T>(a0, b, acc[i][0]);
+          acc[i][1] = mfma16<T>(a1, b, acc[i][1]);
+        }
+      }
+    }
+  }
+
+  // ---- store the slab: D rows = co (4g + j), cols = ci (lane & 15) ----
+  const int ncob = gridDim.y, ncib = gridDim.z;
+  float* slab = p.slab + ((((long long)blockIdx.x * ncob + cob) * ncib + cib) * TAPS) * 1024;
+#pragma unroll
+  for (int i = 0; i < MAXU; ++i) {
+    const int u = wave + 4 * i;
+    if (u < NU) {
+      const int tap = u >> 1, cih = u & 1;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          slab[tap * 1024 + (t * 16 + 4 * g + j) * 32 + cih * 16 + i16] = acc[i][t][j];
+    }
+  }
+}
+
+// dW[co][ci][tap] (+)= alpha * sum_b slab[b][cob][cib][tap][co%32][ci%32]
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int nb, int Cout, int Cin, int taps,
+                                                           float* __restrict__ dW, float alpha) {
+  const long long total = (long long)Cout * Cin * taps;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int tap = (int)(i % taps);
+  const int ci = (int)((i / taps) % Cin);
+  const int co = (int)(i / ((long long)taps * Cin));
+  const int ncob = Cout / 32, ncib = Cin / 32;
+  const long long per_b = (long long)ncob * ncib * taps * 1024;
+  const long long off = ((((long long)(co / 32)) * ncib + ci / 32) * taps + tap) * 1024 + (co % 32) * 32 + (ci % 32);
+  float s = 0.f;
+  for (int b = 0; b < nb; ++b) s += slab[b * per_b + off];
+  dW[i] = alpha * s;
+}
+
+template <typename T, int ND>
+int launch_wgrad(const WgradParams& p, int nb, hipStream_t stream) {
+  using TL = WTile<ND>;
+  constexpr int PZ = TL::TZ + 2 * TL::PADZ, PY = TL::TY + 2, PX = TL::TX + 2;
+  constexpr int PLANE_X = ((PZ * PY * PX * 16 + 255) / 256) * 256 + 64;
+  constexpr int PLANE_Y = ((TL::TZ * TL::TY * TL::TX * 16 + 255) / 256) * 256 + 64;
+  constexpr int LDS = 4 * PLANE_X + 4 * PLANE_Y;
+  static bool attr_set = false;
+  if (!attr_set) {
+    IUNET_CHECK_HIP(hipFuncSetAttribute((const void*)conv3_wgrad_kernel<T, ND>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    attr_set = true;
+  }
+  dim3 grid(nb, p.Cout / 32, p.Cin / 32);
+  hipLaunchKernelGGL((conv3_wgrad_kernel<T, ND>), grid, dim3(256), LDS, stream, p);
+  IUNET_CHECK_HIP(hipGetLastError());
+  return IUNET_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+// number of voxel-walking workgroups per (co, ci) block and the slab size they need
+int iunet_conv3_wgrad_blocks(int nd, int N, int D, int H, int W, int Cin, int Cout) {
+  const int TZ = nd == 3 ? 2 : 1, TY = nd == 3 ? 8 : 16, TX = nd == 3 ? 16 : 32;
+  const long long ntiles = (long long)N * ((D + TZ - 1) / TZ) * ((H + TY - 1) / TY) * ((W + TX - 1) / TX);
+  const int pairs = (Cin / 32) * (Cout / 32);
+  long long nb = (512 + pairs - 1) / pairs;          // about two workgroups per CU in total
+  if (nb > ntiles) nb = ntiles;
+  if (nb < 1) nb = 1;
+  return (int)nb;
+}
+
+long long iunet_conv3_wgrad_slab_floats(int nd, int N, int D, int H, int W, int Cin, int Cout) {
+  const int taps = nd == 3 ? 27 : 9;
+  return (long long)iunet_conv3_wgrad_blocks(nd, N, D, H, W, Cin, Cout) * (Cout / 32) * (Cin / 32) * taps * 1024;
+}
+
+// dW fp32 [Cout][Cin][taps] = alpha * sum over samples and voxels of dy (x) shifted x
+int iunet_conv3_wgrad(int dtype, int nd, const void* x, long long x_ss, const void* dy, long long dy_ss, void* slab,
+                      void* dW, float alpha, int N, int D, int H, int W, int Cin, int Cout, void* stream) {
+  IUNET_REQUIRE(dtype == 0 || dtype == 1, "conv3_wgrad: bad dtype %d", dtype);
+  IUNET_REQUIRE(nd == 2 || nd == 3, "conv3_wgrad: nd must be 2 or 3");
+  IUNET_REQUIRE(Cin % 32 == 0 && Cout % 32 == 0, "conv3_wgrad: channels must be multiples of 32 (%d, %d)", Cin, Cout);
+  IUNET_REQUIRE(x && dy && slab && dW, "conv3_wgrad: null pointer");
+  WgradParams p;
+  p.x = x; p.x_ss = x_ss; p.dy = dy; p.dy_ss = dy_ss; p.slab = (float*)slab;
+  p.N = N; p.D = D; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
+  const int TZ = nd == 3 ? 2 : 1, TY = nd == 3 ? 8 : 16, TX = nd == 3 ? 16 : 32;
+  p.tilesZ = (D + TZ - 1) / TZ; p.tilesY = (H + TY - 1) / TY; p.tilesX = (W + TX - 1) / TX;
+  const int nb = iunet_conv3_wgrad_blocks(nd, N, D, H, W, Cin, Cout);
+  int rc;
+  if (dtype == 0) rc = nd == 3 ? launch_wgrad<f16, 3>(p, nb, (hipStream_t)stream) : launch_wgrad<f16, 2>(p, nb, (hipStream_t)stream);
+  else rc = nd == 3 ? launch_wgrad<bf16, 3>(p, nb, (hipStream_t)stream) : launch_wgrad<bf16, 2>(p, nb, (hipStream_t)stream);
+  if (rc != IUNET_OK) return rc;
+  const int taps = nd == 3 ? 27 : 9;
+  const long long total = (long long)Cout * Cin * taps;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)slab, nb, Cout, Cin, taps, (float*)dW, alpha);
+  IUNET_CHECK_HIP(hipGetLastError());
+  return IUNET_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,611 @@
+// Training-side HBM-bound kernels: BatchNorm batch statistics / apply / backward, the
+// fused 1x1 head + softmax + weighted soft-confusion loss (metrics.py) forward and
+// backward, max-pool backward, slab reductions, AdamW.  All reductions go through
+// per-block partial slabs summed in a fixed order (deterministic, no float atomics).
+#include "common.h"
+
+namespace {
+
+template <typename T> using V8T = typename Vec8<T>::type;
+
+__device__ __forceinline__ float block_sum_256(float v, float* red /* [4] */) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+// ------------------------------------------------------------------ BN statistics -> scale/shift
+// slab [nparts][C][2] (sum, sumsq of the raw conv output).  One block per channel.
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ slab, int nparts, int C, double count,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float* running_mean, float* running_var, float momentum,
+                                                          float eps, float* scale, float* shift, float* mean_o,
+                                                          float* invstd_o) {
+  const int c = blockIdx.x;
+  double s = 0.0, s2 = 0.0;
+  for (int p = threadIdx.x; p < nparts; p += 256) {
+    s += (double)slab[((long long)p * C + c) * 2];
+    s2 += (double)slab[((long long)p * C + c) * 2 + 1];
+  }
+  __shared__ double red[2][256];
+  red[0][threadIdx.x] = s; red[1][threadIdx.x] = s2;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) { red[0][threadIdx.x] += red[0][threadIdx.x + o]; red[1][threadIdx.x] += red[1][threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double mean = red[0][0] / count;
+    double var = red[1][0] / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = gamma[c] * invstd;
+    scale[c] = sc;
+    shift[c] = beta[c] - (float)mean * sc;
+    mean_o[c] = (float)mean;
+    invstd_o[c] = invstd;
+    if (running_mean) {
+      const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+    }
+  }
+}
+
+// z = relu(scale[c] * y + shift[c]), blocked layout, 16 B per thread
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_fwd_kernel(const T* __restrict__ y, long long y_ss, T* __restrict__ z,
+                                                          long long z_ss, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, int planes, long long vox) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= vox * planes) return;
+  const int n = blockIdx.y;
+  const int pl = (int)(i / vox);
+  const V8T<T> v = *(const V8T<T>*)(y + n * y_ss + i * 8);
+  V8T<T> o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    o[j] = from_f32<T>(fmaxf(fmaf(scale[pl * 8 + j], to_f32<T>(v[j]), shift[pl * 8 + j]), 0.f));
+  *(V8T<T>*)(z + n * z_ss + i * 8) = o;
+}
+
+// BN+ReLU backward, pass 1: per-channel s1 = sum(dyh), s2 = sum(dyh * xhat), dyh = dz * (z > 0).
+// grid (chunks, planes, N); slab [(n*chunks + chunk)][C][2]
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dz, long long dz_ss,
+                                                            const T* __restrict__ z, long long z_ss,
+                                                            const T* __restrict__ y, long long y_ss,
+                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                            int C, long long vox, int per_block, float* __restrict__ slab) {
+  const int pl = blockIdx.y, n = blockIdx.z;
+  const long long v0 = (long long)blockIdx.x * per_block;
+  const long long v1 = min(v0 + per_block, vox);
+  float s1[8], s2[8], mu[8], is[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; mu[j] = mean[pl * 8 + j]; is[j] = invstd[pl * 8 + j]; }
+  const long long po = (long long)pl * vox * 8;
+  for (long long v = v0 + threadIdx.x; v < v1; v += 256) {
+    const V8T<T> g = *(const V8T<T>*)(dz + n * dz_ss + po + v * 8);
+    const V8T<T> zz = *(const V8T<T>*)(z + n * z_ss + po + v * 8);
+    const V8T<T> yy = *(const V8T<T>*)(y + n * y_ss + po + v * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float d = to_f32<T>(zz[j]) > 0.f ? to_f32<T>(g[j]) : 0.f;
+      s1[j] += d;
+      s2[j] += d * (to_f32<T>(yy[j]) - mu[j]) * is[j];
+    }
+  }
+  __shared__ float red[4];
+  const long long part = (long long)n * gridDim.x + blockIdx.x;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float a = block_sum_256(s1[j], red);
+    const float b = block_sum_256(s2[j], red);
+    if (threadIdx.x == 0) { slab[(part * C + pl * 8 + j) * 2] = a; slab[(part * C + pl * 8 + j) * 2 + 1] = b; }
+  }
+}
+
+// pass 1b: dgamma = s2, dbeta = s1 (times grad_unscale), coefficients for pass 2
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ slab, int nparts, int C, double count,
+                                                              const float* __restrict__ gamma, const float* __restrict__ invstd,
+                                                              float* dgamma, float* dbeta, float* coef /* [C][3]: a, c1, c2 */) {
+  const int c = blockIdx.x;
+  double s = 0.0, s2 = 0.0;
+  for (int p = threadIdx.x; p < nparts; p += 256) {
+    s += (double)slab[((long long)p * C + c) * 2];
+    s2 += (double)slab[((long long)p * C + c) * 2 + 1];
+  }
+  __shared__ double red[2][256];
+  red[0][threadIdx.x] = s; red[1][threadIdx.x] = s2;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) { red[0][threadIdx.x] += red[0][threadIdx.x + o]; red[1][threadIdx.x] += red[1][threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    dbeta[c] = (float)red[0][0];
+    dgamma[c] = (float)red[1][0];
+    coef[c * 3 + 0] = gamma[c] * invstd[c];
+    coef[c * 3 + 1] = (float)(red[0][0] / count);
+    coef[c * 3 + 2] = (float)(red[1][0] / count);
+  }
+}
+
+// pass 2: dy = a * (dyh - c1 - xhat * c2)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dz, long long dz_ss, const T* __restrict__ z,
+                                                           long long z_ss, const T* __restrict__ y, long long y_ss,
+                                                           T* __restrict__ dy, long long dy_ss, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, const float* __restrict__ coef,
+                                                           int planes, long long vox) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= vox * planes) return;
+  const int n = blockIdx.y;
+  const int pl = (int)(i / vox);
+  const V8T<T> g = *(const V8T<T>*)(dz + n * dz_ss + i * 8);
+  const V8T<T> zz = *(const V8T<T>*)(z + n * z_ss + i * 8);
+  const V8T<T> yy = *(const V8T<T>*)(y + n * y_ss + i * 8);
+  V8T<T> o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = pl * 8 + j;
+    const float d = to_f32<T>(zz[j]) > 0.f ? to_f32<T>(g[j]) : 0.f;
+    const float xh = (to_f32<T>(yy[j]) - mean[c]) * invstd[c];
+    o[j] = from_f32<T>(coef[c * 3] * (d - coef[c * 3 + 1] - xh * coef[c * 3 + 2]));
+  }
+  *(V8T<T>*)(dy + n * dy_ss + i * 8) = o;
+}
+
+// ------------------------------------------------------------------ max-pool backward (+ skip gradient)
+// dz[v] = (dskip ? dskip[v] : 0) + (v is the FIRST maximum of its window ? dpool : 0), in place on dskip.
+template <typename T, int ND>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ z, long long z_ss, const T* __restrict__ dpool,
+                                                          long long dp_ss, T* __restrict__ dz, long long dz_ss, int add_skip,
+                                                          int planes, int Do, int Ho, int Wo) {
+  const long long ovox = (long long)Do * Ho * Wo;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= ovox * planes) return;
+  const int n = blockIdx.y;
+  const int pl = (int)(i / ovox);
+  const long long r = i - (long long)pl * ovox;
+  const int ox = (int)(r % Wo), oy = (int)((r / Wo) % Ho), oz = (int)(r / ((long long)Wo * Ho));
+  const int Di = ND == 3 ? Do * 2 : 1, Hi = Ho * 2, Wi = Wo * 2;
+  const long long ipl = (long long)pl * Di * Hi * Wi * 8;
+  constexpr int NW = ND == 3 ? 8 : 4;
+  V8T<T> win[NW];
+  long long off[NW];
+#pragma unroll
+  for (int s = 0; s < NW; ++s) {
+    const int a = ND == 3 ? (s >> 2) : 0, b = (s >> 1) & 1, c = s & 1;
+    const int zz = ND == 3 ? oz * 2 + a : 0;
+    off[s] = ipl + (((long long)zz * Hi + oy * 2 + b) * Wi + ox * 2 + c) * 8;
+    win[s] = *(const V8T<T>*)(z + n * z_ss + off[s]);
+  }
+  const V8T<T> g = *(const V8T<T>*)(dpool + n * dp_ss + (long long)pl * ovox * 8 + r * 8);
+  int best[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float m = to_f32<T>(win[0][j]); best[j] = 0;
+#pragma unroll
+    for (int s = 1; s < NW; ++s) { const float v = to_f32<T>(win[s][j]); if (v > m) { m = v; best[j] = s; } }
+  }
+#pragma unroll
+  for (int s = 0; s < NW; ++s) {
+    V8T<T> o;
+    if (add_skip) o = *(const V8T<T>*)(dz + n * dz_ss + off[s]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float base = add_skip ? to_f32<T>(o[j]) : 0.f;
+      o[j] = from_f32<T>(base + (best[j] == s ? to_f32<T>(g[j]) : 0.f));
+    }
+    *(V8T<T>*)(dz + n * dz_ss + off[s]) = o;
+  }
+}
+
+// ------------------------------------------------------------------ fused head + softmax + loss
+// targets / weights: [N][ncls][vox] contiguous, f16 (tdtype 1) or f32 (tdtype 0).
+__device__ __forceinline__ float load_t(const void* p, long long off, int dt) {
+  return dt == 0 ? ((const float*)p)[off] : (float)((const f16*)p)[off];
+}
+
+struct HeadLossParams {
+  const void* x; long long x_ss; int planes;
+  const float* w; const float* bias;
+  const void* target; const void* weight; int tdtype;
+  float* slab;          // fwd: [nblocks][ncls][8]
+  const float* coef;    // bwd: [ncls][3] (A, B, CE)
+  void* dx; long long dx_ss;   // bwd: gradient wrt head input (T, blocked)
+  float* dwslab;        // bwd: [nblocks][ncls*(C0+1)]
+  float loss_scale;
+  int N; long long vox;
+};
+
+// sums per class: 0 sw, 1 swy, 2 swp, 3 swyp, 4 swy*log(p+eps), 5 sw*ry, 6 sw*rp, 7 sw*ry*rp
+template <typename T, int NCLS>
+__global__ __launch_bounds__(256) void head_loss_fwd_kernel(HeadLossParams p) {
+  const long long v = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int n = blockIdx.y;
+  const bool ok = v < p.vox;
+  float acc[NCLS][8];
+#pragma unroll
+  for (int c = 0; c < NCLS; ++c)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[c][k] = 0.f;
+  if (ok) {
+    const T* xin = (const T*)p.x + n * p.x_ss + v * 8;
+    float l[NCLS];
+#pragma unroll
+    for (int c = 0; c < NCLS; ++c) l[c] = p.bias[c];
+    for (int pl = 0; pl < p.planes; ++pl) {
+      const V8T<T> xv = *(const V8T<T>*)(xin + (long long)pl * p.vox * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float a = to_f32<T>(xv[j]);
+#pragma unroll
+        for (int c = 0; c < NCLS; ++c) l[c] = fmaf(a, p.w[c * p.planes * 8 + pl * 8 + j], l[c]);
+      }
+    }
+    float mx = l[0];
+#pragma unroll
+    for (int c = 1; c < NCLS; ++c) mx = fmaxf(mx, l[c]);
+    float e[NCLS], s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCLS; ++c) { e[c] = __expf(l[c] - mx); s += e[c]; }
+    const float inv = 1.f / s;
+#pragma unroll
+    for (int c = 0; c < NCLS; ++c) {
+      const float pr = e[c] * inv;
+      const long long to = ((long long)n * NCLS + c) * p.vox + v;
+      const float y = load_t(p.target, to, p.tdtype);
+      const float w = p.weight ? load_t(p.weight, to, p.tdtype) : 1.f;
+      const float ry = rintf(y), rp = rintf(pr);
+      acc[c][0] = w; acc[c][1] = w * y; acc[c][2] = w * pr; acc[c][3] = w * y * pr;
+      acc[c][4] = w * y * __logf(pr + 1e-12f);
+      acc[c][5] = w * ry; acc[c][6] = w * rp; acc[c][7] = w * ry * rp;
+    }
+  }
+  __shared__ float red[4];
+  const long long part = (long long)n * gridDim.x + blockIdx.x;
+#pragma unroll
+  for (int c = 0; c < NCLS; ++c)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float t = block_sum_256(acc[c][k], red);
+      if (threadIdx.x == 0) p.slab[(part * NCLS + c) * 8 + k] = t;
+    }
+}
+
+// One block: reduce the slab, evaluate the reference loss (metrics.py:3-187 with
+// axes = batch + spatial, mean over classes) and the rounded Dice/IoU/MCC of unet.py:75-86,
+// and emit per-class gradient coefficients: dL/dp = w*(A + B*y) - CE * w*y/(p+eps).
+// kind: 0 ce, 1 dice, 2 iou, 3 mcc, 4 dice+ce, 5 iou+ce, 6 mcc+ce.
+__global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restrict__ slab, int nparts, int ncls, int kind,
+                                                            int has_weight, double nvox_total, float* out /* [4]: loss, dice, iou, mcc */,
+                                                            float* coef /* [ncls][3] */) {
+  __shared__ double sums[10][8];
+  __shared__ double red[256];
+  for (int c = 0; c < ncls; ++c)
+    for (int k = 0; k < 8; ++k) {
+      double s = 0.0;
+      for (int pidx = threadIdx.x; pidx < nparts; pidx += 256) s += (double)slab[((long long)pidx * ncls + c) * 8 + k];
+      red[threadIdx.x] = s;
+      __syncthreads();
+      for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+      if (threadIdx.x == 0) sums[c][k] = red[0];
+      __syncthreads();
+    }
+  if (threadIdx.x != 0) return;
+  const double eps = 1e-12;
+  const bool use_ce = (kind == 0 || kind >= 4);
+  const int base = kind >= 4 ? kind - 3 : kind;      // 0 ce only, 1 dice, 2 iou, 3 mcc
+  double loss = 0.0, dice_r = 0.0, iou_r = 0.0, mcc_r = 0.0;
+  const double G = (double)ncls;
+  for (int c = 0; c < ncls; ++c) {
+    const double cnt = has_weight ? sums[c][0] : nvox_total;
+    const double tp = sums[c][3] / cnt, fp = (sums[c][2] - sums[c][3]) / cnt, fn = (sums[c][1] - sums[c][3]) / cnt;
+    const double tn = (sums[c][0] - sums[c][1] - sums[c][2] + sums[c][3]) / cnt;
+    double s_tp = 0, s_tn = 0, s_fp = 0, s_fn = 0, score = 0;
+    if (base == 1) {
+      const double num = 2 * tp + eps, den = 2 * tp + fp + fn + eps;
+      score = num / den; s_tp = (2 * den - 2 * num) / (den * den); s_fp = -num / (den * den); s_fn = s_fp;
+    } else if (base == 2) {
+      const double num = tp + eps, den = tp + fp + fn + eps;
+      score = num / den; s_tp = (den - num) / (den * den); s_fp = -num / (den * den); s_fn = s_fp;
+    } else if (base == 3) {
+      const double a = tp + fp, b = tp + fn, cc = tn + fp, d = tn + fn;
+      const double root = sqrt(a * b * cc * d), num = tp * tn - fp * fn + eps, den = root + eps;
+      score = num / den;
+      const double half = 0.5 / root;
+      const double r_tp = half * (b * cc * d + a * cc * d), r_tn = half * (a * b * d + a * b * cc);
+      const double r_fp = half * (b * cc * d + a * b * d), r_fn = half * (a * cc * d + a * b * cc);
+      s_tp = (tn * den - num * r_tp) / (den * den); s_tn = (tp * den - num * r_tn) / (den * den);
+      s_fp = (-fn * den - num * r_fp) / (den * den); s_fn = (-fp * den - num * r_fn) / (den * den);
+    }
+    if (base != 0) loss += (1.0 - score) / G;
+    if (use_ce) loss += (-sums[c][4] / cnt) / G;
+    // dL/dp = -(1/(G cnt)) w [ y (s_tp - s_fn) + (1-y)(s_fp - s_tn) ]
+    const double k = -1.0 / (G * cnt);
+    coef[c * 3 + 0] = (float)(k * (s_fp - s_tn));
+    coef[c * 3 + 1] = (float)(k * ((s_tp - s_fn) - (s_fp - s_tn)));
+    coef[c * 3 + 2] = use_ce ? (float)(1.0 / (G * cnt)) : 0.f;
+    // rounded metrics
+    const double rtp = sums[c][7] / cnt, rfp = (sums[c][6] - sums[c][7]) / cnt, rfn = (sums[c][5] - sums[c][7]) / cnt;
+    const double rtn = (sums[c][0] - sums[c][5] - sums[c][6] + sums[c][7]) / cnt;
+    dice_r += ((2 * rtp + eps) / (2 * rtp + rfp + rfn + eps)) / G;
+    iou_r += ((rtp + eps) / (rtp + rfp + rfn + eps)) / G;
+    mcc_r += ((rtp * rtn - rfp * rfn + eps) / (sqrt((rtp + rfp) * (rtp + rfn) * (rtn + rfp) * (rtn + rfn)) + eps)) / G;
+  }
+  out[0] = (float)loss; out[1] = (float)dice_r; out[2] = (float)iou_r; out[3] = (float)mcc_r;
+}
+
+// backward through loss, softmax and the 1x1 head.  C0 <= 64.
+template <typename T, int NCLS>
+__global__ __launch_bounds__(256) void head_loss_bwd_kernel(HeadLossParams p) {
+  const long long v = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int n = blockIdx.y;
+  const bool ok = v < p.vox;
+  const int C0 = p.planes * 8;
+  float dl[NCLS];
+#pragma unroll
+  for (int c = 0; c < NCLS; ++c) dl[c] = 0.f;
+  const T* xin = (const T*)p.x + n * p.x_ss + (ok ? v : 0) * 8;
+  if (ok) {
+    float l[NCLS];
+#pragma unroll
+    for (int c = 0; c < NCLS; ++c) l[c] = p.bias[c];
+    for (int pl = 0; pl < p.planes; ++pl) {
+      const V8T<T> xv = *(const V8T<T>*)(xin + (long long)pl * p.vox * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float a = to_f32<T>(xv[j]);
+#pragma unroll
+        for (int c = 0; c < NCLS; ++c) l[c] = fmaf(a, p.w[c * C0 + pl * 8 + j], l[c]);
+      }
+    }
+    float mx = l[0];
+#pragma unroll
+    for (int c = 1; c < NCLS; ++c) mx = fmaxf(mx, l[c]);
+    float e[NCLS], s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCLS; ++c) { e[c] = __expf(l[c] - mx); s += e[c]; }
+    const float inv = 1.f / s;
+    float g[NCLS], dot = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCLS; ++c) {
+      const float pr = e[c] * inv;
+      const long long to = ((long long)n * NCLS + c) * p.vox + v;
+      const float y = load_t(p.target, to, p.tdtype);
+      const float w = p.weight ? load_t(p.weight, to, p.tdtype) : 1.f;
+      g[c] = w * (p.coef[c * 3] + p.coef[c * 3 + 1] * y) - p.coef[c * 3 + 2] * w * y / (pr + 1e-12f);
+      e[c] = pr;
+      dot += g[c] * pr;
+    }
+#pragma unroll
+    for (int c = 0; c < NCLS; ++c) dl[c] = e[c] * (g[c] - dot) * p.loss_scale;     // softmax backward
+    // dx = W^T dl
+    T* dxo = (T*)p.dx + n * p.dx_ss + v * 8;
+    for (int pl = 0; pl < p.planes; ++pl) {
+      V8T<T> o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float a = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCLS; ++c) a = fmaf(dl[c], p.w[c * C0 + pl * 8 + j], a);
+        o[j] = from_f32<T>(a);
+      }
+      *(V8T<T>*)(dxo + (long long)pl * p.vox * 8) = o;
+    }
+  }
+  // dW[c][ch] = sum_v dl[c] * x[ch], db[c] = sum_v dl[c]: block partials
+  __shared__ float red[4];
+  const long long part = (long long)n * gridDim.x + blockIdx.x;
+  float* slab = p.dwslab + part * (NCLS * (C0 + 1));
+  for (int pl = 0; pl < p.planes; ++pl) {
+    V8T<T> xv;
+    if (ok) xv = *(const V8T<T>*)(xin + (long long)pl * p.vox * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float a = ok ? to_f32<T>(xv[j]) : 0.f;
+#pragma unroll
+      for (int c = 0; c < NCLS; ++c) {
+        const float t = block_sum_256(dl[c] * a, red);
+        if (threadIdx.x == 0) slab[c * (C0 + 1) + pl * 8 + j] = t;
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < NCLS; ++c) {
+    const float t = block_sum_256(dl[c], red);
+    if (threadIdx.x == 0) slab[c * (C0 + 1) + C0] = t;
+  }
+}
+
+// out[i] = alpha * sum_p slab[p][i] (+ out[i] if accumulate); fixed order.
+__global__ __launch_bounds__(256) void reduce_slab_kernel(const float* __restrict__ slab, int nparts, long long n,
+                                                          float* __restrict__ out, float alpha, int accumulate) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int p = 0; p < nparts; ++p) s += slab[(long long)p * n + i];
+  out[i] = alpha * s + (accumulate ? out[i] : 0.f);
+}
+
+// ------------------------------------------------------------------ AdamW (torch defaults, decoupled decay)
+// flag[0] != 0 (non-finite gradient found) -> the step is skipped entirely (fp16 loss scaling).
+__global__ __launch_bounds__(256) void check_finite_kernel(const float* __restrict__ g, long long n, int* flag) {
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  bool bad = false;
+  for (; i < n; i += (long long)gridDim.x * 256) bad |= !isfinite(g[i]);
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, long long n, float lr, float b1, float b2,
+                                                    float eps, float wd, float bc1, float bc2_sqrt, float ginv,
+                                                    const int* __restrict__ skip_flag) {
+  if (skip_flag && *skip_flag) return;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float gr = g[i] * ginv;
+  float pv = p[i] * (1.f - lr * wd);
+  const float mn = b1 * m[i] + (1.f - b1) * gr;
+  const float vn = b2 * v[i] + (1.f - b2) * gr * gr;
+  m[i] = mn; v[i] = vn;
+  const float denom = sqrtf(vn) / bc2_sqrt + eps;
+  pv -= (lr / bc1) * (mn / denom);
+  p[i] = pv;
+}
+
+}  // namespace
+
+#define DT_OK(dt) IUNET_REQUIRE((dt) == 0 || (dt) == 1, "dtype must be 0 (f16) or 1 (bf16), got %d", (dt))
+#define LAUNCH_T(kern, grid, ...)                                                              \
+  do {                                                                                         \
+    if (dtype == 0) hipLaunchKernelGGL((kern<f16>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);  \
+    else hipLaunchKernelGGL((kern<bf16>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); \
+  } while (0)
+
+extern "C" {
+
+int iunet_bn_finalize(const void* slab, int nparts, int C, double count, const void* gamma, const void* beta,
+                      void* running_mean, void* running_var, float momentum, float eps, void* scale, void* shift,
+                      void* mean, void* invstd, void* stream) {
+  IUNET_REQUIRE(slab && gamma && beta && scale && shift && mean && invstd, "bn_finalize: null pointer");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, (const float*)slab, nparts, C, count,
+                     (const float*)gamma, (const float*)beta, (float*)running_mean, (float*)running_var, momentum, eps,
+                     (float*)scale, (float*)shift, (float*)mean, (float*)invstd);
+  IUNET_CHECK_HIP(hipGetLastError());
+  return IUNET_OK;
+}
+
+int iunet_bn_relu_fwd(int dtype, const void* y, long long y_ss, void* z, long long z_ss, const void* scale,
+                      const void* shift, int C, int N, long long vox, void* stream) {
+  DT_OK(dtype);
+  const long long total = vox * (C / 8);
+  dim3 grid((unsigned)((total + 255) / 256), N);
+  if (dtype == 0) hipLaunchKernelGGL(bn_relu_fwd_kernel<f16>, grid, dim3(256), 0, (hipStream_t)stream, (const f16*)y, y_ss, (f16*)z, z_ss, (const float*)scale, (const float*)shift, C / 8, vox);
+  else hipLaunchKernelGGL(bn_relu_fwd_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)y, y_ss, (bf16*)z, z_ss, (const float*)scale, (const float*)shift, C / 8, vox);
+  IUNET_CHECK_HIP(hipGetLastError());
+  return IUNET_OK;
+}
+
+int iunet_bn_bwd_num_parts(int N, long long vox) {
+  const int per_block = 16384;
+  return N * (int)((vox + per_block - 1) / per_block);
+}
+
+int iunet_bn_relu_bwd(int dtype, const void* dz, long long dz_ss, const void* z, long long z_ss, const void* y,
+                      long long y_ss, void* dy, long long dy_ss, const void* mean, const void* invstd, const void* gamma,
+                      void* dgamma, void* dbeta, void* slab, void* coef, int C, int N, long long vox, void* stream) {
+  DT_OK(dtype);
+  IUNET_REQUIRE(dz && z && y && dy && slab && coef, "bn_relu_bwd: null pointer");
+  const int per_block = 16384;
+  const int chunks = (int)((vox + per_block - 1) / per_block);
+  dim3 g1(chunks, C / 8, N);
+  if (dtype == 0) hipLaunchKernelGGL(bn_bwd_reduce_kernel<f16>, g1, dim3(256), 0, (hipStream_t)stream, (const f16*)dz, dz_ss, (const f16*)z, z_ss, (const f16*)y, y_ss, (const float*)mean, (const float*)invstd, C, vox, per_block, (float*)slab);
+  else hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16>, g1, dim3(256), 0, (hipStream_t)stream, (const bf16*)dz, dz_ss, (const bf16*)z, z_ss, (const bf16*)y, y_ss, (const float*)mean, (const float*)invstd, C, vox, per_block, (float*)slab);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, (const float*)slab, chunks * N, C,
+                     (double)N * (double)vox, (const float*)gamma, (const float*)invstd, (float*)dgamma, (float*)dbeta, (float*)coef);
+  const long long total = vox * (C / 8);
+  dim3 g2((unsigned)((total + 255) / 256), N);
+  if (dtype == 0) hipLaunchKernelGGL(bn_bwd_apply_kernel<f16>, g2, dim3(256), 0, (hipStream_t)stream, (const f16*)dz, dz_ss, (const f16*)z, z_ss, (const f16*)y, y_ss, (f16*)dy, dy_ss, (const float*)mean, (const float*)invstd, (const float*)coef, C / 8, vox);
+  else hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16>, g2, dim3(256), 0, (hipStream_t)stream, (const bf16*)dz, dz_ss, (const bf16*)z, z_ss, (const bf16*)y, y_ss, (bf16*)dy, dy_ss, (const float*)mean, (const float*)invstd, (const float*)coef, C / 8, vox);
+  IUNET_CHECK_HIP(hipGetLastError());
+  return IUNET_OK;
+}
+
+int iunet_maxpool_bwd(int dtype, int nd, const void* z, long long z_ss, const void* dpool, long long dp_ss, void* dz,
+                      long long dz_ss, int add_skip, int C, int N, int Do, int Ho, int Wo, void* stream) {
+  DT_OK(dtype);
+  const long long total = (long long)Do * Ho * Wo * (C / 8);
+  dim3 grid((unsigned)((total + 255) / 256), N);
+#define MPB(TT, NDV) hipLaunchKernelGGL((maxpool_bwd_kernel<TT, NDV>), grid, dim3(256), 0, (hipStream_t)stream, (const TT*)z, z_ss, (const TT*)dpool, dp_ss, (TT*)dz, dz_ss, add_skip, C / 8, Do, Ho, Wo)
+  if (dtype == 0) { if (nd == 3) MPB(f16, 3); else MPB(f16, 2); } else { if (nd == 3) MPB(bf16, 3); else MPB(bf16, 2); }
+#undef MPB
+  IUNET_CHECK_HIP(hipGetLastError());
+  return IUNET_OK;
+}
+
+int iunet_head_loss_num_parts(int N, long long vox) { return N * (int)((vox + 255) / 256); }
+
+#define HEAD_SWITCH(KERN, TT)                                                                                   \
+  switch (ncls) {                                                                                               \
+    case 2: hipLaunchKernelGGL((KERN<TT, 2>), grid, dim3(256), 0, (hipStream_t)stream, p); break;               \
+    case 3: hipLaunchKernelGGL((KERN<TT, 3>), grid, dim3(256), 0, (hipStream_t)stream, p); break;               \
+    case 4: hipLaunchKernelGGL((KERN<TT, 4>), grid, dim3(256), 0, (hipStream_t)stream, p); break;               \
+    case 5: hipLaunchKernelGGL((KERN<TT, 5>), grid, dim3(256), 0, (hipStream_t)stream, p); break;               \
+    case 6: hipLaunchKernelGGL((KERN<TT, 6>), grid, dim3(256), 0, (hipStream_t)stream, p); break;               \
+    case 7: hipLaunchKernelGGL((KERN<TT, 7>), grid, dim3(256), 0, (hipStream_t)stream, p); break;               \
+    case 8: hipLaunchKernelGGL((KERN<TT, 8>), grid, dim3(256), 0, (hipStream_t)stream, p); break;               \
+    case 9: hipLaunchKernelGGL((KERN<TT, 9>), grid, dim3(256), 0, (hipStream_t)stream, p); break;               \
+    default: hipLaunchKernelGGL((KERN<TT, 10>), grid, dim3(256), 0, (hipStream_t)stream, p); break;             \
+  }
+
+// forward: head + softmax + loss sums -> loss value, rounded metrics, gradient coefficients
+int iunet_head_loss_fwd(int dtype, const void* x, long long x_ss, int C0, const void* w, const void* bias, int ncls,
+                        const void* target, const void* weight, int tdtype, int kind, void* slab, void* out4, void* coef,
+                        int N, long long vox, void* stream) {
+  DT_OK(dtype);
+  IUNET_REQUIRE(x && w && bias && target && slab && out4 && coef, "head_loss_fwd: null pointer");
+  IUNET_REQUIRE(ncls >= 2 && ncls <= 10, "head_loss: num_classes must be 2..10");
+  IUNET_REQUIRE(kind >= 0 && kind <= 6, "head_loss: unknown loss kind %d", kind);
+  IUNET_REQUIRE(tdtype == 0 || tdtype == 1, "head_loss: target dtype must be 0 (f32) or 1 (f16)");
+  HeadLossParams p{};
+  p.x = x; p.x_ss = x_ss; p.planes = C0 / 8; p.w = (const float*)w; p.bias = (const float*)bias;
+  p.target = target; p.weight = weight; p.tdtype = tdtype; p.slab = (float*)slab; p.N = N; p.vox = vox;
+  dim3 grid((unsigned)((vox + 255) / 256), N);
+  if (dtype == 0) { HEAD_SWITCH(head_loss_fwd_kernel, f16) } else { HEAD_SWITCH(head_loss_fwd_kernel, bf16) }
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)slab,
+                     iunet_head_loss_num_parts(N, vox), ncls, kind, weight != nullptr, (double)N * (double)vox,
+                     (float*)out4, (float*)coef);
+  IUNET_CHECK_HIP(hipGetLastError());
+  return IUNET_OK;
+}
+
+// backward: dx (gradient wrt head input), dW/db slabs [num_parts][ncls*(C0+1)]
+int iunet_head_loss_bwd(int dtype, const void* x, long long x_ss, int C0, const void* w, const void* bias, int ncls,
+                        const void* target, const void* weight, int tdtype, const void* coef, float loss_scale, void* dx,
+                        long long dx_ss, void* dwslab, int N, long long vox, void* stream) {
+  DT_OK(dtype);
+  IUNET_REQUIRE(x && w && bias && target && coef && dx && dwslab, "head_loss_bwd: null pointer");
+  IUNET_REQUIRE(ncls >= 2 && ncls <= 10, "head_loss: num_classes must be 2..10");
+  HeadLossParams p{};
+  p.x = x; p.x_ss = x_ss; p.planes = C0 / 8; p.w = (const float*)w; p.bias = (const float*)bias;
+  p.target = target; p.weight = weight; p.tdtype = tdtype; p.coef = (const float*)coef; p.loss_scale = loss_scale;
+  p.dx = dx; p.dx_ss = dx_ss; p.dwslab = (float*)dwslab; p.N = N; p.vox = vox;
+  dim3 grid((unsigned)((vox + 255) / 256), N);
+  if (dtype == 0) { HEAD_SWITCH(head_loss_bwd_kernel, f16) } else { HEAD_SWITCH(head_loss_bwd_kernel, bf16) }
+  IUNET_CHECK_HIP(hipGetLastError());
+  return IUNET_OK;
+}
+
+int iunet_reduce_slab(const void* slab, int nparts, long long n, void* out, float alpha, int accumulate, void* stream) {
+  IUNET_REQUIRE(slab && out, "reduce_slab: null pointer");
+  hipLaunchKernelGGL(reduce_slab_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)slab, nparts, n, (float*)out, alpha, accumulate);
+  IUNET_CHECK_HIP(hipGetLastError());
+  return IUNET_OK;
+}
+
+int iunet_check_finite(const void* g, long long n, void* flag, void* stream) {
+  hipLaunchKernelGGL(check_finite_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, (const float*)g, n, (int*)flag);
+  IUNET_CHECK_HIP(hipGetLastError());
+  return IUNET_OK;
+}
+
+// torch.optim.AdamW(params, lr) defaults of unet.py:71-73: betas (0.9, 0.999), eps 1e-8, wd 1e-2.
+int iunet_adamw_step(void* p, const void* g, void* m, void* v, long long n, float lr, float b1, float b2, float eps,
+                     float wd, int step, float grad_scale_inv, const void* skip_flag, void* stream) {
+  IUNET_REQUIRE(p && g && m && v && step >= 1, "adamw: bad arguments");
+  const float bc1 = 1.f - powf(b1, (float)step);
+  const float bc2s = sqrtf(1.f - powf(b2, (float)step));
+  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (float*)p,
+                     (const float*)g, (float*)m, (float*)v, n, lr, b1, b2, eps, wd, bc1, bc2s, grad_scale_inv,
+                     (const int*)skip_flag);
+  IUNET_CHECK_HIP(hipGetLastError());
+  return IUNET_OK;
+}
+
+}  // extern "C"

@@ -38,7 +38,39 @@ _SIGS = {
                                ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_void_p],
     'iunet_normalize_quantize': [c_void_p, c_void_p, c_void_p, c_ll, c_int, c_float, c_void_p],
     'iunet_div_f32': [c_void_p, c_ll, c_float, c_void_p],
+    # ---- training
+    'iunet_bn_finalize': [c_void_p, c_int, c_int, ctypes.c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
+                          c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    'iunet_bn_relu_fwd': [c_int, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_void_p, c_int, c_int, c_ll, c_void_p],
+    'iunet_bn_bwd_num_parts': [c_int, c_ll],
+    'iunet_bn_relu_bwd': [c_int, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_void_p,
+                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_ll, c_void_p],
+    'iunet_maxpool_bwd': [c_int, c_int, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_ll, c_int, c_int, c_int, c_int,
+                          c_int, c_int, c_void_p],
+    'iunet_head_loss_num_parts': [c_int, c_ll],
+    'iunet_head_loss_fwd': [c_int, c_void_p, c_ll, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int,
+                            c_void_p, c_void_p, c_void_p, c_int, c_ll, c_void_p],
+    'iunet_head_loss_bwd': [c_int, c_void_p, c_ll, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int,
+                            c_void_p, c_float, c_void_p, c_ll, c_void_p, c_int, c_ll, c_void_p],
+    'iunet_reduce_slab': [c_void_p, c_int, c_ll, c_void_p, c_float, c_int, c_void_p],
+    'iunet_check_finite': [c_void_p, c_ll, c_void_p, c_void_p],
+    'iunet_adamw_step': [c_void_p, c_void_p, c_void_p, c_void_p, c_ll, c_float, c_float, c_float, c_float, c_float,
+                         c_int, c_float, c_void_p, c_void_p],
+    'iunet_conv3_wgrad_blocks': [c_int] * 7,
+    'iunet_conv3_wgrad': [c_int, c_int, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_void_p, c_float,
+                          c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    'iunet_pack_convT_dgrad': [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    'iunet_convT_dgrad': [c_int, c_int, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                          c_int, c_void_p],
+    'iunet_convT_wgrad_blocks': [c_int] * 4,
+    'iunet_convT_wgrad': [c_int, c_int, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_void_p, c_int, c_int, c_int,
+                          c_int, c_int, c_int, c_void_p],
+    'iunet_first_conv_wgrad_tiles': [c_int] * 5,
+    'iunet_first_conv_wgrad': [c_int, c_int, c_void_p, c_int, ctypes.POINTER(c_ll), c_void_p, c_ll, c_void_p,
+                               c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
 }
+# functions that return a size / count instead of a status
+_LL_RETURN = {'iunet_conv3_wgrad_slab_floats': [c_int] * 7}
 
 
 class NativeError(RuntimeError):
@@ -59,12 +91,16 @@ def lib():
             fn = getattr(l, name)          # AttributeError here = header/library mismatch
             fn.argtypes = args
             fn.restype = c_int
+        for name, args in _LL_RETURN.items():
+            fn = getattr(l, name)
+            fn.argtypes = args
+            fn.restype = c_ll
         _lib = l
     return _lib
 
 
 def exported_symbols():
-    return ['iunet_last_error'] + list(_SIGS)
+    return ['iunet_last_error'] + list(_SIGS) + list(_LL_RETURN)
 
 
 def check(status):

@@ -136,7 +136,7 @@ class Engine:
                 N, dims[0], dims[1], dims[2], ci, co, 2, s)
 
     def infer(self, x, x_strides, N, D, H, W, logits=None, probs=None, cls=None, out_strides=None,
-              divisor=1.0, accumulate=False):
+              divisor=1.0, accumulate=False, features_only=False):
         """Run the folded network.  `x`: any torch tensor on the device (f32/f16/bf16/u8; u8 is
         scaled by 1/255 as predict.py:30 does); `x_strides` = element strides (n, c, d, h, w).
         Outputs (all optional): logits / probs fp32 written with `out_strides` (n, c, d, h, w),
@@ -178,6 +178,8 @@ class Engine:
                         2 * ch[l], ch[l], s)
             self._conv3(P(ws[f'a{l}']), ch[l] * v, P(ws[f'b{l}']), ch[l] * v, f'dec{l}.conv2', N, dims[l],
                         ch[l], ch[l], s)
+        if features_only:
+            return ws['b0']                       # input of the head, NHWC8c
         hw, hb = self.packed['head']
         if out_strides is None:
             v = _vox(dims[0])

@@ -1,0 +1,422 @@
+"""Native training step of the canonical U-Net: forward with BatchNorm batch statistics,
+fused head + softmax + reference loss (metrics.py), full backward and AdamW, all on
+libiunet kernels.  Replaces what Lightning + autograd + torch.optim.AdamW do under
+unet.py:88-102 / trainer.py:56-63 ('16-mixed': fp32 master weights, fp16/bf16 compute).
+
+PyTorch tensors are only device memory here; every op is a libiunet launch on the current
+HIP stream, except the optional RCCL gradient all-reduce (torch.distributed).
+"""
+import ctypes
+import math
+
+import torch
+
+from . import _native as nv
+from .engine import BN_EPS
+
+LOSS_KINDS = {'ce': 0, 'dice': 1, 'iou': 2, 'mcc': 3, 'dice_ce': 4, 'iou_ce': 5, 'mcc_ce': 6}
+BN_MOMENTUM = 0.1
+
+
+def _vox(d):
+    return d[0] * d[1] * d[2]
+
+
+class TrainEngine:
+    def __init__(self, model, lr=None, loss_kind='mcc_ce', betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2,
+                 loss_scale=None, process_group=None):
+        self.model = model
+        self.dev = model.device
+        if self.dev.type != 'cuda':
+            raise RuntimeError('native training runs on the GPU only (no CPU fallback)')
+        nv.lib()
+        self.dim, self.levels, self.ch = model.dim, model.levels, [model.base * 2 ** l for l in range(model.levels)]
+        self.cin, self.ncls = model.num_channels, model.num_classes
+        self.T = model.act_dtype
+        self.dt = nv.DTYPE_CODE[self.T]
+        self.es = 2
+        self.taps, self.npos = 3 ** self.dim, 2 ** self.dim
+        self.lr = model.lr if lr is None else lr
+        self.kind = LOSS_KINDS[loss_kind] if isinstance(loss_kind, str) else int(loss_kind)
+        self.betas, self.eps, self.wd = betas, eps, weight_decay
+        self.loss_scale = float(loss_scale) if loss_scale is not None else (1024.0 if self.T == torch.float16 else 1.0)
+        self.dynamic_scale = self.T == torch.float16 and loss_scale is None
+        self.good_steps = 0
+        self.step_count = 0
+        self.pg = process_group
+        self._flatten()
+        self._alloc_packed()
+        self._ws = {}
+        self.repack()
+
+    # ------------------------------------------------------------------ parameters
+    def _flatten(self):
+        """Re-home every trainable parameter as a view of one flat fp32 master tensor
+        (single AdamW launch, single all-reduce); gradients get the same layout."""
+        m = self.model
+        names = [n for n in m._names if not (n.endswith('running_mean') or n.endswith('running_var'))]
+        sizes = [m.tensor(n).numel() for n in names]
+        total = sum(sizes)
+        flat = torch.empty(total, dtype=torch.float32, device=self.dev)
+        off = 0
+        self.offsets = {}
+        for n, s in zip(names, sizes):
+            t = m.tensor(n)
+            flat[off:off + s].copy_(t.detach().reshape(-1))
+            t.data = flat[off:off + s].view(t.shape)
+            self.offsets[n] = (off, s)
+            off += s
+        self.flat = flat
+        self.grad = torch.zeros_like(flat)
+        self.m = torch.zeros_like(flat)
+        self.v = torch.zeros_like(flat)
+        self.flag = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        self.names = names
+
+    def p(self, name):
+        return self.model.tensor(name)
+
+    def g(self, name):
+        off, s = self.offsets[name]
+        return self.grad[off:off + s]
+
+    def stage_names(self):
+        return [f'enc{l}' for l in range(self.levels)] + [f'dec{l}' for l in range(self.levels - 2, -1, -1)]
+
+    def stage_io(self, prefix):
+        l = int(prefix[3:])
+        ci = (self.cin if l == 0 else self.ch[l - 1]) if prefix.startswith('enc') else 2 * self.ch[l]
+        return ci, self.ch[l], l
+
+    def _alloc_packed(self):
+        self.pk = {}
+        for prefix in self.stage_names():
+            ci, co, _ = self.stage_io(prefix)
+            for j, (a, b) in enumerate(((ci, co), (co, co)), 1):
+                name = f'{prefix}.conv{j}'
+                if name == 'enc0.conv1':
+                    self.pk[name] = (torch.empty(self.taps * a * b, dtype=torch.float32, device=self.dev), None)
+                else:
+                    self.pk[name] = (torch.empty(self.taps * a * b, dtype=self.T, device=self.dev),
+                                     torch.empty(self.taps * a * b, dtype=self.T, device=self.dev))
+        for l in range(self.levels - 2, -1, -1):
+            n = self.ch[l + 1] * self.ch[l] * self.npos
+            self.pk[f'dec{l}.up'] = (torch.empty(n, dtype=self.T, device=self.dev),
+                                     torch.empty(n, dtype=self.T, device=self.dev))
+
+    def repack(self):
+        """fp32 master weights -> MFMA fragment order (forward and data-gradient operators)."""
+        s = nv.stream()
+        for prefix in self.stage_names():
+            ci, co, _ = self.stage_io(prefix)
+            for j, (a, b) in enumerate(((ci, co), (co, co)), 1):
+                name = f'{prefix}.conv{j}'
+                w = self.p(name + '.weight')
+                fwd, dg = self.pk[name]
+                if name == 'enc0.conv1':
+                    nv.call('iunet_pack_first_conv', self.dt, nv.ptr(w), None, nv.ptr(fwd), b, a, self.taps, s)
+                else:
+                    nv.call('iunet_pack_conv3', self.dt, nv.ptr(w), None, nv.ptr(fwd), b, a, self.taps, 0, s)
+                    nv.call('iunet_pack_conv3', self.dt, nv.ptr(w), None, nv.ptr(dg), b, a, self.taps, 1, s)
+        for l in range(self.levels - 2, -1, -1):
+            w = self.p(f'dec{l}.up.weight')
+            fwd, dg = self.pk[f'dec{l}.up']
+            nv.call('iunet_pack_convT', self.dt, nv.ptr(w), nv.ptr(fwd), self.ch[l + 1], self.ch[l], self.npos, s)
+            nv.call('iunet_pack_convT_dgrad', self.dt, nv.ptr(w), nv.ptr(dg), self.ch[l + 1], self.ch[l], self.npos, s)
+
+    # ------------------------------------------------------------------ workspace
+    def workspace(self, N, D, H, W):
+        key = (N, D, H, W)
+        ws = self._ws.get(key)
+        if ws is not None:
+            return ws
+        f = 2 ** (self.levels - 1)
+        if H % f or W % f or (self.dim == 3 and D % f) or (self.dim == 2 and D != 1):
+            raise ValueError(f'spatial size {(D, H, W)} must be divisible by {f}')
+        L, ch = self.levels, self.ch
+        dims = [((D >> l) if self.dim == 3 else 1, H >> l, W >> l) for l in range(L)]
+        act = lambda c, v: torch.empty(N * c * v, dtype=self.T, device=self.dev)
+        f32 = lambda n: torch.empty(n, dtype=torch.float32, device=self.dev)
+        lib = nv.lib()
+        ws = {'dims': dims}
+        max_stats, max_wslab, max_bn = 0, 0, 0
+        for prefix in self.stage_names():
+            ci, co, l = self.stage_io(prefix)
+            v = _vox(dims[l])
+            d = dims[l]
+            for j, (a, b) in enumerate(((ci, co), (co, co)), 1):
+                name = f'{prefix}.conv{j}'
+                ws['y.' + name] = act(b, v)
+                skip = prefix.startswith('enc') and j == 2 and l < L - 1
+                if not skip:
+                    ws['z.' + name] = act(b, v)
+                    ws['dz.' + name] = act(b, v)
+                for k in ('scale', 'shift', 'mean', 'invstd'):
+                    ws[f'{k}.{name}'] = f32(b)
+                if name == 'enc0.conv1':
+                    max_stats = max(max_stats, lib.iunet_first_conv_num_blocks(N, *d) * b * 2)
+                    max_wslab = max(max_wslab, lib.iunet_first_conv_wgrad_tiles(self.dim, N, *d) * b * a * self.taps)
+                else:
+                    max_stats = max(max_stats, lib.iunet_conv3_num_tiles(self.dim, N, *d) * b * 2)
+                    max_wslab = max(max_wslab, lib.iunet_conv3_wgrad_slab_floats(self.dim, N, *d, a, b))
+                max_bn = max(max_bn, lib.iunet_bn_bwd_num_parts(N, v) * b * 2)
+        for l in range(L):
+            v = _vox(dims[l])
+            if l < L - 1:
+                ws[f'cat{l}'] = act(2 * ch[l], v)
+                ws[f'dcat{l}'] = act(2 * ch[l], v)
+                nb = lib.iunet_convT_wgrad_blocks(N, *dims[l + 1])
+                max_wslab = max(max_wslab, nb * ch[l + 1] * ch[l] * self.npos)
+                ws[f'bslab{l}'] = f32(nb * ch[l])
+            if l > 0:
+                ws[f'pin{l}'] = act(ch[l - 1], v)
+                ws[f'dpin{l}'] = act(ch[l - 1], v)
+        v0 = _vox(dims[0])
+        ws['dy'] = act(max(ch[l] * _vox(dims[l]) for l in range(L)), 1)
+        ws['stats'] = f32(max_stats)
+        ws['wslab'] = f32(max_wslab)
+        ws['bnslab'] = f32(max_bn)
+        ws['bncoef'] = f32(3 * max(ch))
+        nparts = lib.iunet_head_loss_num_parts(N, v0)
+        ws['lslab'] = f32(nparts * self.ncls * 8)
+        ws['hslab'] = f32(nparts * self.ncls * (ch[0] + 1))
+        ws['htmp'] = f32(self.ncls * (ch[0] + 1))
+        ws['out4'] = f32(4)
+        ws['coef'] = f32(self.ncls * 3)
+        self._ws = {key: ws}
+        return ws
+
+    def _P(self, t, off_elems=0):
+        return ctypes.c_void_p(t.data_ptr() + off_elems * self.es)
+
+    # ------------------------------------------------------------------ forward
+    def _stage_conv_fwd(self, ws, name, x_ptr, x_ss, ci, co, l, z_ptr, z_ss, N, x_raw=None, training=True):
+        d = ws['dims'][l]
+        v = _vox(d)
+        s = nv.stream()
+        y = ws['y.' + name]
+        stats = ws['stats']
+        if name == 'enc0.conv1':
+            x, xs = x_raw
+            w, _ = self.pk[name]
+            nparts = nv.lib().iunet_first_conv_num_blocks(N, *d)
+            nv.call('iunet_first_conv_fwd', self.dt, self.dim, nv.ptr(x), nv.IN_DTYPE_CODE[x.dtype], nv.ll_array(xs),
+                    self._P(y), co * v, nv.ptr(w), None, nv.ptr(stats), N, d[0], d[1], d[2], ci, co, 0, s)
+        else:
+            w, _ = self.pk[name]
+            nparts = nv.lib().iunet_conv3_num_tiles(self.dim, N, *d)
+            nv.call('iunet_conv3_fwd', self.dt, self.dim, x_ptr, x_ss, self._P(y), co * v, nv.ptr(w), None,
+                    nv.ptr(stats), N, d[0], d[1], d[2], ci, co, 0, s)
+        bn = name.replace('conv', 'bn')
+        nv.call('iunet_bn_finalize', nv.ptr(stats), nparts, co, float(N) * v,
+                nv.ptr(self.p(bn + '.weight')), nv.ptr(self.p(bn + '.bias')),
+                nv.ptr(self.p(bn + '.running_mean')), nv.ptr(self.p(bn + '.running_var')), BN_MOMENTUM, BN_EPS,
+                nv.ptr(ws['scale.' + name]), nv.ptr(ws['shift.' + name]), nv.ptr(ws['mean.' + name]),
+                nv.ptr(ws['invstd.' + name]), s)
+        nv.call('iunet_bn_relu_fwd', self.dt, self._P(y), co * v, z_ptr, z_ss, nv.ptr(ws['scale.' + name]),
+                nv.ptr(ws['shift.' + name]), co, N, v, s)
+
+    def forward_train(self, x, x_strides, N, D, H, W):
+        ws = self.workspace(N, D, H, W)
+        L, ch, dims = self.levels, self.ch, ws['dims']
+        s = nv.stream()
+        for l in range(L):
+            v = _vox(dims[l])
+            ci = self.cin if l == 0 else ch[l - 1]
+            z1 = ws[f'z.enc{l}.conv1']
+            if l == 0:
+                self._stage_conv_fwd(ws, 'enc0.conv1', None, 0, ci, ch[0], 0, self._P(z1), ch[0] * v, N,
+                                     x_raw=(x, x_strides))
+            else:
+                self._stage_conv_fwd(ws, f'enc{l}.conv1', self._P(ws[f'pin{l}']), ci * v, ci, ch[l], l, self._P(z1),
+                                     ch[l] * v, N)
+            if l < L - 1:
+                self._stage_conv_fwd(ws, f'enc{l}.conv2', self._P(z1), ch[l] * v, ch[l], ch[l], l,
+                                     self._P(ws[f'cat{l}']), 2 * ch[l] * v, N)
+                do = dims[l + 1]
+                nv.call('iunet_maxpool_fwd', self.dt, self.dim, self._P(ws[f'cat{l}']), 2 * ch[l] * v,
+                        self._P(ws[f'pin{l + 1}']), ch[l] * _vox(do), ch[l], N, do[0], do[1], do[2], s)
+            else:
+                self._stage_conv_fwd(ws, f'enc{l}.conv2', self._P(z1), ch[l] * v, ch[l], ch[l], l,
+                                     self._P(ws[f'z.enc{l}.conv2']), ch[l] * v, N)
+        for l in range(L - 2, -1, -1):
+            v, vi, di = _vox(dims[l]), _vox(dims[l + 1]), dims[l + 1]
+            src = ws[f'z.enc{l + 1}.conv2'] if l == L - 2 else ws[f'z.dec{l + 1}.conv2']
+            wf, _ = self.pk[f'dec{l}.up']
+            nv.call('iunet_convT_fwd', self.dt, self.dim, self._P(src), ch[l + 1] * vi, self._P(ws[f'cat{l}'], ch[l] * v),
+                    2 * ch[l] * v, nv.ptr(wf), nv.ptr(self.p(f'dec{l}.up.bias')), N, di[0], di[1], di[2],
+                    ch[l + 1], ch[l], s)
+            z1 = ws[f'z.dec{l}.conv1']
+            self._stage_conv_fwd(ws, f'dec{l}.conv1', self._P(ws[f'cat{l}']), 2 * ch[l] * v, 2 * ch[l], ch[l], l,
+                                 self._P(z1), ch[l] * v, N)
+            self._stage_conv_fwd(ws, f'dec{l}.conv2', self._P(z1), ch[l] * v, ch[l], ch[l], l,
+                                 self._P(ws[f'z.dec{l}.conv2']), ch[l] * v, N)
+        return ws
+
+    def loss_forward(self, ws, feat, y, w, N, vox):
+        """head + softmax + loss sums + loss/metrics/coefs (device scalars in ws['out4'])."""
+        hw = self.p('head.weight')
+        tdt = {torch.float32: 0, torch.float16: 1}[y.dtype]
+        if w is not None and w.dtype != y.dtype:
+            w = w.to(y.dtype)
+        nv.call('iunet_head_loss_fwd', self.dt, self._P(feat), self.ch[0] * vox, self.ch[0], nv.ptr(hw),
+                nv.ptr(self.p('head.bias')), self.ncls, nv.ptr(y), nv.ptr(w), tdt, self.kind, nv.ptr(ws['lslab']),
+                nv.ptr(ws['out4']), nv.ptr(ws['coef']), N, vox, nv.stream())
+        return tdt, w
+
+    # ------------------------------------------------------------------ backward
+    def _stage_conv_bwd(self, ws, name, dz_ptr, dz_ss, z_ptr, z_ss, x_ptr, x_ss, ci, co, l, dx_ptr, dx_ss, N,
+                        x_raw=None):
+        d = ws['dims'][l]
+        v = _vox(d)
+        s = nv.stream()
+        bn = name.replace('conv', 'bn')
+        dy = ws['dy']
+        nv.call('iunet_bn_relu_bwd', self.dt, dz_ptr, dz_ss, z_ptr, z_ss, self._P(ws['y.' + name]), co * v,
+                self._P(dy), co * v, nv.ptr(ws['mean.' + name]), nv.ptr(ws['invstd.' + name]),
+                nv.ptr(self.p(bn + '.weight')), nv.ptr(self.g(bn + '.weight')), nv.ptr(self.g(bn + '.bias')),
+                nv.ptr(ws['bnslab']), nv.ptr(ws['bncoef']), co, N, v, s)
+        gw = self.g(name + '.weight')
+        if name == 'enc0.conv1':
+            x, xs = x_raw
+            nt = nv.lib().iunet_first_conv_wgrad_tiles(self.dim, N, *d)
+            nv.call('iunet_first_conv_wgrad', self.dt, self.dim, nv.ptr(x), nv.IN_DTYPE_CODE[x.dtype], nv.ll_array(xs),
+                    self._P(dy), co * v, nv.ptr(ws['wslab']), N, d[0], d[1], d[2], ci, co, s)
+            nv.call('iunet_reduce_slab', nv.ptr(ws['wslab']), nt, co * ci * self.taps, nv.ptr(gw), 1.0, 0, s)
+        else:
+            nv.call('iunet_conv3_wgrad', self.dt, self.dim, x_ptr, x_ss, self._P(dy), co * v, nv.ptr(ws['wslab']),
+                    nv.ptr(gw), 1.0, N, d[0], d[1], d[2], ci, co, s)
+            _, wd = self.pk[name]
+            nv.call('iunet_conv3_fwd', self.dt, self.dim, self._P(dy), co * v, dx_ptr, dx_ss, nv.ptr(wd), None, None,
+                    N, d[0], d[1], d[2], co, ci, 0, s)
+
+    def backward(self, ws, x, x_strides, y, w, tdt, N):
+        L, ch, dims = self.levels, self.ch, ws['dims']
+        s = nv.stream()
+        v0 = _vox(dims[0])
+        feat = ws['z.dec0.conv2']
+        dfeat = ws['dz.dec0.conv2']
+        nparts = nv.lib().iunet_head_loss_num_parts(N, v0)
+        nv.call('iunet_head_loss_bwd', self.dt, self._P(feat), ch[0] * v0, ch[0], nv.ptr(self.p('head.weight')),
+                nv.ptr(self.p('head.bias')), self.ncls, nv.ptr(y), nv.ptr(w), tdt, nv.ptr(ws['coef']),
+                self.loss_scale, self._P(dfeat), ch[0] * v0, nv.ptr(ws['hslab']), N, v0, s)
+        nv.call('iunet_reduce_slab', nv.ptr(ws['hslab']), nparts, self.ncls * (ch[0] + 1), nv.ptr(ws['htmp']), 1.0, 0, s)
+        ht = ws['htmp'].view(self.ncls, ch[0] + 1)
+        self.g('head.weight').view(self.ncls, ch[0]).copy_(ht[:, :ch[0]])
+        self.g('head.bias').copy_(ht[:, ch[0]])
+        # decoder, level 0 upwards
+        for l in range(0, L - 1):
+            v, vi, di = _vox(dims[l]), _vox(dims[l + 1]), dims[l + 1]
+            z1, z2 = ws[f'z.dec{l}.conv1'], ws[f'z.dec{l}.conv2']
+            dz1, dz2 = ws[f'dz.dec{l}.conv1'], ws[f'dz.dec{l}.conv2']
+            self._stage_conv_bwd(ws, f'dec{l}.conv2', self._P(dz2), ch[l] * v, self._P(z2), ch[l] * v, self._P(z1),
+                                 ch[l] * v, ch[l], ch[l], l, self._P(dz1), ch[l] * v, N)
+            self._stage_conv_bwd(ws, f'dec{l}.conv1', self._P(dz1), ch[l] * v, self._P(z1), ch[l] * v,
+                                 self._P(ws[f'cat{l}']), 2 * ch[l] * v, 2 * ch[l], ch[l], l, self._P(ws[f'dcat{l}']),
+                                 2 * ch[l] * v, N)
+            # transposed conv: weight / bias gradient and data gradient
+            src_name = f'enc{l + 1}.conv2' if l == L - 2 else f'dec{l + 1}.conv2'
+            src, dsrc = ws['z.' + src_name], ws['dz.' + src_name]
+            dup = self._P(ws[f'dcat{l}'], ch[l] * v)
+            nb = nv.lib().iunet_convT_wgrad_blocks(N, *di)
+            nv.call('iunet_convT_wgrad', self.dt, self.dim, self._P(src), ch[l + 1] * vi, dup, 2 * ch[l] * v,
+                    nv.ptr(ws['wslab']), nv.ptr(ws[f'bslab{l}']), N, di[0], di[1], di[2], ch[l + 1], ch[l], s)
+            nv.call('iunet_reduce_slab', nv.ptr(ws['wslab']), nb, ch[l + 1] * ch[l] * self.npos,
+                    nv.ptr(self.g(f'dec{l}.up.weight')), 1.0, 0, s)
+            nv.call('iunet_reduce_slab', nv.ptr(ws[f'bslab{l}']), nb, ch[l], nv.ptr(self.g(f'dec{l}.up.bias')), 1.0, 0, s)
+            _, wd = self.pk[f'dec{l}.up']
+            nv.call('iunet_convT_dgrad', self.dt, self.dim, dup, 2 * ch[l] * v, self._P(dsrc), ch[l + 1] * vi,
+                    nv.ptr(wd), N, di[0], di[1], di[2], ch[l + 1], ch[l], s)
+        # encoder, bottom level upwards
+        for l in range(L - 1, -1, -1):
+            v = _vox(dims[l])
+            z1, dz1 = ws[f'z.enc{l}.conv1'], ws[f'dz.enc{l}.conv1']
+            if l == L - 1:
+                dz2_ptr, dz2_ss = self._P(ws[f'dz.enc{l}.conv2']), ch[l] * v
+                z2_ptr, z2_ss = self._P(ws[f'z.enc{l}.conv2']), ch[l] * v
+            else:
+                do = dims[l + 1]
+                nv.call('iunet_maxpool_bwd', self.dt, self.dim, self._P(ws[f'cat{l}']), 2 * ch[l] * v,
+                        self._P(ws[f'dpin{l + 1}']), ch[l] * _vox(do), self._P(ws[f'dcat{l}']), 2 * ch[l] * v, 1,
+                        ch[l], N, do[0], do[1], do[2], s)
+                dz2_ptr, dz2_ss = self._P(ws[f'dcat{l}']), 2 * ch[l] * v
+                z2_ptr, z2_ss = self._P(ws[f'cat{l}']), 2 * ch[l] * v
+            self._stage_conv_bwd(ws, f'enc{l}.conv2', dz2_ptr, dz2_ss, z2_ptr, z2_ss, self._P(z1), ch[l] * v, ch[l],
+                                 ch[l], l, self._P(dz1), ch[l] * v, N)
+            if l == 0:
+                self._stage_conv_bwd(ws, 'enc0.conv1', self._P(dz1), ch[0] * v, self._P(z1), ch[0] * v, None, 0,
+                                     self.cin, ch[0], 0, None, 0, N, x_raw=(x, x_strides))
+            else:
+                self._stage_conv_bwd(ws, f'enc{l}.conv1', self._P(dz1), ch[l] * v, self._P(z1), ch[l] * v,
+                                     self._P(ws[f'pin{l}']), ch[l - 1] * v, ch[l - 1], ch[l], l,
+                                     self._P(ws[f'dpin{l}']), ch[l - 1] * v, N)
+
+    # ------------------------------------------------------------------ optimiser
+    def optimizer_step(self):
+        s = nv.stream()
+        n = self.flat.numel()
+        if self.pg is not None:
+            import torch.distributed as dist
+            dist.all_reduce(self.grad, group=self.pg)
+            world = dist.get_world_size(self.pg)
+        else:
+            world = 1
+        flag = None
+        if self.T == torch.float16:
+            self.flag.zero_()
+            nv.call('iunet_check_finite', nv.ptr(self.grad), n, nv.ptr(self.flag), s)
+            flag = self.flag
+        self.step_count += 1
+        nv.call('iunet_adamw_step', nv.ptr(self.flat), nv.ptr(self.grad), nv.ptr(self.m), nv.ptr(self.v), n,
+                float(self.lr), self.betas[0], self.betas[1], self.eps, self.wd, self.step_count,
+                1.0 / (self.loss_scale * world), nv.ptr(flag), s)
+        if self.dynamic_scale:
+            if int(self.flag.item()):                  # GradScaler semantics: back off, skip, undo the step count
+                self.loss_scale = max(self.loss_scale * 0.5, 1.0)
+                self.step_count -= 1
+                self.good_steps = 0
+            else:
+                self.good_steps += 1
+                if self.good_steps >= 2000:
+                    self.loss_scale *= 2.0
+                    self.good_steps = 0
+        self.repack()
+        self.model._packed_sig = None          # weights changed behind torch's version counters
+
+    # ------------------------------------------------------------------ public steps
+    def _prep(self, X, y, w):
+        X = X.to(self.dev).contiguous()
+        y = y.to(self.dev).contiguous()
+        w = None if w is None else w.to(self.dev).contiguous()
+        if y.dtype not in (torch.float16, torch.float32):
+            y = y.float()
+        N = X.shape[0]
+        sp = tuple(X.shape[2:])
+        D, H, W = sp if self.dim == 3 else (1,) + sp
+        vox = D * H * W
+        if X.dtype not in nv.IN_DTYPE_CODE:
+            X = X.float()
+        return X, y, w, N, D, H, W, vox, (self.cin * vox, vox, H * W, W, 1)
+
+    def train_step(self, X, y, w=None, sync=True):
+        """One optimisation step (unet.py:88-102 + backward + AdamW).  X [N,C,*sp], y / w
+        [N,ncls,*sp] (fp16 or fp32, the loader's contract loader.py:142-154)."""
+        X, y, w, N, D, H, W, vox, xs = self._prep(X, y, w)
+        ws = self.forward_train(X, xs, N, D, H, W)
+        tdt, w = self.loss_forward(ws, ws['z.dec0.conv2'], y, w, N, vox)
+        self.backward(ws, X, xs, y, w, tdt, N)
+        self.optimizer_step()
+        if sync:
+            o = ws['out4'].tolist()
+            return {'Loss': o[0], 'Dice': o[1], 'IoU': o[2], 'MCC': o[3]}
+        return ws['out4']
+
+    def eval_step(self, X, y, w=None):
+        """validation_step (unet.py:104-116): eval-mode BatchNorm (running statistics)."""
+        X, y, w, N, D, H, W, vox, xs = self._prep(X, y, w)
+        eng = self.model.engine('eval')
+        feat = eng.infer(X, xs, N, D, H, W, features_only=True)
+        ws = self.workspace(N, D, H, W)
+        self.loss_forward(ws, feat, y, w, N, vox)
+        o = ws['out4'].tolist()
+        return {'Loss': o[0], 'Dice': o[1], 'IoU': o[2], 'MCC': o[3]}

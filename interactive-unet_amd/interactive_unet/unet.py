@@ -1,0 +1,184 @@
+"""Drop-in for interactive_unet/unet.py: `UNet` with the reference constructor signature
+(unet.py:15-20), `forward(x) -> softmax probabilities NCHW` (unet.py:65-69), `.lr`,
+`.loss_function`, `.device`, `load_from_checkpoint(checkpoint_path=)`; the network itself is
+the native canonical U-Net (engine.py) instead of segmentation_models_pytorch.
+
+Only architecture='U-Net' exists natively; `encoder_name` is accepted and ignored (the canonical
+net has its own plain conv encoder), `pretrained` is a no-op with a warning (no imagenet
+weights for a from-scratch encoder; no network access).  Extra keyword arguments (dim, levels,
+base, act_dtype) select the 3-D / wider variants of BASELINE.json's configs.
+"""
+import math
+import warnings
+
+import torch
+import torch.nn as nn
+
+from . import metrics
+from .engine import Engine, BN_EPS
+
+_ACT = {'fp16': torch.float16, 'f16': torch.float16, 'bf16': torch.bfloat16,
+        torch.float16: torch.float16, torch.bfloat16: torch.bfloat16}
+
+
+def param_shapes(dim=2, levels=4, base=32, cin=1, ncls=2):
+    """Ordered {name: shape} of the canonical network (same names as the oracle's definition)."""
+    ch = [base * 2 ** l for l in range(levels)]
+    k3, k2, k1 = (3,) * dim, (2,) * dim, (1,) * dim
+    shapes = {}
+
+    def stage(prefix, ci, co):
+        for j, (a, b) in enumerate(((ci, co), (co, co)), 1):
+            shapes[f'{prefix}.conv{j}.weight'] = (b, a) + k3
+            for k in ('weight', 'bias', 'running_mean', 'running_var'):
+                shapes[f'{prefix}.bn{j}.{k}'] = (b,)
+    for l in range(levels):
+        stage(f'enc{l}', cin if l == 0 else ch[l - 1], ch[l])
+    for l in range(levels - 2, -1, -1):
+        shapes[f'dec{l}.up.weight'] = (ch[l + 1], ch[l]) + k2
+        shapes[f'dec{l}.up.bias'] = (ch[l],)
+        stage(f'dec{l}', 2 * ch[l], ch[l])
+    shapes['head.weight'] = (ncls, ch[0]) + k1
+    shapes['head.bias'] = (ncls,)
+    return shapes
+
+
+def _is_buffer(name):
+    return name.endswith('running_mean') or name.endswith('running_var')
+
+
+class UNet(nn.Module):
+    """The UNet model (native MI355X path)."""
+
+    def __init__(self, lr=0.0001, num_channels=1, num_classes=2, loss_function=metrics.mcc_ce_loss,
+                 architecture='U-Net', encoder_name='mit_b0', pretrained=True,
+                 dim=2, levels=4, base=32, act_dtype='fp16'):
+        super().__init__()
+        if architecture != 'U-Net':
+            raise NotImplementedError(f"architecture {architecture!r}: only 'U-Net' has a native MI355X "
+                                      f"implementation (the reference builds the others through smp, unet.py:33-54)")
+        if pretrained:
+            warnings.warn('pretrained=True ignored: the native U-Net encoder is trained from scratch')
+        self.hparams = dict(lr=lr, num_channels=num_channels, num_classes=num_classes,
+                            loss_function=getattr(loss_function, '__name__', str(loss_function)),
+                            architecture=architecture, encoder_name=encoder_name, pretrained=pretrained,
+                            dim=dim, levels=levels, base=base,
+                            act_dtype='bf16' if _ACT[act_dtype] == torch.bfloat16 else 'fp16')
+        self.lr = lr
+        self.loss_function = loss_function
+        self.dim, self.levels, self.base = dim, levels, base
+        self.num_channels, self.num_classes = num_channels, num_classes
+        self.act_dtype = _ACT[act_dtype]
+        self._names = []
+        for name, shp in param_shapes(dim, levels, base, num_channels, num_classes).items():
+            t = torch.empty(shp, dtype=torch.float32)
+            key = name.replace('.', '__')
+            if _is_buffer(name):
+                self.register_buffer(key, t)
+            else:
+                self.register_parameter(key, nn.Parameter(t))
+            self._names.append(name)
+        self.reset_parameters()
+        self._engines = {}
+        self._packed_sig = None
+
+    # ---- parameters ---------------------------------------------------------------------
+    def reset_parameters(self, seed=None):
+        g = None if seed is None else torch.Generator().manual_seed(seed)
+        with torch.no_grad():
+            for name in self._names:
+                t = self.tensor(name)
+                shp = t.shape
+                if name.endswith('conv1.weight') or name.endswith('conv2.weight') or name == 'head.weight':
+                    fan_in = shp[1] * math.prod(shp[2:])
+                    t.copy_(torch.randn(shp, generator=g) * math.sqrt(2.0 / fan_in))      # He-normal
+                elif name.endswith('up.weight'):
+                    t.copy_(torch.randn(shp, generator=g) * math.sqrt(1.0 / shp[0]))
+                elif name.endswith('running_var') or name.endswith('bn1.weight') or name.endswith('bn2.weight'):
+                    t.fill_(1.0)
+                else:
+                    t.zero_()
+
+    def tensor(self, name):
+        return getattr(self, name.replace('.', '__'))
+
+    def named_tensors(self):
+        return {n: self.tensor(n) for n in self._names}
+
+    def load_named(self, tensors):
+        """Copy {canonical name: tensor} (e.g. the oracle's init_params) into the module."""
+        with torch.no_grad():
+            for n in self._names:
+                self.tensor(n).copy_(tensors[n])
+
+    def state_dict(self, *a, **k):
+        sd = super().state_dict(*a, **k)
+        return type(sd)((key.replace('__', '.'), v) for key, v in sd.items())
+
+    def load_state_dict(self, sd, strict=True):
+        return super().load_state_dict({k.replace('.', '__'): v for k, v in sd.items()}, strict=strict)
+
+    @property
+    def device(self):
+        return self.tensor(self._names[0]).device
+
+    # ---- engines ------------------------------------------------------------------------
+    def _signature(self):
+        return tuple((t.data_ptr(), t._version) for t in (self.tensor(n) for n in self._names))
+
+    def engine(self, mode='eval'):
+        """The native engine with current weights packed (re-packs when a parameter changed)."""
+        dev = self.device
+        if dev.type != 'cuda':
+            raise RuntimeError('the native U-Net runs on the GPU only: move the module with .to("cuda") '
+                               '(there is no CPU fallback)')
+        eng = self._engines.get(dev)
+        if eng is None:
+            eng = Engine(self.dim, self.levels, self.base, self.num_channels, self.num_classes, self.act_dtype, dev)
+            self._engines = {dev: eng}
+            self._packed_sig = None
+        sig = self._signature()
+        if self._packed_sig != sig:
+            eng.load_eval(self.named_tensors())
+            self._packed_sig = sig
+        return eng
+
+    # ---- forward (unet.py:65-69) ----------------------------------------------------------
+    def forward(self, x):
+        """x [N, C, H, W] (or [N, C, D, H, W] for dim=3), float or uint8 -> softmax probabilities fp32."""
+        eng = self.engine('eval')
+        x = x.to(self.device)
+        if x.dtype not in (torch.float32, torch.float16, torch.bfloat16, torch.uint8):
+            x = x.float()
+        x = x.contiguous()
+        N = x.shape[0]
+        sp = tuple(x.shape[2:])
+        D, H, W = sp if self.dim == 3 else (1,) + sp
+        vox = D * H * W
+        probs = torch.empty((N, self.num_classes) + sp, dtype=torch.float32, device=self.device)
+        eng.infer(x, (self.num_channels * vox, vox, H * W, W, 1), N, D, H, W, probs=probs)
+        return probs
+
+    # ---- optimiser / steps (unet.py:71-116) -------------------------------------------------
+    def configure_optimizers(self):
+        raise NotImplementedError('the native path steps AdamW inside trainer.NativeTrainer (unet.py:71-73 defaults)')
+
+    # ---- checkpoints (trainer.py:30-49, predict.py:22-24) -----------------------------------
+    def save_checkpoint(self, path):
+        torch.save({'state_dict': {k: v.detach().cpu() for k, v in self.state_dict().items()},
+                    'hyper_parameters': dict(self.hparams)}, path)
+
+    @classmethod
+    def load_from_checkpoint(cls, checkpoint_path, map_location=None, **overrides):
+        ck = torch.load(checkpoint_path, map_location='cpu', weights_only=False)
+        hp = dict(ck['hyper_parameters'])
+        hp.update(overrides)
+        lf = hp.pop('loss_function', 'mcc_ce_loss')
+        hp['loss_function'] = getattr(metrics, lf, metrics.mcc_ce_loss) if isinstance(lf, str) else lf
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            model = cls(**hp)
+        model.load_state_dict(ck['state_dict'])
+        if map_location is not None:
+            model = model.to(map_location)
+        return model

@@ -1,0 +1,314 @@
+"""Parity of the native training kernels and of a whole optimisation step against torch
+CPU autograd on the oracle network and the reference-pinned loss oracle."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import unet_ref, metrics_ref
+from tests.test_gpu_kernels import blocked, unblocked
+
+
+@pytest.fixture(scope='module')
+def nv():
+    from interactive_unet import _native
+    _native.lib()
+    return _native
+
+
+@pytest.mark.parametrize('nd,shape,cin,cout', [(2, (16, 32), 32, 32), (2, (40, 72), 64, 32), (2, (16, 32), 32, 96),
+                                               (3, (2, 8, 16), 32, 32), (3, (6, 12, 20), 64, 64)])
+def test_conv3_wgrad_exact_integers(nv, nd, shape, cin, cout):
+    """dW = sum dy (x) shifted x through the transposing LDS reads; small integers make every
+    product and partial sum exact, so the result must equal the fp32 reference bit for bit."""
+    g = torch.Generator().manual_seed(11)
+    N = 2
+    x = torch.randint(-2, 3, (N, cin) + shape, generator=g).float()
+    dy = torch.randint(-1, 2, (N, cout) + shape, generator=g).float()
+    conv = F.conv2d if nd == 2 else F.conv3d
+    w = torch.zeros((cout, cin) + (3,) * nd, requires_grad=True)
+    (conv(x, w, padding=1) * dy).sum().backward()
+    ref = w.grad
+    D, H, W = shape if nd == 3 else (1,) + shape
+    vox = D * H * W
+    taps = 3 ** nd
+    for dt in (torch.float16, torch.bfloat16):
+        xb, dyb = blocked(x, dt).cuda(), blocked(dy, dt).cuda()
+        nfl = nv.lib().iunet_conv3_wgrad_slab_floats(nd, N, D, H, W, cin, cout)
+        slab = torch.empty(nfl, device='cuda')
+        dW = torch.full((cout, cin, taps), float('nan'), device='cuda')
+        nv.call('iunet_conv3_wgrad', nv.DTYPE_CODE[dt], nd, nv.ptr(xb), cin * vox, nv.ptr(dyb), cout * vox, nv.ptr(slab),
+                nv.ptr(dW), 1.0, N, D, H, W, cin, cout, nv.stream())
+        torch.cuda.synchronize()
+        assert torch.equal(dW.cpu().reshape(ref.shape), ref), (dt, (dW.cpu().reshape(ref.shape) - ref).abs().max())
+
+
+@pytest.mark.parametrize('nd', [2, 3])
+def test_bn_relu_fwd_bwd(nv, nd):
+    g = torch.Generator().manual_seed(12)
+    shape = (24, 40) if nd == 2 else (6, 8, 20)
+    N, C = 2, 32
+    y = (torch.randn((N, C) + shape, generator=g) * 1.5 + 0.3).half().float()
+    gamma = 0.5 + torch.rand(C, generator=g)
+    beta = torch.randn(C, generator=g) * 0.2
+    dz = torch.randn((N, C) + shape, generator=g).half().float()
+    yr = y.clone().requires_grad_(True)
+    ga, be = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    z_ref = F.relu(F.batch_norm(yr, None, None, ga, be, training=True, eps=1e-5))
+    z_ref.backward(dz)
+    vox = int(np.prod(shape))
+    dev = 'cuda'
+    yb = blocked(y, torch.float16).to(dev)
+    dims = [0] + list(range(2, 2 + nd))
+    slab = torch.stack([y.sum(dims), (y * y).sum(dims)], 1).reshape(1, C, 2).contiguous().to(dev)
+    gd, bd = gamma.to(dev), beta.to(dev)
+    rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    scale, shift, mean, invstd = [torch.empty(C, device=dev) for _ in range(4)]
+    nv.call('iunet_bn_finalize', nv.ptr(slab), 1, C, float(N * vox), nv.ptr(gd), nv.ptr(bd), nv.ptr(rm), nv.ptr(rv),
+            0.1, 1e-5, nv.ptr(scale), nv.ptr(shift), nv.ptr(mean), nv.ptr(invstd), nv.stream())
+    z = torch.empty_like(yb)
+    nv.call('iunet_bn_relu_fwd', 0, nv.ptr(yb), C * vox, nv.ptr(z), C * vox, nv.ptr(scale), nv.ptr(shift), C, N, vox, nv.stream())
+    torch.cuda.synchronize()
+    zc = unblocked(z.float().cpu(), N, C, shape)
+    assert (zc - z_ref.detach()).abs().max() < 4e-3
+    assert torch.allclose(rm.cpu(), 0.1 * y.mean(dims), atol=1e-5)
+    assert torch.allclose(rv.cpu(), 0.9 + 0.1 * y.var(dims, unbiased=True), atol=1e-4)
+    # backward uses the stored (rounded) z for the ReLU mask: feed the reference the same mask
+    dzb = blocked(dz, torch.float16).to(dev)
+    dy = torch.empty_like(yb)
+    dgamma, dbeta = torch.empty(C, device=dev), torch.empty(C, device=dev)
+    npart = nv.lib().iunet_bn_bwd_num_parts(N, vox)
+    bslab = torch.empty(npart * C * 2, device=dev)
+    coef = torch.empty(3 * C, device=dev)
+    nv.call('iunet_bn_relu_bwd', 0, nv.ptr(dzb), C * vox, nv.ptr(z), C * vox, nv.ptr(yb), C * vox, nv.ptr(dy), C * vox,
+            nv.ptr(mean), nv.ptr(invstd), nv.ptr(gd), nv.ptr(dgamma), nv.ptr(dbeta), nv.ptr(bslab), nv.ptr(coef), C, N,
+            vox, nv.stream())
+    torch.cuda.synchronize()
+    mask_diff = ((zc > 0) != (z_ref.detach() > 0)).float().mean().item()
+    assert mask_diff < 1e-3
+    dyc = unblocked(dy.float().cpu(), N, C, shape)
+    assert (dyc - yr.grad).abs().max() < 1e-2 * yr.grad.abs().max()
+    assert torch.allclose(dgamma.cpu(), ga.grad, rtol=2e-3, atol=2e-2)
+    assert torch.allclose(dbeta.cpu(), be.grad, rtol=2e-3, atol=2e-2)
+
+
+@pytest.mark.parametrize('nd', [2, 3])
+def test_maxpool_bwd_matches_autograd(nv, nd):
+    g = torch.Generator().manual_seed(13)
+    shape = (8, 12) if nd == 2 else (4, 6, 8)
+    N, C = 2, 16
+    z = torch.randint(0, 4, (N, C) + shape, generator=g).float()      # many ties: first maximum must win
+    zr = z.clone().requires_grad_(True)
+    pooled = (F.max_pool2d if nd == 2 else F.max_pool3d)(zr, 2)
+    dp = torch.randn(pooled.shape, generator=g).half().float()
+    pooled.backward(dp)
+    dskip = torch.randn(z.shape, generator=g).half().float()
+    ref = zr.grad + dskip
+    zb, dpb, dzb = blocked(z, torch.float16).cuda(), blocked(dp, torch.float16).cuda(), blocked(dskip, torch.float16).cuda()
+    osp = tuple(s // 2 for s in shape)
+    Do, Ho, Wo = osp if nd == 3 else (1,) + osp
+    vin, vo = int(np.prod(shape)), int(np.prod(osp))
+    nv.call('iunet_maxpool_bwd', 0, nd, nv.ptr(zb), C * vin, nv.ptr(dpb), C * vo, nv.ptr(dzb), C * vin, 1, C, N, Do, Ho, Wo,
+            nv.stream())
+    torch.cuda.synchronize()
+    got = unblocked(dzb.float().cpu(), N, C, shape)
+    assert (got - ref.half().float()).abs().max() <= 2e-3
+
+
+@pytest.mark.parametrize('nd', [2, 3])
+def test_convT_backward_exact_integers(nv, nd):
+    g = torch.Generator().manual_seed(14)
+    shape = (6, 20) if nd == 2 else (3, 4, 16)
+    N, cin, cout = 2, 64, 32
+    x = torch.randint(-2, 3, (N, cin) + shape, generator=g).float().requires_grad_(True)
+    w = torch.randint(-1, 2, (cin, cout) + (2,) * nd, generator=g).float().requires_grad_(True)
+    b = torch.zeros(cout, requires_grad=True)
+    up = (F.conv_transpose2d if nd == 2 else F.conv_transpose3d)(x, w, bias=b, stride=2)
+    dy = torch.randint(-1, 2, up.shape, generator=g).float()
+    up.backward(dy)
+    D, H, W = shape if nd == 3 else (1,) + shape
+    osp = tuple(2 * s for s in shape)
+    vin, vout = int(np.prod(shape)), int(np.prod(osp))
+    npos = 2 ** nd
+    xb, dyb = blocked(x.detach(), torch.float16).cuda(), blocked(dy, torch.float16).cuda()
+    wd = w.detach().cuda()
+    wpk = torch.empty(w.numel(), dtype=torch.float16, device='cuda')
+    nv.call('iunet_pack_convT_dgrad', 0, nv.ptr(wd), nv.ptr(wpk), cin, cout, npos, nv.stream())
+    dx = torch.full((N * cin * vin,), float('nan'), dtype=torch.float16, device='cuda')
+    nv.call('iunet_convT_dgrad', 0, nd, nv.ptr(dyb), cout * vout, nv.ptr(dx), cin * vin, nv.ptr(wpk), N, D, H, W, cin, cout, nv.stream())
+    nb = nv.lib().iunet_convT_wgrad_blocks(N, D, H, W)
+    wslab = torch.empty(nb * cin * cout * npos, device='cuda')
+    bslab = torch.empty(nb * cout, device='cuda')
+    nv.call('iunet_convT_wgrad', 0, nd, nv.ptr(xb), cin * vin, nv.ptr(dyb), cout * vout, nv.ptr(wslab), nv.ptr(bslab), N, D, H, W, cin, cout, nv.stream())
+    dW = torch.empty(cin * cout * npos, device='cuda')
+    db = torch.empty(cout, device='cuda')
+    nv.call('iunet_reduce_slab', nv.ptr(wslab), nb, cin * cout * npos, nv.ptr(dW), 1.0, 0, nv.stream())
+    nv.call('iunet_reduce_slab', nv.ptr(bslab), nb, cout, nv.ptr(db), 1.0, 0, nv.stream())
+    torch.cuda.synchronize()
+    gx = unblocked(dx.float().cpu(), N, cin, shape)
+    ok = x.grad.abs() <= 2048
+    assert torch.equal(gx[ok], x.grad[ok])
+    assert torch.equal(dW.cpu().reshape(w.shape), w.grad)
+    assert torch.equal(db.cpu(), b.grad)
+
+
+@pytest.mark.parametrize('nd', [2, 3])
+def test_first_conv_wgrad(nv, nd):
+    g = torch.Generator().manual_seed(15)
+    shape = (24, 40) if nd == 2 else (6, 10, 20)
+    N, cin, cout = 2, 1, 32
+    xi = torch.randint(0, 256, (N, cin) + shape, generator=g, dtype=torch.uint8)
+    xf = (xi.float() / 255).half().float()
+    dy = torch.randn((N, cout) + shape, generator=g).half().float()
+    w = torch.zeros((cout, cin) + (3,) * nd, requires_grad=True)
+    ((F.conv2d if nd == 2 else F.conv3d)(xf, w, padding=1) * dy).sum().backward()
+    D, H, W = shape if nd == 3 else (1,) + shape
+    vox = D * H * W
+    taps = 3 ** nd
+    nt = nv.lib().iunet_first_conv_wgrad_tiles(nd, N, D, H, W)
+    slab = torch.empty(nt * cout * cin * taps, device='cuda')
+    dyb = blocked(dy, torch.float16).cuda()
+    xd = xi.cuda()
+    nv.call('iunet_first_conv_wgrad', 0, nd, nv.ptr(xd), 2, nv.ll_array((cin * vox, vox, H * W, W, 1)), nv.ptr(dyb),
+            cout * vox, nv.ptr(slab), N, D, H, W, cin, cout, nv.stream())
+    dW = torch.empty(cout * cin * taps, device='cuda')
+    nv.call('iunet_reduce_slab', nv.ptr(slab), nt, cout * cin * taps, nv.ptr(dW), 1.0, 0, nv.stream())
+    torch.cuda.synchronize()
+    assert torch.allclose(dW.cpu().reshape(w.shape), w.grad, rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize('kind', metrics_ref.KINDS)
+@pytest.mark.parametrize('weighted', [False, True])
+def test_head_loss_fwd_bwd_vs_reference_pinned_oracle(nv, kind, weighted):
+    """Loss value and d loss / d logits of the fused HIP head+softmax+loss against
+    oracle/metrics_ref.py (pinned to the reference's metrics.py by the goldens), axes=[0,2,3]."""
+    from interactive_unet.train_engine import LOSS_KINDS
+    g = torch.Generator().manual_seed(16)
+    N, C0, ncls, shape = 2, 32, 3, (20, 28)
+    vox = shape[0] * shape[1]
+    x = torch.randn((N, C0) + shape, generator=g).half().float()
+    w = torch.randn(ncls, C0, generator=g) * 0.3
+    b = torch.randn(ncls, generator=g) * 0.1
+    lab = torch.randint(0, ncls, (N,) + shape, generator=g)
+    y = torch.stack([(lab == c) for c in range(ncls)], 1).float()
+    wt = None
+    if weighted:
+        wt = (torch.rand((N, 1) + shape, generator=g) > 0.3).float().repeat(1, ncls, 1, 1) * \
+            (0.5 + torch.rand((N, 1) + shape, generator=g)).repeat(1, ncls, 1, 1)
+        y = y * (wt > 0)
+    xr = x.clone().requires_grad_(True)
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    logits = F.conv2d(xr, wr.view(ncls, C0, 1, 1), bias=br)
+    p = torch.softmax(logits, 1)
+    want = metrics_ref.loss(kind, p.detach().numpy(), y.numpy(), None if wt is None else wt.numpy(), axes=(0, 2, 3))
+    gp = torch.tensor(metrics_ref.loss_grad(kind, p.detach().numpy(), y.numpy(), None if wt is None else wt.numpy(),
+                                            axes=(0, 2, 3))).float()
+    p.backward(gp)
+    dev = 'cuda'
+    xb = blocked(x, torch.float16).to(dev)
+    wd, bd, yd = w.to(dev), b.to(dev), y.to(dev).contiguous()
+    wtd = None if wt is None else wt.to(dev).contiguous()
+    nparts = nv.lib().iunet_head_loss_num_parts(N, vox)
+    lslab = torch.empty(nparts * ncls * 8, device=dev)
+    out4, coef = torch.empty(4, device=dev), torch.empty(ncls * 3, device=dev)
+    nv.call('iunet_head_loss_fwd', 0, nv.ptr(xb), C0 * vox, C0, nv.ptr(wd), nv.ptr(bd), ncls, nv.ptr(yd), nv.ptr(wtd), 0,
+            LOSS_KINDS[kind], nv.ptr(lslab), nv.ptr(out4), nv.ptr(coef), N, vox, nv.stream())
+    dx = torch.empty_like(xb)
+    hslab = torch.empty(nparts * ncls * (C0 + 1), device=dev)
+    nv.call('iunet_head_loss_bwd', 0, nv.ptr(xb), C0 * vox, C0, nv.ptr(wd), nv.ptr(bd), ncls, nv.ptr(yd), nv.ptr(wtd), 0,
+            nv.ptr(coef), 1.0, nv.ptr(dx), C0 * vox, nv.ptr(hslab), N, vox, nv.stream())
+    htmp = torch.empty(ncls * (C0 + 1), device=dev)
+    nv.call('iunet_reduce_slab', nv.ptr(hslab), nparts, ncls * (C0 + 1), nv.ptr(htmp), 1.0, 0, nv.stream())
+    torch.cuda.synchronize()
+    o = out4.cpu()
+    assert abs(o[0].item() - want) <= 2e-5 * max(1.0, abs(want)), (o[0].item(), want)
+    r = metrics_ref.rounded_metrics(p.detach().numpy(), y.numpy(), None if wt is None else wt.numpy(), axes=(0, 2, 3))
+    assert np.allclose(o[1:].numpy(), r, atol=2e-5)
+    gx = unblocked(dx.float().cpu(), N, C0, shape)
+    scale = xr.grad.abs().max().item()
+    assert (gx - xr.grad).abs().max() <= 2e-3 * scale + 1e-9        # dx is stored in fp16
+    ht = htmp.cpu().view(ncls, C0 + 1)
+    assert torch.allclose(ht[:, :C0], wr.grad, rtol=1e-3, atol=1e-5 * max(1.0, wr.grad.abs().max().item()))
+    assert torch.allclose(ht[:, C0], br.grad, rtol=1e-3, atol=1e-6)
+
+
+def test_adamw_matches_torch(nv):
+    g = torch.Generator().manual_seed(17)
+    n = 10007
+    p = torch.randn(n, generator=g)
+    ref = torch.nn.Parameter(p.clone())
+    opt = torch.optim.AdamW([ref], lr=1e-3)
+    pd = p.cuda()
+    m, v = torch.zeros(n, device='cuda'), torch.zeros(n, device='cuda')
+    for step in range(1, 4):
+        gr = torch.randn(n, generator=g)
+        ref.grad = gr.clone()
+        opt.step()
+        gd = (gr * 8.0).cuda()              # scaled gradients, un-scaled inside the kernel
+        nv.call('iunet_adamw_step', nv.ptr(pd), nv.ptr(gd), nv.ptr(m), nv.ptr(v), n, 1e-3, 0.9, 0.999, 1e-8, 1e-2, step,
+                1.0 / 8.0, None, nv.stream())
+    torch.cuda.synchronize()
+    assert torch.allclose(pd.cpu(), ref.detach(), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize('dim,shape,dtype', [(2, (64, 96), 'fp16'), (3, (16, 32, 32), 'bf16')])
+def test_full_train_step_vs_autograd(dim, shape, dtype):
+    """One native optimisation step (BatchNorm batch statistics, MCC+CE loss, backward, AdamW)
+    against fp32 CPU autograd on the oracle network with the same weights and batch."""
+    from interactive_unet.unet import UNet
+    from interactive_unet.train_engine import TrainEngine
+    import warnings
+    torch.manual_seed(0)
+    N, ncls = 2, 2
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        model = UNet(lr=1e-3, num_classes=ncls, dim=dim, act_dtype=dtype, pretrained=False)
+    p0 = unet_ref.init_params(dim=dim, ncls=ncls, seed=5)
+    model.load_named(p0)
+    model = model.cuda()
+    from scipy import ndimage
+    rng = np.random.default_rng(0)
+    img = np.stack([ndimage.gaussian_filter(rng.random(shape), 2) for _ in range(N)])
+    img = (255 * (img - img.min()) / (img.max() - img.min())).astype(np.uint8)[:, None]
+    lab = img[:, 0] > 127
+    y = np.stack([~lab, lab], 1).astype(np.float32)
+    wt = np.repeat((rng.random((N, 1) + shape) > 0.2).astype(np.float32), ncls, 1)
+    y = y * wt
+    X = torch.tensor(img.astype(np.float32) / 255.0)
+    # ---- oracle: fp32 autograd
+    pr = {k: v.clone().requires_grad_(not unet_ref.is_buffer(k)) for k, v in p0.items()}
+    stats = {}
+    logits = unet_ref.forward_logits(pr, X, dim=dim, training=True, bn_stats_out=stats)
+    probs = torch.softmax(logits, 1)
+    axes = (0,) + tuple(range(2, 2 + dim))
+    lv = metrics_ref.loss('mcc_ce', probs.detach().numpy(), y, wt, axes=axes)
+    gp = torch.tensor(metrics_ref.loss_grad('mcc_ce', probs.detach().numpy(), y, wt, axes=axes)).float()
+    probs.backward(gp)
+    # ---- native
+    te = TrainEngine(model, lr=1e-3, loss_kind='mcc_ce', loss_scale=(256.0 if dtype == 'fp16' else 1.0))
+    out = te.train_step(X, torch.tensor(y), torch.tensor(wt))
+    torch.cuda.synchronize()
+    print(f'{dim}-D {dtype}: native loss {out["Loss"]:.5f} vs oracle {lv:.5f}')
+    assert abs(out['Loss'] - lv) < (5e-3 if dtype == 'fp16' else 3e-2)
+    worst = 1.0
+    for name in te.names:
+        gn = te.g(name).cpu().reshape(pr[name].shape) / te.loss_scale
+        gr = pr[name].grad
+        cos = torch.nn.functional.cosine_similarity(gn.flatten(), gr.flatten(), dim=0).item()
+        rel = ((gn - gr).norm() / (gr.norm() + 1e-20)).item()
+        worst = min(worst, cos)
+        lim = 0.995 if dtype == 'fp16' else 0.97
+        assert cos > lim, (name, cos, rel)
+    print(f'   worst gradient cosine similarity over {len(te.names)} tensors: {worst:.5f}')
+    # running statistics updated like torch BatchNorm (momentum 0.1)
+    mean, var = stats['enc0.bn1']
+    rm = model.tensor('enc0.bn1.running_mean').cpu()
+    assert torch.allclose(rm, 0.1 * mean, atol=2e-3)
+    # parameters moved by one AdamW step: |delta| ~ lr
+    d = (model.tensor('enc1.conv1.weight').cpu() - p0['enc1.conv1.weight']).abs()
+    assert 0.2e-3 < d.mean().item() < 1.2e-3
+    # eval forward after the step uses the updated weights / running stats
+    ev = te.eval_step(X, torch.tensor(y), torch.tensor(wt))
+    assert np.isfinite(ev['Loss'])
