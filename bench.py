@@ -73,23 +73,37 @@ def conv_roofline(nv, dtype, S, iters=10):
             'ms_per_launch': round(ms, 4), 'flops_per_launch': flops, 'traffic': None}
 
 
-def cpu_baseline(S, ncls):
-    """Oracle forward on the host cores: bounded sample of the same workload."""
-    from oracle import unet_ref
-    torch.set_num_threads(os.cpu_count())
+def cpu_baseline(ncls):
+    """Oracle (torch CPU fp32) on the host cores: bounded sample of the same step --
+    one training step (forward, MCC+CE loss, autograd backward, AdamW) plus one prediction
+    forward, on ONE 64^3 chunk (1/8 of a bench chunk), repeated twice."""
+    from oracle import unet_ref, metrics_ref
+    cores = min(16, len(os.sched_getaffinity(0)))        # a 1-GPU box gets a 16-core share
+    torch.set_num_threads(cores)
+    Sc = 64
     p = unet_ref.init_params(dim=3, ncls=ncls, seed=0)
-    x = torch.rand(1, 1, S, S, S)
-    with torch.inference_mode():
-        unet_ref.forward(p, x[:, :, :32, :32, :32], dim=3)            # warm the thread pool
-        t0 = time.time()
-        reps = 0
-        while reps < 2:
-            unet_ref.forward(p, x, dim=3)
-            reps += 1
-        dt = time.time() - t0
-    return {'value': round(reps * S ** 3 / dt, 1), 'unit': 'voxels/s', 'cores': os.cpu_count(), 'kind': 'port',
-            'sample': f'{reps} forward passes (predict leg only) of the fp32 oracle 3-D U-Net on one {S}^3 chunk, '
-                      f'torch CPU, {os.cpu_count()} threads'}
+    pr = {k: v.clone().requires_grad_(not unet_ref.is_buffer(k)) for k, v in p.items()}
+    m = {k: torch.zeros_like(v) for k, v in pr.items()}
+    v = {k: torch.zeros_like(v) for k, v in pr.items()}
+    x = torch.rand(1, 1, Sc, Sc, Sc)
+    lab = (x > 0.5)
+    y = torch.cat([~lab, lab], 1).float()
+    from interactive_unet import metrics as host_metrics     # plain torch ops on the host (differentiable)
+    reps, t0 = 2, None
+    for it in range(reps + 1):
+        if it == 1:
+            t0 = time.time()                                   # first iteration warms the thread pool
+        probs = unet_ref.forward(pr, x, dim=3, training=True)
+        loss = host_metrics.mcc_ce_loss(probs, y, None, axes=[0, 2, 3, 4])
+        grads = torch.autograd.grad(loss, [t for k, t in pr.items() if t.requires_grad])
+        with torch.no_grad():
+            g = dict(zip([k for k, t in pr.items() if t.requires_grad], grads))
+            unet_ref.adamw_step({k: t.data for k, t in pr.items()}, g, m, v, it + 1, 1e-4)
+            unet_ref.forward(pr, x, dim=3)
+    dt = time.time() - t0
+    return {'value': round(reps * 2 * Sc ** 3 / dt, 1), 'unit': 'voxels/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{reps} x (1 training step + 1 prediction forward) of the fp32 oracle 3-D U-Net on one '
+                      f'{Sc}^3 chunk (1/8 bench chunk), torch CPU, {cores} threads; voxels counted once per leg'}
 
 
 def main():
@@ -121,18 +135,37 @@ def main():
     S, B, ncls = args.size, args.chunks, 2
     dev = torch.device('cuda', local)
     params = {k: v.to(dev) for k, v in unet_ref.init_params(dim=3, ncls=ncls, seed=0).items()}
-    eng = Engine(dim=3, ncls=ncls, act_dtype=dtype, device=dev)
-    eng.load_eval(params)
+    import warnings
+    from interactive_unet.unet import UNet
+    from interactive_unet.train_engine import TrainEngine
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        model = UNet(lr=1e-4, num_classes=ncls, dim=3, act_dtype=args.dtype, pretrained=False)
+    model.load_named(params)
+    model = model.to(dev)
+    trainer = TrainEngine(model, lr=1e-4, loss_kind='mcc_ce', process_group=(dist.group.WORLD if dist else None))
     chunks = synth_chunks(B, S, 1234 + rank, dev)
+    X = chunks.reshape(B, 1, S, S, S)                                   # uint8, /255 in the first conv
+    lab = X > 127
+    y = torch.cat([~lab, lab], 1).to(torch.float16)                     # loader contract: fp16 one-hot (loader.py:150-152)
+    w = (torch.rand((B, 1, S, S, S), device=dev) > 0.1).to(torch.float16).expand(B, ncls, S, S, S).contiguous()
+    y = y * w
     acc = npredict.VolumeAccumulator((B * S, S, S), ncls, S, dev)      # chunks stacked along z
+    legs = {'train': 0.0, 'predict': 0.0}
 
-    def step():
-        eng_probs = acc.block_probs
+    def step(timed=False):
+        t0 = time.time()
+        trainer.train_step(X, y, w, sync=False)
+        if timed:
+            torch.cuda.synchronize(); t1 = time.time(); legs['train'] += t1 - t0
+        eng = model.engine('eval')                                      # re-packs the updated weights (BN folded)
         for b in range(B):
-            eng.infer(chunks[b], (S ** 3, S ** 3, S * S, S, 1), 1, S, S, S, probs=eng_probs,
+            eng.infer(chunks[b], (S ** 3, S ** 3, S * S, S, 1), 1, S, S, S, probs=acc.block_probs,
                       out_strides=(0, 1, S * S * ncls, S * ncls, ncls))
             acc.blend((b * S, 0, 0, (b + 1) * S, S, S), (0, 0, 0, S, S, S))
         acc.finalize()
+        if timed:
+            torch.cuda.synchronize(); legs['predict'] += time.time() - t1
 
     def barrier():
         if dist is not None:
@@ -153,7 +186,11 @@ def main():
         t = torch.tensor([dt], device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
-    vox_per_step = B * S ** 3 * world
+    # leg split, measured in separate (untimed-for-value) steps so the timed region has no extra syncs
+    for _ in range(2):
+        acc.reset()
+        step(timed=True)
+    vox_per_step = 2 * B * S ** 3 * world            # every chunk voxel goes through the train leg and the predict leg
     value = vox_per_step * args.steps / dt
 
     out = None
@@ -165,16 +202,22 @@ def main():
             'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': f'C3: 3-D U-Net 4-level base 32, 1->{ncls} classes, {B} x {S}^3 uint8 chunks per GPU '
-                                   f'per step; step = predict leg only (forward + softmax + Gaussian blend + '
-                                   f'normalise/quantise); training leg not in the step yet',
+                                   f'per step; step = 1 training step (forward with BatchNorm batch stats, MCC+CE loss, '
+                                   f'backward, AdamW, weight re-pack) on the {B} chunks + prediction of the same {B} '
+                                   f'chunks (forward + softmax + Gaussian blend-accumulate + normalise/quantise); '
+                                   f'voxels counted once per leg',
                        'chunks_per_gpu': B, 'chunk': S, 'levels': 4, 'base': 32,
                        'fwd_flop_per_voxel': unet_ref.flops_per_voxel(3, 4, 32, 1, ncls)},
             'roofline': roof,
         }
-        fwd_tflops = unet_ref.flops_per_voxel(3, 4, 32, 1, ncls) * B * S ** 3 * args.steps / dt / 1e12
-        out['predict_tflops_per_gpu'] = round(fwd_tflops, 1)
+        fpv = unet_ref.flops_per_voxel(3, 4, 32, 1, ncls)
+        out['legs'] = {'train_ms': round(legs['train'] / 2 * 1e3, 3), 'predict_ms': round(legs['predict'] / 2 * 1e3, 3),
+                       'train_voxels_per_s_per_gpu': round(B * S ** 3 / (legs['train'] / 2), 1),
+                       'predict_voxels_per_s_per_gpu': round(B * S ** 3 / (legs['predict'] / 2), 1),
+                       'train_tflops_per_gpu(3x fwd)': round(3 * fpv * B * S ** 3 / (legs['train'] / 2) / 1e12, 1),
+                       'predict_tflops_per_gpu': round(fpv * B * S ** 3 / (legs['predict'] / 2) / 1e12, 1)}
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(S, ncls)
+            out['cpu_baseline'] = cpu_baseline(ncls)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -101,6 +101,25 @@ def _rnd(t, act_dtype):
     return t if act_dtype is None else t.to(act_dtype).to(torch.float32)
 
 
+class _RoundBoth(torch.autograd.Function):
+    """Storage rounding in BOTH directions: the value is rounded to act_dtype going forward
+    and the gradient is rounded to act_dtype coming back -- the HIP training path keeps
+    every activation and every activation gradient in act_dtype in HBM."""
+
+    @staticmethod
+    def forward(ctx, x, dt):
+        ctx.dt = dt
+        return x.to(dt).float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(ctx.dt).float(), None
+
+
+def _rnd_ag(t, act_dtype):
+    return t if act_dtype is None else _RoundBoth.apply(t, act_dtype)
+
+
 def fold_bn(w, gamma, beta, mean, var):
     """Eval-mode BatchNorm folded into the preceding bias-free conv (fp32)."""
     a = gamma / torch.sqrt(var + BN_EPS)
@@ -120,7 +139,9 @@ def forward_logits(p, x, dim=2, levels=4, training=False, act_dtype=None, bn_sta
             w = p[f'{prefix}.conv{j}.weight']
             bn = [p[f'{prefix}.bn{j}.{k}'] for k in ('weight', 'bias', 'running_mean', 'running_var')]
             if training:
-                y = conv(t, w, padding=1)
+                # act_dtype set: weights, raw conv output and the stage output are stored in
+                # act_dtype (and so are their gradients), as in the HIP training path
+                y = _rnd_ag(conv(t, _rnd_ag(w, act_dtype), padding=1), act_dtype)
                 dims = [0] + list(range(2, y.dim()))
                 mean = y.mean(dim=dims)
                 var = y.var(dim=dims, unbiased=False)
@@ -129,7 +150,7 @@ def forward_logits(p, x, dim=2, levels=4, training=False, act_dtype=None, bn_sta
                 shape = [1, -1] + [1] * dim
                 y = (y - mean.view(shape)) / torch.sqrt(var.view(shape) + BN_EPS)
                 y = y * bn[0].view(shape) + bn[1].view(shape)
-                t = F.relu(y)
+                t = _rnd_ag(F.relu(y), act_dtype)
             else:
                 wf, bf = fold_bn(w, *bn)
                 t = _rnd(F.relu(conv(t, _rnd(wf, act_dtype), bias=bf, padding=1)), act_dtype)
@@ -143,8 +164,8 @@ def forward_logits(p, x, dim=2, levels=4, training=False, act_dtype=None, bn_sta
             skips.append(t)
             t = pool(t, 2)
     for l in range(levels - 2, -1, -1):
-        up = convT(t, _rnd(p[f'dec{l}.up.weight'], act_dtype), bias=p[f'dec{l}.up.bias'], stride=2)
-        up = _rnd(up, act_dtype)
+        R = _rnd_ag if training else _rnd
+        up = R(convT(t, R(p[f'dec{l}.up.weight'], act_dtype), bias=p[f'dec{l}.up.bias'], stride=2), act_dtype)
         t = stage(f'dec{l}', torch.cat([skips[l], up], dim=1))
     return conv(t, p['head.weight'], bias=p['head.bias'])
 

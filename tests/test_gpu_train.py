@@ -277,31 +277,41 @@ def test_full_train_step_vs_autograd(dim, shape, dtype):
     wt = np.repeat((rng.random((N, 1) + shape) > 0.2).astype(np.float32), ncls, 1)
     y = y * wt
     X = torch.tensor(img.astype(np.float32) / 255.0)
-    # ---- oracle: fp32 autograd
-    pr = {k: v.clone().requires_grad_(not unet_ref.is_buffer(k)) for k, v in p0.items()}
-    stats = {}
-    logits = unet_ref.forward_logits(pr, X, dim=dim, training=True, bn_stats_out=stats)
-    probs = torch.softmax(logits, 1)
+    # ---- oracle: CPU autograd, (a) pure fp32 and (b) with the HIP path's storage rounding
+    # (activations, weights and activation gradients rounded to act_dtype at the same points)
+    act = torch.float16 if dtype == 'fp16' else torch.bfloat16
     axes = (0,) + tuple(range(2, 2 + dim))
-    lv = metrics_ref.loss('mcc_ce', probs.detach().numpy(), y, wt, axes=axes)
-    gp = torch.tensor(metrics_ref.loss_grad('mcc_ce', probs.detach().numpy(), y, wt, axes=axes)).float()
-    probs.backward(gp)
+
+    def oracle_grads(act_dtype):
+        pr = {k: v.clone().requires_grad_(not unet_ref.is_buffer(k)) for k, v in p0.items()}
+        st = {}
+        logits = unet_ref.forward_logits(pr, X, dim=dim, training=True, act_dtype=act_dtype, bn_stats_out=st)
+        probs = torch.softmax(logits, 1)
+        lv = metrics_ref.loss('mcc_ce', probs.detach().numpy(), y, wt, axes=axes)
+        gp = torch.tensor(metrics_ref.loss_grad('mcc_ce', probs.detach().numpy(), y, wt, axes=axes)).float()
+        probs.backward(gp)
+        return pr, st, lv
+    pr32, stats, lv32 = oracle_grads(None)
+    pr, _, lv = oracle_grads(act)
     # ---- native
     te = TrainEngine(model, lr=1e-3, loss_kind='mcc_ce', loss_scale=(256.0 if dtype == 'fp16' else 1.0))
     out = te.train_step(X, torch.tensor(y), torch.tensor(wt))
     torch.cuda.synchronize()
-    print(f'{dim}-D {dtype}: native loss {out["Loss"]:.5f} vs oracle {lv:.5f}')
-    assert abs(out['Loss'] - lv) < (5e-3 if dtype == 'fp16' else 3e-2)
-    worst = 1.0
+    print(f'{dim}-D {dtype}: native loss {out["Loss"]:.5f} vs oracle(same rounding) {lv:.5f} vs oracle(fp32) {lv32:.5f}')
+    assert abs(out['Loss'] - lv) < (2e-3 if dtype == 'fp16' else 1e-2)
+    worst, worst32 = 1.0, 1.0
+    cosine = lambda a, b: torch.nn.functional.cosine_similarity(a.flatten(), b.flatten(), dim=0).item()
     for name in te.names:
         gn = te.g(name).cpu().reshape(pr[name].shape) / te.loss_scale
-        gr = pr[name].grad
-        cos = torch.nn.functional.cosine_similarity(gn.flatten(), gr.flatten(), dim=0).item()
-        rel = ((gn - gr).norm() / (gr.norm() + 1e-20)).item()
-        worst = min(worst, cos)
-        lim = 0.995 if dtype == 'fp16' else 0.97
-        assert cos > lim, (name, cos, rel)
-    print(f'   worst gradient cosine similarity over {len(te.names)} tensors: {worst:.5f}')
+        c = cosine(gn, pr[name].grad)
+        worst, worst32 = min(worst, c), min(worst32, cosine(gn, pr32[name].grad))
+        # against the same-rounding oracle the gradients must agree closely; the distance to the
+        # pure-fp32 gradients (printed) is a property of 16-bit storage, reproduced by the oracle itself
+        assert c > (0.998 if dtype == 'fp16' else 0.99), (name, c)
+        nrm = (gn.norm() / (pr[name].grad.norm() + 1e-20)).item()
+        assert 0.97 < nrm < 1.03, (name, nrm)
+    print(f'   worst gradient cosine over {len(te.names)} tensors: {worst:.5f} vs same-rounding oracle, '
+          f'{worst32:.5f} vs fp32 oracle')
     # running statistics updated like torch BatchNorm (momentum 0.1)
     mean, var = stats['enc0.bn1']
     rm = model.tensor('enc0.bn1.running_mean').cpu()
