@@ -111,8 +111,9 @@ int iunet_head_loss_fwd(int dtype, const void* x, long long x_ss, int C0, const 
 int iunet_head_loss_bwd(int dtype, const void* x, long long x_ss, int C0, const void* w, const void* bias, int ncls,
                         const void* target, const void* weight, int tdtype, const void* coef, float loss_scale, void* dx,
                         long long dx_ss, void* dwslab, int N, long long vox, void* stream);
-/* out[i] = alpha * sum_p slab[p][i] (+ out[i]); fixed summation order. */
-int iunet_reduce_slab(const void* slab, int nparts, long long n, void* out, float alpha, int accumulate, void* stream);
+/* out[i] = alpha * sum_p slab[p][i] (+ out[i]); fixed summation order.  The slab is scratch:
+ * wide slabs are folded in place first. */
+int iunet_reduce_slab(void* slab, int nparts, long long n, void* out, float alpha, int accumulate, void* stream);
 /* weight gradient of the 3^d conv on MFMA (transposing LDS reads): dW fp32 [Cout][Cin][taps]. */
 int iunet_conv3_wgrad_blocks(int nd, int N, int D, int H, int W, int Cin, int Cout);
 long long iunet_conv3_wgrad_slab_floats(int nd, int N, int D, int H, int W, int Cin, int Cout);

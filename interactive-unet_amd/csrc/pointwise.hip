@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void first_conv_kernel(FirstConvParams p) {
   }
   T* yout = (T*)p.y + (long long)n * p.y_sstride;
   const long long plane_stride = vox * 8;
-  __shared__ float red[4][2];
+  __shared__ float red[4][16];
   for (int cb = 0; cb < p.Cout / 8; ++cb) {
     float acc[8];
 #pragma unroll
@@ -69,18 +69,18 @@ __global__ __launch_bounds__(256) void first_conv_kernel(FirstConvParams p) {
       for (int j = 0; j < 8; ++j) acc[j] = fmaf(win[k], wk[j], acc[j]);
     }
     if (p.stats) {
-      // per-channel partial sums of the raw conv output over this block's voxels
+      // per-channel partial sums of the raw conv output over this block's voxels (one barrier per 8 channels)
+      const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+      __syncthreads();
+#pragma unroll
       for (int j = 0; j < 8; ++j) {
-        float s = ok ? acc[j] : 0.f, s2 = ok ? acc[j] * acc[j] : 0.f;
-        s = wave_sum(s); s2 = wave_sum(s2);
-        __syncthreads();
-        if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = s; red[threadIdx.x >> 6][1] = s2; }
-        __syncthreads();
-        if (threadIdx.x < 2) {
-          const float tot = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-          p.stats[(((long long)n * gridDim.x + blockIdx.x) * p.Cout + cb * 8 + j) * 2 + threadIdx.x] = tot;
-        }
+        const float s = wave_sum(ok ? acc[j] : 0.f), s2 = wave_sum(ok ? acc[j] * acc[j] : 0.f);
+        if (lane == 0) { red[wv][2 * j] = s; red[wv][2 * j + 1] = s2; }
       }
+      __syncthreads();
+      if (threadIdx.x < 16)
+        p.stats[(((long long)n * gridDim.x + blockIdx.x) * p.Cout + cb * 8) * 2 + threadIdx.x] =
+            red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
     }
     V8 o;
 #pragma unroll

@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void convT_wgrad_kernel(ConvTWgradParams p) {
   const long long v0 = (long long)blockIdx.x * p.per_block, v1 = min(v0 + p.per_block, total);
   const int Do = ND == 3 ? p.D * 2 : 1, Ho = p.H * 2, Wo = p.W * 2;
   const long long in_plane = vox * 8, out_plane = (long long)Do * Ho * Wo * 8;
-  float acc[NPOS][4], bacc[4] = {0.f, 0.f, 0.f, 0.f};
+  float acc[NPOS][4], bacc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // bacc: channels (t & 3) * 8 + j
 #pragma unroll
   for (int s = 0; s < NPOS; ++s)
 #pragma unroll
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void convT_wgrad_kernel(ConvTWgradParams p) {
                                (((long long)oz * Ho + y * 2 + b) * Wo + x * 2 + c) * 8);
       }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) dys[vv][s][pl * 8 + j] = to_f32<T>(val[j]);
+      for (int j = 0; j < 8; ++j) { const float f = to_f32<T>(val[j]); dys[vv][s][pl * 8 + j] = f; bacc[j] += f; }
     }
     __syncthreads();
 #pragma unroll 4
@@ -157,7 +157,6 @@ __global__ __launch_bounds__(256) void convT_wgrad_kernel(ConvTWgradParams p) {
         for (int k = 0; k < 4; ++k) {
           const float d = dys[vv][s][cog * 4 + k];
           acc[s][k] = fmaf(xv, d, acc[s][k]);
-          if (ci == 0) bacc[k] += d;
         }
     }
   }
@@ -167,9 +166,18 @@ __global__ __launch_bounds__(256) void convT_wgrad_kernel(ConvTWgradParams p) {
 #pragma unroll
     for (int k = 0; k < 4; ++k)
       ws[((long long)(cib * 32 + ci) * p.Cout + cob * 32 + cog * 4 + k) * NPOS + s] = acc[s][k];
-  if (ci == 0 && cib == 0) {
+  if (cib == 0) {       // bias gradient: threads with equal (t & 3) own the same 8 channels -> sum them through LDS
+    __syncthreads();
+    float* red = &dys[0][0][0];                       // reuse: [256][8]
 #pragma unroll
-    for (int k = 0; k < 4; ++k) p.bslab[(long long)blockIdx.x * p.Cout + cob * 32 + cog * 4 + k] = bacc[k];
+    for (int j = 0; j < 8; ++j) red[t * 8 + j] = bacc[j];
+    __syncthreads();
+    if (t < 32) {
+      const int pl = t >> 3, j = t & 7;
+      float sum = 0.f;
+      for (int k = pl; k < 256; k += 4) sum += red[k * 8 + j];
+      p.bslab[(long long)blockIdx.x * p.Cout + cob * 32 + pl * 8 + j] = sum;
+    }
   }
 }
 

@@ -16,6 +16,20 @@ __device__ __forceinline__ float block_sum_256(float v, float* red /* [4] */) {
   return red[0] + red[1] + red[2] + red[3];
 }
 
+// Block reduction of NV per-thread values with ONE barrier: wave shuffles, then 4 wave
+// partials through LDS (lds: [4][NV] floats), thread i < NV writes out[i].  Fixed order.
+template <int NV>
+__device__ __forceinline__ void block_reduce_store(const float (&vals)[NV], float* lds, float* out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const float v = wave_sum(vals[i]);
+    if (lane == 0) lds[wave * NV + i] = v;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < NV; i += 256) out[i] = lds[i] + lds[NV + i] + lds[2 * NV + i] + lds[3 * NV + i];
+}
+
 // ------------------------------------------------------------------ BN statistics -> scale/shift
 // slab [nparts][C][2] (sum, sumsq of the raw conv output).  One block per channel.
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ slab, int nparts, int C, double count,
@@ -97,14 +111,12 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
       s2[j] += d * (to_f32<T>(yy[j]) - mu[j]) * is[j];
     }
   }
-  __shared__ float red[4];
+  __shared__ float red[4 * 16];
   const long long part = (long long)n * gridDim.x + blockIdx.x;
+  float vals[16];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const float a = block_sum_256(s1[j], red);
-    const float b = block_sum_256(s2[j], red);
-    if (threadIdx.x == 0) { slab[(part * C + pl * 8 + j) * 2] = a; slab[(part * C + pl * 8 + j) * 2 + 1] = b; }
-  }
+  for (int j = 0; j < 8; ++j) { vals[2 * j] = s1[j]; vals[2 * j + 1] = s2[j]; }
+  block_reduce_store<16>(vals, red, slab + (part * C + pl * 8) * 2);
 }
 
 // pass 1b: dgamma = s2, dbeta = s1 (times grad_unscale), coefficients for pass 2
@@ -266,15 +278,14 @@ __global__ __launch_bounds__(256) void head_loss_fwd_kernel(HeadLossParams p) {
       acc[c][5] = w * ry; acc[c][6] = w * rp; acc[c][7] = w * ry * rp;
     }
   }
-  __shared__ float red[4];
+  __shared__ float red[4 * NCLS * 8];
   const long long part = (long long)n * gridDim.x + blockIdx.x;
+  float vals[NCLS * 8];
 #pragma unroll
   for (int c = 0; c < NCLS; ++c)
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const float t = block_sum_256(acc[c][k], red);
-      if (threadIdx.x == 0) p.slab[(part * NCLS + c) * 8 + k] = t;
-    }
+    for (int k = 0; k < 8; ++k) vals[c * 8 + k] = acc[c][k];
+  block_reduce_store<NCLS * 8>(vals, red, p.slab + part * NCLS * 8);
 }
 
 // One block: reduce the slab, evaluate the reference loss (metrics.py:3-187 with
@@ -399,27 +410,28 @@ __global__ __launch_bounds__(256) void head_loss_bwd_kernel(HeadLossParams p) {
     }
   }
   // dW[c][ch] = sum_v dl[c] * x[ch], db[c] = sum_v dl[c]: block partials
-  __shared__ float red[4];
+  // slab layout per part: [planes][NCLS][8] weight partials, then [NCLS] bias partials
+  __shared__ float red[4 * NCLS * 8];
   const long long part = (long long)n * gridDim.x + blockIdx.x;
   float* slab = p.dwslab + part * (NCLS * (C0 + 1));
   for (int pl = 0; pl < p.planes; ++pl) {
     V8T<T> xv;
     if (ok) xv = *(const V8T<T>*)(xin + (long long)pl * p.vox * 8);
+    float vals[NCLS * 8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float a = ok ? to_f32<T>(xv[j]) : 0.f;
 #pragma unroll
-      for (int c = 0; c < NCLS; ++c) {
-        const float t = block_sum_256(dl[c] * a, red);
-        if (threadIdx.x == 0) slab[c * (C0 + 1) + pl * 8 + j] = t;
-      }
+      for (int c = 0; c < NCLS; ++c) vals[c * 8 + j] = dl[c] * a;
     }
+    __syncthreads();                       // previous plane's LDS partials are consumed
+    block_reduce_store<NCLS * 8>(vals, red, slab + pl * NCLS * 8);
   }
+  float bv[NCLS];
 #pragma unroll
-  for (int c = 0; c < NCLS; ++c) {
-    const float t = block_sum_256(dl[c], red);
-    if (threadIdx.x == 0) slab[c * (C0 + 1) + C0] = t;
-  }
+  for (int c = 0; c < NCLS; ++c) bv[c] = dl[c];
+  __syncthreads();
+  block_reduce_store<NCLS>(bv, red, slab + p.planes * NCLS * 8);
 }
 
 // out[i] = alpha * sum_p slab[p][i] (+ out[i] if accumulate); fixed order.
@@ -430,6 +442,16 @@ __global__ __launch_bounds__(256) void reduce_slab_kernel(const float* __restric
   float s = 0.f;
   for (int p = 0; p < nparts; ++p) s += slab[(long long)p * n + i];
   out[i] = alpha * s + (accumulate ? out[i] : 0.f);
+}
+
+// stage A of a wide reduction, in place: slab[g][i] += slab[g + G][i] + slab[g + 2G][i] + ...  (g < G)
+__global__ __launch_bounds__(256) void fold_slab_kernel(float* __restrict__ slab, int nparts, long long n, int G) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int g = blockIdx.y;
+  if (i >= n) return;
+  float s = slab[(long long)g * n + i];
+  for (int p = g + G; p < nparts; p += G) s += slab[(long long)p * n + i];
+  slab[(long long)g * n + i] = s;
 }
 
 // ------------------------------------------------------------------ AdamW (torch defaults, decoupled decay)
@@ -581,8 +603,14 @@ int iunet_head_loss_bwd(int dtype, const void* x, long long x_ss, int C0, const 
   return IUNET_OK;
 }
 
-int iunet_reduce_slab(const void* slab, int nparts, long long n, void* out, float alpha, int accumulate, void* stream) {
+int iunet_reduce_slab(void* slab, int nparts, long long n, void* out, float alpha, int accumulate, void* stream) {
   IUNET_REQUIRE(slab && out, "reduce_slab: null pointer");
+  const int G = 64;
+  if (nparts > 2 * G) {      // wide slab: fold it to G rows first (in place; the slab is scratch)
+    hipLaunchKernelGGL(fold_slab_kernel, dim3((unsigned)((n + 255) / 256), G), dim3(256), 0, (hipStream_t)stream,
+                       (float*)slab, nparts, n, G);
+    nparts = G;
+  }
   hipLaunchKernelGGL(reduce_slab_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      (const float*)slab, nparts, n, (float*)out, alpha, accumulate);
   IUNET_CHECK_HIP(hipGetLastError());

@@ -92,7 +92,7 @@ class Engine:
         hw = params['head.weight'].detach().to(self.device, torch.float32).reshape(self.ncls, self.ch[0]).contiguous()
         hb = params['head.bias'].detach().to(self.device, torch.float32).contiguous()
         P['head'] = (hw, hb)
-        torch.cuda.current_stream().synchronize()   # sources in `keep` may be freed after this
+        self._pack_sources = keep    # stay alive until the next re-pack: the pack kernels are still in flight
         self.packed = P
 
     # ------------------------------------------------------------------ workspace

@@ -301,9 +301,11 @@ class TrainEngine:
                 nv.ptr(self.p('head.bias')), self.ncls, nv.ptr(y), nv.ptr(w), tdt, nv.ptr(ws['coef']),
                 self.loss_scale, self._P(dfeat), ch[0] * v0, nv.ptr(ws['hslab']), N, v0, s)
         nv.call('iunet_reduce_slab', nv.ptr(ws['hslab']), nparts, self.ncls * (ch[0] + 1), nv.ptr(ws['htmp']), 1.0, 0, s)
-        ht = ws['htmp'].view(self.ncls, ch[0] + 1)
-        self.g('head.weight').view(self.ncls, ch[0]).copy_(ht[:, :ch[0]])
-        self.g('head.bias').copy_(ht[:, ch[0]])
+        # slab layout: [planes][ncls][8] weight partials, then [ncls] bias partials
+        nw = self.ncls * ch[0]
+        hw = ws['htmp'][:nw].view(ch[0] // 8, self.ncls, 8).permute(1, 0, 2).reshape(self.ncls, ch[0])
+        self.g('head.weight').view(self.ncls, ch[0]).copy_(hw)
+        self.g('head.bias').copy_(ws['htmp'][nw:nw + self.ncls])
         # decoder, level 0 upwards
         for l in range(0, L - 1):
             v, vi, di = _vox(dims[l]), _vox(dims[l + 1]), dims[l + 1]
