@@ -132,15 +132,19 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(Conv3Params p) {
 
     // ---- all taps of this chunk ----
     const V8* wc = wbase + (long long)chunk * TL::TAPS * MI * 64;
-    V8 a_cur[MI];
+    // weight fragments come straight from global/L2 into a register ring, PF taps ahead:
+    // one tap is only 8*MI MFMAs (128 MFMA-cycles at MI = 2), far less than an L2 round trip
+    constexpr int PF = (MI == 2) ? 4 : 1;
+    V8 ring[PF + 1][MI];
 #pragma unroll
-    for (int m = 0; m < MI; ++m) a_cur[m] = wc[m * 64];
+    for (int t = 0; t < PF; ++t)
+#pragma unroll
+      for (int m = 0; m < MI; ++m) ring[t][m] = wc[(t * MI + m) * 64];
 #pragma unroll
     for (int tap = 0; tap < TL::TAPS; ++tap) {
-      V8 a_nxt[MI];
-      if (tap + 1 < TL::TAPS) {
+      if (tap + PF < TL::TAPS) {
 #pragma unroll
-        for (int m = 0; m < MI; ++m) a_nxt[m] = wc[((tap + 1) * MI + m) * 64];
+        for (int m = 0; m < MI; ++m) ring[(tap + PF) % (PF + 1)][m] = wc[((tap + PF) * MI + m) * 64];
       }
       const int dz = (ND == 3) ? tap / 9 : 0;
       const int dy = (tap / 3) % 3, dx = tap % 3;
@@ -150,11 +154,7 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(Conv3Params p) {
       for (int n = 0; n < NI; ++n) {
         const V8 b = *(const V8*)(smem + frag_addr[n] + tapoff);
 #pragma unroll
-        for (int m = 0; m < MI; ++m) acc[m][n] = mfma16<T>(a_cur[m], b, acc[m][n]);
-      }
-      if (tap + 1 < TL::TAPS) {
-#pragma unroll
-        for (int m = 0; m < MI; ++m) a_cur[m] = a_nxt[m];
+        for (int m = 0; m < MI; ++m) acc[m][n] = mfma16<T>(ring[tap % (PF + 1)][m], b, acc[m][n]);
       }
     }
   }

@@ -174,13 +174,13 @@ __global__ __launch_bounds__(256, 2) void conv3_wgrad_kernel(WgradParams p) {
       const unsigned offX = (unsigned)((((fz * PY + fy) * PX) + xh * 16) * 16);
       const typename Vec8<T>::type a0 = tr_frag<T>(laneY + offY);                    // co 0..15
       const typename Vec8<T>::type a1 = tr_frag<T>(laneY + offY + 2 * PLANE_Y);      // co 16..31
+      // branch-free: a wave whose last unit does not exist (u >= NU) recomputes tap 0 into an
+      // accumulator that is never stored (<= 1/14 of its MFMAs) -- keeps the read/MFMA stream pipelined
 #pragma unroll
       for (int i = 0; i < MAXU; ++i) {
-        if (wave + 4 * i < NU) {        // wave-uniform
-          const typename Vec8<T>::type b = tr_frag<T>(laneX + offX + unit_off[i]);
-          acc[i][0] = mfma16<T>(a0, b, acc[i][0]);
-          acc[i][1] = mfma16<T>(a1, b, acc[i][1]);
-        }
+        const typename Vec8<T>::type b = tr_frag<T>(laneX + offX + unit_off[i]);
+        acc[i][0] = mfma16<T>(a0, b, acc[i][0]);
+        acc[i][1] = mfma16<T>(a1, b, acc[i][1]);
       }
     }
   }
@@ -202,21 +202,21 @@ __global__ __launch_bounds__(256, 2) void conv3_wgrad_kernel(WgradParams p) {
   }
 }
 
-// dW[co][ci][tap] (+)= alpha * sum_b slab[b][cob][cib][tap][co%32][ci%32]
+// dW[co][ci][tap] = alpha * sum_b slab[b][cob][cib][tap][co%32][ci%32]; threads walk the slab
+// order (coalesced reads of every part), the small dW write is scattered.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int nb, int Cout, int Cin, int taps,
                                                            float* __restrict__ dW, float alpha) {
-  const long long total = (long long)Cout * Cin * taps;
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= total) return;
-  const int tap = (int)(i % taps);
-  const int ci = (int)((i / taps) % Cin);
-  const int co = (int)(i / ((long long)taps * Cin));
-  const int ncob = Cout / 32, ncib = Cin / 32;
-  const long long per_b = (long long)ncob * ncib * taps * 1024;
-  const long long off = ((((long long)(co / 32)) * ncib + ci / 32) * taps + tap) * 1024 + (co % 32) * 32 + (ci % 32);
+  const long long per_b = (long long)Cout * Cin * taps;
+  const long long j = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (j >= per_b) return;
   float s = 0.f;
-  for (int b = 0; b < nb; ++b) s += slab[b * per_b + off];
-  dW[i] = alpha * s;
+  for (int b = 0; b < nb; ++b) s += slab[b * per_b + j];
+  const int c = (int)(j & 31), r = (int)((j >> 5) & 31);
+  long long t = j >> 10;
+  const int tap = (int)(t % taps); t /= taps;
+  const int ncib = Cin / 32;
+  const int cib = (int)(t % ncib), cob = (int)(t / ncib);
+  dW[((long long)(cob * 32 + r) * Cin + cib * 32 + c) * taps + tap] = alpha * s;
 }
 
 template <typename T, int ND>

@@ -1,0 +1,61 @@
+"""Micro-benchmark of the MFMA conv kernels per U-Net layer shape (HIP events on the launch stream).
+    python tools/bench_conv.py [--dtype bf16] [--n 1] [--size 128] [--dim 3]"""
+import argparse, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'interactive-unet_amd'))
+import torch
+from interactive_unet import _native as nv
+
+def timeit(fn, iters=10, warm=3):
+    for _ in range(warm): fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--dtype', default='bf16'); ap.add_argument('--n', type=int, default=1)
+    ap.add_argument('--size', type=int, default=128); ap.add_argument('--dim', type=int, default=3)
+    ap.add_argument('--wgrad', type=int, default=1)
+    ap.add_argument('--only', default='', help='e.g. 0:64:32 = level:cin:cout')
+    ap.add_argument('--iters', type=int, default=10)
+    a = ap.parse_args()
+    T = torch.bfloat16 if a.dtype == 'bf16' else torch.float16
+    dt = nv.DTYPE_CODE[T]; nd = a.dim; taps = 3 ** nd
+    shapes = [(0, 32, 32), (0, 64, 32), (1, 32, 64), (1, 64, 64), (1, 128, 64), (2, 64, 128), (2, 128, 128), (2, 256, 128),
+              (3, 128, 256), (3, 256, 256)]
+    if a.only:
+        l, ci, co = [int(v) for v in a.only.split(':')]
+        shapes = [(l, ci, co)]
+    tot_f = tot_t = 0
+    for lvl, cin, cout in shapes:
+        S = a.size >> lvl
+        D = S if nd == 3 else 1
+        vox = D * S * S
+        x = (torch.randn(a.n * cin * vox, device='cuda') * 0.5).to(T)
+        y = torch.empty(a.n * cout * vox, dtype=T, device='cuda')
+        w = torch.randn(cout, cin, *([3] * nd), device='cuda') * 0.05
+        wpk = torch.empty(cout * cin * taps, dtype=T, device='cuda')
+        bias = torch.zeros(cout, device='cuda')
+        nv.call('iunet_pack_conv3', dt, nv.ptr(w), None, nv.ptr(wpk), cout, cin, taps, 0, nv.stream())
+        f = lambda: nv.call('iunet_conv3_fwd', dt, nd, nv.ptr(x), cin * vox, nv.ptr(y), cout * vox, nv.ptr(wpk), nv.ptr(bias), None,
+                            a.n, D, S, S, cin, cout, 2, nv.stream())
+        ms = timeit(f, iters=a.iters)
+        fl = 2.0 * taps * cin * cout * vox * a.n
+        line = f'L{lvl} {cin:3d}->{cout:3d} @{S}^{nd} N={a.n}: fwd {ms*1e3:8.1f} us {fl/ms/1e9:7.1f} TF/s'
+        tot_f += fl; tot_t += ms
+        if a.wgrad:
+            dy = (torch.randn(a.n * cout * vox, device='cuda') * 0.5).to(T)
+            nfl = nv.lib().iunet_conv3_wgrad_slab_floats(nd, a.n, D, S, S, cin, cout)
+            slab = torch.empty(nfl, device='cuda'); dW = torch.empty(cout * cin * taps, device='cuda')
+            g = lambda: nv.call('iunet_conv3_wgrad', dt, nd, nv.ptr(x), cin * vox, nv.ptr(dy), cout * vox, nv.ptr(slab), nv.ptr(dW), 1.0,
+                                a.n, D, S, S, cin, cout, nv.stream())
+            ms2 = timeit(g, iters=a.iters)
+            line += f' | wgrad {ms2*1e3:8.1f} us {fl/ms2/1e9:7.1f} TF/s'
+        print(line, flush=True)
+    print(f'sum fwd: {tot_t*1e3:.1f} us, {tot_f/tot_t/1e9:.1f} TF/s')
+
+if __name__ == '__main__':
+    main()
