@@ -51,7 +51,7 @@ def conv_roofline(nv, dtype, S, iters=10):
     x = (torch.randn(cin * vox, device=dev) * 0.5).to(dtype)
     y = torch.empty(cout * vox, dtype=dtype, device=dev)
     w = torch.randn(cout, cin, 3, 3, 3, device=dev) * 0.03
-    wpk = torch.empty(cout * cin * taps, dtype=dtype, device=dev)
+    wpk = torch.empty(nv.pack_conv3_elems(cout, cin, taps), dtype=dtype, device=dev)
     bias = torch.zeros(cout, device=dev)
     dt = nv.DTYPE_CODE[dtype]
     nv.call('iunet_pack_conv3', dt, nv.ptr(w), None, nv.ptr(wpk), cout, cin, taps, 0, nv.stream())

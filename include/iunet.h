@@ -34,7 +34,8 @@ int iunet_abi_version(void);
 /* ---- weight packing (host fp32 master weights -> MFMA fragment order) ---------------- */
 /* conv weights fp32 [Cout][Cin][taps] (torch Conv{2,3}d layout); optional per-cout scale
  * folds an eval-mode BatchNorm.  mode 0: forward operator; mode 1: data-gradient operator
- * (channels transposed, taps mirrored).  dst: Cout*Cin*taps elements of `dtype`. */
+ * (channels transposed, taps mirrored).  dst: iunet_pack_conv3_elems(...) elements of `dtype`. */
+long long iunet_pack_conv3_elems(int Cout, int Cin, int taps, int mode);
 int iunet_pack_conv3(int dtype, const void* w, const void* scale, void* dst, int Cout, int Cin, int taps, int mode,
                      void* stream);
 /* first conv (Cin <= 4): dst fp32 [taps][Cin][Cout], values rounded through `dtype`. */
@@ -51,6 +52,10 @@ int iunet_conv3_fwd(int dtype, int nd, const void* x, long long x_sstride, void*
                     const void* wpk, const void* bias, void* stats, int N, int D, int H, int W, int Cin, int Cout,
                     int epi, void* stream);
 int iunet_conv3_num_tiles(int nd, int N, int D, int H, int W);
+/* profiling only: ablation variants of the bf16 3-D Cout = 32 conv (mask bits: 1 no weight loads, 2 no LDS reads,
+ * 4 no staging, 8 no stores); results are meaningless except for mask 0. */
+int iunet_dbg_conv3_ablate(int exp, const void* x, void* y, const void* wpk, const void* bias, int N, int D, int H, int W,
+                           int Cin, int Cout, void* stream);
 /* first conv reads the caller's tensor directly: in_dtype 0 f32, 1 f16, 2 u8 (x/255,
  * predict.py:30), 3 bf16; in_strides = element strides (n, c, d, h, w). */
 int iunet_first_conv_fwd(int dtype, int nd, const void* x, int in_dtype, const long long* in_strides, void* y,

@@ -19,6 +19,9 @@ int iunet_conv3_launch(int dtype, int nd, const void* x, long long x_sstride, vo
                        const void* wpk, const float* bias, float* stats, int N, int D, int H, int W, int Cin,
                        int Cout, int epi, hipStream_t stream);
 int iunet_conv3_tiles(int nd, int N, int D, int H, int W);
+long long iunet_pack_conv3_size(int Cout, int Cin, int taps, int mode);
+int iunet_conv3_exp_launch(int exp, const void* x, void* y, const void* wpk, const float* bias, int N, int D, int H, int W,
+                           int Cin, int Cout, hipStream_t stream);
 int iunet_pack_conv3_launch(int dtype, const float* w, const float* scale, void* dst, int Cout, int Cin, int taps,
                             int mode, hipStream_t stream);
 int iunet_first_conv_launch(int dtype, int nd, const void* x, int in_dtype, long long sN, long long sC, long long sD,
@@ -61,6 +64,8 @@ int iunet_abi_version(void) { return 1; }
 int iunet_conv3_num_tiles(int nd, int N, int D, int H, int W) { return iunet_conv3_tiles(nd, N, D, H, W); }
 int iunet_first_conv_num_blocks(int N, int D, int H, int W) { return iunet_first_conv_blocks(N, D, H, W); }
 
+long long iunet_pack_conv3_elems(int Cout, int Cin, int taps, int mode) { return iunet_pack_conv3_size(Cout, Cin, taps, mode); }
+
 int iunet_pack_conv3(int dtype, const void* w, const void* scale, void* dst, int Cout, int Cin, int taps, int mode,
                      void* stream) {
   DT_OK(dtype);
@@ -97,6 +102,12 @@ int iunet_conv3_fwd(int dtype, int nd, const void* x, long long x_sstride, void*
   IUNET_REQUIRE(epi >= 0 && epi <= 2, "conv3: bad epilogue %d", epi);
   return iunet_conv3_launch(dtype, nd, x, x_sstride, y, y_sstride, wpk, (const float*)bias, (float*)stats, N, D, H, W,
                             Cin, Cout, epi, (hipStream_t)stream);
+}
+
+/* profiling only: ablation builds of the 3-D Cout=32 bf16 conv (not part of the product path) */
+int iunet_dbg_conv3_ablate(int exp, const void* x, void* y, const void* wpk, const void* bias, int N, int D, int H, int W,
+                           int Cin, int Cout, void* stream) {
+  return iunet_conv3_exp_launch(exp, x, y, wpk, (const float*)bias, N, D, H, W, Cin, Cout, (hipStream_t)stream);
 }
 
 int iunet_first_conv_fwd(int dtype, int nd, const void* x, int in_dtype, const long long* in_strides, void* y,

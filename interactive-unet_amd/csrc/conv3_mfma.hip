@@ -17,6 +17,7 @@
 // Each wave owns 8 voxel fragments (NI = 8) x MI cout tiles: 8*MI MFMA 16x16x32 per tap
 // and chunk against 8 LDS fragment reads and MI weight-fragment loads.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -37,7 +38,9 @@ struct Conv3Params {
 
 enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_RELU = 2 };
 
-template <typename T, int ND, int MI>
+// EXP: ablation switches for profiling builds only (bit 0 no weight loads, 1 no LDS fragment reads,
+// 2 no staging, 3 no epilogue stores); production instantiations use EXP = 0.
+template <typename T, int ND, int MI, int EXP = 0>
 __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(Conv3Params p) {
   using TL = Tile<ND>;
   using V8 = typename Vec8<T>::type;
@@ -95,26 +98,30 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(Conv3Params p) {
   for (int chunk = 0; chunk < nchunk; ++chunk) {
     __syncthreads();   // previous chunk's fragment reads are done
     // ---- stage the halo tile of 32 channels: global -> registers -> LDS ----
-    {
+    if (!(EXP & 4)) {
       const T* xc = xin + (long long)chunk * 4 * plane_stride;
       constexpr int ITERS = (NPIX + 255) / 256;
+      // MI = 2 has the registers to keep all four planes of every pixel in flight at once (one
+      // latency round); MI = 4 stages in two rounds.  Loads are unconditional (clamped address,
+      // zero selected afterwards): no exec-mask branches between the load instructions.
+      constexpr int ROUNDS = (MI == 2) ? 1 : 2;
+      constexpr int PPR = 4 / ROUNDS;                    // planes per round
 #pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        u32x4 v[ITERS][2];
+      for (int rnd = 0; rnd < ROUNDS; ++rnd) {
+        u32x4 v[ITERS][PPR];
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
           const int pix = tid + it * 256;
           const int px = pix % PX, t2 = pix / PX;
-          const int py = t2 % PY, pz = t2 / PY;
+          const int py = t2 % PY, pz = (t2 / PY) % PZ;
           const int gz = z0 + pz - PADZ, gy = y0 + py - 1, gx = x0 + px - 1;
-          const bool ok = (pix < NPIX) && (unsigned)gz < (unsigned)p.D && (unsigned)gy < (unsigned)p.H &&
-                          (unsigned)gx < (unsigned)p.W;
-          const long long goff = (((long long)gz * p.H + gy) * p.W + gx) * 8;
+          const bool ok = (unsigned)gz < (unsigned)p.D && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+          const int cz = min(max(gz, 0), p.D - 1), cy = min(max(gy, 0), p.H - 1), cx = min(max(gx, 0), p.W - 1);
+          const long long goff = (((long long)cz * p.H + cy) * p.W + cx) * 8;
 #pragma unroll
-          for (int k = 0; k < 2; ++k) {
-            u32x4 val = u32x4{0u, 0u, 0u, 0u};
-            if (ok) val = *(const u32x4*)(xc + (half * 2 + k) * plane_stride + goff);
-            v[it][k] = val;
+          for (int k = 0; k < PPR; ++k) {
+            const u32x4 val = *(const u32x4*)(xc + (rnd * PPR + k) * plane_stride + goff);
+            v[it][k] = ok ? val : u32x4{0u, 0u, 0u, 0u};
           }
         }
 #pragma unroll
@@ -122,8 +129,8 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(Conv3Params p) {
           const int pix = tid + it * 256;
           if (pix < NPIX) {
 #pragma unroll
-            for (int k = 0; k < 2; ++k)
-              *(u32x4*)(smem + (half * 2 + k) * PLANE + pix * 16) = v[it][k];
+            for (int k = 0; k < PPR; ++k)
+              *(u32x4*)(smem + (rnd * PPR + k) * PLANE + pix * 16) = v[it][k];
           }
         }
       }
@@ -142,7 +149,7 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(Conv3Params p) {
       for (int m = 0; m < MI; ++m) ring[t][m] = wc[(t * MI + m) * 64];
 #pragma unroll
     for (int tap = 0; tap < TL::TAPS; ++tap) {
-      if (tap + PF < TL::TAPS) {
+      if (tap + PF < TL::TAPS && !(EXP & 1)) {
 #pragma unroll
         for (int m = 0; m < MI; ++m) ring[(tap + PF) % (PF + 1)][m] = wc[((tap + PF) * MI + m) * 64];
       }
@@ -152,9 +159,11 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(Conv3Params p) {
       (void)KD;
 #pragma unroll
       for (int n = 0; n < NI; ++n) {
-        const V8 b = *(const V8*)(smem + frag_addr[n] + tapoff);
+        V8 b;
+        if (EXP & 2) { b = ring[0][0]; asm volatile("" : "+v"(b)); }
+        else b = *(const V8*)(smem + frag_addr[n] + tapoff);
 #pragma unroll
-        for (int m = 0; m < MI; ++m) acc[m][n] = mfma16<T>(ring[tap % (PF + 1)][m], b, acc[m][n]);
+        for (int m = 0; m < MI; ++m) acc[m][n] = mfma16<T>(ring[(EXP & 1) ? (tap % PF) : (tap % (PF + 1))][m], b, acc[m][n]);
       }
     }
   }
@@ -195,7 +204,7 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(Conv3Params p) {
       V8 o;
 #pragma unroll
       for (int j = 0; j < 8; ++j) o[j] = from_f32<T>(vals[j]);
-      if (ok) {
+      if (ok && !((EXP & 8) && vals[0] != 12345.f)) {
         const int plane = (cbase >> 3);
         *(V8*)(yout + (long long)plane * plane_stride + voff) = o;
       }
@@ -263,6 +272,37 @@ __global__ void pack_conv3_kernel(const float* __restrict__ w, const float* __re
   }
 }
 
+// K16 packing for the Cout-32 structure (conv3_v2.hip): [cob32][chunk16][column pair][dy][2][64][8].
+// A filter "column" is a (dz, dx) pair (9 in 3-D, 3 in 2-D); a k-step holds two columns x 16 channels:
+// lane (row = l & 15, q = l >> 4), element j -> column 2 pair + (q >> 1), cin = 16 chunk + 8 (q & 1) + j.
+template <typename T>
+__global__ void pack_conv3_k16_kernel(const float* __restrict__ w, const float* __restrict__ scale, T* __restrict__ dst,
+                                      int CoutP, int CinP, int taps, int dgrad, int CinO) {
+  const int ncol = taps / 3, ncmb = (ncol + 1) / 2, nchunk = CinP >> 4;
+  const long long total = (long long)(CoutP / 32) * nchunk * ncmb * 3 * 2 * 64 * 8;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    long long r = i;
+    const int j = r & 7; r >>= 3;
+    const int lane = r & 63; r >>= 6;
+    const int m = r & 1; r >>= 1;
+    const int dy = r % 3; r /= 3;
+    const int c = r % ncmb; r /= ncmb;
+    const int chunk = r % nchunk;
+    const int cob = r / nchunk;
+    const int row = lane & 15, qq = lane >> 4;
+    const int co = cob * 32 + 8 * (row >> 2) + 4 * m + (row & 3);
+    const int ci = chunk * 16 + 8 * (qq & 1) + j;
+    const int col = 2 * c + (qq >> 1);
+    float v = 0.f;
+    if (col < ncol) {
+      const int tap = ((col / 3) * 3 + dy) * 3 + (col % 3);       // (dz, dy, dx) -> linear tap
+      if (!dgrad) { v = w[((long long)co * CinO + ci) * taps + tap]; if (scale) v *= scale[co]; }
+      else v = w[((long long)ci * CinO + co) * taps + (taps - 1 - tap)];
+    }
+    dst[i] = from_f32<T>(v);
+  }
+}
+
 template <typename T, int ND, int MI>
 int launch_conv3(const Conv3Params& p, hipStream_t stream) {
   using TL = Tile<ND>;
@@ -283,6 +323,10 @@ int launch_conv3(const Conv3Params& p, hipStream_t stream) {
 
 }  // namespace
 
+int iunet_conv3_v2_launch(int dtype, int nd, const void* x, long long x_sstride, void* y, long long y_sstride,
+                          const void* wpk, const float* bias, float* stats, int N, int D, int H, int W, int Cin,
+                          int Cout, int epi, hipStream_t stream);
+
 // Host entry used by the net runtime and the per-kernel C ABI.
 int iunet_conv3_launch(int dtype, int nd, const void* x, long long x_sstride, void* y, long long y_sstride,
                        const void* wpk, const float* bias, float* stats, int N, int D, int H, int W, int Cin,
@@ -297,11 +341,33 @@ int iunet_conv3_launch(int dtype, int nd, const void* x, long long x_sstride, vo
   const int TZ = nd == 3 ? 4 : 1, TY = nd == 3 ? 8 : 16, TX = nd == 3 ? 16 : 32;
   p.tilesZ = (D + TZ - 1) / TZ; p.tilesY = (H + TY - 1) / TY; p.tilesX = (W + TX - 1) / TX;
   const bool wide = (Cout % 64 == 0);
+  // Cout tiles of 32: persistent LDS-fed structure (conv3_v2.hip); IUNET_CONV_V1=1 keeps the first structure (A/B runs)
+  static const bool force_v1 = getenv("IUNET_CONV_V1") != nullptr;
+  if (!wide && !force_v1)
+    return iunet_conv3_v2_launch(dtype, nd, x, x_sstride, y, y_sstride, wpk, bias, stats, N, D, H, W, Cin, Cout, epi, stream);
 #define IUNET_DISPATCH(TT)                                                                   \
   if (nd == 3) return wide ? launch_conv3<TT, 3, 4>(p, stream) : launch_conv3<TT, 3, 2>(p, stream); \
   else         return wide ? launch_conv3<TT, 2, 4>(p, stream) : launch_conv3<TT, 2, 2>(p, stream);
   if (dtype == 0) { IUNET_DISPATCH(f16) } else { IUNET_DISPATCH(bf16) }
 #undef IUNET_DISPATCH
+}
+
+// profiling-only entry: bf16, 3-D, Cout = 32 tile with ablation switches (see EXP above)
+int iunet_conv3_exp_launch(int exp, const void* x, void* y, const void* wpk, const float* bias, int N, int D, int H, int W,
+                           int Cin, int Cout, hipStream_t stream) {
+  Conv3Params p;
+  p.x = x; p.x_sstride = (long long)Cin * D * H * W; p.y = y; p.y_sstride = (long long)Cout * D * H * W; p.wpk = wpk;
+  p.bias = bias; p.stats = nullptr; p.N = N; p.D = D; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.epi = 2;
+  p.tilesZ = (D + 3) / 4; p.tilesY = (H + 7) / 8; p.tilesX = (W + 15) / 16;
+  constexpr int LDS = 4 * 17408;
+  dim3 grid(p.tilesZ * p.tilesY * p.tilesX * N, Cout / 32);
+#define IUNET_EXP_CASE(E) case E: { static bool s = false; if (!s) { IUNET_CHECK_HIP(hipFuncSetAttribute((const void*)conv3_mfma_kernel<bf16, 3, 2, E>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); s = true; } \
+    hipLaunchKernelGGL((conv3_mfma_kernel<bf16, 3, 2, E>), grid, dim3(256), LDS, stream, p); } break;
+  switch (exp) { IUNET_EXP_CASE(0) IUNET_EXP_CASE(1) IUNET_EXP_CASE(2) IUNET_EXP_CASE(4) IUNET_EXP_CASE(8) IUNET_EXP_CASE(3) IUNET_EXP_CASE(7) IUNET_EXP_CASE(15)
+    default: iunet_set_error("conv3_exp: unsupported ablation mask %d", exp); return IUNET_ERR_ARG; }
+#undef IUNET_EXP_CASE
+  IUNET_CHECK_HIP(hipGetLastError());
+  return IUNET_OK;
 }
 
 int iunet_conv3_tiles(int nd, int N, int D, int H, int W) {
@@ -311,12 +377,29 @@ int iunet_conv3_tiles(int nd, int N, int D, int H, int W) {
 
 int iunet_conv3_mi(int Cout) { return (Cout % 64 == 0) ? 4 : 2; }
 
+// elements of the packed operator (the K16 order pads the tap count to an even number)
+long long iunet_pack_conv3_size(int Cout, int Cin, int taps, int mode) {
+  const int CoutP = mode == 0 ? Cout : Cin;
+  static const bool force_v1 = getenv("IUNET_CONV_V1") != nullptr;
+  const int t = (iunet_conv3_mi(CoutP) == 2 && !force_v1) ? ((taps / 3 + 1) / 2) * 6 : taps;
+  return (long long)Cout * Cin * t;
+}
+
 int iunet_pack_conv3_launch(int dtype, const float* w, const float* scale, void* dst, int Cout, int Cin, int taps,
                             int mode, hipStream_t stream) {
   // mode 0: packed operator is Cout x Cin; mode 1 (dgrad): packed operator is Cin x Cout
   const int CoutP = mode == 0 ? Cout : Cin, CinP = mode == 0 ? Cin : Cout;
   IUNET_REQUIRE(CoutP % 32 == 0 && CinP % 32 == 0, "pack_conv3: channel counts must be multiples of 32 (%d, %d)", CoutP, CinP);
   const int MI = iunet_conv3_mi(CoutP);
+  static const bool force_v1 = getenv("IUNET_CONV_V1") != nullptr;
+  if (MI == 2 && !force_v1) {     // Cout tiles of 32 run the LDS-fed structure and its K16 fragment order
+    const long long tot = (long long)(CoutP / 32) * (CinP / 16) * ((taps / 3 + 1) / 2) * 3 * 1024;
+    const int nb = (int)((tot + 255) / 256 < 4096 ? (tot + 255) / 256 : 4096);
+    if (dtype == 0) hipLaunchKernelGGL(pack_conv3_k16_kernel<f16>, dim3(nb), dim3(256), 0, stream, w, scale, (f16*)dst, CoutP, CinP, taps, mode, Cin);
+    else hipLaunchKernelGGL(pack_conv3_k16_kernel<bf16>, dim3(nb), dim3(256), 0, stream, w, scale, (bf16*)dst, CoutP, CinP, taps, mode, Cin);
+    IUNET_CHECK_HIP(hipGetLastError());
+    return IUNET_OK;
+  }
   const long long total = (long long)CoutP * CinP * taps;
   const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
   if (dtype == 0)

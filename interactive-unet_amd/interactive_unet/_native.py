@@ -21,6 +21,7 @@ _SIGS = {
     'iunet_abi_version': [],
     'iunet_conv3_num_tiles': [c_int] * 5,
     'iunet_first_conv_num_blocks': [c_int] * 4,
+    'iunet_dbg_conv3_ablate': [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     'iunet_pack_conv3': [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     'iunet_pack_first_conv': [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     'iunet_pack_convT': [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
@@ -70,7 +71,7 @@ _SIGS = {
                                c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
 }
 # functions that return a size / count instead of a status
-_LL_RETURN = {'iunet_conv3_wgrad_slab_floats': [c_int] * 7}
+_LL_RETURN = {'iunet_conv3_wgrad_slab_floats': [c_int] * 7, 'iunet_pack_conv3_elems': [c_int] * 4}
 
 
 class NativeError(RuntimeError):
@@ -110,6 +111,10 @@ def check(status):
 
 def call(name, *args):
     check(getattr(lib(), name)(*args))
+
+
+def pack_conv3_elems(cout, cin, taps, mode=0):
+    return int(lib().iunet_pack_conv3_elems(cout, cin, taps, mode))
 
 
 def ptr(t):

@@ -79,7 +79,7 @@ class Engine:
                     dst = torch.empty(self.taps * a * b, dtype=torch.float32, device=self.device)
                     nv.call('iunet_pack_first_conv', self.dt, nv.ptr(w), nv.ptr(scale), nv.ptr(dst), b, a, self.taps, s)
                 else:
-                    dst = torch.empty(self.taps * a * b, dtype=self.act_dtype, device=self.device)
+                    dst = torch.empty(nv.pack_conv3_elems(b, a, self.taps, 0), dtype=self.act_dtype, device=self.device)
                     nv.call('iunet_pack_conv3', self.dt, nv.ptr(w), nv.ptr(scale), nv.ptr(dst), b, a, self.taps, 0, s)
                 P[f'{prefix}.conv{j}'] = (dst, bias)
         for l in range(self.levels - 2, -1, -1):

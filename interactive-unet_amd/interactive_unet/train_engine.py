@@ -97,8 +97,8 @@ class TrainEngine:
                 if name == 'enc0.conv1':
                     self.pk[name] = (torch.empty(self.taps * a * b, dtype=torch.float32, device=self.dev), None)
                 else:
-                    self.pk[name] = (torch.empty(self.taps * a * b, dtype=self.T, device=self.dev),
-                                     torch.empty(self.taps * a * b, dtype=self.T, device=self.dev))
+                    self.pk[name] = (torch.empty(nv.pack_conv3_elems(b, a, self.taps, 0), dtype=self.T, device=self.dev),
+                                     torch.empty(nv.pack_conv3_elems(b, a, self.taps, 1), dtype=self.T, device=self.dev))
         for l in range(self.levels - 2, -1, -1):
             n = self.ch[l + 1] * self.ch[l] * self.npos
             self.pk[f'dec{l}.up'] = (torch.empty(n, dtype=self.T, device=self.dev),

@@ -45,7 +45,7 @@ def run_conv3(nv, x, w, dtype, nd, scale=None, bias=None, epi=0, stats=False, mo
     Co_p, Ci_p = (w.shape[0], w.shape[1]) if mode == 0 else (w.shape[1], w.shape[0])
     xb = blocked(x, dtype).to(dev)
     wd = w.contiguous().to(dev)
-    wpk = torch.empty(Co_p * Ci_p * taps, dtype=dtype, device=dev)
+    wpk = torch.empty(nv.pack_conv3_elems(w.shape[0], w.shape[1], taps, mode), dtype=dtype, device=dev)
     sc = None if scale is None else scale.to(dev)
     nv.call('iunet_pack_conv3', nv.DTYPE_CODE[dtype], nv.ptr(wd), nv.ptr(sc), nv.ptr(wpk), w.shape[0], w.shape[1],
             taps, mode, nv.stream())

@@ -37,7 +37,7 @@ def main():
         x = (torch.randn(a.n * cin * vox, device='cuda') * 0.5).to(T)
         y = torch.empty(a.n * cout * vox, dtype=T, device='cuda')
         w = torch.randn(cout, cin, *([3] * nd), device='cuda') * 0.05
-        wpk = torch.empty(cout * cin * taps, dtype=T, device='cuda')
+        wpk = torch.empty(nv.pack_conv3_elems(cout, cin, taps), dtype=T, device='cuda')
         bias = torch.zeros(cout, device='cuda')
         nv.call('iunet_pack_conv3', dt, nv.ptr(w), None, nv.ptr(wpk), cout, cin, taps, 0, nv.stream())
         f = lambda: nv.call('iunet_conv3_fwd', dt, nd, nv.ptr(x), cin * vox, nv.ptr(y), cout * vox, nv.ptr(wpk), nv.ptr(bias), None,
