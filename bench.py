@@ -51,12 +51,13 @@ def conv_roofline(nv, dtype, S, iters=10):
     x = (torch.randn(cin * vox, device=dev) * 0.5).to(dtype)
     y = torch.empty(cout * vox, dtype=dtype, device=dev)
     w = torch.randn(cout, cin, 3, 3, 3, device=dev) * 0.03
-    wpk = torch.empty(nv.pack_conv3_elems(cout, cin, taps), dtype=dtype, device=dev)
-    bias = torch.zeros(cout, device=dev)
     dt = nv.DTYPE_CODE[dtype]
-    nv.call('iunet_pack_conv3', dt, nv.ptr(w), None, nv.ptr(wpk), cout, cin, taps, 0, nv.stream())
+    lay = nv.lib().iunet_conv3_pick_layout(3, 1, S, S, S, cin, cout)
+    wpk = torch.empty(nv.pack_conv3_elems(cout, cin, taps, 2 * lay), dtype=dtype, device=dev)
+    bias = torch.zeros(cout, device=dev)
+    nv.call('iunet_pack_conv3', dt, nv.ptr(w), None, nv.ptr(wpk), cout, cin, taps, 2 * lay, nv.stream())
     run = lambda: nv.call('iunet_conv3_fwd', dt, 3, nv.ptr(x), cin * vox, nv.ptr(y), cout * vox, nv.ptr(wpk),
-                          nv.ptr(bias), None, 1, S, S, S, cin, cout, 2, nv.stream())
+                          nv.ptr(bias), None, 1, S, S, S, cin, cout, 2, lay, nv.stream())
     for _ in range(3):
         run()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -68,7 +69,7 @@ def conv_roofline(nv, dtype, S, iters=10):
     ms = e0.elapsed_time(e1) / iters
     flops = 2.0 * taps * cin * cout * vox
     ach = flops / (ms * 1e-3) / 1e12
-    return {'bound': 'mfma', 'kernel': 'conv3_mfma_kernel<bf16,3,2> (dec0.conv1 64->32 @128^3)',
+    return {'bound': 'mfma', 'kernel': ('conv3_v2_kernel' if lay else 'conv3_mfma_kernel') + f'<{"bf16" if dtype == torch.bfloat16 else "f16"},3> (dec0.conv1 64->32 @128^3)',
             'achieved': round(ach, 2), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / MFMA_PEAK_TFLOPS, 4),
             'ms_per_launch': round(ms, 4), 'flops_per_launch': flops, 'traffic': None}
 

@@ -33,8 +33,8 @@ int iunet_abi_version(void);
 
 /* ---- weight packing (host fp32 master weights -> MFMA fragment order) ---------------- */
 /* conv weights fp32 [Cout][Cin][taps] (torch Conv{2,3}d layout); optional per-cout scale
- * folds an eval-mode BatchNorm.  mode 0: forward operator; mode 1: data-gradient operator
- * (channels transposed, taps mirrored).  dst: iunet_pack_conv3_elems(...) elements of `dtype`. */
+ * folds an eval-mode BatchNorm.  mode bit 0: data-gradient operator (channels transposed, taps
+ * mirrored); mode bit 1: K16 fragment order for weight layout 1 (see iunet_conv3_pick_layout).  dst: iunet_pack_conv3_elems(...) elements of `dtype`. */
 long long iunet_pack_conv3_elems(int Cout, int Cin, int taps, int mode);
 int iunet_pack_conv3(int dtype, const void* w, const void* scale, void* dst, int Cout, int Cin, int taps, int mode,
                      void* stream);
@@ -50,7 +50,11 @@ int iunet_pack_convT(int dtype, const void* w, void* dst, int Cin, int Cout, int
  * the raw output (BatchNorm batch statistics), reduced by the caller. */
 int iunet_conv3_fwd(int dtype, int nd, const void* x, long long x_sstride, void* y, long long y_sstride,
                     const void* wpk, const void* bias, void* stats, int N, int D, int H, int W, int Cin, int Cout,
-                    int epi, void* stream);
+                    int epi, int layout, void* stream);
+/* which kernel structure / weight layout serves this launch best: 0 = 32-channel chunks, weights through
+ * registers (wpk packed with mode bit 1 clear); 1 = persistent LDS-fed Cout-32 structure (mode bit 1 set).
+ * Layout 1 is mandatory when Cout is not a multiple of 64. */
+int iunet_conv3_pick_layout(int nd, int N, int D, int H, int W, int Cin, int Cout);
 int iunet_conv3_num_tiles(int nd, int N, int D, int H, int W);
 /* profiling only: ablation variants of the bf16 3-D Cout = 32 conv (mask bits: 1 no weight loads, 2 no LDS reads,
  * 4 no staging, 8 no stores); results are meaningless except for mask 0. */

@@ -17,7 +17,8 @@ void iunet_set_error(const char* fmt, ...) {
 // internal launchers (conv3_mfma.hip, pointwise.hip)
 int iunet_conv3_launch(int dtype, int nd, const void* x, long long x_sstride, void* y, long long y_sstride,
                        const void* wpk, const float* bias, float* stats, int N, int D, int H, int W, int Cin,
-                       int Cout, int epi, hipStream_t stream);
+                       int Cout, int epi, int layout, hipStream_t stream);
+int iunet_conv3_pick(int nd, int N, int D, int H, int W, int Cin, int Cout);
 int iunet_conv3_tiles(int nd, int N, int D, int H, int W);
 long long iunet_pack_conv3_size(int Cout, int Cin, int taps, int mode);
 int iunet_conv3_exp_launch(int exp, const void* x, void* y, const void* wpk, const float* bias, int N, int D, int H, int W,
@@ -93,15 +94,20 @@ int iunet_pack_convT(int dtype, const void* w, void* dst, int Cin, int Cout, int
   return iunet_pack_convT_launch(dtype, (const float*)w, dst, Cin, Cout, npos, (hipStream_t)stream);
 }
 
+int iunet_conv3_pick_layout(int nd, int N, int D, int H, int W, int Cin, int Cout) {
+  return iunet_conv3_pick(nd, N, D, H, W, Cin, Cout);
+}
+
 int iunet_conv3_fwd(int dtype, int nd, const void* x, long long x_sstride, void* y, long long y_sstride,
                     const void* wpk, const void* bias, void* stats, int N, int D, int H, int W, int Cin, int Cout,
-                    int epi, void* stream) {
+                    int epi, int layout, void* stream) {
   DT_OK(dtype);
   IUNET_REQUIRE(x && y && wpk, "conv3: null pointer");
   IUNET_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0, "conv3: bad shape %d %d %d %d", N, D, H, W);
   IUNET_REQUIRE(epi >= 0 && epi <= 2, "conv3: bad epilogue %d", epi);
+  IUNET_REQUIRE(layout == 0 || layout == 1, "conv3: weight layout must be 0 or 1 (got %d)", layout);
   return iunet_conv3_launch(dtype, nd, x, x_sstride, y, y_sstride, wpk, (const float*)bias, (float*)stats, N, D, H, W,
-                            Cin, Cout, epi, (hipStream_t)stream);
+                            Cin, Cout, epi, layout, (hipStream_t)stream);
 }
 
 /* profiling only: ablation builds of the 3-D Cout=32 bf16 conv (not part of the product path) */

@@ -330,7 +330,7 @@ int iunet_conv3_v2_launch(int dtype, int nd, const void* x, long long x_sstride,
 // Host entry used by the net runtime and the per-kernel C ABI.
 int iunet_conv3_launch(int dtype, int nd, const void* x, long long x_sstride, void* y, long long y_sstride,
                        const void* wpk, const float* bias, float* stats, int N, int D, int H, int W, int Cin,
-                       int Cout, int epi, hipStream_t stream) {
+                       int Cout, int epi, int layout, hipStream_t stream) {
   IUNET_REQUIRE(nd == 2 || nd == 3, "conv3: nd must be 2 or 3 (got %d)", nd);
   IUNET_REQUIRE(Cin % 32 == 0 && Cout % 32 == 0, "conv3: Cin (%d) and Cout (%d) must be multiples of 32", Cin, Cout);
   IUNET_REQUIRE(nd == 3 || D == 1, "conv3: 2-D conv needs D == 1");
@@ -341,9 +341,7 @@ int iunet_conv3_launch(int dtype, int nd, const void* x, long long x_sstride, vo
   const int TZ = nd == 3 ? 4 : 1, TY = nd == 3 ? 8 : 16, TX = nd == 3 ? 16 : 32;
   p.tilesZ = (D + TZ - 1) / TZ; p.tilesY = (H + TY - 1) / TY; p.tilesX = (W + TX - 1) / TX;
   const bool wide = (Cout % 64 == 0);
-  // Cout tiles of 32: persistent LDS-fed structure (conv3_v2.hip); IUNET_CONV_V1=1 keeps the first structure (A/B runs)
-  static const bool force_v1 = getenv("IUNET_CONV_V1") != nullptr;
-  if (!wide && !force_v1)
+  if (layout == 1)
     return iunet_conv3_v2_launch(dtype, nd, x, x_sstride, y, y_sstride, wpk, bias, stats, N, D, H, W, Cin, Cout, epi, stream);
 #define IUNET_DISPATCH(TT)                                                                   \
   if (nd == 3) return wide ? launch_conv3<TT, 3, 4>(p, stream) : launch_conv3<TT, 3, 2>(p, stream); \
@@ -377,35 +375,48 @@ int iunet_conv3_tiles(int nd, int N, int D, int H, int W) {
 
 int iunet_conv3_mi(int Cout) { return (Cout % 64 == 0) ? 4 : 2; }
 
+// Weight layout / kernel structure of a launch: 0 = first structure (conv3_mfma_kernel, 32-channel chunks),
+// 1 = LDS-fed persistent Cout-32 structure (conv3_v2.hip, K16 fragment order).  The second one is used for
+// Cout tiles of 32 and whenever the first structure's grid would under-fill the chip (deep levels):
+// measured at 128^3 / N = 1, levels 2 and 3 run 1.6-2x faster on it, level 1 (Cout 64, 512 tiles) 10 % slower.
+// IUNET_CONV_V1=1 / IUNET_CONV_V2_ALL=1 force one structure (A/B runs).
+int iunet_conv3_pick(int nd, int N, int D, int H, int W, int Cin, int Cout) {
+  static const bool force_v1 = getenv("IUNET_CONV_V1") != nullptr;
+  static const bool force_v2 = getenv("IUNET_CONV_V2_ALL") != nullptr;
+  (void)Cin;
+  if (force_v1) return 0;
+  if (force_v2 || Cout % 64 != 0) return 1;
+  const long long blocks = (long long)iunet_conv3_tiles(nd, N, D, H, W) * (Cout / 64);
+  return blocks < 512 ? 1 : 0;
+}
+
 // elements of the packed operator (the K16 order pads the tap count to an even number)
 long long iunet_pack_conv3_size(int Cout, int Cin, int taps, int mode) {
-  const int CoutP = mode == 0 ? Cout : Cin;
-  static const bool force_v1 = getenv("IUNET_CONV_V1") != nullptr;
-  const int t = (iunet_conv3_mi(CoutP) == 2 && !force_v1) ? ((taps / 3 + 1) / 2) * 6 : taps;
+  const int t = (mode & 2) ? ((taps / 3 + 1) / 2) * 6 : taps;      // K16 order pads the filter columns to pairs
   return (long long)Cout * Cin * t;
 }
 
 int iunet_pack_conv3_launch(int dtype, const float* w, const float* scale, void* dst, int Cout, int Cin, int taps,
                             int mode, hipStream_t stream) {
-  // mode 0: packed operator is Cout x Cin; mode 1 (dgrad): packed operator is Cin x Cout
-  const int CoutP = mode == 0 ? Cout : Cin, CinP = mode == 0 ? Cin : Cout;
+  // mode bit 0: data-gradient operator (Cin x Cout, taps mirrored); bit 1: K16 fragment order (layout 1)
+  const int dg = mode & 1;
+  const int CoutP = dg == 0 ? Cout : Cin, CinP = dg == 0 ? Cin : Cout;
   IUNET_REQUIRE(CoutP % 32 == 0 && CinP % 32 == 0, "pack_conv3: channel counts must be multiples of 32 (%d, %d)", CoutP, CinP);
   const int MI = iunet_conv3_mi(CoutP);
-  static const bool force_v1 = getenv("IUNET_CONV_V1") != nullptr;
-  if (MI == 2 && !force_v1) {     // Cout tiles of 32 run the LDS-fed structure and its K16 fragment order
+  if (mode & 2) {     // the LDS-fed structure's K16 fragment order
     const long long tot = (long long)(CoutP / 32) * (CinP / 16) * ((taps / 3 + 1) / 2) * 3 * 1024;
     const int nb = (int)((tot + 255) / 256 < 4096 ? (tot + 255) / 256 : 4096);
-    if (dtype == 0) hipLaunchKernelGGL(pack_conv3_k16_kernel<f16>, dim3(nb), dim3(256), 0, stream, w, scale, (f16*)dst, CoutP, CinP, taps, mode, Cin);
-    else hipLaunchKernelGGL(pack_conv3_k16_kernel<bf16>, dim3(nb), dim3(256), 0, stream, w, scale, (bf16*)dst, CoutP, CinP, taps, mode, Cin);
+    if (dtype == 0) hipLaunchKernelGGL(pack_conv3_k16_kernel<f16>, dim3(nb), dim3(256), 0, stream, w, scale, (f16*)dst, CoutP, CinP, taps, dg, Cin);
+    else hipLaunchKernelGGL(pack_conv3_k16_kernel<bf16>, dim3(nb), dim3(256), 0, stream, w, scale, (bf16*)dst, CoutP, CinP, taps, dg, Cin);
     IUNET_CHECK_HIP(hipGetLastError());
     return IUNET_OK;
   }
   const long long total = (long long)CoutP * CinP * taps;
   const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
   if (dtype == 0)
-    hipLaunchKernelGGL(pack_conv3_kernel<f16>, dim3(blocks), dim3(256), 0, stream, w, scale, (f16*)dst, CoutP, CinP, taps, MI, mode, Cout, Cin);
+    hipLaunchKernelGGL(pack_conv3_kernel<f16>, dim3(blocks), dim3(256), 0, stream, w, scale, (f16*)dst, CoutP, CinP, taps, MI, dg, Cout, Cin);
   else
-    hipLaunchKernelGGL(pack_conv3_kernel<bf16>, dim3(blocks), dim3(256), 0, stream, w, scale, (bf16*)dst, CoutP, CinP, taps, MI, mode, Cout, Cin);
+    hipLaunchKernelGGL(pack_conv3_kernel<bf16>, dim3(blocks), dim3(256), 0, stream, w, scale, (bf16*)dst, CoutP, CinP, taps, MI, dg, Cout, Cin);
   IUNET_CHECK_HIP(hipGetLastError());
   return IUNET_OK;
 }

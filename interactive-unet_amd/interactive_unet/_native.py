@@ -26,7 +26,8 @@ _SIGS = {
     'iunet_pack_first_conv': [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     'iunet_pack_convT': [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     'iunet_conv3_fwd': [c_int, c_int, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_void_p, c_void_p,
-                        c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+                        c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    'iunet_conv3_pick_layout': [c_int] * 7,
     'iunet_first_conv_fwd': [c_int, c_int, c_void_p, c_int, ctypes.POINTER(c_ll), c_void_p, c_ll, c_void_p, c_void_p,
                              c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     'iunet_maxpool_fwd': [c_int, c_int, c_void_p, c_ll, c_void_p, c_ll, c_int, c_int, c_int, c_int, c_int, c_void_p],
@@ -115,6 +116,31 @@ def call(name, *args):
 
 def pack_conv3_elems(cout, cin, taps, mode=0):
     return int(lib().iunet_pack_conv3_elems(cout, cin, taps, mode))
+
+
+class PackedConv:
+    """A stage conv's weights in the fragment order(s) its launches may need: layout 1 (K16, the
+    LDS-fed Cout-32 structure) always, layout 0 also when Cout is a multiple of 64.  `dgrad`: the
+    data-gradient operator (roles of cin / cout swapped)."""
+
+    def __init__(self, cout, cin, taps, dtype, device, dgrad=False):
+        self.cout, self.cin, self.taps, self.dg = cout, cin, taps, int(bool(dgrad))
+        self.out_ch = cin if dgrad else cout
+        self.dt = DTYPE_CODE[dtype]
+        self.buf = {1: torch.empty(pack_conv3_elems(cout, cin, taps, 2 | self.dg), dtype=dtype, device=device)}
+        if self.out_ch % 64 == 0:
+            self.buf[0] = torch.empty(pack_conv3_elems(cout, cin, taps, self.dg), dtype=dtype, device=device)
+
+    def pack(self, w, scale=None):
+        for lay, b in self.buf.items():
+            call('iunet_pack_conv3', self.dt, ptr(w), ptr(scale), ptr(b), self.cout, self.cin, self.taps,
+                 (2 if lay == 1 else 0) | self.dg, stream())
+
+    def pick(self, nd, N, D, H, W):
+        """(layout, buffer) for a launch on this grid."""
+        in_ch = self.cout if self.dg else self.cin
+        lay = lib().iunet_conv3_pick_layout(nd, N, D, H, W, in_ch, self.out_ch) if 0 in self.buf else 1
+        return lay, self.buf[lay]
 
 
 def ptr(t):

@@ -79,8 +79,8 @@ class Engine:
                     dst = torch.empty(self.taps * a * b, dtype=torch.float32, device=self.device)
                     nv.call('iunet_pack_first_conv', self.dt, nv.ptr(w), nv.ptr(scale), nv.ptr(dst), b, a, self.taps, s)
                 else:
-                    dst = torch.empty(nv.pack_conv3_elems(b, a, self.taps, 0), dtype=self.act_dtype, device=self.device)
-                    nv.call('iunet_pack_conv3', self.dt, nv.ptr(w), nv.ptr(scale), nv.ptr(dst), b, a, self.taps, 0, s)
+                    dst = nv.PackedConv(b, a, self.taps, self.act_dtype, self.device)
+                    dst.pack(w, scale)
                 P[f'{prefix}.conv{j}'] = (dst, bias)
         for l in range(self.levels - 2, -1, -1):
             w = params[f'dec{l}.up.weight'].detach().to(self.device, torch.float32).contiguous()
@@ -131,9 +131,10 @@ class Engine:
 
     # ------------------------------------------------------------------ forward (inference)
     def _conv3(self, x_ptr, x_ss, y_ptr, y_ss, name, N, dims, ci, co, s):
-        wpk, bias = self.packed[name]
+        pk, bias = self.packed[name]
+        lay, wpk = pk.pick(self.dim, N, dims[0], dims[1], dims[2])
         nv.call('iunet_conv3_fwd', self.dt, self.dim, x_ptr, x_ss, y_ptr, y_ss, nv.ptr(wpk), nv.ptr(bias), None,
-                N, dims[0], dims[1], dims[2], ci, co, 2, s)
+                N, dims[0], dims[1], dims[2], ci, co, 2, lay, s)
 
     def infer(self, x, x_strides, N, D, H, W, logits=None, probs=None, cls=None, out_strides=None,
               divisor=1.0, accumulate=False, features_only=False):

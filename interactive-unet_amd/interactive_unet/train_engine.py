@@ -97,8 +97,8 @@ class TrainEngine:
                 if name == 'enc0.conv1':
                     self.pk[name] = (torch.empty(self.taps * a * b, dtype=torch.float32, device=self.dev), None)
                 else:
-                    self.pk[name] = (torch.empty(nv.pack_conv3_elems(b, a, self.taps, 0), dtype=self.T, device=self.dev),
-                                     torch.empty(nv.pack_conv3_elems(b, a, self.taps, 1), dtype=self.T, device=self.dev))
+                    self.pk[name] = (nv.PackedConv(b, a, self.taps, self.T, self.dev),
+                                     nv.PackedConv(b, a, self.taps, self.T, self.dev, dgrad=True))
         for l in range(self.levels - 2, -1, -1):
             n = self.ch[l + 1] * self.ch[l] * self.npos
             self.pk[f'dec{l}.up'] = (torch.empty(n, dtype=self.T, device=self.dev),
@@ -116,8 +116,8 @@ class TrainEngine:
                 if name == 'enc0.conv1':
                     nv.call('iunet_pack_first_conv', self.dt, nv.ptr(w), None, nv.ptr(fwd), b, a, self.taps, s)
                 else:
-                    nv.call('iunet_pack_conv3', self.dt, nv.ptr(w), None, nv.ptr(fwd), b, a, self.taps, 0, s)
-                    nv.call('iunet_pack_conv3', self.dt, nv.ptr(w), None, nv.ptr(dg), b, a, self.taps, 1, s)
+                    fwd.pack(w)
+                    dg.pack(w)
         for l in range(self.levels - 2, -1, -1):
             w = self.p(f'dec{l}.up.weight')
             fwd, dg = self.pk[f'dec{l}.up']
@@ -203,10 +203,11 @@ class TrainEngine:
             nv.call('iunet_first_conv_fwd', self.dt, self.dim, nv.ptr(x), nv.IN_DTYPE_CODE[x.dtype], nv.ll_array(xs),
                     self._P(y), co * v, nv.ptr(w), None, nv.ptr(stats), N, d[0], d[1], d[2], ci, co, 0, s)
         else:
-            w, _ = self.pk[name]
+            pk, _ = self.pk[name]
+            lay, w = pk.pick(self.dim, N, *d)
             nparts = nv.lib().iunet_conv3_num_tiles(self.dim, N, *d)
             nv.call('iunet_conv3_fwd', self.dt, self.dim, x_ptr, x_ss, self._P(y), co * v, nv.ptr(w), None,
-                    nv.ptr(stats), N, d[0], d[1], d[2], ci, co, 0, s)
+                    nv.ptr(stats), N, d[0], d[1], d[2], ci, co, 0, lay, s)
         bn = name.replace('conv', 'bn')
         nv.call('iunet_bn_finalize', nv.ptr(stats), nparts, co, float(N) * v,
                 nv.ptr(self.p(bn + '.weight')), nv.ptr(self.p(bn + '.bias')),
@@ -286,9 +287,10 @@ class TrainEngine:
         else:
             nv.call('iunet_conv3_wgrad', self.dt, self.dim, x_ptr, x_ss, self._P(dy), co * v, nv.ptr(ws['wslab']),
                     nv.ptr(gw), 1.0, N, d[0], d[1], d[2], ci, co, s)
-            _, wd = self.pk[name]
+            _, pkd = self.pk[name]
+            lay, wd = pkd.pick(self.dim, N, *d)
             nv.call('iunet_conv3_fwd', self.dt, self.dim, self._P(dy), co * v, dx_ptr, dx_ss, nv.ptr(wd), None, None,
-                    N, d[0], d[1], d[2], co, ci, 0, s)
+                    N, d[0], d[1], d[2], co, ci, 0, lay, s)
 
     def backward(self, ws, x, x_strides, y, w, tdt, N):
         L, ch, dims = self.levels, self.ch, ws['dims']

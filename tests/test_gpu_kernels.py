@@ -35,7 +35,7 @@ def unblocked(flat, N, C, sp):
     return t.permute(*perm).reshape(N, C, *sp)
 
 
-def run_conv3(nv, x, w, dtype, nd, scale=None, bias=None, epi=0, stats=False, mode=0):
+def run_conv3(nv, x, w, dtype, nd, scale=None, bias=None, epi=0, stats=False, mode=0, layout=None):
     """x [N,Cin,D,H,W] fp32 cpu, w [Cout,Cin,k..] fp32 cpu -> y [N,Cout',D,H,W] fp32 cpu."""
     dev = 'cuda'
     N, Cin = x.shape[:2]
@@ -45,10 +45,13 @@ def run_conv3(nv, x, w, dtype, nd, scale=None, bias=None, epi=0, stats=False, mo
     Co_p, Ci_p = (w.shape[0], w.shape[1]) if mode == 0 else (w.shape[1], w.shape[0])
     xb = blocked(x, dtype).to(dev)
     wd = w.contiguous().to(dev)
-    wpk = torch.empty(nv.pack_conv3_elems(w.shape[0], w.shape[1], taps, mode), dtype=dtype, device=dev)
+    if layout is None:
+        layout = nv.lib().iunet_conv3_pick_layout(nd, N, D, H, W, Ci_p, Co_p)
+    pmode = mode | (2 if layout == 1 else 0)
+    wpk = torch.empty(nv.pack_conv3_elems(w.shape[0], w.shape[1], taps, pmode), dtype=dtype, device=dev)
     sc = None if scale is None else scale.to(dev)
     nv.call('iunet_pack_conv3', nv.DTYPE_CODE[dtype], nv.ptr(wd), nv.ptr(sc), nv.ptr(wpk), w.shape[0], w.shape[1],
-            taps, mode, nv.stream())
+            taps, pmode, nv.stream())
     vox = D * H * W
     y = torch.full((N * Co_p * vox,), float('nan'), dtype=dtype, device=dev)
     bd = None if bias is None else bias.to(dev)
@@ -57,7 +60,7 @@ def run_conv3(nv, x, w, dtype, nd, scale=None, bias=None, epi=0, stats=False, mo
         nt = nv.lib().iunet_conv3_num_tiles(nd, N, D, H, W)
         st = torch.zeros(nt * Co_p * 2, dtype=torch.float32, device=dev)
     nv.call('iunet_conv3_fwd', nv.DTYPE_CODE[dtype], nd, nv.ptr(xb), Ci_p * vox, nv.ptr(y), Co_p * vox, nv.ptr(wpk),
-            nv.ptr(bd), nv.ptr(st), N, D, H, W, Ci_p, Co_p, epi, nv.stream())
+            nv.ptr(bd), nv.ptr(st), N, D, H, W, Ci_p, Co_p, epi, layout, nv.stream())
     torch.cuda.synchronize()
     out = unblocked(y.float().cpu(), N, Co_p, sp)
     if stats:
@@ -78,9 +81,10 @@ def test_conv3_exact_integers(nv, nd, shape, cin, cout):
     w = torch.randint(-1, 2, (cout, cin) + (3,) * nd, generator=g).float()
     ref = (F.conv2d if nd == 2 else F.conv3d)(x, w, padding=1)
     for dt in (torch.float16, torch.bfloat16):
-        got = run_conv3(nv, x, w, dt, nd)
-        ok = ref.abs() <= (2048 if dt == torch.float16 else 256)       # exactly representable outputs
-        assert torch.equal(got[ok], ref[ok]), (dt, (got - ref)[ok].abs().max())
+        for layout in ((0, 1) if cout % 64 == 0 else (1,)):              # both kernel structures where legal
+            got = run_conv3(nv, x, w, dt, nd, layout=layout)
+            ok = ref.abs() <= (2048 if dt == torch.float16 else 256)   # exactly representable outputs
+            assert torch.equal(got[ok], ref[ok]), (dt, layout, (got - ref)[ok].abs().max())
 
 
 @pytest.mark.parametrize('nd', [2, 3])

@@ -11,7 +11,7 @@ for cin in (32, 64):
     x = (torch.randn(cin * vox, device='cuda') * 0.5).to(torch.bfloat16)
     y = torch.empty(cout * vox, dtype=torch.bfloat16, device='cuda')
     w = torch.randn(cout, cin, 3, 3, 3, device='cuda') * 0.05
-    wpk = torch.empty(nv.pack_conv3_elems(cout, cin, taps), dtype=torch.bfloat16, device='cuda')
+    wpk = torch.empty(nv.pack_conv3_elems(cout, cin, taps, 0), dtype=torch.bfloat16, device='cuda')
     bias = torch.zeros(cout, device='cuda')
     nv.call('iunet_pack_conv3', 1, nv.ptr(w), None, nv.ptr(wpk), cout, cin, taps, 0, nv.stream())
     fl = 2.0 * taps * cin * cout * vox

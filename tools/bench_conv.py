@@ -21,6 +21,7 @@ def main():
     ap.add_argument('--wgrad', type=int, default=1)
     ap.add_argument('--only', default='', help='e.g. 0:64:32 = level:cin:cout')
     ap.add_argument('--iters', type=int, default=10)
+    ap.add_argument('--layout', type=int, default=-1, help='-1 = library policy, 0 / 1 = force a kernel structure')
     a = ap.parse_args()
     T = torch.bfloat16 if a.dtype == 'bf16' else torch.float16
     dt = nv.DTYPE_CODE[T]; nd = a.dim; taps = 3 ** nd
@@ -37,14 +38,15 @@ def main():
         x = (torch.randn(a.n * cin * vox, device='cuda') * 0.5).to(T)
         y = torch.empty(a.n * cout * vox, dtype=T, device='cuda')
         w = torch.randn(cout, cin, *([3] * nd), device='cuda') * 0.05
-        wpk = torch.empty(nv.pack_conv3_elems(cout, cin, taps), dtype=T, device='cuda')
+        lay = nv.lib().iunet_conv3_pick_layout(nd, a.n, D, S, S, cin, cout) if a.layout < 0 else a.layout
+        wpk = torch.empty(nv.pack_conv3_elems(cout, cin, taps, 2 * lay), dtype=T, device='cuda')
         bias = torch.zeros(cout, device='cuda')
-        nv.call('iunet_pack_conv3', dt, nv.ptr(w), None, nv.ptr(wpk), cout, cin, taps, 0, nv.stream())
+        nv.call('iunet_pack_conv3', dt, nv.ptr(w), None, nv.ptr(wpk), cout, cin, taps, 2 * lay, nv.stream())
         f = lambda: nv.call('iunet_conv3_fwd', dt, nd, nv.ptr(x), cin * vox, nv.ptr(y), cout * vox, nv.ptr(wpk), nv.ptr(bias), None,
-                            a.n, D, S, S, cin, cout, 2, nv.stream())
+                            a.n, D, S, S, cin, cout, 2, lay, nv.stream())
         ms = timeit(f, iters=a.iters)
         fl = 2.0 * taps * cin * cout * vox * a.n
-        line = f'L{lvl} {cin:3d}->{cout:3d} @{S}^{nd} N={a.n}: fwd {ms*1e3:8.1f} us {fl/ms/1e9:7.1f} TF/s'
+        line = f'L{lvl} {cin:3d}->{cout:3d} @{S}^{nd} N={a.n} layout {lay}: fwd {ms*1e3:8.1f} us {fl/ms/1e9:7.1f} TF/s'
         tot_f += fl; tot_t += ms
         if a.wgrad:
             dy = (torch.randn(a.n * cout * vox, device='cuda') * 0.5).to(T)
