@@ -38,7 +38,9 @@ int iunet_abi_version(void);
 long long iunet_pack_conv3_elems(int Cout, int Cin, int taps, int mode);
 int iunet_pack_conv3(int dtype, const void* w, const void* scale, void* dst, int Cout, int Cin, int taps, int mode,
                      void* stream);
-/* first conv (Cin <= 4): dst fp32 [taps][Cin][Cout], values rounded through `dtype`. */
+/* first conv (Cin <= 4) runs on MFMA with K = taps*Cin padded to 32: dst = iunet_pack_first_conv_elems
+ * elements of `dtype` in fragment order. */
+long long iunet_pack_first_conv_elems(int Cout, int Cin, int taps);
 int iunet_pack_first_conv(int dtype, const void* w, const void* scale, void* dst, int Cout, int Cin, int taps,
                           void* stream);
 /* ConvTranspose k2 s2 weights fp32 [Cin][Cout][2^d]. */
@@ -61,11 +63,11 @@ int iunet_conv3_num_tiles(int nd, int N, int D, int H, int W);
 int iunet_dbg_conv3_ablate(int exp, const void* x, void* y, const void* wpk, const void* bias, int N, int D, int H, int W,
                            int Cin, int Cout, void* stream);
 /* first conv reads the caller's tensor directly: in_dtype 0 f32, 1 f16, 2 u8 (x/255,
- * predict.py:30), 3 bf16; in_strides = element strides (n, c, d, h, w). */
+ * predict.py:30), 3 bf16; in_strides = element strides (n, c, d, h, w).  stats (optional): partial BatchNorm
+ * sums [iunet_conv3_num_tiles][Cout][2], as for iunet_conv3_fwd. */
 int iunet_first_conv_fwd(int dtype, int nd, const void* x, int in_dtype, const long long* in_strides, void* y,
                          long long y_sstride, const void* w, const void* bias, void* stats, int N, int D, int H, int W,
                          int Cin, int Cout, int relu, void* stream);
-int iunet_first_conv_num_blocks(int N, int D, int H, int W);
 int iunet_maxpool_fwd(int dtype, int nd, const void* x, long long x_ss, void* y, long long y_ss, int C, int N, int Do,
                       int Ho, int Wo, void* stream);
 int iunet_convT_fwd(int dtype, int nd, const void* x, long long x_ss, void* y, long long y_ss, const void* wpk,
@@ -98,12 +100,14 @@ int iunet_bn_finalize(const void* slab, int nparts, int C, double count, const v
                       void* mean, void* invstd, void* stream);
 int iunet_bn_relu_fwd(int dtype, const void* y, long long y_ss, void* z, long long z_ss, const void* scale,
                       const void* shift, int C, int N, long long vox, void* stream);
-/* backward of z = relu(bn(y)): dy, dgamma, dbeta from dz, z, y.  slab: iunet_bn_bwd_num_parts*C*2 floats,
- * coef: 3*C floats of scratch. */
+/* backward of z = relu(bn(y)): dy, dgamma, dbeta from dz, y (and z; z may be NULL: the ReLU mask is then
+ * recomputed from y with scale / shift, one tensor read less per pass).  slab: iunet_bn_bwd_num_parts*C*2
+ * floats, coef: 3*C floats of scratch. */
 int iunet_bn_bwd_num_parts(int N, long long vox);
 int iunet_bn_relu_bwd(int dtype, const void* dz, long long dz_ss, const void* z, long long z_ss, const void* y,
                       long long y_ss, void* dy, long long dy_ss, const void* mean, const void* invstd, const void* gamma,
-                      void* dgamma, void* dbeta, void* slab, void* coef, int C, int N, long long vox, void* stream);
+                      const void* scale, const void* shift, void* dgamma, void* dbeta, void* slab, void* coef, int C, int N,
+                      long long vox, void* stream);
 /* dz = (add_skip ? dz : 0) + max-pool backward of dpool (first maximum gets the gradient), in place. */
 int iunet_maxpool_bwd(int dtype, int nd, const void* z, long long z_ss, const void* dpool, long long dp_ss, void* dz,
                       long long dz_ss, int add_skip, int C, int N, int Do, int Ho, int Wo, void* stream);

@@ -26,10 +26,11 @@ int iunet_conv3_exp_launch(int exp, const void* x, void* y, const void* wpk, con
 int iunet_pack_conv3_launch(int dtype, const float* w, const float* scale, void* dst, int Cout, int Cin, int taps,
                             int mode, hipStream_t stream);
 int iunet_first_conv_launch(int dtype, int nd, const void* x, int in_dtype, long long sN, long long sC, long long sD,
-                            long long sH, long long sW, void* y, long long y_sstride, const float* w,
+                            long long sH, long long sW, void* y, long long y_sstride, const void* w,
                             const float* bias, float* stats, int N, int D, int H, int W, int Cin, int Cout, int relu,
                             hipStream_t stream);
-int iunet_first_conv_blocks(int N, int D, int H, int W);
+int iunet_pack_first_conv_launch(int dtype, const float* w, const float* scale, void* dst, int Cout, int Cin, int taps,
+                                 hipStream_t stream);
 int iunet_maxpool_launch(int dtype, int nd, const void* x, long long x_ss, void* y, long long y_ss, int planes, int N,
                          int Do, int Ho, int Wo, hipStream_t stream);
 int iunet_convT_launch(int dtype, int nd, const void* x, long long x_ss, void* y, long long y_ss, const void* wpk,
@@ -40,21 +41,6 @@ int iunet_head_launch(int dtype, const void* x, long long x_ss, int C0, const fl
                       long long oH, long long oW, float divisor, int accumulate, int N, int D, int H, int W,
                       hipStream_t stream);
 
-namespace {
-template <typename T>
-__global__ void pack_first_kernel(const float* __restrict__ w, const float* __restrict__ scale, float* __restrict__ dst,
-                                  int Cout, int Cin, int taps) {
-  const int total = Cout * Cin * taps;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    const int co = i % Cout, r = i / Cout;
-    const int ci = r % Cin, t = r / Cin;
-    float v = w[(co * Cin + ci) * taps + t];
-    if (scale) v *= scale[co];
-    dst[i] = to_f32<T>(from_f32<T>(v));
-  }
-}
-}  // namespace
-
 #define DT_OK(dt) IUNET_REQUIRE((dt) == 0 || (dt) == 1, "dtype must be 0 (f16) or 1 (bf16), got %d", (dt))
 
 extern "C" {
@@ -63,7 +49,6 @@ const char* iunet_last_error(void) { return g_err; }
 int iunet_abi_version(void) { return 1; }
 
 int iunet_conv3_num_tiles(int nd, int N, int D, int H, int W) { return iunet_conv3_tiles(nd, N, D, H, W); }
-int iunet_first_conv_num_blocks(int N, int D, int H, int W) { return iunet_first_conv_blocks(N, D, H, W); }
 
 long long iunet_pack_conv3_elems(int Cout, int Cin, int taps, int mode) { return iunet_pack_conv3_size(Cout, Cin, taps, mode); }
 
@@ -79,12 +64,11 @@ int iunet_pack_first_conv(int dtype, const void* w, const void* scale, void* dst
                           void* stream) {
   DT_OK(dtype);
   IUNET_REQUIRE(w && dst, "pack_first_conv: null pointer");
-  const int total = Cout * Cin * taps;
-  if (dtype == 0) hipLaunchKernelGGL(pack_first_kernel<f16>, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)w, (const float*)scale, (float*)dst, Cout, Cin, taps);
-  else hipLaunchKernelGGL(pack_first_kernel<bf16>, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)w, (const float*)scale, (float*)dst, Cout, Cin, taps);
-  IUNET_CHECK_HIP(hipGetLastError());
-  return IUNET_OK;
+  IUNET_REQUIRE(Cout % 32 == 0 && Cin >= 1 && Cin <= 4, "pack_first_conv: Cout multiple of 32, Cin 1..4");
+  return iunet_pack_first_conv_launch(dtype, (const float*)w, (const float*)scale, dst, Cout, Cin, taps, (hipStream_t)stream);
 }
+
+long long iunet_pack_first_conv_elems(int Cout, int Cin, int taps) { return (long long)Cout * (((taps * Cin + 31) / 32) * 32); }
 
 int iunet_pack_convT(int dtype, const void* w, void* dst, int Cin, int Cout, int npos, void* stream) {
   DT_OK(dtype);
@@ -125,7 +109,7 @@ int iunet_first_conv_fwd(int dtype, int nd, const void* x, int in_dtype, const l
   IUNET_REQUIRE(nd == 2 || nd == 3, "first_conv: nd must be 2 or 3");
   IUNET_REQUIRE(nd == 3 || D == 1, "first_conv: 2-D needs D == 1");
   return iunet_first_conv_launch(dtype, nd, x, in_dtype, in_strides[0], in_strides[1], in_strides[2], in_strides[3],
-                                 in_strides[4], y, y_sstride, (const float*)w, (const float*)bias, (float*)stats, N, D,
+                                 in_strides[4], y, y_sstride, w, (const float*)bias, (float*)stats, N, D,
                                  H, W, Cin, Cout, relu, (hipStream_t)stream);
 }
 

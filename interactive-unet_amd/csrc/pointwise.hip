@@ -13,9 +13,9 @@ struct FirstConvParams {
   long long sN, sC, sD, sH, sW;
   int in_dtype;        // 0 f32, 1 f16, 2 u8 (scaled by 1/255), 3 bf16
   void* y; long long y_sstride;
-  const float* w;      // [taps][Cin][Cout] fp32 (already rounded to the activation dtype)
+  const void* w;       // packed weights [cob32][kstep][2][64][8] of T (iunet_pack_first_conv)
   const float* bias;   // [Cout] or null
-  float* stats;        // [nblocks][Cout][2] or null
+  float* stats;        // [ntiles][Cout][2] or null (ntiles = iunet_conv3_num_tiles)
   int N, D, H, W, Cin, Cout, nd, relu;
 };
 
@@ -28,69 +28,131 @@ __device__ __forceinline__ float load_in(const void* p, long long off, int dt) {
   }
 }
 
+// First conv on the matrix cores: K = taps * Cin (27..108) padded to a multiple of 32; the im2col
+// operand is gathered per lane from a 16-bit LDS image of the halo tile (8 scalar reads feed one
+// k-quad), the packed weights live in registers.  The kernel is bound by its 64 B/voxel output.
 template <typename T, int ND, int CIN>
 __global__ __launch_bounds__(256) void first_conv_kernel(FirstConvParams p) {
-  constexpr int KD = ND == 3 ? 3 : 1;
-  constexpr int TAPS = KD * 9;
   using V8 = typename Vec8<T>::type;
-  const long long vox = (long long)p.D * p.H * p.W;
-  const long long v = (long long)blockIdx.x * 256 + threadIdx.x;
-  const int n = blockIdx.y;
-  const bool ok = v < vox;
-  const long long vv = ok ? v : vox - 1;
-  const int gx = (int)(vv % p.W);
-  const int gy = (int)((vv / p.W) % p.H);
-  const int gz = (int)(vv / ((long long)p.W * p.H));
-
-  float win[TAPS * CIN];
-#pragma unroll
-  for (int t = 0; t < TAPS; ++t) {
-    const int dz = ND == 3 ? t / 9 - 1 : 0, dy = (t / 3) % 3 - 1, dx = t % 3 - 1;
-    const int z = gz + dz, y = gy + dy, x = gx + dx;
-    const bool in = (unsigned)z < (unsigned)p.D && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
-#pragma unroll
-    for (int c = 0; c < CIN; ++c) {
-      float val = 0.f;
-      if (in) val = load_in(p.x, n * p.sN + c * p.sC + z * p.sD + y * p.sH + x * p.sW, p.in_dtype);
-      win[t * CIN + c] = to_f32<T>(from_f32<T>(val));   // activations live in T
-    }
+  constexpr int TZ = ND == 3 ? 4 : 1, TY = ND == 3 ? 8 : 16, TX = ND == 3 ? 16 : 32, PADZ = ND == 3 ? 1 : 0;
+  constexpr int PZ = TZ + 2 * PADZ, PY = TY + 2, PX = TX + 2, NPIX = PZ * PY * PX;
+  constexpr int TAPS = ND == 3 ? 27 : 9, KK = TAPS * CIN, KS = (KK + 31) / 32;
+  constexpr int FX = TX / 16, NI = 8;
+  __shared__ T xs[CIN * NPIX];
+  __shared__ float red[4 * 4 * 8 * 2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, q = lane >> 4;
+  const int tilesZ = (p.D + TZ - 1) / TZ, tilesY = (p.H + TY - 1) / TY, tilesX = (p.W + TX - 1) / TX;
+  const int tps = tilesZ * tilesY * tilesX;
+  const int tile = blockIdx.x, n = tile / tps;
+  int trem = tile - n * tps;
+  const int tz_i = trem / (tilesY * tilesX);
+  trem -= tz_i * tilesY * tilesX;
+  const int ty_i = trem / tilesX, tx_i = trem - ty_i * tilesX;
+  const int z0 = tz_i * TZ, y0 = ty_i * TY, x0 = tx_i * TX;
+  const int cob = blockIdx.y;
+  // ---- stage the halo tile (caller's layout and dtype, rounded to T) ----
+  for (int it = tid; it < NPIX * CIN; it += 256) {
+    const int c = it / NPIX, pix = it - c * NPIX;
+    const int px = pix % PX, t2 = pix / PX, py = t2 % PY, pz = t2 / PY;
+    const int gz = z0 + pz - PADZ, gy = y0 + py - 1, gx = x0 + px - 1;
+    float v = 0.f;
+    if ((unsigned)gz < (unsigned)p.D && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W)
+      v = load_in(p.x, n * p.sN + c * p.sC + gz * p.sD + gy * p.sH + gx * p.sW, p.in_dtype);
+    xs[it] = from_f32<T>(v);
   }
-  T* yout = (T*)p.y + (long long)n * p.y_sstride;
-  const long long plane_stride = vox * 8;
-  __shared__ float red[4][16];
-  for (int cb = 0; cb < p.Cout / 8; ++cb) {
-    float acc[8];
+  // ---- weights: [cob][kstep][2][64][8] ----
+  V8 a[KS][2];
+  const V8* wp = (const V8*)p.w + (long long)cob * KS * 2 * 64 + lane;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  for (int ks = 0; ks < KS; ++ks) { a[ks][0] = wp[(ks * 2 + 0) * 64]; a[ks][1] = wp[(ks * 2 + 1) * 64]; }
+  // per-lane LDS element offsets of the 8 k entries of its k-quad (k = 32 ks + 8 q + j -> tap, channel)
+  int koff[KS][8];
 #pragma unroll
-    for (int k = 0; k < TAPS * CIN; ++k) {
-      const float* wk = p.w + (long long)k * p.Cout + cb * 8;   // wave-uniform -> scalar loads
+  for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] = fmaf(win[k], wk[j], acc[j]);
+    for (int j = 0; j < 8; ++j) {
+      const int k = 32 * ks + 8 * q + j;
+      const int kc = k < KK ? k : 0;                  // padded k: zero weight, any valid address
+      const int tap = kc / CIN, c = kc % CIN;
+      const int dz = ND == 3 ? tap / 9 : 0, dy = (tap / 3) % 3, dx = tap % 3;
+      koff[ks][j] = c * NPIX + (dz * PY + dy) * PX + dx;
     }
-    if (p.stats) {
-      // per-channel partial sums of the raw conv output over this block's voxels (one barrier per 8 channels)
-      const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-      __syncthreads();
+  __syncthreads();
+  T* yout = (T*)p.y + (long long)n * p.y_sstride;
+  const long long plane_stride = (long long)p.D * p.H * p.W * 8;
+  float bias[8], s_sum[8], s_sq[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float s = wave_sum(ok ? acc[j] : 0.f), s2 = wave_sum(ok ? acc[j] * acc[j] : 0.f);
-        if (lane == 0) { red[wv][2 * j] = s; red[wv][2 * j + 1] = s2; }
-      }
-      __syncthreads();
-      if (threadIdx.x < 16)
-        p.stats[(((long long)n * gridDim.x + blockIdx.x) * p.Cout + cb * 8) * 2 + threadIdx.x] =
-            red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+  for (int j = 0; j < 8; ++j) { bias[j] = p.bias ? p.bias[cob * 32 + 8 * q + j] : 0.f; s_sum[j] = 0.f; s_sq[j] = 0.f; }
+#pragma unroll
+  for (int nf = 0; nf < NI; ++nf) {
+    const int f = wave * NI + nf;
+    const int xh = f % FX, row = f / FX, fy = row % TY, fz = row / TY;
+    const int base = (fz * PY + fy) * PX + xh * 16 + l15;
+    f32x4 acc0 = f32x4{0, 0, 0, 0}, acc1 = f32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      V8 b;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) b[j] = xs[base + koff[ks][j]];
+      acc0 = mfma16<T>(a[ks][0], b, acc0);
+      acc1 = mfma16<T>(a[ks][1], b, acc1);
+    }
+    const int gz = z0 + fz, gy = y0 + fy, gx = x0 + xh * 16 + l15;
+    const bool ok = gz < p.D && gy < p.H && gx < p.W;
+    float vals[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { vals[j] = acc0[j]; vals[4 + j] = acc1[j]; }
+    if (p.stats && ok) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { s_sum[j] += vals[j]; s_sq[j] += vals[j] * vals[j]; }
     }
     V8 o;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      float r = acc[j];
-      if (p.bias) r += p.bias[cb * 8 + j];
+      float r = vals[j] + bias[j];
       if (p.relu) r = fmaxf(r, 0.f);
       o[j] = from_f32<T>(r);
     }
-    if (ok) *(V8*)(yout + cb * plane_stride + v * 8) = o;
+    if (ok) *(V8*)(yout + (long long)(cob * 4 + q) * plane_stride + (((long long)gz * p.H + gy) * p.W + gx) * 8) = o;
+  }
+  if (p.stats) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float s1 = s_sum[j], s2 = s_sq[j];
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+      if (l15 == 0) { red[((wave * 4 + q) * 8 + j) * 2] = s1; red[((wave * 4 + q) * 8 + j) * 2 + 1] = s2; }
+    }
+    __syncthreads();
+    if (tid < 64) {
+      const int c = tid >> 1, which = tid & 1;
+      float sum = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) sum += red[((w * 4 + (c >> 3)) * 8 + (c & 7)) * 2 + which];
+      p.stats[((long long)tile * p.Cout + cob * 32 + c) * 2 + which] = sum;
+    }
+  }
+}
+
+// fp32 [Cout][Cin][taps] (x optional per-cout scale) -> [cob32][kstep][2][64][8] of T, k = tap * Cin + c
+template <typename T>
+__global__ void pack_first_conv_kernel(const float* __restrict__ w, const float* __restrict__ scale, T* __restrict__ dst,
+                                       int Cout, int Cin, int taps) {
+  const int KK = taps * Cin, KS = (KK + 31) / 32;
+  const int total = (Cout / 32) * KS * 2 * 64 * 8;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    int r = i;
+    const int j = r & 7; r >>= 3;
+    const int lane = r & 63; r >>= 6;
+    const int t = r & 1; r >>= 1;
+    const int ks = r % KS;
+    const int cob = r / KS;
+    const int row = lane & 15, qq = lane >> 4;
+    const int co = cob * 32 + 8 * (row >> 2) + 4 * t + (row & 3);
+    const int k = 32 * ks + 8 * qq + j;
+    float v = 0.f;
+    if (k < KK) { v = w[(co * Cin + k % Cin) * taps + k / Cin]; if (scale) v *= scale[co]; }
+    dst[i] = from_f32<T>(v);
   }
 }
 
@@ -282,17 +344,17 @@ __global__ __launch_bounds__(256) void head_kernel(HeadParams p) {
 
 // ------------------------------------------------------------------ host launchers
 int iunet_first_conv_launch(int dtype, int nd, const void* x, int in_dtype, long long sN, long long sC, long long sD,
-                            long long sH, long long sW, void* y, long long y_sstride, const float* w,
+                            long long sH, long long sW, void* y, long long y_sstride, const void* w,
                             const float* bias, float* stats, int N, int D, int H, int W, int Cin, int Cout, int relu,
                             hipStream_t stream) {
   IUNET_REQUIRE(Cin >= 1 && Cin <= 4, "first_conv: Cin must be 1..4 (got %d)", Cin);
-  IUNET_REQUIRE(Cout % 8 == 0, "first_conv: Cout must be a multiple of 8 (got %d)", Cout);
+  IUNET_REQUIRE(Cout % 32 == 0, "first_conv: Cout must be a multiple of 32 (got %d)", Cout);
   FirstConvParams p;
   p.x = x; p.sN = sN; p.sC = sC; p.sD = sD; p.sH = sH; p.sW = sW; p.in_dtype = in_dtype;
   p.y = y; p.y_sstride = y_sstride; p.w = w; p.bias = bias; p.stats = stats;
   p.N = N; p.D = D; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.nd = nd; p.relu = relu;
-  const long long vox = (long long)D * H * W;
-  dim3 grid((unsigned)((vox + 255) / 256), N);
+  const int TZ = nd == 3 ? 4 : 1, TY = nd == 3 ? 8 : 16, TX = nd == 3 ? 16 : 32;
+  dim3 grid(N * ((D + TZ - 1) / TZ) * ((H + TY - 1) / TY) * ((W + TX - 1) / TX), Cout / 32);
 #define IUNET_FC(TT, NDV, CI) hipLaunchKernelGGL((first_conv_kernel<TT, NDV, CI>), grid, dim3(256), 0, stream, p)
 #define IUNET_FC_CIN(TT, NDV)                                              \
   switch (Cin) { case 1: IUNET_FC(TT, NDV, 1); break; case 2: IUNET_FC(TT, NDV, 2); break; \
@@ -305,7 +367,14 @@ int iunet_first_conv_launch(int dtype, int nd, const void* x, int in_dtype, long
   return IUNET_OK;
 }
 
-int iunet_first_conv_blocks(int N, int D, int H, int W) { return N * (int)(((long long)D * H * W + 255) / 256); }
+int iunet_pack_first_conv_launch(int dtype, const float* w, const float* scale, void* dst, int Cout, int Cin, int taps,
+                                 hipStream_t stream) {
+  const int total = Cout * (((taps * Cin + 31) / 32) * 32);
+  if (dtype == 0) hipLaunchKernelGGL(pack_first_conv_kernel<f16>, dim3((total + 255) / 256), dim3(256), 0, stream, w, scale, (f16*)dst, Cout, Cin, taps);
+  else hipLaunchKernelGGL(pack_first_conv_kernel<bf16>, dim3((total + 255) / 256), dim3(256), 0, stream, w, scale, (bf16*)dst, Cout, Cin, taps);
+  IUNET_CHECK_HIP(hipGetLastError());
+  return IUNET_OK;
+}
 
 int iunet_maxpool_launch(int dtype, int nd, const void* x, long long x_ss, void* y, long long y_ss, int planes, int N,
                          int Do, int Ho, int Wo, hipStream_t stream) {

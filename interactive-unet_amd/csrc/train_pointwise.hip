@@ -92,18 +92,28 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
                                                             const T* __restrict__ z, long long z_ss,
                                                             const T* __restrict__ y, long long y_ss,
                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                            const float* __restrict__ scale, const float* __restrict__ shift,
                                                             int C, long long vox, int per_block, float* __restrict__ slab) {
   const int pl = blockIdx.y, n = blockIdx.z;
   const long long v0 = (long long)blockIdx.x * per_block;
   const long long v1 = min(v0 + per_block, vox);
-  float s1[8], s2[8], mu[8], is[8];
+  // the ReLU mask (z > 0) is recomputed from y when z is not given: one tensor read less per pass
+  float s1[8], s2[8], mu[8], is[8], sc[8], sh[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; mu[j] = mean[pl * 8 + j]; is[j] = invstd[pl * 8 + j]; }
+  for (int j = 0; j < 8; ++j) {
+    s1[j] = 0.f; s2[j] = 0.f; mu[j] = mean[pl * 8 + j]; is[j] = invstd[pl * 8 + j];
+    sc[j] = scale[pl * 8 + j]; sh[j] = shift[pl * 8 + j];
+  }
   const long long po = (long long)pl * vox * 8;
   for (long long v = v0 + threadIdx.x; v < v1; v += 256) {
     const V8T<T> g = *(const V8T<T>*)(dz + n * dz_ss + po + v * 8);
-    const V8T<T> zz = *(const V8T<T>*)(z + n * z_ss + po + v * 8);
     const V8T<T> yy = *(const V8T<T>*)(y + n * y_ss + po + v * 8);
+    V8T<T> zz;
+    if (z) zz = *(const V8T<T>*)(z + n * z_ss + po + v * 8);
+    else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) zz[j] = from_f32<T>(fmaf(sc[j], to_f32<T>(yy[j]), sh[j]));
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float d = to_f32<T>(zz[j]) > 0.f ? to_f32<T>(g[j]) : 0.f;
@@ -151,14 +161,20 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            long long z_ss, const T* __restrict__ y, long long y_ss,
                                                            T* __restrict__ dy, long long dy_ss, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ coef,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift,
                                                            int planes, long long vox) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= vox * planes) return;
   const int n = blockIdx.y;
   const int pl = (int)(i / vox);
   const V8T<T> g = *(const V8T<T>*)(dz + n * dz_ss + i * 8);
-  const V8T<T> zz = *(const V8T<T>*)(z + n * z_ss + i * 8);
   const V8T<T> yy = *(const V8T<T>*)(y + n * y_ss + i * 8);
+  V8T<T> zz;
+  if (z) zz = *(const V8T<T>*)(z + n * z_ss + i * 8);
+  else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) zz[j] = from_f32<T>(fmaf(scale[pl * 8 + j], to_f32<T>(yy[j]), shift[pl * 8 + j]));
+  }
   V8T<T> o;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -520,20 +536,21 @@ int iunet_bn_bwd_num_parts(int N, long long vox) {
 
 int iunet_bn_relu_bwd(int dtype, const void* dz, long long dz_ss, const void* z, long long z_ss, const void* y,
                       long long y_ss, void* dy, long long dy_ss, const void* mean, const void* invstd, const void* gamma,
-                      void* dgamma, void* dbeta, void* slab, void* coef, int C, int N, long long vox, void* stream) {
+                      const void* scale, const void* shift, void* dgamma, void* dbeta, void* slab, void* coef, int C, int N,
+                      long long vox, void* stream) {
   DT_OK(dtype);
-  IUNET_REQUIRE(dz && z && y && dy && slab && coef, "bn_relu_bwd: null pointer");
+  IUNET_REQUIRE(dz && y && dy && slab && coef && scale && shift, "bn_relu_bwd: null pointer");
   const int per_block = 16384;
   const int chunks = (int)((vox + per_block - 1) / per_block);
   dim3 g1(chunks, C / 8, N);
-  if (dtype == 0) hipLaunchKernelGGL(bn_bwd_reduce_kernel<f16>, g1, dim3(256), 0, (hipStream_t)stream, (const f16*)dz, dz_ss, (const f16*)z, z_ss, (const f16*)y, y_ss, (const float*)mean, (const float*)invstd, C, vox, per_block, (float*)slab);
-  else hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16>, g1, dim3(256), 0, (hipStream_t)stream, (const bf16*)dz, dz_ss, (const bf16*)z, z_ss, (const bf16*)y, y_ss, (const float*)mean, (const float*)invstd, C, vox, per_block, (float*)slab);
+  if (dtype == 0) hipLaunchKernelGGL(bn_bwd_reduce_kernel<f16>, g1, dim3(256), 0, (hipStream_t)stream, (const f16*)dz, dz_ss, (const f16*)z, z_ss, (const f16*)y, y_ss, (const float*)mean, (const float*)invstd, (const float*)scale, (const float*)shift, C, vox, per_block, (float*)slab);
+  else hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16>, g1, dim3(256), 0, (hipStream_t)stream, (const bf16*)dz, dz_ss, (const bf16*)z, z_ss, (const bf16*)y, y_ss, (const float*)mean, (const float*)invstd, (const float*)scale, (const float*)shift, C, vox, per_block, (float*)slab);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, (const float*)slab, chunks * N, C,
                      (double)N * (double)vox, (const float*)gamma, (const float*)invstd, (float*)dgamma, (float*)dbeta, (float*)coef);
   const long long total = vox * (C / 8);
   dim3 g2((unsigned)((total + 255) / 256), N);
-  if (dtype == 0) hipLaunchKernelGGL(bn_bwd_apply_kernel<f16>, g2, dim3(256), 0, (hipStream_t)stream, (const f16*)dz, dz_ss, (const f16*)z, z_ss, (const f16*)y, y_ss, (f16*)dy, dy_ss, (const float*)mean, (const float*)invstd, (const float*)coef, C / 8, vox);
-  else hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16>, g2, dim3(256), 0, (hipStream_t)stream, (const bf16*)dz, dz_ss, (const bf16*)z, z_ss, (const bf16*)y, y_ss, (bf16*)dy, dy_ss, (const float*)mean, (const float*)invstd, (const float*)coef, C / 8, vox);
+  if (dtype == 0) hipLaunchKernelGGL(bn_bwd_apply_kernel<f16>, g2, dim3(256), 0, (hipStream_t)stream, (const f16*)dz, dz_ss, (const f16*)z, z_ss, (const f16*)y, y_ss, (f16*)dy, dy_ss, (const float*)mean, (const float*)invstd, (const float*)coef, (const float*)scale, (const float*)shift, C / 8, vox);
+  else hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16>, g2, dim3(256), 0, (hipStream_t)stream, (const bf16*)dz, dz_ss, (const bf16*)z, z_ss, (const bf16*)y, y_ss, (bf16*)dy, dy_ss, (const float*)mean, (const float*)invstd, (const float*)coef, (const float*)scale, (const float*)shift, C / 8, vox);
   IUNET_CHECK_HIP(hipGetLastError());
   return IUNET_OK;
 }

@@ -20,7 +20,6 @@ c_void_p, c_int, c_ll, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlon
 _SIGS = {
     'iunet_abi_version': [],
     'iunet_conv3_num_tiles': [c_int] * 5,
-    'iunet_first_conv_num_blocks': [c_int] * 4,
     'iunet_dbg_conv3_ablate': [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     'iunet_pack_conv3': [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     'iunet_pack_first_conv': [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
@@ -46,7 +45,7 @@ _SIGS = {
     'iunet_bn_relu_fwd': [c_int, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_void_p, c_int, c_int, c_ll, c_void_p],
     'iunet_bn_bwd_num_parts': [c_int, c_ll],
     'iunet_bn_relu_bwd': [c_int, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_void_p,
-                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_ll, c_void_p],
+                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_ll, c_void_p],
     'iunet_maxpool_bwd': [c_int, c_int, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_ll, c_int, c_int, c_int, c_int,
                           c_int, c_int, c_void_p],
     'iunet_head_loss_num_parts': [c_int, c_ll],
@@ -72,7 +71,8 @@ _SIGS = {
                                c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
 }
 # functions that return a size / count instead of a status
-_LL_RETURN = {'iunet_conv3_wgrad_slab_floats': [c_int] * 7, 'iunet_pack_conv3_elems': [c_int] * 4}
+_LL_RETURN = {'iunet_conv3_wgrad_slab_floats': [c_int] * 7, 'iunet_pack_conv3_elems': [c_int] * 4,
+              'iunet_pack_first_conv_elems': [c_int] * 3}
 
 
 class NativeError(RuntimeError):

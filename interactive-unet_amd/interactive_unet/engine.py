@@ -76,7 +76,8 @@ class Engine:
                 bias = (be - mu * scale).contiguous()
                 keep += [w, scale]
                 if prefix == 'enc0' and j == 1:
-                    dst = torch.empty(self.taps * a * b, dtype=torch.float32, device=self.device)
+                    dst = torch.empty(nv.lib().iunet_pack_first_conv_elems(b, a, self.taps), dtype=self.act_dtype,
+                                      device=self.device)
                     nv.call('iunet_pack_first_conv', self.dt, nv.ptr(w), nv.ptr(scale), nv.ptr(dst), b, a, self.taps, s)
                 else:
                     dst = nv.PackedConv(b, a, self.taps, self.act_dtype, self.device)

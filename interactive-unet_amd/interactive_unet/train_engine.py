@@ -95,7 +95,8 @@ class TrainEngine:
             for j, (a, b) in enumerate(((ci, co), (co, co)), 1):
                 name = f'{prefix}.conv{j}'
                 if name == 'enc0.conv1':
-                    self.pk[name] = (torch.empty(self.taps * a * b, dtype=torch.float32, device=self.dev), None)
+                    self.pk[name] = (torch.empty(nv.lib().iunet_pack_first_conv_elems(b, a, self.taps), dtype=self.T,
+                                                 device=self.dev), None)
                 else:
                     self.pk[name] = (nv.PackedConv(b, a, self.taps, self.T, self.dev),
                                      nv.PackedConv(b, a, self.taps, self.T, self.dev, dgrad=True))
@@ -154,7 +155,7 @@ class TrainEngine:
                 for k in ('scale', 'shift', 'mean', 'invstd'):
                     ws[f'{k}.{name}'] = f32(b)
                 if name == 'enc0.conv1':
-                    max_stats = max(max_stats, lib.iunet_first_conv_num_blocks(N, *d) * b * 2)
+                    max_stats = max(max_stats, lib.iunet_conv3_num_tiles(self.dim, N, *d) * b * 2)
                     max_wslab = max(max_wslab, lib.iunet_first_conv_wgrad_tiles(self.dim, N, *d) * b * a * self.taps)
                 else:
                     max_stats = max(max_stats, lib.iunet_conv3_num_tiles(self.dim, N, *d) * b * 2)
@@ -199,7 +200,7 @@ class TrainEngine:
         if name == 'enc0.conv1':
             x, xs = x_raw
             w, _ = self.pk[name]
-            nparts = nv.lib().iunet_first_conv_num_blocks(N, *d)
+            nparts = nv.lib().iunet_conv3_num_tiles(self.dim, N, *d)
             nv.call('iunet_first_conv_fwd', self.dt, self.dim, nv.ptr(x), nv.IN_DTYPE_CODE[x.dtype], nv.ll_array(xs),
                     self._P(y), co * v, nv.ptr(w), None, nv.ptr(stats), N, d[0], d[1], d[2], ci, co, 0, s)
         else:
@@ -273,9 +274,11 @@ class TrainEngine:
         s = nv.stream()
         bn = name.replace('conv', 'bn')
         dy = ws['dy']
-        nv.call('iunet_bn_relu_bwd', self.dt, dz_ptr, dz_ss, z_ptr, z_ss, self._P(ws['y.' + name]), co * v,
+        # z is not passed: the ReLU mask is recomputed from y (saves one tensor read in each of the two passes)
+        nv.call('iunet_bn_relu_bwd', self.dt, dz_ptr, dz_ss, None, z_ss, self._P(ws['y.' + name]), co * v,
                 self._P(dy), co * v, nv.ptr(ws['mean.' + name]), nv.ptr(ws['invstd.' + name]),
-                nv.ptr(self.p(bn + '.weight')), nv.ptr(self.g(bn + '.weight')), nv.ptr(self.g(bn + '.bias')),
+                nv.ptr(self.p(bn + '.weight')), nv.ptr(ws['scale.' + name]), nv.ptr(ws['shift.' + name]),
+                nv.ptr(self.g(bn + '.weight')), nv.ptr(self.g(bn + '.bias')),
                 nv.ptr(ws['bnslab']), nv.ptr(ws['bncoef']), co, N, v, s)
         gw = self.g(name + '.weight')
         if name == 'enc0.conv1':

@@ -144,12 +144,12 @@ def test_first_conv(nv, nd, in_dtype):
     dev = 'cuda'
     xd = xi.to(dev)
     wd, sd, bd = w.to(dev), scale.to(dev), bias.to(dev)
-    wp = torch.empty(taps * cin * cout, dtype=torch.float32, device=dev)
+    wp = torch.empty(nv.lib().iunet_pack_first_conv_elems(cout, cin, taps), dtype=torch.float16, device=dev)
     nv.call('iunet_pack_first_conv', 0, nv.ptr(wd), nv.ptr(sd), nv.ptr(wp), cout, cin, taps, nv.stream())
     D, H, W = shape if nd == 3 else (1,) + shape
     vox = D * H * W
     y = torch.empty(N * cout * vox, dtype=torch.float16, device=dev)
-    nb = nv.lib().iunet_first_conv_num_blocks(N, D, H, W)
+    nb = nv.lib().iunet_conv3_num_tiles(nd, N, D, H, W)
     st = torch.zeros(nb * cout * 2, dtype=torch.float32, device=dev)
     strides = (cin * vox, vox, H * W, W, 1)
     nv.call('iunet_first_conv_fwd', 0, nd, nv.ptr(xd), nv.IN_DTYPE_CODE[in_dtype], nv.ll_array(strides), nv.ptr(y),

@@ -82,10 +82,16 @@ def test_bn_relu_fwd_bwd(nv, nd):
     npart = nv.lib().iunet_bn_bwd_num_parts(N, vox)
     bslab = torch.empty(npart * C * 2, device=dev)
     coef = torch.empty(3 * C, device=dev)
+    dy2 = torch.empty_like(yb)
     nv.call('iunet_bn_relu_bwd', 0, nv.ptr(dzb), C * vox, nv.ptr(z), C * vox, nv.ptr(yb), C * vox, nv.ptr(dy), C * vox,
-            nv.ptr(mean), nv.ptr(invstd), nv.ptr(gd), nv.ptr(dgamma), nv.ptr(dbeta), nv.ptr(bslab), nv.ptr(coef), C, N,
-            vox, nv.stream())
+            nv.ptr(mean), nv.ptr(invstd), nv.ptr(gd), nv.ptr(scale), nv.ptr(shift), nv.ptr(dgamma), nv.ptr(dbeta),
+            nv.ptr(bslab), nv.ptr(coef), C, N, vox, nv.stream())
+    # same without z: the mask is recomputed from y -> identical result
+    nv.call('iunet_bn_relu_bwd', 0, nv.ptr(dzb), C * vox, None, C * vox, nv.ptr(yb), C * vox, nv.ptr(dy2), C * vox,
+            nv.ptr(mean), nv.ptr(invstd), nv.ptr(gd), nv.ptr(scale), nv.ptr(shift), nv.ptr(dgamma), nv.ptr(dbeta),
+            nv.ptr(bslab), nv.ptr(coef), C, N, vox, nv.stream())
     torch.cuda.synchronize()
+    assert torch.equal(dy, dy2)
     mask_diff = ((zc > 0) != (z_ref.detach() > 0)).float().mean().item()
     assert mask_diff < 1e-3
     dyc = unblocked(dy.float().cpu(), N, C, shape)
