@@ -136,9 +136,10 @@ int iunet_conv3_wgrad(int dtype, int nd, const void* x, long long x_ss, const vo
 int iunet_pack_convT_dgrad(int dtype, const void* w, void* dst, int Cin, int Cout, int npos, void* stream);
 int iunet_convT_dgrad(int dtype, int nd, const void* dy, long long dy_ss, void* dx, long long dx_ss, const void* wpk,
                       int N, int D, int H, int W, int Cin, int Cout, void* stream);
-int iunet_convT_wgrad_blocks(int N, int D, int H, int W);
+/* dW fp32 [Cin][Cout][2^d] and db fp32 [Cout] on MFMA; wslab: blocks*Cin*Cout*2^d floats, bslab: blocks*Cout floats. */
+int iunet_convT_wgrad_blocks(int nd, int N, int D, int H, int W, int Cin, int Cout);
 int iunet_convT_wgrad(int dtype, int nd, const void* x, long long x_ss, const void* dy, long long dy_ss, void* wslab,
-                      void* bslab, int N, int D, int H, int W, int Cin, int Cout, void* stream);
+                      void* bslab, void* dW, void* db, int N, int D, int H, int W, int Cin, int Cout, void* stream);
 int iunet_first_conv_wgrad_tiles(int nd, int N, int D, int H, int W);
 int iunet_first_conv_wgrad(int dtype, int nd, const void* x, int in_dtype, const long long* in_strides, const void* dy,
                            long long dy_ss, void* slab, int N, int D, int H, int W, int Cin, int Cout, void* stream);

@@ -82,103 +82,162 @@ __global__ void pack_convT_dgrad_kernel(const float* __restrict__ w, T* __restri
   }
 }
 
-// ------------------------------------------------------------------ convT weight + bias gradient (VALU)
+// ------------------------------------------------------------------ convT weight + bias gradient (MFMA)
 // dW[ci][co][pos] = sum_v x[ci][v] * dy[co][2v+pos];  db[co] = sum dy[co][.]
-// block: 32 ci x 32 co x all pos over a run of input voxels; thread = (ci, 4 co).
+// Voxels are the k dimension: A[ci][k] = x^T, B[k][co] = dy at the 2x-upsampled position, both read
+// with the transposing LDS read from channel-innermost images (as conv3_wgrad).  One workgroup walks
+// input-voxel tiles for a (32 ci) x (32 co) block; its 4 waves split the 2^d output positions.
+typedef short s16x4w __attribute__((ext_vector_type(4)));
+typedef short s16x8w __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) s16x4w* lds_s4w_ptr;
+
+template <typename T>
+__device__ __forceinline__ typename Vec8<T>::type tr_frag2(unsigned addr, unsigned hi_off) {
+  const s16x4w lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4w_ptr)addr);
+  const s16x4w hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4w_ptr)(addr + hi_off));
+  const s16x8w v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(typename Vec8<T>::type, v);
+}
+
 struct ConvTWgradParams {
   const void* x; long long x_ss;
   const void* dy; long long dy_ss;
-  float* wslab;    // [nb][Cin][Cout][NPOS]
+  float* wslab;    // [nb][Cin/32][Cout/32][NPOS][32][32]
   float* bslab;    // [nb][Cout]
-  int N, D, H, W, Cin, Cout, per_block;
+  int N, D, H, W, Cin, Cout;
+  int tilesZ, tilesY, tilesX;
 };
 
 template <typename T, int ND>
-__global__ __launch_bounds__(256) void convT_wgrad_kernel(ConvTWgradParams p) {
+__global__ __launch_bounds__(256, 2) void convT_wgrad_kernel(ConvTWgradParams p) {
+  using V8 = V8T<T>;
   constexpr int NPOS = ND == 3 ? 8 : 4;
-  constexpr int VC = 32;                       // voxels per LDS sub-chunk
-  __shared__ float xs[VC][33];
-  __shared__ float dys[VC][NPOS][32];
-  const int t = threadIdx.x;
-  const int ci = t & 31, cog = t >> 5;
+  constexpr int TZ = ND == 3 ? 2 : 1, TY = ND == 3 ? 4 : 8, TX = 16;       // input-voxel tile (128 voxels)
+  constexpr int NVI = TZ * TY * TX;
+  constexpr int OZ = ND == 3 ? 2 * TZ : 1, OY = 2 * TY, OX = 2 * TX;         // output tile
+  constexpr int NVO = OZ * OY * OX;
+  constexpr int PLANE_X = NVI * 16 + 64, PLANE_Y = NVO * 16 + 64;            // 64 mod 256
+  constexpr int OFF_Y = 4 * PLANE_X;
+  constexpr int NKS = NVI / 32;
+  constexpr int PL = NPOS / 4;                                               // positions per wave
+  extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3, gh = g >> 1, gl = g & 1;
   const int cib = blockIdx.y, cob = blockIdx.z;
-  const long long vox = (long long)p.D * p.H * p.W;
-  const long long total = vox * p.N;
-  const long long v0 = (long long)blockIdx.x * p.per_block, v1 = min(v0 + p.per_block, total);
+  // lane parts of the tr-read addresses
+  const unsigned laneX = lds0 + (pp >> 1) * PLANE_X + (pp & 1) * 8 + (gh * 16 + gl * 8 + q) * 16;
+  const unsigned laneY = lds0 + OFF_Y + (pp >> 1) * PLANE_Y + (pp & 1) * 8 + (gh * 2 * OX + 2 * (gl * 8 + q)) * 16;
+  unsigned pos_off[PL];
+#pragma unroll
+  for (int i = 0; i < PL; ++i) {
+    const int s = wave * PL + i;
+    const int a = ND == 3 ? (s >> 2) : 0, b = (s >> 1) & 1, c = s & 1;
+    pos_off[i] = (unsigned)(((a * OY + b) * OX + c) * 16);
+  }
+  f32x4 acc[PL][2][2];
+#pragma unroll
+  for (int i = 0; i < PL; ++i)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) { acc[i][t][0] = f32x4{0, 0, 0, 0}; acc[i][t][1] = f32x4{0, 0, 0, 0}; }
+  float bacc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};                   // channels (tid & 3) * 8 + j of this co block
+
+  const int tps = p.tilesZ * p.tilesY * p.tilesX, ntiles = tps * p.N;
   const int Do = ND == 3 ? p.D * 2 : 1, Ho = p.H * 2, Wo = p.W * 2;
-  const long long in_plane = vox * 8, out_plane = (long long)Do * Ho * Wo * 8;
-  float acc[NPOS][4], bacc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // bacc: channels (t & 3) * 8 + j
-#pragma unroll
-  for (int s = 0; s < NPOS; ++s)
-#pragma unroll
-    for (int k = 0; k < 4; ++k) acc[s][k] = 0.f;
-  for (long long vb = v0; vb < v1; vb += VC) {
+  const long long in_plane = (long long)p.D * p.H * p.W * 8, out_plane = (long long)Do * Ho * Wo * 8;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int n = tile / tps;
+    int trem = tile - n * tps;
+    const int tz_i = trem / (p.tilesY * p.tilesX);
+    trem -= tz_i * p.tilesY * p.tilesX;
+    const int ty_i = trem / p.tilesX, tx_i = trem - ty_i * p.tilesX;
+    const int z0 = tz_i * TZ, y0 = ty_i * TY, x0 = tx_i * TX;
+    const T* xin = (const T*)p.x + (long long)n * p.x_ss + (long long)cib * 4 * in_plane;
+    const T* dyin = (const T*)p.dy + (long long)n * p.dy_ss + (long long)cob * 4 * out_plane;
     __syncthreads();
-    // stage x: 32 voxels x 32 ci (4 planes x 8)  -> 128 16-B items; dy: 32 voxels x NPOS x 4 planes
-    for (int it = t; it < VC * 4; it += 256) {
-      const int vv = it >> 2, pl = it & 3;
-      const long long gv = vb + vv;
-      V8T<T> val;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) val[j] = from_f32<T>(0.f);
-      if (gv < v1) {
-        const int n = (int)(gv / vox);
-        const long long r = gv - n * vox;
-        val = *(const V8T<T>*)((const T*)p.x + n * p.x_ss + (long long)(cib * 4 + pl) * in_plane + r * 8);
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) xs[vv][pl * 8 + j] = to_f32<T>(val[j]);
+    for (int it = tid; it < NVI * 4; it += 256) {            // x tile: 4 planes
+      const int pl = it / NVI, pix = it - pl * NVI;
+      const int px = pix % TX, t2 = pix / TX, py = t2 % TY, pz = t2 / TY;
+      const int gz = z0 + pz, gy = y0 + py, gx = x0 + px;
+      u32x4 v = u32x4{0u, 0u, 0u, 0u};
+      if (gz < p.D && gy < p.H && gx < p.W) v = *(const u32x4*)(xin + pl * in_plane + (((long long)gz * p.H + gy) * p.W + gx) * 8);
+      *(u32x4*)(smem + pl * PLANE_X + pix * 16) = v;
     }
-    for (int it = t; it < VC * NPOS * 4; it += 256) {
-      const int pl = it & 3, s = (it >> 2) % NPOS, vv = it / (4 * NPOS);
-      const long long gv = vb + vv;
-      V8T<T> val;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) val[j] = from_f32<T>(0.f);
-      if (gv < v1) {
-        const int n = (int)(gv / vox);
-        const long long r = gv - n * vox;
-        const int x = (int)(r % p.W), y = (int)((r / p.W) % p.H), z = (int)(r / ((long long)p.W * p.H));
-        const int a = ND == 3 ? (s >> 2) : 0, b = (s >> 1) & 1, c = s & 1;
-        const int oz = ND == 3 ? z * 2 + a : 0;
-        val = *(const V8T<T>*)((const T*)p.dy + n * p.dy_ss + (long long)(cob * 4 + pl) * out_plane +
-                               (((long long)oz * Ho + y * 2 + b) * Wo + x * 2 + c) * 8);
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { const float f = to_f32<T>(val[j]); dys[vv][s][pl * 8 + j] = f; bacc[j] += f; }
-    }
-    __syncthreads();
 #pragma unroll 4
-    for (int vv = 0; vv < VC; ++vv) {
-      const float xv = xs[vv][ci];
+    for (int it = tid; it < NVO * 4; it += 256) {            // dy tile: plane = it & 3 = tid & 3
+      const int pl = it & 3, pix = it >> 2;
+      const int px = pix % OX, t2 = pix / OX, py = t2 % OY, pz = t2 / OY;
+      const int gz = 2 * z0 + pz, gy = 2 * y0 + py, gx = 2 * x0 + px;
+      V8 v;
 #pragma unroll
-      for (int s = 0; s < NPOS; ++s)
+      for (int j = 0; j < 8; ++j) v[j] = from_f32<T>(0.f);
+      if (gz < Do && gy < Ho && gx < Wo) v = *(const V8*)(dyin + pl * out_plane + (((long long)gz * Ho + gy) * Wo + gx) * 8);
+      *(V8*)(smem + OFF_Y + pl * PLANE_Y + pix * 16) = v;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const float d = dys[vv][s][cog * 4 + k];
-          acc[s][k] = fmaf(xv, d, acc[s][k]);
-        }
+      for (int j = 0; j < 8; ++j) bacc[j] += to_f32<T>(v[j]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      // in-voxel rows 2ks, 2ks+1 (the lane's own row adds gh, folded into laneX / laneY)
+      const int r = 2 * ks, rz = r / TY, ry = r % TY;
+      const unsigned offX = (unsigned)(r * TX * 16);
+      const unsigned offY = (unsigned)(((2 * rz * OY + 2 * ry) * OX) * 16);
+      const V8 a0 = tr_frag2<T>(laneX + offX, 64);
+      const V8 a1 = tr_frag2<T>(laneX + offX + 2 * PLANE_X, 64);
+#pragma unroll
+      for (int i = 0; i < PL; ++i) {
+        const V8 b0 = tr_frag2<T>(laneY + offY + pos_off[i], 128);                 // 4 voxels further = 8 output pixels
+        const V8 b1 = tr_frag2<T>(laneY + offY + pos_off[i] + 2 * PLANE_Y, 128);
+        acc[i][0][0] = mfma16<T>(a0, b0, acc[i][0][0]);
+        acc[i][0][1] = mfma16<T>(a0, b1, acc[i][0][1]);
+        acc[i][1][0] = mfma16<T>(a1, b0, acc[i][1][0]);
+        acc[i][1][1] = mfma16<T>(a1, b1, acc[i][1][1]);
+      }
     }
   }
-  float* ws = p.wslab + (long long)blockIdx.x * p.Cin * p.Cout * NPOS;
+  // slab: rows = ci (4g + j), cols = co (lane & 15)
+  float* ws = p.wslab + ((((long long)blockIdx.x * gridDim.y + cib) * gridDim.z + cob) * NPOS) * 1024;
 #pragma unroll
-  for (int s = 0; s < NPOS; ++s)
+  for (int i = 0; i < PL; ++i) {
+    const int s = wave * PL + i;
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-      ws[((long long)(cib * 32 + ci) * p.Cout + cob * 32 + cog * 4 + k) * NPOS + s] = acc[s][k];
-  if (cib == 0) {       // bias gradient: threads with equal (t & 3) own the same 8 channels -> sum them through LDS
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ws[s * 1024 + (t * 16 + 4 * g + j) * 32 + u * 16 + i16] = acc[i][t][u][j];
+  }
+  if (cib == 0) {       // bias gradient: threads with equal (tid & 3) own the same 8 channels
     __syncthreads();
-    float* red = &dys[0][0][0];                       // reuse: [256][8]
+    float* red = (float*)smem;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) red[t * 8 + j] = bacc[j];
+    for (int j = 0; j < 8; ++j) red[tid * 8 + j] = bacc[j];
     __syncthreads();
-    if (t < 32) {
-      const int pl = t >> 3, j = t & 7;
+    if (tid < 32) {
+      const int pl = tid >> 3, j = tid & 7;
       float sum = 0.f;
       for (int k = pl; k < 256; k += 4) sum += red[k * 8 + j];
       p.bslab[(long long)blockIdx.x * p.Cout + cob * 32 + pl * 8 + j] = sum;
     }
   }
+}
+
+// dW[ci][co][pos] = sum_b slab[b][cib][cob][pos][ci%32][co%32] (threads walk the slab order)
+__global__ __launch_bounds__(256) void convT_wgrad_reduce_kernel(const float* __restrict__ slab, int nb, int Cin, int Cout, int npos,
+                                                                 float* __restrict__ dW) {
+  const long long per_b = (long long)Cin * Cout * npos;
+  const long long j = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (j >= per_b) return;
+  float s = 0.f;
+  for (int b = 0; b < nb; ++b) s += slab[b * per_b + j];
+  const int c = (int)(j & 31), r = (int)((j >> 5) & 31);
+  long long t = j >> 10;
+  const int pos = (int)(t % npos); t /= npos;
+  const int ncob = Cout / 32;
+  const int cob = (int)(t % ncob), cib = (int)(t / ncob);
+  dW[((long long)(cib * 32 + r) * Cout + cob * 32 + c) * npos + pos] = s;
 }
 
 // ------------------------------------------------------------------ first conv weight gradient (VALU)
@@ -277,6 +336,8 @@ __global__ __launch_bounds__(256) void first_wgrad_kernel(FirstWgradParams p) {
 
 #define DT_OK(dt) IUNET_REQUIRE((dt) == 0 || (dt) == 1, "dtype must be 0 (f16) or 1 (bf16), got %d", (dt))
 
+extern "C" int iunet_reduce_slab(void* slab, int nparts, long long n, void* out, float alpha, int accumulate, void* stream);
+
 extern "C" {
 
 int iunet_pack_convT_dgrad(int dtype, const void* w, void* dst, int Cin, int Cout, int npos, void* stream) {
@@ -308,32 +369,40 @@ int iunet_convT_dgrad(int dtype, int nd, const void* dy, long long dy_ss, void* 
   return IUNET_OK;
 }
 
-int iunet_convT_wgrad_blocks(int N, int D, int H, int W) {
-  const long long total = (long long)N * D * H * W;
-  long long nb = (total + 2047) / 2048;
-  if (nb > 256) nb = 256;
+int iunet_convT_wgrad_blocks(int nd, int N, int D, int H, int W, int Cin, int Cout) {
+  const int TZ = nd == 3 ? 2 : 1, TY = nd == 3 ? 4 : 8, TX = 16;
+  const long long ntiles = (long long)N * ((D + TZ - 1) / TZ) * ((H + TY - 1) / TY) * ((W + TX - 1) / TX);
+  const int pairs = (Cin / 32) * (Cout / 32);
+  long long nb = (512 + pairs - 1) / pairs;
+  if (nb > ntiles) nb = ntiles;
   return (int)(nb < 1 ? 1 : nb);
 }
 
-// wslab: [blocks][Cin][Cout][npos] floats, bslab: [blocks][Cout]; reduce both with iunet_reduce_slab
+// wslab: blocks*Cin*Cout*npos floats, bslab: blocks*Cout floats (scratch); dW fp32 [Cin][Cout][npos], db fp32 [Cout]
 int iunet_convT_wgrad(int dtype, int nd, const void* x, long long x_ss, const void* dy, long long dy_ss, void* wslab,
-                      void* bslab, int N, int D, int H, int W, int Cin, int Cout, void* stream) {
+                      void* bslab, void* dW, void* db, int N, int D, int H, int W, int Cin, int Cout, void* stream) {
   DT_OK(dtype);
-  IUNET_REQUIRE(x && dy && wslab && bslab, "convT_wgrad: null pointer");
+  IUNET_REQUIRE(x && dy && wslab && bslab && dW && db, "convT_wgrad: null pointer");
   IUNET_REQUIRE(Cin % 32 == 0 && Cout % 32 == 0, "convT_wgrad: channels must be multiples of 32");
   ConvTWgradParams p;
   p.x = x; p.x_ss = x_ss; p.dy = dy; p.dy_ss = dy_ss; p.wslab = (float*)wslab; p.bslab = (float*)bslab;
   p.N = N; p.D = D; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
-  const int nb = iunet_convT_wgrad_blocks(N, D, H, W);
-  const long long total = (long long)N * D * H * W;
-  p.per_block = (int)(((total + nb - 1) / nb + 31) / 32 * 32);
+  const int TZ = nd == 3 ? 2 : 1, TY = nd == 3 ? 4 : 8, TX = 16;
+  p.tilesZ = (D + TZ - 1) / TZ; p.tilesY = (H + TY - 1) / TY; p.tilesX = (W + TX - 1) / TX;
+  const int nb = iunet_convT_wgrad_blocks(nd, N, D, H, W, Cin, Cout);
+  const int npos = nd == 3 ? 8 : 4;
+  const int nvi = 128, nvo = nd == 3 ? 1024 : 512;
+  const int lds = 4 * (nvi * 16 + 64) + 4 * (nvo * 16 + 64);
   dim3 grid(nb, Cin / 32, Cout / 32);
-  if (dtype == 0) { if (nd == 3) hipLaunchKernelGGL((convT_wgrad_kernel<f16, 3>), grid, dim3(256), 0, (hipStream_t)stream, p);
-                    else hipLaunchKernelGGL((convT_wgrad_kernel<f16, 2>), grid, dim3(256), 0, (hipStream_t)stream, p); }
-  else { if (nd == 3) hipLaunchKernelGGL((convT_wgrad_kernel<bf16, 3>), grid, dim3(256), 0, (hipStream_t)stream, p);
-         else hipLaunchKernelGGL((convT_wgrad_kernel<bf16, 2>), grid, dim3(256), 0, (hipStream_t)stream, p); }
+#define CTW(TT, NDV) do { static bool s_ = false; if (!s_) { IUNET_CHECK_HIP(hipFuncSetAttribute((const void*)convT_wgrad_kernel<TT, NDV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); s_ = true; } \
+    hipLaunchKernelGGL((convT_wgrad_kernel<TT, NDV>), grid, dim3(256), lds, (hipStream_t)stream, p); } while (0)
+  if (dtype == 0) { if (nd == 3) CTW(f16, 3); else CTW(f16, 2); } else { if (nd == 3) CTW(bf16, 3); else CTW(bf16, 2); }
+#undef CTW
+  const long long total = (long long)Cin * Cout * npos;
+  hipLaunchKernelGGL(convT_wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)wslab, nb, Cin, Cout, npos, (float*)dW);
   IUNET_CHECK_HIP(hipGetLastError());
-  return IUNET_OK;
+  return iunet_reduce_slab(bslab, nb, Cout, db, 1.0f, 0, stream);
 }
 
 int iunet_first_conv_wgrad_tiles(int nd, int N, int D, int H, int W) {

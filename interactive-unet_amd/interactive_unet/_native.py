@@ -63,9 +63,9 @@ _SIGS = {
     'iunet_pack_convT_dgrad': [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     'iunet_convT_dgrad': [c_int, c_int, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_int, c_int, c_int, c_int, c_int,
                           c_int, c_void_p],
-    'iunet_convT_wgrad_blocks': [c_int] * 4,
-    'iunet_convT_wgrad': [c_int, c_int, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_void_p, c_int, c_int, c_int,
-                          c_int, c_int, c_int, c_void_p],
+    'iunet_convT_wgrad_blocks': [c_int] * 7,
+    'iunet_convT_wgrad': [c_int, c_int, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_void_p, c_void_p, c_void_p,
+                          c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     'iunet_first_conv_wgrad_tiles': [c_int] * 5,
     'iunet_first_conv_wgrad': [c_int, c_int, c_void_p, c_int, ctypes.POINTER(c_ll), c_void_p, c_ll, c_void_p,
                                c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],

@@ -166,7 +166,7 @@ class TrainEngine:
             if l < L - 1:
                 ws[f'cat{l}'] = act(2 * ch[l], v)
                 ws[f'dcat{l}'] = act(2 * ch[l], v)
-                nb = lib.iunet_convT_wgrad_blocks(N, *dims[l + 1])
+                nb = lib.iunet_convT_wgrad_blocks(self.dim, N, *dims[l + 1], ch[l + 1], ch[l])
                 max_wslab = max(max_wslab, nb * ch[l + 1] * ch[l] * self.npos)
                 ws[f'bslab{l}'] = f32(nb * ch[l])
             if l > 0:
@@ -325,12 +325,9 @@ class TrainEngine:
             src_name = f'enc{l + 1}.conv2' if l == L - 2 else f'dec{l + 1}.conv2'
             src, dsrc = ws['z.' + src_name], ws['dz.' + src_name]
             dup = self._P(ws[f'dcat{l}'], ch[l] * v)
-            nb = nv.lib().iunet_convT_wgrad_blocks(N, *di)
             nv.call('iunet_convT_wgrad', self.dt, self.dim, self._P(src), ch[l + 1] * vi, dup, 2 * ch[l] * v,
-                    nv.ptr(ws['wslab']), nv.ptr(ws[f'bslab{l}']), N, di[0], di[1], di[2], ch[l + 1], ch[l], s)
-            nv.call('iunet_reduce_slab', nv.ptr(ws['wslab']), nb, ch[l + 1] * ch[l] * self.npos,
-                    nv.ptr(self.g(f'dec{l}.up.weight')), 1.0, 0, s)
-            nv.call('iunet_reduce_slab', nv.ptr(ws[f'bslab{l}']), nb, ch[l], nv.ptr(self.g(f'dec{l}.up.bias')), 1.0, 0, s)
+                    nv.ptr(ws['wslab']), nv.ptr(ws[f'bslab{l}']), nv.ptr(self.g(f'dec{l}.up.weight')),
+                    nv.ptr(self.g(f'dec{l}.up.bias')), N, di[0], di[1], di[2], ch[l + 1], ch[l], s)
             _, wd = self.pk[f'dec{l}.up']
             nv.call('iunet_convT_dgrad', self.dt, self.dim, dup, 2 * ch[l] * v, self._P(dsrc), ch[l + 1] * vi,
                     nv.ptr(wd), N, di[0], di[1], di[2], ch[l + 1], ch[l], s)

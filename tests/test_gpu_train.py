@@ -144,14 +144,13 @@ def test_convT_backward_exact_integers(nv, nd):
     nv.call('iunet_pack_convT_dgrad', 0, nv.ptr(wd), nv.ptr(wpk), cin, cout, npos, nv.stream())
     dx = torch.full((N * cin * vin,), float('nan'), dtype=torch.float16, device='cuda')
     nv.call('iunet_convT_dgrad', 0, nd, nv.ptr(dyb), cout * vout, nv.ptr(dx), cin * vin, nv.ptr(wpk), N, D, H, W, cin, cout, nv.stream())
-    nb = nv.lib().iunet_convT_wgrad_blocks(N, D, H, W)
+    nb = nv.lib().iunet_convT_wgrad_blocks(nd, N, D, H, W, cin, cout)
     wslab = torch.empty(nb * cin * cout * npos, device='cuda')
     bslab = torch.empty(nb * cout, device='cuda')
-    nv.call('iunet_convT_wgrad', 0, nd, nv.ptr(xb), cin * vin, nv.ptr(dyb), cout * vout, nv.ptr(wslab), nv.ptr(bslab), N, D, H, W, cin, cout, nv.stream())
-    dW = torch.empty(cin * cout * npos, device='cuda')
-    db = torch.empty(cout, device='cuda')
-    nv.call('iunet_reduce_slab', nv.ptr(wslab), nb, cin * cout * npos, nv.ptr(dW), 1.0, 0, nv.stream())
-    nv.call('iunet_reduce_slab', nv.ptr(bslab), nb, cout, nv.ptr(db), 1.0, 0, nv.stream())
+    dW = torch.full((cin * cout * npos,), float('nan'), device='cuda')
+    db = torch.full((cout,), float('nan'), device='cuda')
+    nv.call('iunet_convT_wgrad', 0, nd, nv.ptr(xb), cin * vin, nv.ptr(dyb), cout * vout, nv.ptr(wslab), nv.ptr(bslab),
+            nv.ptr(dW), nv.ptr(db), N, D, H, W, cin, cout, nv.stream())
     torch.cuda.synchronize()
     gx = unblocked(dx.float().cpu(), N, cin, shape)
     ok = x.grad.abs() <= 2048
