@@ -43,6 +43,16 @@ def synth_chunks(n, S, seed, device):
     return (x * 254 + 1).to(torch.uint8).reshape(n, S, S, S)
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the roofline kernel from the committed PMC profile (rocprofv3 cannot run
+    inside the timed process): FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate passes."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r01_pmc_conv3_dec0conv1.json')) as f:
+            return json.load(f)['traffic_bytes_per_launch']
+    except Exception:
+        return None
+
+
 def conv_roofline(nv, dtype, S, iters=10):
     """dec0.conv1 of the 3-D net: Cin 64 -> Cout 32, 27 taps, one 128^3 chunk."""
     dev = 'cuda'
@@ -71,7 +81,7 @@ def conv_roofline(nv, dtype, S, iters=10):
     ach = flops / (ms * 1e-3) / 1e12
     return {'bound': 'mfma', 'kernel': ('conv3_v2_kernel' if lay else 'conv3_mfma_kernel') + f'<{"bf16" if dtype == torch.bfloat16 else "f16"},3> (dec0.conv1 64->32 @128^3)',
             'achieved': round(ach, 2), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / MFMA_PEAK_TFLOPS, 4),
-            'ms_per_launch': round(ms, 4), 'flops_per_launch': flops, 'traffic': None}
+            'ms_per_launch': round(ms, 4), 'flops_per_launch': flops, 'traffic': pmc_traffic()}
 
 
 def cpu_baseline(ncls):

@@ -61,8 +61,11 @@ __global__ __launch_bounds__(256, 2) void conv3_v2_kernel(ConvV2Params p) {
   const int cob = blockIdx.y;
   const int tiles_per_sample = p.tilesZ * p.tilesY * p.tilesX;
   const int ntiles = tiles_per_sample * p.N;
-  const int t_begin = (int)((long long)blockIdx.x * ntiles / gridDim.x);
-  const int t_end = (int)((long long)(blockIdx.x + 1) * ntiles / gridDim.x);
+  // workgroups b and b + 8 share an XCD (and its L2): give each XCD a contiguous stretch of the tile
+  // sequence so that neighbouring runs re-use each other's halo lines in that L2 (speed only)
+  const int lb = xcd_remap(blockIdx.x, gridDim.x);
+  const int t_begin = (int)((long long)lb * ntiles / gridDim.x);
+  const int t_end = (int)((long long)(lb + 1) * ntiles / gridDim.x);
   const int nchunk = p.Cin >> 4;
   const int nsteps = (t_end - t_begin) * nchunk;
   if (nsteps <= 0) return;

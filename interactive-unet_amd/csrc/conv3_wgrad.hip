@@ -91,7 +91,10 @@ __global__ __launch_bounds__(256, 2) void conv3_wgrad_kernel(WgradParams p) {
   const int cob = blockIdx.y, cib = blockIdx.z;
   const long long plane_stride = (long long)p.D * p.H * p.W * 8;
 
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  // contiguous run of tiles per workgroup, runs of one XCD adjacent (halo lines stay in that XCD's L2)
+  const int lb = xcd_remap(blockIdx.x, gridDim.x);
+  const int t_begin = (int)((long long)lb * ntiles / gridDim.x), t_end = (int)((long long)(lb + 1) * ntiles / gridDim.x);
+  for (int tile = t_begin; tile < t_end; ++tile) {
     const int n_img = tile / tiles_per_sample;
     int trem = tile - n_img * tiles_per_sample;
     const int tz_i = trem / (p.tilesY * p.tilesX);
