@@ -1,0 +1,113 @@
+"""End-to-end GPU tests of the drop-in entry points: whole-volume prediction against the oracle's
+restatement of predict.py:201-256, the sharded path on one rank, and trainer.train_model's files."""
+import csv
+import glob
+import os
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import unet_ref, predict_ref
+
+
+def _model(dim, ncls=2, seed=3, dtype='fp16'):
+    from interactive_unet.unet import UNet
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        m = UNet(num_classes=ncls, dim=dim, act_dtype=dtype, pretrained=False)
+    p = unet_ref.init_params(dim=dim, ncls=ncls, seed=seed, randomize_bn=True)
+    m.load_named(p)
+    return m.cuda().eval(), p
+
+
+def _volume(shape, seed):
+    from scipy import ndimage
+    rng = np.random.default_rng(seed)
+    v = ndimage.gaussian_filter(rng.random(shape), 2.5)
+    return (255 * (v - v.min()) / (v.max() - v.min())).astype(np.uint8)
+
+
+@pytest.mark.parametrize('dim', [2, 3])
+def test_predict_volume_array_vs_oracle(dim):
+    """Block grid + reflect blocks + (2.5-D | 3-D) block prediction + Gaussian blend + truncating
+    quantisation on device vs the oracle pipeline fed by the oracle network (same rounding points)."""
+    from interactive_unet import predict
+    S, C = 32, 2
+    V = (72, 56, 40)
+    model, p = _model(dim, C)
+    vol = _volume(V, 21)
+    got = predict.predict_volume_array(model, vol, input_size=S, num_classes=C, overlap=0.25).cpu().numpy()
+
+    if dim == 2:
+        net2d = lambda b: unet_ref.forward(p, torch.tensor(b), dim=2, act_dtype=torch.float16).numpy()
+        block_fn = lambda blk: predict_ref.predict_block(net2d, blk, C, 8, (0, 1, 2))
+    else:
+        def block_fn(blk):
+            pr = unet_ref.forward(p, torch.tensor(blk)[None, None], dim=3, act_dtype=torch.float16)
+            return pr[0].permute(1, 2, 3, 0).contiguous().numpy()
+    want, _, _ = predict_ref.blend_volume(vol, block_fn, S, C, 0.25)
+    d = np.abs(got.astype(int) - want.astype(int))
+    print(f'{dim}-D volume predict: max |uint8 diff| = {d.max()}, differing = {(d > 0).mean():.4f}')
+    # probabilities carry the 16-bit-storage noise of the network (<= 3e-3): 255 * 3e-3 < 1 LSB,
+    # plus the truncating cast -> at most 2 LSB anywhere, and the class map equal where classes differ by > 2 LSB
+    assert d.max() <= 2
+    sure = np.abs(want[..., 0].astype(int) - want[..., 1].astype(int)) > 4
+    assert np.array_equal(got.argmax(-1)[sure], want.argmax(-1)[sure])
+
+
+def test_sharded_predict_single_rank_equals_unsharded():
+    from interactive_unet import predict, shard
+    S, C = 32, 2
+    V = (40, 40, 40)
+    model, _ = _model(3, C)
+    vol = torch.tensor(_volume(V, 22)).cuda()
+    ref = predict.predict_volume_array(model, vol, input_size=S, num_classes=C).cpu().numpy()
+    ops = shard.NativeOps(model, C, S)
+    out, stats = shard.predict_volume_sharded(ops, vol, V, S, 0.25)
+    assert stats['blocks'] == len(predict.get_block_coordinates(np.array(V), S, 0.25)[0])
+    assert np.array_equal(out.cpu().numpy(), ref)
+
+
+def test_predict_slice_contract():
+    from interactive_unet import predict
+    model, p = _model(2, 3)
+    img = _volume((64, 96), 23)
+    colored = predict.predict_slice(img, num_classes=3, model=model)
+    assert colored.shape == (64, 96, 3) and colored.dtype == np.uint8
+    probs = predict.predict_slice(img, num_classes=3, return_probabilities=True, model=model)
+    assert probs.shape == (1, 64, 96, 3) and abs(probs.sum(-1).mean() - 1) < 1e-5
+    cls = probs[0].argmax(-1)
+    for i in range(3):
+        assert (colored[cls == i] == predict.COLORS[i + 1]).all()
+
+
+def test_train_model_files_and_learning(tmp_path, monkeypatch):
+    """trainer.train_model with injected loaders: loss goes down, model/model.ckpt and the Lightning-style
+    metrics.csv appear, a second call resumes from the checkpoint (trainer.py:30-49)."""
+    from interactive_unet import trainer, unet
+    monkeypatch.chdir(tmp_path)
+    rng = np.random.default_rng(5)
+    imgs = np.stack([_volume((64, 64), 30 + i) for i in range(4)])
+    X = torch.tensor(imgs[:, None].astype(np.float32) / 255).half()
+    lab = imgs > 127
+    y = torch.tensor(np.stack([~lab, lab], 1).astype(np.float32)).half()
+    w = torch.ones_like(y)
+    train = [(X[:2], y[:2], w[:2]), (X[2:], y[2:], w[2:])]
+    val = [(X[:2], y[:2], w[:2])]
+    trainer.train_model(1e-3, 2, 6, 1, 2, 'MCC + CE', 'U-Net', 'mit_b0', False, train_loader=train, val_loader=val)
+    assert os.path.isfile('model/model.ckpt')
+    files = glob.glob('model/history/*/version_0/metrics.csv')
+    assert len(files) == 1
+    rows = list(csv.DictReader(open(files[0])))
+    tr = [float(r['train/Loss']) for r in rows if r['train/Loss']]
+    va = [float(r['val/Loss']) for r in rows if r['val/Loss']]
+    assert len(tr) == 6 and len(va) == 6 and set(rows[0]) >= {'epoch', 'step', 'train/Dice', 'val/MCC'}
+    assert tr[-1] < tr[0] - 0.05, tr
+    m = unet.UNet.load_from_checkpoint(checkpoint_path='model/model.ckpt')
+    assert m.num_classes == 2 and abs(m.lr - 1e-3) < 1e-12
+    trainer.train_model(5e-4, 2, 1, 1, 2, 'Dice + CE', 'U-Net', 'mit_b0', False, train_loader=train, val_loader=val)
+    assert len(glob.glob('model/history/*/version_0/metrics.csv')) >= 1 and os.path.isfile('model/model.ckpt')
