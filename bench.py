@@ -43,6 +43,17 @@ def synth_chunks(n, S, seed, device):
     return (x * 254 + 1).to(torch.uint8).reshape(n, S, S, S)
 
 
+def flops_per_voxel(dim, levels, base, cin, ncls):
+    """Algorithmic forward FLOPs (2*MAC) per full-resolution voxel of the canonical U-Net."""
+    ch = [base * 2 ** l for l in range(levels)]
+    taps, f = 3 ** dim, 0.0
+    for l in range(levels):
+        f += 2 * taps * ((cin if l == 0 else ch[l - 1]) * ch[l] + ch[l] * ch[l]) / 2 ** (dim * l)
+    for l in range(levels - 2, -1, -1):
+        f += (2 * ch[l + 1] * ch[l] + 2 * taps * (2 * ch[l] * ch[l] + ch[l] * ch[l])) / 2 ** (dim * l)
+    return f + 2 * ch[0] * ncls
+
+
 def pmc_traffic():
     """HBM bytes per launch of the roofline kernel from the committed PMC profile (rocprofv3 cannot run
     inside the timed process): FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate passes."""
@@ -138,21 +149,17 @@ def main():
         dist.init_process_group('nccl', device_id=torch.device('cuda', local))
 
     from interactive_unet import _native as nv
-    from interactive_unet.engine import Engine
-    from interactive_unet import predict as npredict
-    from oracle import unet_ref                      # weights only (init), not in the timed path
 
     dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float16
     S, B, ncls = args.size, args.chunks, 2
     dev = torch.device('cuda', local)
-    params = {k: v.to(dev) for k, v in unet_ref.init_params(dim=3, ncls=ncls, seed=0).items()}
     import warnings
     from interactive_unet.unet import UNet
     from interactive_unet.train_engine import TrainEngine
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
         model = UNet(lr=1e-4, num_classes=ncls, dim=3, act_dtype=args.dtype, pretrained=False)
-    model.load_named(params)
+    model.reset_parameters(seed=0)                                      # random-init weights of the canonical architecture
     model = model.to(dev)
     trainer = TrainEngine(model, lr=1e-4, loss_kind='mcc_ce', process_group=(dist.group.WORLD if dist else None))
     chunks = synth_chunks(B, S, 1234 + rank, dev)
@@ -161,20 +168,27 @@ def main():
     y = torch.cat([~lab, lab], 1).to(torch.float16)                     # loader contract: fp16 one-hot (loader.py:150-152)
     w = (torch.rand((B, 1, S, S, S), device=dev) > 0.1).to(torch.float16).expand(B, ncls, S, S, S).contiguous()
     y = y * w
-    acc = npredict.VolumeAccumulator((B * S, S, S), ncls, S, dev)      # chunks stacked along z
+    # predict leg: ONE volume shared by all ranks, Z = 96*B*world + 32 planes of 128 x 128 -> exactly B
+    # overlapping 128^3 blocks per rank (predict.py:362-411 grid, overlap 0.25); every rank owns a z-slab,
+    # slabs are all-gathered and the overlapping accumulator planes exchanged over RCCL (shard.py)
+    from interactive_unet import shard
+    stride = int(S * 0.75)
+    V = (stride * B * world + (S - stride), S, S)
+    bounds, _ = shard.slab_bounds(V[0], world)
+    my_slab = synth_chunks(1, S, 4321 + rank, dev).reshape(S, S, S)
+    my_slab = my_slab.repeat(-(-(bounds[rank][1] - bounds[rank][0]) // S), 1, 1)[:bounds[rank][1] - bounds[rank][0]].contiguous()
+    ops = shard.NativeOps(model, ncls, S)
     legs = {'train': 0.0, 'predict': 0.0}
+    info = {}
 
     def step(timed=False):
         t0 = time.time()
         trainer.train_step(X, y, w, sync=False)
         if timed:
             torch.cuda.synchronize(); t1 = time.time(); legs['train'] += t1 - t0
-        eng = model.engine('eval')                                      # re-packs the updated weights (BN folded)
-        for b in range(B):
-            eng.infer(chunks[b], (S ** 3, S ** 3, S * S, S, 1), 1, S, S, S, probs=acc.block_probs,
-                      out_strides=(0, 1, S * S * ncls, S * ncls, ncls))
-            acc.blend((b * S, 0, 0, (b + 1) * S, S, S), (0, 0, 0, S, S, S))
-        acc.finalize()
+        model.engine('eval')                                            # re-packs the updated weights (BN folded)
+        out_u8, st = shard.predict_volume_sharded(ops, my_slab, V, S, 0.25, group=(dist.group.WORLD if dist else None))
+        info.update(st)
         if timed:
             torch.cuda.synchronize(); legs['predict'] += time.time() - t1
 
@@ -184,12 +198,10 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        acc.reset()
         step()
     barrier()
     t0 = time.time()
     for _ in range(args.steps):
-        acc.reset()
         step()
     barrier()
     dt = time.time() - t0
@@ -199,7 +211,6 @@ def main():
         dt = t.item()
     # leg split, measured in separate (untimed-for-value) steps so the timed region has no extra syncs
     for _ in range(2):
-        acc.reset()
         step(timed=True)
     vox_per_step = 2 * B * S ** 3 * world            # every chunk voxel goes through the train leg and the predict leg
     value = vox_per_step * args.steps / dt
@@ -214,14 +225,18 @@ def main():
             'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': f'C3: 3-D U-Net 4-level base 32, 1->{ncls} classes, {B} x {S}^3 uint8 chunks per GPU '
                                    f'per step; step = 1 training step (forward with BatchNorm batch stats, MCC+CE loss, '
-                                   f'backward, AdamW, weight re-pack) on the {B} chunks + prediction of the same {B} '
-                                   f'chunks (forward + softmax + Gaussian blend-accumulate + normalise/quantise); '
-                                   f'voxels counted once per leg',
+                                   f'backward, AdamW, weight re-pack; gradients all-reduced over RCCL for N > 1) on the '
+                                   f'{B} chunks + tiled prediction of one {V[0]}x{S}x{S} uint8 volume shared by all ranks = '
+                                   f'{B} overlapping {S}^3 blocks per GPU (reflect-padded block gather, forward + softmax, '
+                                   f'Gaussian blend-accumulate, slab all-gather + overlap exchange over RCCL for N > 1, '
+                                   f'normalise/quantise); voxels = chunk voxels, counted once per leg',
+                       'predict_volume': list(V), 'predict_blocks_per_gpu': info.get('blocks'),
+                       'predict_exchange_bytes_sent_rank0': info.get('bytes_sent'),
                        'chunks_per_gpu': B, 'chunk': S, 'levels': 4, 'base': 32,
-                       'fwd_flop_per_voxel': unet_ref.flops_per_voxel(3, 4, 32, 1, ncls)},
+                       'fwd_flop_per_voxel': flops_per_voxel(3, 4, 32, 1, ncls)},
             'roofline': roof,
         }
-        fpv = unet_ref.flops_per_voxel(3, 4, 32, 1, ncls)
+        fpv = flops_per_voxel(3, 4, 32, 1, ncls)
         out['legs'] = {'train_ms': round(legs['train'] / 2 * 1e3, 3), 'predict_ms': round(legs['predict'] / 2 * 1e3, 3),
                        'train_voxels_per_s_per_gpu': round(B * S ** 3 / (legs['train'] / 2), 1),
                        'predict_voxels_per_s_per_gpu': round(B * S ** 3 / (legs['predict'] / 2), 1),

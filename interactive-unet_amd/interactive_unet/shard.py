@@ -52,9 +52,18 @@ class NativeOps:
         self.device = model.device
         self.eng = model.engine('eval')
         self.blk = torch.empty((input_size,) * 3, dtype=torch.uint8, device=self.device)
+        self._acc = {}
 
     def make_accumulator(self, V):
-        return P.VolumeAccumulator(V, self.C, self.S, self.device)
+        """Accumulators are cached per volume shape (the Gaussian window and 12 B/voxel of HBM are not
+        re-created for every volume of a series); a re-used one is zeroed."""
+        acc = self._acc.get(tuple(V))
+        if acc is None:
+            acc = P.VolumeAccumulator(V, self.C, self.S, self.device)
+            self._acc = {tuple(V): acc}
+        else:
+            acc.reset()
+        return acc
 
     def predict_into(self, acc, volume, block, padded, local):
         S, C = self.S, self.C
