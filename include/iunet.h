@@ -120,7 +120,9 @@ int iunet_head_loss_num_parts(int N, long long vox);
 int iunet_head_loss_fwd(int dtype, const void* x, long long x_ss, int C0, const void* w, const void* bias, int ncls,
                         const void* target, const void* weight, int tdtype, int kind, void* slab, void* out4, void* coef,
                         int N, long long vox, void* stream);
-/* backward through loss, softmax and head: dx (NHWC8c), dW/db partial slab [num_parts][ncls*(C0+1)]. */
+/* backward through loss, softmax and head: dx (NHWC8c), dW/db partial slab
+ * [iunet_head_loss_bwd_num_parts][ncls*(C0+1)] (per row: [C0/8][ncls][8] weight partials, then [ncls] bias partials). */
+int iunet_head_loss_bwd_num_parts(int N, long long vox, int ncls, int C0);
 int iunet_head_loss_bwd(int dtype, const void* x, long long x_ss, int C0, const void* w, const void* bias, int ncls,
                         const void* target, const void* weight, int tdtype, const void* coef, float loss_scale, void* dx,
                         long long dx_ss, void* dwslab, int N, long long vox, void* stream);
@@ -140,9 +142,11 @@ int iunet_convT_dgrad(int dtype, int nd, const void* dy, long long dy_ss, void* 
 int iunet_convT_wgrad_blocks(int nd, int N, int D, int H, int W, int Cin, int Cout);
 int iunet_convT_wgrad(int dtype, int nd, const void* x, long long x_ss, const void* dy, long long dy_ss, void* wslab,
                       void* bslab, void* dW, void* db, int N, int D, int H, int W, int Cin, int Cout, void* stream);
-int iunet_first_conv_wgrad_tiles(int nd, int N, int D, int H, int W);
+/* first conv weight gradient on MFMA: dW fp32 [Cout][Cin][taps]; slab: blocks * Cout * 112 floats of scratch. */
+int iunet_first_conv_wgrad_blocks(int nd, int N, int D, int H, int W);
 int iunet_first_conv_wgrad(int dtype, int nd, const void* x, int in_dtype, const long long* in_strides, const void* dy,
-                           long long dy_ss, void* slab, int N, int D, int H, int W, int Cin, int Cout, void* stream);
+                           long long dy_ss, void* slab, void* dW, int N, int D, int H, int W, int Cin, int Cout,
+                           void* stream);
 /* AdamW with torch defaults (unet.py:71-73); grads are multiplied by grad_scale_inv (loss scaling, 1/world);
  * if *skip_flag != 0 (set by iunet_check_finite) the step is skipped. */
 int iunet_check_finite(const void* g, long long n, void* flag, void* stream);

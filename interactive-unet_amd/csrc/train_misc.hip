@@ -240,12 +240,14 @@ __global__ __launch_bounds__(256) void convT_wgrad_reduce_kernel(const float* __
   dW[((long long)(cib * 32 + r) * Cout + cob * 32 + c) * npos + pos] = s;
 }
 
-// ------------------------------------------------------------------ first conv weight gradient (VALU)
-// dW[co][ci][tap] = sum_v dy[co][v] * x[ci][v + tap - 1]; x read with the caller's strides.
+// ------------------------------------------------------------------ first conv weight gradient (MFMA)
+// dW[co][c][tap] = sum_v dy[co][v] * x[c][v + tap - 1]: voxels are the k dimension; A = dy^T through the
+// transposing LDS read, B = im2col columns gathered from a 16-bit LDS image of the input halo tile
+// (8 scalar reads per k-quad).  x is read with the caller's strides / dtype.  Bound by reading dy.
 struct FirstWgradParams {
   const void* x; long long sN, sC, sD, sH, sW; int in_dtype;
   const void* dy; long long dy_ss;
-  float* slab;     // [ntiles][Cout][Cin][taps]
+  float* slab;     // [nb][Cout][KKP]
   int N, D, H, W, Cin, Cout;
   int tilesZ, tilesY, tilesX;
 };
@@ -260,76 +262,108 @@ __device__ __forceinline__ float load_in2(const void* p, long long off, int dt) 
 }
 
 template <typename T, int ND, int CIN>
-__global__ __launch_bounds__(256) void first_wgrad_kernel(FirstWgradParams p) {
+__global__ __launch_bounds__(256, 2) void first_wgrad_kernel(FirstWgradParams p) {
+  using V8 = V8T<T>;
   constexpr int TZ = ND == 3 ? 4 : 1, TY = ND == 3 ? 8 : 16, TX = ND == 3 ? 16 : 32, PADZ = ND == 3 ? 1 : 0;
   constexpr int PZ = TZ + 2 * PADZ, PY = TY + 2, PX = TX + 2, NPIX = PZ * PY * PX, NVOX = TZ * TY * TX;
-  constexpr int TAPS = ND == 3 ? 27 : 9;
-  constexpr int TPG = (TAPS + 7) / 8;          // taps per thread group
-  __shared__ float xs[CIN][NPIX];
-  __shared__ T dys[NVOX][34];
-  const int t = threadIdx.x;
-  const int co = t & 31, tg = t >> 5;
+  constexpr int TAPS = ND == 3 ? 27 : 9, KK = TAPS * CIN, NT = (KK + 15) / 16, KKP = NT * 16;
+  constexpr int FX = TX / 16, NKS = NVOX / 32;
+  constexpr int PLANE_Y = NVOX * 16 + 64;                      // 64 mod 256: conflict-free tr reads
+  constexpr int XS_BYTES = ((CIN * NPIX * 2 + 255) / 256) * 256;
+  extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
+  T* xs = (T*)smem;                                           // [CIN][NPIX]
+  unsigned char* dys = smem + XS_BYTES;                        // 4 planes
+  const unsigned lds_y = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)dys;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3, gh = g >> 1, gl = g & 1;
   const int cob = blockIdx.y;
-  const int tiles_per_sample = p.tilesZ * p.tilesY * p.tilesX;
-  const int tile = blockIdx.x;
-  const int n = tile / tiles_per_sample;
-  int trem = tile - n * tiles_per_sample;
-  const int tz_i = trem / (p.tilesY * p.tilesX);
-  trem -= tz_i * p.tilesY * p.tilesX;
-  const int ty_i = trem / p.tilesX, tx_i = trem - ty_i * p.tilesX;
-  const int z0 = tz_i * TZ, y0 = ty_i * TY, x0 = tx_i * TX;
-  for (int it = t; it < NPIX * CIN; it += 256) {
-    const int c = it / NPIX, pix = it - c * NPIX;
-    const int px = pix % PX, t2 = pix / PX, py = t2 % PY, pz = t2 / PY;
-    const int gz = z0 + pz - PADZ, gy = y0 + py - 1, gx = x0 + px - 1;
-    float v = 0.f;
-    if ((unsigned)gz < (unsigned)p.D && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W)
-      v = to_f32<T>(from_f32<T>(load_in2(p.x, n * p.sN + c * p.sC + gz * p.sD + gy * p.sH + gx * p.sW, p.in_dtype)));
-    xs[c][pix] = v;
-  }
-  const long long plane = (long long)p.D * p.H * p.W * 8;
-  for (int it = t; it < NVOX * 4; it += 256) {
-    const int pl = it & 3, vv = it >> 2;
-    const int px = vv % TX, t2 = vv / TX, py = t2 % TY, pz = t2 / TY;
-    const int gz = z0 + pz, gy = y0 + py, gx = x0 + px;
-    V8T<T> val;
+  const unsigned laneY = lds_y + (pp >> 1) * PLANE_Y + (pp & 1) * 8 + (gh * 16 + gl * 8 + q) * 16;
+  // this lane's im2col column of every column tile: kk = 16 ct + i16 -> (tap, channel) -> element offset
+  int col_off[NT];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) val[j] = from_f32<T>(0.f);
-    if (gz < p.D && gy < p.H && gx < p.W)
-      val = *(const V8T<T>*)((const T*)p.dy + n * p.dy_ss + (long long)(cob * 4 + pl) * plane +
-                             (((long long)gz * p.H + gy) * p.W + gx) * 8);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) dys[vv][pl * 8 + j] = val[j];
-  }
-  __syncthreads();
-  float acc[TPG][CIN];
-  int toff[TPG];
-#pragma unroll
-  for (int k = 0; k < TPG; ++k) {
-    const int tap = min(tg * TPG + k, TAPS - 1);
+  for (int ct = 0; ct < NT; ++ct) {
+    const int kk = ct * 16 + i16, kc = kk < KK ? kk : 0;        // padded columns are never stored
+    const int tap = kc / CIN, c = kc % CIN;
     const int dz = ND == 3 ? tap / 9 : 0, dy_ = (tap / 3) % 3, dx = tap % 3;
-    toff[k] = (dz * PY + dy_) * PX + dx;
-#pragma unroll
-    for (int c = 0; c < CIN; ++c) acc[k][c] = 0.f;
+    col_off[ct] = c * NPIX + (dz * PY + dy_) * PX + dx;
   }
-  for (int vv = 0; vv < NVOX; ++vv) {
-    const int px = vv % TX, t2 = vv / TX, py = t2 % TY, pz = t2 / TY;
-    const int pix0 = (pz * PY + py) * PX + px;
-    const float d = to_f32<T>(dys[vv][co]);
+  f32x4 acc[2][NT];
 #pragma unroll
-    for (int k = 0; k < TPG; ++k)
+  for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int c = 0; c < CIN; ++c) acc[k][c] = fmaf(d, xs[c][pix0 + toff[k]], acc[k][c]);
-  }
-  float* slab = p.slab + (long long)tile * p.Cout * CIN * TAPS;
+    for (int ct = 0; ct < NT; ++ct) acc[t][ct] = f32x4{0, 0, 0, 0};
+  const int tps = p.tilesZ * p.tilesY * p.tilesX, ntiles = tps * p.N;
+  const long long plane = (long long)p.D * p.H * p.W * 8;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int n = tile / tps;
+    int trem = tile - n * tps;
+    const int tz_i = trem / (p.tilesY * p.tilesX);
+    trem -= tz_i * p.tilesY * p.tilesX;
+    const int ty_i = trem / p.tilesX, tx_i = trem - ty_i * p.tilesX;
+    const int z0 = tz_i * TZ, y0 = ty_i * TY, x0 = tx_i * TX;
+    __syncthreads();
+    for (int it = tid; it < NPIX * CIN; it += 256) {
+      const int c = it / NPIX, pix = it - c * NPIX;
+      const int px = pix % PX, t2 = pix / PX, py = t2 % PY, pz = t2 / PY;
+      const int gz = z0 + pz - PADZ, gy = y0 + py - 1, gx = x0 + px - 1;
+      float v = 0.f;
+      if ((unsigned)gz < (unsigned)p.D && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W)
+        v = load_in2(p.x, n * p.sN + c * p.sC + gz * p.sD + gy * p.sH + gx * p.sW, p.in_dtype);
+      xs[it] = from_f32<T>(v);
+    }
+    const T* dyin = (const T*)p.dy + (long long)n * p.dy_ss + (long long)cob * 4 * plane;
 #pragma unroll
-  for (int k = 0; k < TPG; ++k) {
-    const int tap = tg * TPG + k;
-    if (tap < TAPS) {
+    for (int it = 0; it < NVOX * 4 / 256; ++it) {
+      const int idx = tid + it * 256, pl = idx / NVOX, pix = idx - pl * NVOX;
+      const int px = pix % TX, t2 = pix / TX, py = t2 % TY, pz = t2 / TY;
+      const int gz = z0 + pz, gy = y0 + py, gx = x0 + px;
+      u32x4 v = u32x4{0u, 0u, 0u, 0u};
+      if (gz < p.D && gy < p.H && gx < p.W) v = *(const u32x4*)(dyin + pl * plane + (((long long)gz * p.H + gy) * p.W + gx) * 8);
+      *(u32x4*)(dys + pl * PLANE_Y + pix * 16) = v;
+    }
+    __syncthreads();
+    for (int ks = wave; ks < NKS; ks += 4) {                 // the four waves split the k-steps
+      const int f = 2 * ks + gh;                             // this lane's fragment (16 x voxels)
+      const int xh = f % FX, row = f / FX, fy = row % TY, fz = row / TY;
+      const int vbase = (fz * PY + fy) * PX + xh * 16 + gl * 8;      // first of the lane's 8 voxels, tap (0,0,0)
+      const V8 a0 = tr_frag2<T>(laneY + (unsigned)(2 * ks * 256), 64);
+      const V8 a1 = tr_frag2<T>(laneY + (unsigned)(2 * ks * 256) + 2 * PLANE_Y, 64);
 #pragma unroll
-      for (int c = 0; c < CIN; ++c) slab[((long long)(cob * 32 + co) * CIN + c) * TAPS + tap] = acc[k][c];
+      for (int ct = 0; ct < NT; ++ct) {
+        V8 b;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) b[j] = xs[vbase + j + col_off[ct]];
+        acc[0][ct] = mfma16<T>(a0, b, acc[0][ct]);
+        acc[1][ct] = mfma16<T>(a1, b, acc[1][ct]);
+      }
     }
   }
+  // sum the four waves' accumulators through LDS, then one slab row per workgroup
+  __syncthreads();
+  float* red = (float*)smem;                                  // [4 waves][32 co][KKP]
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) red[(wave * 32 + t * 16 + 4 * g + j) * KKP + ct * 16 + i16] = acc[t][ct][j];
+  __syncthreads();
+  float* slab = p.slab + ((long long)blockIdx.x * p.Cout + cob * 32) * KKP;
+  for (int i = tid; i < 32 * KKP; i += 256)
+    slab[i] = red[i] + red[32 * KKP + i] + red[2 * 32 * KKP + i] + red[3 * 32 * KKP + i];
+}
+
+// dW[co][c][tap] = sum_b slab[b][co][tap * Cin + c]
+__global__ __launch_bounds__(256) void first_wgrad_reduce_kernel(const float* __restrict__ slab, int nb, int Cout, int Cin, int taps,
+                                                                 int KKP, float* __restrict__ dW) {
+  const int total = Cout * Cin * taps;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int tap = i % taps, c = (i / taps) % Cin, co = i / (taps * Cin);
+  float s = 0.f;
+  for (int b = 0; b < nb; ++b) s += slab[((long long)b * Cout + co) * KKP + tap * Cin + c];
+  dW[i] = s;
 }
 
 }  // namespace
@@ -405,16 +439,18 @@ int iunet_convT_wgrad(int dtype, int nd, const void* x, long long x_ss, const vo
   return iunet_reduce_slab(bslab, nb, Cout, db, 1.0f, 0, stream);
 }
 
-int iunet_first_conv_wgrad_tiles(int nd, int N, int D, int H, int W) {
+int iunet_first_conv_wgrad_blocks(int nd, int N, int D, int H, int W) {
   const int TZ = nd == 3 ? 4 : 1, TY = nd == 3 ? 8 : 16, TX = nd == 3 ? 16 : 32;
-  return N * ((D + TZ - 1) / TZ) * ((H + TY - 1) / TY) * ((W + TX - 1) / TX);
+  const long long ntiles = (long long)N * ((D + TZ - 1) / TZ) * ((H + TY - 1) / TY) * ((W + TX - 1) / TX);
+  return (int)(ntiles < 512 ? ntiles : 512);
 }
 
-// slab: [tiles][Cout][Cin][taps] floats; reduce with iunet_reduce_slab
+// slab: iunet_first_conv_wgrad_blocks * Cout * 112 floats of scratch; dW fp32 [Cout][Cin][taps]
 int iunet_first_conv_wgrad(int dtype, int nd, const void* x, int in_dtype, const long long* in_strides, const void* dy,
-                           long long dy_ss, void* slab, int N, int D, int H, int W, int Cin, int Cout, void* stream) {
+                           long long dy_ss, void* slab, void* dW, int N, int D, int H, int W, int Cin, int Cout,
+                           void* stream) {
   DT_OK(dtype);
-  IUNET_REQUIRE(x && dy && slab && in_strides, "first_conv_wgrad: null pointer");
+  IUNET_REQUIRE(x && dy && slab && dW && in_strides, "first_conv_wgrad: null pointer");
   IUNET_REQUIRE(Cin >= 1 && Cin <= 4 && Cout % 32 == 0, "first_conv_wgrad: Cin 1..4, Cout multiple of 32");
   FirstWgradParams p;
   p.x = x; p.sN = in_strides[0]; p.sC = in_strides[1]; p.sD = in_strides[2]; p.sH = in_strides[3]; p.sW = in_strides[4];
@@ -422,13 +458,23 @@ int iunet_first_conv_wgrad(int dtype, int nd, const void* x, int in_dtype, const
   p.N = N; p.D = D; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
   const int TZ = nd == 3 ? 4 : 1, TY = nd == 3 ? 8 : 16, TX = nd == 3 ? 16 : 32;
   p.tilesZ = (D + TZ - 1) / TZ; p.tilesY = (H + TY - 1) / TY; p.tilesX = (W + TX - 1) / TX;
-  dim3 grid(p.tilesZ * p.tilesY * p.tilesX * N, Cout / 32);
-#define FW(TT, NDV, CI) hipLaunchKernelGGL((first_wgrad_kernel<TT, NDV, CI>), grid, dim3(256), 0, (hipStream_t)stream, p)
+  const int nb = iunet_first_conv_wgrad_blocks(nd, N, D, H, W);
+  const int taps = nd == 3 ? 27 : 9, KKP = ((taps * Cin + 15) / 16) * 16;
+  const int npix = (nd == 3 ? 6 : 1) * (TY + 2) * (TX + 2);
+  const int xs_bytes = ((Cin * npix * 2 + 255) / 256) * 256;
+  int lds = xs_bytes + 4 * (512 * 16 + 64);
+  if (lds < 4 * 32 * KKP * 4) lds = 4 * 32 * KKP * 4;
+  dim3 grid(nb, Cout / 32);
+#define FW(TT, NDV, CI) do { static bool s_ = false; if (!s_) { IUNET_CHECK_HIP(hipFuncSetAttribute((const void*)first_wgrad_kernel<TT, NDV, CI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); s_ = true; } \
+    hipLaunchKernelGGL((first_wgrad_kernel<TT, NDV, CI>), grid, dim3(256), lds, (hipStream_t)stream, p); } while (0)
 #define FW_CIN(TT, NDV) switch (Cin) { case 1: FW(TT, NDV, 1); break; case 2: FW(TT, NDV, 2); break; case 3: FW(TT, NDV, 3); break; default: FW(TT, NDV, 4); break; }
   if (dtype == 0) { if (nd == 3) { FW_CIN(f16, 3) } else { FW_CIN(f16, 2) } }
   else            { if (nd == 3) { FW_CIN(bf16, 3) } else { FW_CIN(bf16, 2) } }
 #undef FW_CIN
 #undef FW
+  const int total = Cout * Cin * taps;
+  hipLaunchKernelGGL(first_wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)slab, nb, Cout, Cin, taps, KKP, (float*)dW);
   IUNET_CHECK_HIP(hipGetLastError());
   return IUNET_OK;
 }

@@ -367,30 +367,53 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restr
   out[0] = (float)loss; out[1] = (float)dice_r; out[2] = (float)iou_r; out[3] = (float)mcc_r;
 }
 
-// backward through loss, softmax and the 1x1 head.  C0 <= 64.
-template <typename T, int NCLS>
+// backward through loss, softmax and the 1x1 head.  Each thread walks HB_ITER voxels and keeps its
+// dW / db partial sums in registers (PL planes x NCLS x 8 + NCLS floats), so the block reduction
+// (shuffles + one barrier per plane) is paid once per HB_ITER * 256 voxels.  Instantiated for
+// PL = 4 (base 32) and PL = 8 (base 64); wide heads (NCLS > 4) use HB_ITER = 1 to stay in registers.
+template <int NCLS> struct HeadBwdIter { static constexpr int value = NCLS <= 4 ? 8 : 1; };
+
+template <typename T, int NCLS, int PL>
 __global__ __launch_bounds__(256) void head_loss_bwd_kernel(HeadLossParams p) {
-  const long long v = (long long)blockIdx.x * 256 + threadIdx.x;
+  constexpr int ITER = (PL * NCLS <= 16) ? HeadBwdIter<NCLS>::value : 1;
+  constexpr int C0 = PL * 8;
   const int n = blockIdx.y;
-  const bool ok = v < p.vox;
-  const int C0 = p.planes * 8;
-  float dl[NCLS];
+  float accw[PL][NCLS][8], accb[NCLS];
 #pragma unroll
-  for (int c = 0; c < NCLS; ++c) dl[c] = 0.f;
-  const T* xin = (const T*)p.x + n * p.x_ss + (ok ? v : 0) * 8;
-  if (ok) {
+  for (int pl = 0; pl < PL; ++pl)
+#pragma unroll
+    for (int c = 0; c < NCLS; ++c)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) accw[pl][c][j] = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCLS; ++c) accb[c] = 0.f;
+  float wreg[NCLS][C0 > 32 ? 1 : C0];      // head weights in registers when they fit (base 32)
+  if (C0 <= 32) {
+#pragma unroll
+    for (int c = 0; c < NCLS; ++c)
+#pragma unroll
+      for (int k = 0; k < (C0 > 32 ? 1 : C0); ++k) wreg[c][k] = p.w[c * C0 + k];
+  }
+  auto W = [&](int c, int k) { return C0 <= 32 ? wreg[c][C0 > 32 ? 0 : k] : p.w[c * C0 + k]; };
+#pragma unroll 1
+  for (int it = 0; it < ITER; ++it) {
+    const long long v = ((long long)blockIdx.x * ITER + it) * 256 + threadIdx.x;
+    if (v >= p.vox) break;
+    const T* xin = (const T*)p.x + n * p.x_ss + v * 8;
+    V8T<T> xv[PL];
+#pragma unroll
+    for (int pl = 0; pl < PL; ++pl) xv[pl] = *(const V8T<T>*)(xin + (long long)pl * p.vox * 8);
     float l[NCLS];
 #pragma unroll
     for (int c = 0; c < NCLS; ++c) l[c] = p.bias[c];
-    for (int pl = 0; pl < p.planes; ++pl) {
-      const V8T<T> xv = *(const V8T<T>*)(xin + (long long)pl * p.vox * 8);
+#pragma unroll
+    for (int pl = 0; pl < PL; ++pl)
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const float a = to_f32<T>(xv[j]);
+        const float a = to_f32<T>(xv[pl][j]);
 #pragma unroll
-        for (int c = 0; c < NCLS; ++c) l[c] = fmaf(a, p.w[c * C0 + pl * 8 + j], l[c]);
+        for (int c = 0; c < NCLS; ++c) l[c] = fmaf(a, W(c, pl * 8 + j), l[c]);
       }
-    }
     float mx = l[0];
 #pragma unroll
     for (int c = 1; c < NCLS; ++c) mx = fmaxf(mx, l[c]);
@@ -398,7 +421,7 @@ __global__ __launch_bounds__(256) void head_loss_bwd_kernel(HeadLossParams p) {
 #pragma unroll
     for (int c = 0; c < NCLS; ++c) { e[c] = __expf(l[c] - mx); s += e[c]; }
     const float inv = 1.f / s;
-    float g[NCLS], dot = 0.f;
+    float g[NCLS], dl[NCLS], dot = 0.f;
 #pragma unroll
     for (int c = 0; c < NCLS; ++c) {
       const float pr = e[c] * inv;
@@ -410,44 +433,38 @@ __global__ __launch_bounds__(256) void head_loss_bwd_kernel(HeadLossParams p) {
       dot += g[c] * pr;
     }
 #pragma unroll
-    for (int c = 0; c < NCLS; ++c) dl[c] = e[c] * (g[c] - dot) * p.loss_scale;     // softmax backward
-    // dx = W^T dl
+    for (int c = 0; c < NCLS; ++c) { dl[c] = e[c] * (g[c] - dot) * p.loss_scale; accb[c] += dl[c]; }   // softmax backward
     T* dxo = (T*)p.dx + n * p.dx_ss + v * 8;
-    for (int pl = 0; pl < p.planes; ++pl) {
+#pragma unroll
+    for (int pl = 0; pl < PL; ++pl) {
       V8T<T> o;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
+        const float xa = to_f32<T>(xv[pl][j]);
         float a = 0.f;
 #pragma unroll
-        for (int c = 0; c < NCLS; ++c) a = fmaf(dl[c], p.w[c * C0 + pl * 8 + j], a);
-        o[j] = from_f32<T>(a);
+        for (int c = 0; c < NCLS; ++c) { a = fmaf(dl[c], W(c, pl * 8 + j), a); accw[pl][c][j] = fmaf(dl[c], xa, accw[pl][c][j]); }
+        o[j] = from_f32<T>(a);                        // dx = W^T dl
       }
       *(V8T<T>*)(dxo + (long long)pl * p.vox * 8) = o;
     }
   }
-  // dW[c][ch] = sum_v dl[c] * x[ch], db[c] = sum_v dl[c]: block partials
   // slab layout per part: [planes][NCLS][8] weight partials, then [NCLS] bias partials
   __shared__ float red[4 * NCLS * 8];
   const long long part = (long long)n * gridDim.x + blockIdx.x;
   float* slab = p.dwslab + part * (NCLS * (C0 + 1));
-  for (int pl = 0; pl < p.planes; ++pl) {
-    V8T<T> xv;
-    if (ok) xv = *(const V8T<T>*)(xin + (long long)pl * p.vox * 8);
+#pragma unroll
+  for (int pl = 0; pl < PL; ++pl) {
     float vals[NCLS * 8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float a = ok ? to_f32<T>(xv[j]) : 0.f;
+    for (int c = 0; c < NCLS; ++c)
 #pragma unroll
-      for (int c = 0; c < NCLS; ++c) vals[c * 8 + j] = dl[c] * a;
-    }
+      for (int j = 0; j < 8; ++j) vals[c * 8 + j] = accw[pl][c][j];
     __syncthreads();                       // previous plane's LDS partials are consumed
     block_reduce_store<NCLS * 8>(vals, red, slab + pl * NCLS * 8);
   }
-  float bv[NCLS];
-#pragma unroll
-  for (int c = 0; c < NCLS; ++c) bv[c] = dl[c];
   __syncthreads();
-  block_reduce_store<NCLS>(bv, red, slab + p.planes * NCLS * 8);
+  block_reduce_store<NCLS>(accb, red, slab + PL * NCLS * 8);
 }
 
 // out[i] = alpha * sum_p slab[p][i] (+ out[i] if accumulate); fixed order.
@@ -569,6 +586,12 @@ int iunet_maxpool_bwd(int dtype, int nd, const void* z, long long z_ss, const vo
 
 int iunet_head_loss_num_parts(int N, long long vox) { return N * (int)((vox + 255) / 256); }
 
+// partial-sum rows written by iunet_head_loss_bwd (each workgroup covers 256 * iter voxels)
+int iunet_head_loss_bwd_num_parts(int N, long long vox, int ncls, int C0) {
+  const int iter = (ncls <= 4 && (C0 / 8) * ncls <= 16) ? 8 : 1;
+  return N * (int)((vox + 256LL * iter - 1) / (256LL * iter));
+}
+
 #define HEAD_SWITCH(KERN, TT)                                                                                   \
   switch (ncls) {                                                                                               \
     case 2: hipLaunchKernelGGL((KERN<TT, 2>), grid, dim3(256), 0, (hipStream_t)stream, p); break;               \
@@ -614,8 +637,16 @@ int iunet_head_loss_bwd(int dtype, const void* x, long long x_ss, int C0, const 
   p.x = x; p.x_ss = x_ss; p.planes = C0 / 8; p.w = (const float*)w; p.bias = (const float*)bias;
   p.target = target; p.weight = weight; p.tdtype = tdtype; p.coef = (const float*)coef; p.loss_scale = loss_scale;
   p.dx = dx; p.dx_ss = dx_ss; p.dwslab = (float*)dwslab; p.N = N; p.vox = vox;
-  dim3 grid((unsigned)((vox + 255) / 256), N);
-  if (dtype == 0) { HEAD_SWITCH(head_loss_bwd_kernel, f16) } else { HEAD_SWITCH(head_loss_bwd_kernel, bf16) }
+  IUNET_REQUIRE(C0 == 32 || C0 == 64, "head_loss_bwd: head input must have 32 or 64 channels (got %d)", C0);
+  dim3 grid((unsigned)(iunet_head_loss_bwd_num_parts(N, vox, ncls, C0) / N), N);
+#define HB(TT, NC, PLN) hipLaunchKernelGGL((head_loss_bwd_kernel<TT, NC, PLN>), grid, dim3(256), 0, (hipStream_t)stream, p)
+#define HB_SWITCH(TT, PLN) switch (ncls) { case 2: HB(TT, 2, PLN); break; case 3: HB(TT, 3, PLN); break; case 4: HB(TT, 4, PLN); break; \
+    case 5: HB(TT, 5, PLN); break; case 6: HB(TT, 6, PLN); break; case 7: HB(TT, 7, PLN); break; case 8: HB(TT, 8, PLN); break; \
+    case 9: HB(TT, 9, PLN); break; default: HB(TT, 10, PLN); break; }
+  if (dtype == 0) { if (C0 == 32) { HB_SWITCH(f16, 4) } else { HB_SWITCH(f16, 8) } }
+  else { if (C0 == 32) { HB_SWITCH(bf16, 4) } else { HB_SWITCH(bf16, 8) } }
+#undef HB_SWITCH
+#undef HB
   IUNET_CHECK_HIP(hipGetLastError());
   return IUNET_OK;
 }

@@ -49,6 +49,7 @@ _SIGS = {
     'iunet_maxpool_bwd': [c_int, c_int, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_ll, c_int, c_int, c_int, c_int,
                           c_int, c_int, c_void_p],
     'iunet_head_loss_num_parts': [c_int, c_ll],
+    'iunet_head_loss_bwd_num_parts': [c_int, c_ll, c_int, c_int],
     'iunet_head_loss_fwd': [c_int, c_void_p, c_ll, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int,
                             c_void_p, c_void_p, c_void_p, c_int, c_ll, c_void_p],
     'iunet_head_loss_bwd': [c_int, c_void_p, c_ll, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int,
@@ -66,8 +67,8 @@ _SIGS = {
     'iunet_convT_wgrad_blocks': [c_int] * 7,
     'iunet_convT_wgrad': [c_int, c_int, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_void_p, c_void_p, c_void_p,
                           c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
-    'iunet_first_conv_wgrad_tiles': [c_int] * 5,
-    'iunet_first_conv_wgrad': [c_int, c_int, c_void_p, c_int, ctypes.POINTER(c_ll), c_void_p, c_ll, c_void_p,
+    'iunet_first_conv_wgrad_blocks': [c_int] * 5,
+    'iunet_first_conv_wgrad': [c_int, c_int, c_void_p, c_int, ctypes.POINTER(c_ll), c_void_p, c_ll, c_void_p, c_void_p,
                                c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
 }
 # functions that return a size / count instead of a status

@@ -156,7 +156,7 @@ class TrainEngine:
                     ws[f'{k}.{name}'] = f32(b)
                 if name == 'enc0.conv1':
                     max_stats = max(max_stats, lib.iunet_conv3_num_tiles(self.dim, N, *d) * b * 2)
-                    max_wslab = max(max_wslab, lib.iunet_first_conv_wgrad_tiles(self.dim, N, *d) * b * a * self.taps)
+                    max_wslab = max(max_wslab, lib.iunet_first_conv_wgrad_blocks(self.dim, N, *d) * b * 112)
                 else:
                     max_stats = max(max_stats, lib.iunet_conv3_num_tiles(self.dim, N, *d) * b * 2)
                     max_wslab = max(max_wslab, lib.iunet_conv3_wgrad_slab_floats(self.dim, N, *d, a, b))
@@ -283,10 +283,8 @@ class TrainEngine:
         gw = self.g(name + '.weight')
         if name == 'enc0.conv1':
             x, xs = x_raw
-            nt = nv.lib().iunet_first_conv_wgrad_tiles(self.dim, N, *d)
             nv.call('iunet_first_conv_wgrad', self.dt, self.dim, nv.ptr(x), nv.IN_DTYPE_CODE[x.dtype], nv.ll_array(xs),
-                    self._P(dy), co * v, nv.ptr(ws['wslab']), N, d[0], d[1], d[2], ci, co, s)
-            nv.call('iunet_reduce_slab', nv.ptr(ws['wslab']), nt, co * ci * self.taps, nv.ptr(gw), 1.0, 0, s)
+                    self._P(dy), co * v, nv.ptr(ws['wslab']), nv.ptr(gw), N, d[0], d[1], d[2], ci, co, s)
         else:
             nv.call('iunet_conv3_wgrad', self.dt, self.dim, x_ptr, x_ss, self._P(dy), co * v, nv.ptr(ws['wslab']),
                     nv.ptr(gw), 1.0, N, d[0], d[1], d[2], ci, co, s)
@@ -301,7 +299,7 @@ class TrainEngine:
         v0 = _vox(dims[0])
         feat = ws['z.dec0.conv2']
         dfeat = ws['dz.dec0.conv2']
-        nparts = nv.lib().iunet_head_loss_num_parts(N, v0)
+        nparts = nv.lib().iunet_head_loss_bwd_num_parts(N, v0, self.ncls, ch[0])
         nv.call('iunet_head_loss_bwd', self.dt, self._P(feat), ch[0] * v0, ch[0], nv.ptr(self.p('head.weight')),
                 nv.ptr(self.p('head.bias')), self.ncls, nv.ptr(y), nv.ptr(w), tdt, nv.ptr(ws['coef']),
                 self.loss_scale, self._P(dfeat), ch[0] * v0, nv.ptr(ws['hslab']), N, v0, s)

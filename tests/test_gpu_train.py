@@ -172,14 +172,13 @@ def test_first_conv_wgrad(nv, nd):
     D, H, W = shape if nd == 3 else (1,) + shape
     vox = D * H * W
     taps = 3 ** nd
-    nt = nv.lib().iunet_first_conv_wgrad_tiles(nd, N, D, H, W)
-    slab = torch.empty(nt * cout * cin * taps, device='cuda')
+    nb = nv.lib().iunet_first_conv_wgrad_blocks(nd, N, D, H, W)
+    slab = torch.empty(nb * cout * 112, device='cuda')
     dyb = blocked(dy, torch.float16).cuda()
     xd = xi.cuda()
+    dW = torch.full((cout * cin * taps,), float('nan'), device='cuda')
     nv.call('iunet_first_conv_wgrad', 0, nd, nv.ptr(xd), 2, nv.ll_array((cin * vox, vox, H * W, W, 1)), nv.ptr(dyb),
-            cout * vox, nv.ptr(slab), N, D, H, W, cin, cout, nv.stream())
-    dW = torch.empty(cout * cin * taps, device='cuda')
-    nv.call('iunet_reduce_slab', nv.ptr(slab), nt, cout * cin * taps, nv.ptr(dW), 1.0, 0, nv.stream())
+            cout * vox, nv.ptr(slab), nv.ptr(dW), N, D, H, W, cin, cout, nv.stream())
     torch.cuda.synchronize()
     assert torch.allclose(dW.cpu().reshape(w.shape), w.grad, rtol=1e-4, atol=1e-3)
 
@@ -221,11 +220,12 @@ def test_head_loss_fwd_bwd_vs_reference_pinned_oracle(nv, kind, weighted):
     nv.call('iunet_head_loss_fwd', 0, nv.ptr(xb), C0 * vox, C0, nv.ptr(wd), nv.ptr(bd), ncls, nv.ptr(yd), nv.ptr(wtd), 0,
             LOSS_KINDS[kind], nv.ptr(lslab), nv.ptr(out4), nv.ptr(coef), N, vox, nv.stream())
     dx = torch.empty_like(xb)
-    hslab = torch.empty(nparts * ncls * (C0 + 1), device=dev)
+    nparts_b = nv.lib().iunet_head_loss_bwd_num_parts(N, vox, ncls, C0)
+    hslab = torch.empty(nparts_b * ncls * (C0 + 1), device=dev)
     nv.call('iunet_head_loss_bwd', 0, nv.ptr(xb), C0 * vox, C0, nv.ptr(wd), nv.ptr(bd), ncls, nv.ptr(yd), nv.ptr(wtd), 0,
             nv.ptr(coef), 1.0, nv.ptr(dx), C0 * vox, nv.ptr(hslab), N, vox, nv.stream())
     htmp = torch.empty(ncls * (C0 + 1), device=dev)
-    nv.call('iunet_reduce_slab', nv.ptr(hslab), nparts, ncls * (C0 + 1), nv.ptr(htmp), 1.0, 0, nv.stream())
+    nv.call('iunet_reduce_slab', nv.ptr(hslab), nparts_b, ncls * (C0 + 1), nv.ptr(htmp), 1.0, 0, nv.stream())
     torch.cuda.synchronize()
     o = out4.cpu()
     assert abs(o[0].item() - want) <= 2e-5 * max(1.0, abs(want)), (o[0].item(), want)
