@@ -68,21 +68,33 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   }
 }
 
-// z = relu(scale[c] * y + shift[c]), blocked layout, 16 B per thread
+// z = relu(scale[c] * y + shift[c]), blocked layout.  The channel plane is a grid dimension, so the
+// per-channel constants are wave-uniform (scalar loads); two 16-byte items per thread in flight.
 template <typename T>
 __global__ __launch_bounds__(256) void bn_relu_fwd_kernel(const T* __restrict__ y, long long y_ss, T* __restrict__ z,
                                                           long long z_ss, const float* __restrict__ scale,
                                                           const float* __restrict__ shift, int planes, long long vox) {
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= vox * planes) return;
-  const int n = blockIdx.y;
-  const int pl = (int)(i / vox);
-  const V8T<T> v = *(const V8T<T>*)(y + n * y_ss + i * 8);
-  V8T<T> o;
+  const int pl = blockIdx.y, n = blockIdx.z;
+  const long long v0 = (long long)blockIdx.x * 512 + threadIdx.x;
+  float sc[8], sh[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j)
-    o[j] = from_f32<T>(fmaxf(fmaf(scale[pl * 8 + j], to_f32<T>(v[j]), shift[pl * 8 + j]), 0.f));
-  *(V8T<T>*)(z + n * z_ss + i * 8) = o;
+  for (int j = 0; j < 8; ++j) { sc[j] = scale[pl * 8 + j]; sh[j] = shift[pl * 8 + j]; }
+  const long long base = (long long)pl * vox * 8;
+  V8T<T> in[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const long long v = v0 + u * 256;
+    if (v < vox) in[u] = *(const V8T<T>*)(y + n * y_ss + base + v * 8);
+  }
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const long long v = v0 + u * 256;
+    if (v >= vox) continue;
+    V8T<T> o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = from_f32<T>(fmaxf(fmaf(sc[j], to_f32<T>(in[u][j]), sh[j]), 0.f));
+    *(V8T<T>*)(z + n * z_ss + base + v * 8) = o;
+  }
 }
 
 // BN+ReLU backward, pass 1: per-channel s1 = sum(dyh), s2 = sum(dyh * xhat), dyh = dz * (z > 0).
@@ -155,7 +167,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
   }
 }
 
-// pass 2: dy = a * (dyh - c1 - xhat * c2)
+// pass 2: dy = a * (dyh - c1 - xhat * c2); plane = grid dimension (wave-uniform constants), two items per thread
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dz, long long dz_ss, const T* __restrict__ z,
                                                            long long z_ss, const T* __restrict__ y, long long y_ss,
@@ -163,27 +175,41 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ invstd, const float* __restrict__ coef,
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
                                                            int planes, long long vox) {
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= vox * planes) return;
-  const int n = blockIdx.y;
-  const int pl = (int)(i / vox);
-  const V8T<T> g = *(const V8T<T>*)(dz + n * dz_ss + i * 8);
-  const V8T<T> yy = *(const V8T<T>*)(y + n * y_ss + i * 8);
-  V8T<T> zz;
-  if (z) zz = *(const V8T<T>*)(z + n * z_ss + i * 8);
-  else {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) zz[j] = from_f32<T>(fmaf(scale[pl * 8 + j], to_f32<T>(yy[j]), shift[pl * 8 + j]));
-  }
-  V8T<T> o;
+  const int pl = blockIdx.y, n = blockIdx.z;
+  const long long v0 = (long long)blockIdx.x * 512 + threadIdx.x;
+  float mu[8], is[8], ca[8], c1[8], c2[8], sc[8], sh[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int c = pl * 8 + j;
-    const float d = to_f32<T>(zz[j]) > 0.f ? to_f32<T>(g[j]) : 0.f;
-    const float xh = (to_f32<T>(yy[j]) - mean[c]) * invstd[c];
-    o[j] = from_f32<T>(coef[c * 3] * (d - coef[c * 3 + 1] - xh * coef[c * 3 + 2]));
+    mu[j] = mean[c]; is[j] = invstd[c]; ca[j] = coef[c * 3]; c1[j] = coef[c * 3 + 1]; c2[j] = coef[c * 3 + 2];
+    sc[j] = scale[c]; sh[j] = shift[c];
   }
-  *(V8T<T>*)(dy + n * dy_ss + i * 8) = o;
+  const long long base = (long long)pl * vox * 8;
+  V8T<T> g[2], yy[2], zz[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const long long v = v0 + u * 256;
+    if (v < vox) {
+      g[u] = *(const V8T<T>*)(dz + n * dz_ss + base + v * 8);
+      yy[u] = *(const V8T<T>*)(y + n * y_ss + base + v * 8);
+      if (z) zz[u] = *(const V8T<T>*)(z + n * z_ss + base + v * 8);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const long long v = v0 + u * 256;
+    if (v >= vox) continue;
+    V8T<T> o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float yv = to_f32<T>(yy[u][j]);
+      const float zv = z ? to_f32<T>(zz[u][j]) : to_f32<T>(from_f32<T>(fmaf(sc[j], yv, sh[j])));
+      const float d = zv > 0.f ? to_f32<T>(g[u][j]) : 0.f;
+      const float xh = (yv - mu[j]) * is[j];
+      o[j] = from_f32<T>(ca[j] * (d - c1[j] - xh * c2[j]));
+    }
+    *(V8T<T>*)(dy + n * dy_ss + base + v * 8) = o;
+  }
 }
 
 // ------------------------------------------------------------------ max-pool backward (+ skip gradient)
@@ -538,8 +564,7 @@ int iunet_bn_finalize(const void* slab, int nparts, int C, double count, const v
 int iunet_bn_relu_fwd(int dtype, const void* y, long long y_ss, void* z, long long z_ss, const void* scale,
                       const void* shift, int C, int N, long long vox, void* stream) {
   DT_OK(dtype);
-  const long long total = vox * (C / 8);
-  dim3 grid((unsigned)((total + 255) / 256), N);
+  dim3 grid((unsigned)((vox + 511) / 512), C / 8, N);
   if (dtype == 0) hipLaunchKernelGGL(bn_relu_fwd_kernel<f16>, grid, dim3(256), 0, (hipStream_t)stream, (const f16*)y, y_ss, (f16*)z, z_ss, (const float*)scale, (const float*)shift, C / 8, vox);
   else hipLaunchKernelGGL(bn_relu_fwd_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)y, y_ss, (bf16*)z, z_ss, (const float*)scale, (const float*)shift, C / 8, vox);
   IUNET_CHECK_HIP(hipGetLastError());
@@ -564,8 +589,7 @@ int iunet_bn_relu_bwd(int dtype, const void* dz, long long dz_ss, const void* z,
   else hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16>, g1, dim3(256), 0, (hipStream_t)stream, (const bf16*)dz, dz_ss, (const bf16*)z, z_ss, (const bf16*)y, y_ss, (const float*)mean, (const float*)invstd, (const float*)scale, (const float*)shift, C, vox, per_block, (float*)slab);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, (const float*)slab, chunks * N, C,
                      (double)N * (double)vox, (const float*)gamma, (const float*)invstd, (float*)dgamma, (float*)dbeta, (float*)coef);
-  const long long total = vox * (C / 8);
-  dim3 g2((unsigned)((total + 255) / 256), N);
+  dim3 g2((unsigned)((vox + 511) / 512), C / 8, N);
   if (dtype == 0) hipLaunchKernelGGL(bn_bwd_apply_kernel<f16>, g2, dim3(256), 0, (hipStream_t)stream, (const f16*)dz, dz_ss, (const f16*)z, z_ss, (const f16*)y, y_ss, (f16*)dy, dy_ss, (const float*)mean, (const float*)invstd, (const float*)coef, (const float*)scale, (const float*)shift, C / 8, vox);
   else hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16>, g2, dim3(256), 0, (hipStream_t)stream, (const bf16*)dz, dz_ss, (const bf16*)z, z_ss, (const bf16*)y, y_ss, (bf16*)dy, dy_ss, (const float*)mean, (const float*)invstd, (const float*)coef, (const float*)scale, (const float*)shift, C / 8, vox);
   IUNET_CHECK_HIP(hipGetLastError());
