@@ -152,3 +152,32 @@ def test_gather_blend_quantise_bit_exact(golden_dir):
     assert np.array_equal(final.cpu().numpy(), of)          # same inputs -> bit-exact vs the oracle
     d = np.abs(final.cpu().numpy().astype(int) - g['blend_final'].astype(int))
     assert d.max() <= 1 and (d > 0).mean() < 1e-3            # golden used torch's softmax for the stub
+
+
+def test_c5_shape_5_level_base64_4_class_forward_and_step():
+    """BASELINE.json configs[4] architecture (3-D, 5 levels, base 64, 4 classes) in bf16 activations:
+    forward parity with the oracle and one native training step (the fp8-weight variant of that config
+    is not built; this pins the architecture generality of the engine: levels, base, head width)."""
+    import warnings
+    from interactive_unet.unet import UNet
+    from interactive_unet.train_engine import TrainEngine
+    dim, levels, base, ncls = 3, 5, 64, 4
+    p = unet_ref.init_params(dim=dim, levels=levels, base=base, ncls=ncls, seed=4, randomize_bn=True)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        m = UNet(num_classes=ncls, dim=dim, levels=levels, base=base, act_dtype='bf16', pretrained=False)
+    m.load_named(p)
+    m = m.cuda().eval()
+    shape = (32, 32, 48)
+    x = torch.tensor(_smooth(shape, 3))[None, None]
+    probs = m(x.cuda()).cpu()
+    ref = unet_ref.forward(p, x.float() / 255.0, dim=dim, levels=levels, act_dtype=torch.bfloat16)
+    err = (probs - ref).abs().max().item()
+    print(f'C5-shape forward: max |prob - oracle| = {err:.2e}')
+    assert err < 3e-2                                   # bf16 storage through 22 convs (see tolerance note above)
+    lab = torch.tensor(_smooth(shape, 4))[None] // 64
+    y = torch.stack([(lab == c) for c in range(ncls)], 1).float()
+    te = TrainEngine(m, lr=1e-3, loss_kind='dice_ce')
+    out1 = te.train_step(x, y, None)
+    out2 = te.train_step(x, y, None)
+    assert np.isfinite(out1['Loss']) and np.isfinite(out2['Loss']) and out2['Loss'] < out1['Loss'] + 0.05
