@@ -46,6 +46,13 @@ int iunet_pack_first_conv(int dtype, const void* w, const void* scale, void* dst
 /* ConvTranspose k2 s2 weights fp32 [Cin][Cout][2^d]. */
 int iunet_pack_convT(int dtype, const void* w, void* dst, int Cin, int Cout, int npos, void* stream);
 
+/* All layers in one launch: `descs` = device array of n descriptors (struct layout: csrc/pack_batch.hip PackDesc,
+ * mirrored by interactive_unet/_native.py; iunet_pack_desc_bytes() = its size).  kind 0/1 conv3 layout 0/1, 2 first
+ * conv, 3 convT, 4 convT data-gradient; a non-NULL gamma folds BatchNorm (scale = gamma / sqrt(var + eps)) and writes
+ * the folded bias.  Element mappings are identical to the per-layer entry points above. */
+int iunet_pack_desc_bytes(void);
+int iunet_pack_batch(const void* descs, int n, void* stream);
+
 /* ---- forward kernels (replace the smp conv stack under unet.py:65-69) ----------------- */
 /* 3^d conv, stride 1, pad 1, implicit GEMM on MFMA.  epi: 0 raw, 1 +bias, 2 +bias+ReLU.
  * stats (optional): fp32 [iunet_conv3_num_tiles][Cout][2] partial sum / sum of squares of

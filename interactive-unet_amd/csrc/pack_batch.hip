@@ -1,0 +1,134 @@
+// One launch packs every layer of the network (after each optimiser step, and when BatchNorm is folded for
+// inference): the per-layer pack kernels are a few microseconds of work each behind ~5 us of launch latency,
+// ~150 launches per step.  A descriptor table in device memory (built once by the host: all pointers are
+// stable) drives one kernel; blockIdx.y selects the layer.  The element mappings are the ones of the per-layer
+// kernels (conv3_mfma.hip, pointwise.hip, train_misc.hip) -- tests/test_gpu_kernels.py checks bit equality.
+#include "common.h"
+
+namespace {
+
+struct PackDesc {                // mirrored by interactive_unet/_native.py: PackDesc (ctypes)
+  const float* w;                // fp32 master weights
+  const float* gamma;            // BatchNorm fold (all four or none): scale = gamma / sqrt(var + eps)
+  const float* beta;
+  const float* mean;
+  const float* var;
+  float* bias_out;               // folded bias [Cout] = beta - mean * scale (or null)
+  void* dst;                     // packed operator
+  long long total;               // elements of dst
+  int Cout, Cin, taps;           // original operator dims (convT: Cin, Cout, npos in `taps`)
+  int kind;                      // 0 conv3 layout 0, 1 conv3 K16 (layout 1), 2 first conv, 3 convT fwd, 4 convT dgrad
+  int dgrad;                     // conv3 only: data-gradient operator
+  int dtype;                     // 0 f16, 1 bf16
+  float eps;
+  int pad_;
+};
+
+// The fold is the IEEE fp32 formula of the host / oracle (oracle/unet_ref.py: fold_bn): every operation rounded
+// on its own (no fma contraction; hipcc's default sqrt and divide are correctly rounded).
+__device__ __forceinline__ float fold_scale(const PackDesc& d, int co) {
+#pragma clang fp contract(off)
+  if (!d.gamma) return 1.0f;
+  const float s = d.var[co] + d.eps;
+  return d.gamma[co] / sqrtf(s);
+}
+__device__ __forceinline__ float fold_bias(const PackDesc& d, int co) {
+#pragma clang fp contract(off)
+  const float t = d.mean[co] * fold_scale(d, co);
+  return d.beta[co] - t;
+}
+__device__ __forceinline__ float mul_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+
+__device__ __forceinline__ float elem(const PackDesc& d, long long i) {
+  long long r = i;
+  const int j = r & 7; r >>= 3;
+  const int lane = r & 63; r >>= 6;
+  const int row = lane & 15, qq = lane >> 4;
+  const float* w = d.w;
+  if (d.kind == 0) {                                   // [cob][chunk32][tap][MI][64][8]
+    const int CoutP = d.dgrad ? d.Cin : d.Cout, CinP = d.dgrad ? d.Cout : d.Cin;
+    const int MI = (CoutP % 64 == 0) ? 4 : 2, nchunk = CinP >> 5;
+    const int m = r % MI; r /= MI;
+    const int tap = r % d.taps; r /= d.taps;
+    const int chunk = r % nchunk, cob = r / nchunk;
+    const int co = cob * 16 * MI + 32 * (m >> 1) + 8 * (row >> 2) + 4 * (m & 1) + (row & 3);
+    const int ci = chunk * 32 + 8 * qq + j;
+    if (!d.dgrad) return mul_rn(w[((long long)co * d.Cin + ci) * d.taps + tap], fold_scale(d, co));
+    return w[((long long)ci * d.Cin + co) * d.taps + (d.taps - 1 - tap)];
+  }
+  if (d.kind == 1) {                                   // [cob32][chunk16][column pair][dy][2][64][8]
+    const int CinP = d.dgrad ? d.Cout : d.Cin;
+    const int ncol = d.taps / 3, ncmb = (ncol + 1) / 2, nchunk = CinP >> 4;
+    const int m = r & 1; r >>= 1;
+    const int dy = r % 3; r /= 3;
+    const int c = r % ncmb; r /= ncmb;
+    const int chunk = r % nchunk, cob = r / nchunk;
+    const int co = cob * 32 + 8 * (row >> 2) + 4 * m + (row & 3);
+    const int ci = chunk * 16 + 8 * (qq & 1) + j;
+    const int col = 2 * c + (qq >> 1);
+    if (col >= ncol) return 0.f;
+    const int tap = ((col / 3) * 3 + dy) * 3 + (col % 3);
+    if (!d.dgrad) return mul_rn(w[((long long)co * d.Cin + ci) * d.taps + tap], fold_scale(d, co));
+    return w[((long long)ci * d.Cin + co) * d.taps + (d.taps - 1 - tap)];
+  }
+  if (d.kind == 2) {                                   // first conv: [cob32][kstep][2][64][8], k = tap * Cin + c
+    const int KK = d.taps * d.Cin, KS = (KK + 31) / 32;
+    const int t = r & 1; r >>= 1;
+    const int ks = r % KS, cob = r / KS;
+    const int co = cob * 32 + 8 * (row >> 2) + 4 * t + (row & 3);
+    const int k = 32 * ks + 8 * qq + j;
+    if (k >= KK) return 0.f;
+    return mul_rn(w[(co * d.Cin + k % d.Cin) * d.taps + k / d.Cin], fold_scale(d, co));
+  }
+  const int npos = d.taps;
+  if (d.kind == 3) {                                   // convT fwd: [cob32][kstep][pos][t][64][8]
+    const int nk = d.Cin >> 5;
+    const int t = r & 1; r >>= 1;
+    const int s = r % npos; r /= npos;
+    const int ks = r % nk, cob = r / nk;
+    const int co = cob * 32 + 8 * (row >> 2) + 4 * t + (row & 3);
+    const int ci = ks * 32 + 8 * qq + j;
+    return w[((long long)ci * d.Cout + co) * npos + s];
+  }
+  {                                                    // convT dgrad: [cib32][pos][kc][t][64][8]
+    const int nk = d.Cout >> 5;
+    const int t = r & 1; r >>= 1;
+    const int kc = r % nk; r /= nk;
+    const int s = r % npos, cib = r / npos;
+    const int ci = cib * 32 + 8 * (row >> 2) + 4 * t + (row & 3);
+    const int co = kc * 32 + 8 * qq + j;
+    return w[((long long)ci * d.Cout + co) * npos + s];
+  }
+}
+
+__global__ __launch_bounds__(256) void pack_batch_kernel(const PackDesc* __restrict__ descs) {
+  const PackDesc d = descs[blockIdx.y];
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < d.total; i += (long long)gridDim.x * 256) {
+    const float v = elem(d, i);
+    if (d.dtype == 0) ((f16*)d.dst)[i] = from_f32<f16>(v);
+    else ((bf16*)d.dst)[i] = from_f32<bf16>(v);
+  }
+  if (d.bias_out && blockIdx.x == 0) {
+    for (int co = threadIdx.x; co < d.Cout; co += 256)      // separately rounded, as the host formula beta - mean * scale
+      d.bias_out[co] = fold_bias(d, co);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int iunet_pack_desc_bytes(void) { return (int)sizeof(PackDesc); }
+
+// descs: device array of `n` descriptors (layout: see PackDesc above / _native.PackDesc)
+int iunet_pack_batch(const void* descs, int n, void* stream) {
+  IUNET_REQUIRE(descs && n > 0, "pack_batch: empty descriptor table");
+  hipLaunchKernelGGL(pack_batch_kernel, dim3(64, n), dim3(256), 0, (hipStream_t)stream, (const PackDesc*)descs);
+  IUNET_CHECK_HIP(hipGetLastError());
+  return IUNET_OK;
+}
+
+}  // extern "C"

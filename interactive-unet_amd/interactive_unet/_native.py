@@ -24,6 +24,7 @@ _SIGS = {
     'iunet_pack_conv3': [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     'iunet_pack_first_conv': [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     'iunet_pack_convT': [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    'iunet_pack_batch': [c_void_p, c_int, c_void_p],
     'iunet_conv3_fwd': [c_int, c_int, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_void_p, c_void_p,
                         c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     'iunet_conv3_pick_layout': [c_int] * 7,
@@ -72,6 +73,7 @@ _SIGS = {
                                c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
 }
 # functions that return a size / count instead of a status
+_INT_RETURN = ['iunet_pack_desc_bytes']
 _LL_RETURN = {'iunet_conv3_wgrad_slab_floats': [c_int] * 7, 'iunet_pack_conv3_elems': [c_int] * 4,
               'iunet_pack_first_conv_elems': [c_int] * 3}
 
@@ -94,6 +96,9 @@ def lib():
             fn = getattr(l, name)          # AttributeError here = header/library mismatch
             fn.argtypes = args
             fn.restype = c_int
+        for name in _INT_RETURN:
+            getattr(l, name).restype = c_int
+            getattr(l, name).argtypes = []
         for name, args in _LL_RETURN.items():
             fn = getattr(l, name)
             fn.argtypes = args
@@ -103,7 +108,7 @@ def lib():
 
 
 def exported_symbols():
-    return ['iunet_last_error'] + list(_SIGS) + list(_LL_RETURN)
+    return ['iunet_last_error'] + list(_SIGS) + list(_LL_RETURN) + list(_INT_RETURN)
 
 
 def check(status):
@@ -117,6 +122,38 @@ def call(name, *args):
 
 def pack_conv3_elems(cout, cin, taps, mode=0):
     return int(lib().iunet_pack_conv3_elems(cout, cin, taps, mode))
+
+
+class PackDesc(ctypes.Structure):
+    """One layer of iunet_pack_batch (mirror of csrc/pack_batch.hip: PackDesc)."""
+    _fields_ = [('w', c_void_p), ('gamma', c_void_p), ('beta', c_void_p), ('mean', c_void_p), ('var', c_void_p),
+                ('bias_out', c_void_p), ('dst', c_void_p), ('total', c_ll), ('Cout', c_int), ('Cin', c_int),
+                ('taps', c_int), ('kind', c_int), ('dgrad', c_int), ('dtype', c_int), ('eps', c_float), ('pad_', c_int)]
+
+
+def make_desc(w, dst, cout, cin, taps, kind, dtype, dgrad=0, bn=None, bias_out=None, eps=1e-5):
+    d = PackDesc()
+    d.w, d.dst, d.total = w.data_ptr(), dst.data_ptr(), dst.numel()
+    d.Cout, d.Cin, d.taps, d.kind, d.dgrad, d.dtype, d.eps = cout, cin, taps, kind, int(dgrad), DTYPE_CODE[dtype], eps
+    if bn is not None:
+        d.gamma, d.beta, d.mean, d.var = [t.data_ptr() for t in bn]
+        d.bias_out = None if bias_out is None else bias_out.data_ptr()
+    return d
+
+
+class PackTable:
+    """Descriptor table of iunet_pack_batch in device memory; `sources` keeps the tensors whose addresses it holds."""
+
+    def __init__(self, descs, device, sources=()):
+        assert lib().iunet_pack_desc_bytes() == ctypes.sizeof(PackDesc), 'PackDesc layout mismatch with libiunet'
+        arr = (PackDesc * len(descs))(*descs)
+        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+        self.dev = host.to(device)
+        self.n = len(descs)
+        self.sources = list(sources)
+
+    def run(self):
+        call('iunet_pack_batch', ptr(self.dev), self.n, stream())
 
 
 class PackedConv:
@@ -136,6 +173,14 @@ class PackedConv:
         for lay, b in self.buf.items():
             call('iunet_pack_conv3', self.dt, ptr(w), ptr(scale), ptr(b), self.cout, self.cin, self.taps,
                  (2 if lay == 1 else 0) | self.dg, stream())
+
+    def descs(self, w, bn=None, bias_out=None, eps=1e-5):
+        """Descriptors of all layouts for iunet_pack_batch (the first one also writes the folded bias)."""
+        out = []
+        for k, (lay, b) in enumerate(sorted(self.buf.items(), reverse=True)):
+            out.append(make_desc(w, b, self.cout, self.cin, self.taps, 1 if lay == 1 else 0, b.dtype, self.dg, bn,
+                                 bias_out if k == 0 else None, eps))
+        return out
 
     def pick(self, nd, N, D, H, W):
         """(layout, buffer) for a launch on this grid."""

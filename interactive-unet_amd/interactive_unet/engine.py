@@ -58,43 +58,63 @@ class Engine:
             ci = 2 * self.ch[l]
         return ci, self.ch[l]
 
+    def _source(self, params, name):
+        """fp32 device tensor the pack kernel reads: the parameter itself when it already lives on the device
+        (stable address, in-place optimiser updates are seen), otherwise a persistent staging copy."""
+        t = params[name].detach()
+        if t.device == self.device and t.dtype == torch.float32 and t.is_contiguous():
+            return t
+        st = self._stage.get(name)
+        if st is None or st.shape != t.shape:
+            st = self._stage[name] = torch.empty(t.shape, dtype=torch.float32, device=self.device)
+        st.copy_(t)
+        return st
+
     def load_eval(self, params):
-        """Fold eval-mode BatchNorm into the stage convs and pack everything into MFMA
-        fragment order.  `params`: {name: fp32 tensor on the device}."""
-        s = nv.stream()
-        P = {}
-        keep = []
+        """Fold eval-mode BatchNorm into the stage convs and pack everything into MFMA fragment order: ONE
+        launch over a device-resident descriptor table (iunet_pack_batch), rebuilt only when a source tensor
+        moves.  `params`: {name: fp32 tensor}."""
+        if not hasattr(self, '_stage'):
+            self._stage, self._eval_sig, self._eval_table = {}, None, None
+        src = {}
         for prefix in self.stage_names():
-            ci, co = self.stage_io(prefix)
-            for j, (a, b) in enumerate(((ci, co), (co, co)), 1):
-                w = params[f'{prefix}.conv{j}.weight'].detach().to(self.device, torch.float32).contiguous()
-                g = params[f'{prefix}.bn{j}.weight'].detach().to(self.device, torch.float32)
-                be = params[f'{prefix}.bn{j}.bias'].detach().to(self.device, torch.float32)
-                mu = params[f'{prefix}.bn{j}.running_mean'].detach().to(self.device, torch.float32)
-                var = params[f'{prefix}.bn{j}.running_var'].detach().to(self.device, torch.float32)
-                scale = (g / torch.sqrt(var + BN_EPS)).contiguous()
-                bias = (be - mu * scale).contiguous()
-                keep += [w, scale]
-                if prefix == 'enc0' and j == 1:
-                    dst = torch.empty(nv.lib().iunet_pack_first_conv_elems(b, a, self.taps), dtype=self.act_dtype,
-                                      device=self.device)
-                    nv.call('iunet_pack_first_conv', self.dt, nv.ptr(w), nv.ptr(scale), nv.ptr(dst), b, a, self.taps, s)
-                else:
-                    dst = nv.PackedConv(b, a, self.taps, self.act_dtype, self.device)
-                    dst.pack(w, scale)
-                P[f'{prefix}.conv{j}'] = (dst, bias)
-        for l in range(self.levels - 2, -1, -1):
-            w = params[f'dec{l}.up.weight'].detach().to(self.device, torch.float32).contiguous()
-            bias = params[f'dec{l}.up.bias'].detach().to(self.device, torch.float32).contiguous()
-            dst = torch.empty(w.numel(), dtype=self.act_dtype, device=self.device)
-            nv.call('iunet_pack_convT', self.dt, nv.ptr(w), nv.ptr(dst), self.ch[l + 1], self.ch[l], self.npos, s)
-            keep.append(w)
-            P[f'dec{l}.up'] = (dst, bias)
-        hw = params['head.weight'].detach().to(self.device, torch.float32).reshape(self.ncls, self.ch[0]).contiguous()
-        hb = params['head.bias'].detach().to(self.device, torch.float32).contiguous()
-        P['head'] = (hw, hb)
-        self._pack_sources = keep    # stay alive until the next re-pack: the pack kernels are still in flight
-        self.packed = P
+            for j in (1, 2):
+                src[f'{prefix}.conv{j}.weight'] = self._source(params, f'{prefix}.conv{j}.weight')
+                for k in ('weight', 'bias', 'running_mean', 'running_var'):
+                    src[f'{prefix}.bn{j}.{k}'] = self._source(params, f'{prefix}.bn{j}.{k}')
+        for l in range(self.levels - 1):
+            src[f'dec{l}.up.weight'] = self._source(params, f'dec{l}.up.weight')
+            src[f'dec{l}.up.bias'] = self._source(params, f'dec{l}.up.bias')
+        src['head.weight'] = self._source(params, 'head.weight')
+        src['head.bias'] = self._source(params, 'head.bias')
+        sig = tuple(t.data_ptr() for t in src.values())
+        if sig != self._eval_sig:
+            P, descs = {}, []
+            for prefix in self.stage_names():
+                ci, co = self.stage_io(prefix)
+                for j, (a, b) in enumerate(((ci, co), (co, co)), 1):
+                    w = src[f'{prefix}.conv{j}.weight']
+                    bn = [src[f'{prefix}.bn{j}.{k}'] for k in ('weight', 'bias', 'running_mean', 'running_var')]
+                    bias = torch.empty(b, dtype=torch.float32, device=self.device)
+                    if prefix == 'enc0' and j == 1:
+                        dst = torch.empty(nv.lib().iunet_pack_first_conv_elems(b, a, self.taps), dtype=self.act_dtype,
+                                          device=self.device)
+                        descs.append(nv.make_desc(w, dst, b, a, self.taps, 2, self.act_dtype, bn=bn, bias_out=bias,
+                                                  eps=BN_EPS))
+                    else:
+                        dst = nv.PackedConv(b, a, self.taps, self.act_dtype, self.device)
+                        descs += dst.descs(w, bn, bias, BN_EPS)
+                    P[f'{prefix}.conv{j}'] = (dst, bias)
+            for l in range(self.levels - 2, -1, -1):
+                w = src[f'dec{l}.up.weight']
+                dst = torch.empty(w.numel(), dtype=self.act_dtype, device=self.device)
+                descs.append(nv.make_desc(w, dst, self.ch[l], self.ch[l + 1], self.npos, 3, self.act_dtype))
+                P[f'dec{l}.up'] = (dst, src[f'dec{l}.up.bias'])
+            P['head'] = (src['head.weight'].reshape(self.ncls, self.ch[0]), src['head.bias'])
+            self._eval_table = nv.PackTable(descs, self.device, sources=list(src.values()))
+            self._eval_sig = sig
+            self.packed = P
+        self._eval_table.run()
 
     # ------------------------------------------------------------------ workspace
     def level_dims(self, D, H, W):

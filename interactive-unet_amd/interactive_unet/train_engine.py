@@ -106,24 +106,27 @@ class TrainEngine:
                                      torch.empty(n, dtype=self.T, device=self.dev))
 
     def repack(self):
-        """fp32 master weights -> MFMA fragment order (forward and data-gradient operators)."""
-        s = nv.stream()
-        for prefix in self.stage_names():
-            ci, co, _ = self.stage_io(prefix)
-            for j, (a, b) in enumerate(((ci, co), (co, co)), 1):
-                name = f'{prefix}.conv{j}'
-                w = self.p(name + '.weight')
-                fwd, dg = self.pk[name]
-                if name == 'enc0.conv1':
-                    nv.call('iunet_pack_first_conv', self.dt, nv.ptr(w), None, nv.ptr(fwd), b, a, self.taps, s)
-                else:
-                    fwd.pack(w)
-                    dg.pack(w)
-        for l in range(self.levels - 2, -1, -1):
-            w = self.p(f'dec{l}.up.weight')
-            fwd, dg = self.pk[f'dec{l}.up']
-            nv.call('iunet_pack_convT', self.dt, nv.ptr(w), nv.ptr(fwd), self.ch[l + 1], self.ch[l], self.npos, s)
-            nv.call('iunet_pack_convT_dgrad', self.dt, nv.ptr(w), nv.ptr(dg), self.ch[l + 1], self.ch[l], self.npos, s)
+        """fp32 master weights -> MFMA fragment order (forward and data-gradient operators): one launch over a
+        descriptor table built once (the flat master tensor and the packed buffers never move)."""
+        if getattr(self, '_pack_table', None) is None:
+            descs = []
+            for prefix in self.stage_names():
+                ci, co, _ = self.stage_io(prefix)
+                for j, (a, b) in enumerate(((ci, co), (co, co)), 1):
+                    name = f'{prefix}.conv{j}'
+                    w = self.p(name + '.weight')
+                    fwd, dg = self.pk[name]
+                    if name == 'enc0.conv1':
+                        descs.append(nv.make_desc(w, fwd, b, a, self.taps, 2, self.T))
+                    else:
+                        descs += fwd.descs(w) + dg.descs(w)
+            for l in range(self.levels - 2, -1, -1):
+                w = self.p(f'dec{l}.up.weight')
+                fwd, dg = self.pk[f'dec{l}.up']
+                descs.append(nv.make_desc(w, fwd, self.ch[l], self.ch[l + 1], self.npos, 3, self.T))
+                descs.append(nv.make_desc(w, dg, self.ch[l], self.ch[l + 1], self.npos, 4, self.T))
+            self._pack_table = nv.PackTable(descs, self.dev, sources=[self.flat])
+        self._pack_table.run()
 
     # ------------------------------------------------------------------ workspace
     def workspace(self, N, D, H, W):

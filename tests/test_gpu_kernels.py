@@ -233,3 +233,69 @@ def test_head_softmax_argmax(nv, ncls):
     # class map must be exactly np.argmax of the probabilities we returned (predict.py:38)
     want = np.argmax(probs.cpu().numpy(), axis=1).reshape(N, vox)
     assert np.array_equal(cls.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize('dt', ['f16', 'bf16'])
+def test_pack_batch_matches_per_layer_packs(nv, dt):
+    """iunet_pack_batch (one launch, in-kernel BatchNorm fold) is bit-identical to the per-layer pack entry
+    points fed with the (CPU, correctly rounded) fold scale = gamma / sqrt(var + eps), bias = beta - mean * scale."""
+    T, code, dev = DT[dt], nv.DTYPE_CODE[DT[dt]], 'cuda'
+    g = torch.Generator().manual_seed(11)
+    rnd = lambda *s: torch.randn(*s, generator=g).to(dev)
+    s = nv.stream()
+    descs, expect, keep = [], [], []
+
+    def bn_of(c):
+        bn = [torch.randn(c, generator=g), torch.randn(c, generator=g), torch.randn(c, generator=g),
+              torch.rand(c, generator=g) + 0.1]
+        n = [t.numpy() for t in bn]                            # numpy fp32: every operation correctly rounded
+        scale = n[0] / np.sqrt(n[3] + np.float32(1e-5))         # (torch's CPU sqrt/divide differ from it by an ulp)
+        bias = n[1] - n[2] * scale
+        return [t.to(dev) for t in bn], torch.from_numpy(scale).to(dev), torch.from_numpy(bias).to(dev)
+
+    for taps in (9, 27):
+        for cout, cin in ((32, 64), (64, 32), (128, 64)):
+            w = rnd(cout, cin, taps)
+            bn, scale, bias = bn_of(cout)
+            for dg in (0, 1):
+                pc = nv.PackedConv(cout, cin, taps, T, dev, dgrad=bool(dg))
+                pc.pack(w, None if dg else scale)
+                ref = {lay: b.clone() for lay, b in pc.buf.items()}
+                for b in pc.buf.values():
+                    b.zero_()
+                bias_out = torch.zeros(cout, device=dev)
+                ds = pc.descs(w, None if dg else bn, None if dg else bias_out)
+                descs += ds
+                for lay in sorted(pc.buf, reverse=True):
+                    expect.append((f'conv3 taps{taps} {cout}x{cin} dg{dg} layout{lay}', pc.buf[lay], ref[lay]))
+                if not dg:
+                    expect.append((f'bias taps{taps} {cout}x{cin}', bias_out, bias))
+                keep += [w, bn, pc]
+        # first conv (Cin 1..4) with fold
+        for cin in (1, 3):
+            w = rnd(32, cin, taps)
+            bn, scale, bias = bn_of(32)
+            n = nv.lib().iunet_pack_first_conv_elems(32, cin, taps)
+            ref = torch.zeros(n, dtype=T, device=dev)
+            nv.call('iunet_pack_first_conv', code, nv.ptr(w), nv.ptr(scale), nv.ptr(ref), 32, cin, taps, s)
+            dst, bias_out = torch.zeros(n, dtype=T, device=dev), torch.zeros(32, device=dev)
+            descs.append(nv.make_desc(w, dst, 32, cin, taps, 2, T, bn=bn, bias_out=bias_out))
+            expect += [(f'first taps{taps} cin{cin}', dst, ref), (f'first bias taps{taps} cin{cin}', bias_out, bias)]
+            keep += [w, bn]
+    for npos in (4, 8):
+        for cin, cout in ((64, 32), (256, 128)):
+            w = rnd(cin, cout, npos)
+            for kind, fn in ((3, 'iunet_pack_convT'), (4, 'iunet_pack_convT_dgrad')):
+                ref = torch.zeros(w.numel(), dtype=T, device=dev)
+                nv.call(fn, code, nv.ptr(w), nv.ptr(ref), cin, cout, npos, s)
+                dst = torch.zeros(w.numel(), dtype=T, device=dev)
+                descs.append(nv.make_desc(w, dst, cout, cin, npos, kind, T))
+                expect.append((f'{fn} npos{npos} {cin}->{cout}', dst, ref))
+            keep.append(w)
+    table = nv.PackTable(descs, dev)
+    table.run()
+    torch.cuda.synchronize()
+    for name, got, ref in expect:
+        assert got.dtype == ref.dtype and got.shape == ref.shape, name
+        bits = torch.int16 if got.dtype != torch.float32 else torch.int32
+        assert torch.equal(got.view(bits), ref.view(bits)), name
