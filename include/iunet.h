@@ -61,8 +61,9 @@ int iunet_conv3_fwd(int dtype, int nd, const void* x, long long x_sstride, void*
                     const void* wpk, const void* bias, void* stats, int N, int D, int H, int W, int Cin, int Cout,
                     int epi, int layout, void* stream);
 /* which kernel structure / weight layout serves this launch best: 0 = 32-channel chunks, weights through
- * registers (wpk packed with mode bit 1 clear); 1 = persistent LDS-fed Cout-32 structure (mode bit 1 set).
- * Layout 1 is mandatory when Cout is not a multiple of 64. */
+ * registers (wpk packed with mode bit 1 clear); 1 = persistent LDS-fed Cout-32 structure (mode bit 1 set);
+ * 2 = weight-stationary variant of 1 (same mode-bit-1 operator; 3-D, Cin <= 64: all weights of a Cout tile stay
+ * in LDS for the whole launch).  Layout 1 or 2 is mandatory when Cout is not a multiple of 64. */
 int iunet_conv3_pick_layout(int nd, int N, int D, int H, int W, int Cin, int Cout);
 int iunet_conv3_num_tiles(int nd, int N, int D, int H, int W);
 /* profiling only: ablation variants of the bf16 3-D Cout = 32 conv (mask bits: 1 no weight loads, 2 no LDS reads,

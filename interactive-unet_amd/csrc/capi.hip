@@ -89,7 +89,7 @@ int iunet_conv3_fwd(int dtype, int nd, const void* x, long long x_sstride, void*
   IUNET_REQUIRE(x && y && wpk, "conv3: null pointer");
   IUNET_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0, "conv3: bad shape %d %d %d %d", N, D, H, W);
   IUNET_REQUIRE(epi >= 0 && epi <= 2, "conv3: bad epilogue %d", epi);
-  IUNET_REQUIRE(layout == 0 || layout == 1, "conv3: weight layout must be 0 or 1 (got %d)", layout);
+  IUNET_REQUIRE(layout >= 0 && layout <= 2, "conv3: layout must be 0, 1 or 2 (got %d)", layout);
   return iunet_conv3_launch(dtype, nd, x, x_sstride, y, y_sstride, wpk, (const float*)bias, (float*)stats, N, D, H, W,
                             Cin, Cout, epi, layout, (hipStream_t)stream);
 }

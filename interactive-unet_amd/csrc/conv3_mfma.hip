@@ -326,6 +326,13 @@ int launch_conv3(const Conv3Params& p, hipStream_t stream) {
 int iunet_conv3_v2_launch(int dtype, int nd, const void* x, long long x_sstride, void* y, long long y_sstride,
                           const void* wpk, const float* bias, float* stats, int N, int D, int H, int W, int Cin,
                           int Cout, int epi, hipStream_t stream);
+int iunet_conv3_v3_ok(int nd, int Cin, int Cout);
+int iunet_conv3_v3_launch(int dtype, const void* x, long long x_sstride, void* y, long long y_sstride, const void* wpk,
+                          const float* bias, float* stats, int N, int D, int H, int W, int Cin, int Cout, int epi,
+                          hipStream_t stream);
+int iunet_conv3_v4_launch(int dtype, const void* x, long long x_sstride, void* y, long long y_sstride, const void* wpk,
+                          const float* bias, float* stats, int N, int D, int H, int W, int Cin, int Cout, int epi,
+                          hipStream_t stream);
 
 // Host entry used by the net runtime and the per-kernel C ABI.
 int iunet_conv3_launch(int dtype, int nd, const void* x, long long x_sstride, void* y, long long y_sstride,
@@ -341,6 +348,12 @@ int iunet_conv3_launch(int dtype, int nd, const void* x, long long x_sstride, vo
   const int TZ = nd == 3 ? 4 : 1, TY = nd == 3 ? 8 : 16, TX = nd == 3 ? 16 : 32;
   p.tilesZ = (D + TZ - 1) / TZ; p.tilesY = (H + TY - 1) / TY; p.tilesX = (W + TX - 1) / TX;
   const bool wide = (Cout % 64 == 0);
+  if (layout == 2) {
+    IUNET_REQUIRE(nd == 3, "conv3: layout 2 is 3-D only");
+    static const bool use_v3 = getenv("IUNET_L2_V3") != nullptr;      // A/B runs: the barrier-locked weight-stationary variant
+    if (!use_v3) return iunet_conv3_v4_launch(dtype, x, x_sstride, y, y_sstride, wpk, bias, stats, N, D, H, W, Cin, Cout, epi, stream);
+    return iunet_conv3_v3_launch(dtype, x, x_sstride, y, y_sstride, wpk, bias, stats, N, D, H, W, Cin, Cout, epi, stream);
+  }
   if (layout == 1)
     return iunet_conv3_v2_launch(dtype, nd, x, x_sstride, y, y_sstride, wpk, bias, stats, N, D, H, W, Cin, Cout, epi, stream);
 #define IUNET_DISPATCH(TT)                                                                   \
@@ -376,17 +389,22 @@ int iunet_conv3_tiles(int nd, int N, int D, int H, int W) {
 int iunet_conv3_mi(int Cout) { return (Cout % 64 == 0) ? 4 : 2; }
 
 // Weight layout / kernel structure of a launch: 0 = first structure (conv3_mfma_kernel, 32-channel chunks),
-// 1 = LDS-fed persistent Cout-32 structure (conv3_v2.hip, K16 fragment order).  The second one is used for
+// 1 = LDS-fed persistent Cout-32 structure (conv3_v2.hip, K16 fragment order), 2 = weight-stationary variant of 1
+// (conv3_v3.hip, same K16 operator; 3-D, Cin <= 64).  The second one is used for
 // Cout tiles of 32 and whenever the first structure's grid would under-fill the chip (deep levels):
 // measured at 128^3 / N = 1, levels 2 and 3 run 1.6-2x faster on it, level 1 (Cout 64, 512 tiles) 10 % slower.
 // IUNET_CONV_V1=1 / IUNET_CONV_V2_ALL=1 force one structure (A/B runs).
 int iunet_conv3_pick(int nd, int N, int D, int H, int W, int Cin, int Cout) {
   static const bool force_v1 = getenv("IUNET_CONV_V1") != nullptr;
   static const bool force_v2 = getenv("IUNET_CONV_V2_ALL") != nullptr;
-  (void)Cin;
+  static const int v3 = getenv("IUNET_CONV_V3") ? atoi(getenv("IUNET_CONV_V3")) : 1;   // 0: layouts 0 / 1 only (A/B runs)
   if (force_v1) return 0;
+  const long long tiles = iunet_conv3_tiles(nd, N, D, H, W);
+  // 3-D: the wave-specialised structure wins at every level of the U-Net (profiles/r01_conv_levels.md), marginally
+  // behind layout 0 only for 128 -> 64 at 64^3 (-4 %)
+  if (v3 && nd == 3 && Cin >= 32) return 2;
   if (force_v2 || Cout % 64 != 0) return 1;
-  const long long blocks = (long long)iunet_conv3_tiles(nd, N, D, H, W) * (Cout / 64);
+  const long long blocks = tiles * (Cout / 64);
   return blocks < 512 ? 1 : 0;
 }
 

@@ -1,0 +1,323 @@
+// 3x3x3 convolution for Cout tiles of 32 channels, wave-specialised structure (layout 2).
+//
+// What the ablations of the earlier structures showed (tools/_run_v3.sh): the MFMA loop alone
+// runs at the clock-limited peak (1.5-1.66 PF), but a wave that also issues the global loads of the next
+// chunk blocks on the CU's vector-memory queue for thousands of cycles (the path sustains 12-25 B/clk per CU),
+// and a blocked wave issues no MFMAs; two such workgroups per CU, or half the bytes (weights kept in LDS), did not
+// change that.  So here the roles are split inside one persistent workgroup per CU:
+//   * 8 CONSUMER waves (two per SIMD) only read LDS and issue MFMAs (plus the tile's output stores);
+//   * 4 LOADER waves (one per SIMD) fetch the next 16-channel chunk of the halo tile (and, for Cin > 32, its
+//     30 KB of weights) global -> registers -> the OTHER LDS buffer, wait for it, and meet the consumers at the
+//     one barrier per step.  Their stalls on the memory queue cost no MFMA issue slots.
+// Tile 4 x 8 x 16 voxels, 64 voxels per consumer wave; k-step = 2 filter columns x 16 channels (the K16 operator of
+// layout 1), 6 activation row fragments reused over the three dy taps.  LDS: 2 x 34 KB activations + the weights
+// (Cin <= 32: all of them, resident for the whole launch; else 2 x 30 KB, streamed with the activations).
+#include "common.h"
+#include <cstdlib>
+
+namespace {
+
+struct ConvV4Params {
+  const void* x;  long long x_sstride;
+  void* y;        long long y_sstride;
+  const void* wpk;                            // K16 order: [cob][chunk16][column pair][dy][2][64][8]
+  const float* bias;
+  float* stats;                               // [N * tiles][Cout][2] or null
+  int N, D, H, W, Cin, Cout;
+  int tilesZ, tilesY, tilesX;
+  int bz, by, bx;                             // tiles per brick (bz * by * bx = workgroups per XCD and Cout tile)
+  int nbz, nby, nbx;                          // bricks per sample
+  int epi;
+  int dbg;                                    // profiling only (IUNET_V4_DBG): 1 no refill after step 0, 2 no MFMA phase, 4 no stores
+};
+
+template <typename T, bool WS>
+__global__ __launch_bounds__(768, 1) void conv3_v4_kernel(ConvV4Params p) {
+  using V8 = typename Vec8<T>::type;
+  constexpr int NCW = 8, NLT = 256;                    // consumer waves; loader threads
+  constexpr int TZ = 4, TY = 8, TX = 16, NI = 4;
+  constexpr int PZ = TZ + 2, PY = TY + 2, PX = TX + 2;
+  constexpr int NPIX = PZ * PY * PX;                   // 1080
+  constexpr int PLANE = ((NPIX * 16 + 255) / 256) * 256;
+  constexpr int ABUF = 2 * PLANE;                      // one 16-channel chunk of the halo tile
+  constexpr int NCMB = 5, KS = 15;
+  constexpr int WBYTES = KS * 2 * 1024;                // one 16-channel chunk of packed weights
+  constexpr int OFF_W = 2 * ABUF;
+  constexpr int AIT = (NPIX + NLT - 1) / NLT;          // halo pixels per loader thread (5)
+  constexpr int WIT = (WBYTES / 16 + NLT - 1) / NLT;   // 16-byte weight items per loader thread (8)
+
+  extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cob = blockIdx.y;
+  // Brick schedule: the 32 / ncob workgroups of an XCD (blocks b, b + 8, ... share an XCD and its 4 MB L2) work on the
+  // tiles of ONE compact brick of bz x by x bx tiles at the same time and move on together, so the halo voxels a tile
+  // shares with its neighbours are fetched from HBM once and then hit in that L2 (contiguous per-workgroup runs had
+  // every concurrent tile 32 tiles apart: the 2.1x halo re-fetch all went to HBM / Infinity Cache at ~20 GB/s per CU).
+  // Slots of a brick that stick out of the tile grid are processed fully masked (speed only, never correctness).
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int sx = slot % p.bx, sy = (slot / p.bx) % p.by, sz = slot / (p.bx * p.by);
+  const int nbricks = p.N * p.nbz * p.nby * p.nbx;
+  const int b_begin = (int)((long long)xcd * nbricks / 8), b_end = (int)((long long)(xcd + 1) * nbricks / 8);
+  const int nchunk = p.Cin >> 4;
+  const int nsteps = (b_end - b_begin) * nchunk;
+  if (nsteps <= 0) return;
+  const long long plane_stride = (long long)p.D * p.H * p.W * 8;
+  const int off_red = OFF_W + (WS ? nchunk : 2) * WBYTES;   // 2 KB of scratch for the BatchNorm partial sums
+  const u32x4* wsrc = (const u32x4*)p.wpk + (long long)cob * nchunk * (WBYTES / 16);
+
+  auto tile_origin = [&](int k, int& n_img, int& z0, int& y0, int& x0) -> bool {      // this workgroup's k-th tile
+    int b = b_begin + k;
+    const int Bx = b % p.nbx; b /= p.nbx;
+    const int By = b % p.nby; b /= p.nby;
+    const int Bz = b % p.nbz; n_img = b / p.nbz;
+    const int tz = Bz * p.bz + sz, ty = By * p.by + sy, tx = Bx * p.bx + sx;
+    z0 = tz * TZ; y0 = ty * TY; x0 = tx * TX;
+    return tz < p.tilesZ && ty < p.tilesY && tx < p.tilesX;
+  };
+
+  if (WS) {     // all weights of this Cout tile: global -> LDS once, by everybody
+    const int nitems = nchunk * (WBYTES / 16);
+    for (int i = tid; i < nitems; i += 768) *(u32x4*)(smem + OFF_W + i * 16) = wsrc[i];
+  }
+
+  if (wave >= NCW) {
+    // ================================================================== loader waves
+    const int lt = tid - NCW * 64;
+    int pcoord[AIT];
+#pragma unroll
+    for (int it = 0; it < AIT; ++it) {
+      const int pix = min(lt + it * NLT, NPIX - 1);
+      const int px = pix % PX, t2 = pix / PX;
+      pcoord[it] = px | ((t2 % PY) << 8) | ((t2 / PY) << 16);
+    }
+    struct Staged { u32x4 a[AIT][2]; u32x4 w[WS ? 1 : WIT]; unsigned ok; };
+    auto load = [&](int s, Staged& r) {               // issue the global loads of step s's chunk (nothing consumes them here)
+      const int chunk = s - (s / nchunk) * nchunk;
+      int n_img, z0, y0, x0;
+      tile_origin(s / nchunk, n_img, z0, y0, x0);
+      const T* xc = (const T*)p.x + (long long)n_img * p.x_sstride + (long long)chunk * 2 * plane_stride;
+      r.ok = 0;
+      if (!(p.dbg & 32))
+#pragma unroll
+      for (int it = 0; it < AIT; ++it) {
+        const int px = pcoord[it] & 255, py = (pcoord[it] >> 8) & 255, pz = pcoord[it] >> 16;
+        const int gz = z0 + pz - 1, gy = y0 + py - 1, gx = x0 + px - 1;
+        const bool ok = (unsigned)gz < (unsigned)p.D && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+        const int cz = min(max(gz, 0), p.D - 1), cy = min(max(gy, 0), p.H - 1), cx = min(max(gx, 0), p.W - 1);
+        const long long goff = (((long long)cz * p.H + cy) * p.W + cx) * 8;
+        r.a[it][0] = *(const u32x4*)(xc + goff);
+        r.a[it][1] = *(const u32x4*)(xc + plane_stride + goff);
+        r.ok |= ok ? (1u << it) : 0u;
+      }
+      if (!WS && !(p.dbg & 16)) {
+        const u32x4* ws = wsrc + (long long)chunk * (WBYTES / 16);
+#pragma unroll
+        for (int it = 0; it < WIT; ++it) r.w[it] = ws[min(lt + it * NLT, WBYTES / 16 - 1)];
+      }
+    };
+    auto commit = [&](int s, const Staged& r) {       // registers -> LDS buffer s & 1
+      unsigned char* ab = smem + (s & 1) * ABUF;
+#pragma unroll
+      for (int it = 0; it < AIT; ++it) {
+        const int pix = lt + it * NLT;
+        if (pix < NPIX) {
+          const bool ok = (r.ok >> it) & 1u;
+          *(u32x4*)(ab + pix * 16) = ok ? r.a[it][0] : u32x4{0u, 0u, 0u, 0u};
+          *(u32x4*)(ab + PLANE + pix * 16) = ok ? r.a[it][1] : u32x4{0u, 0u, 0u, 0u};
+        }
+      }
+      if (!WS) {
+        unsigned char* wb = smem + OFF_W + (s & 1) * WBYTES;
+#pragma unroll
+        for (int it = 0; it < WIT; ++it) {
+          const int idx = lt + it * NLT;
+          if (idx < WBYTES / 16) *(u32x4*)(wb + idx * 16) = r.w[it];
+        }
+      }
+    };
+    auto step_barriers = [&](int s) {
+      const int chunk = s - (s / nchunk) * nchunk;
+      if (p.stats != nullptr && chunk == nchunk - 1) __syncthreads();      // mirrors the consumers' statistics barrier
+      __syncthreads();
+    };
+    // two register sets: the loads of step s + 2 are in flight while step s + 1 is written to LDS, so the memory
+    // latency is never exposed to the barrier
+    Staged r0, r1;
+    load(0, r0);
+    commit(0, r0);
+    __syncthreads();
+    const bool refill = !(p.dbg & 1);
+    if (nsteps > 1 && refill) load(1, r0);
+    for (int s = 0; s < nsteps; s += 2) {
+      if (s + 2 < nsteps && refill) load(s + 2, r1);
+      if (s + 1 < nsteps && refill) commit(s + 1, r0);
+      step_barriers(s);
+      if (s + 1 >= nsteps) break;
+      if (s + 3 < nsteps && refill) load(s + 3, r0);
+      if (s + 2 < nsteps && refill) commit(s + 2, r1);
+      step_barriers(s + 1);
+    }
+    return;
+  }
+
+  // ==================================================================== consumer waves
+  const int l15 = lane & 15, q = lane >> 4;
+  int col_off[NCMB];
+#pragma unroll
+  for (int c = 0; c < NCMB; ++c) {
+    const int col = min(2 * c + (q >> 1), 8);                  // the missing partner re-reads a valid column (zero weights)
+    const int dz = col / 3, dx = col % 3;
+    col_off[c] = (dz * PY * PX + dx) * 16;
+  }
+  const int row0 = wave * NI;                                  // first output row (z * TY + y) of this wave
+  const int rbase = (q & 1) * PLANE + ((((row0 / TY) * PY + (row0 % TY)) * PX) + l15) * 16;
+  float bias_r[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) bias_r[j] = (p.epi != 0) ? p.bias[cob * 32 + 8 * q + j] : 0.f;
+
+  f32x4 acc[2][NI];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < NI; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  __syncthreads();                                             // step 0 (and the resident weights) are in LDS
+
+  for (int s = 0; s < nsteps; ++s) {
+    const int chunk = s - (s / nchunk) * nchunk;
+    const unsigned char* ab = smem + (s & 1) * ABUF + rbase;
+    const unsigned char* wl = smem + OFF_W + (WS ? chunk : (s & 1)) * WBYTES + lane * 16;
+
+    if (!(p.dbg & 2)) {
+      // software pipeline over the 5 column pairs: the 12 fragment reads of pair c + 1 (6 activation rows, 6 weight
+      // fragments) are issued between the 24 MFMAs of pair c, one read per two MFMAs
+      V8 R[2][NI + 2], A[2][3][2];
+      auto load_group = [&](int c, int b) {
+#pragma unroll
+        for (int r = 0; r < NI + 2; ++r) R[b][r] = *(const V8*)(ab + r * PX * 16 + col_off[c]);
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+          A[b][dy][0] = *(const V8*)(wl + ((c * 3 + dy) * 2 + 0) * 1024);
+          A[b][dy][1] = *(const V8*)(wl + ((c * 3 + dy) * 2 + 1) * 1024);
+        }
+      };
+      load_group(0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int c = 0; c < NCMB; ++c) {
+        const int b = c & 1;
+        if (c + 1 < NCMB) load_group(c + 1, b ^ 1);
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+          for (int n = 0; n < NI; ++n) {
+            acc[0][n] = mfma16<T>(A[b][dy][0], R[b][n + dy], acc[0][n]);
+            acc[1][n] = mfma16<T>(A[b][dy][1], R[b][n + dy], acc[1][n]);
+          }
+        if (c + 1 < NCMB) {
+#pragma unroll
+          for (int i = 0; i < 12; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // one LDS read
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);     // two MFMAs
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);                         // nothing moves across the pair boundary
+      }
+    }
+
+    if (chunk == nchunk - 1) {
+      // ---- epilogue of this tile ----
+      int n_img, z0, y0, x0;
+      const bool tile_ok = tile_origin(s / nchunk, n_img, z0, y0, x0);
+      T* yout = (T*)p.y + (long long)n_img * p.y_sstride;
+      float s_sum[8], s_sq[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { s_sum[j] = 0.f; s_sq[j] = 0.f; }
+#pragma unroll
+      for (int n = 0; n < NI; ++n) {
+        const int row = row0 + n;
+        const int gz = z0 + row / TY, gy = y0 + row % TY, gx = x0 + l15;
+        const bool ok = gz < p.D && gy < p.H && gx < p.W;
+        float vals[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { vals[j] = acc[0][n][j]; vals[4 + j] = acc[1][n][j]; }
+        if (p.stats != nullptr && ok) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { s_sum[j] += vals[j]; s_sq[j] += vals[j] * vals[j]; }
+        }
+        V8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float r = vals[j] + bias_r[j];
+          if (p.epi == 2) r = fmaxf(r, 0.f);
+          o[j] = from_f32<T>(r);
+        }
+        if (ok && !(p.dbg & 4)) *(V8*)(yout + (long long)(cob * 4 + q) * plane_stride + (((long long)gz * p.H + gy) * p.W + gx) * 8) = o;
+        acc[0][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        acc[1][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      if (p.stats != nullptr) {
+        // partial BatchNorm sums of this tile: 16 x-lanes by shuffles, the 8 waves in wave order through LDS
+        float* red = (float*)(smem + off_red);                 // [8 waves][4 q][8][2]
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float a = s_sum[j], b = s_sq[j];
+#pragma unroll
+          for (int sh = 8; sh > 0; sh >>= 1) { a += __shfl_xor(a, sh); b += __shfl_xor(b, sh); }
+          if (l15 == 0) { red[((wave * 4 + q) * 8 + j) * 2] = a; red[((wave * 4 + q) * 8 + j) * 2 + 1] = b; }
+        }
+        __syncthreads();
+        if (tid < 64 && tile_ok) {
+          const int c = tid >> 1, which = tid & 1;             // c = 8 g + j
+          float sum = 0.f;
+#pragma unroll
+          for (int w = 0; w < NCW; ++w) sum += red[((w * 4 + (c >> 3)) * 8 + (c & 7)) * 2 + which];
+          const long long stile = (((long long)n_img * p.tilesZ + z0 / TZ) * p.tilesY + y0 / TY) * p.tilesX + x0 / TX;
+          p.stats[(stile * p.Cout + cob * 32 + c) * 2 + which] = sum;
+        }
+      }
+    }
+    __syncthreads();                 // consumers are done with this step's buffers, the loaders have filled the others
+  }
+}
+
+template <typename T, bool WS>
+int launch_v4(ConvV4Params p, hipStream_t stream) {
+  constexpr int PLANE = ((1080 * 16 + 255) / 256) * 256;
+  const int lds = 4 * PLANE + (WS ? p.Cin / 16 : 2) * 30720 + 2048;
+  static int attr_lds = 0;
+  if (lds > attr_lds) {
+    IUNET_CHECK_HIP(hipFuncSetAttribute((const void*)conv3_v4_kernel<T, WS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_lds = lds;
+  }
+  const int ncob = p.Cout / 32;
+  // one workgroup per CU: 8 XCDs x (bz x by x bx) brick slots per Cout tile
+  if (ncob == 1)      { p.bz = 2; p.by = 4; p.bx = 4; }
+  else if (ncob == 2) { p.bz = 2; p.by = 4; p.bx = 2; }
+  else if (ncob <= 4) { p.bz = 2; p.by = 2; p.bx = 2; }
+  else                { p.bz = 1; p.by = 2; p.bx = 2; }
+  p.nbz = (p.tilesZ + p.bz - 1) / p.bz; p.nby = (p.tilesY + p.by - 1) / p.by; p.nbx = (p.tilesX + p.bx - 1) / p.bx;
+  const int gx = 8 * p.bz * p.by * p.bx;
+  hipLaunchKernelGGL((conv3_v4_kernel<T, WS>), dim3(gx, ncob), dim3(768), lds, stream, p);
+  IUNET_CHECK_HIP(hipGetLastError());
+  return IUNET_OK;
+}
+
+}  // namespace
+
+int iunet_conv3_v4_launch(int dtype, const void* x, long long x_sstride, void* y, long long y_sstride, const void* wpk,
+                          const float* bias, float* stats, int N, int D, int H, int W, int Cin, int Cout, int epi,
+                          hipStream_t stream) {
+  IUNET_REQUIRE(Cin % 16 == 0 && Cin >= 32 && Cout % 32 == 0, "conv3 layout 2: Cin %% 16, Cin >= 32, Cout %% 32 (got %d -> %d)", Cin, Cout);
+  ConvV4Params p;
+  p.x = x; p.x_sstride = x_sstride; p.y = y; p.y_sstride = y_sstride; p.wpk = wpk; p.bias = bias; p.stats = stats;
+  p.N = N; p.D = D; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.epi = epi;
+  p.tilesZ = (D + 3) / 4; p.tilesY = (H + 7) / 8; p.tilesX = (W + 15) / 16;
+  p.bz = p.by = p.bx = p.nbz = p.nby = p.nbx = 0;
+  static const int dbg = getenv("IUNET_V4_DBG") ? atoi(getenv("IUNET_V4_DBG")) : 0;
+  p.dbg = dbg;
+  if (Cin <= 32) return dtype == 0 ? launch_v4<f16, true>(p, stream) : launch_v4<bf16, true>(p, stream);
+  return dtype == 0 ? launch_v4<f16, false>(p, stream) : launch_v4<bf16, false>(p, stream);
+}

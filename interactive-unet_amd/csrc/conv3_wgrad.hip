@@ -209,11 +209,17 @@ __global__ __launch_bounds__(256, 2) void conv3_wgrad_kernel(WgradParams p) {
 // order (coalesced reads of every part), the small dW write is scattered.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int nb, int Cout, int Cin, int taps,
                                                            float* __restrict__ dW, float alpha) {
+  // 64 slab columns x 4 row groups per block (per_b is a multiple of 1024); fixed summation order
+  __shared__ float red[4][64];
   const long long per_b = (long long)Cout * Cin * taps;
-  const long long j = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (j >= per_b) return;
+  const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const long long j = (long long)blockIdx.x * 64 + col;
   float s = 0.f;
-  for (int b = 0; b < nb; ++b) s += slab[b * per_b + j];
+  for (int b = grp; b < nb; b += 4) s += slab[b * per_b + j];
+  red[grp][col] = s;
+  __syncthreads();
+  if (grp != 0) return;
+  s = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
   const int c = (int)(j & 31), r = (int)((j >> 5) & 31);
   long long t = j >> 10;
   const int tap = (int)(t % taps); t /= taps;
@@ -279,7 +285,7 @@ int iunet_conv3_wgrad(int dtype, int nd, const void* x, long long x_ss, const vo
   if (rc != IUNET_OK) return rc;
   const int taps = nd == 3 ? 27 : 9;
   const long long total = (long long)Cout * Cin * taps;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(total / 64)), dim3(256), 0, (hipStream_t)stream,
                      (const float*)slab, nb, Cout, Cin, taps, (float*)dW, alpha);
   IUNET_CHECK_HIP(hipGetLastError());
   return IUNET_OK;

@@ -43,7 +43,7 @@ __device__ __forceinline__ float mul_rn(float a, float b) {
 }
 
 __device__ __forceinline__ float elem(const PackDesc& d, long long i) {
-  long long r = i;
+  int r = (int)i;                                      // a layer has < 2^31 elements: 32-bit divisions
   const int j = r & 7; r >>= 3;
   const int lane = r & 63; r >>= 6;
   const int row = lane & 15, qq = lane >> 4;
@@ -126,7 +126,7 @@ int iunet_pack_desc_bytes(void) { return (int)sizeof(PackDesc); }
 // descs: device array of `n` descriptors (layout: see PackDesc above / _native.PackDesc)
 int iunet_pack_batch(const void* descs, int n, void* stream) {
   IUNET_REQUIRE(descs && n > 0, "pack_batch: empty descriptor table");
-  hipLaunchKernelGGL(pack_batch_kernel, dim3(64, n), dim3(256), 0, (hipStream_t)stream, (const PackDesc*)descs);
+  hipLaunchKernelGGL(pack_batch_kernel, dim3(256, n), dim3(256), 0, (hipStream_t)stream, (const PackDesc*)descs);
   IUNET_CHECK_HIP(hipGetLastError());
   return IUNET_OK;
 }

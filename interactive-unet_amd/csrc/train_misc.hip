@@ -227,11 +227,16 @@ __global__ __launch_bounds__(256, 2) void convT_wgrad_kernel(ConvTWgradParams p)
 // dW[ci][co][pos] = sum_b slab[b][cib][cob][pos][ci%32][co%32] (threads walk the slab order)
 __global__ __launch_bounds__(256) void convT_wgrad_reduce_kernel(const float* __restrict__ slab, int nb, int Cin, int Cout, int npos,
                                                                  float* __restrict__ dW) {
+  __shared__ float red[4][64];                                   // 64 slab columns x 4 row groups, fixed order
   const long long per_b = (long long)Cin * Cout * npos;
-  const long long j = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (j >= per_b) return;
+  const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const long long j = (long long)blockIdx.x * 64 + col;
   float s = 0.f;
-  for (int b = 0; b < nb; ++b) s += slab[b * per_b + j];
+  for (int b = grp; b < nb; b += 4) s += slab[b * per_b + j];
+  red[grp][col] = s;
+  __syncthreads();
+  if (grp != 0) return;
+  s = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
   const int c = (int)(j & 31), r = (int)((j >> 5) & 31);
   long long t = j >> 10;
   const int pos = (int)(t % npos); t /= npos;
@@ -354,16 +359,27 @@ __global__ __launch_bounds__(256, 2) void first_wgrad_kernel(FirstWgradParams p)
     slab[i] = red[i] + red[32 * KKP + i] + red[2 * 32 * KKP + i] + red[3 * 32 * KKP + i];
 }
 
-// dW[co][c][tap] = sum_b slab[b][co][tap * Cin + c]
+// dW[co][c][tap] = sum_b slab[b][co][tap * Cin + c]: 32 outputs x 8 row groups per block, fixed order
 __global__ __launch_bounds__(256) void first_wgrad_reduce_kernel(const float* __restrict__ slab, int nb, int Cout, int Cin, int taps,
                                                                  int KKP, float* __restrict__ dW) {
+  __shared__ float red[8][32];
   const int total = Cout * Cin * taps;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= total) return;
-  const int tap = i % taps, c = (i / taps) % Cin, co = i / (taps * Cin);
+  const int o = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + o;
   float s = 0.f;
-  for (int b = 0; b < nb; ++b) s += slab[((long long)b * Cout + co) * KKP + tap * Cin + c];
-  dW[i] = s;
+  if (i < total) {
+    const int tap = i % taps, c = (i / taps) % Cin, co = i / (taps * Cin);
+    const float* src = slab + (long long)co * KKP + tap * Cin + c;
+    for (int b = grp; b < nb; b += 8) s += src[(long long)b * Cout * KKP];
+  }
+  red[grp][o] = s;
+  __syncthreads();
+  if (grp == 0 && i < total) {
+    float a = red[0][o];
+#pragma unroll
+    for (int g = 1; g < 8; ++g) a += red[g][o];
+    dW[i] = a;
+  }
 }
 
 }  // namespace
@@ -433,7 +449,7 @@ int iunet_convT_wgrad(int dtype, int nd, const void* x, long long x_ss, const vo
   if (dtype == 0) { if (nd == 3) CTW(f16, 3); else CTW(f16, 2); } else { if (nd == 3) CTW(bf16, 3); else CTW(bf16, 2); }
 #undef CTW
   const long long total = (long long)Cin * Cout * npos;
-  hipLaunchKernelGGL(convT_wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(convT_wgrad_reduce_kernel, dim3((unsigned)(total / 64)), dim3(256), 0, (hipStream_t)stream,
                      (const float*)wslab, nb, Cin, Cout, npos, (float*)dW);
   IUNET_CHECK_HIP(hipGetLastError());
   return iunet_reduce_slab(bslab, nb, Cout, db, 1.0f, 0, stream);
@@ -473,7 +489,7 @@ int iunet_first_conv_wgrad(int dtype, int nd, const void* x, int in_dtype, const
 #undef FW_CIN
 #undef FW
   const int total = Cout * Cin * taps;
-  hipLaunchKernelGGL(first_wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(first_wgrad_reduce_kernel, dim3((total + 31) / 32), dim3(256), 0, (hipStream_t)stream,
                      (const float*)slab, nb, Cout, Cin, taps, KKP, (float*)dW);
   IUNET_CHECK_HIP(hipGetLastError());
   return IUNET_OK;

@@ -339,16 +339,28 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restr
                                                             float* coef /* [ncls][3] */) {
   __shared__ double sums[10][8];
   __shared__ double red[256];
-  for (int c = 0; c < ncls; ++c)
-    for (int k = 0; k < 8; ++k) {
-      double s = 0.0;
-      for (int pidx = threadIdx.x; pidx < nparts; pidx += 256) s += (double)slab[((long long)pidx * ncls + c) * 8 + k];
-      red[threadIdx.x] = s;
-      __syncthreads();
-      for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
-      if (threadIdx.x == 0) sums[c][k] = red[0];
-      __syncthreads();
+  // one coalesced pass over the slab: thread t owns item (class, k) = t % (ncls*8) of every (256 / items)-th part;
+  // fixed summation order -> deterministic
+  const int items = ncls * 8, groups = 256 / items, t = threadIdx.x;
+  double s = 0.0;
+  if (t < groups * items) {
+    const long long total = (long long)nparts * items;
+    long long e = t;
+    for (; e + 3LL * groups * items < total; e += 4LL * groups * items) {
+      const float a = slab[e], b = slab[e + (long long)groups * items], c = slab[e + 2LL * groups * items],
+                  d = slab[e + 3LL * groups * items];
+      s += (double)a; s += (double)b; s += (double)c; s += (double)d;
     }
+    for (; e < total; e += (long long)groups * items) s += (double)slab[e];
+  }
+  red[t] = s;
+  __syncthreads();
+  if (t < items) {
+    double a = 0.0;
+    for (int g = 0; g < groups; ++g) a += red[g * items + t];
+    sums[t >> 3][t & 7] = a;
+  }
+  __syncthreads();
   if (threadIdx.x != 0) return;
   const double eps = 1e-12;
   const bool use_ce = (kind == 0 || kind >= 4);

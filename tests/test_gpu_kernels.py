@@ -47,7 +47,7 @@ def run_conv3(nv, x, w, dtype, nd, scale=None, bias=None, epi=0, stats=False, mo
     wd = w.contiguous().to(dev)
     if layout is None:
         layout = nv.lib().iunet_conv3_pick_layout(nd, N, D, H, W, Ci_p, Co_p)
-    pmode = mode | (2 if layout == 1 else 0)
+    pmode = mode | (2 if layout in (1, 2) else 0)
     wpk = torch.empty(nv.pack_conv3_elems(w.shape[0], w.shape[1], taps, pmode), dtype=dtype, device=dev)
     sc = None if scale is None else scale.to(dev)
     nv.call('iunet_pack_conv3', nv.DTYPE_CODE[dtype], nv.ptr(wd), nv.ptr(sc), nv.ptr(wpk), w.shape[0], w.shape[1],
@@ -70,7 +70,8 @@ def run_conv3(nv, x, w, dtype, nd, scale=None, bias=None, epi=0, stats=False, mo
 
 @pytest.mark.parametrize('nd,shape,cin,cout', [
     (2, (16, 32), 32, 32), (2, (48, 40), 64, 64), (2, (20, 70), 64, 32), (2, (16, 16), 32, 128),
-    (3, (4, 8, 16), 32, 32), (3, (6, 12, 20), 64, 64), (3, (8, 8, 8), 32, 64)])
+    (3, (4, 8, 16), 32, 32), (3, (6, 12, 20), 64, 64), (3, (8, 8, 8), 32, 64), (3, (20, 24, 40), 32, 32),
+    (3, (12, 16, 48), 64, 32), (3, (9, 7, 17), 32, 32)])
 def test_conv3_exact_integers(nv, nd, shape, cin, cout):
     """Small-integer data: every product and sum is exact in f16 x f16 -> f32, so the MFMA
     path must equal the fp32 reference bit for bit (catches any fragment-map / tap / halo
@@ -81,7 +82,8 @@ def test_conv3_exact_integers(nv, nd, shape, cin, cout):
     w = torch.randint(-1, 2, (cout, cin) + (3,) * nd, generator=g).float()
     ref = (F.conv2d if nd == 2 else F.conv3d)(x, w, padding=1)
     for dt in (torch.float16, torch.bfloat16):
-        for layout in ((0, 1) if cout % 64 == 0 else (1,)):              # both kernel structures where legal
+        layouts = ((0, 1) if cout % 64 == 0 and cin % 32 == 0 else (1,)) + ((2,) if nd == 3 and cin <= 64 else ())
+        for layout in layouts:                                            # every kernel structure that is legal
             got = run_conv3(nv, x, w, dt, nd, layout=layout)
             ok = ref.abs() <= (2048 if dt == torch.float16 else 256)   # exactly representable outputs
             assert torch.equal(got[ok], ref[ok]), (dt, layout, (got - ref)[ok].abs().max())
@@ -101,12 +103,20 @@ def test_conv3_random_bias_relu_stats(nv, nd):
     ref = F.relu(conv(x, wf, bias=bias, padding=1))
     got = run_conv3(nv, x, w, torch.float16, nd, scale=scale, bias=bias, epi=2)
     assert (got - ref).abs().max() <= 2e-3 * max(1.0, ref.abs().max().item())
-    raw, st = run_conv3(nv, x, w, torch.float16, nd, stats=True)
     rr = conv(x, w.half().float(), padding=1)
     dims = [0] + list(range(2, 2 + nd))
-    assert torch.allclose(st[:, 0], rr.sum(dims), rtol=1e-3, atol=1e-1)
-    assert torch.allclose(st[:, 1], (rr * rr).sum(dims), rtol=1e-3, atol=1e-1)
-    assert (raw - rr).abs().max() <= 2e-3 * rr.abs().max().item()
+    for layout in (None, 2) if nd == 3 else (None,):
+        raw, st = run_conv3(nv, x, w, torch.float16, nd, stats=True, layout=layout)
+        assert torch.allclose(st[:, 0], rr.sum(dims), rtol=1e-3, atol=1e-1), layout
+        assert torch.allclose(st[:, 1], (rr * rr).sum(dims), rtol=1e-3, atol=1e-1), layout
+        assert (raw - rr).abs().max() <= 2e-3 * rr.abs().max().item(), layout
+    if nd == 3:      # the weight-stationary structure with the 8 x 8 x 16 tile (Cin 32): same statistics grid
+        x2, w2 = x[:, :32].contiguous(), w[:32, :32].contiguous()
+        r2 = conv(x2, w2.half().float(), padding=1)
+        for layout in (1, 2):
+            raw, st = run_conv3(nv, x2, w2, torch.float16, nd, stats=True, layout=layout)
+            assert torch.allclose(st[:, 0], r2.sum(dims), rtol=1e-3, atol=1e-1), layout
+            assert torch.allclose(st[:, 1], (r2 * r2).sum(dims), rtol=1e-3, atol=1e-1), layout
 
 
 @pytest.mark.parametrize('nd', [2, 3])

@@ -39,9 +39,9 @@ def main():
         y = torch.empty(a.n * cout * vox, dtype=T, device='cuda')
         w = torch.randn(cout, cin, *([3] * nd), device='cuda') * 0.05
         lay = nv.lib().iunet_conv3_pick_layout(nd, a.n, D, S, S, cin, cout) if a.layout < 0 else a.layout
-        wpk = torch.empty(nv.pack_conv3_elems(cout, cin, taps, 2 * lay), dtype=T, device='cuda')
+        wpk = torch.empty(nv.pack_conv3_elems(cout, cin, taps, 2 * (lay > 0)), dtype=T, device='cuda')
         bias = torch.zeros(cout, device='cuda')
-        nv.call('iunet_pack_conv3', dt, nv.ptr(w), None, nv.ptr(wpk), cout, cin, taps, 2 * lay, nv.stream())
+        nv.call('iunet_pack_conv3', dt, nv.ptr(w), None, nv.ptr(wpk), cout, cin, taps, 2 * (lay > 0), nv.stream())
         f = lambda: nv.call('iunet_conv3_fwd', dt, nd, nv.ptr(x), cin * vox, nv.ptr(y), cout * vox, nv.ptr(wpk), nv.ptr(bias), None,
                             a.n, D, S, S, cin, cout, 2, lay, nv.stream())
         ms = timeit(f, iters=a.iters)
