@@ -74,9 +74,10 @@ def conv_roofline(nv, dtype, S, iters=10):
     w = torch.randn(cout, cin, 3, 3, 3, device=dev) * 0.03
     dt = nv.DTYPE_CODE[dtype]
     lay = nv.lib().iunet_conv3_pick_layout(3, 1, S, S, S, cin, cout)
-    wpk = torch.empty(nv.pack_conv3_elems(cout, cin, taps, 2 * lay), dtype=dtype, device=dev)
+    pmode = 2 if lay > 0 else 0                 # layouts 1 and 2 share the K16 operator
+    wpk = torch.empty(nv.pack_conv3_elems(cout, cin, taps, pmode), dtype=dtype, device=dev)
     bias = torch.zeros(cout, device=dev)
-    nv.call('iunet_pack_conv3', dt, nv.ptr(w), None, nv.ptr(wpk), cout, cin, taps, 2 * lay, nv.stream())
+    nv.call('iunet_pack_conv3', dt, nv.ptr(w), None, nv.ptr(wpk), cout, cin, taps, pmode, nv.stream())
     run = lambda: nv.call('iunet_conv3_fwd', dt, 3, nv.ptr(x), cin * vox, nv.ptr(y), cout * vox, nv.ptr(wpk),
                           nv.ptr(bias), None, 1, S, S, S, cin, cout, 2, lay, nv.stream())
     for _ in range(3):
@@ -90,7 +91,8 @@ def conv_roofline(nv, dtype, S, iters=10):
     ms = e0.elapsed_time(e1) / iters
     flops = 2.0 * taps * cin * cout * vox
     ach = flops / (ms * 1e-3) / 1e12
-    return {'bound': 'mfma', 'kernel': ('conv3_v2_kernel' if lay else 'conv3_mfma_kernel') + f'<{"bf16" if dtype == torch.bfloat16 else "f16"},3> (dec0.conv1 64->32 @128^3)',
+    kname = {0: 'conv3_mfma_kernel', 1: 'conv3_v2_kernel', 2: 'conv3_v4_kernel'}[lay]
+    return {'bound': 'mfma', 'kernel': kname + f'<{"bf16" if dtype == torch.bfloat16 else "f16"},3> (dec0.conv1 64->32 @128^3)',
             'achieved': round(ach, 2), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / MFMA_PEAK_TFLOPS, 4),
             'ms_per_launch': round(ms, 4), 'flops_per_launch': flops, 'traffic': pmc_traffic()}
 

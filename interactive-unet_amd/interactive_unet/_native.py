@@ -185,7 +185,9 @@ class PackedConv:
     def pick(self, nd, N, D, H, W):
         """(layout, buffer) for a launch on this grid."""
         in_ch = self.cout if self.dg else self.cin
-        lay = lib().iunet_conv3_pick_layout(nd, N, D, H, W, in_ch, self.out_ch) if 0 in self.buf else 1
+        lay = lib().iunet_conv3_pick_layout(nd, N, D, H, W, in_ch, self.out_ch)
+        if lay == 0 and 0 not in self.buf:
+            lay = 1
         return lay, self.buf[1 if lay == 2 else lay]      # layout 2 runs on the K16 operator of layout 1
 
 
