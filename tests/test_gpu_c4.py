@@ -1,0 +1,78 @@
+"""C4 (BASELINE.json configs[3]) at full size on one GPU: a 1024^3 uint8 volume, 128^3 blocks, overlap 0.25 ->
+11^3 = 1 331 blocks through the native 3-D network.  A CPU oracle of the whole volume is out of reach (1.2 PFLOP),
+so the run is checked through size-independent properties of predict.py:201-256 plus an exact oracle comparison
+of the one region that a single block covers."""
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import unet_ref, predict_ref
+
+
+def _box_sums(win, boxes):
+    """sum of win[z0:z1, y0:y1, x0:x1] for every box, through a float64 summed-area table."""
+    sat = np.zeros(tuple(s + 1 for s in win.shape), dtype=np.float64)
+    sat[1:, 1:, 1:] = win.astype(np.float64).cumsum(0).cumsum(1).cumsum(2)
+    tot = 0.0
+    for z0, y0, x0, z1, y1, x1 in boxes:
+        tot += (sat[z1, y1, x1] - sat[z0, y1, x1] - sat[z1, y0, x1] - sat[z1, y1, x0]
+                + sat[z0, y0, x1] + sat[z0, y1, x0] + sat[z1, y0, x0] - sat[z0, y0, x0])
+    return tot
+
+
+def test_c4_full_size_volume_properties():
+    from interactive_unet import predict
+    from interactive_unet.unet import UNet
+    S, C, V = 128, 2, (1024, 1024, 1024)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        model = UNet(num_classes=C, dim=3, act_dtype='fp16', pretrained=False)
+    p = unet_ref.init_params(dim=3, ncls=C, seed=5, randomize_bn=True)
+    model.load_named(p)
+    model = model.cuda().eval()
+    g = torch.Generator(device='cuda').manual_seed(2)
+    vol = torch.randint(0, 256, V, dtype=torch.uint8, device='cuda', generator=g)       # rng(2), generated on device
+    bc, pbc, lbc = predict.get_block_coordinates(np.array(V), input_size=S, overlap=0.25)
+    assert len(pbc) == 1331 and tuple(pbc[0][:3]) == (-32, -32, -32) and tuple(pbc[-1][3:]) == (1056, 1056, 1056)
+
+    import time
+    torch.cuda.synchronize()
+    t0 = time.time()
+    acc = predict.predict_volume_array(model, vol, input_size=S, num_classes=C, overlap=0.25, finalize=False)
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    print(f'C4 on one GPU: 1331 blocks in {dt:.2f} s = {1024 ** 3 / dt / 1e6:.0f} M volume voxels/s '
+          f'({1331 * 128 ** 3 / dt / 1e6:.0f} M processed voxels/s), first call (includes workspace allocation)')
+
+    # (1) checksum of the blend weights: sum over the volume == sum over blocks of the window over its local box
+    win = predict_ref.gaussian_3d(S)
+    want = _box_sums(win, [tuple(int(v) for v in l) for l in lbc])
+    got = acc.weight.sum(dtype=torch.float64).item()
+    assert abs(got - want) <= 1e-6 * want, (got, want)
+    assert acc.weight.min().item() >= 1e-3                     # every voxel is covered (window floor, predict.py:343)
+
+    # (2) softmax partition of unity survives the blend: sum_c pred == weight (fp32 accumulation error only)
+    zs = slice(448, 576)                                       # a 128-plane slab is enough (and fits comfortably)
+    dev = (acc.pred[zs].sum(-1) - acc.weight[zs]).abs().max().item()
+    assert dev <= 1e-5 * acc.weight[zs].max().item() * 27, dev
+
+    out = acc.finalize()
+    assert out.shape == V + (C,) and out.dtype == torch.uint8
+    s = out[zs].sum(-1, dtype=torch.int32)
+    assert s.min().item() >= 253 and s.max().item() <= 255     # truncating cast: each class loses < 1 LSB
+
+    # (3) the corner [0, 64)^3 is covered by block 0 alone (block 1 starts at 64): result == uint8(255 * P_block0)
+    corner = vol[:96, :96, :96].cpu().numpy()
+    blk = predict_ref.get_padded_block(corner, *[int(v) for v in pbc[0]])
+    assert blk.shape == (S, S, S)
+    torch.manual_seed(0)
+    pr = unet_ref.forward(p, torch.tensor(blk.astype(np.float32) / 255)[None, None], dim=3, act_dtype=torch.float16)
+    want_c = (255 * pr[0].permute(1, 2, 3, 0).numpy()[32:96, 32:96, 32:96]).astype(np.uint8)
+    got_c = out[:64, :64, :64].cpu().numpy()
+    d = np.abs(got_c.astype(int) - want_c.astype(int))
+    print(f'C4 corner vs oracle: max |uint8 diff| = {d.max()}, differing = {(d > 0).mean():.4f}')
+    assert d.max() <= 2
