@@ -49,9 +49,12 @@ int iunet_pack_convT(int dtype, const void* w, void* dst, int Cin, int Cout, int
 /* All layers in one launch: `descs` = device array of n descriptors (struct layout: csrc/pack_batch.hip PackDesc,
  * mirrored by interactive_unet/_native.py; iunet_pack_desc_bytes() = its size).  kind 0/1 conv3 layout 0/1, 2 first
  * conv, 3 convT, 4 convT data-gradient; a non-NULL gamma folds BatchNorm (scale = gamma / sqrt(var + eps)) and writes
- * the folded bias.  Element mappings are identical to the per-layer entry points above. */
+ * the folded bias.  Element mappings are identical to the per-layer entry points above.  A descriptor with a qscale
+ * buffer (fp32 [Cout]) has its folded weights quantised to OCP e4m3 values x a per-output-channel power-of-two scale
+ * (BASELINE config C5: fp8 weights, 16-bit activations; the products are exact in f16 / bf16, so the MFMA path is the
+ * same); pass quant_max_cout = the largest Cout of such descriptors, 0 if there are none. */
 int iunet_pack_desc_bytes(void);
-int iunet_pack_batch(const void* descs, int n, void* stream);
+int iunet_pack_batch(const void* descs, int n, int quant_max_cout, void* stream);
 
 /* ---- forward kernels (replace the smp conv stack under unet.py:65-69) ----------------- */
 /* 3^d conv, stride 1, pad 1, implicit GEMM on MFMA.  epi: 0 raw, 1 +bias, 2 +bias+ReLU.

@@ -22,7 +22,27 @@ struct PackDesc {                // mirrored by interactive_unet/_native.py: Pac
   int dtype;                     // 0 f16, 1 bf16
   float eps;
   int pad_;
+  float* qscale;                 // [output channels] or null.  Non-null: weights are quantised to OCP e4m3 values times a
+                                 // per-output-channel power-of-two scale (exact in f16 / bf16) -- BASELINE config C5
 };
+
+// round |x| <= 448 to the nearest OCP e4m3 value (4 exponent bits, bias 7, 3 mantissa bits, subnormal step 2^-9), ties to even
+__device__ __forceinline__ float round_e4m3(float x) {
+  const float a = fabsf(x);
+  int e;
+  (void)frexpf(a, &e);                                     // a = m 2^e, m in [0.5, 1)
+  const int fl = (a == 0.f || e - 1 < -6) ? -6 : e - 1;     // exponent of the binade (subnormals share -6)
+  const float step = ldexpf(1.0f, fl - 3);
+  return copysignf(rintf(a / step) * step, x);
+}
+
+// per-output-channel scale 2^k with max |w| / 2^k <= 448 (k minimal)
+__device__ __forceinline__ float e4m3_scale(float amax) {
+  if (!(amax > 0.f)) return 1.0f;
+  int e;
+  const float m = frexpf(amax / 448.0f, &e);
+  return ldexpf(1.0f, m == 0.5f ? e - 1 : e);
+}
 
 // The fold is the IEEE fp32 formula of the host / oracle (oracle/unet_ref.py: fold_bn): every operation rounded
 // on its own (no fma contraction; hipcc's default sqrt and divide are correctly rounded).
@@ -42,7 +62,8 @@ __device__ __forceinline__ float mul_rn(float a, float b) {
   return a * b;
 }
 
-__device__ __forceinline__ float elem(const PackDesc& d, long long i) {
+__device__ __forceinline__ float elem(const PackDesc& d, long long i, int& oc) {
+  oc = 0;
   int r = (int)i;                                      // a layer has < 2^31 elements: 32-bit divisions
   const int j = r & 7; r >>= 3;
   const int lane = r & 63; r >>= 6;
@@ -56,6 +77,7 @@ __device__ __forceinline__ float elem(const PackDesc& d, long long i) {
     const int chunk = r % nchunk, cob = r / nchunk;
     const int co = cob * 16 * MI + 32 * (m >> 1) + 8 * (row >> 2) + 4 * (m & 1) + (row & 3);
     const int ci = chunk * 32 + 8 * qq + j;
+    oc = co;
     if (!d.dgrad) return mul_rn(w[((long long)co * d.Cin + ci) * d.taps + tap], fold_scale(d, co));
     return w[((long long)ci * d.Cin + co) * d.taps + (d.taps - 1 - tap)];
   }
@@ -71,6 +93,7 @@ __device__ __forceinline__ float elem(const PackDesc& d, long long i) {
     const int col = 2 * c + (qq >> 1);
     if (col >= ncol) return 0.f;
     const int tap = ((col / 3) * 3 + dy) * 3 + (col % 3);
+    oc = co;
     if (!d.dgrad) return mul_rn(w[((long long)co * d.Cin + ci) * d.taps + tap], fold_scale(d, co));
     return w[((long long)ci * d.Cin + co) * d.taps + (d.taps - 1 - tap)];
   }
@@ -81,6 +104,7 @@ __device__ __forceinline__ float elem(const PackDesc& d, long long i) {
     const int co = cob * 32 + 8 * (row >> 2) + 4 * t + (row & 3);
     const int k = 32 * ks + 8 * qq + j;
     if (k >= KK) return 0.f;
+    oc = co;
     return mul_rn(w[(co * d.Cin + k % d.Cin) * d.taps + k / d.Cin], fold_scale(d, co));
   }
   const int npos = d.taps;
@@ -91,6 +115,7 @@ __device__ __forceinline__ float elem(const PackDesc& d, long long i) {
     const int ks = r % nk, cob = r / nk;
     const int co = cob * 32 + 8 * (row >> 2) + 4 * t + (row & 3);
     const int ci = ks * 32 + 8 * qq + j;
+    oc = co;
     return w[((long long)ci * d.Cout + co) * npos + s];
   }
   {                                                    // convT dgrad: [cib32][pos][kc][t][64][8]
@@ -107,7 +132,9 @@ __device__ __forceinline__ float elem(const PackDesc& d, long long i) {
 __global__ __launch_bounds__(256) void pack_batch_kernel(const PackDesc* __restrict__ descs) {
   const PackDesc d = descs[blockIdx.y];
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < d.total; i += (long long)gridDim.x * 256) {
-    const float v = elem(d, i);
+    int oc;
+    float v = elem(d, i, oc);
+    if (d.qscale) { const float sc = d.qscale[oc]; v = sc * round_e4m3(v / sc); }
     if (d.dtype == 0) ((f16*)d.dst)[i] = from_f32<f16>(v);
     else ((bf16*)d.dst)[i] = from_f32<bf16>(v);
   }
@@ -117,6 +144,27 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const PackDesc* __restr
   }
 }
 
+// one block per (layer, output channel): scale of the e4m3 quantisation from max |folded weight|
+__global__ __launch_bounds__(256) void pack_qscale_kernel(const PackDesc* __restrict__ descs) {
+  const PackDesc d = descs[blockIdx.y];
+  const int co = blockIdx.x;
+  if (!d.qscale || d.dgrad || d.kind == 4 || co >= d.Cout) return;
+  __shared__ float red[256];
+  float m = 0.f;
+  if (d.kind == 3) {                                     // convT: w[ci][co][pos]
+    for (int i = threadIdx.x; i < d.Cin * d.taps; i += 256)
+      m = fmaxf(m, fabsf(d.w[((long long)(i / d.taps) * d.Cout + co) * d.taps + i % d.taps]));
+  } else {                                               // conv: w[co][ci][tap], folded
+    const float fs = fold_scale(d, co);
+    const float* w = d.w + (long long)co * d.Cin * d.taps;
+    for (int i = threadIdx.x; i < d.Cin * d.taps; i += 256) m = fmaxf(m, fabsf(mul_rn(w[i], fs)));
+  }
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]); __syncthreads(); }
+  if (threadIdx.x == 0) d.qscale[co] = e4m3_scale(red[0]);
+}
+
 }  // namespace
 
 extern "C" {
@@ -124,8 +172,11 @@ extern "C" {
 int iunet_pack_desc_bytes(void) { return (int)sizeof(PackDesc); }
 
 // descs: device array of `n` descriptors (layout: see PackDesc above / _native.PackDesc)
-int iunet_pack_batch(const void* descs, int n, void* stream) {
+// quant_max_cout > 0: some descriptors carry a qscale buffer (e4m3 weight quantisation); the scales are computed first
+int iunet_pack_batch(const void* descs, int n, int quant_max_cout, void* stream) {
   IUNET_REQUIRE(descs && n > 0, "pack_batch: empty descriptor table");
+  if (quant_max_cout > 0)
+    hipLaunchKernelGGL(pack_qscale_kernel, dim3(quant_max_cout, n), dim3(256), 0, (hipStream_t)stream, (const PackDesc*)descs);
   hipLaunchKernelGGL(pack_batch_kernel, dim3(256, n), dim3(256), 0, (hipStream_t)stream, (const PackDesc*)descs);
   IUNET_CHECK_HIP(hipGetLastError());
   return IUNET_OK;

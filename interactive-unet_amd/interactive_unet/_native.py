@@ -24,7 +24,7 @@ _SIGS = {
     'iunet_pack_conv3': [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     'iunet_pack_first_conv': [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     'iunet_pack_convT': [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
-    'iunet_pack_batch': [c_void_p, c_int, c_void_p],
+    'iunet_pack_batch': [c_void_p, c_int, c_int, c_void_p],
     'iunet_conv3_fwd': [c_int, c_int, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_void_p, c_void_p,
                         c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     'iunet_conv3_pick_layout': [c_int] * 7,
@@ -128,16 +128,18 @@ class PackDesc(ctypes.Structure):
     """One layer of iunet_pack_batch (mirror of csrc/pack_batch.hip: PackDesc)."""
     _fields_ = [('w', c_void_p), ('gamma', c_void_p), ('beta', c_void_p), ('mean', c_void_p), ('var', c_void_p),
                 ('bias_out', c_void_p), ('dst', c_void_p), ('total', c_ll), ('Cout', c_int), ('Cin', c_int),
-                ('taps', c_int), ('kind', c_int), ('dgrad', c_int), ('dtype', c_int), ('eps', c_float), ('pad_', c_int)]
+                ('taps', c_int), ('kind', c_int), ('dgrad', c_int), ('dtype', c_int), ('eps', c_float), ('pad_', c_int),
+                ('qscale', c_void_p)]
 
 
-def make_desc(w, dst, cout, cin, taps, kind, dtype, dgrad=0, bn=None, bias_out=None, eps=1e-5):
+def make_desc(w, dst, cout, cin, taps, kind, dtype, dgrad=0, bn=None, bias_out=None, eps=1e-5, qscale=None):
     d = PackDesc()
     d.w, d.dst, d.total = w.data_ptr(), dst.data_ptr(), dst.numel()
     d.Cout, d.Cin, d.taps, d.kind, d.dgrad, d.dtype, d.eps = cout, cin, taps, kind, int(dgrad), DTYPE_CODE[dtype], eps
     if bn is not None:
         d.gamma, d.beta, d.mean, d.var = [t.data_ptr() for t in bn]
         d.bias_out = None if bias_out is None else bias_out.data_ptr()
+    d.qscale = None if qscale is None else qscale.data_ptr()
     return d
 
 
@@ -151,9 +153,10 @@ class PackTable:
         self.dev = host.to(device)
         self.n = len(descs)
         self.sources = list(sources)
+        self.quant_max_cout = max([d.Cout for d in descs if d.qscale] + [0])
 
     def run(self):
-        call('iunet_pack_batch', ptr(self.dev), self.n, stream())
+        call('iunet_pack_batch', ptr(self.dev), self.n, self.quant_max_cout, stream())
 
 
 class PackedConv:
@@ -174,12 +177,12 @@ class PackedConv:
             call('iunet_pack_conv3', self.dt, ptr(w), ptr(scale), ptr(b), self.cout, self.cin, self.taps,
                  (2 if lay == 1 else 0) | self.dg, stream())
 
-    def descs(self, w, bn=None, bias_out=None, eps=1e-5):
+    def descs(self, w, bn=None, bias_out=None, eps=1e-5, qscale=None):
         """Descriptors of all layouts for iunet_pack_batch (the first one also writes the folded bias)."""
         out = []
         for k, (lay, b) in enumerate(sorted(self.buf.items(), reverse=True)):
             out.append(make_desc(w, b, self.cout, self.cin, self.taps, 1 if lay == 1 else 0, b.dtype, self.dg, bn,
-                                 bias_out if k == 0 else None, eps))
+                                 bias_out if k == 0 else None, eps, qscale))
         return out
 
     def pick(self, nd, N, D, H, W):

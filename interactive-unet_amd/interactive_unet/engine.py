@@ -25,7 +25,8 @@ def _vox(dims):
 
 
 class Engine:
-    def __init__(self, dim=2, levels=4, base=32, cin=1, ncls=2, act_dtype=torch.float16, device='cuda'):
+    def __init__(self, dim=2, levels=4, base=32, cin=1, ncls=2, act_dtype=torch.float16, device='cuda',
+                 weight_dtype=None):
         if dim not in (2, 3):
             raise ValueError('dim must be 2 or 3')
         if base % 32 != 0:
@@ -36,6 +37,9 @@ class Engine:
             raise NotImplementedError('native U-Net supports 2..10 classes (app.py:162)')
         self.dim, self.levels, self.base, self.cin, self.ncls = dim, levels, base, cin, ncls
         self.act_dtype = act_dtype
+        if weight_dtype not in (None, 'fp8_e4m3'):
+            raise ValueError("weight_dtype must be None (= activation dtype) or 'fp8_e4m3'")
+        self.weight_dtype = weight_dtype      # 'fp8_e4m3': inference weights on the OCP e4m3 grid (config C5)
         self.dt = nv.DTYPE_CODE[act_dtype]
         self.device = torch.device(device)
         self.ch = [base * 2 ** l for l in range(levels)]
@@ -89,29 +93,33 @@ class Engine:
         src['head.bias'] = self._source(params, 'head.bias')
         sig = tuple(t.data_ptr() for t in src.values())
         if sig != self._eval_sig:
-            P, descs = {}, []
+            P, descs, keep_q = {}, [], []
             for prefix in self.stage_names():
                 ci, co = self.stage_io(prefix)
                 for j, (a, b) in enumerate(((ci, co), (co, co)), 1):
                     w = src[f'{prefix}.conv{j}.weight']
                     bn = [src[f'{prefix}.bn{j}.{k}'] for k in ('weight', 'bias', 'running_mean', 'running_var')]
                     bias = torch.empty(b, dtype=torch.float32, device=self.device)
+                    qs = torch.empty(b, dtype=torch.float32, device=self.device) if self.weight_dtype else None
                     if prefix == 'enc0' and j == 1:
                         dst = torch.empty(nv.lib().iunet_pack_first_conv_elems(b, a, self.taps), dtype=self.act_dtype,
                                           device=self.device)
                         descs.append(nv.make_desc(w, dst, b, a, self.taps, 2, self.act_dtype, bn=bn, bias_out=bias,
-                                                  eps=BN_EPS))
+                                                  eps=BN_EPS, qscale=qs))
                     else:
                         dst = nv.PackedConv(b, a, self.taps, self.act_dtype, self.device)
-                        descs += dst.descs(w, bn, bias, BN_EPS)
+                        descs += dst.descs(w, bn, bias, BN_EPS, qs)
                     P[f'{prefix}.conv{j}'] = (dst, bias)
+                    keep_q.append(qs)
             for l in range(self.levels - 2, -1, -1):
                 w = src[f'dec{l}.up.weight']
                 dst = torch.empty(w.numel(), dtype=self.act_dtype, device=self.device)
-                descs.append(nv.make_desc(w, dst, self.ch[l], self.ch[l + 1], self.npos, 3, self.act_dtype))
+                qs = torch.empty(self.ch[l], dtype=torch.float32, device=self.device) if self.weight_dtype else None
+                keep_q.append(qs)
+                descs.append(nv.make_desc(w, dst, self.ch[l], self.ch[l + 1], self.npos, 3, self.act_dtype, qscale=qs))
                 P[f'dec{l}.up'] = (dst, src[f'dec{l}.up.bias'])
             P['head'] = (src['head.weight'].reshape(self.ncls, self.ch[0]), src['head.bias'])
-            self._eval_table = nv.PackTable(descs, self.device, sources=list(src.values()))
+            self._eval_table = nv.PackTable(descs, self.device, sources=list(src.values()) + keep_q)
             self._eval_sig = sig
             self.packed = P
         self._eval_table.run()

@@ -52,7 +52,7 @@ class UNet(nn.Module):
 
     def __init__(self, lr=0.0001, num_channels=1, num_classes=2, loss_function=metrics.mcc_ce_loss,
                  architecture='U-Net', encoder_name='mit_b0', pretrained=True,
-                 dim=2, levels=4, base=32, act_dtype='fp16'):
+                 dim=2, levels=4, base=32, act_dtype='fp16', weight_dtype=None):
         super().__init__()
         if architecture != 'U-Net':
             raise NotImplementedError(f"architecture {architecture!r}: only 'U-Net' has a native MI355X "
@@ -63,12 +63,16 @@ class UNet(nn.Module):
                             loss_function=getattr(loss_function, '__name__', str(loss_function)),
                             architecture=architecture, encoder_name=encoder_name, pretrained=pretrained,
                             dim=dim, levels=levels, base=base,
-                            act_dtype='bf16' if _ACT[act_dtype] == torch.bfloat16 else 'fp16')
+                            act_dtype='bf16' if _ACT[act_dtype] == torch.bfloat16 else 'fp16',
+                            weight_dtype=weight_dtype)
         self.lr = lr
         self.loss_function = loss_function
         self.dim, self.levels, self.base = dim, levels, base
         self.num_channels, self.num_classes = num_channels, num_classes
         self.act_dtype = _ACT[act_dtype]
+        # 'fp8_e4m3' (BASELINE config C5): inference runs on weights quantised to OCP e4m3 with per-output-channel
+        # power-of-two scales (after the BatchNorm fold); training keeps fp32 masters and 16-bit operators
+        self.weight_dtype = weight_dtype
         self._names = []
         for name, shp in param_shapes(dim, levels, base, num_channels, num_classes).items():
             t = torch.empty(shp, dtype=torch.float32)
@@ -134,7 +138,8 @@ class UNet(nn.Module):
                                '(there is no CPU fallback)')
         eng = self._engines.get(dev)
         if eng is None:
-            eng = Engine(self.dim, self.levels, self.base, self.num_channels, self.num_classes, self.act_dtype, dev)
+            eng = Engine(self.dim, self.levels, self.base, self.num_channels, self.num_classes, self.act_dtype, dev,
+                         weight_dtype=self.weight_dtype)
             self._engines = {dev: eng}
             self._packed_sig = None
         sig = self._signature()

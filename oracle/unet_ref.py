@@ -20,6 +20,7 @@ Two evaluation modes:
   stage conv / transposed conv; head in fp32 from act_dtype activations.
 """
 import math
+import numpy as np
 import torch
 import torch.nn.functional as F
 
@@ -126,7 +127,38 @@ def fold_bn(w, gamma, beta, mean, var):
     return w * a.view(-1, *([1] * (w.dim() - 1))), beta - mean * a
 
 
-def forward_logits(p, x, dim=2, levels=4, training=False, act_dtype=None, bn_stats_out=None):
+def fold_bn_exact(w, gamma, beta, mean, var):
+    """fold_bn with every fp32 operation correctly rounded (numpy; torch's CPU sqrt / divide differ by an ulp):
+    the quantised path below needs the fold bit-identical to the device's."""
+    g, b, m, v = [t.detach().numpy().astype(np.float32) for t in (gamma, beta, mean, var)]
+    a = g / np.sqrt(v + np.float32(BN_EPS))
+    wf = w.detach().numpy().astype(np.float32) * a.reshape(-1, *([1] * (w.dim() - 1)))
+    return torch.from_numpy(wf), torch.from_numpy(b - m * a)
+
+
+def round_e4m3(x):
+    """Nearest OCP e4m3 value (4 exponent bits, bias 7, 3 mantissa bits, subnormal step 2^-9), ties to even,
+    for |x| <= 448.  numpy float32."""
+    x = np.asarray(x, dtype=np.float32)
+    a = np.abs(x)
+    _, e = np.frexp(a)
+    fl = np.where((a == 0) | (e - 1 < -6), -6, e - 1)
+    step = np.ldexp(np.float32(1), fl - 3).astype(np.float32)
+    return np.copysign(np.rint(a / step) * step, x).astype(np.float32)
+
+
+def quantize_e4m3(w, out_axis=0):
+    """Config C5's weight format: per-output-channel scale 2^k (k minimal with max|w| / 2^k <= 448) times an
+    e4m3 value.  Returns the dequantised fp32 tensor (exactly representable in f16 and bf16)."""
+    a = w.detach().numpy().astype(np.float32)
+    red = tuple(i for i in range(a.ndim) if i != out_axis)
+    amax = np.abs(a).max(axis=red, keepdims=True)
+    m, e = np.frexp((amax / np.float32(448)).astype(np.float32))
+    scale = np.where(amax > 0, np.ldexp(np.float32(1), np.where(m == 0.5, e - 1, e)), np.float32(1)).astype(np.float32)
+    return torch.from_numpy((scale * round_e4m3(a / scale)).astype(np.float32))
+
+
+def forward_logits(p, x, dim=2, levels=4, training=False, act_dtype=None, bn_stats_out=None, weight_quant=None):
     """x: [N, cin, *spatial] float32 in [0,1].  Returns fp32 logits [N, ncls, *spatial].
 
     training=True uses batch statistics in BatchNorm (and, if bn_stats_out is a dict,
@@ -151,6 +183,9 @@ def forward_logits(p, x, dim=2, levels=4, training=False, act_dtype=None, bn_sta
                 y = (y - mean.view(shape)) / torch.sqrt(var.view(shape) + BN_EPS)
                 y = y * bn[0].view(shape) + bn[1].view(shape)
                 t = _rnd_ag(F.relu(y), act_dtype)
+            elif weight_quant == 'fp8_e4m3':
+                wf, bf = fold_bn_exact(w, *bn)
+                t = _rnd(F.relu(conv(t, quantize_e4m3(wf), bias=bf, padding=1)), act_dtype)
             else:
                 wf, bf = fold_bn(w, *bn)
                 t = _rnd(F.relu(conv(t, _rnd(wf, act_dtype), bias=bf, padding=1)), act_dtype)
@@ -165,14 +200,17 @@ def forward_logits(p, x, dim=2, levels=4, training=False, act_dtype=None, bn_sta
             t = pool(t, 2)
     for l in range(levels - 2, -1, -1):
         R = _rnd_ag if training else _rnd
-        up = R(convT(t, R(p[f'dec{l}.up.weight'], act_dtype), bias=p[f'dec{l}.up.bias'], stride=2), act_dtype)
+        wu = p[f'dec{l}.up.weight']
+        if weight_quant == 'fp8_e4m3' and not training:
+            wu = quantize_e4m3(wu, out_axis=1)
+        up = R(convT(t, R(wu, act_dtype), bias=p[f'dec{l}.up.bias'], stride=2), act_dtype)
         t = stage(f'dec{l}', torch.cat([skips[l], up], dim=1))
     return conv(t, p['head.weight'], bias=p['head.bias'])
 
 
-def forward(p, x, dim=2, levels=4, training=False, act_dtype=None):
+def forward(p, x, dim=2, levels=4, training=False, act_dtype=None, weight_quant=None):
     """Softmax probabilities NCHW(D), as UNet.forward returns them (unet.py:65-69)."""
-    return torch.softmax(forward_logits(p, x, dim, levels, training, act_dtype), dim=1)
+    return torch.softmax(forward_logits(p, x, dim, levels, training, act_dtype, weight_quant=weight_quant), dim=1)
 
 
 def flops_per_voxel(dim=2, levels=4, base=32, cin=1, ncls=2):

@@ -309,3 +309,44 @@ def test_pack_batch_matches_per_layer_packs(nv, dt):
         assert got.dtype == ref.dtype and got.shape == ref.shape, name
         bits = torch.int16 if got.dtype != torch.float32 else torch.int32
         assert torch.equal(got.view(bits), ref.view(bits)), name
+
+
+def test_pack_batch_e4m3_quantisation_matches_oracle(nv):
+    """Device-side e4m3 weight quantisation (in-kernel BatchNorm fold -> per-output-channel scale -> round) packs the
+    same bits as packing the oracle's quantised weights unquantised."""
+    from oracle import unet_ref
+    T, dev = torch.bfloat16, 'cuda'
+    code = nv.DTYPE_CODE[T]
+    g = torch.Generator().manual_seed(12)
+    descs, expect, keep = [], [], []
+    for taps, cout, cin in ((27, 64, 32), (9, 32, 64), (27, 32, 32)):
+        w = torch.randn(cout, cin, taps, generator=g) * (2.0 / (cin * taps)) ** 0.5
+        w[3] *= 2.0 ** -7                                    # a channel deep in the subnormal range of another scale
+        w[5] = 0                                             # an all-zero channel
+        bn = [0.75 + 0.5 * torch.rand(cout, generator=g), 0.1 * torch.randn(cout, generator=g),
+              0.2 * torch.randn(cout, generator=g), 0.5 + torch.rand(cout, generator=g)]
+        wf, bf = unet_ref.fold_bn_exact(w, *bn)
+        wq = unet_ref.quantize_e4m3(wf).to(dev)
+        wd, bnd = w.to(dev), [t.to(dev) for t in bn]
+        pc = nv.PackedConv(cout, cin, taps, T, dev)
+        pc.pack(wq, None)
+        ref = {lay: b.clone() for lay, b in pc.buf.items()}
+        for b in pc.buf.values():
+            b.zero_()
+        qs, bias = torch.zeros(cout, device=dev), torch.zeros(cout, device=dev)
+        descs += pc.descs(wd, bnd, bias, 1e-5, qs)
+        expect += [(f'conv taps{taps} {cout}x{cin} layout{lay}', pc.buf[lay], ref[lay]) for lay in pc.buf]
+        expect.append((f'bias taps{taps}', bias, bf.to(dev)))
+        keep += [wd, bnd, pc, wq, qs]
+    wt = torch.randn(64, 32, 8, generator=g) * 0.2           # transposed conv: output channels on axis 1
+    wtq = unet_ref.quantize_e4m3(wt, out_axis=1).to(dev)
+    ref = torch.zeros(wt.numel(), dtype=T, device=dev)
+    nv.call('iunet_pack_convT', code, nv.ptr(wtq), nv.ptr(ref), 64, 32, 8, nv.stream())
+    dst, qs, wtd = torch.zeros(wt.numel(), dtype=T, device=dev), torch.zeros(32, device=dev), wt.to(dev)
+    descs.append(nv.make_desc(wtd, dst, 32, 64, 8, 3, T, qscale=qs))
+    expect.append(('convT', dst, ref))
+    nv.PackTable(descs, dev).run()
+    torch.cuda.synchronize()
+    for name, got, want in expect:
+        bits = torch.int16 if got.dtype != torch.float32 else torch.int32
+        assert torch.equal(got.view(bits), want.view(bits)), name

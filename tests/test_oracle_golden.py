@@ -116,3 +116,21 @@ def test_slicer_geometry(G):
         assert np.array_equal(upd, g[f's{i}_upd_vol'])
         # to_dict/from_dict re-derives the vectors from the *normalised* rotation vector (slicer.py:84-92)
         assert np.array_equal(slicer_ref.orientation_vectors(rot_vec)[2], g[f's{i}_rt_u'])
+
+
+def test_e4m3_rounding_matches_torch_float8():
+    """oracle.unet_ref.round_e4m3 (the definition the device quantiser is tested against) equals torch's
+    float8_e4m3fn conversion on the whole finite range, including subnormals and ties."""
+    import numpy as np
+    import torch
+    from oracle import unet_ref
+    rng = np.random.default_rng(0)
+    x = np.concatenate([(rng.standard_normal(200000) * s).astype(np.float32) for s in (100, 1, 0.01)]).clip(-448, 448)
+    ties = np.float32([0, 448, -448, 2 ** -9, 2 ** -10, 3 * 2 ** -10, 2 ** -6, 1.0625, 1.1875, 17, 19, 416, 432, 447.9])
+    x = np.concatenate([x, ties, -ties])
+    want = torch.from_numpy(x).to(torch.float8_e4m3fn).float().numpy()
+    assert np.array_equal(unet_ref.round_e4m3(x), want)
+    w = torch.randn(16, 8, 3, 3, 3, generator=torch.Generator().manual_seed(1)) * 0.07
+    q = unet_ref.quantize_e4m3(w)
+    assert torch.equal(q.half().float(), q) and torch.equal(q.bfloat16().float(), q)        # exact in both 16-bit types
+    assert (q - w).abs().max() <= w.abs().amax(dim=(1, 2, 3, 4)).max() * 2 ** -4             # half an e4m3 step at the top binade
