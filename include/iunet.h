@@ -102,6 +102,13 @@ int iunet_normalize_quantize(const void* pred, const void* weight, void* out_u8,
                              void* stream);
 int iunet_div_f32(void* p, long long n, float d, void* stream);
 
+/* ---- oblique slices (slicer.py:94-115, :196-228; SURVEY 8f "Slicer on device") ----------- */
+/* out[i][j] (uint8 [sw][sw]) = map_coordinates(vol[lo : lo + len], origin + a * r_i + b * r_j - lo, order, mode
+ * 'constant'), r_k = start + k; bit-exact with scipy for orders 0 and 1.  geom: 9 host doubles a[3], b[3], origin[3];
+ * lo, len: host ints [3] (the reference's bounding-box crop). */
+int iunet_slice_gather(const void* vol, int Z, int Y, int X, const double* geom, const int* lo, const int* len, int sw,
+                       int start, int order, void* out, void* stream);
+
 /* ---- training step (replaces autograd + AMP + AdamW under unet.py:71-102, trainer.py:56-63) -- */
 /* BatchNorm batch statistics: slab = partial (sum, sumsq) [nparts][C][2] written by the conv
  * epilogues -> per-channel scale/shift (gamma*invstd, beta-mean*scale), mean, invstd; updates

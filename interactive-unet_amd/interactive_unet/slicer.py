@@ -1,5 +1,7 @@
-"""Drop-in for interactive_unet/slicer.py (interface row a19 of SURVEY.md section 8: kept
-compatible, not accelerated this round).  Same class, attributes and method signatures;
+"""Drop-in for interactive_unet/slicer.py (row a19 of SURVEY.md section 8).  Same class, attributes and method
+signatures; `get_slice` on a uint8 volume that is a CUDA tensor runs on the device (libiunet: iunet_slice_gather,
+bit-exact with the scipy path for orders 0 and 1 -- SURVEY 8f "Slicer on device"), numpy volumes take the reference's
+scipy path;
 geometry written as small pure helpers (orientation from a rotation vector by Rodrigues'
 formula, plane grids, nearest/linear sampling through scipy) with the reference's numeric
 conventions: 15-decimal rounding then normalisation (slicer.py:22-35), eps-shifted rotation
@@ -97,7 +99,44 @@ class Slicer(object):
                 + self.volume_shape * (1 - origin_shift_range)
         return self.rot_vec, self.u, self.v, self.w, self.origin
 
+    def _plane_vectors(self, axis):
+        return ((self.v, self.w), (self.u, self.w), (self.u, self.v))[axis]
+
+    def _get_slice_device(self, volume, axis, slice_width, order):
+        """slicer.py:196-228 on a resident uint8 volume: only the 4 corner points are computed on the host (each
+        coordinate is monotone in r_i and r_j, rounding included, so the bounding box of the grid is the bounding box
+        of its corners); the gather runs in one kernel and the slice stays on the device."""
+        import ctypes
+        import torch
+        from . import _native as nv
+        if volume.dtype != torch.uint8 or volume.dim() != 3:
+            raise NotImplementedError('device get_slice handles uint8 [Z, Y, X] volumes')
+        if order not in (0, 1):
+            raise NotImplementedError('device get_slice implements spline orders 0 and 1 (the reference uses those)')
+        volume = volume.contiguous()
+        a, b = self._plane_vectors(axis)
+        start = int(-np.floor(slice_width / 2))
+        ends = np.array([start, start + slice_width - 1], dtype=float)
+        corners = a[:, None, None] * ends[None, :, None] + b[:, None, None] * ends[None, None, :] \
+            + self.origin[:, None, None]
+        shape = np.array(volume.shape)
+        lo = np.maximum(np.floor(corners.min(axis=(1, 2))).astype(int), 0)
+        hi = np.minimum(np.ceil(corners.max(axis=(1, 2))).astype(int), shape)
+        if self.sampling_axis in ('x', 'y', 'z'):
+            hi['xyz'.index(self.sampling_axis)] += 1
+        hi = np.minimum(hi, shape)                             # what the slicing of the crop does
+        lo = np.minimum(lo, shape)
+        length = np.maximum(hi - lo, 0)
+        out = torch.empty((slice_width, slice_width), dtype=torch.uint8, device=volume.device)
+        geom = (ctypes.c_double * 9)(*[float(t) for t in (*a, *b, *np.asarray(self.origin, float))])
+        with torch.cuda.device(volume.device):
+            nv.call('iunet_slice_gather', nv.ptr(volume), int(shape[0]), int(shape[1]), int(shape[2]), geom,
+                    nv.int_array(lo), nv.int_array(length), int(slice_width), start, int(order), nv.ptr(out), nv.stream())
+        return out
+
     def get_slice(self, volume, axis=0, slice_width=256, order=0):
+        if hasattr(volume, 'is_cuda') and volume.is_cuda:
+            return self._get_slice_device(volume, axis, slice_width, order)
         coords = self.get_interpolation_coords(slice_width=slice_width)[axis]
         lo = np.maximum(np.floor(coords.min(axis=(1, 2))).astype(int), 0)
         hi = np.minimum(np.ceil(coords.max(axis=(1, 2))).astype(int), np.array(volume.shape))

@@ -111,3 +111,42 @@ def test_train_model_files_and_learning(tmp_path, monkeypatch):
     assert m.num_classes == 2 and abs(m.lr - 1e-3) < 1e-12
     trainer.train_model(5e-4, 2, 1, 1, 2, 'Dice + CE', 'U-Net', 'mit_b0', False, train_loader=train, val_loader=val)
     assert len(glob.glob('model/history/*/version_0/metrics.csv')) >= 1 and os.path.isfile('model/model.ckpt')
+
+
+def test_device_slicer_bit_exact(golden_dir):
+    """Slicer.get_slice on a resident uint8 volume (iunet_slice_gather) against (a) the slices the REFERENCE produced
+    for the golden cases (tests/golden/slicer.npz, orders 0 and 1, all three planes) and (b) the oracle's scipy path
+    on larger random poses, axis-aligned ones and poses that leave the volume: identical bytes."""
+    from interactive_unet.slicer import Slicer
+    from oracle import slicer_ref
+    g = np.load(os.path.join(golden_dir, 'slicer.npz'))
+    vol = g['ramp']                  # the volume the reference sliced (make_golden.py: make_slicer)
+    vd = torch.tensor(vol).cuda()
+    for i in range(int(g['n'])):
+        s = Slicer(volume_shape=list(vol.shape))
+        s.update_orientation_vectors(g[f's{i}_rv'])
+        s.origin = g[f's{i}_origin'].astype(float)
+        for axis in range(3):
+            for order in (0, 1):
+                got = s.get_slice(vd, axis=axis, slice_width=24, order=order).cpu().numpy()
+                assert np.array_equal(got, g[f's{i}_slice_a{axis}_o{order}']), (i, axis, order)
+    rng = np.random.default_rng(7)
+    V = (70, 96, 83)
+    big = rng.integers(0, 256, V, dtype=np.uint8)
+    bd = torch.tensor(big).cuda()
+    np.random.seed(11)
+    for trial in range(12):
+        s = Slicer(volume_shape=list(V))
+        if trial % 4 == 3:
+            s.randomize(sampling_mode='grid')                       # axis-aligned, integer normal
+        else:
+            s.randomize(sampling_mode='random', origin_shift_range=1.0 if trial % 2 else 0.8)
+        if trial == 5:
+            s.origin = np.array([-40.0, 10.0, 70.0])                # mostly outside the volume
+        for axis in range(3):
+            for order in (0, 1):
+                for sw in (64, 129):
+                    want = slicer_ref.get_slice(big, s.u, s.v, s.w, s.origin, axis=axis, slice_width=sw, order=order,
+                                                sampling_axis=s.sampling_axis)
+                    got = s.get_slice(bd, axis=axis, slice_width=sw, order=order).cpu().numpy()
+                    assert np.array_equal(got, want), (trial, axis, order, sw, np.abs(got.astype(int) - want).max())
