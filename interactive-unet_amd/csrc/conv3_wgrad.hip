@@ -14,6 +14,7 @@
 // LDS plane strides are 64 mod 256 bytes: a 32-lane half of the tr-read touches planes
 // p, p+1 and pixels P..P+3, P+8..P+11 -> 32 distinct 8-byte slots of the 256-B bank row.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -248,10 +249,19 @@ int launch_wgrad(const WgradParams& p, int nb, hipStream_t stream) {
 
 }  // namespace
 
+int iunet_conv3_wgrad_v2_blocks(int N, int D, int H, int W, int Cin, int Cout);
+int iunet_conv3_wgrad_v2_launch(int dtype, const void* x, long long x_ss, const void* dy, long long dy_ss, float* slab,
+                                int N, int D, int H, int W, int Cin, int Cout, hipStream_t stream);
+static bool wgrad_use_v2(int nd) {
+  static const bool off = getenv("IUNET_WGRAD_V1") != nullptr;       // A/B runs: the two-workgroups-per-CU structure
+  return nd == 3 && !off;
+}
+
 extern "C" {
 
 // number of voxel-walking workgroups per (co, ci) block and the slab size they need
 int iunet_conv3_wgrad_blocks(int nd, int N, int D, int H, int W, int Cin, int Cout) {
+  if (wgrad_use_v2(nd)) return iunet_conv3_wgrad_v2_blocks(N, D, H, W, Cin, Cout);
   const int TZ = nd == 3 ? 2 : 1, TY = nd == 3 ? 8 : 16, TX = nd == 3 ? 16 : 32;
   const long long ntiles = (long long)N * ((D + TZ - 1) / TZ) * ((H + TY - 1) / TY) * ((W + TX - 1) / TX);
   const int pairs = (Cin / 32) * (Cout / 32);
@@ -280,7 +290,8 @@ int iunet_conv3_wgrad(int dtype, int nd, const void* x, long long x_ss, const vo
   p.tilesZ = (D + TZ - 1) / TZ; p.tilesY = (H + TY - 1) / TY; p.tilesX = (W + TX - 1) / TX;
   const int nb = iunet_conv3_wgrad_blocks(nd, N, D, H, W, Cin, Cout);
   int rc;
-  if (dtype == 0) rc = nd == 3 ? launch_wgrad<f16, 3>(p, nb, (hipStream_t)stream) : launch_wgrad<f16, 2>(p, nb, (hipStream_t)stream);
+  if (wgrad_use_v2(nd)) rc = iunet_conv3_wgrad_v2_launch(dtype, x, x_ss, dy, dy_ss, (float*)slab, N, D, H, W, Cin, Cout, (hipStream_t)stream);
+  else if (dtype == 0) rc = nd == 3 ? launch_wgrad<f16, 3>(p, nb, (hipStream_t)stream) : launch_wgrad<f16, 2>(p, nb, (hipStream_t)stream);
   else rc = nd == 3 ? launch_wgrad<bf16, 3>(p, nb, (hipStream_t)stream) : launch_wgrad<bf16, 2>(p, nb, (hipStream_t)stream);
   if (rc != IUNET_OK) return rc;
   const int taps = nd == 3 ? 27 : 9;

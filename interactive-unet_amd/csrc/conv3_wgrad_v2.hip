@@ -1,0 +1,300 @@
+// Weight gradient of the 3x3x3 convolution, wave-specialised structure (see conv3_wgrad.hip for the math and the
+// transposing-LDS-read fragment scheme, conv3_v4.hip for why the roles are split).
+//
+// One persistent 12-wave workgroup per CU and (32 co) x (32 ci) filter block:
+//   * 4 LOADER waves stage the next tile (x halo 4 x 10 x 18 voxels x 32 ci + dy 2 x 8 x 16 voxels x 32 co, 62 KB)
+//     global -> registers -> the other LDS buffer; the loads of tile t + 2 are issued right after tile t + 1 has been
+//     written, so they are in flight during a whole consumer tile.  Tiles are walked z-fastest, so two of the four halo z-planes of every tile were fetched by
+//     this CU one step earlier (L2 hits);
+//   * 8 CONSUMER waves = 2 voxel (k) halves x 4 unit waves: a unit wave owns 14 of the 54 (tap, ci half) units
+//     (112 accumulator registers, as before); each k half walks 4 of the tile's 8 k-steps.  One barrier per tile.
+//   At the end the two k halves are added through LDS and one fp32 slab is stored; the slab reduce is unchanged
+//   (and reads half as many slabs: one workgroup per CU instead of two).
+#include "common.h"
+#include <cstdlib>
+
+namespace {
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) s16x4* lds_s4_ptr;
+
+struct WgradV2Params {
+  const void* x;  long long x_ss;     // conv input  (Cin/8 planes)
+  const void* dy; long long dy_ss;    // output grad (Cout/8 planes)
+  float* slab;                        // [gridDim.x][Cout/32][Cin/32][27][32][32]
+  int N, D, H, W, Cin, Cout;
+  int tilesZ, tilesY, tilesX;
+  int dbg;                            // profiling only (IUNET_WG2_DBG): 1 no refill after tile 0, 2 no MFMA phase
+};
+
+template <typename T>
+__device__ __forceinline__ typename Vec8<T>::type tr_frag_v2(unsigned addr) {
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)addr);
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(addr + 64));
+  const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(typename Vec8<T>::type, v);
+}
+
+template <typename T>
+__global__ __launch_bounds__(768, 1) void conv3_wgrad_v2_kernel(WgradV2Params p) {
+  constexpr int TZ = 2, TY = 8, TX = 16, TAPS = 27;
+  constexpr int PY = TY + 2, PX = TX + 2;
+  constexpr int ZPIX = PY * PX;                                    // 180 voxels per halo z-plane
+  constexpr int NSLOT = 6;                                         // z-plane ring: 4 in use + 2 incoming
+  constexpr int NVOX = TZ * TY * TX;                               // 256
+  constexpr int NKS = NVOX / 32;                                   // 8 k-steps of 32 voxels
+  constexpr int PLANE_X = NSLOT * ZPIX * 16 + 192;                 // 17 472 = 64 mod 256: conflict-free transposing reads
+  constexpr int PLANE_Y = ((NVOX * 16 + 255) / 256) * 256 + 64;
+  constexpr int OFF_Y = 4 * PLANE_X;
+  constexpr int YBUF = 4 * PLANE_Y;
+  constexpr int NU = TAPS * 2, MAXU = (NU + 3) / 4;                // 54 units, 14 per unit wave
+  constexpr int NCW = 8, NLT = 256;
+  constexpr int XIT = (4 * ZPIX * 4 + NLT - 1) / NLT;              // 16-byte x items per loader thread, 4 z-planes (12)
+  constexpr int YIT = NVOX * 4 / NLT;                              // dy items per loader thread (4)
+  static_assert(PLANE_X % 256 == 64, "x plane stride must be 64 mod 256");
+
+  extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cob = blockIdx.y, cib = blockIdx.z;
+  const int tiles_per_sample = p.tilesZ * p.tilesY * p.tilesX;
+  const int ntiles = tiles_per_sample * p.N;
+  const long long plane_stride = (long long)p.D * p.H * p.W * 8;
+  const int lb = xcd_remap(blockIdx.x, gridDim.x);
+  const int t_begin = (int)((long long)lb * ntiles / gridDim.x), t_end = (int)((long long)(lb + 1) * ntiles / gridDim.x);
+  const int nt = t_end - t_begin;
+
+  // tiles are walked z-fastest: inside a z column the halo of tile k + 1 shares two of its four z-planes with tile k,
+  // and those stay where they are in the LDS ring -- only the two new planes travel (x bytes per tile halved)
+  auto tile_origin = [&](int k, int& n_img, int& z0, int& y0, int& x0) {
+    const int tile = t_begin + k;
+    n_img = tile / tiles_per_sample;
+    int trem = tile - n_img * tiles_per_sample;
+    const int tz_i = trem % p.tilesZ; trem /= p.tilesZ;
+    const int tx_i = trem % p.tilesX, ty_i = trem / p.tilesX;
+    z0 = tz_i * TZ; y0 = ty_i * TY; x0 = tx_i * TX;
+  };
+  auto fresh = [&](int k) { return k == 0 || (t_begin + k) % p.tilesZ == 0; };      // first tile of a z column (or of the run)
+
+  if (wave >= NCW) {
+    // ================================================================== loader waves
+    const int lt = tid - NCW * 64;
+    struct Staged { u32x4 x[XIT]; u32x4 y[YIT]; unsigned okx, oky; };
+    // per-thread item tables, computed once: the loaders' integer arithmetic per tile is what their rate depends on
+    // x item = (zi, channel plane, voxel of the z-plane): packed zi | pl << 4 | py << 8 | px << 16, and its LDS offset
+    int xc[XIT], xl[XIT], yc[YIT], yl[YIT];
+#pragma unroll
+    for (int it = 0; it < XIT; ++it) {
+      const int item = min(lt + it * NLT, 16 * ZPIX - 1);
+      const int zi = item / (4 * ZPIX), rem = item - zi * (4 * ZPIX), pl = rem / ZPIX, pix = rem - pl * ZPIX;
+      const int py = pix / PX, px = pix - py * PX;
+      xc[it] = zi | (pl << 4) | (py << 8) | (px << 16);
+      xl[it] = pl * PLANE_X + pix * 16;
+    }
+#pragma unroll
+    for (int it = 0; it < YIT; ++it) {
+      const int item = lt + it * NLT;
+      const int pl = item / NVOX, pix = item - pl * NVOX;
+      const int px = pix % TX, t2 = pix / TX, py = t2 % TY, pz = t2 / TY;
+      yc[it] = pz | (pl << 4) | (py << 8) | (px << 16);
+      yl[it] = pl * PLANE_Y + pix * 16;
+    }
+    // tile k's new planes: all four (pz 0..3) when fresh, else pz 2, 3
+    auto load = [&](int k, Staged& r) {
+      int n_img, z0, y0, x0;
+      tile_origin(k, n_img, z0, y0, x0);
+      const bool fr = fresh(k);
+      const int nitems = (fr ? 4 : 2) * 4 * ZPIX, pz0 = fr ? 0 : 2;
+      const T* xin = (const T*)p.x + (long long)n_img * p.x_ss + (long long)cib * 4 * plane_stride;
+      const T* dyin = (const T*)p.dy + (long long)n_img * p.dy_ss + (long long)cob * 4 * plane_stride;
+      r.okx = 0; r.oky = 0;
+#pragma unroll
+      for (int it = 0; it < XIT; ++it) {
+        if (lt + it * NLT < nitems) {
+          const int zi = xc[it] & 15, pl = (xc[it] >> 4) & 15, py = (xc[it] >> 8) & 255, px = xc[it] >> 16;
+          const int gz = z0 + pz0 + zi - 1, gy = y0 + py - 1, gx = x0 + px - 1;
+          const bool ok = (unsigned)gz < (unsigned)p.D && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+          const int cz = min(max(gz, 0), p.D - 1), cy = min(max(gy, 0), p.H - 1), cx = min(max(gx, 0), p.W - 1);
+          r.x[it] = *(const u32x4*)(xin + pl * plane_stride + (long long)((cz * p.H + cy) * p.W + cx) * 8);
+          r.okx |= ok ? (1u << it) : 0u;
+        }
+      }
+#pragma unroll
+      for (int it = 0; it < YIT; ++it) {
+        const int pz = yc[it] & 15, pl = (yc[it] >> 4) & 15, py = (yc[it] >> 8) & 255, px = yc[it] >> 16;
+        const int gz = z0 + pz, gy = y0 + py, gx = x0 + px;
+        const bool ok = gz < p.D && gy < p.H && gx < p.W;
+        const int cz = min(gz, p.D - 1), cy = min(gy, p.H - 1), cx = min(gx, p.W - 1);
+        r.y[it] = *(const u32x4*)(dyin + pl * plane_stride + (long long)((cz * p.H + cy) * p.W + cx) * 8);
+        r.oky |= ok ? (1u << it) : 0u;
+      }
+    };
+    // x planes zi in [zi_lo, zi_hi) of the staged tile -> ring slots (slot0 + zi) mod 6
+    auto commit_x = [&](const Staged& r, int nitems, int zi_lo, int zi_hi, int slot0) {
+#pragma unroll
+      for (int it = 0; it < XIT; ++it) {
+        const int zi = xc[it] & 15;
+        if (lt + it * NLT < nitems && zi >= zi_lo && zi < zi_hi) {
+          const int slot = (slot0 + zi) % NSLOT;
+          *(u32x4*)(smem + xl[it] + slot * (ZPIX * 16)) = ((r.okx >> it) & 1u) ? r.x[it] : u32x4{0u, 0u, 0u, 0u};
+        }
+      }
+    };
+    auto commit_y = [&](int k, const Staged& r) {
+      unsigned char* b = smem + OFF_Y + (k & 1) * YBUF;
+#pragma unroll
+      for (int it = 0; it < YIT; ++it) *(u32x4*)(b + yl[it]) = ((r.oky >> it) & 1u) ? r.y[it] : u32x4{0u, 0u, 0u, 0u};
+    };
+    const bool refill = !(p.dbg & 1);
+    Staged r;
+    int base = 0;                                   // ring slot of halo plane pz = 0 of the tile being consumed
+    if (nt > 0) { load(0, r); commit_x(r, 16 * ZPIX, 0, 4, 0); commit_y(0, r); }
+    if (nt > 1 && refill) load(1, r);
+    __syncthreads();
+    for (int k = 0; k < nt; ++k) {
+      const bool more = k + 1 < nt && refill;
+      const bool fr = more && fresh(k + 1);
+      if (more) {
+        // incoming planes go to the two free slots base + 4, base + 5: pz 2, 3 of a continuing column, pz 0, 1 of a new one
+        if (fr) commit_x(r, 16 * ZPIX, 0, 2, base + 4); else commit_x(r, 8 * ZPIX, 0, 2, base + 4);
+        commit_y(k + 1, r);
+      }
+      __syncthreads();                              // tile k is consumed
+      if (k + 1 < nt && fresh(k + 1)) {             // (same condition as the consumers': the barrier count must match)
+        if (fr) commit_x(r, 16 * ZPIX, 2, 4, base + 4);      // pz 2, 3 of the new column into the slots tile k just released
+        __syncthreads();
+        base = (base + 4) % NSLOT;
+      } else {
+        base = (base + 2) % NSLOT;
+      }
+      if (k + 2 < nt && refill) load(k + 2, r);
+    }
+    __syncthreads();          // the two barriers of the consumers' final reduction
+    __syncthreads();
+    return;
+  }
+
+  // ==================================================================== consumer waves
+  const int kg = wave >> 2, uw = wave & 3;                         // voxel (k) half = z slice of the tile, unit wave
+  const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3;
+  const int gh = g >> 1, gl = g & 1;
+  // lane part of the tr-read addresses (bytes): voxel (gl*8 + q) of fragment gh, channels 4pp..4pp+3
+  const unsigned laneY = lds0 + OFF_Y + (pp >> 1) * PLANE_Y + (pp & 1) * 8 + (gh * 16 + gl * 8 + q) * 16;
+  const unsigned laneX = lds0 + (pp >> 1) * PLANE_X + (pp & 1) * 8 + (gh * PX + gl * 8 + q) * 16;
+  unsigned unit_off[MAXU];                                         // in-plane part: (dy, dx) shift and ci half
+  int unit_dz[MAXU];
+#pragma unroll
+  for (int i = 0; i < MAXU; ++i) {
+    const int u = uw + 4 * i;
+    const int tap = (u < NU ? u : 0) >> 1, cih = u & 1;
+    const int dz = tap / 9, dy_ = (tap / 3) % 3, dx = tap % 3;
+    unit_off[i] = (unsigned)__builtin_amdgcn_readfirstlane((dy_ * PX + dx) * 16 + cih * 2 * PLANE_X);   // wave-uniform: scalar registers
+    unit_dz[i] = __builtin_amdgcn_readfirstlane(dz);
+  }
+  f32x4 acc[MAXU][2];
+#pragma unroll
+  for (int i = 0; i < MAXU; ++i) { acc[i][0] = f32x4{0, 0, 0, 0}; acc[i][1] = f32x4{0, 0, 0, 0}; }
+
+  int base = 0;
+  __syncthreads();                                                 // tile 0 is in LDS
+  for (int k = 0; k < nt; ++k) {
+    // this wave's output z slice is kg, so unit i reads halo plane pz = kg + dz_i -> ring slot (base + pz) mod 6
+    unsigned uoff[MAXU];
+#pragma unroll
+    for (int i = 0; i < MAXU; ++i)
+      uoff[i] = (unsigned)__builtin_amdgcn_readfirstlane((int)unit_off[i] + ((base + kg + unit_dz[i]) % NSLOT) * ZPIX * 16);
+    const unsigned yoff = (unsigned)((k & 1) * YBUF);
+    if (!(p.dbg & 2))
+#pragma unroll 2
+    for (int kk = 0; kk < NKS / 2; ++kk) {
+      const int f = 2 * (kg * (NKS / 2) + kk);                     // fragment pair (rows 2kk, 2kk + 1 of z slice kg)
+      const int fy = f % TY;
+      const unsigned offY = yoff + (unsigned)(f * 16 * 16);
+      const unsigned offX = (unsigned)(fy * PX * 16);
+      const typename Vec8<T>::type a0 = tr_frag_v2<T>(laneY + offY);                    // co 0..15
+      const typename Vec8<T>::type a1 = tr_frag_v2<T>(laneY + offY + 2 * PLANE_Y);      // co 16..31
+      // branch-free: a wave whose last unit does not exist (u >= NU) recomputes tap 0 into an accumulator that is never stored
+#pragma unroll
+      for (int i = 0; i < MAXU; ++i) {
+        const typename Vec8<T>::type b = tr_frag_v2<T>(laneX + offX + uoff[i]);
+        acc[i][0] = mfma16<T>(a0, b, acc[i][0]);
+        acc[i][1] = mfma16<T>(a1, b, acc[i][1]);
+      }
+    }
+    __syncthreads();
+    if (k + 1 < nt && fresh(k + 1)) {
+      __syncthreads();                                             // the loaders complete the new column's first tile
+      base = (base + 4) % NSLOT;
+    } else {
+      base = (base + 2) % NSLOT;
+    }
+  }
+
+  // ---- add the two k halves (through LDS, 28 KB per unit wave), then store the slab: rows = co (4g + j), cols = ci ----
+  f32x4* red = (f32x4*)smem + (uw * MAXU * 2) * 64 + lane;
+  if (kg == 1) {
+#pragma unroll
+    for (int i = 0; i < MAXU; ++i) { red[(i * 2 + 0) * 64] = acc[i][0]; red[(i * 2 + 1) * 64] = acc[i][1]; }
+  }
+  __syncthreads();
+  if (kg == 0) {
+    const int ncob = gridDim.y, ncib = gridDim.z;
+    float* slab = p.slab + ((((long long)blockIdx.x * ncob + cob) * ncib + cib) * TAPS) * 1024;
+#pragma unroll
+    for (int i = 0; i < MAXU; ++i) {
+      const int u = uw + 4 * i;
+      if (u < NU) {
+        const int tap = u >> 1, cih = u & 1;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const f32x4 o = red[(i * 2 + t) * 64];
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            slab[tap * 1024 + (t * 16 + 4 * g + j) * 32 + cih * 16 + i16] = acc[i][t][j] + o[j];
+        }
+      }
+    }
+  }
+  __syncthreads();
+}
+
+}  // namespace
+
+int iunet_conv3_wgrad_v2_blocks(int N, int D, int H, int W, int Cin, int Cout) {
+  const long long ntiles = (long long)N * ((D + 1) / 2) * ((H + 7) / 8) * ((W + 15) / 16);
+  const int pairs = (Cin / 32) * (Cout / 32);
+  long long nb = (256 + pairs - 1) / pairs;             // one workgroup per CU in total
+  if (nb > ntiles) nb = ntiles;
+  if (nb < 1) nb = 1;
+  return (int)nb;
+}
+
+int iunet_conv3_wgrad_v2_launch(int dtype, const void* x, long long x_ss, const void* dy, long long dy_ss, float* slab,
+                                int N, int D, int H, int W, int Cin, int Cout, hipStream_t stream) {
+  WgradV2Params p;
+  p.x = x; p.x_ss = x_ss; p.dy = dy; p.dy_ss = dy_ss; p.slab = slab;
+  p.N = N; p.D = D; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
+  p.tilesZ = (D + 1) / 2; p.tilesY = (H + 7) / 8; p.tilesX = (W + 15) / 16;
+  static const int dbg = getenv("IUNET_WG2_DBG") ? atoi(getenv("IUNET_WG2_DBG")) : 0;
+  p.dbg = dbg;
+  constexpr int PLANE_X = 6 * 180 * 16 + 192, PLANE_Y = 256 * 16 + 64;
+  constexpr int RING = 4 * PLANE_X + 2 * 4 * PLANE_Y;     // 103 168 B: x z-plane ring + two dy buffers
+  constexpr int RED = 4 * 14 * 2 * 64 * 16;                // 114 688 B: the k halves meet here at the end
+  constexpr int LDS = RED > RING ? RED : RING;
+  const int nb = iunet_conv3_wgrad_v2_blocks(N, D, H, W, Cin, Cout);
+  dim3 grid(nb, Cout / 32, Cin / 32);
+  if (dtype == 0) {
+    static bool s = false;
+    if (!s) { IUNET_CHECK_HIP(hipFuncSetAttribute((const void*)conv3_wgrad_v2_kernel<f16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); s = true; }
+    hipLaunchKernelGGL(conv3_wgrad_v2_kernel<f16>, grid, dim3(768), LDS, stream, p);
+  } else {
+    static bool s = false;
+    if (!s) { IUNET_CHECK_HIP(hipFuncSetAttribute((const void*)conv3_wgrad_v2_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); s = true; }
+    hipLaunchKernelGGL(conv3_wgrad_v2_kernel<bf16>, grid, dim3(768), LDS, stream, p);
+  }
+  IUNET_CHECK_HIP(hipGetLastError());
+  return IUNET_OK;
+}
