@@ -55,6 +55,14 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return base + (bid >> 3);
 }
 
+// Workgroup barrier that orders LDS traffic ONLY.  __syncthreads() is a full fence: it also waits vmcnt(0), i.e. for
+// every global load a loader wave has just put in flight for a later step and for every output store of a consumer
+// wave -- that wait (1-2 us per step) is exactly what the wave-specialised kernels must not pay.  Use where the only
+// cross-wave communication of the step is through LDS.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

@@ -139,15 +139,15 @@ __global__ __launch_bounds__(768, 1) void conv3_v4_kernel(ConvV4Params p) {
     };
     auto step_barriers = [&](int s) {
       const int chunk = s - (s / nchunk) * nchunk;
-      if (p.stats != nullptr && chunk == nchunk - 1) __syncthreads();      // mirrors the consumers' statistics barrier
-      __syncthreads();
+      if (p.stats != nullptr && chunk == nchunk - 1) lds_barrier();      // mirrors the consumers' statistics barrier
+      lds_barrier();
     };
     // two register sets: the loads of step s + 2 are in flight while step s + 1 is written to LDS, so the memory
     // latency is never exposed to the barrier
     Staged r0, r1;
     load(0, r0);
     commit(0, r0);
-    __syncthreads();
+    lds_barrier();
     const bool refill = !(p.dbg & 1);
     if (nsteps > 1 && refill) load(1, r0);
     for (int s = 0; s < nsteps; s += 2) {
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(768, 1) void conv3_v4_kernel(ConvV4Params p) {
 #pragma unroll
     for (int n = 0; n < NI; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  __syncthreads();                                             // step 0 (and the resident weights) are in LDS
+  lds_barrier();                                             // step 0 (and the resident weights) are in LDS
 
   for (int s = 0; s < nsteps; ++s) {
     const int chunk = s - (s / nchunk) * nchunk;
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(768, 1) void conv3_v4_kernel(ConvV4Params p) {
           for (int sh = 8; sh > 0; sh >>= 1) { a += __shfl_xor(a, sh); b += __shfl_xor(b, sh); }
           if (l15 == 0) { red[((wave * 4 + q) * 8 + j) * 2] = a; red[((wave * 4 + q) * 8 + j) * 2 + 1] = b; }
         }
-        __syncthreads();
+        lds_barrier();
         if (tid < 64 && tile_ok) {
           const int c = tid >> 1, which = tid & 1;             // c = 8 g + j
           float sum = 0.f;
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(768, 1) void conv3_v4_kernel(ConvV4Params p) {
         }
       }
     }
-    __syncthreads();                 // consumers are done with this step's buffers, the loaders have filled the others
+    lds_barrier();                 // consumers are done with this step's buffers, the loaders have filled the others
   }
 }
 

@@ -153,7 +153,7 @@ __global__ __launch_bounds__(768, 1) void conv3_wgrad_v2_kernel(WgradV2Params p)
     int base = 0;                                   // ring slot of halo plane pz = 0 of the tile being consumed
     if (nt > 0) { load(0, r); commit_x(r, 16 * ZPIX, 0, 4, 0); commit_y(0, r); }
     if (nt > 1 && refill) load(1, r);
-    __syncthreads();
+    lds_barrier();
     for (int k = 0; k < nt; ++k) {
       const bool more = k + 1 < nt && refill;
       const bool fr = more && fresh(k + 1);
@@ -162,18 +162,18 @@ __global__ __launch_bounds__(768, 1) void conv3_wgrad_v2_kernel(WgradV2Params p)
         if (fr) commit_x(r, 16 * ZPIX, 0, 2, base + 4); else commit_x(r, 8 * ZPIX, 0, 2, base + 4);
         commit_y(k + 1, r);
       }
-      __syncthreads();                              // tile k is consumed
+      lds_barrier();                              // tile k is consumed
       if (k + 1 < nt && fresh(k + 1)) {             // (same condition as the consumers': the barrier count must match)
         if (fr) commit_x(r, 16 * ZPIX, 2, 4, base + 4);      // pz 2, 3 of the new column into the slots tile k just released
-        __syncthreads();
+        lds_barrier();
         base = (base + 4) % NSLOT;
       } else {
         base = (base + 2) % NSLOT;
       }
       if (k + 2 < nt && refill) load(k + 2, r);
     }
-    __syncthreads();          // the two barriers of the consumers' final reduction
-    __syncthreads();
+    lds_barrier();          // the two barriers of the consumers' final reduction
+    lds_barrier();
     return;
   }
 
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(768, 1) void conv3_wgrad_v2_kernel(WgradV2Params p)
   for (int i = 0; i < MAXU; ++i) { acc[i][0] = f32x4{0, 0, 0, 0}; acc[i][1] = f32x4{0, 0, 0, 0}; }
 
   int base = 0;
-  __syncthreads();                                                 // tile 0 is in LDS
+  lds_barrier();                                                 // tile 0 is in LDS
   for (int k = 0; k < nt; ++k) {
     // this wave's output z slice is kg, so unit i reads halo plane pz = kg + dz_i -> ring slot (base + pz) mod 6
     unsigned uoff[MAXU];
@@ -224,9 +224,9 @@ __global__ __launch_bounds__(768, 1) void conv3_wgrad_v2_kernel(WgradV2Params p)
         acc[i][1] = mfma16<T>(a1, b, acc[i][1]);
       }
     }
-    __syncthreads();
+    lds_barrier();
     if (k + 1 < nt && fresh(k + 1)) {
-      __syncthreads();                                             // the loaders complete the new column's first tile
+      lds_barrier();                                             // the loaders complete the new column's first tile
       base = (base + 4) % NSLOT;
     } else {
       base = (base + 2) % NSLOT;
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(768, 1) void conv3_wgrad_v2_kernel(WgradV2Params p)
 #pragma unroll
     for (int i = 0; i < MAXU; ++i) { red[(i * 2 + 0) * 64] = acc[i][0]; red[(i * 2 + 1) * 64] = acc[i][1]; }
   }
-  __syncthreads();
+  lds_barrier();
   if (kg == 0) {
     const int ncob = gridDim.y, ncib = gridDim.z;
     float* slab = p.slab + ((((long long)blockIdx.x * ncob + cob) * ncib + cib) * TAPS) * 1024;
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(768, 1) void conv3_wgrad_v2_kernel(WgradV2Params p)
       }
     }
   }
-  __syncthreads();
+  lds_barrier();
 }
 
 }  // namespace
