@@ -101,6 +101,9 @@ int iunet_blend_accumulate(void* pred, void* weight, const void* P, const void* 
 int iunet_normalize_quantize(const void* pred, const void* weight, void* out_u8, long long nvox, int C, float eps,
                              void* stream);
 int iunet_div_f32(void* p, long long n, float d, void* stream);
+/* class map -> colours (predict.py:41-45 + utils.py:351-357): out_rgb uint8 [n][3] = palette[cls[i]], palette uint8
+ * [ncls][3] on the device, classes >= ncls black. */
+int iunet_colorize(const void* cls, long long n, const void* palette, int ncls, void* out_rgb, void* stream);
 
 /* ---- oblique slices (slicer.py:94-115, :196-228; SURVEY 8f "Slicer on device") ----------- */
 /* out[i][j] (uint8 [sw][sw]) = map_coordinates(vol[lo : lo + len], origin + a * r_i + b * r_j - lo, order, mode

@@ -67,6 +67,18 @@ __global__ __launch_bounds__(256) void div_kernel(float* __restrict__ p, long lo
   if (i < n) p[i] = __fdiv_rn(p[i], d);
 }
 
+// class map -> palette colours (predict.py:41-45: one-hot * 255 -> utils.convert_categorical_to_color): 3 bytes per pixel
+__global__ __launch_bounds__(256) void colorize_kernel(const unsigned char* __restrict__ cls, long long n,
+                                                      unsigned char* __restrict__ out,
+                                                      const unsigned char* __restrict__ palette, int ncls) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int c = cls[i];
+  unsigned char r = 0, g = 0, b = 0;
+  if (c < ncls) { r = palette[c * 3]; g = palette[c * 3 + 1]; b = palette[c * 3 + 2]; }
+  out[i * 3] = r; out[i * 3 + 1] = g; out[i * 3 + 2] = b;
+}
+
 }  // namespace
 
 extern "C" {
@@ -112,6 +124,16 @@ int iunet_normalize_quantize(const void* pred, const void* weight, void* out_u8,
 
 int iunet_div_f32(void* p, long long n, float d, void* stream) {
   hipLaunchKernelGGL(div_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (float*)p, n, d);
+  IUNET_CHECK_HIP(hipGetLastError());
+  return IUNET_OK;
+}
+
+// out[i] = palette[cls[i]] (uint8 [n][3]); classes >= ncls are black.  palette: uint8 [ncls][3] on the device.
+int iunet_colorize(const void* cls, long long n, const void* palette, int ncls, void* out_rgb, void* stream) {
+  IUNET_REQUIRE(cls && palette && out_rgb && n >= 0 && ncls > 0, "colorize: bad arguments");
+  if (n == 0) return IUNET_OK;
+  hipLaunchKernelGGL(colorize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const unsigned char*)cls, n, (unsigned char*)out_rgb, (const unsigned char*)palette, ncls);
   IUNET_CHECK_HIP(hipGetLastError());
   return IUNET_OK;
 }

@@ -40,6 +40,7 @@ _SIGS = {
                                ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_void_p],
     'iunet_normalize_quantize': [c_void_p, c_void_p, c_void_p, c_ll, c_int, c_float, c_void_p],
     'iunet_div_f32': [c_void_p, c_ll, c_float, c_void_p],
+    'iunet_colorize': [c_void_p, c_ll, c_void_p, c_int, c_void_p, c_void_p],
     'iunet_slice_gather': [c_void_p, c_int, c_int, c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int),
                            ctypes.POINTER(c_int), c_int, c_int, c_int, c_void_p, c_void_p],
     # ---- training

@@ -196,6 +196,16 @@ def _load_model(num_channels, num_classes, device):
     return model
 
 
+_PALETTES = {}
+
+
+def _palette(device, ncls):
+    key = (str(device), ncls)
+    if key not in _PALETTES:
+        _PALETTES[key] = torch.tensor(np.asarray(COLORS[1:ncls + 1], dtype=np.uint8)).to(device).contiguous()
+    return _PALETTES[key]
+
+
 def predict_slice(image_slice, num_channels=1, num_classes=2, return_probabilities=False, model=None):
     """predict.py:16-47: uint8 [H,W] -> palette-coloured uint8 [H,W,3] (or probabilities
     [1,H,W,C]).  /255, forward, argmax over the first num_classes channels, one-hot*255,
@@ -213,13 +223,17 @@ def predict_slice(image_slice, num_channels=1, num_classes=2, return_probabiliti
     eng.infer(x, (H * W, H * W, H * W, W, 1), 1, 1, H, W, probs=probs, cls=cls)
     if return_probabilities:
         return np.moveaxis(probs.cpu().numpy(), 1, -1)
-    c = cls.cpu().numpy().reshape(H, W)
-    if num_classes < eng.ncls:                         # argmax over the first num_classes only
+    if num_classes < eng.ncls:                         # argmax over the first num_classes only (rare: host path)
         c = np.argmax(probs.cpu().numpy()[0, :num_classes], axis=0)
-    colored = np.zeros((H, W, 3), dtype='uint8')
-    for i in range(num_classes):
-        colored[c == i, :] = COLORS[i + 1]
-    return colored
+        colored = np.zeros((H, W, 3), dtype='uint8')
+        for i in range(num_classes):
+            colored[c == i, :] = COLORS[i + 1]
+        return colored
+    # class map -> colours on the device (the numpy masking loop was 2.6 of the call's 3.1 ms at 512^2)
+    pal = _palette(device, eng.ncls)
+    rgb = torch.empty((H, W, 3), dtype=torch.uint8, device=device)
+    nv.call('iunet_colorize', nv.ptr(cls), H * W, nv.ptr(pal), min(num_classes, eng.ncls), nv.ptr(rgb), nv.stream())
+    return rgb.cpu().numpy()
 
 
 def predict_volume_array(model, volume, input_size=256, num_classes=2, overlap=0.25, batch_size=None,
