@@ -64,8 +64,11 @@ def pmc_traffic():
         return None
 
 
-def conv_roofline(nv, dtype, S, iters=10):
-    """dec0.conv1 of the 3-D net: Cin 64 -> Cout 32, 27 taps, one 128^3 chunk."""
+def conv_roofline(nv, dtype, S, iters=20):
+    """dec0.conv1 of the 3-D net: Cin 64 -> Cout 32, 27 taps, one 128^3 chunk.  3 warm-up + 20 timed back-to-back launches,
+    the same sequence as `tools/bench_conv.py --only 0:64:32 --wgrad 0 --iters 20` whose rocprofv3 summary is committed as
+    profiles/r01_roofline_kernel_stats.csv (the launch time drifts from 0.22 to 0.28 ms over such a run as the clock
+    settles under sustained MFMA load, so the number of launches matters)."""
     dev = 'cuda'
     cin, cout, taps = 64, 32, 27
     vox = S ** 3
