@@ -326,10 +326,6 @@ int launch_conv3(const Conv3Params& p, hipStream_t stream) {
 int iunet_conv3_v2_launch(int dtype, int nd, const void* x, long long x_sstride, void* y, long long y_sstride,
                           const void* wpk, const float* bias, float* stats, int N, int D, int H, int W, int Cin,
                           int Cout, int epi, hipStream_t stream);
-int iunet_conv3_v3_ok(int nd, int Cin, int Cout);
-int iunet_conv3_v3_launch(int dtype, const void* x, long long x_sstride, void* y, long long y_sstride, const void* wpk,
-                          const float* bias, float* stats, int N, int D, int H, int W, int Cin, int Cout, int epi,
-                          hipStream_t stream);
 int iunet_conv3_v4_launch(int dtype, const void* x, long long x_sstride, void* y, long long y_sstride, const void* wpk,
                           const float* bias, float* stats, int N, int D, int H, int W, int Cin, int Cout, int epi,
                           hipStream_t stream);
@@ -350,9 +346,7 @@ int iunet_conv3_launch(int dtype, int nd, const void* x, long long x_sstride, vo
   const bool wide = (Cout % 64 == 0);
   if (layout == 2) {
     IUNET_REQUIRE(nd == 3, "conv3: layout 2 is 3-D only");
-    static const bool use_v3 = getenv("IUNET_L2_V3") != nullptr;      // A/B runs: the barrier-locked weight-stationary variant
-    if (!use_v3) return iunet_conv3_v4_launch(dtype, x, x_sstride, y, y_sstride, wpk, bias, stats, N, D, H, W, Cin, Cout, epi, stream);
-    return iunet_conv3_v3_launch(dtype, x, x_sstride, y, y_sstride, wpk, bias, stats, N, D, H, W, Cin, Cout, epi, stream);
+    return iunet_conv3_v4_launch(dtype, x, x_sstride, y, y_sstride, wpk, bias, stats, N, D, H, W, Cin, Cout, epi, stream);
   }
   if (layout == 1)
     return iunet_conv3_v2_launch(dtype, nd, x, x_sstride, y, y_sstride, wpk, bias, stats, N, D, H, W, Cin, Cout, epi, stream);
@@ -389,8 +383,8 @@ int iunet_conv3_tiles(int nd, int N, int D, int H, int W) {
 int iunet_conv3_mi(int Cout) { return (Cout % 64 == 0) ? 4 : 2; }
 
 // Weight layout / kernel structure of a launch: 0 = first structure (conv3_mfma_kernel, 32-channel chunks),
-// 1 = LDS-fed persistent Cout-32 structure (conv3_v2.hip, K16 fragment order), 2 = weight-stationary variant of 1
-// (conv3_v3.hip, same K16 operator; 3-D, Cin <= 64).  The second one is used for
+// 1 = LDS-fed persistent Cout-32 structure (conv3_v2.hip, K16 fragment order), 2 = wave-specialised structure on the
+// same K16 operator (conv3_v4.hip; 3-D).  The second one is used for
 // Cout tiles of 32 and whenever the first structure's grid would under-fill the chip (deep levels):
 // measured at 128^3 / N = 1, levels 2 and 3 run 1.6-2x faster on it, level 1 (Cout 64, 512 tiles) 10 % slower.
 // IUNET_CONV_V1=1 / IUNET_CONV_V2_ALL=1 force one structure (A/B runs).

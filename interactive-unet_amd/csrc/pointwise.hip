@@ -242,17 +242,143 @@ __global__ __launch_bounds__(256) void convT_kernel(ConvTParams p) {
   float bias[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) bias[j] = p.bias ? p.bias[cob * 32 + q * 8 + j] : 0.f;
+  // Stores: a lane owns input voxel x, i.e. the output voxel pair (2x, 2x + 1) = 32 contiguous bytes per plane, but one
+  // store instruction moves 16 B per lane -- written lane by lane, each instruction would fill every other 16 B of its
+  // cache lines.  So the two x positions (c = 0, 1) are exchanged across lanes first (ds_bpermute): instruction "h"
+  // then writes the 16 consecutive output voxels 2 x0 + 16 h + l15, full 256-B runs per channel plane.
+  const int src_lo = ((lane & 48) | (l15 >> 1)) * 4, src_hi = src_lo + 8 * 4;     // byte index of the source lane
+  const bool odd = l15 & 1;
+  const int x0 = xb * 16;
 #pragma unroll
-  for (int s = 0; s < NPOS; ++s) {
-    const int a = ND == 3 ? (s >> 2) : 0, b = (s >> 1) & 1, c = s & 1;
-    V8 o;
+  for (int sp = 0; sp < NPOS / 2; ++sp) {
+    const int a = ND == 3 ? (sp >> 1) : 0, b = sp & 1;
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    i32x4 oc[2];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      o[j] = from_f32<T>(acc[s][0][j] + bias[j]);
-      o[4 + j] = from_f32<T>(acc[s][1][j] + bias[4 + j]);
+    for (int c = 0; c < 2; ++c) {
+      V8 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        o[j] = from_f32<T>(acc[sp * 2 + c][0][j] + bias[j]);
+        o[4 + j] = from_f32<T>(acc[sp * 2 + c][1][j] + bias[4 + j]);
+      }
+      oc[c] = __builtin_bit_cast(i32x4, o);
     }
     const int oz = ND == 3 ? z * 2 + a : 0;
-    if (ok) *(V8*)(yout + (((long long)oz * Ho + y * 2 + b) * Wo + x * 2 + c) * 8) = o;
+    T* row = yout + (((long long)oz * Ho + y * 2 + b) * Wo + 2 * x0) * 8;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int src = h ? src_hi : src_lo;
+      i32x4 v;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const int t0 = __builtin_amdgcn_ds_bpermute(src, oc[0][d]);
+        const int t1 = __builtin_amdgcn_ds_bpermute(src, oc[1][d]);
+        v[d] = odd ? t1 : t0;
+      }
+      const int xo = 2 * x0 + 16 * h + l15;                    // output x of this lane in instruction h
+      if (xo < Wo) *(i32x4*)(row + (16 * h + l15) * 8) = v;
+    }
+  }
+}
+
+// Same operator with the weights of the Cout tile resident in LDS (Cin <= 128: 32 / 64 KB) and two 16-voxel groups per
+// wave and step: the kernel above fetches 16 KB of weight fragments per k-step and wave through the vector cache to
+// move 10 KB of activations -- 4x more cache traffic for the weights than for the tensor, 3.0 TB/s.  Here the only
+// global traffic is the tensor itself.
+template <typename T, int ND, int NK>
+__global__ __launch_bounds__(256) void convT_lds_kernel(ConvTParams p) {
+  using V8 = typename Vec8<T>::type;
+  constexpr int NPOS = ND == 3 ? 8 : 4;
+  constexpr int G = 2;                                           // voxel groups per wave and step
+  extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l15 = lane & 15, q = lane >> 4;
+  const int cob = blockIdx.y;
+  {
+    const u32x4* wsrc = (const u32x4*)p.wpk + (long long)cob * NK * NPOS * 2 * 64;
+    for (int i = threadIdx.x; i < NK * NPOS * 2 * 64; i += 256) *(u32x4*)(smem + i * 16) = wsrc[i];
+  }
+  __syncthreads();
+  const int xg = (p.W + 15) / 16;
+  const long long rows = (long long)p.D * p.H * xg, ngroups = rows * p.N;
+  const long long in_plane = (long long)p.D * p.H * p.W * 8;
+  const int Do = ND == 3 ? p.D * 2 : 1, Ho = p.H * 2, Wo = p.W * 2;
+  const long long out_plane = (long long)Do * Ho * Wo * 8;
+  float bias[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) bias[j] = p.bias ? p.bias[cob * 32 + q * 8 + j] : 0.f;
+  const int src_lo = ((lane & 48) | (l15 >> 1)) * 4, src_hi = src_lo + 8 * 4;
+  const bool odd = l15 & 1;
+  const V8* wl = (const V8*)smem + lane;
+
+  for (long long g0 = ((long long)blockIdx.x * 4 + wave) * G; g0 < ngroups; g0 += (long long)gridDim.x * 4 * G) {
+    int n_[G], z_[G], y_[G], xb_[G];
+    V8 b[G][NK];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const long long wid = g0 + g < ngroups ? g0 + g : ngroups - 1;      // a missing partner recomputes the last group (never stored)
+      n_[g] = (int)(wid / rows);
+      const long long r = wid - n_[g] * rows;
+      xb_[g] = (int)(r % xg); y_[g] = (int)((r / xg) % p.H); z_[g] = (int)(r / ((long long)xg * p.H));
+      const int xc = min(xb_[g] * 16 + l15, p.W - 1);
+      const T* xin = (const T*)p.x + n_[g] * p.x_sstride + (((long long)z_[g] * p.H + y_[g]) * p.W + xc) * 8;
+#pragma unroll
+      for (int ks = 0; ks < NK; ++ks) b[g][ks] = *(const V8*)(xin + (long long)(ks * 4 + q) * in_plane);
+    }
+    f32x4 acc[G][NPOS][2];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int s = 0; s < NPOS; ++s) { acc[g][s][0] = f32x4{0, 0, 0, 0}; acc[g][s][1] = f32x4{0, 0, 0, 0}; }
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks)
+#pragma unroll
+      for (int s = 0; s < NPOS; ++s) {
+        const V8 a0 = wl[((ks * NPOS + s) * 2 + 0) * 64];
+        const V8 a1 = wl[((ks * NPOS + s) * 2 + 1) * 64];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          acc[g][s][0] = mfma16<T>(a0, b[g][ks], acc[g][s][0]);
+          acc[g][s][1] = mfma16<T>(a1, b[g][ks], acc[g][s][1]);
+        }
+      }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      if (g0 + g >= ngroups) break;
+      T* yout = (T*)p.y + n_[g] * p.y_sstride + (long long)(cob * 4 + q) * out_plane;
+      const int x0 = xb_[g] * 16;
+#pragma unroll
+      for (int sp = 0; sp < NPOS / 2; ++sp) {
+        const int a = ND == 3 ? (sp >> 1) : 0, bb = sp & 1;
+        typedef int i32x4 __attribute__((ext_vector_type(4)));
+        i32x4 oc[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          V8 o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            o[j] = from_f32<T>(acc[g][sp * 2 + c][0][j] + bias[j]);
+            o[4 + j] = from_f32<T>(acc[g][sp * 2 + c][1][j] + bias[4 + j]);
+          }
+          oc[c] = __builtin_bit_cast(i32x4, o);
+        }
+        const int oz = ND == 3 ? z_[g] * 2 + a : 0;
+        T* row = yout + (((long long)oz * Ho + y_[g] * 2 + bb) * Wo + 2 * x0) * 8;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int src = h ? src_hi : src_lo;
+          i32x4 v;
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {
+            const int t0 = __builtin_amdgcn_ds_bpermute(src, oc[0][d]);
+            const int t1 = __builtin_amdgcn_ds_bpermute(src, oc[1][d]);
+            v[d] = odd ? t1 : t0;
+          }
+          if (2 * x0 + 16 * h + l15 < Wo) *(i32x4*)(row + (16 * h + l15) * 8) = v;
+        }
+      }
+    }
   }
 }
 
@@ -398,6 +524,25 @@ int iunet_convT_launch(int dtype, int nd, const void* x, long long x_ss, void* y
   p.x = x; p.x_sstride = x_ss; p.y = y; p.y_sstride = y_ss; p.wpk = wpk; p.bias = bias;
   p.N = N; p.D = D; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
   const long long waves = (long long)N * D * H * ((W + 15) / 16);
+  const int nk = Cin / 32;
+  if (nk <= 4 && waves >= 256) {
+    // weights of the Cout tile in LDS, grid-stride walk over the voxel groups
+    const int npos = nd == 3 ? 8 : 4;
+    const int lds = nk * npos * 2 * 1024;
+    int gx = (int)((waves + 7) / 8);
+    const int cap = 1024 / (Cout / 32);                // ~4 workgroups per CU in total
+    if (gx > cap) gx = cap;
+    dim3 g2(gx, Cout / 32);
+#define CTL(TT, NDV, NKV) do { static bool s_ = false; if (!s_) { IUNET_CHECK_HIP(hipFuncSetAttribute((const void*)convT_lds_kernel<TT, NDV, NKV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); s_ = true; } \
+    hipLaunchKernelGGL((convT_lds_kernel<TT, NDV, NKV>), g2, dim3(256), lds, stream, p); } while (0)
+#define CTL_NK(TT, NDV) switch (nk) { case 1: CTL(TT, NDV, 1); break; case 2: CTL(TT, NDV, 2); break; case 3: CTL(TT, NDV, 3); break; default: CTL(TT, NDV, 4); break; }
+    if (dtype == 0) { if (nd == 3) { CTL_NK(f16, 3) } else { CTL_NK(f16, 2) } }
+    else            { if (nd == 3) { CTL_NK(bf16, 3) } else { CTL_NK(bf16, 2) } }
+#undef CTL_NK
+#undef CTL
+    IUNET_CHECK_HIP(hipGetLastError());
+    return IUNET_OK;
+  }
   dim3 grid((unsigned)((waves + 3) / 4), Cout / 32);
   if (dtype == 0) {
     if (nd == 3) hipLaunchKernelGGL((convT_kernel<f16, 3>), grid, dim3(256), 0, stream, p);
