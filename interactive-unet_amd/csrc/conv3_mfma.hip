@@ -326,7 +326,7 @@ int launch_conv3(const Conv3Params& p, hipStream_t stream) {
 int iunet_conv3_v2_launch(int dtype, int nd, const void* x, long long x_sstride, void* y, long long y_sstride,
                           const void* wpk, const float* bias, float* stats, int N, int D, int H, int W, int Cin,
                           int Cout, int epi, hipStream_t stream);
-int iunet_conv3_v4_launch(int dtype, const void* x, long long x_sstride, void* y, long long y_sstride, const void* wpk,
+int iunet_conv3_v4_launch(int dtype, int nd, const void* x, long long x_sstride, void* y, long long y_sstride, const void* wpk,
                           const float* bias, float* stats, int N, int D, int H, int W, int Cin, int Cout, int epi,
                           hipStream_t stream);
 
@@ -345,8 +345,7 @@ int iunet_conv3_launch(int dtype, int nd, const void* x, long long x_sstride, vo
   p.tilesZ = (D + TZ - 1) / TZ; p.tilesY = (H + TY - 1) / TY; p.tilesX = (W + TX - 1) / TX;
   const bool wide = (Cout % 64 == 0);
   if (layout == 2) {
-    IUNET_REQUIRE(nd == 3, "conv3: layout 2 is 3-D only");
-    return iunet_conv3_v4_launch(dtype, x, x_sstride, y, y_sstride, wpk, bias, stats, N, D, H, W, Cin, Cout, epi, stream);
+    return iunet_conv3_v4_launch(dtype, nd, x, x_sstride, y, y_sstride, wpk, bias, stats, N, D, H, W, Cin, Cout, epi, stream);
   }
   if (layout == 1)
     return iunet_conv3_v2_launch(dtype, nd, x, x_sstride, y, y_sstride, wpk, bias, stats, N, D, H, W, Cin, Cout, epi, stream);
@@ -396,7 +395,9 @@ int iunet_conv3_pick(int nd, int N, int D, int H, int W, int Cin, int Cout) {
   const long long tiles = iunet_conv3_tiles(nd, N, D, H, W);
   // 3-D: the wave-specialised structure wins at every level of the U-Net (profiles/r01_conv_levels.md), marginally
   // behind layout 0 only for 128 -> 64 at 64^3 (-4 %)
-  if (v3 && nd == 3 && Cin >= 32) return 2;
+  // 2-D: the same structure wins where the weights stay resident in LDS (Cin <= 64: +5-12 % on the HBM-bound level-0
+  // layers); for wider inputs layout 0 has no K16 padding (a quarter of the 2-D k-steps) and stays ahead
+  if (v3 && Cin >= 32 && (nd == 3 || Cin <= 64)) return 2;
   if (force_v2 || Cout % 64 != 0) return 1;
   const long long blocks = tiles * (Cout / 64);
   return blocks < 512 ? 1 : 0;

@@ -9,13 +9,19 @@
 //   * 4 LOADER waves (one per SIMD) fetch the next 16-channel chunk of the halo tile (and, for Cin > 32, its
 //     30 KB of weights) global -> registers -> the OTHER LDS buffer, wait for it, and meet the consumers at the
 //     one barrier per step.  Their stalls on the memory queue cost no MFMA issue slots.
-// Tile 4 x 8 x 16 voxels, 64 voxels per consumer wave; k-step = 2 filter columns x 16 channels (the K16 operator of
-// layout 1), 6 activation row fragments reused over the three dy taps.  LDS: 2 x 34 KB activations + the weights
-// (Cin <= 32: all of them, resident for the whole launch; else 2 x 30 KB, streamed with the activations).
+// 3-D: tile 4 x 8 x 16 voxels, a step = one 16-channel chunk; 2-D: tile 16 x 32 pixels, a step = 32 channels (the 2-D
+// filter has a third of the taps, so a 16-channel step would be too short between barriers).  64 voxels per consumer
+// wave; k-step = 2 filter columns x 16 channels (the K16 operator of layout 1), activation row fragments reused over
+// the three dy taps.  LDS: 2 x 34 KB (3-D) / 2 x 39 KB (2-D) activations + the weights (all of them, resident for the
+// whole launch, when they fit: Cin <= 32 in 3-D, <= 64 in 2-D; else two step-sized buffers streamed with the activations).
 #include "common.h"
 #include <cstdlib>
 
 namespace {
+
+template <int ND> struct V4Tile;
+template <> struct V4Tile<3> { static constexpr int TZ = 4, TY = 8, TX = 16, PADZ = 1, NCOL = 9, S16 = 1; };
+template <> struct V4Tile<2> { static constexpr int TZ = 1, TY = 16, TX = 32, PADZ = 0, NCOL = 3, S16 = 2; };
 
 struct ConvV4Params {
   const void* x;  long long x_sstride;
@@ -31,20 +37,27 @@ struct ConvV4Params {
   int dbg;                                    // profiling only (IUNET_V4_DBG): 1 no refill after step 0, 2 no MFMA phase, 4 no stores
 };
 
-template <typename T, bool WS>
+template <typename T, int ND, bool WS>
 __global__ __launch_bounds__(768, 1) void conv3_v4_kernel(ConvV4Params p) {
   using V8 = typename Vec8<T>::type;
+  using TL = V4Tile<ND>;
   constexpr int NCW = 8, NLT = 256;                    // consumer waves; loader threads
-  constexpr int TZ = 4, TY = 8, TX = 16, NI = 4;
-  constexpr int PZ = TZ + 2, PY = TY + 2, PX = TX + 2;
-  constexpr int NPIX = PZ * PY * PX;                   // 1080
+  constexpr int TZ = TL::TZ, TY = TL::TY, TX = TL::TX, PADZ = TL::PADZ, NCOL = TL::NCOL, S16 = TL::S16;
+  constexpr int NI = 4, FX = TX / 16, NR = NI / FX;    // fragments per consumer wave; x halves; tile rows per wave
+  constexpr int PZ = TZ + 2 * PADZ, PY = TY + 2, PX = TX + 2;
+  constexpr int NPIX = PZ * PY * PX;                   // 1080 / 612
   constexpr int PLANE = ((NPIX * 16 + 255) / 256) * 256;
-  constexpr int ABUF = 2 * PLANE;                      // one 16-channel chunk of the halo tile
-  constexpr int NCMB = 5, KS = 15;
+  constexpr int CP = 2 * S16;                          // planes (of 8 channels) per step
+  constexpr int ABUF = CP * PLANE;                     // one step of the halo tile
+  constexpr int NCMB = (NCOL + 1) / 2, KS = NCMB * 3;
   constexpr int WBYTES = KS * 2 * 1024;                // one 16-channel chunk of packed weights
+  constexpr int WSTEP = S16 * WBYTES;                  // the weights of one step
   constexpr int OFF_W = 2 * ABUF;
-  constexpr int AIT = (NPIX + NLT - 1) / NLT;          // halo pixels per loader thread (5)
-  constexpr int WIT = (WBYTES / 16 + NLT - 1) / NLT;   // 16-byte weight items per loader thread (8)
+  constexpr int AIT = (NPIX + NLT - 1) / NLT;          // halo pixels per loader thread (5 / 3)
+  constexpr int WIT = (WSTEP / 16 + NLT - 1) / NLT;    // 16-byte weight items per loader thread (8 / 6)
+  constexpr int NGRP = S16 * NCMB;                     // (16-channel sub-chunk, column pair) groups per step
+  constexpr int NRD = FX * (NR + 2) + 6;               // LDS fragment reads per group
+  static_assert(NCW * NI == TZ * TY * FX, "consumer waves x fragments must cover the tile");
 
   extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
 
@@ -60,12 +73,12 @@ __global__ __launch_bounds__(768, 1) void conv3_v4_kernel(ConvV4Params p) {
   const int sx = slot % p.bx, sy = (slot / p.bx) % p.by, sz = slot / (p.bx * p.by);
   const int nbricks = p.N * p.nbz * p.nby * p.nbx;
   const int b_begin = (int)((long long)xcd * nbricks / 8), b_end = (int)((long long)(xcd + 1) * nbricks / 8);
-  const int nchunk = p.Cin >> 4;
+  const int nchunk = p.Cin / (16 * S16);               // steps per tile
   const int nsteps = (b_end - b_begin) * nchunk;
   if (nsteps <= 0) return;
   const long long plane_stride = (long long)p.D * p.H * p.W * 8;
-  const int off_red = OFF_W + (WS ? nchunk : 2) * WBYTES;   // 2 KB of scratch for the BatchNorm partial sums
-  const u32x4* wsrc = (const u32x4*)p.wpk + (long long)cob * nchunk * (WBYTES / 16);
+  const int off_red = OFF_W + (WS ? nchunk : 2) * WSTEP;    // 2 KB of scratch for the BatchNorm partial sums
+  const u32x4* wsrc = (const u32x4*)p.wpk + (long long)cob * nchunk * (WSTEP / 16);
 
   auto tile_origin = [&](int k, int& n_img, int& z0, int& y0, int& x0) -> bool {      // this workgroup's k-th tile
     int b = b_begin + k;
@@ -78,7 +91,7 @@ __global__ __launch_bounds__(768, 1) void conv3_v4_kernel(ConvV4Params p) {
   };
 
   if (WS) {     // all weights of this Cout tile: global -> LDS once, by everybody
-    const int nitems = nchunk * (WBYTES / 16);
+    const int nitems = nchunk * (WSTEP / 16);
     for (int i = tid; i < nitems; i += 768) *(u32x4*)(smem + OFF_W + i * 16) = wsrc[i];
   }
 
@@ -92,29 +105,29 @@ __global__ __launch_bounds__(768, 1) void conv3_v4_kernel(ConvV4Params p) {
       const int px = pix % PX, t2 = pix / PX;
       pcoord[it] = px | ((t2 % PY) << 8) | ((t2 / PY) << 16);
     }
-    struct Staged { u32x4 a[AIT][2]; u32x4 w[WS ? 1 : WIT]; unsigned ok; };
-    auto load = [&](int s, Staged& r) {               // issue the global loads of step s's chunk (nothing consumes them here)
+    struct Staged { u32x4 a[AIT][CP]; u32x4 w[WS ? 1 : WIT]; unsigned ok; };
+    auto load = [&](int s, Staged& r) {               // issue the global loads of step s (nothing consumes them here)
       const int chunk = s - (s / nchunk) * nchunk;
       int n_img, z0, y0, x0;
       tile_origin(s / nchunk, n_img, z0, y0, x0);
-      const T* xc = (const T*)p.x + (long long)n_img * p.x_sstride + (long long)chunk * 2 * plane_stride;
+      const T* xc = (const T*)p.x + (long long)n_img * p.x_sstride + (long long)chunk * CP * plane_stride;
       r.ok = 0;
       if (!(p.dbg & 32))
 #pragma unroll
       for (int it = 0; it < AIT; ++it) {
         const int px = pcoord[it] & 255, py = (pcoord[it] >> 8) & 255, pz = pcoord[it] >> 16;
-        const int gz = z0 + pz - 1, gy = y0 + py - 1, gx = x0 + px - 1;
+        const int gz = z0 + pz - PADZ, gy = y0 + py - 1, gx = x0 + px - 1;
         const bool ok = (unsigned)gz < (unsigned)p.D && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
         const int cz = min(max(gz, 0), p.D - 1), cy = min(max(gy, 0), p.H - 1), cx = min(max(gx, 0), p.W - 1);
         const long long goff = (((long long)cz * p.H + cy) * p.W + cx) * 8;
-        r.a[it][0] = *(const u32x4*)(xc + goff);
-        r.a[it][1] = *(const u32x4*)(xc + plane_stride + goff);
+#pragma unroll
+        for (int k = 0; k < CP; ++k) r.a[it][k] = *(const u32x4*)(xc + k * plane_stride + goff);
         r.ok |= ok ? (1u << it) : 0u;
       }
       if (!WS && !(p.dbg & 16)) {
-        const u32x4* ws = wsrc + (long long)chunk * (WBYTES / 16);
+        const u32x4* ws = wsrc + (long long)chunk * (WSTEP / 16);
 #pragma unroll
-        for (int it = 0; it < WIT; ++it) r.w[it] = ws[min(lt + it * NLT, WBYTES / 16 - 1)];
+        for (int it = 0; it < WIT; ++it) r.w[it] = ws[min(lt + it * NLT, WSTEP / 16 - 1)];
       }
     };
     auto commit = [&](int s, const Staged& r) {       // registers -> LDS buffer s & 1
@@ -124,40 +137,33 @@ __global__ __launch_bounds__(768, 1) void conv3_v4_kernel(ConvV4Params p) {
         const int pix = lt + it * NLT;
         if (pix < NPIX) {
           const bool ok = (r.ok >> it) & 1u;
-          *(u32x4*)(ab + pix * 16) = ok ? r.a[it][0] : u32x4{0u, 0u, 0u, 0u};
-          *(u32x4*)(ab + PLANE + pix * 16) = ok ? r.a[it][1] : u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+          for (int k = 0; k < CP; ++k) *(u32x4*)(ab + k * PLANE + pix * 16) = ok ? r.a[it][k] : u32x4{0u, 0u, 0u, 0u};
         }
       }
       if (!WS) {
-        unsigned char* wb = smem + OFF_W + (s & 1) * WBYTES;
+        unsigned char* wb = smem + OFF_W + (s & 1) * WSTEP;
 #pragma unroll
         for (int it = 0; it < WIT; ++it) {
           const int idx = lt + it * NLT;
-          if (idx < WBYTES / 16) *(u32x4*)(wb + idx * 16) = r.w[it];
+          if (idx < WSTEP / 16) *(u32x4*)(wb + idx * 16) = r.w[it];
         }
       }
     };
-    auto step_barriers = [&](int s) {
+    // one register set: step s + 1 is written to LDS, then the loads of step s + 2 are issued into the same registers and
+    // stay in flight over the barrier and the consumers' whole next step
+    const bool refill = !(p.dbg & 1);
+    Staged r;
+    load(0, r);
+    commit(0, r);
+    if (nsteps > 1 && refill) load(1, r);
+    lds_barrier();
+    for (int s = 0; s < nsteps; ++s) {
+      if (s + 1 < nsteps && refill) commit(s + 1, r);
+      if (s + 2 < nsteps && refill) load(s + 2, r);
       const int chunk = s - (s / nchunk) * nchunk;
       if (p.stats != nullptr && chunk == nchunk - 1) lds_barrier();      // mirrors the consumers' statistics barrier
       lds_barrier();
-    };
-    // two register sets: the loads of step s + 2 are in flight while step s + 1 is written to LDS, so the memory
-    // latency is never exposed to the barrier
-    Staged r0, r1;
-    load(0, r0);
-    commit(0, r0);
-    lds_barrier();
-    const bool refill = !(p.dbg & 1);
-    if (nsteps > 1 && refill) load(1, r0);
-    for (int s = 0; s < nsteps; s += 2) {
-      if (s + 2 < nsteps && refill) load(s + 2, r1);
-      if (s + 1 < nsteps && refill) commit(s + 1, r0);
-      step_barriers(s);
-      if (s + 1 >= nsteps) break;
-      if (s + 3 < nsteps && refill) load(s + 3, r0);
-      if (s + 2 < nsteps && refill) commit(s + 2, r1);
-      step_barriers(s + 1);
     }
     return;
   }
@@ -167,12 +173,13 @@ __global__ __launch_bounds__(768, 1) void conv3_v4_kernel(ConvV4Params p) {
   int col_off[NCMB];
 #pragma unroll
   for (int c = 0; c < NCMB; ++c) {
-    const int col = min(2 * c + (q >> 1), 8);                  // the missing partner re-reads a valid column (zero weights)
-    const int dz = col / 3, dx = col % 3;
+    const int col = min(2 * c + (q >> 1), NCOL - 1);           // the missing partner re-reads a valid column (zero weights)
+    const int dz = ND == 3 ? col / 3 : 0, dx = ND == 3 ? col % 3 : col;
     col_off[c] = (dz * PY * PX + dx) * 16;
   }
-  const int row0 = wave * NI;                                  // first output row (z * TY + y) of this wave
-  const int rbase = (q & 1) * PLANE + ((((row0 / TY) * PY + (row0 % TY)) * PX) + l15) * 16;
+  const int f0 = wave * NI;                                    // first fragment of this wave: fragment f = row * FX + x half
+  const int row_first = f0 / FX;                               // first tile row (z * TY + y)
+  const int rbase = (q & 1) * PLANE + ((((row_first / TY) * PY + (row_first % TY)) * PX) + l15) * 16;
   float bias_r[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) bias_r[j] = (p.epi != 0) ? p.bias[cob * 32 + 8 * q + j] : 0.f;
@@ -188,42 +195,50 @@ __global__ __launch_bounds__(768, 1) void conv3_v4_kernel(ConvV4Params p) {
   for (int s = 0; s < nsteps; ++s) {
     const int chunk = s - (s / nchunk) * nchunk;
     const unsigned char* ab = smem + (s & 1) * ABUF + rbase;
-    const unsigned char* wl = smem + OFF_W + (WS ? chunk : (s & 1)) * WBYTES + lane * 16;
+    const unsigned char* wl = smem + OFF_W + (WS ? chunk : (s & 1)) * WSTEP + lane * 16;
 
     if (!(p.dbg & 2)) {
-      // software pipeline over the 5 column pairs: the 12 fragment reads of pair c + 1 (6 activation rows, 6 weight
-      // fragments) are issued between the 24 MFMAs of pair c, one read per two MFMAs
-      V8 R[2][NI + 2], A[2][3][2];
-      auto load_group = [&](int c, int b) {
+      // software pipeline over the groups (16-channel sub-chunk h, column pair c) of the step: the fragment reads of
+      // group g + 1 (activation rows + 6 weight fragments) are issued between the 24 MFMAs of group g
+      V8 R[2][FX][NR + 2], A[2][3][2];
+      auto load_group = [&](int g, int b) {
+        const int h = g / NCMB, c = g - h * NCMB;
 #pragma unroll
-        for (int r = 0; r < NI + 2; ++r) R[b][r] = *(const V8*)(ab + r * PX * 16 + col_off[c]);
+        for (int xh = 0; xh < FX; ++xh)
+#pragma unroll
+          for (int r = 0; r < NR + 2; ++r) R[b][xh][r] = *(const V8*)(ab + h * 2 * PLANE + (r * PX + xh * 16) * 16 + col_off[c]);
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy) {
-          A[b][dy][0] = *(const V8*)(wl + ((c * 3 + dy) * 2 + 0) * 1024);
-          A[b][dy][1] = *(const V8*)(wl + ((c * 3 + dy) * 2 + 1) * 1024);
+          A[b][dy][0] = *(const V8*)(wl + h * WBYTES + ((c * 3 + dy) * 2 + 0) * 1024);
+          A[b][dy][1] = *(const V8*)(wl + h * WBYTES + ((c * 3 + dy) * 2 + 1) * 1024);
         }
       };
       load_group(0, 0);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int c = 0; c < NCMB; ++c) {
-        const int b = c & 1;
-        if (c + 1 < NCMB) load_group(c + 1, b ^ 1);
+      for (int g = 0; g < NGRP; ++g) {
+        const int b = g & 1;
+        if (g + 1 < NGRP) load_group(g + 1, b ^ 1);
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
           for (int n = 0; n < NI; ++n) {
-            acc[0][n] = mfma16<T>(A[b][dy][0], R[b][n + dy], acc[0][n]);
-            acc[1][n] = mfma16<T>(A[b][dy][1], R[b][n + dy], acc[1][n]);
+            acc[0][n] = mfma16<T>(A[b][dy][0], R[b][n % FX][n / FX + dy], acc[0][n]);
+            acc[1][n] = mfma16<T>(A[b][dy][1], R[b][n % FX][n / FX + dy], acc[1][n]);
           }
-        if (c + 1 < NCMB) {
+        if (g + 1 < NGRP) {
 #pragma unroll
-          for (int i = 0; i < 12; ++i) {
+          for (int i = 0; i < NRD - 12; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);     // two LDS reads
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);     // two MFMAs
+          }
+#pragma unroll
+          for (int i = NRD - 12; i < 12; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // one LDS read
             __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);     // two MFMAs
           }
         }
-        __builtin_amdgcn_sched_barrier(0);                         // nothing moves across the pair boundary
+        __builtin_amdgcn_sched_barrier(0);                         // nothing moves across the group boundary
       }
     }
 
@@ -237,8 +252,8 @@ __global__ __launch_bounds__(768, 1) void conv3_v4_kernel(ConvV4Params p) {
       for (int j = 0; j < 8; ++j) { s_sum[j] = 0.f; s_sq[j] = 0.f; }
 #pragma unroll
       for (int n = 0; n < NI; ++n) {
-        const int row = row0 + n;
-        const int gz = z0 + row / TY, gy = y0 + row % TY, gx = x0 + l15;
+        const int f = f0 + n, row = f / FX;
+        const int gz = z0 + (ND == 3 ? row / TY : 0), gy = y0 + row % TY, gx = x0 + (f % FX) * 16 + l15;
         const bool ok = gz < p.D && gy < p.H && gx < p.W;
         float vals[8];
 #pragma unroll
@@ -283,41 +298,57 @@ __global__ __launch_bounds__(768, 1) void conv3_v4_kernel(ConvV4Params p) {
   }
 }
 
-template <typename T, bool WS>
+template <typename T, int ND, bool WS>
 int launch_v4(ConvV4Params p, hipStream_t stream) {
-  constexpr int PLANE = ((1080 * 16 + 255) / 256) * 256;
-  const int lds = 4 * PLANE + (WS ? p.Cin / 16 : 2) * 30720 + 2048;
+  using TL = V4Tile<ND>;
+  constexpr int NPIX = (TL::TZ + 2 * TL::PADZ) * (TL::TY + 2) * (TL::TX + 2);
+  constexpr int PLANE = ((NPIX * 16 + 255) / 256) * 256;
+  constexpr int WSTEP = TL::S16 * ((TL::NCOL + 1) / 2) * 3 * 2 * 1024;
+  const int lds = 2 * 2 * TL::S16 * PLANE + (WS ? p.Cin / (16 * TL::S16) : 2) * WSTEP + 2048;
   static int attr_lds = 0;
   if (lds > attr_lds) {
-    IUNET_CHECK_HIP(hipFuncSetAttribute((const void*)conv3_v4_kernel<T, WS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    IUNET_CHECK_HIP(hipFuncSetAttribute((const void*)conv3_v4_kernel<T, ND, WS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_lds = lds;
   }
+  p.tilesZ = (p.D + TL::TZ - 1) / TL::TZ; p.tilesY = (p.H + TL::TY - 1) / TL::TY; p.tilesX = (p.W + TL::TX - 1) / TL::TX;
   const int ncob = p.Cout / 32;
   // one workgroup per CU: 8 XCDs x (bz x by x bx) brick slots per Cout tile
-  if (ncob == 1)      { p.bz = 2; p.by = 4; p.bx = 4; }
-  else if (ncob == 2) { p.bz = 2; p.by = 4; p.bx = 2; }
-  else if (ncob <= 4) { p.bz = 2; p.by = 2; p.bx = 2; }
-  else                { p.bz = 1; p.by = 2; p.bx = 2; }
+  if (ND == 3) {
+    if (ncob == 1)      { p.bz = 2; p.by = 4; p.bx = 4; }
+    else if (ncob == 2) { p.bz = 2; p.by = 4; p.bx = 2; }
+    else if (ncob <= 4) { p.bz = 2; p.by = 2; p.bx = 2; }
+    else                { p.bz = 1; p.by = 2; p.bx = 2; }
+  } else {
+    p.bz = 1;
+    if (ncob == 1)      { p.by = 4; p.bx = 8; }
+    else if (ncob == 2) { p.by = 4; p.bx = 4; }
+    else if (ncob <= 4) { p.by = 2; p.bx = 4; }
+    else                { p.by = 2; p.bx = 2; }
+  }
   p.nbz = (p.tilesZ + p.bz - 1) / p.bz; p.nby = (p.tilesY + p.by - 1) / p.by; p.nbx = (p.tilesX + p.bx - 1) / p.bx;
   const int gx = 8 * p.bz * p.by * p.bx;
-  hipLaunchKernelGGL((conv3_v4_kernel<T, WS>), dim3(gx, ncob), dim3(768), lds, stream, p);
+  hipLaunchKernelGGL((conv3_v4_kernel<T, ND, WS>), dim3(gx, ncob), dim3(768), lds, stream, p);
   IUNET_CHECK_HIP(hipGetLastError());
   return IUNET_OK;
 }
 
 }  // namespace
 
-int iunet_conv3_v4_launch(int dtype, const void* x, long long x_sstride, void* y, long long y_sstride, const void* wpk,
+int iunet_conv3_v4_launch(int dtype, int nd, const void* x, long long x_sstride, void* y, long long y_sstride, const void* wpk,
                           const float* bias, float* stats, int N, int D, int H, int W, int Cin, int Cout, int epi,
                           hipStream_t stream) {
-  IUNET_REQUIRE(Cin % 16 == 0 && Cin >= 32 && Cout % 32 == 0, "conv3 layout 2: Cin %% 16, Cin >= 32, Cout %% 32 (got %d -> %d)", Cin, Cout);
+  IUNET_REQUIRE(Cin % 32 == 0 && Cout % 32 == 0, "conv3 layout 2: Cin %% 32, Cout %% 32 (got %d -> %d)", Cin, Cout);
   ConvV4Params p;
   p.x = x; p.x_sstride = x_sstride; p.y = y; p.y_sstride = y_sstride; p.wpk = wpk; p.bias = bias; p.stats = stats;
   p.N = N; p.D = D; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.epi = epi;
-  p.tilesZ = (D + 3) / 4; p.tilesY = (H + 7) / 8; p.tilesX = (W + 15) / 16;
+  p.tilesZ = p.tilesY = p.tilesX = 0;
   p.bz = p.by = p.bx = p.nbz = p.nby = p.nbx = 0;
   static const int dbg = getenv("IUNET_V4_DBG") ? atoi(getenv("IUNET_V4_DBG")) : 0;
   p.dbg = dbg;
-  if (Cin <= 32) return dtype == 0 ? launch_v4<f16, true>(p, stream) : launch_v4<bf16, true>(p, stream);
-  return dtype == 0 ? launch_v4<f16, false>(p, stream) : launch_v4<bf16, false>(p, stream);
+  // weights resident in LDS for the whole launch when they fit beside the two activation buffers
+  const bool ws = nd == 3 ? Cin <= 32 : Cin <= 64;
+#define V4_GO(TT) (nd == 3 ? (ws ? launch_v4<TT, 3, true>(p, stream) : launch_v4<TT, 3, false>(p, stream)) \
+                           : (ws ? launch_v4<TT, 2, true>(p, stream) : launch_v4<TT, 2, false>(p, stream)))
+  return dtype == 0 ? V4_GO(f16) : V4_GO(bf16);
+#undef V4_GO
 }

@@ -82,7 +82,7 @@ def test_conv3_exact_integers(nv, nd, shape, cin, cout):
     w = torch.randint(-1, 2, (cout, cin) + (3,) * nd, generator=g).float()
     ref = (F.conv2d if nd == 2 else F.conv3d)(x, w, padding=1)
     for dt in (torch.float16, torch.bfloat16):
-        layouts = ((0, 1) if cout % 64 == 0 and cin % 32 == 0 else (1,)) + ((2,) if nd == 3 and cin <= 64 else ())
+        layouts = ((0, 1) if cout % 64 == 0 and cin % 32 == 0 else (1,)) + (2,)
         for layout in layouts:                                            # every kernel structure that is legal
             got = run_conv3(nv, x, w, dt, nd, layout=layout)
             ok = ref.abs() <= (2048 if dt == torch.float16 else 256)   # exactly representable outputs
@@ -105,7 +105,7 @@ def test_conv3_random_bias_relu_stats(nv, nd):
     assert (got - ref).abs().max() <= 2e-3 * max(1.0, ref.abs().max().item())
     rr = conv(x, w.half().float(), padding=1)
     dims = [0] + list(range(2, 2 + nd))
-    for layout in (None, 2) if nd == 3 else (None,):
+    for layout in (None, 1, 2):
         raw, st = run_conv3(nv, x, w, torch.float16, nd, stats=True, layout=layout)
         assert torch.allclose(st[:, 0], rr.sum(dims), rtol=1e-3, atol=1e-1), layout
         assert torch.allclose(st[:, 1], (rr * rr).sum(dims), rtol=1e-3, atol=1e-1), layout
