@@ -6,7 +6,7 @@
 // and a blocked wave issues no MFMAs; two such workgroups per CU, or half the bytes (weights kept in LDS), did not
 // change that.  So here the roles are split inside one persistent workgroup per CU:
 //   * 8 CONSUMER waves (two per SIMD) only read LDS and issue MFMAs (plus the tile's output stores);
-//   * 4 LOADER waves (one per SIMD) fetch the next 16-channel chunk of the halo tile (and, for Cin > 32, its
+//   * 4 or 8 LOADER waves (one or two per SIMD) fetch the next 16-channel chunk of the halo tile (and, for Cin > 32, its
 //     30 KB of weights) global -> registers -> the OTHER LDS buffer, wait for it, and meet the consumers at the
 //     one barrier per step.  Their stalls on the memory queue cost no MFMA issue slots.
 // 3-D: tile 4 x 8 x 16 voxels, a step = one 16-channel chunk; 2-D: tile 16 x 32 pixels, a step = 32 channels (the 2-D
@@ -38,10 +38,12 @@ struct ConvV4Params {
 };
 
 template <typename T, int ND, bool WS>
-__global__ __launch_bounds__(768, 1) void conv3_v4_kernel(ConvV4Params p) {
+__global__ __launch_bounds__(WS ? 768 : 1024, 1) void conv3_v4_kernel(ConvV4Params p) {
   using V8 = typename Vec8<T>::type;
   using TL = V4Tile<ND>;
-  constexpr int NCW = 8, NLT = 256;                    // consumer waves; loader threads
+  // consumer waves; loader threads: 4 loader waves when only activations stream, 8 when the weights stream too (twice the
+  // bytes per step: the extra waves double the loads in flight, -6...-11 % on those layers)
+  constexpr int NCW = 8, NLT = WS ? 256 : 512;
   constexpr int TZ = TL::TZ, TY = TL::TY, TX = TL::TX, PADZ = TL::PADZ, NCOL = TL::NCOL, S16 = TL::S16;
   constexpr int NI = 4, FX = TX / 16, NR = NI / FX;    // fragments per consumer wave; x halves; tile rows per wave
   constexpr int PZ = TZ + 2 * PADZ, PY = TY + 2, PX = TX + 2;
@@ -92,7 +94,7 @@ __global__ __launch_bounds__(768, 1) void conv3_v4_kernel(ConvV4Params p) {
 
   if (WS) {     // all weights of this Cout tile: global -> LDS once, by everybody
     const int nitems = nchunk * (WSTEP / 16);
-    for (int i = tid; i < nitems; i += 768) *(u32x4*)(smem + OFF_W + i * 16) = wsrc[i];
+    for (int i = tid; i < nitems; i += 512 + NLT) *(u32x4*)(smem + OFF_W + i * 16) = wsrc[i];
   }
 
   if (wave >= NCW) {
@@ -327,7 +329,7 @@ int launch_v4(ConvV4Params p, hipStream_t stream) {
   }
   p.nbz = (p.tilesZ + p.bz - 1) / p.bz; p.nby = (p.tilesY + p.by - 1) / p.by; p.nbx = (p.tilesX + p.bx - 1) / p.bx;
   const int gx = 8 * p.bz * p.by * p.bx;
-  hipLaunchKernelGGL((conv3_v4_kernel<T, ND, WS>), dim3(gx, ncob), dim3(768), lds, stream, p);
+  hipLaunchKernelGGL((conv3_v4_kernel<T, ND, WS>), dim3(gx, ncob), dim3(WS ? 768 : 1024), lds, stream, p);
   IUNET_CHECK_HIP(hipGetLastError());
   return IUNET_OK;
 }

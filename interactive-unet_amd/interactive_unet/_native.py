@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), 'lib', 'libiunet.so')
+LIB_PATH = os.environ.get('IUNET_LIB') or os.path.join(os.path.dirname(_HERE), 'lib', 'libiunet.so')   # IUNET_LIB: A/B builds
 
 _lib = None
 
