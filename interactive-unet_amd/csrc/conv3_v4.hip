@@ -19,6 +19,10 @@
 
 namespace {
 
+#ifndef V4_NCW
+#define V4_NCW 8                                         // consumer waves (A/B: 4 waves x 8 fragments measured the same, +-2 %)
+#endif
+
 template <int ND> struct V4Tile;
 template <> struct V4Tile<3> { static constexpr int TZ = 4, TY = 8, TX = 16, PADZ = 1, NCOL = 9, S16 = 1; };
 template <> struct V4Tile<2> { static constexpr int TZ = 1, TY = 16, TX = 32, PADZ = 0, NCOL = 3, S16 = 2; };
@@ -38,14 +42,14 @@ struct ConvV4Params {
 };
 
 template <typename T, int ND, bool WS>
-__global__ __launch_bounds__(WS ? 768 : 1024, 1) void conv3_v4_kernel(ConvV4Params p) {
+__global__ __launch_bounds__(V4_NCW * 64 + (WS ? 256 : 512), 1) void conv3_v4_kernel(ConvV4Params p) {
   using V8 = typename Vec8<T>::type;
   using TL = V4Tile<ND>;
   // consumer waves; loader threads: 4 loader waves when only activations stream, 8 when the weights stream too (twice the
   // bytes per step: the extra waves double the loads in flight, -6...-11 % on those layers)
-  constexpr int NCW = 8, NLT = WS ? 256 : 512;
+  constexpr int NCW = V4_NCW, NLT = WS ? 256 : 512;
   constexpr int TZ = TL::TZ, TY = TL::TY, TX = TL::TX, PADZ = TL::PADZ, NCOL = TL::NCOL, S16 = TL::S16;
-  constexpr int NI = 4, FX = TX / 16, NR = NI / FX;    // fragments per consumer wave; x halves; tile rows per wave
+  constexpr int FX = TX / 16, NI = TZ * TY * FX / NCW, NR = NI / FX;    // x halves; fragments per consumer wave; tile rows per wave
   constexpr int PZ = TZ + 2 * PADZ, PY = TY + 2, PX = TX + 2;
   constexpr int NPIX = PZ * PY * PX;                   // 1080 / 612
   constexpr int PLANE = ((NPIX * 16 + 255) / 256) * 256;
@@ -94,7 +98,7 @@ __global__ __launch_bounds__(WS ? 768 : 1024, 1) void conv3_v4_kernel(ConvV4Para
 
   if (WS) {     // all weights of this Cout tile: global -> LDS once, by everybody
     const int nitems = nchunk * (WSTEP / 16);
-    for (int i = tid; i < nitems; i += 512 + NLT) *(u32x4*)(smem + OFF_W + i * 16) = wsrc[i];
+    for (int i = tid; i < nitems; i += NCW * 64 + NLT) *(u32x4*)(smem + OFF_W + i * 16) = wsrc[i];
   }
 
   if (wave >= NCW) {
@@ -229,15 +233,11 @@ __global__ __launch_bounds__(WS ? 768 : 1024, 1) void conv3_v4_kernel(ConvV4Para
             acc[1][n] = mfma16<T>(A[b][dy][1], R[b][n % FX][n / FX + dy], acc[1][n]);
           }
         if (g + 1 < NGRP) {
+          constexpr int MPR = (3 * NI * 2) / NRD > 0 ? (3 * NI * 2) / NRD : 1;      // MFMAs per LDS read in the interleave
 #pragma unroll
-          for (int i = 0; i < NRD - 12; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);     // two LDS reads
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);     // two MFMAs
-          }
-#pragma unroll
-          for (int i = NRD - 12; i < 12; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // one LDS read
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);     // two MFMAs
+          for (int i = 0; i < NRD; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);       // one LDS read
+            __builtin_amdgcn_sched_group_barrier(0x008, MPR, 0);     // MPR MFMAs
           }
         }
         __builtin_amdgcn_sched_barrier(0);                         // nothing moves across the group boundary
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(WS ? 768 : 1024, 1) void conv3_v4_kernel(ConvV4Para
       }
       if (p.stats != nullptr) {
         // partial BatchNorm sums of this tile: 16 x-lanes by shuffles, the 8 waves in wave order through LDS
-        float* red = (float*)(smem + off_red);                 // [8 waves][4 q][8][2]
+        float* red = (float*)(smem + off_red);                 // [consumer waves][4 q][8][2]
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           float a = s_sum[j], b = s_sq[j];
@@ -329,7 +329,7 @@ int launch_v4(ConvV4Params p, hipStream_t stream) {
   }
   p.nbz = (p.tilesZ + p.bz - 1) / p.bz; p.nby = (p.tilesY + p.by - 1) / p.by; p.nbx = (p.tilesX + p.bx - 1) / p.bx;
   const int gx = 8 * p.bz * p.by * p.bx;
-  hipLaunchKernelGGL((conv3_v4_kernel<T, ND, WS>), dim3(gx, ncob), dim3(WS ? 768 : 1024), lds, stream, p);
+  hipLaunchKernelGGL((conv3_v4_kernel<T, ND, WS>), dim3(gx, ncob), dim3(V4_NCW * 64 + (WS ? 256 : 512)), lds, stream, p);
   IUNET_CHECK_HIP(hipGetLastError());
   return IUNET_OK;
 }
