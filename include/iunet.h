@@ -68,6 +68,11 @@ int iunet_conv3_fwd(int dtype, int nd, const void* x, long long x_sstride, void*
  * 2 = weight-stationary variant of 1 (same mode-bit-1 operator; 3-D, Cin <= 64: all weights of a Cout tile stay
  * in LDS for the whole launch).  Layout 1 or 2 is mandatory when Cout is not a multiple of 64. */
 int iunet_conv3_pick_layout(int nd, int N, int D, int H, int W, int Cin, int Cout);
+/* iunet_conv3_fwd whose input is relu(in_scale[c] * x + in_shift[c]) (fp32 [Cin] each): in training the BatchNorm + ReLU of
+ * the previous conv is applied by the loader waves instead of a separate pass over HBM.  Layout 2 only. */
+int iunet_conv3_fwd_act(int dtype, int nd, const void* x, long long x_sstride, void* y, long long y_sstride,
+                        const void* wpk, const void* bias, void* stats, const void* in_scale, const void* in_shift,
+                        int N, int D, int H, int W, int Cin, int Cout, int epi, int layout, void* stream);
 int iunet_conv3_num_tiles(int nd, int N, int D, int H, int W);
 /* profiling only: ablation variants of the bf16 3-D Cout = 32 conv (mask bits: 1 no weight loads, 2 no LDS reads,
  * 4 no staging, 8 no stores); results are meaningless except for mask 0. */
@@ -155,6 +160,10 @@ int iunet_conv3_wgrad_blocks(int nd, int N, int D, int H, int W, int Cin, int Co
 long long iunet_conv3_wgrad_slab_floats(int nd, int N, int D, int H, int W, int Cin, int Cout);
 int iunet_conv3_wgrad(int dtype, int nd, const void* x, long long x_ss, const void* dy, long long dy_ss, void* slab,
                       void* dW, float alpha, int N, int D, int H, int W, int Cin, int Cout, void* stream);
+/* the same with the conv input given as relu(x_scale[c] * x + x_shift[c]) (see iunet_conv3_fwd_act); 3-D only. */
+int iunet_conv3_wgrad_act(int dtype, int nd, const void* x, long long x_ss, const void* dy, long long dy_ss, void* slab,
+                          void* dW, float alpha, const void* x_scale, const void* x_shift, int N, int D, int H, int W,
+                          int Cin, int Cout, void* stream);
 /* transposed conv backward (N, D, H, W, Cin, Cout describe the forward op). */
 int iunet_pack_convT_dgrad(int dtype, const void* w, void* dst, int Cin, int Cout, int npos, void* stream);
 int iunet_convT_dgrad(int dtype, int nd, const void* dy, long long dy_ss, void* dx, long long dx_ss, const void* wpk,

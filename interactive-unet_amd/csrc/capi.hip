@@ -17,7 +17,8 @@ void iunet_set_error(const char* fmt, ...) {
 // internal launchers (conv3_mfma.hip, pointwise.hip)
 int iunet_conv3_launch(int dtype, int nd, const void* x, long long x_sstride, void* y, long long y_sstride,
                        const void* wpk, const float* bias, float* stats, int N, int D, int H, int W, int Cin,
-                       int Cout, int epi, int layout, hipStream_t stream);
+                       int Cout, int epi, int layout, hipStream_t stream, const float* in_scale = nullptr,
+                       const float* in_shift = nullptr);
 int iunet_conv3_pick(int nd, int N, int D, int H, int W, int Cin, int Cout);
 int iunet_conv3_tiles(int nd, int N, int D, int H, int W);
 long long iunet_pack_conv3_size(int Cout, int Cin, int taps, int mode);
@@ -92,6 +93,20 @@ int iunet_conv3_fwd(int dtype, int nd, const void* x, long long x_sstride, void*
   IUNET_REQUIRE(layout >= 0 && layout <= 2, "conv3: layout must be 0, 1 or 2 (got %d)", layout);
   return iunet_conv3_launch(dtype, nd, x, x_sstride, y, y_sstride, wpk, (const float*)bias, (float*)stats, N, D, H, W,
                             Cin, Cout, epi, layout, (hipStream_t)stream);
+}
+
+// iunet_conv3_fwd whose input is relu(in_scale[c] * x + in_shift[c]) (training: the BatchNorm + ReLU of the previous
+// conv, applied by the loader waves instead of a separate pass); layout 2 only.
+int iunet_conv3_fwd_act(int dtype, int nd, const void* x, long long x_sstride, void* y, long long y_sstride,
+                        const void* wpk, const void* bias, void* stats, const void* in_scale, const void* in_shift,
+                        int N, int D, int H, int W, int Cin, int Cout, int epi, int layout, void* stream) {
+  DT_OK(dtype);
+  IUNET_REQUIRE(x && y && wpk && in_scale && in_shift, "conv3_act: null pointer");
+  IUNET_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0, "conv3: bad shape %d %d %d %d", N, D, H, W);
+  IUNET_REQUIRE(epi >= 0 && epi <= 2, "conv3: bad epilogue %d", epi);
+  IUNET_REQUIRE(layout == 2, "conv3_act: the fused input activation exists in layout 2 only (got %d)", layout);
+  return iunet_conv3_launch(dtype, nd, x, x_sstride, y, y_sstride, wpk, (const float*)bias, (float*)stats, N, D, H, W,
+                            Cin, Cout, epi, layout, (hipStream_t)stream, (const float*)in_scale, (const float*)in_shift);
 }
 
 /* profiling only: ablation builds of the 3-D Cout=32 bf16 conv (not part of the product path) */

@@ -328,12 +328,12 @@ int iunet_conv3_v2_launch(int dtype, int nd, const void* x, long long x_sstride,
                           int Cout, int epi, hipStream_t stream);
 int iunet_conv3_v4_launch(int dtype, int nd, const void* x, long long x_sstride, void* y, long long y_sstride, const void* wpk,
                           const float* bias, float* stats, int N, int D, int H, int W, int Cin, int Cout, int epi,
-                          hipStream_t stream);
+                          const float* in_scale, const float* in_shift, hipStream_t stream);
 
 // Host entry used by the net runtime and the per-kernel C ABI.
 int iunet_conv3_launch(int dtype, int nd, const void* x, long long x_sstride, void* y, long long y_sstride,
                        const void* wpk, const float* bias, float* stats, int N, int D, int H, int W, int Cin,
-                       int Cout, int epi, int layout, hipStream_t stream) {
+                       int Cout, int epi, int layout, hipStream_t stream, const float* in_scale, const float* in_shift) {
   IUNET_REQUIRE(nd == 2 || nd == 3, "conv3: nd must be 2 or 3 (got %d)", nd);
   IUNET_REQUIRE(Cin % 32 == 0 && Cout % 32 == 0, "conv3: Cin (%d) and Cout (%d) must be multiples of 32", Cin, Cout);
   IUNET_REQUIRE(nd == 3 || D == 1, "conv3: 2-D conv needs D == 1");
@@ -344,8 +344,11 @@ int iunet_conv3_launch(int dtype, int nd, const void* x, long long x_sstride, vo
   const int TZ = nd == 3 ? 4 : 1, TY = nd == 3 ? 8 : 16, TX = nd == 3 ? 16 : 32;
   p.tilesZ = (D + TZ - 1) / TZ; p.tilesY = (H + TY - 1) / TY; p.tilesX = (W + TX - 1) / TX;
   const bool wide = (Cout % 64 == 0);
+  IUNET_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv3: in_scale and in_shift come together");
+  IUNET_REQUIRE(in_scale == nullptr || layout == 2, "conv3: a fused input activation needs layout 2 (got %d)", layout);
   if (layout == 2) {
-    return iunet_conv3_v4_launch(dtype, nd, x, x_sstride, y, y_sstride, wpk, bias, stats, N, D, H, W, Cin, Cout, epi, stream);
+    return iunet_conv3_v4_launch(dtype, nd, x, x_sstride, y, y_sstride, wpk, bias, stats, N, D, H, W, Cin, Cout, epi,
+                                 in_scale, in_shift, stream);
   }
   if (layout == 1)
     return iunet_conv3_v2_launch(dtype, nd, x, x_sstride, y, y_sstride, wpk, bias, stats, N, D, H, W, Cin, Cout, epi, stream);

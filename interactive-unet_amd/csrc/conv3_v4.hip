@@ -32,6 +32,8 @@ struct ConvV4Params {
   void* y;        long long y_sstride;
   const void* wpk;                            // K16 order: [cob][chunk16][column pair][dy][2][64][8]
   const float* bias;
+  const float* in_scale;                      // optional [Cin] pair: the input is relu(in_scale * x + in_shift), applied by the
+  const float* in_shift;                      // loader waves (training: BatchNorm + ReLU of the previous conv, never materialised)
   float* stats;                               // [N * tiles][Cout][2] or null
   int N, D, H, W, Cin, Cout;
   int tilesZ, tilesY, tilesX;
@@ -144,7 +146,19 @@ __global__ __launch_bounds__(V4_NCW * 64 + (WS ? 256 : 512), 1) void conv3_v4_ke
         if (pix < NPIX) {
           const bool ok = (r.ok >> it) & 1u;
 #pragma unroll
-          for (int k = 0; k < CP; ++k) *(u32x4*)(ab + k * PLANE + pix * 16) = ok ? r.a[it][k] : u32x4{0u, 0u, 0u, 0u};
+          for (int k = 0; k < CP; ++k) {
+            u32x4 v = r.a[it][k];
+            if (p.in_scale != nullptr) {               // z = relu(scale * y + shift), the arithmetic of bn_relu_fwd_kernel
+              const int cbase = ((s - (s / nchunk) * nchunk) * CP + k) * 8;
+              const V8 in = __builtin_bit_cast(V8, v);
+              V8 o;
+#pragma unroll
+              for (int j = 0; j < 8; ++j)
+                o[j] = from_f32<T>(fmaxf(fmaf(p.in_scale[cbase + j], to_f32<T>(in[j]), p.in_shift[cbase + j]), 0.f));
+              v = __builtin_bit_cast(u32x4, o);
+            }
+            *(u32x4*)(ab + k * PLANE + pix * 16) = ok ? v : u32x4{0u, 0u, 0u, 0u};      // padding stays zero AFTER the activation
+          }
         }
       }
       if (!WS) {
@@ -338,11 +352,12 @@ int launch_v4(ConvV4Params p, hipStream_t stream) {
 
 int iunet_conv3_v4_launch(int dtype, int nd, const void* x, long long x_sstride, void* y, long long y_sstride, const void* wpk,
                           const float* bias, float* stats, int N, int D, int H, int W, int Cin, int Cout, int epi,
-                          hipStream_t stream) {
+                          const float* in_scale, const float* in_shift, hipStream_t stream) {
   IUNET_REQUIRE(Cin % 32 == 0 && Cout % 32 == 0, "conv3 layout 2: Cin %% 32, Cout %% 32 (got %d -> %d)", Cin, Cout);
   ConvV4Params p;
   p.x = x; p.x_sstride = x_sstride; p.y = y; p.y_sstride = y_sstride; p.wpk = wpk; p.bias = bias; p.stats = stats;
   p.N = N; p.D = D; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.epi = epi;
+  p.in_scale = in_scale; p.in_shift = in_shift;
   p.tilesZ = p.tilesY = p.tilesX = 0;
   p.bz = p.by = p.bx = p.nbz = p.nby = p.nbx = 0;
   static const int dbg = getenv("IUNET_V4_DBG") ? atoi(getenv("IUNET_V4_DBG")) : 0;

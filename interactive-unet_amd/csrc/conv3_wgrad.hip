@@ -251,7 +251,8 @@ int launch_wgrad(const WgradParams& p, int nb, hipStream_t stream) {
 
 int iunet_conv3_wgrad_v2_blocks(int N, int D, int H, int W, int Cin, int Cout);
 int iunet_conv3_wgrad_v2_launch(int dtype, const void* x, long long x_ss, const void* dy, long long dy_ss, float* slab,
-                                int N, int D, int H, int W, int Cin, int Cout, hipStream_t stream);
+                                int N, int D, int H, int W, int Cin, int Cout, const float* x_scale, const float* x_shift,
+                                hipStream_t stream);
 static bool wgrad_use_v2(int nd) {
   static const bool off = getenv("IUNET_WGRAD_V1") != nullptr;       // A/B runs: the two-workgroups-per-CU structure
   return nd == 3 && !off;
@@ -276,9 +277,9 @@ long long iunet_conv3_wgrad_slab_floats(int nd, int N, int D, int H, int W, int 
   return (long long)iunet_conv3_wgrad_blocks(nd, N, D, H, W, Cin, Cout) * (Cout / 32) * (Cin / 32) * taps * 1024;
 }
 
-// dW fp32 [Cout][Cin][taps] = alpha * sum over samples and voxels of dy (x) shifted x
-int iunet_conv3_wgrad(int dtype, int nd, const void* x, long long x_ss, const void* dy, long long dy_ss, void* slab,
-                      void* dW, float alpha, int N, int D, int H, int W, int Cin, int Cout, void* stream) {
+static int wgrad_impl(int dtype, int nd, const void* x, long long x_ss, const void* dy, long long dy_ss, void* slab,
+                      void* dW, float alpha, int N, int D, int H, int W, int Cin, int Cout, const float* x_scale,
+                      const float* x_shift, void* stream) {
   IUNET_REQUIRE(dtype == 0 || dtype == 1, "conv3_wgrad: bad dtype %d", dtype);
   IUNET_REQUIRE(nd == 2 || nd == 3, "conv3_wgrad: nd must be 2 or 3");
   IUNET_REQUIRE(Cin % 32 == 0 && Cout % 32 == 0, "conv3_wgrad: channels must be multiples of 32 (%d, %d)", Cin, Cout);
@@ -290,7 +291,8 @@ int iunet_conv3_wgrad(int dtype, int nd, const void* x, long long x_ss, const vo
   p.tilesZ = (D + TZ - 1) / TZ; p.tilesY = (H + TY - 1) / TY; p.tilesX = (W + TX - 1) / TX;
   const int nb = iunet_conv3_wgrad_blocks(nd, N, D, H, W, Cin, Cout);
   int rc;
-  if (wgrad_use_v2(nd)) rc = iunet_conv3_wgrad_v2_launch(dtype, x, x_ss, dy, dy_ss, (float*)slab, N, D, H, W, Cin, Cout, (hipStream_t)stream);
+  IUNET_REQUIRE(x_scale == nullptr || wgrad_use_v2(nd), "conv3_wgrad: a fused input activation needs the 3-D wave-specialised kernel");
+  if (wgrad_use_v2(nd)) rc = iunet_conv3_wgrad_v2_launch(dtype, x, x_ss, dy, dy_ss, (float*)slab, N, D, H, W, Cin, Cout, x_scale, x_shift, (hipStream_t)stream);
   else if (dtype == 0) rc = nd == 3 ? launch_wgrad<f16, 3>(p, nb, (hipStream_t)stream) : launch_wgrad<f16, 2>(p, nb, (hipStream_t)stream);
   else rc = nd == 3 ? launch_wgrad<bf16, 3>(p, nb, (hipStream_t)stream) : launch_wgrad<bf16, 2>(p, nb, (hipStream_t)stream);
   if (rc != IUNET_OK) return rc;
@@ -300,6 +302,21 @@ int iunet_conv3_wgrad(int dtype, int nd, const void* x, long long x_ss, const vo
                      (const float*)slab, nb, Cout, Cin, taps, (float*)dW, alpha);
   IUNET_CHECK_HIP(hipGetLastError());
   return IUNET_OK;
+}
+
+// dW fp32 [Cout][Cin][taps] = alpha * sum over samples and voxels of dy (x) shifted x
+int iunet_conv3_wgrad(int dtype, int nd, const void* x, long long x_ss, const void* dy, long long dy_ss, void* slab,
+                      void* dW, float alpha, int N, int D, int H, int W, int Cin, int Cout, void* stream) {
+  return wgrad_impl(dtype, nd, x, x_ss, dy, dy_ss, slab, dW, alpha, N, D, H, W, Cin, Cout, nullptr, nullptr, stream);
+}
+
+// the same with the conv input given as relu(x_scale[c] * x + x_shift[c]) (see iunet_conv3_fwd_act); 3-D only
+int iunet_conv3_wgrad_act(int dtype, int nd, const void* x, long long x_ss, const void* dy, long long dy_ss, void* slab,
+                          void* dW, float alpha, const void* x_scale, const void* x_shift, int N, int D, int H, int W,
+                          int Cin, int Cout, void* stream) {
+  IUNET_REQUIRE(x_scale && x_shift, "conv3_wgrad_act: null scale / shift");
+  return wgrad_impl(dtype, nd, x, x_ss, dy, dy_ss, slab, dW, alpha, N, D, H, W, Cin, Cout, (const float*)x_scale,
+                    (const float*)x_shift, stream);
 }
 
 }  // extern "C"

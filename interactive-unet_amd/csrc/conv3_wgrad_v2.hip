@@ -22,6 +22,8 @@ typedef __attribute__((address_space(3))) s16x4* lds_s4_ptr;
 struct WgradV2Params {
   const void* x;  long long x_ss;     // conv input  (Cin/8 planes)
   const void* dy; long long dy_ss;    // output grad (Cout/8 planes)
+  const float* x_scale;               // optional [Cin] pair: the conv input is relu(x_scale * x + x_shift), applied by the
+  const float* x_shift;               // loader waves (the BatchNorm + ReLU of the previous conv, never materialised)
   float* slab;                        // [gridDim.x][Cout/32][Cin/32][27][32][32]
   int N, D, H, W, Cin, Cout;
   int tilesZ, tilesY, tilesX;
@@ -50,7 +52,7 @@ __global__ __launch_bounds__(768, 1) void conv3_wgrad_v2_kernel(WgradV2Params p)
   constexpr int YBUF = 4 * PLANE_Y;
   constexpr int NU = TAPS * 2, MAXU = (NU + 3) / 4;                // 54 units, 14 per unit wave
   constexpr int NCW = 8, NLT = 256;
-  constexpr int XIT = (4 * ZPIX * 4 + NLT - 1) / NLT;              // 16-byte x items per loader thread, 4 z-planes (12)
+  constexpr int XIT = (4 * ZPIX + 63) / 64;                        // 16-byte x items per loader lane: 4 z-planes of one channel plane (12)
   constexpr int YIT = NVOX * 4 / NLT;                              // dy items per loader thread (4)
   static_assert(PLANE_X % 256 == 64, "x plane stride must be 64 mod 256");
 
@@ -84,15 +86,23 @@ __global__ __launch_bounds__(768, 1) void conv3_wgrad_v2_kernel(WgradV2Params p)
     const int lt = tid - NCW * 64;
     struct Staged { u32x4 x[XIT]; u32x4 y[YIT]; unsigned okx, oky; };
     // per-thread item tables, computed once: the loaders' integer arithmetic per tile is what their rate depends on
-    // x item = (zi, channel plane, voxel of the z-plane): packed zi | pl << 4 | py << 8 | px << 16, and its LDS offset
+    // x: loader wave w owns channel plane w (its BatchNorm constants are then wave-uniform); item = (zi, voxel of the
+    // z-plane): packed zi | py << 8 | px << 16, and its LDS offset
+    const int lw = lt >> 6, ll = lt & 63;
     int xc[XIT], xl[XIT], yc[YIT], yl[YIT];
 #pragma unroll
     for (int it = 0; it < XIT; ++it) {
-      const int item = min(lt + it * NLT, 16 * ZPIX - 1);
-      const int zi = item / (4 * ZPIX), rem = item - zi * (4 * ZPIX), pl = rem / ZPIX, pix = rem - pl * ZPIX;
+      const int idx = min(ll + it * 64, 4 * ZPIX - 1);
+      const int zi = idx / ZPIX, pix = idx - zi * ZPIX;
       const int py = pix / PX, px = pix - py * PX;
-      xc[it] = zi | (pl << 4) | (py << 8) | (px << 16);
-      xl[it] = pl * PLANE_X + pix * 16;
+      xc[it] = zi | (py << 8) | (px << 16);
+      xl[it] = lw * PLANE_X + pix * 16;
+    }
+    float xsc[8], xsh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      xsc[j] = p.x_scale ? p.x_scale[cib * 32 + lw * 8 + j] : 1.f;
+      xsh[j] = p.x_scale ? p.x_shift[cib * 32 + lw * 8 + j] : 0.f;
     }
 #pragma unroll
     for (int it = 0; it < YIT; ++it) {
@@ -107,18 +117,18 @@ __global__ __launch_bounds__(768, 1) void conv3_wgrad_v2_kernel(WgradV2Params p)
       int n_img, z0, y0, x0;
       tile_origin(k, n_img, z0, y0, x0);
       const bool fr = fresh(k);
-      const int nitems = (fr ? 4 : 2) * 4 * ZPIX, pz0 = fr ? 0 : 2;
-      const T* xin = (const T*)p.x + (long long)n_img * p.x_ss + (long long)cib * 4 * plane_stride;
+      const int nitems = (fr ? 4 : 2) * ZPIX, pz0 = fr ? 0 : 2;       // per channel plane
+      const T* xin = (const T*)p.x + (long long)n_img * p.x_ss + (long long)(cib * 4 + lw) * plane_stride;
       const T* dyin = (const T*)p.dy + (long long)n_img * p.dy_ss + (long long)cob * 4 * plane_stride;
       r.okx = 0; r.oky = 0;
 #pragma unroll
       for (int it = 0; it < XIT; ++it) {
-        if (lt + it * NLT < nitems) {
-          const int zi = xc[it] & 15, pl = (xc[it] >> 4) & 15, py = (xc[it] >> 8) & 255, px = xc[it] >> 16;
+        if (ll + it * 64 < nitems) {
+          const int zi = xc[it] & 15, py = (xc[it] >> 8) & 255, px = xc[it] >> 16;
           const int gz = z0 + pz0 + zi - 1, gy = y0 + py - 1, gx = x0 + px - 1;
           const bool ok = (unsigned)gz < (unsigned)p.D && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
           const int cz = min(max(gz, 0), p.D - 1), cy = min(max(gy, 0), p.H - 1), cx = min(max(gx, 0), p.W - 1);
-          r.x[it] = *(const u32x4*)(xin + pl * plane_stride + (long long)((cz * p.H + cy) * p.W + cx) * 8);
+          r.x[it] = *(const u32x4*)(xin + (long long)((cz * p.H + cy) * p.W + cx) * 8);
           r.okx |= ok ? (1u << it) : 0u;
         }
       }
@@ -133,13 +143,21 @@ __global__ __launch_bounds__(768, 1) void conv3_wgrad_v2_kernel(WgradV2Params p)
       }
     };
     // x planes zi in [zi_lo, zi_hi) of the staged tile -> ring slots (slot0 + zi) mod 6
-    auto commit_x = [&](const Staged& r, int nitems, int zi_lo, int zi_hi, int slot0) {
+    auto commit_x = [&](const Staged& r, int nitems, int zi_lo, int zi_hi, int slot0) {      // nitems: per channel plane
 #pragma unroll
       for (int it = 0; it < XIT; ++it) {
         const int zi = xc[it] & 15;
-        if (lt + it * NLT < nitems && zi >= zi_lo && zi < zi_hi) {
+        if (ll + it * 64 < nitems && zi >= zi_lo && zi < zi_hi) {
           const int slot = (slot0 + zi) % NSLOT;
-          *(u32x4*)(smem + xl[it] + slot * (ZPIX * 16)) = ((r.okx >> it) & 1u) ? r.x[it] : u32x4{0u, 0u, 0u, 0u};
+          u32x4 v = r.x[it];
+          if (p.x_scale != nullptr) {                    // z = relu(scale * y + shift), the arithmetic of bn_relu_fwd_kernel
+            const typename Vec8<T>::type in = __builtin_bit_cast(typename Vec8<T>::type, v);
+            typename Vec8<T>::type o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = from_f32<T>(fmaxf(fmaf(xsc[j], to_f32<T>(in[j]), xsh[j]), 0.f));
+            v = __builtin_bit_cast(u32x4, o);
+          }
+          *(u32x4*)(smem + xl[it] + slot * (ZPIX * 16)) = ((r.okx >> it) & 1u) ? v : u32x4{0u, 0u, 0u, 0u};
         }
       }
     };
@@ -151,7 +169,7 @@ __global__ __launch_bounds__(768, 1) void conv3_wgrad_v2_kernel(WgradV2Params p)
     const bool refill = !(p.dbg & 1);
     Staged r;
     int base = 0;                                   // ring slot of halo plane pz = 0 of the tile being consumed
-    if (nt > 0) { load(0, r); commit_x(r, 16 * ZPIX, 0, 4, 0); commit_y(0, r); }
+    if (nt > 0) { load(0, r); commit_x(r, 4 * ZPIX, 0, 4, 0); commit_y(0, r); }
     if (nt > 1 && refill) load(1, r);
     lds_barrier();
     for (int k = 0; k < nt; ++k) {
@@ -159,12 +177,12 @@ __global__ __launch_bounds__(768, 1) void conv3_wgrad_v2_kernel(WgradV2Params p)
       const bool fr = more && fresh(k + 1);
       if (more) {
         // incoming planes go to the two free slots base + 4, base + 5: pz 2, 3 of a continuing column, pz 0, 1 of a new one
-        if (fr) commit_x(r, 16 * ZPIX, 0, 2, base + 4); else commit_x(r, 8 * ZPIX, 0, 2, base + 4);
+        if (fr) commit_x(r, 4 * ZPIX, 0, 2, base + 4); else commit_x(r, 2 * ZPIX, 0, 2, base + 4);
         commit_y(k + 1, r);
       }
       lds_barrier();                              // tile k is consumed
       if (k + 1 < nt && fresh(k + 1)) {             // (same condition as the consumers': the barrier count must match)
-        if (fr) commit_x(r, 16 * ZPIX, 2, 4, base + 4);      // pz 2, 3 of the new column into the slots tile k just released
+        if (fr) commit_x(r, 4 * ZPIX, 2, 4, base + 4);      // pz 2, 3 of the new column into the slots tile k just released
         lds_barrier();
         base = (base + 4) % NSLOT;
       } else {
@@ -273,9 +291,10 @@ int iunet_conv3_wgrad_v2_blocks(int N, int D, int H, int W, int Cin, int Cout) {
 }
 
 int iunet_conv3_wgrad_v2_launch(int dtype, const void* x, long long x_ss, const void* dy, long long dy_ss, float* slab,
-                                int N, int D, int H, int W, int Cin, int Cout, hipStream_t stream) {
+                                int N, int D, int H, int W, int Cin, int Cout, const float* x_scale, const float* x_shift,
+                                hipStream_t stream) {
   WgradV2Params p;
-  p.x = x; p.x_ss = x_ss; p.dy = dy; p.dy_ss = dy_ss; p.slab = slab;
+  p.x = x; p.x_ss = x_ss; p.dy = dy; p.dy_ss = dy_ss; p.slab = slab; p.x_scale = x_scale; p.x_shift = x_shift;
   p.N = N; p.D = D; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
   p.tilesZ = (D + 1) / 2; p.tilesY = (H + 7) / 8; p.tilesX = (W + 15) / 16;
   static const int dbg = getenv("IUNET_WG2_DBG") ? atoi(getenv("IUNET_WG2_DBG")) : 0;

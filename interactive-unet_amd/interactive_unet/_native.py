@@ -28,6 +28,8 @@ _SIGS = {
     'iunet_conv3_fwd': [c_int, c_int, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_void_p, c_void_p,
                         c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     'iunet_conv3_pick_layout': [c_int] * 7,
+    'iunet_conv3_fwd_act': [c_int, c_int, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                            c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     'iunet_first_conv_fwd': [c_int, c_int, c_void_p, c_int, ctypes.POINTER(c_ll), c_void_p, c_ll, c_void_p, c_void_p,
                              c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     'iunet_maxpool_fwd': [c_int, c_int, c_void_p, c_ll, c_void_p, c_ll, c_int, c_int, c_int, c_int, c_int, c_void_p],
@@ -65,6 +67,8 @@ _SIGS = {
     'iunet_conv3_wgrad_blocks': [c_int] * 7,
     'iunet_conv3_wgrad': [c_int, c_int, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_void_p, c_float,
                           c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    'iunet_conv3_wgrad_act': [c_int, c_int, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
+                              c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     'iunet_pack_convT_dgrad': [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     'iunet_convT_dgrad': [c_int, c_int, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_int, c_int, c_int, c_int, c_int,
                           c_int, c_void_p],

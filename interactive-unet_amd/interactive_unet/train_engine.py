@@ -9,6 +9,8 @@ HIP stream, except the optional RCCL gradient all-reduce (torch.distributed).
 import ctypes
 import math
 
+import os
+
 import torch
 
 from . import _native as nv
@@ -44,6 +46,9 @@ class TrainEngine:
         self.good_steps = 0
         self.step_count = 0
         self.pg = process_group
+        # 3-D: the BatchNorm + ReLU between the two convs of a stage is applied by the consumers' loader waves
+        # (IUNET_NO_ACT_FUSION=1: materialise it, for A/B runs)
+        self.fuse_act = self.dim == 3 and not os.environ.get('IUNET_NO_ACT_FUSION')
         self._flatten()
         self._alloc_packed()
         self._ws = {}
@@ -194,7 +199,10 @@ class TrainEngine:
         return ctypes.c_void_p(t.data_ptr() + off_elems * self.es)
 
     # ------------------------------------------------------------------ forward
-    def _stage_conv_fwd(self, ws, name, x_ptr, x_ss, ci, co, l, z_ptr, z_ss, N, x_raw=None, training=True):
+    def _stage_conv_fwd(self, ws, name, x_ptr, x_ss, ci, co, l, z_ptr, z_ss, N, x_raw=None, training=True, x_act=None):
+        """conv -> raw output y + BatchNorm batch statistics -> scale / shift; z = relu(bn(y)) is written unless z_ptr
+        is None (the consumer applies it in its loader waves).  x_act: name of the conv whose y is this conv's input
+        with its BatchNorm + ReLU still to be applied (iunet_conv3_fwd_act)."""
         d = ws['dims'][l]
         v = _vox(d)
         s = nv.stream()
@@ -210,16 +218,31 @@ class TrainEngine:
             pk, _ = self.pk[name]
             lay, w = pk.pick(self.dim, N, *d)
             nparts = nv.lib().iunet_conv3_num_tiles(self.dim, N, *d)
-            nv.call('iunet_conv3_fwd', self.dt, self.dim, x_ptr, x_ss, self._P(y), co * v, nv.ptr(w), None,
-                    nv.ptr(stats), N, d[0], d[1], d[2], ci, co, 0, lay, s)
+            if x_act is None:
+                nv.call('iunet_conv3_fwd', self.dt, self.dim, x_ptr, x_ss, self._P(y), co * v, nv.ptr(w), None,
+                        nv.ptr(stats), N, d[0], d[1], d[2], ci, co, 0, lay, s)
+            else:
+                nv.call('iunet_conv3_fwd_act', self.dt, self.dim, x_ptr, x_ss, self._P(y), co * v, nv.ptr(w), None,
+                        nv.ptr(stats), nv.ptr(ws['scale.' + x_act]), nv.ptr(ws['shift.' + x_act]),
+                        N, d[0], d[1], d[2], ci, co, 0, lay, s)
         bn = name.replace('conv', 'bn')
         nv.call('iunet_bn_finalize', nv.ptr(stats), nparts, co, float(N) * v,
                 nv.ptr(self.p(bn + '.weight')), nv.ptr(self.p(bn + '.bias')),
                 nv.ptr(self.p(bn + '.running_mean')), nv.ptr(self.p(bn + '.running_var')), BN_MOMENTUM, BN_EPS,
                 nv.ptr(ws['scale.' + name]), nv.ptr(ws['shift.' + name]), nv.ptr(ws['mean.' + name]),
                 nv.ptr(ws['invstd.' + name]), s)
-        nv.call('iunet_bn_relu_fwd', self.dt, self._P(y), co * v, z_ptr, z_ss, nv.ptr(ws['scale.' + name]),
-                nv.ptr(ws['shift.' + name]), co, N, v, s)
+        if z_ptr is not None:
+            nv.call('iunet_bn_relu_fwd', self.dt, self._P(y), co * v, z_ptr, z_ss, nv.ptr(ws['scale.' + name]),
+                    nv.ptr(ws['shift.' + name]), co, N, v, s)
+
+    def _conv2_input(self, ws, stage, l, N):
+        """(x_ptr, x_act, z1_ptr) of a stage's second conv.  3-D: conv1's BatchNorm + ReLU output is never written --
+        conv2 and its weight gradient read conv1's raw output and apply scale / shift / ReLU in their loader waves
+        (one tensor write and one read less per stage, and no bn_relu_fwd launch)."""
+        if self.fuse_act:
+            return self._P(ws[f'y.{stage}.conv1']), f'{stage}.conv1', None
+        z1 = ws[f'z.{stage}.conv1']
+        return self._P(z1), None, self._P(z1)
 
     def forward_train(self, x, x_strides, N, D, H, W):
         ws = self.workspace(N, D, H, W)
@@ -228,22 +251,20 @@ class TrainEngine:
         for l in range(L):
             v = _vox(dims[l])
             ci = self.cin if l == 0 else ch[l - 1]
-            z1 = ws[f'z.enc{l}.conv1']
+            x2, act, z1p = self._conv2_input(ws, f'enc{l}', l, N)
             if l == 0:
-                self._stage_conv_fwd(ws, 'enc0.conv1', None, 0, ci, ch[0], 0, self._P(z1), ch[0] * v, N,
-                                     x_raw=(x, x_strides))
+                self._stage_conv_fwd(ws, 'enc0.conv1', None, 0, ci, ch[0], 0, z1p, ch[0] * v, N, x_raw=(x, x_strides))
             else:
-                self._stage_conv_fwd(ws, f'enc{l}.conv1', self._P(ws[f'pin{l}']), ci * v, ci, ch[l], l, self._P(z1),
-                                     ch[l] * v, N)
+                self._stage_conv_fwd(ws, f'enc{l}.conv1', self._P(ws[f'pin{l}']), ci * v, ci, ch[l], l, z1p, ch[l] * v, N)
             if l < L - 1:
-                self._stage_conv_fwd(ws, f'enc{l}.conv2', self._P(z1), ch[l] * v, ch[l], ch[l], l,
-                                     self._P(ws[f'cat{l}']), 2 * ch[l] * v, N)
+                self._stage_conv_fwd(ws, f'enc{l}.conv2', x2, ch[l] * v, ch[l], ch[l], l,
+                                     self._P(ws[f'cat{l}']), 2 * ch[l] * v, N, x_act=act)
                 do = dims[l + 1]
                 nv.call('iunet_maxpool_fwd', self.dt, self.dim, self._P(ws[f'cat{l}']), 2 * ch[l] * v,
                         self._P(ws[f'pin{l + 1}']), ch[l] * _vox(do), ch[l], N, do[0], do[1], do[2], s)
             else:
-                self._stage_conv_fwd(ws, f'enc{l}.conv2', self._P(z1), ch[l] * v, ch[l], ch[l], l,
-                                     self._P(ws[f'z.enc{l}.conv2']), ch[l] * v, N)
+                self._stage_conv_fwd(ws, f'enc{l}.conv2', x2, ch[l] * v, ch[l], ch[l], l,
+                                     self._P(ws[f'z.enc{l}.conv2']), ch[l] * v, N, x_act=act)
         for l in range(L - 2, -1, -1):
             v, vi, di = _vox(dims[l]), _vox(dims[l + 1]), dims[l + 1]
             src = ws[f'z.enc{l + 1}.conv2'] if l == L - 2 else ws[f'z.dec{l + 1}.conv2']
@@ -251,11 +272,11 @@ class TrainEngine:
             nv.call('iunet_convT_fwd', self.dt, self.dim, self._P(src), ch[l + 1] * vi, self._P(ws[f'cat{l}'], ch[l] * v),
                     2 * ch[l] * v, nv.ptr(wf), nv.ptr(self.p(f'dec{l}.up.bias')), N, di[0], di[1], di[2],
                     ch[l + 1], ch[l], s)
-            z1 = ws[f'z.dec{l}.conv1']
+            x2, act, z1p = self._conv2_input(ws, f'dec{l}', l, N)
             self._stage_conv_fwd(ws, f'dec{l}.conv1', self._P(ws[f'cat{l}']), 2 * ch[l] * v, 2 * ch[l], ch[l], l,
-                                 self._P(z1), ch[l] * v, N)
-            self._stage_conv_fwd(ws, f'dec{l}.conv2', self._P(z1), ch[l] * v, ch[l], ch[l], l,
-                                 self._P(ws[f'z.dec{l}.conv2']), ch[l] * v, N)
+                                 z1p, ch[l] * v, N)
+            self._stage_conv_fwd(ws, f'dec{l}.conv2', x2, ch[l] * v, ch[l], ch[l], l,
+                                 self._P(ws[f'z.dec{l}.conv2']), ch[l] * v, N, x_act=act)
         return ws
 
     def loss_forward(self, ws, feat, y, w, N, vox):
@@ -271,7 +292,7 @@ class TrainEngine:
 
     # ------------------------------------------------------------------ backward
     def _stage_conv_bwd(self, ws, name, dz_ptr, dz_ss, z_ptr, z_ss, x_ptr, x_ss, ci, co, l, dx_ptr, dx_ss, N,
-                        x_raw=None):
+                        x_raw=None, x_act=None):
         d = ws['dims'][l]
         v = _vox(d)
         s = nv.stream()
@@ -289,8 +310,13 @@ class TrainEngine:
             nv.call('iunet_first_conv_wgrad', self.dt, self.dim, nv.ptr(x), nv.IN_DTYPE_CODE[x.dtype], nv.ll_array(xs),
                     self._P(dy), co * v, nv.ptr(ws['wslab']), nv.ptr(gw), N, d[0], d[1], d[2], ci, co, s)
         else:
-            nv.call('iunet_conv3_wgrad', self.dt, self.dim, x_ptr, x_ss, self._P(dy), co * v, nv.ptr(ws['wslab']),
-                    nv.ptr(gw), 1.0, N, d[0], d[1], d[2], ci, co, s)
+            if x_act is None:
+                nv.call('iunet_conv3_wgrad', self.dt, self.dim, x_ptr, x_ss, self._P(dy), co * v, nv.ptr(ws['wslab']),
+                        nv.ptr(gw), 1.0, N, d[0], d[1], d[2], ci, co, s)
+            else:
+                nv.call('iunet_conv3_wgrad_act', self.dt, self.dim, x_ptr, x_ss, self._P(dy), co * v, nv.ptr(ws['wslab']),
+                        nv.ptr(gw), 1.0, nv.ptr(ws['scale.' + x_act]), nv.ptr(ws['shift.' + x_act]),
+                        N, d[0], d[1], d[2], ci, co, s)
             _, pkd = self.pk[name]
             lay, wd = pkd.pick(self.dim, N, *d)
             nv.call('iunet_conv3_fwd', self.dt, self.dim, self._P(dy), co * v, dx_ptr, dx_ss, nv.ptr(wd), None, None,
@@ -317,8 +343,9 @@ class TrainEngine:
             v, vi, di = _vox(dims[l]), _vox(dims[l + 1]), dims[l + 1]
             z1, z2 = ws[f'z.dec{l}.conv1'], ws[f'z.dec{l}.conv2']
             dz1, dz2 = ws[f'dz.dec{l}.conv1'], ws[f'dz.dec{l}.conv2']
-            self._stage_conv_bwd(ws, f'dec{l}.conv2', self._P(dz2), ch[l] * v, self._P(z2), ch[l] * v, self._P(z1),
-                                 ch[l] * v, ch[l], ch[l], l, self._P(dz1), ch[l] * v, N)
+            x2, act, _ = self._conv2_input(ws, f'dec{l}', l, N)
+            self._stage_conv_bwd(ws, f'dec{l}.conv2', self._P(dz2), ch[l] * v, self._P(z2), ch[l] * v, x2,
+                                 ch[l] * v, ch[l], ch[l], l, self._P(dz1), ch[l] * v, N, x_act=act)
             self._stage_conv_bwd(ws, f'dec{l}.conv1', self._P(dz1), ch[l] * v, self._P(z1), ch[l] * v,
                                  self._P(ws[f'cat{l}']), 2 * ch[l] * v, 2 * ch[l], ch[l], l, self._P(ws[f'dcat{l}']),
                                  2 * ch[l] * v, N)
@@ -346,8 +373,9 @@ class TrainEngine:
                         ch[l], N, do[0], do[1], do[2], s)
                 dz2_ptr, dz2_ss = self._P(ws[f'dcat{l}']), 2 * ch[l] * v
                 z2_ptr, z2_ss = self._P(ws[f'cat{l}']), 2 * ch[l] * v
-            self._stage_conv_bwd(ws, f'enc{l}.conv2', dz2_ptr, dz2_ss, z2_ptr, z2_ss, self._P(z1), ch[l] * v, ch[l],
-                                 ch[l], l, self._P(dz1), ch[l] * v, N)
+            x2, act, _ = self._conv2_input(ws, f'enc{l}', l, N)
+            self._stage_conv_bwd(ws, f'enc{l}.conv2', dz2_ptr, dz2_ss, z2_ptr, z2_ss, x2, ch[l] * v, ch[l],
+                                 ch[l], l, self._P(dz1), ch[l] * v, N, x_act=act)
             if l == 0:
                 self._stage_conv_bwd(ws, 'enc0.conv1', self._P(dz1), ch[0] * v, self._P(z1), ch[0] * v, None, 0,
                                      self.cin, ch[0], 0, None, 0, N, x_raw=(x, x_strides))
