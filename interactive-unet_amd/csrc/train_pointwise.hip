@@ -277,18 +277,20 @@ struct HeadLossParams {
   int N; long long vox;
 };
 
+#define HEAD_FWD_ITER 8
 // sums per class: 0 sw, 1 swy, 2 swp, 3 swyp, 4 swy*log(p+eps), 5 sw*ry, 6 sw*rp, 7 sw*ry*rp
 template <typename T, int NCLS>
 __global__ __launch_bounds__(256) void head_loss_fwd_kernel(HeadLossParams p) {
-  const long long v = (long long)blockIdx.x * 256 + threadIdx.x;
   const int n = blockIdx.y;
-  const bool ok = v < p.vox;
   float acc[NCLS][8];
 #pragma unroll
   for (int c = 0; c < NCLS; ++c)
 #pragma unroll
     for (int k = 0; k < 8; ++k) acc[c][k] = 0.f;
-  if (ok) {
+  // HEAD_FWD_ITER x 256 voxels per workgroup: one block reduction (and one slab row for the finalize pass) per 2048 voxels
+  for (int it = 0; it < HEAD_FWD_ITER; ++it) {
+    const long long v = ((long long)blockIdx.x * HEAD_FWD_ITER + it) * 256 + threadIdx.x;
+    if (v >= p.vox) break;
     const T* xin = (const T*)p.x + n * p.x_ss + v * 8;
     float l[NCLS];
 #pragma unroll
@@ -316,9 +318,9 @@ __global__ __launch_bounds__(256) void head_loss_fwd_kernel(HeadLossParams p) {
       const float y = load_t(p.target, to, p.tdtype);
       const float w = p.weight ? load_t(p.weight, to, p.tdtype) : 1.f;
       const float ry = rintf(y), rp = rintf(pr);
-      acc[c][0] = w; acc[c][1] = w * y; acc[c][2] = w * pr; acc[c][3] = w * y * pr;
-      acc[c][4] = w * y * __logf(pr + 1e-12f);
-      acc[c][5] = w * ry; acc[c][6] = w * rp; acc[c][7] = w * ry * rp;
+      acc[c][0] += w; acc[c][1] += w * y; acc[c][2] += w * pr; acc[c][3] += w * y * pr;
+      acc[c][4] += w * y * __logf(pr + 1e-12f);
+      acc[c][5] += w * ry; acc[c][6] += w * rp; acc[c][7] += w * ry * rp;
     }
   }
   __shared__ float red[4 * NCLS * 8];
@@ -623,7 +625,7 @@ int iunet_maxpool_bwd(int dtype, int nd, const void* z, long long z_ss, const vo
   return IUNET_OK;
 }
 
-int iunet_head_loss_num_parts(int N, long long vox) { return N * (int)((vox + 255) / 256); }
+int iunet_head_loss_num_parts(int N, long long vox) { return N * (int)((vox + 256 * HEAD_FWD_ITER - 1) / (256 * HEAD_FWD_ITER)); }
 
 // partial-sum rows written by iunet_head_loss_bwd (each workgroup covers 256 * iter voxels)
 int iunet_head_loss_bwd_num_parts(int N, long long vox, int ncls, int C0) {
@@ -656,7 +658,7 @@ int iunet_head_loss_fwd(int dtype, const void* x, long long x_ss, int C0, const 
   HeadLossParams p{};
   p.x = x; p.x_ss = x_ss; p.planes = C0 / 8; p.w = (const float*)w; p.bias = (const float*)bias;
   p.target = target; p.weight = weight; p.tdtype = tdtype; p.slab = (float*)slab; p.N = N; p.vox = vox;
-  dim3 grid((unsigned)((vox + 255) / 256), N);
+  dim3 grid((unsigned)(iunet_head_loss_num_parts(N, vox) / N), N);
   if (dtype == 0) { HEAD_SWITCH(head_loss_fwd_kernel, f16) } else { HEAD_SWITCH(head_loss_fwd_kernel, bf16) }
   hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)slab,
                      iunet_head_loss_num_parts(N, vox), ncls, kind, weight != nullptr, (double)N * (double)vox,

@@ -188,7 +188,7 @@ class TrainEngine:
         ws['bncoef'] = f32(3 * max(ch))
         nparts = lib.iunet_head_loss_num_parts(N, v0)
         ws['lslab'] = f32(nparts * self.ncls * 8)
-        ws['hslab'] = f32(nparts * self.ncls * (ch[0] + 1))
+        ws['hslab'] = f32(lib.iunet_head_loss_bwd_num_parts(N, v0, self.ncls, ch[0]) * self.ncls * (ch[0] + 1))
         ws['htmp'] = f32(self.ncls * (ch[0] + 1))
         ws['out4'] = f32(4)
         ws['coef'] = f32(self.ncls * 3)
