@@ -58,7 +58,7 @@ int iunet_pack_batch(const void* descs, int n, int quant_max_cout, void* stream)
 
 /* ---- forward kernels (replace the smp conv stack under unet.py:65-69) ----------------- */
 /* 3^d conv, stride 1, pad 1, implicit GEMM on MFMA.  epi: 0 raw, 1 +bias, 2 +bias+ReLU.
- * stats (optional): fp32 [iunet_conv3_num_tiles][Cout][2] partial sum / sum of squares of
+ * stats (optional): fp32 [iunet_conv3_stats_parts(..., layout)][Cout][2] partial sum / sum of squares of
  * the raw output (BatchNorm batch statistics), reduced by the caller. */
 int iunet_conv3_fwd(int dtype, int nd, const void* x, long long x_sstride, void* y, long long y_sstride,
                     const void* wpk, const void* bias, void* stats, int N, int D, int H, int W, int Cin, int Cout,
@@ -74,6 +74,8 @@ int iunet_conv3_fwd_act(int dtype, int nd, const void* x, long long x_sstride, v
                         const void* wpk, const void* bias, void* stats, const void* in_scale, const void* in_shift,
                         int N, int D, int H, int W, int Cin, int Cout, int epi, int layout, void* stream);
 int iunet_conv3_num_tiles(int nd, int N, int D, int H, int W);
+/* rows of partial sums a conv3_fwd launch writes: one per tile (layouts 0, 1) or one per workgroup (layout 2) */
+int iunet_conv3_stats_parts(int nd, int N, int D, int H, int W, int Cout, int layout);
 /* profiling only: ablation variants of the bf16 3-D Cout = 32 conv (mask bits: 1 no weight loads, 2 no LDS reads,
  * 4 no staging, 8 no stores); results are meaningless except for mask 0. */
 int iunet_dbg_conv3_ablate(int exp, const void* x, void* y, const void* wpk, const void* bias, int N, int D, int H, int W,

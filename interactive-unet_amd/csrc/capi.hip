@@ -20,6 +20,7 @@ int iunet_conv3_launch(int dtype, int nd, const void* x, long long x_sstride, vo
                        int Cout, int epi, int layout, hipStream_t stream, const float* in_scale = nullptr,
                        const float* in_shift = nullptr);
 int iunet_conv3_pick(int nd, int N, int D, int H, int W, int Cin, int Cout);
+int iunet_conv3_v4_stats_parts(int nd, int Cout);
 int iunet_conv3_tiles(int nd, int N, int D, int H, int W);
 long long iunet_pack_conv3_size(int Cout, int Cin, int taps, int mode);
 int iunet_conv3_exp_launch(int exp, const void* x, void* y, const void* wpk, const float* bias, int N, int D, int H, int W,
@@ -50,6 +51,11 @@ const char* iunet_last_error(void) { return g_err; }
 int iunet_abi_version(void) { return 1; }
 
 int iunet_conv3_num_tiles(int nd, int N, int D, int H, int W) { return iunet_conv3_tiles(nd, N, D, H, W); }
+
+// rows of the statistics buffer a conv3_fwd launch with this layout writes (and bn_finalize must read)
+int iunet_conv3_stats_parts(int nd, int N, int D, int H, int W, int Cout, int layout) {
+  return layout == 2 ? iunet_conv3_v4_stats_parts(nd, Cout) : iunet_conv3_tiles(nd, N, D, H, W);
+}
 
 long long iunet_pack_conv3_elems(int Cout, int Cin, int taps, int mode) { return iunet_pack_conv3_size(Cout, Cin, taps, mode); }
 

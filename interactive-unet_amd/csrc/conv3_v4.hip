@@ -34,7 +34,7 @@ struct ConvV4Params {
   const float* bias;
   const float* in_scale;                      // optional [Cin] pair: the input is relu(in_scale * x + in_shift), applied by the
   const float* in_shift;                      // loader waves (training: BatchNorm + ReLU of the previous conv, never materialised)
-  float* stats;                               // [N * tiles][Cout][2] or null
+  float* stats;                               // [gridDim.x][Cout][2] or null: one row of BatchNorm partial sums per workgroup
   int N, D, H, W, Cin, Cout;
   int tilesZ, tilesY, tilesX;
   int bz, by, bx;                             // tiles per brick (bz * by * bx = workgroups per XCD and Cout tile)
@@ -83,7 +83,10 @@ __global__ __launch_bounds__(V4_NCW * 64 + (WS ? 256 : 512), 1) void conv3_v4_ke
   const int b_begin = (int)((long long)xcd * nbricks / 8), b_end = (int)((long long)(xcd + 1) * nbricks / 8);
   const int nchunk = p.Cin / (16 * S16);               // steps per tile
   const int nsteps = (b_end - b_begin) * nchunk;
-  if (nsteps <= 0) return;
+  if (nsteps <= 0) {                                   // no tile for this workgroup: its statistics row is zero
+    if (p.stats != nullptr && tid < 64) p.stats[((long long)blockIdx.x * p.Cout + cob * 32 + (tid >> 1)) * 2 + (tid & 1)] = 0.f;
+    return;
+  }
   const long long plane_stride = (long long)p.D * p.H * p.W * 8;
   const int off_red = OFF_W + (WS ? nchunk : 2) * WSTEP;    // 2 KB of scratch for the BatchNorm partial sums
   const u32x4* wsrc = (const u32x4*)p.wpk + (long long)cob * nchunk * (WSTEP / 16);
@@ -181,10 +184,9 @@ __global__ __launch_bounds__(V4_NCW * 64 + (WS ? 256 : 512), 1) void conv3_v4_ke
     for (int s = 0; s < nsteps; ++s) {
       if (s + 1 < nsteps && refill) commit(s + 1, r);
       if (s + 2 < nsteps && refill) load(s + 2, r);
-      const int chunk = s - (s / nchunk) * nchunk;
-      if (p.stats != nullptr && chunk == nchunk - 1) lds_barrier();      // mirrors the consumers' statistics barrier
       lds_barrier();
     }
+    if (p.stats != nullptr) lds_barrier();            // the consumers' final statistics reduction
     return;
   }
 
@@ -210,6 +212,7 @@ __global__ __launch_bounds__(V4_NCW * 64 + (WS ? 256 : 512), 1) void conv3_v4_ke
 #pragma unroll
     for (int n = 0; n < NI; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  float stat_acc = 0.f;      // BatchNorm partial sums over all tiles of this workgroup: lane (q, l15) holds value l15 = which * 8 + j
   lds_barrier();                                             // step 0 (and the resident weights) are in LDS
 
   for (int s = 0; s < nsteps; ++s) {
@@ -261,7 +264,7 @@ __global__ __launch_bounds__(V4_NCW * 64 + (WS ? 256 : 512), 1) void conv3_v4_ke
     if (chunk == nchunk - 1) {
       // ---- epilogue of this tile ----
       int n_img, z0, y0, x0;
-      const bool tile_ok = tile_origin(s / nchunk, n_img, z0, y0, x0);
+      tile_origin(s / nchunk, n_img, z0, y0, x0);
       T* yout = (T*)p.y + (long long)n_img * p.y_sstride;
       float s_sum[8], s_sq[8];
 #pragma unroll
@@ -290,27 +293,37 @@ __global__ __launch_bounds__(V4_NCW * 64 + (WS ? 256 : 512), 1) void conv3_v4_ke
         acc[1][n] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
       if (p.stats != nullptr) {
-        // partial BatchNorm sums of this tile: 16 x-lanes by shuffles, the 8 waves in wave order through LDS
-        float* red = (float*)(smem + off_red);                 // [consumer waves][4 q][8][2]
+        // this tile's 16 partial sums per 16-lane group, reduce-scattered over the x lanes (15 exchanges): lane l15 ends
+        // up with value l15 and adds it to its running total -- no barrier, no LDS, one register of state
+        float vals[16];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          float a = s_sum[j], b = s_sq[j];
+        for (int j = 0; j < 8; ++j) { vals[j] = s_sum[j]; vals[8 + j] = s_sq[j]; }
 #pragma unroll
-          for (int sh = 8; sh > 0; sh >>= 1) { a += __shfl_xor(a, sh); b += __shfl_xor(b, sh); }
-          if (l15 == 0) { red[((wave * 4 + q) * 8 + j) * 2] = a; red[((wave * 4 + q) * 8 + j) * 2 + 1] = b; }
+        for (int h = 8; h >= 1; h >>= 1) {
+          const bool up = (l15 & h) != 0;
+#pragma unroll
+          for (int i = 0; i < h; ++i) {
+            const float send = up ? vals[i] : vals[i + h], keep = up ? vals[i + h] : vals[i];
+            vals[i] = keep + __shfl_xor(send, h);
+          }
         }
-        lds_barrier();
-        if (tid < 64 && tile_ok) {
-          const int c = tid >> 1, which = tid & 1;             // c = 8 g + j
-          float sum = 0.f;
-#pragma unroll
-          for (int w = 0; w < NCW; ++w) sum += red[((w * 4 + (c >> 3)) * 8 + (c & 7)) * 2 + which];
-          const long long stile = (((long long)n_img * p.tilesZ + z0 / TZ) * p.tilesY + y0 / TY) * p.tilesX + x0 / TX;
-          p.stats[(stile * p.Cout + cob * 32 + c) * 2 + which] = sum;
-        }
+        stat_acc += vals[0];
       }
     }
     lds_barrier();                 // consumers are done with this step's buffers, the loaders have filled the others
+  }
+  if (p.stats != nullptr) {
+    // the consumer waves' totals meet in LDS (wave order: deterministic) and become this workgroup's statistics row
+    float* red = (float*)(smem + off_red);                     // [consumer waves][4 q][16]
+    red[(wave * 4 + q) * 16 + l15] = stat_acc;
+    lds_barrier();
+    if (tid < 64) {
+      const int c = tid >> 1, which = tid & 1;                 // c = 8 g + j
+      float sum = 0.f;
+#pragma unroll
+      for (int w = 0; w < NCW; ++w) sum += red[(w * 4 + (c >> 3)) * 16 + which * 8 + (c & 7)];
+      p.stats[((long long)blockIdx.x * p.Cout + cob * 32 + c) * 2 + which] = sum;
+    }
   }
 }
 
@@ -349,6 +362,13 @@ int launch_v4(ConvV4Params p, hipStream_t stream) {
 }
 
 }  // namespace
+
+// rows of BatchNorm partial sums a layout-2 launch writes: one per workgroup of a Cout tile
+int iunet_conv3_v4_stats_parts(int nd, int Cout) {
+  (void)nd;                                            // 2-D and 3-D bricks have the same number of slots
+  const int ncob = Cout / 32;
+  return 8 * (ncob == 1 ? 32 : ncob == 2 ? 16 : ncob <= 4 ? 8 : 4);
+}
 
 int iunet_conv3_v4_launch(int dtype, int nd, const void* x, long long x_sstride, void* y, long long y_sstride, const void* wpk,
                           const float* bias, float* stats, int N, int D, int H, int W, int Cin, int Cout, int epi,

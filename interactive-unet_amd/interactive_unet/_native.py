@@ -20,6 +20,7 @@ c_void_p, c_int, c_ll, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlon
 _SIGS = {
     'iunet_abi_version': [],
     'iunet_conv3_num_tiles': [c_int] * 5,
+    'iunet_conv3_stats_parts': [c_int] * 7,
     'iunet_dbg_conv3_ablate': [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     'iunet_pack_conv3': [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     'iunet_pack_first_conv': [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],

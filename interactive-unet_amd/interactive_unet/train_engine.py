@@ -166,7 +166,7 @@ class TrainEngine:
                     max_stats = max(max_stats, lib.iunet_conv3_num_tiles(self.dim, N, *d) * b * 2)
                     max_wslab = max(max_wslab, lib.iunet_first_conv_wgrad_blocks(self.dim, N, *d) * b * 112)
                 else:
-                    max_stats = max(max_stats, lib.iunet_conv3_num_tiles(self.dim, N, *d) * b * 2)
+                    max_stats = max(max_stats, max(lib.iunet_conv3_stats_parts(self.dim, N, *d, b, lay) for lay in (0, 2)) * b * 2)
                     max_wslab = max(max_wslab, lib.iunet_conv3_wgrad_slab_floats(self.dim, N, *d, a, b))
                 max_bn = max(max_bn, lib.iunet_bn_bwd_num_parts(N, v) * b * 2)
         for l in range(L):
@@ -217,7 +217,7 @@ class TrainEngine:
         else:
             pk, _ = self.pk[name]
             lay, w = pk.pick(self.dim, N, *d)
-            nparts = nv.lib().iunet_conv3_num_tiles(self.dim, N, *d)
+            nparts = nv.lib().iunet_conv3_stats_parts(self.dim, N, *d, co, lay)
             if x_act is None:
                 nv.call('iunet_conv3_fwd', self.dt, self.dim, x_ptr, x_ss, self._P(y), co * v, nv.ptr(w), None,
                         nv.ptr(stats), N, d[0], d[1], d[2], ci, co, 0, lay, s)

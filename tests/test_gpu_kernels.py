@@ -57,8 +57,8 @@ def run_conv3(nv, x, w, dtype, nd, scale=None, bias=None, epi=0, stats=False, mo
     bd = None if bias is None else bias.to(dev)
     st = None
     if stats:
-        nt = nv.lib().iunet_conv3_num_tiles(nd, N, D, H, W)
-        st = torch.zeros(nt * Co_p * 2, dtype=torch.float32, device=dev)
+        nt = nv.lib().iunet_conv3_stats_parts(nd, N, D, H, W, Co_p, layout)
+        st = torch.full((nt * Co_p * 2,), float('nan'), dtype=torch.float32, device=dev)     # every row must be written
     nv.call('iunet_conv3_fwd', nv.DTYPE_CODE[dtype], nd, nv.ptr(xb), Ci_p * vox, nv.ptr(y), Co_p * vox, nv.ptr(wpk),
             nv.ptr(bd), nv.ptr(st), N, D, H, W, Ci_p, Co_p, epi, layout, nv.stream())
     torch.cuda.synchronize()

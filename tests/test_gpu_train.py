@@ -357,7 +357,7 @@ def test_conv3_fwd_and_wgrad_with_fused_input_activation(nv, cin):
     nv.call('iunet_bn_relu_fwd', dt, nv.ptr(yb), cin * vox, nv.ptr(z), cin * vox, nv.ptr(scale), nv.ptr(shift), cin, N, vox, s)
     wpk = torch.empty(nv.pack_conv3_elems(cout, cin, 27, 2), dtype=T, device='cuda')
     nv.call('iunet_pack_conv3', dt, nv.ptr(w), None, nv.ptr(wpk), cout, cin, 27, 2, s)
-    nt = nv.lib().iunet_conv3_num_tiles(3, N, D, H, W)
+    nt = nv.lib().iunet_conv3_stats_parts(3, N, D, H, W, cout, 2)
     outs, stats = [], []
     for fused in (False, True):
         out = torch.full((N * cout * vox,), float('nan'), dtype=T, device='cuda')
