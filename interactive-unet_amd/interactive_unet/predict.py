@@ -101,6 +101,14 @@ class VolumeAccumulator:
         w = gaussian_3d(self.S, sigma=0.125) if window is None else window      # predict.py:153
         self.window = torch.from_numpy(np.ascontiguousarray(w, dtype=np.float32)).to(self.device)
         self.block_probs = torch.empty((self.S,) * 3 + (self.C,), dtype=torch.float32, device=self.device)
+        self._batch = None
+
+    def batch_buffers(self, nb):
+        """uint8 [nb, S, S, S] blocks and fp32 [nb, S, S, S, C] probabilities for a batched 3-D forward."""
+        if self._batch is None or self._batch[0].shape[0] < nb:
+            self._batch = (torch.empty((nb,) + (self.S,) * 3, dtype=torch.uint8, device=self.device),
+                           torch.empty((nb,) + (self.S,) * 3 + (self.C,), dtype=torch.float32, device=self.device))
+        return self._batch
 
     def reset(self):
         self.pred.zero_()
@@ -130,6 +138,25 @@ def gather_block(volume_dev, padded_coords, S, out=None):
 
 
 # --------------------------------------------------------------------------- block prediction
+BLOCK_BATCH = 2      # 3-D blocks per forward: the deep levels (16^3, 32^3 per block) fill the chip better, half the launches (4: no further gain)
+
+
+def predict_blocks_3d(eng, acc, volume, blocks, padded, local, lo, hi, batch=None):
+    """Blocks lo..hi-1 of the flat list through the 3-D net, `batch` at a time (gather -> forward + softmax -> blend);
+    the blends happen in list order, so the accumulators are those of the one-block-at-a-time loop."""
+    S, C = acc.S, acc.C
+    B = max(1, int(batch or BLOCK_BATCH))
+    blk, probs = acc.batch_buffers(B)
+    for i in range(lo, hi, B):
+        nb = min(B, hi - i)
+        for j in range(nb):
+            gather_block(volume, padded[i + j], S, out=blk[j])
+        eng.infer(blk, (S ** 3, S ** 3, S * S, S, 1), nb, S, S, S, probs=probs,
+                  out_strides=(S ** 3 * C, 1, S * S * C, S * C, C))
+        for j in range(nb):
+            acc.blend(blocks[i + j], local[i + j], probs=probs[j])
+
+
 def predict_block_device(model, block, out, num_classes=2, batch_size=None, axes=(0, 1, 2)):
     """2.5-D prediction of one S^3 block entirely on the device (predict.py:79-112): for each
     axis the 2-D net runs over the slices along that axis -- strided views of the same block,
@@ -251,15 +278,14 @@ def predict_volume_array(model, volume, input_size=256, num_classes=2, overlap=0
     bc, pbc, lbc = get_block_coordinates(np.array(V), input_size=S, overlap=overlap)
     lo, hi = (0, len(pbc)) if block_range is None else block_range
     eng = model.engine('eval')
-    blk = torch.empty((S, S, S), dtype=torch.uint8, device=dev)
-    for i in range(lo, hi):
-        gather_block(vol, pbc[i], S, out=blk)
-        if eng.dim == 2:
+    if eng.dim == 3:
+        predict_blocks_3d(eng, acc, vol, bc, pbc, lbc, lo, hi)
+    else:
+        blk = torch.empty((S, S, S), dtype=torch.uint8, device=dev)
+        for i in range(lo, hi):
+            gather_block(vol, pbc[i], S, out=blk)
             predict_block_device(model, blk, acc.block_probs, C, batch_size, axes)
-        else:
-            eng.infer(blk, (S ** 3, S ** 3, S * S, S, 1), 1, S, S, S, probs=acc.block_probs,
-                      out_strides=(0, 1, S * S * C, S * C, C))
-        acc.blend(bc[i], lbc[i])
+            acc.blend(bc[i], lbc[i])
     return acc.finalize() if finalize else acc
 
 

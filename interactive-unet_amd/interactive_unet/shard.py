@@ -75,6 +75,14 @@ class NativeOps:
                            out_strides=(0, 1, S * S * C, S * C, C))
         acc.blend(block, local)
 
+    def predict_run(self, acc, volume, bc, pbc, lbc, lo, hi):
+        """Blocks lo..hi-1 of the flat list (3-D net: batched forward; 2-D net: one block at a time)."""
+        if self.eng.dim == 3:
+            P.predict_blocks_3d(self.eng, acc, volume, bc, pbc, lbc, lo, hi)
+        else:
+            for i in range(lo, hi):
+                self.predict_into(acc, volume, bc[i], pbc[i], lbc[i])
+
     def finalize_slab(self, acc, z0, z1):
         """uint8(255 * pred / max(weight, 1e-3)) for planes [z0, z1) -> uint8 [z1-z0, Y, X, C]."""
         from . import _native as nv
@@ -110,8 +118,11 @@ def predict_volume_sharded(ops, my_slab, volume_shape, input_size, overlap=0.25,
     runs = partition_blocks(len(pbc), world)
     lo, hi = runs[rank]
     acc = ops.make_accumulator(V)
-    for i in range(lo, hi):
-        ops.predict_into(acc, volume, bc[i], pbc[i], lbc[i])
+    if hasattr(ops, 'predict_run'):
+        ops.predict_run(acc, volume, bc, pbc, lbc, lo, hi)
+    else:
+        for i in range(lo, hi):
+            ops.predict_into(acc, volume, bc[i], pbc[i], lbc[i])
     # ---- output exchange: footprint pieces to their slab owners, point to point ----
     sent = 0
     if world > 1:
