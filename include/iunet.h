@@ -128,6 +128,10 @@ int iunet_bn_finalize(const void* slab, int nparts, int C, double count, const v
                       void* mean, void* invstd, void* stream);
 int iunet_bn_relu_fwd(int dtype, const void* y, long long y_ss, void* z, long long z_ss, const void* scale,
                       const void* shift, int C, int N, long long vox, void* stream);
+/* the same plus the 2^d max-pool of z in one pass (encoder stages); (Do, Ho, Wo) is the pooled grid. */
+int iunet_bn_relu_pool_fwd(int dtype, int nd, const void* y, long long y_ss, void* z, long long z_ss, void* pooled,
+                           long long p_ss, const void* scale, const void* shift, int C, int N, int Do, int Ho, int Wo,
+                           void* stream);
 /* backward of z = relu(bn(y)): dy, dgamma, dbeta from dz, y (and z; z may be NULL: the ReLU mask is then
  * recomputed from y with scale / shift, one tensor read less per pass).  slab: iunet_bn_bwd_num_parts*C*2
  * floats, coef: 3*C floats of scratch. */

@@ -97,6 +97,52 @@ __global__ __launch_bounds__(256) void bn_relu_fwd_kernel(const T* __restrict__ 
   }
 }
 
+// z = relu(scale[c] * y + shift[c]) AND its 2^d max-pool in one pass (encoder stages: the pool would re-read z right
+// away).  One thread per pooled voxel and channel plane: 2^d reads of y, 2^d writes of z, one write of the pooled value.
+template <typename T, int ND>
+__global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const T* __restrict__ y, long long y_ss, T* __restrict__ z,
+                                                               long long z_ss, T* __restrict__ pooled, long long p_ss,
+                                                               const float* __restrict__ scale, const float* __restrict__ shift,
+                                                               int Do, int Ho, int Wo) {
+  const long long ovox = (long long)Do * Ho * Wo;
+  const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (r >= ovox) return;
+  const int pl = blockIdx.y, n = blockIdx.z;
+  float sc[8], sh[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { sc[j] = scale[pl * 8 + j]; sh[j] = shift[pl * 8 + j]; }
+  const int ox = (int)(r % Wo), oy = (int)((r / Wo) % Ho), oz = (int)(r / ((long long)Wo * Ho));
+  const int Di = ND == 3 ? Do * 2 : 1, Hi = Ho * 2, Wi = Wo * 2;
+  const long long ipl = (long long)pl * Di * Hi * Wi * 8;
+  constexpr int NW = ND == 3 ? 8 : 4;
+  V8T<T> win[NW];
+  long long off[NW];
+#pragma unroll
+  for (int s = 0; s < NW; ++s) {
+    const int a = ND == 3 ? (s >> 2) : 0, b = (s >> 1) & 1, c = s & 1;
+    const int zz = ND == 3 ? oz * 2 + a : 0;
+    off[s] = ipl + (((long long)zz * Hi + oy * 2 + b) * Wi + ox * 2 + c) * 8;
+    win[s] = *(const V8T<T>*)(y + n * y_ss + off[s]);
+  }
+  float m[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) m[j] = -INFINITY;
+#pragma unroll
+  for (int s = 0; s < NW; ++s) {
+    V8T<T> o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      o[j] = from_f32<T>(fmaxf(fmaf(sc[j], to_f32<T>(win[s][j]), sh[j]), 0.f));     // = bn_relu_fwd_kernel
+      m[j] = fmaxf(m[j], to_f32<T>(o[j]));                                            // = maxpool_kernel on the stored value
+    }
+    *(V8T<T>*)(z + n * z_ss + off[s]) = o;
+  }
+  V8T<T> o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = from_f32<T>(m[j]);
+  *(V8T<T>*)(pooled + n * p_ss + (long long)pl * ovox * 8 + r * 8) = o;
+}
+
 // BN+ReLU backward, pass 1: per-channel s1 = sum(dyh), s2 = sum(dyh * xhat), dyh = dz * (z > 0).
 // grid (chunks, planes, N); slab [(n*chunks + chunk)][C][2]
 template <typename T>
@@ -582,6 +628,22 @@ int iunet_bn_relu_fwd(int dtype, const void* y, long long y_ss, void* z, long lo
   dim3 grid((unsigned)((vox + 511) / 512), C / 8, N);
   if (dtype == 0) hipLaunchKernelGGL(bn_relu_fwd_kernel<f16>, grid, dim3(256), 0, (hipStream_t)stream, (const f16*)y, y_ss, (f16*)z, z_ss, (const float*)scale, (const float*)shift, C / 8, vox);
   else hipLaunchKernelGGL(bn_relu_fwd_kernel<bf16>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)y, y_ss, (bf16*)z, z_ss, (const float*)scale, (const float*)shift, C / 8, vox);
+  IUNET_CHECK_HIP(hipGetLastError());
+  return IUNET_OK;
+}
+
+// bn_relu_fwd and the 2^d max-pool of its output in one pass; (Do, Ho, Wo) = pooled grid, y / z on the 2x grid
+int iunet_bn_relu_pool_fwd(int dtype, int nd, const void* y, long long y_ss, void* z, long long z_ss, void* pooled,
+                           long long p_ss, const void* scale, const void* shift, int C, int N, int Do, int Ho, int Wo,
+                           void* stream) {
+  DT_OK(dtype);
+  IUNET_REQUIRE(y && z && pooled && scale && shift, "bn_relu_pool_fwd: null pointer");
+  IUNET_REQUIRE(nd == 2 || nd == 3, "bn_relu_pool_fwd: nd must be 2 or 3");
+  const long long ovox = (long long)Do * Ho * Wo;
+  dim3 grid((unsigned)((ovox + 255) / 256), C / 8, N);
+#define BRP(TT, NDV) hipLaunchKernelGGL((bn_relu_pool_fwd_kernel<TT, NDV>), grid, dim3(256), 0, (hipStream_t)stream, (const TT*)y, y_ss, (TT*)z, z_ss, (TT*)pooled, p_ss, (const float*)scale, (const float*)shift, Do, Ho, Wo)
+  if (dtype == 0) { if (nd == 3) BRP(f16, 3); else BRP(f16, 2); } else { if (nd == 3) BRP(bf16, 3); else BRP(bf16, 2); }
+#undef BRP
   IUNET_CHECK_HIP(hipGetLastError());
   return IUNET_OK;
 }

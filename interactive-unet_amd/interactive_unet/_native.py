@@ -50,6 +50,8 @@ _SIGS = {
     'iunet_bn_finalize': [c_void_p, c_int, c_int, ctypes.c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                           c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     'iunet_bn_relu_fwd': [c_int, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_void_p, c_int, c_int, c_ll, c_void_p],
+    'iunet_bn_relu_pool_fwd': [c_int, c_int, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_void_p,
+                               c_int, c_int, c_int, c_int, c_int, c_void_p],
     'iunet_bn_bwd_num_parts': [c_int, c_ll],
     'iunet_bn_relu_bwd': [c_int, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_void_p,
                           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_ll, c_void_p],

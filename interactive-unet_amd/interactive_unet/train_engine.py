@@ -199,7 +199,8 @@ class TrainEngine:
         return ctypes.c_void_p(t.data_ptr() + off_elems * self.es)
 
     # ------------------------------------------------------------------ forward
-    def _stage_conv_fwd(self, ws, name, x_ptr, x_ss, ci, co, l, z_ptr, z_ss, N, x_raw=None, training=True, x_act=None):
+    def _stage_conv_fwd(self, ws, name, x_ptr, x_ss, ci, co, l, z_ptr, z_ss, N, x_raw=None, training=True, x_act=None,
+                        pool=None):
         """conv -> raw output y + BatchNorm batch statistics -> scale / shift; z = relu(bn(y)) is written unless z_ptr
         is None (the consumer applies it in its loader waves).  x_act: name of the conv whose y is this conv's input
         with its BatchNorm + ReLU still to be applied (iunet_conv3_fwd_act)."""
@@ -231,7 +232,11 @@ class TrainEngine:
                 nv.ptr(self.p(bn + '.running_mean')), nv.ptr(self.p(bn + '.running_var')), BN_MOMENTUM, BN_EPS,
                 nv.ptr(ws['scale.' + name]), nv.ptr(ws['shift.' + name]), nv.ptr(ws['mean.' + name]),
                 nv.ptr(ws['invstd.' + name]), s)
-        if z_ptr is not None:
+        if z_ptr is not None and pool is not None:       # encoder stage: activation and its max-pool in one pass
+            p_ptr, p_ss, do = pool
+            nv.call('iunet_bn_relu_pool_fwd', self.dt, self.dim, self._P(y), co * v, z_ptr, z_ss, p_ptr, p_ss,
+                    nv.ptr(ws['scale.' + name]), nv.ptr(ws['shift.' + name]), co, N, do[0], do[1], do[2], s)
+        elif z_ptr is not None:
             nv.call('iunet_bn_relu_fwd', self.dt, self._P(y), co * v, z_ptr, z_ss, nv.ptr(ws['scale.' + name]),
                     nv.ptr(ws['shift.' + name]), co, N, v, s)
 
@@ -257,11 +262,10 @@ class TrainEngine:
             else:
                 self._stage_conv_fwd(ws, f'enc{l}.conv1', self._P(ws[f'pin{l}']), ci * v, ci, ch[l], l, z1p, ch[l] * v, N)
             if l < L - 1:
-                self._stage_conv_fwd(ws, f'enc{l}.conv2', x2, ch[l] * v, ch[l], ch[l], l,
-                                     self._P(ws[f'cat{l}']), 2 * ch[l] * v, N, x_act=act)
                 do = dims[l + 1]
-                nv.call('iunet_maxpool_fwd', self.dt, self.dim, self._P(ws[f'cat{l}']), 2 * ch[l] * v,
-                        self._P(ws[f'pin{l + 1}']), ch[l] * _vox(do), ch[l], N, do[0], do[1], do[2], s)
+                self._stage_conv_fwd(ws, f'enc{l}.conv2', x2, ch[l] * v, ch[l], ch[l], l,
+                                     self._P(ws[f'cat{l}']), 2 * ch[l] * v, N, x_act=act,
+                                     pool=(self._P(ws[f'pin{l + 1}']), ch[l] * _vox(do), do))
             else:
                 self._stage_conv_fwd(ws, f'enc{l}.conv2', x2, ch[l] * v, ch[l], ch[l], l,
                                      self._P(ws[f'z.enc{l}.conv2']), ch[l] * v, N, x_act=act)

@@ -387,3 +387,28 @@ def test_conv3_fwd_and_wgrad_with_fused_input_activation(nv, cin):
         dws.append(dW)
     torch.cuda.synchronize()
     assert torch.equal(dws[0], dws[1])
+
+
+@pytest.mark.parametrize('nd', [2, 3])
+def test_bn_relu_pool_fwd_equals_two_passes(nv, nd):
+    """iunet_bn_relu_pool_fwd == iunet_bn_relu_fwd followed by iunet_maxpool_fwd, bit for bit (both outputs)."""
+    g = torch.Generator().manual_seed(29)
+    T, dt, dev = torch.bfloat16, 1, 'cuda'
+    N, C = 2, 32
+    shape = (12, 40) if nd == 2 else (4, 6, 24)
+    D, H, W = shape if nd == 3 else (1,) + shape
+    vox = D * H * W
+    do = (D // 2 if nd == 3 else 1, H // 2, W // 2)
+    ovox = do[0] * do[1] * do[2]
+    y = blocked(torch.randn((N, C) + shape, generator=g), T).to(dev)
+    scale, shift = (0.5 + torch.rand(C, generator=g)).to(dev), (0.3 * torch.randn(C, generator=g)).to(dev)
+    s = nv.stream()
+    z1, p1 = torch.zeros_like(y), torch.zeros(N * C * ovox, dtype=T, device=dev)
+    nv.call('iunet_bn_relu_fwd', dt, nv.ptr(y), C * vox, nv.ptr(z1), C * vox, nv.ptr(scale), nv.ptr(shift), C, N, vox, s)
+    nv.call('iunet_maxpool_fwd', dt, nd, nv.ptr(z1), C * vox, nv.ptr(p1), C * ovox, C, N, do[0], do[1], do[2], s)
+    z2, p2 = torch.zeros_like(y), torch.zeros_like(p1)
+    nv.call('iunet_bn_relu_pool_fwd', dt, nd, nv.ptr(y), C * vox, nv.ptr(z2), C * vox, nv.ptr(p2), C * ovox,
+            nv.ptr(scale), nv.ptr(shift), C, N, do[0], do[1], do[2], s)
+    torch.cuda.synchronize()
+    assert torch.equal(z1.view(torch.int16), z2.view(torch.int16))
+    assert torch.equal(p1.view(torch.int16), p2.view(torch.int16))
