@@ -140,6 +140,13 @@ int iunet_bn_relu_bwd(int dtype, const void* dz, long long dz_ss, const void* z,
                       long long y_ss, void* dy, long long dy_ss, const void* mean, const void* invstd, const void* gamma,
                       const void* scale, const void* shift, void* dgamma, void* dbeta, void* slab, void* coef, int C, int N,
                       long long vox, void* stream);
+/* iunet_maxpool_bwd (add_skip) + iunet_bn_relu_bwd of an encoder stage's second conv without materialising the gradient of
+ * the stage output: dz = dskip + route(dpool), routed to the first maximum of each 2^d window of relu(bn(y)) (recomputed).
+ * (Do, Ho, Wo) = pooled grid; dskip, y, dy on the 2x grid; slab as for iunet_bn_relu_bwd on the 2x grid. */
+int iunet_bn_relu_pool_bwd(int dtype, int nd, const void* dskip, long long ds_ss, const void* dpool, long long dp_ss,
+                           const void* y, long long y_ss, void* dy, long long dy_ss, const void* mean, const void* invstd,
+                           const void* gamma, const void* scale, const void* shift, void* dgamma, void* dbeta, void* slab,
+                           void* coef, int C, int N, int Do, int Ho, int Wo, void* stream);
 /* dz = (add_skip ? dz : 0) + max-pool backward of dpool (first maximum gets the gradient), in place. */
 int iunet_maxpool_bwd(int dtype, int nd, const void* z, long long z_ss, const void* dpool, long long dp_ss, void* dz,
                       long long dz_ss, int add_skip, int C, int N, int Do, int Ho, int Wo, void* stream);

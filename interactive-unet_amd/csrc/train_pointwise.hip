@@ -188,6 +188,81 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
   block_reduce_store<16>(vals, red, slab + (part * C + pl * 8) * 2);
 }
 
+// BatchNorm + ReLU backward of an encoder stage's second conv with the max-pool backward folded in: the gradient of the
+// stage output is dz = dskip + route(dpool) (dskip = the decoder's gradient of the skip connection, route = to the first
+// maximum of each 2^d window of z = relu(bn(y)), recomputed from y) and is never written.  One thread per pooled voxel
+// and channel plane.  PASS 1: per-channel sums (as bn_bwd_reduce_kernel), PASS 2: dy (as bn_bwd_apply_kernel).
+// Every value is rounded where the three-kernel sequence maxpool_bwd -> reduce -> apply rounds it.
+template <typename T, int ND, int PASS>
+__global__ __launch_bounds__(256) void bn_pool_bwd_kernel(const T* __restrict__ dskip, long long ds_ss,
+                                                          const T* __restrict__ dpool, long long dp_ss,
+                                                          const T* __restrict__ y, long long y_ss, T* __restrict__ dy,
+                                                          long long dy_ss, const float* __restrict__ mean,
+                                                          const float* __restrict__ invstd, const float* __restrict__ coef,
+                                                          const float* __restrict__ scale, const float* __restrict__ shift,
+                                                          int C, int Do, int Ho, int Wo, int per_block, float* __restrict__ slab) {
+  constexpr int NW = ND == 3 ? 8 : 4;
+  const int pl = blockIdx.y, n = blockIdx.z;
+  const long long ovox = (long long)Do * Ho * Wo;
+  const int Di = ND == 3 ? Do * 2 : 1, Hi = Ho * 2, Wi = Wo * 2;
+  const long long ipl = (long long)pl * Di * Hi * Wi * 8;
+  float mu[8], is[8], sc[8], sh[8], ca[8], c1[8], c2[8], s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = pl * 8 + j;
+    mu[j] = mean[c]; is[j] = invstd[c]; sc[j] = scale[c]; sh[j] = shift[c]; s1[j] = 0.f; s2[j] = 0.f;
+    if (PASS == 2) { ca[j] = coef[c * 3]; c1[j] = coef[c * 3 + 1]; c2[j] = coef[c * 3 + 2]; }
+  }
+  const long long r0 = (long long)blockIdx.x * per_block, r1 = min(r0 + per_block, ovox);
+  for (long long r = r0 + threadIdx.x; r < r1; r += 256) {
+    const int ox = (int)(r % Wo), oy = (int)((r / Wo) % Ho), oz = (int)(r / ((long long)Wo * Ho));
+    V8T<T> yy[NW], gs[NW];
+    long long off[NW];
+#pragma unroll
+    for (int s = 0; s < NW; ++s) {
+      const int a = ND == 3 ? (s >> 2) : 0, b = (s >> 1) & 1, c = s & 1;
+      const int zz = ND == 3 ? oz * 2 + a : 0;
+      off[s] = ipl + (((long long)zz * Hi + oy * 2 + b) * Wi + ox * 2 + c) * 8;
+      yy[s] = *(const V8T<T>*)(y + n * y_ss + off[s]);
+      gs[s] = *(const V8T<T>*)(dskip + n * ds_ss + off[s]);
+    }
+    const V8T<T> gp = *(const V8T<T>*)(dpool + n * dp_ss + (long long)pl * ovox * 8 + r * 8);
+    int best[8];
+    float zv[NW][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float m = 0.f;
+#pragma unroll
+      for (int s = 0; s < NW; ++s) {
+        zv[s][j] = to_f32<T>(from_f32<T>(fmaxf(fmaf(sc[j], to_f32<T>(yy[s][j]), sh[j]), 0.f)));     // z as bn_relu_fwd stored it
+        if (s == 0) { m = zv[0][j]; best[j] = 0; } else if (zv[s][j] > m) { m = zv[s][j]; best[j] = s; }   // first maximum
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < NW; ++s) {
+      V8T<T> o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        // dz as maxpool_bwd_kernel (add_skip) stored it, then the ReLU mask
+        const float dz = to_f32<T>(from_f32<T>(to_f32<T>(gs[s][j]) + (best[j] == s ? to_f32<T>(gp[j]) : 0.f)));
+        const float d = zv[s][j] > 0.f ? dz : 0.f;
+        const float xh = (to_f32<T>(yy[s][j]) - mu[j]) * is[j];
+        if (PASS == 1) { s1[j] += d; s2[j] += d * xh; }
+        else o[j] = from_f32<T>(ca[j] * (d - c1[j] - xh * c2[j]));
+      }
+      if (PASS == 2) *(V8T<T>*)(dy + n * dy_ss + off[s]) = o;
+    }
+  }
+  if (PASS == 1) {
+    __shared__ float red[4 * 16];
+    const long long part = (long long)n * gridDim.x + blockIdx.x;
+    float vals[16];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { vals[2 * j] = s1[j]; vals[2 * j + 1] = s2[j]; }
+    block_reduce_store<16>(vals, red, slab + (part * C + pl * 8) * 2);
+  }
+}
+
 // pass 1b: dgamma = s2, dbeta = s1 (times grad_unscale), coefficients for pass 2
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ slab, int nparts, int C, double count,
                                                               const float* __restrict__ gamma, const float* __restrict__ invstd,
@@ -671,6 +746,35 @@ int iunet_bn_relu_bwd(int dtype, const void* dz, long long dz_ss, const void* z,
   dim3 g2((unsigned)((vox + 511) / 512), C / 8, N);
   if (dtype == 0) hipLaunchKernelGGL(bn_bwd_apply_kernel<f16>, g2, dim3(256), 0, (hipStream_t)stream, (const f16*)dz, dz_ss, (const f16*)z, z_ss, (const f16*)y, y_ss, (f16*)dy, dy_ss, (const float*)mean, (const float*)invstd, (const float*)coef, (const float*)scale, (const float*)shift, C / 8, vox);
   else hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16>, g2, dim3(256), 0, (hipStream_t)stream, (const bf16*)dz, dz_ss, (const bf16*)z, z_ss, (const bf16*)y, y_ss, (bf16*)dy, dy_ss, (const float*)mean, (const float*)invstd, (const float*)coef, (const float*)scale, (const float*)shift, C / 8, vox);
+  IUNET_CHECK_HIP(hipGetLastError());
+  return IUNET_OK;
+}
+
+// iunet_maxpool_bwd (add_skip) + iunet_bn_relu_bwd of an encoder stage's second conv in two passes instead of three: dskip is
+// the decoder's gradient of the skip connection (2x grid), dpool the gradient of the pooled tensor ((Do, Ho, Wo) grid);
+// slab: iunet_bn_bwd_num_parts(N, 2^nd * Do*Ho*Wo) * C * 2 floats.
+int iunet_bn_relu_pool_bwd(int dtype, int nd, const void* dskip, long long ds_ss, const void* dpool, long long dp_ss,
+                           const void* y, long long y_ss, void* dy, long long dy_ss, const void* mean, const void* invstd,
+                           const void* gamma, const void* scale, const void* shift, void* dgamma, void* dbeta, void* slab,
+                           void* coef, int C, int N, int Do, int Ho, int Wo, void* stream) {
+  DT_OK(dtype);
+  IUNET_REQUIRE(dskip && dpool && y && dy && slab && coef && scale && shift, "bn_relu_pool_bwd: null pointer");
+  IUNET_REQUIRE(nd == 2 || nd == 3, "bn_relu_pool_bwd: nd must be 2 or 3");
+  const long long ovox = (long long)Do * Ho * Wo, vox = ovox * (nd == 3 ? 8 : 4);
+  const int per_block = BN_BWD_PER_BLOCK / (nd == 3 ? 8 : 4);              // pooled voxels: the part count of bn_relu_bwd
+  const int chunks = (int)((ovox + per_block - 1) / per_block);
+  IUNET_REQUIRE(chunks * N <= iunet_bn_bwd_num_parts(N, vox), "bn_relu_pool_bwd: slab part count");
+  dim3 g1(chunks, C / 8, N), g2((unsigned)((ovox + 255) / 256), C / 8, N);
+#define BPB(TT, NDV, PASSV, GRID, PB) hipLaunchKernelGGL((bn_pool_bwd_kernel<TT, NDV, PASSV>), GRID, dim3(256), 0, (hipStream_t)stream, \
+    (const TT*)dskip, ds_ss, (const TT*)dpool, dp_ss, (const TT*)y, y_ss, (TT*)dy, dy_ss, (const float*)mean, (const float*)invstd, \
+    (const float*)coef, (const float*)scale, (const float*)shift, C, Do, Ho, Wo, PB, (float*)slab)
+  if (dtype == 0) { if (nd == 3) BPB(f16, 3, 1, g1, per_block); else BPB(f16, 2, 1, g1, per_block); }
+  else { if (nd == 3) BPB(bf16, 3, 1, g1, per_block); else BPB(bf16, 2, 1, g1, per_block); }
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, (const float*)slab, chunks * N, C,
+                     (double)N * (double)vox, (const float*)gamma, (const float*)invstd, (float*)dgamma, (float*)dbeta, (float*)coef);
+  if (dtype == 0) { if (nd == 3) BPB(f16, 3, 2, g2, 256); else BPB(f16, 2, 2, g2, 256); }
+  else { if (nd == 3) BPB(bf16, 3, 2, g2, 256); else BPB(bf16, 2, 2, g2, 256); }
+#undef BPB
   IUNET_CHECK_HIP(hipGetLastError());
   return IUNET_OK;
 }

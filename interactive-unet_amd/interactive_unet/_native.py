@@ -55,6 +55,9 @@ _SIGS = {
     'iunet_bn_bwd_num_parts': [c_int, c_ll],
     'iunet_bn_relu_bwd': [c_int, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_void_p,
                           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_ll, c_void_p],
+    'iunet_bn_relu_pool_bwd': [c_int, c_int, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_void_p,
+                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                               c_int, c_int, c_void_p],
     'iunet_maxpool_bwd': [c_int, c_int, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_ll, c_int, c_int, c_int, c_int,
                           c_int, c_int, c_void_p],
     'iunet_head_loss_num_parts': [c_int, c_ll],

@@ -296,18 +296,27 @@ class TrainEngine:
 
     # ------------------------------------------------------------------ backward
     def _stage_conv_bwd(self, ws, name, dz_ptr, dz_ss, z_ptr, z_ss, x_ptr, x_ss, ci, co, l, dx_ptr, dx_ss, N,
-                        x_raw=None, x_act=None):
+                        x_raw=None, x_act=None, pool_bwd=None):
         d = ws['dims'][l]
         v = _vox(d)
         s = nv.stream()
         bn = name.replace('conv', 'bn')
         dy = ws['dy']
-        # z is not passed: the ReLU mask is recomputed from y (saves one tensor read in each of the two passes)
-        nv.call('iunet_bn_relu_bwd', self.dt, dz_ptr, dz_ss, None, z_ss, self._P(ws['y.' + name]), co * v,
-                self._P(dy), co * v, nv.ptr(ws['mean.' + name]), nv.ptr(ws['invstd.' + name]),
-                nv.ptr(self.p(bn + '.weight')), nv.ptr(ws['scale.' + name]), nv.ptr(ws['shift.' + name]),
-                nv.ptr(self.g(bn + '.weight')), nv.ptr(self.g(bn + '.bias')),
-                nv.ptr(ws['bnslab']), nv.ptr(ws['bncoef']), co, N, v, s)
+        if pool_bwd is not None:
+            # encoder stage: dz = skip gradient (dz_ptr) + max-pool backward of dpool, formed on the fly in both passes
+            dp_ptr, dp_ss, do = pool_bwd
+            nv.call('iunet_bn_relu_pool_bwd', self.dt, self.dim, dz_ptr, dz_ss, dp_ptr, dp_ss, self._P(ws['y.' + name]), co * v,
+                    self._P(dy), co * v, nv.ptr(ws['mean.' + name]), nv.ptr(ws['invstd.' + name]),
+                    nv.ptr(self.p(bn + '.weight')), nv.ptr(ws['scale.' + name]), nv.ptr(ws['shift.' + name]),
+                    nv.ptr(self.g(bn + '.weight')), nv.ptr(self.g(bn + '.bias')),
+                    nv.ptr(ws['bnslab']), nv.ptr(ws['bncoef']), co, N, do[0], do[1], do[2], s)
+        else:
+            # z is not passed: the ReLU mask is recomputed from y (saves one tensor read in each of the two passes)
+            nv.call('iunet_bn_relu_bwd', self.dt, dz_ptr, dz_ss, None, z_ss, self._P(ws['y.' + name]), co * v,
+                    self._P(dy), co * v, nv.ptr(ws['mean.' + name]), nv.ptr(ws['invstd.' + name]),
+                    nv.ptr(self.p(bn + '.weight')), nv.ptr(ws['scale.' + name]), nv.ptr(ws['shift.' + name]),
+                    nv.ptr(self.g(bn + '.weight')), nv.ptr(self.g(bn + '.bias')),
+                    nv.ptr(ws['bnslab']), nv.ptr(ws['bncoef']), co, N, v, s)
         gw = self.g(name + '.weight')
         if name == 'enc0.conv1':
             x, xs = x_raw
@@ -367,19 +376,18 @@ class TrainEngine:
         for l in range(L - 1, -1, -1):
             v = _vox(dims[l])
             z1, dz1 = ws[f'z.enc{l}.conv1'], ws[f'dz.enc{l}.conv1']
+            pool_bwd = None
             if l == L - 1:
                 dz2_ptr, dz2_ss = self._P(ws[f'dz.enc{l}.conv2']), ch[l] * v
                 z2_ptr, z2_ss = self._P(ws[f'z.enc{l}.conv2']), ch[l] * v
             else:
                 do = dims[l + 1]
-                nv.call('iunet_maxpool_bwd', self.dt, self.dim, self._P(ws[f'cat{l}']), 2 * ch[l] * v,
-                        self._P(ws[f'dpin{l + 1}']), ch[l] * _vox(do), self._P(ws[f'dcat{l}']), 2 * ch[l] * v, 1,
-                        ch[l], N, do[0], do[1], do[2], s)
+                pool_bwd = (self._P(ws[f'dpin{l + 1}']), ch[l] * _vox(do), do)      # folded into the BatchNorm backward below
                 dz2_ptr, dz2_ss = self._P(ws[f'dcat{l}']), 2 * ch[l] * v
                 z2_ptr, z2_ss = self._P(ws[f'cat{l}']), 2 * ch[l] * v
             x2, act, _ = self._conv2_input(ws, f'enc{l}', l, N)
             self._stage_conv_bwd(ws, f'enc{l}.conv2', dz2_ptr, dz2_ss, z2_ptr, z2_ss, x2, ch[l] * v, ch[l],
-                                 ch[l], l, self._P(dz1), ch[l] * v, N, x_act=act)
+                                 ch[l], l, self._P(dz1), ch[l] * v, N, x_act=act, pool_bwd=pool_bwd)
             if l == 0:
                 self._stage_conv_bwd(ws, 'enc0.conv1', self._P(dz1), ch[0] * v, self._P(z1), ch[0] * v, None, 0,
                                      self.cin, ch[0], 0, None, 0, N, x_raw=(x, x_strides))

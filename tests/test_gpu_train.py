@@ -412,3 +412,50 @@ def test_bn_relu_pool_fwd_equals_two_passes(nv, nd):
     torch.cuda.synchronize()
     assert torch.equal(z1.view(torch.int16), z2.view(torch.int16))
     assert torch.equal(p1.view(torch.int16), p2.view(torch.int16))
+
+
+@pytest.mark.parametrize('nd', [2, 3])
+def test_bn_relu_pool_bwd_equals_three_kernels(nv, nd):
+    """iunet_bn_relu_pool_bwd == iunet_maxpool_bwd (add_skip) -> iunet_bn_relu_bwd: dy bit for bit, dgamma / dbeta to fp32
+    summation order."""
+    g = torch.Generator().manual_seed(31)
+    T, dt, dev = torch.bfloat16, 1, 'cuda'
+    N, C = 2, 32
+    shape = (12, 40) if nd == 2 else (4, 6, 24)
+    D, H, W = shape if nd == 3 else (1,) + shape
+    vox = D * H * W
+    do = (D // 2 if nd == 3 else 1, H // 2, W // 2)
+    ovox = do[0] * do[1] * do[2]
+    y = blocked(torch.randn((N, C) + shape, generator=g), T).to(dev)
+    dskip = blocked(torch.randn((N, C) + shape, generator=g), T).to(dev)
+    dpool = (torch.randn(N * C * ovox, generator=g)).to(T).to(dev)
+    gamma = (0.5 + torch.rand(C, generator=g)).to(dev)
+    mean, invstd = (0.1 * torch.randn(C, generator=g)).to(dev), (0.8 + 0.4 * torch.rand(C, generator=g)).to(dev)
+    beta = (0.2 * torch.randn(C, generator=g)).to(dev)
+    scale = gamma * invstd
+    shift = beta - mean * scale
+    s = nv.stream()
+    z = torch.zeros_like(y)
+    nv.call('iunet_bn_relu_fwd', dt, nv.ptr(y), C * vox, nv.ptr(z), C * vox, nv.ptr(scale), nv.ptr(shift), C, N, vox, s)
+    nparts = nv.lib().iunet_bn_bwd_num_parts(N, vox)
+    res = []
+    for fused in (False, True):
+        dy = torch.zeros_like(y)
+        dgam, dbet = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+        slab, coef = torch.zeros(nparts * C * 2, device=dev), torch.zeros(C * 3, device=dev)
+        if fused:
+            nv.call('iunet_bn_relu_pool_bwd', dt, nd, nv.ptr(dskip), C * vox, nv.ptr(dpool), C * ovox, nv.ptr(y), C * vox,
+                    nv.ptr(dy), C * vox, nv.ptr(mean), nv.ptr(invstd), nv.ptr(gamma), nv.ptr(scale), nv.ptr(shift),
+                    nv.ptr(dgam), nv.ptr(dbet), nv.ptr(slab), nv.ptr(coef), C, N, do[0], do[1], do[2], s)
+        else:
+            dz = dskip.clone()
+            nv.call('iunet_maxpool_bwd', dt, nd, nv.ptr(z), C * vox, nv.ptr(dpool), C * ovox, nv.ptr(dz), C * vox, 1, C, N,
+                    do[0], do[1], do[2], s)
+            nv.call('iunet_bn_relu_bwd', dt, nv.ptr(dz), C * vox, None, 0, nv.ptr(y), C * vox, nv.ptr(dy), C * vox,
+                    nv.ptr(mean), nv.ptr(invstd), nv.ptr(gamma), nv.ptr(scale), nv.ptr(shift), nv.ptr(dgam), nv.ptr(dbet),
+                    nv.ptr(slab), nv.ptr(coef), C, N, vox, s)
+        res.append((dy, dgam, dbet))
+    torch.cuda.synchronize()
+    assert torch.allclose(res[0][1], res[1][1], rtol=1e-5, atol=1e-4) and torch.allclose(res[0][2], res[1][2], rtol=1e-5, atol=1e-4)
+    d = (res[0][0].float() - res[1][0].float()).abs().max().item()
+    assert d <= 2e-2 * res[0][0].float().abs().max().item() * 2 ** -7 + 1e-6, d     # identical up to the fp32 order of the sums
