@@ -109,7 +109,7 @@ struct ConvTWgradParams {
 };
 
 template <typename T, int ND>
-__global__ __launch_bounds__(256, 2) void convT_wgrad_kernel(ConvTWgradParams p) {
+__global__ __launch_bounds__(256, 2) void convT_wgrad_kernel(ConvTWgradParams p) {   // 2 per CU: 74 KB of LDS each
   using V8 = V8T<T>;
   constexpr int NPOS = ND == 3 ? 8 : 4;
   constexpr int TZ = ND == 3 ? 2 : 1, TY = ND == 3 ? 4 : 8, TX = 16;       // input-voxel tile (128 voxels)
@@ -146,7 +146,12 @@ __global__ __launch_bounds__(256, 2) void convT_wgrad_kernel(ConvTWgradParams p)
   const int tps = p.tilesZ * p.tilesY * p.tilesX, ntiles = tps * p.N;
   const int Do = ND == 3 ? p.D * 2 : 1, Ho = p.H * 2, Wo = p.W * 2;
   const long long in_plane = (long long)p.D * p.H * p.W * 8, out_plane = (long long)Do * Ho * Wo * 8;
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  // Split staging: the global loads of tile t + 1 are issued (into registers) before the MFMA phase of tile t and are
+  // written to LDS after it, so their latency hides behind the compute instead of sitting between two barriers.
+  constexpr int XIT = NVI * 4 / 256, YIT = NVO * 4 / 256;      // 16-byte items per thread: x 2, dy 16 (3-D) / 8 (2-D)
+  u32x4 xr[XIT];
+  V8 yr[YIT];
+  auto load_tile = [&](int tile) {
     const int n = tile / tps;
     int trem = tile - n * tps;
     const int tz_i = trem / (p.tilesY * p.tilesX);
@@ -155,17 +160,19 @@ __global__ __launch_bounds__(256, 2) void convT_wgrad_kernel(ConvTWgradParams p)
     const int z0 = tz_i * TZ, y0 = ty_i * TY, x0 = tx_i * TX;
     const T* xin = (const T*)p.x + (long long)n * p.x_ss + (long long)cib * 4 * in_plane;
     const T* dyin = (const T*)p.dy + (long long)n * p.dy_ss + (long long)cob * 4 * out_plane;
-    __syncthreads();
-    for (int it = tid; it < NVI * 4; it += 256) {            // x tile: 4 planes
+#pragma unroll
+    for (int k = 0; k < XIT; ++k) {                              // x tile: 4 planes
+      const int it = tid + k * 256;
       const int pl = it / NVI, pix = it - pl * NVI;
       const int px = pix % TX, t2 = pix / TX, py = t2 % TY, pz = t2 / TY;
       const int gz = z0 + pz, gy = y0 + py, gx = x0 + px;
       u32x4 v = u32x4{0u, 0u, 0u, 0u};
       if (gz < p.D && gy < p.H && gx < p.W) v = *(const u32x4*)(xin + pl * in_plane + (((long long)gz * p.H + gy) * p.W + gx) * 8);
-      *(u32x4*)(smem + pl * PLANE_X + pix * 16) = v;
+      xr[k] = v;
     }
-#pragma unroll 4
-    for (int it = tid; it < NVO * 4; it += 256) {            // dy tile: plane = it & 3 = tid & 3
+#pragma unroll
+    for (int k = 0; k < YIT; ++k) {                              // dy tile: plane = it & 3 = tid & 3
+      const int it = tid + k * 256;
       const int pl = it & 3, pix = it >> 2;
       const int px = pix % OX, t2 = pix / OX, py = t2 % OY, pz = t2 / OY;
       const int gz = 2 * z0 + pz, gy = 2 * y0 + py, gx = 2 * x0 + px;
@@ -173,11 +180,31 @@ __global__ __launch_bounds__(256, 2) void convT_wgrad_kernel(ConvTWgradParams p)
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = from_f32<T>(0.f);
       if (gz < Do && gy < Ho && gx < Wo) v = *(const V8*)(dyin + pl * out_plane + (((long long)gz * Ho + gy) * Wo + gx) * 8);
-      *(V8*)(smem + OFF_Y + pl * PLANE_Y + pix * 16) = v;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) bacc[j] += to_f32<T>(v[j]);
+      yr[k] = v;
     }
+  };
+  auto commit_tile = [&]() {
+#pragma unroll
+    for (int k = 0; k < XIT; ++k) {
+      const int it = tid + k * 256;
+      const int pl = it / NVI, pix = it - pl * NVI;
+      *(u32x4*)(smem + pl * PLANE_X + pix * 16) = xr[k];
+    }
+#pragma unroll
+    for (int k = 0; k < YIT; ++k) {
+      const int it = tid + k * 256;
+      const int pl = it & 3, pix = it >> 2;
+      *(V8*)(smem + OFF_Y + pl * PLANE_Y + pix * 16) = yr[k];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bacc[j] += to_f32<T>(yr[k][j]);
+    }
+  };
+  if ((int)blockIdx.x < ntiles) load_tile(blockIdx.x);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    __syncthreads();                                             // the previous tile's fragment reads are done
+    commit_tile();
     __syncthreads();
+    if (tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x);       // in flight during the MFMA phase
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
       // in-voxel rows 2ks, 2ks+1 (the lane's own row adds gh, folded into laneX / laneY)
