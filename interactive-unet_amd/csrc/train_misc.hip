@@ -327,34 +327,58 @@ __global__ __launch_bounds__(256, 2) void first_wgrad_kernel(FirstWgradParams p)
     for (int ct = 0; ct < NT; ++ct) acc[t][ct] = f32x4{0, 0, 0, 0};
   const int tps = p.tilesZ * p.tilesY * p.tilesX, ntiles = tps * p.N;
   const long long plane = (long long)p.D * p.H * p.W * 8;
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  // split staging: the loads of tile t + 1 (input halo and dy tile) are issued into registers before the MFMA phase of
+  // tile t and written to LDS after it
+  constexpr int XIT = (NPIX * CIN + 255) / 256, YIT = NVOX * 4 / 256;
+  float xr[XIT];
+  u32x4 yr[YIT];
+  auto load_tile = [&](int tile) {
     const int n = tile / tps;
     int trem = tile - n * tps;
     const int tz_i = trem / (p.tilesY * p.tilesX);
     trem -= tz_i * p.tilesY * p.tilesX;
     const int ty_i = trem / p.tilesX, tx_i = trem - ty_i * p.tilesX;
     const int z0 = tz_i * TZ, y0 = ty_i * TY, x0 = tx_i * TX;
-    __syncthreads();
-    for (int it = tid; it < NPIX * CIN; it += 256) {
+#pragma unroll
+    for (int k = 0; k < XIT; ++k) {
+      const int it = tid + k * 256;
       const int c = it / NPIX, pix = it - c * NPIX;
       const int px = pix % PX, t2 = pix / PX, py = t2 % PY, pz = t2 / PY;
       const int gz = z0 + pz - PADZ, gy = y0 + py - 1, gx = x0 + px - 1;
       float v = 0.f;
-      if ((unsigned)gz < (unsigned)p.D && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W)
+      if (it < NPIX * CIN && (unsigned)gz < (unsigned)p.D && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W)
         v = load_in2(p.x, n * p.sN + c * p.sC + gz * p.sD + gy * p.sH + gx * p.sW, p.in_dtype);
-      xs[it] = from_f32<T>(v);
+      xr[k] = v;
     }
     const T* dyin = (const T*)p.dy + (long long)n * p.dy_ss + (long long)cob * 4 * plane;
 #pragma unroll
-    for (int it = 0; it < NVOX * 4 / 256; ++it) {
+    for (int it = 0; it < YIT; ++it) {
       const int idx = tid + it * 256, pl = idx / NVOX, pix = idx - pl * NVOX;
       const int px = pix % TX, t2 = pix / TX, py = t2 % TY, pz = t2 / TY;
       const int gz = z0 + pz, gy = y0 + py, gx = x0 + px;
       u32x4 v = u32x4{0u, 0u, 0u, 0u};
       if (gz < p.D && gy < p.H && gx < p.W) v = *(const u32x4*)(dyin + pl * plane + (((long long)gz * p.H + gy) * p.W + gx) * 8);
-      *(u32x4*)(dys + pl * PLANE_Y + pix * 16) = v;
+      yr[it] = v;
     }
+  };
+  auto commit_tile = [&]() {
+#pragma unroll
+    for (int k = 0; k < XIT; ++k) {
+      const int it = tid + k * 256;
+      if (it < NPIX * CIN) xs[it] = from_f32<T>(xr[k]);
+    }
+#pragma unroll
+    for (int it = 0; it < YIT; ++it) {
+      const int idx = tid + it * 256, pl = idx / NVOX, pix = idx - pl * NVOX;
+      *(u32x4*)(dys + pl * PLANE_Y + pix * 16) = yr[it];
+    }
+  };
+  if ((int)blockIdx.x < ntiles) load_tile(blockIdx.x);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     __syncthreads();
+    commit_tile();
+    __syncthreads();
+    if (tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x);
     for (int ks = wave; ks < NKS; ks += 4) {                 // the four waves split the k-steps
       const int f = 2 * ks + gh;                             // this lane's fragment (16 x voxels)
       const int xh = f % FX, row = f / FX, fy = row % TY, fz = row / TY;
