@@ -62,6 +62,71 @@ __global__ __launch_bounds__(256) void convT_dgrad_kernel(ConvTDgradParams p) {
     *(V8*)((T*)p.dx + n * p.dx_ss + (long long)(cib * 4 + q) * in_plane + (((long long)z * p.H + y) * p.W + x) * 8) = o;
 }
 
+// Same operator with the weights of the ci block resident in LDS (Cout <= 128: 16 KB per 32 output channels of the
+// forward conv) and two 16-voxel groups per wave and step: as in convT_lds_kernel (pointwise.hip), the per-wave weight
+// fetches through the vector cache were 2x the tensor traffic.
+template <typename T, int ND, int NK>
+__global__ __launch_bounds__(256) void convT_dgrad_lds_kernel(ConvTDgradParams p) {
+  using V8 = V8T<T>;
+  constexpr int NPOS = ND == 3 ? 8 : 4, G = 2;
+  extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l15 = lane & 15, q = lane >> 4;
+  const int cib = blockIdx.y;
+  {
+    const u32x4* wsrc = (const u32x4*)p.wpk + (long long)cib * NPOS * NK * 2 * 64;
+    for (int i = threadIdx.x; i < NPOS * NK * 2 * 64; i += 256) *(u32x4*)(smem + i * 16) = wsrc[i];
+  }
+  __syncthreads();
+  const int xg = (p.W + 15) / 16;
+  const long long rows = (long long)p.D * p.H * xg, ngroups = rows * p.N;
+  const int Do = ND == 3 ? p.D * 2 : 1, Ho = p.H * 2, Wo = p.W * 2;
+  const long long out_plane = (long long)Do * Ho * Wo * 8, in_plane = (long long)p.D * p.H * p.W * 8;
+  const V8* wl = (const V8*)smem + lane;
+  for (long long g0 = ((long long)blockIdx.x * 4 + wave) * G; g0 < ngroups; g0 += (long long)gridDim.x * 4 * G) {
+    f32x4 acc[G][2];
+    const T* dyb[G];
+    long long xoff[G];
+    bool okg[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const long long wid = g0 + g < ngroups ? g0 + g : ngroups - 1;
+      const int n = (int)(wid / rows);
+      const long long r = wid - n * rows;
+      const int xb = (int)(r % xg), y = (int)((r / xg) % p.H), z = (int)(r / ((long long)xg * p.H));
+      const int x = xb * 16 + l15, xc = min(x, p.W - 1);
+      okg[g] = x < p.W && g0 + g < ngroups;
+      const int oz = ND == 3 ? z * 2 : 0;
+      dyb[g] = (const T*)p.dy + n * p.dy_ss + (((long long)oz * Ho + y * 2) * Wo + xc * 2) * 8;
+      xoff[g] = n * p.dx_ss + (long long)(cib * 4 + q) * in_plane + (((long long)z * p.H + y) * p.W + x) * 8;
+      acc[g][0] = f32x4{0, 0, 0, 0}; acc[g][1] = f32x4{0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int s = 0; s < NPOS; ++s) {
+      const int a = ND == 3 ? (s >> 2) : 0, b = (s >> 1) & 1, c = s & 1;
+      const long long voff = (((long long)a * Ho + b) * Wo + c) * 8;
+#pragma unroll
+      for (int kc = 0; kc < NK; ++kc) {
+        const V8 a0 = wl[((s * NK + kc) * 2 + 0) * 64];
+        const V8 a1 = wl[((s * NK + kc) * 2 + 1) * 64];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          const V8 bf = *(const V8*)(dyb[g] + (long long)(kc * 4 + q) * out_plane + voff);
+          acc[g][0] = mfma16<T>(a0, bf, acc[g][0]);
+          acc[g][1] = mfma16<T>(a1, bf, acc[g][1]);
+        }
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      V8 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { o[j] = from_f32<T>(acc[g][0][j]); o[4 + j] = from_f32<T>(acc[g][1][j]); }
+      if (okg[g]) *(V8*)((T*)p.dx + xoff[g]) = o;
+    }
+  }
+}
+
 // fp32 [Cin][Cout][npos] -> [cib32][pos][kc][t][64][8], rows = ci (8g + 4t + r), k = co
 template <typename T>
 __global__ void pack_convT_dgrad_kernel(const float* __restrict__ w, T* __restrict__ dst, int Cin, int Cout, int npos) {
@@ -461,6 +526,23 @@ int iunet_convT_dgrad(int dtype, int nd, const void* dy, long long dy_ss, void* 
   ConvTDgradParams p;
   p.dy = dy; p.dy_ss = dy_ss; p.dx = dx; p.dx_ss = dx_ss; p.wpk = wpk; p.N = N; p.D = D; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
   const long long waves = (long long)N * D * H * ((W + 15) / 16);
+  const int nk = Cout / 32;
+  if (nk <= 4 && waves >= 256) {
+    const int lds = (nd == 3 ? 8 : 4) * nk * 2 * 1024;
+    int gx = (int)((waves + 7) / 8);
+    const int cap = 1024 / (Cin / 32);
+    if (gx > cap) gx = cap;
+    dim3 g2(gx, Cin / 32);
+#define CDL(TT, NDV, NKV) do { static bool s_ = false; if (!s_) { IUNET_CHECK_HIP(hipFuncSetAttribute((const void*)convT_dgrad_lds_kernel<TT, NDV, NKV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); s_ = true; } \
+    hipLaunchKernelGGL((convT_dgrad_lds_kernel<TT, NDV, NKV>), g2, dim3(256), lds, (hipStream_t)stream, p); } while (0)
+#define CDL_NK(TT, NDV) switch (nk) { case 1: CDL(TT, NDV, 1); break; case 2: CDL(TT, NDV, 2); break; case 3: CDL(TT, NDV, 3); break; default: CDL(TT, NDV, 4); break; }
+    if (dtype == 0) { if (nd == 3) { CDL_NK(f16, 3) } else { CDL_NK(f16, 2) } }
+    else            { if (nd == 3) { CDL_NK(bf16, 3) } else { CDL_NK(bf16, 2) } }
+#undef CDL_NK
+#undef CDL
+    IUNET_CHECK_HIP(hipGetLastError());
+    return IUNET_OK;
+  }
   dim3 grid((unsigned)((waves + 3) / 4), Cin / 32);
   if (dtype == 0) { if (nd == 3) hipLaunchKernelGGL((convT_dgrad_kernel<f16, 3>), grid, dim3(256), 0, (hipStream_t)stream, p);
                     else hipLaunchKernelGGL((convT_dgrad_kernel<f16, 2>), grid, dim3(256), 0, (hipStream_t)stream, p); }

@@ -123,10 +123,13 @@ def test_maxpool_bwd_matches_autograd(nv, nd):
     assert (got - ref.half().float()).abs().max() <= 2e-3
 
 
-@pytest.mark.parametrize('nd', [2, 3])
-def test_convT_backward_exact_integers(nv, nd):
+@pytest.mark.parametrize('nd,big', [(2, False), (3, False), (2, True), (3, True)])
+def test_convT_backward_exact_integers(nv, nd, big):
     g = torch.Generator().manual_seed(14)
-    shape = (6, 20) if nd == 2 else (3, 4, 16)
+    if big:      # enough 16-voxel groups for the resident-weight data-gradient kernel, ragged x extent
+        shape = (24, 52) if nd == 2 else (6, 8, 40)
+    else:
+        shape = (6, 20) if nd == 2 else (3, 4, 16)
     N, cin, cout = 2, 64, 32
     x = torch.randint(-2, 3, (N, cin) + shape, generator=g).float().requires_grad_(True)
     w = torch.randint(-1, 2, (cin, cout) + (2,) * nd, generator=g).float().requires_grad_(True)
