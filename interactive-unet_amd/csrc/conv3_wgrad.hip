@@ -95,7 +95,12 @@ __global__ __launch_bounds__(256, 2) void conv3_wgrad_kernel(WgradParams p) {
   // contiguous run of tiles per workgroup, runs of one XCD adjacent (halo lines stay in that XCD's L2)
   const int lb = xcd_remap(blockIdx.x, gridDim.x);
   const int t_begin = (int)((long long)lb * ntiles / gridDim.x), t_end = (int)((long long)(lb + 1) * ntiles / gridDim.x);
-  for (int tile = t_begin; tile < t_end; ++tile) {
+  // split staging: the loads of tile t + 1 are issued into registers before the MFMA phase of tile t and written to LDS
+  // after it (their latency hides behind the compute)
+  constexpr int XITERS = (NPIX + 255) / 256, YITERS = NVOX / 256;
+  static_assert(NVOX % 256 == 0, "tile voxels must be a multiple of 256");
+  u32x4 xr[XITERS][4], yr[YITERS][4];
+  auto load_tile = [&](int tile) {
     const int n_img = tile / tiles_per_sample;
     int trem = tile - n_img * tiles_per_sample;
     const int tz_i = trem / (p.tilesY * p.tilesX);
@@ -104,68 +109,60 @@ __global__ __launch_bounds__(256, 2) void conv3_wgrad_kernel(WgradParams p) {
     const int z0 = tz_i * TZ, y0 = ty_i * TY, x0 = tx_i * TX;
     const T* xin = (const T*)p.x + (long long)n_img * p.x_ss + (long long)cib * 4 * plane_stride;
     const T* dyin = (const T*)p.dy + (long long)n_img * p.dy_ss + (long long)cob * 4 * plane_stride;
-
+#pragma unroll
+    for (int it = 0; it < XITERS; ++it) {
+      const int pix = tid + it * 256;
+      const int px = pix % PX, t2 = pix / PX;
+      const int py = t2 % PY, pz = t2 / PY;
+      const int gz = z0 + pz - PADZ, gy = y0 + py - 1, gx = x0 + px - 1;
+      const bool ok = (pix < NPIX) && (unsigned)gz < (unsigned)p.D && (unsigned)gy < (unsigned)p.H &&
+                      (unsigned)gx < (unsigned)p.W;
+      const long long goff = (((long long)gz * p.H + gy) * p.W + gx) * 8;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        u32x4 val = u32x4{0u, 0u, 0u, 0u};
+        if (ok) val = *(const u32x4*)(xin + k * plane_stride + goff);
+        xr[it][k] = val;
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < YITERS; ++it) {
+      const int pix = tid + it * 256;
+      const int px = pix % TX, t2 = pix / TX;
+      const int py = t2 % TY, pz = t2 / TY;
+      const int gz = z0 + pz, gy = y0 + py, gx = x0 + px;
+      const bool ok = gz < p.D && gy < p.H && gx < p.W;
+      const long long goff = (((long long)gz * p.H + gy) * p.W + gx) * 8;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        u32x4 val = u32x4{0u, 0u, 0u, 0u};
+        if (ok) val = *(const u32x4*)(dyin + k * plane_stride + goff);
+        yr[it][k] = val;
+      }
+    }
+  };
+  auto commit_tile = [&]() {
+#pragma unroll
+    for (int it = 0; it < XITERS; ++it) {
+      const int pix = tid + it * 256;
+      if (pix < NPIX) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) *(u32x4*)(smem + k * PLANE_X + pix * 16) = xr[it][k];
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < YITERS; ++it) {
+      const int pix = tid + it * 256;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) *(u32x4*)(smem + OFF_Y + k * PLANE_Y + pix * 16) = yr[it][k];
+    }
+  };
+  if (t_begin < t_end) load_tile(t_begin);
+  for (int tile = t_begin; tile < t_end; ++tile) {
     __syncthreads();    // previous tile's reads are done
-    // ---- stage x halo tile (4 planes) ----
-    {
-      constexpr int ITERS = (NPIX + 255) / 256;
-#pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        u32x4 v[ITERS][2];
-#pragma unroll
-        for (int it = 0; it < ITERS; ++it) {
-          const int pix = tid + it * 256;
-          const int px = pix % PX, t2 = pix / PX;
-          const int py = t2 % PY, pz = t2 / PY;
-          const int gz = z0 + pz - PADZ, gy = y0 + py - 1, gx = x0 + px - 1;
-          const bool ok = (pix < NPIX) && (unsigned)gz < (unsigned)p.D && (unsigned)gy < (unsigned)p.H &&
-                          (unsigned)gx < (unsigned)p.W;
-          const long long goff = (((long long)gz * p.H + gy) * p.W + gx) * 8;
-#pragma unroll
-          for (int k = 0; k < 2; ++k) {
-            u32x4 val = u32x4{0u, 0u, 0u, 0u};
-            if (ok) val = *(const u32x4*)(xin + (half * 2 + k) * plane_stride + goff);
-            v[it][k] = val;
-          }
-        }
-#pragma unroll
-        for (int it = 0; it < ITERS; ++it) {
-          const int pix = tid + it * 256;
-          if (pix < NPIX) {
-#pragma unroll
-            for (int k = 0; k < 2; ++k) *(u32x4*)(smem + (half * 2 + k) * PLANE_X + pix * 16) = v[it][k];
-          }
-        }
-      }
-    }
-    // ---- stage dy tile (4 planes, no halo), zero outside the image ----
-    {
-      constexpr int ITERS = NVOX / 256;
-      static_assert(NVOX % 256 == 0, "tile voxels must be a multiple of 256");
-      u32x4 v[ITERS][4];
-#pragma unroll
-      for (int it = 0; it < ITERS; ++it) {
-        const int pix = tid + it * 256;
-        const int px = pix % TX, t2 = pix / TX;
-        const int py = t2 % TY, pz = t2 / TY;
-        const int gz = z0 + pz, gy = y0 + py, gx = x0 + px;
-        const bool ok = gz < p.D && gy < p.H && gx < p.W;
-        const long long goff = (((long long)gz * p.H + gy) * p.W + gx) * 8;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          u32x4 val = u32x4{0u, 0u, 0u, 0u};
-          if (ok) val = *(const u32x4*)(dyin + k * plane_stride + goff);
-          v[it][k] = val;
-        }
-      }
-#pragma unroll
-      for (int it = 0; it < ITERS; ++it) {
-        const int pix = tid + it * 256;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) *(u32x4*)(smem + OFF_Y + k * PLANE_Y + pix * 16) = v[it][k];
-      }
-    }
+    commit_tile();
     __syncthreads();
+    if (tile + 1 < t_end) load_tile(tile + 1);
 
     // ---- k loop over 32-voxel steps (fragments 2ks, 2ks+1) ----
 #pragma unroll 2
