@@ -173,18 +173,33 @@ __global__ __launch_bounds__(V4_NCW * 64 + (WS ? 256 : 512), 1) void conv3_v4_ke
         }
       }
     };
-    // one register set: step s + 1 is written to LDS, then the loads of step s + 2 are issued into the same registers and
-    // stay in flight over the barrier and the consumers' whole next step
     const bool refill = !(p.dbg & 1);
     Staged r;
     load(0, r);
     commit(0, r);
     if (nsteps > 1 && refill) load(1, r);
     lds_barrier();
-    for (int s = 0; s < nsteps; ++s) {
-      if (s + 1 < nsteps && refill) commit(s + 1, r);
-      if (s + 2 < nsteps && refill) load(s + 2, r);
-      lds_barrier();
+    if (WS) {
+      // one register set: step s + 1 is written to LDS, then the loads of step s + 2 are issued into the same registers
+      // and stay in flight over the barrier and the consumers' whole next step
+      for (int s = 0; s < nsteps; ++s) {
+        if (s + 1 < nsteps && refill) commit(s + 1, r);
+        if (s + 2 < nsteps && refill) load(s + 2, r);
+        lds_barrier();
+      }
+    } else {
+      // weights stream too (the loaders bound these layers): two register sets, the loads of step s + 2 are issued BEFORE
+      // step s + 1 is waited for and written, so two steps of loads are in flight
+      Staged r2;
+      for (int s = 0; s < nsteps; s += 2) {
+        if (s + 2 < nsteps && refill) load(s + 2, r2);
+        if (s + 1 < nsteps && refill) commit(s + 1, r);
+        lds_barrier();
+        if (s + 1 >= nsteps) break;
+        if (s + 3 < nsteps && refill) load(s + 3, r);
+        if (s + 2 < nsteps && refill) commit(s + 2, r2);
+        lds_barrier();
+      }
     }
     if (p.stats != nullptr) lds_barrier();            // the consumers' final statistics reduction
     return;
