@@ -19,13 +19,13 @@
 
 namespace {
 
-#ifndef V4_NCW
-#define V4_NCW 8                                         // consumer waves (A/B: 4 waves x 8 fragments measured the same, +-2 %)
-#endif
-
-template <int ND> struct V4Tile;
-template <> struct V4Tile<3> { static constexpr int TZ = 4, TY = 8, TX = 16, PADZ = 1, NCOL = 9, S16 = 1; };
-template <> struct V4Tile<2> { static constexpr int TZ = 1, TY = 16, TX = 32, PADZ = 0, NCOL = 3, S16 = 2; };
+// tile shape, consumer waves (NCW; A/B: 4 waves x 8 fragments on the big 3-D tile measured the same, +-2 %), filter columns,
+// 16-channel sub-chunks per step.  SMALL (3-D): half the tile and half the consumer waves, for launches whose 4 x 8 x 16 tiles
+// would leave CUs idle (16^3 grids: 16 tiles per sample).
+template <int ND, bool SMALL> struct V4Tile;
+template <> struct V4Tile<3, false> { static constexpr int TZ = 4, TY = 8, TX = 16, PADZ = 1, NCOL = 9, S16 = 1, NCW = 8; };
+template <> struct V4Tile<3, true>  { static constexpr int TZ = 2, TY = 8, TX = 16, PADZ = 1, NCOL = 9, S16 = 1, NCW = 4; };
+template <bool SMALL> struct V4Tile<2, SMALL> { static constexpr int TZ = 1, TY = 16, TX = 32, PADZ = 0, NCOL = 3, S16 = 2, NCW = 8; };
 
 struct ConvV4Params {
   const void* x;  long long x_sstride;
@@ -43,13 +43,13 @@ struct ConvV4Params {
   int dbg;                                    // profiling only (IUNET_V4_DBG): 1 no refill after step 0, 2 no MFMA phase, 4 no stores
 };
 
-template <typename T, int ND, bool WS>
-__global__ __launch_bounds__(V4_NCW * 64 + (WS ? 256 : 512), 1) void conv3_v4_kernel(ConvV4Params p) {
+template <typename T, int ND, bool WS, bool SMALL>
+__global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + (WS ? 256 : 512)), 1) void conv3_v4_kernel(ConvV4Params p) {
   using V8 = typename Vec8<T>::type;
-  using TL = V4Tile<ND>;
+  using TL = V4Tile<ND, SMALL>;
   // consumer waves; loader threads: 4 loader waves when only activations stream, 8 when the weights stream too (twice the
   // bytes per step: the extra waves double the loads in flight, -6...-11 % on those layers)
-  constexpr int NCW = V4_NCW, NLT = WS ? 256 : 512;
+  constexpr int NCW = TL::NCW, NLT = WS ? 256 : 512;
   constexpr int TZ = TL::TZ, TY = TL::TY, TX = TL::TX, PADZ = TL::PADZ, NCOL = TL::NCOL, S16 = TL::S16;
   constexpr int FX = TX / 16, NI = TZ * TY * FX / NCW, NR = NI / FX;    // x halves; fragments per consumer wave; tile rows per wave
   constexpr int PZ = TZ + 2 * PADZ, PY = TY + 2, PX = TX + 2;
@@ -342,16 +342,16 @@ __global__ __launch_bounds__(V4_NCW * 64 + (WS ? 256 : 512), 1) void conv3_v4_ke
   }
 }
 
-template <typename T, int ND, bool WS>
+template <typename T, int ND, bool WS, bool SMALL>
 int launch_v4(ConvV4Params p, hipStream_t stream) {
-  using TL = V4Tile<ND>;
+  using TL = V4Tile<ND, SMALL>;
   constexpr int NPIX = (TL::TZ + 2 * TL::PADZ) * (TL::TY + 2) * (TL::TX + 2);
   constexpr int PLANE = ((NPIX * 16 + 255) / 256) * 256;
   constexpr int WSTEP = TL::S16 * ((TL::NCOL + 1) / 2) * 3 * 2 * 1024;
   const int lds = 2 * 2 * TL::S16 * PLANE + (WS ? p.Cin / (16 * TL::S16) : 2) * WSTEP + 2048;
   static int attr_lds = 0;
   if (lds > attr_lds) {
-    IUNET_CHECK_HIP(hipFuncSetAttribute((const void*)conv3_v4_kernel<T, ND, WS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    IUNET_CHECK_HIP(hipFuncSetAttribute((const void*)conv3_v4_kernel<T, ND, WS, SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_lds = lds;
   }
   p.tilesZ = (p.D + TL::TZ - 1) / TL::TZ; p.tilesY = (p.H + TL::TY - 1) / TL::TY; p.tilesX = (p.W + TL::TX - 1) / TL::TX;
@@ -371,7 +371,7 @@ int launch_v4(ConvV4Params p, hipStream_t stream) {
   }
   p.nbz = (p.tilesZ + p.bz - 1) / p.bz; p.nby = (p.tilesY + p.by - 1) / p.by; p.nbx = (p.tilesX + p.bx - 1) / p.bx;
   const int gx = 8 * p.bz * p.by * p.bx;
-  hipLaunchKernelGGL((conv3_v4_kernel<T, ND, WS>), dim3(gx, ncob), dim3(V4_NCW * 64 + (WS ? 256 : 512)), lds, stream, p);
+  hipLaunchKernelGGL((conv3_v4_kernel<T, ND, WS, SMALL>), dim3(gx, ncob), dim3(TL::NCW * 64 + (WS ? 256 : 512)), lds, stream, p);
   IUNET_CHECK_HIP(hipGetLastError());
   return IUNET_OK;
 }
@@ -399,8 +399,13 @@ int iunet_conv3_v4_launch(int dtype, int nd, const void* x, long long x_sstride,
   p.dbg = dbg;
   // weights resident in LDS for the whole launch when they fit beside the two activation buffers
   const bool ws = nd == 3 ? Cin <= 32 : Cin <= 64;
-#define V4_GO(TT) (nd == 3 ? (ws ? launch_v4<TT, 3, true>(p, stream) : launch_v4<TT, 3, false>(p, stream)) \
-                           : (ws ? launch_v4<TT, 2, true>(p, stream) : launch_v4<TT, 2, false>(p, stream)))
+  // 3-D launches whose 4 x 8 x 16 tiles would occupy fewer than half of the CUs run on the half-size tile (measured on the
+  // 16^3 level: 1.4-1.6x faster there; at 128 of 256 CUs the doubled weight streaming costs more than the idle CUs)
+  const long long big_tiles = (long long)N * ((D + 3) / 4) * ((H + 7) / 8) * ((W + 15) / 16);
+  const bool small = nd == 3 && !ws && big_tiles * (Cout / 32) < 128;
+#define V4_GO(TT) (nd == 3 ? (ws ? launch_v4<TT, 3, true, false>(p, stream)                                          \
+                                 : (small ? launch_v4<TT, 3, false, true>(p, stream) : launch_v4<TT, 3, false, false>(p, stream))) \
+                           : (ws ? launch_v4<TT, 2, true, false>(p, stream) : launch_v4<TT, 2, false, false>(p, stream)))
   return dtype == 0 ? V4_GO(f16) : V4_GO(bf16);
 #undef V4_GO
 }
