@@ -150,3 +150,28 @@ def test_device_slicer_bit_exact(golden_dir):
                                                 sampling_axis=s.sampling_axis)
                     got = s.get_slice(bd, axis=axis, slice_width=sw, order=order).cpu().numpy()
                     assert np.array_equal(got, want), (trial, axis, order, sw, np.abs(got.astype(int) - want).max())
+
+
+def test_data_parallel_step_over_rccl_single_rank():
+    """The N > 1 training path of bench.py (flat-gradient all-reduce through torch.distributed 'nccl' = RCCL, gradient
+    divided by the world size) on a one-rank process group: same loss sequence as the plain engine."""
+    import torch.distributed as dist
+    from interactive_unet.train_engine import TrainEngine
+    if dist.is_initialized():
+        pytest.skip('a process group already exists in this process')
+    dist.init_process_group('nccl', init_method='tcp://127.0.0.1:29533', rank=0, world_size=1,
+                            device_id=torch.device('cuda', 0))
+    try:
+        g = torch.Generator().manual_seed(41)
+        X = torch.randint(1, 255, (1, 1, 16, 32, 32), dtype=torch.uint8, generator=g)
+        lab = X > 127
+        y = torch.cat([~lab, lab], 1).half()
+        losses = []
+        for pg in (None, dist.group.WORLD):
+            model, _ = _model(3, 2, seed=7, dtype='bf16')
+            te = TrainEngine(model.train(), lr=1e-3, loss_kind='mcc_ce', process_group=pg)
+            losses.append([te.train_step(X, y, None)['Loss'] for _ in range(3)])
+        assert np.allclose(losses[0], losses[1], rtol=0, atol=1e-6), losses
+        assert losses[0][2] < losses[0][0]
+    finally:
+        dist.destroy_process_group()
