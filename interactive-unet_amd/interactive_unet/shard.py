@@ -54,15 +54,19 @@ class NativeOps:
         self.blk = torch.empty((input_size,) * 3, dtype=torch.uint8, device=self.device)
         self._acc = {}
 
-    def make_accumulator(self, V):
+    def make_accumulator(self, V, zero=None):
         """Accumulators are cached per volume shape (the Gaussian window and 12 B/voxel of HBM are not
-        re-created for every volume of a series); a re-used one is zeroed."""
+        re-created for every volume of a series); a re-used one is zeroed -- only planes [zero[0], zero[1]) when given
+        (a rank touches its footprint and its slab, not the whole height: 1/8 of the planes at 8 ranks)."""
         acc = self._acc.get(tuple(V))
         if acc is None:
             acc = P.VolumeAccumulator(V, self.C, self.S, self.device)
             self._acc = {tuple(V): acc}
-        else:
+        elif zero is None:
             acc.reset()
+        else:
+            acc.pred[zero[0]:zero[1]].zero_()
+            acc.weight[zero[0]:zero[1]].zero_()
         return acc
 
     def predict_into(self, acc, volume, block, padded, local):
@@ -117,7 +121,12 @@ def predict_volume_sharded(ops, my_slab, volume_shape, input_size, overlap=0.25,
     bc, pbc, lbc = P.get_block_coordinates(np.array(V), input_size=input_size, overlap=overlap)
     runs = partition_blocks(len(pbc), world)
     lo, hi = runs[rank]
-    acc = ops.make_accumulator(V)
+    f0, f1 = footprint(bc, lo, hi)
+    z_lo, z_hi = min(f0, bounds[rank][0]), max(f1, bounds[rank][1])      # everything this rank reads or writes
+    try:
+        acc = ops.make_accumulator(V, zero=(z_lo, z_hi))
+    except TypeError:                                                    # ops without partial zeroing (tests)
+        acc = ops.make_accumulator(V)
     if hasattr(ops, 'predict_run'):
         ops.predict_run(acc, volume, bc, pbc, lbc, lo, hi)
     else:
