@@ -77,6 +77,11 @@ class TrainEngine:
         self.v = torch.zeros_like(flat)
         self.flag = torch.zeros(1, dtype=torch.int32, device=self.dev)
         self.names = names
+        # first element of the decoder + head parameters (they follow the encoder in the flat order): bucket boundary of
+        # the data-parallel all-reduce
+        first_dec = f'dec{self.levels - 2}.up.weight'
+        self._dec_start = self.offsets[first_dec][0] if first_dec in self.offsets else 0
+        self._pending = []
 
     def p(self, name):
         return self.model.tensor(name)
@@ -372,6 +377,12 @@ class TrainEngine:
             _, wd = self.pk[f'dec{l}.up']
             nv.call('iunet_convT_dgrad', self.dt, self.dim, dup, 2 * ch[l] * v, self._P(dsrc), ch[l + 1] * vi,
                     nv.ptr(wd), N, di[0], di[1], di[2], ch[l + 1], ch[l], s)
+        # data parallel: the decoder + head gradients (the tail of the flat tensor) are complete -- their all-reduce runs
+        # on RCCL's stream while the encoder backward below still computes
+        self._pending = []
+        if self.pg is not None and self._dec_start > 0:
+            import torch.distributed as dist
+            self._pending.append(dist.all_reduce(self.grad[self._dec_start:], group=self.pg, async_op=True))
         # encoder, bottom level upwards
         for l in range(L - 1, -1, -1):
             v = _vox(dims[l])
@@ -402,7 +413,12 @@ class TrainEngine:
         n = self.flat.numel()
         if self.pg is not None:
             import torch.distributed as dist
-            dist.all_reduce(self.grad, group=self.pg)
+            pending = getattr(self, '_pending', [])
+            head = self._dec_start if pending else self.grad.numel()        # what backward() has not reduced yet
+            pending.append(dist.all_reduce(self.grad[:head], group=self.pg, async_op=True))
+            for work in pending:
+                work.wait()
+            self._pending = []
             world = dist.get_world_size(self.pg)
         else:
             world = 1
