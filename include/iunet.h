@@ -173,7 +173,7 @@ int iunet_conv3_wgrad_blocks(int nd, int N, int D, int H, int W, int Cin, int Co
 long long iunet_conv3_wgrad_slab_floats(int nd, int N, int D, int H, int W, int Cin, int Cout);
 int iunet_conv3_wgrad(int dtype, int nd, const void* x, long long x_ss, const void* dy, long long dy_ss, void* slab,
                       void* dW, float alpha, int N, int D, int H, int W, int Cin, int Cout, void* stream);
-/* the same with the conv input given as relu(x_scale[c] * x + x_shift[c]) (see iunet_conv3_fwd_act); 3-D only. */
+/* the same with the conv input given as relu(x_scale[c] * x + x_shift[c]) (see iunet_conv3_fwd_act). */
 int iunet_conv3_wgrad_act(int dtype, int nd, const void* x, long long x_ss, const void* dy, long long dy_ss, void* slab,
                           void* dW, float alpha, const void* x_scale, const void* x_shift, int N, int D, int H, int W,
                           int Cin, int Cout, void* stream);

@@ -30,6 +30,8 @@ struct WgradParams {
   const void* x;  long long x_ss;     // conv input  (Cin/8 planes)
   const void* dy; long long dy_ss;    // output grad (Cout/8 planes)
   float* slab;                        // [gridDim.x][Cout/32][Cin/32][TAPS][32][32]
+  const float* x_scale;               // optional [Cin] pair: the conv input is relu(x_scale * x + x_shift) (applied while staging)
+  const float* x_shift;
   int N, D, H, W, Cin, Cout;
   int tilesZ, tilesY, tilesX;
 };
@@ -100,7 +102,9 @@ __global__ __launch_bounds__(256, 2) void conv3_wgrad_kernel(WgradParams p) {
   constexpr int XITERS = (NPIX + 255) / 256, YITERS = NVOX / 256;
   static_assert(NVOX % 256 == 0, "tile voxels must be a multiple of 256");
   u32x4 xr[XITERS][4], yr[YITERS][4];
+  unsigned okx = 0;                   // bit it: halo pixel slot `it` of the staged tile lies inside the image
   auto load_tile = [&](int tile) {
+    okx = 0;
     const int n_img = tile / tiles_per_sample;
     int trem = tile - n_img * tiles_per_sample;
     const int tz_i = trem / (p.tilesY * p.tilesX);
@@ -118,6 +122,7 @@ __global__ __launch_bounds__(256, 2) void conv3_wgrad_kernel(WgradParams p) {
       const bool ok = (pix < NPIX) && (unsigned)gz < (unsigned)p.D && (unsigned)gy < (unsigned)p.H &&
                       (unsigned)gx < (unsigned)p.W;
       const long long goff = (((long long)gz * p.H + gy) * p.W + gx) * 8;
+      okx |= ok ? (1u << it) : 0u;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         u32x4 val = u32x4{0u, 0u, 0u, 0u};
@@ -147,7 +152,20 @@ __global__ __launch_bounds__(256, 2) void conv3_wgrad_kernel(WgradParams p) {
       const int pix = tid + it * 256;
       if (pix < NPIX) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) *(u32x4*)(smem + k * PLANE_X + pix * 16) = xr[it][k];
+        for (int k = 0; k < 4; ++k) {
+          u32x4 v = xr[it][k];
+          if (p.x_scale != nullptr && ((okx >> it) & 1u)) {       // z = relu(scale * y + shift) as bn_relu_fwd_kernel; padding stays 0
+            const typename Vec8<T>::type in = __builtin_bit_cast(typename Vec8<T>::type, v);
+            typename Vec8<T>::type o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const int c = cib * 32 + k * 8 + j;
+              o[j] = from_f32<T>(fmaxf(fmaf(p.x_scale[c], to_f32<T>(in[j]), p.x_shift[c]), 0.f));
+            }
+            v = __builtin_bit_cast(u32x4, o);
+          }
+          *(u32x4*)(smem + k * PLANE_X + pix * 16) = v;
+        }
       }
     }
 #pragma unroll
@@ -282,13 +300,12 @@ static int wgrad_impl(int dtype, int nd, const void* x, long long x_ss, const vo
   IUNET_REQUIRE(Cin % 32 == 0 && Cout % 32 == 0, "conv3_wgrad: channels must be multiples of 32 (%d, %d)", Cin, Cout);
   IUNET_REQUIRE(x && dy && slab && dW, "conv3_wgrad: null pointer");
   WgradParams p;
-  p.x = x; p.x_ss = x_ss; p.dy = dy; p.dy_ss = dy_ss; p.slab = (float*)slab;
+  p.x = x; p.x_ss = x_ss; p.dy = dy; p.dy_ss = dy_ss; p.slab = (float*)slab; p.x_scale = x_scale; p.x_shift = x_shift;
   p.N = N; p.D = D; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
   const int TZ = nd == 3 ? 2 : 1, TY = nd == 3 ? 8 : 16, TX = nd == 3 ? 16 : 32;
   p.tilesZ = (D + TZ - 1) / TZ; p.tilesY = (H + TY - 1) / TY; p.tilesX = (W + TX - 1) / TX;
   const int nb = iunet_conv3_wgrad_blocks(nd, N, D, H, W, Cin, Cout);
   int rc;
-  IUNET_REQUIRE(x_scale == nullptr || wgrad_use_v2(nd), "conv3_wgrad: a fused input activation needs the 3-D wave-specialised kernel");
   if (wgrad_use_v2(nd)) rc = iunet_conv3_wgrad_v2_launch(dtype, x, x_ss, dy, dy_ss, (float*)slab, N, D, H, W, Cin, Cout, x_scale, x_shift, (hipStream_t)stream);
   else if (dtype == 0) rc = nd == 3 ? launch_wgrad<f16, 3>(p, nb, (hipStream_t)stream) : launch_wgrad<f16, 2>(p, nb, (hipStream_t)stream);
   else rc = nd == 3 ? launch_wgrad<bf16, 3>(p, nb, (hipStream_t)stream) : launch_wgrad<bf16, 2>(p, nb, (hipStream_t)stream);
@@ -307,7 +324,7 @@ int iunet_conv3_wgrad(int dtype, int nd, const void* x, long long x_ss, const vo
   return wgrad_impl(dtype, nd, x, x_ss, dy, dy_ss, slab, dW, alpha, N, D, H, W, Cin, Cout, nullptr, nullptr, stream);
 }
 
-// the same with the conv input given as relu(x_scale[c] * x + x_shift[c]) (see iunet_conv3_fwd_act); 3-D only
+// the same with the conv input given as relu(x_scale[c] * x + x_shift[c]) (see iunet_conv3_fwd_act)
 int iunet_conv3_wgrad_act(int dtype, int nd, const void* x, long long x_ss, const void* dy, long long dy_ss, void* slab,
                           void* dW, float alpha, const void* x_scale, const void* x_shift, int N, int D, int H, int W,
                           int Cin, int Cout, void* stream) {

@@ -46,9 +46,10 @@ class TrainEngine:
         self.good_steps = 0
         self.step_count = 0
         self.pg = process_group
-        # 3-D: the BatchNorm + ReLU between the two convs of a stage is applied by the consumers' loader waves
+        # the BatchNorm + ReLU between the two convs of a stage is applied by the consumers while they stage their input
+        # wherever the second conv runs on layout 2 (3-D: always; 2-D: up to 64 channels) -- see _conv2_input
         # (IUNET_NO_ACT_FUSION=1: materialise it, for A/B runs)
-        self.fuse_act = self.dim == 3 and not os.environ.get('IUNET_NO_ACT_FUSION')
+        self.fuse_act = not os.environ.get('IUNET_NO_ACT_FUSION')
         self._flatten()
         self._alloc_packed()
         self._ws = {}
@@ -246,10 +247,10 @@ class TrainEngine:
                     nv.ptr(ws['shift.' + name]), co, N, v, s)
 
     def _conv2_input(self, ws, stage, l, N):
-        """(x_ptr, x_act, z1_ptr) of a stage's second conv.  3-D: conv1's BatchNorm + ReLU output is never written --
+        """(x_ptr, x_act, z1_ptr) of a stage's second conv.  Where that conv runs on layout 2, conv1's BatchNorm + ReLU output is never written --
         conv2 and its weight gradient read conv1's raw output and apply scale / shift / ReLU in their loader waves
         (one tensor write and one read less per stage, and no bn_relu_fwd launch)."""
-        if self.fuse_act:
+        if self.fuse_act and (self.dim == 3 or self.ch[l] <= 64):
             return self._P(ws[f'y.{stage}.conv1']), f'{stage}.conv1', None
         z1 = ws[f'z.{stage}.conv1']
         return self._P(z1), None, self._P(z1)

@@ -341,51 +341,53 @@ def test_full_train_step_vs_autograd(dim, shape, dtype):
     assert np.isfinite(ev['Loss'])
 
 
-@pytest.mark.parametrize('cin', [32, 64])
-def test_conv3_fwd_and_wgrad_with_fused_input_activation(nv, cin):
-    """iunet_conv3_fwd_act / iunet_conv3_wgrad_act (input = relu(scale * y + shift) applied by the loader waves) equal
+@pytest.mark.parametrize('nd,cin', [(3, 32), (3, 64), (2, 32), (2, 64)])
+def test_conv3_fwd_and_wgrad_with_fused_input_activation(nv, nd, cin):
+    """iunet_conv3_fwd_act / iunet_conv3_wgrad_act (input = relu(scale * y + shift) applied while staging) equal
     the unfused sequence bn_relu_fwd -> conv3_fwd / conv3_wgrad bit for bit (same rounding of the activation)."""
     g = torch.Generator().manual_seed(21)
     T, dt = torch.bfloat16, 1
-    N, cout, shape = 2, 32, (6, 12, 20)
-    D, H, W = shape
+    N, cout = 2, 32
+    shape = (6, 12, 20) if nd == 3 else (24, 44)
+    D, H, W = shape if nd == 3 else (1,) + shape
+    taps = 3 ** nd
     vox = D * H * W
     y1 = torch.randn((N, cin) + shape, generator=g)
     scale, shift = (0.5 + torch.rand(cin, generator=g)).cuda(), (0.3 * torch.randn(cin, generator=g)).cuda()
-    w = (torch.randn((cout, cin, 3, 3, 3), generator=g) * 0.05).cuda()
+    w = (torch.randn((cout, cin) + (3,) * nd, generator=g) * 0.05).cuda()
     dy = torch.randn((N, cout) + shape, generator=g)
     yb, dyb = blocked(y1, T).cuda(), blocked(dy, T).cuda()
     s = nv.stream()
     z = torch.empty_like(yb)
     nv.call('iunet_bn_relu_fwd', dt, nv.ptr(yb), cin * vox, nv.ptr(z), cin * vox, nv.ptr(scale), nv.ptr(shift), cin, N, vox, s)
-    wpk = torch.empty(nv.pack_conv3_elems(cout, cin, 27, 2), dtype=T, device='cuda')
-    nv.call('iunet_pack_conv3', dt, nv.ptr(w), None, nv.ptr(wpk), cout, cin, 27, 2, s)
-    nt = nv.lib().iunet_conv3_stats_parts(3, N, D, H, W, cout, 2)
+    wpk = torch.empty(nv.pack_conv3_elems(cout, cin, taps, 2), dtype=T, device='cuda')
+    nv.call('iunet_pack_conv3', dt, nv.ptr(w), None, nv.ptr(wpk), cout, cin, taps, 2, s)
+    nt = nv.lib().iunet_conv3_stats_parts(nd, N, D, H, W, cout, 2)
     outs, stats = [], []
     for fused in (False, True):
         out = torch.full((N * cout * vox,), float('nan'), dtype=T, device='cuda')
         st = torch.zeros(nt * cout * 2, device='cuda')
         if fused:
-            nv.call('iunet_conv3_fwd_act', dt, 3, nv.ptr(yb), cin * vox, nv.ptr(out), cout * vox, nv.ptr(wpk), None,
+            nv.call('iunet_conv3_fwd_act', dt, nd, nv.ptr(yb), cin * vox, nv.ptr(out), cout * vox, nv.ptr(wpk), None,
                     nv.ptr(st), nv.ptr(scale), nv.ptr(shift), N, D, H, W, cin, cout, 0, 2, s)
         else:
-            nv.call('iunet_conv3_fwd', dt, 3, nv.ptr(z), cin * vox, nv.ptr(out), cout * vox, nv.ptr(wpk), None,
+            nv.call('iunet_conv3_fwd', dt, nd, nv.ptr(z), cin * vox, nv.ptr(out), cout * vox, nv.ptr(wpk), None,
                     nv.ptr(st), N, D, H, W, cin, cout, 0, 2, s)
         outs.append(out); stats.append(st)
     torch.cuda.synchronize()
     assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
     assert torch.equal(stats[0], stats[1])
     assert (z.float() == 0).float().mean() > 0.1          # the ReLU does clip a good part of the input
-    nfl = nv.lib().iunet_conv3_wgrad_slab_floats(3, N, D, H, W, cin, cout)
+    nfl = nv.lib().iunet_conv3_wgrad_slab_floats(nd, N, D, H, W, cin, cout)
     slab = torch.empty(nfl, device='cuda')
     dws = []
     for fused in (False, True):
-        dW = torch.full((cout, cin, 27), float('nan'), device='cuda')
+        dW = torch.full((cout, cin, taps), float('nan'), device='cuda')
         if fused:
-            nv.call('iunet_conv3_wgrad_act', dt, 3, nv.ptr(yb), cin * vox, nv.ptr(dyb), cout * vox, nv.ptr(slab), nv.ptr(dW),
+            nv.call('iunet_conv3_wgrad_act', dt, nd, nv.ptr(yb), cin * vox, nv.ptr(dyb), cout * vox, nv.ptr(slab), nv.ptr(dW),
                     1.0, nv.ptr(scale), nv.ptr(shift), N, D, H, W, cin, cout, s)
         else:
-            nv.call('iunet_conv3_wgrad', dt, 3, nv.ptr(z), cin * vox, nv.ptr(dyb), cout * vox, nv.ptr(slab), nv.ptr(dW),
+            nv.call('iunet_conv3_wgrad', dt, nd, nv.ptr(z), cin * vox, nv.ptr(dyb), cout * vox, nv.ptr(slab), nv.ptr(dW),
                     1.0, N, D, H, W, cin, cout, s)
         dws.append(dW)
     torch.cuda.synchronize()
