@@ -190,6 +190,13 @@ int iunet_first_conv_wgrad_blocks(int nd, int N, int D, int H, int W);
 int iunet_first_conv_wgrad(int dtype, int nd, const void* x, int in_dtype, const long long* in_strides, const void* dy,
                            long long dy_ss, void* slab, void* dW, int N, int D, int H, int W, int Cin, int Cout,
                            void* stream);
+/* the same with the second BatchNorm-backward pass folded in: dz = gradient of the first conv's activation, y = its raw
+ * output, coef from iunet_bn_relu_bwd called with dy = NULL (sums + coefficients only); the gradient of the raw output is
+ * never written. */
+int iunet_first_conv_wgrad_bn(int dtype, int nd, const void* x, int in_dtype, const long long* in_strides, const void* dz,
+                              long long dz_ss, const void* y, long long y_ss, const void* mean, const void* invstd,
+                              const void* coef, const void* scale, const void* shift, void* slab, void* dW, int N, int D, int H,
+                              int W, int Cin, int Cout, void* stream);
 /* AdamW with torch defaults (unet.py:71-73); grads are multiplied by grad_scale_inv (loss scaling, 1/world);
  * if *skip_flag != 0 (set by iunet_check_finite) the step is skipped. */
 int iunet_check_finite(const void* g, long long n, void* flag, void* stream);

@@ -344,6 +344,10 @@ __global__ __launch_bounds__(256) void convT_wgrad_reduce_kernel(const float* __
 struct FirstWgradParams {
   const void* x; long long sN, sC, sD, sH, sW; int in_dtype;
   const void* dy; long long dy_ss;
+  // optional BatchNorm + ReLU backward applied while staging: `dy` is then the gradient of the activation (dz), `yraw` the
+  // conv's raw output, and the operand is a * (dz * mask - c1 - xhat * c2) rounded as bn_bwd_apply_kernel stores it
+  const void* yraw; long long y_ss;
+  const float* mean; const float* invstd; const float* coef; const float* scale; const float* shift;
   float* slab;     // [nb][Cout][KKP]
   int N, D, H, W, Cin, Cout;
   int tilesZ, tilesY, tilesX;
@@ -396,8 +400,10 @@ __global__ __launch_bounds__(256, 2) void first_wgrad_kernel(FirstWgradParams p)
   // tile t and written to LDS after it
   constexpr int XIT = (NPIX * CIN + 255) / 256, YIT = NVOX * 4 / 256;
   float xr[XIT];
-  u32x4 yr[YIT];
+  u32x4 yr[YIT], yw[YIT];
+  unsigned oky = 0;                  // bit it: dy item `it` of the staged tile lies inside the image
   auto load_tile = [&](int tile) {
+    oky = 0;
     const int n = tile / tps;
     int trem = tile - n * tps;
     const int tz_i = trem / (p.tilesY * p.tilesX);
@@ -424,6 +430,13 @@ __global__ __launch_bounds__(256, 2) void first_wgrad_kernel(FirstWgradParams p)
       u32x4 v = u32x4{0u, 0u, 0u, 0u};
       if (gz < p.D && gy < p.H && gx < p.W) v = *(const u32x4*)(dyin + pl * plane + (((long long)gz * p.H + gy) * p.W + gx) * 8);
       yr[it] = v;
+      oky |= (gz < p.D && gy < p.H && gx < p.W) ? (1u << it) : 0u;
+      if (p.yraw != nullptr) {
+        u32x4 w = u32x4{0u, 0u, 0u, 0u};
+        if (gz < p.D && gy < p.H && gx < p.W)
+          w = *(const u32x4*)((const T*)p.yraw + (long long)n * p.y_ss + (long long)(cob * 4 + pl) * plane + (((long long)gz * p.H + gy) * p.W + gx) * 8);
+        yw[it] = w;
+      }
     }
   };
   auto commit_tile = [&]() {
@@ -435,7 +448,22 @@ __global__ __launch_bounds__(256, 2) void first_wgrad_kernel(FirstWgradParams p)
 #pragma unroll
     for (int it = 0; it < YIT; ++it) {
       const int idx = tid + it * 256, pl = idx / NVOX, pix = idx - pl * NVOX;
-      *(u32x4*)(dys + pl * PLANE_Y + pix * 16) = yr[it];
+      u32x4 v = yr[it];
+      if (p.yraw != nullptr && ((oky >> it) & 1u)) {      // dy = a * (dz * [z > 0] - c1 - xhat * c2) as bn_bwd_apply_kernel; outside the image: 0
+        const V8 g = __builtin_bit_cast(V8, v), yy = __builtin_bit_cast(V8, yw[it]);
+        V8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int c = cob * 32 + pl * 8 + j;
+          const float yv = to_f32<T>(yy[j]);
+          const float zv = to_f32<T>(from_f32<T>(fmaf(p.scale[c], yv, p.shift[c])));
+          const float d = zv > 0.f ? to_f32<T>(g[j]) : 0.f;
+          const float xh = (yv - p.mean[c]) * p.invstd[c];
+          o[j] = from_f32<T>(p.coef[c * 3] * (d - p.coef[c * 3 + 1] - xh * p.coef[c * 3 + 2]));
+        }
+        v = __builtin_bit_cast(u32x4, o);
+      }
+      *(u32x4*)(dys + pl * PLANE_Y + pix * 16) = v;
     }
   };
   if ((int)blockIdx.x < ntiles) load_tile(blockIdx.x);
@@ -595,15 +623,17 @@ int iunet_first_conv_wgrad_blocks(int nd, int N, int D, int H, int W) {
 }
 
 // slab: iunet_first_conv_wgrad_blocks * Cout * 112 floats of scratch; dW fp32 [Cout][Cin][taps]
-int iunet_first_conv_wgrad(int dtype, int nd, const void* x, int in_dtype, const long long* in_strides, const void* dy,
-                           long long dy_ss, void* slab, void* dW, int N, int D, int H, int W, int Cin, int Cout,
-                           void* stream) {
+static int first_wgrad_impl(int dtype, int nd, const void* x, int in_dtype, const long long* in_strides, const void* dy,
+                            long long dy_ss, void* slab, void* dW, int N, int D, int H, int W, int Cin, int Cout,
+                            const void* yraw, long long y_ss, const float* mean, const float* invstd, const float* coef,
+                            const float* scale, const float* shift, void* stream) {
   DT_OK(dtype);
   IUNET_REQUIRE(x && dy && slab && dW && in_strides, "first_conv_wgrad: null pointer");
   IUNET_REQUIRE(Cin >= 1 && Cin <= 4 && Cout % 32 == 0, "first_conv_wgrad: Cin 1..4, Cout multiple of 32");
   FirstWgradParams p;
   p.x = x; p.sN = in_strides[0]; p.sC = in_strides[1]; p.sD = in_strides[2]; p.sH = in_strides[3]; p.sW = in_strides[4];
   p.in_dtype = in_dtype; p.dy = dy; p.dy_ss = dy_ss; p.slab = (float*)slab;
+  p.yraw = yraw; p.y_ss = y_ss; p.mean = mean; p.invstd = invstd; p.coef = coef; p.scale = scale; p.shift = shift;
   p.N = N; p.D = D; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
   const int TZ = nd == 3 ? 4 : 1, TY = nd == 3 ? 8 : 16, TX = nd == 3 ? 16 : 32;
   p.tilesZ = (D + TZ - 1) / TZ; p.tilesY = (H + TY - 1) / TY; p.tilesX = (W + TX - 1) / TX;
@@ -626,6 +656,26 @@ int iunet_first_conv_wgrad(int dtype, int nd, const void* x, int in_dtype, const
                      (const float*)slab, nb, Cout, Cin, taps, KKP, (float*)dW);
   IUNET_CHECK_HIP(hipGetLastError());
   return IUNET_OK;
+}
+
+int iunet_first_conv_wgrad(int dtype, int nd, const void* x, int in_dtype, const long long* in_strides, const void* dy,
+                           long long dy_ss, void* slab, void* dW, int N, int D, int H, int W, int Cin, int Cout,
+                           void* stream) {
+  return first_wgrad_impl(dtype, nd, x, in_dtype, in_strides, dy, dy_ss, slab, dW, N, D, H, W, Cin, Cout, nullptr, 0, nullptr,
+                          nullptr, nullptr, nullptr, nullptr, stream);
+}
+
+// first_conv_wgrad with the second BatchNorm-backward pass folded in: dz = gradient of the first conv's activation, y = its raw
+// output; mean / invstd / scale / shift from the forward pass, coef [Cout][3] from the BatchNorm-backward reduction
+// (iunet_bn_relu_bwd with dy = NULL).  The gradient of the raw output is never written.
+int iunet_first_conv_wgrad_bn(int dtype, int nd, const void* x, int in_dtype, const long long* in_strides, const void* dz,
+                              long long dz_ss, const void* y, long long y_ss, const void* mean, const void* invstd,
+                              const void* coef, const void* scale, const void* shift, void* slab, void* dW, int N, int D, int H,
+                              int W, int Cin, int Cout, void* stream) {
+  IUNET_REQUIRE(y && mean && invstd && coef && scale && shift, "first_conv_wgrad_bn: null pointer");
+  return first_wgrad_impl(dtype, nd, x, in_dtype, in_strides, dz, dz_ss, slab, dW, N, D, H, W, Cin, Cout, y, y_ss,
+                          (const float*)mean, (const float*)invstd, (const float*)coef, (const float*)scale,
+                          (const float*)shift, stream);
 }
 
 }  // extern "C"

@@ -735,7 +735,7 @@ int iunet_bn_relu_bwd(int dtype, const void* dz, long long dz_ss, const void* z,
                       const void* scale, const void* shift, void* dgamma, void* dbeta, void* slab, void* coef, int C, int N,
                       long long vox, void* stream) {
   DT_OK(dtype);
-  IUNET_REQUIRE(dz && y && dy && slab && coef && scale && shift, "bn_relu_bwd: null pointer");
+  IUNET_REQUIRE(dz && y && slab && coef && scale && shift, "bn_relu_bwd: null pointer");      // dy NULL: sums + coefficients only
   const int per_block = BN_BWD_PER_BLOCK;
   const int chunks = (int)((vox + per_block - 1) / per_block);
   dim3 g1(chunks, C / 8, N);
@@ -743,6 +743,7 @@ int iunet_bn_relu_bwd(int dtype, const void* dz, long long dz_ss, const void* z,
   else hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16>, g1, dim3(256), 0, (hipStream_t)stream, (const bf16*)dz, dz_ss, (const bf16*)z, z_ss, (const bf16*)y, y_ss, (const float*)mean, (const float*)invstd, (const float*)scale, (const float*)shift, C, vox, per_block, (float*)slab);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, (const float*)slab, chunks * N, C,
                      (double)N * (double)vox, (const float*)gamma, (const float*)invstd, (float*)dgamma, (float*)dbeta, (float*)coef);
+  if (dy == nullptr) { IUNET_CHECK_HIP(hipGetLastError()); return IUNET_OK; }      // the consumer applies pass 2 while staging
   dim3 g2((unsigned)((vox + 511) / 512), C / 8, N);
   if (dtype == 0) hipLaunchKernelGGL(bn_bwd_apply_kernel<f16>, g2, dim3(256), 0, (hipStream_t)stream, (const f16*)dz, dz_ss, (const f16*)z, z_ss, (const f16*)y, y_ss, (f16*)dy, dy_ss, (const float*)mean, (const float*)invstd, (const float*)coef, (const float*)scale, (const float*)shift, C / 8, vox);
   else hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16>, g2, dim3(256), 0, (hipStream_t)stream, (const bf16*)dz, dz_ss, (const bf16*)z, z_ss, (const bf16*)y, y_ss, (bf16*)dy, dy_ss, (const float*)mean, (const float*)invstd, (const float*)coef, (const float*)scale, (const float*)shift, C / 8, vox);

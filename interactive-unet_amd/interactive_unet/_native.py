@@ -82,6 +82,9 @@ _SIGS = {
     'iunet_convT_wgrad': [c_int, c_int, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_void_p, c_void_p, c_void_p,
                           c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     'iunet_first_conv_wgrad_blocks': [c_int] * 5,
+    'iunet_first_conv_wgrad_bn': [c_int, c_int, c_void_p, c_int, ctypes.POINTER(c_ll), c_void_p, c_ll, c_void_p, c_ll, c_void_p,
+                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                  c_int, c_void_p],
     'iunet_first_conv_wgrad': [c_int, c_int, c_void_p, c_int, ctypes.POINTER(c_ll), c_void_p, c_ll, c_void_p, c_void_p,
                                c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
 }

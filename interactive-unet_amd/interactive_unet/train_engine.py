@@ -308,6 +308,7 @@ class TrainEngine:
         s = nv.stream()
         bn = name.replace('conv', 'bn')
         dy = ws['dy']
+        first = name == 'enc0.conv1'
         if pool_bwd is not None:
             # encoder stage: dz = skip gradient (dz_ptr) + max-pool backward of dpool, formed on the fly in both passes
             dp_ptr, dp_ss, do = pool_bwd
@@ -317,17 +318,20 @@ class TrainEngine:
                     nv.ptr(self.g(bn + '.weight')), nv.ptr(self.g(bn + '.bias')),
                     nv.ptr(ws['bnslab']), nv.ptr(ws['bncoef']), co, N, do[0], do[1], do[2], s)
         else:
-            # z is not passed: the ReLU mask is recomputed from y (saves one tensor read in each of the two passes)
+            # z is not passed: the ReLU mask is recomputed from y (saves one tensor read in each of the two passes).
+            # First layer: only the sums (dy = NULL) -- its single consumer, the weight gradient, applies pass 2 itself.
             nv.call('iunet_bn_relu_bwd', self.dt, dz_ptr, dz_ss, None, z_ss, self._P(ws['y.' + name]), co * v,
-                    self._P(dy), co * v, nv.ptr(ws['mean.' + name]), nv.ptr(ws['invstd.' + name]),
+                    None if first else self._P(dy), co * v, nv.ptr(ws['mean.' + name]), nv.ptr(ws['invstd.' + name]),
                     nv.ptr(self.p(bn + '.weight')), nv.ptr(ws['scale.' + name]), nv.ptr(ws['shift.' + name]),
                     nv.ptr(self.g(bn + '.weight')), nv.ptr(self.g(bn + '.bias')),
                     nv.ptr(ws['bnslab']), nv.ptr(ws['bncoef']), co, N, v, s)
         gw = self.g(name + '.weight')
-        if name == 'enc0.conv1':
+        if first:
             x, xs = x_raw
-            nv.call('iunet_first_conv_wgrad', self.dt, self.dim, nv.ptr(x), nv.IN_DTYPE_CODE[x.dtype], nv.ll_array(xs),
-                    self._P(dy), co * v, nv.ptr(ws['wslab']), nv.ptr(gw), N, d[0], d[1], d[2], ci, co, s)
+            nv.call('iunet_first_conv_wgrad_bn', self.dt, self.dim, nv.ptr(x), nv.IN_DTYPE_CODE[x.dtype], nv.ll_array(xs),
+                    dz_ptr, dz_ss, self._P(ws['y.' + name]), co * v, nv.ptr(ws['mean.' + name]), nv.ptr(ws['invstd.' + name]),
+                    nv.ptr(ws['bncoef']), nv.ptr(ws['scale.' + name]), nv.ptr(ws['shift.' + name]),
+                    nv.ptr(ws['wslab']), nv.ptr(gw), N, d[0], d[1], d[2], ci, co, s)
         else:
             if x_act is None:
                 nv.call('iunet_conv3_wgrad', self.dt, self.dim, x_ptr, x_ss, self._P(dy), co * v, nv.ptr(ws['wslab']),

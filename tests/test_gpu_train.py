@@ -464,3 +464,46 @@ def test_bn_relu_pool_bwd_equals_three_kernels(nv, nd):
     assert torch.allclose(res[0][1], res[1][1], rtol=1e-5, atol=1e-4) and torch.allclose(res[0][2], res[1][2], rtol=1e-5, atol=1e-4)
     d = (res[0][0].float() - res[1][0].float()).abs().max().item()
     assert d <= 2e-2 * res[0][0].float().abs().max().item() * 2 ** -7 + 1e-6, d     # identical up to the fp32 order of the sums
+
+
+@pytest.mark.parametrize('nd', [2, 3])
+def test_first_conv_wgrad_with_folded_bn_backward(nv, nd):
+    """iunet_bn_relu_bwd(dy = NULL) + iunet_first_conv_wgrad_bn == iunet_bn_relu_bwd + iunet_first_conv_wgrad, bit for bit."""
+    g = torch.Generator().manual_seed(37)
+    T, dt, dev = torch.bfloat16, 1, 'cuda'
+    N, cin, C = 2, 1, 32
+    shape = (24, 40) if nd == 2 else (6, 10, 24)
+    D, H, W = shape if nd == 3 else (1,) + shape
+    vox = D * H * W
+    x = torch.randint(0, 256, (N, cin) + shape, dtype=torch.uint8, generator=g).to(dev)
+    y = blocked(torch.randn((N, C) + shape, generator=g), T).to(dev)
+    dz = blocked(torch.randn((N, C) + shape, generator=g), T).to(dev)
+    gamma = (0.5 + torch.rand(C, generator=g)).to(dev)
+    mean, invstd = (0.1 * torch.randn(C, generator=g)).to(dev), (0.8 + 0.4 * torch.rand(C, generator=g)).to(dev)
+    scale = gamma * invstd
+    shift = (0.2 * torch.randn(C, generator=g)).to(dev) - mean * scale
+    s = nv.stream()
+    xs = nv.ll_array((cin * vox, vox, H * W, W, 1))
+    nparts = nv.lib().iunet_bn_bwd_num_parts(N, vox)
+    nb = nv.lib().iunet_first_conv_wgrad_blocks(nd, N, D, H, W)
+    res = []
+    for fused in (False, True):
+        dy = torch.zeros_like(y)
+        dgam, dbet = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+        slab, coef = torch.zeros(nparts * C * 2, device=dev), torch.zeros(C * 3, device=dev)
+        wslab = torch.zeros(nb * C * 112, device=dev)
+        dW = torch.zeros(C * cin * 3 ** nd, device=dev)
+        nv.call('iunet_bn_relu_bwd', dt, nv.ptr(dz), C * vox, None, 0, nv.ptr(y), C * vox, None if fused else nv.ptr(dy), C * vox,
+                nv.ptr(mean), nv.ptr(invstd), nv.ptr(gamma), nv.ptr(scale), nv.ptr(shift), nv.ptr(dgam), nv.ptr(dbet),
+                nv.ptr(slab), nv.ptr(coef), C, N, vox, s)
+        if fused:
+            nv.call('iunet_first_conv_wgrad_bn', dt, nd, nv.ptr(x), nv.IN_DTYPE_CODE[x.dtype], xs, nv.ptr(dz), C * vox,
+                    nv.ptr(y), C * vox, nv.ptr(mean), nv.ptr(invstd), nv.ptr(coef), nv.ptr(scale), nv.ptr(shift),
+                    nv.ptr(wslab), nv.ptr(dW), N, D, H, W, cin, C, s)
+        else:
+            nv.call('iunet_first_conv_wgrad', dt, nd, nv.ptr(x), nv.IN_DTYPE_CODE[x.dtype], xs, nv.ptr(dy), C * vox,
+                    nv.ptr(wslab), nv.ptr(dW), N, D, H, W, cin, C, s)
+        res.append((dW, dgam, dbet))
+    torch.cuda.synchronize()
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b)
