@@ -159,7 +159,11 @@ def test_data_parallel_step_over_rccl_single_rank():
     from interactive_unet.train_engine import TrainEngine
     if dist.is_initialized():
         pytest.skip('a process group already exists in this process')
-    dist.init_process_group('nccl', init_method='tcp://127.0.0.1:29533', rank=0, world_size=1,
+    import socket
+    with socket.socket() as sk:                      # a free port for the one-rank rendezvous
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1,
                             device_id=torch.device('cuda', 0))
     try:
         g = torch.Generator().manual_seed(41)
