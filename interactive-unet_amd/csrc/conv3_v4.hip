@@ -16,6 +16,7 @@
 // whole launch, when they fit: Cin <= 32 in 3-D, <= 64 in 2-D; else two step-sized buffers streamed with the activations).
 #include "common.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -40,7 +41,7 @@ struct ConvV4Params {
   int bz, by, bx;                             // tiles per brick (bz * by * bx = workgroups per XCD and Cout tile)
   int nbz, nby, nbx;                          // bricks per sample
   int epi;
-  int dbg;                                    // profiling only (IUNET_V4_DBG): 1 no refill after step 0, 2 no MFMA phase, 4 no stores
+  int dbg;                                    // profiling only (IUNET_V4_DBG): 2 no MFMA phase, 4 no stores
 };
 
 template <typename T, int ND, bool WS, bool SMALL>
@@ -89,6 +90,7 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + (WS ? 256 : 512)), 1
   }
   const long long plane_stride = (long long)p.D * p.H * p.W * 8;
   const int off_red = OFF_W + (WS ? nchunk : 2) * WSTEP;    // 2 KB of scratch for the BatchNorm partial sums
+  const int off_act = off_red + 2048;                       // the fused input activation: [Cin / 8][scale 8 | shift 8] floats
   const u32x4* wsrc = (const u32x4*)p.wpk + (long long)cob * nchunk * (WSTEP / 16);
 
   auto tile_origin = [&](int k, int& n_img, int& z0, int& y0, int& x0) -> bool {      // this workgroup's k-th tile
@@ -106,6 +108,15 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + (WS ? 256 : 512)), 1
     for (int i = tid; i < nitems; i += NCW * 64 + NLT) *(u32x4*)(smem + OFF_W + i * 16) = wsrc[i];
   }
 
+  if (p.in_scale != nullptr) {
+    float* ap = (float*)(smem + off_act);
+    for (int c = tid; c < p.Cin; c += NCW * 64 + NLT) {
+      ap[(c >> 3) * 16 + (c & 7)] = p.in_scale[c];
+      ap[(c >> 3) * 16 + 8 + (c & 7)] = p.in_shift[c];
+    }
+    __syncthreads();
+  }
+
   if (wave >= NCW) {
     // ================================================================== loader waves
     const int lt = tid - NCW * 64;
@@ -116,14 +127,33 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + (WS ? 256 : 512)), 1
       const int px = pix % PX, t2 = pix / PX;
       pcoord[it] = px | ((t2 % PY) << 8) | ((t2 / PY) << 16);
     }
-    struct Staged { u32x4 a[AIT][CP]; u32x4 w[WS ? 1 : WIT]; unsigned ok; };
+    struct Staged { u32x4 a[AIT][CP]; unsigned ok; };
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const int lw = __builtin_amdgcn_readfirstlane(lt >> 6);                 // loader wave index
+    // streamed weights go global -> LDS directly (LDS-DMA: no staging registers, no ds_write): a lane-linear copy of the
+    // step's WSTEP bytes; one wave instruction moves 64 x 16 B to M0-base + lane * 16.  The copy is in flight on the
+    // vector-memory counter; the wait for the activation loads that were issued before it retires it too (in order).
+    auto dma_weights = [&](int s, int buf) {           // the weights of step s -> weight buffer buf
+      const int chunk = s - (s / nchunk) * nchunk;
+      const u32x4* ws = wsrc + (long long)chunk * (WSTEP / 16);
+#pragma unroll
+      for (int it = 0; it < WIT; ++it) {
+        const int base = it * NLT + lw * 64;                                  // first item of this wave instruction
+        if (base < WSTEP / 16) {
+          const u32x4* gsrc = ws + min(base + (lt & 63), WSTEP / 16 - 1);
+          const unsigned dst = lds0 + OFF_W + buf * WSTEP + base * 16;
+          unsigned keep;
+          asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                       : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+        }
+      }
+    };
     auto load = [&](int s, Staged& r) {               // issue the global loads of step s (nothing consumes them here)
       const int chunk = s - (s / nchunk) * nchunk;
       int n_img, z0, y0, x0;
       tile_origin(s / nchunk, n_img, z0, y0, x0);
       const T* xc = (const T*)p.x + (long long)n_img * p.x_sstride + (long long)chunk * CP * plane_stride;
       r.ok = 0;
-      if (!(p.dbg & 32))
 #pragma unroll
       for (int it = 0; it < AIT; ++it) {
         const int px = pcoord[it] & 255, py = (pcoord[it] >> 8) & 255, pz = pcoord[it] >> 16;
@@ -135,72 +165,83 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + (WS ? 256 : 512)), 1
         for (int k = 0; k < CP; ++k) r.a[it][k] = *(const u32x4*)(xc + k * plane_stride + goff);
         r.ok |= ok ? (1u << it) : 0u;
       }
-      if (!WS && !(p.dbg & 16)) {
-        const u32x4* ws = wsrc + (long long)chunk * (WSTEP / 16);
-#pragma unroll
-        for (int it = 0; it < WIT; ++it) r.w[it] = ws[min(lt + it * NLT, WSTEP / 16 - 1)];
-      }
     };
-    auto commit = [&](int s, const Staged& r) {       // registers -> LDS buffer s & 1
+    // registers -> LDS buffer s & 1; ACT: z = relu(scale * y + shift), the arithmetic of bn_relu_fwd_kernel, with the
+    // per-channel pairs read from LDS (a global load here would sit on the vector-memory counter and its wait would
+    // drain the prefetched next step too)
+    auto commit = [&](int s, const Staged& r, auto ACT) {
+      constexpr bool act = decltype(ACT)::value;
       unsigned char* ab = smem + (s & 1) * ABUF;
+      const int cfirst = (s - (s / nchunk) * nchunk) * CP * 8;
 #pragma unroll
-      for (int it = 0; it < AIT; ++it) {
-        const int pix = lt + it * NLT;
-        if (pix < NPIX) {
-          const bool ok = (r.ok >> it) & 1u;
+      for (int k = 0; k < CP; ++k) {
+        float sc[8], sh[8];
+        if (act) {
+          const f32x4* ap = (const f32x4*)(smem + off_act) + (cfirst + k * 8) / 2;        // [channel / 8][scale 8 | shift 8]
+          const f32x4 s0 = ap[0], s1 = ap[1], h0 = ap[2], h1 = ap[3];
 #pragma unroll
-          for (int k = 0; k < CP; ++k) {
-            u32x4 v = r.a[it][k];
-            if (p.in_scale != nullptr) {               // z = relu(scale * y + shift), the arithmetic of bn_relu_fwd_kernel
-              const int cbase = ((s - (s / nchunk) * nchunk) * CP + k) * 8;
+          for (int j = 0; j < 4; ++j) { sc[j] = s0[j]; sc[4 + j] = s1[j]; sh[j] = h0[j]; sh[4 + j] = h1[j]; }
+        }
+#pragma unroll
+        for (int it = 0; it < AIT; ++it) {
+          const int pix = lt + it * NLT;
+          u32x4 v = r.a[it][k];
+          asm volatile("" : "+v"(v));          // the load is waited for on EVERY path (a wait only inside the branch below
+                                               // leaves it "pending" for the compiler, which then drains younger loads later)
+          if (pix < NPIX) {
+            const bool ok = (r.ok >> it) & 1u;
+            if (act) {
               const V8 in = __builtin_bit_cast(V8, v);
               V8 o;
 #pragma unroll
-              for (int j = 0; j < 8; ++j)
-                o[j] = from_f32<T>(fmaxf(fmaf(p.in_scale[cbase + j], to_f32<T>(in[j]), p.in_shift[cbase + j]), 0.f));
+              for (int j = 0; j < 8; ++j) o[j] = from_f32<T>(fmaxf(fmaf(sc[j], to_f32<T>(in[j]), sh[j]), 0.f));
               v = __builtin_bit_cast(u32x4, o);
             }
             *(u32x4*)(ab + k * PLANE + pix * 16) = ok ? v : u32x4{0u, 0u, 0u, 0u};      // padding stays zero AFTER the activation
           }
         }
       }
-      if (!WS) {
-        unsigned char* wb = smem + OFF_W + (s & 1) * WSTEP;
-#pragma unroll
-        for (int it = 0; it < WIT; ++it) {
-          const int idx = lt + it * NLT;
-          if (idx < WSTEP / 16) *(u32x4*)(wb + idx * 16) = r.w[it];
+    };
+    // Straight-line steps: every load / copy / commit of a step index past the end is clamped to the last step (its
+    // target buffer is not the one being read) instead of being skipped, so the compiler's vector-memory counting sees
+    // ONE path and waits for exactly the loads a commit needs, never for the younger prefetch.
+    auto run = [&](auto ACT) {
+      const int last = nsteps - 1;
+      Staged r;
+      if (!WS) dma_weights(0, 0);
+      load(0, r);
+      commit(0, r, ACT);
+      load(min(1, last), r);
+      if (!WS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the first weight copy has landed
+      lds_barrier();
+      if (WS) {
+        // one register set: step s + 1 is written to LDS, then the loads of step s + 2 are issued into the same registers
+        // and stay in flight over the barrier and the consumers' whole next step
+        for (int s = 0; s < nsteps; ++s) {
+          commit(s + 1, r, ACT);                                       // (buffer (s + 1) & 1: garbage after the last step, unread)
+          load(min(s + 2, last), r);
+          lds_barrier();
         }
+      } else {
+        // weights stream too (the loaders bound these layers): the weights of step s + 1 go by LDS-DMA into the buffer the
+        // consumers released at the last barrier; two register sets for the activations, the loads of step s + 2 are
+        // issued BEFORE step s + 1 is waited for and written, so two steps of loads are in flight
+        Staged r2;
+        int s = 0;
+        for (; s + 1 < nsteps; s += 2) {
+          dma_weights(s + 1, 1);
+          load(min(s + 2, last), r2);
+          commit(s + 1, r, ACT);
+          lds_barrier();
+          dma_weights(min(s + 2, last), 0);
+          load(min(s + 3, last), r);
+          commit(s + 2, r2, ACT);
+          lds_barrier();
+        }
+        if (s < nsteps) lds_barrier();                                 // odd step count: the last step has nothing to prefetch
       }
     };
-    const bool refill = !(p.dbg & 1);
-    Staged r;
-    load(0, r);
-    commit(0, r);
-    if (nsteps > 1 && refill) load(1, r);
-    lds_barrier();
-    if (WS) {
-      // one register set: step s + 1 is written to LDS, then the loads of step s + 2 are issued into the same registers
-      // and stay in flight over the barrier and the consumers' whole next step
-      for (int s = 0; s < nsteps; ++s) {
-        if (s + 1 < nsteps && refill) commit(s + 1, r);
-        if (s + 2 < nsteps && refill) load(s + 2, r);
-        lds_barrier();
-      }
-    } else {
-      // weights stream too (the loaders bound these layers): two register sets, the loads of step s + 2 are issued BEFORE
-      // step s + 1 is waited for and written, so two steps of loads are in flight
-      Staged r2;
-      for (int s = 0; s < nsteps; s += 2) {
-        if (s + 2 < nsteps && refill) load(s + 2, r2);
-        if (s + 1 < nsteps && refill) commit(s + 1, r);
-        lds_barrier();
-        if (s + 1 >= nsteps) break;
-        if (s + 3 < nsteps && refill) load(s + 3, r);
-        if (s + 2 < nsteps && refill) commit(s + 2, r2);
-        lds_barrier();
-      }
-    }
+    if (p.in_scale != nullptr) run(std::true_type{}); else run(std::false_type{});
     if (p.stats != nullptr) lds_barrier();            // the consumers' final statistics reduction
     return;
   }
@@ -348,7 +389,7 @@ int launch_v4(ConvV4Params p, hipStream_t stream) {
   constexpr int NPIX = (TL::TZ + 2 * TL::PADZ) * (TL::TY + 2) * (TL::TX + 2);
   constexpr int PLANE = ((NPIX * 16 + 255) / 256) * 256;
   constexpr int WSTEP = TL::S16 * ((TL::NCOL + 1) / 2) * 3 * 2 * 1024;
-  const int lds = 2 * 2 * TL::S16 * PLANE + (WS ? p.Cin / (16 * TL::S16) : 2) * WSTEP + 2048;
+  const int lds = 2 * 2 * TL::S16 * PLANE + (WS ? p.Cin / (16 * TL::S16) : 2) * WSTEP + 2048 + p.Cin * 8;
   static int attr_lds = 0;
   if (lds > attr_lds) {
     IUNET_CHECK_HIP(hipFuncSetAttribute((const void*)conv3_v4_kernel<T, ND, WS, SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
