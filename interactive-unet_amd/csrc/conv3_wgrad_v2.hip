@@ -50,8 +50,8 @@ __global__ __launch_bounds__(768, 1) void conv3_wgrad_v2_kernel(WgradV2Params p)
   constexpr int PLANE_Y = ((NVOX * 16 + 255) / 256) * 256 + 64;
   constexpr int OFF_Y = 4 * PLANE_X;
   constexpr int YBUF = 4 * PLANE_Y;
-  constexpr int NU = TAPS * 2, MAXU = (NU + 3) / 4;                // 54 units, 14 per unit wave
   constexpr int NCW = 8, NLT = 256;
+  constexpr int NU = TAPS * 2, MAXU = (NU + NCW - 1) / NCW;        // 54 units, 7 per consumer wave
   constexpr int XIT = (4 * ZPIX + 63) / 64;                        // 16-byte x items per loader lane: 4 z-planes of one channel plane (12)
   constexpr int YIT = NVOX * 4 / NLT;                              // dy items per loader thread (4)
   static_assert(PLANE_X % 256 == 64, "x plane stride must be 64 mod 256");
@@ -190,13 +190,16 @@ __global__ __launch_bounds__(768, 1) void conv3_wgrad_v2_kernel(WgradV2Params p)
       }
       if (k + 2 < nt && refill) load(k + 2, r);
     }
-    lds_barrier();          // the two barriers of the consumers' final reduction
-    lds_barrier();
     return;
   }
 
   // ==================================================================== consumer waves
-  const int kg = wave >> 2, uw = wave & 3;                         // voxel (k) half = z slice of the tile, unit wave
+  // Unit wave uw owns units u = uw + 8 i (unit = tap x ci half: a 32 co x 16 ci block of dW) and walks ALL eight k-steps of
+  // a tile, so its 7 x 2 accumulators are complete sums: no reduction between waves, and 56 accumulator registers leave
+  // room for a deep fragment pipeline.  (Splitting the voxels over two wave groups instead halved the dy fragment reads
+  // but needed 112 accumulator registers: at the 168-register cap the reads could not be issued ahead of their MFMAs.)
+  using V8 = typename Vec8<T>::type;
+  const int uw = wave;
   const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3;
   const int gh = g >> 1, gl = g & 1;
   // lane part of the tr-read addresses (bytes): voxel (gl*8 + q) of fragment gh, channels 4pp..4pp+3
@@ -206,7 +209,7 @@ __global__ __launch_bounds__(768, 1) void conv3_wgrad_v2_kernel(WgradV2Params p)
   int unit_dz[MAXU];
 #pragma unroll
   for (int i = 0; i < MAXU; ++i) {
-    const int u = uw + 4 * i;
+    const int u = uw + NCW * i;
     const int tap = (u < NU ? u : 0) >> 1, cih = u & 1;
     const int dz = tap / 9, dy_ = (tap / 3) % 3, dx = tap % 3;
     unit_off[i] = (unsigned)__builtin_amdgcn_readfirstlane((dy_ * PX + dx) * 16 + cih * 2 * PLANE_X);   // wave-uniform: scalar registers
@@ -219,27 +222,40 @@ __global__ __launch_bounds__(768, 1) void conv3_wgrad_v2_kernel(WgradV2Params p)
   int base = 0;
   lds_barrier();                                                 // tile 0 is in LDS
   for (int k = 0; k < nt; ++k) {
-    // this wave's output z slice is kg, so unit i reads halo plane pz = kg + dz_i -> ring slot (base + pz) mod 6
-    unsigned uoff[MAXU];
+    // k-step ks = output z slice ks / 4, rows 2 (ks % 4), 2 (ks % 4) + 1; unit i reads halo plane pz = z slice + dz_i
+    // -> ring slot (base + pz) mod 6
+    unsigned uoff[2][MAXU];
 #pragma unroll
-    for (int i = 0; i < MAXU; ++i)
-      uoff[i] = (unsigned)__builtin_amdgcn_readfirstlane((int)unit_off[i] + ((base + kg + unit_dz[i]) % NSLOT) * ZPIX * 16);
-    const unsigned yoff = (unsigned)((k & 1) * YBUF);
-    if (!(p.dbg & 2))
-#pragma unroll 2
-    for (int kk = 0; kk < NKS / 2; ++kk) {
-      const int f = 2 * (kg * (NKS / 2) + kk);                     // fragment pair (rows 2kk, 2kk + 1 of z slice kg)
-      const int fy = f % TY;
-      const unsigned offY = yoff + (unsigned)(f * 16 * 16);
-      const unsigned offX = (unsigned)(fy * PX * 16);
-      const typename Vec8<T>::type a0 = tr_frag_v2<T>(laneY + offY);                    // co 0..15
-      const typename Vec8<T>::type a1 = tr_frag_v2<T>(laneY + offY + 2 * PLANE_Y);      // co 16..31
-      // branch-free: a wave whose last unit does not exist (u >= NU) recomputes tap 0 into an accumulator that is never stored
+    for (int kz = 0; kz < 2; ++kz)
 #pragma unroll
-      for (int i = 0; i < MAXU; ++i) {
-        const typename Vec8<T>::type b = tr_frag_v2<T>(laneX + offX + uoff[i]);
-        acc[i][0] = mfma16<T>(a0, b, acc[i][0]);
-        acc[i][1] = mfma16<T>(a1, b, acc[i][1]);
+      for (int i = 0; i < MAXU; ++i)
+        uoff[kz][i] = (unsigned)__builtin_amdgcn_readfirstlane((int)unit_off[i] + ((base + kz + unit_dz[i]) % NSLOT) * ZPIX * 16);
+    if (!(p.dbg & 2)) {
+      // One flat, software-pipelined sequence of NKS x MAXU unit steps (2 MFMAs each): the x fragment of step t + DEPTH
+      // is read right after the MFMAs of step t, the dy fragments of the next k-step at the start of the current one, so
+      // every LDS read has DEPTH - 1 unit steps (64 MFMA cycles each) to land.  (Left to the compiler, each read was
+      // issued directly before its two MFMAs and waited for with lgkmcnt(0): the matrix pipe was busy 29 % of the time.)
+      constexpr int NSTEP = NKS * MAXU, DEPTH = 5;
+      const unsigned baseY = laneY + (unsigned)((k & 1) * YBUF);
+      auto rdA = [&](int ks, int h) { return tr_frag_v2<T>(baseY + (unsigned)(ks * 2 * 16 * 16 + h * 2 * PLANE_Y)); };
+      auto rdB = [&](int t) {
+        const int ks = t / MAXU;
+        return tr_frag_v2<T>(laneX + (unsigned)(2 * (ks & 3) * PX * 16) + uoff[ks >> 2][t % MAXU]);
+      };
+      V8 a[2][2], bq[DEPTH];
+      a[0][0] = rdA(0, 0); a[0][1] = rdA(0, 1);
+#pragma unroll
+      for (int d = 0; d < DEPTH; ++d) bq[d] = rdB(d);
+#pragma unroll
+      for (int t = 0; t < NSTEP; ++t) {
+        const int ks = t / MAXU, i = t % MAXU;
+        if (i == 0 && ks + 1 < NKS) { a[(ks + 1) & 1][0] = rdA(ks + 1, 0); a[(ks + 1) & 1][1] = rdA(ks + 1, 1); }
+        // branch-free: a wave whose last unit does not exist (u >= NU) recomputes tap 0 into an accumulator that is never stored
+        const V8 cur = bq[t % DEPTH];
+        acc[i][0] = mfma16<T>(a[ks & 1][0], cur, acc[i][0]);
+        acc[i][1] = mfma16<T>(a[ks & 1][1], cur, acc[i][1]);
+        if (t + DEPTH < NSTEP) bq[t % DEPTH] = rdB(t + DEPTH);
+        __builtin_amdgcn_sched_barrier(0);             // keep this order (the scheduler sinks the reads back to their MFMAs)
       }
     }
     lds_barrier();
@@ -251,32 +267,20 @@ __global__ __launch_bounds__(768, 1) void conv3_wgrad_v2_kernel(WgradV2Params p)
     }
   }
 
-  // ---- add the two k halves (through LDS, 28 KB per unit wave), then store the slab: rows = co (4g + j), cols = ci ----
-  f32x4* red = (f32x4*)smem + (uw * MAXU * 2) * 64 + lane;
-  if (kg == 1) {
+  // ---- store the slab: rows = co (4g + j), cols = ci ----
+  const int ncob = gridDim.y, ncib = gridDim.z;
+  float* slab = p.slab + ((((long long)blockIdx.x * ncob + cob) * ncib + cib) * TAPS) * 1024;
 #pragma unroll
-    for (int i = 0; i < MAXU; ++i) { red[(i * 2 + 0) * 64] = acc[i][0]; red[(i * 2 + 1) * 64] = acc[i][1]; }
-  }
-  lds_barrier();
-  if (kg == 0) {
-    const int ncob = gridDim.y, ncib = gridDim.z;
-    float* slab = p.slab + ((((long long)blockIdx.x * ncob + cob) * ncib + cib) * TAPS) * 1024;
+  for (int i = 0; i < MAXU; ++i) {
+    const int u = uw + NCW * i;
+    if (u < NU) {
+      const int tap = u >> 1, cih = u & 1;
 #pragma unroll
-    for (int i = 0; i < MAXU; ++i) {
-      const int u = uw + 4 * i;
-      if (u < NU) {
-        const int tap = u >> 1, cih = u & 1;
+      for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const f32x4 o = red[(i * 2 + t) * 64];
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            slab[tap * 1024 + (t * 16 + 4 * g + j) * 32 + cih * 16 + i16] = acc[i][t][j] + o[j];
-        }
-      }
+        for (int j = 0; j < 4; ++j) slab[tap * 1024 + (t * 16 + 4 * g + j) * 32 + cih * 16 + i16] = acc[i][t][j];
     }
   }
-  lds_barrier();
 }
 
 }  // namespace
@@ -300,9 +304,7 @@ int iunet_conv3_wgrad_v2_launch(int dtype, const void* x, long long x_ss, const 
   static const int dbg = getenv("IUNET_WG2_DBG") ? atoi(getenv("IUNET_WG2_DBG")) : 0;
   p.dbg = dbg;
   constexpr int PLANE_X = 6 * 180 * 16 + 192, PLANE_Y = 256 * 16 + 64;
-  constexpr int RING = 4 * PLANE_X + 2 * 4 * PLANE_Y;     // 103 168 B: x z-plane ring + two dy buffers
-  constexpr int RED = 4 * 14 * 2 * 64 * 16;                // 114 688 B: the k halves meet here at the end
-  constexpr int LDS = RED > RING ? RED : RING;
+  constexpr int LDS = 4 * PLANE_X + 2 * 4 * PLANE_Y;      // 103 168 B: x z-plane ring + two dy buffers
   const int nb = iunet_conv3_wgrad_v2_blocks(N, D, H, W, Cin, Cout);
   dim3 grid(nb, Cout / 32, Cin / 32);
   if (dtype == 0) {
