@@ -13,6 +13,14 @@
 #include "common.h"
 #include <cstdlib>
 
+#ifdef IUNET_STAMPS
+// Diagnostic build only (build.sh never defines IUNET_STAMPS): cycles and real time around the consumers' tile loop, to
+// read the in-kernel clock (s_memtime / s_memrealtime x 100 MHz) and the cycles per tile; tools/wgrad_clock.py reads them.
+__device__ unsigned long long g_wg2_stamps[4 * 512];
+extern "C" int iunet_wg2_stamps_read(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wg2_stamps), sizeof(unsigned long long) * 4 * 512);
+}
+#endif
 namespace {
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -221,6 +229,9 @@ __global__ __launch_bounds__(768, 1) void conv3_wgrad_v2_kernel(WgradV2Params p)
 
   int base = 0;
   lds_barrier();                                                 // tile 0 is in LDS
+#ifdef IUNET_STAMPS
+  const unsigned long long st0 = __builtin_amdgcn_s_memtime(), sr0 = __builtin_amdgcn_s_memrealtime();
+#endif
   for (int k = 0; k < nt; ++k) {
     // k-step ks = output z slice ks / 4, rows 2 (ks % 4), 2 (ks % 4) + 1; unit i reads halo plane pz = z slice + dz_i
     // -> ring slot (base + pz) mod 6
@@ -235,7 +246,10 @@ __global__ __launch_bounds__(768, 1) void conv3_wgrad_v2_kernel(WgradV2Params p)
       // is read right after the MFMAs of step t, the dy fragments of the next k-step at the start of the current one, so
       // every LDS read has DEPTH - 1 unit steps (64 MFMA cycles each) to land.  (Left to the compiler, each read was
       // issued directly before its two MFMAs and waited for with lgkmcnt(0): the matrix pipe was busy 29 % of the time.)
-      constexpr int NSTEP = NKS * MAXU, DEPTH = 5;
+#ifndef WG2_DEPTH
+#define WG2_DEPTH 5
+#endif
+      constexpr int NSTEP = NKS * MAXU, DEPTH = WG2_DEPTH;
       const unsigned baseY = laneY + (unsigned)((k & 1) * YBUF);
       auto rdA = [&](int ks, int h) { return tr_frag_v2<T>(baseY + (unsigned)(ks * 2 * 16 * 16 + h * 2 * PLANE_Y)); };
       auto rdB = [&](int t) {
@@ -252,9 +266,15 @@ __global__ __launch_bounds__(768, 1) void conv3_wgrad_v2_kernel(WgradV2Params p)
         if (i == 0 && ks + 1 < NKS) { a[(ks + 1) & 1][0] = rdA(ks + 1, 0); a[(ks + 1) & 1][1] = rdA(ks + 1, 1); }
         // branch-free: a wave whose last unit does not exist (u >= NU) recomputes tap 0 into an accumulator that is never stored
         const V8 cur = bq[t % DEPTH];
+#ifdef WG2_NOMFMA                                          // ablation builds (never defined by build.sh)
+        asm volatile("" :: "v"(cur), "v"(a[ks & 1][0]), "v"(a[ks & 1][1]));
+#else
         acc[i][0] = mfma16<T>(a[ks & 1][0], cur, acc[i][0]);
         acc[i][1] = mfma16<T>(a[ks & 1][1], cur, acc[i][1]);
+#endif
+#ifndef WG2_NOREAD
         if (t + DEPTH < NSTEP) bq[t % DEPTH] = rdB(t + DEPTH);
+#endif
         __builtin_amdgcn_sched_barrier(0);             // keep this order (the scheduler sinks the reads back to their MFMAs)
       }
     }
@@ -267,6 +287,12 @@ __global__ __launch_bounds__(768, 1) void conv3_wgrad_v2_kernel(WgradV2Params p)
     }
   }
 
+#ifdef IUNET_STAMPS
+  if (wave == 0 && lane == 0 && cob == 0 && cib == 0 && blockIdx.x < 512) {
+    const unsigned long long st1 = __builtin_amdgcn_s_memtime(), sr1 = __builtin_amdgcn_s_memrealtime();
+    g_wg2_stamps[blockIdx.x * 4 + 0] = st1 - st0; g_wg2_stamps[blockIdx.x * 4 + 1] = sr1 - sr0; g_wg2_stamps[blockIdx.x * 4 + 2] = nt;
+  }
+#endif
   // ---- store the slab: rows = co (4g + j), cols = ci ----
   const int ncob = gridDim.y, ncib = gridDim.z;
   float* slab = p.slab + ((((long long)blockIdx.x * ncob + cob) * ncib + cib) * TAPS) * 1024;
