@@ -18,6 +18,14 @@
 #include <cstdlib>
 #include <type_traits>
 
+#ifdef IUNET_STAMPS
+// Diagnostic build only (build.sh never defines IUNET_STAMPS): cycles and real time around the consumers' step loop, to
+// read the in-kernel clock (s_memtime / s_memrealtime x 100 MHz) and the cycles per step; tools/conv_clock.py reads them.
+__device__ unsigned long long g_v4_stamps[4 * 512];
+extern "C" int iunet_v4_stamps_read(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_v4_stamps), sizeof(unsigned long long) * 4 * 512);
+}
+#endif
 namespace {
 
 // tile shape, consumer waves (NCW; A/B: 4 waves x 8 fragments on the big 3-D tile measured the same, +-2 %), filter columns,
@@ -270,6 +278,9 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + (WS ? 256 : 512)), 1
 
   float stat_acc = 0.f;      // BatchNorm partial sums over all tiles of this workgroup: lane (q, l15) holds value l15 = which * 8 + j
   lds_barrier();                                             // step 0 (and the resident weights) are in LDS
+#ifdef IUNET_STAMPS
+  const unsigned long long st0 = __builtin_amdgcn_s_memtime(), sr0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
   for (int s = 0; s < nsteps; ++s) {
     const int chunk = s - (s / nchunk) * nchunk;
@@ -368,6 +379,12 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + (WS ? 256 : 512)), 1
     }
     lds_barrier();                 // consumers are done with this step's buffers, the loaders have filled the others
   }
+#ifdef IUNET_STAMPS
+  if (wave == 0 && lane == 0 && cob == 0 && blockIdx.x < 512) {
+    const unsigned long long st1 = __builtin_amdgcn_s_memtime(), sr1 = __builtin_amdgcn_s_memrealtime();
+    g_v4_stamps[blockIdx.x * 4 + 0] = st1 - st0; g_v4_stamps[blockIdx.x * 4 + 1] = sr1 - sr0; g_v4_stamps[blockIdx.x * 4 + 2] = nsteps;
+  }
+#endif
   if (p.stats != nullptr) {
     // the consumer waves' totals meet in LDS (wave order: deterministic) and become this workgroup's statistics row
     float* red = (float*)(smem + off_red);                     // [consumer waves][4 q][16]
