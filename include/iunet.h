@@ -119,6 +119,22 @@ int iunet_colorize(const void* cls, long long n, const void* palette, int ncls, 
 int iunet_slice_gather(const void* vol, int Z, int Y, int X, const double* geom, const int* lo, const int* len, int sw,
                        int start, int order, void* out, void* stream);
 
+/* ---- multiscale pyramid (utils.py:29-77 resize_volume / add_multiscales; SURVEY 8f "Zarr block I/O ... 0.5x nearest
+ * multiscale pyramid on device") ----------------------------------------------------------------------------------- */
+/* scipy.ndimage.zoom(x, zoom, order=0) index arithmetic for one axis (host only, no GPU): n_out = round-half-even(n_in *
+ * zoom); table[o] = floor(o * z + 0.5), z = (n_in - 1) / (n_out - 1) in double (1 if n_out == 1), or -1 where scipy's
+ * mode='constant' yields 0 (o * z > n_in - 1: the last sample of some sizes, e.g. 32 or 384 at zoom 0.5). */
+int iunet_zoom_nearest_len(int n_in, double zoom);
+int iunet_zoom_nearest_table(int n_in, double zoom, int* table, int n_out);
+/* dst uint8 [d0][d1][d2][d3] = src[t0[o0]][t1[o1]][t2[o2]][t3[o3]] (0 where any index is -1); src_dims, src_strides,
+ * dst_strides, dst_dims: 4 host values each, strides in bytes (source and destination may be blocks of larger volumes;
+ * the two inner destination axes must be contiguous); tables: device int32, the four tables concatenated (d0 + d1 + d2 +
+ * d3 entries, every entry -1 or < src_dims of its axis).  3-D volumes pass 1 for the fourth axis.  One call = one
+ * `dst[block] = ndimage.zoom(src[block], zoom, order=0)` of resize_volume (utils.py:46), or -- with tables that
+ * concatenate the blocks' tables, which is what the host side does -- the whole block loop of utils.py:33-48. */
+int iunet_zoom_nearest_u8(const void* src, const int* src_dims, const long long* src_strides, void* dst,
+                          const long long* dst_strides, const int* dst_dims, const int* tables, void* stream);
+
 /* ---- training step (replaces autograd + AMP + AdamW under unet.py:71-102, trainer.py:56-63) -- */
 /* BatchNorm batch statistics: slab = partial (sum, sumsq) [nparts][C][2] written by the conv
  * epilogues -> per-channel scale/shift (gamma*invstd, beta-mean*scale), mean, invstd; updates

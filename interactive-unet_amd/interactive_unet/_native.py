@@ -46,6 +46,9 @@ _SIGS = {
     'iunet_colorize': [c_void_p, c_ll, c_void_p, c_int, c_void_p, c_void_p],
     'iunet_slice_gather': [c_void_p, c_int, c_int, c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int),
                            ctypes.POINTER(c_int), c_int, c_int, c_int, c_void_p, c_void_p],
+    'iunet_zoom_nearest_table': [c_int, ctypes.c_double, ctypes.POINTER(c_int), c_int],
+    'iunet_zoom_nearest_u8': [c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(c_ll), c_void_p, ctypes.POINTER(c_ll),
+                              ctypes.POINTER(c_int), c_void_p, c_void_p],
     # ---- training
     'iunet_bn_finalize': [c_void_p, c_int, c_int, ctypes.c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                           c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
@@ -90,6 +93,7 @@ _SIGS = {
 }
 # functions that return a size / count instead of a status
 _INT_RETURN = ['iunet_pack_desc_bytes']
+_INT_RETURN_ARGS = {'iunet_zoom_nearest_len': [c_int, ctypes.c_double]}
 _LL_RETURN = {'iunet_conv3_wgrad_slab_floats': [c_int] * 7, 'iunet_pack_conv3_elems': [c_int] * 4,
               'iunet_pack_first_conv_elems': [c_int] * 3}
 
@@ -115,6 +119,9 @@ def lib():
         for name in _INT_RETURN:
             getattr(l, name).restype = c_int
             getattr(l, name).argtypes = []
+        for name, args in _INT_RETURN_ARGS.items():
+            getattr(l, name).restype = c_int
+            getattr(l, name).argtypes = args
         for name, args in _LL_RETURN.items():
             fn = getattr(l, name)
             fn.argtypes = args
@@ -124,7 +131,7 @@ def lib():
 
 
 def exported_symbols():
-    return ['iunet_last_error'] + list(_SIGS) + list(_LL_RETURN) + list(_INT_RETURN)
+    return ['iunet_last_error'] + list(_SIGS) + list(_LL_RETURN) + list(_INT_RETURN) + list(_INT_RETURN_ARGS)
 
 
 def check(status):

@@ -14,6 +14,7 @@ import numpy as np
 import torch
 
 from . import _native as nv
+from . import utils
 
 
 # --------------------------------------------------------------------------- helpers (predict.py:270-411)
@@ -309,5 +310,7 @@ def predict_volumes(input_size=256, num_channels=1, num_classes=2, overlap=0.25,
         arr = root.create_array(name='0', shape=list(final.shape), dtype='uint8', overwrite=True,
                                 chunks=(chunk_size,) * 3 + (num_classes,), shards=(shard_size,) * 3 + (num_classes,))
         arr[...] = final.cpu().numpy()
+        del root, arr
+        utils.add_multiscales(save_path, scale=0.5)                      # predict.py:261 (levels zoomed on the device)
         print(f'Completed volume {os.path.basename(f)} {tuple(volume.shape)} in {time.time() - start}.')
     print('\nAll volumes segmented.\n')

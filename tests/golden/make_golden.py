@@ -4,7 +4,7 @@
 
 Imports /root/reference/interactive_unet/{metrics,slicer}.py as they are and exec's the
 pure helper line ranges of predict.py (79-112 and 270-411; the module itself does not
-parse on Python 3.10 and imports zarr).  Writes small .npz fixtures next to this file.
+parse on Python 3.10 and imports zarr) and of utils.py (29-48, resize_volume; the module imports cv2, zarr, numba).  Writes small .npz fixtures next to this file.
 The fixtures hold only inputs and expected outputs -- no reference source text.
 The reference never travels to the GPU box; tests there read the .npz files.
 """
@@ -208,7 +208,33 @@ def make_slicer():
     print('slicer.npz done')
 
 
+def ref_resize_volume():
+    from scipy import ndimage
+    src = open(os.path.join(REF, 'interactive_unet', 'utils.py')).read().split('\n')
+    ns = {'np': np, 'ndimage': ndimage}
+    exec('\n'.join(src[28:48]), ns)       # resize_volume           (utils.py:29-48)
+    return ns['resize_volume']
+
+
+def make_multiscale():
+    """resize_volume of the reference on small uint8 volumes: several blocks per axis, ragged last blocks, sizes whose
+    last sample scipy fills with 0 (32, 48, 56), a 4-D [V, V, V, C] prediction volume (the channel axis is zoomed too)."""
+    rv = ref_resize_volume()
+    rng = np.random.default_rng(5)
+    out = {}
+    cases = [((40, 32, 70), 16), ((64, 48, 56), 32), ((50, 50, 50), 512), ((24, 24, 24, 2), 8), ((32, 20, 36, 4), 16)]
+    for i, (shape, block) in enumerate(cases):
+        src = rng.integers(1, 256, shape, dtype=np.uint8)          # never 0: scipy's constant fill is visible
+        dst = np.full(tuple(int(x * 0.5) for x in shape), 7, dtype=np.uint8)
+        rv(src, dst, scale=0.5, block_size=block, order=0)
+        out[f'c{i}_src'], out[f'c{i}_dst'], out[f'c{i}_block'] = src, dst, np.array(block)
+    out['n'] = np.array(len(cases))
+    np.savez_compressed(os.path.join(HERE, 'multiscale.npz'), **out)
+    print('multiscale.npz done')
+
+
 if __name__ == '__main__':
+    make_multiscale()
     make_losses()
     make_predict()
     make_slicer()

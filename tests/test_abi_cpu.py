@@ -37,3 +37,25 @@ def test_error_reporting_without_gpu():
     assert rc < 0 and b'dtype' in l.iunet_last_error()
     with pytest.raises(nv.NativeError):
         nv.check(rc)
+
+
+def test_zoom_table_host_function_matches_oracle():
+    """iunet_zoom_nearest_table / _len are host-only arithmetic (no GPU): identical to the oracle's table (itself pinned
+    against scipy.ndimage.zoom in test_oracle_golden.py), and bad arguments are refused."""
+    import numpy as np
+    from oracle import multiscale_ref as mr
+    nv, _ = _lib()
+    l = nv.lib()
+    for n in list(range(1, 200)) + [255, 256, 257, 384, 512, 1000, 1024]:
+        for zoom in (0.5, 0.25, 0.3, 0.75):
+            want = mr.zoom_table(n, zoom)
+            m = l.iunet_zoom_nearest_len(n, zoom)
+            assert m == len(want), (n, zoom)
+            if m == 0:
+                continue
+            t = (nv.c_int * m)()
+            assert l.iunet_zoom_nearest_table(n, zoom, t, m) == 0
+            assert np.array_equal(np.frombuffer(t, dtype=np.int32), want), (n, zoom)
+    t = (nv.c_int * 4)()
+    assert l.iunet_zoom_nearest_table(8, 0.5, t, 3) < 0 and b'n_out' in l.iunet_last_error()
+    assert l.iunet_zoom_nearest_len(0, 0.5) == 0

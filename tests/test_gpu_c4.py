@@ -76,3 +76,29 @@ def test_c4_full_size_volume_properties():
     d = np.abs(got_c.astype(int) - want_c.astype(int))
     print(f'C4 corner vs oracle: max |uint8 diff| = {d.max()}, differing = {(d > 0).mean():.4f}')
     assert d.max() <= 2
+
+
+def test_c4_full_size_pyramid():
+    """The multiscale pyramid of a 1024^3 uint8 volume (utils.py:50-77: 128^3 chunks, 256^3 shards -> levels 512^3, 256^3,
+    128^3) on the device.  Checked exactly against the scipy-pinned oracle on sampled shards of every level, plus the
+    size-independent property that with 256^3 blocks of an even size nothing is constant-filled: every level is a pure
+    gather, so its value histogram support is a subset of the source's and level l only holds voxels of level l - 1."""
+    from interactive_unet import utils
+    from oracle import multiscale_ref as mr
+    V = (1024, 1024, 1024)
+    g = torch.Generator(device='cuda').manual_seed(7)
+    vol = torch.randint(1, 256, V, dtype=torch.uint8, device='cuda', generator=g)        # no zeros: a constant fill would show
+    levels = utils.multiscale_levels(vol, (128,) * 3, (256,) * 3)
+    assert [tuple(l.shape) for l in levels] == [(512,) * 3, (256,) * 3, (128,) * 3]
+    src = vol
+    rng = np.random.default_rng(3)
+    for lv in levels:
+        assert int((lv == 0).sum()) == 0
+        nb = src.shape[0] // 256
+        picks = {(0, 0, 0), (nb - 1, nb - 1, nb - 1)} | {tuple(rng.integers(0, nb, 3)) for _ in range(2)}
+        for bi, bj, bk in picks:
+            blk = src[bi * 256:(bi + 1) * 256, bj * 256:(bj + 1) * 256, bk * 256:(bk + 1) * 256].cpu().numpy()
+            want = mr.zoom_nearest(blk, 0.5)
+            got = lv[bi * 128:(bi + 1) * 128, bj * 128:(bj + 1) * 128, bk * 128:(bk + 1) * 128].cpu().numpy()
+            assert np.array_equal(got, want), (tuple(lv.shape), bi, bj, bk)
+        src = lv

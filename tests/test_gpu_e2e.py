@@ -179,3 +179,43 @@ def test_data_parallel_step_over_rccl_single_rank():
         assert losses[0][2] < losses[0][0]
     finally:
         dist.destroy_process_group()
+
+
+def test_multiscale_pyramid_bit_exact(golden_dir):
+    """utils.resize_volume / multiscale_levels on the device (iunet_zoom_nearest_u8) against (a) the volumes the REFERENCE's
+    resize_volume produced (tests/golden/multiscale.npz: several blocks per axis, ragged blocks, scipy's constant fill,
+    4-D prediction volumes), device-resident and host-staged, and (b) the oracle on larger volumes and a whole pyramid:
+    identical bytes.  Odd blocks whose zoomed shape does not fit their slot raise like numpy does in the reference."""
+    from interactive_unet import utils
+    from oracle import multiscale_ref as mr
+    g = np.load(os.path.join(golden_dir, 'multiscale.npz'))
+    for i in range(int(g['n'])):
+        src, want, block = g[f'c{i}_src'], g[f'c{i}_dst'], int(g[f'c{i}_block'])
+        dst = torch.full(want.shape, 7, dtype=torch.uint8, device='cuda')
+        utils.resize_volume(torch.tensor(src).cuda(), dst, scale=0.5, block_size=block, order=0)
+        assert np.array_equal(dst.cpu().numpy(), want), i
+        host = np.full_like(want, 7)                                    # host (Zarr-like) arrays: blocks staged through the GPU
+        utils.resize_volume(src, host, scale=0.5, block_size=block, order=0)
+        assert np.array_equal(host, want), i
+    rng = np.random.default_rng(11)
+    for shape, block in [((130, 96, 258), 64), ((96, 64, 80, 2), 32), ((64, 64, 64, 3), 64), ((33, 35, 37), 512)]:
+        src = rng.integers(1, 256, shape, dtype=np.uint8)
+        want = np.full(tuple(int(x * 0.5) for x in shape), 9, dtype=np.uint8)
+        try:
+            mr.resize_volume(src, want, 0.5, block)
+        except ValueError:
+            with pytest.raises(ValueError):
+                utils.resize_volume(torch.tensor(src).cuda(), torch.empty(want.shape, dtype=torch.uint8, device='cuda'), 0.5, block)
+            continue
+        dst = torch.full(want.shape, 9, dtype=torch.uint8, device='cuda')
+        utils.resize_volume(torch.tensor(src).cuda(), dst, scale=0.5, block_size=block)
+        assert np.array_equal(dst.cpu().numpy(), want), shape
+    # a whole pyramid (add_multiscales on arrays): 256 x 192 x 320 with 32^3 chunks and 64^3 shards -> 3 levels
+    vol = rng.integers(0, 256, (256, 192, 320), dtype=np.uint8)
+    want = mr.multiscale_levels(vol, (32,) * 3, (64,) * 3)
+    got = utils.multiscale_levels(torch.tensor(vol).cuda(), (32,) * 3, (64,) * 3)
+    assert len(got) == len(want) == 3
+    for a, b in zip(got, want):
+        assert np.array_equal(a.cpu().numpy(), b)
+    with pytest.raises(ValueError):
+        utils.resize_volume(torch.tensor(vol).cuda(), got[0], order=1)

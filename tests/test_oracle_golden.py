@@ -1,5 +1,5 @@
 """Oracle vs golden vectors captured from the reference (tests/golden/make_golden.py).
-CPU only.  Pins oracle/{metrics,predict,slicer}_ref.py to the reference's own outputs."""
+CPU only.  Pins oracle/{metrics,predict,slicer,multiscale}_ref.py to the reference's own outputs."""
 import os
 import numpy as np
 import pytest
@@ -134,3 +134,38 @@ def test_e4m3_rounding_matches_torch_float8():
     q = unet_ref.quantize_e4m3(w)
     assert torch.equal(q.half().float(), q) and torch.equal(q.bfloat16().float(), q)        # exact in both 16-bit types
     assert (q - w).abs().max() <= w.abs().amax(dim=(1, 2, 3, 4)).max() * 2 ** -4             # half an e4m3 step at the top binade
+
+
+def test_multiscale_oracle_matches_reference_resize_volume(golden_dir):
+    """oracle/multiscale_ref.py against the reference's resize_volume (utils.py:29-48) on the golden volumes: several
+    blocks per axis, ragged last blocks, the sizes whose last sample scipy fills with 0, 4-D prediction volumes."""
+    from oracle import multiscale_ref as mr
+    g = np.load(os.path.join(golden_dir, 'multiscale.npz'))
+    zeros = 0
+    for i in range(int(g['n'])):
+        src, want, block = g[f'c{i}_src'], g[f'c{i}_dst'], int(g[f'c{i}_block'])
+        got = np.full_like(want, 7)
+        mr.resize_volume(src, got, 0.5, block)
+        assert np.array_equal(got, want), i
+        zeros += int((want == 0).sum())
+    assert zeros > 0          # the constant-fill quirk is exercised (the sources hold no zeros)
+
+
+def test_multiscale_oracle_matches_scipy_zoom():
+    """The per-axis index table against scipy.ndimage.zoom(order=0) itself (the third-party call under utils.py:46) for every
+    length 1..300, powers of two and their neighbours, several zoom factors; N-d zoom on random uint8 blocks."""
+    from scipy import ndimage
+    from oracle import multiscale_ref as mr
+    for n in list(range(1, 301)) + [511, 512, 513, 1000, 1023, 1024, 1025, 2048]:
+        a = np.arange(1, n + 1, dtype=np.int64)
+        for zoom in (0.5, 0.25, 0.3, 0.75, 0.125):
+            t = mr.zoom_table(n, zoom)
+            if len(t) == 0:
+                continue
+            assert np.array_equal(ndimage.zoom(a, zoom, order=0), np.where(t < 0, 0, a[np.clip(t, 0, n - 1)])), (n, zoom)
+    rng = np.random.default_rng(0)
+    for shape in [(40, 33, 70), (32, 48, 56), (7, 9, 11), (20, 20, 20, 2), (16, 16, 16, 3)]:
+        x = rng.integers(1, 255, shape, dtype=np.uint8)
+        for zoom in (0.5, 0.25):
+            assert np.array_equal(ndimage.zoom(x, zoom, order=0), mr.zoom_nearest(x, zoom)), (shape, zoom)
+    assert mr.num_steps((1024,) * 3, (128,) * 3) == 3 and mr.num_steps((300, 260, 129), (128,) * 3) == 1
