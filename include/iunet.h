@@ -118,6 +118,14 @@ int iunet_colorize(const void* cls, long long n, const void* palette, int ncls, 
  * lo, len: host ints [3] (the reference's bounding-box crop). */
 int iunet_slice_gather(const void* vol, int Z, int Y, int X, const double* geom, const int* lo, const int* len, int sw,
                        int start, int order, void* out, void* stream);
+/* Slicer.update_volume (slicer.py:230-257): vol[round-half-even(origin + a * r_i + b * r_j), clipped to the volume] =
+ * data[i][j] for the sw x sw pixels in row-major order -- where several pixels land on one voxel the last one wins, as in
+ * numpy's fancy-index assignment (resolved on the device through an owner table, so the result is deterministic).
+ * vol: uint8 [Z][Y][X][C] (C = 1: plain volume), data: uint8 [sw][sw][C], both on the device; geom as above; workspace:
+ * iunet_slice_scatter_workspace_bytes(sw) bytes of device memory; sw <= 1024. */
+long long iunet_slice_scatter_workspace_bytes(int sw);
+int iunet_slice_scatter(void* vol, int Z, int Y, int X, int C, const double* geom, int sw, int start, const void* data,
+                        void* workspace, void* stream);
 
 /* ---- multiscale pyramid (utils.py:29-77 resize_volume / add_multiscales; SURVEY 8f "Zarr block I/O ... 0.5x nearest
  * multiscale pyramid on device") ----------------------------------------------------------------------------------- */

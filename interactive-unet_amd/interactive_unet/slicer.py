@@ -145,7 +145,32 @@ class Slicer(object):
         crop = volume[lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]]
         return ndimage.map_coordinates(crop, coords - lo[:, None, None], order=order)
 
+    def _update_volume_device(self, data, volume, axis):
+        """slicer.py:230-257 on a resident uint8 volume ([Z, Y, X] or [Z, Y, X, C]): one scatter on the device, duplicates
+        resolved like numpy's assignment (the last pixel in row-major order wins)."""
+        import ctypes
+        import torch
+        from . import _native as nv
+        if volume.dtype != torch.uint8 or volume.dim() not in (3, 4) or not volume.is_contiguous():
+            raise NotImplementedError('device update_volume handles contiguous uint8 [Z, Y, X] / [Z, Y, X, C] volumes')
+        d = data if torch.is_tensor(data) else torch.from_numpy(np.ascontiguousarray(data))
+        d = d.to(device=volume.device, dtype=torch.uint8).contiguous()
+        C = 1 if volume.dim() == 3 else int(volume.shape[3])
+        sw = int(d.shape[0])
+        if d.numel() != sw * sw * C:
+            raise ValueError(f'shape mismatch: data {tuple(d.shape)} for a volume with {C} channel(s)')
+        a, b = self._plane_vectors(axis)
+        start = int(-np.floor(sw / 2))
+        geom = (ctypes.c_double * 9)(*[float(t) for t in (*a, *b, *np.asarray(self.origin, float))])
+        ws = torch.empty(int(nv.lib().iunet_slice_scatter_workspace_bytes(sw)), dtype=torch.uint8, device=volume.device)
+        with torch.cuda.device(volume.device):
+            nv.call('iunet_slice_scatter', nv.ptr(volume), int(volume.shape[0]), int(volume.shape[1]), int(volume.shape[2]), C,
+                    geom, sw, start, nv.ptr(d), nv.ptr(ws), nv.stream())
+        return volume
+
     def update_volume(self, data, volume, axis=0):
+        if hasattr(volume, 'is_cuda') and volume.is_cuda:
+            return self._update_volume_device(data, volume, axis)
         coords = self.get_interpolation_coords(slice_width=data.shape[0])[axis]
         idx = np.round(coords).reshape(3, -1).astype(int)
         idx = np.array([np.clip(idx[i], 0, volume.shape[i] - 1) for i in range(3)])

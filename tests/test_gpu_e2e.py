@@ -219,3 +219,33 @@ def test_multiscale_pyramid_bit_exact(golden_dir):
         assert np.array_equal(a.cpu().numpy(), b)
     with pytest.raises(ValueError):
         utils.resize_volume(torch.tensor(vol).cuda(), got[0], order=1)
+
+
+def test_device_update_volume_bit_exact(golden_dir):
+    """Slicer.update_volume on a resident uint8 volume (iunet_slice_scatter) against (a) the volumes the REFERENCE wrote for
+    the golden poses (tests/golden/slicer.npz) and (b) the numpy path of the host mirror (pinned by the same goldens) on poses
+    with many duplicate targets: slices larger than the volume (everything outside is clipped onto the faces), oblique
+    planes, 4-D [Z, Y, X, C] volumes.  Identical bytes: the last pixel in row-major order wins, as in numpy."""
+    from interactive_unet.slicer import Slicer
+    g = np.load(os.path.join(golden_dir, 'slicer.npz'))
+    for i in range(int(g['n'])):
+        s = Slicer(volume_shape=[32, 32, 32])
+        s.update_orientation_vectors(g[f's{i}_rv'])
+        s.origin = g[f's{i}_origin'].copy()
+        vol = torch.tensor(g['vol']).cuda()
+        out = s.update_volume(g[f's{i}_upd_data'], vol, axis=1)
+        assert out is vol and np.array_equal(vol.cpu().numpy(), g[f's{i}_upd_vol']), i
+    rng = np.random.default_rng(21)
+    for trial in range(12):
+        shape = [int(v) for v in rng.integers(20, 70, 3)]
+        C = [None, 3][trial % 2]
+        s = Slicer(volume_shape=shape)
+        s.update_orientation_vectors(rng.normal(size=3))
+        s.origin = np.array(shape) * rng.random(3)
+        sw = int(rng.choice([16, 31, 64, 100, 129]))
+        data = rng.integers(0, 256, (sw, sw) if C is None else (sw, sw, C), dtype=np.uint8)
+        base = rng.integers(0, 256, shape if C is None else shape + [C], dtype=np.uint8)
+        for axis in (0, 1, 2):
+            want = s.update_volume(data, base.copy(), axis=axis)                 # numpy path (host mirror)
+            got = s.update_volume(data, torch.tensor(base).cuda(), axis=axis)
+            assert np.array_equal(got.cpu().numpy(), want), (trial, axis)
