@@ -143,6 +143,19 @@ int iunet_zoom_nearest_table(int n_in, double zoom, int* table, int n_out);
 int iunet_zoom_nearest_u8(const void* src, const int* src_dims, const long long* src_strides, void* dst,
                           const long long* dst_strides, const int* dst_dims, const int* tables, void* stream);
 
+/* ---- batch producer (loader.py:28-44, :125-154; SURVEY 8f "Batch producer") ------------------------------------------ */
+/* One launch = one batch of UNetDataset.__getitem__ results: for sample b, X[b] = image, y[b] = mask, w[b] = weight of the
+ * annotation after hflip, vflip, rotation (nearest, zero padding), crop + nearest resize to OH x OW, as fp16 of
+ * float32(uint8 / 255), mask and weight zero where image channel 0 is 0 (loader.py:40-42), weight repeated over the C
+ * classes.  descs: device array of B descriptors (struct AugDesc in csrc/augment.hip, mirrored by
+ * interactive_unet/loader.py; iunet_augment_desc_bytes() = its size): source pointers (uint8 [H][W][ch], [H][W][C],
+ * [H][W]), the rotation's base grids and rescaled matrix, flip flags, crop box.  lut_f16: 256 fp16 values on the device.
+ * X [B][ch][OH][OW], y and w [B][C][OH][OW] fp16.  The index arithmetic is torchvision's (v2 rotate / resized_crop on
+ * CPU tensors), see oracle/loader_ref.py. */
+int iunet_augment_desc_bytes(void);
+int iunet_augment_batch(const void* descs, int B, int ch, int C, int OH, int OW, const void* lut_f16, void* X, void* y, void* w,
+                        void* stream);
+
 /* ---- training step (replaces autograd + AMP + AdamW under unet.py:71-102, trainer.py:56-63) -- */
 /* BatchNorm batch statistics: slab = partial (sum, sumsq) [nparts][C][2] written by the conv
  * epilogues -> per-channel scale/shift (gamma*invstd, beta-mean*scale), mean, invstd; updates

@@ -48,6 +48,7 @@ _SIGS = {
                            ctypes.POINTER(c_int), c_int, c_int, c_int, c_void_p, c_void_p],
     'iunet_slice_scatter': [c_void_p, c_int, c_int, c_int, c_int, ctypes.POINTER(ctypes.c_double), c_int, c_int, c_void_p, c_void_p,
                             c_void_p],
+    'iunet_augment_batch': [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     'iunet_zoom_nearest_table': [c_int, ctypes.c_double, ctypes.POINTER(c_int), c_int],
     'iunet_zoom_nearest_u8': [c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(c_ll), c_void_p, ctypes.POINTER(c_ll),
                               ctypes.POINTER(c_int), c_void_p, c_void_p],
@@ -94,7 +95,7 @@ _SIGS = {
                                c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
 }
 # functions that return a size / count instead of a status
-_INT_RETURN = ['iunet_pack_desc_bytes']
+_INT_RETURN = ['iunet_pack_desc_bytes', 'iunet_augment_desc_bytes']
 _INT_RETURN_ARGS = {'iunet_zoom_nearest_len': [c_int, ctypes.c_double]}
 _LL_RETURN = {'iunet_conv3_wgrad_slab_floats': [c_int] * 7, 'iunet_pack_conv3_elems': [c_int] * 4,
               'iunet_pack_first_conv_elems': [c_int] * 3, 'iunet_slice_scatter_workspace_bytes': [c_int]}

@@ -22,11 +22,7 @@ METRICS = ('Loss', 'Dice', 'IoU', 'MCC')
 
 
 def _loaders(num_classes, batch_size, reslice, reslice_factor):
-    try:
-        from . import loader                       # the caller-side batch producer (loader.py:84-101)
-    except ImportError as e:
-        raise ImportError('train_model needs train_loader/val_loader arguments or the reference loader module '
-                          '(TIFF + torchvision batch producer, outside the native hot path)') from e
+    from . import loader                           # the device batch producer (loader.py:84-101)
     tr = loader.get_data_loader(set_type='train', num_classes=num_classes, batch_size=batch_size, reslice=reslice,
                                 reslice_factor=reslice_factor, augment=True, shuffle=True)
     va = loader.get_data_loader(set_type='val', num_classes=num_classes, batch_size=batch_size, reslice=False,

@@ -4,7 +4,8 @@
 
 Imports /root/reference/interactive_unet/{metrics,slicer}.py as they are and exec's the
 pure helper line ranges of predict.py (79-112 and 270-411; the module itself does not
-parse on Python 3.10 and imports zarr) and of utils.py (29-48, resize_volume; the module imports cv2, zarr, numba).  Writes small .npz fixtures next to this file.
+parse on Python 3.10 and imports zarr) and of utils.py (29-48, resize_volume; the module imports cv2, zarr, numba) and loader.py (32-42, the normalisation
+block of load_annotations; the module imports skimage and torchvision).  Writes small .npz fixtures next to this file.
 The fixtures hold only inputs and expected outputs -- no reference source text.
 The reference never travels to the GPU box; tests there read the .npz files.
 """
@@ -233,7 +234,35 @@ def make_multiscale():
     print('multiscale.npz done')
 
 
+def make_loader():
+    """The normalisation block of load_annotations (loader.py:32-42, the body of its per-file loop) exec'd on small uint8
+    annotations: 2-D and multi-channel images, zeros in the image (mask / weight zeroing), 2 and 3 classes."""
+    import textwrap
+    src = open(os.path.join(REF, 'interactive_unet', 'loader.py')).read().split('\n')
+    first = next(k for k, l in enumerate(src) if 'if len(image_slice.shape) == 2:' in l)
+    last = next(k for k, l in enumerate(src) if 'mask_slice[c][image_slice[0] == 0] = 0.0' in l)
+    assert (first, last) == (31, 41), (first, last)                      # loader.py:32-42
+    block = textwrap.dedent('\n'.join(src[first:last + 1]))
+    rng = np.random.default_rng(9)
+    out = {}
+    cases = [((24, 20), 2, None), ((17, 31), 3, None), ((16, 16), 2, 3)]
+    for k, (hw, C, ch) in enumerate(cases):
+        image = rng.integers(0, 256, hw if ch is None else hw + (ch,), dtype=np.uint8)
+        image[rng.random(image.shape) < 0.2] = 0
+        cls = rng.integers(0, C, hw)
+        mask = (np.eye(C, dtype=np.uint8)[cls] * 255).astype(np.uint8)
+        weight = rng.integers(0, 256, hw, dtype=np.uint8)
+        ns = {'np': np, 'image_slice': image.copy(), 'mask_slice': mask.copy(), 'weight_slice': weight.copy()}
+        exec(block, ns)
+        out[f'c{k}_image'], out[f'c{k}_mask'], out[f'c{k}_weight'] = image, mask, weight
+        out[f'c{k}_image_f'], out[f'c{k}_mask_f'], out[f'c{k}_weight_f'] = ns['image_slice'], ns['mask_slice'], ns['weight_slice']
+    out['n'] = np.array(len(cases))
+    np.savez_compressed(os.path.join(HERE, 'loader.npz'), **out)
+    print('loader.npz done')
+
+
 if __name__ == '__main__':
+    make_loader()
     make_multiscale()
     make_losses()
     make_predict()

@@ -249,3 +249,86 @@ def test_device_update_volume_bit_exact(golden_dir):
             want = s.update_volume(data, base.copy(), axis=axis)                 # numpy path (host mirror)
             got = s.update_volume(data, torch.tensor(base).cuda(), axis=axis)
             assert np.array_equal(got.cpu().numpy(), want), (trial, axis)
+
+
+def _annotation(rng, H, W, C, ch=None):
+    image = rng.integers(0, 256, (H, W) if ch is None else (H, W, ch), dtype=np.uint8)
+    image[rng.random(image.shape) < 0.15] = 0
+    mask = (np.eye(C, dtype=np.uint8)[rng.integers(0, C, (H, W))] * 255).astype(np.uint8)
+    weight = rng.integers(0, 256, (H, W), dtype=np.uint8)
+    return image, mask, weight
+
+
+def test_device_batch_producer_bit_exact(golden_dir):
+    """loader.UNetDataset.batch (iunet_augment_batch) against the oracle's loader restatement for given transform parameters:
+    (a) without augmentation the reference's own normalised annotations (tests/golden/loader.npz) in float16; (b) with
+    augmentation: random angles, the rot90 fast paths, flips, square / non-square / multi-channel annotations, mixed sizes
+    in one batch -- identical float16 bits for image, mask and weight."""
+    from interactive_unet import loader
+    from oracle import loader_ref as lr
+    g = np.load(os.path.join(golden_dir, 'loader.npz'))
+    for k in range(int(g['n'])):
+        ann = loader.annotations_from_arrays([(g[f'c{k}_image'], g[f'c{k}_mask'], g[f'c{k}_weight'])])
+        X, y, w = loader.UNetDataset(ann, None, augment=False)[0]
+        for got, name in zip((X, y, w), ('image', 'mask', 'weight')):
+            want = torch.from_numpy(g[f'c{k}_{name}_f']).to(torch.float16)
+            assert got.dtype == torch.float16 and torch.equal(got.cpu(), want), (k, name)
+    rng = np.random.default_rng(4)
+    fixed = [0.0, 180.0, 90.0, -90.0, 360.0, 270.0]
+    for trial in range(10):
+        C, ch = [(2, None), (3, None), (2, 3)][trial % 3]
+        sizes = [(512, 512), (300, 400), (256, 256), (611, 389)]
+        samples = [_annotation(rng, *sizes[(trial + b) % 4], C, ch) for b in range(3)]
+        ds = loader.UNetDataset(loader.annotations_from_arrays(samples), None, augment=True)
+        params = []
+        for b, (image, _, _) in enumerate(samples):
+            H, W = image.shape[:2]
+            ang = fixed[trial] if (trial < len(fixed) and b == 0) else float(rng.uniform(-360, 360))
+            crop = lr.resized_crop_params(H, W, lambda a, c: float(rng.uniform(a, c)), lambda n: int(rng.integers(n)))
+            params.append((bool(rng.integers(2)), bool(rng.integers(2)), ang, crop))
+        X, y, w = ds.batch([0, 1, 2], params=params)
+        assert X.shape == (3, 1 if ch is None else ch, 512, 512) and y.shape == w.shape == (3, C, 512, 512)
+        for b, (image, mask, weight) in enumerate(samples):
+            want = lr.get_item(*lr.normalise(image, mask, weight), *params[b])
+            for got, ref, name in zip((X[b], y[b], w[b]), want, ('image', 'mask', 'weight')):
+                assert torch.equal(got.cpu(), ref), (trial, b, name)
+    # the loader: epoch length, batch shapes, determinism under a seeded generator, shuffling
+    samples = [_annotation(rng, 256, 256, 2) for _ in range(5)]
+    ann = loader.annotations_from_arrays(samples)
+    a = [t[0].clone() for t in loader.get_data_loader(batch_size=2, annotations=ann, generator=torch.Generator().manual_seed(5))]
+    b = [t[0].clone() for t in loader.get_data_loader(batch_size=2, annotations=ann, generator=torch.Generator().manual_seed(5))]
+    assert len(a) == 3 and a[0].shape == (2, 1, 512, 512) and a[2].shape[0] == 1
+    assert all(torch.equal(u, v) for u, v in zip(a, b))
+    val = list(loader.get_data_loader(set_type='val', batch_size=5, augment=False, shuffle=False, annotations=ann))
+    assert len(val) == 1 and val[0][0].shape == (5, 1, 256, 256)
+    with pytest.raises(RuntimeError):
+        loader.UNetDataset(loader.annotations_from_arrays([_annotation(rng, 64, 64, 2), _annotation(rng, 64, 80, 2)]), None).batch([0, 1])
+
+
+def test_train_model_reads_annotation_files(tmp_path, monkeypatch):
+    """trainer.train_model exactly as app.py:719 calls it (positional arguments, no loaders injected): the annotations are
+    read from data/{train,val}/{images,masks,weights} (colour masks decoded like utils.colored_to_categorical), batches come
+    from the device producer (augmented 512 x 512 for training, as-is for validation), checkpoint and history appear."""
+    from PIL import Image
+    from interactive_unet import trainer, loader
+    monkeypatch.chdir(tmp_path)
+    rng = np.random.default_rng(8)
+    for split, n in (('train', 3), ('val', 2)):
+        for sub in ('images', 'masks', 'weights'):
+            os.makedirs(os.path.join('data', split, sub))
+        for k in range(n):
+            img = _volume((96, 96), 50 + k)
+            img[:4] = 0                                                    # a black border: mask / weight are zeroed there
+            cls = (img > 127).astype(int) + 1                             # palette colours 1 and 2; colour 0 = unlabelled
+            cls[rng.random(cls.shape) < 0.1] = 0
+            Image.fromarray(img).save(os.path.join('data', split, 'images', f'{k:04d}.tiff'))
+            Image.fromarray(loader.COLORS[cls]).save(os.path.join('data', split, 'masks', f'{k:04d}.tiff'))
+            Image.fromarray(np.full((96, 96), 255, np.uint8)).save(os.path.join('data', split, 'weights', f'{k:04d}.tiff'))
+    ann = loader.load_annotations('train')
+    assert len(ann) == 3 and ann[0][0].shape == (96, 96, 1) and ann[0][1].shape == (96, 96, 2) and ann[0][0].is_cuda
+    mask0, weight0 = loader.colored_to_categorical(np.asarray(Image.open('data/train/masks/0000.tiff')))
+    assert set(np.unique(mask0)) <= {0, 255} and np.array_equal(weight0 == 255, mask0.sum(-1) == 255)
+    trainer.train_model(1e-3, 2, 2, 1, 2, 'MCC + CE', 'U-Net', 'mit_b0', False)
+    assert os.path.isfile('model/model.ckpt')
+    rows = list(csv.DictReader(open(glob.glob('model/history/*/version_0/metrics.csv')[0])))
+    assert len([r for r in rows if r['train/Loss']]) == 2 and len([r for r in rows if r['val/Loss']]) == 2

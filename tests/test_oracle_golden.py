@@ -1,5 +1,5 @@
 """Oracle vs golden vectors captured from the reference (tests/golden/make_golden.py).
-CPU only.  Pins oracle/{metrics,predict,slicer,multiscale}_ref.py to the reference's own outputs."""
+CPU only.  Pins oracle/{metrics,predict,slicer,multiscale,loader}_ref.py to the reference's own outputs."""
 import os
 import numpy as np
 import pytest
@@ -169,3 +169,36 @@ def test_multiscale_oracle_matches_scipy_zoom():
         for zoom in (0.5, 0.25):
             assert np.array_equal(ndimage.zoom(x, zoom, order=0), mr.zoom_nearest(x, zoom)), (shape, zoom)
     assert mr.num_steps((1024,) * 3, (128,) * 3) == 3 and mr.num_steps((300, 260, 129), (128,) * 3) == 1
+
+
+def test_loader_normalisation_matches_reference(golden_dir):
+    """oracle/loader_ref.normalise against the reference's own normalisation block (loader.py:32-42): /255 through float64,
+    weight repeated over the classes, mask and weight zeroed where image channel 0 is 0."""
+    from oracle import loader_ref as lr
+    g = np.load(os.path.join(golden_dir, 'loader.npz'))
+    for k in range(int(g['n'])):
+        got = lr.normalise(g[f'c{k}_image'], g[f'c{k}_mask'], g[f'c{k}_weight'])
+        for x, name in zip(got, ('image', 'mask', 'weight')):
+            want = g[f'c{k}_{name}_f']
+            assert x.dtype == want.dtype and np.array_equal(x, want), (k, name)
+
+
+def test_loader_index_arithmetic_matches_torch_primitives():
+    """The explicit per-pixel index arithmetic of the transform chain (what the HIP kernel implements) against the same chain
+    run through torch's own flip / grid_sample(nearest, zeros, align_corners=False) / interpolate(nearest): identical on every
+    pixel -- random angles, the rot90 fast paths, square and non-square annotations, crops from torchvision's parameter rule."""
+    import torch
+    from oracle import loader_ref as lr
+    rng = np.random.default_rng(0)
+    fixed = [0.0, 180.0, 90.0, -90.0, 360.0, -180.0, 270.0, 45.0]
+    for trial in range(24):
+        H, W = [(512, 512), (300, 400), (256, 256), (200, 150), (129, 333)][trial % 5]
+        x = rng.random((2, H, W)).astype(np.float32)
+        hf, vf = bool(rng.integers(2)), bool(rng.integers(2))
+        ang = fixed[trial] if trial < len(fixed) else float(rng.uniform(-360, 360))
+        crop = lr.resized_crop_params(H, W, lambda a, b: float(rng.uniform(a, b)), lambda n: int(rng.integers(n)))
+        want = lr.transform_reference_ops(x, hf, vf, ang, crop).numpy()
+        got = lr.transform(x, hf, vf, ang, crop)
+        assert np.array_equal(got, want), (trial, H, W, ang, crop)
+    i, j, h, w = lr.resized_crop_params(100, 1000, lambda a, b: 1.0 if a < 0.5 else b, lambda n: 0)      # never fits: centre-crop fallback
+    assert (h, w) == (100, 133) and (i, j) == (0, 433)
