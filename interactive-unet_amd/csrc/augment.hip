@@ -24,7 +24,7 @@ struct AugDesc {                 // one sample of the batch (mirrored by interac
   int kind;                      // 0 affine grid, 1 identity, 2 rot90 k=2, 3 rot90 k=1, 4 rot90 k=3 (torchvision rotate fast paths)
   int ci, cj, ch, cw;            // crop of the rotated image: top, left, height, width
   float r[6];                    // theta^T / (W/2, H/2): r00 r10 r20 (x) r01 r11 r21 (y)
-  int pad_;
+  int keep_dark;                 // 1: mask / weight are NOT zeroed where the image is 0 (the Suggestor's tensors)
 };
 
 struct AugParams {
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void augment_batch_kernel(AugParams p) {
   bool lit = false;                                   // image[0] != 0 at the source pixel
   for (int c = 0; c < p.ch; ++c) {
     const unsigned char v = ok ? d.image[src * p.ch + c] : (unsigned char)0;
-    if (c == 0) lit = ok && v != 0;
+    if (c == 0) lit = ok && (v != 0 || d.keep_dark);
     p.X[((long long)b * p.ch + c) * plane + o] = p.lut[v];
   }
   const f16 wv = lit ? p.lut[d.weight[src]] : zero;

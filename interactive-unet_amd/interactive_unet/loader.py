@@ -29,7 +29,7 @@ class AugDesc(ctypes.Structure):
     _fields_ = [('image', ctypes.c_void_p), ('mask', ctypes.c_void_p), ('weight', ctypes.c_void_p), ('xg', ctypes.c_void_p),
                 ('yg', ctypes.c_void_p), ('H', ctypes.c_int), ('W', ctypes.c_int), ('hflip', ctypes.c_int), ('vflip', ctypes.c_int),
                 ('kind', ctypes.c_int), ('ci', ctypes.c_int), ('cj', ctypes.c_int), ('ch', ctypes.c_int), ('cw', ctypes.c_int),
-                ('r', ctypes.c_float * 6), ('pad_', ctypes.c_int)]
+                ('r', ctypes.c_float * 6), ('keep_dark', ctypes.c_int)]
 
 
 def colored_to_categorical(colored_mask):
@@ -137,13 +137,18 @@ def _rotation(angle, H, W):
 class UNetDataset:
     """loader.py:103-154.  `annotations`: the list from load_annotations / annotations_from_arrays."""
 
-    def __init__(self, annotations, resliced_annotations=None, reslice=False, reslice_factor=2, augment=False, generator=None):
+    def __init__(self, annotations, resliced_annotations=None, reslice=False, reslice_factor=2, augment=False, generator=None,
+                 out_size=OUT_SIZE, keep_dark=False):
         if reslice:
             raise NotImplementedError('reslice=True (load_resliced_annotations) is not provided; the reference never enables it')
         self.annotations = annotations
         self.resliced_annotations = resliced_annotations
         self.reslice, self.reslice_factor, self.augment = reslice, reslice_factor, augment
         self.generator = generator
+        # out_size: the augmented output (the reference's loader: 512 x 512 always); keep_dark: do not zero mask / weight where
+        # the image is 0 (the Suggestor's tensors, suggestor.py:60-65, carry no such masking)
+        self.out_size = (out_size, out_size) if isinstance(out_size, int) else tuple(out_size)
+        self.keep_dark = bool(keep_dark)
         self._grids, self._lut = {}, None
 
     def __len__(self):
@@ -162,7 +167,7 @@ class UNetDataset:
         dev = ann[0][0].device
         ch, C = int(ann[0][0].shape[2]), int(ann[0][1].shape[2])
         if self.augment:
-            OH = OW = OUT_SIZE
+            OH, OW = self.out_size
         else:
             OH, OW = int(ann[0][0].shape[0]), int(ann[0][0].shape[1])
         descs = (AugDesc * len(ann))()
@@ -180,6 +185,7 @@ class UNetDataset:
             d.xg, d.yg = self._grid(W, dev).data_ptr(), self._grid(H, dev).data_ptr()
             d.H, d.W, d.hflip, d.vflip, d.kind = H, W, int(hflip), int(vflip), kind
             d.ci, d.cj, d.ch, d.cw = [int(v) for v in crop]
+            d.keep_dark = int(self.keep_dark)
             for q in range(6):
                 d.r[q] = r[q]
         if self._lut is None or self._lut.device != dev:

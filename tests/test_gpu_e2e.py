@@ -332,3 +332,38 @@ def test_train_model_reads_annotation_files(tmp_path, monkeypatch):
     assert os.path.isfile('model/model.ckpt')
     rows = list(csv.DictReader(open(glob.glob('model/history/*/version_0/metrics.csv')[0])))
     assert len([r for r in rows if r['train/Loss']]) == 2 and len([r for r in rows if r['val/Loss']]) == 2
+
+
+def test_suggestor_contract_and_learning():
+    """suggestor.make_suggestions (suggestor.py:43-116) on the native train step: return types and shapes, the single-class
+    shortcut (pure numpy in the reference: identical bytes), model reuse while the class count stays, a new model when it
+    changes, and that the fine-tune learns an easy two-region slice from sparse scribbles (the network differs from the
+    reference's smp mobilenet -- parity unpinned there -- so the learning check is a property, not a comparison)."""
+    from interactive_unet import suggestor, loader
+    rng = np.random.default_rng(12)
+    S = 128
+    truth = np.zeros((S, S), int)
+    truth[:, S // 2:] = 1
+    img = np.clip(np.where(truth == 1, 200, 60) + rng.normal(0, 12, (S, S)), 1, 255).astype(np.uint8)
+    feats = (img / 255).astype('float32')[None, None, :, :]                        # app.py:311
+    mask = np.zeros((S, S, 3), np.uint8)                                            # black = unlabelled
+    for r in (20, 64, 100):                                                          # sparse scribbles in both regions
+        mask[r:r + 3, 8:48] = loader.COLORS[1]
+        mask[r:r + 3, 80:120] = loader.COLORS[2]
+    one = np.zeros((S, S, 3), np.uint8)
+    one[10:20, 10:20] = loader.COLORS[3]
+    sug, m0 = suggestor.make_suggestions(feats, one, model='kept')
+    assert m0 == 'kept' and sug.shape == (S, S, 3) and sug.dtype == np.uint8 and (sug == loader.COLORS[3]).all()
+    gen = torch.Generator().manual_seed(3)
+    sug, model = suggestor.make_suggestions(feats, mask, lr=1e-3, steps=60, generator=gen)
+    assert sug.shape == (S, S, 3) and sug.dtype == np.uint8 and isinstance(model, suggestor.Suggestor)
+    colours = {tuple(c) for c in sug.reshape(-1, 3)}
+    assert colours <= {tuple(loader.COLORS[1]), tuple(loader.COLORS[2])}
+    pred = (sug == loader.COLORS[2]).all(-1).astype(int)
+    assert (pred == truth).mean() > 0.9, (pred == truth).mean()
+    sug2, model2 = suggestor.make_suggestions(feats, mask, model=model, generator=gen)           # defaults: lr 1e-4, 30 steps
+    assert model2 is model and ((sug2 == loader.COLORS[2]).all(-1).astype(int) == truth).mean() > 0.8
+    mask3 = mask.copy()
+    mask3[60:70, 56:72] = loader.COLORS[4]
+    sug3, model3 = suggestor.make_suggestions(feats, mask3, steps=2, model=model, generator=gen)
+    assert model3 is not model and model3.num_classes == 3 and sug3.shape == (S, S, 3)
