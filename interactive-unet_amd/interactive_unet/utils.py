@@ -6,6 +6,8 @@ out-of-range last sample); volumes may be CUDA tensors (zoomed in place on the d
 is staged through the device, as the reference stages it through scipy).  The rest of the reference's utils.py (project
 directories, TIFF import, colours, plots) is outside the hot path.
 """
+import itertools
+
 import numpy as np
 import torch
 
@@ -86,26 +88,21 @@ def resize_volume(src_vol, dst_vol, scale=0.5, block_size=512, order=0):
     if dev_src and dev_dst:
         return _resize_device(src_vol, dst_vol, scale, int(block_size))
     device = src_vol.device if dev_src else (dst_vol.device if dev_dst else torch.device('cuda'))
-    n = [int(v) for v in src_vol.shape]
-    for i in range(0, n[0], block_size):
-        i0, i1 = i, min(i + block_size, n[0])
-        t_i0, t_i1 = int(i0 * scale), int(i1 * scale)
-        for j in range(0, n[1], block_size):
-            j0, j1 = j, min(j + block_size, n[1])
-            t_j0, t_j1 = int(j0 * scale), int(j1 * scale)
-            for k in range(0, n[2], block_size):
-                k0, k1 = k, min(k + block_size, n[2])
-                t_k0, t_k1 = int(k0 * scale), int(k1 * scale)
-                sb = src_vol[i0:i1, j0:j1, k0:k1]
-                if not dev_src:                  # host / Zarr source: the block travels to the device
-                    sb = torch.from_numpy(np.ascontiguousarray(sb)).to(device)
-                shp = (t_i1 - t_i0, t_j1 - t_j0, t_k1 - t_k0) + tuple(_tables(sb.shape, scale, block_size, device)[1][3:])
-                if dev_dst:
-                    _resize_device(sb, dst_vol[t_i0:t_i1, t_j0:t_j1, t_k0:t_k1], scale, int(block_size))
-                else:
-                    tmp = torch.empty(shp, dtype=torch.uint8, device=device)
-                    _resize_device(sb, tmp, scale, int(block_size))
-                    dst_vol[t_i0:t_i1, t_j0:t_j1, t_k0:t_k1] = tmp.cpu().numpy()
+    extent = [int(v) for v in src_vol.shape[:3]]
+    starts = [range(0, n, block_size) for n in extent]
+    for origin in itertools.product(*starts):
+        src_box = tuple(slice(o, min(o + block_size, n)) for o, n in zip(origin, extent))
+        dst_box = tuple(slice(int(b.start * scale), int(b.stop * scale)) for b in src_box)
+        block = src_vol[src_box]
+        if not dev_src:                              # host / Zarr source: the block travels to the device
+            block = torch.from_numpy(np.ascontiguousarray(block)).to(device)
+        if dev_dst:
+            _resize_device(block, dst_vol[dst_box], scale, int(block_size))
+        else:
+            zoomed = tuple(b.stop - b.start for b in dst_box) + tuple(_tables(block.shape, scale, block_size, device)[1][3:])
+            staged = torch.empty(zoomed, dtype=torch.uint8, device=device)
+            _resize_device(block, staged, scale, int(block_size))
+            dst_vol[dst_box] = staged.cpu().numpy()
 
 
 def num_multiscale_steps(volume_shape, chunk_shape, scale=0.5):
