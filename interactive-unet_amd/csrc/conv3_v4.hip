@@ -222,6 +222,10 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + (WS ? 256 : 512)), 1
       load(min(1, last), r);
       if (!WS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the first weight copy has landed
       lds_barrier();
+#ifdef V4_NOLOAD                                                    // ablation build (never defined by build.sh): consumers alone
+      for (int s = 0; s < nsteps; ++s) lds_barrier();
+      return;
+#endif
       if (WS) {
         // one register set: step s + 1 is written to LDS, then the loads of step s + 2 are issued into the same registers
         // and stay in flight over the barrier and the consumers' whole next step
@@ -282,52 +286,32 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + (WS ? 256 : 512)), 1
   const unsigned long long st0 = __builtin_amdgcn_s_memtime(), sr0 = __builtin_amdgcn_s_memrealtime();
 #endif
 
-  for (int s = 0; s < nsteps; ++s) {
+  // Fragment registers: two sets (R: activation rows, A: weights), group t of the launch-wide sequence uses set t & 1.  The
+  // software pipeline runs ACROSS the steps: the reads of step s + 1's first group are issued during the last group of step
+  // s, and the step's one barrier sits in front of that last group -- there every read of step s's buffers has landed
+  // (lgkmcnt(0)), so the loaders may overwrite them, and the loaders have finished step s + 1's buffers.  (With the barrier
+  // at the end of the step both consumer waves of a SIMD refilled their pipeline from empty at the same moment, every step.)
+  V8 R[2][FX][NR + 2], A[2][3][2];
+  auto step_ptrs = [&](int s, const unsigned char*& ab, const unsigned char*& wl) {
     const int chunk = s - (s / nchunk) * nchunk;
-    const unsigned char* ab = smem + (s & 1) * ABUF + rbase;
-    const unsigned char* wl = smem + OFF_W + (WS ? chunk : (s & 1)) * WSTEP + lane * 16;
-
-    if (!(p.dbg & 2)) {
-      // software pipeline over the groups (16-channel sub-chunk h, column pair c) of the step: the fragment reads of
-      // group g + 1 (activation rows + 6 weight fragments) are issued between the 24 MFMAs of group g
-      V8 R[2][FX][NR + 2], A[2][3][2];
-      auto load_group = [&](int g, int b) {
-        const int h = g / NCMB, c = g - h * NCMB;
+    ab = smem + (s & 1) * ABUF + rbase;
+    wl = smem + OFF_W + (WS ? chunk : (s & 1)) * WSTEP + lane * 16;
+  };
+  auto load_group = [&](const unsigned char* ab, const unsigned char* wl, int g, auto BUF) {
+    constexpr int b = decltype(BUF)::value;
+    const int h = g / NCMB, c = g - h * NCMB;
 #pragma unroll
-        for (int xh = 0; xh < FX; ++xh)
+    for (int xh = 0; xh < FX; ++xh)
 #pragma unroll
-          for (int r = 0; r < NR + 2; ++r) R[b][xh][r] = *(const V8*)(ab + h * 2 * PLANE + (r * PX + xh * 16) * 16 + col_off[c]);
+      for (int r = 0; r < NR + 2; ++r) R[b][xh][r] = *(const V8*)(ab + h * 2 * PLANE + (r * PX + xh * 16) * 16 + col_off[c]);
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy) {
-          A[b][dy][0] = *(const V8*)(wl + h * WBYTES + ((c * 3 + dy) * 2 + 0) * 1024);
-          A[b][dy][1] = *(const V8*)(wl + h * WBYTES + ((c * 3 + dy) * 2 + 1) * 1024);
-        }
-      };
-      load_group(0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int g = 0; g < NGRP; ++g) {
-        const int b = g & 1;
-        if (g + 1 < NGRP) load_group(g + 1, b ^ 1);
-#pragma unroll
-        for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-          for (int n = 0; n < NI; ++n) {
-            acc[0][n] = mfma16<T>(A[b][dy][0], R[b][n % FX][n / FX + dy], acc[0][n]);
-            acc[1][n] = mfma16<T>(A[b][dy][1], R[b][n % FX][n / FX + dy], acc[1][n]);
-          }
-        if (g + 1 < NGRP) {
-          constexpr int MPR = (3 * NI * 2) / NRD > 0 ? (3 * NI * 2) / NRD : 1;      // MFMAs per LDS read in the interleave
-#pragma unroll
-          for (int i = 0; i < NRD; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);       // one LDS read
-            __builtin_amdgcn_sched_group_barrier(0x008, MPR, 0);     // MPR MFMAs
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);                         // nothing moves across the group boundary
-      }
+    for (int dy = 0; dy < 3; ++dy) {
+      A[b][dy][0] = *(const V8*)(wl + h * WBYTES + ((c * 3 + dy) * 2 + 0) * 1024);
+      A[b][dy][1] = *(const V8*)(wl + h * WBYTES + ((c * 3 + dy) * 2 + 1) * 1024);
     }
-
+  };
+  auto tile_epilogue = [&](int s) {
+    const int chunk = s - (s / nchunk) * nchunk;
     if (chunk == nchunk - 1) {
       // ---- epilogue of this tile ----
       int n_img, z0, y0, x0;
@@ -377,7 +361,83 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + (WS ? 256 : 512)), 1
         stat_acc += vals[0];
       }
     }
-    lds_barrier();                 // consumers are done with this step's buffers, the loaders have filled the others
+  };
+  // The MFMAs of group g on fragment set b, with the LDS reads issued just before them spread between the MFMAs.
+  auto group_mfmas = [&](auto BUF, bool reads_pending) {
+    constexpr int b = decltype(BUF)::value;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int n = 0; n < NI; ++n) {
+        acc[0][n] = mfma16<T>(A[b][dy][0], R[b][n % FX][n / FX + dy], acc[0][n]);
+        acc[1][n] = mfma16<T>(A[b][dy][1], R[b][n % FX][n / FX + dy], acc[1][n]);
+      }
+    if (reads_pending) {
+      constexpr int MPR = (3 * NI * 2) / NRD > 0 ? (3 * NI * 2) / NRD : 1;      // MFMAs per LDS read in the interleave
+#pragma unroll
+      for (int i = 0; i < NRD; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);       // one LDS read
+        __builtin_amdgcn_sched_group_barrier(0x008, MPR, 0);     // MPR MFMAs
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);                           // nothing moves across the group boundary
+  };
+  // The groups of one step of the cross-step pipeline; PAR = fragment set of its first group.
+  constexpr bool XSTEP = WS;       // cross-step pipeline: the variants with resident weights (168-register cap)
+  auto step_groups = [&](int s, auto PAR) {
+    constexpr int par = decltype(PAR)::value;
+    using B0 = std::integral_constant<int, par>;                       // set of the even groups of this step
+    using B1 = std::integral_constant<int, par ^ 1>;
+    using BL = std::integral_constant<int, (NGRP - 1 + par) & 1>;      // set of the last group
+    using BN = std::integral_constant<int, (NGRP + par) & 1>;          // set of the next step's first group
+    const unsigned char *ab, *wl, *abn, *wln;
+    step_ptrs(s, ab, wl);
+    step_ptrs(min(s + 1, nsteps - 1), abn, wln);           // (after the last step: a harmless re-read of its own buffers)
+#pragma unroll
+    for (int g = 0; g + 1 < NGRP; ++g) {
+      if ((g & 1) == 0) { load_group(ab, wl, g + 1, B1{}); group_mfmas(B0{}, true); }
+      else              { load_group(ab, wl, g + 1, B0{}); group_mfmas(B1{}, true); }
+    }
+    lds_barrier();                   // this step's buffers are read, the next step's are filled
+    load_group(abn, wln, 0, BN{});
+    group_mfmas(BL{}, true);
+    tile_epilogue(s);
+  };
+  if (!(p.dbg & 2)) {
+    if constexpr (XSTEP) {
+      const unsigned char *ab0, *wl0;
+      step_ptrs(0, ab0, wl0);
+      load_group(ab0, wl0, 0, std::integral_constant<int, 0>{});
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (NGRP % 2 == 1) {           // odd group count: the first group's fragment set alternates from step to step
+        for (int s = 0; s < nsteps; s += 2) {
+          step_groups(s, std::integral_constant<int, 0>{});
+          if (s + 1 < nsteps) step_groups(s + 1, std::integral_constant<int, 1>{});
+        }
+      } else {
+        for (int s = 0; s < nsteps; ++s) step_groups(s, std::integral_constant<int, 0>{});
+      }
+    } else {
+      // streamed-weight variants (128-register cap: accumulators + two fragment sets fill it; a set that stays live over the
+      // barrier and the epilogue spills): the pipeline restarts every step, the barrier closes the step
+      using B0 = std::integral_constant<int, 0>;
+      using B1 = std::integral_constant<int, 1>;
+      for (int s = 0; s < nsteps; ++s) {
+        const unsigned char *ab, *wl;
+        step_ptrs(s, ab, wl);
+        load_group(ab, wl, 0, B0{});
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < NGRP; ++g) {
+          if ((g & 1) == 0) { if (g + 1 < NGRP) load_group(ab, wl, g + 1, B1{}); group_mfmas(B0{}, g + 1 < NGRP); }
+          else              { if (g + 1 < NGRP) load_group(ab, wl, g + 1, B0{}); group_mfmas(B1{}, g + 1 < NGRP); }
+        }
+        tile_epilogue(s);
+        lds_barrier();               // consumers are done with this step's buffers, the loaders have filled the others
+      }
+    }
+  } else {
+    for (int s = 0; s < nsteps; ++s) lds_barrier();            // profiling only: nothing is computed or stored
   }
 #ifdef IUNET_STAMPS
   if (wave == 0 && lane == 0 && cob == 0 && blockIdx.x < 512) {
