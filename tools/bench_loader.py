@@ -40,17 +40,36 @@ def main():
     print(f'batch {B} x {S}^2, {C} classes -> 512^2 fp16: {ms * 1e3:.1f} us GPU per batch ({wall * 1e3:.1f} us wall with parameter draw + '
           f'descriptor upload), {(out_b + in_b) / ms / 1e6:.0f} GB/s ({out_b / 1e6:.1f} MB written, <= {in_b / 1e6:.1f} MB gathered), '
           f'{B * 512 * 512 / ms / 1e6:.2f} Gpixel/s')
-    from oracle import loader_ref as lr
-    img, mask, weight = lr.normalise(*samples[0])
+    # the reference's per-sample CPU work, through torch's own primitives (the transforms of loader.py:125-129 are torchvision's
+    # rotate = affine grid + grid_sample(nearest) and resized_crop = crop + interpolate(nearest); torchvision itself is not installed)
+    import math
+    import torch.nn.functional as F
+    img, mask, weight = samples[0]
+    f32 = [torch.from_numpy((np.moveaxis(a if a.ndim == 3 else a[:, :, None], -1, 0) / 255).astype('float32')) for a in (img, mask, weight)]
+
+    def chain(t, hflip, vflip, angle, crop):
+        if hflip: t = t.flip(-1)
+        if vflip: t = t.flip(-2)
+        C, H, W = t.shape
+        rot = math.radians(-angle)
+        theta = torch.tensor([math.cos(rot), math.sin(rot), 0.0, -math.sin(rot), math.cos(rot), 0.0]).reshape(1, 2, 3)
+        base = torch.empty(1, H, W, 3)
+        base[..., 0].copy_(torch.linspace((1.0 - W) * 0.5, (W - 1.0) * 0.5, steps=W))
+        base[..., 1].copy_(torch.linspace((1.0 - H) * 0.5, (H - 1.0) * 0.5, steps=H).unsqueeze(-1))
+        base[..., 2].fill_(1)
+        grid = base.view(1, H * W, 3).bmm(theta.transpose(1, 2) / torch.tensor([0.5 * W, 0.5 * H])).view(1, H, W, 2)
+        t = F.grid_sample(t[None], grid, mode='nearest', padding_mode='zeros', align_corners=False)[0]
+        i, j, h, w = crop
+        return F.interpolate(t[None, :, i:i + h, j:j + w], size=[512, 512], mode='nearest')[0].to(torch.float16)
+
     t0 = time.time()
     n = 5
     for k in range(n):
-        for t in (img, mask, weight):
-            lr.transform_reference_ops(t, *params[k % B]).to(torch.float16)
+        for t in f32:
+            chain(t, *params[k % B])
     cpu = (time.time() - t0) / n
     print(f'CPU, one sample through torch flip / grid_sample / interpolate ({torch.get_num_threads()} threads): {cpu * 1e3:.1f} ms '
           f'= {512 * 512 / cpu / 1e6:.1f} Mpixel/s; a batch of {B}: {cpu * B * 1e3:.0f} ms')
-
 
 if __name__ == '__main__':
     main()

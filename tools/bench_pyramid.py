@@ -1,6 +1,6 @@
 """Time the device multiscale pyramid (interactive_unet.utils.multiscale_levels, iunet_zoom_nearest_u8) on a V^3 uint8
-volume and report bytes moved against the HBM roofline; the oracle (scipy-pinned numpy restatement) is timed on one
-256^3 shard for the CPU figure.   python tools/bench_pyramid.py [--size 1024] [--channels 0]"""
+volume and report bytes moved against the HBM roofline; scipy.ndimage.zoom (the call the reference makes per shard,
+utils.py:46) is timed on one 256^3 shard for the CPU figure.   python tools/bench_pyramid.py [--size 1024] [--channels 0]"""
 import argparse, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'interactive-unet_amd')); sys.path.insert(0, ROOT)
@@ -40,14 +40,11 @@ def main():
     print(f'{V}: {len(lv)} levels {[tuple(l.shape) for l in lv]}: {ms:.3f} ms GPU ({wall:.3f} ms wall), '
           f'{(out_b + in_b) / ms / 1e6:.0f} GB/s algorithmic ({out_b / 1e6:.0f} MB written, {in_b / 1e6:.0f} MB of lines read), '
           f'{vol.numel() / ms / 1e6:.1f} G source voxels/s')
-    from oracle import multiscale_ref as mr
-    blk = vol[:256, :256, :256].cpu().numpy()
-    t0 = time.time(); mr.zoom_nearest(blk, 0.5); t1 = time.time() - t0
     from scipy import ndimage
+    blk = vol[:256, :256, :256].cpu().numpy()
     t0 = time.time(); ndimage.zoom(blk, 0.5, order=0); t2 = time.time() - t0
-    print(f'CPU, one {blk.shape} shard: oracle {t1 * 1e3:.1f} ms, scipy.ndimage.zoom {t2 * 1e3:.1f} ms '
+    print(f'CPU, one {blk.shape} shard through scipy.ndimage.zoom(order=0): {t2 * 1e3:.1f} ms '
           f'({blk.size / t2 / 1e6:.0f} M source voxels/s, 1 thread)')
-
 
 if __name__ == '__main__':
     main()
