@@ -210,6 +210,13 @@ def test_multiscale_pyramid_bit_exact(golden_dir):
         dst = torch.full(want.shape, 9, dtype=torch.uint8, device='cuda')
         utils.resize_volume(torch.tensor(src).cuda(), dst, scale=0.5, block_size=block)
         assert np.array_equal(dst.cpu().numpy(), want), shape
+    for scale, shape, block in [(0.25, (128, 64, 192), 64), (0.25, (96, 96, 96, 4), 32), (0.75, (64, 32, 48), 16)]:      # other zoom factors
+        src = rng.integers(1, 256, shape, dtype=np.uint8)
+        want = np.full(tuple(int(x * scale) for x in shape), 5, dtype=np.uint8)
+        mr.resize_volume(src, want, scale, block)
+        dst = torch.full(want.shape, 5, dtype=torch.uint8, device='cuda')
+        utils.resize_volume(torch.tensor(src).cuda(), dst, scale=scale, block_size=block)
+        assert np.array_equal(dst.cpu().numpy(), want), (scale, shape)
     # a whole pyramid (add_multiscales on arrays): 256 x 192 x 320 with 32^3 chunks and 64^3 shards -> 3 levels
     vol = rng.integers(0, 256, (256, 192, 320), dtype=np.uint8)
     want = mr.multiscale_levels(vol, (32,) * 3, (64,) * 3)
