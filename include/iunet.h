@@ -98,6 +98,32 @@ int iunet_head_fwd(int dtype, const void* x, long long x_ss, int C0, const void*
                    void* logits, void* probs, void* cls, const long long* out_strides, float divisor, int accumulate,
                    int N, int D, int H, int W, void* stream);
 
+/* ---- fp32 parity mode -------------------------------------------------------------------------------------------------
+ * BASELINE.json north_star: "outputs match the reference CPU PyTorch path within 1e-3 on logits (integer-exact on argmax
+ * class map)".  The 16-bit paths above round every activation in HBM and cannot reach that (5e-3 .. 7e-2 measured); these
+ * entry points run the same forward graph (unet.py:65-69 over the canonical network) with fp32 activations, fp32 weights
+ * and the f32-input matrix instruction (exact fp32 products and sums), 1/16 of the bf16 rate.  Layout of THIS mode: planar
+ * fp32, C planes of [D][H][W]; `*_ss` = elements between consecutive samples. */
+/* operator packing: conv w fp32 [Cout][Cin][taps] (taps 9 / 27) or, transposed != 0, ConvTranspose k2 s2 w fp32
+ * [Cin][Cout][taps] (taps 4 / 8); a non-NULL gamma folds an eval-mode BatchNorm (w * gamma / sqrt(var + eps); bias_out =
+ * beta - mean * that scale; every operation separately rounded, as the CPU oracle's fold).  dst:
+ * iunet_f32_pack_conv_elems floats. */
+long long iunet_f32_pack_conv_elems(int Cout, int Cin, int taps);
+int iunet_f32_pack_conv(const void* w, void* dst, void* bias_out, const void* gamma, const void* beta, const void* mean,
+                        const void* var, float eps, int Cout, int Cin, int taps, int transposed, void* stream);
+/* 3^d conv pad 1 (transposed == 0) or ConvTranspose k2 s2 (transposed != 0; D, H, W = input grid, output 2x) + bias + optional
+ * ReLU.  The input is read through element strides in_strides (n, c, d, h, w) and in_dtype (0 f32, 1 f16, 2 u8 / 255, 3
+ * bf16), so the first conv takes the caller's tensor or a 2.5-D view of a block directly; y: planar fp32. */
+int iunet_f32_conv_fwd(int nd, const void* x, int in_dtype, const long long* in_strides, void* y, long long y_ss,
+                       const void* wpk, const void* bias, int N, int D, int H, int W, int Cin, int Cout, int relu,
+                       int transposed, void* stream);
+int iunet_f32_maxpool_fwd(int nd, const void* x, long long x_ss, void* y, long long y_ss, int C, int N, int Do, int Ho, int Wo,
+                          void* stream);
+/* iunet_head_fwd on planar fp32 features: w fp32 [ncls][C0]; same output contract. */
+int iunet_f32_head_fwd(const void* x, long long x_ss, int C0, const void* w, const void* bias, int ncls, void* logits,
+                       void* probs, void* cls, const long long* out_strides, float divisor, int accumulate, int N, int D, int H,
+                       int W, void* stream);
+
 /* ---- whole-volume prediction (predict.py:201-256) -------------------------------------- */
 /* get_padded_block (predict.py:291-316): reflect-padded S^3 uint8 block of a device volume. */
 int iunet_gather_block(const void* vol, int Vz, int Vy, int Vx, int i0, int j0, int k0, int S, void* out, void* stream);

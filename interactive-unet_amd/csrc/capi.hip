@@ -43,6 +43,20 @@ int iunet_head_launch(int dtype, const void* x, long long x_ss, int C0, const fl
                       long long oH, long long oW, float divisor, int accumulate, int N, int D, int H, int W,
                       hipStream_t stream);
 
+// fp32 parity mode (precise_f32.hip)
+long long iunet_f32_pack_size(int Cout, int Cin, int taps);
+int iunet_f32_pack_launch(const float* w, float* dst, float* bias_out, const float* gamma, const float* beta,
+                          const float* mean, const float* var, float eps, int Cout, int Cin, int taps, int transposed,
+                          hipStream_t stream);
+int iunet_f32_conv_launch(int nd, const void* x, int in_dtype, const long long* st, float* y, long long y_ss, const float* wpk,
+                          const float* bias, int N, int D, int H, int W, int Cin, int Cout, int relu, int transposed,
+                          hipStream_t stream);
+int iunet_f32_maxpool_launch(int nd, const float* x, long long x_ss, float* y, long long y_ss, int C, int N, int Do, int Ho,
+                             int Wo, hipStream_t stream);
+int iunet_f32_head_launch(const float* x, long long x_ss, int C0, const float* w, const float* bias, int ncls, float* logits,
+                          float* probs, unsigned char* cls, const long long* os, float divisor, int accumulate, int N, int D,
+                          int H, int W, hipStream_t stream);
+
 #define DT_OK(dt) IUNET_REQUIRE((dt) == 0 || (dt) == 1, "dtype must be 0 (f16) or 1 (bf16), got %d", (dt))
 
 extern "C" {
@@ -158,6 +172,53 @@ int iunet_head_fwd(int dtype, const void* x, long long x_ss, int C0, const void*
   return iunet_head_launch(dtype, x, x_ss, C0, (const float*)w, (const float*)bias, ncls, (float*)logits, (float*)probs,
                            (unsigned char*)cls, out_strides[0], out_strides[1], out_strides[2], out_strides[3],
                            out_strides[4], divisor, accumulate, N, D, H, W, (hipStream_t)stream);
+}
+
+/* ---- fp32 parity mode (precise_f32.hip): planar fp32 activations, v_mfma_f32_16x16x4_f32 ------------------- */
+long long iunet_f32_pack_conv_elems(int Cout, int Cin, int taps) {
+  if (Cout <= 0 || Cout % 32 || Cin <= 0 || taps <= 0) return 0;
+  return iunet_f32_pack_size(Cout, Cin, taps);
+}
+
+int iunet_f32_pack_conv(const void* w, void* dst, void* bias_out, const void* gamma, const void* beta, const void* mean,
+                        const void* var, float eps, int Cout, int Cin, int taps, int transposed, void* stream) {
+  IUNET_REQUIRE(w && dst, "f32_pack_conv: null pointer");
+  IUNET_REQUIRE(Cout > 0 && Cout % 32 == 0 && Cin > 0, "f32_pack_conv: Cout must be a positive multiple of 32, Cin > 0 (got %d, %d)", Cout, Cin);
+  IUNET_REQUIRE(transposed ? (taps == 4 || taps == 8) : (taps == 9 || taps == 27),
+                "f32_pack_conv: taps must be 9 / 27 (conv) or 4 / 8 (transposed), got %d", taps);
+  IUNET_REQUIRE(!gamma || (beta && mean && var && bias_out), "f32_pack_conv: a BatchNorm fold needs gamma, beta, mean, var and bias_out");
+  return iunet_f32_pack_launch((const float*)w, (float*)dst, (float*)bias_out, (const float*)gamma, (const float*)beta,
+                               (const float*)mean, (const float*)var, eps, Cout, Cin, taps, transposed, (hipStream_t)stream);
+}
+
+int iunet_f32_conv_fwd(int nd, const void* x, int in_dtype, const long long* in_strides, void* y, long long y_ss,
+                       const void* wpk, const void* bias, int N, int D, int H, int W, int Cin, int Cout, int relu,
+                       int transposed, void* stream) {
+  IUNET_REQUIRE(x && y && wpk && in_strides, "f32_conv: null pointer");
+  IUNET_REQUIRE(nd == 2 || nd == 3, "f32_conv: nd must be 2 or 3");
+  IUNET_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && (nd == 3 || D == 1), "f32_conv: bad shape %d %d %d %d", N, D, H, W);
+  IUNET_REQUIRE(in_dtype >= 0 && in_dtype <= 3, "f32_conv: bad input dtype %d", in_dtype);
+  IUNET_REQUIRE(Cout > 0 && Cout % 32 == 0 && Cin > 0, "f32_conv: Cout must be a positive multiple of 32, Cin > 0 (got %d, %d)", Cout, Cin);
+  return iunet_f32_conv_launch(nd, x, in_dtype, in_strides, (float*)y, y_ss, (const float*)wpk, (const float*)bias, N, D, H, W,
+                               Cin, Cout, relu, transposed, (hipStream_t)stream);
+}
+
+int iunet_f32_maxpool_fwd(int nd, const void* x, long long x_ss, void* y, long long y_ss, int C, int N, int Do, int Ho, int Wo,
+                          void* stream) {
+  IUNET_REQUIRE(x && y, "f32_maxpool: null pointer");
+  IUNET_REQUIRE(nd == 2 || nd == 3, "f32_maxpool: nd must be 2 or 3");
+  IUNET_REQUIRE(C > 0 && N > 0 && Do > 0 && Ho > 0 && Wo > 0, "f32_maxpool: bad shape");
+  return iunet_f32_maxpool_launch(nd, (const float*)x, x_ss, (float*)y, y_ss, C, N, Do, Ho, Wo, (hipStream_t)stream);
+}
+
+int iunet_f32_head_fwd(const void* x, long long x_ss, int C0, const void* w, const void* bias, int ncls, void* logits,
+                       void* probs, void* cls, const long long* out_strides, float divisor, int accumulate, int N, int D, int H,
+                       int W, void* stream) {
+  IUNET_REQUIRE(x && w && bias && out_strides, "f32_head: null pointer");
+  IUNET_REQUIRE(ncls >= 2 && ncls <= 10, "f32_head: num_classes must be 2..10 (got %d)", ncls);
+  return iunet_f32_head_launch((const float*)x, x_ss, C0, (const float*)w, (const float*)bias, ncls, (float*)logits,
+                               (float*)probs, (unsigned char*)cls, out_strides, divisor, accumulate, N, D, H, W,
+                               (hipStream_t)stream);
 }
 
 }  // extern "C"

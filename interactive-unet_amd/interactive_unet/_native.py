@@ -38,6 +38,13 @@ _SIGS = {
                         c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     'iunet_head_fwd': [c_int, c_void_p, c_ll, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                        ctypes.POINTER(c_ll), c_float, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    # ---- fp32 parity mode
+    'iunet_f32_pack_conv': [c_void_p] * 7 + [c_float, c_int, c_int, c_int, c_int, c_void_p],
+    'iunet_f32_conv_fwd': [c_int, c_void_p, c_int, ctypes.POINTER(c_ll), c_void_p, c_ll, c_void_p, c_void_p,
+                           c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    'iunet_f32_maxpool_fwd': [c_int, c_void_p, c_ll, c_void_p, c_ll, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    'iunet_f32_head_fwd': [c_void_p, c_ll, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                           ctypes.POINTER(c_ll), c_float, c_int, c_int, c_int, c_int, c_int, c_void_p],
     'iunet_gather_block': [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     'iunet_blend_accumulate': [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_void_p],
@@ -97,7 +104,7 @@ _SIGS = {
 # functions that return a size / count instead of a status
 _INT_RETURN = ['iunet_pack_desc_bytes', 'iunet_augment_desc_bytes']
 _INT_RETURN_ARGS = {'iunet_zoom_nearest_len': [c_int, ctypes.c_double]}
-_LL_RETURN = {'iunet_conv3_wgrad_slab_floats': [c_int] * 7, 'iunet_pack_conv3_elems': [c_int] * 4,
+_LL_RETURN = {'iunet_conv3_wgrad_slab_floats': [c_int] * 7, 'iunet_f32_pack_conv_elems': [c_int] * 3, 'iunet_pack_conv3_elems': [c_int] * 4,
               'iunet_pack_first_conv_elems': [c_int] * 3, 'iunet_slice_scatter_workspace_bytes': [c_int]}
 
 

@@ -35,6 +35,9 @@ class TrainEngine:
         self.dim, self.levels, self.ch = model.dim, model.levels, [model.base * 2 ** l for l in range(model.levels)]
         self.cin, self.ncls = model.num_channels, model.num_classes
         self.T = model.act_dtype
+        if self.T not in nv.DTYPE_CODE:
+            raise NotImplementedError("native training runs with 16-bit activations (act_dtype 'fp16' / 'bf16'); "
+                                      "act_dtype='fp32' is the inference parity mode")
         self.dt = nv.DTYPE_CODE[self.T]
         self.es = 2
         self.taps, self.npos = 3 ** self.dim, 2 ** self.dim

@@ -6,7 +6,10 @@ the native canonical U-Net (engine.py) instead of segmentation_models_pytorch.
 Only architecture='U-Net' exists natively; `encoder_name` is accepted and ignored (the canonical
 net has its own plain conv encoder), `pretrained` is a no-op with a warning (no imagenet
 weights for a from-scratch encoder; no network access).  Extra keyword arguments (dim, levels,
-base, act_dtype) select the 3-D / wider variants of BASELINE.json's configs.
+base, act_dtype) select the 3-D / wider variants of BASELINE.json's configs.  act_dtype: 'fp16' / 'bf16' =
+16-bit activations on the bf16/fp16 matrix cores (the throughput path); 'fp32' = the parity mode (fp32
+activations and operators on the f32-input matrix instruction, engine_f32.py: logits within 1e-3 of the CPU
+fp32 path, inference only).
 """
 import math
 import warnings
@@ -17,8 +20,9 @@ import torch.nn as nn
 from . import metrics
 from .engine import Engine, BN_EPS
 
-_ACT = {'fp16': torch.float16, 'f16': torch.float16, 'bf16': torch.bfloat16,
-        torch.float16: torch.float16, torch.bfloat16: torch.bfloat16}
+_ACT = {'fp16': torch.float16, 'f16': torch.float16, 'bf16': torch.bfloat16, 'fp32': torch.float32, 'f32': torch.float32,
+        torch.float16: torch.float16, torch.bfloat16: torch.bfloat16, torch.float32: torch.float32}
+_ACT_NAME = {torch.float16: 'fp16', torch.bfloat16: 'bf16', torch.float32: 'fp32'}
 
 
 def param_shapes(dim=2, levels=4, base=32, cin=1, ncls=2):
@@ -63,7 +67,7 @@ class UNet(nn.Module):
                             loss_function=getattr(loss_function, '__name__', str(loss_function)),
                             architecture=architecture, encoder_name=encoder_name, pretrained=pretrained,
                             dim=dim, levels=levels, base=base,
-                            act_dtype='bf16' if _ACT[act_dtype] == torch.bfloat16 else 'fp16',
+                            act_dtype=_ACT_NAME[_ACT[act_dtype]],
                             weight_dtype=weight_dtype)
         self.lr = lr
         self.loss_function = loss_function
@@ -138,8 +142,14 @@ class UNet(nn.Module):
                                '(there is no CPU fallback)')
         eng = self._engines.get(dev)
         if eng is None:
-            eng = Engine(self.dim, self.levels, self.base, self.num_channels, self.num_classes, self.act_dtype, dev,
-                         weight_dtype=self.weight_dtype)
+            if self.act_dtype == torch.float32:
+                from .engine_f32 import EngineF32
+                if self.weight_dtype is not None:
+                    raise ValueError("act_dtype='fp32' is the parity mode: it takes no weight_dtype")
+                eng = EngineF32(self.dim, self.levels, self.base, self.num_channels, self.num_classes, dev)
+            else:
+                eng = Engine(self.dim, self.levels, self.base, self.num_channels, self.num_classes, self.act_dtype, dev,
+                             weight_dtype=self.weight_dtype)
             self._engines = {dev: eng}
             self._packed_sig = None
         sig = self._signature()
@@ -166,7 +176,8 @@ class UNet(nn.Module):
 
     # ---- optimiser / steps (unet.py:71-116) -------------------------------------------------
     def configure_optimizers(self):
-        raise NotImplementedError('the native path steps AdamW inside trainer.NativeTrainer (unet.py:71-73 defaults)')
+        raise NotImplementedError('the native path steps AdamW inside train_engine.TrainEngine (fused flat AdamW with the '
+                                  'torch defaults of unet.py:71-73); trainer.train_model drives it')
 
     # ---- checkpoints (trainer.py:30-49, predict.py:22-24) -----------------------------------
     def save_checkpoint(self, path):

@@ -1,0 +1,191 @@
+"""North-star parity gate (BASELINE.json): "outputs match the reference CPU PyTorch path within 1e-3 on logits
+(integer-exact on argmax class map) on the same synthetic volume ... segmentation IoU identical to reference".
+
+The CPU path is oracle/unet_ref.forward_logits in plain fp32 (no rounding points).  Three native modes are held
+against it, at small shapes (ragged tiles, several input channels / dtypes) and at the HEADLINE sizes of
+BASELINE.json's configs (one 128^3 chunk of C3, 512^2 slices of C2):
+
+* act_dtype='fp32' (engine_f32.py, the parity mode): max |logit - oracle| <= 1e-3 ABSOLUTE, asserted; class map
+  compared on ALL voxels; IoU (metrics.py:49-66 on rounded probabilities, unet.py:80-85) equal to the oracle's.
+* act_dtype='fp16' / 'bf16' (the throughput modes): the deviation from the fp32 oracle is MEASURED, printed and
+  held under a per-dtype regression bound stated here -- these modes round every activation to 16 bits in HBM and
+  do not reach 1e-3; their class-map mismatch count and IoU difference are reported.
+"""
+import time
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import metrics_ref, unet_ref
+
+TOL = 1e-3                       # north_star: absolute, on logits, vs the fp32 CPU path
+# regression bounds of the 16-bit modes: max |logit - fp32 oracle| / max |logit|.  Measured on MI355X (round 2):
+#   128^3 chunk  fp16 3.6e-3 abs (2.1e-3 rel, 972 of 2 097 152 class-map voxels differ), bf16 3.0e-2 abs (1.7e-2 rel, 7 466)
+#   2 x 512^2    fp16 6.8e-3 abs (1.7e-3 rel, 109 of 524 288),                          bf16 6.0e-2 abs (1.5e-2 rel, 770)
+# NOT the parity gate -- that is TOL on the fp32 mode (8e-6 / 1e-5 abs measured, 2 / 0 voxels: ties at fp32 resolution).
+REL_BOUND_16 = {torch.float16: 4e-3, torch.bfloat16: 3e-2}
+
+
+def _smooth(shape, seed, sigma=3):
+    from scipy import ndimage
+    rng = np.random.default_rng(seed)
+    v = ndimage.gaussian_filter(rng.random(shape), sigma)
+    v = (v - v.min()) / (v.max() - v.min())
+    return (v * 254 + 1).astype(np.uint8)
+
+
+def _native_engine(p, dim, cin, ncls, dtype):
+    if dtype == torch.float32:
+        from interactive_unet.engine_f32 import EngineF32
+        e = EngineF32(dim=dim, cin=cin, ncls=ncls)
+    else:
+        from interactive_unet.engine import Engine
+        e = Engine(dim=dim, cin=cin, ncls=ncls, act_dtype=dtype)
+    e.load_eval({k: v.cuda() for k, v in p.items()})
+    return e
+
+
+def _forward(e, x, dim, ncls):
+    """x: [N, cin, *shape] on the device (any supported dtype) -> logits, probs (fp32 NC*), cls uint8 [N, vox]."""
+    N, cin = x.shape[:2]
+    shape = tuple(x.shape[2:])
+    D, H, W = shape if dim == 3 else (1,) + shape
+    vox = D * H * W
+    logits = torch.empty((N, ncls) + shape, device='cuda')
+    probs = torch.empty((N, ncls) + shape, device='cuda')
+    cls = torch.empty(N, vox, dtype=torch.uint8, device='cuda')
+    e.infer(x, (cin * vox, vox, H * W, W, 1), N, D, H, W, logits=logits, probs=probs, cls=cls)
+    torch.cuda.synchronize()
+    return logits.cpu(), probs.cpu(), cls.cpu()
+
+
+def _compare(tag, logits, probs, cls, ref, y_true):
+    """-> dict of the parity figures of one native mode against the fp32 oracle logits `ref`."""
+    N, C = ref.shape[:2]
+    vox = ref[0, 0].numel()
+    err = (logits - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    want = ref.argmax(1).reshape(N, vox)
+    got = cls.long()
+    mism = got != want
+    top2 = torch.topk(ref, 2, dim=1).values
+    margin = (top2[:, 0] - top2[:, 1]).reshape(N, vox)
+    ref_p = torch.softmax(ref, 1).numpy()
+    axes = (0,) + tuple(range(2, ref.dim()))
+    iou_ref = metrics_ref.rounded_metrics(ref_p, y_true, None, axes)[1]
+    iou_nat = metrics_ref.rounded_metrics(probs.numpy(), y_true, None, axes)[1]
+    rdiff = np.round(probs.numpy().astype(np.float64)) != np.round(ref_p.astype(np.float64))
+    out = dict(err=err, scale=scale, mismatches=int(mism.sum()), voxels=N * vox, round_mismatches=int(rdiff.sum()),
+               worst_round_margin=(float(np.abs(ref_p[rdiff] - 0.5).max()) if rdiff.any() else 0.0),
+               worst_mismatch_margin=(margin[mism].max().item() if mism.any() else 0.0),
+               iou_ref=float(iou_ref), iou_native=float(iou_nat),
+               prob_err=float(np.abs(probs.numpy() - ref_p).max()))
+    print(f'[parity {tag}] max|logit - fp32 oracle| = {err:.3e} (logit scale {scale:.2f}, rel {err / scale:.2e}); '
+          f'class-map mismatches {out["mismatches"]} / {out["voxels"]} (largest oracle margin among them '
+          f'{out["worst_mismatch_margin"]:.2e}); rounded-probability mismatches {out["round_mismatches"]}; IoU native {iou_nat:.9f} vs oracle {iou_ref:.9f}; '
+          f'max|prob diff| = {out["prob_err"]:.2e}')
+    return out
+
+
+def _assert_fp32_mode(r):
+    assert r['err'] <= TOL, f'fp32 mode: logits off by {r["err"]:.2e} > {TOL}'
+    # integer-exact class map on ALL voxels: a voxel may differ only where the oracle's own top-2 margin is below
+    # twice the measured logit error (the two modes then disagree on a tie, not on a class)
+    assert r['worst_mismatch_margin'] <= 2 * r['err'] + 1e-7, r
+    assert r['mismatches'] <= max(2, r['voxels'] // 200000), r       # ties at fp32 resolution: a handful per million at most
+    # IoU as unet.py:80-85 logs it (metrics.py:49-66 on round()-ed probabilities): identical whenever the rounded tensors
+    # are; a probability may round differently only where the oracle's own value is within the error of 0.5
+    assert r['worst_round_margin'] <= r['prob_err'] + 1e-7, r
+    assert r['round_mismatches'] <= max(2, r['voxels'] // 100000), r
+    if r['round_mismatches'] == 0:
+        assert r['iou_native'] == r['iou_ref']
+    assert abs(r['iou_native'] - r['iou_ref']) <= 4.0 * r['round_mismatches'] / r['voxels'] + 1e-12
+    assert r['prob_err'] <= TOL
+
+
+def _labels(img, ncls):
+    """Synthetic ground truth: intensity classes of the image (one-hot float32 [N, ncls, *shape])."""
+    lab = np.minimum(img[:, 0].astype(np.int64) * ncls // 256, ncls - 1)
+    return np.stack([(lab == c) for c in range(ncls)], 1).astype(np.float32)
+
+
+@pytest.mark.parametrize('dim,shape,cin,ncls,in_dtype', [
+    (2, (64, 96), 1, 3, torch.uint8),
+    (2, (40, 72), 3, 2, torch.float32),        # ragged 16x16 tiles, 3 input channels
+    (3, (16, 32, 48), 1, 3, torch.uint8),
+    (3, (8, 24, 40), 2, 4, torch.float16),     # deepest level 1 x 3 x 5: every tile is partial
+])
+def test_fp32_mode_small_shapes(dim, shape, cin, ncls, in_dtype):
+    p = unet_ref.init_params(dim=dim, cin=cin, ncls=ncls, seed=3, randomize_bn=True)
+    N = 2
+    img = np.stack([np.stack([_smooth(shape, 10 * i + c) for c in range(cin)]) for i in range(N)])     # N, cin, *shape
+    x = torch.tensor(img)
+    if in_dtype == torch.uint8:
+        xd, xf = x.cuda(), x.float() / 255.0
+    else:
+        xf = (x.float() / 255.0).to(in_dtype).float()
+        xd = xf.to(in_dtype).cuda()
+    ref = unet_ref.forward_logits(p, xf, dim=dim)
+    e = _native_engine(p, dim, cin, ncls, torch.float32)
+    r = _compare(f'fp32 {dim}-D {shape} cin={cin}', *_forward(e, xd, dim, ncls), ref, _labels(img, ncls))
+    _assert_fp32_mode(r)
+    assert r['err'] <= 1e-4 * max(1.0, r['scale'])      # in fact the only difference is the order of fp32 sums
+
+
+def _headline(dim, shape, N, seed):
+    ncls = 2
+    p = unet_ref.init_params(dim=dim, ncls=ncls, seed=seed, randomize_bn=True)
+    img = np.stack([_smooth(shape, seed * 100 + i, sigma=6) for i in range(N)])[:, None]
+    x = torch.tensor(img)
+    t0 = time.time()
+    ref = unet_ref.forward_logits(p, x.float() / 255.0, dim=dim)
+    print(f'[parity] fp32 oracle forward of {N} x {shape}: {time.time() - t0:.1f} s on {torch.get_num_threads()} threads')
+    y_true = _labels(img, ncls)
+    res = {}
+    for dtype in (torch.float32, torch.float16, torch.bfloat16):
+        e = _native_engine(p, dim, 1, ncls, dtype)
+        res[dtype] = _compare(f'{str(dtype).split(".")[1]} {dim}-D {N} x {shape}', *_forward(e, x.cuda(), dim, ncls), ref, y_true)
+        del e
+        torch.cuda.empty_cache()
+    _assert_fp32_mode(res[torch.float32])
+    for dtype in (torch.float16, torch.bfloat16):
+        r = res[dtype]
+        assert r['err'] <= REL_BOUND_16[dtype] * max(1.0, r['scale']), (dtype, r)
+        # what a 16-bit mode may get wrong: only voxels whose oracle margin is inside its own logit error
+        assert r['worst_mismatch_margin'] <= 2 * r['err'], (dtype, r)
+        assert r['worst_round_margin'] <= r['prob_err'] + 1e-7, (dtype, r)
+    return res
+
+
+def test_headline_c3_one_128_cubed_chunk():
+    """BASELINE.json configs[2]: 3-D U-Net 4-level base 32, one 128^3 uint8 chunk."""
+    _headline(3, (128, 128, 128), 1, seed=5)
+
+
+def test_headline_c2_512_squared_slices():
+    """BASELINE.json configs[1]: 2-D U-Net 4-level base 32, 512 x 512 uint8 slices (batch of 2)."""
+    _headline(2, (512, 512), 2, seed=6)
+
+
+def test_unet_module_fp32_mode_matches_oracle_probabilities():
+    """UNet(act_dtype='fp32') -- what a user of the boundary switches on -- returns the oracle's softmax
+    probabilities (unet.py:65-69) to 1e-5."""
+    import warnings
+    from interactive_unet.unet import UNet
+    p = unet_ref.init_params(dim=2, ncls=3, seed=8, randomize_bn=True)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        m = UNet(num_classes=3, act_dtype='fp32', pretrained=False)
+    m.load_named(p)
+    m = m.cuda().eval()
+    x = torch.tensor(_smooth((96, 64), 2))[None, None]
+    got = m(x.cuda()).cpu()
+    want = unet_ref.forward(p, x.float() / 255.0, dim=2)
+    assert (got - want).abs().max().item() <= 1e-5
+    assert m.hparams['act_dtype'] == 'fp32'
+    from interactive_unet.train_engine import TrainEngine
+    with pytest.raises(NotImplementedError):
+        TrainEngine(m)
