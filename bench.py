@@ -1,24 +1,41 @@
 """Benchmark of the native U-Net hot path on MI355X.
 
-    python bench.py [--gpus N --steps K --warmup W]         (N > 1: launched by torch.distributed.run)
+    python bench.py [--gpus N --steps K --warmup W] [--workload c3|c4|c5|c2]
 
-Workload (BASELINE.json configs[2], "C3"): 3-D U-Net 4-level base 32, 1 -> 2 classes, bf16
-activations, batches of 128^3 uint8 chunks resident in HBM.  One step = one training step
-(forward + MCC+CE loss + backward + AdamW) on `--chunks` chunks, when the training path is
-built, followed by one prediction pass (forward + softmax + Gaussian blend-accumulate +
-normalise/quantise) over the same number of chunks.  value = voxels through the step / s,
-whole job (all ranks; weak scaling: every rank owns its own chunks, gradients all-reduced
-over RCCL when training is in the step).
+`--gpus N` with N > 1 and no torch.distributed environment: bench.py starts itself under
+`python -m torch.distributed.run --nproc-per-node N` (child processes; this process has not touched the GPU) and
+exits with their code.  Under a launcher (WORLD_SIZE set) it is one rank per GPU over RCCL.
+
+Workloads (BASELINE.json `configs`; the metric is "voxels/sec (train step + full-volume predict) on 128^3 chunks"):
+
+  c3 (default, configs[2])  3-D U-Net 4-level base 32, 1 -> 2 classes, bf16, `--chunks` 128^3 uint8 chunks per GPU
+       resident in HBM.  One step = one training step on the chunks (forward with BatchNorm batch statistics, MCC+CE
+       loss, backward, AdamW, weight re-pack; gradients all-reduced over RCCL for N > 1) + tiled prediction of one
+       (96*chunks*N + 32) x 128 x 128 volume shared by the N ranks = `chunks` overlapping 128^3 blocks per GPU
+       (reflect-padded block gather, forward + softmax, Gaussian blend, piece exchange for N > 1, normalise +
+       quantise).  value = (training chunk voxels + UNIQUE predicted volume voxels) / s, whole job, weak scaling.
+       The same run then times the C4 volume once (`"c4"` object of the line; `--c4-reps 0` skips it).
+  c4 (configs[3])  the fixed 1024^3 uint8 volume (generated on the device from the voxel coordinates, identical for
+       every N), 1 331 blocks of 128^3, overlap 0.25, sharded over the N ranks (shard.py): one step = one whole-volume
+       prediction, wall time including every exchange.  value = unique volume voxels / s; STRONG scaling.
+  c5 (configs[4])  3-D 5-level base 64, 4 classes: training step in bf16 + prediction with e4m3 weights, 1 chunk.
+  c2 (configs[1])  2-D 4-level base 32, fp16: training step on 8 slices of 512^2 + prediction of the 8 slices.
 
 The JSON line also carries
-  roofline     -- the bottleneck 3x3x3 conv (dec0.conv1: 64 -> 32 channels at 128^3), timed
-                  live with HIP events on the launch stream, against the dense MFMA peak;
-  cpu_baseline -- the oracle (oracle/unet_ref.py, torch CPU fp32, all host cores) timed on a
-                  bounded sample of the same workload, rank 0 / N = 1 only.
+  roofline     -- the workload's bottleneck 3x3(x3) conv (dec0.conv1), timed live with HIP events on the launch
+                  stream over 50 back-to-back launches (average = `achieved`; the first 8 and the last 20 are given
+                  as burst / settled: the clock drops under sustained MFMA load), against the dense MFMA peak;
+  parity       -- max |logit| deviation and class-map mismatches of the benchmarked dtype against the native fp32
+                  parity mode on one chunk (that mode is held within 1e-3 of the CPU oracle by tests/test_gpu_parity.py),
+                  plus, when the CPU baseline runs, both modes against the CPU fp32 oracle on its sample;
+  cpu_baseline -- the oracle (oracle/unet_ref.py, torch CPU fp32, host cores) timed on a bounded sample of the same
+                  workload, rank 0 / N = 1 only.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,15 +49,42 @@ import torch
 MFMA_PEAK_TFLOPS = 2500.0          # dense bf16/fp16, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
 HBM_PEAK_GBS = 8000.0
 
+WORKLOADS = {
+    #        dim levels base ncls dtype   infer weights  tile            chunks
+    'c3': dict(dim=3, levels=4, base=32, ncls=2, dtype='bf16', wq=None, tile=(128, 128, 128), chunks=2),
+    'c4': dict(dim=3, levels=4, base=32, ncls=2, dtype='bf16', wq=None, tile=(128, 128, 128), chunks=0),
+    'c5': dict(dim=3, levels=5, base=64, ncls=4, dtype='bf16', wq='fp8_e4m3', tile=(128, 128, 128), chunks=1),
+    'c2': dict(dim=2, levels=4, base=32, ncls=2, dtype='f16', wq=None, tile=(512, 512), chunks=8),
+}
 
-def synth_chunks(n, S, seed, device):
-    """Seeded, non-zero, smooth-ish uint8 chunks generated on the device (no files)."""
+
+def synth_chunks(n, shape, seed, device):
+    """Seeded, non-zero, smooth-ish uint8 tiles generated on the device (no files)."""
     g = torch.Generator(device=device).manual_seed(seed)
-    x = torch.rand((n, 1, S // 4, S // 4, S // 4), generator=g, device=device)
-    x = torch.nn.functional.interpolate(x, size=(S, S, S), mode='trilinear', align_corners=False)
-    x = x + 0.15 * torch.rand((n, 1, S, S, S), generator=g, device=device)
+    nd = len(shape)
+    x = torch.rand((n, 1) + tuple(s // 4 for s in shape), generator=g, device=device)
+    x = torch.nn.functional.interpolate(x, size=shape, mode='trilinear' if nd == 3 else 'bilinear', align_corners=False)
+    x = x + 0.15 * torch.rand((n, 1) + tuple(shape), generator=g, device=device)
     x = (x - x.amin()) / (x.amax() - x.amin())
-    return (x * 254 + 1).to(torch.uint8).reshape(n, S, S, S)
+    return (x * 254 + 1).to(torch.uint8).reshape((n,) + tuple(shape))
+
+
+def synth_volume_slab(z0, z1, Y, X, device):
+    """Planes [z0, z1) of the C4 volume: a function of the voxel coordinates only (smooth blobs + a coordinate hash for
+    texture), so every rank of every world size generates the same 1024^3 volume without a file."""
+    out = torch.empty((z1 - z0, Y, X), dtype=torch.uint8, device=device)
+    yy = torch.arange(Y, device=device, dtype=torch.float32).view(1, Y, 1)
+    xx = torch.arange(X, device=device, dtype=torch.float32).view(1, 1, X)
+    yi = torch.arange(Y, device=device, dtype=torch.int64).view(1, Y, 1)
+    xi = torch.arange(X, device=device, dtype=torch.int64).view(1, 1, X)
+    for a in range(z0, z1, 32):
+        b = min(a + 32, z1)
+        zz = torch.arange(a, b, device=device, dtype=torch.float32).view(-1, 1, 1)
+        zi = torch.arange(a, b, device=device, dtype=torch.int64).view(-1, 1, 1)
+        f = torch.sin(0.051 * zz + 0.3) + torch.sin(0.043 * yy + 1.0) * torch.cos(0.037 * xx) + torch.sin(0.029 * (xx + zz) + 2.0)
+        h = ((zi * 73856093) ^ (yi * 19349663) ^ (xi * 83492791)) & 31
+        out[a - z0:b - z0] = (128.0 + 30.0 * f + h.float()).clamp_(1, 255).to(torch.uint8)
+    return out
 
 
 def flops_per_voxel(dim, levels, base, cin, ncls):
@@ -54,83 +98,166 @@ def flops_per_voxel(dim, levels, base, cin, ncls):
     return f + 2 * ch[0] * ncls
 
 
-def pmc_traffic():
-    """HBM bytes per launch of the roofline kernel from the committed PMC profile (rocprofv3 cannot run
-    inside the timed process): FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate passes."""
-    try:
-        with open(os.path.join(ROOT, 'profiles', 'r01_pmc_conv3_dec0conv1.json')) as f:
-            return json.load(f)['traffic_bytes_per_launch']
-    except Exception:
-        return None
+def pmc_traffic(workload):
+    """HBM bytes per launch of the roofline kernel from the committed PMC profile (rocprofv3 cannot run inside the timed
+    process): FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate passes.  None where no profile is committed."""
+    for name in (f'r02_pmc_{workload}_dec0conv1.json', 'r01_pmc_conv3_dec0conv1.json' if workload in ('c3', 'c4') else ''):
+        try:
+            with open(os.path.join(ROOT, 'profiles', name)) as f:
+                return json.load(f)['traffic_bytes_per_launch']
+        except Exception:
+            continue
+    return None
 
 
-def conv_roofline(nv, dtype, S, iters=20):
-    """dec0.conv1 of the 3-D net: Cin 64 -> Cout 32, 27 taps, one 128^3 chunk.  3 warm-up + 20 timed back-to-back launches,
-    the same sequence as `tools/bench_conv.py --only 0:64:32 --wgrad 0 --iters 20` whose rocprofv3 summary is committed as
-    profiles/r01_roofline_kernel_stats.csv (the launch time drifts from 0.22 to 0.28 ms over such a run as the clock
-    settles under sustained MFMA load, so the number of launches matters)."""
+def conv_roofline(nv, cfg, workload, dtype, iters=50):
+    """dec0.conv1 of the workload's net (Cin = 2*base -> Cout = base, 3^d taps) on one step's tile batch: 3 warm-up +
+    `iters` timed back-to-back launches, an event around every launch.  achieved = average over all timed launches (what
+    `rocprofv3 --kernel-trace --stats` of tools/bench_conv.py averages too); burst = first 8, settled = last 20."""
     dev = 'cuda'
-    cin, cout, taps = 64, 32, 27
-    vox = S ** 3
-    x = (torch.randn(cin * vox, device=dev) * 0.5).to(dtype)
-    y = torch.empty(cout * vox, dtype=dtype, device=dev)
-    w = torch.randn(cout, cin, 3, 3, 3, device=dev) * 0.03
+    dim, base = cfg['dim'], cfg['base']
+    cin, cout, taps = 2 * base, base, 3 ** dim
+    shape = cfg['tile']
+    N = 1 if dim == 3 else max(1, cfg['chunks'])
+    D, H, W = shape if dim == 3 else (1,) + tuple(shape)
+    vox = D * H * W
+    x = (torch.randn(N * cin * vox, device=dev) * 0.5).to(dtype)
+    y = torch.empty(N * cout * vox, dtype=dtype, device=dev)
+    w = torch.randn((cout, cin) + (3,) * dim, device=dev) * 0.03
     dt = nv.DTYPE_CODE[dtype]
-    lay = nv.lib().iunet_conv3_pick_layout(3, 1, S, S, S, cin, cout)
+    lay = nv.lib().iunet_conv3_pick_layout(dim, N, D, H, W, cin, cout)
     pmode = 2 if lay > 0 else 0                 # layouts 1 and 2 share the K16 operator
     wpk = torch.empty(nv.pack_conv3_elems(cout, cin, taps, pmode), dtype=dtype, device=dev)
     bias = torch.zeros(cout, device=dev)
     nv.call('iunet_pack_conv3', dt, nv.ptr(w), None, nv.ptr(wpk), cout, cin, taps, pmode, nv.stream())
-    run = lambda: nv.call('iunet_conv3_fwd', dt, 3, nv.ptr(x), cin * vox, nv.ptr(y), cout * vox, nv.ptr(wpk),
-                          nv.ptr(bias), None, 1, S, S, S, cin, cout, 2, lay, nv.stream())
+    run = lambda: nv.call('iunet_conv3_fwd', dt, dim, nv.ptr(x), cin * vox, nv.ptr(y), cout * vox, nv.ptr(wpk),
+                          nv.ptr(bias), None, N, D, H, W, cin, cout, 2, lay, nv.stream())
     for _ in range(3):
         run()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(iters + 1)]
+    ev[0].record()
+    for i in range(iters):
         run()
-    e1.record()
+        ev[i + 1].record()
     torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / iters
-    flops = 2.0 * taps * cin * cout * vox
-    ach = flops / (ms * 1e-3) / 1e12
+    per = [ev[i].elapsed_time(ev[i + 1]) for i in range(iters)]
+    ms = ev[0].elapsed_time(ev[iters]) / iters
+    flops = 2.0 * taps * cin * cout * vox * N
+    tf = lambda t: flops / (t * 1e-3) / 1e12
+    burst, settled = sum(per[:8]) / 8, sum(per[-20:]) / 20
     kname = {0: 'conv3_mfma_kernel', 1: 'conv3_v2_kernel', 2: 'conv3_v4_kernel'}[lay]
-    return {'bound': 'mfma', 'kernel': kname + f'<{"bf16" if dtype == torch.bfloat16 else "f16"},3> (dec0.conv1 64->32 @128^3)',
-            'achieved': round(ach, 2), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / MFMA_PEAK_TFLOPS, 4),
-            'ms_per_launch': round(ms, 4), 'flops_per_launch': flops, 'traffic': pmc_traffic()}
+    tname = 'bf16' if dtype == torch.bfloat16 else 'f16'
+    where = f'{N} x {"x".join(str(s) for s in shape)}'
+    out = {'bound': 'mfma', 'kernel': f'{kname}<{tname},{dim}> (dec0.conv1 {cin}->{cout} @ {where})',
+           'achieved': round(tf(ms), 2), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(tf(ms) / MFMA_PEAK_TFLOPS, 4),
+           'ms_per_launch': round(ms, 4), 'launches': iters, 'flops_per_launch': flops,
+           'burst_ms_first8': round(burst, 4), 'burst_frac': round(tf(burst) / MFMA_PEAK_TFLOPS, 4),
+           'settled_ms_last20': round(settled, 4), 'settled_frac': round(tf(settled) / MFMA_PEAK_TFLOPS, 4),
+           'traffic': pmc_traffic(workload)}
+    alg_bytes = (cin + cout) * 2.0 * vox * N
+    out['algorithmic_bytes_per_launch'] = alg_bytes
+    out['hbm_gbs_algorithmic'] = round(alg_bytes / (ms * 1e-3) / 1e9, 1)
+    return out
 
 
-def cpu_baseline(ncls):
-    """Oracle (torch CPU fp32) on the host cores: bounded sample of the same step --
-    one training step (forward, MCC+CE loss, autograd backward, AdamW) plus one prediction
-    forward, on ONE 64^3 chunk (1/8 of a bench chunk), repeated twice."""
-    from oracle import unet_ref, metrics_ref
+def native_parity(model, cfg, chunk_u8):
+    """The benchmarked dtype against the native fp32 parity mode on one tile (same weights): max |logit| difference and
+    class-map mismatches.  Device only -- the fp32 mode is itself checked against the CPU oracle in the tests."""
+    from interactive_unet.engine_f32 import EngineF32
+    dim, ncls = cfg['dim'], cfg['ncls']
+    shape = tuple(chunk_u8.shape)
+    D, H, W = shape if dim == 3 else (1,) + shape
+    vox = D * H * W
+    e32 = EngineF32(dim, cfg['levels'], cfg['base'], 1, ncls, model.device)
+    e32.load_eval(model.named_tensors())
+    eng = model.engine('eval')
+    outs = []
+    for e in (eng, e32):
+        lg = torch.empty((1, ncls) + shape, device=model.device)
+        cl = torch.empty((1, vox), dtype=torch.uint8, device=model.device)
+        e.infer(chunk_u8, (vox, vox, H * W, W, 1), 1, D, H, W, logits=lg, cls=cl)
+        outs.append((lg, cl))
+    torch.cuda.synchronize()
+    (lg, cl), (lg32, cl32) = outs
+    res = {'tile': list(shape), 'dtype_vs': 'native fp32 parity mode (engine_f32, f32-input MFMA)',
+           'max_abs_logit_vs_fp32': float((lg - lg32).abs().max()), 'logit_scale': float(lg32.abs().max()),
+           'argmax_mismatch': int((cl != cl32).sum()), 'voxels': vox}
+    del e32
+    return res, lg32
+
+
+def cpu_baseline(cfg, model=None, chunk_u8=None):
+    """Oracle (torch CPU fp32) on the host cores: bounded sample of the same step -- one training step (forward,
+    MCC+CE loss, autograd backward, AdamW) plus one prediction forward on ONE reduced tile, repeated twice.  With
+    `model` given, the oracle's logits of the sample are also held against the native modes (checker use)."""
+    from oracle import unet_ref
+    from interactive_unet import metrics as host_metrics     # plain torch ops on the host (differentiable)
     cores = min(16, len(os.sched_getaffinity(0)))        # a 1-GPU box gets a 16-core share
     torch.set_num_threads(cores)
-    Sc = 64
-    p = unet_ref.init_params(dim=3, ncls=ncls, seed=0)
+    dim, levels, base, ncls = cfg['dim'], cfg['levels'], cfg['base'], cfg['ncls']
+    shp = (64, 64, 64) if dim == 3 and base == 32 else ((32, 32, 32) if dim == 3 else (256, 256))
+    frac = float(np.prod(shp)) / float(np.prod(cfg['tile']))
+    p = unet_ref.init_params(dim=dim, levels=levels, base=base, ncls=ncls, seed=0)
     pr = {k: v.clone().requires_grad_(not unet_ref.is_buffer(k)) for k, v in p.items()}
     m = {k: torch.zeros_like(v) for k, v in pr.items()}
     v = {k: torch.zeros_like(v) for k, v in pr.items()}
-    x = torch.rand(1, 1, Sc, Sc, Sc)
-    lab = (x > 0.5)
-    y = torch.cat([~lab, lab], 1).float()
-    from interactive_unet import metrics as host_metrics     # plain torch ops on the host (differentiable)
+    x = torch.rand((1, 1) + shp)
+    lab = (x * ncls).long().clamp_(max=ncls - 1)
+    y = torch.cat([(lab == c) for c in range(ncls)], 1).float()
+    axes = [0] + list(range(2, 2 + dim))
     reps, t0 = 2, None
     for it in range(reps + 1):
         if it == 1:
             t0 = time.time()                                   # first iteration warms the thread pool
-        probs = unet_ref.forward(pr, x, dim=3, training=True)
-        loss = host_metrics.mcc_ce_loss(probs, y, None, axes=[0, 2, 3, 4])
+        probs = unet_ref.forward(pr, x, dim=dim, levels=levels, training=True)
+        loss = host_metrics.mcc_ce_loss(probs, y, None, axes=axes)
         grads = torch.autograd.grad(loss, [t for k, t in pr.items() if t.requires_grad])
         with torch.no_grad():
             g = dict(zip([k for k, t in pr.items() if t.requires_grad], grads))
             unet_ref.adamw_step({k: t.data for k, t in pr.items()}, g, m, v, it + 1, 1e-4)
-            unet_ref.forward(pr, x, dim=3)
+            unet_ref.forward(pr, x, dim=dim, levels=levels)
     dt = time.time() - t0
-    return {'value': round(reps * 2 * Sc ** 3 / dt, 1), 'unit': 'voxels/s', 'cores': cores, 'kind': 'port',
-            'sample': f'{reps} x (1 training step + 1 prediction forward) of the fp32 oracle 3-D U-Net on one '
-                      f'{Sc}^3 chunk (1/8 bench chunk), torch CPU, {cores} threads; voxels counted once per leg'}
+    nvox = int(np.prod(shp))
+    out = {'value': round(reps * 2 * nvox / dt, 1), 'unit': 'voxels/s', 'cores': cores, 'kind': 'port',
+           'sample': f'{reps} x (1 training step + 1 prediction forward) of the fp32 oracle ({dim}-D U-Net, {levels} levels, '
+                     f'base {base}) on one {"x".join(map(str, shp))} tile ({frac:.3g} of a bench tile), torch CPU, '
+                     f'{cores} threads; voxels counted once per leg'}
+    chk = None
+    if model is not None and chunk_u8 is not None:
+        # checker: oracle logits of a crop of the bench tile with the MODEL's current weights vs both native modes
+        from interactive_unet.engine_f32 import EngineF32
+        sl = tuple(slice(0, s) for s in shp)
+        crop = chunk_u8[sl].contiguous()
+        params = {k: t.detach().float().cpu() for k, t in model.named_tensors().items()}
+        with torch.no_grad():
+            ref = unet_ref.forward_logits(params, crop.cpu().float()[None, None] / 255.0, dim=dim, levels=levels)
+        D, H, W = shp if dim == 3 else (1,) + shp
+        e32 = EngineF32(dim, levels, base, 1, ncls, model.device)
+        e32.load_eval(model.named_tensors())
+        chk = {'sample': f'{"x".join(map(str, shp))} crop of a bench tile, current weights'}
+        for name, e in ((cfg['dtype'], model.engine('eval')), ('fp32_mode', e32)):
+            lg = torch.empty((1, ncls) + shp, device=model.device)
+            cl = torch.empty((1, nvox), dtype=torch.uint8, device=model.device)
+            e.infer(crop, (nvox, nvox, H * W, W, 1), 1, D, H, W, logits=lg, cls=cl)
+            torch.cuda.synchronize()
+            chk[f'{name}_max_abs_logit_vs_cpu_fp32'] = float((lg.cpu() - ref).abs().max())
+            chk[f'{name}_argmax_mismatch'] = int((cl.cpu().long().reshape(-1) != ref.argmax(1).reshape(-1)).sum())
+        chk['voxels'] = nvox
+    return out, chk
+
+
+def relaunch(args):
+    """--gpus N without a launcher: start N ranks of this script under torch.distributed.run as CHILD processes
+    (nothing in this process has touched the GPU) and hand back their exit code."""
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
@@ -138,69 +265,129 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--chunks', type=int, default=2, help='128^3 chunks per GPU per step')
-    ap.add_argument('--size', type=int, default=128)
-    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f16'])
+    ap.add_argument('--workload', default='c3', choices=sorted(WORKLOADS))
+    ap.add_argument('--chunks', type=int, default=None, help='tiles per GPU per step (default: the workload\'s)')
+    ap.add_argument('--c4-reps', type=int, default=1, help='c3 only: timed 1024^3 predictions appended to the line (0 = skip)')
+    ap.add_argument('--c4-size', type=int, default=1024)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(relaunch(args))
 
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
+    if world != args.gpus:
+        sys.exit(f'bench.py: --gpus {args.gpus} but the launcher started {world} ranks')
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+    group = dist.group.WORLD if dist else None
 
     from interactive_unet import _native as nv
-
-    dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float16
-    S, B, ncls = args.size, args.chunks, 2
-    dev = torch.device('cuda', local)
-    import warnings
+    from interactive_unet import shard
     from interactive_unet.unet import UNet
     from interactive_unet.train_engine import TrainEngine
+    import warnings
+
+    cfg = dict(WORKLOADS[args.workload])
+    if args.chunks is not None:
+        cfg['chunks'] = args.chunks
+    dim, levels, base, ncls, B = cfg['dim'], cfg['levels'], cfg['base'], cfg['ncls'], cfg['chunks']
+    tile = tuple(cfg['tile'])
+    S = tile[0]
+    tvox = int(np.prod(tile))
+    dtype = torch.bfloat16 if cfg['dtype'] == 'bf16' else torch.float16
+    dev = torch.device('cuda', local)
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
-        model = UNet(lr=1e-4, num_classes=ncls, dim=3, act_dtype=args.dtype, pretrained=False)
+        model = UNet(lr=1e-4, num_classes=ncls, dim=dim, levels=levels, base=base, act_dtype=cfg['dtype'], pretrained=False,
+                     weight_dtype=cfg['wq'])
     model.reset_parameters(seed=0)                                      # random-init weights of the canonical architecture
     model = model.to(dev)
-    trainer = TrainEngine(model, lr=1e-4, loss_kind='mcc_ce', process_group=(dist.group.WORLD if dist else None))
-    chunks = synth_chunks(B, S, 1234 + rank, dev)
-    X = chunks.reshape(B, 1, S, S, S)                                   # uint8, /255 in the first conv
-    lab = X > 127
-    y = torch.cat([~lab, lab], 1).to(torch.float16)                     # loader contract: fp16 one-hot (loader.py:150-152)
-    w = (torch.rand((B, 1, S, S, S), device=dev) > 0.1).to(torch.float16).expand(B, ncls, S, S, S).contiguous()
-    y = y * w
-    # predict leg: ONE volume shared by all ranks, Z = 96*B*world + 32 planes of 128 x 128 -> exactly B
-    # overlapping 128^3 blocks per rank (predict.py:362-411 grid, overlap 0.25); every rank owns a z-slab,
-    # slabs are all-gathered and the overlapping accumulator planes exchanged over RCCL (shard.py)
-    from interactive_unet import shard
-    stride = int(S * 0.75)
-    V = (stride * B * world + (S - stride), S, S)
-    bounds, _ = shard.slab_bounds(V[0], world)
-    my_slab = synth_chunks(1, S, 4321 + rank, dev).reshape(S, S, S)
-    my_slab = my_slab.repeat(-(-(bounds[rank][1] - bounds[rank][0]) // S), 1, 1)[:bounds[rank][1] - bounds[rank][0]].contiguous()
-    ops = shard.NativeOps(model, ncls, S)
+    fpv = flops_per_voxel(dim, levels, base, 1, ncls)
     legs = {'train': 0.0, 'predict': 0.0}
     info = {}
 
-    def step(timed=False):
-        t0 = time.time()
-        trainer.train_step(X, y, w, sync=False)
-        if timed:
-            torch.cuda.synchronize(); t1 = time.time(); legs['train'] += t1 - t0
-        model.engine('eval')                                            # re-packs the updated weights (BN folded)
-        out_u8, st = shard.predict_volume_sharded(ops, my_slab, V, S, 0.25, group=(dist.group.WORLD if dist else None))
-        info.update(st)
-        if timed:
-            torch.cuda.synchronize(); legs['predict'] += time.time() - t1
+    # ------------------------------------------------------------------ the step of each workload
+    if args.workload == 'c4':
+        Vs = args.c4_size
+        V = (Vs, Vs, Vs)
+        bounds, _ = shard.slab_bounds(V[0], world)
+        my_slab = synth_volume_slab(bounds[rank][0], bounds[rank][1], V[1], V[2], dev)
+        ops = shard.NativeOps(model, ncls, S)
+
+        def step(timed=False):
+            t0 = time.time()
+            _, st = shard.predict_volume_sharded(ops, my_slab, V, S, 0.25, group=group)
+            info.update(st)
+            if timed:
+                torch.cuda.synchronize(); legs['predict'] += time.time() - t0
+        unique_vox = float(np.prod(V))
+        nblocks = len(shard.P.get_block_coordinates(np.array(V), S, 0.25)[0])
+        processed_vox = float(nblocks) * tvox
+        train_vox = 0.0
+        scaling = 'strong'
+    else:
+        trainer = TrainEngine(model, lr=1e-4, loss_kind='mcc_ce', process_group=group)
+        chunks = synth_chunks(B, tile, 1234 + rank, dev)
+        X = chunks.reshape((B, 1) + tile)                                  # uint8, /255 in the first conv
+        lab = (X.to(torch.int32) * ncls // 256).clamp_(max=ncls - 1)
+        y = torch.cat([(lab == c) for c in range(ncls)], 1).to(torch.float16)       # loader contract: fp16 one-hot (loader.py:150-152)
+        w = (torch.rand((B, 1) + tile, device=dev) > 0.1).to(torch.float16).expand((B, ncls) + tile).contiguous()
+        y = y * w
+        if dim == 3:
+            # predict leg: ONE volume shared by all ranks, Z = 96*B*world + 32 planes of S x S -> exactly B overlapping
+            # S^3 blocks per rank (predict.py:362-411 grid, overlap 0.25); every rank owns a z-slab, the slabs are
+            # all-gathered and the pieces of the block probabilities exchanged over RCCL (shard.py)
+            stride = int(S * 0.75)
+            V = (stride * B * world + (S - stride), S, S)
+            bounds, _ = shard.slab_bounds(V[0], world)
+            my_slab = synth_chunks(1, tile, 4321 + rank, dev).reshape(tile)
+            hh = bounds[rank][1] - bounds[rank][0]
+            my_slab = my_slab.repeat(-(-hh // S), 1, 1)[:hh].contiguous()
+            ops = shard.NativeOps(model, ncls, S)
+            unique_vox = float(np.prod(V))
+            processed_vox = float(B * world) * tvox
+
+            def predict_leg():
+                _, st = shard.predict_volume_sharded(ops, my_slab, V, S, 0.25, group=group)
+                info.update(st)
+        else:
+            # 2-D: the slices of the batch through the forward + softmax + argmax (predict.py:16-47 per slice)
+            V = (B * world,) + tile
+            probs = torch.empty((B, ncls) + tile, dtype=torch.float32, device=dev)
+            cls = torch.empty((B, tvox), dtype=torch.uint8, device=dev)
+            unique_vox = processed_vox = float(B * world) * tvox
+
+            def predict_leg():
+                model.engine('eval').infer(chunks, (tvox, tvox, tvox, tile[1], 1), B, 1, tile[0], tile[1], probs=probs, cls=cls)
+        train_vox = float(B * world) * tvox
+        scaling = 'weak'
+
+        def step(timed=False):
+            t0 = time.time()
+            trainer.train_step(X, y, w, sync=False)
+            if timed:
+                torch.cuda.synchronize(); t1 = time.time(); legs['train'] += t1 - t0
+            model.engine('eval')                                            # re-packs the updated weights (BN folded)
+            predict_leg()
+            if timed:
+                torch.cuda.synchronize(); legs['predict'] += time.time() - t1
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def max_over_ranks(dt):
+        if dist is None:
+            return dt
+        t = torch.tensor([dt], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return t.item()
 
     for _ in range(args.warmup):
         step()
@@ -209,48 +396,91 @@ def main():
     for _ in range(args.steps):
         step()
     barrier()
-    dt = time.time() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
+    dt = max_over_ranks(time.time() - t0)
     # leg split, measured in separate (untimed-for-value) steps so the timed region has no extra syncs
-    for _ in range(2):
+    nleg = 2 if args.workload != 'c4' else 1
+    for _ in range(nleg):
         step(timed=True)
-    vox_per_step = 2 * B * S ** 3 * world            # every chunk voxel goes through the train leg and the predict leg
-    value = vox_per_step * args.steps / dt
+    value = (train_vox + unique_vox) * args.steps / dt
+
+    # ------------------------------------------------------------------ c3: the C4 volume, timed in the same run
+    c4 = None
+    if args.workload == 'c3' and args.c4_reps > 0:
+        Vs = args.c4_size
+        V4 = (Vs, Vs, Vs)
+        b4, _ = shard.slab_bounds(Vs, world)
+        slab4 = synth_volume_slab(b4[rank][0], b4[rank][1], Vs, Vs, dev)
+        st4 = {}
+        run4 = lambda: st4.update(shard.predict_volume_sharded(ops, slab4, V4, S, 0.25, group=group)[1])
+        run4()                                                             # warm-up (allocations)
+        barrier()
+        t4 = time.time()
+        for _ in range(args.c4_reps):
+            run4()
+        barrier()
+        d4 = max_over_ranks(time.time() - t4) / args.c4_reps
+        nb4 = len(shard.P.get_block_coordinates(np.array(V4), S, 0.25)[0])
+        c4 = {'volume': list(V4), 'blocks': nb4, 'reps': args.c4_reps, 'seconds_per_volume': round(d4, 4), 'scaling': 'strong',
+              'volume_voxels_per_s': round(Vs ** 3 / d4, 1), 'processed_voxels_per_s': round(nb4 * tvox / d4, 1),
+              'tflops': round(fpv * nb4 * tvox / d4 / 1e12, 1), 'blocks_rank0': st4.get('blocks'),
+              'exchange_bytes_sent_rank0': st4.get('bytes_sent'), 'pieces_blended_rank0': st4.get('pieces_blended')}
+        del slab4
 
     out = None
     if rank == 0:
-        roof = conv_roofline(nv, dtype, S)
+        roof = conv_roofline(nv, cfg, args.workload, dtype)
+        tile_s = 'x'.join(str(s) for s in tile)
+        if args.workload == 'c4':
+            desc = (f'C4: tiled prediction of one {V[0]}^3 uint8 volume (generated on the device from the voxel coordinates), '
+                    f'{nblocks} blocks of {S}^3, overlap 0.25, 3-D U-Net {levels}-level base {base}, 1->{ncls} classes, {cfg["dtype"]}; '
+                    f'one step = one whole-volume prediction sharded over the {world} rank(s): slab all-gather, block forwards + '
+                    f'softmax, point-to-point exchange of the probability pieces in 8 rounds overlapped with the forwards, blend in '
+                    f'flat block order by the slab owners, normalise/quantise; wall time includes every exchange')
+        else:
+            desc = (f'{args.workload.upper()}: {dim}-D U-Net {levels}-level base {base}, 1->{ncls} classes, {cfg["dtype"]}'
+                    f'{", inference weights e4m3" if cfg["wq"] else ""}; {B} x {tile_s} uint8 tiles per GPU per step; step = 1 training '
+                    f'step (forward with BatchNorm batch stats, MCC+CE loss, backward, AdamW, weight re-pack; gradients all-reduced '
+                    f'over RCCL for N > 1) on the {B} tiles + ' +
+                    (f'tiled prediction of one {V[0]}x{S}x{S} uint8 volume shared by all ranks = {B} overlapping {S}^3 blocks per GPU '
+                     f'(reflect-padded block gather, forward + softmax, Gaussian blend, piece exchange over RCCL for N > 1, '
+                     f'normalise/quantise)' if dim == 3 else f'forward + softmax + argmax of the same {B} slices') +
+                    '; value = (training tile voxels + UNIQUE predicted voxels) / s')
         out = {
             'metric': 'voxels/sec (train step + full-volume predict) on 128^3 chunks',
             'value': round(value, 1), 'unit': 'voxels/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
-            'config': {'workload': f'C3: 3-D U-Net 4-level base 32, 1->{ncls} classes, {B} x {S}^3 uint8 chunks per GPU '
-                                   f'per step; step = 1 training step (forward with BatchNorm batch stats, MCC+CE loss, '
-                                   f'backward, AdamW, weight re-pack; gradients all-reduced over RCCL for N > 1) on the '
-                                   f'{B} chunks + tiled prediction of one {V[0]}x{S}x{S} uint8 volume shared by all ranks = '
-                                   f'{B} overlapping {S}^3 blocks per GPU (reflect-padded block gather, forward + softmax, '
-                                   f'Gaussian blend-accumulate, slab all-gather + overlap exchange over RCCL for N > 1, '
-                                   f'normalise/quantise); voxels = chunk voxels, counted once per leg',
-                       'predict_volume': list(V), 'predict_blocks_per_gpu': info.get('blocks'),
+            'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': scaling,
+            'vs_baseline': None, 'dtype': cfg['dtype'], 'data': 'synthetic',
+            'config': {'workload': desc, 'predict_volume': list(V), 'predict_blocks_per_gpu': info.get('blocks'),
                        'predict_exchange_bytes_sent_rank0': info.get('bytes_sent'),
-                       'chunks_per_gpu': B, 'chunk': S, 'levels': 4, 'base': 32,
-                       'fwd_flop_per_voxel': flops_per_voxel(3, 4, 32, 1, ncls)},
+                       'tiles_per_gpu': B, 'tile': list(tile), 'levels': levels, 'base': base,
+                       'train_voxels_per_step': train_vox, 'predict_unique_voxels_per_step': unique_vox,
+                       'predict_processed_voxels_per_step': processed_vox, 'fwd_flop_per_voxel': fpv},
             'roofline': roof,
         }
-        fpv = flops_per_voxel(3, 4, 32, 1, ncls)
-        out['legs'] = {'train_ms': round(legs['train'] / 2 * 1e3, 3), 'predict_ms': round(legs['predict'] / 2 * 1e3, 3),
-                       'train_voxels_per_s_per_gpu': round(B * S ** 3 / (legs['train'] / 2), 1),
-                       'predict_voxels_per_s_per_gpu': round(B * S ** 3 / (legs['predict'] / 2), 1),
-                       'train_tflops_per_gpu(3x fwd)': round(3 * fpv * B * S ** 3 / (legs['train'] / 2) / 1e12, 1),
-                       'predict_tflops_per_gpu': round(fpv * B * S ** 3 / (legs['predict'] / 2) / 1e12, 1)}
+        lg = {}
+        if legs['train'] > 0:
+            tt = legs['train'] / nleg
+            lg.update({'train_ms': round(tt * 1e3, 3), 'train_voxels_per_s_per_gpu': round(train_vox / world / tt, 1),
+                       'train_tflops_per_gpu(3x fwd)': round(3 * fpv * train_vox / world / tt / 1e12, 1)})
+        tp = legs['predict'] / nleg
+        lg.update({'predict_ms': round(tp * 1e3, 3), 'predict_volume_voxels_per_s': round(unique_vox / tp, 1),
+                   'predict_processed_voxels_per_s': round(processed_vox / tp, 1),
+                   'predict_tflops_per_gpu': round(fpv * processed_vox / world / tp / 1e12, 1)})
+        out['legs'] = lg
+        if c4 is not None:
+            out['c4'] = c4
+        if args.workload == 'c4':
+            probe = my_slab[:S, :S, :S].contiguous()
+        else:
+            probe = chunks[0]
+        out['parity'], _ = native_parity(model, cfg, probe)
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(ncls)
+            out['cpu_baseline'], chk = cpu_baseline(cfg, model, probe)
+            if chk:
+                out['parity']['vs_cpu_oracle'] = chk
         print(json.dumps(out), flush=True)
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

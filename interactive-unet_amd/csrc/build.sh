@@ -1,9 +1,11 @@
 #!/bin/bash
-# Build libiunet.so for gfx950 (cross-compiles without a GPU).
+# Build libiunet.so for gfx950 (cross-compiles without a GPU).  build.sh: incremental (sources newer than their objects);
+# build.sh --clean: every .hip file from scratch.
 set -e
 HERE="$(cd "$(dirname "$0")" && pwd)"
 OUT="$HERE/../lib"
 mkdir -p "$OUT" "$HERE/obj"
+if [ "$1" = "--clean" ]; then rm -f "$HERE"/obj/*.o "$OUT/libiunet.so"; fi      # full rebuild (~30 s on 8 cores): what build() runs
 FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-result -Wno-int-to-pointer-cast"
 pids=()
 for f in "$HERE"/*.hip; do

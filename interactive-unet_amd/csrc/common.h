@@ -84,7 +84,34 @@ void iunet_set_error(const char* fmt, ...);
       return IUNET_ERR_HIP;                                                          \
     }                                                                                \
   } while (0)
+#define IUNET_REQUIRE_GRID(what, N, D, H, W)                                          \
+  IUNET_REQUIRE((N) > 0 && (D) > 0 && (H) > 0 && (W) > 0, what ": bad shape N %d, %d x %d x %d", (N), (D), (H), (W))
 #define IUNET_REQUIRE(cond, ...)                                                     \
   do {                                                                               \
     if (!(cond)) { iunet_set_error(__VA_ARGS__); return IUNET_ERR_ARG; }             \
+  } while (0)
+
+// Opt a kernel in to more than 64 KB of dynamic LDS: once per (kernel, device), thread-safe.  The reference calls into
+// this path from threads (app.py:737-739, :774-778) and a process may run the model on several GPUs (Engine(device=...)):
+// a plain `static bool` would race, and would skip the call on the second device.  State = one slot per device holding
+// the largest size set so far; racing threads at worst both make the (idempotent) call.
+#include <atomic>
+struct IunetLdsOnce { std::atomic<int> set[32]; };
+inline int iunet_set_max_lds(IunetLdsOnce& st, const void* fn, int lds) {
+  int dev = 0;
+  IUNET_CHECK_HIP(hipGetDevice(&dev));
+  const bool tracked = dev >= 0 && dev < 32;
+  if (tracked && st.set[dev].load(std::memory_order_acquire) >= lds) return IUNET_OK;
+  IUNET_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  if (tracked) {
+    int cur = st.set[dev].load(std::memory_order_relaxed);
+    while (cur < lds && !st.set[dev].compare_exchange_weak(cur, lds, std::memory_order_release)) {}
+  }
+  return IUNET_OK;
+}
+#define IUNET_SET_MAX_LDS(fn, lds)                                              \
+  do {                                                                          \
+    static IunetLdsOnce once_;                                                  \
+    const int rc_ = iunet_set_max_lds(once_, (const void*)(fn), (lds));         \
+    if (rc_ != IUNET_OK) return rc_;                                            \
   } while (0)

@@ -309,12 +309,7 @@ int launch_conv3(const Conv3Params& p, hipStream_t stream) {
   constexpr int PZ = TL::TZ + 2 * TL::PADZ, PY = TL::TY + 2, PX = TL::TX + 2;
   constexpr int PLANE = ((PZ * PY * PX * 16 + 255) / 256) * 256;
   constexpr int LDS = 4 * PLANE;
-  static bool attr_set = false;
-  if (!attr_set) {
-    IUNET_CHECK_HIP(hipFuncSetAttribute((const void*)conv3_mfma_kernel<T, ND, MI>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-    attr_set = true;
-  }
+  IUNET_SET_MAX_LDS((conv3_mfma_kernel<T, ND, MI>), LDS);
   dim3 grid(p.tilesZ * p.tilesY * p.tilesX * p.N, p.Cout / (16 * MI));
   hipLaunchKernelGGL((conv3_mfma_kernel<T, ND, MI>), grid, dim3(256), LDS, stream, p);
   IUNET_CHECK_HIP(hipGetLastError());
@@ -368,7 +363,7 @@ int iunet_conv3_exp_launch(int exp, const void* x, void* y, const void* wpk, con
   p.tilesZ = (D + 3) / 4; p.tilesY = (H + 7) / 8; p.tilesX = (W + 15) / 16;
   constexpr int LDS = 4 * 17408;
   dim3 grid(p.tilesZ * p.tilesY * p.tilesX * N, Cout / 32);
-#define IUNET_EXP_CASE(E) case E: { static bool s = false; if (!s) { IUNET_CHECK_HIP(hipFuncSetAttribute((const void*)conv3_mfma_kernel<bf16, 3, 2, E>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); s = true; } \
+#define IUNET_EXP_CASE(E) case E: { IUNET_SET_MAX_LDS((conv3_mfma_kernel<bf16, 3, 2, E>), LDS); \
     hipLaunchKernelGGL((conv3_mfma_kernel<bf16, 3, 2, E>), grid, dim3(256), LDS, stream, p); } break;
   switch (exp) { IUNET_EXP_CASE(0) IUNET_EXP_CASE(1) IUNET_EXP_CASE(2) IUNET_EXP_CASE(4) IUNET_EXP_CASE(8) IUNET_EXP_CASE(3) IUNET_EXP_CASE(7) IUNET_EXP_CASE(15)
     default: iunet_set_error("conv3_exp: unsupported ablation mask %d", exp); return IUNET_ERR_ARG; }

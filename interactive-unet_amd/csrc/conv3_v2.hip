@@ -259,11 +259,7 @@ int launch_v2(const ConvV2Params& p, hipStream_t stream) {
   constexpr int PZ = TL::TZ + 2 * TL::PADZ, PY = TL::TY + 2, PX = TL::TX + 2;
   constexpr int PLANE = ((PZ * PY * PX * 16 + 255) / 256) * 256;
   constexpr int LDS = 2 * PLANE + ((TL::TAPS / 3 + 1) / 2) * 3 * 2 * 1024;
-  static bool attr_set = false;
-  if (!attr_set) {
-    IUNET_CHECK_HIP(hipFuncSetAttribute((const void*)conv3_v2_kernel<T, ND>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-    attr_set = true;
-  }
+  IUNET_SET_MAX_LDS((conv3_v2_kernel<T, ND>), LDS);
   const int ntiles = p.tilesZ * p.tilesY * p.tilesX * p.N;
   const int ncob = p.Cout / 32;
   // two workgroups per CU; with several cout blocks the CUs are split between them

@@ -467,11 +467,7 @@ int launch_v4(ConvV4Params p, hipStream_t stream) {
   constexpr int PLANE = ((NPIX * 16 + 255) / 256) * 256;
   constexpr int WSTEP = TL::S16 * ((TL::NCOL + 1) / 2) * 3 * 2 * 1024;
   const int lds = 2 * 2 * TL::S16 * PLANE + (WS ? p.Cin / (16 * TL::S16) : 2) * WSTEP + 2048 + p.Cin * 8;
-  static int attr_lds = 0;
-  if (lds > attr_lds) {
-    IUNET_CHECK_HIP(hipFuncSetAttribute((const void*)conv3_v4_kernel<T, ND, WS, SMALL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    attr_lds = lds;
-  }
+  IUNET_SET_MAX_LDS((conv3_v4_kernel<T, ND, WS, SMALL>), lds);
   p.tilesZ = (p.D + TL::TZ - 1) / TL::TZ; p.tilesY = (p.H + TL::TY - 1) / TL::TY; p.tilesX = (p.W + TL::TX - 1) / TL::TX;
   const int ncob = p.Cout / 32;
   // one workgroup per CU: 8 XCDs x (bz x by x bx) brick slots per Cout tile

@@ -251,11 +251,7 @@ int launch_wgrad(const WgradParams& p, int nb, hipStream_t stream) {
   constexpr int PLANE_X = ((PZ * PY * PX * 16 + 255) / 256) * 256 + 64;
   constexpr int PLANE_Y = ((TL::TZ * TL::TY * TL::TX * 16 + 255) / 256) * 256 + 64;
   constexpr int LDS = 4 * PLANE_X + 4 * PLANE_Y;
-  static bool attr_set = false;
-  if (!attr_set) {
-    IUNET_CHECK_HIP(hipFuncSetAttribute((const void*)conv3_wgrad_kernel<T, ND>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-    attr_set = true;
-  }
+  IUNET_SET_MAX_LDS((conv3_wgrad_kernel<T, ND>), LDS);
   dim3 grid(nb, p.Cout / 32, p.Cin / 32);
   hipLaunchKernelGGL((conv3_wgrad_kernel<T, ND>), grid, dim3(256), LDS, stream, p);
   IUNET_CHECK_HIP(hipGetLastError());
@@ -277,6 +273,7 @@ extern "C" {
 
 // number of voxel-walking workgroups per (co, ci) block and the slab size they need
 int iunet_conv3_wgrad_blocks(int nd, int N, int D, int H, int W, int Cin, int Cout) {
+  if (N < 1 || D < 1 || H < 1 || W < 1 || Cin < 32 || Cout < 32 || (nd != 2 && nd != 3)) return 0;
   if (wgrad_use_v2(nd)) return iunet_conv3_wgrad_v2_blocks(N, D, H, W, Cin, Cout);
   const int TZ = nd == 3 ? 2 : 1, TY = nd == 3 ? 8 : 16, TX = nd == 3 ? 16 : 32;
   const long long ntiles = (long long)N * ((D + TZ - 1) / TZ) * ((H + TY - 1) / TY) * ((W + TX - 1) / TX);
@@ -297,7 +294,9 @@ static int wgrad_impl(int dtype, int nd, const void* x, long long x_ss, const vo
                       const float* x_shift, void* stream) {
   IUNET_REQUIRE(dtype == 0 || dtype == 1, "conv3_wgrad: bad dtype %d", dtype);
   IUNET_REQUIRE(nd == 2 || nd == 3, "conv3_wgrad: nd must be 2 or 3");
-  IUNET_REQUIRE(Cin % 32 == 0 && Cout % 32 == 0, "conv3_wgrad: channels must be multiples of 32 (%d, %d)", Cin, Cout);
+  IUNET_REQUIRE(Cin >= 32 && Cout >= 32 && Cin % 32 == 0 && Cout % 32 == 0, "conv3_wgrad: channels must be positive multiples of 32 (%d, %d)", Cin, Cout);
+  IUNET_REQUIRE_GRID("conv3_wgrad", N, D, H, W);
+  IUNET_REQUIRE(nd == 3 || D == 1, "conv3_wgrad: 2-D needs D == 1");
   IUNET_REQUIRE(x && dy && slab && dW, "conv3_wgrad: null pointer");
   WgradParams p;
   p.x = x; p.x_ss = x_ss; p.dy = dy; p.dy_ss = dy_ss; p.slab = (float*)slab; p.x_scale = x_scale; p.x_shift = x_shift;

@@ -334,12 +334,10 @@ int iunet_conv3_wgrad_v2_launch(int dtype, const void* x, long long x_ss, const 
   const int nb = iunet_conv3_wgrad_v2_blocks(N, D, H, W, Cin, Cout);
   dim3 grid(nb, Cout / 32, Cin / 32);
   if (dtype == 0) {
-    static bool s = false;
-    if (!s) { IUNET_CHECK_HIP(hipFuncSetAttribute((const void*)conv3_wgrad_v2_kernel<f16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); s = true; }
+    IUNET_SET_MAX_LDS(conv3_wgrad_v2_kernel<f16>, LDS);
     hipLaunchKernelGGL(conv3_wgrad_v2_kernel<f16>, grid, dim3(768), LDS, stream, p);
   } else {
-    static bool s = false;
-    if (!s) { IUNET_CHECK_HIP(hipFuncSetAttribute((const void*)conv3_wgrad_v2_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); s = true; }
+    IUNET_SET_MAX_LDS(conv3_wgrad_v2_kernel<bf16>, LDS);
     hipLaunchKernelGGL(conv3_wgrad_v2_kernel<bf16>, grid, dim3(768), LDS, stream, p);
   }
   IUNET_CHECK_HIP(hipGetLastError());

@@ -533,7 +533,7 @@ int iunet_convT_launch(int dtype, int nd, const void* x, long long x_ss, void* y
     const int cap = 1024 / (Cout / 32);                // ~4 workgroups per CU in total
     if (gx > cap) gx = cap;
     dim3 g2(gx, Cout / 32);
-#define CTL(TT, NDV, NKV) do { static bool s_ = false; if (!s_) { IUNET_CHECK_HIP(hipFuncSetAttribute((const void*)convT_lds_kernel<TT, NDV, NKV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); s_ = true; } \
+#define CTL(TT, NDV, NKV) do { IUNET_SET_MAX_LDS((convT_lds_kernel<TT, NDV, NKV>), lds); \
     hipLaunchKernelGGL((convT_lds_kernel<TT, NDV, NKV>), g2, dim3(256), lds, stream, p); } while (0)
 #define CTL_NK(TT, NDV) switch (nk) { case 1: CTL(TT, NDV, 1); break; case 2: CTL(TT, NDV, 2); break; case 3: CTL(TT, NDV, 3); break; default: CTL(TT, NDV, 4); break; }
     if (dtype == 0) { if (nd == 3) { CTL_NK(f16, 3) } else { CTL_NK(f16, 2) } }

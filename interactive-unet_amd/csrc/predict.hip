@@ -85,6 +85,7 @@ extern "C" {
 
 // predict.get_padded_block (predict.py:291-316) on a device-resident uint8 volume.
 int iunet_gather_block(const void* vol, int Vz, int Vy, int Vx, int i0, int j0, int k0, int S, void* out, void* stream) {
+  IUNET_REQUIRE(vol && out, "gather_block: null pointer");
   IUNET_REQUIRE(S > 0 && Vz > 0 && Vy > 0 && Vx > 0, "gather_block: bad shape");
   IUNET_REQUIRE(i0 < Vz && j0 < Vy && k0 < Vx && i0 + S > 0 && j0 + S > 0 && k0 + S > 0,
                 "gather_block: block does not intersect the volume");
@@ -98,6 +99,8 @@ int iunet_gather_block(const void* vol, int Vz, int Vy, int Vx, int i0, int j0, 
 // blend-accumulate of predict.py:244-245.  block = clipped volume coords [6], local = coords inside the block [6].
 int iunet_blend_accumulate(void* pred, void* weight, const void* P, const void* window, int Vz, int Vy, int Vx, int C,
                            int S, const int* block, const int* local, void* stream) {
+  IUNET_REQUIRE(pred && weight && P && window && block && local, "blend: null pointer");
+  IUNET_REQUIRE(C > 0 && S > 0, "blend: bad class count %d / block size %d", C, S);
   const int ez = block[3] - block[0], ey = block[4] - block[1], ex = block[5] - block[2];
   IUNET_REQUIRE(ez > 0 && ey > 0 && ex > 0, "blend: empty block");
   IUNET_REQUIRE(block[0] >= 0 && block[1] >= 0 && block[2] >= 0 && block[3] <= Vz && block[4] <= Vy && block[5] <= Vx,
@@ -115,6 +118,8 @@ int iunet_blend_accumulate(void* pred, void* weight, const void* P, const void* 
 // normalise + quantise of predict.py:252-256.
 int iunet_normalize_quantize(const void* pred, const void* weight, void* out_u8, long long nvox, int C, float eps,
                              void* stream) {
+  IUNET_REQUIRE(pred && weight && out_u8, "normalize_quantize: null pointer");
+  IUNET_REQUIRE(nvox > 0 && C > 0, "normalize_quantize: %lld voxels, %d classes", nvox, C);
   const long long total = nvox * C;
   hipLaunchKernelGGL(normalize_quantize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, (const float*)pred, (const float*)weight, (unsigned char*)out_u8, nvox, C, eps);
@@ -123,6 +128,7 @@ int iunet_normalize_quantize(const void* pred, const void* weight, void* out_u8,
 }
 
 int iunet_div_f32(void* p, long long n, float d, void* stream) {
+  IUNET_REQUIRE(p && n > 0, "div_f32: null pointer or empty range");
   hipLaunchKernelGGL(div_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (float*)p, n, d);
   IUNET_CHECK_HIP(hipGetLastError());
   return IUNET_OK;

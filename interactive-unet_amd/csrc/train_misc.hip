@@ -537,7 +537,8 @@ extern "C" {
 int iunet_pack_convT_dgrad(int dtype, const void* w, void* dst, int Cin, int Cout, int npos, void* stream) {
   DT_OK(dtype);
   IUNET_REQUIRE(w && dst, "pack_convT_dgrad: null pointer");
-  IUNET_REQUIRE(Cin % 32 == 0 && Cout % 32 == 0, "pack_convT_dgrad: channels must be multiples of 32");
+  IUNET_REQUIRE(Cin >= 32 && Cout >= 32 && Cin % 32 == 0 && Cout % 32 == 0, "pack_convT_dgrad: channels must be positive multiples of 32");
+  IUNET_REQUIRE(npos == 4 || npos == 8, "pack_convT_dgrad: npos must be 4 or 8");
   const long long total = (long long)Cin * Cout * npos;
   const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
   if (dtype == 0) hipLaunchKernelGGL(pack_convT_dgrad_kernel<f16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)w, (f16*)dst, Cin, Cout, npos);
@@ -551,6 +552,9 @@ int iunet_convT_dgrad(int dtype, int nd, const void* dy, long long dy_ss, void* 
                       int N, int D, int H, int W, int Cin, int Cout, void* stream) {
   DT_OK(dtype);
   IUNET_REQUIRE(dy && dx && wpk, "convT_dgrad: null pointer");
+  IUNET_REQUIRE(nd == 2 || nd == 3, "convT_dgrad: nd must be 2 or 3");
+  IUNET_REQUIRE_GRID("convT_dgrad", N, D, H, W);
+  IUNET_REQUIRE(Cin >= 32 && Cout >= 32 && Cin % 32 == 0 && Cout % 32 == 0, "convT_dgrad: channels must be positive multiples of 32 (%d, %d)", Cin, Cout);
   ConvTDgradParams p;
   p.dy = dy; p.dy_ss = dy_ss; p.dx = dx; p.dx_ss = dx_ss; p.wpk = wpk; p.N = N; p.D = D; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
   const long long waves = (long long)N * D * H * ((W + 15) / 16);
@@ -561,7 +565,7 @@ int iunet_convT_dgrad(int dtype, int nd, const void* dy, long long dy_ss, void* 
     const int cap = 1024 / (Cin / 32);
     if (gx > cap) gx = cap;
     dim3 g2(gx, Cin / 32);
-#define CDL(TT, NDV, NKV) do { static bool s_ = false; if (!s_) { IUNET_CHECK_HIP(hipFuncSetAttribute((const void*)convT_dgrad_lds_kernel<TT, NDV, NKV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); s_ = true; } \
+#define CDL(TT, NDV, NKV) do { IUNET_SET_MAX_LDS((convT_dgrad_lds_kernel<TT, NDV, NKV>), lds); \
     hipLaunchKernelGGL((convT_dgrad_lds_kernel<TT, NDV, NKV>), g2, dim3(256), lds, (hipStream_t)stream, p); } while (0)
 #define CDL_NK(TT, NDV) switch (nk) { case 1: CDL(TT, NDV, 1); break; case 2: CDL(TT, NDV, 2); break; case 3: CDL(TT, NDV, 3); break; default: CDL(TT, NDV, 4); break; }
     if (dtype == 0) { if (nd == 3) { CDL_NK(f16, 3) } else { CDL_NK(f16, 2) } }
@@ -581,6 +585,7 @@ int iunet_convT_dgrad(int dtype, int nd, const void* dy, long long dy_ss, void* 
 }
 
 int iunet_convT_wgrad_blocks(int nd, int N, int D, int H, int W, int Cin, int Cout) {
+  if (N < 1 || D < 1 || H < 1 || W < 1 || Cin < 32 || Cout < 32) return 0;
   const int TZ = nd == 3 ? 2 : 1, TY = nd == 3 ? 4 : 8, TX = 16;
   const long long ntiles = (long long)N * ((D + TZ - 1) / TZ) * ((H + TY - 1) / TY) * ((W + TX - 1) / TX);
   const int pairs = (Cin / 32) * (Cout / 32);
@@ -594,7 +599,9 @@ int iunet_convT_wgrad(int dtype, int nd, const void* x, long long x_ss, const vo
                       void* bslab, void* dW, void* db, int N, int D, int H, int W, int Cin, int Cout, void* stream) {
   DT_OK(dtype);
   IUNET_REQUIRE(x && dy && wslab && bslab && dW && db, "convT_wgrad: null pointer");
-  IUNET_REQUIRE(Cin % 32 == 0 && Cout % 32 == 0, "convT_wgrad: channels must be multiples of 32");
+  IUNET_REQUIRE(Cin >= 32 && Cout >= 32 && Cin % 32 == 0 && Cout % 32 == 0, "convT_wgrad: channels must be positive multiples of 32");
+  IUNET_REQUIRE(nd == 2 || nd == 3, "convT_wgrad: nd must be 2 or 3");
+  IUNET_REQUIRE_GRID("convT_wgrad", N, D, H, W);
   ConvTWgradParams p;
   p.x = x; p.x_ss = x_ss; p.dy = dy; p.dy_ss = dy_ss; p.wslab = (float*)wslab; p.bslab = (float*)bslab;
   p.N = N; p.D = D; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
@@ -605,7 +612,7 @@ int iunet_convT_wgrad(int dtype, int nd, const void* x, long long x_ss, const vo
   const int nvi = 128, nvo = nd == 3 ? 1024 : 512;
   const int lds = 4 * (nvi * 16 + 64) + 4 * (nvo * 16 + 64);
   dim3 grid(nb, Cin / 32, Cout / 32);
-#define CTW(TT, NDV) do { static bool s_ = false; if (!s_) { IUNET_CHECK_HIP(hipFuncSetAttribute((const void*)convT_wgrad_kernel<TT, NDV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); s_ = true; } \
+#define CTW(TT, NDV) do { IUNET_SET_MAX_LDS((convT_wgrad_kernel<TT, NDV>), lds); \
     hipLaunchKernelGGL((convT_wgrad_kernel<TT, NDV>), grid, dim3(256), lds, (hipStream_t)stream, p); } while (0)
   if (dtype == 0) { if (nd == 3) CTW(f16, 3); else CTW(f16, 2); } else { if (nd == 3) CTW(bf16, 3); else CTW(bf16, 2); }
 #undef CTW
@@ -617,6 +624,7 @@ int iunet_convT_wgrad(int dtype, int nd, const void* x, long long x_ss, const vo
 }
 
 int iunet_first_conv_wgrad_blocks(int nd, int N, int D, int H, int W) {
+  if (N < 1 || D < 1 || H < 1 || W < 1) return 0;
   const int TZ = nd == 3 ? 4 : 1, TY = nd == 3 ? 8 : 16, TX = nd == 3 ? 16 : 32;
   const long long ntiles = (long long)N * ((D + TZ - 1) / TZ) * ((H + TY - 1) / TY) * ((W + TX - 1) / TX);
   return (int)(ntiles < 512 ? ntiles : 512);
@@ -629,7 +637,10 @@ static int first_wgrad_impl(int dtype, int nd, const void* x, int in_dtype, cons
                             const float* scale, const float* shift, void* stream) {
   DT_OK(dtype);
   IUNET_REQUIRE(x && dy && slab && dW && in_strides, "first_conv_wgrad: null pointer");
-  IUNET_REQUIRE(Cin >= 1 && Cin <= 4 && Cout % 32 == 0, "first_conv_wgrad: Cin 1..4, Cout multiple of 32");
+  IUNET_REQUIRE(Cin >= 1 && Cin <= 4 && Cout >= 32 && Cout % 32 == 0, "first_conv_wgrad: Cin 1..4, Cout a positive multiple of 32");
+  IUNET_REQUIRE(nd == 2 || nd == 3, "first_conv_wgrad: nd must be 2 or 3");
+  IUNET_REQUIRE(in_dtype >= 0 && in_dtype <= 3, "first_conv_wgrad: bad input dtype %d", in_dtype);
+  IUNET_REQUIRE_GRID("first_conv_wgrad", N, D, H, W);
   FirstWgradParams p;
   p.x = x; p.sN = in_strides[0]; p.sC = in_strides[1]; p.sD = in_strides[2]; p.sH = in_strides[3]; p.sW = in_strides[4];
   p.in_dtype = in_dtype; p.dy = dy; p.dy_ss = dy_ss; p.slab = (float*)slab;
@@ -644,7 +655,7 @@ static int first_wgrad_impl(int dtype, int nd, const void* x, int in_dtype, cons
   int lds = xs_bytes + 4 * (512 * 16 + 64);
   if (lds < 4 * 32 * KKP * 4) lds = 4 * 32 * KKP * 4;
   dim3 grid(nb, Cout / 32);
-#define FW(TT, NDV, CI) do { static bool s_ = false; if (!s_) { IUNET_CHECK_HIP(hipFuncSetAttribute((const void*)first_wgrad_kernel<TT, NDV, CI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); s_ = true; } \
+#define FW(TT, NDV, CI) do { IUNET_SET_MAX_LDS((first_wgrad_kernel<TT, NDV, CI>), lds); \
     hipLaunchKernelGGL((first_wgrad_kernel<TT, NDV, CI>), grid, dim3(256), lds, (hipStream_t)stream, p); } while (0)
 #define FW_CIN(TT, NDV) switch (Cin) { case 1: FW(TT, NDV, 1); break; case 2: FW(TT, NDV, 2); break; case 3: FW(TT, NDV, 3); break; default: FW(TT, NDV, 4); break; }
   if (dtype == 0) { if (nd == 3) { FW_CIN(f16, 3) } else { FW_CIN(f16, 2) } }

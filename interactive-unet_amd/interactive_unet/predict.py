@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from . import _native as nv
-from . import utils
+from . import multiscale
 
 
 # --------------------------------------------------------------------------- helpers (predict.py:270-411)
@@ -123,6 +123,8 @@ class VolumeAccumulator:
 
     def finalize(self, eps=1e-3):
         """predict.py:252-256: uint8(255 * pred / max(weight, eps)), truncating."""
+        if self.V[0] * self.V[1] * self.V[2] == 0:
+            return self.final
         nv.call('iunet_normalize_quantize', nv.ptr(self.pred), nv.ptr(self.weight), nv.ptr(self.final),
                 self.V[0] * self.V[1] * self.V[2], self.C, float(eps), nv.stream())
         return self.final
@@ -292,25 +294,23 @@ def predict_volume_array(model, volume, input_size=256, num_classes=2, overlap=0
 
 def predict_volumes(input_size=256, num_channels=1, num_classes=2, overlap=0.25, chunk_size=128, shard_size=256,
                     batch_size=None, axes=[0, 1, 2]):
-    """predict.py:114-266.  Zarr I/O (data/image_volumes/*.zarr -> data/predicted_volumes) is the
-    caller-side format layer; the compute between read and write is
-    predict_volume_array.  Needs the `zarr` package for the I/O."""
-    try:
-        import zarr
-    except ImportError as e:       # pragma: no cover
-        raise ImportError('predict_volumes needs zarr for volume I/O; use predict_volume_array for arrays') from e
+    """predict.py:114-266: every data/image_volumes/<name>.zarr['0'] (uint8 [Z,Y,X]) -> data/predicted_volumes/<name>.zarr
+    ['0'] uint8 [Z,Y,X,C], chunks (chunk_size,)*3 + (C,) inside shards (shard_size,)*3 + (C,) (predict.py:173-180), then the
+    multiscale pyramid (predict.py:261).  The store is read and written by zarr3.py shard by shard through pinned staging;
+    everything between -- block grid, reflect-padded blocks, block prediction, Gaussian blend, normalise + quantise, the
+    pyramid levels -- stays in HBM (the reference keeps float32 accumulators in temporary Zarr arrays on disk)."""
+    from . import zarr3
     device = torch.device('cuda')
     model = _load_model(num_channels, num_classes, device)
     for f in np.sort(glob.glob('data/image_volumes/*.zarr')):
         start = time.time()
-        volume = np.asarray(zarr.open(f, mode='r')['0'])
+        volume = zarr3.open(f, mode='r')['0'].to_device(device)
         final = predict_volume_array(model, volume, input_size, num_classes, overlap, batch_size, axes)
         save_path = f.replace('image_volumes', 'predicted_volumes')
-        root = zarr.open(save_path, mode='w')
+        root = zarr3.open(save_path, mode='w')
         arr = root.create_array(name='0', shape=list(final.shape), dtype='uint8', overwrite=True,
                                 chunks=(chunk_size,) * 3 + (num_classes,), shards=(shard_size,) * 3 + (num_classes,))
-        arr[...] = final.cpu().numpy()
-        del root, arr
-        utils.add_multiscales(save_path, scale=0.5)                      # predict.py:261 (levels zoomed on the device)
+        arr.from_device(final)
+        multiscale.add_multiscales(save_path, scale=0.5, level0=final)     # predict.py:261 (levels zoomed on the device)
         print(f'Completed volume {os.path.basename(f)} {tuple(volume.shape)} in {time.time() - start}.')
     print('\nAll volumes segmented.\n')

@@ -3,20 +3,26 @@
 The reference only sketches "one block per GPU" in comments (predict.py:137-147, :204-232).
 Here:
 
-* data ownership   z-slabs of the volume: rank r owns planes [r*Z/W, (r+1)*Z/W) of the uint8
-                    input and of the float32 accumulators / uint8 output;
-* compute          the flat (i, j, k) block list is cut into W contiguous runs (balanced to one
-                    block; a split by block planes would cap 8 GPUs at 5.5x for an 11^3 grid);
-* input exchange   all-gather of the uint8 slabs (RCCL; 1 GiB total for 1024^3 -- a block run
-                    touches neighbouring slabs through overlap and reflect padding);
-* output exchange  every rank blends its blocks into a full-height accumulator, then the part of
-                    its footprint that lies in another rank's slab goes to that owner as ONE
-                    point-to-point message per peer (xGMI is point-to-point: each peer has its
-                    own link, so direct sends beat a ring), and the owner adds the pieces in
-                    ascending source-rank order (deterministic).
+* data ownership   z-slabs of the volume: rank r owns planes [r*h, (r+1)*h) of the uint8 input, of the float32
+                    accumulators and of the uint8 output -- and NOTHING else: its accumulators are slab-sized
+                    (1.6 GB of the 12 GiB at 1024^3 on 8 ranks);
+* compute          the flat (i, j, k) block list is cut into W contiguous runs (balanced to one block; a split by
+                    block planes would cap 8 GPUs at 5.5x for an 11^3 grid); a rank runs the network on its blocks
+                    and keeps their probabilities [S,S,S,C] in HBM;
+* input exchange   all-gather of the uint8 slabs (RCCL; 1 GiB total for 1024^3 -- a block run touches neighbouring
+                    slabs through overlap and reflect padding);
+* output exchange  a block's probabilities are cut along z at the slab boundaries into PIECES (contiguous memory);
+                    the pieces that fall in another rank's slab go to that owner point to point (xGMI is point to
+                    point: each peer has its own link), in `rounds` grouped exchanges issued while the next blocks
+                    compute, so only the last round is exposed;
+* blending         every owner blends the pieces of its slab -- its own and the received ones -- in FLAT BLOCK
+                    ORDER with the same kernel as the single-process path (pred += P * win, weight += win, each
+                    operation separately rounded).  Every voxel therefore sees exactly the additions of the
+                    one-process loop in exactly its order: the N-rank result is byte-identical to the 1-rank
+                    result (tests/test_shard_cpu.py), which fp32 partial sums per rank cannot give.
 
-The compute is behind a small `ops` interface so the same sharding logic runs on the GPU
-(NativeOps -> libiunet) and in the world_size-2 gloo tests on CPU (a numpy stand-in there).
+The compute is behind a small `ops` interface so the same sharding logic runs on the GPU (NativeOps -> libiunet)
+and in the world_size-2 / 3 gloo tests on CPU (a numpy stand-in there).
 """
 import numpy as np
 import torch
@@ -44,6 +50,18 @@ def footprint(block_coords, lo, hi):
     return int(b[:, 0].min()), int(b[:, 3].max())
 
 
+def block_pieces(block, local, bounds):
+    """Cut one block along z at the slab boundaries: [(owner, za, zb, pa)] with [za, zb) the piece's planes in volume
+    coordinates and pa the block-local z of its first plane (block = clipped volume coords, local = coords inside
+    the S^3 block, as get_block_coordinates returns them)."""
+    out = []
+    for q, (s0, s1) in enumerate(bounds):
+        za, zb = max(int(block[0]), s0), min(int(block[3]), s1)
+        if zb > za:
+            out.append((q, za, zb, int(local[0]) + za - int(block[0])))
+    return out
+
+
 class NativeOps:
     """GPU implementation of the per-block work (libiunet through the predict shim)."""
 
@@ -51,118 +69,168 @@ class NativeOps:
         self.model, self.C, self.S, self.bs, self.axes = model, num_classes, input_size, batch_size, list(axes)
         self.device = model.device
         self.eng = model.engine('eval')
-        self.blk = torch.empty((input_size,) * 3, dtype=torch.uint8, device=self.device)
-        self._acc = {}
+        self._acc, self._store, self._blk = {}, None, None
 
-    def make_accumulator(self, V, zero=None):
-        """Accumulators are cached per volume shape (the Gaussian window and 12 B/voxel of HBM are not
-        re-created for every volume of a series); a re-used one is zeroed -- only planes [zero[0], zero[1]) when given
-        (a rank touches its footprint and its slab, not the whole height: 1/8 of the planes at 8 ranks)."""
+    # ---- single-rank path: blend at once into a whole-volume accumulator (predict.predict_volume_array's loop)
+    def make_accumulator(self, V):
+        """Accumulators are cached per shape (the Gaussian window and 12 B/voxel of HBM are not re-created for every
+        volume of a series); a re-used one is zeroed."""
         acc = self._acc.get(tuple(V))
         if acc is None:
             acc = P.VolumeAccumulator(V, self.C, self.S, self.device)
             self._acc = {tuple(V): acc}
-        elif zero is None:
-            acc.reset()
         else:
-            acc.pred[zero[0]:zero[1]].zero_()
-            acc.weight[zero[0]:zero[1]].zero_()
+            acc.reset()
         return acc
 
-    def predict_into(self, acc, volume, block, padded, local):
-        S, C = self.S, self.C
-        P.gather_block(volume, padded, S, out=self.blk)
-        if self.eng.dim == 2:
-            P.predict_block_device(self.model, self.blk, acc.block_probs, C, self.bs, self.axes)
-        else:
-            self.eng.infer(self.blk, (S ** 3, S ** 3, S * S, S, 1), 1, S, S, S, probs=acc.block_probs,
-                           out_strides=(0, 1, S * S * C, S * C, C))
-        acc.blend(block, local)
-
     def predict_run(self, acc, volume, bc, pbc, lbc, lo, hi):
-        """Blocks lo..hi-1 of the flat list (3-D net: batched forward; 2-D net: one block at a time)."""
+        """Blocks lo..hi-1 of the flat list, blended in list order (3-D net: batched forward; 2-D net: 2.5-D)."""
         if self.eng.dim == 3:
             P.predict_blocks_3d(self.eng, acc, volume, bc, pbc, lbc, lo, hi)
         else:
+            blk = torch.empty((self.S,) * 3, dtype=torch.uint8, device=self.device)
             for i in range(lo, hi):
-                self.predict_into(acc, volume, bc[i], pbc[i], lbc[i])
+                P.gather_block(volume, pbc[i], self.S, out=blk)
+                P.predict_block_device(self.model, blk, acc.block_probs, self.C, self.bs, self.axes)
+                acc.blend(bc[i], lbc[i])
 
-    def finalize_slab(self, acc, z0, z1):
-        """uint8(255 * pred / max(weight, 1e-3)) for planes [z0, z1) -> uint8 [z1-z0, Y, X, C]."""
+    def finalize(self, acc):
+        return acc.finalize()
+
+    # ---- multi-rank path: probabilities kept per block, blended later by the slab owners
+    def new_store(self, n):
+        """fp32 [n, S, S, S, C] probabilities of this rank's blocks (16 MB per 128^3 block at C = 2); cached."""
+        S, C = self.S, self.C
+        if self._store is None or self._store.shape[0] < n:
+            self._store = torch.empty((max(n, 1), S, S, S, C), dtype=torch.float32, device=self.device)
+        return self._store
+
+    def new_piece(self, nz):
+        return torch.empty((nz, self.S, self.S, self.C), dtype=torch.float32, device=self.device)
+
+    def forward_blocks(self, volume, padded, store, j0):
+        """Probabilities of the blocks with padded coordinates `padded` into store[j0 : j0 + len(padded)]."""
+        S, C, nb = self.S, self.C, len(padded)
+        if self.eng.dim == 3:
+            B = max(1, int(P.BLOCK_BATCH))
+            if self._blk is None or self._blk.shape[0] < B:
+                self._blk = torch.empty((B,) + (S,) * 3, dtype=torch.uint8, device=self.device)
+            for i in range(0, nb, B):
+                n = min(B, nb - i)
+                for j in range(n):
+                    P.gather_block(volume, padded[i + j], S, out=self._blk[j])
+                self.eng.infer(self._blk, (S ** 3, S ** 3, S * S, S, 1), n, S, S, S, probs=store[j0 + i:j0 + i + n],
+                               out_strides=(S ** 3 * C, 1, S * S * C, S * C, C))
+        else:
+            blk = torch.empty((S,) * 3, dtype=torch.uint8, device=self.device)
+            for i in range(nb):
+                P.gather_block(volume, padded[i], S, out=blk)
+                P.predict_block_device(self.model, blk, store[j0 + i], C, self.bs, self.axes)
+
+    def make_slab_accumulator(self, h, Y, X):
+        acc = self._acc.get(('slab', h, Y, X))
+        if acc is None:
+            acc = P.VolumeAccumulator((h, Y, X), self.C, self.S, self.device)
+            self._acc = {('slab', h, Y, X): acc}
+        else:
+            acc.reset()
+        return acc
+
+    def blend_piece(self, acc, piece, pa, block, local):
+        """Blend planes [block[0], block[3]) (slab-relative) of one block into the slab accumulator; `piece` holds the
+        block's probabilities from block-local plane `pa` on ([nz, S, S, C], contiguous)."""
         from . import _native as nv
-        n = (z1 - z0) * acc.V[1] * acc.V[2]
-        out = torch.empty((z1 - z0,) + acc.V[1:] + (acc.C,), dtype=torch.uint8, device=self.device)
-        if n:
-            nv.call('iunet_normalize_quantize', nv.ptr(acc.pred[z0:z1]), nv.ptr(acc.weight[z0:z1]), nv.ptr(out), n, acc.C,
-                    1e-3, nv.stream())
-        return out
+        S, C = self.S, self.C
+        base = piece.data_ptr() - pa * S * S * C * 4          # where block-local plane 0 would be; never dereferenced below pa
+        nv.call('iunet_blend_accumulate', nv.ptr(acc.pred), nv.ptr(acc.weight), nv.c_void_p(base), nv.ptr(acc.window),
+                acc.V[0], acc.V[1], acc.V[2], C, S, nv.int_array(block), nv.int_array(local), nv.stream())
 
 
-def predict_volume_sharded(ops, my_slab, volume_shape, input_size, overlap=0.25, group=None):
-    """Whole-volume prediction across the ranks of `group`.
+class DistComm:
+    """The communicator of the product path: torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box, gloo
+    in the CPU tests).  predict_volume_sharded needs exactly two operations of it."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+
+    def all_gather(self, t):
+        parts = [torch.empty_like(t) for _ in range(self.world)]
+        dist.all_gather(parts, t, group=self.group)
+        return parts
+
+    def exchange(self, sends, recvs):
+        """One grouped point-to-point round (ncclGroupStart/End: no ordering deadlock between the pairs):
+        sends [(tensor, dst)], recvs [(tensor, src)] -> work handles; the transfers run on RCCL's stream."""
+        ops = [dist.P2POp(dist.isend, t, dst, group=self.group) for t, dst in sends]
+        ops += [dist.P2POp(dist.irecv, t, src, group=self.group) for t, src in recvs]
+        return dist.batch_isend_irecv(ops) if ops else []
+
+
+def predict_volume_sharded(ops, my_slab, volume_shape, input_size, overlap=0.25, group=None, rounds=8, comm=None):
+    """Whole-volume prediction across the ranks of `group` (or of `comm`, an object with DistComm's interface).
 
     my_slab: this rank's uint8 z-slab [h_r, Y, X] of the input (device of `ops`).
-    Returns (uint8 [h_r, Y, X, C] result for the same slab, stats dict)."""
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    Returns (uint8 [h_r, Y, X, C] result for the same slab, stats dict).  The result is byte-identical to the slab
+    of the single-process result whatever the number of ranks."""
+    comm = comm or DistComm(group)
+    world, rank = comm.world, comm.rank
     V = tuple(int(v) for v in volume_shape)
+    S = int(input_size)
     bounds, h = slab_bounds(V[0], world)
     dev = my_slab.device
-    # ---- input exchange: all-gather the (padded) uint8 slabs ----
-    if world > 1:
-        padded = torch.zeros((h,) + V[1:], dtype=torch.uint8, device=dev)
-        padded[:my_slab.shape[0]] = my_slab
-        parts = [torch.empty_like(padded) for _ in range(world)]
-        dist.all_gather(parts, padded, group=group)
-        volume = torch.cat(parts, 0)[:V[0]].contiguous()
-    else:
-        volume = my_slab
-    # ---- compute: my run of the flat block list into a full-height accumulator ----
-    bc, pbc, lbc = P.get_block_coordinates(np.array(V), input_size=input_size, overlap=overlap)
+    bc, pbc, lbc = P.get_block_coordinates(np.array(V), input_size=S, overlap=overlap)
     runs = partition_blocks(len(pbc), world)
     lo, hi = runs[rank]
-    f0, f1 = footprint(bc, lo, hi)
-    z_lo, z_hi = min(f0, bounds[rank][0]), max(f1, bounds[rank][1])      # everything this rank reads or writes
-    try:
-        acc = ops.make_accumulator(V, zero=(z_lo, z_hi))
-    except TypeError:                                                    # ops without partial zeroing (tests)
-        acc = ops.make_accumulator(V)
-    if hasattr(ops, 'predict_run'):
-        ops.predict_run(acc, volume, bc, pbc, lbc, lo, hi)
-    else:
-        for i in range(lo, hi):
-            ops.predict_into(acc, volume, bc[i], pbc[i], lbc[i])
-    # ---- output exchange: footprint pieces to their slab owners, point to point ----
-    sent = 0
-    if world > 1:
-        fps = [footprint(bc, *runs[r]) for r in range(world)]
-        ops_list, recv_bufs = [], []
-        for src in range(world):
-            f0, f1 = fps[src]
-            for dst in range(world):
-                if src == dst:
-                    continue
-                z0, z1 = max(f0, bounds[dst][0]), min(f1, bounds[dst][1])
-                if z1 <= z0:
-                    continue
-                if rank == src:
-                    for t in (acc.pred[z0:z1], acc.weight[z0:z1]):
-                        ops_list.append(dist.P2POp(dist.isend, t, dst, group=group))
-                        sent += t.numel() * 4
-                elif rank == dst:
-                    bp = torch.empty_like(acc.pred[z0:z1])
-                    bw = torch.empty_like(acc.weight[z0:z1])
-                    ops_list.append(dist.P2POp(dist.irecv, bp, src, group=group))
-                    ops_list.append(dist.P2POp(dist.irecv, bw, src, group=group))
-                    recv_bufs.append((src, z0, z1, bp, bw))
-        if ops_list:
-            for req in dist.batch_isend_irecv(ops_list):
-                req.wait()
-        if recv_bufs and dev.type == 'cuda':
-            torch.cuda.current_stream().synchronize()
-        for src, z0, z1, bp, bw in sorted(recv_bufs, key=lambda t: t[0]):      # fixed order
-            acc.pred[z0:z1] += bp
-            acc.weight[z0:z1] += bw
     z0, z1 = bounds[rank]
-    out = ops.finalize_slab(acc, z0, z1)
-    return out, {'blocks': hi - lo, 'bytes_sent': sent, 'slab': (z0, z1)}
+    if world == 1:
+        acc = ops.make_accumulator(V)
+        ops.predict_run(acc, my_slab, bc, pbc, lbc, lo, hi)
+        return ops.finalize(acc), {'blocks': hi - lo, 'bytes_sent': 0, 'slab': (z0, z1), 'pieces_blended': hi - lo,
+                                   'rounds': 0}
+    # ---- input exchange: all-gather the (padded) uint8 slabs ----
+    padded = torch.zeros((h,) + V[1:], dtype=torch.uint8, device=dev)
+    padded[:my_slab.shape[0]] = my_slab
+    parts = comm.all_gather(padded)
+    volume = torch.cat(parts, 0)[:V[0]].contiguous()
+    del parts
+    # ---- schedule (identical on every rank): local block t of every run belongs to round t // per_round ----
+    longest = max(b - a for a, b in runs)
+    rounds = max(1, min(int(rounds), longest))
+    per_round = -(-longest // rounds)
+    pieces = [block_pieces(bc[b], lbc[b], bounds) for b in range(len(pbc))]
+    store = ops.new_store(hi - lo)
+    mine = []                    # (flat block index, piece tensor, pa, za, zb): everything that lands in my slab
+    pending, sent = [], 0
+    for t in range(rounds):
+        a, b = min(lo + t * per_round, hi), min(lo + (t + 1) * per_round, hi)
+        if b > a:
+            ops.forward_blocks(volume, pbc[a:b], store, a - lo)
+        sends, recvs = [], []
+        for src, (rl, rh) in enumerate(runs):
+            for blk in range(min(rl + t * per_round, rh), min(rl + (t + 1) * per_round, rh)):
+                for q, za, zb, pa in pieces[blk]:
+                    if src == rank:
+                        piece = store[blk - lo, pa:pa + (zb - za)]
+                        if q == rank:
+                            mine.append((blk, piece, pa, za, zb))
+                        else:
+                            sends.append((piece, q))
+                            sent += piece.numel() * 4
+                    elif q == rank:
+                        buf = ops.new_piece(zb - za)
+                        recvs.append((buf, src))
+                        mine.append((blk, buf, pa, za, zb))
+        pending += comm.exchange(sends, recvs)             # in flight while the next round's blocks compute
+    for work in pending:
+        work.wait()
+    # ---- blend my slab's pieces in flat block order, normalise + quantise ----
+    acc = ops.make_slab_accumulator(z1 - z0, V[1], V[2])
+    for blk, piece, pa, za, zb in sorted(mine, key=lambda m: m[0]):
+        c, l = bc[blk], lbc[blk]
+        block = (za - z0, int(c[1]), int(c[2]), zb - z0, int(c[4]), int(c[5]))
+        local = (pa, int(l[1]), int(l[2]), pa + (zb - za), int(l[4]), int(l[5]))
+        ops.blend_piece(acc, piece, pa, block, local)
+    out = ops.finalize(acc)
+    return out, {'blocks': hi - lo, 'bytes_sent': sent, 'slab': (z0, z1), 'pieces_blended': len(mine), 'rounds': rounds}

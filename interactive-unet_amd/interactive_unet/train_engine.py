@@ -54,9 +54,17 @@ class TrainEngine:
         # (IUNET_NO_ACT_FUSION=1: materialise it, for A/B runs)
         self.fuse_act = not os.environ.get('IUNET_NO_ACT_FUSION')
         self._flatten()
+        if self.pg is not None:
+            # every rank continues from rank 0's weights and BatchNorm statistics (each rank's module drew its own
+            # initialisation, or read a checkpoint that rank 0 is about to replace)
+            from . import dp
+            dp.broadcast_state(self.flat, [model.tensor(n) for n in model._names
+                                           if n.endswith('running_mean') or n.endswith('running_var')], self.pg)
+            self.buckets = dp.GradBuckets(self.grad, self._dec_start, self.pg)
         self._alloc_packed()
         self._ws = {}
         self.repack()
+        model._packed_sig = None
 
     # ------------------------------------------------------------------ parameters
     def _flatten(self):
@@ -85,7 +93,6 @@ class TrainEngine:
         # the data-parallel all-reduce
         first_dec = f'dec{self.levels - 2}.up.weight'
         self._dec_start = self.offsets[first_dec][0] if first_dec in self.offsets else 0
-        self._pending = []
 
     def p(self, name):
         return self.model.tensor(name)
@@ -387,10 +394,8 @@ class TrainEngine:
                     nv.ptr(wd), N, di[0], di[1], di[2], ch[l + 1], ch[l], s)
         # data parallel: the decoder + head gradients (the tail of the flat tensor) are complete -- their all-reduce runs
         # on RCCL's stream while the encoder backward below still computes
-        self._pending = []
-        if self.pg is not None and self._dec_start > 0:
-            import torch.distributed as dist
-            self._pending.append(dist.all_reduce(self.grad[self._dec_start:], group=self.pg, async_op=True))
+        if self.pg is not None:
+            self.buckets.start_tail()
         # encoder, bottom level upwards
         for l in range(L - 1, -1, -1):
             v = _vox(dims[l])
@@ -419,17 +424,7 @@ class TrainEngine:
     def optimizer_step(self):
         s = nv.stream()
         n = self.flat.numel()
-        if self.pg is not None:
-            import torch.distributed as dist
-            pending = getattr(self, '_pending', [])
-            head = self._dec_start if pending else self.grad.numel()        # what backward() has not reduced yet
-            pending.append(dist.all_reduce(self.grad[:head], group=self.pg, async_op=True))
-            for work in pending:
-                work.wait()
-            self._pending = []
-            world = dist.get_world_size(self.pg)
-        else:
-            world = 1
+        world = self.buckets.finish() if self.pg is not None else 1
         flag = None
         if self.T == torch.float16:
             self.flag.zero_()

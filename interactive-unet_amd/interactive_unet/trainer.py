@@ -55,11 +55,13 @@ def train_model(lr=0.0001, batch_size=1, epochs=10, num_channels=1, num_classes=
                               architecture=architecture, encoder_name=encoder_name, pretrained=pretrained, dim=dim,
                               act_dtype=act_dtype)
     model = model.to(device)
-    if os.path.isfile(model_path):                  # remove old checkpoint (trainer.py:41-43)
+    rank0 = process_group is None or torch.distributed.get_rank(process_group) == 0
+    if process_group is not None:                   # every rank has read the checkpoint before rank 0 removes it
+        torch.distributed.barrier(group=process_group)
+    if rank0 and os.path.isfile(model_path):        # remove old checkpoint (trainer.py:41-43)
         os.remove(model_path)
     os.makedirs('model', exist_ok=True)
     log_dir = os.path.join('model', 'history', time.strftime('%Y-%m-%d_%H-%M-%S'), 'version_0')
-    rank0 = process_group is None or torch.distributed.get_rank(process_group) == 0
     if rank0:
         os.makedirs(log_dir, exist_ok=True)
     fields = ['epoch', 'step'] + [f'train/{m}' for m in METRICS] + [f'val/{m}' for m in METRICS]

@@ -72,17 +72,76 @@ def test_sharded_predict_single_rank_equals_unsharded():
     assert np.array_equal(out.cpu().numpy(), ref)
 
 
-def test_predict_slice_contract():
+def test_predict_slice_vs_oracle():
+    """predict.py:16-47 against the ORACLE: the colours are the palette (utils.py:304-306) applied to the argmax of the
+    oracle network's probabilities (oracle/predict_ref.predict_slice_post) on every pixel whose oracle top-2 margin is
+    beyond the 16-bit storage noise, and the returned probabilities are the oracle's; in the fp32 parity mode the whole
+    coloured image is identical."""
     from interactive_unet import predict
-    model, p = _model(2, 3)
+    C = 3
     img = _volume((64, 96), 23)
-    colored = predict.predict_slice(img, num_classes=3, model=model)
-    assert colored.shape == (64, 96, 3) and colored.dtype == np.uint8
-    probs = predict.predict_slice(img, num_classes=3, return_probabilities=True, model=model)
-    assert probs.shape == (1, 64, 96, 3) and abs(probs.sum(-1).mean() - 1) < 1e-5
-    cls = probs[0].argmax(-1)
-    for i in range(3):
-        assert (colored[cls == i] == predict.COLORS[i + 1]).all()
+    x = torch.tensor(img)[None, None].float() / 255.0
+    for dtype, tol in (('fp16', 3e-3), ('fp32', 1e-5)):
+        model, p = _model(2, C, dtype=dtype)
+        want_p = unet_ref.forward(p, x, dim=2).numpy()                       # fp32 oracle, NCHW
+        cls, onehot, want_col = predict_ref.predict_slice_post(want_p, C)
+        colored = predict.predict_slice(img, num_classes=C, model=model)
+        assert colored.shape == (64, 96, 3) and colored.dtype == np.uint8
+        probs = predict.predict_slice(img, num_classes=C, return_probabilities=True, model=model)
+        assert probs.shape == (1, 64, 96, C)
+        err = np.abs(probs - np.moveaxis(want_p, 1, -1)).max()
+        top2 = np.sort(want_p[0], axis=0)
+        sure = (top2[-1] - top2[-2]) > 2 * max(err, 1e-6)
+        print(f'predict_slice {dtype}: max |prob - oracle| = {err:.2e}, sure pixels {sure.mean():.3f}')
+        assert err <= tol * 4 and sure.mean() > 0.9
+        assert np.array_equal(colored[sure], want_col[sure])
+        if dtype == 'fp32':
+            assert np.array_equal(colored, want_col)
+
+
+def test_find_max_batch_size_contract():
+    """predict.py:49-77's contract without the OOM probing: a power-of-two multiple of `start`, at least `start`, at most
+    `max_limit`, non-increasing in the slice size, and a batch of that size really runs."""
+    from interactive_unet import predict
+    model, _ = _model(2, 2)
+    sizes = [predict.find_max_batch_size(model, input_size=s, start=4, max_limit=512) for s in (128, 256, 512)]
+    for b in sizes:
+        assert 4 <= b <= 512 and (b // 4) & (b // 4 - 1) == 0 and b % 4 == 0
+    assert sizes[0] >= sizes[1] >= sizes[2]
+    assert predict.find_max_batch_size(model, input_size=128, start=4, max_limit=8) == 8
+    b = min(sizes[0], 64)
+    x = torch.zeros((b, 1, 128, 128), dtype=torch.uint8, device='cuda')
+    assert model(x).shape == (b, 2, 128, 128)
+
+
+def test_predict_volumes_zarr_end_to_end(tmp_path, monkeypatch):
+    """predict.py:114-266 through the store: data/image_volumes/<name>.zarr (written by utils.create_multiscale_zarr's
+    layout: chunks inside shards) -> data/predicted_volumes/<name>.zarr['0'] uint8 [Z,Y,X,C] + pyramid levels, read and
+    written by the built-in Zarr v3 reader / writer (zarr3.py) shard by shard through pinned staging."""
+    from interactive_unet import predict, multiscale, zarr3
+    monkeypatch.chdir(tmp_path)
+    S, C, V = 32, 2, (72, 56, 40)
+    model, _ = _model(3, C)
+    os.makedirs('model')
+    model.save_checkpoint(os.path.join('model', 'model.ckpt'))               # predict.py:22-24 loads it
+    vol = _volume(V, 41)
+    os.makedirs(os.path.join('data', 'image_volumes'))
+    os.makedirs(os.path.join('data', 'predicted_volumes'))
+    multiscale.create_multiscale_zarr(vol, os.path.join('data', 'image_volumes', 'a.zarr'), chunk_size=16, shard_size=32)
+    src = zarr3.open(os.path.join('data', 'image_volumes', 'a.zarr'))
+    assert np.array_equal(src['0'][...], vol) and src['0'].chunks == (16, 16, 16) and src['0'].shards == (32, 32, 32)
+    assert src.array_keys() == ['0', '1', '2']                               # 72 -> 36 -> 18 (fits a 16^3 chunk at 2 steps)
+    want = predict.predict_volume_array(model, vol, input_size=S, num_classes=C).cpu().numpy()
+    predict.predict_volumes(input_size=S, num_classes=C, chunk_size=16, shard_size=32)
+    out = zarr3.open(os.path.join('data', 'predicted_volumes', 'a.zarr'))
+    a0 = out['0']
+    assert a0.shape == V + (C,) and a0.chunks == (16, 16, 16, C) and a0.shards == (32, 32, 32, C)
+    assert np.array_equal(a0[...], want)
+    levels = multiscale.multiscale_levels(torch.tensor(want).cuda(), a0.chunks, a0.shards)
+    assert out.array_keys() == [str(i) for i in range(len(levels) + 1)]
+    for i, lv in enumerate(levels):
+        assert np.array_equal(out[str(i + 1)][...], lv.cpu().numpy())
+    assert multiscale.read_volume(os.path.join('data', 'predicted_volumes', 'a.zarr'), level=1).shape == tuple(levels[0].shape)
 
 
 def test_train_model_files_and_learning(tmp_path, monkeypatch):

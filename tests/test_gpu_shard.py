@@ -1,0 +1,104 @@
+"""The multi-rank path of shard.predict_volume_sharded with the REAL device ops (shard.NativeOps -> libiunet) on one
+GPU: N virtual ranks run as threads of this process and exchange through an in-process communicator with DistComm's
+interface ("multi-GPU tests without a cluster via ... a fake in-process communicator"); the
+result must be byte-identical to the single-rank result.  The same logic over a real process group
+(gloo, world_size 2 / 3) is tests/test_shard_cpu.py."""
+import threading
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import unet_ref
+
+
+class _Shared:
+    def __init__(self, world):
+        self.world = world
+        self.barrier = threading.Barrier(world)
+        self.slots = [None] * world
+        self.mail = {}
+        self.lock = threading.Lock()
+
+
+class ThreadComm:
+    """all_gather / exchange between threads of one process; every tensor lives on the one GPU, copies are enqueued on
+    the shared stream after a host barrier, so they are ordered behind the producers' kernels."""
+
+    def __init__(self, shared, rank):
+        self.sh, self.rank, self.world = shared, rank, shared.world
+
+    def all_gather(self, t):
+        self.sh.slots[self.rank] = t
+        self.sh.barrier.wait()
+        parts = [s.clone() for s in self.sh.slots]
+        self.sh.barrier.wait()
+        return parts
+
+    def exchange(self, sends, recvs):
+        with self.sh.lock:
+            for t, dst in sends:
+                self.sh.mail.setdefault((self.rank, dst), []).append(t)
+        self.sh.barrier.wait()
+        for buf, src in recvs:
+            with self.sh.lock:
+                t = self.sh.mail[(src, self.rank)].pop(0)       # FIFO per pair, like matched send / recv
+            assert t.shape == buf.shape
+            buf.copy_(t)
+        self.sh.barrier.wait()
+        return []
+
+
+def _model(dim, C, seed=3):
+    from interactive_unet.unet import UNet
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        m = UNet(num_classes=C, dim=dim, act_dtype='fp16', pretrained=False)
+    m.load_named(unet_ref.init_params(dim=dim, ncls=C, seed=seed, randomize_bn=True))
+    return m.cuda().eval()
+
+
+def _volume(shape, seed):
+    from scipy import ndimage
+    rng = np.random.default_rng(seed)
+    v = ndimage.gaussian_filter(rng.random(shape), 2.5)
+    return (255 * (v - v.min()) / (v.max() - v.min())).astype(np.uint8)
+
+
+@pytest.mark.parametrize('dim,world,V,rounds', [(3, 3, (100, 56, 72), 4), (3, 4, (72, 40, 40), 8), (2, 2, (56, 40, 72), 3)])
+def test_virtual_ranks_byte_identical_to_single_rank(dim, world, V, rounds):
+    from interactive_unet import predict, shard
+    S, C = 32, 2
+    vol = torch.tensor(_volume(V, 31)).cuda()
+    want = predict.predict_volume_array(_model(dim, C), vol, input_size=S, num_classes=C).cpu().numpy()
+    bounds, _ = shard.slab_bounds(V[0], world)
+    shared = _Shared(world)
+    # one model (engine + workspace) per virtual rank: the ranks' launches interleave on the stream
+    opss = [shard.NativeOps(_model(dim, C), C, S) for _ in range(world)]
+    res, errs = [None] * world, []
+
+    def run(r):
+        try:
+            z0, z1 = bounds[r]
+            out, st = shard.predict_volume_sharded(opss[r], vol[z0:z1].contiguous(), V, S, 0.25, rounds=rounds,
+                                                   comm=ThreadComm(shared, r))
+            torch.cuda.synchronize()
+            res[r] = (out.cpu().numpy(), st)
+        except Exception as e:                                   # pragma: no cover
+            errs.append(e)
+            shared.barrier.abort()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    assert not errs, errs
+    got = np.concatenate([r[0] for r in res], 0)
+    nblocks = len(predict.get_block_coordinates(np.array(V), S, 0.25)[0])
+    assert sum(r[1]['blocks'] for r in res) == nblocks
+    assert sum(r[1]['bytes_sent'] for r in res) > 0
+    assert np.array_equal(got, want), f'{(got != want).sum()} of {got.size} bytes differ'

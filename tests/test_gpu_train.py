@@ -507,3 +507,61 @@ def test_first_conv_wgrad_with_folded_bn_backward(nv, nd):
     torch.cuda.synchronize()
     for a, b in zip(res[0], res[1]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('dim,shape,dtype', [(2, (64, 96), 'fp16'), (3, (16, 32, 48), 'bf16')])
+def test_train_step_is_deterministic_bit_for_bit(dim, shape, dtype):
+    """Race screen (SURVEY.md section 5 "repeated-run race screens"): the same training step from the same state, run
+    three times, must leave bit-identical gradients, parameters, BatchNorm statistics and loss.  Every reduction on the
+    path (BatchNorm statistics, weight gradients, loss sums) is a fixed-order slab reduction, no float atomics -- a race
+    between workgroups or a missing barrier shows up here as a differing bit."""
+    from interactive_unet.unet import UNet
+    from interactive_unet.train_engine import TrainEngine
+    import warnings
+    N, ncls = 2, 3
+    rng = np.random.default_rng(11)
+    img = rng.integers(1, 256, (N, 1) + shape, dtype=np.uint8)
+    lab = img[:, 0] // 86
+    y = torch.tensor(np.stack([(lab == c) for c in range(ncls)], 1).astype(np.float32))
+    w = torch.tensor(np.repeat((rng.random((N, 1) + shape) > 0.2).astype(np.float32), ncls, 1))
+    X = torch.tensor(img)
+    p0 = unet_ref.init_params(dim=dim, ncls=ncls, seed=9, randomize_bn=True)
+    runs = []
+    for rep in range(3):
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            model = UNet(lr=1e-3, num_classes=ncls, dim=dim, act_dtype=dtype, pretrained=False)
+        model.load_named(p0)
+        model = model.cuda()
+        te = TrainEngine(model, lr=1e-3, loss_kind='dice_ce')
+        out = [te.train_step(X, y * w, w), te.train_step(X, y * w, w)]          # two steps: the second runs on updated weights
+        torch.cuda.synchronize()
+        runs.append((te.grad.clone(), te.flat.clone(), [model.tensor(n).clone() for n in model._names if 'running' in n], out))
+    g0, f0, b0, o0 = runs[0]
+    assert torch.isfinite(g0).all() and g0.abs().max() > 0
+    for g, f, b, o in runs[1:]:
+        assert torch.equal(g, g0), f'{(g != g0).sum().item()} gradient elements differ between two identical runs'
+        assert torch.equal(f, f0)
+        assert all(torch.equal(x, y_) for x, y_ in zip(b, b0))
+        assert o == o0
+
+
+@pytest.mark.parametrize('dim,shape,dtype', [(2, (128, 160), torch.float16), (3, (32, 32, 48), torch.bfloat16)])
+def test_forward_is_deterministic_bit_for_bit(dim, shape, dtype):
+    """The same forward three times (persistent wave-specialised convolutions, XCD-aware tile walk): identical bits."""
+    from interactive_unet.engine import Engine
+    p = unet_ref.init_params(dim=dim, ncls=2, seed=2, randomize_bn=True)
+    e = Engine(dim=dim, ncls=2, act_dtype=dtype)
+    e.load_eval({k: v.cuda() for k, v in p.items()})
+    rng = np.random.default_rng(3)
+    N = 2
+    x = torch.tensor(rng.integers(1, 256, (N, 1) + shape, dtype=np.uint8)).cuda()
+    D, H, W = shape if dim == 3 else (1,) + shape
+    vox = D * H * W
+    outs = []
+    for _ in range(3):
+        lg = torch.empty((N, 2) + shape, device='cuda')
+        e.infer(x, (vox, vox, H * W, W, 1), N, D, H, W, logits=lg)
+        torch.cuda.synchronize()
+        outs.append(lg)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
