@@ -124,6 +124,21 @@ int iunet_f32_head_fwd(const void* x, long long x_ss, int C0, const void* w, con
                        void* probs, void* cls, const long long* out_strides, float divisor, int accumulate, int N, int D, int H,
                        int W, void* stream);
 
+/* ---- fp8 matrix cores: BASELINE config C5 ("fp8 weights / bf16 activations on CDNA4 fp8 MFMA") ------------------------
+ * The stage convolutions of the forward pass (unet.py:65-69 over the canonical network) with the operator stored as OCP
+ * e4m3 BYTES (half the weight bytes in HBM and LDS) and the product on v_mfma_f32_16x16x32_fp8_fp8; the 16-bit activations
+ * in HBM are rounded to e4m3 (saturating at 448) on their way into LDS -- gfx950 has no mixed fp8 x bf16 MFMA. */
+/* w fp32 [Cout][Cin][taps] (x an optional eval-mode BatchNorm fold, as iunet_f32_pack_conv) -> dst: iunet_f8_pack_conv3_bytes
+ * bytes (K16 fragment order of iunet_conv3_pick_layout's layouts 1 / 2, one byte per element), wscale fp32 [Cout]: the
+ * power-of-two scale 2^k, k minimal with max |w'| / 2^k <= 448, each weight = e4m3(w' / scale); bias_out fp32 [Cout]. */
+long long iunet_f8_pack_conv3_bytes(int Cout, int Cin, int taps);
+int iunet_f8_pack_conv3(const void* w, const void* gamma, const void* beta, const void* mean, const void* var, float eps,
+                        void* dst, void* wscale, void* bias_out, int Cout, int Cin, int taps, void* stream);
+/* y = epilogue(wscale[c] * sum e4m3(x) * w8 + bias[c]); x, y: NHWC8c of `dtype`; epi as iunet_conv3_fwd. */
+int iunet_conv3_f8_fwd(int dtype, int nd, const void* x, long long x_sstride, void* y, long long y_sstride, const void* wpk,
+                       const void* wscale, const void* bias, int N, int D, int H, int W, int Cin, int Cout, int epi,
+                       void* stream);
+
 /* ---- whole-volume prediction (predict.py:201-256) -------------------------------------- */
 /* get_padded_block (predict.py:291-316): reflect-padded S^3 uint8 block of a device volume. */
 int iunet_gather_block(const void* vol, int Vz, int Vy, int Vx, int i0, int j0, int k0, int S, void* out, void* stream);

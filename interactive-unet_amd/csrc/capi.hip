@@ -57,6 +57,14 @@ int iunet_f32_head_launch(const float* x, long long x_ss, int C0, const float* w
                           float* probs, unsigned char* cls, const long long* os, float divisor, int accumulate, int N, int D,
                           int H, int W, hipStream_t stream);
 
+// fp8 matrix-core convolution (conv3_f8.hip)
+long long iunet_f8_pack_bytes(int Cout, int Cin, int taps);
+int iunet_f8_pack_launch(const float* w, const float* gamma, const float* beta, const float* mean, const float* var, float eps,
+                         void* dst, float* wscale, float* bias_out, int Cout, int Cin, int taps, hipStream_t stream);
+int iunet_conv3_f8_launch(int dtype, int nd, const void* x, long long x_sstride, void* y, long long y_sstride, const void* wpk,
+                          const float* wscale, const float* bias, int N, int D, int H, int W, int Cin, int Cout, int epi,
+                          hipStream_t stream);
+
 #define DT_OK(dt) IUNET_REQUIRE((dt) == 0 || (dt) == 1, "dtype must be 0 (f16) or 1 (bf16), got %d", (dt))
 
 extern "C" {
@@ -219,6 +227,37 @@ int iunet_f32_head_fwd(const void* x, long long x_ss, int C0, const void* w, con
   return iunet_f32_head_launch((const float*)x, x_ss, C0, (const float*)w, (const float*)bias, ncls, (float*)logits,
                                (float*)probs, (unsigned char*)cls, out_strides, divisor, accumulate, N, D, H, W,
                                (hipStream_t)stream);
+}
+
+/* ---- fp8 matrix cores (conv3_f8.hip): BASELINE config C5 ---------------------------------------------------- */
+long long iunet_f8_pack_conv3_bytes(int Cout, int Cin, int taps) {
+  if (Cout <= 0 || Cout % 32 || Cin <= 0 || Cin % 32 || (taps != 9 && taps != 27)) return 0;
+  return iunet_f8_pack_bytes(Cout, Cin, taps);
+}
+
+int iunet_f8_pack_conv3(const void* w, const void* gamma, const void* beta, const void* mean, const void* var, float eps,
+                        void* dst, void* wscale, void* bias_out, int Cout, int Cin, int taps, void* stream) {
+  IUNET_REQUIRE(w && dst && wscale, "f8_pack_conv3: null pointer");
+  IUNET_REQUIRE(Cout > 0 && Cout % 32 == 0 && Cin > 0 && Cin % 32 == 0, "f8_pack_conv3: channels must be positive multiples of 32 (%d, %d)", Cout, Cin);
+  IUNET_REQUIRE(taps == 9 || taps == 27, "f8_pack_conv3: taps must be 9 or 27 (got %d)", taps);
+  IUNET_REQUIRE(!gamma || (beta && mean && var && bias_out), "f8_pack_conv3: a BatchNorm fold needs gamma, beta, mean, var and bias_out");
+  return iunet_f8_pack_launch((const float*)w, (const float*)gamma, (const float*)beta, (const float*)mean, (const float*)var, eps,
+                              dst, (float*)wscale, (float*)bias_out, Cout, Cin, taps, (hipStream_t)stream);
+}
+
+int iunet_conv3_f8_fwd(int dtype, int nd, const void* x, long long x_sstride, void* y, long long y_sstride, const void* wpk,
+                       const void* wscale, const void* bias, int N, int D, int H, int W, int Cin, int Cout, int epi,
+                       void* stream) {
+  DT_OK(dtype);
+  IUNET_REQUIRE(x && y && wpk && wscale, "conv3_f8: null pointer");
+  IUNET_REQUIRE(nd == 2 || nd == 3, "conv3_f8: nd must be 2 or 3");
+  IUNET_REQUIRE_GRID("conv3_f8", N, D, H, W);
+  IUNET_REQUIRE(nd == 3 || D == 1, "conv3_f8: 2-D needs D == 1");
+  IUNET_REQUIRE(Cin >= 32 && Cout >= 32 && Cin % 32 == 0 && Cout % 32 == 0, "conv3_f8: channels must be positive multiples of 32 (%d, %d)", Cin, Cout);
+  IUNET_REQUIRE(epi >= 0 && epi <= 2, "conv3_f8: bad epilogue %d", epi);
+  IUNET_REQUIRE(epi == 0 || bias != nullptr, "conv3_f8: epilogue %d needs a bias", epi);
+  return iunet_conv3_f8_launch(dtype, nd, x, x_sstride, y, y_sstride, wpk, (const float*)wscale, (const float*)bias, N, D, H, W,
+                               Cin, Cout, epi, (hipStream_t)stream);
 }
 
 }  // extern "C"

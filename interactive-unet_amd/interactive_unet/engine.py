@@ -24,6 +24,13 @@ def _vox(dims):
     return dims[0] * dims[1] * dims[2]
 
 
+class F8Conv:
+    """A stage conv's operator for the fp8 matrix cores: e4m3 bytes (K16 order) + fp32 per-output-channel scales."""
+
+    def __init__(self, bytes_, scale):
+        self.bytes, self.scale = bytes_, scale
+
+
 class Engine:
     def __init__(self, dim=2, levels=4, base=32, cin=1, ncls=2, act_dtype=torch.float16, device='cuda',
                  weight_dtype=None):
@@ -93,7 +100,7 @@ class Engine:
         src['head.bias'] = self._source(params, 'head.bias')
         sig = tuple(t.data_ptr() for t in src.values())
         if sig != self._eval_sig:
-            P, descs, keep_q = {}, [], []
+            P, descs, keep_q, f8 = {}, [], [], []
             for prefix in self.stage_names():
                 ci, co = self.stage_io(prefix)
                 for j, (a, b) in enumerate(((ci, co), (co, co)), 1):
@@ -106,6 +113,14 @@ class Engine:
                                           device=self.device)
                         descs.append(nv.make_desc(w, dst, b, a, self.taps, 2, self.act_dtype, bn=bn, bias_out=bias,
                                                   eps=BN_EPS, qscale=qs))
+                    elif self.weight_dtype:
+                        # config C5: the stage convolutions run on the fp8 matrix cores -- operator stored as e4m3 bytes +
+                        # per-output-channel scales, packed by its own kernel (re-run with the table below)
+                        dst = torch.empty(nv.lib().iunet_f8_pack_conv3_bytes(b, a, self.taps), dtype=torch.uint8, device=self.device)
+                        f8.append((w, bn, dst, qs, bias, b, a))
+                        P[f'{prefix}.conv{j}'] = (F8Conv(dst, qs), bias)
+                        keep_q.append(qs)
+                        continue
                     else:
                         dst = nv.PackedConv(b, a, self.taps, self.act_dtype, self.device)
                         descs += dst.descs(w, bn, bias, BN_EPS, qs)
@@ -121,8 +136,12 @@ class Engine:
             P['head'] = (src['head.weight'].reshape(self.ncls, self.ch[0]), src['head.bias'])
             self._eval_table = nv.PackTable(descs, self.device, sources=list(src.values()) + keep_q)
             self._eval_sig = sig
+            self._f8 = f8
             self.packed = P
         self._eval_table.run()
+        for w, bn, dst, qs, bias, b, a in self._f8:
+            nv.call('iunet_f8_pack_conv3', nv.ptr(w), nv.ptr(bn[0]), nv.ptr(bn[1]), nv.ptr(bn[2]), nv.ptr(bn[3]), BN_EPS,
+                    nv.ptr(dst), nv.ptr(qs), nv.ptr(bias), b, a, self.taps, nv.stream())
 
     # ------------------------------------------------------------------ workspace
     def level_dims(self, D, H, W):
@@ -161,6 +180,10 @@ class Engine:
     # ------------------------------------------------------------------ forward (inference)
     def _conv3(self, x_ptr, x_ss, y_ptr, y_ss, name, N, dims, ci, co, s):
         pk, bias = self.packed[name]
+        if isinstance(pk, F8Conv):
+            nv.call('iunet_conv3_f8_fwd', self.dt, self.dim, x_ptr, x_ss, y_ptr, y_ss, nv.ptr(pk.bytes), nv.ptr(pk.scale),
+                    nv.ptr(bias), N, dims[0], dims[1], dims[2], ci, co, 2, s)
+            return
         lay, wpk = pk.pick(self.dim, N, dims[0], dims[1], dims[2])
         nv.call('iunet_conv3_fwd', self.dt, self.dim, x_ptr, x_ss, y_ptr, y_ss, nv.ptr(wpk), nv.ptr(bias), None,
                 N, dims[0], dims[1], dims[2], ci, co, 2, lay, s)

@@ -158,7 +158,14 @@ def quantize_e4m3(w, out_axis=0):
     return torch.from_numpy((scale * round_e4m3(a / scale)).astype(np.float32))
 
 
-def forward_logits(p, x, dim=2, levels=4, training=False, act_dtype=None, bn_stats_out=None, weight_quant=None):
+def quantize_act_e4m3(t):
+    """What the fp8 convolution does to its 16-bit input on the way into LDS: round to the nearest e4m3 value (ties to
+    even), saturating at +-448."""
+    a = np.clip(t.detach().numpy().astype(np.float32), -448.0, 448.0)
+    return torch.from_numpy(round_e4m3(a))
+
+
+def forward_logits(p, x, dim=2, levels=4, training=False, act_dtype=None, bn_stats_out=None, weight_quant=None, act_quant=False):
     """x: [N, cin, *spatial] float32 in [0,1].  Returns fp32 logits [N, ncls, *spatial].
 
     training=True uses batch statistics in BatchNorm (and, if bn_stats_out is a dict,
@@ -185,7 +192,10 @@ def forward_logits(p, x, dim=2, levels=4, training=False, act_dtype=None, bn_sta
                 t = _rnd_ag(F.relu(y), act_dtype)
             elif weight_quant == 'fp8_e4m3':
                 wf, bf = fold_bn_exact(w, *bn)
-                t = _rnd(F.relu(conv(t, quantize_e4m3(wf), bias=bf, padding=1)), act_dtype)
+                # act_quant: the stage convs (every conv but the first, Cin >= 32) run on the fp8 matrix cores -- their
+                # 16-bit input is rounded to e4m3 as well (csrc/conv3_f8.hip); products of two e4m3 values are exact
+                tin = quantize_act_e4m3(t) if (act_quant and w.shape[1] >= 32) else t
+                t = _rnd(F.relu(conv(tin, quantize_e4m3(wf), bias=bf, padding=1)), act_dtype)
             else:
                 wf, bf = fold_bn(w, *bn)
                 t = _rnd(F.relu(conv(t, _rnd(wf, act_dtype), bias=bf, padding=1)), act_dtype)
@@ -208,9 +218,10 @@ def forward_logits(p, x, dim=2, levels=4, training=False, act_dtype=None, bn_sta
     return conv(t, p['head.weight'], bias=p['head.bias'])
 
 
-def forward(p, x, dim=2, levels=4, training=False, act_dtype=None, weight_quant=None):
+def forward(p, x, dim=2, levels=4, training=False, act_dtype=None, weight_quant=None, act_quant=False):
     """Softmax probabilities NCHW(D), as UNet.forward returns them (unet.py:65-69)."""
-    return torch.softmax(forward_logits(p, x, dim, levels, training, act_dtype, weight_quant=weight_quant), dim=1)
+    return torch.softmax(forward_logits(p, x, dim, levels, training, act_dtype, weight_quant=weight_quant,
+                                        act_quant=act_quant), dim=1)
 
 
 def flops_per_voxel(dim=2, levels=4, base=32, cin=1, ncls=2):

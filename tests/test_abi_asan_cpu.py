@@ -63,10 +63,12 @@ def _driver_source():
 def test_every_declared_entry_point_survives_sanitizers():
     protos = _prototypes()
     assert len(protos) >= 60
-    # objects are cached beside the test (git- and gpurun-ignored) and rebuilt when their source is newer
+    # objects are cached in a scratch directory (outside the repo: nothing of it is committed or shipped to the GPU box) and
+    # rebuilt when their source is newer
+    import tempfile
     from pathlib import Path
-    tmp_path = Path(ROOT) / 'tests' / 'abi_asan' / '_build'
-    tmp_path.mkdir(exist_ok=True)
+    tmp_path = Path(os.environ.get('IUNET_ASAN_BUILD') or os.path.join(tempfile.gettempdir(), 'iunet_abi_asan_build'))
+    tmp_path.mkdir(parents=True, exist_ok=True)
     drv = tmp_path / 'driver.hip'
     src = _driver_source()
     if not drv.exists() or drv.read_text() != src:

@@ -1,0 +1,190 @@
+"""BASELINE config C5 on the fp8 matrix cores (csrc/conv3_f8.hip): operator stored as OCP e4m3 bytes + per-output-channel
+power-of-two scales, 16-bit activations rounded to e4m3 on their way into LDS, v_mfma_f32_16x16x32_fp8_fp8.
+
+* packing: the bytes, read back as torch.float8_e4m3fn, times the scales are EXACTLY the oracle's quantisation of the
+  (BatchNorm-folded) fp32 weights (oracle/unet_ref.quantize_e4m3, itself pinned against torch's e4m3 cast in the CPU suite);
+* kernel: small-integer data, where every e4m3 product and fp32 sum is exact -> bit equality with torch's fp32 conv
+  (fragment map of the fp8 MFMA, taps, halos, resident / streamed weights, the half-size tile);
+* rounding of the activations: values that are NOT e4m3-representable -> equality with the conv of the oracle's rounded
+  input (round to nearest even, saturation at 448);
+* network: C5's architecture against the CPU emulation with the same quantised operands, tolerance stated there.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import unet_ref
+from tests.test_gpu_kernels import blocked, unblocked, nv      # noqa: F401  (fixture + layout helpers)
+
+DT = {'f16': torch.float16, 'bf16': torch.bfloat16}
+
+
+def run_conv_f8(nv, x, w, dtype, nd, bn=None, epi=0, bias=None):
+    """x [N,Cin,*sp] fp32 cpu (values exact in `dtype`), w [Cout,Cin,k..] -> (y fp32 cpu, bytes uint8, scale fp32, bias)."""
+    dev = 'cuda'
+    N, Cin = x.shape[:2]
+    Cout = w.shape[0]
+    sp = tuple(x.shape[2:])
+    D, H, W = sp if nd == 3 else (1,) + sp
+    taps, vox = 3 ** nd, D * H * W
+    wd = w.contiguous().to(dev)
+    dst = torch.zeros(nv.lib().iunet_f8_pack_conv3_bytes(Cout, Cin, taps), dtype=torch.uint8, device=dev)
+    sc = torch.empty(Cout, device=dev)
+    b_out = torch.empty(Cout, device=dev)
+    bnp = [None] * 4 if bn is None else [nv.ptr(t.to(dev)) for t in bn]
+    keep = None if bn is None else [t.to(dev) for t in bn]
+    if bn is not None:
+        bnp = [nv.ptr(t) for t in keep]
+    nv.call('iunet_f8_pack_conv3', nv.ptr(wd), bnp[0], bnp[1], bnp[2], bnp[3], 1e-5, nv.ptr(dst), nv.ptr(sc),
+            nv.ptr(b_out) if bn is not None else None, Cout, Cin, taps, nv.stream())
+    bd = b_out if bn is not None else (None if bias is None else bias.to(dev))
+    xb = blocked(x, dtype).to(dev)
+    y = torch.full((N * Cout * vox,), float('nan'), dtype=dtype, device=dev)
+    nv.call('iunet_conv3_f8_fwd', nv.DTYPE_CODE[dtype], nd, nv.ptr(xb), Cin * vox, nv.ptr(y), Cout * vox, nv.ptr(dst), nv.ptr(sc),
+            nv.ptr(bd), N, D, H, W, Cin, Cout, epi, nv.stream())
+    torch.cuda.synchronize()
+    return unblocked(y.float().cpu(), N, Cout, sp), dst.cpu(), sc.cpu(), (None if bd is None else bd.cpu())
+
+
+def unpack_k16(bytes_u8, cout, cin, taps):
+    """Inverse of the K16 order [cob32][chunk16][column pair][dy][2][64][8] -> float32 [Cout][Cin][taps] (e4m3 values)."""
+    vals = bytes_u8.view(torch.float8_e4m3fn).float().numpy()
+    ncol = taps // 3
+    ncmb, nchunk = (ncol + 1) // 2, cin // 16
+    v = vals.reshape(cout // 32, nchunk, ncmb, 3, 2, 64, 8)
+    out = np.zeros((cout, cin, taps), np.float32)
+    for lane in range(64):
+        row, qq = lane & 15, lane >> 4
+        for m in range(2):
+            co_in = 8 * (row >> 2) + 4 * m + (row & 3)
+            for c in range(ncmb):
+                col = 2 * c + (qq >> 1)
+                if col >= ncol:
+                    assert not v[:, :, c, :, m, lane, :].any()        # the missing column of the last pair is zero
+                    continue
+                for dy in range(3):
+                    tap = ((col // 3) * 3 + dy) * 3 + col % 3
+                    for j in range(8):
+                        out[co_in::32, 8 * (qq & 1) + j::16, tap] = v[:, :, c, dy, m, lane, j]
+    return out
+
+
+@pytest.mark.parametrize('nd,cout,cin', [(3, 32, 32), (3, 64, 256), (2, 64, 64)])
+def test_packed_bytes_are_the_oracle_quantisation(nv, nd, cout, cin):
+    g = torch.Generator().manual_seed(3)
+    taps = 3 ** nd
+    w = torch.randn((cout, cin) + (3,) * nd, generator=g) * 0.05
+    w[0] *= 40.0                                                     # channels with very different ranges -> different scales
+    w[1] *= 1e-3
+    bn = [0.75 + 0.5 * torch.rand(cout, generator=g), 0.1 * torch.randn(cout, generator=g),
+          0.2 * torch.randn(cout, generator=g), 0.5 + torch.rand(cout, generator=g)]
+    x = torch.zeros((1, cin) + ((4, 8, 16) if nd == 3 else (16, 32)))
+    _, bytes_u8, sc, bias = run_conv_f8(nv, x, w, torch.bfloat16, nd, bn=bn)
+    wf, bf = unet_ref.fold_bn_exact(w, *bn)
+    want = unet_ref.quantize_e4m3(wf).numpy().reshape(cout, cin, taps)          # scale x e4m3 value, fp32
+    got = unpack_k16(bytes_u8, cout, cin, taps) * sc.numpy()[:, None, None]
+    assert np.array_equal(got, want)
+    assert np.array_equal(bias.numpy(), bf.numpy())
+    assert set(np.unique(np.log2(sc.numpy()) % 1)) == {0.0}         # powers of two
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'f16'])
+@pytest.mark.parametrize('nd,shape,cin,cout', [
+    (3, (4, 8, 16), 32, 32), (3, (6, 12, 20), 64, 64), (3, (9, 7, 17), 128, 32), (3, (8, 8, 16), 256, 64),   # 256: streamed weights
+    (3, (16, 16, 16), 256, 256), (3, (2, 8, 16), 256, 32),                                                    # few tiles: half-size tile
+    (2, (16, 32), 32, 32), (2, (20, 70), 64, 32), (2, (48, 40), 256, 64), (2, (16, 32), 512, 32)])
+def test_conv3_f8_exact_integers(nv, nd, shape, cin, cout, dtype):
+    g = torch.Generator().manual_seed(1)
+    N = 2
+    x = torch.randint(-4, 5, (N, cin) + shape, generator=g).float()            # exact in e4m3 and in 16 bits
+    w = torch.randint(-3, 4, (cout, cin) + (3,) * nd, generator=g).float()      # x 2^k: exact in e4m3
+    w[:, :, (0,) * nd] += 0                                                      # (asymmetric by construction: random)
+    bias = torch.randint(-8, 9, (cout,), generator=g).float()
+    conv = F.conv3d if nd == 3 else F.conv2d
+    want = torch.relu(conv(x, w, bias=bias, padding=1))
+    got, _, sc, _ = run_conv_f8(nv, x, w, DT[dtype], nd, epi=2, bias=bias)
+    assert torch.isfinite(got).all()
+    # every product and every fp32 sum is exact (|sums| < 2^24); the one rounding is the store to 16 bits, round to nearest even
+    assert torch.equal(got, want.to(DT[dtype]).float()), f'{(got != want.to(DT[dtype]).float()).sum().item()} of {got.numel()} differ'
+
+
+@pytest.mark.parametrize('nd', [2, 3])
+def test_conv3_f8_rounds_activations_like_the_oracle(nv, nd):
+    """Inputs that are not e4m3 values (and some beyond 448): the result equals the fp32 conv of the ORACLE's rounding of
+    the same input (quantize_act_e4m3: nearest even, saturating) -- sums of exact products, compared with a tolerance of
+    one fp32 accumulation order."""
+    g = torch.Generator().manual_seed(5)
+    cin, cout = 64, 32
+    shape = (4, 8, 16) if nd == 3 else (16, 32)
+    x = (torch.randn((1, cin) + shape, generator=g) * 3).to(torch.bfloat16).float()
+    x.view(-1)[:7] = torch.tensor([500.0, -1000.0, 448.0, 0.0009765625, -0.0029296875, 17.0, 0.0])   # saturation, subnormals, ties
+    w = torch.randint(-3, 4, (cout, cin) + (3,) * nd, generator=g).float()
+    conv = F.conv3d if nd == 3 else F.conv2d
+    xq = unet_ref.quantize_act_e4m3(x)
+    assert xq.abs().max() == 448 and not torch.equal(xq, x)
+    want = conv(xq, w, padding=1)
+    got, _, _, _ = run_conv_f8(nv, x, w, torch.bfloat16, nd, epi=0)
+    want_b = want.to(torch.bfloat16).float()
+    # the device rounds its fp32 sum to bf16 once; the sums themselves differ by the order of fp32 additions at most
+    assert (got - want_b).abs().max() <= 2 ** -7 * want.abs().max()
+    assert ((got - want_b).abs() > 0).float().mean() < 0.02
+
+
+def _f8_net_case(dim, levels, base, ncls, shape, seed):
+    import warnings
+    from interactive_unet.unet import UNet
+    from interactive_unet.engine import F8Conv
+    from scipy import ndimage
+    p = unet_ref.init_params(dim=dim, levels=levels, base=base, ncls=ncls, seed=seed, randomize_bn=True)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        m = UNet(num_classes=ncls, dim=dim, levels=levels, base=base, act_dtype='bf16', pretrained=False,
+                 weight_dtype='fp8_e4m3')
+    m.load_named(p)
+    m = m.cuda().eval()
+    eng = m.engine('eval')
+    assert isinstance(eng.packed['enc0.conv2'][0], F8Conv) and isinstance(eng.packed['dec0.conv1'][0], F8Conv)
+    assert eng.packed['dec0.conv1'][0].bytes.dtype == torch.uint8              # one byte per weight in HBM
+    rng = np.random.default_rng(5)
+    v = ndimage.gaussian_filter(rng.random(shape), 3)
+    x = torch.tensor(((v - v.min()) / (v.max() - v.min()) * 255).astype(np.uint8))[None, None]
+    probs = m(x.cuda()).cpu()
+    xf = x.float() / 255.0
+    kw = dict(dim=dim, levels=levels, act_dtype=torch.bfloat16, weight_quant='fp8_e4m3')
+    ref_q = unet_ref.forward(p, xf, act_quant=True, **kw)                       # same quantised operands as the device
+    ref_w = unet_ref.forward(p, xf, **kw)                                        # weights only (the round-1 fake-quant path)
+    ref_f = unet_ref.forward(p, xf, dim=dim, levels=levels)                      # fp32
+    d = (probs - ref_q).abs()
+    r = dict(mean=d.mean().item(), max=d.max().item(), agree=(probs.argmax(1) == ref_q.argmax(1)).float().mean().item(),
+             dev_vs_f32=(probs - ref_f).abs().mean().item(), emu_vs_f32=(ref_q - ref_f).abs().mean().item(),
+             dev_vs_wonly=(probs - ref_w).abs().mean().item())
+    print(f'{dim}-D {levels} levels base {base} on fp8 MFMA: vs same-operand emulation mean |dp| = {r["mean"]:.2e}, max = {r["max"]:.2e}, '
+          f'class map equal on {100 * r["agree"]:.2f} %; mean |dp| vs fp32: device {r["dev_vs_f32"]:.2e}, emulation {r["emu_vs_f32"]:.2e}')
+    return r
+
+
+def test_shallow_network_on_fp8_matrix_cores_tracks_the_emulation():
+    """Two levels (6 stage convs): little depth for a differently rounded value to spread -- the device and the CPU emulation
+    with the same quantised operands agree closely."""
+    for dim, shape in ((3, (16, 32, 48)), (2, (64, 96))):
+        r = _f8_net_case(dim, 2, 32, 3, shape, seed=7)
+        assert r['mean'] <= 2e-3 and r['agree'] >= 0.995, r
+        assert r['mean'] < r['dev_vs_wonly']                  # the activation rounding is really applied
+
+
+def test_c5_network_on_fp8_matrix_cores():
+    """BASELINE.json configs[4]: 3-D, 5 levels, base 64, 4 classes; stage convs on the fp8 MFMA.  Checker = the CPU emulation
+    with the SAME quantised operands (e4m3 weights with the same scales, activations rounded to bf16 in memory and to e4m3
+    in front of every stage conv).  Tolerance (stated, not 1e-3: SURVEY 8d "fp8 is not held to 1e-3 vs fp32"): an e4m3
+    rounding step is 2^-4 relative; a value near a rounding boundary rounds differently after a different fp32 summation
+    order, and 22 quantising layers spread that -- the device and the emulation are two equally valid evaluations of the
+    same quantised network, as far from each other as each is from fp32 (measured: mean |dp| 1.1e-2 between them, 1.5e-2
+    emulation vs fp32; this random-init 4-class net has near-uniform probabilities, so 4 % of the argmax flips).  Asserted:
+    mean |dp| <= 2e-2, max <= 0.3, class map equal on >= 93 %, and the device is no further from fp32 than 1.3 x the
+    emulation is."""
+    r = _f8_net_case(3, 5, 64, 4, (32, 32, 48), seed=6)
+    assert r['mean'] <= 2e-2 and r['max'] <= 0.3 and r['agree'] >= 0.93, r
+    assert r['dev_vs_f32'] <= 1.3 * r['emu_vs_f32'], r

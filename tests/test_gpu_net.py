@@ -181,33 +181,3 @@ def test_c5_shape_5_level_base64_4_class_forward_and_step():
     out1 = te.train_step(x, y, None)
     out2 = te.train_step(x, y, None)
     assert np.isfinite(out1['Loss']) and np.isfinite(out2['Loss']) and out2['Loss'] < out1['Loss'] + 0.05
-
-
-def test_c5_fp8_weights_forward():
-    """BASELINE.json configs[4]: 3-D, 5 levels, base 64, 4 classes, weights in OCP e4m3 with per-output-channel
-    power-of-two scales (quantised on the device while packing, after the BatchNorm fold), bf16 activations.
-    The oracle runs the same network on ITS quantisation of the same fp32 weights (round_e4m3 is pinned against
-    torch.float8_e4m3fn in the CPU suite); e4m3 x 2^k values are exact in bf16, so the tolerance is the bf16
-    storage tolerance of the unquantised net, not an fp8 tolerance."""
-    import warnings
-    from interactive_unet.unet import UNet
-    dim, levels, base, ncls = 3, 5, 64, 4
-    p = unet_ref.init_params(dim=dim, levels=levels, base=base, ncls=ncls, seed=6, randomize_bn=True)
-    with warnings.catch_warnings():
-        warnings.simplefilter('ignore')
-        m = UNet(num_classes=ncls, dim=dim, levels=levels, base=base, act_dtype='bf16', pretrained=False,
-                 weight_dtype='fp8_e4m3')
-    m.load_named(p)
-    m = m.cuda().eval()
-    shape = (32, 32, 48)
-    x = torch.tensor(_smooth(shape, 5))[None, None]
-    probs = m(x.cuda()).cpu()
-    ref_q = unet_ref.forward(p, x.float() / 255.0, dim=dim, levels=levels, act_dtype=torch.bfloat16,
-                             weight_quant='fp8_e4m3')
-    ref_f = unet_ref.forward(p, x.float() / 255.0, dim=dim, levels=levels, act_dtype=torch.bfloat16)
-    err = (probs - ref_q).abs().max().item()
-    qerr = (ref_q - ref_f).abs().max().item()
-    print(f'C5 fp8 weights: max |prob - quantised oracle| = {err:.2e}; quantisation itself moves probs by {qerr:.2e}')
-    assert err < 3e-2
-    assert qerr > 1e-3          # the quantised net is a different function: the test would notice an unquantised device path
-    assert (probs - ref_f).abs().max().item() > 0.5 * qerr

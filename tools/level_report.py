@@ -1,17 +1,20 @@
-"""Merge gpurun_out/levels/* (tools/level_report.sh) into profiles/r01_conv_levels.md."""
-import csv, glob, os, re
+"""Merge gpurun_out/levels_<tag>/* (tools/level_report.sh) into profiles/<round>_conv_levels_<tag>.md.
+    python tools/level_report.py [tag=3d] [round=r02]"""
+import csv, glob, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-L = os.path.join(ROOT, 'gpurun_out', 'levels')
-rows = []
+tag_ = sys.argv[1] if len(sys.argv) > 1 else '3d'
+rnd = sys.argv[2] if len(sys.argv) > 2 else 'r02'
+L = os.path.join(ROOT, 'gpurun_out', f'levels_{tag_}')
+rows, head = [], None
 for f in sorted(glob.glob(os.path.join(L, 'time_*.txt'))):
     tag = os.path.basename(f)[5:-4]
     line = open(f).readline()
-    m = re.search(r'L(\d)\s+(\d+)->\s*(\d+) @(\d+)\^3 N=1 layout (\d): fwd\s+([\d.]+) us\s+([\d.]+) TF/s', line)
+    m = re.search(r'L(\d)\s+(\d+)->\s*(\d+) @(\d+)\^(\d) N=(\d+) layout (\d): fwd\s+([\d.]+) us\s+([\d.]+) TF/s', line)
     if not m:
         continue
-    lvl, cin, cout, S, lay, us, tf = m.groups()
+    lvl, cin, cout, S, nd, n, lay, us, tf = m.groups()
     def ctr(kind, name):
-        g = glob.glob(os.path.join(L, f'{kind}_{tag}', '*', '*_counter_collection.csv'))
+        g = glob.glob(os.path.join(L, f'{kind}_{tag}', '**', '*_counter_collection.csv'), recursive=True)
         if not g:
             return None
         vals = [float(r['Counter_Value']) for r in csv.DictReader(open(g[0]))
@@ -20,18 +23,23 @@ for f in sorted(glob.glob(os.path.join(L, 'time_*.txt'))):
     busy, gui = ctr('mfma', 'SQ_VALU_MFMA_BUSY_CYCLES'), ctr('mfma', 'GRBM_GUI_ACTIVE')
     fetch, write = ctr('fetch', 'FETCH_SIZE'), ctr('write', 'WRITE_SIZE')
     util = busy / (gui / 8 * 1024) if busy and gui else None       # 1024 SIMDs, GUI_ACTIVE summed over 8 XCDs
-    vox = int(S) ** 3
+    nd, n = int(nd), int(n)
+    vox = int(S) ** nd * n
     alg = (int(cin) + int(cout)) * 2 * vox
     traffic = (2 * fetch + write) * 1024 if fetch is not None and write is not None else None
-    rows.append((lvl, cin, cout, S, lay, float(us), float(tf), util, alg, traffic))
-with open(os.path.join(ROOT, 'profiles', 'r01_conv_levels.md'), 'w') as o:
-    o.write('# 3x3x3 conv forward per resolution level (bf16, one 128^3 chunk, N = 1) -- rocprofv3 PMC, MI355X\n\n')
-    o.write('MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs); HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE '
-            '(gfx950 FETCH_SIZE correction), separate passes; % of peak vs 2.5 PFLOP/s dense bf16 and 8 TB/s.\n\n')
-    o.write('| level | layer | kernel layout | time (us) | TFLOP/s | % MFMA peak | MFMA pipe busy | algorithmic MB | HBM MB (PMC) | HBM GB/s | % HBM peak |\n|---|---|---|---|---|---|---|---|---|---|---|\n')
-    for lvl, cin, cout, S, lay, us, tf, util, alg, traffic in rows:
+    head = (nd, n)
+    rows.append((lvl, cin, cout, S, lay, float(us), float(tf), util, alg, traffic, nd))
+out = os.path.join(ROOT, 'profiles', f'{rnd}_conv_levels_{tag_}.md')
+with open(out, 'w') as o:
+    nd, n = head
+    o.write(f'# 3^{nd} conv forward per resolution level ({n} x level-0 tile per launch) -- rocprofv3 PMC, MI355X\n\n')
+    o.write('time / TFLOP/s: HIP events over 30 back-to-back launches (tools/bench_conv.py); MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / '
+            '(GRBM_GUI_ACTIVE / 8 x 1024 SIMDs); HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE (gfx950 FETCH_SIZE correction), separate '
+            'passes; % of peak vs 2.5 PFLOP/s dense 16-bit MFMA and 8 TB/s.  Produced by tools/level_report.sh + level_report.py.\n\n')
+    o.write('| level | layer | kernel layout | time (us) | TFLOP/s | % MFMA peak | MFMA pipe busy | algorithmic MB | HBM MB (PMC) | traffic / algorithmic | HBM GB/s | % HBM peak |\n|---|---|---|---|---|---|---|---|---|---|---|---|\n')
+    for lvl, cin, cout, S, lay, us, tf, util, alg, traffic, nd in rows:
         gbs = traffic / (us * 1e-6) / 1e9 if traffic else None
-        o.write(f'| {lvl} ({S}^3) | {cin}->{cout} | {lay} | {us:.1f} | {tf:.0f} | {tf / 25:.1f} % | '
+        o.write(f'| {lvl} ({S}^{nd}) | {cin}->{cout} | {lay} | {us:.1f} | {tf:.0f} | {tf / 25:.1f} % | '
                 f'{"%.0f %%" % (100 * util) if util else "n/a"} | {alg / 1e6:.0f} | {"%.0f" % (traffic / 1e6) if traffic else "n/a"} | '
-                f'{"%.0f" % gbs if gbs else "n/a"} | {"%.1f %%" % (gbs / 80) if gbs else "n/a"} |\n')
-print(open(os.path.join(ROOT, 'profiles', 'r01_conv_levels.md')).read())
+                f'{"%.2f x" % (traffic / alg) if traffic else "n/a"} | {"%.0f" % gbs if gbs else "n/a"} | {"%.1f %%" % (gbs / 80) if gbs else "n/a"} |\n')
+print(open(out).read())
