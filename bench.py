@@ -132,6 +132,12 @@ def conv_roofline(nv, cfg, workload, dtype, iters=50):
     nv.call('iunet_pack_conv3', dt, nv.ptr(w), None, nv.ptr(wpk), cout, cin, taps, pmode, nv.stream())
     run = lambda: nv.call('iunet_conv3_fwd', dt, dim, nv.ptr(x), cin * vox, nv.ptr(y), cout * vox, nv.ptr(wpk),
                           nv.ptr(bias), None, N, D, H, W, cin, cout, 2, lay, nv.stream())
+    if cfg['wq']:            # C5: the same layer on the fp8 matrix cores (e4m3 weight bytes, activations rounded in the loaders)
+        wb = torch.zeros(nv.lib().iunet_f8_pack_conv3_bytes(cout, cin, taps), dtype=torch.uint8, device=dev)
+        wsc = torch.empty(cout, device=dev)
+        nv.call('iunet_f8_pack_conv3', nv.ptr(w), None, None, None, None, 1e-5, nv.ptr(wb), nv.ptr(wsc), None, cout, cin, taps, nv.stream())
+        run = lambda: nv.call('iunet_conv3_f8_fwd', dt, dim, nv.ptr(x), cin * vox, nv.ptr(y), cout * vox, nv.ptr(wb), nv.ptr(wsc),
+                              nv.ptr(bias), N, D, H, W, cin, cout, 2, None, nv.stream())
     for _ in range(3):
         run()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(iters + 1)]
@@ -145,7 +151,7 @@ def conv_roofline(nv, cfg, workload, dtype, iters=50):
     flops = 2.0 * taps * cin * cout * vox * N
     tf = lambda t: flops / (t * 1e-3) / 1e12
     burst, settled = sum(per[:8]) / 8, sum(per[-20:]) / 20
-    kname = {0: 'conv3_mfma_kernel', 1: 'conv3_v2_kernel', 2: 'conv3_v4_kernel'}[lay]
+    kname = 'conv3_f8_kernel' if cfg['wq'] else {0: 'conv3_mfma_kernel', 1: 'conv3_v2_kernel', 2: 'conv3_v4_kernel'}[lay]
     tname = 'bf16' if dtype == torch.bfloat16 else 'f16'
     where = f'{N} x {"x".join(str(s) for s in shape)}'
     out = {'bound': 'mfma', 'kernel': f'{kname}<{tname},{dim}> (dec0.conv1 {cin}->{cout} @ {where})',

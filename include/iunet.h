@@ -134,10 +134,14 @@ int iunet_f32_head_fwd(const void* x, long long x_ss, int C0, const void* w, con
 long long iunet_f8_pack_conv3_bytes(int Cout, int Cin, int taps);
 int iunet_f8_pack_conv3(const void* w, const void* gamma, const void* beta, const void* mean, const void* var, float eps,
                         void* dst, void* wscale, void* bias_out, int Cout, int Cin, int taps, void* stream);
-/* y = epilogue(wscale[c] * sum e4m3(x) * w8 + bias[c]); x, y: NHWC8c of `dtype`; epi as iunet_conv3_fwd. */
+/* y = epilogue(wscale[c] * sum e4m3(x) * w8 + bias[c]); x, y: NHWC8c of `dtype`; epi as iunet_conv3_fwd.
+ * workspace: iunet_conv3_f8_workspace_elems floats of scratch or NULL.  With a workspace, launches whose grid would leave most
+ * of the chip idle behind a long loop over the input channels (the 16^3 / 8^3 levels of C5) are split along Cin: each share
+ * is a workgroup of its own writing fp32 partial sums there, and a fixed-order reduction applies scale, bias and ReLU. */
+long long iunet_conv3_f8_workspace_elems(int nd, int N, int D, int H, int W, int Cin, int Cout);
 int iunet_conv3_f8_fwd(int dtype, int nd, const void* x, long long x_sstride, void* y, long long y_sstride, const void* wpk,
                        const void* wscale, const void* bias, int N, int D, int H, int W, int Cin, int Cout, int epi,
-                       void* stream);
+                       void* workspace, void* stream);
 
 /* ---- whole-volume prediction (predict.py:201-256) -------------------------------------- */
 /* get_padded_block (predict.py:291-316): reflect-padded S^3 uint8 block of a device volume. */

@@ -63,7 +63,8 @@ int iunet_f8_pack_launch(const float* w, const float* gamma, const float* beta, 
                          void* dst, float* wscale, float* bias_out, int Cout, int Cin, int taps, hipStream_t stream);
 int iunet_conv3_f8_launch(int dtype, int nd, const void* x, long long x_sstride, void* y, long long y_sstride, const void* wpk,
                           const float* wscale, const float* bias, int N, int D, int H, int W, int Cin, int Cout, int epi,
-                          hipStream_t stream);
+                          float* workspace, hipStream_t stream);
+long long iunet_conv3_f8_workspace_floats(int nd, int N, int D, int H, int W, int Cin, int Cout);
 
 #define DT_OK(dt) IUNET_REQUIRE((dt) == 0 || (dt) == 1, "dtype must be 0 (f16) or 1 (bf16), got %d", (dt))
 
@@ -245,9 +246,14 @@ int iunet_f8_pack_conv3(const void* w, const void* gamma, const void* beta, cons
                               dst, (float*)wscale, (float*)bias_out, Cout, Cin, taps, (hipStream_t)stream);
 }
 
+long long iunet_conv3_f8_workspace_elems(int nd, int N, int D, int H, int W, int Cin, int Cout) {
+  if ((nd != 2 && nd != 3) || N < 1 || D < 1 || H < 1 || W < 1 || Cin < 32 || Cout < 32 || Cin % 32 || Cout % 32) return 0;
+  return iunet_conv3_f8_workspace_floats(nd, N, D, H, W, Cin, Cout);
+}
+
 int iunet_conv3_f8_fwd(int dtype, int nd, const void* x, long long x_sstride, void* y, long long y_sstride, const void* wpk,
                        const void* wscale, const void* bias, int N, int D, int H, int W, int Cin, int Cout, int epi,
-                       void* stream) {
+                       void* workspace, void* stream) {
   DT_OK(dtype);
   IUNET_REQUIRE(x && y && wpk && wscale, "conv3_f8: null pointer");
   IUNET_REQUIRE(nd == 2 || nd == 3, "conv3_f8: nd must be 2 or 3");
@@ -257,7 +263,7 @@ int iunet_conv3_f8_fwd(int dtype, int nd, const void* x, long long x_sstride, vo
   IUNET_REQUIRE(epi >= 0 && epi <= 2, "conv3_f8: bad epilogue %d", epi);
   IUNET_REQUIRE(epi == 0 || bias != nullptr, "conv3_f8: epilogue %d needs a bias", epi);
   return iunet_conv3_f8_launch(dtype, nd, x, x_sstride, y, y_sstride, wpk, (const float*)wscale, (const float*)bias, N, D, H, W,
-                               Cin, Cout, epi, (hipStream_t)stream);
+                               Cin, Cout, epi, (float*)workspace, (hipStream_t)stream);
 }
 
 }  // extern "C"

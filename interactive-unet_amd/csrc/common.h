@@ -115,3 +115,34 @@ inline int iunet_set_max_lds(IunetLdsOnce& st, const void* fn, int lds) {
     const int rc_ = iunet_set_max_lds(once_, (const void*)(fn), (lds));         \
     if (rc_ != IUNET_OK) return rc_;                                            \
   } while (0)
+
+// Brick shape of the wave-specialised convolutions (conv3_v4.hip, conv3_f8.hip): the 32 / ncob workgroups that an XCD gives
+// one Cout tile work on one compact brick of bz x by x bx tiles at a time.  A brick wider than the tile grid would make its
+// surplus slots run fully masked -- whole workgroups of wasted work on the small grids of the deep levels (16^3: half of them,
+// 8^3: three quarters) -- so every extent is clamped to the grid and the lost factor handed to the other axes.
+inline void iunet_brick_shape(int nd, int ncob, int tilesZ, int tilesY, int tilesX, int* bz, int* by, int* bx) {
+  auto p2 = [](int v) { int r = 1; while (r * 2 <= v) r *= 2; return r; };
+  int z, y, x;
+  if (nd == 3) {
+    if (ncob == 1)      { z = 2; y = 4; x = 4; }
+    else if (ncob == 2) { z = 2; y = 4; x = 2; }
+    else if (ncob <= 4) { z = 2; y = 2; x = 2; }
+    else                { z = 1; y = 2; x = 2; }
+  } else {
+    z = 1;
+    if (ncob == 1)      { y = 4; x = 8; }
+    else if (ncob == 2) { y = 4; x = 4; }
+    else if (ncob <= 4) { y = 2; x = 4; }
+    else                { y = 2; x = 2; }
+  }
+  const int want = z * y * x;
+  const int mz = nd == 3 ? p2(tilesZ) : 1, my = p2(tilesY), mx = p2(tilesX);
+  z = z < mz ? z : mz; y = y < my ? y : my; x = x < mx ? x : mx;
+  while (z * y * x < want) {
+    if (y * 2 <= my) y *= 2;
+    else if (x * 2 <= mx) x *= 2;
+    else if (z * 2 <= mz) z *= 2;
+    else break;                                       // the grid has fewer tiles than slots: the launch is simply smaller
+  }
+  *bz = z; *by = y; *bx = x;
+}

@@ -41,6 +41,8 @@ struct ConvF8Params {
   int bz, by, bx;
   int nbz, nby, nbx;
   int epi;
+  int ksplit;                                 // > 1: blockIdx.z owns Cin / ksplit input channels and writes fp32 partial sums
+  float* partial;                             // [ksplit][N][Cout / 8][voxels][8] fp32 (split-K only)
 };
 
 // 8 activations of type T -> 8 e4m3 bytes (round to nearest even, saturating at +-448)
@@ -85,15 +87,20 @@ __global__ __launch_bounds__((F8Tile<ND, SMALL>::NCW * 64 + (WS ? 256 : 512)), 1
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int cob = blockIdx.y;
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  // blocks b and b + 8 share an XCD whatever blockIdx.y / .z are (the grid's x extent is a multiple of 8), so the brick range
+  // of a workgroup is rotated by its Cout tile and split: small grids (fewer bricks than XCDs) then spread over all XCDs
+  const int xcd = (blockIdx.x + blockIdx.y + 3 * blockIdx.z) & 7, slot = blockIdx.x >> 3;
   const int sx = slot % p.bx, sy = (slot / p.bx) % p.by, sz = slot / (p.bx * p.by);
   const int nbricks = p.N * p.nbz * p.nby * p.nbx;
   const int b_begin = (int)((long long)xcd * nbricks / 8), b_end = (int)((long long)(xcd + 1) * nbricks / 8);
-  const int nchunk = p.Cin / (16 * S16);
+  // split-K: this workgroup's share of the input channels (chunks chunk0 .. chunk0 + nchunk - 1 of every tile)
+  const int nchunk_all = p.Cin / (16 * S16);
+  const int nchunk = nchunk_all / p.ksplit;
+  const int chunk0 = (int)blockIdx.z * nchunk;
   const int nsteps = (b_end - b_begin) * nchunk;
   if (nsteps <= 0) return;
   const long long plane_stride = (long long)p.D * p.H * p.W * 8;
-  const u32x4* wsrc = (const u32x4*)p.wpk + (long long)cob * nchunk * (WSTEP / 16);
+  const u32x4* wsrc = (const u32x4*)p.wpk + ((long long)cob * nchunk_all + chunk0) * (WSTEP / 16);
 
   auto tile_origin = [&](int k, int& n_img, int& z0, int& y0, int& x0) -> bool {
     int b = b_begin + k;
@@ -142,7 +149,7 @@ __global__ __launch_bounds__((F8Tile<ND, SMALL>::NCW * 64 + (WS ? 256 : 512)), 1
       const int chunk = s - (s / nchunk) * nchunk;
       int n_img, z0, y0, x0;
       tile_origin(s / nchunk, n_img, z0, y0, x0);
-      const T* xc = (const T*)p.x + (long long)n_img * p.x_sstride + (long long)chunk * CP * plane_stride;
+      const T* xc = (const T*)p.x + (long long)n_img * p.x_sstride + (long long)(chunk0 + chunk) * CP * plane_stride;
       r.ok = 0;
 #pragma unroll
       for (int it = 0; it < AIT; ++it) {
@@ -264,15 +271,21 @@ __global__ __launch_bounds__((F8Tile<ND, SMALL>::NCW * 64 + (WS ? 256 : 512)), 1
         const int f = f0 + n, row = f / FX;
         const int gz = z0 + (ND == 3 ? row / TY : 0), gy = y0 + row % TY, gx = x0 + (f % FX) * 16 + l15;
         const bool ok = gz < p.D && gy < p.H && gx < p.W;
-        V8 o;
+        const long long vo = (((long long)gz * p.H + gy) * p.W + gx) * 8;
+        if (p.ksplit > 1) {          // raw fp32 partial sums; scale, bias and activation happen in the reduction
+          float* po = p.partial + ((long long)((int)blockIdx.z * p.N + n_img) * (p.Cout / 8) + cob * 4 + q) * plane_stride + vo;
+          if (ok) { *(f32x4*)po = acc[0][n]; *(f32x4*)(po + 4) = acc[1][n]; }
+        } else {
+          V8 o;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float a = j < 4 ? acc[0][n][j] : acc[1][n][j - 4];
-          float r = __fmul_rn(a, ws_r[j]) + bias_r[j];          // the scale is a power of two: the product is exact
-          if (p.epi == 2) r = fmaxf(r, 0.f);
-          o[j] = from_f32<T>(r);
+          for (int j = 0; j < 8; ++j) {
+            const float a = j < 4 ? acc[0][n][j] : acc[1][n][j - 4];
+            float r = __fmul_rn(a, ws_r[j]) + bias_r[j];          // the scale is a power of two: the product is exact
+            if (p.epi == 2) r = fmaxf(r, 0.f);
+            o[j] = from_f32<T>(r);
+          }
+          if (ok) *(V8*)(yout + (long long)(cob * 4 + q) * plane_stride + vo) = o;
         }
-        if (ok) *(V8*)(yout + (long long)(cob * 4 + q) * plane_stride + (((long long)gz * p.H + gy) * p.W + gx) * 8) = o;
         acc[0][n] = f32x4{0.f, 0.f, 0.f, 0.f};
         acc[1][n] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
@@ -338,25 +351,14 @@ int launch_f8(ConvF8Params p, hipStream_t stream) {
   constexpr int NPIX = (TL::TZ + 2 * TL::PADZ) * (TL::TY + 2) * (TL::TX + 2);
   constexpr int PLANE = ((NPIX * 16 + 255) / 256) * 256;
   constexpr int WSTEP = TL::S16 * ((TL::NCOL + 1) / 2) * 3 * 2 * 512;
-  const int lds = 2 * TL::S16 * PLANE + (WS ? p.Cin / (16 * TL::S16) : 2) * WSTEP;
+  const int lds = 2 * TL::S16 * PLANE + (WS ? p.Cin / p.ksplit / (16 * TL::S16) : 2) * WSTEP;
   IUNET_SET_MAX_LDS((conv3_f8_kernel<T, ND, WS, SMALL>), lds);
   p.tilesZ = (p.D + TL::TZ - 1) / TL::TZ; p.tilesY = (p.H + TL::TY - 1) / TL::TY; p.tilesX = (p.W + TL::TX - 1) / TL::TX;
   const int ncob = p.Cout / 32;
-  if (ND == 3) {
-    if (ncob == 1)      { p.bz = 2; p.by = 4; p.bx = 4; }
-    else if (ncob == 2) { p.bz = 2; p.by = 4; p.bx = 2; }
-    else if (ncob <= 4) { p.bz = 2; p.by = 2; p.bx = 2; }
-    else                { p.bz = 1; p.by = 2; p.bx = 2; }
-  } else {
-    p.bz = 1;
-    if (ncob == 1)      { p.by = 4; p.bx = 8; }
-    else if (ncob == 2) { p.by = 4; p.bx = 4; }
-    else if (ncob <= 4) { p.by = 2; p.bx = 4; }
-    else                { p.by = 2; p.bx = 2; }
-  }
+  iunet_brick_shape(ND, ncob, p.tilesZ, p.tilesY, p.tilesX, &p.bz, &p.by, &p.bx);
   p.nbz = (p.tilesZ + p.bz - 1) / p.bz; p.nby = (p.tilesY + p.by - 1) / p.by; p.nbx = (p.tilesX + p.bx - 1) / p.bx;
   const int gx = 8 * p.bz * p.by * p.bx;
-  hipLaunchKernelGGL((conv3_f8_kernel<T, ND, WS, SMALL>), dim3(gx, ncob), dim3(TL::NCW * 64 + (WS ? 256 : 512)), lds, stream, p);
+  hipLaunchKernelGGL((conv3_f8_kernel<T, ND, WS, SMALL>), dim3(gx, ncob, p.ksplit), dim3(TL::NCW * 64 + (WS ? 256 : 512)), lds, stream, p);
   IUNET_CHECK_HIP(hipGetLastError());
   return IUNET_OK;
 }
@@ -426,7 +428,59 @@ __global__ __launch_bounds__(256) void pack_f8_kernel(const float* __restrict__ 
   }
 }
 
+// split-K reduction: y = epilogue(wscale[c] * sum over the splits + bias[c]), fixed order; one thread per voxel and
+// 8-channel plane
+template <typename T>
+__global__ __launch_bounds__(256) void f8_splitk_reduce_kernel(const float* __restrict__ partial, int ksplit, T* __restrict__ y,
+                                                               long long y_ss, const float* __restrict__ wscale,
+                                                               const float* __restrict__ bias, int N, int planes, long long vox,
+                                                               int epi) {
+  using V8 = typename Vec8<T>::type;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= vox) return;
+  const int pl = blockIdx.y, n = blockIdx.z;
+  float a[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) a[j] = 0.f;
+  for (int z = 0; z < ksplit; ++z) {
+    const float* pp = partial + (((long long)(z * N + n) * planes + pl) * vox + i) * 8;
+    const f32x4 v0 = *(const f32x4*)pp, v1 = *(const f32x4*)(pp + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { a[j] += v0[j]; a[4 + j] += v1[j]; }
+  }
+  V8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float r = __fmul_rn(a[j], wscale[pl * 8 + j]) + (epi != 0 ? bias[pl * 8 + j] : 0.f);
+    if (epi == 2) r = fmaxf(r, 0.f);
+    o[j] = from_f32<T>(r);
+  }
+  *(V8*)(y + n * y_ss + ((long long)pl * vox + i) * 8) = o;
+}
+
 }  // namespace
+
+// Split-K policy.  A layer whose (voxel tiles x Cout tiles) leave most CUs idle and whose input channels make a long serial
+// loop per workgroup (C5's 16^3 and 8^3 levels: 64 .. 128 workgroups of 32 .. 64 steps each, 90 .. 470 TFLOP/s) is cut along
+// Cin into `ksplit` shares, each its own workgroup: the chip fills, the loop shortens, the shares' filters fit in LDS.
+int iunet_conv3_f8_ksplit(int nd, int N, int D, int H, int W, int Cin, int Cout) {
+  static const int forced = getenv("IUNET_F8_KSPLIT") ? atoi(getenv("IUNET_F8_KSPLIT")) : 0;
+  const long long tiles = nd == 3 ? (long long)N * ((D + 3) / 4) * ((H + 7) / 8) * ((W + 15) / 16)
+                                  : (long long)N * ((H + 15) / 16) * ((W + 31) / 32);
+  const long long tasks = tiles * (Cout / 32);                   // (tile, Cout tile) pairs: one workgroup each
+  const int nchunk = Cin / (nd == 3 ? 16 : 32);
+  // measured on C5's 16^3 level (tools/bench_conv.py --f8 1, IUNET_F8_KSPLIT sweep): two shares win from Cin = 512 on
+  // (512 -> 512: 69 -> 56 us, 1024 -> 512: 130 -> 88 us); four are slower again (more partial sums than they save), and
+  // shorter loops (Cin <= 256) lose to the reduction pass
+  int ks = forced > 0 ? forced : ((tasks < 256 && Cin >= 512) ? 2 : 1);
+  while (ks > 1 && (nchunk % ks != 0)) ks >>= 1;
+  return ks;
+}
+
+long long iunet_conv3_f8_workspace_floats(int nd, int N, int D, int H, int W, int Cin, int Cout) {
+  const int ks = iunet_conv3_f8_ksplit(nd, N, D, H, W, Cin, Cout);
+  return ks > 1 ? (long long)ks * N * Cout * D * H * W : 0;
+}
 
 long long iunet_f8_pack_bytes(int Cout, int Cin, int taps) {
   return (long long)Cout * Cin * ((taps / 3 + 1) / 2) * 6;       // K16 order pads the filter columns to pairs; one byte each
@@ -442,20 +496,36 @@ int iunet_f8_pack_launch(const float* w, const float* gamma, const float* beta, 
 
 int iunet_conv3_f8_launch(int dtype, int nd, const void* x, long long x_sstride, void* y, long long y_sstride, const void* wpk,
                           const float* wscale, const float* bias, int N, int D, int H, int W, int Cin, int Cout, int epi,
-                          hipStream_t stream) {
+                          float* workspace, hipStream_t stream) {
   ConvF8Params p;
+  p.ksplit = workspace ? iunet_conv3_f8_ksplit(nd, N, D, H, W, Cin, Cout) : 1;
+  p.partial = workspace;
   p.x = x; p.x_sstride = x_sstride; p.y = y; p.y_sstride = y_sstride; p.wpk = wpk; p.wscale = wscale; p.bias = bias;
   p.N = N; p.D = D; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.epi = epi;
   p.tilesZ = p.tilesY = p.tilesX = 0;
   p.bz = p.by = p.bx = p.nbz = p.nby = p.nbx = 0;
   // resident weights when they fit beside the two activation buffers (160 KB of LDS): 3-D up to Cin = 128 (2 x 17 KB +
   // 15 KB per 16 channels), 2-D up to Cin = 256 (2 x 19.5 KB + 12 KB per 32 channels)
-  const bool ws = nd == 3 ? Cin <= 128 : Cin <= 256;
-  const long long big_tiles = (long long)N * ((D + 3) / 4) * ((H + 7) / 8) * ((W + 15) / 16);
-  const bool small = nd == 3 && !ws && big_tiles * (Cout / 32) < 128;
+  const int cin_wg = Cin / p.ksplit;
+  // resident weights when they fit beside the two activation buffers (160 KB of LDS: 3-D up to 128 input channels per
+  // workgroup, 2-D up to 256) AND the workgroup walks at least two tiles: the resident filter is loaded before the first
+  // MFMA, which a one-tile workgroup (the 16^3 level at N = 1: 21 us resident, 15 us streamed) cannot amortise
+  const long long big_tiles = nd == 3 ? (long long)N * ((D + 3) / 4) * ((H + 7) / 8) * ((W + 15) / 16)
+                                      : (long long)N * ((H + 15) / 16) * ((W + 31) / 32);
+  const long long slots = Cout / 32 >= 256 ? 1 : 256 / (Cout / 32);      // workgroups (CUs) per Cout tile
+  const bool fits = nd == 3 ? cin_wg <= 128 : cin_wg <= 256;
+  const bool ws = fits && big_tiles >= 2 * slots;
+  const bool small = nd == 3 && !ws && big_tiles * (Cout / 32) * p.ksplit < 128;
 #define F8_GO(TT) (nd == 3 ? (ws ? launch_f8<TT, 3, true, false>(p, stream)                                          \
                                  : (small ? launch_f8<TT, 3, false, true>(p, stream) : launch_f8<TT, 3, false, false>(p, stream))) \
                            : (ws ? launch_f8<TT, 2, true, false>(p, stream) : launch_f8<TT, 2, false, false>(p, stream)))
-  return dtype == 0 ? F8_GO(f16) : F8_GO(bf16);
+  const int rc = dtype == 0 ? F8_GO(f16) : F8_GO(bf16);
 #undef F8_GO
+  if (rc != IUNET_OK || p.ksplit == 1) return rc;
+  const long long vox = (long long)D * H * W;
+  dim3 grid((unsigned)((vox + 255) / 256), Cout / 8, N);
+  if (dtype == 0) hipLaunchKernelGGL(f8_splitk_reduce_kernel<f16>, grid, dim3(256), 0, stream, workspace, p.ksplit, (f16*)y, y_sstride, wscale, bias, N, Cout / 8, vox, epi);
+  else hipLaunchKernelGGL(f8_splitk_reduce_kernel<bf16>, grid, dim3(256), 0, stream, workspace, p.ksplit, (bf16*)y, y_sstride, wscale, bias, N, Cout / 8, vox, epi);
+  IUNET_CHECK_HIP(hipGetLastError());
+  return IUNET_OK;
 }

@@ -26,6 +26,8 @@ extern "C" int iunet_v4_stamps_read(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_v4_stamps), sizeof(unsigned long long) * 4 * 512);
 }
 #endif
+int iunet_conv3_v4_stats_parts(int nd, int Cout);
+
 namespace {
 
 // tile shape, consumer waves (NCW; A/B: 4 waves x 8 fragments on the big 3-D tile measured the same, +-2 %), filter columns,
@@ -86,7 +88,9 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + (WS ? 256 : 512)), 1
   // shares with its neighbours are fetched from HBM once and then hit in that L2 (contiguous per-workgroup runs had
   // every concurrent tile 32 tiles apart: the 2.1x halo re-fetch all went to HBM / Infinity Cache at ~20 GB/s per CU).
   // Slots of a brick that stick out of the tile grid are processed fully masked (speed only, never correctness).
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  // blocks b and b + 8 share an XCD whatever blockIdx.y is (the grid's x extent is a multiple of 8): the brick range of a
+  // workgroup is rotated by its Cout tile, so a grid with fewer bricks than XCDs still spreads over all of them
+  const int xcd = (blockIdx.x + blockIdx.y) & 7, slot = blockIdx.x >> 3;
   const int sx = slot % p.bx, sy = (slot / p.bx) % p.by, sz = slot / (p.bx * p.by);
   const int nbricks = p.N * p.nbz * p.nby * p.nbx;
   const int b_begin = (int)((long long)xcd * nbricks / 8), b_end = (int)((long long)(xcd + 1) * nbricks / 8);
@@ -471,20 +475,16 @@ int launch_v4(ConvV4Params p, hipStream_t stream) {
   p.tilesZ = (p.D + TL::TZ - 1) / TL::TZ; p.tilesY = (p.H + TL::TY - 1) / TL::TY; p.tilesX = (p.W + TL::TX - 1) / TL::TX;
   const int ncob = p.Cout / 32;
   // one workgroup per CU: 8 XCDs x (bz x by x bx) brick slots per Cout tile
-  if (ND == 3) {
-    if (ncob == 1)      { p.bz = 2; p.by = 4; p.bx = 4; }
-    else if (ncob == 2) { p.bz = 2; p.by = 4; p.bx = 2; }
-    else if (ncob <= 4) { p.bz = 2; p.by = 2; p.bx = 2; }
-    else                { p.bz = 1; p.by = 2; p.bx = 2; }
-  } else {
-    p.bz = 1;
-    if (ncob == 1)      { p.by = 4; p.bx = 8; }
-    else if (ncob == 2) { p.by = 4; p.bx = 4; }
-    else if (ncob <= 4) { p.by = 2; p.bx = 4; }
-    else                { p.by = 2; p.bx = 2; }
-  }
+  iunet_brick_shape(ND, ncob, p.tilesZ, p.tilesY, p.tilesX, &p.bz, &p.by, &p.bx);
   p.nbz = (p.tilesZ + p.bz - 1) / p.bz; p.nby = (p.tilesY + p.by - 1) / p.by; p.nbx = (p.tilesX + p.bx - 1) / p.bx;
   const int gx = 8 * p.bz * p.by * p.bx;
+  if (p.stats != nullptr) {
+    // the caller reduces iunet_conv3_v4_stats_parts rows (the brick table's slot count); a brick clamped to a small tile grid
+    // launches fewer workgroups: the rows nobody writes are zeroed
+    const int rows = iunet_conv3_v4_stats_parts(ND, p.Cout);
+    if (gx < rows)
+      IUNET_CHECK_HIP(hipMemsetAsync(p.stats + (long long)gx * p.Cout * 2, 0, (size_t)(rows - gx) * p.Cout * 2 * sizeof(float), stream));
+  }
   hipLaunchKernelGGL((conv3_v4_kernel<T, ND, WS, SMALL>), dim3(gx, ncob), dim3(TL::NCW * 64 + (WS ? 256 : 512)), lds, stream, p);
   IUNET_CHECK_HIP(hipGetLastError());
   return IUNET_OK;

@@ -48,7 +48,7 @@ _SIGS = {
     # ---- fp8 matrix cores (config C5)
     'iunet_f8_pack_conv3': [c_void_p] * 5 + [c_float, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     'iunet_conv3_f8_fwd': [c_int, c_int, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_void_p, c_void_p,
-                           c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+                           c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     'iunet_gather_block': [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     'iunet_blend_accumulate': [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_void_p],
@@ -108,7 +108,7 @@ _SIGS = {
 # functions that return a size / count instead of a status
 _INT_RETURN = ['iunet_pack_desc_bytes', 'iunet_augment_desc_bytes']
 _INT_RETURN_ARGS = {'iunet_zoom_nearest_len': [c_int, ctypes.c_double]}
-_LL_RETURN = {'iunet_conv3_wgrad_slab_floats': [c_int] * 7, 'iunet_f32_pack_conv_elems': [c_int] * 3, 'iunet_f8_pack_conv3_bytes': [c_int] * 3, 'iunet_pack_conv3_elems': [c_int] * 4,
+_LL_RETURN = {'iunet_conv3_wgrad_slab_floats': [c_int] * 7, 'iunet_f32_pack_conv_elems': [c_int] * 3, 'iunet_f8_pack_conv3_bytes': [c_int] * 3, 'iunet_conv3_f8_workspace_elems': [c_int] * 7, 'iunet_pack_conv3_elems': [c_int] * 4,
               'iunet_pack_first_conv_elems': [c_int] * 3, 'iunet_slice_scatter_workspace_bytes': [c_int]}
 
 

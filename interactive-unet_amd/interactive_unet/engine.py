@@ -54,6 +54,7 @@ class Engine:
         self.npos = 2 ** dim
         self.packed = None
         self._ws_cache = {}
+        self._f8_ws = None
         nv.lib()   # fail loudly now if the HIP library is missing
 
     # ------------------------------------------------------------------ weights
@@ -181,8 +182,11 @@ class Engine:
     def _conv3(self, x_ptr, x_ss, y_ptr, y_ss, name, N, dims, ci, co, s):
         pk, bias = self.packed[name]
         if isinstance(pk, F8Conv):
+            need = nv.lib().iunet_conv3_f8_workspace_elems(self.dim, N, dims[0], dims[1], dims[2], ci, co)      # split-K scratch
+            if need > (self._f8_ws.numel() if self._f8_ws is not None else 0):
+                self._f8_ws = torch.empty(need, dtype=torch.float32, device=self.device)
             nv.call('iunet_conv3_f8_fwd', self.dt, self.dim, x_ptr, x_ss, y_ptr, y_ss, nv.ptr(pk.bytes), nv.ptr(pk.scale),
-                    nv.ptr(bias), N, dims[0], dims[1], dims[2], ci, co, 2, s)
+                    nv.ptr(bias), N, dims[0], dims[1], dims[2], ci, co, 2, nv.ptr(self._f8_ws) if need else None, s)
             return
         lay, wpk = pk.pick(self.dim, N, dims[0], dims[1], dims[2])
         nv.call('iunet_conv3_fwd', self.dt, self.dim, x_ptr, x_ss, y_ptr, y_ss, nv.ptr(wpk), nv.ptr(bias), None,

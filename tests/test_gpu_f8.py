@@ -22,7 +22,7 @@ from tests.test_gpu_kernels import blocked, unblocked, nv      # noqa: F401  (fi
 DT = {'f16': torch.float16, 'bf16': torch.bfloat16}
 
 
-def run_conv_f8(nv, x, w, dtype, nd, bn=None, epi=0, bias=None):
+def run_conv_f8(nv, x, w, dtype, nd, bn=None, epi=0, bias=None, splitk=True):
     """x [N,Cin,*sp] fp32 cpu (values exact in `dtype`), w [Cout,Cin,k..] -> (y fp32 cpu, bytes uint8, scale fp32, bias)."""
     dev = 'cuda'
     N, Cin = x.shape[:2]
@@ -43,8 +43,10 @@ def run_conv_f8(nv, x, w, dtype, nd, bn=None, epi=0, bias=None):
     bd = b_out if bn is not None else (None if bias is None else bias.to(dev))
     xb = blocked(x, dtype).to(dev)
     y = torch.full((N * Cout * vox,), float('nan'), dtype=dtype, device=dev)
+    need = nv.lib().iunet_conv3_f8_workspace_elems(nd, N, D, H, W, Cin, Cout) if splitk else 0
+    ws = torch.full((need,), float('nan'), device=dev) if need else None
     nv.call('iunet_conv3_f8_fwd', nv.DTYPE_CODE[dtype], nd, nv.ptr(xb), Cin * vox, nv.ptr(y), Cout * vox, nv.ptr(dst), nv.ptr(sc),
-            nv.ptr(bd), N, D, H, W, Cin, Cout, epi, nv.stream())
+            nv.ptr(bd), N, D, H, W, Cin, Cout, epi, nv.ptr(ws), nv.stream())
     torch.cuda.synchronize()
     return unblocked(y.float().cpu(), N, Cout, sp), dst.cpu(), sc.cpu(), (None if bd is None else bd.cpu())
 
@@ -95,6 +97,7 @@ def test_packed_bytes_are_the_oracle_quantisation(nv, nd, cout, cin):
 @pytest.mark.parametrize('nd,shape,cin,cout', [
     (3, (4, 8, 16), 32, 32), (3, (6, 12, 20), 64, 64), (3, (9, 7, 17), 128, 32), (3, (8, 8, 16), 256, 64),   # 256: streamed weights
     (3, (16, 16, 16), 256, 256), (3, (2, 8, 16), 256, 32),                                                    # few tiles: half-size tile
+    (3, (8, 8, 8), 512, 128), (3, (4, 8, 16), 1024, 64), (3, (8, 8, 16), 256, 32),                            # split along Cin
     (2, (16, 32), 32, 32), (2, (20, 70), 64, 32), (2, (48, 40), 256, 64), (2, (16, 32), 512, 32)])
 def test_conv3_f8_exact_integers(nv, nd, shape, cin, cout, dtype):
     g = torch.Generator().manual_seed(1)
@@ -109,6 +112,10 @@ def test_conv3_f8_exact_integers(nv, nd, shape, cin, cout, dtype):
     assert torch.isfinite(got).all()
     # every product and every fp32 sum is exact (|sums| < 2^24); the one rounding is the store to 16 bits, round to nearest even
     assert torch.equal(got, want.to(DT[dtype]).float()), f'{(got != want.to(DT[dtype]).float()).sum().item()} of {got.numel()} differ'
+    D, H, W = shape if nd == 3 else (1,) + shape
+    if nv.lib().iunet_conv3_f8_workspace_elems(nd, N, D, H, W, cin, cout):      # a split-K shape: the unsplit launch gives the same bits
+        got1, _, _, _ = run_conv_f8(nv, x, w, DT[dtype], nd, epi=2, bias=bias, splitk=False)
+        assert torch.equal(got1, got)
 
 
 @pytest.mark.parametrize('nd', [2, 3])

@@ -22,11 +22,17 @@ def main():
     ap.add_argument('--only', default='', help='e.g. 0:64:32 = level:cin:cout')
     ap.add_argument('--iters', type=int, default=10)
     ap.add_argument('--layout', type=int, default=-1, help='-1 = library policy, 0 / 1 = force a kernel structure')
+    ap.add_argument('--base', type=int, default=32, help='channels at level 0 (64: the C5 network)')
+    ap.add_argument('--levels', type=int, default=4)
+    ap.add_argument('--f8', type=int, default=0, help='1: also time the fp8 matrix-core kernel (conv3_f8.hip) on each shape')
     a = ap.parse_args()
     T = torch.bfloat16 if a.dtype == 'bf16' else torch.float16
     dt = nv.DTYPE_CODE[T]; nd = a.dim; taps = 3 ** nd
-    shapes = [(0, 32, 32), (0, 64, 32), (1, 32, 64), (1, 64, 64), (1, 128, 64), (2, 64, 128), (2, 128, 128), (2, 256, 128),
-              (3, 128, 256), (3, 256, 256)]
+    b = a.base
+    shapes = [(0, b, b), (0, 2 * b, b)]
+    for l in range(1, a.levels):
+        c = b << l
+        shapes += [(l, c // 2, c), (l, c, c)] + ([(l, 2 * c, c)] if l < a.levels - 1 else [])
     if a.only:
         l, ci, co = [int(v) for v in a.only.split(':')]
         shapes = [(l, ci, co)]
@@ -56,6 +62,16 @@ def main():
                                 a.n, D, S, S, cin, cout, nv.stream())
             ms2 = timeit(g, iters=a.iters)
             line += f' | wgrad {ms2*1e3:8.1f} us {fl/ms2/1e9:7.1f} TF/s'
+        if a.f8:
+            wb = torch.zeros(nv.lib().iunet_f8_pack_conv3_bytes(cout, cin, taps), dtype=torch.uint8, device='cuda')
+            sc = torch.empty(cout, device='cuda')
+            nv.call('iunet_f8_pack_conv3', nv.ptr(w), None, None, None, None, 1e-5, nv.ptr(wb), nv.ptr(sc), None, cout, cin, taps, nv.stream())
+            need = nv.lib().iunet_conv3_f8_workspace_elems(nd, a.n, D, S, S, cin, cout)
+            wk = torch.empty(need, device='cuda') if need else None
+            h = lambda: nv.call('iunet_conv3_f8_fwd', dt, nd, nv.ptr(x), cin * vox, nv.ptr(y), cout * vox, nv.ptr(wb), nv.ptr(sc),
+                                nv.ptr(bias), a.n, D, S, S, cin, cout, 2, nv.ptr(wk), nv.stream())
+            ms3 = timeit(h, iters=a.iters)
+            line += f' | fp8 {ms3*1e3:8.1f} us {fl/ms3/1e9:7.1f} TF/s ({ms/ms3:.2f}x){" split-K" if need else ""}'
         print(line, flush=True)
     print(f'sum fwd: {tot_t*1e3:.1f} us, {tot_f/tot_t/1e9:.1f} TF/s')
 
