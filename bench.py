@@ -154,15 +154,22 @@ def conv_roofline(nv, cfg, workload, dtype, iters=50):
     kname = 'conv3_f8_kernel' if cfg['wq'] else {0: 'conv3_mfma_kernel', 1: 'conv3_v2_kernel', 2: 'conv3_v4_kernel'}[lay]
     tname = 'bf16' if dtype == torch.bfloat16 else 'f16'
     where = f'{N} x {"x".join(str(s) for s in shape)}'
-    out = {'bound': 'mfma', 'kernel': f'{kname}<{tname},{dim}> (dec0.conv1 {cin}->{cout} @ {where})',
-           'achieved': round(tf(ms), 2), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(tf(ms) / MFMA_PEAK_TFLOPS, 4),
-           'ms_per_launch': round(ms, 4), 'launches': iters, 'flops_per_launch': flops,
-           'burst_ms_first8': round(burst, 4), 'burst_frac': round(tf(burst) / MFMA_PEAK_TFLOPS, 4),
-           'settled_ms_last20': round(settled, 4), 'settled_frac': round(tf(settled) / MFMA_PEAK_TFLOPS, 4),
-           'traffic': pmc_traffic(workload)}
     alg_bytes = (cin + cout) * 2.0 * vox * N
-    out['algorithmic_bytes_per_launch'] = alg_bytes
-    out['hbm_gbs_algorithmic'] = round(alg_bytes / (ms * 1e-3) / 1e9, 1)
+    gbs = lambda t: alg_bytes / (t * 1e-3) / 1e9
+    # which roof bounds this layer: arithmetic intensity (activations once in, once out) against the ridge of the two peaks
+    hbm_bound = flops / alg_bytes < MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
+    out = {'bound': 'hbm' if hbm_bound else 'mfma', 'kernel': f'{kname}<{tname},{dim}> (dec0.conv1 {cin}->{cout} @ {where})'}
+    if hbm_bound:
+        out.update({'achieved': round(gbs(ms), 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(gbs(ms) / HBM_PEAK_GBS, 4),
+                    'burst_frac': round(gbs(burst) / HBM_PEAK_GBS, 4), 'settled_frac': round(gbs(settled) / HBM_PEAK_GBS, 4),
+                    'tflops': round(tf(ms), 2), 'mfma_frac': round(tf(ms) / MFMA_PEAK_TFLOPS, 4)})
+    else:
+        out.update({'achieved': round(tf(ms), 2), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(tf(ms) / MFMA_PEAK_TFLOPS, 4),
+                    'burst_frac': round(tf(burst) / MFMA_PEAK_TFLOPS, 4), 'settled_frac': round(tf(settled) / MFMA_PEAK_TFLOPS, 4),
+                    'hbm_gbs_algorithmic': round(gbs(ms), 1)})
+    out.update({'ms_per_launch': round(ms, 4), 'launches': iters, 'flops_per_launch': flops,
+                'algorithmic_bytes_per_launch': alg_bytes, 'flop_per_byte': round(flops / alg_bytes, 1),
+                'burst_ms_first8': round(burst, 4), 'settled_ms_last20': round(settled, 4), 'traffic': pmc_traffic(workload)})
     return out
 
 
@@ -201,7 +208,9 @@ def cpu_baseline(cfg, model=None, chunk_u8=None):
     cores = min(16, len(os.sched_getaffinity(0)))        # a 1-GPU box gets a 16-core share
     torch.set_num_threads(cores)
     dim, levels, base, ncls = cfg['dim'], cfg['levels'], cfg['base'], cfg['ncls']
-    shp = (64, 64, 64) if dim == 3 and base == 32 else ((32, 32, 32) if dim == 3 else (256, 256))
+    # 2-D: the whole C1 case of BASELINE.json configs[0] (one 512 x 512 slice: training step + validation forward = the
+    # reference's "one epoch" on its CPU-runnable configuration); 3-D: a reduced tile
+    shp = (64, 64, 64) if dim == 3 and base == 32 else ((32, 32, 32) if dim == 3 else (512, 512))
     frac = float(np.prod(shp)) / float(np.prod(cfg['tile']))
     p = unet_ref.init_params(dim=dim, levels=levels, base=base, ncls=ncls, seed=0)
     pr = {k: v.clone().requires_grad_(not unet_ref.is_buffer(k)) for k, v in p.items()}

@@ -87,11 +87,12 @@ __global__ __launch_bounds__((F8Tile<ND, SMALL>::NCW * 64 + (WS ? 256 : 512)), 1
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int cob = blockIdx.y;
-  // blocks b and b + 8 share an XCD whatever blockIdx.y / .z are (the grid's x extent is a multiple of 8), so the brick range
-  // of a workgroup is rotated by its Cout tile and split: small grids (fewer bricks than XCDs) then spread over all XCDs
-  const int xcd = (blockIdx.x + blockIdx.y + 3 * blockIdx.z) & 7, slot = blockIdx.x >> 3;
-  const int sx = slot % p.bx, sy = (slot / p.bx) % p.by, sz = slot / (p.bx * p.by);
+  // blocks b and b + 8 share an XCD whatever blockIdx.y / .z are (the grid's x extent is a multiple of 8), so on a grid with
+  // fewer bricks than XCDs the brick range of a workgroup is rotated by its Cout tile and split, and the launch spreads over
+  // all XCDs; larger grids keep the Cout tiles of one brick on one XCD (they read the same input: the second one hits in L2)
   const int nbricks = p.N * p.nbz * p.nby * p.nbx;
+  const int xcd = (blockIdx.x + (nbricks < 8 ? blockIdx.y + 3 * blockIdx.z : 0)) & 7, slot = blockIdx.x >> 3;
+  const int sx = slot % p.bx, sy = (slot / p.bx) % p.by, sz = slot / (p.bx * p.by);
   const int b_begin = (int)((long long)xcd * nbricks / 8), b_end = (int)((long long)(xcd + 1) * nbricks / 8);
   // split-K: this workgroup's share of the input channels (chunks chunk0 .. chunk0 + nchunk - 1 of every tile)
   const int nchunk_all = p.Cin / (16 * S16);

@@ -88,11 +88,12 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + (WS ? 256 : 512)), 1
   // shares with its neighbours are fetched from HBM once and then hit in that L2 (contiguous per-workgroup runs had
   // every concurrent tile 32 tiles apart: the 2.1x halo re-fetch all went to HBM / Infinity Cache at ~20 GB/s per CU).
   // Slots of a brick that stick out of the tile grid are processed fully masked (speed only, never correctness).
-  // blocks b and b + 8 share an XCD whatever blockIdx.y is (the grid's x extent is a multiple of 8): the brick range of a
-  // workgroup is rotated by its Cout tile, so a grid with fewer bricks than XCDs still spreads over all of them
-  const int xcd = (blockIdx.x + blockIdx.y) & 7, slot = blockIdx.x >> 3;
-  const int sx = slot % p.bx, sy = (slot / p.bx) % p.by, sz = slot / (p.bx * p.by);
+  // blocks b and b + 8 share an XCD whatever blockIdx.y is (the grid's x extent is a multiple of 8): on a grid with fewer
+  // bricks than XCDs the brick range of a workgroup is rotated by its Cout tile, so the launch still spreads over all XCDs;
+  // larger grids keep the Cout tiles of one brick on one XCD (they read the same input: the second one hits in L2)
   const int nbricks = p.N * p.nbz * p.nby * p.nbx;
+  const int xcd = (blockIdx.x + (nbricks < 8 ? blockIdx.y : 0)) & 7, slot = blockIdx.x >> 3;
+  const int sx = slot % p.bx, sy = (slot / p.bx) % p.by, sz = slot / (p.bx * p.by);
   const int b_begin = (int)((long long)xcd * nbricks / 8), b_end = (int)((long long)(xcd + 1) * nbricks / 8);
   const int nchunk = p.Cin / (16 * S16);               // steps per tile
   const int nsteps = (b_end - b_begin) * nchunk;

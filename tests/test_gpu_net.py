@@ -46,10 +46,14 @@ def _stub(kind):
 @pytest.mark.parametrize('dim,shape,dtype', [(2, (64, 96), torch.float16), (2, (128, 128), torch.bfloat16),
                                              (3, (16, 32, 48), torch.float16), (3, (32, 32, 32), torch.bfloat16)])
 def test_forward_logits_vs_oracle(dim, shape, dtype):
-    """Logits within 1e-3 (fp16) of the oracle evaluated with the same rounding points
-    (act_dtype storage, fp32 accumulate); argmax class map integer-exact wherever the
-    oracle's top-2 logit margin exceeds twice that tolerance.  The deviation from the
-    pure-fp32 oracle is printed (it is bounded by the storage precision, not by the kernel)."""
+    """16-bit modes at small shapes against TWO oracles (the north-star gate -- 1e-3 absolute against the fp32 CPU path --
+    is tests/test_gpu_parity.py, on the fp32 parity mode):
+    (a) the oracle evaluated with the SAME rounding points (act_dtype storage, fp32 accumulate): max |dlogit| <=
+        3e-3 x scale (fp16) / 2.4e-2 x scale (bf16), rms <= 6e-4 x scale (x 8 for bf16), scale = max |logit| -- this pins
+        the kernels (fragment maps, epilogues, folds), not the storage precision;
+    (b) the pure-fp32 oracle: asserted bound max |dlogit| <= 4e-3 x scale (fp16) / 3e-2 x scale (bf16), the measured
+        deviation of 16-bit activation storage through 18 convs with 2x headroom (assert it, do not just print it).
+    The class map is integer-exact wherever the same-rounding oracle's top-2 margin exceeds twice tolerance (a)."""
     e, p = _engine(dim, ncls=3, dtype=dtype, seed=1)
     N = 2
     img = np.stack([_smooth(shape, 10 + i) for i in range(N)])[:, None]        # N,1,*shape uint8
@@ -82,6 +86,7 @@ def test_forward_logits_vs_oracle(dim, shape, dtype):
     print(f'   rms = {rms:.2e}, tol(max) = {tol:.2e}')
     assert err <= tol
     assert rms <= 6e-4 * ulp * scale
+    assert err32 <= (4e-3 if dtype == torch.float16 else 3e-2) * scale, (err32, scale)      # (b): storage-precision bound vs fp32
     top2 = torch.topk(ref, 2, dim=1).values
     margin = (top2[:, 0] - top2[:, 1]).reshape(N, vox)
     sure = margin > 2 * tol

@@ -1,0 +1,45 @@
+#!/bin/bash
+# Collect the round's profile artefacts on the GPU box (run from the repo root through gpurun); the summaries land in
+# gpurun_out/profiles_$RND/ and are copied into profiles/ (tracked) afterwards.   bash tools/collect_profiles.sh [r02]
+RND=${1:-r02}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/profiles_$RND
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+stats() {   # stats <name> <program args...>: rocprofv3 --kernel-trace --stats, keep the kernel_stats.csv
+  local name=$1; shift
+  rm -rf $OUT/tmp_$name
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/tmp_$name -- "$@" > $OUT/${name}.log 2>&1
+  cp $(ls $OUT/tmp_$name/*/*_kernel_stats.csv | head -1) $OUT/${RND}_${name}_kernel_stats.csv
+  cp $(ls $OUT/tmp_$name/*/*_kernel_trace.csv | head -1) $OUT/${name}_kernel_trace.csv
+  rm -rf $OUT/tmp_$name
+  echo "done stats $name"
+}
+pmc() {     # pmc <name> <counter> <program args...>
+  local name=$1 ctr=$2; shift 2
+  rm -rf $OUT/tmp_pmc
+  rocprofv3 --pmc $ctr --output-format csv -d $OUT/tmp_pmc -- "$@" > /dev/null 2>&1
+  cp $(ls $OUT/tmp_pmc/*/*_counter_collection.csv | head -1) $OUT/${RND}_pmc_${ctr}_${name}.csv
+  rm -rf $OUT/tmp_pmc
+  echo "done pmc $name $ctr"
+}
+# 1. plain bench lines (unprofiled) of every workload
+python3 $R/bench.py --steps 20 --warmup 5 > $OUT/${RND}_bench_c3.json.log 2>/dev/null; echo "done bench c3"
+python3 $R/bench.py --workload c4 --steps 3 --warmup 1 > $OUT/${RND}_bench_c4.json.log 2>/dev/null; echo "done bench c4"
+python3 $R/bench.py --workload c5 --steps 10 --warmup 3 > $OUT/${RND}_bench_c5.json.log 2>/dev/null; echo "done bench c5"
+python3 $R/bench.py --workload c2 --steps 20 --warmup 5 > $OUT/${RND}_bench_c2.json.log 2>/dev/null; echo "done bench c2"
+# 2. rocprofv3 summaries of the same commands (short runs)
+stats bench_c3 python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --c4-reps 0
+stats bench_c5 python3 $R/bench.py --workload c5 --steps 3 --warmup 1 --no-cpu-baseline
+stats bench_c2 python3 $R/bench.py --workload c2 --steps 5 --warmup 2 --no-cpu-baseline
+# 3. the roofline kernels alone: 3 warm-up + 50 launches, the sequence bench.py times
+stats roofline_c3 python3 $R/tools/bench_conv.py --only 0:64:32 --wgrad 0 --iters 50
+stats roofline_c5 python3 $R/tools/bench_conv.py --only 0:128:64 --base 64 --levels 5 --wgrad 0 --f8 1 --iters 50
+stats roofline_c2 python3 $R/tools/bench_conv.py --only 0:64:32 --dim 2 --size 512 --n 8 --dtype f16 --wgrad 0 --iters 50
+# 4. HBM traffic of the roofline kernels (separate passes, as the guide prescribes)
+for c in FETCH_SIZE WRITE_SIZE; do
+  pmc c3 $c python3 $R/tools/bench_conv.py --only 0:64:32 --wgrad 0 --iters 2
+  pmc c5 $c python3 $R/tools/bench_conv.py --only 0:128:64 --base 64 --levels 5 --wgrad 0 --f8 1 --iters 2
+  pmc c2 $c python3 $R/tools/bench_conv.py --only 0:64:32 --dim 2 --size 512 --n 8 --dtype f16 --wgrad 0 --iters 2
+done
+ls -la $OUT
