@@ -294,11 +294,19 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', 0))
     if world != args.gpus:
         sys.exit(f'bench.py: --gpus {args.gpus} but the launcher started {world} ranks')
+    # rehearsal switches for a box with ONE GPU (the builder's): IUNET_BENCH_BACKEND=gloo IUNET_BENCH_SHARE_GPU=1 run the N ranks of
+    # the whole distributed path on cuda:0 over gloo (which moves CUDA tensors through the host); never used by the driver
+    backend = os.environ.get('IUNET_BENCH_BACKEND', 'nccl')
+    if os.environ.get('IUNET_BENCH_SHARE_GPU'):
+        local = 0
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(backend)
     group = dist.group.WORLD if dist else None
 
     from interactive_unet import _native as nv
