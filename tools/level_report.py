@@ -25,7 +25,7 @@ for f in sorted(glob.glob(os.path.join(L, 'time_*.txt'))):
     util = busy / (gui / 8 * 1024) if busy and gui else None       # 1024 SIMDs, GUI_ACTIVE summed over 8 XCDs
     nd, n = int(nd), int(n)
     vox = int(S) ** nd * n
-    alg = (int(cin) + int(cout)) * 2 * vox
+    alg = (int(cin) + int(cout)) * 2 * vox + int(cin) * int(cout) * 3 ** nd * 2      # activations once in, once out + the filter once
     traffic = (2 * fetch + write) * 1024 if fetch is not None and write is not None else None
     head = (nd, n)
     rows.append((lvl, cin, cout, S, lay, float(us), float(tf), util, alg, traffic, nd))
@@ -35,7 +35,8 @@ with open(out, 'w') as o:
     o.write(f'# 3^{nd} conv forward per resolution level ({n} x level-0 tile per launch) -- rocprofv3 PMC, MI355X\n\n')
     o.write('time / TFLOP/s: HIP events over 30 back-to-back launches (tools/bench_conv.py); MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / '
             '(GRBM_GUI_ACTIVE / 8 x 1024 SIMDs); HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE (gfx950 FETCH_SIZE correction), separate '
-            'passes; % of peak vs 2.5 PFLOP/s dense 16-bit MFMA and 8 TB/s.  Produced by tools/level_report.sh + level_report.py.\n\n')
+            'passes; algorithmic MB = activations once in + once out + the filter once; % of peak vs 2.5 PFLOP/s dense 16-bit MFMA and 8 TB/s.  '
+            'Produced by tools/level_report.sh + level_report.py.\n\n')
     o.write('| level | layer | kernel layout | time (us) | TFLOP/s | % MFMA peak | MFMA pipe busy | algorithmic MB | HBM MB (PMC) | traffic / algorithmic | HBM GB/s | % HBM peak |\n|---|---|---|---|---|---|---|---|---|---|---|---|\n')
     for lvl, cin, cout, S, lay, us, tf, util, alg, traffic, nd in rows:
         gbs = traffic / (us * 1e-6) / 1e9 if traffic else None
