@@ -222,6 +222,17 @@ int iunet_bn_relu_bwd(int dtype, const void* dz, long long dz_ss, const void* z,
                       long long y_ss, void* dy, long long dy_ss, const void* mean, const void* invstd, const void* gamma,
                       const void* scale, const void* shift, void* dgamma, void* dbeta, void* slab, void* coef, int C, int N,
                       long long vox, void* stream);
+/* GroupNorm + ReLU (north_star "GroupNorm/BN"; the GroupNorm(8) variant of SURVEY 8d's canonical stage): statistics per
+ * (sample, group), identical at training and inference -- nothing folds into the conv.  z = relu(group_norm(y)); slab:
+ * iunet_gn_num_parts(N, vox) * C * 2 floats of scratch; scale / shift / mean / invstd: fp32 [N][C], written by the forward
+ * and read by the backward; coef: N * C * 3 floats of scratch; C <= 1024 in the backward. */
+int iunet_gn_num_parts(int N, long long vox);
+int iunet_gn_relu_fwd(int dtype, const void* y, long long y_ss, void* z, long long z_ss, const void* gamma, const void* beta,
+                      int groups, float eps, void* slab, void* scale, void* shift, void* mean, void* invstd, int C, int N,
+                      long long vox, void* stream);
+int iunet_gn_relu_bwd(int dtype, const void* dz, long long dz_ss, const void* y, long long y_ss, void* dy, long long dy_ss,
+                      const void* gamma, int groups, const void* scale, const void* shift, const void* mean, const void* invstd,
+                      void* dgamma, void* dbeta, void* slab, void* coef, int C, int N, long long vox, void* stream);
 /* iunet_maxpool_bwd (add_skip) + iunet_bn_relu_bwd of an encoder stage's second conv without materialising the gradient of
  * the stage output: dz = dskip + route(dpool), routed to the first maximum of each 2^d window of relu(bn(y)) (recomputed).
  * (Do, Ho, Wo) = pooled grid; dskip, y, dy on the 2x grid; slab as for iunet_bn_relu_bwd on the 2x grid. */

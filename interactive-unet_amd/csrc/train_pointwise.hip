@@ -334,6 +334,105 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
   }
 }
 
+// ------------------------------------------------------------------ GroupNorm (north_star "GroupNorm/BN"; SURVEY 8d: GroupNorm(8) variant)
+// Statistics are per (sample, group) -- the same at training and at inference, nothing to fold.  Everything per-channel of
+// the BatchNorm kernels above becomes per (sample, channel): the passes over the tensors are the BatchNorm ones launched
+// per sample with that sample's rows of scale / shift / mean / invstd / coef; only the small finalize steps are new.
+// pass 1 of the forward: per-(sample, channel) sum and sum of squares of the raw conv output; grid (chunks, planes, N);
+// slab [(n * chunks + chunk)][C][2]
+template <typename T>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ y, long long y_ss, int C, long long vox, int per_block,
+                                                       float* __restrict__ slab) {
+  const int pl = blockIdx.y, n = blockIdx.z;
+  const long long v0 = (long long)blockIdx.x * per_block, v1 = min(v0 + per_block, vox);
+  const long long po = (long long)pl * vox * 8;
+  float s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+#pragma unroll 4
+  for (long long v = v0 + threadIdx.x; v < v1; v += 256) {
+    const V8T<T> yy = *(const V8T<T>*)(y + n * y_ss + po + v * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float a = to_f32<T>(yy[j]); s1[j] += a; s2[j] = fmaf(a, a, s2[j]); }
+  }
+  __shared__ float red[4 * 16];
+  float vals[16];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { vals[2 * j] = s1[j]; vals[2 * j + 1] = s2[j]; }
+  block_reduce_store<16>(vals, red, slab + (((long long)n * gridDim.x + blockIdx.x) * C + pl * 8) * 2);
+}
+
+// one block per (group, sample): mean / biased variance over the group's channels x voxels (double, fixed order) ->
+// per-(sample, channel) scale = gamma * invstd, shift = beta - mean * scale, mean, invstd  ([N][C] each)
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ slab, int chunks, int C, int groups, double vox,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                         float* scale, float* shift, float* mean_o, float* invstd_o) {
+  const int g = blockIdx.x, n = blockIdx.y, cpg = C / groups;
+  double s = 0.0, s2 = 0.0;
+  for (int i = threadIdx.x; i < chunks * cpg; i += 64) {
+    const int ch = i / cpg, c = g * cpg + i % cpg;
+    const float* p = slab + (((long long)n * chunks + ch) * C + c) * 2;
+    s += (double)p[0]; s2 += (double)p[1];
+  }
+  __shared__ double red[2][64];
+  red[0][threadIdx.x] = s; red[1][threadIdx.x] = s2;
+  __syncthreads();
+  for (int o = 32; o > 0; o >>= 1) {
+    if (threadIdx.x < o) { red[0][threadIdx.x] += red[0][threadIdx.x + o]; red[1][threadIdx.x] += red[1][threadIdx.x + o]; }
+    __syncthreads();
+  }
+  const double cnt = vox * cpg, mean = red[0][0] / cnt;
+  double var = red[1][0] / cnt - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  for (int k = threadIdx.x; k < cpg; k += 64) {
+    const int c = g * cpg + k;
+    const float sc = gamma[c] * invstd;
+    scale[n * C + c] = sc;
+    shift[n * C + c] = beta[c] - (float)mean * sc;
+    mean_o[n * C + c] = (float)mean;
+    invstd_o[n * C + c] = invstd;
+  }
+}
+
+// backward finalize.  slab [(n * chunks + chunk)][C][2] = (s1, s2) of bn_bwd_reduce_kernel run per sample with that sample's
+// mean / invstd: s1 = sum dz', s2 = sum dz' * xhat (dz' = dz where relu passed).  One block of C threads (C <= 1024):
+//   dgamma[c] = sum_n s2, dbeta[c] = sum_n s1;
+//   per (n, group): m1 = sum_c gamma_c s1 / M, m2 = sum_c gamma_c s2 / M, M = channels per group x voxels;
+//   dy = invstd_g (gamma_c dz' - m1 - xhat m2) = a (dz' - c1 - xhat c2) with coef[n][c] = (gamma_c invstd, m1 / gamma_c, m2 / gamma_c)
+__global__ __launch_bounds__(1024) void gn_bwd_finalize_kernel(const float* __restrict__ slab, int chunks, int C, int groups, int N,
+                                                              double vox, const float* __restrict__ gamma,
+                                                              const float* __restrict__ invstd, float* dgamma, float* dbeta,
+                                                              float* coef) {
+  const int c = threadIdx.x, cpg = C / groups;
+  __shared__ double gs[2][1024];
+  double dg = 0.0, db = 0.0;
+  const float gam = c < C ? gamma[c] : 0.f;
+  for (int n = 0; n < N; ++n) {
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C)
+      for (int ch = 0; ch < chunks; ++ch) {
+        const float* p = slab + (((long long)n * chunks + ch) * C + c) * 2;
+        s1 += (double)p[0]; s2 += (double)p[1];
+      }
+    db += s1; dg += s2;
+    __syncthreads();
+    gs[0][c] = (double)gam * s1; gs[1][c] = (double)gam * s2;
+    __syncthreads();
+    if (c < C) {
+      const int g0 = (c / cpg) * cpg;
+      double m1 = 0.0, m2 = 0.0;
+      for (int k = 0; k < cpg; ++k) { m1 += gs[0][g0 + k]; m2 += gs[1][g0 + k]; }
+      const double M = vox * cpg;
+      const float gsafe = gam != 0.f ? gam : 1e-20f;            // gamma = 0: the channel's own term vanishes with a = 0
+      coef[((long long)n * C + c) * 3 + 0] = gam * invstd[n * C + c];
+      coef[((long long)n * C + c) * 3 + 1] = (float)(m1 / M) / gsafe;
+      coef[((long long)n * C + c) * 3 + 2] = (float)(m2 / M) / gsafe;
+    }
+  }
+  if (c < C) { dgamma[c] = (float)dg; dbeta[c] = (float)db; }
+}
+
 // ------------------------------------------------------------------ max-pool backward (+ skip gradient)
 // dz[v] = (dskip ? dskip[v] : 0) + (v is the FIRST maximum of its window ? dpool : 0), in place on dskip.
 template <typename T, int ND>
@@ -747,6 +846,76 @@ int iunet_bn_relu_bwd(int dtype, const void* dz, long long dz_ss, const void* z,
   dim3 g2((unsigned)((vox + 511) / 512), C / 8, N);
   if (dtype == 0) hipLaunchKernelGGL(bn_bwd_apply_kernel<f16>, g2, dim3(256), 0, (hipStream_t)stream, (const f16*)dz, dz_ss, (const f16*)z, z_ss, (const f16*)y, y_ss, (f16*)dy, dy_ss, (const float*)mean, (const float*)invstd, (const float*)coef, (const float*)scale, (const float*)shift, C / 8, vox);
   else hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16>, g2, dim3(256), 0, (hipStream_t)stream, (const bf16*)dz, dz_ss, (const bf16*)z, z_ss, (const bf16*)y, y_ss, (bf16*)dy, dy_ss, (const float*)mean, (const float*)invstd, (const float*)coef, (const float*)scale, (const float*)shift, C / 8, vox);
+  IUNET_CHECK_HIP(hipGetLastError());
+  return IUNET_OK;
+}
+
+/* ---- GroupNorm + ReLU (north_star "GroupNorm/BN") ------------------------------------------------------- */
+int iunet_gn_num_parts(int N, long long vox) { return iunet_bn_bwd_num_parts(N, vox); }
+
+// z = relu(group_norm(y, groups, gamma, beta, eps)): statistics pass + finalize + one normalise pass per sample.
+// slab: iunet_gn_num_parts(N, vox) * C * 2 floats; scale / shift / mean / invstd: fp32 [N][C] outputs (the backward reads them).
+int iunet_gn_relu_fwd(int dtype, const void* y, long long y_ss, void* z, long long z_ss, const void* gamma, const void* beta,
+                      int groups, float eps, void* slab, void* scale, void* shift, void* mean, void* invstd, int C, int N,
+                      long long vox, void* stream) {
+  DT_OK(dtype);
+  IUNET_REQUIRE(y && z && gamma && beta && slab && scale && shift && mean && invstd, "gn_relu_fwd: null pointer");
+  IUNET_REQUIRE(C > 0 && C % 8 == 0 && N > 0 && vox > 0, "gn_relu_fwd: C %d (multiple of 8), N %d, %lld voxels", C, N, vox);
+  IUNET_REQUIRE(groups > 0 && C % groups == 0, "gn_relu_fwd: %d channels do not split into %d groups", C, groups);
+  const int per_block = BN_BWD_PER_BLOCK;
+  const int chunks = (int)((vox + per_block - 1) / per_block);
+  dim3 g1(chunks, C / 8, N);
+  if (dtype == 0) hipLaunchKernelGGL(gn_stats_kernel<f16>, g1, dim3(256), 0, (hipStream_t)stream, (const f16*)y, y_ss, C, vox, per_block, (float*)slab);
+  else hipLaunchKernelGGL(gn_stats_kernel<bf16>, g1, dim3(256), 0, (hipStream_t)stream, (const bf16*)y, y_ss, C, vox, per_block, (float*)slab);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, N), dim3(64), 0, (hipStream_t)stream, (const float*)slab, chunks, C, groups,
+                     (double)vox, (const float*)gamma, (const float*)beta, eps, (float*)scale, (float*)shift, (float*)mean, (float*)invstd);
+  const int es = 2;
+  dim3 g2((unsigned)((vox + 511) / 512), C / 8, 1);
+  for (int n = 0; n < N; ++n) {
+    const char* yn = (const char*)y + (long long)n * y_ss * es;
+    char* zn = (char*)z + (long long)n * z_ss * es;
+    const float* sc = (const float*)scale + (long long)n * C;
+    const float* sh = (const float*)shift + (long long)n * C;
+    if (dtype == 0) hipLaunchKernelGGL(bn_relu_fwd_kernel<f16>, g2, dim3(256), 0, (hipStream_t)stream, (const f16*)yn, y_ss, (f16*)zn, z_ss, sc, sh, C / 8, vox);
+    else hipLaunchKernelGGL(bn_relu_fwd_kernel<bf16>, g2, dim3(256), 0, (hipStream_t)stream, (const bf16*)yn, y_ss, (bf16*)zn, z_ss, sc, sh, C / 8, vox);
+  }
+  IUNET_CHECK_HIP(hipGetLastError());
+  return IUNET_OK;
+}
+
+// backward of z = relu(group_norm(y)): dy, dgamma, dbeta from dz and y; scale / shift / mean / invstd [N][C] from the forward;
+// slab as above, coef: N * C * 3 floats of scratch.  C <= 1024.
+int iunet_gn_relu_bwd(int dtype, const void* dz, long long dz_ss, const void* y, long long y_ss, void* dy, long long dy_ss,
+                      const void* gamma, int groups, const void* scale, const void* shift, const void* mean, const void* invstd,
+                      void* dgamma, void* dbeta, void* slab, void* coef, int C, int N, long long vox, void* stream) {
+  DT_OK(dtype);
+  IUNET_REQUIRE(dz && y && dy && gamma && scale && shift && mean && invstd && dgamma && dbeta && slab && coef, "gn_relu_bwd: null pointer");
+  IUNET_REQUIRE(C > 0 && C % 8 == 0 && C <= 1024 && N > 0 && vox > 0, "gn_relu_bwd: C %d (multiple of 8, <= 1024), N %d, %lld voxels", C, N, vox);
+  IUNET_REQUIRE(groups > 0 && C % groups == 0, "gn_relu_bwd: %d channels do not split into %d groups", C, groups);
+  const int per_block = BN_BWD_PER_BLOCK, es = 2;
+  const int chunks = (int)((vox + per_block - 1) / per_block);
+  dim3 g1(chunks, C / 8, 1), g2((unsigned)((vox + 511) / 512), C / 8, 1);
+  for (int n = 0; n < N; ++n) {
+    const char* dzn = (const char*)dz + (long long)n * dz_ss * es;
+    const char* yn = (const char*)y + (long long)n * y_ss * es;
+    const float *mu = (const float*)mean + (long long)n * C, *is = (const float*)invstd + (long long)n * C;
+    const float *sc = (const float*)scale + (long long)n * C, *sh = (const float*)shift + (long long)n * C;
+    float* sl = (float*)slab + (long long)n * chunks * C * 2;
+    if (dtype == 0) hipLaunchKernelGGL(bn_bwd_reduce_kernel<f16>, g1, dim3(256), 0, (hipStream_t)stream, (const f16*)dzn, dz_ss, (const f16*)nullptr, 0LL, (const f16*)yn, y_ss, mu, is, sc, sh, C, vox, per_block, sl);
+    else hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16>, g1, dim3(256), 0, (hipStream_t)stream, (const bf16*)dzn, dz_ss, (const bf16*)nullptr, 0LL, (const bf16*)yn, y_ss, mu, is, sc, sh, C, vox, per_block, sl);
+  }
+  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const float*)slab, chunks, C, groups, N,
+                     (double)vox, (const float*)gamma, (const float*)invstd, (float*)dgamma, (float*)dbeta, (float*)coef);
+  for (int n = 0; n < N; ++n) {
+    const char* dzn = (const char*)dz + (long long)n * dz_ss * es;
+    const char* yn = (const char*)y + (long long)n * y_ss * es;
+    char* dyn = (char*)dy + (long long)n * dy_ss * es;
+    const float *mu = (const float*)mean + (long long)n * C, *is = (const float*)invstd + (long long)n * C;
+    const float *sc = (const float*)scale + (long long)n * C, *sh = (const float*)shift + (long long)n * C;
+    const float* cf = (const float*)coef + (long long)n * C * 3;
+    if (dtype == 0) hipLaunchKernelGGL(bn_bwd_apply_kernel<f16>, g2, dim3(256), 0, (hipStream_t)stream, (const f16*)dzn, dz_ss, (const f16*)nullptr, 0LL, (const f16*)yn, y_ss, (f16*)dyn, dy_ss, mu, is, cf, sc, sh, C / 8, vox);
+    else hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16>, g2, dim3(256), 0, (hipStream_t)stream, (const bf16*)dzn, dz_ss, (const bf16*)nullptr, 0LL, (const bf16*)yn, y_ss, (bf16*)dyn, dy_ss, mu, is, cf, sc, sh, C / 8, vox);
+  }
   IUNET_CHECK_HIP(hipGetLastError());
   return IUNET_OK;
 }

@@ -33,7 +33,7 @@ class F8Conv:
 
 class Engine:
     def __init__(self, dim=2, levels=4, base=32, cin=1, ncls=2, act_dtype=torch.float16, device='cuda',
-                 weight_dtype=None):
+                 weight_dtype=None, norm='batch', groups=8):
         if dim not in (2, 3):
             raise ValueError('dim must be 2 or 3')
         if base % 32 != 0:
@@ -47,6 +47,15 @@ class Engine:
         if weight_dtype not in (None, 'fp8_e4m3'):
             raise ValueError("weight_dtype must be None (= activation dtype) or 'fp8_e4m3'")
         self.weight_dtype = weight_dtype      # 'fp8_e4m3': inference weights on the OCP e4m3 grid (config C5)
+        if norm not in ('batch', 'group'):
+            raise ValueError("norm must be 'batch' or 'group'")
+        if norm == 'group' and weight_dtype:
+            raise NotImplementedError('the fp8 operator format folds the norm into the weights: BatchNorm only')
+        if norm == 'group' and base % groups:
+            raise ValueError(f'{groups} groups do not divide {base} channels')
+        # 'group': GroupNorm(groups) + ReLU after every stage conv instead of (folded) BatchNorm -- per-sample statistics, so the
+        # convs write their raw output and a statistics + normalise pass follows (iunet_gn_relu_fwd)
+        self.norm, self.groups = norm, groups
         self.dt = nv.DTYPE_CODE[act_dtype]
         self.device = torch.device(device)
         self.ch = [base * 2 ** l for l in range(levels)]
@@ -107,6 +116,16 @@ class Engine:
                 for j, (a, b) in enumerate(((ci, co), (co, co)), 1):
                     w = src[f'{prefix}.conv{j}.weight']
                     bn = [src[f'{prefix}.bn{j}.{k}'] for k in ('weight', 'bias', 'running_mean', 'running_var')]
+                    if self.norm == 'group':                 # nothing folds: raw operator, gamma / beta go to the norm pass
+                        if prefix == 'enc0' and j == 1:
+                            dst = torch.empty(nv.lib().iunet_pack_first_conv_elems(b, a, self.taps), dtype=self.act_dtype,
+                                              device=self.device)
+                            descs.append(nv.make_desc(w, dst, b, a, self.taps, 2, self.act_dtype))
+                        else:
+                            dst = nv.PackedConv(b, a, self.taps, self.act_dtype, self.device)
+                            descs += dst.descs(w)
+                        P[f'{prefix}.conv{j}'] = (dst, None, bn[0], bn[1])
+                        continue
                     bias = torch.empty(b, dtype=torch.float32, device=self.device)
                     qs = torch.empty(b, dtype=torch.float32, device=self.device) if self.weight_dtype else None
                     if prefix == 'enc0' and j == 1:
@@ -173,14 +192,33 @@ class Engine:
                     ws[f'cat{l}'] = mk(2 * self.ch[l], v)
                 if l > 0:
                     ws[f'pin{l}'] = mk(self.ch[l - 1], v)
+            if self.norm == 'group':
+                f32 = lambda n: torch.empty(n, dtype=torch.float32, device=self.device)
+                ws['raw'] = mk(max(self.ch[l] * _vox(dims[l]) for l in range(self.levels)), 1)
+                ws['gn'] = [f32(N * max(self.ch)) for _ in range(4)]
+                ws['gnslab'] = f32(max(nv.lib().iunet_gn_num_parts(N, _vox(dims[l])) * self.ch[l] * 2 for l in range(self.levels)))
             if len(self._ws_cache) > 4:
                 self._ws_cache.clear()
             self._ws_cache[key] = ws
         return ws
 
     # ------------------------------------------------------------------ forward (inference)
-    def _conv3(self, x_ptr, x_ss, y_ptr, y_ss, name, N, dims, ci, co, s):
-        pk, bias = self.packed[name]
+    def _group_norm(self, name, ws, y_ptr, y_ss, N, dims, co, s):
+        """z = relu(group_norm(raw conv output in ws['raw'])) -> y_ptr (which may be a strided view of a concat buffer)."""
+        gamma, beta = self.packed[name][2], self.packed[name][3]
+        sc, sh, mu, ist = ws['gn']
+        v = _vox(dims)
+        nv.call('iunet_gn_relu_fwd', self.dt, nv.ptr(ws['raw']), co * v, y_ptr, y_ss, nv.ptr(gamma), nv.ptr(beta), self.groups,
+                BN_EPS, nv.ptr(ws['gnslab']), nv.ptr(sc), nv.ptr(sh), nv.ptr(mu), nv.ptr(ist), co, N, v, s)
+
+    def _conv3(self, x_ptr, x_ss, y_ptr, y_ss, name, N, dims, ci, co, s, ws=None):
+        pk, bias = self.packed[name][0], self.packed[name][1]
+        if self.norm == 'group':
+            lay, wpk = pk.pick(self.dim, N, dims[0], dims[1], dims[2])
+            nv.call('iunet_conv3_fwd', self.dt, self.dim, x_ptr, x_ss, nv.ptr(ws['raw']), co * _vox(dims), nv.ptr(wpk), None, None,
+                    N, dims[0], dims[1], dims[2], ci, co, 0, lay, s)
+            self._group_norm(name, ws, y_ptr, y_ss, N, dims, co, s)
+            return
         if isinstance(pk, F8Conv):
             need = nv.lib().iunet_conv3_f8_workspace_elems(self.dim, N, dims[0], dims[1], dims[2], ci, co)      # split-K scratch
             if need > (self._f8_ws.numel() if self._f8_ws is not None else 0):
@@ -209,22 +247,25 @@ class Engine:
         for l in range(L):
             v = _vox(dims[l])
             if l == 0:
-                w, b = self.packed['enc0.conv1']
+                w, b = self.packed['enc0.conv1'][0], self.packed['enc0.conv1'][1]
+                gn = self.norm == 'group'
                 nv.call('iunet_first_conv_fwd', self.dt, self.dim, nv.ptr(x), nv.IN_DTYPE_CODE[x.dtype],
-                        nv.ll_array(x_strides), P(ws['a0']), ch[0] * v, nv.ptr(w), nv.ptr(b), None,
-                        N, dims[0][0], dims[0][1], dims[0][2], self.cin, ch[0], 1, s)
+                        nv.ll_array(x_strides), P(ws['raw']) if gn else P(ws['a0']), ch[0] * v, nv.ptr(w), nv.ptr(b), None,
+                        N, dims[0][0], dims[0][1], dims[0][2], self.cin, ch[0], 0 if gn else 1, s)
+                if gn:
+                    self._group_norm('enc0.conv1', ws, P(ws['a0']), ch[0] * v, N, dims[0], ch[0], s)
             else:
                 self._conv3(P(ws[f'pin{l}']), ch[l - 1] * v, P(ws[f'a{l}']), ch[l] * v, f'enc{l}.conv1', N, dims[l],
-                            ch[l - 1], ch[l], s)
+                            ch[l - 1], ch[l], s, ws)
             if l < L - 1:
                 self._conv3(P(ws[f'a{l}']), ch[l] * v, P(ws[f'cat{l}']), 2 * ch[l] * v, f'enc{l}.conv2', N, dims[l],
-                            ch[l], ch[l], s)
+                            ch[l], ch[l], s, ws)
                 vo = _vox(dims[l + 1])
                 nv.call('iunet_maxpool_fwd', self.dt, self.dim, P(ws[f'cat{l}']), 2 * ch[l] * v, P(ws[f'pin{l + 1}']),
                         ch[l] * vo, ch[l], N, dims[l + 1][0], dims[l + 1][1], dims[l + 1][2], s)
             else:
                 self._conv3(P(ws[f'a{l}']), ch[l] * v, P(ws[f'b{l}']), ch[l] * v, f'enc{l}.conv2', N, dims[l],
-                            ch[l], ch[l], s)
+                            ch[l], ch[l], s, ws)
         for l in range(L - 2, -1, -1):
             v, vi = _vox(dims[l]), _vox(dims[l + 1])
             wpk, bias = self.packed[f'dec{l}.up']
@@ -232,9 +273,9 @@ class Engine:
                     P(ws[f'cat{l}'], ch[l] * v), 2 * ch[l] * v, nv.ptr(wpk), nv.ptr(bias),
                     N, dims[l + 1][0], dims[l + 1][1], dims[l + 1][2], ch[l + 1], ch[l], s)
             self._conv3(P(ws[f'cat{l}']), 2 * ch[l] * v, P(ws[f'a{l}']), ch[l] * v, f'dec{l}.conv1', N, dims[l],
-                        2 * ch[l], ch[l], s)
+                        2 * ch[l], ch[l], s, ws)
             self._conv3(P(ws[f'a{l}']), ch[l] * v, P(ws[f'b{l}']), ch[l] * v, f'dec{l}.conv2', N, dims[l],
-                        ch[l], ch[l], s)
+                        ch[l], ch[l], s, ws)
         if features_only:
             return ws['b0']                       # input of the head, NHWC8c
         hw, hb = self.packed['head']

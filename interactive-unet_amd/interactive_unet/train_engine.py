@@ -53,6 +53,13 @@ class TrainEngine:
         # wherever the second conv runs on layout 2 (3-D: always; 2-D: up to 64 channels) -- see _conv2_input
         # (IUNET_NO_ACT_FUSION=1: materialise it, for A/B runs)
         self.fuse_act = not os.environ.get('IUNET_NO_ACT_FUSION')
+        # GroupNorm variant: statistics per (sample, group) -- the per-channel fusions of the BatchNorm path (activation applied in
+        # the next conv's loaders, pooling folded into the norm passes, first-layer weight gradient with the norm backward inside)
+        # do not apply; every norm is iunet_gn_relu_fwd / _bwd on materialised tensors
+        self.norm, self.groups = getattr(model, 'norm', 'batch'), getattr(model, 'groups', 8)
+        self.gn = self.norm == 'group'
+        if self.gn:
+            self.fuse_act = False
         self._flatten()
         if self.pg is not None:
             # every rank continues from rank 0's weights and BatchNorm statistics (each rank's module drew its own
@@ -177,7 +184,7 @@ class TrainEngine:
                     ws['z.' + name] = act(b, v)
                     ws['dz.' + name] = act(b, v)
                 for k in ('scale', 'shift', 'mean', 'invstd'):
-                    ws[f'{k}.{name}'] = f32(b)
+                    ws[f'{k}.{name}'] = f32(b * (N if self.gn else 1))
                 if name == 'enc0.conv1':
                     max_stats = max(max_stats, lib.iunet_conv3_num_tiles(self.dim, N, *d) * b * 2)
                     max_wslab = max(max_wslab, lib.iunet_first_conv_wgrad_blocks(self.dim, N, *d) * b * 112)
@@ -201,7 +208,7 @@ class TrainEngine:
         ws['stats'] = f32(max_stats)
         ws['wslab'] = f32(max_wslab)
         ws['bnslab'] = f32(max_bn)
-        ws['bncoef'] = f32(3 * max(ch))
+        ws['bncoef'] = f32(3 * max(ch) * (N if self.gn else 1))
         nparts = lib.iunet_head_loss_num_parts(N, v0)
         ws['lslab'] = f32(nparts * self.ncls * 8)
         ws['hslab'] = f32(lib.iunet_head_loss_bwd_num_parts(N, v0, self.ncls, ch[0]) * self.ncls * (ch[0] + 1))
@@ -230,19 +237,27 @@ class TrainEngine:
             w, _ = self.pk[name]
             nparts = nv.lib().iunet_conv3_num_tiles(self.dim, N, *d)
             nv.call('iunet_first_conv_fwd', self.dt, self.dim, nv.ptr(x), nv.IN_DTYPE_CODE[x.dtype], nv.ll_array(xs),
-                    self._P(y), co * v, nv.ptr(w), None, nv.ptr(stats), N, d[0], d[1], d[2], ci, co, 0, s)
+                    self._P(y), co * v, nv.ptr(w), None, None if self.gn else nv.ptr(stats), N, d[0], d[1], d[2], ci, co, 0, s)
         else:
             pk, _ = self.pk[name]
             lay, w = pk.pick(self.dim, N, *d)
             nparts = nv.lib().iunet_conv3_stats_parts(self.dim, N, *d, co, lay)
             if x_act is None:
                 nv.call('iunet_conv3_fwd', self.dt, self.dim, x_ptr, x_ss, self._P(y), co * v, nv.ptr(w), None,
-                        nv.ptr(stats), N, d[0], d[1], d[2], ci, co, 0, lay, s)
+                        None if self.gn else nv.ptr(stats), N, d[0], d[1], d[2], ci, co, 0, lay, s)
             else:
                 nv.call('iunet_conv3_fwd_act', self.dt, self.dim, x_ptr, x_ss, self._P(y), co * v, nv.ptr(w), None,
                         nv.ptr(stats), nv.ptr(ws['scale.' + x_act]), nv.ptr(ws['shift.' + x_act]),
                         N, d[0], d[1], d[2], ci, co, 0, lay, s)
         bn = name.replace('conv', 'bn')
+        if self.gn:
+            nv.call('iunet_gn_relu_fwd', self.dt, self._P(y), co * v, z_ptr, z_ss, nv.ptr(self.p(bn + '.weight')),
+                    nv.ptr(self.p(bn + '.bias')), self.groups, BN_EPS, nv.ptr(ws['bnslab']), nv.ptr(ws['scale.' + name]),
+                    nv.ptr(ws['shift.' + name]), nv.ptr(ws['mean.' + name]), nv.ptr(ws['invstd.' + name]), co, N, v, s)
+            if pool is not None:
+                p_ptr, p_ss, do = pool
+                nv.call('iunet_maxpool_fwd', self.dt, self.dim, z_ptr, z_ss, p_ptr, p_ss, co, N, do[0], do[1], do[2], s)
+            return
         nv.call('iunet_bn_finalize', nv.ptr(stats), nparts, co, float(N) * v,
                 nv.ptr(self.p(bn + '.weight')), nv.ptr(self.p(bn + '.bias')),
                 nv.ptr(self.p(bn + '.running_mean')), nv.ptr(self.p(bn + '.running_var')), BN_MOMENTUM, BN_EPS,
@@ -319,7 +334,15 @@ class TrainEngine:
         bn = name.replace('conv', 'bn')
         dy = ws['dy']
         first = name == 'enc0.conv1'
-        if pool_bwd is not None:
+        if self.gn:
+            if pool_bwd is not None:         # encoder stage: dz = skip gradient + max-pool backward of dpool (in place on the skip gradient)
+                dp_ptr, dp_ss, do = pool_bwd
+                nv.call('iunet_maxpool_bwd', self.dt, self.dim, z_ptr, z_ss, dp_ptr, dp_ss, dz_ptr, dz_ss, 1, co, N, do[0], do[1], do[2], s)
+            nv.call('iunet_gn_relu_bwd', self.dt, dz_ptr, dz_ss, self._P(ws['y.' + name]), co * v, self._P(dy), co * v,
+                    nv.ptr(self.p(bn + '.weight')), self.groups, nv.ptr(ws['scale.' + name]), nv.ptr(ws['shift.' + name]),
+                    nv.ptr(ws['mean.' + name]), nv.ptr(ws['invstd.' + name]), nv.ptr(self.g(bn + '.weight')),
+                    nv.ptr(self.g(bn + '.bias')), nv.ptr(ws['bnslab']), nv.ptr(ws['bncoef']), co, N, v, s)
+        elif pool_bwd is not None:
             # encoder stage: dz = skip gradient (dz_ptr) + max-pool backward of dpool, formed on the fly in both passes
             dp_ptr, dp_ss, do = pool_bwd
             nv.call('iunet_bn_relu_pool_bwd', self.dt, self.dim, dz_ptr, dz_ss, dp_ptr, dp_ss, self._P(ws['y.' + name]), co * v,
@@ -336,7 +359,11 @@ class TrainEngine:
                     nv.ptr(self.g(bn + '.weight')), nv.ptr(self.g(bn + '.bias')),
                     nv.ptr(ws['bnslab']), nv.ptr(ws['bncoef']), co, N, v, s)
         gw = self.g(name + '.weight')
-        if first:
+        if first and self.gn:
+            x, xs = x_raw
+            nv.call('iunet_first_conv_wgrad', self.dt, self.dim, nv.ptr(x), nv.IN_DTYPE_CODE[x.dtype], nv.ll_array(xs),
+                    self._P(dy), co * v, nv.ptr(ws['wslab']), nv.ptr(gw), N, d[0], d[1], d[2], ci, co, s)
+        elif first:
             x, xs = x_raw
             nv.call('iunet_first_conv_wgrad_bn', self.dt, self.dim, nv.ptr(x), nv.IN_DTYPE_CODE[x.dtype], nv.ll_array(xs),
                     dz_ptr, dz_ss, self._P(ws['y.' + name]), co * v, nv.ptr(ws['mean.' + name]), nv.ptr(ws['invstd.' + name]),

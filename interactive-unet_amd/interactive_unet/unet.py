@@ -56,7 +56,7 @@ class UNet(nn.Module):
 
     def __init__(self, lr=0.0001, num_channels=1, num_classes=2, loss_function=metrics.mcc_ce_loss,
                  architecture='U-Net', encoder_name='mit_b0', pretrained=True,
-                 dim=2, levels=4, base=32, act_dtype='fp16', weight_dtype=None):
+                 dim=2, levels=4, base=32, act_dtype='fp16', weight_dtype=None, norm='batch', groups=8):
         super().__init__()
         if architecture != 'U-Net':
             raise NotImplementedError(f"architecture {architecture!r}: only 'U-Net' has a native MI355X "
@@ -68,7 +68,7 @@ class UNet(nn.Module):
                             architecture=architecture, encoder_name=encoder_name, pretrained=pretrained,
                             dim=dim, levels=levels, base=base,
                             act_dtype=_ACT_NAME[_ACT[act_dtype]],
-                            weight_dtype=weight_dtype)
+                            weight_dtype=weight_dtype, norm=norm, groups=groups)
         self.lr = lr
         self.loss_function = loss_function
         self.dim, self.levels, self.base = dim, levels, base
@@ -77,6 +77,11 @@ class UNet(nn.Module):
         # 'fp8_e4m3' (BASELINE config C5): inference runs on weights quantised to OCP e4m3 with per-output-channel
         # power-of-two scales (after the BatchNorm fold); training keeps fp32 masters and 16-bit operators
         self.weight_dtype = weight_dtype
+        # norm='group': GroupNorm(groups) instead of BatchNorm after every stage conv (north_star "GroupNorm/BN"); the
+        # bn{j}.weight / .bias parameters are its affine pair, the running statistics are unused
+        if norm not in ('batch', 'group'):
+            raise ValueError("norm must be 'batch' or 'group'")
+        self.norm, self.groups = norm, groups
         self._names = []
         for name, shp in param_shapes(dim, levels, base, num_channels, num_classes).items():
             t = torch.empty(shp, dtype=torch.float32)
@@ -144,12 +149,12 @@ class UNet(nn.Module):
         if eng is None:
             if self.act_dtype == torch.float32:
                 from .engine_f32 import EngineF32
-                if self.weight_dtype is not None:
-                    raise ValueError("act_dtype='fp32' is the parity mode: it takes no weight_dtype")
+                if self.weight_dtype is not None or self.norm != 'batch':
+                    raise ValueError("act_dtype='fp32' is the parity mode: BatchNorm network, no weight_dtype")
                 eng = EngineF32(self.dim, self.levels, self.base, self.num_channels, self.num_classes, dev)
             else:
                 eng = Engine(self.dim, self.levels, self.base, self.num_channels, self.num_classes, self.act_dtype, dev,
-                             weight_dtype=self.weight_dtype)
+                             weight_dtype=self.weight_dtype, norm=self.norm, groups=self.groups)
             self._engines = {dev: eng}
             self._packed_sig = None
         sig = self._signature()

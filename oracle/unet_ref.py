@@ -165,7 +165,8 @@ def quantize_act_e4m3(t):
     return torch.from_numpy(round_e4m3(a))
 
 
-def forward_logits(p, x, dim=2, levels=4, training=False, act_dtype=None, bn_stats_out=None, weight_quant=None, act_quant=False):
+def forward_logits(p, x, dim=2, levels=4, training=False, act_dtype=None, bn_stats_out=None, weight_quant=None, act_quant=False,
+                   norm='batch', groups=8):
     """x: [N, cin, *spatial] float32 in [0,1].  Returns fp32 logits [N, ncls, *spatial].
 
     training=True uses batch statistics in BatchNorm (and, if bn_stats_out is a dict,
@@ -177,7 +178,13 @@ def forward_logits(p, x, dim=2, levels=4, training=False, act_dtype=None, bn_sta
         for j in (1, 2):
             w = p[f'{prefix}.conv{j}.weight']
             bn = [p[f'{prefix}.bn{j}.{k}'] for k in ('weight', 'bias', 'running_mean', 'running_var')]
-            if training:
+            if norm == 'group':
+                # GroupNorm(groups) variant (north_star "GroupNorm/BN"): statistics per (sample, group), the same at training
+                # and inference -- nothing folds; rounding points of the HIP path: weights, raw conv output, stage output
+                R = _rnd_ag if training else _rnd
+                y = R(conv(t, R(w, act_dtype), padding=1), act_dtype)
+                t = R(F.relu(F.group_norm(y, groups, bn[0], bn[1], eps=BN_EPS)), act_dtype)
+            elif training:
                 # act_dtype set: weights, raw conv output and the stage output are stored in
                 # act_dtype (and so are their gradients), as in the HIP training path
                 y = _rnd_ag(conv(t, _rnd_ag(w, act_dtype), padding=1), act_dtype)
@@ -218,10 +225,10 @@ def forward_logits(p, x, dim=2, levels=4, training=False, act_dtype=None, bn_sta
     return conv(t, p['head.weight'], bias=p['head.bias'])
 
 
-def forward(p, x, dim=2, levels=4, training=False, act_dtype=None, weight_quant=None, act_quant=False):
+def forward(p, x, dim=2, levels=4, training=False, act_dtype=None, weight_quant=None, act_quant=False, norm='batch', groups=8):
     """Softmax probabilities NCHW(D), as UNet.forward returns them (unet.py:65-69)."""
     return torch.softmax(forward_logits(p, x, dim, levels, training, act_dtype, weight_quant=weight_quant,
-                                        act_quant=act_quant), dim=1)
+                                        act_quant=act_quant, norm=norm, groups=groups), dim=1)
 
 
 def flops_per_voxel(dim=2, levels=4, base=32, cin=1, ncls=2):

@@ -1,0 +1,138 @@
+"""GroupNorm(8) variant of the canonical stage (north_star: "Conv2d/Conv3d + GroupNorm/BN + ReLU"): statistics per
+(sample, group), identical at training and inference.  Kernel level against torch's F.group_norm + autograd, network level
+against the oracle (oracle/unet_ref.forward_logits(norm='group')), one training step against CPU autograd."""
+import warnings
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import metrics_ref, unet_ref
+from tests.test_gpu_kernels import blocked, unblocked, nv      # noqa: F401
+
+
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('N,C,groups,sp', [(2, 32, 8, (5, 7, 9)), (3, 64, 8, (40, 33)), (1, 256, 8, (4, 4, 4)), (2, 32, 4, (9000,))])
+def test_gn_relu_fwd_bwd_vs_torch(nv, dtype, N, C, groups, sp):
+    g = torch.Generator().manual_seed(0)
+    y = (torch.randn((N, C) + sp, generator=g) * 1.5 + 0.3).to(dtype).float()
+    y[:, 3] *= 4.0                                                   # channels of one group with different ranges
+    dz = (torch.randn((N, C) + sp, generator=g)).to(dtype).float()
+    gamma = 0.5 + torch.rand(C, generator=g)
+    beta = 0.3 * torch.randn(C, generator=g)
+    yr = y.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    z_ref = F.relu(F.group_norm(yr, groups, gr, br, eps=1e-5))
+    z_ref.backward(dz)
+    vox = int(np.prod(sp))
+    dev = 'cuda'
+    yb, dzb = blocked(y, dtype).to(dev), blocked(dz, dtype).to(dev)
+    z = torch.full_like(yb, float('nan'))
+    dy = torch.full_like(yb, float('nan'))
+    parts = nv.lib().iunet_gn_num_parts(N, vox)
+    slab = torch.empty(parts * C * 2, device=dev)
+    st = [torch.empty(N * C, device=dev) for _ in range(4)]
+    coef = torch.empty(N * C * 3, device=dev)
+    dg, db = torch.empty(C, device=dev), torch.empty(C, device=dev)
+    gd, bd = gamma.to(dev), beta.to(dev)
+    dt = nv.DTYPE_CODE[dtype]
+    nv.call('iunet_gn_relu_fwd', dt, nv.ptr(yb), C * vox, nv.ptr(z), C * vox, nv.ptr(gd), nv.ptr(bd), groups, 1e-5, nv.ptr(slab),
+            nv.ptr(st[0]), nv.ptr(st[1]), nv.ptr(st[2]), nv.ptr(st[3]), C, N, vox, nv.stream())
+    nv.call('iunet_gn_relu_bwd', dt, nv.ptr(dzb), C * vox, nv.ptr(yb), C * vox, nv.ptr(dy), C * vox, nv.ptr(gd), groups,
+            nv.ptr(st[0]), nv.ptr(st[1]), nv.ptr(st[2]), nv.ptr(st[3]), nv.ptr(dg), nv.ptr(db), nv.ptr(slab), nv.ptr(coef), C, N, vox,
+            nv.stream())
+    torch.cuda.synchronize()
+    ulp = 2 ** -10 if dtype == torch.float16 else 2 ** -7
+    got_z = unblocked(z.float().cpu(), N, C, sp)
+    got_dy = unblocked(dy.float().cpu(), N, C, sp)
+    zr = z_ref.detach()
+    assert (got_z - zr).abs().max() <= 1.5 * ulp * max(1.0, zr.abs().max().item())
+    # mean / invstd of every (sample, group), broadcast to its channels
+    cpg = C // groups
+    yg = y.reshape(N, groups, -1)
+    mean = yg.mean(-1)
+    invstd = 1.0 / torch.sqrt(yg.var(-1, unbiased=False) + 1e-5)
+    assert torch.allclose(st[2].cpu().reshape(N, C), mean.repeat_interleave(cpg, 1), rtol=1e-5, atol=1e-5)
+    assert torch.allclose(st[3].cpu().reshape(N, C), invstd.repeat_interleave(cpg, 1), rtol=1e-5, atol=1e-6)
+    # the ReLU mask of an element whose z is within rounding of 0 may differ: compare gradients away from those
+    sure = zr.abs() > 4 * ulp * zr.abs().max()
+    dyr = yr.grad
+    assert ((got_dy - dyr).abs()[sure | (zr == 0)]).max() <= 3 * ulp * max(1.0, dyr.abs().max().item()) + 4e-3 * dyr.abs().max().item()
+    scale_g = max(1.0, gr.grad.abs().max().item())
+    assert (dg.cpu() - gr.grad).abs().max() <= 2e-2 * scale_g, (dg.cpu() - gr.grad).abs().max()
+    assert (db.cpu() - br.grad).abs().max() <= 2e-2 * max(1.0, br.grad.abs().max().item())
+
+
+def _model(dim, ncls, dtype, seed=2):
+    from interactive_unet.unet import UNet
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        m = UNet(lr=1e-3, num_classes=ncls, dim=dim, act_dtype=dtype, pretrained=False, norm='group', groups=8)
+    p = unet_ref.init_params(dim=dim, ncls=ncls, seed=seed, randomize_bn=True)
+    m.load_named(p)
+    return m.cuda(), p
+
+
+@pytest.mark.parametrize('dim,shape,dtype', [(2, (64, 96), 'fp16'), (3, (16, 32, 48), 'bf16')])
+def test_groupnorm_network_forward_vs_oracle(dim, shape, dtype):
+    act = torch.float16 if dtype == 'fp16' else torch.bfloat16
+    m, p = _model(dim, 3, dtype)
+    m.eval()
+    rng = np.random.default_rng(4)
+    x = torch.tensor(rng.integers(0, 256, (2, 1) + shape, dtype=np.uint8))
+    got = m(x.cuda()).cpu()
+    xf = x.float() / 255.0
+    want = unet_ref.forward(p, xf, dim=dim, act_dtype=act, norm='group', groups=8)
+    want32 = unet_ref.forward(p, xf, dim=dim, norm='group', groups=8)
+    err, err32 = (got - want).abs().max().item(), (got - want32).abs().max().item()
+    print(f'GroupNorm net {dim}-D {dtype}: max |prob - same-rounding oracle| = {err:.2e}, vs fp32 oracle = {err32:.2e}')
+    assert err <= (3e-3 if dtype == 'fp16' else 2.4e-2)
+    assert m.hparams['norm'] == 'group'
+    # the BatchNorm running statistics play no role: changing them changes nothing
+    with torch.no_grad():
+        for n in m._names:
+            if 'running' in n:
+                m.tensor(n).add_(1.0)
+    assert torch.equal(m(x.cuda()).cpu(), got)
+
+
+@pytest.mark.parametrize('dim,shape,dtype', [(2, (64, 64), 'fp16'), (3, (16, 16, 32), 'bf16')])
+def test_groupnorm_train_step_vs_autograd(dim, shape, dtype):
+    from interactive_unet.train_engine import TrainEngine
+    act = torch.float16 if dtype == 'fp16' else torch.bfloat16
+    N, ncls = 2, 2
+    m, p0 = _model(dim, ncls, dtype, seed=5)
+    m.train()
+    rng = np.random.default_rng(1)
+    img = rng.integers(1, 256, (N, 1) + shape, dtype=np.uint8)
+    lab = img[:, 0] > 127
+    y = np.stack([~lab, lab], 1).astype(np.float32)
+    wt = np.repeat((rng.random((N, 1) + shape) > 0.2).astype(np.float32), ncls, 1)
+    y = y * wt
+    X = torch.tensor(img.astype(np.float32) / 255.0)
+    axes = (0,) + tuple(range(2, 2 + dim))
+    pr = {k: v.clone().requires_grad_(not unet_ref.is_buffer(k)) for k, v in p0.items()}
+    logits = unet_ref.forward_logits(pr, X, dim=dim, training=True, act_dtype=act, norm='group', groups=8)
+    probs = torch.softmax(logits, 1)
+    lv = metrics_ref.loss('dice_ce', probs.detach().numpy(), y, wt, axes=axes)
+    gp = torch.tensor(metrics_ref.loss_grad('dice_ce', probs.detach().numpy(), y, wt, axes=axes)).float()
+    probs.backward(gp)
+    te = TrainEngine(m, lr=1e-3, loss_kind='dice_ce')
+    out = te.train_step(torch.tensor(img), torch.tensor(y), torch.tensor(wt))
+    assert abs(out['Loss'] - lv) <= (2e-3 if dtype == 'fp16' else 1e-2), (out['Loss'], lv)
+    scale = te.loss_scale
+    worst = 1.0
+    for name in ('head.weight', 'dec0.conv2.weight', 'dec0.bn2.weight', 'dec0.bn2.bias', 'dec0.conv1.weight', 'enc0.conv2.weight',
+                 'enc0.bn1.weight', 'enc0.conv1.weight', 'dec1.up.weight', 'enc1.conv1.weight'):
+        gn = te.g(name).cpu().reshape(-1) / scale
+        go = pr[name].grad.reshape(-1)
+        cos = float((gn * go).sum() / (gn.norm() * go.norm() + 1e-30))
+        ratio = float(gn.norm() / (go.norm() + 1e-30))
+        worst = min(worst, cos)
+        assert cos > (0.98 if dtype == 'fp16' else 0.95) and 0.9 < ratio < 1.1, (name, cos, ratio)
+    print(f'GroupNorm train step {dim}-D {dtype}: loss {out["Loss"]:.5f} vs oracle {lv:.5f}; worst gradient cosine {worst:.4f}')
+    losses = [te.train_step(torch.tensor(img), torch.tensor(y), torch.tensor(wt))['Loss'] for _ in range(6)]
+    assert losses[-1] < out['Loss']
