@@ -98,34 +98,92 @@ def flops_per_voxel(dim, levels, base, cin, ncls):
     return f + 2 * ch[0] * ncls
 
 
-def pmc_traffic(workload):
+def pmc_traffic(workload, tiles=1):
     """HBM bytes per launch of the roofline kernel from the committed PMC profile (rocprofv3 cannot run inside the timed
-    process): FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate passes.  None where no profile is committed."""
-    for name in (f'r02_pmc_{workload}_dec0conv1.json', 'r01_pmc_conv3_dec0conv1.json' if workload in ('c3', 'c4') else ''):
+    process): FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate passes, scaled to the tiles of the launch.  None where
+    no profile is committed."""
+    for name in (f'r02_pmc_{workload}_dec0conv1.json', 'r02_pmc_c3_dec0conv1.json' if workload == 'c4' else ''):
         try:
             with open(os.path.join(ROOT, 'profiles', name)) as f:
-                return json.load(f)['traffic_bytes_per_launch']
+                d = json.load(f)
+            return int(d['traffic_bytes_per_launch'] * tiles / d.get('tiles_per_launch', 1))
         except Exception:
             continue
     return None
 
 
-def conv_roofline(nv, cfg, workload, dtype, iters=50):
-    """dec0.conv1 of the workload's net (Cin = 2*base -> Cout = base, 3^d taps) on one step's tile batch: 3 warm-up +
-    `iters` timed back-to-back launches, an event around every launch.  achieved = average over all timed launches (what
-    `rocprofv3 --kernel-trace --stats` of tools/bench_conv.py averages too); burst = first 8, settled = last 20."""
+def _roof_fields(flops, alg_bytes, ms, burst=None, settled=None):
+    """Roofline numbers of one launch shape: bound by arithmetic intensity (activations once in, once out) against the ridge
+    of the two peaks; `ms` = average launch duration."""
+    tf = lambda t: flops / (t * 1e-3) / 1e12
+    gbs = lambda t: alg_bytes / (t * 1e-3) / 1e9
+    hbm_bound = flops / alg_bytes < MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
+    out = {'bound': 'hbm' if hbm_bound else 'mfma'}
+    if hbm_bound:
+        out.update({'achieved': round(gbs(ms), 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(gbs(ms) / HBM_PEAK_GBS, 4),
+                    'tflops': round(tf(ms), 2), 'mfma_frac': round(tf(ms) / MFMA_PEAK_TFLOPS, 4)})
+        rate, peak = gbs, HBM_PEAK_GBS
+    else:
+        out.update({'achieved': round(tf(ms), 2), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(tf(ms) / MFMA_PEAK_TFLOPS, 4),
+                    'hbm_gbs_algorithmic': round(gbs(ms), 1)})
+        rate, peak = tf, MFMA_PEAK_TFLOPS
+    if burst is not None:
+        out.update({'burst_ms_first8': round(burst, 4), 'burst_frac': round(rate(burst) / peak, 4),
+                    'settled_ms_last20': round(settled, 4), 'settled_frac': round(rate(settled) / peak, 4)})
+    out.update({'ms_per_launch': round(ms, 4), 'flops_per_launch': flops, 'algorithmic_bytes_per_launch': alg_bytes,
+                'flop_per_byte': round(flops / alg_bytes, 1)})
+    return out
+
+
+def _roof_kernel_name(nv, cfg, dtype, N):
+    dim, base = cfg['dim'], cfg['base']
+    shape = cfg['tile']
+    D, H, W = shape if dim == 3 else (1,) + tuple(shape)
+    lay = nv.lib().iunet_conv3_pick_layout(dim, N, D, H, W, 2 * base, base)
+    kname = 'conv3_f8_kernel' if cfg['wq'] else {0: 'conv3_mfma_kernel', 1: 'conv3_v2_kernel', 2: 'conv3_v4_kernel'}[lay]
+    tname = 'bf16' if dtype == torch.bfloat16 else 'f16'
+    return f'{kname}<{tname},{dim}> (dec0.conv1 {2 * base}->{base} @ {N} x {"x".join(str(s) for s in shape)})', lay
+
+
+def conv_roofline_in_situ(nv, cfg, workload, dtype, events):
+    """The workload's bottleneck conv (dec0.conv1) as the STEP launches it: HIP events recorded around every forward launch
+    of that layer inside real steps (engine / train_engine `probe`), on the stream the kernels run on.  achieved = algorithmic
+    FLOPs (or bytes) of those launches / their summed duration."""
+    dim, base = cfg['dim'], cfg['base']
+    cin, cout, taps = 2 * base, base, 3 ** dim
+    vox = int(np.prod(cfg['tile']))
+    torch.cuda.synchronize()
+    per = [(e0.elapsed_time(e1), n) for e0, e1, n in events]
+    ms_tot = sum(t for t, _ in per)
+    n_tot = sum(n for _, n in per)
+    N = max(n for _, n in per)
+    ms = ms_tot / len(per) * (N * len(per) / n_tot)             # average duration of a launch of N tiles
+    flops = 2.0 * taps * cin * cout * vox * N
+    out = _roof_fields(flops, (cin + cout) * 2.0 * vox * N, ms)
+    name, _ = _roof_kernel_name(nv, cfg, dtype, N)
+    out = {'bound': out.pop('bound'), 'kernel': name, **out}
+    out.update({'launches': len(per), 'tiles_per_launch': N, 'measured': 'in situ: HIP events around the forward launches of this layer '
+                'inside real steps (training forward with the BatchNorm-statistics epilogue and prediction forward)',
+                'min_ms': round(min(t for t, _ in per), 4), 'max_ms': round(max(t for t, _ in per), 4),
+                'traffic': pmc_traffic(workload, N)})
+    return out
+
+
+def conv_roofline_back_to_back(nv, cfg, workload, dtype, N, iters=50):
+    """The same layer alone: 3 warm-up + `iters` back-to-back launches, an event around each (what `rocprofv3 --kernel-trace
+    --stats` of tools/bench_conv.py averages too).  Under sustained MFMA load the chip lowers its clock, so this reads lower
+    than the in-situ figure: burst = first 8 launches, settled = last 20."""
     dev = 'cuda'
     dim, base = cfg['dim'], cfg['base']
     cin, cout, taps = 2 * base, base, 3 ** dim
     shape = cfg['tile']
-    N = 1 if dim == 3 else max(1, cfg['chunks'])
     D, H, W = shape if dim == 3 else (1,) + tuple(shape)
     vox = D * H * W
     x = (torch.randn(N * cin * vox, device=dev) * 0.5).to(dtype)
     y = torch.empty(N * cout * vox, dtype=dtype, device=dev)
     w = torch.randn((cout, cin) + (3,) * dim, device=dev) * 0.03
     dt = nv.DTYPE_CODE[dtype]
-    lay = nv.lib().iunet_conv3_pick_layout(dim, N, D, H, W, cin, cout)
+    name, lay = _roof_kernel_name(nv, cfg, dtype, N)
     pmode = 2 if lay > 0 else 0                 # layouts 1 and 2 share the K16 operator
     wpk = torch.empty(nv.pack_conv3_elems(cout, cin, taps, pmode), dtype=dtype, device=dev)
     bias = torch.zeros(cout, device=dev)
@@ -148,28 +206,9 @@ def conv_roofline(nv, cfg, workload, dtype, iters=50):
     torch.cuda.synchronize()
     per = [ev[i].elapsed_time(ev[i + 1]) for i in range(iters)]
     ms = ev[0].elapsed_time(ev[iters]) / iters
-    flops = 2.0 * taps * cin * cout * vox * N
-    tf = lambda t: flops / (t * 1e-3) / 1e12
-    burst, settled = sum(per[:8]) / 8, sum(per[-20:]) / 20
-    kname = 'conv3_f8_kernel' if cfg['wq'] else {0: 'conv3_mfma_kernel', 1: 'conv3_v2_kernel', 2: 'conv3_v4_kernel'}[lay]
-    tname = 'bf16' if dtype == torch.bfloat16 else 'f16'
-    where = f'{N} x {"x".join(str(s) for s in shape)}'
-    alg_bytes = (cin + cout) * 2.0 * vox * N
-    gbs = lambda t: alg_bytes / (t * 1e-3) / 1e9
-    # which roof bounds this layer: arithmetic intensity (activations once in, once out) against the ridge of the two peaks
-    hbm_bound = flops / alg_bytes < MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
-    out = {'bound': 'hbm' if hbm_bound else 'mfma', 'kernel': f'{kname}<{tname},{dim}> (dec0.conv1 {cin}->{cout} @ {where})'}
-    if hbm_bound:
-        out.update({'achieved': round(gbs(ms), 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(gbs(ms) / HBM_PEAK_GBS, 4),
-                    'burst_frac': round(gbs(burst) / HBM_PEAK_GBS, 4), 'settled_frac': round(gbs(settled) / HBM_PEAK_GBS, 4),
-                    'tflops': round(tf(ms), 2), 'mfma_frac': round(tf(ms) / MFMA_PEAK_TFLOPS, 4)})
-    else:
-        out.update({'achieved': round(tf(ms), 2), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(tf(ms) / MFMA_PEAK_TFLOPS, 4),
-                    'burst_frac': round(tf(burst) / MFMA_PEAK_TFLOPS, 4), 'settled_frac': round(tf(settled) / MFMA_PEAK_TFLOPS, 4),
-                    'hbm_gbs_algorithmic': round(gbs(ms), 1)})
-    out.update({'ms_per_launch': round(ms, 4), 'launches': iters, 'flops_per_launch': flops,
-                'algorithmic_bytes_per_launch': alg_bytes, 'flop_per_byte': round(flops / alg_bytes, 1),
-                'burst_ms_first8': round(burst, 4), 'settled_ms_last20': round(settled, 4), 'traffic': pmc_traffic(workload)})
+    out = _roof_fields(2.0 * taps * cin * cout * vox * N, (cin + cout) * 2.0 * vox * N, ms, sum(per[:8]) / 8, sum(per[-20:]) / 20)
+    out = {'bound': out.pop('bound'), 'kernel': name, **out}
+    out.update({'launches': iters, 'tiles_per_launch': N, 'measured': f'3 warm-up + {iters} back-to-back launches of the layer alone'})
     return out
 
 
@@ -449,9 +488,27 @@ def main():
               'exchange_bytes_sent_rank0': st4.get('bytes_sent'), 'pieces_blended_rank0': st4.get('pieces_blended')}
         del slab4
 
+    # ------------------------------------------------------------------ roofline: the bottleneck conv as the step launches it
+    probe_events = []
+    eng = model.engine('eval')
+    eng.probe = {'name': 'dec0.conv1', 'events': probe_events}
+    if args.workload != 'c4':
+        trainer.probe = eng.probe
+    for _ in range(1 if args.workload == 'c4' else 10):
+        step()
+        if len(probe_events) > 400:
+            break
+    torch.cuda.synchronize()
+    eng.probe = None
+    if args.workload != 'c4':
+        trainer.probe = None
+
     out = None
     if rank == 0:
-        roof = conv_roofline(nv, cfg, args.workload, dtype)
+        roof = conv_roofline_in_situ(nv, cfg, args.workload, dtype, probe_events[:400])
+        roof['back_to_back'] = conv_roofline_back_to_back(nv, cfg, args.workload, dtype, roof['tiles_per_launch'])
+        if dim == 3 and roof['tiles_per_launch'] != 1:
+            roof['back_to_back_1_tile'] = conv_roofline_back_to_back(nv, cfg, args.workload, dtype, 1)
         tile_s = 'x'.join(str(s) for s in tile)
         if args.workload == 'c4':
             desc = (f'C4: tiled prediction of one {V[0]}^3 uint8 volume (generated on the device from the voxel coordinates), '

@@ -64,6 +64,7 @@ class Engine:
         self.packed = None
         self._ws_cache = {}
         self._f8_ws = None
+        self.probe = None          # {'name': layer, 'events': []}: timing hook of one layer's launches (bench.py roofline)
         nv.lib()   # fail loudly now if the HIP library is missing
 
     # ------------------------------------------------------------------ weights
@@ -219,6 +220,19 @@ class Engine:
                     N, dims[0], dims[1], dims[2], ci, co, 0, lay, s)
             self._group_norm(name, ws, y_ptr, y_ss, N, dims, co, s)
             return
+        probe = self.probe if (self.probe is not None and self.probe['name'] == name) else None
+        if probe is not None:                       # bench.py: HIP events around THIS layer's launch inside the real step
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self._conv3_launch(x_ptr, x_ss, y_ptr, y_ss, name, N, dims, ci, co, s, ws)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            probe['events'].append((e0, e1, N))
+            return
+        self._conv3_launch(x_ptr, x_ss, y_ptr, y_ss, name, N, dims, ci, co, s, ws)
+
+    def _conv3_launch(self, x_ptr, x_ss, y_ptr, y_ss, name, N, dims, ci, co, s, ws=None):
+        pk, bias = self.packed[name][0], self.packed[name][1]
         if isinstance(pk, F8Conv):
             need = nv.lib().iunet_conv3_f8_workspace_elems(self.dim, N, dims[0], dims[1], dims[2], ci, co)      # split-K scratch
             if need > (self._f8_ws.numel() if self._f8_ws is not None else 0):

@@ -70,6 +70,7 @@ class TrainEngine:
             self.buckets = dp.GradBuckets(self.grad, self._dec_start, self.pg)
         self._alloc_packed()
         self._ws = {}
+        self.probe = None          # timing hook of one layer's forward launches (bench.py roofline), see engine.Engine.probe
         self.repack()
         model._packed_sig = None
 
@@ -242,6 +243,10 @@ class TrainEngine:
             pk, _ = self.pk[name]
             lay, w = pk.pick(self.dim, N, *d)
             nparts = nv.lib().iunet_conv3_stats_parts(self.dim, N, *d, co, lay)
+            probe = self.probe if (self.probe is not None and self.probe['name'] == name) else None
+            if probe is not None:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e0.record()
             if x_act is None:
                 nv.call('iunet_conv3_fwd', self.dt, self.dim, x_ptr, x_ss, self._P(y), co * v, nv.ptr(w), None,
                         None if self.gn else nv.ptr(stats), N, d[0], d[1], d[2], ci, co, 0, lay, s)
@@ -249,6 +254,10 @@ class TrainEngine:
                 nv.call('iunet_conv3_fwd_act', self.dt, self.dim, x_ptr, x_ss, self._P(y), co * v, nv.ptr(w), None,
                         nv.ptr(stats), nv.ptr(ws['scale.' + x_act]), nv.ptr(ws['shift.' + x_act]),
                         N, d[0], d[1], d[2], ci, co, 0, lay, s)
+            if probe is not None:
+                e1 = torch.cuda.Event(enable_timing=True)
+                e1.record()
+                probe['events'].append((e0, e1, N))
         bn = name.replace('conv', 'bn')
         if self.gn:
             nv.call('iunet_gn_relu_fwd', self.dt, self._P(y), co * v, z_ptr, z_ss, nv.ptr(self.p(bn + '.weight')),
