@@ -222,6 +222,19 @@ int iunet_bn_relu_bwd(int dtype, const void* dz, long long dz_ss, const void* z,
                       long long y_ss, void* dy, long long dy_ss, const void* mean, const void* invstd, const void* gamma,
                       const void* scale, const void* shift, void* dgamma, void* dbeta, void* slab, void* coef, int C, int N,
                       long long vox, void* stream);
+/* The first pass of iunet_bn_relu_bwd folded into the data-gradient launch that produces dz.  iunet_conv3_dgrad_bnstats =
+ * iunet_conv3_fwd (layout 2, epi 0) on the data-gradient operator, whose epilogue also reads yp (the raw output of the layer the
+ * gradient flows into, z = relu(bn(yp))) and writes per-workgroup rows of (sum dz', sum dz' * xhat) to stats
+ * [iunet_conv3_stats_parts(nd, N, D, H, W, Cout, 2)][Cout][2]; iunet_bn_relu_bwd_apply finalizes those rows (dgamma, dbeta,
+ * coefficients) and runs pass 2 (dy NULL: coefficients only, for iunet_first_conv_wgrad_bn). */
+int iunet_conv3_dgrad_bnstats(int dtype, int nd, const void* dy, long long dy_sstride, void* dz, long long dz_sstride,
+                              const void* wpk, void* stats, const void* yp, long long yp_sstride, const void* mean,
+                              const void* invstd, const void* scale, const void* shift, int N, int D, int H, int W, int Cin,
+                              int Cout, void* stream);
+int iunet_bn_relu_bwd_apply(int dtype, const void* dz, long long dz_ss, const void* y, long long y_ss, void* dy, long long dy_ss,
+                            const void* mean, const void* invstd, const void* gamma, const void* scale, const void* shift,
+                            void* dgamma, void* dbeta, const void* slab, int nparts, void* coef, int C, int N, long long vox,
+                            void* stream);
 /* GroupNorm + ReLU (north_star "GroupNorm/BN"; the GroupNorm(8) variant of SURVEY 8d's canonical stage): statistics per
  * (sample, group), identical at training and inference -- nothing folds into the conv.  z = relu(group_norm(y)); slab:
  * iunet_gn_num_parts(N, vox) * C * 2 floats of scratch; scale / shift / mean / invstd: fp32 [N][C], written by the forward

@@ -18,7 +18,8 @@ void iunet_set_error(const char* fmt, ...) {
 int iunet_conv3_launch(int dtype, int nd, const void* x, long long x_sstride, void* y, long long y_sstride,
                        const void* wpk, const float* bias, float* stats, int N, int D, int H, int W, int Cin,
                        int Cout, int epi, int layout, hipStream_t stream, const float* in_scale = nullptr,
-                       const float* in_shift = nullptr);
+                       const float* in_shift = nullptr, const void* bw_y = nullptr, long long bw_y_ss = 0,
+                       const float* const* bw_par = nullptr);
 int iunet_conv3_pick(int nd, int N, int D, int H, int W, int Cin, int Cout);
 int iunet_conv3_v4_stats_parts(int nd, int Cout);
 int iunet_conv3_tiles(int nd, int N, int D, int H, int W);
@@ -136,6 +137,21 @@ int iunet_conv3_fwd_act(int dtype, int nd, const void* x, long long x_sstride, v
   IUNET_REQUIRE(layout == 2, "conv3_act: the fused input activation exists in layout 2 only (got %d)", layout);
   return iunet_conv3_launch(dtype, nd, x, x_sstride, y, y_sstride, wpk, (const float*)bias, (float*)stats, N, D, H, W,
                             Cin, Cout, epi, layout, (hipStream_t)stream, (const float*)in_scale, (const float*)in_shift);
+}
+
+// iunet_conv3_fwd used as the data gradient of a conv whose INPUT was z = relu(bn(yp)): besides dz (its output) it accumulates
+// the BatchNorm-backward sums of that producer layer -- sum dz', sum dz' * xhat with dz' = dz where z > 0 -- in its epilogue
+// (the reduction pass of iunet_bn_relu_bwd over dz and yp goes away); stats: [iunet_conv3_stats_parts(.., layout 2)][Cout][2].
+int iunet_conv3_dgrad_bnstats(int dtype, int nd, const void* dy, long long dy_sstride, void* dz, long long dz_sstride,
+                              const void* wpk, void* stats, const void* yp, long long yp_sstride, const void* mean,
+                              const void* invstd, const void* scale, const void* shift, int N, int D, int H, int W, int Cin,
+                              int Cout, void* stream) {
+  DT_OK(dtype);
+  IUNET_REQUIRE(dy && dz && wpk && stats && yp && mean && invstd && scale && shift, "conv3_dgrad_bnstats: null pointer");
+  IUNET_REQUIRE_GRID("conv3_dgrad_bnstats", N, D, H, W);
+  const float* par[4] = {(const float*)mean, (const float*)invstd, (const float*)scale, (const float*)shift};
+  return iunet_conv3_launch(dtype, nd, dy, dy_sstride, dz, dz_sstride, wpk, nullptr, (float*)stats, N, D, H, W, Cin, Cout, 0, 2,
+                            (hipStream_t)stream, nullptr, nullptr, yp, yp_sstride, par);
 }
 
 /* profiling only: ablation builds of the 3-D Cout=32 bf16 conv (not part of the product path) */

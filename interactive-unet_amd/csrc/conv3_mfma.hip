@@ -323,12 +323,14 @@ int iunet_conv3_v2_launch(int dtype, int nd, const void* x, long long x_sstride,
                           int Cout, int epi, hipStream_t stream);
 int iunet_conv3_v4_launch(int dtype, int nd, const void* x, long long x_sstride, void* y, long long y_sstride, const void* wpk,
                           const float* bias, float* stats, int N, int D, int H, int W, int Cin, int Cout, int epi,
-                          const float* in_scale, const float* in_shift, hipStream_t stream);
+                          const float* in_scale, const float* in_shift, hipStream_t stream, const void* bw_y = nullptr,
+                          long long bw_y_ss = 0, const float* const* bw_par = nullptr);
 
 // Host entry used by the net runtime and the per-kernel C ABI.
 int iunet_conv3_launch(int dtype, int nd, const void* x, long long x_sstride, void* y, long long y_sstride,
                        const void* wpk, const float* bias, float* stats, int N, int D, int H, int W, int Cin,
-                       int Cout, int epi, int layout, hipStream_t stream, const float* in_scale, const float* in_shift) {
+                       int Cout, int epi, int layout, hipStream_t stream, const float* in_scale, const float* in_shift,
+                       const void* bw_y, long long bw_y_ss, const float* const* bw_par) {
   IUNET_REQUIRE(nd == 2 || nd == 3, "conv3: nd must be 2 or 3 (got %d)", nd);
   IUNET_REQUIRE(Cin % 32 == 0 && Cout % 32 == 0, "conv3: Cin (%d) and Cout (%d) must be multiples of 32", Cin, Cout);
   IUNET_REQUIRE(nd == 3 || D == 1, "conv3: 2-D conv needs D == 1");
@@ -341,9 +343,10 @@ int iunet_conv3_launch(int dtype, int nd, const void* x, long long x_sstride, vo
   const bool wide = (Cout % 64 == 0);
   IUNET_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv3: in_scale and in_shift come together");
   IUNET_REQUIRE(in_scale == nullptr || layout == 2, "conv3: a fused input activation needs layout 2 (got %d)", layout);
+  IUNET_REQUIRE(bw_y == nullptr || layout == 2, "conv3: the fused BatchNorm-backward sums need layout 2 (got %d)", layout);
   if (layout == 2) {
     return iunet_conv3_v4_launch(dtype, nd, x, x_sstride, y, y_sstride, wpk, bias, stats, N, D, H, W, Cin, Cout, epi,
-                                 in_scale, in_shift, stream);
+                                 in_scale, in_shift, stream, bw_y, bw_y_ss, bw_par);
   }
   if (layout == 1)
     return iunet_conv3_v2_launch(dtype, nd, x, x_sstride, y, y_sstride, wpk, bias, stats, N, D, H, W, Cin, Cout, epi, stream);

@@ -52,9 +52,17 @@ struct ConvV4Params {
   int nbz, nby, nbx;                          // bricks per sample
   int epi;
   int dbg;                                    // profiling only (IUNET_V4_DBG): 2 no MFMA phase, 4 no stores
+  // Data-gradient launches: this launch's output IS the gradient dz of the producer layer's activation z = relu(bn(yp)).  With
+  // bw_y set, the epilogue also reads yp at its output voxels and accumulates the BatchNorm-backward sums of that layer --
+  // s1 = sum dz', s2 = sum dz' * xhat, dz' = dz where z > 0 (the arithmetic of bn_bwd_reduce_kernel on the STORED, rounded dz)
+  // -- into `stats` ([workgroups][Cout][2], as the forward statistics): the separate reduction pass over dz and yp goes away.
+  const void* bw_y; long long bw_y_ss;
+  const float* bw_mean; const float* bw_invstd; const float* bw_scale; const float* bw_shift;      // [Cout] of the producer layer
 };
 
-template <typename T, int ND, bool WS, bool SMALL>
+// BW: the data-gradient variant that also accumulates the BatchNorm-backward sums of the layer its output flows into (bw_y); a
+// template parameter so that its extra registers (the prefetched yp fragments) never touch the forward instantiations
+template <typename T, int ND, bool WS, bool SMALL, bool BW = false>
 __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + (WS ? 256 : 512)), 1) void conv3_v4_kernel(ConvV4Params p) {
   using V8 = typename Vec8<T>::type;
   using TL = V4Tile<ND, SMALL>;
@@ -104,6 +112,12 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + (WS ? 256 : 512)), 1
   const long long plane_stride = (long long)p.D * p.H * p.W * 8;
   const int off_red = OFF_W + (WS ? nchunk : 2) * WSTEP;    // 2 KB of scratch for the BatchNorm partial sums
   const int off_act = off_red + 2048;                       // the fused input activation: [Cin / 8][scale 8 | shift 8] floats
+  const int off_bw = off_act + p.Cin * 8;                   // bw_y: [mean | invstd | scale | shift][32] floats of this Cout tile
+  constexpr bool bw = BW;
+  if (bw && tid < 128) {
+    const float* src = (tid >> 5) == 0 ? p.bw_mean : (tid >> 5) == 1 ? p.bw_invstd : (tid >> 5) == 2 ? p.bw_scale : p.bw_shift;
+    ((float*)(smem + off_bw))[tid] = src[cob * 32 + (tid & 31)];       // read in tile epilogues, many barriers later
+  }
   const u32x4* wsrc = (const u32x4*)p.wpk + (long long)cob * nchunk * (WSTEP / 16);
 
   auto tile_origin = [&](int k, int& n_img, int& z0, int& y0, int& x0) -> bool {      // this workgroup's k-th tile
@@ -286,6 +300,21 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + (WS ? 256 : 512)), 1
     for (int n = 0; n < NI; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   float stat_acc = 0.f;      // BatchNorm partial sums over all tiles of this workgroup: lane (q, l15) holds value l15 = which * 8 + j
+  V8 bw_yv[BW ? NI : 1];     // bw: the producer layer's raw output at this wave's output voxels, fetched one step ahead of the epilogue
+  auto bw_prefetch = [&](int s) {
+    const int chunk = s - (s / nchunk) * nchunk;
+    if constexpr (BW) if (chunk == nchunk - 1) {
+      int n_img, z0, y0, x0;
+      tile_origin(s / nchunk, n_img, z0, y0, x0);
+      const T* yp = (const T*)p.bw_y + (long long)n_img * p.bw_y_ss + (long long)(cob * 4 + q) * plane_stride;
+#pragma unroll
+      for (int n = 0; n < NI; ++n) {
+        const int f = f0 + n, row = f / FX;
+        const int gz = min(z0 + (ND == 3 ? row / TY : 0), p.D - 1), gy = min(y0 + row % TY, p.H - 1), gx = min(x0 + (f % FX) * 16 + l15, p.W - 1);
+        bw_yv[n] = *(const V8*)(yp + (((long long)gz * p.H + gy) * p.W + gx) * 8);
+      }
+    }
+  };
   lds_barrier();                                             // step 0 (and the resident weights) are in LDS
 #ifdef IUNET_STAMPS
   const unsigned long long st0 = __builtin_amdgcn_s_memtime(), sr0 = __builtin_amdgcn_s_memrealtime();
@@ -333,7 +362,7 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + (WS ? 256 : 512)), 1
         float vals[8];
 #pragma unroll
         for (int j = 0; j < 4; ++j) { vals[j] = acc[0][n][j]; vals[4 + j] = acc[1][n][j]; }
-        if (p.stats != nullptr && ok) {
+        if (p.stats != nullptr && ok && !bw) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) { s_sum[j] += vals[j]; s_sq[j] += vals[j] * vals[j]; }
         }
@@ -343,6 +372,20 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + (WS ? 256 : 512)), 1
           float r = vals[j] + bias_r[j];
           if (p.epi == 2) r = fmaxf(r, 0.f);
           o[j] = from_f32<T>(r);
+        }
+        if constexpr (BW) if (ok) {
+          const f32x4* bp = (const f32x4*)(smem + off_bw) + 2 * q;          // [param][32]: this lane's 8 channels of each
+          const f32x4 m0 = bp[0], m1 = bp[1], i0 = bp[8], i1 = bp[9], c0 = bp[16], c1 = bp[17], h0 = bp[24], h1 = bp[25];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float mu = j < 4 ? m0[j & 3] : m1[j & 3], is = j < 4 ? i0[j & 3] : i1[j & 3];
+            const float sc = j < 4 ? c0[j & 3] : c1[j & 3], sh = j < 4 ? h0[j & 3] : h1[j & 3];
+            const float yy = to_f32<T>(bw_yv[n][j]);
+            const float zz = to_f32<T>(from_f32<T>(fmaf(sc, yy, sh)));       // the stored activation (bn_bwd_reduce_kernel)
+            const float d = zz > 0.f ? to_f32<T>(o[j]) : 0.f;                // the stored gradient
+            s_sum[j] += d;
+            s_sq[j] += d * (yy - mu) * is;
+          }
         }
         if (ok && !(p.dbg & 4)) *(V8*)(yout + (long long)(cob * 4 + q) * plane_stride + (((long long)gz * p.H + gy) * p.W + gx) * 8) = o;
         acc[0][n] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -388,7 +431,7 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + (WS ? 256 : 512)), 1
     __builtin_amdgcn_sched_barrier(0);                           // nothing moves across the group boundary
   };
   // The groups of one step of the cross-step pipeline; PAR = fragment set of its first group.
-  constexpr bool XSTEP = WS;       // cross-step pipeline: the variants with resident weights (168-register cap)
+  constexpr bool XSTEP = WS && !BW;       // cross-step pipeline: the variants with resident weights (168-register cap); BW keeps its yp fragments instead
   auto step_groups = [&](int s, auto PAR) {
     constexpr int par = decltype(PAR)::value;
     using B0 = std::integral_constant<int, par>;                       // set of the even groups of this step
@@ -398,6 +441,7 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + (WS ? 256 : 512)), 1
     const unsigned char *ab, *wl, *abn, *wln;
     step_ptrs(s, ab, wl);
     step_ptrs(min(s + 1, nsteps - 1), abn, wln);           // (after the last step: a harmless re-read of its own buffers)
+    bw_prefetch(s);
 #pragma unroll
     for (int g = 0; g + 1 < NGRP; ++g) {
       if ((g & 1) == 0) { load_group(ab, wl, g + 1, B1{}); group_mfmas(B0{}, true); }
@@ -430,6 +474,7 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + (WS ? 256 : 512)), 1
       for (int s = 0; s < nsteps; ++s) {
         const unsigned char *ab, *wl;
         step_ptrs(s, ab, wl);
+        bw_prefetch(s);
         load_group(ab, wl, 0, B0{});
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -465,14 +510,14 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + (WS ? 256 : 512)), 1
   }
 }
 
-template <typename T, int ND, bool WS, bool SMALL>
+template <typename T, int ND, bool WS, bool SMALL, bool BW = false>
 int launch_v4(ConvV4Params p, hipStream_t stream) {
   using TL = V4Tile<ND, SMALL>;
   constexpr int NPIX = (TL::TZ + 2 * TL::PADZ) * (TL::TY + 2) * (TL::TX + 2);
   constexpr int PLANE = ((NPIX * 16 + 255) / 256) * 256;
   constexpr int WSTEP = TL::S16 * ((TL::NCOL + 1) / 2) * 3 * 2 * 1024;
-  const int lds = 2 * 2 * TL::S16 * PLANE + (WS ? p.Cin / (16 * TL::S16) : 2) * WSTEP + 2048 + p.Cin * 8;
-  IUNET_SET_MAX_LDS((conv3_v4_kernel<T, ND, WS, SMALL>), lds);
+  const int lds = 2 * 2 * TL::S16 * PLANE + (WS ? p.Cin / (16 * TL::S16) : 2) * WSTEP + 2048 + p.Cin * 8 + 512;
+  IUNET_SET_MAX_LDS((conv3_v4_kernel<T, ND, WS, SMALL, BW>), lds);
   p.tilesZ = (p.D + TL::TZ - 1) / TL::TZ; p.tilesY = (p.H + TL::TY - 1) / TL::TY; p.tilesX = (p.W + TL::TX - 1) / TL::TX;
   const int ncob = p.Cout / 32;
   // one workgroup per CU: 8 XCDs x (bz x by x bx) brick slots per Cout tile
@@ -486,7 +531,7 @@ int launch_v4(ConvV4Params p, hipStream_t stream) {
     if (gx < rows)
       IUNET_CHECK_HIP(hipMemsetAsync(p.stats + (long long)gx * p.Cout * 2, 0, (size_t)(rows - gx) * p.Cout * 2 * sizeof(float), stream));
   }
-  hipLaunchKernelGGL((conv3_v4_kernel<T, ND, WS, SMALL>), dim3(gx, ncob), dim3(TL::NCW * 64 + (WS ? 256 : 512)), lds, stream, p);
+  hipLaunchKernelGGL((conv3_v4_kernel<T, ND, WS, SMALL, BW>), dim3(gx, ncob), dim3(TL::NCW * 64 + (WS ? 256 : 512)), lds, stream, p);
   IUNET_CHECK_HIP(hipGetLastError());
   return IUNET_OK;
 }
@@ -502,12 +547,17 @@ int iunet_conv3_v4_stats_parts(int nd, int Cout) {
 
 int iunet_conv3_v4_launch(int dtype, int nd, const void* x, long long x_sstride, void* y, long long y_sstride, const void* wpk,
                           const float* bias, float* stats, int N, int D, int H, int W, int Cin, int Cout, int epi,
-                          const float* in_scale, const float* in_shift, hipStream_t stream) {
+                          const float* in_scale, const float* in_shift, hipStream_t stream, const void* bw_y, long long bw_y_ss,
+                          const float* const* bw_par) {
   IUNET_REQUIRE(Cin % 32 == 0 && Cout % 32 == 0, "conv3 layout 2: Cin %% 32, Cout %% 32 (got %d -> %d)", Cin, Cout);
   ConvV4Params p;
   p.x = x; p.x_sstride = x_sstride; p.y = y; p.y_sstride = y_sstride; p.wpk = wpk; p.bias = bias; p.stats = stats;
   p.N = N; p.D = D; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.epi = epi;
   p.in_scale = in_scale; p.in_shift = in_shift;
+  p.bw_y = bw_y; p.bw_y_ss = bw_y_ss;
+  p.bw_mean = bw_y ? bw_par[0] : nullptr; p.bw_invstd = bw_y ? bw_par[1] : nullptr;
+  p.bw_scale = bw_y ? bw_par[2] : nullptr; p.bw_shift = bw_y ? bw_par[3] : nullptr;
+  IUNET_REQUIRE(bw_y == nullptr || stats != nullptr, "conv3 layout 2: the fused BatchNorm-backward sums need a statistics buffer");
   p.tilesZ = p.tilesY = p.tilesX = 0;
   p.bz = p.by = p.bx = p.nbz = p.nby = p.nbx = 0;
   static const int dbg = getenv("IUNET_V4_DBG") ? atoi(getenv("IUNET_V4_DBG")) : 0;
@@ -518,9 +568,10 @@ int iunet_conv3_v4_launch(int dtype, int nd, const void* x, long long x_sstride,
   // 16^3 level: 1.4-1.6x faster there; at 128 of 256 CUs the doubled weight streaming costs more than the idle CUs)
   const long long big_tiles = (long long)N * ((D + 3) / 4) * ((H + 7) / 8) * ((W + 15) / 16);
   const bool small = nd == 3 && !ws && big_tiles * (Cout / 32) < 128;
-#define V4_GO(TT) (nd == 3 ? (ws ? launch_v4<TT, 3, true, false>(p, stream)                                          \
-                                 : (small ? launch_v4<TT, 3, false, true>(p, stream) : launch_v4<TT, 3, false, false>(p, stream))) \
-                           : (ws ? launch_v4<TT, 2, true, false>(p, stream) : launch_v4<TT, 2, false, false>(p, stream)))
-  return dtype == 0 ? V4_GO(f16) : V4_GO(bf16);
+#define V4_GO(TT, BWV) (nd == 3 ? (ws ? launch_v4<TT, 3, true, false, BWV>(p, stream)                                          \
+                                      : (small ? launch_v4<TT, 3, false, true, BWV>(p, stream) : launch_v4<TT, 3, false, false, BWV>(p, stream))) \
+                                : (ws ? launch_v4<TT, 2, true, false, BWV>(p, stream) : launch_v4<TT, 2, false, false, BWV>(p, stream)))
+  if (bw_y != nullptr) return dtype == 0 ? V4_GO(f16, true) : V4_GO(bf16, true);
+  return dtype == 0 ? V4_GO(f16, false) : V4_GO(bf16, false);
 #undef V4_GO
 }

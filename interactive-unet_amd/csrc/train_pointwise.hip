@@ -850,6 +850,26 @@ int iunet_bn_relu_bwd(int dtype, const void* dz, long long dz_ss, const void* z,
   return IUNET_OK;
 }
 
+// iunet_bn_relu_bwd whose first pass has already been done: `slab` holds nparts rows [C][2] of (sum dz', sum dz' * xhat) written by
+// the data-gradient launch that produced dz (iunet_conv3_dgrad_bnstats).  Finalize (dgamma, dbeta, coefficients) + pass 2
+// (dy; NULL: the consumer applies it).
+int iunet_bn_relu_bwd_apply(int dtype, const void* dz, long long dz_ss, const void* y, long long y_ss, void* dy, long long dy_ss,
+                            const void* mean, const void* invstd, const void* gamma, const void* scale, const void* shift,
+                            void* dgamma, void* dbeta, const void* slab, int nparts, void* coef, int C, int N, long long vox,
+                            void* stream) {
+  DT_OK(dtype);
+  IUNET_REQUIRE(dz && y && slab && coef && scale && shift && mean && invstd && gamma && dgamma && dbeta, "bn_relu_bwd_apply: null pointer");
+  IUNET_REQUIRE(C > 0 && C % 8 == 0 && N > 0 && vox > 0 && nparts > 0, "bn_relu_bwd_apply: C %d, N %d, %lld voxels, %d rows", C, N, vox, nparts);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, (const float*)slab, nparts, C,
+                     (double)N * (double)vox, (const float*)gamma, (const float*)invstd, (float*)dgamma, (float*)dbeta, (float*)coef);
+  if (dy == nullptr) { IUNET_CHECK_HIP(hipGetLastError()); return IUNET_OK; }
+  dim3 g2((unsigned)((vox + 511) / 512), C / 8, N);
+  if (dtype == 0) hipLaunchKernelGGL(bn_bwd_apply_kernel<f16>, g2, dim3(256), 0, (hipStream_t)stream, (const f16*)dz, dz_ss, (const f16*)nullptr, 0LL, (const f16*)y, y_ss, (f16*)dy, dy_ss, (const float*)mean, (const float*)invstd, (const float*)coef, (const float*)scale, (const float*)shift, C / 8, vox);
+  else hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16>, g2, dim3(256), 0, (hipStream_t)stream, (const bf16*)dz, dz_ss, (const bf16*)nullptr, 0LL, (const bf16*)y, y_ss, (bf16*)dy, dy_ss, (const float*)mean, (const float*)invstd, (const float*)coef, (const float*)scale, (const float*)shift, C / 8, vox);
+  IUNET_CHECK_HIP(hipGetLastError());
+  return IUNET_OK;
+}
+
 /* ---- GroupNorm + ReLU (north_star "GroupNorm/BN") ------------------------------------------------------- */
 int iunet_gn_num_parts(int N, long long vox) { return iunet_bn_bwd_num_parts(N, vox); }
 

@@ -70,6 +70,10 @@ _SIGS = {
     'iunet_bn_relu_pool_fwd': [c_int, c_int, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_void_p,
                                c_int, c_int, c_int, c_int, c_int, c_void_p],
     'iunet_bn_bwd_num_parts': [c_int, c_ll],
+    'iunet_conv3_dgrad_bnstats': [c_int, c_int, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_void_p, c_void_p, c_ll, c_void_p, c_void_p,
+                                  c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    'iunet_bn_relu_bwd_apply': [c_int, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_ll, c_void_p],
     'iunet_gn_num_parts': [c_int, c_ll],
     'iunet_gn_relu_fwd': [c_int, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p,
                           c_void_p, c_void_p, c_int, c_int, c_ll, c_void_p],

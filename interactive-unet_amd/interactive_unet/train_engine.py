@@ -60,6 +60,10 @@ class TrainEngine:
         self.gn = self.norm == 'group'
         if self.gn:
             self.fuse_act = False
+        # the BatchNorm-backward sums of a stage's conv1 ride in the epilogue of conv2's data gradient (IUNET_NO_BW_FUSION=1: separate
+        # reduction pass, for A/B runs)
+        self.fuse_bw = not self.gn and not os.environ.get('IUNET_NO_BW_FUSION')
+        self._bw_ready = {}
         self._flatten()
         if self.pg is not None:
             # every rank continues from rank 0's weights and BatchNorm statistics (each rank's module drew its own
@@ -336,7 +340,11 @@ class TrainEngine:
 
     # ------------------------------------------------------------------ backward
     def _stage_conv_bwd(self, ws, name, dz_ptr, dz_ss, z_ptr, z_ss, x_ptr, x_ss, ci, co, l, dx_ptr, dx_ss, N,
-                        x_raw=None, x_act=None, pool_bwd=None):
+                        x_raw=None, x_act=None, pool_bwd=None, feeds=None):
+        """Backward of one stage conv: BatchNorm + ReLU backward, weight gradient, data gradient.  `feeds`: name of the layer
+        whose activation is this conv's only input (a stage's conv1 for its conv2) -- the data-gradient launch then also
+        accumulates that layer's BatchNorm-backward sums in its epilogue (iunet_conv3_dgrad_bnstats), and that layer's own
+        call skips its reduction pass (one read of dz and y less per conv1)."""
         d = ws['dims'][l]
         v = _vox(d)
         s = nv.stream()
@@ -359,6 +367,14 @@ class TrainEngine:
                     nv.ptr(self.p(bn + '.weight')), nv.ptr(ws['scale.' + name]), nv.ptr(ws['shift.' + name]),
                     nv.ptr(self.g(bn + '.weight')), nv.ptr(self.g(bn + '.bias')),
                     nv.ptr(ws['bnslab']), nv.ptr(ws['bncoef']), co, N, do[0], do[1], do[2], s)
+        elif name in self._bw_ready:
+            # pass 1 was done by the data-gradient launch that produced dz: finalize its rows, then pass 2
+            nparts = self._bw_ready.pop(name)
+            nv.call('iunet_bn_relu_bwd_apply', self.dt, dz_ptr, dz_ss, self._P(ws['y.' + name]), co * v,
+                    None if first else self._P(dy), co * v, nv.ptr(ws['mean.' + name]), nv.ptr(ws['invstd.' + name]),
+                    nv.ptr(self.p(bn + '.weight')), nv.ptr(ws['scale.' + name]), nv.ptr(ws['shift.' + name]),
+                    nv.ptr(self.g(bn + '.weight')), nv.ptr(self.g(bn + '.bias')), nv.ptr(ws['stats']), nparts,
+                    nv.ptr(ws['bncoef']), co, N, v, s)
         else:
             # z is not passed: the ReLU mask is recomputed from y (saves one tensor read in each of the two passes).
             # First layer: only the sums (dy = NULL) -- its single consumer, the weight gradient, applies pass 2 itself.
@@ -388,8 +404,15 @@ class TrainEngine:
                         N, d[0], d[1], d[2], ci, co, s)
             _, pkd = self.pk[name]
             lay, wd = pkd.pick(self.dim, N, *d)
-            nv.call('iunet_conv3_fwd', self.dt, self.dim, self._P(dy), co * v, dx_ptr, dx_ss, nv.ptr(wd), None, None,
-                    N, d[0], d[1], d[2], co, ci, 0, lay, s)
+            if feeds is not None and lay == 2 and self.fuse_bw:
+                nv.call('iunet_conv3_dgrad_bnstats', self.dt, self.dim, self._P(dy), co * v, dx_ptr, dx_ss, nv.ptr(wd),
+                        nv.ptr(ws['stats']), self._P(ws['y.' + feeds]), ci * v, nv.ptr(ws['mean.' + feeds]),
+                        nv.ptr(ws['invstd.' + feeds]), nv.ptr(ws['scale.' + feeds]), nv.ptr(ws['shift.' + feeds]),
+                        N, d[0], d[1], d[2], co, ci, s)
+                self._bw_ready[feeds] = nv.lib().iunet_conv3_stats_parts(self.dim, N, d[0], d[1], d[2], ci, 2)
+            else:
+                nv.call('iunet_conv3_fwd', self.dt, self.dim, self._P(dy), co * v, dx_ptr, dx_ss, nv.ptr(wd), None, None,
+                        N, d[0], d[1], d[2], co, ci, 0, lay, s)
 
     def backward(self, ws, x, x_strides, y, w, tdt, N):
         L, ch, dims = self.levels, self.ch, ws['dims']
@@ -414,7 +437,7 @@ class TrainEngine:
             dz1, dz2 = ws[f'dz.dec{l}.conv1'], ws[f'dz.dec{l}.conv2']
             x2, act, _ = self._conv2_input(ws, f'dec{l}', l, N)
             self._stage_conv_bwd(ws, f'dec{l}.conv2', self._P(dz2), ch[l] * v, self._P(z2), ch[l] * v, x2,
-                                 ch[l] * v, ch[l], ch[l], l, self._P(dz1), ch[l] * v, N, x_act=act)
+                                 ch[l] * v, ch[l], ch[l], l, self._P(dz1), ch[l] * v, N, x_act=act, feeds=f'dec{l}.conv1')
             self._stage_conv_bwd(ws, f'dec{l}.conv1', self._P(dz1), ch[l] * v, self._P(z1), ch[l] * v,
                                  self._P(ws[f'cat{l}']), 2 * ch[l] * v, 2 * ch[l], ch[l], l, self._P(ws[f'dcat{l}']),
                                  2 * ch[l] * v, N)
@@ -447,7 +470,7 @@ class TrainEngine:
                 z2_ptr, z2_ss = self._P(ws[f'cat{l}']), 2 * ch[l] * v
             x2, act, _ = self._conv2_input(ws, f'enc{l}', l, N)
             self._stage_conv_bwd(ws, f'enc{l}.conv2', dz2_ptr, dz2_ss, z2_ptr, z2_ss, x2, ch[l] * v, ch[l],
-                                 ch[l], l, self._P(dz1), ch[l] * v, N, x_act=act, pool_bwd=pool_bwd)
+                                 ch[l], l, self._P(dz1), ch[l] * v, N, x_act=act, pool_bwd=pool_bwd, feeds=f'enc{l}.conv1')
             if l == 0:
                 self._stage_conv_bwd(ws, 'enc0.conv1', self._P(dz1), ch[0] * v, self._P(z1), ch[0] * v, None, 0,
                                      self.cin, ch[0], 0, None, 0, N, x_raw=(x, x_strides))
