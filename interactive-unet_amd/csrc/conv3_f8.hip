@@ -405,27 +405,29 @@ __global__ __launch_bounds__(256) void pack_f8_kernel(const float* __restrict__ 
     wscale[co] = sc;
     if (bias_out) bias_out[co] = gamma ? beta[co] - mean[co] * fs : 0.f;
   }
-  // elements of this output channel in the K16 order [cob32][chunk16][column pair][dy][2][64][8]
+  // elements of this output channel in the K16 order [cob32][chunk16][column pair][dy][2][64][8]: one thread = the 8 bytes of
+  // one lane slot (8 consecutive input channels of one tap), written as one 8-byte store
   const int ncol = taps / 3, ncmb = (ncol + 1) / 2, nchunk = Cin >> 4;
   const int cob = co >> 5, r32 = co & 31;
   const int mt = (r32 >> 2) & 1, row = (r32 >> 3) * 4 + (r32 & 3);       // co = cob*32 + 8 (row >> 2) + 4 m + (row & 3)
-  for (int i = threadIdx.x; i < nchunk * ncmb * 3 * 4 * 8; i += 256) {   // (chunk, c, dy, qq, j)
+  for (int i = threadIdx.x; i < nchunk * ncmb * 3 * 4; i += 256) {       // (chunk, c, dy, qq)
     int r = i;
-    const int j = r & 7; r >>= 3;
     const int qq = r & 3; r >>= 2;
     const int dy = r % 3; r /= 3;
     const int c = r % ncmb;
     const int chunk = r / ncmb;
-    const int ci = chunk * 16 + 8 * (qq & 1) + j;
     const int col = 2 * c + (qq >> 1);
-    float v = 0.f;
+    unsigned long long pk = 0;
     if (col < ncol) {
       const int tap = ((col / 3) * 3 + dy) * 3 + (col % 3);
-      v = f8_round_e4m3((wc[ci * taps + tap] * fs) / sc);
+      const int ci0 = chunk * 16 + 8 * (qq & 1);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        pk |= (unsigned long long)f8_encode_e4m3(f8_round_e4m3((wc[(ci0 + j) * taps + tap] * fs) / sc)) << (8 * j);
     }
     const int lane = qq * 16 + row;
-    const long long o = ((((((long long)cob * nchunk + chunk) * ncmb + c) * 3 + dy) * 2 + mt) * 64 + lane) * 8 + j;
-    dst[o] = f8_encode_e4m3(v);
+    const long long o = ((((((long long)cob * nchunk + chunk) * ncmb + c) * 3 + dy) * 2 + mt) * 64 + lane) * 8;
+    *(unsigned long long*)(dst + o) = pk;
   }
 }
 

@@ -177,7 +177,9 @@ int iunet_pack_batch(const void* descs, int n, int quant_max_cout, void* stream)
   IUNET_REQUIRE(descs && n > 0, "pack_batch: empty descriptor table");
   if (quant_max_cout > 0)
     hipLaunchKernelGGL(pack_qscale_kernel, dim3(quant_max_cout, n), dim3(256), 0, (hipStream_t)stream, (const PackDesc*)descs);
-  hipLaunchKernelGGL(pack_batch_kernel, dim3(256, n), dim3(256), 0, (hipStream_t)stream, (const PackDesc*)descs);
+  // 1024 workgroups per layer (grid-stride; the small layers' surplus exits at once): the largest operators (28 M elements in C5) need
+  // more than one workgroup per CU to hide their gather latency
+  hipLaunchKernelGGL(pack_batch_kernel, dim3(1024, n), dim3(256), 0, (hipStream_t)stream, (const PackDesc*)descs);
   IUNET_CHECK_HIP(hipGetLastError());
   return IUNET_OK;
 }

@@ -215,7 +215,10 @@ class PackedConv:
         self.out_ch = cin if dgrad else cout
         self.dt = DTYPE_CODE[dtype]
         self.buf = {1: torch.empty(pack_conv3_elems(cout, cin, taps, 2 | self.dg), dtype=dtype, device=device)}
-        if self.out_ch % 64 == 0:
+        # layout 0 is only ever picked for 2-D launches with more than 64 input channels (iunet_conv3_pick_layout: every 3-D conv
+        # and the narrow 2-D ones run on the K16 operator): packing it for the others was half of the per-step pack work
+        in_ch = cout if dgrad else cin
+        if self.out_ch % 64 == 0 and taps == 9 and in_ch > 64:
             self.buf[0] = torch.empty(pack_conv3_elems(cout, cin, taps, self.dg), dtype=dtype, device=device)
 
     def pack(self, w, scale=None):
