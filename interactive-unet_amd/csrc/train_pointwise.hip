@@ -728,6 +728,130 @@ __global__ __launch_bounds__(256) void head_loss_bwd_kernel(HeadLossParams p) {
   block_reduce_store<NCLS>(accb, red, slab + PL * NCLS * 8);
 }
 
+// The same backward for the shapes whose dW partials do not fit the register file (PL * NCLS > 16: base 64 with three or
+// more classes, base 32 with five or more).  Two phases per 256-voxel chunk: (1) one thread per voxel computes dl and
+// dx = W^T dl and parks its x planes and dl in LDS; (2) the workgroup re-reads them as 256 / PL voxel lanes per channel
+// plane, so a thread carries NCLS x 8 dW partials only.  One cross-lane reduction per HEAD_BWD_WIDE_ITER chunks.
+#define HEAD_BWD_WIDE_ITER 8
+template <typename T, int NCLS, int PL>
+__global__ __launch_bounds__(256) void head_loss_bwd_wide_kernel(HeadLossParams p) {
+  constexpr int C0 = PL * 8, SUBS = 256 / PL;
+  const int n = blockIdx.y, t = threadIdx.x;
+  __shared__ V8T<T> xs[PL][256];
+  __shared__ float dls[256][NCLS];
+  __shared__ float red[4 * NCLS];
+  float accw[NCLS][8], accb[NCLS];
+#pragma unroll
+  for (int c = 0; c < NCLS; ++c) {
+    accb[c] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) accw[c][j] = 0.f;
+  }
+  const int mypl = t / SUBS, sub = t % SUBS;
+#pragma unroll 1
+  for (int it = 0; it < HEAD_BWD_WIDE_ITER; ++it) {
+    const long long v0 = ((long long)blockIdx.x * HEAD_BWD_WIDE_ITER + it) * 256;
+    if (v0 >= p.vox) break;
+    const long long v = v0 + t;
+    const bool live = v < p.vox;
+    V8T<T> xv[PL];
+    float dl[NCLS];
+#pragma unroll
+    for (int c = 0; c < NCLS; ++c) dl[c] = 0.f;
+    if (live) {
+      const T* xin = (const T*)p.x + n * p.x_ss + v * 8;
+#pragma unroll
+      for (int pl = 0; pl < PL; ++pl) xv[pl] = *(const V8T<T>*)(xin + (long long)pl * p.vox * 8);
+      float l[NCLS];
+#pragma unroll
+      for (int c = 0; c < NCLS; ++c) l[c] = p.bias[c];
+#pragma unroll
+      for (int pl = 0; pl < PL; ++pl)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float a = to_f32<T>(xv[pl][j]);
+#pragma unroll
+          for (int c = 0; c < NCLS; ++c) l[c] = fmaf(a, p.w[c * C0 + pl * 8 + j], l[c]);
+        }
+      float mx = l[0];
+#pragma unroll
+      for (int c = 1; c < NCLS; ++c) mx = fmaxf(mx, l[c]);
+      float e[NCLS], s = 0.f;
+#pragma unroll
+      for (int c = 0; c < NCLS; ++c) { e[c] = __expf(l[c] - mx); s += e[c]; }
+      const float inv = 1.f / s;
+      float g[NCLS], dot = 0.f;
+#pragma unroll
+      for (int c = 0; c < NCLS; ++c) {
+        const float pr = e[c] * inv;
+        const long long to = ((long long)n * NCLS + c) * p.vox + v;
+        const float y = load_t(p.target, to, p.tdtype);
+        const float w = p.weight ? load_t(p.weight, to, p.tdtype) : 1.f;
+        g[c] = w * (p.coef[c * 3] + p.coef[c * 3 + 1] * y) - p.coef[c * 3 + 2] * w * y / (pr + 1e-12f);
+        e[c] = pr;
+        dot += g[c] * pr;
+      }
+#pragma unroll
+      for (int c = 0; c < NCLS; ++c) { dl[c] = e[c] * (g[c] - dot) * p.loss_scale; accb[c] += dl[c]; }   // softmax backward
+      T* dxo = (T*)p.dx + n * p.dx_ss + v * 8;
+#pragma unroll
+      for (int pl = 0; pl < PL; ++pl) {
+        V8T<T> o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float a = 0.f;
+#pragma unroll
+          for (int c = 0; c < NCLS; ++c) a = fmaf(dl[c], p.w[c * C0 + pl * 8 + j], a);
+          o[j] = from_f32<T>(a);                        // dx = W^T dl
+        }
+        *(V8T<T>*)(dxo + (long long)pl * p.vox * 8) = o;
+      }
+    }
+    __syncthreads();                                    // the previous chunk's phase 2 has read xs / dls
+#pragma unroll
+    for (int c = 0; c < NCLS; ++c) dls[t][c] = dl[c];   // dl = 0 for a voxel past the end: its stale x adds nothing
+    if (live) {
+#pragma unroll
+      for (int pl = 0; pl < PL; ++pl) xs[pl][t] = xv[pl];
+    } else {
+      V8T<T> z;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) z[j] = from_f32<T>(0.f);
+#pragma unroll
+      for (int pl = 0; pl < PL; ++pl) xs[pl][t] = z;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < PL; ++i) {                      // dW[c][mypl*8 + j] += dl[c][v] x[mypl*8 + j][v]
+      const int vv = sub + i * SUBS;
+      const V8T<T> xq = xs[mypl][vv];
+      float d[NCLS];
+#pragma unroll
+      for (int c = 0; c < NCLS; ++c) d[c] = dls[vv][c];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float xa = to_f32<T>(xq[j]);
+#pragma unroll
+        for (int c = 0; c < NCLS; ++c) accw[c][j] = fmaf(d[c], xa, accw[c][j]);
+      }
+    }
+  }
+  // slab layout per part: [planes][NCLS][8] weight partials, then [NCLS] bias partials
+  const long long part = (long long)n * gridDim.x + blockIdx.x;
+  float* slab = p.dwslab + part * (NCLS * (C0 + 1));
+#pragma unroll
+  for (int c = 0; c < NCLS; ++c)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float a = accw[c][j];
+#pragma unroll
+      for (int o = SUBS / 2; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+      if (sub == 0) slab[mypl * NCLS * 8 + c * 8 + j] = a;
+    }
+  __syncthreads();
+  block_reduce_store<NCLS>(accb, red, slab + PL * NCLS * 8);
+}
+
 // out[i] = alpha * sum_p slab[p][i] (+ out[i] if accumulate); fixed order.
 __global__ __launch_bounds__(256) void reduce_slab_kernel(const float* __restrict__ slab, int nparts, long long n,
                                                           float* __restrict__ out, float alpha, int accumulate) {
@@ -985,7 +1109,7 @@ int iunet_head_loss_num_parts(int N, long long vox) { return N * (int)((vox + 25
 
 // partial-sum rows written by iunet_head_loss_bwd (each workgroup covers 256 * iter voxels)
 int iunet_head_loss_bwd_num_parts(int N, long long vox, int ncls, int C0) {
-  const int iter = (ncls <= 4 && (C0 / 8) * ncls <= 16) ? 8 : 1;
+  const int iter = (C0 / 8) * ncls <= 16 ? 8 : HEAD_BWD_WIDE_ITER;       // register kernel : LDS kernel (head_loss_bwd_wide_kernel)
   return N * (int)((vox + 256LL * iter - 1) / (256LL * iter));
 }
 
@@ -1036,7 +1160,8 @@ int iunet_head_loss_bwd(int dtype, const void* x, long long x_ss, int C0, const 
   p.dx = dx; p.dx_ss = dx_ss; p.dwslab = (float*)dwslab; p.N = N; p.vox = vox;
   IUNET_REQUIRE(C0 == 32 || C0 == 64, "head_loss_bwd: head input must have 32 or 64 channels (got %d)", C0);
   dim3 grid((unsigned)(iunet_head_loss_bwd_num_parts(N, vox, ncls, C0) / N), N);
-#define HB(TT, NC, PLN) hipLaunchKernelGGL((head_loss_bwd_kernel<TT, NC, PLN>), grid, dim3(256), 0, (hipStream_t)stream, p)
+#define HB(TT, NC, PLN) do { if constexpr (PLN * NC <= 16) hipLaunchKernelGGL((head_loss_bwd_kernel<TT, NC, PLN>), grid, dim3(256), 0, (hipStream_t)stream, p); \
+    else hipLaunchKernelGGL((head_loss_bwd_wide_kernel<TT, NC, PLN>), grid, dim3(256), 0, (hipStream_t)stream, p); } while (0)
 #define HB_SWITCH(TT, PLN) switch (ncls) { case 2: HB(TT, 2, PLN); break; case 3: HB(TT, 3, PLN); break; case 4: HB(TT, 4, PLN); break; \
     case 5: HB(TT, 5, PLN); break; case 6: HB(TT, 6, PLN); break; case 7: HB(TT, 7, PLN); break; case 8: HB(TT, 8, PLN); break; \
     case 9: HB(TT, 9, PLN); break; default: HB(TT, 10, PLN); break; }

@@ -191,9 +191,21 @@ def test_first_conv_wgrad(nv, nd):
 def test_head_loss_fwd_bwd_vs_reference_pinned_oracle(nv, kind, weighted):
     """Loss value and d loss / d logits of the fused HIP head+softmax+loss against
     oracle/metrics_ref.py (pinned to the reference's metrics.py by the goldens), axes=[0,2,3]."""
+    _head_loss_case(nv, kind, weighted, 32, 3, (20, 28))
+
+
+@pytest.mark.parametrize('C0,ncls,shape', [(64, 2, (20, 28)), (64, 4, (40, 59)), (64, 3, (16, 16)), (32, 6, (48, 50)), (64, 10, (33, 31)),
+                                           (32, 4, (70, 64))])
+def test_head_loss_bwd_kernel_variants(nv, C0, ncls, shape):
+    """Both backward kernels (dW partials in registers; in LDS for PL * ncls > 16), sizes that end inside a 256-voxel chunk and
+    that span several workgroups."""
+    _head_loss_case(nv, 'dice_ce', True, C0, ncls, shape)
+
+
+def _head_loss_case(nv, kind, weighted, C0, ncls, shape):
     from interactive_unet.train_engine import LOSS_KINDS
     g = torch.Generator().manual_seed(16)
-    N, C0, ncls, shape = 2, 32, 3, (20, 28)
+    N = 2
     vox = shape[0] * shape[1]
     x = torch.randn((N, C0) + shape, generator=g).half().float()
     w = torch.randn(ncls, C0, generator=g) * 0.3
