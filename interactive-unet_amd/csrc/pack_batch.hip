@@ -129,14 +129,106 @@ __device__ __forceinline__ float elem(const PackDesc& d, long long i, int& oc) {
   }
 }
 
+// The 8 elements of one 16-byte granule (j = 0..7) differ in the input channel only: one index decode per granule, then 8 loads
+// at a fixed stride.  Returns false for a zero granule (the padded partner column of the K16 order).  kind 2 (first conv: k runs
+// over taps and channels) is decoded per element by elem().
+__device__ __forceinline__ bool granule(const PackDesc& d, int r, const float*& src, long long& stride, float& fs, int& oc) {
+  oc = 0; fs = 1.0f;
+  const int lane = r & 63; r >>= 6;
+  const int row = lane & 15, qq = lane >> 4;
+  if (d.kind == 0) {
+    const int CoutP = d.dgrad ? d.Cin : d.Cout, CinP = d.dgrad ? d.Cout : d.Cin;
+    const int MI = (CoutP % 64 == 0) ? 4 : 2, nchunk = CinP >> 5;
+    const int m = r % MI; r /= MI;
+    const int tap = r % d.taps; r /= d.taps;
+    const int chunk = r % nchunk, cob = r / nchunk;
+    const int co = cob * 16 * MI + 32 * (m >> 1) + 8 * (row >> 2) + 4 * (m & 1) + (row & 3);
+    const int ci = chunk * 32 + 8 * qq;
+    oc = co;
+    if (!d.dgrad) { src = d.w + ((long long)co * d.Cin + ci) * d.taps + tap; stride = d.taps; fs = fold_scale(d, co); }
+    else { src = d.w + ((long long)ci * d.Cin + co) * d.taps + (d.taps - 1 - tap); stride = (long long)d.Cin * d.taps; }
+    return true;
+  }
+  if (d.kind == 1) {
+    const int CinP = d.dgrad ? d.Cout : d.Cin;
+    const int ncol = d.taps / 3, ncmb = (ncol + 1) / 2, nchunk = CinP >> 4;
+    const int m = r & 1; r >>= 1;
+    const int dy = r % 3; r /= 3;
+    const int c = r % ncmb; r /= ncmb;
+    const int chunk = r % nchunk, cob = r / nchunk;
+    const int co = cob * 32 + 8 * (row >> 2) + 4 * m + (row & 3);
+    const int ci = chunk * 16 + 8 * (qq & 1);
+    const int col = 2 * c + (qq >> 1);
+    if (col >= ncol) return false;
+    const int tap = ((col / 3) * 3 + dy) * 3 + (col % 3);
+    oc = co;
+    if (!d.dgrad) { src = d.w + ((long long)co * d.Cin + ci) * d.taps + tap; stride = d.taps; fs = fold_scale(d, co); }
+    else { src = d.w + ((long long)ci * d.Cin + co) * d.taps + (d.taps - 1 - tap); stride = (long long)d.Cin * d.taps; }
+    return true;
+  }
+  const int npos = d.taps;
+  if (d.kind == 3) {
+    const int nk = d.Cin >> 5;
+    const int t = r & 1; r >>= 1;
+    const int s = r % npos; r /= npos;
+    const int ks = r % nk, cob = r / nk;
+    const int co = cob * 32 + 8 * (row >> 2) + 4 * t + (row & 3);
+    const int ci = ks * 32 + 8 * qq;
+    oc = co;
+    src = d.w + ((long long)ci * d.Cout + co) * npos + s; stride = (long long)d.Cout * npos;
+    return true;
+  }
+  {
+    const int nk = d.Cout >> 5;
+    const int t = r & 1; r >>= 1;
+    const int kc = r % nk; r /= nk;
+    const int s = r % npos, cib = r / npos;
+    const int ci = cib * 32 + 8 * (row >> 2) + 4 * t + (row & 3);
+    const int co = kc * 32 + 8 * qq;
+    src = d.w + ((long long)ci * d.Cout + co) * npos + s; stride = npos;
+    return true;
+  }
+}
+
 __global__ __launch_bounds__(256) void pack_batch_kernel(const PackDesc* __restrict__ descs) {
   const PackDesc d = descs[blockIdx.y];
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < d.total; i += (long long)gridDim.x * 256) {
-    int oc;
-    float v = elem(d, i, oc);
-    if (d.qscale) { const float sc = d.qscale[oc]; v = sc * round_e4m3(v / sc); }
-    if (d.dtype == 0) ((f16*)d.dst)[i] = from_f32<f16>(v);
-    else ((bf16*)d.dst)[i] = from_f32<bf16>(v);
+  const bool fold = d.gamma != nullptr && !d.dgrad && d.kind <= 1;     // the kinds whose elem() multiplies by the folded scale
+  for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g * 8 < d.total; g += (long long)gridDim.x * 256) {
+    float v[8];
+    int oc = 0;
+    if (d.kind == 2) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = elem(d, g * 8 + j, oc);
+    } else {
+      const float* src; long long stride; float fs;
+      if (granule(d, (int)g, src, stride, fs, oc)) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = src[j * stride];
+        if (fold) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = mul_rn(v[j], fs);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = 0.f;
+      }
+    }
+    if (d.qscale) {
+      const float sc = d.qscale[oc];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = sc * round_e4m3(v[j] / sc);
+    }
+    if (d.dtype == 0) {
+      typename Vec8<f16>::type o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = from_f32<f16>(v[j]);
+      *(typename Vec8<f16>::type*)((f16*)d.dst + g * 8) = o;
+    } else {
+      typename Vec8<bf16>::type o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = from_f32<bf16>(v[j]);
+      *(typename Vec8<bf16>::type*)((bf16*)d.dst + g * 8) = o;
+    }
   }
   if (d.bias_out && blockIdx.x == 0) {
     for (int co = threadIdx.x; co < d.Cout; co += 256)      // separately rounded, as the host formula beta - mean * scale
