@@ -190,8 +190,95 @@ __device__ __forceinline__ bool granule(const PackDesc& d, int r, const float*& 
   }
 }
 
+// K16 operators (every 3^d conv of the network: all but a few thousand of the elements a step packs) go through LDS: one
+// workgroup per (32-output-channel tile, 16-channel chunk) block reads the block's source rows as whole 16-byte runs -- 32 rows of
+// 16 x taps floats (forward: w[co][chunk]), 16 rows of 32 x taps floats (data gradient: w[chunk][co tile]) -- and writes the
+// block's 30 KB (3-D) of packed operator from there.  The direct gather of pack_batch_kernel's other kinds touches a 128-byte line
+// for 4 useful bytes at a time: on C5's 90 M parameters that was ~1 ms per step.
+__device__ __forceinline__ void pack_k16_block(const PackDesc& d, int blk, float* tile) {
+  const int CoutP = d.dgrad ? d.Cin : d.Cout, CinP = d.dgrad ? d.Cout : d.Cin;
+  const int taps = d.taps, ncol = taps / 3, ncmb = (ncol + 1) / 2, nchunk = CinP >> 4;
+  const int chunk = blk % nchunk, cob = blk / nchunk;
+  (void)CoutP;
+  // ---- source rows -> LDS ----
+  const int nrows = d.dgrad ? 16 : 32, rowlen = (d.dgrad ? 32 : 16) * taps;       // floats; rowlen % 4 == 0
+  const int rl4 = rowlen >> 2;
+  auto row_base = [&](int row) -> long long {
+    return d.dgrad ? ((long long)(chunk * 16 + row) * d.Cin + cob * 32) * taps : ((long long)(cob * 32 + row) * d.Cin + chunk * 16) * taps;
+  };
+  if (((size_t)d.w & 15) == 0) {                       // every row starts on a 16-byte boundary when the tensor does
+    for (int i = threadIdx.x; i < nrows * rl4; i += 256) {
+      const int row = i / rl4, o4 = i - row * rl4;
+      *(f32x4*)(tile + row * rowlen + o4 * 4) = *(const f32x4*)(d.w + row_base(row) + o4 * 4);
+    }
+  } else {                                             // a parameter at an odd offset of the flat vector
+    for (int i = threadIdx.x; i < nrows * rowlen; i += 256) {
+      const int row = i / rowlen, o = i - row * rowlen;
+      tile[row * rowlen + o] = d.w[row_base(row) + o];
+    }
+  }
+  __syncthreads();
+  // ---- granules of this block: [column pair][dy][m][lane] x 8 channels ----
+  const int ngran = ncmb * 3 * 2 * 64;
+  const long long out0 = (long long)blk * ngran;                                 // granule index of the block's first granule
+  for (int r0 = threadIdx.x; r0 < ngran; r0 += 256) {
+    int r = r0;
+    const int lane = r & 63; r >>= 6;
+    const int row = lane & 15, qq = lane >> 4;
+    const int m = r & 1; r >>= 1;
+    const int dy = r % 3, c = r / 3;
+    const int col = 2 * c + (qq >> 1);
+    const int co_l = 8 * (row >> 2) + 4 * m + (row & 3), ci_l = 8 * (qq & 1);
+    const int oc = cob * 32 + co_l;
+    float v[8];
+    if (col < ncol) {
+      const int tap = ((col / 3) * 3 + dy) * 3 + (col % 3);
+      if (!d.dgrad) {
+        const float fs = fold_scale(d, oc);
+        const float* src = tile + co_l * rowlen + ci_l * taps + tap;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = mul_rn(src[j * taps], fs);
+      } else {
+        const float* src = tile + ci_l * rowlen + co_l * taps + (taps - 1 - tap);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = src[j * rowlen];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    }
+    if (d.qscale) {
+      const float sc = d.qscale[col < ncol ? oc : 0];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = sc * round_e4m3(v[j] / sc);
+    }
+    if (d.dtype == 0) {
+      typename Vec8<f16>::type o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = from_f32<f16>(v[j]);
+      *(typename Vec8<f16>::type*)((f16*)d.dst + (out0 + r0) * 8) = o;
+    } else {
+      typename Vec8<bf16>::type o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = from_f32<bf16>(v[j]);
+      *(typename Vec8<bf16>::type*)((bf16*)d.dst + (out0 + r0) * 8) = o;
+    }
+  }
+  __syncthreads();                                     // the tile is reused by this workgroup's next block
+}
+
 __global__ __launch_bounds__(256) void pack_batch_kernel(const PackDesc* __restrict__ descs) {
   const PackDesc d = descs[blockIdx.y];
+  __shared__ __attribute__((aligned(16))) float tile[32 * 16 * 27];               // one K16 block of source weights (54 KB)
+  if (d.kind == 1) {
+    const int CoutP = d.dgrad ? d.Cin : d.Cout, CinP = d.dgrad ? d.Cout : d.Cin;
+    const int nblocks = (CoutP >> 5) * (CinP >> 4);
+    for (int blk = blockIdx.x; blk < nblocks; blk += gridDim.x) pack_k16_block(d, blk, tile);
+    if (d.bias_out && blockIdx.x == 0) {
+      for (int co = threadIdx.x; co < d.Cout; co += 256) d.bias_out[co] = fold_bias(d, co);
+    }
+    return;
+  }
   const bool fold = d.gamma != nullptr && !d.dgrad && d.kind <= 1;     // the kinds whose elem() multiplies by the folded scale
   for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g * 8 < d.total; g += (long long)gridDim.x * 256) {
     float v[8];
