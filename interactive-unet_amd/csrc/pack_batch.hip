@@ -17,7 +17,8 @@ struct PackDesc {                // mirrored by interactive_unet/_native.py: Pac
   void* dst;                     // packed operator
   long long total;               // elements of dst
   int Cout, Cin, taps;           // original operator dims (convT: Cin, Cout, npos in `taps`)
-  int kind;                      // 0 conv3 layout 0, 1 conv3 K16 (layout 1), 2 first conv, 3 convT fwd, 4 convT dgrad
+  int kind;                      // 0 conv3 layout 0, 1 conv3 K16 (layout 1), 2 first conv, 3 convT fwd, 4 convT dgrad,
+                                 // 5 conv3 K16 as OCP e4m3 bytes (conv3_f8.hip's operator; qscale = its per-channel scales, required)
   int dgrad;                     // conv3 only: data-gradient operator
   int dtype;                     // 0 f16, 1 bf16
   float eps;
@@ -42,6 +43,17 @@ __device__ __forceinline__ float e4m3_scale(float amax) {
   int e;
   const float m = frexpf(amax / 448.0f, &e);
   return ldexpf(1.0f, m == 0.5f ? e - 1 : e);
+}
+
+// byte of an e4m3 value (conv3_f8.hip: f8_encode_e4m3): sign | 4 exponent bits (bias 7) | 3 mantissa bits
+__device__ __forceinline__ unsigned char encode_e4m3(float v) {
+  const float a = fabsf(v);
+  const unsigned char s = v < 0.f || (v == 0.f && __builtin_signbit(v)) ? 0x80 : 0;
+  if (a == 0.f) return s;
+  int e;
+  const float m = frexpf(a, &e);                                  // a = m 2^e, m in [0.5, 1)
+  if (e - 1 < -6) return s | (unsigned char)(int)ldexpf(a, 9);    // subnormal: a / 2^-9
+  return s | (unsigned char)(((e - 1 + 7) << 3) | ((int)ldexpf(m, 4) - 8));
 }
 
 // The fold is the IEEE fp32 formula of the host / oracle (oracle/unet_ref.py: fold_bn): every operation rounded
@@ -247,6 +259,16 @@ __device__ __forceinline__ void pack_k16_block(const PackDesc& d, int blk, float
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = 0.f;
     }
+    if (d.kind == 5) {                                 // e4m3 bytes of w * fold / scale (the arithmetic of conv3_f8.hip: pack_f8_kernel)
+      const float sc = d.qscale[oc];
+      unsigned long long pk = 0;
+      if (col < ncol) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pk |= (unsigned long long)encode_e4m3(round_e4m3(v[j] / sc)) << (8 * j);
+      }
+      *(unsigned long long*)((unsigned char*)d.dst + (out0 + r0) * 8) = pk;
+      continue;
+    }
     if (d.qscale) {
       const float sc = d.qscale[col < ncol ? oc : 0];
 #pragma unroll
@@ -270,7 +292,7 @@ __device__ __forceinline__ void pack_k16_block(const PackDesc& d, int blk, float
 __global__ __launch_bounds__(256) void pack_batch_kernel(const PackDesc* __restrict__ descs) {
   const PackDesc d = descs[blockIdx.y];
   __shared__ __attribute__((aligned(16))) float tile[32 * 16 * 27];               // one K16 block of source weights (54 KB)
-  if (d.kind == 1) {
+  if (d.kind == 1 || d.kind == 5) {
     const int CoutP = d.dgrad ? d.Cin : d.Cout, CinP = d.dgrad ? d.Cout : d.Cin;
     const int nblocks = (CoutP >> 5) * (CinP >> 4);
     for (int blk = blockIdx.x; blk < nblocks; blk += gridDim.x) pack_k16_block(d, blk, tile);

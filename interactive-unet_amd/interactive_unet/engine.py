@@ -111,7 +111,7 @@ class Engine:
         src['head.bias'] = self._source(params, 'head.bias')
         sig = tuple(t.data_ptr() for t in src.values())
         if sig != self._eval_sig:
-            P, descs, keep_q, f8 = {}, [], [], []
+            P, descs, keep_q = {}, [], []
             for prefix in self.stage_names():
                 ci, co = self.stage_io(prefix)
                 for j, (a, b) in enumerate(((ci, co), (co, co)), 1):
@@ -136,9 +136,9 @@ class Engine:
                                                   eps=BN_EPS, qscale=qs))
                     elif self.weight_dtype:
                         # config C5: the stage convolutions run on the fp8 matrix cores -- operator stored as e4m3 bytes +
-                        # per-output-channel scales, packed by its own kernel (re-run with the table below)
+                        # per-output-channel scales (descriptor kind 5 of the same table)
                         dst = torch.empty(nv.lib().iunet_f8_pack_conv3_bytes(b, a, self.taps), dtype=torch.uint8, device=self.device)
-                        f8.append((w, bn, dst, qs, bias, b, a))
+                        descs.append(nv.make_desc(w, dst, b, a, self.taps, 5, self.act_dtype, bn=bn, bias_out=bias, eps=BN_EPS, qscale=qs))
                         P[f'{prefix}.conv{j}'] = (F8Conv(dst, qs), bias)
                         keep_q.append(qs)
                         continue
@@ -157,12 +157,8 @@ class Engine:
             P['head'] = (src['head.weight'].reshape(self.ncls, self.ch[0]), src['head.bias'])
             self._eval_table = nv.PackTable(descs, self.device, sources=list(src.values()) + keep_q)
             self._eval_sig = sig
-            self._f8 = f8
             self.packed = P
         self._eval_table.run()
-        for w, bn, dst, qs, bias, b, a in self._f8:
-            nv.call('iunet_f8_pack_conv3', nv.ptr(w), nv.ptr(bn[0]), nv.ptr(bn[1]), nv.ptr(bn[2]), nv.ptr(bn[3]), BN_EPS,
-                    nv.ptr(dst), nv.ptr(qs), nv.ptr(bias), b, a, self.taps, nv.stream())
 
     # ------------------------------------------------------------------ workspace
     def level_dims(self, D, H, W):

@@ -93,6 +93,36 @@ def test_packed_bytes_are_the_oracle_quantisation(nv, nd, cout, cin):
     assert set(np.unique(np.log2(sc.numpy()) % 1)) == {0.0}         # powers of two
 
 
+@pytest.mark.parametrize('nd,cout,cin,fold', [(3, 32, 32, True), (3, 128, 64, True), (2, 64, 96, False), (3, 64, 512, True)])
+def test_pack_table_kind5_equals_the_per_layer_entry(nv, nd, cout, cin, fold):
+    """The engine packs its e4m3 operators through the descriptor table (iunet_pack_batch, kind 5, LDS-staged): bytes, scales and
+    folded bias must equal iunet_f8_pack_conv3's, which the test above pins to the oracle.  The weight tensor sits at an odd
+    float offset of its storage once (the scalar load path of the staging)."""
+    g = torch.Generator().manual_seed(11)
+    taps, dev = 3 ** nd, 'cuda'
+    for off in (0, 3):
+        store = torch.zeros(off + cout * cin * taps, device=dev)
+        w = store[off:].view((cout, cin) + (3,) * nd)
+        w.copy_(torch.randn((cout, cin) + (3,) * nd, generator=g) * 0.05)
+        w[0] *= 30.0
+        bn = [t.to(dev) for t in (0.75 + 0.5 * torch.rand(cout, generator=g), 0.1 * torch.randn(cout, generator=g),
+                                  0.2 * torch.randn(cout, generator=g), 0.5 + torch.rand(cout, generator=g))] if fold else None
+        nb = nv.lib().iunet_f8_pack_conv3_bytes(cout, cin, taps)
+        ref, got = (torch.full((nb,), 0xAA, dtype=torch.uint8, device=dev) for _ in range(2))
+        sc_ref, sc_got = torch.empty(cout, device=dev), torch.empty(cout, device=dev)
+        b_ref, b_got = torch.empty(cout, device=dev), torch.empty(cout, device=dev)
+        bp = [None] * 4 if bn is None else [nv.ptr(t) for t in bn]
+        nv.call('iunet_f8_pack_conv3', nv.ptr(w), bp[0], bp[1], bp[2], bp[3], 1e-5, nv.ptr(ref), nv.ptr(sc_ref),
+                nv.ptr(b_ref) if fold else None, cout, cin, taps, nv.stream())
+        desc = nv.make_desc(w, got, cout, cin, taps, 5, torch.bfloat16, bn=bn, bias_out=b_got if fold else None, eps=1e-5, qscale=sc_got)
+        nv.PackTable([desc], dev, sources=[store, got, sc_got, b_got] + (bn or [])).run()
+        torch.cuda.synchronize()
+        assert torch.equal(sc_got, sc_ref)
+        assert torch.equal(got, ref), (off, int((got != ref).sum()))
+        if fold:
+            assert torch.equal(b_got, b_ref)
+
+
 @pytest.mark.parametrize('dtype', ['bf16', 'f16'])
 @pytest.mark.parametrize('nd,shape,cin,cout', [
     (3, (4, 8, 16), 32, 32), (3, (6, 12, 20), 64, 64), (3, (9, 7, 17), 128, 32), (3, (8, 8, 16), 256, 64),   # 256: streamed weights
