@@ -68,6 +68,9 @@ int iunet_conv3_fwd(int dtype, int nd, const void* x, long long x_sstride, void*
  * 2 = weight-stationary variant of 1 (same mode-bit-1 operator; 3-D, Cin <= 64: all weights of a Cout tile stay
  * in LDS for the whole launch).  Layout 1 or 2 is mandatory when Cout is not a multiple of 64. */
 int iunet_conv3_pick_layout(int nd, int N, int D, int H, int W, int Cin, int Cout);
+/* 1 if a layout-2 launch of this shape walks its tiles in pairs (one weight stream per two tiles: 3-D, streamed weights, an even
+ * number of tiles per workgroup), else 0.  Speed only: the results are the same bits either way.  Exposed for the tests. */
+int iunet_conv3_tile_pairs(int nd, int N, int D, int H, int W, int Cin, int Cout);
 /* iunet_conv3_fwd whose input is relu(in_scale[c] * x + in_shift[c]) (fp32 [Cin] each): in training the BatchNorm + ReLU of
  * the previous conv is applied by the loader waves instead of a separate pass over HBM.  Layout 2 only. */
 int iunet_conv3_fwd_act(int dtype, int nd, const void* x, long long x_sstride, void* y, long long y_sstride,

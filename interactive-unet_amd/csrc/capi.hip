@@ -22,6 +22,7 @@ int iunet_conv3_launch(int dtype, int nd, const void* x, long long x_sstride, vo
                        const float* const* bw_par = nullptr);
 int iunet_conv3_pick(int nd, int N, int D, int H, int W, int Cin, int Cout);
 int iunet_conv3_v4_stats_parts(int nd, int Cout);
+int iunet_conv3_v4_pairs(int nd, int N, int D, int H, int W, int Cin, int Cout, int bw);
 int iunet_conv3_tiles(int nd, int N, int D, int H, int W);
 long long iunet_pack_conv3_size(int Cout, int Cin, int taps, int mode);
 int iunet_conv3_exp_launch(int exp, const void* x, void* y, const void* wpk, const float* bias, int N, int D, int H, int W,
@@ -111,6 +112,11 @@ int iunet_pack_convT(int dtype, const void* w, void* dst, int Cin, int Cout, int
 
 int iunet_conv3_pick_layout(int nd, int N, int D, int H, int W, int Cin, int Cout) {
   return iunet_conv3_pick(nd, N, D, H, W, Cin, Cout);
+}
+
+int iunet_conv3_tile_pairs(int nd, int N, int D, int H, int W, int Cin, int Cout) {
+  if ((nd != 2 && nd != 3) || N < 1 || D < 1 || H < 1 || W < 1 || Cin < 32 || Cout < 32 || Cin % 32 || Cout % 32) return 0;
+  return iunet_conv3_v4_pairs(nd, N, D, H, W, Cin, Cout, 0);
 }
 
 int iunet_conv3_fwd(int dtype, int nd, const void* x, long long x_sstride, void* y, long long y_sstride,

@@ -26,7 +26,10 @@ extern "C" int iunet_v4_stamps_read(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_v4_stamps), sizeof(unsigned long long) * 4 * 512);
 }
 #endif
+// 16 zero bytes: the source of the halo pixels outside the image when the halo tile goes global -> LDS without registers
+__device__ __attribute__((aligned(16))) unsigned int g_v4_zero16[4] = {0u, 0u, 0u, 0u};
 int iunet_conv3_v4_stats_parts(int nd, int Cout);
+int iunet_conv3_v4_pairs(int nd, int N, int D, int H, int W, int Cin, int Cout, int bw);
 
 namespace {
 
@@ -51,7 +54,7 @@ struct ConvV4Params {
   int bz, by, bx;                             // tiles per brick (bz * by * bx = workgroups per XCD and Cout tile)
   int nbz, nby, nbx;                          // bricks per sample
   int epi;
-  int dbg;                                    // profiling only (IUNET_V4_DBG): 2 no MFMA phase, 4 no stores
+  int dbg;                                    // profiling only (IUNET_V4_DBG): 2 no MFMA phase, 4 no stores, 64 halo tiles through registers always
   // Data-gradient launches: this launch's output IS the gradient dz of the producer layer's activation z = relu(bn(yp)).  With
   // bw_y set, the epilogue also reads yp at its output voxels and accumulates the BatchNorm-backward sums of that layer --
   // s1 = sum dz', s2 = sum dz' * xhat, dz' = dz where z > 0 (the arithmetic of bn_bwd_reduce_kernel on the STORED, rounded dz)
@@ -62,13 +65,19 @@ struct ConvV4Params {
 
 // BW: the data-gradient variant that also accumulates the BatchNorm-backward sums of the layer its output flows into (bw_y); a
 // template parameter so that its extra registers (the prefetched yp fragments) never touch the forward instantiations
-template <typename T, int ND, bool WS, bool SMALL, bool BW = false>
-__global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + (WS ? 256 : 512)), 1) void conv3_v4_kernel(ConvV4Params p) {
+// PAIR (streamed weights only): the workgroup walks its tiles two at a time -- steps (chunk c, tile A), (chunk c, tile B), (chunk c + 1,
+// tile A), ... -- so a 30 KB weight chunk is streamed once per TWO tiles.  The launch is bound by the bytes that cross the L2 -> CU
+// fabric (64 -> 32 @ 2 x 128^3 moves 2.4 GB of halo tiles, weights and outputs in 0.35-0.43 ms = 5.6-6.9 TB/s, the
+// rate the chip sustains), and the re-streamed weights are 41 % of them.  Cost: a second accumulator set (32 registers), so 4 loader
+// waves instead of 8 (12 waves per CU: 168 registers each).
+template <typename T, int ND, bool WS, bool SMALL, bool BW = false, bool PAIR = false>
+__global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + ((WS || PAIR) ? 256 : 512)), 1) void conv3_v4_kernel(ConvV4Params p) {
+  static_assert(!PAIR || (!WS && !BW && ND == 3), "tile pairs: the streamed-weight 3-D forward / data-gradient variant only");
   using V8 = typename Vec8<T>::type;
   using TL = V4Tile<ND, SMALL>;
   // consumer waves; loader threads: 4 loader waves when only activations stream, 8 when the weights stream too (twice the
   // bytes per step: the extra waves double the loads in flight, -6...-11 % on those layers)
-  constexpr int NCW = TL::NCW, NLT = WS ? 256 : 512;
+  constexpr int NCW = TL::NCW, NLT = (WS || PAIR) ? 256 : 512;
   constexpr int TZ = TL::TZ, TY = TL::TY, TX = TL::TX, PADZ = TL::PADZ, NCOL = TL::NCOL, S16 = TL::S16;
   constexpr int FX = TX / 16, NI = TZ * TY * FX / NCW, NR = NI / FX;    // x halves; fragments per consumer wave; tile rows per wave
   constexpr int PZ = TZ + 2 * PADZ, PY = TY + 2, PX = TX + 2;
@@ -105,6 +114,9 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + (WS ? 256 : 512)), 1
   const int b_begin = (int)((long long)xcd * nbricks / 8), b_end = (int)((long long)(xcd + 1) * nbricks / 8);
   const int nchunk = p.Cin / (16 * S16);               // steps per tile
   const int nsteps = (b_end - b_begin) * nchunk;
+  // step -> (tile of this workgroup, 16-channel chunk).  PAIR: tile = 2 * pair + (s & 1), chunk advances every second step
+  auto tile_of = [&](int s) -> int { return PAIR ? 2 * (s / (2 * nchunk)) + (s & 1) : s / nchunk; };
+  auto chunk_of = [&](int s) -> int { return PAIR ? (s - (s / (2 * nchunk)) * 2 * nchunk) >> 1 : s - (s / nchunk) * nchunk; };
   if (nsteps <= 0) {                                   // no tile for this workgroup: its statistics row is zero
     if (p.stats != nullptr && tid < 64) p.stats[((long long)blockIdx.x * p.Cout + cob * 32 + (tid >> 1)) * 2 + (tid & 1)] = 0.f;
     return;
@@ -160,15 +172,16 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + (WS ? 256 : 512)), 1
     // streamed weights go global -> LDS directly (LDS-DMA: no staging registers, no ds_write): a lane-linear copy of the
     // step's WSTEP bytes; one wave instruction moves 64 x 16 B to M0-base + lane * 16.  The copy is in flight on the
     // vector-memory counter; the wait for the activation loads that were issued before it retires it too (in order).
-    auto dma_weights = [&](int s, int buf) {           // the weights of step s -> weight buffer buf
-      const int chunk = s - (s / nchunk) * nchunk;
+    auto dma_weights = [&](int s, int buf, int it0 = 0, int it1 = 1 << 20) {     // the weights of step s -> weight buffer buf (items it0..it1 of each thread)
+      const int chunk = chunk_of(s);
       const u32x4* ws = wsrc + (long long)chunk * (WSTEP / 16);
 #pragma unroll
       for (int it = 0; it < WIT; ++it) {
+        if (it < it0 || it >= it1) continue;
         const int base = it * NLT + lw * 64;                                  // first item of this wave instruction
         if (base < WSTEP / 16) {
           const u32x4* gsrc = ws + min(base + (lt & 63), WSTEP / 16 - 1);
-          const unsigned dst = lds0 + OFF_W + buf * WSTEP + base * 16;
+          const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + OFF_W + buf * WSTEP + base * 16);   // uniform by construction; keeps it in an SGPR for M0
           unsigned keep;
           asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                        : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
@@ -176,9 +189,9 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + (WS ? 256 : 512)), 1
       }
     };
     auto load = [&](int s, Staged& r) {               // issue the global loads of step s (nothing consumes them here)
-      const int chunk = s - (s / nchunk) * nchunk;
+      const int chunk = chunk_of(s);
       int n_img, z0, y0, x0;
-      tile_origin(s / nchunk, n_img, z0, y0, x0);
+      tile_origin(tile_of(s), n_img, z0, y0, x0);
       const T* xc = (const T*)p.x + (long long)n_img * p.x_sstride + (long long)chunk * CP * plane_stride;
       r.ok = 0;
 #pragma unroll
@@ -193,13 +206,50 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + (WS ? 256 : 512)), 1
         r.ok |= ok ? (1u << it) : 0u;
       }
     };
+    // The halo tile of step s global -> LDS buffer s & 1 WITHOUT registers (launches whose input needs no arithmetic on the way: every
+    // conv but the training forward of a stage's second conv).  Measured with the register path's parts switched off one at a time
+    // (64 -> 32 @ 2 x 128^3: 466 us; no activation global loads 366; no ds_write 438; no weight LDS-DMA 456; consumers alone 361):
+    // the consumers lose their time to the register-staged loads, not to the same bytes moved by LDS-DMA.  A wave instruction copies
+    // 64 consecutive halo pixels (16 B each, per-lane source address) to 1 KB of the plane; pixels outside the image read 16 zero
+    // bytes.  The buffer is free once the consumers have passed the previous step's barrier, so the copy is issued, waited for
+    // (vmcnt(0)) and published by the next barrier within ONE step -- no prefetch across the barrier, none needed (a second register
+    // set in the register path measured no gain: the loads land well within a step).
+    auto dma_acts = [&](int s) {
+      const int chunk = chunk_of(s);
+      int n_img, z0, y0, x0;
+      tile_origin(tile_of(s), n_img, z0, y0, x0);
+      const T* xc = (const T*)p.x + (long long)n_img * p.x_sstride + (long long)chunk * CP * plane_stride;
+      const unsigned abuf = lds0 + (s & 1) * ABUF;
+#pragma unroll
+      for (int it = 0; it < AIT; ++it) {
+        const int base = it * NLT + lw * 64;                                  // first pixel of this wave instruction
+        if (base < PLANE / 16) {
+          const int pix = lt + it * NLT;
+          const int px = pcoord[it] & 255, py = (pcoord[it] >> 8) & 255, pz = pcoord[it] >> 16;
+          const int gz = z0 + pz - PADZ, gy = y0 + py - 1, gx = x0 + px - 1;
+          const bool ok = pix < NPIX && (unsigned)gz < (unsigned)p.D && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+          const long long goff = (((long long)gz * p.H + gy) * p.W + gx) * 8;
+          if (pix < PLANE / 16) {                                             // (2-D: the last instruction would run past the plane)
+#pragma unroll
+            for (int k = 0; k < CP; ++k) {
+              const u32x4* gsrc = ok ? (const u32x4*)(xc + k * plane_stride + goff) : (const u32x4*)g_v4_zero16;
+              const unsigned dst = __builtin_amdgcn_readfirstlane(abuf + k * PLANE + base * 16);
+              unsigned keep;
+              asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                           : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+            }
+          }
+        }
+      }
+    };
+    auto landed = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
     // registers -> LDS buffer s & 1; ACT: z = relu(scale * y + shift), the arithmetic of bn_relu_fwd_kernel, with the
     // per-channel pairs read from LDS (a global load here would sit on the vector-memory counter and its wait would
     // drain the prefetched next step too)
     auto commit = [&](int s, const Staged& r, auto ACT) {
       constexpr bool act = decltype(ACT)::value;
       unsigned char* ab = smem + (s & 1) * ABUF;
-      const int cfirst = (s - (s / nchunk) * nchunk) * CP * 8;
+      const int cfirst = chunk_of(s) * CP * 8;
 #pragma unroll
       for (int k = 0; k < CP; ++k) {
         float sc[8], sh[8];
@@ -234,6 +284,37 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + (WS ? 256 : 512)), 1
     // ONE path and waits for exactly the loads a commit needs, never for the younger prefetch.
     auto run = [&](auto ACT) {
       const int last = nsteps - 1;
+      if (!decltype(ACT)::value && !(p.dbg & 64)) {      // (IUNET_V4_DBG=64: the register path for every launch -- A/B switch)
+        // ---- everything by LDS-DMA: in iteration s (consumers on step s) the buffers of step s + 1 are filled ----
+        if (!WS) dma_weights(0, 0);
+        dma_acts(0);
+        landed();
+        lds_barrier();
+        if (PAIR) {
+          for (int s = 0; s + 1 < nsteps; s += 2) {
+            // steps s, s + 1: tiles A, B on the weights of one chunk (buffer = chunk parity); the next chunk's weights go half in each
+            const bool more = s + 2 < nsteps;                          // (the last pair prefetches no weights: its clamped target is in use)
+            const int nb = chunk_of(min(s + 2, last)) & 1;
+            if (more) dma_weights(s + 2, nb, 0, WIT / 2);
+            dma_acts(s + 1);
+            landed();
+            lds_barrier();
+            if (more) { dma_weights(s + 2, nb, WIT / 2, WIT); dma_acts(s + 2); }
+            landed();
+            lds_barrier();
+          }
+        } else {
+          for (int s = 0; s < nsteps; ++s) {
+            if (s + 1 < nsteps) {                                      // (the last step has nothing to prepare)
+              if (!WS) dma_weights(s + 1, (s + 1) & 1);
+              dma_acts(s + 1);
+            }
+            landed();
+            lds_barrier();
+          }
+        }
+        return;
+      }
       Staged r;
       if (!WS) dma_weights(0, 0);
       load(0, r);
@@ -248,9 +329,41 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + (WS ? 256 : 512)), 1
       if (WS) {
         // one register set: step s + 1 is written to LDS, then the loads of step s + 2 are issued into the same registers
         // and stay in flight over the barrier and the consumers' whole next step
+#ifdef V4_WS_DEPTH2
+        Staged r2;
+        load(min(2, last), r2);
+        for (int s = 0; s < nsteps; s += 2) {
+          commit(s + 1, r, ACT);
+          load(min(s + 3, last), r);
+          lds_barrier();
+          if (s + 1 < nsteps) {
+            commit(s + 2, r2, ACT);
+            load(min(s + 4, last), r2);
+            lds_barrier();
+          }
+        }
+#else
         for (int s = 0; s < nsteps; ++s) {
           commit(s + 1, r, ACT);                                       // (buffer (s + 1) & 1: garbage after the last step, unread)
           load(min(s + 2, last), r);
+          lds_barrier();
+        }
+#endif
+      } else if (PAIR) {
+        // steps s (tile A) and s + 1 (tile B) share the weights of one chunk (buffer = chunk parity); the next chunk's weights are
+        // copied half in each of the two steps into the other buffer (last read two steps ago).  Each half is issued BEFORE the
+        // step's activation loads, so the wait inside the following commit retires it before the step's barrier.
+        Staged r2;
+        for (int s = 0; s + 1 < nsteps; s += 2) {
+          const bool more = s + 2 < nsteps;                            // (the last pair prefetches no weights: its clamped target is in use)
+          const int nb = chunk_of(min(s + 2, last)) & 1;
+          if (more) dma_weights(s + 2, nb, 0, WIT / 2);
+          load(min(s + 2, last), r2);
+          commit(s + 1, r, ACT);
+          lds_barrier();
+          if (more) dma_weights(s + 2, nb, WIT / 2, WIT);
+          load(min(s + 3, last), r);
+          commit(s + 2, r2, ACT);
           lds_barrier();
         }
       } else {
@@ -293,19 +406,22 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + (WS ? 256 : 512)), 1
 #pragma unroll
   for (int j = 0; j < 8; ++j) bias_r[j] = (p.epi != 0) ? p.bias[cob * 32 + 8 * q + j] : 0.f;
 
-  f32x4 acc[2][NI];
+  constexpr int NACC = PAIR ? 2 : 1;                           // accumulator sets: one per tile in flight
+  f32x4 acc[NACC][2][NI];
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
+  for (int t = 0; t < NACC; ++t)
 #pragma unroll
-    for (int n = 0; n < NI; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int n = 0; n < NI; ++n) acc[t][m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   float stat_acc = 0.f;      // BatchNorm partial sums over all tiles of this workgroup: lane (q, l15) holds value l15 = which * 8 + j
   V8 bw_yv[BW ? NI : 1];     // bw: the producer layer's raw output at this wave's output voxels, fetched one step ahead of the epilogue
   auto bw_prefetch = [&](int s) {
-    const int chunk = s - (s / nchunk) * nchunk;
+    const int chunk = chunk_of(s);
     if constexpr (BW) if (chunk == nchunk - 1) {
       int n_img, z0, y0, x0;
-      tile_origin(s / nchunk, n_img, z0, y0, x0);
+      tile_origin(tile_of(s), n_img, z0, y0, x0);
       const T* yp = (const T*)p.bw_y + (long long)n_img * p.bw_y_ss + (long long)(cob * 4 + q) * plane_stride;
 #pragma unroll
       for (int n = 0; n < NI; ++n) {
@@ -327,9 +443,9 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + (WS ? 256 : 512)), 1
   // at the end of the step both consumer waves of a SIMD refilled their pipeline from empty at the same moment, every step.)
   V8 R[2][FX][NR + 2], A[2][3][2];
   auto step_ptrs = [&](int s, const unsigned char*& ab, const unsigned char*& wl) {
-    const int chunk = s - (s / nchunk) * nchunk;
+    const int chunk = chunk_of(s);
     ab = smem + (s & 1) * ABUF + rbase;
-    wl = smem + OFF_W + (WS ? chunk : (s & 1)) * WSTEP + lane * 16;
+    wl = smem + OFF_W + (WS ? chunk : PAIR ? (chunk & 1) : (s & 1)) * WSTEP + lane * 16;
   };
   auto load_group = [&](const unsigned char* ab, const unsigned char* wl, int g, auto BUF) {
     constexpr int b = decltype(BUF)::value;
@@ -344,12 +460,13 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + (WS ? 256 : 512)), 1
       A[b][dy][1] = *(const V8*)(wl + h * WBYTES + ((c * 3 + dy) * 2 + 1) * 1024);
     }
   };
-  auto tile_epilogue = [&](int s) {
-    const int chunk = s - (s / nchunk) * nchunk;
+  auto tile_epilogue = [&](int s, auto TSET) {
+    constexpr int ts = decltype(TSET)::value;
+    const int chunk = chunk_of(s);
     if (chunk == nchunk - 1) {
       // ---- epilogue of this tile ----
       int n_img, z0, y0, x0;
-      tile_origin(s / nchunk, n_img, z0, y0, x0);
+      tile_origin(tile_of(s), n_img, z0, y0, x0);
       T* yout = (T*)p.y + (long long)n_img * p.y_sstride;
       float s_sum[8], s_sq[8];
 #pragma unroll
@@ -361,7 +478,7 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + (WS ? 256 : 512)), 1
         const bool ok = gz < p.D && gy < p.H && gx < p.W;
         float vals[8];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { vals[j] = acc[0][n][j]; vals[4 + j] = acc[1][n][j]; }
+        for (int j = 0; j < 4; ++j) { vals[j] = acc[ts][0][n][j]; vals[4 + j] = acc[ts][1][n][j]; }
         if (p.stats != nullptr && ok && !bw) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) { s_sum[j] += vals[j]; s_sq[j] += vals[j] * vals[j]; }
@@ -388,8 +505,8 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + (WS ? 256 : 512)), 1
           }
         }
         if (ok && !(p.dbg & 4)) *(V8*)(yout + (long long)(cob * 4 + q) * plane_stride + (((long long)gz * p.H + gy) * p.W + gx) * 8) = o;
-        acc[0][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-        acc[1][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        acc[ts][0][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        acc[ts][1][n] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
       if (p.stats != nullptr) {
         // this tile's 16 partial sums per 16-lane group, reduce-scattered over the x lanes (15 exchanges): lane l15 ends
@@ -411,14 +528,14 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + (WS ? 256 : 512)), 1
     }
   };
   // The MFMAs of group g on fragment set b, with the LDS reads issued just before them spread between the MFMAs.
-  auto group_mfmas = [&](auto BUF, bool reads_pending) {
-    constexpr int b = decltype(BUF)::value;
+  auto group_mfmas = [&](auto BUF, bool reads_pending, auto TSET) {
+    constexpr int b = decltype(BUF)::value, ts = decltype(TSET)::value;
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
       for (int n = 0; n < NI; ++n) {
-        acc[0][n] = mfma16<T>(A[b][dy][0], R[b][n % FX][n / FX + dy], acc[0][n]);
-        acc[1][n] = mfma16<T>(A[b][dy][1], R[b][n % FX][n / FX + dy], acc[1][n]);
+        acc[ts][0][n] = mfma16<T>(A[b][dy][0], R[b][n % FX][n / FX + dy], acc[ts][0][n]);
+        acc[ts][1][n] = mfma16<T>(A[b][dy][1], R[b][n % FX][n / FX + dy], acc[ts][1][n]);
       }
     if (reads_pending) {
       constexpr int MPR = (3 * NI * 2) / NRD > 0 ? (3 * NI * 2) / NRD : 1;      // MFMAs per LDS read in the interleave
@@ -432,6 +549,8 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + (WS ? 256 : 512)), 1
   };
   // The groups of one step of the cross-step pipeline; PAR = fragment set of its first group.
   constexpr bool XSTEP = WS && !BW;       // cross-step pipeline: the variants with resident weights (168-register cap); BW keeps its yp fragments instead
+  using TS0 = std::integral_constant<int, 0>;
+  using TS1 = std::integral_constant<int, PAIR ? 1 : 0>;
   auto step_groups = [&](int s, auto PAR) {
     constexpr int par = decltype(PAR)::value;
     using B0 = std::integral_constant<int, par>;                       // set of the even groups of this step
@@ -444,13 +563,13 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + (WS ? 256 : 512)), 1
     bw_prefetch(s);
 #pragma unroll
     for (int g = 0; g + 1 < NGRP; ++g) {
-      if ((g & 1) == 0) { load_group(ab, wl, g + 1, B1{}); group_mfmas(B0{}, true); }
-      else              { load_group(ab, wl, g + 1, B0{}); group_mfmas(B1{}, true); }
+      if ((g & 1) == 0) { load_group(ab, wl, g + 1, B1{}); group_mfmas(B0{}, true, TS0{}); }
+      else              { load_group(ab, wl, g + 1, B0{}); group_mfmas(B1{}, true, TS0{}); }
     }
     lds_barrier();                   // this step's buffers are read, the next step's are filled
     load_group(abn, wln, 0, BN{});
-    group_mfmas(BL{}, true);
-    tile_epilogue(s);
+    group_mfmas(BL{}, true, TS0{});
+    tile_epilogue(s, TS0{});
   };
   if (!(p.dbg & 2)) {
     if constexpr (XSTEP) {
@@ -471,7 +590,7 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + (WS ? 256 : 512)), 1
       // barrier and the epilogue spills): the pipeline restarts every step, the barrier closes the step
       using B0 = std::integral_constant<int, 0>;
       using B1 = std::integral_constant<int, 1>;
-      for (int s = 0; s < nsteps; ++s) {
+      auto one_step = [&](int s, auto TSET) {
         const unsigned char *ab, *wl;
         step_ptrs(s, ab, wl);
         bw_prefetch(s);
@@ -479,11 +598,16 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + (WS ? 256 : 512)), 1
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int g = 0; g < NGRP; ++g) {
-          if ((g & 1) == 0) { if (g + 1 < NGRP) load_group(ab, wl, g + 1, B1{}); group_mfmas(B0{}, g + 1 < NGRP); }
-          else              { if (g + 1 < NGRP) load_group(ab, wl, g + 1, B0{}); group_mfmas(B1{}, g + 1 < NGRP); }
+          if ((g & 1) == 0) { if (g + 1 < NGRP) load_group(ab, wl, g + 1, B1{}); group_mfmas(B0{}, g + 1 < NGRP, TSET); }
+          else              { if (g + 1 < NGRP) load_group(ab, wl, g + 1, B0{}); group_mfmas(B1{}, g + 1 < NGRP, TSET); }
         }
-        tile_epilogue(s);
+        tile_epilogue(s, TSET);
         lds_barrier();               // consumers are done with this step's buffers, the loaders have filled the others
+      };
+      if constexpr (PAIR) {
+        for (int s = 0; s + 1 < nsteps; s += 2) { one_step(s, TS0{}); one_step(s + 1, TS1{}); }     // tile A, tile B of the same chunk
+      } else {
+        for (int s = 0; s < nsteps; ++s) one_step(s, TS0{});
       }
     }
   } else {
@@ -510,14 +634,14 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + (WS ? 256 : 512)), 1
   }
 }
 
-template <typename T, int ND, bool WS, bool SMALL, bool BW = false>
+template <typename T, int ND, bool WS, bool SMALL, bool BW = false, bool PAIR = false>
 int launch_v4(ConvV4Params p, hipStream_t stream) {
   using TL = V4Tile<ND, SMALL>;
   constexpr int NPIX = (TL::TZ + 2 * TL::PADZ) * (TL::TY + 2) * (TL::TX + 2);
   constexpr int PLANE = ((NPIX * 16 + 255) / 256) * 256;
   constexpr int WSTEP = TL::S16 * ((TL::NCOL + 1) / 2) * 3 * 2 * 1024;
   const int lds = 2 * 2 * TL::S16 * PLANE + (WS ? p.Cin / (16 * TL::S16) : 2) * WSTEP + 2048 + p.Cin * 8 + 512;
-  IUNET_SET_MAX_LDS((conv3_v4_kernel<T, ND, WS, SMALL, BW>), lds);
+  IUNET_SET_MAX_LDS((conv3_v4_kernel<T, ND, WS, SMALL, BW, PAIR>), lds);
   p.tilesZ = (p.D + TL::TZ - 1) / TL::TZ; p.tilesY = (p.H + TL::TY - 1) / TL::TY; p.tilesX = (p.W + TL::TX - 1) / TL::TX;
   const int ncob = p.Cout / 32;
   // one workgroup per CU: 8 XCDs x (bz x by x bx) brick slots per Cout tile
@@ -531,7 +655,7 @@ int launch_v4(ConvV4Params p, hipStream_t stream) {
     if (gx < rows)
       IUNET_CHECK_HIP(hipMemsetAsync(p.stats + (long long)gx * p.Cout * 2, 0, (size_t)(rows - gx) * p.Cout * 2 * sizeof(float), stream));
   }
-  hipLaunchKernelGGL((conv3_v4_kernel<T, ND, WS, SMALL, BW>), dim3(gx, ncob), dim3(TL::NCW * 64 + (WS ? 256 : 512)), lds, stream, p);
+  hipLaunchKernelGGL((conv3_v4_kernel<T, ND, WS, SMALL, BW, PAIR>), dim3(gx, ncob), dim3(TL::NCW * 64 + ((WS || PAIR) ? 256 : 512)), lds, stream, p);
   IUNET_CHECK_HIP(hipGetLastError());
   return IUNET_OK;
 }
@@ -543,6 +667,19 @@ int iunet_conv3_v4_stats_parts(int nd, int Cout) {
   (void)nd;                                            // 2-D and 3-D bricks have the same number of slots
   const int ncob = Cout / 32;
   return 8 * (ncob == 1 ? 32 : ncob == 2 ? 16 : ncob <= 4 ? 8 : 4);
+}
+
+// does this launch walk its tiles in pairs (PAIR variant: one weight stream per two tiles)?  3-D, big tiles, streamed weights, no
+// fused BatchNorm-backward sums, and every XCD's share of the bricks even (nbricks a multiple of 16).  IUNET_V4_PAIR=0: A/B switch.
+int iunet_conv3_v4_pairs(int nd, int N, int D, int H, int W, int Cin, int Cout, int bw) {
+  static const int pair_on = getenv("IUNET_V4_PAIR") ? atoi(getenv("IUNET_V4_PAIR")) : 1;
+  if (nd != 3 || bw || !pair_on || Cin <= 32) return 0;                      // Cin <= 32: resident weights
+  const int tz = (D + 3) / 4, ty = (H + 7) / 8, tx = (W + 15) / 16;
+  if ((long long)N * tz * ty * tx * (Cout / 32) < 128) return 0;              // the half-size tile variant
+  int bz, by, bx;
+  iunet_brick_shape(3, Cout / 32, tz, ty, tx, &bz, &by, &bx);
+  const long long nbricks = (long long)N * ((tz + bz - 1) / bz) * ((ty + by - 1) / by) * ((tx + bx - 1) / bx);
+  return nbricks % 16 == 0;
 }
 
 int iunet_conv3_v4_launch(int dtype, int nd, const void* x, long long x_sstride, void* y, long long y_sstride, const void* wpk,
@@ -568,6 +705,8 @@ int iunet_conv3_v4_launch(int dtype, int nd, const void* x, long long x_sstride,
   // 16^3 level: 1.4-1.6x faster there; at 128 of 256 CUs the doubled weight streaming costs more than the idle CUs)
   const long long big_tiles = (long long)N * ((D + 3) / 4) * ((H + 7) / 8) * ((W + 15) / 16);
   const bool small = nd == 3 && !ws && big_tiles * (Cout / 32) < 128;
+  const bool pair = iunet_conv3_v4_pairs(nd, N, D, H, W, Cin, Cout, bw_y != nullptr) != 0;
+  if (pair) return dtype == 0 ? launch_v4<f16, 3, false, false, false, true>(p, stream) : launch_v4<bf16, 3, false, false, false, true>(p, stream);
 #define V4_GO(TT, BWV) (nd == 3 ? (ws ? launch_v4<TT, 3, true, false, BWV>(p, stream)                                          \
                                       : (small ? launch_v4<TT, 3, false, true, BWV>(p, stream) : launch_v4<TT, 3, false, false, BWV>(p, stream))) \
                                 : (ws ? launch_v4<TT, 2, true, false, BWV>(p, stream) : launch_v4<TT, 2, false, false, BWV>(p, stream)))

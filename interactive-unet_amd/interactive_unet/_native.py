@@ -29,6 +29,7 @@ _SIGS = {
     'iunet_conv3_fwd': [c_int, c_int, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_void_p, c_void_p,
                         c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     'iunet_conv3_pick_layout': [c_int] * 7,
+    'iunet_conv3_tile_pairs': [c_int] * 7,
     'iunet_conv3_fwd_act': [c_int, c_int, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                             c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     'iunet_first_conv_fwd': [c_int, c_int, c_void_p, c_int, ctypes.POINTER(c_ll), c_void_p, c_ll, c_void_p, c_void_p,

@@ -89,6 +89,29 @@ def test_conv3_exact_integers(nv, nd, shape, cin, cout):
             assert torch.equal(got[ok], ref[ok]), (dt, layout, (got - ref)[ok].abs().max())
 
 
+@pytest.mark.parametrize('shape,cin,cout', [((58, 62, 120), 64, 32), ((32, 32, 64), 128, 64)])
+def test_conv3_tile_pairs_exact_integers(nv, shape, cin, cout):
+    """Grids on which the layout-2 kernel walks its tiles in pairs (one weight stream per two tiles, two accumulator sets;
+    iunet_conv3_tile_pairs): ragged on every axis, forward with statistics and the data gradient, bit for bit."""
+    g = torch.Generator().manual_seed(21)
+    N = 2
+    assert nv.lib().iunet_conv3_tile_pairs(3, N, *shape, cin, cout) == 1
+    x = torch.randint(-2, 3, (N, cin) + shape, generator=g).float()
+    w = torch.randint(-1, 2, (cout, cin, 3, 3, 3), generator=g).float()
+    ref = F.conv3d(x, w, padding=1)
+    for dt in (torch.float16, torch.bfloat16):
+        got, st = run_conv3(nv, x, w, dt, 3, layout=2, stats=True)
+        ok = ref.abs() <= (2048 if dt == torch.float16 else 256)
+        assert torch.equal(got[ok], ref[ok]), (dt, (got - ref)[ok].abs().max())
+        assert torch.equal(st[:, 0], ref.sum((0, 2, 3, 4)))                 # integer sums below 2^24: exact in fp32 in any order
+    if nv.lib().iunet_conv3_tile_pairs(3, N, *shape, cout, cin) == 1:       # the data gradient: roles of Cin / Cout swapped
+        dy = torch.randint(-2, 3, (N, cout) + shape, generator=g).float()
+        want = F.conv_transpose3d(dy, w, padding=1)
+        got = run_conv3(nv, dy, w, torch.float16, 3, layout=2, mode=1)
+        ok = want.abs() <= 2048
+        assert torch.equal(got[ok], want[ok])
+
+
 @pytest.mark.parametrize('nd', [2, 3])
 def test_conv3_random_bias_relu_stats(nv, nd):
     g = torch.Generator().manual_seed(2)
