@@ -284,7 +284,9 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + ((WS || PAIR) ? 256 
     // ONE path and waits for exactly the loads a commit needs, never for the younger prefetch.
     auto run = [&](auto ACT) {
       const int last = nsteps - 1;
-      if (!decltype(ACT)::value && !(p.dbg & 64)) {      // (IUNET_V4_DBG=64: the register path for every launch -- A/B switch)
+      // 3-D only: the 2-D level-0 layers are HBM-bound and need the register path's loads in flight across the barrier (measured:
+      // C2's dec0.conv1 at 45 % of the HBM peak by LDS-DMA against 49 % through registers)
+      if (ND == 3 && !decltype(ACT)::value && !(p.dbg & 64)) {      // (IUNET_V4_DBG=64: the register path for every launch -- A/B switch)
         // ---- everything by LDS-DMA: in iteration s (consumers on step s) the buffers of step s + 1 are filled ----
         if (!WS) dma_weights(0, 0);
         dma_acts(0);
@@ -329,26 +331,11 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + ((WS || PAIR) ? 256 
       if (WS) {
         // one register set: step s + 1 is written to LDS, then the loads of step s + 2 are issued into the same registers
         // and stay in flight over the barrier and the consumers' whole next step
-#ifdef V4_WS_DEPTH2
-        Staged r2;
-        load(min(2, last), r2);
-        for (int s = 0; s < nsteps; s += 2) {
-          commit(s + 1, r, ACT);
-          load(min(s + 3, last), r);
-          lds_barrier();
-          if (s + 1 < nsteps) {
-            commit(s + 2, r2, ACT);
-            load(min(s + 4, last), r2);
-            lds_barrier();
-          }
-        }
-#else
         for (int s = 0; s < nsteps; ++s) {
           commit(s + 1, r, ACT);                                       // (buffer (s + 1) & 1: garbage after the last step, unread)
           load(min(s + 2, last), r);
           lds_barrier();
         }
-#endif
       } else if (PAIR) {
         // steps s (tile A) and s + 1 (tile B) share the weights of one chunk (buffer = chunk parity); the next chunk's weights are
         // copied half in each of the two steps into the other buffer (last read two steps ago).  Each half is issued BEFORE the
