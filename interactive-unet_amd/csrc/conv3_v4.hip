@@ -284,6 +284,11 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + ((WS || PAIR) ? 256 
     // ONE path and waits for exactly the loads a commit needs, never for the younger prefetch.
     auto run = [&](auto ACT) {
       const int last = nsteps - 1;
+#ifdef V4_NOLOAD                                                    // ablation build (never defined by build.sh): consumers alone
+      lds_barrier();
+      for (int s = 0; s < nsteps; ++s) lds_barrier();
+      return;
+#endif
       // 3-D only: the 2-D level-0 layers are HBM-bound and need the register path's loads in flight across the barrier (measured:
       // C2's dec0.conv1 at 45 % of the HBM peak by LDS-DMA against 49 % through registers)
       if (ND == 3 && !decltype(ACT)::value && !(p.dbg & 64)) {      // (IUNET_V4_DBG=64: the register path for every launch -- A/B switch)
@@ -324,10 +329,6 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + ((WS || PAIR) ? 256 
       load(min(1, last), r);
       if (!WS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the first weight copy has landed
       lds_barrier();
-#ifdef V4_NOLOAD                                                    // ablation build (never defined by build.sh): consumers alone
-      for (int s = 0; s < nsteps; ++s) lds_barrier();
-      return;
-#endif
       if (WS) {
         // one register set: step s + 1 is written to LDS, then the loads of step s + 2 are issued into the same registers
         // and stay in flight over the barrier and the consumers' whole next step
