@@ -7,8 +7,12 @@
 // change that.  So here the roles are split inside one persistent workgroup per CU:
 //   * 8 CONSUMER waves (two per SIMD) only read LDS and issue MFMAs (plus the tile's output stores);
 //   * 4 or 8 LOADER waves (one or two per SIMD) fetch the next 16-channel chunk of the halo tile (and, for Cin > 32, its
-//     30 KB of weights) global -> registers -> the OTHER LDS buffer, wait for it, and meet the consumers at the
-//     one barrier per step.  Their stalls on the memory queue cost no MFMA issue slots.
+//     30 KB of weights) into the OTHER LDS buffer, wait for it, and meet the consumers at the one barrier per step.  Their
+//     stalls on the memory queue cost no MFMA issue slots.  Weights always travel by LDS-DMA; the halo tile does too in 3-D
+//     launches whose input needs no arithmetic on the way (dma_acts), else through registers (load / commit: the fused
+//     BatchNorm + ReLU of the training forward, and the HBM-bound 2-D layers, which need loads in flight across the barrier).
+// Round 2 measured what is left: with and without the loader waves the consumers take the same cycles per
+// step (4 800, 80 % of them MFMA); the difference is the clock the chip holds (1.54 vs 1.75 GHz at 64 -> 32 @ 128^3).
 // 3-D: tile 4 x 8 x 16 voxels, a step = one 16-channel chunk; 2-D: tile 16 x 32 pixels, a step = 32 channels (the 2-D
 // filter has a third of the taps, so a 16-channel step would be too short between barriers).  64 voxels per consumer
 // wave; k-step = 2 filter columns x 16 channels (the K16 operator of layout 1), activation row fragments reused over
