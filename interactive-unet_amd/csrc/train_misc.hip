@@ -374,6 +374,11 @@ __global__ __launch_bounds__(256, 2) void first_wgrad_kernel(FirstWgradParams p)
   extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
   T* xs = (T*)smem;                                           // [CIN][NPIX]
   unsigned char* dys = smem + XS_BYTES;                        // 4 planes
+  __shared__ __attribute__((aligned(16))) float par[7 * 32];   // [scale | shift | mean | invstd | coef0 | coef1 | coef2][32 channels of this Cout tile]
+  if (p.yraw != nullptr && threadIdx.x < 7 * 32) {
+    const int k = threadIdx.x >> 5, c = blockIdx.y * 32 + (threadIdx.x & 31);
+    par[threadIdx.x] = k == 0 ? p.scale[c] : k == 1 ? p.shift[c] : k == 2 ? p.mean[c] : k == 3 ? p.invstd[c] : p.coef[c * 3 + (k - 4)];
+  }
   const unsigned lds_y = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)dys;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -452,14 +457,23 @@ __global__ __launch_bounds__(256, 2) void first_wgrad_kernel(FirstWgradParams p)
       if (p.yraw != nullptr && ((oky >> it) & 1u)) {      // dy = a * (dz * [z > 0] - c1 - xhat * c2) as bn_bwd_apply_kernel; outside the image: 0
         const V8 g = __builtin_bit_cast(V8, v), yy = __builtin_bit_cast(V8, yw[it]);
         V8 o;
+        // the 7 per-channel constants of this plane's 8 channels: broadcast LDS reads (one global load per constant and
+        // element -- 448 per thread and tile -- was what this kernel spent its time on)
+        const f32x4* pp = (const f32x4*)(par + pl * 8);
+        float cs[7][8];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+          const f32x4 lo = pp[k * 8], hi = pp[k * 8 + 1];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { cs[k][j] = lo[j]; cs[k][4 + j] = hi[j]; }
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const int c = cob * 32 + pl * 8 + j;
           const float yv = to_f32<T>(yy[j]);
-          const float zv = to_f32<T>(from_f32<T>(fmaf(p.scale[c], yv, p.shift[c])));
+          const float zv = to_f32<T>(from_f32<T>(fmaf(cs[0][j], yv, cs[1][j])));
           const float d = zv > 0.f ? to_f32<T>(g[j]) : 0.f;
-          const float xh = (yv - p.mean[c]) * p.invstd[c];
-          o[j] = from_f32<T>(p.coef[c * 3] * (d - p.coef[c * 3 + 1] - xh * p.coef[c * 3 + 2]));
+          const float xh = (yv - cs[2][j]) * cs[3][j];
+          o[j] = from_f32<T>(cs[4][j] * (d - cs[5][j] - xh * cs[6][j]));
         }
         v = __builtin_bit_cast(u32x4, o);
       }
