@@ -65,17 +65,20 @@ __global__ __launch_bounds__(256) void convT_dgrad_kernel(ConvTDgradParams p) {
 // Same operator with the weights of the ci block resident in LDS (Cout <= 128: 16 KB per 32 output channels of the
 // forward conv) and two 16-voxel groups per wave and step: as in convT_lds_kernel (pointwise.hip), the per-wave weight
 // fetches through the vector cache were 2x the tensor traffic.
-template <typename T, int ND, int NK>
+// NCI: input-channel blocks (of 32) per workgroup.  Every ci block needs the whole gradient tensor dy; with one block per
+// workgroup the level-0 launch (Cin = 64) read its 268 MB twice and ran at the HBM rate of the doubled traffic.
+template <typename T, int ND, int NK, int NCI>
 __global__ __launch_bounds__(256) void convT_dgrad_lds_kernel(ConvTDgradParams p) {
   using V8 = V8T<T>;
   constexpr int NPOS = ND == 3 ? 8 : 4, G = 2;
+  constexpr int WCI = NPOS * NK * 2 * 64;                        // 16-byte granules of one ci block's operator
   extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l15 = lane & 15, q = lane >> 4;
-  const int cib = blockIdx.y;
+  const int cib0 = blockIdx.y * NCI;
   {
-    const u32x4* wsrc = (const u32x4*)p.wpk + (long long)cib * NPOS * NK * 2 * 64;
-    for (int i = threadIdx.x; i < NPOS * NK * 2 * 64; i += 256) *(u32x4*)(smem + i * 16) = wsrc[i];
+    const u32x4* wsrc = (const u32x4*)p.wpk + (long long)cib0 * WCI;
+    for (int i = threadIdx.x; i < NCI * WCI; i += 256) *(u32x4*)(smem + i * 16) = wsrc[i];
   }
   __syncthreads();
   const int xg = (p.W + 15) / 16;
@@ -84,7 +87,7 @@ __global__ __launch_bounds__(256) void convT_dgrad_lds_kernel(ConvTDgradParams p
   const long long out_plane = (long long)Do * Ho * Wo * 8, in_plane = (long long)p.D * p.H * p.W * 8;
   const V8* wl = (const V8*)smem + lane;
   for (long long g0 = ((long long)blockIdx.x * 4 + wave) * G; g0 < ngroups; g0 += (long long)gridDim.x * 4 * G) {
-    f32x4 acc[G][2];
+    f32x4 acc[NCI][G][2];
     const T* dyb[G];
     long long xoff[G];
     bool okg[G];
@@ -98,8 +101,9 @@ __global__ __launch_bounds__(256) void convT_dgrad_lds_kernel(ConvTDgradParams p
       okg[g] = x < p.W && g0 + g < ngroups;
       const int oz = ND == 3 ? z * 2 : 0;
       dyb[g] = (const T*)p.dy + n * p.dy_ss + (((long long)oz * Ho + y * 2) * Wo + xc * 2) * 8;
-      xoff[g] = n * p.dx_ss + (long long)(cib * 4 + q) * in_plane + (((long long)z * p.H + y) * p.W + x) * 8;
-      acc[g][0] = f32x4{0, 0, 0, 0}; acc[g][1] = f32x4{0, 0, 0, 0};
+      xoff[g] = n * p.dx_ss + (long long)(cib0 * 4 + q) * in_plane + (((long long)z * p.H + y) * p.W + x) * 8;
+#pragma unroll
+      for (int c = 0; c < NCI; ++c) { acc[c][g][0] = f32x4{0, 0, 0, 0}; acc[c][g][1] = f32x4{0, 0, 0, 0}; }
     }
 #pragma unroll
     for (int s = 0; s < NPOS; ++s) {
@@ -107,23 +111,30 @@ __global__ __launch_bounds__(256) void convT_dgrad_lds_kernel(ConvTDgradParams p
       const long long voff = (((long long)a * Ho + b) * Wo + c) * 8;
 #pragma unroll
       for (int kc = 0; kc < NK; ++kc) {
-        const V8 a0 = wl[((s * NK + kc) * 2 + 0) * 64];
-        const V8 a1 = wl[((s * NK + kc) * 2 + 1) * 64];
+        V8 bf[G];
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-          const V8 bf = *(const V8*)(dyb[g] + (long long)(kc * 4 + q) * out_plane + voff);
-          acc[g][0] = mfma16<T>(a0, bf, acc[g][0]);
-          acc[g][1] = mfma16<T>(a1, bf, acc[g][1]);
+        for (int g = 0; g < G; ++g) bf[g] = *(const V8*)(dyb[g] + (long long)(kc * 4 + q) * out_plane + voff);
+#pragma unroll
+        for (int c = 0; c < NCI; ++c) {
+          const V8 a0 = wl[c * WCI + ((s * NK + kc) * 2 + 0) * 64];
+          const V8 a1 = wl[c * WCI + ((s * NK + kc) * 2 + 1) * 64];
+#pragma unroll
+          for (int g = 0; g < G; ++g) {
+            acc[c][g][0] = mfma16<T>(a0, bf[g], acc[c][g][0]);
+            acc[c][g][1] = mfma16<T>(a1, bf[g], acc[c][g][1]);
+          }
         }
       }
     }
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-      V8 o;
+    for (int c = 0; c < NCI; ++c)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { o[j] = from_f32<T>(acc[g][0][j]); o[4 + j] = from_f32<T>(acc[g][1][j]); }
-      if (okg[g]) *(V8*)((T*)p.dx + xoff[g]) = o;
-    }
+      for (int g = 0; g < G; ++g) {
+        V8 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { o[j] = from_f32<T>(acc[c][g][0][j]); o[4 + j] = from_f32<T>(acc[c][g][1][j]); }
+        if (okg[g]) *(V8*)((T*)p.dx + xoff[g] + (long long)c * 4 * in_plane) = o;
+      }
   }
 }
 
@@ -173,7 +184,9 @@ struct ConvTWgradParams {
   int tilesZ, tilesY, tilesX;
 };
 
-template <typename T, int ND>
+// NCI: input-channel blocks (of 32) per workgroup.  The 64 KB dy tile is what this kernel moves; every ci block of a workgroup
+// uses the one copy in LDS (its own 8 KB x tile is swapped in between two MFMA phases), so dy is read once per NCI ci blocks.
+template <typename T, int ND, int NCI>
 __global__ __launch_bounds__(256, 2) void convT_wgrad_kernel(ConvTWgradParams p) {   // 2 per CU: 74 KB of LDS each
   using V8 = V8T<T>;
   constexpr int NPOS = ND == 3 ? 8 : 4;
@@ -190,7 +203,7 @@ __global__ __launch_bounds__(256, 2) void convT_wgrad_kernel(ConvTWgradParams p)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3, gh = g >> 1, gl = g & 1;
-  const int cib = blockIdx.y, cob = blockIdx.z;
+  const int cib0 = blockIdx.y * NCI, cob = blockIdx.z;
   // lane parts of the tr-read addresses
   const unsigned laneX = lds0 + (pp >> 1) * PLANE_X + (pp & 1) * 8 + (gh * 16 + gl * 8 + q) * 16;
   const unsigned laneY = lds0 + OFF_Y + (pp >> 1) * PLANE_Y + (pp & 1) * 8 + (gh * 2 * OX + 2 * (gl * 8 + q)) * 16;
@@ -201,11 +214,13 @@ __global__ __launch_bounds__(256, 2) void convT_wgrad_kernel(ConvTWgradParams p)
     const int a = ND == 3 ? (s >> 2) : 0, b = (s >> 1) & 1, c = s & 1;
     pos_off[i] = (unsigned)(((a * OY + b) * OX + c) * 16);
   }
-  f32x4 acc[PL][2][2];
+  f32x4 acc[NCI][PL][2][2];
 #pragma unroll
-  for (int i = 0; i < PL; ++i)
+  for (int c = 0; c < NCI; ++c)
 #pragma unroll
-    for (int t = 0; t < 2; ++t) { acc[i][t][0] = f32x4{0, 0, 0, 0}; acc[i][t][1] = f32x4{0, 0, 0, 0}; }
+    for (int i = 0; i < PL; ++i)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) { acc[c][i][t][0] = f32x4{0, 0, 0, 0}; acc[c][i][t][1] = f32x4{0, 0, 0, 0}; }
   float bacc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};                   // channels (tid & 3) * 8 + j of this co block
 
   const int tps = p.tilesZ * p.tilesY * p.tilesX, ntiles = tps * p.N;
@@ -214,7 +229,7 @@ __global__ __launch_bounds__(256, 2) void convT_wgrad_kernel(ConvTWgradParams p)
   // Split staging: the global loads of tile t + 1 are issued (into registers) before the MFMA phase of tile t and are
   // written to LDS after it, so their latency hides behind the compute instead of sitting between two barriers.
   constexpr int XIT = NVI * 4 / 256, YIT = NVO * 4 / 256;      // 16-byte items per thread: x 2, dy 16 (3-D) / 8 (2-D)
-  u32x4 xr[XIT];
+  u32x4 xr[NCI * XIT], xkeep[NCI > 1 ? XIT : 1];              // xkeep: the second ci block's x tile of the tile being consumed
   V8 yr[YIT];
   auto load_tile = [&](int tile) {
     const int n = tile / tps;
@@ -223,10 +238,10 @@ __global__ __launch_bounds__(256, 2) void convT_wgrad_kernel(ConvTWgradParams p)
     trem -= tz_i * p.tilesY * p.tilesX;
     const int ty_i = trem / p.tilesX, tx_i = trem - ty_i * p.tilesX;
     const int z0 = tz_i * TZ, y0 = ty_i * TY, x0 = tx_i * TX;
-    const T* xin = (const T*)p.x + (long long)n * p.x_ss + (long long)cib * 4 * in_plane;
+    const T* xin = (const T*)p.x + (long long)n * p.x_ss + (long long)cib0 * 4 * in_plane;
     const T* dyin = (const T*)p.dy + (long long)n * p.dy_ss + (long long)cob * 4 * out_plane;
 #pragma unroll
-    for (int k = 0; k < XIT; ++k) {                              // x tile: 4 planes
+    for (int k = 0; k < NCI * XIT; ++k) {                        // x tile: 4 planes per ci block
       const int it = tid + k * 256;
       const int pl = it / NVI, pix = it - pl * NVI;
       const int px = pix % TX, t2 = pix / TX, py = t2 % TY, pz = t2 / TY;
@@ -248,12 +263,19 @@ __global__ __launch_bounds__(256, 2) void convT_wgrad_kernel(ConvTWgradParams p)
       yr[k] = v;
     }
   };
-  auto commit_tile = [&]() {
+  auto commit_x = [&](const u32x4* src) {                      // one ci block's 4 planes
 #pragma unroll
     for (int k = 0; k < XIT; ++k) {
       const int it = tid + k * 256;
       const int pl = it / NVI, pix = it - pl * NVI;
-      *(u32x4*)(smem + pl * PLANE_X + pix * 16) = xr[k];
+      *(u32x4*)(smem + pl * PLANE_X + pix * 16) = src[k];
+    }
+  };
+  auto commit_tile = [&]() {
+    commit_x(xr);
+    if (NCI > 1) {
+#pragma unroll
+      for (int k = 0; k < XIT; ++k) xkeep[k] = xr[XIT + k];
     }
 #pragma unroll
     for (int k = 0; k < YIT; ++k) {
@@ -271,37 +293,48 @@ __global__ __launch_bounds__(256, 2) void convT_wgrad_kernel(ConvTWgradParams p)
     __syncthreads();
     if (tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x);       // in flight during the MFMA phase
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) {
-      // in-voxel rows 2ks, 2ks+1 (the lane's own row adds gh, folded into laneX / laneY)
-      const int r = 2 * ks, rz = r / TY, ry = r % TY;
-      const unsigned offX = (unsigned)(r * TX * 16);
-      const unsigned offY = (unsigned)(((2 * rz * OY + 2 * ry) * OX) * 16);
-      const V8 a0 = tr_frag2<T>(laneX + offX, 64);
-      const V8 a1 = tr_frag2<T>(laneX + offX + 2 * PLANE_X, 64);
+    for (int c = 0; c < NCI; ++c) {
+      if (c > 0) {                                               // next ci block: its x tile replaces the first one's, dy stays
+        __syncthreads();
+        commit_x(xkeep);
+        __syncthreads();
+      }
 #pragma unroll
-      for (int i = 0; i < PL; ++i) {
-        const V8 b0 = tr_frag2<T>(laneY + offY + pos_off[i], 128);                 // 4 voxels further = 8 output pixels
-        const V8 b1 = tr_frag2<T>(laneY + offY + pos_off[i] + 2 * PLANE_Y, 128);
-        acc[i][0][0] = mfma16<T>(a0, b0, acc[i][0][0]);
-        acc[i][0][1] = mfma16<T>(a0, b1, acc[i][0][1]);
-        acc[i][1][0] = mfma16<T>(a1, b0, acc[i][1][0]);
-        acc[i][1][1] = mfma16<T>(a1, b1, acc[i][1][1]);
+      for (int ks = 0; ks < NKS; ++ks) {
+        // in-voxel rows 2ks, 2ks+1 (the lane's own row adds gh, folded into laneX / laneY)
+        const int r = 2 * ks, rz = r / TY, ry = r % TY;
+        const unsigned offX = (unsigned)(r * TX * 16);
+        const unsigned offY = (unsigned)(((2 * rz * OY + 2 * ry) * OX) * 16);
+        const V8 a0 = tr_frag2<T>(laneX + offX, 64);
+        const V8 a1 = tr_frag2<T>(laneX + offX + 2 * PLANE_X, 64);
+#pragma unroll
+        for (int i = 0; i < PL; ++i) {
+          const V8 b0 = tr_frag2<T>(laneY + offY + pos_off[i], 128);                 // 4 voxels further = 8 output pixels
+          const V8 b1 = tr_frag2<T>(laneY + offY + pos_off[i] + 2 * PLANE_Y, 128);
+          acc[c][i][0][0] = mfma16<T>(a0, b0, acc[c][i][0][0]);
+          acc[c][i][0][1] = mfma16<T>(a0, b1, acc[c][i][0][1]);
+          acc[c][i][1][0] = mfma16<T>(a1, b0, acc[c][i][1][0]);
+          acc[c][i][1][1] = mfma16<T>(a1, b1, acc[c][i][1][1]);
+        }
       }
     }
   }
   // slab: rows = ci (4g + j), cols = co (lane & 15)
-  float* ws = p.wslab + ((((long long)blockIdx.x * gridDim.y + cib) * gridDim.z + cob) * NPOS) * 1024;
 #pragma unroll
-  for (int i = 0; i < PL; ++i) {
-    const int s = wave * PL + i;
+  for (int c = 0; c < NCI; ++c) {
+    float* ws = p.wslab + ((((long long)blockIdx.x * (gridDim.y * NCI) + cib0 + c) * gridDim.z + cob) * NPOS) * 1024;
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int i = 0; i < PL; ++i) {
+      const int s = wave * PL + i;
 #pragma unroll
-      for (int u = 0; u < 2; ++u)
+      for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) ws[s * 1024 + (t * 16 + 4 * g + j) * 32 + u * 16 + i16] = acc[i][t][u][j];
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) ws[s * 1024 + (t * 16 + 4 * g + j) * 32 + u * 16 + i16] = acc[c][i][t][u][j];
+    }
   }
-  if (cib == 0) {       // bias gradient: threads with equal (tid & 3) own the same 8 channels
+  if (blockIdx.y == 0) {       // bias gradient: threads with equal (tid & 3) own the same 8 channels
     __syncthreads();
     float* red = (float*)smem;
 #pragma unroll
@@ -319,22 +352,29 @@ __global__ __launch_bounds__(256, 2) void convT_wgrad_kernel(ConvTWgradParams p)
 // dW[ci][co][pos] = sum_b slab[b][cib][cob][pos][ci%32][co%32] (threads walk the slab order)
 __global__ __launch_bounds__(256) void convT_wgrad_reduce_kernel(const float* __restrict__ slab, int nb, int Cin, int Cout, int npos,
                                                                  float* __restrict__ dW) {
-  __shared__ float red[4][64];                                   // 64 slab columns x 4 row groups, fixed order
-  const long long per_b = (long long)Cin * Cout * npos;
-  const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  const long long j = (long long)blockIdx.x * 64 + col;
-  float s = 0.f;
-  for (int b = grp; b < nb; b += 4) s += slab[b * per_b + j];
-  red[grp][col] = s;
+  // 64 slab columns per block as 16 float4 lanes x 16 row groups (16-byte loads, nb / 16 of them per thread), fixed order
+  __shared__ f32x4 red[16][16];
+  const long long per_b4 = (long long)Cin * Cout * npos / 4;
+  const int col4 = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const long long j4 = (long long)blockIdx.x * 16 + col4;
+  const f32x4* slab4 = (const f32x4*)slab;
+  f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int b = grp; b < nb; b += 16) s += slab4[b * per_b4 + j4];
+  red[grp][col4] = s;
   __syncthreads();
   if (grp != 0) return;
-  s = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
-  const int c = (int)(j & 31), r = (int)((j >> 5) & 31);
-  long long t = j >> 10;
-  const int pos = (int)(t % npos); t /= npos;
+#pragma unroll
+  for (int g = 1; g < 16; ++g) s += red[g][col4];
   const int ncob = Cout / 32;
-  const int cob = (int)(t % ncob), cib = (int)(t / ncob);
-  dW[((long long)(cib * 32 + r) * Cout + cob * 32 + c) * npos + pos] = s;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const long long j = j4 * 4 + k;
+    const int c = (int)(j & 31), r = (int)((j >> 5) & 31);
+    long long t = j >> 10;
+    const int pos = (int)(t % npos); t /= npos;
+    const int cob = (int)(t % ncob), cib = (int)(t / ncob);
+    dW[((long long)(cib * 32 + r) * Cout + cob * 32 + c) * npos + pos] = s[k];
+  }
 }
 
 // ------------------------------------------------------------------ first conv weight gradient (MFMA)
@@ -574,13 +614,17 @@ int iunet_convT_dgrad(int dtype, int nd, const void* dy, long long dy_ss, void* 
   const long long waves = (long long)N * D * H * ((W + 15) / 16);
   const int nk = Cout / 32;
   if (nk <= 4 && waves >= 256) {
-    const int lds = (nd == 3 ? 8 : 4) * nk * 2 * 1024;
+    // two ci blocks per workgroup (dy read once for both) where their operators stay within 32 KB of LDS
+    const int nci = (nk <= 2 && (Cin / 32) % 2 == 0 && (nd == 3 ? 8 : 4) * nk * 2 * 1024 * 2 <= 32768) ? 2 : 1;
+    const int lds = (nd == 3 ? 8 : 4) * nk * 2 * 1024 * nci;
     int gx = (int)((waves + 7) / 8);
-    const int cap = 1024 / (Cin / 32);
+    const int cap = 1024 / (Cin / 32 / nci);
     if (gx > cap) gx = cap;
-    dim3 g2(gx, Cin / 32);
-#define CDL(TT, NDV, NKV) do { IUNET_SET_MAX_LDS((convT_dgrad_lds_kernel<TT, NDV, NKV>), lds); \
-    hipLaunchKernelGGL((convT_dgrad_lds_kernel<TT, NDV, NKV>), g2, dim3(256), lds, (hipStream_t)stream, p); } while (0)
+    dim3 g2(gx, Cin / 32 / nci);
+#define CDL(TT, NDV, NKV) do { if (nci == 2) { IUNET_SET_MAX_LDS((convT_dgrad_lds_kernel<TT, NDV, NKV, 2>), lds); \
+      hipLaunchKernelGGL((convT_dgrad_lds_kernel<TT, NDV, NKV, 2>), g2, dim3(256), lds, (hipStream_t)stream, p); } \
+    else { IUNET_SET_MAX_LDS((convT_dgrad_lds_kernel<TT, NDV, NKV, 1>), lds); \
+      hipLaunchKernelGGL((convT_dgrad_lds_kernel<TT, NDV, NKV, 1>), g2, dim3(256), lds, (hipStream_t)stream, p); } } while (0)
 #define CDL_NK(TT, NDV) switch (nk) { case 1: CDL(TT, NDV, 1); break; case 2: CDL(TT, NDV, 2); break; case 3: CDL(TT, NDV, 3); break; default: CDL(TT, NDV, 4); break; }
     if (dtype == 0) { if (nd == 3) { CDL_NK(f16, 3) } else { CDL_NK(f16, 2) } }
     else            { if (nd == 3) { CDL_NK(bf16, 3) } else { CDL_NK(bf16, 2) } }
@@ -602,7 +646,8 @@ int iunet_convT_wgrad_blocks(int nd, int N, int D, int H, int W, int Cin, int Co
   if (N < 1 || D < 1 || H < 1 || W < 1 || Cin < 32 || Cout < 32) return 0;
   const int TZ = nd == 3 ? 2 : 1, TY = nd == 3 ? 4 : 8, TX = 16;
   const long long ntiles = (long long)N * ((D + TZ - 1) / TZ) * ((H + TY - 1) / TY) * ((W + TX - 1) / TX);
-  const int pairs = (Cin / 32) * (Cout / 32);
+  const int nci = (Cin / 32) % 2 == 0 ? 2 : 1;                       // ci blocks per workgroup (convT_wgrad_kernel: NCI)
+  const int pairs = (Cin / 32 / nci) * (Cout / 32);
   long long nb = (512 + pairs - 1) / pairs;
   if (nb > ntiles) nb = ntiles;
   return (int)(nb < 1 ? 1 : nb);
@@ -625,9 +670,12 @@ int iunet_convT_wgrad(int dtype, int nd, const void* x, long long x_ss, const vo
   const int npos = nd == 3 ? 8 : 4;
   const int nvi = 128, nvo = nd == 3 ? 1024 : 512;
   const int lds = 4 * (nvi * 16 + 64) + 4 * (nvo * 16 + 64);
-  dim3 grid(nb, Cin / 32, Cout / 32);
-#define CTW(TT, NDV) do { IUNET_SET_MAX_LDS((convT_wgrad_kernel<TT, NDV>), lds); \
-    hipLaunchKernelGGL((convT_wgrad_kernel<TT, NDV>), grid, dim3(256), lds, (hipStream_t)stream, p); } while (0)
+  const int nci = (Cin / 32) % 2 == 0 ? 2 : 1;
+  dim3 grid(nb, Cin / 32 / nci, Cout / 32);
+#define CTW(TT, NDV) do { if (nci == 2) { IUNET_SET_MAX_LDS((convT_wgrad_kernel<TT, NDV, 2>), lds); \
+      hipLaunchKernelGGL((convT_wgrad_kernel<TT, NDV, 2>), grid, dim3(256), lds, (hipStream_t)stream, p); } \
+    else { IUNET_SET_MAX_LDS((convT_wgrad_kernel<TT, NDV, 1>), lds); \
+      hipLaunchKernelGGL((convT_wgrad_kernel<TT, NDV, 1>), grid, dim3(256), lds, (hipStream_t)stream, p); } } while (0)
   if (dtype == 0) { if (nd == 3) CTW(f16, 3); else CTW(f16, 2); } else { if (nd == 3) CTW(bf16, 3); else CTW(bf16, 2); }
 #undef CTW
   const long long total = (long long)Cin * Cout * npos;
