@@ -225,23 +225,30 @@ __global__ __launch_bounds__(256, 2) void conv3_wgrad_kernel(WgradParams p) {
 // order (coalesced reads of every part), the small dW write is scattered.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int nb, int Cout, int Cin, int taps,
                                                            float* __restrict__ dW, float alpha) {
-  // 64 slab columns x 4 row groups per block (per_b is a multiple of 1024); fixed summation order
-  __shared__ float red[4][64];
-  const long long per_b = (long long)Cout * Cin * taps;
-  const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  const long long j = (long long)blockIdx.x * 64 + col;
-  float s = 0.f;
-  for (int b = grp; b < nb; b += 4) s += slab[b * per_b + j];
-  red[grp][col] = s;
+  // 64 slab columns per block as 16 float4 lanes x 16 row groups (per_b is a multiple of 1024): 16-byte loads, nb / 16 of them
+  // per thread; fixed summation order
+  __shared__ f32x4 red[16][16];
+  const long long per_b4 = (long long)Cout * Cin * taps / 4;
+  const int col4 = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const long long j4 = (long long)blockIdx.x * 16 + col4;
+  const f32x4* slab4 = (const f32x4*)slab;
+  f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int b = grp; b < nb; b += 16) s += slab4[b * per_b4 + j4];
+  red[grp][col4] = s;
   __syncthreads();
   if (grp != 0) return;
-  s = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
-  const int c = (int)(j & 31), r = (int)((j >> 5) & 31);
-  long long t = j >> 10;
-  const int tap = (int)(t % taps); t /= taps;
+#pragma unroll
+  for (int g = 1; g < 16; ++g) s += red[g][col4];
   const int ncib = Cin / 32;
-  const int cib = (int)(t % ncib), cob = (int)(t / ncib);
-  dW[((long long)(cob * 32 + r) * Cin + cib * 32 + c) * taps + tap] = alpha * s;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const long long j = j4 * 4 + k;
+    const int c = (int)(j & 31), r = (int)((j >> 5) & 31);
+    long long t = j >> 10;
+    const int tap = (int)(t % taps); t /= taps;
+    const int cib = (int)(t % ncib), cob = (int)(t / ncib);
+    dW[((long long)(cob * 32 + r) * Cin + cib * 32 + c) * taps + tap] = alpha * s[k];
+  }
 }
 
 template <typename T, int ND>

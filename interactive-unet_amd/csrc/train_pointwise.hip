@@ -862,6 +862,32 @@ __global__ __launch_bounds__(256) void reduce_slab_kernel(const float* __restric
   out[i] = alpha * s + (accumulate ? out[i] : 0.f);
 }
 
+// narrow slabs: 4 columns x 64 row groups per block; a thread walks nparts / 64 rows, four loads in flight, and the groups meet
+// in LDS (fixed order).  The one-thread-per-column kernel above walks ALL rows in one thread: 2 048 loads, each waited for, for
+// the head gradient.
+__global__ __launch_bounds__(256) void reduce_slab_tree_kernel(const float* __restrict__ slab, int nparts, long long n,
+                                                               float* __restrict__ out, float alpha, int accumulate) {
+  __shared__ float red[64][4];
+  const int col = threadIdx.x & 3, grp = threadIdx.x >> 2;
+  const long long i = (long long)blockIdx.x * 4 + col;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (i < n) {
+    int p = grp;
+    for (; p + 192 < nparts; p += 256) {
+      const float a = slab[(long long)p * n + i], b = slab[(long long)(p + 64) * n + i];
+      const float c = slab[(long long)(p + 128) * n + i], d = slab[(long long)(p + 192) * n + i];
+      s0 += a; s1 += b; s2 += c; s3 += d;
+    }
+    for (; p < nparts; p += 64) s0 += slab[(long long)p * n + i];
+  }
+  red[grp][col] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (grp != 0 || i >= n) return;
+  float s = red[0][col];
+  for (int g = 1; g < 64; ++g) s += red[g][col];
+  out[i] = alpha * s + (accumulate ? out[i] : 0.f);
+}
+
 // stage A of a wide reduction, in place: slab[g][i] += slab[g + G][i] + slab[g + 2G][i] + ...  (g < G)
 __global__ __launch_bounds__(256) void fold_slab_kernel(float* __restrict__ slab, int nparts, long long n, int G) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -1175,6 +1201,12 @@ int iunet_head_loss_bwd(int dtype, const void* x, long long x_ss, int C0, const 
 
 int iunet_reduce_slab(void* slab, int nparts, long long n, void* out, float alpha, int accumulate, void* stream) {
   IUNET_REQUIRE(slab && out, "reduce_slab: null pointer");
+  if (n <= 16384 && nparts > 16) {       // narrow slab (head / bias gradients: tens of columns, hundreds of rows): one launch, 64 row groups
+    hipLaunchKernelGGL(reduce_slab_tree_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)slab, nparts, n, (float*)out, alpha, accumulate);
+    IUNET_CHECK_HIP(hipGetLastError());
+    return IUNET_OK;
+  }
   const int G = 64;
   if (nparts > 2 * G) {      // wide slab: fold it to G rows first (in place; the slab is scratch)
     hipLaunchKernelGGL(fold_slab_kernel, dim3((unsigned)((n + 255) / 256), G), dim3(256), 0, (hipStream_t)stream,
