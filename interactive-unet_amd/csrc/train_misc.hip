@@ -568,7 +568,15 @@ __global__ __launch_bounds__(256) void first_wgrad_reduce_kernel(const float* __
   if (i < total) {
     const int tap = i % taps, c = (i / taps) % Cin, co = i / (taps * Cin);
     const float* src = slab + (long long)co * KKP + tap * Cin + c;
-    for (int b = grp; b < nb; b += 8) s += src[(long long)b * Cout * KKP];
+    const long long st = (long long)Cout * KKP;
+    int b = grp;
+    float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (; b + 24 < nb; b += 32) {                       // four loads in flight (one waited-for load per row took 21 us)
+      const float a0 = src[b * st], a1 = src[(b + 8) * st], a2 = src[(b + 16) * st], a3 = src[(b + 24) * st];
+      s += a0; s1 += a1; s2 += a2; s3 += a3;
+    }
+    for (; b < nb; b += 8) s += src[b * st];
+    s = (s + s1) + (s2 + s3);
   }
   red[grp][o] = s;
   __syncthreads();

@@ -43,12 +43,16 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     s += (double)slab[((long long)p * C + c) * 2];
     s2 += (double)slab[((long long)p * C + c) * 2 + 1];
   }
-  __shared__ double red[2][256];
-  red[0][threadIdx.x] = s; red[1][threadIdx.x] = s2;
+  // wave sums by lane exchange, the four waves meet in LDS: one barrier instead of the nine of a 256-wide LDS tree (these
+  // kernels are a few microseconds of pure latency between two convolutions, 28 of them per training step)
+  __shared__ double red[2][4];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); s2 += __shfl_xor(s2, o); }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = s2; }
   __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (threadIdx.x < o) { red[0][threadIdx.x] += red[0][threadIdx.x + o]; red[1][threadIdx.x] += red[1][threadIdx.x + o]; }
-    __syncthreads();
+  if (threadIdx.x == 0) {
+    red[0][0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    red[1][0] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
   }
   if (threadIdx.x == 0) {
     const double mean = red[0][0] / count;
@@ -273,12 +277,16 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
     s += (double)slab[((long long)p * C + c) * 2];
     s2 += (double)slab[((long long)p * C + c) * 2 + 1];
   }
-  __shared__ double red[2][256];
-  red[0][threadIdx.x] = s; red[1][threadIdx.x] = s2;
+  // wave sums by lane exchange, the four waves meet in LDS: one barrier instead of the nine of a 256-wide LDS tree (these
+  // kernels are a few microseconds of pure latency between two convolutions, 28 of them per training step)
+  __shared__ double red[2][4];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); s2 += __shfl_xor(s2, o); }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = s2; }
   __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (threadIdx.x < o) { red[0][threadIdx.x] += red[0][threadIdx.x + o]; red[1][threadIdx.x] += red[1][threadIdx.x + o]; }
-    __syncthreads();
+  if (threadIdx.x == 0) {
+    red[0][0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    red[1][0] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
   }
   if (threadIdx.x == 0) {
     dbeta[c] = (float)red[0][0];
