@@ -274,6 +274,17 @@ int iunet_head_loss_bwd_num_parts(int N, long long vox, int ncls, int C0);
 int iunet_head_loss_bwd(int dtype, const void* x, long long x_ss, int C0, const void* w, const void* bias, int ncls,
                         const void* target, const void* weight, int tdtype, const void* coef, float loss_scale, void* dx,
                         long long dx_ss, void* dwslab, int N, long long vox, void* stream);
+/* both with the head input given as relu(in_scale[c] * x + in_shift[c]) rounded to the activation dtype (fp32 [C0] each; see
+ * iunet_conv3_fwd_act): in training the BatchNorm + ReLU of the last stage conv is applied while loading and its output
+ * tensor is never written (bit-identical to running on the tensor iunet_bn_relu_fwd would store).  dx of the backward is the
+ * gradient of that ACTIVATION, i.e. what iunet_bn_relu_bwd takes as dz. */
+int iunet_head_loss_fwd_act(int dtype, const void* x, long long x_ss, int C0, const void* w, const void* bias, int ncls,
+                            const void* target, const void* weight, int tdtype, int kind, void* slab, void* out4, void* coef,
+                            const void* in_scale, const void* in_shift, int N, long long vox, void* stream);
+int iunet_head_loss_bwd_act(int dtype, const void* x, long long x_ss, int C0, const void* w, const void* bias, int ncls,
+                            const void* target, const void* weight, int tdtype, const void* coef, float loss_scale, void* dx,
+                            long long dx_ss, void* dwslab, const void* in_scale, const void* in_shift, int N, long long vox,
+                            void* stream);
 /* out[i] = alpha * sum_p slab[p][i] (+ out[i]); fixed summation order.  The slab is scratch:
  * wide slabs are folded in place first. */
 int iunet_reduce_slab(void* slab, int nparts, long long n, void* out, float alpha, int accumulate, void* stream);

@@ -503,7 +503,21 @@ struct HeadLossParams {
   float* dwslab;        // bwd: [nblocks][ncls*(C0+1)]
   float loss_scale;
   int N; long long vox;
+  // optional [C0] pair: the head input is relu(in_scale * x + in_shift) rounded to T -- the BatchNorm + ReLU of the last stage conv,
+  // applied while loading (training: that activation is read only by the head, so it is never written; bit-identical to reading
+  // the tensor bn_relu_fwd_kernel would have stored)
+  const float* in_scale; const float* in_shift;
 };
+
+template <typename T>
+__device__ __forceinline__ V8T<T> head_act(const HeadLossParams& p, V8T<T> v, int pl) {
+  if (p.in_scale == nullptr) return v;
+  V8T<T> o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    o[j] = from_f32<T>(fmaxf(fmaf(p.in_scale[pl * 8 + j], to_f32<T>(v[j]), p.in_shift[pl * 8 + j]), 0.f));
+  return o;
+}
 
 #define HEAD_FWD_ITER 8
 // sums per class: 0 sw, 1 swy, 2 swp, 3 swyp, 4 swy*log(p+eps), 5 sw*ry, 6 sw*rp, 7 sw*ry*rp
@@ -524,7 +538,7 @@ __global__ __launch_bounds__(256) void head_loss_fwd_kernel(HeadLossParams p) {
 #pragma unroll
     for (int c = 0; c < NCLS; ++c) l[c] = p.bias[c];
     for (int pl = 0; pl < p.planes; ++pl) {
-      const V8T<T> xv = *(const V8T<T>*)(xin + (long long)pl * p.vox * 8);
+      const V8T<T> xv = head_act<T>(p, *(const V8T<T>*)(xin + (long long)pl * p.vox * 8), pl);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float a = to_f32<T>(xv[j]);
@@ -671,7 +685,7 @@ __global__ __launch_bounds__(256) void head_loss_bwd_kernel(HeadLossParams p) {
     const T* xin = (const T*)p.x + n * p.x_ss + v * 8;
     V8T<T> xv[PL];
 #pragma unroll
-    for (int pl = 0; pl < PL; ++pl) xv[pl] = *(const V8T<T>*)(xin + (long long)pl * p.vox * 8);
+    for (int pl = 0; pl < PL; ++pl) xv[pl] = head_act<T>(p, *(const V8T<T>*)(xin + (long long)pl * p.vox * 8), pl);
     float l[NCLS];
 #pragma unroll
     for (int c = 0; c < NCLS; ++c) l[c] = p.bias[c];
@@ -769,7 +783,7 @@ __global__ __launch_bounds__(256) void head_loss_bwd_wide_kernel(HeadLossParams 
     if (live) {
       const T* xin = (const T*)p.x + n * p.x_ss + v * 8;
 #pragma unroll
-      for (int pl = 0; pl < PL; ++pl) xv[pl] = *(const V8T<T>*)(xin + (long long)pl * p.vox * 8);
+      for (int pl = 0; pl < PL; ++pl) xv[pl] = head_act<T>(p, *(const V8T<T>*)(xin + (long long)pl * p.vox * 8), pl);
       float l[NCLS];
 #pragma unroll
       for (int c = 0; c < NCLS; ++c) l[c] = p.bias[c];
@@ -1161,9 +1175,9 @@ int iunet_head_loss_bwd_num_parts(int N, long long vox, int ncls, int C0) {
   }
 
 // forward: head + softmax + loss sums -> loss value, rounded metrics, gradient coefficients
-int iunet_head_loss_fwd(int dtype, const void* x, long long x_ss, int C0, const void* w, const void* bias, int ncls,
-                        const void* target, const void* weight, int tdtype, int kind, void* slab, void* out4, void* coef,
-                        int N, long long vox, void* stream) {
+static int head_loss_fwd_impl(int dtype, const void* x, long long x_ss, int C0, const void* w, const void* bias, int ncls,
+                              const void* target, const void* weight, int tdtype, int kind, void* slab, void* out4, void* coef,
+                              int N, long long vox, const void* in_scale, const void* in_shift, void* stream) {
   DT_OK(dtype);
   IUNET_REQUIRE(x && w && bias && target && slab && out4 && coef, "head_loss_fwd: null pointer");
   IUNET_REQUIRE(ncls >= 2 && ncls <= 10, "head_loss: num_classes must be 2..10");
@@ -1172,6 +1186,7 @@ int iunet_head_loss_fwd(int dtype, const void* x, long long x_ss, int C0, const 
   HeadLossParams p{};
   p.x = x; p.x_ss = x_ss; p.planes = C0 / 8; p.w = (const float*)w; p.bias = (const float*)bias;
   p.target = target; p.weight = weight; p.tdtype = tdtype; p.slab = (float*)slab; p.N = N; p.vox = vox;
+  p.in_scale = (const float*)in_scale; p.in_shift = (const float*)in_shift;
   dim3 grid((unsigned)(iunet_head_loss_num_parts(N, vox) / N), N);
   if (dtype == 0) { HEAD_SWITCH(head_loss_fwd_kernel, f16) } else { HEAD_SWITCH(head_loss_fwd_kernel, bf16) }
   hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)slab,
@@ -1181,10 +1196,26 @@ int iunet_head_loss_fwd(int dtype, const void* x, long long x_ss, int C0, const 
   return IUNET_OK;
 }
 
+int iunet_head_loss_fwd(int dtype, const void* x, long long x_ss, int C0, const void* w, const void* bias, int ncls,
+                        const void* target, const void* weight, int tdtype, int kind, void* slab, void* out4, void* coef,
+                        int N, long long vox, void* stream) {
+  return head_loss_fwd_impl(dtype, x, x_ss, C0, w, bias, ncls, target, weight, tdtype, kind, slab, out4, coef, N, vox, nullptr, nullptr, stream);
+}
+
+// the same with the head input given as relu(in_scale[c] * x + in_shift[c]) (see iunet_conv3_fwd_act): the BatchNorm + ReLU of the
+// last stage conv is applied while loading, its output tensor is never written
+int iunet_head_loss_fwd_act(int dtype, const void* x, long long x_ss, int C0, const void* w, const void* bias, int ncls,
+                            const void* target, const void* weight, int tdtype, int kind, void* slab, void* out4, void* coef,
+                            const void* in_scale, const void* in_shift, int N, long long vox, void* stream) {
+  IUNET_REQUIRE(in_scale && in_shift, "head_loss_fwd_act: null scale / shift");
+  return head_loss_fwd_impl(dtype, x, x_ss, C0, w, bias, ncls, target, weight, tdtype, kind, slab, out4, coef, N, vox, in_scale, in_shift, stream);
+}
+
 // backward: dx (gradient wrt head input), dW/db slabs [num_parts][ncls*(C0+1)]
-int iunet_head_loss_bwd(int dtype, const void* x, long long x_ss, int C0, const void* w, const void* bias, int ncls,
-                        const void* target, const void* weight, int tdtype, const void* coef, float loss_scale, void* dx,
-                        long long dx_ss, void* dwslab, int N, long long vox, void* stream) {
+static int head_loss_bwd_impl(int dtype, const void* x, long long x_ss, int C0, const void* w, const void* bias, int ncls,
+                              const void* target, const void* weight, int tdtype, const void* coef, float loss_scale, void* dx,
+                              long long dx_ss, void* dwslab, int N, long long vox, const void* in_scale, const void* in_shift,
+                              void* stream) {
   DT_OK(dtype);
   IUNET_REQUIRE(x && w && bias && target && coef && dx && dwslab, "head_loss_bwd: null pointer");
   IUNET_REQUIRE(ncls >= 2 && ncls <= 10, "head_loss: num_classes must be 2..10");
@@ -1192,6 +1223,7 @@ int iunet_head_loss_bwd(int dtype, const void* x, long long x_ss, int C0, const 
   p.x = x; p.x_ss = x_ss; p.planes = C0 / 8; p.w = (const float*)w; p.bias = (const float*)bias;
   p.target = target; p.weight = weight; p.tdtype = tdtype; p.coef = (const float*)coef; p.loss_scale = loss_scale;
   p.dx = dx; p.dx_ss = dx_ss; p.dwslab = (float*)dwslab; p.N = N; p.vox = vox;
+  p.in_scale = (const float*)in_scale; p.in_shift = (const float*)in_shift;
   IUNET_REQUIRE(C0 == 32 || C0 == 64, "head_loss_bwd: head input must have 32 or 64 channels (got %d)", C0);
   dim3 grid((unsigned)(iunet_head_loss_bwd_num_parts(N, vox, ncls, C0) / N), N);
 #define HB(TT, NC, PLN) do { if constexpr (PLN * NC <= 16) hipLaunchKernelGGL((head_loss_bwd_kernel<TT, NC, PLN>), grid, dim3(256), 0, (hipStream_t)stream, p); \
@@ -1205,6 +1237,23 @@ int iunet_head_loss_bwd(int dtype, const void* x, long long x_ss, int C0, const 
 #undef HB
   IUNET_CHECK_HIP(hipGetLastError());
   return IUNET_OK;
+}
+
+int iunet_head_loss_bwd(int dtype, const void* x, long long x_ss, int C0, const void* w, const void* bias, int ncls,
+                        const void* target, const void* weight, int tdtype, const void* coef, float loss_scale, void* dx,
+                        long long dx_ss, void* dwslab, int N, long long vox, void* stream) {
+  return head_loss_bwd_impl(dtype, x, x_ss, C0, w, bias, ncls, target, weight, tdtype, coef, loss_scale, dx, dx_ss, dwslab, N, vox,
+                            nullptr, nullptr, stream);
+}
+
+// dx is then the gradient of the ACTIVATION relu(in_scale * x + in_shift) (what the BatchNorm backward of that layer takes)
+int iunet_head_loss_bwd_act(int dtype, const void* x, long long x_ss, int C0, const void* w, const void* bias, int ncls,
+                            const void* target, const void* weight, int tdtype, const void* coef, float loss_scale, void* dx,
+                            long long dx_ss, void* dwslab, const void* in_scale, const void* in_shift, int N, long long vox,
+                            void* stream) {
+  IUNET_REQUIRE(in_scale && in_shift, "head_loss_bwd_act: null scale / shift");
+  return head_loss_bwd_impl(dtype, x, x_ss, C0, w, bias, ncls, target, weight, tdtype, coef, loss_scale, dx, dx_ss, dwslab, N, vox,
+                            in_scale, in_shift, stream);
 }
 
 int iunet_reduce_slab(void* slab, int nparts, long long n, void* out, float alpha, int accumulate, void* stream) {

@@ -93,6 +93,10 @@ _SIGS = {
                             c_void_p, c_void_p, c_void_p, c_int, c_ll, c_void_p],
     'iunet_head_loss_bwd': [c_int, c_void_p, c_ll, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int,
                             c_void_p, c_float, c_void_p, c_ll, c_void_p, c_int, c_ll, c_void_p],
+    'iunet_head_loss_fwd_act': [c_int, c_void_p, c_ll, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int,
+                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_ll, c_void_p],
+    'iunet_head_loss_bwd_act': [c_int, c_void_p, c_ll, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int,
+                                c_void_p, c_float, c_void_p, c_ll, c_void_p, c_void_p, c_void_p, c_int, c_ll, c_void_p],
     'iunet_reduce_slab': [c_void_p, c_int, c_ll, c_void_p, c_float, c_int, c_void_p],
     'iunet_check_finite': [c_void_p, c_ll, c_void_p, c_void_p],
     'iunet_adamw_step': [c_void_p, c_void_p, c_void_p, c_void_p, c_ll, c_float, c_float, c_float, c_float, c_float,

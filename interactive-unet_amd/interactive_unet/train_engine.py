@@ -63,6 +63,7 @@ class TrainEngine:
         # the BatchNorm-backward sums of a stage's conv1 ride in the epilogue of conv2's data gradient (IUNET_NO_BW_FUSION=1: separate
         # reduction pass, for A/B runs)
         self.fuse_bw = not self.gn and not os.environ.get('IUNET_NO_BW_FUSION')
+        self.head_act = not self.gn and not os.environ.get('IUNET_NO_HEAD_ACT')     # A/B switch: materialise the last activation
         self._bw_ready = {}
         self._flatten()
         if self.pg is not None:
@@ -323,19 +324,28 @@ class TrainEngine:
             x2, act, z1p = self._conv2_input(ws, f'dec{l}', l, N)
             self._stage_conv_fwd(ws, f'dec{l}.conv1', self._P(ws[f'cat{l}']), 2 * ch[l] * v, 2 * ch[l], ch[l], l,
                                  z1p, ch[l] * v, N)
-            self._stage_conv_fwd(ws, f'dec{l}.conv2', x2, ch[l] * v, ch[l], ch[l], l,
-                                 self._P(ws[f'z.dec{l}.conv2']), ch[l] * v, N, x_act=act)
+            # the last stage's activation is read by the head only: with head_act the head kernels apply its BatchNorm + ReLU
+            # while loading the raw conv output (iunet_head_loss_fwd_act / _bwd_act) and the tensor is never written
+            z2 = None if (l == 0 and self.head_act) else self._P(ws[f'z.dec{l}.conv2'])
+            self._stage_conv_fwd(ws, f'dec{l}.conv2', x2, ch[l] * v, ch[l], ch[l], l, z2, ch[l] * v, N, x_act=act)
         return ws
 
-    def loss_forward(self, ws, feat, y, w, N, vox):
-        """head + softmax + loss sums + loss/metrics/coefs (device scalars in ws['out4'])."""
+    def loss_forward(self, ws, feat, y, w, N, vox, act=None):
+        """head + softmax + loss sums + loss/metrics/coefs (device scalars in ws['out4']).  act: name of the layer whose raw
+        output `feat` is (its BatchNorm + ReLU is then applied by the head kernel while loading)."""
         hw = self.p('head.weight')
         tdt = {torch.float32: 0, torch.float16: 1}[y.dtype]
         if w is not None and w.dtype != y.dtype:
             w = w.to(y.dtype)
-        nv.call('iunet_head_loss_fwd', self.dt, self._P(feat), self.ch[0] * vox, self.ch[0], nv.ptr(hw),
-                nv.ptr(self.p('head.bias')), self.ncls, nv.ptr(y), nv.ptr(w), tdt, self.kind, nv.ptr(ws['lslab']),
-                nv.ptr(ws['out4']), nv.ptr(ws['coef']), N, vox, nv.stream())
+        if act is None:
+            nv.call('iunet_head_loss_fwd', self.dt, self._P(feat), self.ch[0] * vox, self.ch[0], nv.ptr(hw),
+                    nv.ptr(self.p('head.bias')), self.ncls, nv.ptr(y), nv.ptr(w), tdt, self.kind, nv.ptr(ws['lslab']),
+                    nv.ptr(ws['out4']), nv.ptr(ws['coef']), N, vox, nv.stream())
+        else:
+            nv.call('iunet_head_loss_fwd_act', self.dt, self._P(feat), self.ch[0] * vox, self.ch[0], nv.ptr(hw),
+                    nv.ptr(self.p('head.bias')), self.ncls, nv.ptr(y), nv.ptr(w), tdt, self.kind, nv.ptr(ws['lslab']),
+                    nv.ptr(ws['out4']), nv.ptr(ws['coef']), nv.ptr(ws['scale.' + act]), nv.ptr(ws['shift.' + act]),
+                    N, vox, nv.stream())
         return tdt, w
 
     # ------------------------------------------------------------------ backward
@@ -418,12 +428,17 @@ class TrainEngine:
         L, ch, dims = self.levels, self.ch, ws['dims']
         s = nv.stream()
         v0 = _vox(dims[0])
-        feat = ws['z.dec0.conv2']
         dfeat = ws['dz.dec0.conv2']
         nparts = nv.lib().iunet_head_loss_bwd_num_parts(N, v0, self.ncls, ch[0])
-        nv.call('iunet_head_loss_bwd', self.dt, self._P(feat), ch[0] * v0, ch[0], nv.ptr(self.p('head.weight')),
-                nv.ptr(self.p('head.bias')), self.ncls, nv.ptr(y), nv.ptr(w), tdt, nv.ptr(ws['coef']),
-                self.loss_scale, self._P(dfeat), ch[0] * v0, nv.ptr(ws['hslab']), N, v0, s)
+        if self.head_act:
+            nv.call('iunet_head_loss_bwd_act', self.dt, self._P(ws['y.dec0.conv2']), ch[0] * v0, ch[0], nv.ptr(self.p('head.weight')),
+                    nv.ptr(self.p('head.bias')), self.ncls, nv.ptr(y), nv.ptr(w), tdt, nv.ptr(ws['coef']),
+                    self.loss_scale, self._P(dfeat), ch[0] * v0, nv.ptr(ws['hslab']), nv.ptr(ws['scale.dec0.conv2']),
+                    nv.ptr(ws['shift.dec0.conv2']), N, v0, s)
+        else:
+            nv.call('iunet_head_loss_bwd', self.dt, self._P(ws['z.dec0.conv2']), ch[0] * v0, ch[0], nv.ptr(self.p('head.weight')),
+                    nv.ptr(self.p('head.bias')), self.ncls, nv.ptr(y), nv.ptr(w), tdt, nv.ptr(ws['coef']),
+                    self.loss_scale, self._P(dfeat), ch[0] * v0, nv.ptr(ws['hslab']), N, v0, s)
         nv.call('iunet_reduce_slab', nv.ptr(ws['hslab']), nparts, self.ncls * (ch[0] + 1), nv.ptr(ws['htmp']), 1.0, 0, s)
         # slab layout: [planes][ncls][8] weight partials, then [ncls] bias partials
         nw = self.ncls * ch[0]
@@ -526,7 +541,10 @@ class TrainEngine:
         [N,ncls,*sp] (fp16 or fp32, the loader's contract loader.py:142-154)."""
         X, y, w, N, D, H, W, vox, xs = self._prep(X, y, w)
         ws = self.forward_train(X, xs, N, D, H, W)
-        tdt, w = self.loss_forward(ws, ws['z.dec0.conv2'], y, w, N, vox)
+        if self.head_act:
+            tdt, w = self.loss_forward(ws, ws['y.dec0.conv2'], y, w, N, vox, act='dec0.conv2')
+        else:
+            tdt, w = self.loss_forward(ws, ws['z.dec0.conv2'], y, w, N, vox)
         self.backward(ws, X, xs, y, w, tdt, N)
         self.optimizer_step()
         if sync:

@@ -202,6 +202,49 @@ def test_head_loss_bwd_kernel_variants(nv, C0, ncls, shape):
     _head_loss_case(nv, 'dice_ce', True, C0, ncls, shape)
 
 
+@pytest.mark.parametrize('C0,ncls,dtype', [(32, 2, torch.bfloat16), (64, 4, torch.float16), (32, 7, torch.float16)])
+def test_head_loss_act_variants_equal_the_materialised_path(nv, C0, ncls, dtype):
+    """iunet_head_loss_fwd_act / _bwd_act apply relu(scale * y + shift) while loading: every output must carry the bits of the
+    plain entry points run on the tensor iunet_bn_relu_fwd stores (register and LDS variants of the backward)."""
+    from interactive_unet.train_engine import LOSS_KINDS
+    g = torch.Generator().manual_seed(31)
+    N, shape, dev = 2, (24, 44), 'cuda'
+    vox = shape[0] * shape[1]
+    yraw = (torch.randn((N, C0) + shape, generator=g) * 1.5).to(dtype)
+    scale, shift = (0.5 + torch.rand(C0, generator=g)).to(dev), (0.4 * torch.randn(C0, generator=g)).to(dev)
+    yb = blocked(yraw.float(), dtype).to(dev)
+    zb = torch.empty_like(yb)
+    nv.call('iunet_bn_relu_fwd', nv.DTYPE_CODE[dtype], nv.ptr(yb), C0 * vox, nv.ptr(zb), C0 * vox, nv.ptr(scale), nv.ptr(shift), C0, N, vox, nv.stream())
+    w, b = (torch.randn(ncls, C0, generator=g) * 0.3).to(dev), (torch.randn(ncls, generator=g) * 0.1).to(dev)
+    lab = torch.randint(0, ncls, (N,) + shape, generator=g)
+    tgt = torch.stack([(lab == c) for c in range(ncls)], 1).float().to(dev).contiguous()
+    wt = (0.5 + torch.rand((N, 1) + shape, generator=g)).repeat(1, ncls, 1, 1).to(dev).contiguous()
+    dt = nv.DTYPE_CODE[dtype]
+    res = []
+    for act in (False, True):
+        nparts = nv.lib().iunet_head_loss_num_parts(N, vox)
+        lslab = torch.zeros(nparts * ncls * 8, device=dev)
+        out4, coef = torch.zeros(4, device=dev), torch.zeros(ncls * 3, device=dev)
+        dx = torch.zeros_like(yb)
+        nb = nv.lib().iunet_head_loss_bwd_num_parts(N, vox, ncls, C0)
+        hslab = torch.zeros(nb * ncls * (C0 + 1), device=dev)
+        if act:
+            nv.call('iunet_head_loss_fwd_act', dt, nv.ptr(yb), C0 * vox, C0, nv.ptr(w), nv.ptr(b), ncls, nv.ptr(tgt), nv.ptr(wt), 0,
+                    LOSS_KINDS['dice_ce'], nv.ptr(lslab), nv.ptr(out4), nv.ptr(coef), nv.ptr(scale), nv.ptr(shift), N, vox, nv.stream())
+            nv.call('iunet_head_loss_bwd_act', dt, nv.ptr(yb), C0 * vox, C0, nv.ptr(w), nv.ptr(b), ncls, nv.ptr(tgt), nv.ptr(wt), 0,
+                    nv.ptr(coef), 128.0, nv.ptr(dx), C0 * vox, nv.ptr(hslab), nv.ptr(scale), nv.ptr(shift), N, vox, nv.stream())
+        else:
+            nv.call('iunet_head_loss_fwd', dt, nv.ptr(zb), C0 * vox, C0, nv.ptr(w), nv.ptr(b), ncls, nv.ptr(tgt), nv.ptr(wt), 0,
+                    LOSS_KINDS['dice_ce'], nv.ptr(lslab), nv.ptr(out4), nv.ptr(coef), N, vox, nv.stream())
+            nv.call('iunet_head_loss_bwd', dt, nv.ptr(zb), C0 * vox, C0, nv.ptr(w), nv.ptr(b), ncls, nv.ptr(tgt), nv.ptr(wt), 0,
+                    nv.ptr(coef), 128.0, nv.ptr(dx), C0 * vox, nv.ptr(hslab), N, vox, nv.stream())
+        torch.cuda.synchronize()
+        res.append((out4.cpu(), coef.cpu(), dx.cpu(), hslab.cpu()))
+    for a, c in zip(*res):
+        assert torch.equal(a, c)
+    assert res[0][2].float().abs().max() > 0
+
+
 def _head_loss_case(nv, kind, weighted, C0, ncls, shape):
     from interactive_unet.train_engine import LOSS_KINDS
     g = torch.Generator().manual_seed(16)
