@@ -757,11 +757,20 @@ __global__ __launch_bounds__(256) void head_loss_bwd_kernel(HeadLossParams p) {
 #define HEAD_BWD_WIDE_ITER 8
 template <typename T, int NCLS, int PL>
 __global__ __launch_bounds__(256) void head_loss_bwd_wide_kernel(HeadLossParams p) {
+ 
   constexpr int C0 = PL * 8, SUBS = 256 / PL;
   const int n = blockIdx.y, t = threadIdx.x;
   __shared__ V8T<T> xs[PL][256];
   __shared__ float dls[256][NCLS];
   __shared__ float red[4 * NCLS];
+  // head weights and the optional input activation's constants in LDS (broadcast reads): left as global loads the compiler
+  // keeps all NCLS x C0 + 2 C0 of them in vector registers -- 256 VGPRs, one wave per SIMD, 468 us at C5's 64 x 4 head
+  __shared__ float wsm[NCLS * C0];
+  __shared__ float actp[2 * C0];
+  for (int i = threadIdx.x; i < NCLS * C0; i += 256) wsm[i] = p.w[i];
+  if (p.in_scale != nullptr)
+    for (int i = threadIdx.x; i < C0; i += 256) { actp[i] = p.in_scale[i]; actp[C0 + i] = p.in_shift[i]; }
+  __syncthreads();
   float accw[NCLS][8], accb[NCLS];
 #pragma unroll
   for (int c = 0; c < NCLS; ++c) {
@@ -776,25 +785,38 @@ __global__ __launch_bounds__(256) void head_loss_bwd_wide_kernel(HeadLossParams 
     if (v0 >= p.vox) break;
     const long long v = v0 + t;
     const bool live = v < p.vox;
-    V8T<T> xv[PL];
+    // Phase 1, one channel plane at a time in ROLLED loops: with the planes unrolled the compiler keeps all NCLS x C0 head weights
+    // (and the planes themselves) live at once -- 366 registers at C5's 64 x 4 head, one wave per SIMD or 200 spills.
+    __syncthreads();                                    // the previous chunk's phase 2 has read xs / dls
+    const T* xin = (const T*)p.x + n * p.x_ss + (live ? v : 0) * 8;
+    float l[NCLS];
+#pragma unroll
+    for (int c = 0; c < NCLS; ++c) l[c] = p.bias[c];
+#pragma unroll 1
+    for (int pl = 0; pl < PL; ++pl) {
+      V8T<T> x;
+      if (live) {
+        x = *(const V8T<T>*)(xin + (long long)pl * p.vox * 8);
+        if (p.in_scale != nullptr) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) x[j] = from_f32<T>(fmaxf(fmaf(actp[pl * 8 + j], to_f32<T>(x[j]), actp[C0 + pl * 8 + j]), 0.f));
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = from_f32<T>(0.f);
+      }
+      xs[pl][t] = x;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float xa = to_f32<T>(x[j]);
+#pragma unroll
+        for (int c = 0; c < NCLS; ++c) l[c] = fmaf(xa, wsm[c * C0 + pl * 8 + j], l[c]);
+      }
+    }
     float dl[NCLS];
 #pragma unroll
     for (int c = 0; c < NCLS; ++c) dl[c] = 0.f;
     if (live) {
-      const T* xin = (const T*)p.x + n * p.x_ss + v * 8;
-#pragma unroll
-      for (int pl = 0; pl < PL; ++pl) xv[pl] = head_act<T>(p, *(const V8T<T>*)(xin + (long long)pl * p.vox * 8), pl);
-      float l[NCLS];
-#pragma unroll
-      for (int c = 0; c < NCLS; ++c) l[c] = p.bias[c];
-#pragma unroll
-      for (int pl = 0; pl < PL; ++pl)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float a = to_f32<T>(xv[pl][j]);
-#pragma unroll
-          for (int c = 0; c < NCLS; ++c) l[c] = fmaf(a, p.w[c * C0 + pl * 8 + j], l[c]);
-        }
       float mx = l[0];
 #pragma unroll
       for (int c = 1; c < NCLS; ++c) mx = fmaxf(mx, l[c]);
@@ -816,34 +838,23 @@ __global__ __launch_bounds__(256) void head_loss_bwd_wide_kernel(HeadLossParams 
 #pragma unroll
       for (int c = 0; c < NCLS; ++c) { dl[c] = e[c] * (g[c] - dot) * p.loss_scale; accb[c] += dl[c]; }   // softmax backward
       T* dxo = (T*)p.dx + n * p.dx_ss + v * 8;
-#pragma unroll
+#pragma unroll 1
       for (int pl = 0; pl < PL; ++pl) {
         V8T<T> o;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           float a = 0.f;
 #pragma unroll
-          for (int c = 0; c < NCLS; ++c) a = fmaf(dl[c], p.w[c * C0 + pl * 8 + j], a);
+          for (int c = 0; c < NCLS; ++c) a = fmaf(dl[c], wsm[c * C0 + pl * 8 + j], a);
           o[j] = from_f32<T>(a);                        // dx = W^T dl
         }
         *(V8T<T>*)(dxo + (long long)pl * p.vox * 8) = o;
       }
     }
-    __syncthreads();                                    // the previous chunk's phase 2 has read xs / dls
 #pragma unroll
-    for (int c = 0; c < NCLS; ++c) dls[t][c] = dl[c];   // dl = 0 for a voxel past the end: its stale x adds nothing
-    if (live) {
-#pragma unroll
-      for (int pl = 0; pl < PL; ++pl) xs[pl][t] = xv[pl];
-    } else {
-      V8T<T> z;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) z[j] = from_f32<T>(0.f);
-#pragma unroll
-      for (int pl = 0; pl < PL; ++pl) xs[pl][t] = z;
-    }
+    for (int c = 0; c < NCLS; ++c) dls[t][c] = dl[c];   // dl = 0 for a voxel past the end: its zero x adds nothing
     __syncthreads();
-#pragma unroll
+#pragma unroll 2
     for (int i = 0; i < PL; ++i) {                      // dW[c][mypl*8 + j] += dl[c][v] x[mypl*8 + j][v]
       const int vv = sub + i * SUBS;
       const V8T<T> xq = xs[mypl][vv];
@@ -1227,7 +1238,7 @@ static int head_loss_bwd_impl(int dtype, const void* x, long long x_ss, int C0, 
   p.in_scale = (const float*)in_scale; p.in_shift = (const float*)in_shift;
   IUNET_REQUIRE(C0 == 32 || C0 == 64, "head_loss_bwd: head input must have 32 or 64 channels (got %d)", C0);
   dim3 grid((unsigned)(iunet_head_loss_bwd_num_parts(N, vox, ncls, C0) / N), N);
-#define HB(TT, NC, PLN) do { if constexpr (PLN * NC <= 16) hipLaunchKernelGGL((head_loss_bwd_kernel<TT, NC, PLN>), grid, dim3(256), 0, (hipStream_t)stream, p); \
+#define HB(TT, NC, PLN) do { if constexpr (PLN == 4 && NC <= 4) hipLaunchKernelGGL((head_loss_bwd_kernel<TT, NC, PLN>), grid, dim3(256), 0, (hipStream_t)stream, p); \
     else hipLaunchKernelGGL((head_loss_bwd_wide_kernel<TT, NC, PLN>), grid, dim3(256), 0, (hipStream_t)stream, p); } while (0)
 #define HB_SWITCH(TT, PLN) switch (ncls) { case 2: HB(TT, 2, PLN); break; case 3: HB(TT, 3, PLN); break; case 4: HB(TT, 4, PLN); break; \
     case 5: HB(TT, 5, PLN); break; case 6: HB(TT, 6, PLN); break; case 7: HB(TT, 7, PLN); break; case 8: HB(TT, 8, PLN); break; \
