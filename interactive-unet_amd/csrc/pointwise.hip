@@ -382,6 +382,142 @@ __global__ __launch_bounds__(256) void convT_lds_kernel(ConvTParams p) {
   }
 }
 
+// Cin > 128: the Cout tile's weights (16 KB per 32 input channels in 3-D) no longer fit in LDS at once, and the direct kernel at
+// the top fetches them per wave and k-step through the vector cache (1 KB of weight fragments per voxel and k-step: C5's
+// 256 / 512 / 1024-channel levels ran 60-115 us on a few MB of tensor).  Here they pass through LDS in chunks of NK = 4 k-steps
+// shared by the workgroup's 4 waves x 2 voxel groups; the accumulators live across the chunks.
+template <typename T, int ND>
+__global__ __launch_bounds__(256) void convT_chunk_kernel(ConvTParams p) {
+  constexpr int NK = 4;
+  using V8 = typename Vec8<T>::type;
+  constexpr int NPOS = ND == 3 ? 8 : 4;
+  constexpr int G = 2;                                           // voxel groups per wave and step
+  extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l15 = lane & 15, q = lane >> 4;
+  const int cob = blockIdx.y;
+  const int nchunks = (p.Cin >> 5) / NK;
+  const u32x4* wsrc = (const u32x4*)p.wpk + (long long)cob * nchunks * NK * NPOS * 2 * 64;
+  const int xg = (p.W + 15) / 16;
+  const long long rows = (long long)p.D * p.H * xg, ngroups = rows * p.N;
+  const long long in_plane = (long long)p.D * p.H * p.W * 8;
+  const int Do = ND == 3 ? p.D * 2 : 1, Ho = p.H * 2, Wo = p.W * 2;
+  const long long out_plane = (long long)Do * Ho * Wo * 8;
+  float bias[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) bias[j] = p.bias ? p.bias[cob * 32 + q * 8 + j] : 0.f;
+  const int src_lo = ((lane & 48) | (l15 >> 1)) * 4, src_hi = src_lo + 8 * 4;
+  const bool odd = l15 & 1;
+  const V8* wl = (const V8*)smem + lane;
+
+  for (long long base = (long long)blockIdx.x * 4 * G; base < ngroups; base += (long long)gridDim.x * 4 * G) {      // uniform trip count: barriers inside
+    const long long g0 = base + wave * G;
+    int n_[G], z_[G], y_[G], xb_[G];
+    const T* xin_[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const long long wid = g0 + g < ngroups ? g0 + g : ngroups - 1;      // a missing partner recomputes the last group (never stored)
+      n_[g] = (int)(wid / rows);
+      const long long r = wid - n_[g] * rows;
+      xb_[g] = (int)(r % xg); y_[g] = (int)((r / xg) % p.H); z_[g] = (int)(r / ((long long)xg * p.H));
+      const int xc = min(xb_[g] * 16 + l15, p.W - 1);
+      xin_[g] = (const T*)p.x + n_[g] * p.x_sstride + (((long long)z_[g] * p.H + y_[g]) * p.W + xc) * 8;
+    }
+    f32x4 acc[G][NPOS][2];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int s = 0; s < NPOS; ++s) { acc[g][s][0] = f32x4{0, 0, 0, 0}; acc[g][s][1] = f32x4{0, 0, 0, 0}; }
+    // chunk ch's weights travel global -> LDS buffer ch & 1 by LDS-DMA (lane-linear, no registers) while chunk ch - 1 is
+    // multiplied; the activation fragments of the next chunk are fetched into a second register set meanwhile.  One barrier per
+    // chunk: behind it every wave has finished the MFMAs that read the buffer the next copy overwrites.
+    constexpr int CHB = NK * NPOS * 2 * 1024;                      // bytes of one chunk (64 KB in 3-D)
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    auto dma_chunk = [&](int ch) {
+      const u32x4* src = wsrc + (long long)ch * (CHB / 16);
+#pragma unroll
+      for (int i = 0; i < CHB / 16 / 256; ++i) {
+        const int base = (i * 4 + wave) * 64;                       // first 16-byte item of this wave instruction
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (ch & 1) * CHB + base * 16);
+        const u32x4* gsrc = src + base + lane;
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+      }
+    };
+    auto load_b = [&](int ch, V8 (&bb)[G][NK]) {
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) bb[g][ks] = *(const V8*)(xin_[g] + (long long)((ch * NK + ks) * 4 + q) * in_plane);
+    };
+    V8 bcur[G][NK], bnext[G][NK];
+    __syncthreads();                                               // the previous pass's last chunk is read
+    dma_chunk(0);
+    load_b(0, bcur);
+    for (int ch = 0; ch < nchunks; ++ch) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this chunk's weights and fragments have landed
+      __syncthreads();
+      if (ch + 1 < nchunks) { dma_chunk(ch + 1); load_b(ch + 1, bnext); }
+      const V8* wb = wl + (ch & 1) * (CHB / 16);
+#pragma unroll
+      for (int ks = 0; ks < NK; ++ks)
+#pragma unroll
+        for (int s = 0; s < NPOS; ++s) {
+          const V8 a0 = wb[((ks * NPOS + s) * 2 + 0) * 64];
+          const V8 a1 = wb[((ks * NPOS + s) * 2 + 1) * 64];
+#pragma unroll
+          for (int g = 0; g < G; ++g) {
+            acc[g][s][0] = mfma16<T>(a0, bcur[g][ks], acc[g][s][0]);
+            acc[g][s][1] = mfma16<T>(a1, bcur[g][ks], acc[g][s][1]);
+          }
+        }
+      if (ch + 1 < nchunks) {
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+          for (int ks = 0; ks < NK; ++ks) bcur[g][ks] = bnext[g][ks];
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      if (g0 + g >= ngroups) break;
+      T* yout = (T*)p.y + n_[g] * p.y_sstride + (long long)(cob * 4 + q) * out_plane;
+      const int x0 = xb_[g] * 16;
+#pragma unroll
+      for (int sp = 0; sp < NPOS / 2; ++sp) {
+        const int a = ND == 3 ? (sp >> 1) : 0, bb = sp & 1;
+        typedef int i32x4 __attribute__((ext_vector_type(4)));
+        i32x4 oc[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          V8 o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            o[j] = from_f32<T>(acc[g][sp * 2 + c][0][j] + bias[j]);
+            o[4 + j] = from_f32<T>(acc[g][sp * 2 + c][1][j] + bias[4 + j]);
+          }
+          oc[c] = __builtin_bit_cast(i32x4, o);
+        }
+        const int oz = ND == 3 ? z_[g] * 2 + a : 0;
+        T* row = yout + (((long long)oz * Ho + y_[g] * 2 + bb) * Wo + 2 * x0) * 8;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int src = h ? src_hi : src_lo;
+          i32x4 v;
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {
+            const int t0 = __builtin_amdgcn_ds_bpermute(src, oc[0][d]);
+            const int t1 = __builtin_amdgcn_ds_bpermute(src, oc[1][d]);
+            v[d] = odd ? t1 : t0;
+          }
+          if (2 * x0 + 16 * h + l15 < Wo) *(i32x4*)(row + (16 * h + l15) * 8) = v;
+        }
+      }
+    }
+  }
+}
+
 // pack ConvTranspose weights fp32 [Cin][Cout][2^d] -> [cob32][kstep][pos][t][64][8]
 template <typename T>
 __global__ void pack_convT_kernel(const float* __restrict__ w, T* __restrict__ dst, int Cin, int Cout, int npos) {
@@ -540,6 +676,21 @@ int iunet_convT_launch(int dtype, int nd, const void* x, long long x_ss, void* y
     else            { if (nd == 3) { CTL_NK(bf16, 3) } else { CTL_NK(bf16, 2) } }
 #undef CTL_NK
 #undef CTL
+    IUNET_CHECK_HIP(hipGetLastError());
+    return IUNET_OK;
+  }
+  if (nk > 4 && nk % 4 == 0 && waves >= 64) {
+    // weights through LDS in chunks of 4 k-steps (convT_chunk_kernel): few workgroups, each walking many voxel groups per weight pass
+    const int npos = nd == 3 ? 8 : 4;
+    const int lds = 2 * 4 * npos * 2 * 1024;           // two chunk buffers
+    int gx = (int)((waves + 7) / 8);
+    const int cap = 512 / (Cout / 32) > 1 ? 512 / (Cout / 32) : 1;
+    if (gx > cap) gx = cap;
+    dim3 g2(gx, Cout / 32);
+#define CTC(TT, NDV) do { IUNET_SET_MAX_LDS((convT_chunk_kernel<TT, NDV>), lds); \
+    hipLaunchKernelGGL((convT_chunk_kernel<TT, NDV>), g2, dim3(256), lds, stream, p); } while (0)
+    if (dtype == 0) { if (nd == 3) CTC(f16, 3); else CTC(f16, 2); } else { if (nd == 3) CTC(bf16, 3); else CTC(bf16, 2); }
+#undef CTC
     IUNET_CHECK_HIP(hipGetLastError());
     return IUNET_OK;
   }
