@@ -397,14 +397,16 @@ def test_full_train_step_vs_autograd(dim, shape, dtype):
     assert np.isfinite(ev['Loss'])
 
 
-@pytest.mark.parametrize('nd,cin', [(3, 32), (3, 64), (2, 32), (2, 64)])
-def test_conv3_fwd_and_wgrad_with_fused_input_activation(nv, nd, cin):
+@pytest.mark.parametrize('nd,cin,big', [(3, 32, False), (3, 64, False), (2, 32, False), (2, 64, False), (3, 64, True)])
+def test_conv3_fwd_and_wgrad_with_fused_input_activation(nv, nd, cin, big):
     """iunet_conv3_fwd_act / iunet_conv3_wgrad_act (input = relu(scale * y + shift) applied while staging) equal
-    the unfused sequence bn_relu_fwd -> conv3_fwd / conv3_wgrad bit for bit (same rounding of the activation)."""
+    the unfused sequence bn_relu_fwd -> conv3_fwd / conv3_wgrad bit for bit (same rounding of the activation).
+    big: a grid walked in tile pairs -- the fused launch stages its halo tiles through registers, the plain one by LDS-DMA."""
     g = torch.Generator().manual_seed(21)
     T, dt = torch.bfloat16, 1
     N, cout = 2, 32
-    shape = (6, 12, 20) if nd == 3 else (24, 44)
+    shape = (58, 62, 120) if big else (6, 12, 20) if nd == 3 else (24, 44)
+    assert nv.lib().iunet_conv3_tile_pairs(nd, N, *(shape if nd == 3 else (1,) + shape), cin, cout) == int(big)
     D, H, W = shape if nd == 3 else (1,) + shape
     taps = 3 ** nd
     vox = D * H * W
