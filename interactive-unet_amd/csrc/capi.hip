@@ -79,7 +79,7 @@ int iunet_conv3_num_tiles(int nd, int N, int D, int H, int W) { return iunet_con
 
 // rows of the statistics buffer a conv3_fwd launch with this layout writes (and bn_finalize must read)
 int iunet_conv3_stats_parts(int nd, int N, int D, int H, int W, int Cout, int layout) {
-  return layout == 2 ? iunet_conv3_v4_stats_parts(nd, Cout) : iunet_conv3_tiles(nd, N, D, H, W);
+  return layout >= 2 ? iunet_conv3_v4_stats_parts(nd, Cout) : iunet_conv3_tiles(nd, N, D, H, W);
 }
 
 long long iunet_pack_conv3_elems(int Cout, int Cin, int taps, int mode) { return iunet_pack_conv3_size(Cout, Cin, taps, mode); }
@@ -126,7 +126,7 @@ int iunet_conv3_fwd(int dtype, int nd, const void* x, long long x_sstride, void*
   IUNET_REQUIRE(x && y && wpk, "conv3: null pointer");
   IUNET_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0, "conv3: bad shape %d %d %d %d", N, D, H, W);
   IUNET_REQUIRE(epi >= 0 && epi <= 2, "conv3: bad epilogue %d", epi);
-  IUNET_REQUIRE(layout >= 0 && layout <= 2, "conv3: layout must be 0, 1 or 2 (got %d)", layout);
+  IUNET_REQUIRE(layout >= 0 && layout <= 3, "conv3: layout must be 0, 1, 2 or 3 (got %d)", layout);
   return iunet_conv3_launch(dtype, nd, x, x_sstride, y, y_sstride, wpk, (const float*)bias, (float*)stats, N, D, H, W,
                             Cin, Cout, epi, layout, (hipStream_t)stream);
 }
@@ -140,7 +140,7 @@ int iunet_conv3_fwd_act(int dtype, int nd, const void* x, long long x_sstride, v
   IUNET_REQUIRE(x && y && wpk && in_scale && in_shift, "conv3_act: null pointer");
   IUNET_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0, "conv3: bad shape %d %d %d %d", N, D, H, W);
   IUNET_REQUIRE(epi >= 0 && epi <= 2, "conv3: bad epilogue %d", epi);
-  IUNET_REQUIRE(layout == 2, "conv3_act: the fused input activation exists in layout 2 only (got %d)", layout);
+  IUNET_REQUIRE(layout == 2 || layout == 3, "conv3_act: the fused input activation exists in layouts 2 and 3 only (got %d)", layout);
   return iunet_conv3_launch(dtype, nd, x, x_sstride, y, y_sstride, wpk, (const float*)bias, (float*)stats, N, D, H, W,
                             Cin, Cout, epi, layout, (hipStream_t)stream, (const float*)in_scale, (const float*)in_shift);
 }

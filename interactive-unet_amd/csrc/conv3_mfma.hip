@@ -303,6 +303,36 @@ __global__ void pack_conv3_k16_kernel(const float* __restrict__ w, const float* 
   }
 }
 
+// Compact K16 order of the 3^3 filter (mode bit 2; conv3_v4.hip's padding-free step): the ninth (dz, dx) column of two consecutive
+// 16-channel chunks shares one k-step instead of being padded to a pair with zeros.  Per Cout tile and chunk PAIR (32 channels):
+//   [even chunk: column pairs 0..3][dy][2][64][8]  (24 KB)  |  [odd chunk: the same]  (24 KB)  |  [cross: dy][2][64][8]  (6 KB),
+// cross lanes q >> 1 = 0: column 8 of the even chunk, q >> 1 = 1: column 8 of the odd chunk.  Cout x Cin x 27 elements: no padding.
+template <typename T>
+__global__ void pack_conv3_k16c_kernel(const float* __restrict__ w, const float* __restrict__ scale, T* __restrict__ dst,
+                                       int CoutP, int CinP, int dgrad, int CinO) {
+  constexpr int taps = 27, FR = 512, EVEN = 4 * 3 * 2 * FR, PAIR = 2 * EVEN + 3 * 2 * FR;      // elements
+  const int npair = CinP >> 5;
+  const long long total = (long long)(CoutP / 32) * npair * PAIR;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int e = (int)(i % PAIR);
+    long long r = i / PAIR;
+    const int pr = (int)(r % npair), cob = (int)(r / npair);
+    const int j = e & 7, lane = (e >> 3) & 63;
+    const int row = lane & 15, qq = lane >> 4;
+    int frag = e >> 9, chunk, col;                                  // fragment index within the pair block
+    if (frag < 48) { chunk = 2 * pr + frag / 24; frag %= 24; col = 2 * (frag / 6) + (qq >> 1); frag %= 6; }
+    else { frag -= 48; chunk = 2 * pr + (qq >> 1); col = 8; }
+    const int dy = frag >> 1, m = frag & 1;
+    const int co = cob * 32 + 8 * (row >> 2) + 4 * m + (row & 3);
+    const int ci = chunk * 16 + 8 * (qq & 1) + j;
+    const int tap = ((col / 3) * 3 + dy) * 3 + (col % 3);
+    float v;
+    if (!dgrad) { v = w[((long long)co * CinO + ci) * taps + tap]; if (scale) v *= scale[co]; }
+    else v = w[((long long)ci * CinO + co) * taps + (taps - 1 - tap)];
+    dst[i] = from_f32<T>(v);
+  }
+}
+
 template <typename T, int ND, int MI>
 int launch_conv3(const Conv3Params& p, hipStream_t stream) {
   using TL = Tile<ND>;
@@ -324,7 +354,7 @@ int iunet_conv3_v2_launch(int dtype, int nd, const void* x, long long x_sstride,
 int iunet_conv3_v4_launch(int dtype, int nd, const void* x, long long x_sstride, void* y, long long y_sstride, const void* wpk,
                           const float* bias, float* stats, int N, int D, int H, int W, int Cin, int Cout, int epi,
                           const float* in_scale, const float* in_shift, hipStream_t stream, const void* bw_y = nullptr,
-                          long long bw_y_ss = 0, const float* const* bw_par = nullptr);
+                          long long bw_y_ss = 0, const float* const* bw_par = nullptr, int compact = 0);
 
 // Host entry used by the net runtime and the per-kernel C ABI.
 int iunet_conv3_launch(int dtype, int nd, const void* x, long long x_sstride, void* y, long long y_sstride,
@@ -342,11 +372,11 @@ int iunet_conv3_launch(int dtype, int nd, const void* x, long long x_sstride, vo
   p.tilesZ = (D + TZ - 1) / TZ; p.tilesY = (H + TY - 1) / TY; p.tilesX = (W + TX - 1) / TX;
   const bool wide = (Cout % 64 == 0);
   IUNET_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv3: in_scale and in_shift come together");
-  IUNET_REQUIRE(in_scale == nullptr || layout == 2, "conv3: a fused input activation needs layout 2 (got %d)", layout);
+  IUNET_REQUIRE(in_scale == nullptr || layout >= 2, "conv3: a fused input activation needs layout 2 or 3 (got %d)", layout);
   IUNET_REQUIRE(bw_y == nullptr || layout == 2, "conv3: the fused BatchNorm-backward sums need layout 2 (got %d)", layout);
-  if (layout == 2) {
+  if (layout >= 2) {
     return iunet_conv3_v4_launch(dtype, nd, x, x_sstride, y, y_sstride, wpk, bias, stats, N, D, H, W, Cin, Cout, epi,
-                                 in_scale, in_shift, stream, bw_y, bw_y_ss, bw_par);
+                                 in_scale, in_shift, stream, bw_y, bw_y_ss, bw_par, layout == 3);
   }
   if (layout == 1)
     return iunet_conv3_v2_launch(dtype, nd, x, x_sstride, y, y_sstride, wpk, bias, stats, N, D, H, W, Cin, Cout, epi, stream);
@@ -406,6 +436,7 @@ int iunet_conv3_pick(int nd, int N, int D, int H, int W, int Cin, int Cout) {
 
 // elements of the packed operator (the K16 order pads the tap count to an even number)
 long long iunet_pack_conv3_size(int Cout, int Cin, int taps, int mode) {
+  if ((mode & 4) && taps == 27) return (long long)Cout * Cin * taps;   // compact K16 (3-D): no padding
   const int t = (mode & 2) ? ((taps / 3 + 1) / 2) * 6 : taps;      // K16 order pads the filter columns to pairs
   return (long long)Cout * Cin * t;
 }
@@ -417,6 +448,15 @@ int iunet_pack_conv3_launch(int dtype, const float* w, const float* scale, void*
   const int CoutP = dg == 0 ? Cout : Cin, CinP = dg == 0 ? Cin : Cout;
   IUNET_REQUIRE(CoutP % 32 == 0 && CinP % 32 == 0, "pack_conv3: channel counts must be multiples of 32 (%d, %d)", CoutP, CinP);
   const int MI = iunet_conv3_mi(CoutP);
+  if (mode & 4) {     // compact K16 (conv3_v4.hip layout 3: 3-D only)
+    IUNET_REQUIRE(taps == 27, "pack_conv3: the compact K16 order exists for the 3^3 filter only");
+    const long long tot = (long long)CoutP * CinP * 27;
+    const int nb = (int)((tot + 255) / 256 < 4096 ? (tot + 255) / 256 : 4096);
+    if (dtype == 0) hipLaunchKernelGGL(pack_conv3_k16c_kernel<f16>, dim3(nb), dim3(256), 0, stream, w, scale, (f16*)dst, CoutP, CinP, dg, Cin);
+    else hipLaunchKernelGGL(pack_conv3_k16c_kernel<bf16>, dim3(nb), dim3(256), 0, stream, w, scale, (bf16*)dst, CoutP, CinP, dg, Cin);
+    IUNET_CHECK_HIP(hipGetLastError());
+    return IUNET_OK;
+  }
   if (mode & 2) {     // the LDS-fed structure's K16 fragment order
     const long long tot = (long long)(CoutP / 32) * (CinP / 16) * ((taps / 3 + 1) / 2) * 3 * 1024;
     const int nb = (int)((tot + 255) / 256 < 4096 ? (tot + 255) / 256 : 4096);

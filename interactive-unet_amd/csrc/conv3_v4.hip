@@ -74,9 +74,14 @@ struct ConvV4Params {
 // fabric (64 -> 32 @ 2 x 128^3 moves 2.4 GB of halo tiles, weights and outputs in 0.35-0.43 ms = 5.6-6.9 TB/s, the
 // rate the chip sustains), and the re-streamed weights are 41 % of them.  Cost: a second accumulator set (32 registers), so 4 loader
 // waves instead of 8 (12 waves per CU: 168 registers each).
-template <typename T, int ND, bool WS, bool SMALL, bool BW = false, bool PAIR = false>
+// NP ("no padding", layout 3, experimental): the compact operator order of pack mode bit 2.  A 16-channel step multiplies column pairs
+// 0..3 only; the ninth column waits for the next chunk: the odd step adds one "cross" group whose k-slot holds column 8 of the
+// previous chunk (read from the previous step's halo buffer, which a ring of THREE buffers keeps alive) and column 8 of its own.
+// 27 taps in 27 K-slots: -10 % MFMAs, fragment reads and weight bytes.  LDS: 3 x 34 816 + 24 576 + 30 720 + scratch = 162 304 B.
+template <typename T, int ND, bool WS, bool SMALL, bool BW = false, bool PAIR = false, bool NP = false>
 __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + ((WS || PAIR) ? 256 : 512)), 1) void conv3_v4_kernel(ConvV4Params p) {
   static_assert(!PAIR || (!WS && !BW && ND == 3), "tile pairs: the streamed-weight 3-D forward / data-gradient variant only");
+  static_assert(!NP || (!WS && !BW && !SMALL && !PAIR && ND == 3), "padding-free step: the streamed-weight 3-D big-tile variant only (so far)");
   using V8 = typename Vec8<T>::type;
   using TL = V4Tile<ND, SMALL>;
   // consumer waves; loader threads: 4 loader waves when only activations stream, 8 when the weights stream too (twice the
@@ -92,9 +97,11 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + ((WS || PAIR) ? 256 
   constexpr int NCMB = (NCOL + 1) / 2, KS = NCMB * 3;
   constexpr int WBYTES = KS * 2 * 1024;                // one 16-channel chunk of packed weights
   constexpr int WSTEP = S16 * WBYTES;                  // the weights of one step
-  constexpr int OFF_W = 2 * ABUF;
+  constexpr int NBUF = NP ? 3 : 2;                     // halo buffers
+  constexpr int OFF_W = NBUF * ABUF;
+  constexpr int WE = 4 * 3 * 2 * 1024, WO = WE + 3 * 2 * 1024;      // NP: bytes of an even step's weights (4 column pairs) / an odd step's (+ the cross pair)
   constexpr int AIT = (NPIX + NLT - 1) / NLT;          // halo pixels per loader thread (5 / 3)
-  constexpr int WIT = (WSTEP / 16 + NLT - 1) / NLT;    // 16-byte weight items per loader thread (8 / 6)
+  constexpr int WIT = ((NP ? WO : WSTEP) / 16 + NLT - 1) / NLT;    // 16-byte weight items per loader thread (8 / 6)
   constexpr int NGRP = S16 * NCMB;                     // (16-channel sub-chunk, column pair) groups per step
   constexpr int NRD = FX * (NR + 2) + 6;               // LDS fragment reads per group
   static_assert(NCW * NI == TZ * TY * FX, "consumer waves x fragments must cover the tile");
@@ -126,15 +133,16 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + ((WS || PAIR) ? 256 
     return;
   }
   const long long plane_stride = (long long)p.D * p.H * p.W * 8;
-  const int off_red = OFF_W + (WS ? nchunk : 2) * WSTEP;    // 2 KB of scratch for the BatchNorm partial sums
+  const int off_red = OFF_W + (NP ? WE + WO : (WS ? nchunk : 2) * WSTEP);    // 2 KB of scratch for the BatchNorm partial sums
   const int off_act = off_red + 2048;                       // the fused input activation: [Cin / 8][scale 8 | shift 8] floats
-  const int off_bw = off_act + p.Cin * 8;                   // bw_y: [mean | invstd | scale | shift][32] floats of this Cout tile
+  const int off_bw = off_act + (p.in_scale != nullptr || !NP ? p.Cin * 8 : 0);                   // bw_y: [mean | invstd | scale | shift][32] floats of this Cout tile
   constexpr bool bw = BW;
   if (bw && tid < 128) {
     const float* src = (tid >> 5) == 0 ? p.bw_mean : (tid >> 5) == 1 ? p.bw_invstd : (tid >> 5) == 2 ? p.bw_scale : p.bw_shift;
     ((float*)(smem + off_bw))[tid] = src[cob * 32 + (tid & 31)];       // read in tile epilogues, many barriers later
   }
-  const u32x4* wsrc = (const u32x4*)p.wpk + (long long)cob * nchunk * (WSTEP / 16);
+  const u32x4* wsrc = (const u32x4*)p.wpk + (long long)cob * (NP ? (nchunk / 2) * ((WE + WO) / 16) : nchunk * (WSTEP / 16));
+  auto abuf_of = [&](int s) -> int { return NP ? (s - 3 * (s / 3)) * ABUF : (s & 1) * ABUF; };      // halo buffer of step s
 
   auto tile_origin = [&](int k, int& n_img, int& z0, int& y0, int& x0) -> bool {      // this workgroup's k-th tile
     int b = b_begin + k;
@@ -178,14 +186,18 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + ((WS || PAIR) ? 256 
     // vector-memory counter; the wait for the activation loads that were issued before it retires it too (in order).
     auto dma_weights = [&](int s, int buf, int it0 = 0, int it1 = 1 << 20) {     // the weights of step s -> weight buffer buf (items it0..it1 of each thread)
       const int chunk = chunk_of(s);
-      const u32x4* ws = wsrc + (long long)chunk * (WSTEP / 16);
+      // NP: the pair block of the chunk's pair is [even 24 KB | odd 24 KB | cross 6 KB]; an even step takes the first part into the
+      // "even" region, an odd step the rest into the "odd" region (each region is free again after the next step of the other parity)
+      const u32x4* ws = NP ? wsrc + (long long)(chunk >> 1) * ((WE + WO) / 16) + ((chunk & 1) ? WE / 16 : 0) : wsrc + (long long)chunk * (WSTEP / 16);
+      const int nitem = NP ? ((chunk & 1) ? WO / 16 : WE / 16) : WSTEP / 16;
+      const int woff = NP ? ((chunk & 1) ? WE : 0) : buf * WSTEP;
 #pragma unroll
       for (int it = 0; it < WIT; ++it) {
         if (it < it0 || it >= it1) continue;
         const int base = it * NLT + lw * 64;                                  // first item of this wave instruction
-        if (base < WSTEP / 16) {
-          const u32x4* gsrc = ws + min(base + (lt & 63), WSTEP / 16 - 1);
-          const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + OFF_W + buf * WSTEP + base * 16);   // uniform by construction; keeps it in an SGPR for M0
+        if (base < nitem) {
+          const u32x4* gsrc = ws + min(base + (lt & 63), nitem - 1);
+          const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + OFF_W + woff + base * 16);   // uniform by construction; keeps it in an SGPR for M0
           unsigned keep;
           asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                        : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
@@ -223,7 +235,7 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + ((WS || PAIR) ? 256 
       int n_img, z0, y0, x0;
       tile_origin(tile_of(s), n_img, z0, y0, x0);
       const T* xc = (const T*)p.x + (long long)n_img * p.x_sstride + (long long)chunk * CP * plane_stride;
-      const unsigned abuf = lds0 + (s & 1) * ABUF;
+      const unsigned abuf = lds0 + abuf_of(s);
 #pragma unroll
       for (int it = 0; it < AIT; ++it) {
         const int base = it * NLT + lw * 64;                                  // first pixel of this wave instruction
@@ -252,7 +264,7 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + ((WS || PAIR) ? 256 
     // drain the prefetched next step too)
     auto commit = [&](int s, const Staged& r, auto ACT) {
       constexpr bool act = decltype(ACT)::value;
-      unsigned char* ab = smem + (s & 1) * ABUF;
+      unsigned char* ab = smem + abuf_of(s);
       const int cfirst = chunk_of(s) * CP * 8;
 #pragma unroll
       for (int k = 0; k < CP; ++k) {
@@ -369,7 +381,7 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + ((WS || PAIR) ? 256 
           load(min(s + 2, last), r2);
           commit(s + 1, r, ACT);
           lds_barrier();
-          dma_weights(min(s + 2, last), 0);
+          if (!NP || s + 2 <= last) dma_weights(min(s + 2, last), 0);     // (NP: a clamped copy would land in the region being read)
           load(min(s + 3, last), r);
           commit(s + 2, r2, ACT);
           lds_barrier();
@@ -436,8 +448,23 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + ((WS || PAIR) ? 256 
   V8 R[2][FX][NR + 2], A[2][3][2];
   auto step_ptrs = [&](int s, const unsigned char*& ab, const unsigned char*& wl) {
     const int chunk = chunk_of(s);
-    ab = smem + (s & 1) * ABUF + rbase;
-    wl = smem + OFF_W + (WS ? chunk : PAIR ? (chunk & 1) : (s & 1)) * WSTEP + lane * 16;
+    ab = smem + abuf_of(s) + rbase;
+    wl = smem + OFF_W + (NP ? ((chunk & 1) ? WE : 0) : (WS ? chunk : PAIR ? (chunk & 1) : (s & 1)) * WSTEP) + lane * 16;
+  };
+  // NP, odd steps: the cross group.  Lanes q >> 1 = 0 read column 8 of the PREVIOUS step's halo buffer, q >> 1 = 1 of this step's;
+  // the weights follow the four regular pairs in the odd region.
+  auto load_cross = [&](const unsigned char* ab, const unsigned char* abp, const unsigned char* wl, auto BUF) {
+    constexpr int b = decltype(BUF)::value;
+    const unsigned char* ax = (q >> 1) ? ab : abp;
+#pragma unroll
+    for (int xh = 0; xh < FX; ++xh)
+#pragma unroll
+      for (int r = 0; r < NR + 2; ++r) R[b][xh][r] = *(const V8*)(ax + (r * PX + xh * 16) * 16 + col_off[NCMB - 1]);
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      A[b][dy][0] = *(const V8*)(wl + WE + (dy * 2 + 0) * 1024);
+      A[b][dy][1] = *(const V8*)(wl + WE + (dy * 2 + 1) * 1024);
+    }
   };
   auto load_group = [&](const unsigned char* ab, const unsigned char* wl, int g, auto BUF) {
     constexpr int b = decltype(BUF)::value;
@@ -582,24 +609,34 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + ((WS || PAIR) ? 256 
       // barrier and the epilogue spills): the pipeline restarts every step, the barrier closes the step
       using B0 = std::integral_constant<int, 0>;
       using B1 = std::integral_constant<int, 1>;
-      auto one_step = [&](int s, auto TSET) {
-        const unsigned char *ab, *wl;
+      auto one_step = [&](int s, auto TSET, auto ODD) {
+        // NP: an even step has the four regular column pairs, an odd step those plus the cross pair (ODD: compile-time parity)
+        constexpr int NG = NP ? (decltype(ODD)::value ? NCMB : NCMB - 1) : NGRP;
+        const unsigned char *ab, *wl, *abp = nullptr;
         step_ptrs(s, ab, wl);
+        if constexpr (NP) abp = smem + abuf_of(s - 1) + rbase;
         bw_prefetch(s);
         load_group(ab, wl, 0, B0{});
         __builtin_amdgcn_sched_barrier(0);
+        auto fetch = [&](int g, auto BUF) {
+          if (NP && g == NCMB - 1) load_cross(ab, abp, wl, BUF); else load_group(ab, wl, g, BUF);
+        };
 #pragma unroll
-        for (int g = 0; g < NGRP; ++g) {
-          if ((g & 1) == 0) { if (g + 1 < NGRP) load_group(ab, wl, g + 1, B1{}); group_mfmas(B0{}, g + 1 < NGRP, TSET); }
-          else              { if (g + 1 < NGRP) load_group(ab, wl, g + 1, B0{}); group_mfmas(B1{}, g + 1 < NGRP, TSET); }
+        for (int g = 0; g < NG; ++g) {
+          if ((g & 1) == 0) { if (g + 1 < NG) fetch(g + 1, B1{}); group_mfmas(B0{}, g + 1 < NG, TSET); }
+          else              { if (g + 1 < NG) fetch(g + 1, B0{}); group_mfmas(B1{}, g + 1 < NG, TSET); }
         }
         tile_epilogue(s, TSET);
         lds_barrier();               // consumers are done with this step's buffers, the loaders have filled the others
       };
+      using EVEN = std::integral_constant<int, 0>;
+      using ODDS = std::integral_constant<int, 1>;
       if constexpr (PAIR) {
-        for (int s = 0; s + 1 < nsteps; s += 2) { one_step(s, TS0{}); one_step(s + 1, TS1{}); }     // tile A, tile B of the same chunk
+        for (int s = 0; s + 1 < nsteps; s += 2) { one_step(s, TS0{}, EVEN{}); one_step(s + 1, TS1{}, EVEN{}); }     // tile A, tile B of the same chunk
+      } else if constexpr (NP) {
+        for (int s = 0; s + 1 < nsteps; s += 2) { one_step(s, TS0{}, EVEN{}); one_step(s + 1, TS0{}, ODDS{}); }     // chunk parity = step parity (nchunk is even)
       } else {
-        for (int s = 0; s < nsteps; ++s) one_step(s, TS0{});
+        for (int s = 0; s < nsteps; ++s) one_step(s, TS0{}, EVEN{});
       }
     }
   } else {
@@ -626,14 +663,16 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + ((WS || PAIR) ? 256 
   }
 }
 
-template <typename T, int ND, bool WS, bool SMALL, bool BW = false, bool PAIR = false>
+template <typename T, int ND, bool WS, bool SMALL, bool BW = false, bool PAIR = false, bool NP = false>
 int launch_v4(ConvV4Params p, hipStream_t stream) {
   using TL = V4Tile<ND, SMALL>;
   constexpr int NPIX = (TL::TZ + 2 * TL::PADZ) * (TL::TY + 2) * (TL::TX + 2);
   constexpr int PLANE = ((NPIX * 16 + 255) / 256) * 256;
   constexpr int WSTEP = TL::S16 * ((TL::NCOL + 1) / 2) * 3 * 2 * 1024;
-  const int lds = 2 * 2 * TL::S16 * PLANE + (WS ? p.Cin / (16 * TL::S16) : 2) * WSTEP + 2048 + p.Cin * 8 + 512;
-  IUNET_SET_MAX_LDS((conv3_v4_kernel<T, ND, WS, SMALL, BW, PAIR>), lds);
+  const int lds = NP ? 3 * 2 * PLANE + (24576 + 30720) + 2048 + (p.in_scale != nullptr ? p.Cin * 8 : 0) + 512
+                     : 2 * 2 * TL::S16 * PLANE + (WS ? p.Cin / (16 * TL::S16) : 2) * WSTEP + 2048 + p.Cin * 8 + 512;
+  IUNET_REQUIRE(lds <= 160 * 1024, "conv3 layout 3: %d bytes of LDS (a fused input activation fits up to 192 input channels)", lds);
+  IUNET_SET_MAX_LDS((conv3_v4_kernel<T, ND, WS, SMALL, BW, PAIR, NP>), lds);
   p.tilesZ = (p.D + TL::TZ - 1) / TL::TZ; p.tilesY = (p.H + TL::TY - 1) / TL::TY; p.tilesX = (p.W + TL::TX - 1) / TL::TX;
   const int ncob = p.Cout / 32;
   // one workgroup per CU: 8 XCDs x (bz x by x bx) brick slots per Cout tile
@@ -647,7 +686,7 @@ int launch_v4(ConvV4Params p, hipStream_t stream) {
     if (gx < rows)
       IUNET_CHECK_HIP(hipMemsetAsync(p.stats + (long long)gx * p.Cout * 2, 0, (size_t)(rows - gx) * p.Cout * 2 * sizeof(float), stream));
   }
-  hipLaunchKernelGGL((conv3_v4_kernel<T, ND, WS, SMALL, BW, PAIR>), dim3(gx, ncob), dim3(TL::NCW * 64 + ((WS || PAIR) ? 256 : 512)), lds, stream, p);
+  hipLaunchKernelGGL((conv3_v4_kernel<T, ND, WS, SMALL, BW, PAIR, NP>), dim3(gx, ncob), dim3(TL::NCW * 64 + ((WS || PAIR) ? 256 : 512)), lds, stream, p);
   IUNET_CHECK_HIP(hipGetLastError());
   return IUNET_OK;
 }
@@ -677,7 +716,7 @@ int iunet_conv3_v4_pairs(int nd, int N, int D, int H, int W, int Cin, int Cout, 
 int iunet_conv3_v4_launch(int dtype, int nd, const void* x, long long x_sstride, void* y, long long y_sstride, const void* wpk,
                           const float* bias, float* stats, int N, int D, int H, int W, int Cin, int Cout, int epi,
                           const float* in_scale, const float* in_shift, hipStream_t stream, const void* bw_y, long long bw_y_ss,
-                          const float* const* bw_par) {
+                          const float* const* bw_par, int compact) {
   IUNET_REQUIRE(Cin % 32 == 0 && Cout % 32 == 0, "conv3 layout 2: Cin %% 32, Cout %% 32 (got %d -> %d)", Cin, Cout);
   ConvV4Params p;
   p.x = x; p.x_sstride = x_sstride; p.y = y; p.y_sstride = y_sstride; p.wpk = wpk; p.bias = bias; p.stats = stats;
@@ -697,6 +736,10 @@ int iunet_conv3_v4_launch(int dtype, int nd, const void* x, long long x_sstride,
   // 16^3 level: 1.4-1.6x faster there; at 128 of 256 CUs the doubled weight streaming costs more than the idle CUs)
   const long long big_tiles = (long long)N * ((D + 3) / 4) * ((H + 7) / 8) * ((W + 15) / 16);
   const bool small = nd == 3 && !ws && big_tiles * (Cout / 32) < 128;
+  if (compact) {      // layout 3: the compact operator, padding-free step (streamed weights, big tiles, no fused BatchNorm-backward sums so far)
+    IUNET_REQUIRE(nd == 3 && !ws && !small && bw_y == nullptr, "conv3 layout 3: 3-D, Cin > 32, >= 128 workgroup tiles, no fused BatchNorm-backward sums");
+    return dtype == 0 ? launch_v4<f16, 3, false, false, false, false, true>(p, stream) : launch_v4<bf16, 3, false, false, false, false, true>(p, stream);
+  }
   const bool pair = iunet_conv3_v4_pairs(nd, N, D, H, W, Cin, Cout, bw_y != nullptr) != 0;
   if (pair) return dtype == 0 ? launch_v4<f16, 3, false, false, false, true>(p, stream) : launch_v4<bf16, 3, false, false, false, true>(p, stream);
 #define V4_GO(TT, BWV) (nd == 3 ? (ws ? launch_v4<TT, 3, true, false, BWV>(p, stream)                                          \

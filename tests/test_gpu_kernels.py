@@ -47,7 +47,7 @@ def run_conv3(nv, x, w, dtype, nd, scale=None, bias=None, epi=0, stats=False, mo
     wd = w.contiguous().to(dev)
     if layout is None:
         layout = nv.lib().iunet_conv3_pick_layout(nd, N, D, H, W, Ci_p, Co_p)
-    pmode = mode | (2 if layout in (1, 2) else 0)
+    pmode = mode | (6 if layout == 3 else 2 if layout in (1, 2) else 0)      # layout 3: the compact K16 order (mode bit 2)
     wpk = torch.empty(nv.pack_conv3_elems(w.shape[0], w.shape[1], taps, pmode), dtype=dtype, device=dev)
     sc = None if scale is None else scale.to(dev)
     nv.call('iunet_pack_conv3', nv.DTYPE_CODE[dtype], nv.ptr(wd), nv.ptr(sc), nv.ptr(wpk), w.shape[0], w.shape[1],
@@ -108,6 +108,28 @@ def test_conv3_tile_pairs_exact_integers(nv, shape, cin, cout):
         dy = torch.randint(-2, 3, (N, cout) + shape, generator=g).float()
         want = F.conv_transpose3d(dy, w, padding=1)
         got = run_conv3(nv, dy, w, torch.float16, 3, layout=2, mode=1)
+        ok = want.abs() <= 2048
+        assert torch.equal(got[ok], want[ok])
+
+
+@pytest.mark.parametrize('shape,cin,cout', [((58, 62, 120), 64, 32), ((32, 32, 64), 128, 64), ((20, 24, 40), 64, 64)])
+def test_conv3_compact_operator_exact_integers(nv, shape, cin, cout):
+    """Layout 3: the compact K16 order and the padding-free step (the ninth filter column of two consecutive 16-channel chunks in
+    one k-slot, three halo buffers): forward with statistics and the data gradient, bit for bit."""
+    g = torch.Generator().manual_seed(22)
+    N = 2
+    x = torch.randint(-2, 3, (N, cin) + shape, generator=g).float()
+    w = torch.randint(-1, 2, (cout, cin, 3, 3, 3), generator=g).float()
+    ref = F.conv3d(x, w, padding=1)
+    for dt in (torch.float16, torch.bfloat16):
+        got, st = run_conv3(nv, x, w, dt, 3, layout=3, stats=True)
+        ok = ref.abs() <= (2048 if dt == torch.float16 else 256)
+        assert torch.equal(got[ok], ref[ok]), (dt, (got - ref)[ok].abs().max())
+        assert torch.equal(st[:, 0], ref.sum((0, 2, 3, 4)))
+    if cout > 32:
+        dy = torch.randint(-2, 3, (N, cout) + shape, generator=g).float()
+        want = F.conv_transpose3d(dy, w, padding=1)
+        got = run_conv3(nv, dy, w, torch.float16, 3, layout=3, mode=1)
         ok = want.abs() <= 2048
         assert torch.equal(got[ok], want[ok])
 

@@ -21,7 +21,7 @@ def main():
     ap.add_argument('--wgrad', type=int, default=1)
     ap.add_argument('--only', default='', help='e.g. 0:64:32 = level:cin:cout')
     ap.add_argument('--iters', type=int, default=10)
-    ap.add_argument('--layout', type=int, default=-1, help='-1 = library policy, 0 / 1 = force a kernel structure')
+    ap.add_argument('--layout', type=int, default=-1, help='-1 = library policy, 0 / 1 / 2 / 3 = force a kernel structure (3: compact operator, padding-free step)')
     ap.add_argument('--base', type=int, default=32, help='channels at level 0 (64: the C5 network)')
     ap.add_argument('--levels', type=int, default=4)
     ap.add_argument('--f8', type=int, default=0, help='1: also time the fp8 matrix-core kernel (conv3_f8.hip) on each shape')
@@ -45,9 +45,10 @@ def main():
         y = torch.empty(a.n * cout * vox, dtype=T, device='cuda')
         w = torch.randn(cout, cin, *([3] * nd), device='cuda') * 0.05
         lay = nv.lib().iunet_conv3_pick_layout(nd, a.n, D, S, S, cin, cout) if a.layout < 0 else a.layout
-        wpk = torch.empty(nv.pack_conv3_elems(cout, cin, taps, 2 * (lay > 0)), dtype=T, device='cuda')
+        pm = 6 if lay == 3 else 2 * (lay > 0)            # layout 3: the compact K16 order (pack mode bit 2)
+        wpk = torch.empty(nv.pack_conv3_elems(cout, cin, taps, pm), dtype=T, device='cuda')
         bias = torch.zeros(cout, device='cuda')
-        nv.call('iunet_pack_conv3', dt, nv.ptr(w), None, nv.ptr(wpk), cout, cin, taps, 2 * (lay > 0), nv.stream())
+        nv.call('iunet_pack_conv3', dt, nv.ptr(w), None, nv.ptr(wpk), cout, cin, taps, pm, nv.stream())
         f = lambda: nv.call('iunet_conv3_fwd', dt, nd, nv.ptr(x), cin * vox, nv.ptr(y), cout * vox, nv.ptr(wpk), nv.ptr(bias), None,
                             a.n, D, S, S, cin, cout, 2, lay, nv.stream())
         ms = timeit(f, iters=a.iters)
