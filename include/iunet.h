@@ -34,7 +34,7 @@ int iunet_abi_version(void);
 /* ---- weight packing (host fp32 master weights -> MFMA fragment order) ---------------- */
 /* conv weights fp32 [Cout][Cin][taps] (torch Conv{2,3}d layout); optional per-cout scale
  * folds an eval-mode BatchNorm.  mode bit 0: data-gradient operator (channels transposed, taps
- * mirrored); mode bit 1: K16 fragment order for weight layout 1 (see iunet_conv3_pick_layout).  dst: iunet_pack_conv3_elems(...) elements of `dtype`. */
+ * mirrored); mode bit 1: K16 fragment order for weight layout 1 (see iunet_conv3_pick_layout); mode bit 2: the compact K16 order of layout 3 (taps = 27 only).  dst: iunet_pack_conv3_elems(...) elements of `dtype`. */
 long long iunet_pack_conv3_elems(int Cout, int Cin, int taps, int mode);
 int iunet_pack_conv3(int dtype, const void* w, const void* scale, void* dst, int Cout, int Cin, int taps, int mode,
                      void* stream);
@@ -71,6 +71,12 @@ int iunet_conv3_pick_layout(int nd, int N, int D, int H, int W, int Cin, int Cou
 /* 1 if a layout-2 launch of this shape walks its tiles in pairs (one weight stream per two tiles: 3-D, streamed weights, an even
  * number of tiles per workgroup), else 0.  Speed only: the results are the same bits either way.  Exposed for the tests. */
 int iunet_conv3_tile_pairs(int nd, int N, int D, int H, int W, int Cin, int Cout);
+/* layout 3 of iunet_conv3_fwd / _fwd_act: the layout-2 kernel on the COMPACT K16 operator (iunet_pack_conv3 mode bit 2; 3^3 filters:
+ * Cout * Cin * 27 elements, the ninth filter column of two consecutive 16-channel chunks shares one k-slot) -- 10 % fewer matrix
+ * instructions and weight bytes.  1 if this launch qualifies (3-D, Cin > 32, no fused BatchNorm-backward sums (bw), a fused
+ * input activation (act) only up to 192 input channels), else 0: use layout 2.  The answer does not depend on the grid: layouts
+ * 2 and 3 add the taps in different orders, and a layer keeps one order whatever the number of blocks in a launch. */
+int iunet_conv3_compact_ok(int nd, int N, int D, int H, int W, int Cin, int Cout, int act, int bw);
 /* iunet_conv3_fwd whose input is relu(in_scale[c] * x + in_shift[c]) (fp32 [Cin] each): in training the BatchNorm + ReLU of
  * the previous conv is applied by the loader waves instead of a separate pass over HBM.  Layout 2 only. */
 int iunet_conv3_fwd_act(int dtype, int nd, const void* x, long long x_sstride, void* y, long long y_sstride,

@@ -114,6 +114,13 @@ int iunet_conv3_pick_layout(int nd, int N, int D, int H, int W, int Cin, int Cou
   return iunet_conv3_pick(nd, N, D, H, W, Cin, Cout);
 }
 
+// can this launch run on layout 3 (compact operator, padding-free step: conv3_v4.hip NP)?  3-D, streamed weights (Cin > 32), no fused
+// BatchNorm-backward sums, a fused input activation up to 192 input channels (LDS)
+int iunet_conv3_compact_ok(int nd, int N, int D, int H, int W, int Cin, int Cout, int act, int bw) {
+  if (nd != 3 || N < 1 || D < 1 || H < 1 || W < 1 || Cin <= 32 || Cout < 32 || Cin % 32 || Cout % 32 || bw) return 0;
+  return !(act && Cin > 192);        // independent of the grid: a layer keeps one summation order whatever the launch size
+}
+
 int iunet_conv3_tile_pairs(int nd, int N, int D, int H, int W, int Cin, int Cout) {
   if ((nd != 2 && nd != 3) || N < 1 || D < 1 || H < 1 || W < 1 || Cin < 32 || Cout < 32 || Cin % 32 || Cout % 32) return 0;
   return iunet_conv3_v4_pairs(nd, N, D, H, W, Cin, Cout, 0);

@@ -81,7 +81,7 @@ struct ConvV4Params {
 template <typename T, int ND, bool WS, bool SMALL, bool BW = false, bool PAIR = false, bool NP = false>
 __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + ((WS || PAIR) ? 256 : 512)), 1) void conv3_v4_kernel(ConvV4Params p) {
   static_assert(!PAIR || (!WS && !BW && ND == 3), "tile pairs: the streamed-weight 3-D forward / data-gradient variant only");
-  static_assert(!NP || (!WS && !BW && !SMALL && !PAIR && ND == 3), "padding-free step: the streamed-weight 3-D big-tile variant only (so far)");
+  static_assert(!NP || (!WS && !BW && !PAIR && ND == 3), "padding-free step: the streamed-weight 3-D variants without fused BatchNorm-backward sums (so far)");
   using V8 = typename Vec8<T>::type;
   using TL = V4Tile<ND, SMALL>;
   // consumer waves; loader threads: 4 loader waves when only activations stream, 8 when the weights stream too (twice the
@@ -737,7 +737,10 @@ int iunet_conv3_v4_launch(int dtype, int nd, const void* x, long long x_sstride,
   const long long big_tiles = (long long)N * ((D + 3) / 4) * ((H + 7) / 8) * ((W + 15) / 16);
   const bool small = nd == 3 && !ws && big_tiles * (Cout / 32) < 128;
   if (compact) {      // layout 3: the compact operator, padding-free step (streamed weights, big tiles, no fused BatchNorm-backward sums so far)
-    IUNET_REQUIRE(nd == 3 && !ws && !small && bw_y == nullptr, "conv3 layout 3: 3-D, Cin > 32, >= 128 workgroup tiles, no fused BatchNorm-backward sums");
+    // (every grid size: a layer must not change its summation order with the number of blocks in a launch -- the sharded prediction
+    //  is byte-identical across world sizes)
+    IUNET_REQUIRE(nd == 3 && !ws && bw_y == nullptr, "conv3 layout 3: 3-D, Cin > 32, no fused BatchNorm-backward sums");
+    if (small) return dtype == 0 ? launch_v4<f16, 3, false, true, false, false, true>(p, stream) : launch_v4<bf16, 3, false, true, false, false, true>(p, stream);
     return dtype == 0 ? launch_v4<f16, 3, false, false, false, false, true>(p, stream) : launch_v4<bf16, 3, false, false, false, false, true>(p, stream);
   }
   const bool pair = iunet_conv3_v4_pairs(nd, N, D, H, W, Cin, Cout, bw_y != nullptr) != 0;

@@ -18,7 +18,8 @@ struct PackDesc {                // mirrored by interactive_unet/_native.py: Pac
   long long total;               // elements of dst
   int Cout, Cin, taps;           // original operator dims (convT: Cin, Cout, npos in `taps`)
   int kind;                      // 0 conv3 layout 0, 1 conv3 K16 (layout 1), 2 first conv, 3 convT fwd, 4 convT dgrad,
-                                 // 5 conv3 K16 as OCP e4m3 bytes (conv3_f8.hip's operator; qscale = its per-channel scales, required)
+                                 // 5 conv3 K16 as OCP e4m3 bytes (conv3_f8.hip's operator; qscale = its per-channel scales, required),
+                                 // 6 conv3 compact K16 (3^3 only; conv3_v4.hip layout 3, conv3_mfma.hip: pack_conv3_k16c_kernel)
   int dgrad;                     // conv3 only: data-gradient operator
   int dtype;                     // 0 f16, 1 bf16
   float eps;
@@ -289,13 +290,82 @@ __device__ __forceinline__ void pack_k16_block(const PackDesc& d, int blk, float
   __syncthreads();                                     // the tile is reused by this workgroup's next block
 }
 
+// kind 6: the compact K16 order (per Cout tile and chunk PAIR: [even chunk 24 KB | odd chunk 24 KB | cross pair 6 KB]).  One
+// workgroup per (Cout tile, 16-channel chunk) as above: the chunk's four regular column pairs, and its half of the cross fragments
+// (the lanes q >> 1 = chunk parity: column 8 of this chunk).
+__device__ __forceinline__ void pack_k16c_block(const PackDesc& d, int blk, float* tile) {
+  const int CinP = d.dgrad ? d.Cout : d.Cin;
+  constexpr int taps = 27;
+  const int nchunk = CinP >> 4, chunk = blk % nchunk, cob = blk / nchunk;
+  const int nrows = d.dgrad ? 16 : 32, rowlen = (d.dgrad ? 32 : 16) * taps, rl4 = rowlen >> 2;
+  auto row_base = [&](int row) -> long long {
+    return d.dgrad ? ((long long)(chunk * 16 + row) * d.Cin + cob * 32) * taps : ((long long)(cob * 32 + row) * d.Cin + chunk * 16) * taps;
+  };
+  if (((size_t)d.w & 15) == 0) {
+    for (int i = threadIdx.x; i < nrows * rl4; i += 256) {
+      const int row = i / rl4, o4 = i - row * rl4;
+      *(f32x4*)(tile + row * rowlen + o4 * 4) = *(const f32x4*)(d.w + row_base(row) + o4 * 4);
+    }
+  } else {
+    for (int i = threadIdx.x; i < nrows * rowlen; i += 256) {
+      const int row = i / rowlen, o = i - row * rowlen;
+      tile[row * rowlen + o] = d.w[row_base(row) + o];
+    }
+  }
+  __syncthreads();
+  const int par = chunk & 1;
+  const long long pair_base = ((long long)cob * (nchunk >> 1) + (chunk >> 1)) * 3456;      // granules (16 B)
+  for (int t = threadIdx.x; t < 1536 + 192; t += 256) {
+    int frag, lane, col;
+    long long og;
+    if (t < 1536) { frag = t >> 6; lane = t & 63; col = 2 * (frag / 6) + (lane >> 5); frag %= 6; og = pair_base + par * 1536 + t; }
+    else {
+      const int u = t - 1536, l32 = u & 31;
+      frag = u >> 5; lane = (par * 2 + (l32 >> 4)) * 16 + (l32 & 15); col = 8; og = pair_base + 3072 + frag * 64 + lane;
+    }
+    const int dy = frag >> 1, m = frag & 1;
+    const int row = lane & 15, qq = lane >> 4;
+    const int co_l = 8 * (row >> 2) + 4 * m + (row & 3), ci_l = 8 * (qq & 1);
+    const int oc = cob * 32 + co_l;
+    const int tap = ((col / 3) * 3 + dy) * 3 + (col % 3);
+    float v[8];
+    if (!d.dgrad) {
+      const float fs = fold_scale(d, oc);
+      const float* src = tile + co_l * rowlen + ci_l * taps + tap;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = mul_rn(src[j * taps], fs);
+    } else {
+      const float* src = tile + ci_l * rowlen + co_l * taps + (taps - 1 - tap);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = src[j * rowlen];
+    }
+    if (d.qscale) {
+      const float sc = d.qscale[oc];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = sc * round_e4m3(v[j] / sc);
+    }
+    if (d.dtype == 0) {
+      typename Vec8<f16>::type o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = from_f32<f16>(v[j]);
+      *(typename Vec8<f16>::type*)((f16*)d.dst + og * 8) = o;
+    } else {
+      typename Vec8<bf16>::type o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = from_f32<bf16>(v[j]);
+      *(typename Vec8<bf16>::type*)((bf16*)d.dst + og * 8) = o;
+    }
+  }
+  __syncthreads();
+}
+
 __global__ __launch_bounds__(256) void pack_batch_kernel(const PackDesc* __restrict__ descs) {
   const PackDesc d = descs[blockIdx.y];
   __shared__ __attribute__((aligned(16))) float tile[32 * 16 * 27];               // one K16 block of source weights (54 KB)
-  if (d.kind == 1 || d.kind == 5) {
+  if (d.kind == 1 || d.kind == 5 || d.kind == 6) {
     const int CoutP = d.dgrad ? d.Cin : d.Cout, CinP = d.dgrad ? d.Cout : d.Cin;
     const int nblocks = (CoutP >> 5) * (CinP >> 4);
-    for (int blk = blockIdx.x; blk < nblocks; blk += gridDim.x) pack_k16_block(d, blk, tile);
+    for (int blk = blockIdx.x; blk < nblocks; blk += gridDim.x) { if (d.kind == 6) pack_k16c_block(d, blk, tile); else pack_k16_block(d, blk, tile); }
     if (d.bias_out && blockIdx.x == 0) {
       for (int co = threadIdx.x; co < d.Cout; co += 256) d.bias_out[co] = fold_bias(d, co);
     }

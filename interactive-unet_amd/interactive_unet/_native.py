@@ -30,6 +30,7 @@ _SIGS = {
                         c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     'iunet_conv3_pick_layout': [c_int] * 7,
     'iunet_conv3_tile_pairs': [c_int] * 7,
+    'iunet_conv3_compact_ok': [c_int] * 9,
     'iunet_conv3_fwd_act': [c_int, c_int, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                             c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     'iunet_first_conv_fwd': [c_int, c_int, c_void_p, c_int, ctypes.POINTER(c_ll), c_void_p, c_ll, c_void_p, c_void_p,
@@ -225,23 +226,30 @@ class PackedConv:
         in_ch = cout if dgrad else cin
         if self.out_ch % 64 == 0 and taps == 9 and in_ch > 64:
             self.buf[0] = torch.empty(pack_conv3_elems(cout, cin, taps, self.dg), dtype=dtype, device=device)
+        # layout 3: the compact K16 order (3^3 filters with streamed weights: the padding-free step of conv3_v4.hip) beside the padded one,
+        # which the launches that do not qualify keep using (small grids, fused BatchNorm-backward sums)
+        if taps == 27 and in_ch > 32 and not os.environ.get('IUNET_NO_COMPACT'):
+            self.buf[3] = torch.empty(pack_conv3_elems(cout, cin, taps, 6 | self.dg), dtype=dtype, device=device)
 
     def pack(self, w, scale=None):
         for lay, b in self.buf.items():
             call('iunet_pack_conv3', self.dt, ptr(w), ptr(scale), ptr(b), self.cout, self.cin, self.taps,
-                 (2 if lay == 1 else 0) | self.dg, stream())
+                 (6 if lay == 3 else 2 if lay == 1 else 0) | self.dg, stream())
 
     def descs(self, w, bn=None, bias_out=None, eps=1e-5, qscale=None):
         """Descriptors of all layouts for iunet_pack_batch (the first one also writes the folded bias)."""
         out = []
         for k, (lay, b) in enumerate(sorted(self.buf.items(), reverse=True)):
-            out.append(make_desc(w, b, self.cout, self.cin, self.taps, 1 if lay == 1 else 0, b.dtype, self.dg, bn,
+            out.append(make_desc(w, b, self.cout, self.cin, self.taps, 6 if lay == 3 else 1 if lay == 1 else 0, b.dtype, self.dg, bn,
                                  bias_out if k == 0 else None, eps, qscale))
         return out
 
-    def pick(self, nd, N, D, H, W):
-        """(layout, buffer) for a launch on this grid."""
+    def pick(self, nd, N, D, H, W, act=False, bw=False):
+        """(layout, buffer) for a launch on this grid.  act: the launch applies a fused input activation (iunet_conv3_fwd_act);
+        bw: it accumulates the BatchNorm-backward sums (iunet_conv3_dgrad_bnstats)."""
         in_ch = self.cout if self.dg else self.cin
+        if 3 in self.buf and lib().iunet_conv3_compact_ok(nd, N, D, H, W, in_ch, self.out_ch, int(bool(act)), int(bool(bw))):
+            return 3, self.buf[3]
         lay = lib().iunet_conv3_pick_layout(nd, N, D, H, W, in_ch, self.out_ch)
         if lay == 0 and 0 not in self.buf:
             lay = 1

@@ -246,7 +246,7 @@ class TrainEngine:
                     self._P(y), co * v, nv.ptr(w), None, None if self.gn else nv.ptr(stats), N, d[0], d[1], d[2], ci, co, 0, s)
         else:
             pk, _ = self.pk[name]
-            lay, w = pk.pick(self.dim, N, *d)
+            lay, w = pk.pick(self.dim, N, *d, act=x_act is not None)
             nparts = nv.lib().iunet_conv3_stats_parts(self.dim, N, *d, co, lay)
             probe = self.probe if (self.probe is not None and self.probe['name'] == name) else None
             if probe is not None:
@@ -413,7 +413,7 @@ class TrainEngine:
                         nv.ptr(gw), 1.0, nv.ptr(ws['scale.' + x_act]), nv.ptr(ws['shift.' + x_act]),
                         N, d[0], d[1], d[2], ci, co, s)
             _, pkd = self.pk[name]
-            lay, wd = pkd.pick(self.dim, N, *d)
+            lay, wd = pkd.pick(self.dim, N, *d, bw=feeds is not None and self.fuse_bw)
             if feeds is not None and lay == 2 and self.fuse_bw:
                 nv.call('iunet_conv3_dgrad_bnstats', self.dt, self.dim, self._P(dy), co * v, dx_ptr, dx_ss, nv.ptr(wd),
                         nv.ptr(ws['stats']), self._P(ws['y.' + feeds]), ci * v, nv.ptr(ws['mean.' + feeds]),

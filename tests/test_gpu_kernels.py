@@ -112,7 +112,8 @@ def test_conv3_tile_pairs_exact_integers(nv, shape, cin, cout):
         assert torch.equal(got[ok], want[ok])
 
 
-@pytest.mark.parametrize('shape,cin,cout', [((58, 62, 120), 64, 32), ((32, 32, 64), 128, 64), ((20, 24, 40), 64, 64)])
+@pytest.mark.parametrize('shape,cin,cout', [((58, 62, 120), 64, 32), ((32, 32, 64), 128, 64), ((20, 24, 40), 64, 64),
+                                            ((4, 8, 16), 64, 32), ((6, 9, 17), 256, 64)])         # the last two: the half-size tile
 def test_conv3_compact_operator_exact_integers(nv, shape, cin, cout):
     """Layout 3: the compact K16 order and the padding-free step (the ninth filter column of two consecutive 16-channel chunks in
     one k-slot, three halo buffers): forward with statistics and the data gradient, bit for bit."""
