@@ -33,7 +33,7 @@ stats bench_c3 python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --c4-r
 stats bench_c5 python3 $R/bench.py --workload c5 --steps 3 --warmup 1 --no-cpu-baseline
 stats bench_c2 python3 $R/bench.py --workload c2 --steps 5 --warmup 2 --no-cpu-baseline
 # the launches of the roofline layer (dec0.conv1 forward) inside the profiled steps: what bench.py's in-situ `roofline` times
-python3 $R/tools/roofline_launches.py $OUT/bench_c3_kernel_trace.csv conv3_v4_kernel 300 420 196608 1 > $OUT/${RND}_bench_c3_roofline_launches.txt      # 256 workgroups x 768 threads: the tile-pair variant
+python3 $R/tools/roofline_launches.py $OUT/bench_c3_kernel_trace.csv conv3_v4_kernel 300 420 262144 1 > $OUT/${RND}_bench_c3_roofline_launches.txt      # 256 workgroups x 1024 threads: the compact-operator variant (8 loader waves)
 python3 $R/tools/roofline_launches.py $OUT/bench_c5_kernel_trace.csv conv3_f8_kernel 400 1000 98304 2 > $OUT/${RND}_bench_c5_roofline_launches.txt
 python3 $R/tools/roofline_launches.py $OUT/bench_c2_kernel_trace.csv conv3_v4_kernel 85 140 196608 1 > $OUT/${RND}_bench_c2_roofline_launches.txt
 # 3. the roofline kernels alone: 3 warm-up + 50 launches, the sequence bench.py times
