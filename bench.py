@@ -140,7 +140,9 @@ def _roof_kernel_name(nv, cfg, dtype, N):
     shape = cfg['tile']
     D, H, W = shape if dim == 3 else (1,) + tuple(shape)
     lay = nv.lib().iunet_conv3_pick_layout(dim, N, D, H, W, 2 * base, base)
-    kname = 'conv3_f8_kernel' if cfg['wq'] else {0: 'conv3_mfma_kernel', 1: 'conv3_v2_kernel', 2: 'conv3_v4_kernel'}[lay]
+    if nv.lib().iunet_conv3_compact_ok(dim, N, D, H, W, 2 * base, base, 0, 0):
+        lay = 3                                    # what the engines launch (PackedConv.pick): the compact operator, padding-free step
+    kname = 'conv3_f8_kernel' if cfg['wq'] else {0: 'conv3_mfma_kernel', 1: 'conv3_v2_kernel', 2: 'conv3_v4_kernel', 3: 'conv3_v4_kernel'}[lay]
     tname = 'bf16' if dtype == torch.bfloat16 else 'f16'
     return f'{kname}<{tname},{dim}> (dec0.conv1 {2 * base}->{base} @ {N} x {"x".join(str(s) for s in shape)})', lay
 
@@ -185,7 +187,7 @@ def conv_roofline_back_to_back(nv, cfg, workload, dtype, N, iters=50):
     w = torch.randn((cout, cin) + (3,) * dim, device=dev) * 0.03
     dt = nv.DTYPE_CODE[dtype]
     name, lay = _roof_kernel_name(nv, cfg, dtype, N)
-    pmode = 2 if lay > 0 else 0                 # layouts 1 and 2 share the K16 operator
+    pmode = 6 if lay == 3 else 2 if lay > 0 else 0          # layouts 1 and 2 share the K16 operator, layout 3 takes the compact one
     wpk = torch.empty(nv.pack_conv3_elems(cout, cin, taps, pmode), dtype=dtype, device=dev)
     bias = torch.zeros(cout, device=dev)
     nv.call('iunet_pack_conv3', dt, nv.ptr(w), None, nv.ptr(wpk), cout, cin, taps, pmode, nv.stream())

@@ -44,7 +44,12 @@ def main():
         x = (torch.randn(a.n * cin * vox, device='cuda') * 0.5).to(T)
         y = torch.empty(a.n * cout * vox, dtype=T, device='cuda')
         w = torch.randn(cout, cin, *([3] * nd), device='cuda') * 0.05
-        lay = nv.lib().iunet_conv3_pick_layout(nd, a.n, D, S, S, cin, cout) if a.layout < 0 else a.layout
+        if a.layout >= 0:
+            lay = a.layout
+        elif nv.lib().iunet_conv3_compact_ok(nd, a.n, D, S, S, cin, cout, 0, 0):
+            lay = 3                                    # what PackedConv.pick chooses for a plain launch (compact operator)
+        else:
+            lay = nv.lib().iunet_conv3_pick_layout(nd, a.n, D, S, S, cin, cout)
         pm = 6 if lay == 3 else 2 * (lay > 0)            # layout 3: the compact K16 order (pack mode bit 2)
         wpk = torch.empty(nv.pack_conv3_elems(cout, cin, taps, pm), dtype=T, device='cuda')
         bias = torch.zeros(cout, device='cuda')
