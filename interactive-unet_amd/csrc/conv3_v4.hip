@@ -11,6 +11,9 @@
 //     stalls on the memory queue cost no MFMA issue slots.  Weights always travel by LDS-DMA; the halo tile does too in 3-D
 //     launches whose input needs no arithmetic on the way (dma_acts), else through registers (load / commit: the fused
 //     BatchNorm + ReLU of the training forward, and the HBM-bound 2-D layers, which need loads in flight across the barrier).
+// Two operator orders: the K16 order of layout 1 (9 filter columns padded to 5 pairs: 30 k-slots for 27 taps) and, for 3-D launches
+// with streamed weights, the COMPACT order (template flag NP, layout 3): even steps multiply 4 column pairs, odd steps those plus one
+// cross pair holding the ninth column of both chunks -- 27 taps in 27 k-slots, a ring of three halo buffers.
 // Round 2 measured what is left: with and without the loader waves the consumers take the same cycles per
 // step (4 800, 80 % of them MFMA); the difference is the clock the chip holds (1.54 vs 1.75 GHz at 64 -> 32 @ 128^3).
 // 3-D: tile 4 x 8 x 16 voxels, a step = one 16-channel chunk; 2-D: tile 16 x 32 pixels, a step = 32 channels (the 2-D
