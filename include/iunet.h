@@ -133,6 +133,40 @@ int iunet_f32_head_fwd(const void* x, long long x_ss, int C0, const void* w, con
                        void* probs, void* cls, const long long* out_strides, float divisor, int accumulate, int N, int D, int H,
                        int W, void* stream);
 
+/* ---- fp16x2 split precision: the tolerance-meeting forward on the 16-bit matrix cores ------------------------------------
+ * BASELINE.json north_star's 1e-3 on logits / integer-exact class map against the fp32 reference predict (predict.py:30-35,
+ * unet.py:65-69), at a third of the 16-bit matrix rate instead of the sixteenth of the f32-input instruction: every activation
+ * and operator entry is two fp16 words, hi = f16(v) and lo = f16(v - hi) (22 bits); a product is x_hi w_hi + x_lo w_hi +
+ * x_hi w_lo on v_mfma_f32_16x16x32_f16 into one fp32 accumulator.  Tensor layout of THIS mode: C/8 hi planes [D][H][W][8] of
+ * fp16 + C/8 lo planes `*_lo` PLANES further on (halves of a concat buffer stay views); `*_ss` = fp16 elements between samples.
+ * Activations are stored multiplied by a power of two act_scale; csrc/split16.hip states the scaling. */
+/* operator preparation: w fp32 [Cout][Cin][taps] (transposed == 0; taps 9 / 27) or ConvTranspose w [Cin][Cout][taps]
+ * (transposed != 0; taps 4 / 8), optional eval-mode BatchNorm fold (gamma..var, as iunet_f32_pack_conv) or the layer's own
+ * bias_in -> wv: the VIRTUAL fp32 operator over 3 Cin input channels [w_hi | w_hi | w_lo] (3 Cout Cin taps floats; feed it to
+ * iunet_pack_conv3 mode 2 / iunet_pack_first_conv / iunet_pack_convT with "Cin" = 3 Cin, dtype 0), oscale [Cout] = the power of
+ * two the accumulator is multiplied by (act_out / (act_in * row scale)), bias_out [Cout] = act_out * bias. */
+int iunet_x2_prep(const void* w, void* wv, void* oscale, void* bias_out, const void* gamma, const void* beta, const void* mean,
+                  const void* var, const void* bias_in, float eps, float act_in, float act_out, int Cout, int Cin, int taps,
+                  int transposed, void* stream);
+/* first conv: the caller's tensor (strides / dtype as iunet_first_conv_fwd; u8 is x / 255 correctly rounded, predict.py:30),
+ * multiplied by act_scale and split -> y = split(relu?(acc * oscale + bias)) */
+int iunet_x2_first_conv_fwd(int nd, const void* x, int in_dtype, const long long* in_strides, void* y, long long y_sstride, int y_lo,
+                            const void* w, const void* oscale, const void* bias, float act_scale, int N, int D, int H, int W, int Cin,
+                            int Cout, int relu, void* stream);
+/* stage conv 3^d pad 1 (epi as iunet_conv3_fwd); Cin = real input channels */
+int iunet_x2_conv3_fwd(int nd, const void* x, long long x_sstride, int x_lo, void* y, long long y_sstride, int y_lo, const void* wpk,
+                       const void* oscale, const void* bias, int N, int D, int H, int W, int Cin, int Cout, int epi, void* stream);
+/* 2^d max-pool on hi + lo sums (the winner's word pair is copied: no rounding) */
+int iunet_x2_maxpool_fwd(int nd, const void* x, long long x_ss, int x_lo, void* y, long long y_ss, int y_lo, int C, int N, int Do,
+                         int Ho, int Wo, void* stream);
+/* ConvTranspose k2 s2 (+ bias); D, H, W = input grid */
+int iunet_x2_convT_fwd(int nd, const void* x, long long x_ss, int x_lo, void* y, long long y_ss, int y_lo, const void* wpk,
+                       const void* oscale, const void* bias, int N, int D, int H, int W, int Cin, int Cout, void* stream);
+/* iunet_head_fwd on split features ((hi + lo) / act_scale, exact), fp32 arithmetic of iunet_f32_head_fwd; same output contract */
+int iunet_x2_head_fwd(const void* x, long long x_ss, int x_lo, int C0, const void* w, const void* bias, float act_scale, int ncls,
+                      void* logits, void* probs, void* cls, const long long* out_strides, float divisor, int accumulate, int N, int D,
+                      int H, int W, void* stream);
+
 /* ---- fp8 matrix cores: BASELINE config C5 ("fp8 weights / bf16 activations on CDNA4 fp8 MFMA") ------------------------
  * The stage convolutions of the forward pass (unet.py:65-69 over the canonical network) with the operator stored as OCP
  * e4m3 BYTES (half the weight bytes in HBM and LDS) and the product on v_mfma_f32_16x16x32_fp8_fp8; the 16-bit activations

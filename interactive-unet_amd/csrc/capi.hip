@@ -96,7 +96,7 @@ int iunet_pack_first_conv(int dtype, const void* w, const void* scale, void* dst
                           void* stream) {
   DT_OK(dtype);
   IUNET_REQUIRE(w && dst, "pack_first_conv: null pointer");
-  IUNET_REQUIRE(Cout % 32 == 0 && Cin >= 1 && Cin <= 4, "pack_first_conv: Cout multiple of 32, Cin 1..4");
+  IUNET_REQUIRE(Cout % 32 == 0 && Cin >= 1 && Cin <= 12, "pack_first_conv: Cout multiple of 32, Cin 1..4 (3..12: the virtual operator of iunet_x2_prep)");
   return iunet_pack_first_conv_launch(dtype, (const float*)w, (const float*)scale, dst, Cout, Cin, taps, (hipStream_t)stream);
 }
 

@@ -35,6 +35,16 @@ template <> struct Vec8<bf16> { typedef bf16x8 type; };
 template <typename T> __device__ __forceinline__ float to_f32(T v) { return (float)v; }
 template <typename T> __device__ __forceinline__ T from_f32(float v) { return (T)v; }
 
+// fp16x2 split precision: v ~ hi + lo with hi = T(v), lo = T(v - hi) -- for T = f16 22 significant bits (the lo word is subnormal, i.e.
+// exact to 2^-24, once |v| < 2^-2: callers keep activations scaled up by a power of two).  Finite by construction: |v| is clamped
+// to the largest T below the rounding-to-infinity threshold.
+template <typename T>
+__device__ __forceinline__ void split16(float v, T& hi, T& lo) {
+  v = fminf(fmaxf(v, -65504.f), 65504.f);
+  hi = from_f32<T>(v);
+  lo = from_f32<T>(v - to_f32<T>(hi));
+}
+
 template <typename T>
 __device__ __forceinline__ f32x4 mfma16(typename Vec8<T>::type a, typename Vec8<T>::type b, f32x4 c);
 template <>

@@ -68,6 +68,12 @@ struct ConvV4Params {
   // -- into `stats` ([workgroups][Cout][2], as the forward statistics): the separate reduction pass over dz and yp goes away.
   const void* bw_y; long long bw_y_ss;
   const float* bw_mean; const float* bw_invstd; const float* bw_scale; const float* bw_shift;      // [Cout] of the producer layer
+  // fp16x2 split precision (template flag SPL, split16.hip): every value travels as hi = f16(v), lo = f16(v - hi) in two plane sets.
+  // The launch is a conv over Cin' = 3 Cin virtual channels -- parts [x_hi | x_lo | x_hi] against the operator rows
+  // [w_hi | w_hi | w_lo] -- so the step loop, the LDS images and the operator orders are the 16-bit kernel's own; only the source
+  // plane of a chunk and the epilogue differ.  split_nc = steps per part, x_lo / y_lo = plane offset of the lo planes.
+  int split_nc, x_lo, y_lo;
+  const float* oscale;                        // [Cout]: power-of-two factor on the accumulator (operator and activation scales)
 };
 
 // BW: the data-gradient variant that also accumulates the BatchNorm-backward sums of the layer its output flows into (bw_y); a
@@ -81,8 +87,9 @@ struct ConvV4Params {
 // 0..3 only; the ninth column waits for the next chunk: the odd step adds one "cross" group whose k-slot holds column 8 of the
 // previous chunk (read from the previous step's halo buffer, which a ring of THREE buffers keeps alive) and column 8 of its own.
 // 27 taps in 27 K-slots: -10 % MFMAs, fragment reads and weight bytes.  LDS: 3 x 34 816 + 24 576 + 30 720 + scratch = 162 304 B.
-template <typename T, int ND, bool WS, bool SMALL, bool BW = false, bool PAIR = false, bool NP = false>
+template <typename T, int ND, bool WS, bool SMALL, bool BW = false, bool PAIR = false, bool NP = false, bool SPL = false>
 __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + ((WS || PAIR) ? 256 : 512)), 1) void conv3_v4_kernel(ConvV4Params p) {
+  static_assert(!SPL || (!WS && !BW), "split precision: streamed weights (Cin' = 3 Cin >= 96), forward only");
   static_assert(!PAIR || (!WS && !BW && ND == 3), "tile pairs: the streamed-weight 3-D forward / data-gradient variant only");
   static_assert(!NP || (!WS && !BW && !PAIR && ND == 3), "padding-free step: the streamed-weight 3-D variants without fused BatchNorm-backward sums (so far)");
   using V8 = typename Vec8<T>::type;
@@ -146,6 +153,14 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + ((WS || PAIR) ? 256 
   }
   const u32x4* wsrc = (const u32x4*)p.wpk + (long long)cob * (NP ? (nchunk / 2) * ((WE + WO) / 16) : nchunk * (WSTEP / 16));
   auto abuf_of = [&](int s) -> int { return NP ? (s - 3 * (s / 3)) * ABUF : (s & 1) * ABUF; };      // halo buffer of step s
+  // first source plane of a chunk.  SPL: chunk = part * split_nc + c; parts 0 and 2 read the hi planes of channel chunk c, part 1 the lo planes
+  auto src_plane = [&](int chunk) -> long long {
+    if constexpr (SPL) {
+      const int part = chunk / p.split_nc, c = chunk - part * p.split_nc;
+      return (long long)c * CP + (part == 1 ? p.x_lo : 0);
+    }
+    return (long long)chunk * CP;
+  };
 
   auto tile_origin = [&](int k, int& n_img, int& z0, int& y0, int& x0) -> bool {      // this workgroup's k-th tile
     int b = b_begin + k;
@@ -157,6 +172,9 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + ((WS || PAIR) ? 256 
     return tz < p.tilesZ && ty < p.tilesY && tx < p.tilesX;
   };
 
+  if constexpr (SPL) {     // [oscale 32 | bias 32] of this Cout tile in the (unused) statistics scratch: read by the tile epilogues
+    if (tid < 64) ((float*)(smem + off_red))[tid] = tid < 32 ? p.oscale[cob * 32 + tid] : (p.epi != 0 ? p.bias[cob * 32 + tid - 32] : 0.f);
+  }
   if (WS) {     // all weights of this Cout tile: global -> LDS once, by everybody
     const int nitems = nchunk * (WSTEP / 16);
     for (int i = tid; i < nitems; i += NCW * 64 + NLT) *(u32x4*)(smem + OFF_W + i * 16) = wsrc[i];
@@ -211,7 +229,7 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + ((WS || PAIR) ? 256 
       const int chunk = chunk_of(s);
       int n_img, z0, y0, x0;
       tile_origin(tile_of(s), n_img, z0, y0, x0);
-      const T* xc = (const T*)p.x + (long long)n_img * p.x_sstride + (long long)chunk * CP * plane_stride;
+      const T* xc = (const T*)p.x + (long long)n_img * p.x_sstride + src_plane(chunk) * plane_stride;
       r.ok = 0;
 #pragma unroll
       for (int it = 0; it < AIT; ++it) {
@@ -237,7 +255,7 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + ((WS || PAIR) ? 256 
       const int chunk = chunk_of(s);
       int n_img, z0, y0, x0;
       tile_origin(tile_of(s), n_img, z0, y0, x0);
-      const T* xc = (const T*)p.x + (long long)n_img * p.x_sstride + (long long)chunk * CP * plane_stride;
+      const T* xc = (const T*)p.x + (long long)n_img * p.x_sstride + src_plane(chunk) * plane_stride;
       const unsigned abuf = lds0 + abuf_of(s);
 #pragma unroll
       for (int it = 0; it < AIT; ++it) {
@@ -409,9 +427,11 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + ((WS || PAIR) ? 256 
   const int f0 = wave * NI;                                    // first fragment of this wave: fragment f = row * FX + x half
   const int row_first = f0 / FX;                               // first tile row (z * TY + y)
   const int rbase = (q & 1) * PLANE + ((((row_first / TY) * PY + (row_first % TY)) * PX) + l15) * 16;
-  float bias_r[8];
+  float bias_r[SPL ? 1 : 8];
+  if constexpr (!SPL) {
 #pragma unroll
-  for (int j = 0; j < 8; ++j) bias_r[j] = (p.epi != 0) ? p.bias[cob * 32 + 8 * q + j] : 0.f;
+    for (int j = 0; j < 8; ++j) bias_r[j] = (p.epi != 0) ? p.bias[cob * 32 + 8 * q + j] : 0.f;
+  }
 
   constexpr int NACC = PAIR ? 2 : 1;                           // accumulator sets: one per tile in flight
   f32x4 acc[NACC][2][NI];
@@ -506,11 +526,25 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + ((WS || PAIR) ? 256 
           for (int j = 0; j < 8; ++j) { s_sum[j] += vals[j]; s_sq[j] += vals[j] * vals[j]; }
         }
         V8 o;
+        [[maybe_unused]] V8 o_lo;
+        if constexpr (SPL) {
+          const f32x4* sp = (const f32x4*)(smem + off_red) + 2 * q;           // [oscale 32 | bias 32]: this lane's 8 channels of each
+          const f32x4 c0 = sp[0], c1 = sp[1], b0 = sp[8], b1 = sp[9];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          float r = vals[j] + bias_r[j];
-          if (p.epi == 2) r = fmaxf(r, 0.f);
-          o[j] = from_f32<T>(r);
+          for (int j = 0; j < 8; ++j) {
+            float r = fmaf(vals[j], j < 4 ? c0[j & 3] : c1[j & 3], j < 4 ? b0[j & 3] : b1[j & 3]);
+            if (p.epi == 2) r = fmaxf(r, 0.f);
+            T hi, lo;
+            split16<T>(r, hi, lo);
+            o[j] = hi; o_lo[j] = lo;
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            float r = vals[j] + bias_r[j];
+            if (p.epi == 2) r = fmaxf(r, 0.f);
+            o[j] = from_f32<T>(r);
+          }
         }
         if constexpr (BW) if (ok) {
           const f32x4* bp = (const f32x4*)(smem + off_bw) + 2 * q;          // [param][32]: this lane's 8 channels of each
@@ -527,6 +561,8 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + ((WS || PAIR) ? 256 
           }
         }
         if (ok && !(p.dbg & 4)) *(V8*)(yout + (long long)(cob * 4 + q) * plane_stride + (((long long)gz * p.H + gy) * p.W + gx) * 8) = o;
+        if constexpr (SPL)
+          if (ok && !(p.dbg & 4)) *(V8*)(yout + (long long)(p.y_lo + cob * 4 + q) * plane_stride + (((long long)gz * p.H + gy) * p.W + gx) * 8) = o_lo;
         acc[ts][0][n] = f32x4{0.f, 0.f, 0.f, 0.f};
         acc[ts][1][n] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
@@ -666,7 +702,7 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + ((WS || PAIR) ? 256 
   }
 }
 
-template <typename T, int ND, bool WS, bool SMALL, bool BW = false, bool PAIR = false, bool NP = false>
+template <typename T, int ND, bool WS, bool SMALL, bool BW = false, bool PAIR = false, bool NP = false, bool SPL = false>
 int launch_v4(ConvV4Params p, hipStream_t stream) {
   using TL = V4Tile<ND, SMALL>;
   constexpr int NPIX = (TL::TZ + 2 * TL::PADZ) * (TL::TY + 2) * (TL::TX + 2);
@@ -675,7 +711,7 @@ int launch_v4(ConvV4Params p, hipStream_t stream) {
   const int lds = NP ? 3 * 2 * PLANE + (24576 + 30720) + 2048 + (p.in_scale != nullptr ? p.Cin * 8 : 0) + 512
                      : 2 * 2 * TL::S16 * PLANE + (WS ? p.Cin / (16 * TL::S16) : 2) * WSTEP + 2048 + p.Cin * 8 + 512;
   IUNET_REQUIRE(lds <= 160 * 1024, "conv3 layout 3: %d bytes of LDS (a fused input activation fits up to 192 input channels)", lds);
-  IUNET_SET_MAX_LDS((conv3_v4_kernel<T, ND, WS, SMALL, BW, PAIR, NP>), lds);
+  IUNET_SET_MAX_LDS((conv3_v4_kernel<T, ND, WS, SMALL, BW, PAIR, NP, SPL>), lds);
   p.tilesZ = (p.D + TL::TZ - 1) / TL::TZ; p.tilesY = (p.H + TL::TY - 1) / TL::TY; p.tilesX = (p.W + TL::TX - 1) / TL::TX;
   const int ncob = p.Cout / 32;
   // one workgroup per CU: 8 XCDs x (bz x by x bx) brick slots per Cout tile
@@ -689,7 +725,7 @@ int launch_v4(ConvV4Params p, hipStream_t stream) {
     if (gx < rows)
       IUNET_CHECK_HIP(hipMemsetAsync(p.stats + (long long)gx * p.Cout * 2, 0, (size_t)(rows - gx) * p.Cout * 2 * sizeof(float), stream));
   }
-  hipLaunchKernelGGL((conv3_v4_kernel<T, ND, WS, SMALL, BW, PAIR, NP>), dim3(gx, ncob), dim3(TL::NCW * 64 + ((WS || PAIR) ? 256 : 512)), lds, stream, p);
+  hipLaunchKernelGGL((conv3_v4_kernel<T, ND, WS, SMALL, BW, PAIR, NP, SPL>), dim3(gx, ncob), dim3(TL::NCW * 64 + ((WS || PAIR) ? 256 : 512)), lds, stream, p);
   IUNET_CHECK_HIP(hipGetLastError());
   return IUNET_OK;
 }
@@ -731,6 +767,7 @@ int iunet_conv3_v4_launch(int dtype, int nd, const void* x, long long x_sstride,
   IUNET_REQUIRE(bw_y == nullptr || stats != nullptr, "conv3 layout 2: the fused BatchNorm-backward sums need a statistics buffer");
   p.tilesZ = p.tilesY = p.tilesX = 0;
   p.bz = p.by = p.bx = p.nbz = p.nby = p.nbx = 0;
+  p.split_nc = 0; p.x_lo = p.y_lo = 0; p.oscale = nullptr;
   static const int dbg = getenv("IUNET_V4_DBG") ? atoi(getenv("IUNET_V4_DBG")) : 0;
   p.dbg = dbg;
   // weights resident in LDS for the whole launch when they fit beside the two activation buffers
@@ -754,4 +791,29 @@ int iunet_conv3_v4_launch(int dtype, int nd, const void* x, long long x_sstride,
   if (bw_y != nullptr) return dtype == 0 ? V4_GO(f16, true) : V4_GO(bf16, true);
   return dtype == 0 ? V4_GO(f16, false) : V4_GO(bf16, false);
 #undef V4_GO
+}
+
+// fp16x2 split-precision forward (split16.hip): Cin real input channels; x / y are views of Cin / 8 (Cout / 8) hi planes with the lo
+// planes x_lo / y_lo planes further on; wpk = the K16 order (layout 1 / 2) of the VIRTUAL operator
+// [Cout][3 Cin][taps] = [w_hi | w_hi | w_lo]; y = split(relu?(acc * oscale + bias)).
+int iunet_conv3_v4_x2_launch(int nd, const void* x, long long x_sstride, int x_lo, void* y, long long y_sstride, int y_lo, const void* wpk,
+                             const float* oscale, const float* bias, int N, int D, int H, int W, int Cin, int Cout, int epi,
+                             hipStream_t stream) {
+  IUNET_REQUIRE(Cin % 32 == 0 && Cout % 32 == 0, "conv3 x2: Cin %% 32, Cout %% 32 (got %d -> %d)", Cin, Cout);
+  ConvV4Params p;
+  p.x = x; p.x_sstride = x_sstride; p.y = y; p.y_sstride = y_sstride; p.wpk = wpk; p.bias = bias; p.stats = nullptr;
+  p.N = N; p.D = D; p.H = H; p.W = W; p.Cin = 3 * Cin; p.Cout = Cout; p.epi = epi;
+  p.in_scale = p.in_shift = nullptr;
+  p.bw_y = nullptr; p.bw_y_ss = 0; p.bw_mean = p.bw_invstd = p.bw_scale = p.bw_shift = nullptr;
+  p.tilesZ = p.tilesY = p.tilesX = 0;
+  p.bz = p.by = p.bx = p.nbz = p.nby = p.nbx = 0;
+  p.dbg = 0;
+  p.split_nc = Cin / (nd == 3 ? 16 : 32); p.x_lo = x_lo; p.y_lo = y_lo; p.oscale = oscale;
+  if (nd == 2) return launch_v4<f16, 2, false, false, false, false, false, true>(p, stream);
+  // the tile size follows the grid as in the 16-bit launch (the operator order -- the padded K16 one -- does not: a layer keeps one
+  // summation order whatever the grid).  The compact order's split instantiation spills its fragment arrays (640 B per lane) and is not built.
+  const long long big_tiles = (long long)N * ((D + 3) / 4) * ((H + 7) / 8) * ((W + 15) / 16);
+  const bool small = big_tiles * (Cout / 32) < 128;
+  return small ? launch_v4<f16, 3, false, true, false, false, false, true>(p, stream)
+               : launch_v4<f16, 3, false, false, false, false, false, true>(p, stream);
 }

@@ -1,0 +1,506 @@
+// fp16x2 split precision ("x2" mode): the tolerance-meeting forward on the 16-bit matrix cores.
+//
+// BASELINE.json north_star wants the logits within 1e-3 of the CPU fp32 path and the class map integer-exact; the reference
+// predicts in fp32 (predict.py:30-35).  The 16-bit throughput modes round every activation to 11 / 8 bits in HBM (3.6e-3 /
+// 3e-2 on the logits); the f32-input MFMA of precise_f32.hip is exact but runs at 1/16 of the 16-bit rate.  Here every value
+// -- activation and operator entry -- is carried as TWO fp16 words, hi = f16(v) and lo = f16(v - hi): 22 significant bits.
+// A product (x_hi + x_lo)(w_hi + w_lo) is evaluated as x_hi w_hi + x_lo w_hi + x_hi w_lo on v_mfma_f32_16x16x32_f16 (the
+// dropped lo x lo term is 2^-22 of the product, the size of the representation error itself); all three terms accumulate in
+// the same fp32 accumulator: three matrix instructions per product instead of sixteen.
+//
+// Layout: a tensor of C channels = C/8 "hi" planes [D][H][W][8] of fp16 (the NHWC8c planes of the 16-bit modes) + C/8 "lo" planes
+// at a caller-given plane offset (so the two halves of a skip-concat buffer stay views: [skip_hi | up_hi | skip_lo | up_lo]).
+// Scaling: fp16 has 5 exponent bits, so the lo word of a value below 2^-2 is subnormal (exact to 2^-24 only).  Activations
+// are therefore kept multiplied by a power of two `act_scale` (default 2^6: exact, undone in the next operator's scale), and
+// every operator row is scaled per output channel by the power of two that puts its largest entry in [2^9, 2^10); the
+// epilogues multiply the accumulator by the inverse powers (exact) before the bias.  Values are clamped to +-65504.
+//
+// The convolutions run as the 16-bit kernels over Cin' = 3 Cin VIRTUAL input channels: parts [x_hi | x_lo | x_hi] against operator
+// rows [w_hi | w_hi | w_lo] (conv3_v4.hip, template flag SPL).  This file holds what surrounds them: the operator preparation
+// (BatchNorm fold in the oracle's fp32 operation order, scaling, split into the virtual fp32 operator that the ordinary pack
+// kernels then reorder), the first convolution, the max-pool, the transposed convolution and the head.
+#include "common.h"
+
+int iunet_conv3_v4_x2_launch(int nd, const void* x, long long x_sstride, int x_lo, void* y, long long y_sstride, int y_lo, const void* wpk,
+                             const float* oscale, const float* bias, int N, int D, int H, int W, int Cin, int Cout, int epi,
+                             hipStream_t stream);
+
+namespace {
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------ operator preparation
+// kind 0: conv  w [Cout][Cin][taps]   -> wv [Cout][3 Cin][taps]
+// kind 1: convT w [Cin][Cout][npos]   -> wv [3 Cin][Cout][npos]
+// virtual channel order [hi | hi | lo] (the activation parts are [hi | lo | hi]).  One workgroup per output channel:
+// a = gamma / sqrt(var + eps), w' = w * a, bias' = beta - mean * a (each operation rounded on its own, oracle/unet_ref.py fold_bn),
+// s = 2^k with max |w'| * s in [2^9, 2^10), w'' = w' * s (exact), hi = f16(w''), lo = f16(w'' - hi);
+// oscale = act_out / (act_in * s), bias_out = bias' * act_out (powers of two: exact).
+__global__ __launch_bounds__(256) void x2_prep_kernel(const float* __restrict__ w, float* __restrict__ wv, float* __restrict__ oscale,
+                                                     float* __restrict__ bias_out, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, const float* __restrict__ mean,
+                                                     const float* __restrict__ var, const float* __restrict__ bias_in, float eps,
+                                                     float act_in, float act_out, int Cout, int Cin, int taps, int kind) {
+#pragma clang fp contract(off)
+  __shared__ float red[256];
+  const int co = blockIdx.x, tid = threadIdx.x;
+  float a = 1.0f;
+  if (gamma) { const float s = var[co] + eps; a = gamma[co] / sqrtf(s); }
+  const int n = Cin * taps;
+  auto src = [&](int i) -> float {                       // i = ci * taps + tap
+    const int ci = i / taps, t = i - ci * taps;
+    const float v = kind == 0 ? w[((long long)co * Cin + ci) * taps + t] : w[((long long)ci * Cout + co) * taps + t];
+    return gamma ? v * a : v;
+  };
+  float m = 0.f;
+  for (int i = tid; i < n; i += 256) m = fmaxf(m, fabsf(src(i)));
+  red[tid] = m;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] = fmaxf(red[tid], red[tid + o]); __syncthreads(); }
+  m = red[0];
+  float s = 1.0f;
+  if (m > 0.f && m < INFINITY) {
+    int e;
+    (void)frexpf(m, &e);                                 // m = f 2^e, f in [0.5, 1)
+    int k = 10 - e;
+    k = k < -40 ? -40 : k > 40 ? 40 : k;
+    s = ldexpf(1.0f, k);
+  }
+  for (int i = tid; i < n; i += 256) {
+    const int ci = i / taps, t = i - ci * taps;
+    const float v = src(i) * s;
+    f16 hi, lo;
+    split16<f16>(v, hi, lo);
+    const float fh = (float)hi, fl = (float)lo;
+    if (kind == 0) {
+      float* d = wv + ((long long)co * 3 * Cin) * taps + t;
+      d[(long long)ci * taps] = fh; d[(long long)(Cin + ci) * taps] = fh; d[(long long)(2 * Cin + ci) * taps] = fl;
+    } else {
+      float* d = wv + (long long)co * taps + t;
+      d[((long long)ci * Cout) * taps] = fh; d[((long long)(Cin + ci) * Cout) * taps] = fh; d[((long long)(2 * Cin + ci) * Cout) * taps] = fl;
+    }
+  }
+  if (tid == 0) {
+    oscale[co] = act_out / (act_in * s);
+    float b = 0.f;
+    if (gamma) { const float t = mean[co] * a; b = beta[co] - t; }
+    else if (bias_in) b = bias_in[co];
+    bias_out[co] = b * act_out;
+  }
+}
+
+// ------------------------------------------------------------------ first conv
+struct X2FirstParams {
+  const void* x; long long sN, sC, sD, sH, sW; int in_dtype;       // caller's tensor, generic element strides; 0 f32, 1 f16, 2 u8 (/ 255), 3 bf16
+  void* y; long long y_sstride; int y_lo;
+  const void* w;                        // virtual operator [Cout][3 Cin][taps] in the first conv's fragment order (pack_first_conv, "Cin" = 3 Cin)
+  const float* oscale; const float* bias;
+  float act_scale;
+  int N, D, H, W, Cout, relu;
+};
+
+__device__ __forceinline__ float x2_load_in(const void* p, long long off, int dt) {
+  switch (dt) {
+    case 0: return ((const float*)p)[off];
+    case 1: return (float)((const f16*)p)[off];
+    case 2: return __fdiv_rn((float)((const unsigned char*)p)[off], 255.0f);      // predict.py:30, correctly rounded as torch's
+    default: return (float)((const bf16*)p)[off];
+  }
+}
+
+// The structure of pointwise.hip's first_conv_kernel (K = taps x channels padded to 32, im2col operand gathered per lane from an
+// LDS image of the halo tile) over the 3 CIN virtual channels [hi | lo | hi] of act_scale * x.
+template <int ND, int CIN>
+__global__ __launch_bounds__(256) void x2_first_conv_kernel(X2FirstParams p) {
+  constexpr int VC = 3 * CIN;
+  constexpr int TZ = ND == 3 ? 4 : 1, TY = ND == 3 ? 8 : 16, TX = ND == 3 ? 16 : 32, PADZ = ND == 3 ? 1 : 0;
+  constexpr int PZ = TZ + 2 * PADZ, PY = TY + 2, PX = TX + 2, NPIX = PZ * PY * PX;
+  constexpr int TAPS = ND == 3 ? 27 : 9, KK = TAPS * VC, KS = (KK + 31) / 32;
+  constexpr int FX = TX / 16, NI = 8;
+  __shared__ f16 xs[VC * NPIX];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, q = lane >> 4;
+  const int tilesZ = (p.D + TZ - 1) / TZ, tilesY = (p.H + TY - 1) / TY, tilesX = (p.W + TX - 1) / TX;
+  const int tps = tilesZ * tilesY * tilesX;
+  const int tile = blockIdx.x, n = tile / tps;
+  int trem = tile - n * tps;
+  const int tz_i = trem / (tilesY * tilesX);
+  trem -= tz_i * tilesY * tilesX;
+  const int ty_i = trem / tilesX, tx_i = trem - ty_i * tilesX;
+  const int z0 = tz_i * TZ, y0 = ty_i * TY, x0 = tx_i * TX;
+  const int cob = blockIdx.y;
+  for (int it = tid; it < NPIX * CIN; it += 256) {
+    const int c = it / NPIX, pix = it - c * NPIX;
+    const int px = pix % PX, t2 = pix / PX, py = t2 % PY, pz = t2 / PY;
+    const int gz = z0 + pz - PADZ, gy = y0 + py - 1, gx = x0 + px - 1;
+    float v = 0.f;
+    if ((unsigned)gz < (unsigned)p.D && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W)
+      v = x2_load_in(p.x, n * p.sN + c * p.sC + gz * p.sD + gy * p.sH + gx * p.sW, p.in_dtype);
+    f16 hi, lo;
+    split16<f16>(v * p.act_scale, hi, lo);
+    xs[c * NPIX + pix] = hi; xs[(CIN + c) * NPIX + pix] = lo; xs[(2 * CIN + c) * NPIX + pix] = hi;
+  }
+  const f16x8* wp = (const f16x8*)p.w + (long long)cob * KS * 2 * 64 + lane;
+  // per-lane LDS element offsets of the 8 k entries of its k-quad (k = 32 ks + 8 q + j = tap * VC + c, pack_first_conv_kernel)
+  int koff[KS][8];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = 32 * ks + 8 * q + j;
+      const int kc = k < KK ? k : 0;                  // padded k: zero weight, any valid address
+      const int tap = kc / VC, c = kc % VC;
+      const int dz = ND == 3 ? tap / 9 : 0, dy = (tap / 3) % 3, dx = tap % 3;
+      koff[ks][j] = c * NPIX + (dz * PY + dy) * PX + dx;
+    }
+  __syncthreads();
+  f16* yout = (f16*)p.y + (long long)n * p.y_sstride;
+  const long long plane_stride = (long long)p.D * p.H * p.W * 8;
+  float bias[8], osc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { bias[j] = p.bias[cob * 32 + 8 * q + j]; osc[j] = p.oscale[cob * 32 + 8 * q + j]; }
+#pragma unroll 1
+  for (int nf = 0; nf < NI; ++nf) {
+    const int f = wave * NI + nf;
+    const int xh = f % FX, row = f / FX, fy = row % TY, fz = row / TY;
+    const int base = (fz * PY + fy) * PX + xh * 16 + l15;
+    f32x4 acc0 = f32x4{0, 0, 0, 0}, acc1 = f32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      f16x8 b;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) b[j] = xs[base + koff[ks][j]];
+      acc0 = mfma16<f16>(wp[(ks * 2 + 0) * 64], b, acc0);
+      acc1 = mfma16<f16>(wp[(ks * 2 + 1) * 64], b, acc1);
+    }
+    const int gz = z0 + fz, gy = y0 + fy, gx = x0 + xh * 16 + l15;
+    const bool ok = gz < p.D && gy < p.H && gx < p.W;
+    f16x8 o, ol;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float r = fmaf(j < 4 ? acc0[j & 3] : acc1[j & 3], osc[j], bias[j]);
+      if (p.relu) r = fmaxf(r, 0.f);
+      f16 hi, lo;
+      split16<f16>(r, hi, lo);
+      o[j] = hi; ol[j] = lo;
+    }
+    if (ok) {
+      const long long off = (((long long)gz * p.H + gy) * p.W + gx) * 8;
+      *(f16x8*)(yout + (long long)(cob * 4 + q) * plane_stride + off) = o;
+      *(f16x8*)(yout + (long long)(p.y_lo + cob * 4 + q) * plane_stride + off) = ol;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ max-pool 2^d
+// the larger hi + lo sum (exact in fp32: 22 bits) wins and its word pair is copied -- no re-split, the pooled tensor holds exactly
+// the values of its source
+template <int ND>
+__global__ __launch_bounds__(256) void x2_maxpool_kernel(const f16* __restrict__ x, long long x_ss, int x_lo, f16* __restrict__ y,
+                                                         long long y_ss, int y_lo, int planes, int Do, int Ho, int Wo) {
+  const long long ovox = (long long)Do * Ho * Wo;
+  const long long total = ovox * planes;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int n = blockIdx.y;
+  const int pl = (int)(i / ovox);
+  const long long r = i - (long long)pl * ovox;
+  const int ox = (int)(r % Wo), oy = (int)((r / Wo) % Ho), oz = (int)(r / ((long long)Wo * Ho));
+  const int Di = ND == 3 ? Do * 2 : 1, Hi = Ho * 2, Wi = Wo * 2;
+  const long long ivox = (long long)Di * Hi * Wi;
+  const f16* xh = x + n * x_ss + (long long)pl * ivox * 8;
+  const f16* xl = xh + (long long)x_lo * ivox * 8;
+  float m[8];
+  f16x8 oh, ol;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) m[j] = -INFINITY;
+#pragma unroll
+  for (int a = 0; a < (ND == 3 ? 2 : 1); ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int z = ND == 3 ? oz * 2 + a : 0;
+        const long long off = (((long long)z * Hi + oy * 2 + b) * Wi + ox * 2 + c) * 8;
+        const f16x8 vh = *(const f16x8*)(xh + off), vl = *(const f16x8*)(xl + off);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float v = (float)vh[j] + (float)vl[j];
+          if (v > m[j]) { m[j] = v; oh[j] = vh[j]; ol[j] = vl[j]; }
+        }
+      }
+  f16* yh = y + n * y_ss + (long long)pl * ovox * 8 + r * 8;
+  *(f16x8*)yh = oh;
+  *(f16x8*)(yh + (long long)y_lo * ovox * 8) = ol;
+}
+
+// ------------------------------------------------------------------ transposed conv k2 s2
+// pointwise.hip's convT_kernel (one wave = 16 input x voxels x 32 couts x all 2^d output positions, operands straight from
+// global) over the 3 Cin virtual channels; the stride-2 interleave of the two x positions for full-line stores is the same.
+struct X2ConvTParams {
+  const void* x; long long x_sstride; int x_lo;
+  void* y; long long y_sstride; int y_lo;
+  const void* wpk; const float* oscale; const float* bias;
+  int N, D, H, W, Cin, Cout;            // input grid; Cin = real input channels
+};
+
+template <int ND>
+__global__ __launch_bounds__(256) void x2_convT_kernel(X2ConvTParams p) {
+  constexpr int NPOS = ND == 3 ? 8 : 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l15 = lane & 15, q = lane >> 4;
+  const int xg = (p.W + 15) / 16;
+  const long long rows = (long long)p.D * p.H * xg;
+  const long long wid = (long long)blockIdx.x * 4 + wave;
+  if (wid >= rows * p.N) return;
+  const int n = (int)(wid / rows);
+  const long long r = wid - n * rows;
+  const int xb = (int)(r % xg), y = (int)((r / xg) % p.H), z = (int)(r / ((long long)xg * p.H));
+  const int cob = blockIdx.y;
+  const int x = xb * 16 + l15;
+  const int xc = x < p.W ? x : p.W - 1;
+  const long long in_plane = (long long)p.D * p.H * p.W * 8;
+  const f16* xin = (const f16*)p.x + n * p.x_sstride + (((long long)z * p.H + y) * p.W + xc) * 8;
+  const int nk0 = p.Cin >> 5, nk = 3 * nk0;
+  const f16x8* wp = (const f16x8*)p.wpk + (long long)cob * nk * NPOS * 2 * 64 + lane;
+
+  f32x4 acc[NPOS][2];
+#pragma unroll
+  for (int s = 0; s < NPOS; ++s) { acc[s][0] = f32x4{0, 0, 0, 0}; acc[s][1] = f32x4{0, 0, 0, 0}; }
+  for (int ks = 0; ks < nk; ++ks) {
+    const int part = ks / nk0, c = ks - part * nk0;
+    const f16x8 b = *(const f16x8*)(xin + (long long)(c * 4 + q + (part == 1 ? p.x_lo : 0)) * in_plane);
+#pragma unroll
+    for (int s = 0; s < NPOS; ++s) {
+      acc[s][0] = mfma16<f16>(wp[((ks * NPOS + s) * 2 + 0) * 64], b, acc[s][0]);
+      acc[s][1] = mfma16<f16>(wp[((ks * NPOS + s) * 2 + 1) * 64], b, acc[s][1]);
+    }
+  }
+  const int Do = ND == 3 ? p.D * 2 : 1, Ho = p.H * 2, Wo = p.W * 2;
+  const long long out_plane = (long long)Do * Ho * Wo * 8;
+  f16* yout = (f16*)p.y + n * p.y_sstride + (long long)(cob * 4 + q) * out_plane;
+  float bias[8], osc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { bias[j] = p.bias[cob * 32 + q * 8 + j]; osc[j] = p.oscale[cob * 32 + q * 8 + j]; }
+  const int src_lo = ((lane & 48) | (l15 >> 1)) * 4, src_hi = src_lo + 8 * 4;     // byte index of the source lane
+  const bool odd = l15 & 1;
+  const int x0 = xb * 16;
+#pragma unroll
+  for (int sp = 0; sp < NPOS / 2; ++sp) {
+    const int a = ND == 3 ? (sp >> 1) : 0, b = sp & 1;
+    i32x4 oc[2][2];                                    // [x position][hi | lo]
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      f16x8 o, ol;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float rr = fmaf(j < 4 ? acc[sp * 2 + c][0][j & 3] : acc[sp * 2 + c][1][j & 3], osc[j], bias[j]);
+        f16 hi, lo;
+        split16<f16>(rr, hi, lo);
+        o[j] = hi; ol[j] = lo;
+      }
+      oc[c][0] = __builtin_bit_cast(i32x4, o);
+      oc[c][1] = __builtin_bit_cast(i32x4, ol);
+    }
+    const int oz = ND == 3 ? z * 2 + a : 0;
+    f16* row = yout + (((long long)oz * Ho + y * 2 + b) * Wo + 2 * x0) * 8;
+#pragma unroll
+    for (int w = 0; w < 2; ++w)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int src = h ? src_hi : src_lo;
+        i32x4 v;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          const int t0 = __builtin_amdgcn_ds_bpermute(src, oc[0][w][d]);
+          const int t1 = __builtin_amdgcn_ds_bpermute(src, oc[1][w][d]);
+          v[d] = odd ? t1 : t0;
+        }
+        const int xo = 2 * x0 + 16 * h + l15;
+        if (xo < Wo) *(i32x4*)(row + (w ? (long long)p.y_lo * out_plane : 0) + (16 * h + l15) * 8) = v;
+      }
+  }
+}
+
+// ------------------------------------------------------------------ 1x1 head + softmax / argmax
+struct X2HeadParams {
+  const void* x; long long x_sstride; int planes, x_lo;
+  const float* w; const float* bias; float inv_act;
+  float* logits; float* probs; unsigned char* cls;
+  long long oN, oC, oD, oH, oW;
+  float divisor; int accumulate;
+  int N, D, H, W;
+};
+
+// fp32 arithmetic of precise_f32.hip's head (fmaf chain over the channels, expf, correctly rounded division) on the
+// reconstructed features (hi + lo) / act_scale (exact)
+template <int NCLS>
+__global__ __launch_bounds__(256) void x2_head_kernel(X2HeadParams p) {
+  const long long vox = (long long)p.D * p.H * p.W;
+  const long long v = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (v >= vox) return;
+  const int n = blockIdx.y;
+  const f16* xin = (const f16*)p.x + n * p.x_sstride + v * 8;
+  float l[NCLS];
+#pragma unroll
+  for (int c = 0; c < NCLS; ++c) l[c] = 0.f;
+  for (int pl = 0; pl < p.planes; ++pl) {
+    const f16x8 xh = *(const f16x8*)(xin + (long long)pl * vox * 8);
+    const f16x8 xl = *(const f16x8*)(xin + (long long)(p.x_lo + pl) * vox * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float a = ((float)xh[j] + (float)xl[j]) * p.inv_act;
+#pragma unroll
+      for (int c = 0; c < NCLS; ++c) l[c] = fmaf(a, p.w[c * p.planes * 8 + pl * 8 + j], l[c]);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < NCLS; ++c) l[c] = __fadd_rn(l[c], p.bias[c]);
+  const int gx = (int)(v % p.W), gy = (int)((v / p.W) % p.H), gz = (int)(v / ((long long)p.W * p.H));
+  const long long obase = n * p.oN + gz * p.oD + gy * p.oH + gx * p.oW;
+  float mx = l[0];
+#pragma unroll
+  for (int c = 1; c < NCLS; ++c) mx = fmaxf(mx, l[c]);
+  if (p.logits) {
+#pragma unroll
+    for (int c = 0; c < NCLS; ++c) p.logits[obase + c * p.oC] = l[c];
+  }
+  float e[NCLS], s = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCLS; ++c) { e[c] = expf(l[c] - mx); s += e[c]; }
+  float pr[NCLS];
+  pr[0] = __fdiv_rn(e[0], s);
+  float pm = pr[0]; int am = 0;
+#pragma unroll
+  for (int c = 1; c < NCLS; ++c) { pr[c] = __fdiv_rn(e[c], s); if (pr[c] > pm) { pm = pr[c]; am = c; } }
+  if (p.cls) p.cls[n * vox + v] = (unsigned char)am;
+  if (p.probs) {
+#pragma unroll
+    for (int c = 0; c < NCLS; ++c) {
+      float* o = p.probs + obase + c * p.oC;
+      float r = p.accumulate ? __fadd_rn(*o, pr[c]) : pr[c];
+      if (p.divisor != 1.0f) r = __fdiv_rn(r, p.divisor);
+      *o = r;
+    }
+  }
+}
+
+bool pow2(float v) { int e; return v > 0.f && frexpf(v, &e) == 0.5f; }
+
+}  // namespace
+
+extern "C" {
+
+/* virtual fp32 operator of a stage conv (transposed = 0: [Cout][3 Cin][taps]) or a transposed conv (transposed = 1: [3 Cin][Cout][npos])
+ * + its accumulator scale and scaled bias; gamma..var: the eval-mode BatchNorm folded in (or null), bias_in: the layer's own bias (or null) */
+int iunet_x2_prep(const void* w, void* wv, void* oscale, void* bias_out, const void* gamma, const void* beta, const void* mean,
+                  const void* var, const void* bias_in, float eps, float act_in, float act_out, int Cout, int Cin, int taps,
+                  int transposed, void* stream) {
+  IUNET_REQUIRE(w && wv && oscale && bias_out, "x2_prep: null pointer");
+  IUNET_REQUIRE(Cout > 0 && Cin > 0 && taps > 0, "x2_prep: bad operator %d x %d x %d", Cout, Cin, taps);
+  IUNET_REQUIRE(!gamma || (beta && mean && var), "x2_prep: a BatchNorm fold needs gamma, beta, mean and var");
+  IUNET_REQUIRE(pow2(act_in) && pow2(act_out), "x2_prep: the activation scales must be powers of two (got %g, %g)", act_in, act_out);
+  hipLaunchKernelGGL(x2_prep_kernel, dim3(Cout), dim3(256), 0, (hipStream_t)stream, (const float*)w, (float*)wv, (float*)oscale,
+                     (float*)bias_out, (const float*)gamma, (const float*)beta, (const float*)mean, (const float*)var,
+                     (const float*)bias_in, eps, act_in, act_out, Cout, Cin, taps, transposed ? 1 : 0);
+  IUNET_CHECK_HIP(hipGetLastError());
+  return IUNET_OK;
+}
+
+/* unet.py:65-69 first conv of the split-precision forward: the caller's tensor (strides, dtype as iunet_first_conv_fwd) ->
+ * split(relu?(conv * oscale + bias)); w = iunet_pack_first_conv of the virtual operator with "Cin" = 3 Cin */
+int iunet_x2_first_conv_fwd(int nd, const void* x, int in_dtype, const long long* in_strides, void* y, long long y_sstride, int y_lo,
+                            const void* w, const void* oscale, const void* bias, float act_scale, int N, int D, int H, int W, int Cin,
+                            int Cout, int relu, void* stream) {
+  IUNET_REQUIRE(x && y && w && oscale && bias && in_strides, "x2_first_conv: null pointer");
+  IUNET_REQUIRE(nd == 2 || nd == 3, "x2_first_conv: nd must be 2 or 3");
+  IUNET_REQUIRE_GRID("x2_first_conv", N, D, H, W);
+  IUNET_REQUIRE(nd == 3 || D == 1, "x2_first_conv: 2-D needs D == 1");
+  IUNET_REQUIRE(in_dtype >= 0 && in_dtype <= 3, "x2_first_conv: bad input dtype %d", in_dtype);
+  IUNET_REQUIRE(Cin >= 1 && Cin <= 4, "x2_first_conv: Cin must be 1..4 (got %d)", Cin);
+  IUNET_REQUIRE(Cout > 0 && Cout % 32 == 0, "x2_first_conv: Cout must be a multiple of 32 (got %d)", Cout);
+  IUNET_REQUIRE(pow2(act_scale), "x2_first_conv: the activation scale must be a power of two (got %g)", act_scale);
+  X2FirstParams p;
+  p.x = x; p.sN = in_strides[0]; p.sC = in_strides[1]; p.sD = in_strides[2]; p.sH = in_strides[3]; p.sW = in_strides[4];
+  p.in_dtype = in_dtype; p.y = y; p.y_sstride = y_sstride; p.y_lo = y_lo; p.w = w; p.oscale = (const float*)oscale;
+  p.bias = (const float*)bias; p.act_scale = act_scale; p.N = N; p.D = D; p.H = H; p.W = W; p.Cout = Cout; p.relu = relu;
+  const int TZ = nd == 3 ? 4 : 1, TY = nd == 3 ? 8 : 16, TX = nd == 3 ? 16 : 32;
+  dim3 grid(N * ((D + TZ - 1) / TZ) * ((H + TY - 1) / TY) * ((W + TX - 1) / TX), Cout / 32);
+#define X2FC(NDV, CI) hipLaunchKernelGGL((x2_first_conv_kernel<NDV, CI>), grid, dim3(256), 0, (hipStream_t)stream, p)
+#define X2FC_CIN(NDV) switch (Cin) { case 1: X2FC(NDV, 1); break; case 2: X2FC(NDV, 2); break; case 3: X2FC(NDV, 3); break; default: X2FC(NDV, 4); break; }
+  if (nd == 3) { X2FC_CIN(3) } else { X2FC_CIN(2) }
+#undef X2FC_CIN
+#undef X2FC
+  IUNET_CHECK_HIP(hipGetLastError());
+  return IUNET_OK;
+}
+
+/* stage conv 3^d of the split-precision forward: x / y = Cin / 8 (Cout / 8) hi planes, the lo planes x_lo / y_lo planes further on;
+ * wpk = iunet_pack_conv3 (K16 order, mode 2) of the virtual operator [Cout][3 Cin][taps]; epi as iunet_conv3_fwd */
+int iunet_x2_conv3_fwd(int nd, const void* x, long long x_sstride, int x_lo, void* y, long long y_sstride, int y_lo, const void* wpk,
+                       const void* oscale, const void* bias, int N, int D, int H, int W, int Cin, int Cout, int epi, void* stream) {
+  IUNET_REQUIRE(x && y && wpk && oscale, "x2_conv3: null pointer");
+  IUNET_REQUIRE(nd == 2 || nd == 3, "x2_conv3: nd must be 2 or 3");
+  IUNET_REQUIRE_GRID("x2_conv3", N, D, H, W);
+  IUNET_REQUIRE(nd == 3 || D == 1, "x2_conv3: 2-D needs D == 1");
+  IUNET_REQUIRE(Cin >= 32 && Cout >= 32 && Cin % 32 == 0 && Cout % 32 == 0, "x2_conv3: channels must be positive multiples of 32 (%d, %d)", Cin, Cout);
+  IUNET_REQUIRE(epi >= 0 && epi <= 2, "x2_conv3: bad epilogue %d", epi);
+  IUNET_REQUIRE(epi == 0 || bias != nullptr, "x2_conv3: epilogue %d needs a bias", epi);
+  return iunet_conv3_v4_x2_launch(nd, x, x_sstride, x_lo, y, y_sstride, y_lo, wpk, (const float*)oscale, (const float*)bias, N, D, H, W,
+                                  Cin, Cout, epi, (hipStream_t)stream);
+}
+
+int iunet_x2_maxpool_fwd(int nd, const void* x, long long x_ss, int x_lo, void* y, long long y_ss, int y_lo, int C, int N, int Do,
+                         int Ho, int Wo, void* stream) {
+  IUNET_REQUIRE(x && y, "x2_maxpool: null pointer");
+  IUNET_REQUIRE(nd == 2 || nd == 3, "x2_maxpool: nd must be 2 or 3");
+  IUNET_REQUIRE(C > 0 && C % 8 == 0 && N > 0 && Do > 0 && Ho > 0 && Wo > 0, "x2_maxpool: bad shape");
+  const long long total = (long long)Do * Ho * Wo * (C / 8);
+  dim3 grid((unsigned)((total + 255) / 256), N);
+  if (nd == 3) hipLaunchKernelGGL((x2_maxpool_kernel<3>), grid, dim3(256), 0, (hipStream_t)stream, (const f16*)x, x_ss, x_lo, (f16*)y, y_ss, y_lo, C / 8, Do, Ho, Wo);
+  else hipLaunchKernelGGL((x2_maxpool_kernel<2>), grid, dim3(256), 0, (hipStream_t)stream, (const f16*)x, x_ss, x_lo, (f16*)y, y_ss, y_lo, C / 8, Do, Ho, Wo);
+  IUNET_CHECK_HIP(hipGetLastError());
+  return IUNET_OK;
+}
+
+/* transposed conv k2 s2; wpk = iunet_pack_convT of the virtual operator [3 Cin][Cout][npos] */
+int iunet_x2_convT_fwd(int nd, const void* x, long long x_ss, int x_lo, void* y, long long y_ss, int y_lo, const void* wpk,
+                       const void* oscale, const void* bias, int N, int D, int H, int W, int Cin, int Cout, void* stream) {
+  IUNET_REQUIRE(x && y && wpk && oscale && bias, "x2_convT: null pointer");
+  IUNET_REQUIRE(nd == 2 || nd == 3, "x2_convT: nd must be 2 or 3");
+  IUNET_REQUIRE_GRID("x2_convT", N, D, H, W);
+  IUNET_REQUIRE(Cin >= 32 && Cout >= 32 && Cin % 32 == 0 && Cout % 32 == 0, "x2_convT: channels must be positive multiples of 32 (%d, %d)", Cin, Cout);
+  X2ConvTParams p;
+  p.x = x; p.x_sstride = x_ss; p.x_lo = x_lo; p.y = y; p.y_sstride = y_ss; p.y_lo = y_lo; p.wpk = wpk;
+  p.oscale = (const float*)oscale; p.bias = (const float*)bias; p.N = N; p.D = D; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
+  const long long waves = (long long)N * D * H * ((W + 15) / 16);
+  dim3 grid((unsigned)((waves + 3) / 4), Cout / 32);
+  if (nd == 3) hipLaunchKernelGGL((x2_convT_kernel<3>), grid, dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL((x2_convT_kernel<2>), grid, dim3(256), 0, (hipStream_t)stream, p);
+  IUNET_CHECK_HIP(hipGetLastError());
+  return IUNET_OK;
+}
+
+/* 1x1 head + softmax + class map (unet.py:63-69, predict.py:38) from split features; output contract of iunet_head_fwd */
+int iunet_x2_head_fwd(const void* x, long long x_ss, int x_lo, int C0, const void* w, const void* bias, float act_scale, int ncls,
+                      void* logits, void* probs, void* cls, const long long* out_strides, float divisor, int accumulate, int N, int D,
+                      int H, int W, void* stream) {
+  IUNET_REQUIRE(x && w && bias && out_strides, "x2_head: null pointer");
+  IUNET_REQUIRE(C0 > 0 && C0 % 8 == 0, "x2_head: C0 must be a multiple of 8");
+  IUNET_REQUIRE(ncls >= 2 && ncls <= 10, "x2_head: num_classes must be 2..10 (got %d)", ncls);
+  IUNET_REQUIRE_GRID("x2_head", N, D, H, W);
+  IUNET_REQUIRE(pow2(act_scale), "x2_head: the activation scale must be a power of two (got %g)", act_scale);
+  X2HeadParams p;
+  p.x = x; p.x_sstride = x_ss; p.planes = C0 / 8; p.x_lo = x_lo; p.w = (const float*)w; p.bias = (const float*)bias;
+  p.inv_act = 1.0f / act_scale; p.logits = (float*)logits; p.probs = (float*)probs; p.cls = (unsigned char*)cls;
+  p.oN = out_strides[0]; p.oC = out_strides[1]; p.oD = out_strides[2]; p.oH = out_strides[3]; p.oW = out_strides[4];
+  p.divisor = divisor; p.accumulate = accumulate; p.N = N; p.D = D; p.H = H; p.W = W;
+  const long long vox = (long long)D * H * W;
+  dim3 grid((unsigned)((vox + 255) / 256), N);
+#define X2_HEAD(NC) case NC: hipLaunchKernelGGL((x2_head_kernel<NC>), grid, dim3(256), 0, (hipStream_t)stream, p); break;
+  switch (ncls) { X2_HEAD(2) X2_HEAD(3) X2_HEAD(4) X2_HEAD(5) X2_HEAD(6) X2_HEAD(7) X2_HEAD(8) X2_HEAD(9) X2_HEAD(10) }
+#undef X2_HEAD
+  IUNET_CHECK_HIP(hipGetLastError());
+  return IUNET_OK;
+}
+
+}  // extern "C"

@@ -47,6 +47,17 @@ _SIGS = {
     'iunet_f32_maxpool_fwd': [c_int, c_void_p, c_ll, c_void_p, c_ll, c_int, c_int, c_int, c_int, c_int, c_void_p],
     'iunet_f32_head_fwd': [c_void_p, c_ll, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                            ctypes.POINTER(c_ll), c_float, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    # ---- fp16x2 split precision (the tolerance-meeting mode on the 16-bit matrix cores)
+    'iunet_x2_prep': [c_void_p] * 9 + [c_float, c_float, c_float, c_int, c_int, c_int, c_int, c_void_p],
+    'iunet_x2_first_conv_fwd': [c_int, c_void_p, c_int, ctypes.POINTER(c_ll), c_void_p, c_ll, c_int, c_void_p, c_void_p, c_void_p,
+                                c_float, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    'iunet_x2_conv3_fwd': [c_int, c_void_p, c_ll, c_int, c_void_p, c_ll, c_int, c_void_p, c_void_p, c_void_p,
+                           c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    'iunet_x2_maxpool_fwd': [c_int, c_void_p, c_ll, c_int, c_void_p, c_ll, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    'iunet_x2_convT_fwd': [c_int, c_void_p, c_ll, c_int, c_void_p, c_ll, c_int, c_void_p, c_void_p, c_void_p,
+                           c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    'iunet_x2_head_fwd': [c_void_p, c_ll, c_int, c_int, c_void_p, c_void_p, c_float, c_int, c_void_p, c_void_p, c_void_p,
+                          ctypes.POINTER(c_ll), c_float, c_int, c_int, c_int, c_int, c_int, c_void_p],
     # ---- fp8 matrix cores (config C5)
     'iunet_f8_pack_conv3': [c_void_p] * 5 + [c_float, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     'iunet_conv3_f8_fwd': [c_int, c_int, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_void_p, c_void_p,

@@ -1,0 +1,202 @@
+"""Split-precision ("fp16x2") mode of the native forward: the tolerance-meeting path on the 16-bit matrix cores.
+
+BASELINE.json north_star: logits within 1e-3 of the CPU fp32 path, class map integer-exact; the reference predicts in fp32
+(predict.py:30-35).  Same graph and the same host interface as engine.Engine (`load_eval`, `infer`), but every activation
+and every operator entry is carried as two fp16 words (hi + lo = 22 significant bits) and a product costs three
+`v_mfma_f32_16x16x32_f16` instead of the sixteen-times-slower f32-input instruction of engine_f32.EngineF32
+(csrc/split16.hip has the arithmetic, csrc/conv3_v4.hip the convolution).  This is what `UNet(act_dtype='fp16x2')` and the
+default prediction path run.
+
+Tensors: C channels = C/8 hi planes + C/8 lo planes of [D][H][W][8] fp16; the two halves of a skip-concat buffer stay views
+([skip_hi | up_hi | skip_lo | up_lo]); activations are kept multiplied by `act_scale` (a power of two, undone exactly by the
+next operator's accumulator scale).
+"""
+import ctypes
+
+import torch
+
+from . import _native as nv
+from .engine import BN_EPS, _vox
+
+
+class EngineX2:
+    act_dtype = 'fp16x2'
+    weight_dtype = None
+    norm = 'batch'
+
+    def __init__(self, dim=2, levels=4, base=32, cin=1, ncls=2, device='cuda', act_scale=64.0):
+        if dim not in (2, 3):
+            raise ValueError('dim must be 2 or 3')
+        if base % 32 != 0:
+            raise NotImplementedError('native U-Net needs base channels to be a multiple of 32')
+        if not (1 <= cin <= 4):
+            raise NotImplementedError('native U-Net supports 1..4 input channels')
+        if not (2 <= ncls <= 10):
+            raise NotImplementedError('native U-Net supports 2..10 classes (app.py:162)')
+        self.dim, self.levels, self.base, self.cin, self.ncls = dim, levels, base, cin, ncls
+        self.act_scale = float(act_scale)
+        self.device = torch.device(device)
+        self.ch = [base * 2 ** l for l in range(levels)]
+        self.taps, self.npos = 3 ** dim, 2 ** dim
+        self.packed = None
+        self._ws_cache = {}
+        self.probe = None          # {'name': layer, 'events': []}: timing hook of one layer's launches (bench.py)
+        nv.lib()
+
+    def stage_names(self):
+        return [f'enc{l}' for l in range(self.levels)] + [f'dec{l}' for l in range(self.levels - 2, -1, -1)]
+
+    def stage_io(self, prefix):
+        l = int(prefix[3:])
+        ci = (self.cin if l == 0 else self.ch[l - 1]) if prefix.startswith('enc') else 2 * self.ch[l]
+        return ci, self.ch[l]
+
+    # ------------------------------------------------------------------ weights
+    def load_eval(self, params):
+        """Fold eval-mode BatchNorm (fp32, the oracle's operation order), scale, split and pack every operator."""
+        dev = self.device
+        f32 = lambda n: torch.empty(n, dtype=torch.float32, device=dev)
+        f16 = lambda n: torch.empty(n, dtype=torch.float16, device=dev)
+        src = lambda name: params[name].detach().to(dev, torch.float32).contiguous()
+        lib, s, P, A = nv.lib(), nv.stream(), {}, self.act_scale
+        for prefix in self.stage_names():
+            ci, co = self.stage_io(prefix)
+            for j, (a, b) in enumerate(((ci, co), (co, co)), 1):
+                w = src(f'{prefix}.conv{j}.weight')
+                bn = [src(f'{prefix}.bn{j}.{k}') for k in ('weight', 'bias', 'running_mean', 'running_var')]
+                wv, osc, bias = f32(b * 3 * a * self.taps), f32(b), f32(b)
+                nv.call('iunet_x2_prep', nv.ptr(w), nv.ptr(wv), nv.ptr(osc), nv.ptr(bias), nv.ptr(bn[0]), nv.ptr(bn[1]),
+                        nv.ptr(bn[2]), nv.ptr(bn[3]), None, BN_EPS, A, A, b, a, self.taps, 0, s)
+                if prefix == 'enc0' and j == 1:
+                    dst = f16(lib.iunet_pack_first_conv_elems(b, 3 * a, self.taps))
+                    nv.call('iunet_pack_first_conv', 0, nv.ptr(wv), None, nv.ptr(dst), b, 3 * a, self.taps, s)
+                else:
+                    dst = f16(nv.pack_conv3_elems(b, 3 * a, self.taps, 2))
+                    nv.call('iunet_pack_conv3', 0, nv.ptr(wv), None, nv.ptr(dst), b, 3 * a, self.taps, 2, s)
+                P[f'{prefix}.conv{j}'] = (dst, osc, bias)
+        for l in range(self.levels - 2, -1, -1):
+            w, b0 = src(f'dec{l}.up.weight'), src(f'dec{l}.up.bias')
+            ci, co = self.ch[l + 1], self.ch[l]
+            wv, osc, bias = f32(3 * ci * co * self.npos), f32(co), f32(co)
+            nv.call('iunet_x2_prep', nv.ptr(w), nv.ptr(wv), nv.ptr(osc), nv.ptr(bias), None, None, None, None, nv.ptr(b0),
+                    BN_EPS, A, A, co, ci, self.npos, 1, s)
+            dst = f16(3 * ci * co * self.npos)
+            nv.call('iunet_pack_convT', 0, nv.ptr(wv), nv.ptr(dst), 3 * ci, co, self.npos, s)
+            P[f'dec{l}.up'] = (dst, osc, bias)
+        P['head'] = (src('head.weight').reshape(self.ncls, self.ch[0]).contiguous(), src('head.bias'))
+        torch.cuda.current_stream().synchronize()          # the virtual operators / staging copies above are freed here
+        self.packed = P
+
+    # ------------------------------------------------------------------ workspace
+    def level_dims(self, D, H, W):
+        return [((D >> l) if self.dim == 3 else 1, H >> l, W >> l) for l in range(self.levels)]
+
+    def check_shape(self, D, H, W):
+        f = 2 ** (self.levels - 1)
+        if H % f or W % f or (self.dim == 3 and D % f) or (self.dim == 2 and D != 1):
+            raise ValueError(f'spatial size {(D, H, W)} must be divisible by {f} (and D == 1 in 2-D)')
+
+    def workspace(self, N, D, H, W):
+        key = (N, D, H, W)
+        ws = self._ws_cache.get(key)
+        if ws is None:
+            self.check_shape(D, H, W)
+            dims = self.level_dims(D, H, W)
+            mk = lambda c, v: torch.empty(N * 2 * c * v, dtype=torch.float16, device=self.device)     # hi + lo planes
+            ws = {'dims': dims}
+            for l in range(self.levels):
+                v = _vox(dims[l])
+                ws[f'a{l}'] = mk(self.ch[l], v)
+                ws[f'b{l}'] = mk(self.ch[l], v)
+                if l < self.levels - 1:
+                    ws[f'cat{l}'] = mk(2 * self.ch[l], v)
+                if l > 0:
+                    ws[f'pin{l}'] = mk(self.ch[l - 1], v)
+            if len(self._ws_cache) > 4:
+                self._ws_cache.clear()
+            self._ws_cache[key] = ws
+        return ws
+
+    # ------------------------------------------------------------------ forward (inference)
+    def _conv3(self, name, xp, x_ss, x_lo, yp, y_ss, y_lo, N, d, ci, co, s):
+        w, osc, b = self.packed[name]
+        probe = self.probe if (self.probe is not None and self.probe['name'] == name) else None
+        if probe is not None:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+        nv.call('iunet_x2_conv3_fwd', self.dim, xp, x_ss, x_lo, yp, y_ss, y_lo, nv.ptr(w), nv.ptr(osc), nv.ptr(b),
+                N, d[0], d[1], d[2], ci, co, 2, s)
+        if probe is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            probe['events'].append((e0, e1, N))
+
+    def infer(self, x, x_strides, N, D, H, W, logits=None, probs=None, cls=None, out_strides=None,
+              divisor=1.0, accumulate=False, features_only=False):
+        """engine.Engine.infer in split precision (same arguments and output contract)."""
+        if self.packed is None:
+            raise RuntimeError('EngineX2.load_eval() has not been called')
+        ws = self.workspace(N, D, H, W)
+        dims, L, ch, s = ws['dims'], self.levels, self.ch, nv.stream()
+        Pt = lambda t, planes=0, v=0: ctypes.c_void_p(t.data_ptr() + 2 * planes * v * 8)      # view starting `planes` planes in
+        for l in range(L):
+            d, v = dims[l], _vox(dims[l])
+            c8 = ch[l] // 8
+            if l == 0:
+                w, osc, b = self.packed['enc0.conv1']
+                nv.call('iunet_x2_first_conv_fwd', self.dim, nv.ptr(x), nv.IN_DTYPE_CODE[x.dtype], nv.ll_array(x_strides),
+                        Pt(ws['a0']), 2 * ch[0] * v, c8, nv.ptr(w), nv.ptr(osc), nv.ptr(b), self.act_scale,
+                        N, d[0], d[1], d[2], self.cin, ch[0], 1, s)
+            else:
+                self._conv3(f'enc{l}.conv1', Pt(ws[f'pin{l}']), 2 * ch[l - 1] * v, ch[l - 1] // 8, Pt(ws[f'a{l}']), 2 * ch[l] * v, c8,
+                            N, d, ch[l - 1], ch[l], s)
+            if l < L - 1:
+                # skip half of the concat buffer: hi planes [0, c8), lo planes [2 c8, 3 c8)
+                self._conv3(f'enc{l}.conv2', Pt(ws[f'a{l}']), 2 * ch[l] * v, c8, Pt(ws[f'cat{l}']), 4 * ch[l] * v, 2 * c8,
+                            N, d, ch[l], ch[l], s)
+                do = dims[l + 1]
+                nv.call('iunet_x2_maxpool_fwd', self.dim, Pt(ws[f'cat{l}']), 4 * ch[l] * v, 2 * c8, Pt(ws[f'pin{l + 1}']),
+                        2 * ch[l] * _vox(do), c8, ch[l], N, do[0], do[1], do[2], s)
+            else:
+                self._conv3(f'enc{l}.conv2', Pt(ws[f'a{l}']), 2 * ch[l] * v, c8, Pt(ws[f'b{l}']), 2 * ch[l] * v, c8,
+                            N, d, ch[l], ch[l], s)
+        for l in range(L - 2, -1, -1):
+            d, v, di, vi = dims[l], _vox(dims[l]), dims[l + 1], _vox(dims[l + 1])
+            c8 = ch[l] // 8
+            w, osc, b = self.packed[f'dec{l}.up']
+            # up half of the concat buffer: hi planes [c8, 2 c8), lo planes [3 c8, 4 c8)
+            nv.call('iunet_x2_convT_fwd', self.dim, Pt(ws[f'b{l + 1}']), 2 * ch[l + 1] * vi, ch[l + 1] // 8,
+                    Pt(ws[f'cat{l}'], c8, v), 4 * ch[l] * v, 2 * c8, nv.ptr(w), nv.ptr(osc), nv.ptr(b),
+                    N, di[0], di[1], di[2], ch[l + 1], ch[l], s)
+            self._conv3(f'dec{l}.conv1', Pt(ws[f'cat{l}']), 4 * ch[l] * v, 2 * c8, Pt(ws[f'a{l}']), 2 * ch[l] * v, c8,
+                        N, d, 2 * ch[l], ch[l], s)
+            self._conv3(f'dec{l}.conv2', Pt(ws[f'a{l}']), 2 * ch[l] * v, c8, Pt(ws[f'b{l}']), 2 * ch[l] * v, c8,
+                        N, d, ch[l], ch[l], s)
+        if features_only:
+            return ws['b0']                       # input of the head: [N][hi planes | lo planes], scaled by act_scale
+        hw, hb = self.packed['head']
+        if out_strides is None:
+            v = _vox(dims[0])
+            out_strides = (self.ncls * v, v, H * W, W, 1)
+        nv.call('iunet_x2_head_fwd', Pt(ws['b0']), 2 * ch[0] * _vox(dims[0]), ch[0] // 8, ch[0], nv.ptr(hw), nv.ptr(hb),
+                self.act_scale, self.ncls, nv.ptr(logits), nv.ptr(probs), nv.ptr(cls), nv.ll_array(out_strides),
+                float(divisor), int(bool(accumulate)), N, D, H, W, s)
+
+    # ------------------------------------------------------------------ layout helpers (tests)
+    def to_split(self, t):
+        """fp32 [N, C, *spatial] -> flat split tensor [N][C/8 hi planes | C/8 lo planes][*spatial][8] of act_scale * t."""
+        N, C = t.shape[:2]
+        sp = t.shape[2:]
+        v = t.float() * self.act_scale
+        hi = v.to(torch.float16)
+        lo = (v - hi.float()).to(torch.float16)
+
+        def blocked(u):
+            u = u.reshape(N, C // 8, 8, *sp)
+            return u.permute(0, 1, *range(3, 3 + len(sp)), 2).contiguous()
+        return torch.cat([blocked(hi), blocked(lo)], 1).reshape(-1)
+
+    def from_split(self, flat, N, C, sp):
+        t = flat.reshape(N, 2, C // 8, *sp, 8).float()
+        t = (t[:, 0] + t[:, 1]) / self.act_scale
+        return t.permute(0, 1, 2 + len(sp), *range(2, 2 + len(sp))).reshape(N, C, *sp)
