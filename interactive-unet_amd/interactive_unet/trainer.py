@@ -36,7 +36,7 @@ def _mean(rows):
 
 def train_model(lr=0.0001, batch_size=1, epochs=10, num_channels=1, num_classes=2, loss_function_name='MCC + CE',
                 architecture='U-Net', encoder_name='mit_b0', pretrained=True, reslice=False, reslice_factor=2,
-                train_loader=None, val_loader=None, dim=2, act_dtype='fp16', process_group=None):
+                train_loader=None, val_loader=None, dim=2, act_dtype=None, process_group=None):
     if train_loader is None or val_loader is None:
         train_loader, val_loader = _loaders(num_classes, batch_size, reslice, reslice_factor)
     loss_function = metrics.loss_name_to_function(loss_function_name)

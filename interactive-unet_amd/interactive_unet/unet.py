@@ -6,10 +6,15 @@ the native canonical U-Net (engine.py) instead of segmentation_models_pytorch.
 Only architecture='U-Net' exists natively; `encoder_name` is accepted and ignored (the canonical
 net has its own plain conv encoder), `pretrained` is a no-op with a warning (no imagenet
 weights for a from-scratch encoder; no network access).  Extra keyword arguments (dim, levels,
-base, act_dtype) select the 3-D / wider variants of BASELINE.json's configs.  act_dtype: 'fp16' / 'bf16' =
-16-bit activations on the bf16/fp16 matrix cores (the throughput path); 'fp32' = the parity mode (fp32
-activations and operators on the f32-input matrix instruction, engine_f32.py: logits within 1e-3 of the CPU
-fp32 path, inference only).
+base, act_dtype, infer_dtype) select the 3-D / wider variants of BASELINE.json's configs.
+
+Numeric modes.  The reference TRAINS under `precision='16-mixed'` (trainer.py:59) and PREDICTS in fp32 (predict.py:30-35).
+The default module (act_dtype=None) does the same: native training with fp16 activations, `forward()` / prediction in the
+split-precision mode 'fp16x2' (engine_x2.py: every value two fp16 words, three 16-bit MFMAs per product; logits within
+1e-3 of the CPU fp32 path, class map exact).  An explicit act_dtype selects one mode for both: 'fp16' / 'bf16' = 16-bit
+activations on the matrix cores (the throughput path: logits off the fp32 path by 4e-3 / 3e-2); 'fp16x2' and 'fp32' (the
+f32-input matrix instruction, engine_f32.py, 1/16 of the 16-bit rate) are inference-only.  `infer_dtype` overrides the
+mode of `forward()` alone.
 """
 import math
 import warnings
@@ -20,9 +25,10 @@ import torch.nn as nn
 from . import metrics
 from .engine import Engine, BN_EPS
 
+X2 = 'fp16x2'          # split precision (engine_x2.py): not a torch dtype
 _ACT = {'fp16': torch.float16, 'f16': torch.float16, 'bf16': torch.bfloat16, 'fp32': torch.float32, 'f32': torch.float32,
-        torch.float16: torch.float16, torch.bfloat16: torch.bfloat16, torch.float32: torch.float32}
-_ACT_NAME = {torch.float16: 'fp16', torch.bfloat16: 'bf16', torch.float32: 'fp32'}
+        torch.float16: torch.float16, torch.bfloat16: torch.bfloat16, torch.float32: torch.float32, X2: X2, 'x2': X2}
+_ACT_NAME = {torch.float16: 'fp16', torch.bfloat16: 'bf16', torch.float32: 'fp32', X2: X2}
 
 
 def param_shapes(dim=2, levels=4, base=32, cin=1, ncls=2):
@@ -56,7 +62,7 @@ class UNet(nn.Module):
 
     def __init__(self, lr=0.0001, num_channels=1, num_classes=2, loss_function=metrics.mcc_ce_loss,
                  architecture='U-Net', encoder_name='mit_b0', pretrained=True,
-                 dim=2, levels=4, base=32, act_dtype='fp16', weight_dtype=None, norm='batch', groups=8):
+                 dim=2, levels=4, base=32, act_dtype=None, weight_dtype=None, norm='batch', groups=8, infer_dtype=None):
         super().__init__()
         if architecture != 'U-Net':
             raise NotImplementedError(f"architecture {architecture!r}: only 'U-Net' has a native MI355X "
@@ -67,13 +73,22 @@ class UNet(nn.Module):
                             loss_function=getattr(loss_function, '__name__', str(loss_function)),
                             architecture=architecture, encoder_name=encoder_name, pretrained=pretrained,
                             dim=dim, levels=levels, base=base,
-                            act_dtype=_ACT_NAME[_ACT[act_dtype]],
-                            weight_dtype=weight_dtype, norm=norm, groups=groups)
+                            act_dtype=None if act_dtype is None else _ACT_NAME[_ACT[act_dtype]],
+                            weight_dtype=weight_dtype, norm=norm, groups=groups,
+                            infer_dtype=None if infer_dtype is None else _ACT_NAME[_ACT[infer_dtype]])
         self.lr = lr
         self.loss_function = loss_function
         self.dim, self.levels, self.base = dim, levels, base
         self.num_channels, self.num_classes = num_channels, num_classes
-        self.act_dtype = _ACT[act_dtype]
+        # act_dtype None = the reference's pair: 16-bit training (trainer.py:59) + tolerance-meeting prediction (predict.py:30-35);
+        # the split mode folds BatchNorm into its operators, so GroupNorm / fp8-weight networks predict in their 16-bit mode
+        self.act_dtype = torch.float16 if act_dtype is None else _ACT[act_dtype]
+        if infer_dtype is not None:
+            self.infer_dtype = _ACT[infer_dtype]
+        elif act_dtype is None and weight_dtype is None and norm == 'batch':
+            self.infer_dtype = X2
+        else:
+            self.infer_dtype = self.act_dtype
         # 'fp8_e4m3' (BASELINE config C5): inference runs on weights quantised to OCP e4m3 with per-output-channel
         # power-of-two scales (after the BatchNorm fold); training keeps fp32 masters and 16-bit operators
         self.weight_dtype = weight_dtype
@@ -147,13 +162,17 @@ class UNet(nn.Module):
                                '(there is no CPU fallback)')
         eng = self._engines.get(dev)
         if eng is None:
-            if self.act_dtype == torch.float32:
-                from .engine_f32 import EngineF32
+            if self.infer_dtype in (torch.float32, X2):
                 if self.weight_dtype is not None or self.norm != 'batch':
-                    raise ValueError("act_dtype='fp32' is the parity mode: BatchNorm network, no weight_dtype")
-                eng = EngineF32(self.dim, self.levels, self.base, self.num_channels, self.num_classes, dev)
+                    raise ValueError(f"{_ACT_NAME[self.infer_dtype]!r} is a parity mode: BatchNorm network, no weight_dtype")
+                if self.infer_dtype == X2:
+                    from .engine_x2 import EngineX2
+                    eng = EngineX2(self.dim, self.levels, self.base, self.num_channels, self.num_classes, dev)
+                else:
+                    from .engine_f32 import EngineF32
+                    eng = EngineF32(self.dim, self.levels, self.base, self.num_channels, self.num_classes, dev)
             else:
-                eng = Engine(self.dim, self.levels, self.base, self.num_channels, self.num_classes, self.act_dtype, dev,
+                eng = Engine(self.dim, self.levels, self.base, self.num_channels, self.num_classes, self.infer_dtype, dev,
                              weight_dtype=self.weight_dtype, norm=self.norm, groups=self.groups)
             self._engines = {dev: eng}
             self._packed_sig = None
