@@ -23,8 +23,13 @@ Workloads (BASELINE.json `configs`; the metric is "voxels/sec (train step + full
 
 The JSON line also carries
   roofline     -- the workload's bottleneck 3x3(x3) conv (dec0.conv1), timed live with HIP events on the launch
-                  stream over 50 back-to-back launches (average = `achieved`; the first 8 and the last 20 are given
-                  as burst / settled: the clock drops under sustained MFMA load), against the dense MFMA peak;
+                  stream over 50 back-to-back launches (average = `achieved`: the figure the committed rocprofv3
+                  summary of the same launch sequence reproduces; the first 8 and the last 20 are given as burst /
+                  settled: the clock drops under sustained MFMA load), against the dense MFMA peak; `in_situ` = the
+                  same layer's launches inside real steps (events around each);
+  parity_mode  -- the same step timed a second time with the prediction leg in the tolerance-meeting mode (fp16x2
+                  split precision: logits within 1e-3 of the CPU fp32 path), value / ms_per_step computed as the
+                  headline's; the training leg stays 16-bit as the reference's ('16-mixed');
   parity       -- max |logit| deviation and class-map mismatches of the benchmarked dtype against the native fp32
                   parity mode on one chunk (that mode is held within 1e-3 of the CPU oracle by tests/test_gpu_parity.py),
                   plus, when the CPU baseline runs, both modes against the CPU fp32 oracle on its sample;
@@ -216,28 +221,37 @@ def conv_roofline_back_to_back(nv, cfg, workload, dtype, N, iters=50):
 
 
 def native_parity(model, cfg, chunk_u8):
-    """The benchmarked dtype against the native fp32 parity mode on one tile (same weights): max |logit| difference and
-    class-map mismatches.  Device only -- the fp32 mode is itself checked against the CPU oracle in the tests."""
+    """The benchmarked dtype and the split-precision mode (fp16x2) against the native fp32 parity mode on one tile (same weights):
+    max |logit| difference and class-map mismatches.  Device only -- the fp32 and fp16x2 modes are themselves checked against the
+    CPU oracle in the tests."""
     from interactive_unet.engine_f32 import EngineF32
+    from interactive_unet.engine_x2 import EngineX2
     dim, ncls = cfg['dim'], cfg['ncls']
     shape = tuple(chunk_u8.shape)
     D, H, W = shape if dim == 3 else (1,) + shape
     vox = D * H * W
     e32 = EngineF32(dim, cfg['levels'], cfg['base'], 1, ncls, model.device)
     e32.load_eval(model.named_tensors())
-    eng = model.engine('eval')
+    engs = [model.engine('eval'), e32]
+    if not cfg['wq']:
+        ex2 = EngineX2(dim, cfg['levels'], cfg['base'], 1, ncls, model.device)
+        ex2.load_eval(model.named_tensors())
+        engs.append(ex2)
     outs = []
-    for e in (eng, e32):
+    for e in engs:
         lg = torch.empty((1, ncls) + shape, device=model.device)
         cl = torch.empty((1, vox), dtype=torch.uint8, device=model.device)
         e.infer(chunk_u8, (vox, vox, H * W, W, 1), 1, D, H, W, logits=lg, cls=cl)
         outs.append((lg, cl))
     torch.cuda.synchronize()
-    (lg, cl), (lg32, cl32) = outs
+    (lg, cl), (lg32, cl32) = outs[:2]
     res = {'tile': list(shape), 'dtype_vs': 'native fp32 parity mode (engine_f32, f32-input MFMA)',
            'max_abs_logit_vs_fp32': float((lg - lg32).abs().max()), 'logit_scale': float(lg32.abs().max()),
            'argmax_mismatch': int((cl != cl32).sum()), 'voxels': vox}
-    del e32
+    if len(outs) > 2:
+        res['fp16x2_max_abs_logit_vs_fp32'] = float((outs[2][0] - lg32).abs().max())
+        res['fp16x2_argmax_mismatch'] = int((outs[2][1] != cl32).sum())
+    del engs
     return res, lg32
 
 
@@ -292,7 +306,13 @@ def cpu_baseline(cfg, model=None, chunk_u8=None):
         e32 = EngineF32(dim, levels, base, 1, ncls, model.device)
         e32.load_eval(model.named_tensors())
         chk = {'sample': f'{"x".join(map(str, shp))} crop of a bench tile, current weights'}
-        for name, e in ((cfg['dtype'], model.engine('eval')), ('fp32_mode', e32)):
+        modes = [(cfg['dtype'], model.engine('eval')), ('fp32_mode', e32)]
+        if not cfg['wq']:
+            from interactive_unet.engine_x2 import EngineX2
+            ex2 = EngineX2(dim, levels, base, 1, ncls, model.device)
+            ex2.load_eval(model.named_tensors())
+            modes.append(('fp16x2', ex2))
+        for name, e in modes:
             lg = torch.empty((1, ncls) + shp, device=model.device)
             cl = torch.empty((1, nvox), dtype=torch.uint8, device=model.device)
             e.infer(crop, (nvox, nvox, H * W, W, 1), 1, D, H, W, logits=lg, cls=cl)
@@ -327,6 +347,7 @@ def main():
     ap.add_argument('--c4-reps', type=int, default=1, help='c3 only: timed 1024^3 predictions appended to the line (0 = skip)')
     ap.add_argument('--c4-size', type=int, default=1024)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-parity-mode', action='store_true', help='skip the second timed region (prediction leg in fp16x2)')
     args = ap.parse_args()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(relaunch(args))
@@ -507,10 +528,56 @@ def main():
     if probe_train:
         trainer.probe = None
 
+    # ------------------------------------------------------------------ parity mode: the same step with the prediction leg in the
+    # tolerance-meeting mode (fp16x2 split precision, engine_x2.py: logits within 1e-3 of the CPU fp32 path, what UNet() predicts in
+    # by default; the reference trains under '16-mixed' and predicts in fp32, trainer.py:59 / predict.py:30-35).  Timed exactly as
+    # `value` is: warm-up, barrier, K steps, barrier, max over ranks.
+    pm = None
+    if not cfg['wq'] and not args.no_parity_mode:
+        model.infer_dtype, model._engines, model._packed_sig = 'fp16x2', {}, None
+        if dim == 3:
+            ops = shard.NativeOps(model, ncls, S)                 # (step / predict_leg look `ops` up at call time)
+        legs16, legs = legs, {'train': 0.0, 'predict': 0.0}
+        for _ in range(max(1, args.warmup)):
+            step()
+        barrier()
+        tp0 = time.time()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        dtp = max_over_ranks(time.time() - tp0)
+        for _ in range(nleg):
+            step(timed=True)
+        tpp = legs['predict'] / nleg
+        pm = {'dtype': ('train ' + cfg['dtype'] + ' + ' if train_vox else '') + 'predict fp16x2 (split precision: hi + lo fp16 words, 3 MFMAs per product)',
+              'value': round((train_vox + unique_vox) * args.steps / dtp, 1), 'unit': 'voxels/s', 'steps': args.steps,
+              'ms_per_step': round(dtp / args.steps * 1e3, 3), 'predict_ms': round(tpp * 1e3, 3),
+              'predict_volume_voxels_per_s': round(unique_vox / tpp, 1), 'predict_processed_voxels_per_s': round(processed_vox / tpp, 1),
+              'predict_tflops_per_gpu(algorithmic)': round(fpv * processed_vox / world / tpp / 1e12, 1)}
+        if legs['train'] > 0:
+            pm['train_ms'] = round(legs['train'] / nleg * 1e3, 3)
+        if args.workload == 'c3' and args.c4_reps > 0:
+            slab4 = synth_volume_slab(b4[rank][0], b4[rank][1], Vs, Vs, dev)
+            run4 = lambda: shard.predict_volume_sharded(ops, slab4, V4, S, 0.25, group=group)
+            barrier()
+            t4 = time.time()
+            run4()
+            barrier()
+            d4 = max_over_ranks(time.time() - t4)
+            pm['c4'] = {'volume': list(V4), 'blocks': nb4, 'reps': 1, 'seconds_per_volume': round(d4, 4),
+                        'volume_voxels_per_s': round(Vs ** 3 / d4, 1), 'processed_voxels_per_s': round(nb4 * tvox / d4, 1)}
+            del slab4
+        legs = legs16
+        model.infer_dtype, model._engines, model._packed_sig = dtype, {}, None      # back to the benchmarked 16-bit mode
+
     out = None
     if rank == 0:
-        roof = conv_roofline_in_situ(nv, cfg, args.workload, dtype, probe_events[:400])
-        roof['back_to_back'] = conv_roofline_back_to_back(nv, cfg, args.workload, dtype, roof['tiles_per_launch'])
+        # `roofline` top level = the layer alone, back to back (the figure `rocprofv3 --kernel-trace --stats` of tools/bench_conv.py
+        # reproduces: profiles/r03_roofline_*); the launches inside real steps are the `in_situ` sub-object
+        in_situ = conv_roofline_in_situ(nv, cfg, args.workload, dtype, probe_events[:400])
+        roof = conv_roofline_back_to_back(nv, cfg, args.workload, dtype, in_situ['tiles_per_launch'])
+        roof['traffic'] = in_situ.pop('traffic')
+        roof['in_situ'] = in_situ
         if dim == 3 and roof['tiles_per_launch'] != 1:
             roof['back_to_back_1_tile'] = conv_roofline_back_to_back(nv, cfg, args.workload, dtype, 1)
         tile_s = 'x'.join(str(s) for s in tile)
@@ -553,6 +620,8 @@ def main():
         out['legs'] = lg
         if c4 is not None:
             out['c4'] = c4
+        if pm is not None:
+            out['parity_mode'] = pm
         if args.workload == 'c4':
             probe = my_slab[:S, :S, :S].contiguous()
         else:

@@ -52,39 +52,59 @@ class EngineX2:
         return ci, self.ch[l]
 
     # ------------------------------------------------------------------ weights
+    def _source(self, params, name):
+        """fp32 device tensor the preparation kernel reads: the parameter itself when it already lives on the device, otherwise a
+        persistent staging copy (engine.Engine._source)."""
+        t = params[name].detach()
+        if t.device == self.device and t.dtype == torch.float32 and t.is_contiguous():
+            return t
+        st = self._stage.get(name)
+        if st is None or st.shape != t.shape:
+            st = self._stage[name] = torch.empty(t.shape, dtype=torch.float32, device=self.device)
+        st.copy_(t)
+        return st
+
     def load_eval(self, params):
-        """Fold eval-mode BatchNorm (fp32, the oracle's operation order), scale, split and pack every operator."""
+        """Fold eval-mode BatchNorm (fp32, the oracle's operation order), scale, split and pack every operator.  Every buffer is
+        allocated once: a re-pack after an optimiser step is launches only (no allocation, no synchronisation)."""
+        if not hasattr(self, '_stage'):
+            self._stage, self._bufs = {}, {}
         dev = self.device
-        f32 = lambda n: torch.empty(n, dtype=torch.float32, device=dev)
-        f16 = lambda n: torch.empty(n, dtype=torch.float16, device=dev)
-        src = lambda name: params[name].detach().to(dev, torch.float32).contiguous()
         lib, s, P, A = nv.lib(), nv.stream(), {}, self.act_scale
+
+        def bufs(name, n_virtual, n_packed, co):
+            b = self._bufs.get(name)
+            if b is None:
+                b = self._bufs[name] = (torch.empty(n_virtual, dtype=torch.float32, device=dev),
+                                        torch.empty(n_packed, dtype=torch.float16, device=dev),
+                                        torch.empty(co, dtype=torch.float32, device=dev), torch.empty(co, dtype=torch.float32, device=dev))
+            return b
         for prefix in self.stage_names():
             ci, co = self.stage_io(prefix)
             for j, (a, b) in enumerate(((ci, co), (co, co)), 1):
-                w = src(f'{prefix}.conv{j}.weight')
-                bn = [src(f'{prefix}.bn{j}.{k}') for k in ('weight', 'bias', 'running_mean', 'running_var')]
-                wv, osc, bias = f32(b * 3 * a * self.taps), f32(b), f32(b)
+                name = f'{prefix}.conv{j}'
+                first = prefix == 'enc0' and j == 1
+                w = self._source(params, f'{name}.weight')
+                bn = [self._source(params, f'{prefix}.bn{j}.{k}') for k in ('weight', 'bias', 'running_mean', 'running_var')]
+                npk = lib.iunet_pack_first_conv_elems(b, 3 * a, self.taps) if first else nv.pack_conv3_elems(b, 3 * a, self.taps, 2)
+                wv, dst, osc, bias = bufs(name, b * 3 * a * self.taps, npk, b)
                 nv.call('iunet_x2_prep', nv.ptr(w), nv.ptr(wv), nv.ptr(osc), nv.ptr(bias), nv.ptr(bn[0]), nv.ptr(bn[1]),
                         nv.ptr(bn[2]), nv.ptr(bn[3]), None, BN_EPS, A, A, b, a, self.taps, 0, s)
-                if prefix == 'enc0' and j == 1:
-                    dst = f16(lib.iunet_pack_first_conv_elems(b, 3 * a, self.taps))
+                if first:
                     nv.call('iunet_pack_first_conv', 0, nv.ptr(wv), None, nv.ptr(dst), b, 3 * a, self.taps, s)
                 else:
-                    dst = f16(nv.pack_conv3_elems(b, 3 * a, self.taps, 2))
                     nv.call('iunet_pack_conv3', 0, nv.ptr(wv), None, nv.ptr(dst), b, 3 * a, self.taps, 2, s)
-                P[f'{prefix}.conv{j}'] = (dst, osc, bias)
+                P[name] = (dst, osc, bias)
         for l in range(self.levels - 2, -1, -1):
-            w, b0 = src(f'dec{l}.up.weight'), src(f'dec{l}.up.bias')
+            name = f'dec{l}.up'
+            w, b0 = self._source(params, f'{name}.weight'), self._source(params, f'{name}.bias')
             ci, co = self.ch[l + 1], self.ch[l]
-            wv, osc, bias = f32(3 * ci * co * self.npos), f32(co), f32(co)
+            wv, dst, osc, bias = bufs(name, 3 * ci * co * self.npos, 3 * ci * co * self.npos, co)
             nv.call('iunet_x2_prep', nv.ptr(w), nv.ptr(wv), nv.ptr(osc), nv.ptr(bias), None, None, None, None, nv.ptr(b0),
                     BN_EPS, A, A, co, ci, self.npos, 1, s)
-            dst = f16(3 * ci * co * self.npos)
             nv.call('iunet_pack_convT', 0, nv.ptr(wv), nv.ptr(dst), 3 * ci, co, self.npos, s)
-            P[f'dec{l}.up'] = (dst, osc, bias)
-        P['head'] = (src('head.weight').reshape(self.ncls, self.ch[0]).contiguous(), src('head.bias'))
-        torch.cuda.current_stream().synchronize()          # the virtual operators / staging copies above are freed here
+            P[name] = (dst, osc, bias)
+        P['head'] = (self._source(params, 'head.weight').reshape(self.ncls, self.ch[0]), self._source(params, 'head.bias'))
         self.packed = P
 
     # ------------------------------------------------------------------ workspace
