@@ -142,12 +142,16 @@ int iunet_f32_head_fwd(const void* x, long long x_ss, int C0, const void* w, con
  * Activations are stored multiplied by a power of two act_scale; csrc/split16.hip states the scaling. */
 /* operator preparation: w fp32 [Cout][Cin][taps] (transposed == 0; taps 9 / 27) or ConvTranspose w [Cin][Cout][taps]
  * (transposed != 0; taps 4 / 8), optional eval-mode BatchNorm fold (gamma..var, as iunet_f32_pack_conv) or the layer's own
- * bias_in -> wv: the VIRTUAL fp32 operator over 3 Cin input channels [w_hi | w_hi | w_lo] (3 Cout Cin taps floats; feed it to
- * iunet_pack_conv3 mode 2 / iunet_pack_first_conv / iunet_pack_convT with "Cin" = 3 Cin, dtype 0), oscale [Cout] = the power of
- * two the accumulator is multiplied by (act_out / (act_in * row scale)), bias_out [Cout] = act_out * bias. */
+ * bias_in -> wv: transposed 0: the VIRTUAL fp32 operator over 3 Cin input channels, [w_hi | w_hi | w_lo] per chunk of `chunk`
+ * channels -- the step of the kernel that consumes it: 16 (3-D stage conv), 32 (2-D), Cin (first conv) -- (3 Cout Cin taps
+ * floats; feed it to iunet_pack_conv3 mode 2 / iunet_pack_first_conv with "Cin" = 3 Cin, dtype 0); transposed 2 (what
+ * iunet_x2_convT_fwd takes; Cin % 32 == 0): both words once over 2 Cin channels, in chunks of iunet_x2_convT_kc(Cin) k-steps of 32
+ * channels [chunk][hi | lo][k-step][32] (feed it to iunet_pack_convT with "Cin" = 2 Cin); oscale [Cout] = the power of two the
+ * accumulator is multiplied by (act_out / (act_in * row scale)), bias_out [Cout] = act_out * bias. */
+int iunet_x2_convT_kc(int Cin);
 int iunet_x2_prep(const void* w, void* wv, void* oscale, void* bias_out, const void* gamma, const void* beta, const void* mean,
                   const void* var, const void* bias_in, float eps, float act_in, float act_out, int Cout, int Cin, int taps,
-                  int transposed, void* stream);
+                  int transposed, int chunk, void* stream);
 /* first conv: the caller's tensor (strides / dtype as iunet_first_conv_fwd; u8 is x / 255 correctly rounded, predict.py:30),
  * multiplied by act_scale and split -> y = split(relu?(acc * oscale + bias)) */
 int iunet_x2_first_conv_fwd(int nd, const void* x, int in_dtype, const long long* in_strides, void* y, long long y_sstride, int y_lo,

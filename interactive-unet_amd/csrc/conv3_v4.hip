@@ -69,9 +69,9 @@ struct ConvV4Params {
   const void* bw_y; long long bw_y_ss;
   const float* bw_mean; const float* bw_invstd; const float* bw_scale; const float* bw_shift;      // [Cout] of the producer layer
   // fp16x2 split precision (template flag SPL, split16.hip): every value travels as hi = f16(v), lo = f16(v - hi) in two plane sets.
-  // The launch is a conv over Cin' = 3 Cin virtual channels -- parts [x_hi | x_lo | x_hi] against the operator rows
-  // [w_hi | w_hi | w_lo] -- so the step loop, the LDS images and the operator orders are the 16-bit kernel's own; only the source
-  // plane of a chunk and the epilogue differ.  split_nc = steps per part, x_lo / y_lo = plane offset of the lo planes.
+  // The launch is a conv over Cin' = 3 Cin virtual channels -- per channel chunk the parts [x_lo | x_hi | x_hi] against the operator
+  // rows [w_hi | w_hi | w_lo] -- so the step loop, the LDS images and the operator order are the 16-bit kernel's own; only the source
+  // plane of a chunk, the buffer naming and the epilogue differ.  split_nc = channel chunks, x_lo / y_lo = plane offset of the lo planes.
   int split_nc, x_lo, y_lo;
   const float* oscale;                        // [Cout]: power-of-two factor on the accumulator (operator and activation scales)
 };
@@ -89,7 +89,7 @@ struct ConvV4Params {
 // 27 taps in 27 K-slots: -10 % MFMAs, fragment reads and weight bytes.  LDS: 3 x 34 816 + 24 576 + 30 720 + scratch = 162 304 B.
 template <typename T, int ND, bool WS, bool SMALL, bool BW = false, bool PAIR = false, bool NP = false, bool SPL = false>
 __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + ((WS || PAIR) ? 256 : 512)), 1) void conv3_v4_kernel(ConvV4Params p) {
-  static_assert(!SPL || (!WS && !BW), "split precision: streamed weights (Cin' = 3 Cin >= 96), forward only");
+  static_assert(!SPL || (!WS && !BW && !PAIR && !NP), "split precision: streamed weights (Cin' = 3 Cin >= 96), forward only, padded operator");
   static_assert(!PAIR || (!WS && !BW && ND == 3), "tile pairs: the streamed-weight 3-D forward / data-gradient variant only");
   static_assert(!NP || (!WS && !BW && !PAIR && ND == 3), "padding-free step: the streamed-weight 3-D variants without fused BatchNorm-backward sums (so far)");
   using V8 = typename Vec8<T>::type;
@@ -152,12 +152,20 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + ((WS || PAIR) ? 256 
     ((float*)(smem + off_bw))[tid] = src[cob * 32 + (tid & 31)];       // read in tile epilogues, many barriers later
   }
   const u32x4* wsrc = (const u32x4*)p.wpk + (long long)cob * (NP ? (nchunk / 2) * ((WE + WO) / 16) : nchunk * (WSTEP / 16));
-  auto abuf_of = [&](int s) -> int { return NP ? (s - 3 * (s / 3)) * ABUF : (s & 1) * ABUF; };      // halo buffer of step s
-  // first source plane of a chunk.  SPL: chunk = part * split_nc + c; parts 0 and 2 read the hi planes of channel chunk c, part 1 the lo planes
+  // SPL: virtual chunk = 3 * c + part for channel chunk c; part 0 = x_lo w_hi, 1 = x_hi w_hi, 2 = x_hi w_lo.  Consecutive parts share an
+  // operand -- 0 -> 1 the weights, 1 -> 2 the halo tile -- so the buffers are named by what they hold instead of by step parity (halo:
+  // 0 = lo, 1 = hi; weights: 0 = w_hi, 1 = w_lo) and the loaders skip what is resident: 2 halo tiles + 2 weight chunks per channel
+  // chunk instead of 3 + 3.
+  auto part_of = [&](int s) -> int { const int c = chunk_of(s); return c - 3 * (c / 3); };
+  auto abuf_of = [&](int s) -> int {                                                               // halo buffer of step s
+    if constexpr (SPL) return part_of(s) == 0 ? 0 : ABUF;
+    return NP ? (s - 3 * (s / 3)) * ABUF : (s & 1) * ABUF;
+  };
+  // first source plane of a chunk
   auto src_plane = [&](int chunk) -> long long {
     if constexpr (SPL) {
-      const int part = chunk / p.split_nc, c = chunk - part * p.split_nc;
-      return (long long)c * CP + (part == 1 ? p.x_lo : 0);
+      const int c = chunk / 3, part = chunk - 3 * c;
+      return (long long)c * CP + (part == 0 ? p.x_lo : 0);
     }
     return (long long)chunk * CP;
   };
@@ -328,12 +336,26 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + ((WS || PAIR) ? 256 
 #endif
       // 3-D only: the 2-D level-0 layers are HBM-bound and need the register path's loads in flight across the barrier (measured:
       // C2's dec0.conv1 at 45 % of the HBM peak by LDS-DMA against 49 % through registers)
-      if (ND == 3 && !decltype(ACT)::value && !(p.dbg & 64)) {      // (IUNET_V4_DBG=64: the register path for every launch -- A/B switch)
+      if ((ND == 3 || SPL) && !decltype(ACT)::value && !(p.dbg & 64)) {      // (IUNET_V4_DBG=64: the register path for every launch -- A/B switch)
         // ---- everything by LDS-DMA: in iteration s (consumers on step s) the buffers of step s + 1 are filled ----
         if (!WS) dma_weights(0, 0);
         dma_acts(0);
         landed();
         lds_barrier();
+        if constexpr (SPL) {
+          // step s + 1 = part 0: lo halo -> buffer 0 (last read two steps ago) + w_hi -> weight buffer 0 (read until step s - 1);
+          // part 1: hi halo -> buffer 1 (read until step s - 1), w_hi stays; part 2: w_lo -> weight buffer 1, the hi halo stays
+          for (int s = 0; s < nsteps; ++s) {
+            if (s + 1 < nsteps) {
+              const int pn = part_of(s + 1);
+              if (pn != 1) dma_weights(s + 1, pn == 2 ? 1 : 0);
+              if (pn != 2) dma_acts(s + 1);
+            }
+            landed();
+            lds_barrier();
+          }
+          return;
+        }
         if (PAIR) {
           for (int s = 0; s + 1 < nsteps; s += 2) {
             // steps s, s + 1: tiles A, B on the weights of one chunk (buffer = chunk parity); the next chunk's weights go half in each
@@ -472,7 +494,7 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + ((WS || PAIR) ? 256 
   auto step_ptrs = [&](int s, const unsigned char*& ab, const unsigned char*& wl) {
     const int chunk = chunk_of(s);
     ab = smem + abuf_of(s) + rbase;
-    wl = smem + OFF_W + (NP ? ((chunk & 1) ? WE : 0) : (WS ? chunk : PAIR ? (chunk & 1) : (s & 1)) * WSTEP) + lane * 16;
+    wl = smem + OFF_W + (NP ? ((chunk & 1) ? WE : 0) : (WS ? chunk : PAIR ? (chunk & 1) : SPL ? (chunk - 3 * (chunk / 3) == 2) : (s & 1)) * WSTEP) + lane * 16;
   };
   // NP, odd steps: the cross group.  Lanes q >> 1 = 0 read column 8 of the PREVIOUS step's halo buffer, q >> 1 = 1 of this step's;
   // the weights follow the four regular pairs in the odd region.

@@ -30,9 +30,11 @@ namespace {
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------ operator preparation
-// kind 0: conv  w [Cout][Cin][taps]   -> wv [Cout][3 Cin][taps]
-// kind 1: convT w [Cin][Cout][npos]   -> wv [3 Cin][Cout][npos]
-// virtual channel order [hi | hi | lo] (the activation parts are [hi | lo | hi]).  One workgroup per output channel:
+// kind 0: conv  w [Cout][Cin][taps]   -> wv [Cout][3 Cin][taps]: per chunk of kc input channels (the consuming kernel's step: 16 in
+//         3-D, 32 in 2-D, all Cin for the first conv) the rows [w_hi | w_hi | w_lo]; the activation parts are [x_lo | x_hi | x_hi]
+// kind 1: convT w [Cin][Cout][npos]   -> wv [3 Cin][Cout][npos], [hi | hi | lo] over all channels (activation parts [hi | lo | hi])
+// kind 2: convT w [Cin][Cout][npos]   -> wv [2 Cin][Cout][npos]: both words of every entry once, in chunks of kc k-steps (of 32
+// channels) [chunk][hi | lo][kc][32] -- the operator x2_convT_lds_kernel keeps in LDS.  One workgroup per output channel:
 // a = gamma / sqrt(var + eps), w' = w * a, bias' = beta - mean * a (each operation rounded on its own, oracle/unet_ref.py fold_bn),
 // s = 2^k with max |w'| * s in [2^9, 2^10), w'' = w' * s (exact), hi = f16(w''), lo = f16(w'' - hi);
 // oscale = act_out / (act_in * s), bias_out = bias' * act_out (powers of two: exact).
@@ -40,7 +42,7 @@ __global__ __launch_bounds__(256) void x2_prep_kernel(const float* __restrict__ 
                                                      float* __restrict__ bias_out, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, const float* __restrict__ mean,
                                                      const float* __restrict__ var, const float* __restrict__ bias_in, float eps,
-                                                     float act_in, float act_out, int Cout, int Cin, int taps, int kind) {
+                                                     float act_in, float act_out, int Cout, int Cin, int taps, int kind, int kc) {
 #pragma clang fp contract(off)
   __shared__ float red[256];
   const int co = blockIdx.x, tid = threadIdx.x;
@@ -73,11 +75,19 @@ __global__ __launch_bounds__(256) void x2_prep_kernel(const float* __restrict__ 
     split16<f16>(v, hi, lo);
     const float fh = (float)hi, fl = (float)lo;
     if (kind == 0) {
+      // kc = channels per chunk of the consuming kernel (16 / 32 / Cin): virtual channel (3 c + part) * kc + i
+      const int c = ci / kc, i = ci - c * kc;
       float* d = wv + ((long long)co * 3 * Cin) * taps + t;
-      d[(long long)ci * taps] = fh; d[(long long)(Cin + ci) * taps] = fh; d[(long long)(2 * Cin + ci) * taps] = fl;
-    } else {
+      d[(long long)((3 * c + 0) * kc + i) * taps] = fh; d[(long long)((3 * c + 1) * kc + i) * taps] = fh;
+      d[(long long)((3 * c + 2) * kc + i) * taps] = fl;
+    } else if (kind == 1) {
       float* d = wv + (long long)co * taps + t;
       d[((long long)ci * Cout) * taps] = fh; d[((long long)(Cin + ci) * Cout) * taps] = fh; d[((long long)(2 * Cin + ci) * Cout) * taps] = fl;
+    } else {
+      const int ks = ci >> 5, chunk = ks / kc, j = ks - chunk * kc, i = ci & 31;
+      float* d = wv + (long long)co * taps + t;
+      d[((long long)(((chunk * 2 + 0) * kc + j) * 32 + i) * Cout) * taps] = fh;
+      d[((long long)(((chunk * 2 + 1) * kc + j) * 32 + i) * Cout) * taps] = fl;
     }
   }
   if (tid == 0) {
@@ -109,7 +119,7 @@ __device__ __forceinline__ float x2_load_in(const void* p, long long off, int dt
 }
 
 // The structure of pointwise.hip's first_conv_kernel (K = taps x channels padded to 32, im2col operand gathered per lane from an
-// LDS image of the halo tile) over the 3 CIN virtual channels [hi | lo | hi] of act_scale * x.
+// LDS image of the halo tile) over the 3 CIN virtual channels [lo | hi | hi] of act_scale * x (operator rows [w_hi | w_hi | w_lo]).
 template <int ND, int CIN>
 __global__ __launch_bounds__(256) void x2_first_conv_kernel(X2FirstParams p) {
   constexpr int VC = 3 * CIN;
@@ -137,7 +147,7 @@ __global__ __launch_bounds__(256) void x2_first_conv_kernel(X2FirstParams p) {
       v = x2_load_in(p.x, n * p.sN + c * p.sC + gz * p.sD + gy * p.sH + gx * p.sW, p.in_dtype);
     f16 hi, lo;
     split16<f16>(v * p.act_scale, hi, lo);
-    xs[c * NPIX + pix] = hi; xs[(CIN + c) * NPIX + pix] = lo; xs[(2 * CIN + c) * NPIX + pix] = hi;
+    xs[c * NPIX + pix] = lo; xs[(CIN + c) * NPIX + pix] = hi; xs[(2 * CIN + c) * NPIX + pix] = hi;      // parts [x_lo | x_hi | x_hi]
   }
   const f16x8* wp = (const f16x8*)p.w + (long long)cob * KS * 2 * 64 + lane;
   // per-lane LDS element offsets of the 8 k entries of its k-quad (k = 32 ks + 8 q + j = tap * VC + c, pack_first_conv_kernel)
@@ -234,8 +244,8 @@ __global__ __launch_bounds__(256) void x2_maxpool_kernel(const f16* __restrict__
 }
 
 // ------------------------------------------------------------------ transposed conv k2 s2
-// pointwise.hip's convT_kernel (one wave = 16 input x voxels x 32 couts x all 2^d output positions, operands straight from
-// global) over the 3 Cin virtual channels; the stride-2 interleave of the two x positions for full-line stores is the same.
+// pointwise.hip's transposed conv (one wave = 16 input x voxels x 32 couts x all 2^d output positions, B operand straight from
+// global, stride-2 interleave of the two x positions for full-line stores).
 struct X2ConvTParams {
   const void* x; long long x_sstride; int x_lo;
   void* y; long long y_sstride; int y_lo;
@@ -243,81 +253,151 @@ struct X2ConvTParams {
   int N, D, H, W, Cin, Cout;            // input grid; Cin = real input channels
 };
 
-template <int ND>
-__global__ __launch_bounds__(256) void x2_convT_kernel(X2ConvTParams p) {
+// The Cout tile's weights sit in LDS -- BOTH words of every entry once ([hi | lo], prep kind 2), in chunks of KC k-steps -- and a wave
+// takes two 16-voxel groups: a first version that fetched 3 x 16 KB of weight fragments per k-step and wave through the vector
+// cache (the virtual [hi | hi | lo] operator) spent 12 % of the 128^3 forward on 1.7 % of its FLOPs.  One chunk (Cin <= 64): loaded once per workgroup, which then
+// walks its voxel groups; more: double-buffered by LDS-DMA through every pass (the structure of pointwise.hip's convT_chunk_kernel).
+// Per (k-step, position, cout half): 2 fragment reads feed 3 MFMAs per voxel group: x_hi w_hi + x_lo w_hi + x_hi w_lo.
+template <int ND, int KC>
+__global__ __launch_bounds__(256) void x2_convT_lds_kernel(X2ConvTParams p) {
   constexpr int NPOS = ND == 3 ? 8 : 4;
+  constexpr int G = 2;
+  constexpr int CHB = 2 * KC * NPOS * 2 * 1024;                 // bytes of one chunk
+  extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l15 = lane & 15, q = lane >> 4;
-  const int xg = (p.W + 15) / 16;
-  const long long rows = (long long)p.D * p.H * xg;
-  const long long wid = (long long)blockIdx.x * 4 + wave;
-  if (wid >= rows * p.N) return;
-  const int n = (int)(wid / rows);
-  const long long r = wid - n * rows;
-  const int xb = (int)(r % xg), y = (int)((r / xg) % p.H), z = (int)(r / ((long long)xg * p.H));
   const int cob = blockIdx.y;
-  const int x = xb * 16 + l15;
-  const int xc = x < p.W ? x : p.W - 1;
+  const int nchunks = (p.Cin >> 5) / KC;
+  const u32x4* wsrc = (const u32x4*)p.wpk + (long long)cob * nchunks * (CHB / 16);
+  const int xg = (p.W + 15) / 16;
+  const long long rows = (long long)p.D * p.H * xg, ngroups = rows * p.N;
   const long long in_plane = (long long)p.D * p.H * p.W * 8;
-  const f16* xin = (const f16*)p.x + n * p.x_sstride + (((long long)z * p.H + y) * p.W + xc) * 8;
-  const int nk0 = p.Cin >> 5, nk = 3 * nk0;
-  const f16x8* wp = (const f16x8*)p.wpk + (long long)cob * nk * NPOS * 2 * 64 + lane;
-
-  f32x4 acc[NPOS][2];
-#pragma unroll
-  for (int s = 0; s < NPOS; ++s) { acc[s][0] = f32x4{0, 0, 0, 0}; acc[s][1] = f32x4{0, 0, 0, 0}; }
-  for (int ks = 0; ks < nk; ++ks) {
-    const int part = ks / nk0, c = ks - part * nk0;
-    const f16x8 b = *(const f16x8*)(xin + (long long)(c * 4 + q + (part == 1 ? p.x_lo : 0)) * in_plane);
-#pragma unroll
-    for (int s = 0; s < NPOS; ++s) {
-      acc[s][0] = mfma16<f16>(wp[((ks * NPOS + s) * 2 + 0) * 64], b, acc[s][0]);
-      acc[s][1] = mfma16<f16>(wp[((ks * NPOS + s) * 2 + 1) * 64], b, acc[s][1]);
-    }
-  }
   const int Do = ND == 3 ? p.D * 2 : 1, Ho = p.H * 2, Wo = p.W * 2;
   const long long out_plane = (long long)Do * Ho * Wo * 8;
-  f16* yout = (f16*)p.y + n * p.y_sstride + (long long)(cob * 4 + q) * out_plane;
   float bias[8], osc[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { bias[j] = p.bias[cob * 32 + q * 8 + j]; osc[j] = p.oscale[cob * 32 + q * 8 + j]; }
-  const int src_lo = ((lane & 48) | (l15 >> 1)) * 4, src_hi = src_lo + 8 * 4;     // byte index of the source lane
+  const int src_lo = ((lane & 48) | (l15 >> 1)) * 4, src_hi = src_lo + 8 * 4;
   const bool odd = l15 & 1;
-  const int x0 = xb * 16;
+  const f16x8* wl = (const f16x8*)smem + lane;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  auto dma_chunk = [&](int ch) {
+    const u32x4* src = wsrc + (long long)ch * (CHB / 16);
 #pragma unroll
-  for (int sp = 0; sp < NPOS / 2; ++sp) {
-    const int a = ND == 3 ? (sp >> 1) : 0, b = sp & 1;
-    i32x4 oc[2][2];                                    // [x position][hi | lo]
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      f16x8 o, ol;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float rr = fmaf(j < 4 ? acc[sp * 2 + c][0][j & 3] : acc[sp * 2 + c][1][j & 3], osc[j], bias[j]);
-        f16 hi, lo;
-        split16<f16>(rr, hi, lo);
-        o[j] = hi; ol[j] = lo;
-      }
-      oc[c][0] = __builtin_bit_cast(i32x4, o);
-      oc[c][1] = __builtin_bit_cast(i32x4, ol);
+    for (int i = 0; i < CHB / 16 / 256; ++i) {
+      const int base = (i * 4 + wave) * 64;                       // first 16-byte item of this wave instruction
+      const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (ch & 1) * CHB + base * 16);
+      const u32x4* gsrc = src + base + lane;
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
     }
-    const int oz = ND == 3 ? z * 2 + a : 0;
-    f16* row = yout + (((long long)oz * Ho + y * 2 + b) * Wo + 2 * x0) * 8;
+  };
+  bool resident = false;                                           // one chunk: it stays in LDS over the passes
+  for (long long base = (long long)blockIdx.x * 4 * G; base < ngroups; base += (long long)gridDim.x * 4 * G) {      // uniform trip count
+    const long long g0 = base + wave * G;
+    int n_[G], z_[G], y_[G], xb_[G];
+    const f16* xin_[G];
 #pragma unroll
-    for (int w = 0; w < 2; ++w)
+    for (int g = 0; g < G; ++g) {
+      const long long wid = g0 + g < ngroups ? g0 + g : ngroups - 1;      // a missing partner recomputes the last group (never stored)
+      n_[g] = (int)(wid / rows);
+      const long long r = wid - n_[g] * rows;
+      xb_[g] = (int)(r % xg); y_[g] = (int)((r / xg) % p.H); z_[g] = (int)(r / ((long long)xg * p.H));
+      const int xc = min(xb_[g] * 16 + l15, p.W - 1);
+      xin_[g] = (const f16*)p.x + n_[g] * p.x_sstride + (((long long)z_[g] * p.H + y_[g]) * p.W + xc) * 8;
+    }
+    f32x4 acc[G][NPOS][2];
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int src = h ? src_hi : src_lo;
-        i32x4 v;
+    for (int g = 0; g < G; ++g)
 #pragma unroll
-        for (int d = 0; d < 4; ++d) {
-          const int t0 = __builtin_amdgcn_ds_bpermute(src, oc[0][w][d]);
-          const int t1 = __builtin_amdgcn_ds_bpermute(src, oc[1][w][d]);
-          v[d] = odd ? t1 : t0;
+      for (int s = 0; s < NPOS; ++s) { acc[g][s][0] = f32x4{0, 0, 0, 0}; acc[g][s][1] = f32x4{0, 0, 0, 0}; }
+    auto load_b = [&](int ch, f16x8 (&bb)[G][2][KC]) {
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int j = 0; j < KC; ++j) {
+          const long long pl = (long long)((ch * KC + j) * 4 + q);
+          bb[g][0][j] = *(const f16x8*)(xin_[g] + pl * in_plane);
+          bb[g][1][j] = *(const f16x8*)(xin_[g] + (pl + p.x_lo) * in_plane);
         }
-        const int xo = 2 * x0 + 16 * h + l15;
-        if (xo < Wo) *(i32x4*)(row + (w ? (long long)p.y_lo * out_plane : 0) + (16 * h + l15) * 8) = v;
+    };
+    f16x8 bcur[G][2][KC], bnext[G][2][KC];
+    if (!resident) {
+      __syncthreads();                                             // the previous pass's last chunk is read
+      dma_chunk(0);
+    }
+    load_b(0, bcur);
+    for (int ch = 0; ch < nchunks; ++ch) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this chunk's weights and fragments have landed
+      __syncthreads();
+      if (ch + 1 < nchunks) { dma_chunk(ch + 1); load_b(ch + 1, bnext); }
+      const f16x8* wb = wl + (ch & 1) * (CHB / 16);
+#pragma unroll
+      for (int j = 0; j < KC; ++j)
+#pragma unroll
+        for (int s = 0; s < NPOS; ++s)
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const f16x8 ah = wb[(((0 * KC + j) * NPOS + s) * 2 + t) * 64];
+            const f16x8 al = wb[(((1 * KC + j) * NPOS + s) * 2 + t) * 64];
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+              acc[g][s][t] = mfma16<f16>(ah, bcur[g][0][j], acc[g][s][t]);
+              acc[g][s][t] = mfma16<f16>(ah, bcur[g][1][j], acc[g][s][t]);
+              acc[g][s][t] = mfma16<f16>(al, bcur[g][0][j], acc[g][s][t]);
+            }
+          }
+      if (ch + 1 < nchunks) {
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < KC; ++j) bcur[g][h][j] = bnext[g][h][j];
       }
+    }
+    resident = nchunks == 1;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      if (g0 + g >= ngroups) break;
+      f16* yout = (f16*)p.y + n_[g] * p.y_sstride + (long long)(cob * 4 + q) * out_plane;
+      const int x0 = xb_[g] * 16;
+#pragma unroll
+      for (int sp = 0; sp < NPOS / 2; ++sp) {
+        const int a = ND == 3 ? (sp >> 1) : 0, b = sp & 1;
+        i32x4 oc[2][2];                                  // [x position][hi | lo]
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          f16x8 o, ol;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float rr = fmaf(j < 4 ? acc[g][sp * 2 + c][0][j & 3] : acc[g][sp * 2 + c][1][j & 3], osc[j], bias[j]);
+            f16 hi, lo;
+            split16<f16>(rr, hi, lo);
+            o[j] = hi; ol[j] = lo;
+          }
+          oc[c][0] = __builtin_bit_cast(i32x4, o);
+          oc[c][1] = __builtin_bit_cast(i32x4, ol);
+        }
+        const int oz = ND == 3 ? z_[g] * 2 + a : 0;
+        f16* row = yout + (((long long)oz * Ho + y_[g] * 2 + b) * Wo + 2 * x0) * 8;
+#pragma unroll
+        for (int w = 0; w < 2; ++w)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int src = h ? src_hi : src_lo;
+            i32x4 v;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+              const int t0 = __builtin_amdgcn_ds_bpermute(src, oc[0][w][d]);
+              const int t1 = __builtin_amdgcn_ds_bpermute(src, oc[1][w][d]);
+              v[d] = odd ? t1 : t0;
+            }
+            if (2 * x0 + 16 * h + l15 < Wo) *(i32x4*)(row + (w ? (long long)p.y_lo * out_plane : 0) + (16 * h + l15) * 8) = v;
+          }
+      }
+    }
   }
 }
 
@@ -390,18 +470,27 @@ bool pow2(float v) { int e; return v > 0.f && frexpf(v, &e) == 0.5f; }
 
 extern "C" {
 
-/* virtual fp32 operator of a stage conv (transposed = 0: [Cout][3 Cin][taps]) or a transposed conv (transposed = 1: [3 Cin][Cout][npos])
- * + its accumulator scale and scaled bias; gamma..var: the eval-mode BatchNorm folded in (or null), bias_in: the layer's own bias (or null) */
+/* k-steps (of 32 input channels) per LDS chunk of the transposed conv's [hi | lo] operator (iunet_x2_prep transposed = 2) */
+int iunet_x2_convT_kc(int Cin) { return (Cin / 32) % 2 == 0 ? 2 : 1; }
+
+/* fp32 operator of a stage conv (transposed = 0: VIRTUAL [Cout][3 Cin][taps] = [w_hi | w_hi | w_lo]) or a transposed conv (transposed = 1:
+ * virtual [3 Cin][Cout][npos]; transposed = 2: [2 Cin][Cout][npos], both words once in chunks of iunet_x2_convT_kc k-steps -- what
+ * iunet_x2_convT_fwd takes) + its accumulator scale and scaled bias; gamma..var: the eval-mode BatchNorm folded in (or null),
+ * bias_in: the layer's own bias (or null) */
 int iunet_x2_prep(const void* w, void* wv, void* oscale, void* bias_out, const void* gamma, const void* beta, const void* mean,
                   const void* var, const void* bias_in, float eps, float act_in, float act_out, int Cout, int Cin, int taps,
-                  int transposed, void* stream) {
+                  int transposed, int chunk, void* stream) {
   IUNET_REQUIRE(w && wv && oscale && bias_out, "x2_prep: null pointer");
+  IUNET_REQUIRE(transposed || (chunk > 0 && Cin % chunk == 0), "x2_prep: the chunk (%d) must divide Cin (%d)", chunk, Cin);
   IUNET_REQUIRE(Cout > 0 && Cin > 0 && taps > 0, "x2_prep: bad operator %d x %d x %d", Cout, Cin, taps);
+  IUNET_REQUIRE(transposed >= 0 && transposed <= 2, "x2_prep: transposed must be 0, 1 or 2 (got %d)", transposed);
+  IUNET_REQUIRE(transposed != 2 || Cin % 32 == 0, "x2_prep: the chunked transposed operator needs Cin %% 32 == 0 (got %d)", Cin);
   IUNET_REQUIRE(!gamma || (beta && mean && var), "x2_prep: a BatchNorm fold needs gamma, beta, mean and var");
   IUNET_REQUIRE(pow2(act_in) && pow2(act_out), "x2_prep: the activation scales must be powers of two (got %g, %g)", act_in, act_out);
   hipLaunchKernelGGL(x2_prep_kernel, dim3(Cout), dim3(256), 0, (hipStream_t)stream, (const float*)w, (float*)wv, (float*)oscale,
                      (float*)bias_out, (const float*)gamma, (const float*)beta, (const float*)mean, (const float*)var,
-                     (const float*)bias_in, eps, act_in, act_out, Cout, Cin, taps, transposed ? 1 : 0);
+                     (const float*)bias_in, eps, act_in, act_out, Cout, Cin, taps, transposed,
+                     transposed ? iunet_x2_convT_kc(Cin) : chunk);
   IUNET_CHECK_HIP(hipGetLastError());
   return IUNET_OK;
 }
@@ -462,7 +551,7 @@ int iunet_x2_maxpool_fwd(int nd, const void* x, long long x_ss, int x_lo, void* 
   return IUNET_OK;
 }
 
-/* transposed conv k2 s2; wpk = iunet_pack_convT of the virtual operator [3 Cin][Cout][npos] */
+/* transposed conv k2 s2; wpk = iunet_pack_convT ("Cin" = 2 Cin) of iunet_x2_prep's transposed = 2 operator [2 Cin][Cout][npos] */
 int iunet_x2_convT_fwd(int nd, const void* x, long long x_ss, int x_lo, void* y, long long y_ss, int y_lo, const void* wpk,
                        const void* oscale, const void* bias, int N, int D, int H, int W, int Cin, int Cout, void* stream) {
   IUNET_REQUIRE(x && y && wpk && oscale && bias, "x2_convT: null pointer");
@@ -473,9 +562,17 @@ int iunet_x2_convT_fwd(int nd, const void* x, long long x_ss, int x_lo, void* y,
   p.x = x; p.x_sstride = x_ss; p.x_lo = x_lo; p.y = y; p.y_sstride = y_ss; p.y_lo = y_lo; p.wpk = wpk;
   p.oscale = (const float*)oscale; p.bias = (const float*)bias; p.N = N; p.D = D; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
   const long long waves = (long long)N * D * H * ((W + 15) / 16);
-  dim3 grid((unsigned)((waves + 3) / 4), Cout / 32);
-  if (nd == 3) hipLaunchKernelGGL((x2_convT_kernel<3>), grid, dim3(256), 0, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL((x2_convT_kernel<2>), grid, dim3(256), 0, (hipStream_t)stream, p);
+  const int kc = iunet_x2_convT_kc(Cin), nchunks = Cin / 32 / kc, npos = nd == 3 ? 8 : 4;
+  const int chb = 2 * kc * npos * 2 * 1024, lds = (nchunks == 1 ? 1 : 2) * chb;
+  int gx = (int)((waves + 7) / 8);
+  const int per_cu = lds <= 80 * 1024 ? 2 : 1;
+  const int cap = per_cu * 256 / (Cout / 32) > 1 ? per_cu * 256 / (Cout / 32) : 1;
+  if (gx > cap) gx = cap;
+  dim3 grid(gx, Cout / 32);
+#define X2CT(NDV, KCV) do { IUNET_SET_MAX_LDS((x2_convT_lds_kernel<NDV, KCV>), lds); \
+    hipLaunchKernelGGL((x2_convT_lds_kernel<NDV, KCV>), grid, dim3(256), lds, (hipStream_t)stream, p); } while (0)
+  if (nd == 3) { if (kc == 2) X2CT(3, 2); else X2CT(3, 1); } else { if (kc == 2) X2CT(2, 2); else X2CT(2, 1); }
+#undef X2CT
   IUNET_CHECK_HIP(hipGetLastError());
   return IUNET_OK;
 }

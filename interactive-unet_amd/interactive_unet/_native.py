@@ -48,7 +48,7 @@ _SIGS = {
     'iunet_f32_head_fwd': [c_void_p, c_ll, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                            ctypes.POINTER(c_ll), c_float, c_int, c_int, c_int, c_int, c_int, c_void_p],
     # ---- fp16x2 split precision (the tolerance-meeting mode on the 16-bit matrix cores)
-    'iunet_x2_prep': [c_void_p] * 9 + [c_float, c_float, c_float, c_int, c_int, c_int, c_int, c_void_p],
+    'iunet_x2_prep': [c_void_p] * 9 + [c_float, c_float, c_float, c_int, c_int, c_int, c_int, c_int, c_void_p],
     'iunet_x2_first_conv_fwd': [c_int, c_void_p, c_int, ctypes.POINTER(c_ll), c_void_p, c_ll, c_int, c_void_p, c_void_p, c_void_p,
                                 c_float, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     'iunet_x2_conv3_fwd': [c_int, c_void_p, c_ll, c_int, c_void_p, c_ll, c_int, c_void_p, c_void_p, c_void_p,
@@ -133,7 +133,7 @@ _SIGS = {
 }
 # functions that return a size / count instead of a status
 _INT_RETURN = ['iunet_pack_desc_bytes', 'iunet_augment_desc_bytes']
-_INT_RETURN_ARGS = {'iunet_zoom_nearest_len': [c_int, ctypes.c_double]}
+_INT_RETURN_ARGS = {'iunet_zoom_nearest_len': [c_int, ctypes.c_double], 'iunet_x2_convT_kc': [c_int]}
 _LL_RETURN = {'iunet_conv3_wgrad_slab_floats': [c_int] * 7, 'iunet_f32_pack_conv_elems': [c_int] * 3, 'iunet_f8_pack_conv3_bytes': [c_int] * 3, 'iunet_conv3_f8_workspace_elems': [c_int] * 7, 'iunet_pack_conv3_elems': [c_int] * 4,
               'iunet_pack_first_conv_elems': [c_int] * 3, 'iunet_slice_scatter_workspace_bytes': [c_int]}
 

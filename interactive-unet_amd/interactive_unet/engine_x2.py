@@ -89,7 +89,7 @@ class EngineX2:
                 npk = lib.iunet_pack_first_conv_elems(b, 3 * a, self.taps) if first else nv.pack_conv3_elems(b, 3 * a, self.taps, 2)
                 wv, dst, osc, bias = bufs(name, b * 3 * a * self.taps, npk, b)
                 nv.call('iunet_x2_prep', nv.ptr(w), nv.ptr(wv), nv.ptr(osc), nv.ptr(bias), nv.ptr(bn[0]), nv.ptr(bn[1]),
-                        nv.ptr(bn[2]), nv.ptr(bn[3]), None, BN_EPS, A, A, b, a, self.taps, 0, s)
+                        nv.ptr(bn[2]), nv.ptr(bn[3]), None, BN_EPS, A, A, b, a, self.taps, 0, a if first else (16 if self.dim == 3 else 32), s)
                 if first:
                     nv.call('iunet_pack_first_conv', 0, nv.ptr(wv), None, nv.ptr(dst), b, 3 * a, self.taps, s)
                 else:
@@ -99,10 +99,10 @@ class EngineX2:
             name = f'dec{l}.up'
             w, b0 = self._source(params, f'{name}.weight'), self._source(params, f'{name}.bias')
             ci, co = self.ch[l + 1], self.ch[l]
-            wv, dst, osc, bias = bufs(name, 3 * ci * co * self.npos, 3 * ci * co * self.npos, co)
+            wv, dst, osc, bias = bufs(name, 2 * ci * co * self.npos, 2 * ci * co * self.npos, co)
             nv.call('iunet_x2_prep', nv.ptr(w), nv.ptr(wv), nv.ptr(osc), nv.ptr(bias), None, None, None, None, nv.ptr(b0),
-                    BN_EPS, A, A, co, ci, self.npos, 1, s)
-            nv.call('iunet_pack_convT', 0, nv.ptr(wv), nv.ptr(dst), 3 * ci, co, self.npos, s)
+                    BN_EPS, A, A, co, ci, self.npos, 2, 0, s)         # both words once, chunked for the LDS-resident kernel
+            nv.call('iunet_pack_convT', 0, nv.ptr(wv), nv.ptr(dst), 2 * ci, co, self.npos, s)
             P[name] = (dst, osc, bias)
         P['head'] = (self._source(params, 'head.weight').reshape(self.ncls, self.ch[0]), self._source(params, 'head.bias'))
         self.packed = P

@@ -39,15 +39,16 @@ def _prep_conv(nv, w, bn=None, bias=None, transposed=False):
     else:
         co, ci = w.shape[:2]
     taps = int(np.prod(w.shape[2:]))
-    wv = torch.empty(3 * ci * co * taps, device=dev)
+    nparts = 2 if transposed else 3
+    wv = torch.empty(nparts * ci * co * taps, device=dev)
     osc, b = torch.empty(co, device=dev), torch.empty(co, device=dev)
     bnp = [None] * 4 if bn is None else [t.to(dev, torch.float32).contiguous() for t in bn]
     bi = None if bias is None else bias.to(dev, torch.float32).contiguous()
     nv.call('iunet_x2_prep', nv.ptr(w), nv.ptr(wv), nv.ptr(osc), nv.ptr(b), *[nv.ptr(t) for t in bnp], nv.ptr(bi),
-            1e-5, A, A, co, ci, taps, int(transposed), nv.stream())
+            1e-5, A, A, co, ci, taps, 2 if transposed else 0, 0 if transposed else (ci if ci <= 4 else 16 if taps == 27 else 32), nv.stream())
     if transposed:
-        dst = torch.empty(3 * ci * co * taps, dtype=torch.float16, device=dev)
-        nv.call('iunet_pack_convT', 0, nv.ptr(wv), nv.ptr(dst), 3 * ci, co, taps, nv.stream())
+        dst = torch.empty(2 * ci * co * taps, dtype=torch.float16, device=dev)
+        nv.call('iunet_pack_convT', 0, nv.ptr(wv), nv.ptr(dst), 2 * ci, co, taps, nv.stream())
     elif ci <= 4:
         dst = torch.empty(nv.lib().iunet_pack_first_conv_elems(co, 3 * ci, taps), dtype=torch.float16, device=dev)
         nv.call('iunet_pack_first_conv', 0, nv.ptr(wv), None, nv.ptr(dst), co, 3 * ci, taps, nv.stream())
@@ -128,11 +129,11 @@ def test_first_conv_x2(dim, shape, cin):
     assert err < 3e-6, err
 
 
-@pytest.mark.parametrize('dim,shape', [(3, (4, 6, 10)), (2, (10, 18))])
-def test_maxpool_convT_x2(dim, shape):
+@pytest.mark.parametrize('dim,shape,ci,co', [(3, (4, 6, 10), 64, 32), (2, (10, 18), 64, 32), (3, (2, 4, 20), 96, 64), (3, (4, 4, 8), 256, 128)])
+def test_maxpool_convT_x2(dim, shape, ci, co):
     nv, e = _nv(), _engine(dim)
     g = torch.Generator().manual_seed(3)
-    N, ci, co = 2, 64, 32
+    N = 2
     sp = (1,) + shape if dim == 2 else shape
     vox = int(np.prod(shape))
     x = torch.randn((N, ci) + shape, generator=g)
