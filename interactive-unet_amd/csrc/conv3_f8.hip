@@ -468,9 +468,12 @@ __global__ __launch_bounds__(256) void f8_splitk_reduce_kernel(const float* __re
 // Cin into `ksplit` shares, each its own workgroup: the chip fills, the loop shortens, the shares' filters fit in LDS.
 int iunet_conv3_f8_ksplit(int nd, int N, int D, int H, int W, int Cin, int Cout) {
   static const int forced = getenv("IUNET_F8_KSPLIT") ? atoi(getenv("IUNET_F8_KSPLIT")) : 0;
-  const long long tiles = nd == 3 ? (long long)N * ((D + 3) / 4) * ((H + 7) / 8) * ((W + 15) / 16)
-                                  : (long long)N * ((H + 15) / 16) * ((W + 31) / 32);
-  const long long tasks = tiles * (Cout / 32);                   // (tile, Cout tile) pairs: one workgroup each
+  // PER-SAMPLE tiles: the split changes the order of the fp32 sums, and a layer must keep one summation order whatever the number
+  // of blocks in a launch (predict.BLOCK_BATCH with a tail of 1, per-rank block runs: shard.py's byte identity across world sizes)
+  (void)N;
+  const long long tiles = nd == 3 ? (long long)((D + 3) / 4) * ((H + 7) / 8) * ((W + 15) / 16)
+                                  : (long long)((H + 15) / 16) * ((W + 31) / 32);
+  const long long tasks = tiles * (Cout / 32);                   // (tile, Cout tile) pairs of one sample: one workgroup each
   const int nchunk = Cin / (nd == 3 ? 16 : 32);
   // measured on C5's 16^3 level (tools/bench_conv.py --f8 1, IUNET_F8_KSPLIT sweep): two shares win from Cin = 512 on
   // (512 -> 512: 69 -> 56 us, 1024 -> 512: 130 -> 88 us); four are slower again (more partial sums than they save), and

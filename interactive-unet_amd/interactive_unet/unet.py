@@ -62,7 +62,8 @@ class UNet(nn.Module):
 
     def __init__(self, lr=0.0001, num_channels=1, num_classes=2, loss_function=metrics.mcc_ce_loss,
                  architecture='U-Net', encoder_name='mit_b0', pretrained=True,
-                 dim=2, levels=4, base=32, act_dtype=None, weight_dtype=None, norm='batch', groups=8, infer_dtype=None):
+                 dim=2, levels=4, base=32, act_dtype=None, weight_dtype=None, norm='batch', groups=8, infer_dtype=None,
+                 act_quant=None):
         super().__init__()
         if architecture != 'U-Net':
             raise NotImplementedError(f"architecture {architecture!r}: only 'U-Net' has a native MI355X "
@@ -75,7 +76,7 @@ class UNet(nn.Module):
                             dim=dim, levels=levels, base=base,
                             act_dtype=None if act_dtype is None else _ACT_NAME[_ACT[act_dtype]],
                             weight_dtype=weight_dtype, norm=norm, groups=groups,
-                            infer_dtype=None if infer_dtype is None else _ACT_NAME[_ACT[infer_dtype]])
+                            infer_dtype=None if infer_dtype is None else _ACT_NAME[_ACT[infer_dtype]], act_quant=act_quant)
         self.lr = lr
         self.loss_function = loss_function
         self.dim, self.levels, self.base = dim, levels, base
@@ -90,8 +91,10 @@ class UNet(nn.Module):
         else:
             self.infer_dtype = self.act_dtype
         # 'fp8_e4m3' (BASELINE config C5): inference runs on weights quantised to OCP e4m3 with per-output-channel
-        # power-of-two scales (after the BatchNorm fold); training keeps fp32 masters and 16-bit operators
-        self.weight_dtype = weight_dtype
+        # power-of-two scales (after the BatchNorm fold); training keeps fp32 masters and 16-bit operators.  act_quant (default
+        # True = W8A8): the stage convs run on the fp8 matrix cores, which also rounds their ACTIVATIONS to e4m3; False = W8A16,
+        # e4m3-valued operators on the 16-bit matrix cores with unquantised activations (engine.Engine has the numbers)
+        self.weight_dtype, self.act_quant = weight_dtype, act_quant
         # norm='group': GroupNorm(groups) instead of BatchNorm after every stage conv (north_star "GroupNorm/BN"); the
         # bn{j}.weight / .bias parameters are its affine pair, the running statistics are unused
         if norm not in ('batch', 'group'):
@@ -173,7 +176,7 @@ class UNet(nn.Module):
                     eng = EngineF32(self.dim, self.levels, self.base, self.num_channels, self.num_classes, dev)
             else:
                 eng = Engine(self.dim, self.levels, self.base, self.num_channels, self.num_classes, self.infer_dtype, dev,
-                             weight_dtype=self.weight_dtype, norm=self.norm, groups=self.groups)
+                             weight_dtype=self.weight_dtype, norm=self.norm, groups=self.groups, act_quant=self.act_quant)
             self._engines = {dev: eng}
             self._packed_sig = None
         sig = self._signature()

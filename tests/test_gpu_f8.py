@@ -225,3 +225,72 @@ def test_c5_network_on_fp8_matrix_cores():
     r = _f8_net_case(3, 5, 64, 4, (32, 32, 48), seed=6)
     assert r['mean'] <= 2e-2 and r['max'] <= 0.3 and r['agree'] >= 0.93, r
     assert r['dev_vs_f32'] <= 1.3 * r['emu_vs_f32'], r
+
+
+def test_weights_only_mode_w8a16():
+    """UNet(weight_dtype='fp8_e4m3', act_quant=False): BASELINE C5's literal "fp8 weights / bf16 activations" -- e4m3-valued
+    operators (per-channel power-of-two scales) on the 16-bit matrix cores, activations NOT quantised.  Checker: the oracle
+    with quantised weights only."""
+    import warnings
+    from interactive_unet.unet import UNet
+    from interactive_unet.engine import F8Conv
+    from scipy import ndimage
+    dim, levels, base, ncls, shape = 3, 2, 32, 3, (16, 32, 48)
+    p = unet_ref.init_params(dim=dim, levels=levels, base=base, ncls=ncls, seed=7, randomize_bn=True)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        m = UNet(num_classes=ncls, dim=dim, levels=levels, base=base, act_dtype='bf16', pretrained=False,
+                 weight_dtype='fp8_e4m3', act_quant=False)
+    m.load_named(p)
+    m = m.cuda().eval()
+    assert not isinstance(m.engine('eval').packed['dec0.conv1'][0], F8Conv)
+    rng = np.random.default_rng(5)
+    v = ndimage.gaussian_filter(rng.random(shape), 3)
+    x = torch.tensor(((v - v.min()) / (v.max() - v.min()) * 255).astype(np.uint8))[None, None]
+    probs = m(x.cuda()).cpu()
+    xf = x.float() / 255.0
+    kw = dict(dim=dim, levels=levels, act_dtype=torch.bfloat16, weight_quant='fp8_e4m3')
+    ref_w = unet_ref.forward(p, xf, **kw)
+    ref_q = unet_ref.forward(p, xf, act_quant=True, **kw)
+    d = (probs - ref_w).abs()
+    print(f'W8A16: mean |dp| vs weights-only oracle {d.mean().item():.2e}, max {d.max().item():.2e}; vs W8A8 emulation {(probs - ref_q).abs().mean().item():.2e}')
+    assert d.mean().item() <= 1e-3 and d.max().item() <= 3e-2
+    assert d.mean().item() < (probs - ref_q).abs().mean().item()
+
+
+def test_c5_at_128_cubed_against_the_fp32_mode():
+    """BASELINE.json configs[4] at its full tile (one 128^3 chunk, 5 levels, base 64, 4 classes): the fp8 matrix-core forward
+    (W8A8) and the weights-only mode (W8A16) against the native fp32 mode with the UNQUANTISED operators -- the device-side
+    stand-in for the CPU oracle at a size it cannot finish in a test.  fp8 is not held to 1e-3: the figures are
+    printed; asserted are the bounds measured at 32 x 32 x 48 against the CPU (mean |dp| <= 2.5e-2, class map >= 90 %), and
+    that quantising the activations too costs accuracy in the expected direction."""
+    import warnings
+    from interactive_unet.unet import UNet
+    from interactive_unet.engine_f32 import EngineF32
+    dim, levels, base, ncls, S = 3, 5, 64, 4, 128
+    p = unet_ref.init_params(dim=dim, levels=levels, base=base, ncls=ncls, seed=6, randomize_bn=True)
+    g = torch.Generator(device='cuda').manual_seed(0)
+    x = torch.rand((1, 1, S // 4, S // 4, S // 4), generator=g, device='cuda')
+    x = torch.nn.functional.interpolate(x, size=(S, S, S), mode='trilinear', align_corners=False)
+    x = ((x - x.amin()) / (x.amax() - x.amin()) * 254 + 1).to(torch.uint8)
+    vox = S ** 3
+    e32 = EngineF32(dim, levels, base, 1, ncls, 'cuda')
+    e32.load_eval({k: v.cuda() for k, v in p.items()})
+    ref = torch.empty((1, ncls, S, S, S), device='cuda')
+    e32.infer(x, (vox, vox, S * S, S, 1), 1, S, S, S, probs=ref)
+    del e32
+    res = {}
+    for name, aq in (('W8A8', True), ('W8A16', False)):
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            m = UNet(num_classes=ncls, dim=dim, levels=levels, base=base, act_dtype='bf16', pretrained=False,
+                     weight_dtype='fp8_e4m3', act_quant=aq)
+        m.load_named(p)
+        probs = m.cuda().eval()(x)
+        d = (probs - ref).abs()
+        res[name] = (d.mean().item(), d.max().item(), (probs.argmax(1) == ref.argmax(1)).float().mean().item())
+        print(f'C5 @ 128^3 {name} vs fp32 mode: mean |dp| = {res[name][0]:.2e}, max = {res[name][1]:.2e}, class map equal on {100 * res[name][2]:.2f} %')
+        del m
+        torch.cuda.empty_cache()
+    assert res['W8A8'][0] <= 2.5e-2 and res['W8A8'][2] >= 0.90, res
+    assert res['W8A16'][0] <= res['W8A8'][0], res

@@ -52,12 +52,13 @@ class ThreadComm:
         return []
 
 
-def _model(dim, C, seed=3):
+def _model(dim, C, seed=3, **kw):
     from interactive_unet.unet import UNet
+    kw = dict(kw) or {'act_dtype': 'fp16'}
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
-        m = UNet(num_classes=C, dim=dim, act_dtype='fp16', pretrained=False)
-    m.load_named(unet_ref.init_params(dim=dim, ncls=C, seed=seed, randomize_bn=True))
+        m = UNet(num_classes=C, dim=dim, pretrained=False, **kw)
+    m.load_named(unet_ref.init_params(dim=dim, ncls=C, seed=seed, randomize_bn=True, levels=kw.get('levels', 4), base=kw.get('base', 32)))
     return m.cuda().eval()
 
 
@@ -68,16 +69,22 @@ def _volume(shape, seed):
     return (255 * (v - v.min()) / (v.max() - v.min())).astype(np.uint8)
 
 
-@pytest.mark.parametrize('dim,world,V,rounds', [(3, 3, (100, 56, 72), 4), (3, 4, (72, 40, 40), 8), (2, 2, (56, 40, 72), 3)])
-def test_virtual_ranks_byte_identical_to_single_rank(dim, world, V, rounds):
+@pytest.mark.parametrize('dim,world,V,rounds,kw', [
+    (3, 3, (100, 56, 72), 4, {}), (3, 4, (72, 40, 40), 8, {}), (2, 2, (56, 40, 72), 3, {}),
+    (3, 2, (72, 40, 40), 4, {'act_dtype': 'fp16x2'}),                  # the default prediction mode (split precision)
+    # config C5's numerics: e4m3 operators on the fp8 matrix cores, 5 levels, base 64 -- the 512- and 1024-channel layers take the
+    # split-K path, whose share count must not depend on how many blocks a launch holds
+    (3, 2, (72, 40, 40), 4, {'act_dtype': 'bf16', 'weight_dtype': 'fp8_e4m3', 'levels': 5, 'base': 64}),
+])
+def test_virtual_ranks_byte_identical_to_single_rank(dim, world, V, rounds, kw):
     from interactive_unet import predict, shard
     S, C = 32, 2
     vol = torch.tensor(_volume(V, 31)).cuda()
-    want = predict.predict_volume_array(_model(dim, C), vol, input_size=S, num_classes=C).cpu().numpy()
+    want = predict.predict_volume_array(_model(dim, C, **kw), vol, input_size=S, num_classes=C).cpu().numpy()
     bounds, _ = shard.slab_bounds(V[0], world)
     shared = _Shared(world)
     # one model (engine + workspace) per virtual rank: the ranks' launches interleave on the stream
-    opss = [shard.NativeOps(_model(dim, C), C, S) for _ in range(world)]
+    opss = [shard.NativeOps(_model(dim, C, **kw), C, S) for _ in range(world)]
     res, errs = [None] * world, []
 
     def run(r):
