@@ -539,6 +539,7 @@ class TrainEngine:
     def train_step(self, X, y, w=None, sync=True):
         """One optimisation step (unet.py:88-102 + backward + AdamW).  X [N,C,*sp], y / w
         [N,ncls,*sp] (fp16 or fp32, the loader's contract loader.py:142-154)."""
+        self.sync_weights()
         X, y, w, N, D, H, W, vox, xs = self._prep(X, y, w)
         ws = self.forward_train(X, xs, N, D, H, W)
         if self.head_act:
@@ -552,10 +553,63 @@ class TrainEngine:
             return {'Loss': o[0], 'Dice': o[1], 'IoU': o[2], 'MCC': o[3]}
         return ws['out4']
 
+    def _eval_engine(self):
+        """The folded-BatchNorm forward in the TRAINING dtype (its features feed the fused head + loss kernel): the module's own
+        engine when it predicts in that dtype, else (the default module predicts in split precision) one kept here."""
+        m = self.model
+        if m.infer_dtype == self.T:
+            return m.engine('eval')
+        if getattr(self, '_eval_eng', None) is None:
+            from .engine import Engine
+            self._eval_eng = Engine(self.dim, self.levels, m.base, self.cin, self.ncls, self.T, self.dev, norm=self.norm,
+                                    groups=self.groups)
+        self._eval_eng.load_eval(m.named_tensors())              # one launch over a cached descriptor table
+        return self._eval_eng
+
+    def sync_weights(self):
+        """Re-pack the operators when something other than optimizer_step changed the parameters (an external optimiser stepping
+        the module's parameters -- UNet.configure_optimizers -- or load_state_dict): torch's version counters tell."""
+        ver = sum(self.p(n)._version for n in self.names)
+        if ver != getattr(self, '_seen_version', None):
+            if getattr(self, '_seen_version', None) is not None:
+                self.repack()
+                self.model._packed_sig = None
+            self._seen_version = ver
+
+    def step_forward(self, X, y, w=None):
+        """Forward half of a training step (unet.py:88-102): -> (out4 = [Loss, Dice, IoU, MCC] device tensor, state for
+        step_backward).  UNet.training_step wraps the pair in an autograd function."""
+        self.sync_weights()
+        X, y, w, N, D, H, W, vox, xs = self._prep(X, y, w)
+        ws = self.forward_train(X, xs, N, D, H, W)
+        if self.head_act:
+            tdt, w = self.loss_forward(ws, ws['y.dec0.conv2'], y, w, N, vox, act='dec0.conv2')
+        else:
+            tdt, w = self.loss_forward(ws, ws['z.dec0.conv2'], y, w, N, vox)
+        return ws['out4'], (ws, X, xs, y, w, tdt, N)
+
+    def step_backward(self, state):
+        """Backward half: the flat fp32 gradient of loss_scale x loss in self.grad (all-reduced over the process group, if any).
+        -> (flat gradient of the loss itself as a new tensor, finite?).  fp16: a non-finite gradient halves the loss scale
+        (GradScaler's back-off) and comes back as zeros."""
+        ws, X, xs, y, w, tdt, N = state
+        self.backward(ws, X, xs, y, w, tdt, N)
+        world = self.buckets.finish() if self.pg is not None else 1
+        g = self.grad * (1.0 / (self.loss_scale * world))
+        ok = True
+        if self.T == torch.float16:
+            ok = bool(torch.isfinite(g).all().item())
+            if not ok:
+                if self.dynamic_scale:
+                    self.loss_scale = max(self.loss_scale * 0.5, 1.0)
+                g.zero_()
+        return g, ok
+
     def eval_step(self, X, y, w=None):
         """validation_step (unet.py:104-116): eval-mode BatchNorm (running statistics)."""
+        self.sync_weights()
         X, y, w, N, D, H, W, vox, xs = self._prep(X, y, w)
-        eng = self.model.engine('eval')
+        eng = self._eval_engine()
         feat = eng.infer(X, xs, N, D, H, W, features_only=True)
         ws = self.workspace(N, D, H, W)
         self.loss_forward(ws, feat, y, w, N, vox)

@@ -57,6 +57,31 @@ def _is_buffer(name):
     return name.endswith('running_mean') or name.endswith('running_var')
 
 
+class _NativeStep(torch.autograd.Function):
+    """One native training step as an autograd node: forward = TrainEngine.step_forward (forward with batch statistics + fused
+    head / softmax / loss), backward = TrainEngine.step_backward; the parameters are inputs so that `loss.backward()` leaves
+    their gradients in `.grad` exactly as torch autograd would."""
+
+    @staticmethod
+    def forward(ctx, te, X, y, w, *params):
+        out4, state = te.step_forward(X, y, w)
+        ctx.te, ctx.state = te, state
+        out4 = out4.clone()
+        ctx.mark_non_differentiable(out4)
+        return out4[0].clone(), out4
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_metrics):
+        te = ctx.te
+        flat, _ok = te.step_backward(ctx.state)
+        flat = flat * g_loss
+        grads = []
+        for n in te.names:
+            off, sz = te.offsets[n]
+            grads.append(flat[off:off + sz].view(te.p(n).shape))
+        return (None, None, None, None) + tuple(grads)
+
+
 class UNet(nn.Module):
     """The UNet model (native MI355X path)."""
 
@@ -112,6 +137,7 @@ class UNet(nn.Module):
         self.reset_parameters()
         self._engines = {}
         self._packed_sig = None
+        self.logged_metrics = {}
 
     # ---- parameters ---------------------------------------------------------------------
     def reset_parameters(self, seed=None):
@@ -203,8 +229,53 @@ class UNet(nn.Module):
 
     # ---- optimiser / steps (unet.py:71-116) -------------------------------------------------
     def configure_optimizers(self):
-        raise NotImplementedError('the native path steps AdamW inside train_engine.TrainEngine (fused flat AdamW with the '
-                                  'torch defaults of unet.py:71-73); trainer.train_model drives it')
+        """unet.py:71-73: `torch.optim.AdamW(self.parameters(), lr=self.lr)` (torch defaults: betas (0.9, 0.999), eps 1e-8,
+        weight_decay 1e-2).  It steps the module's parameters in place; the native engine re-packs its operators when it sees
+        their version counters move.  (trainer.train_model uses the fused flat AdamW of train_engine.TrainEngine instead: the
+        same update in one launch.)"""
+        return torch.optim.AdamW(self.parameters(), lr=self.lr)
+
+    def train_engine(self):
+        """The native training engine bound to this module (created on first use: it re-homes the parameters in one flat tensor)."""
+        te = getattr(self, '_train_engine', None)
+        if te is None or te.dev != self.device:
+            from .train_engine import TrainEngine
+            lk = getattr(self.loss_function, 'native_kind', None)
+            if lk is None:
+                raise NotImplementedError(f'loss_function {self.loss_function!r} has no native kernel: use one of metrics.py\'s seven')
+            te = TrainEngine(self, lr=self.lr, loss_kind=lk)
+            object.__setattr__(self, '_train_engine', te)
+        return te
+
+    def log(self, name, value, **kwargs):
+        """Lightning's self.log (unet.py:83-86) without Lightning: the last value per name, kept as device tensors (no sync)."""
+        self.logged_metrics[name] = value
+
+    def _log_metrics(self, set_name, out4):
+        # unet.py:75-86: Loss + Dice / IoU / MCC on the ROUNDED tensors -- the fused head + loss kernel computes all four
+        for i, k in enumerate(('Loss', 'Dice', 'IoU', 'MCC')):
+            self.log(f'{set_name}/{k}', out4[i], on_step=False, on_epoch=True)
+
+    def training_step(self, batch, batch_idx=None):
+        """unet.py:88-102: X, y, w = batch; y_hat = self(X) with BatchNorm batch statistics; loss = loss_function(y_hat, y, w,
+        axes=[0, 2, 3]); metrics logged.  Returns the loss as a tensor whose `.backward()` runs the native backward pass and
+        leaves the gradients in the parameters' `.grad` (so `configure_optimizers()`' AdamW, or any torch optimiser, steps them)."""
+        X, y, w = batch
+        te = self.train_engine()
+        params = [te.p(n) for n in te.names]
+        loss, out4 = _NativeStep.apply(te, X, y, w, *params)
+        self._log_metrics('train', out4)
+        return loss
+
+    def validation_step(self, batch, batch_idx=None):
+        """unet.py:104-116: the same with eval-mode BatchNorm (running statistics), no gradient."""
+        X, y, w = batch
+        te = self.train_engine()
+        with torch.no_grad():
+            row = te.eval_step(X, y, w)
+        out4 = torch.tensor([row[k] for k in ('Loss', 'Dice', 'IoU', 'MCC')], device=self.device)
+        self._log_metrics('val', out4)
+        return out4[0]
 
     # ---- checkpoints (trainer.py:30-49, predict.py:22-24) -----------------------------------
     def save_checkpoint(self, path):

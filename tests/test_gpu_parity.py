@@ -217,4 +217,4 @@ def test_unet_module_fp32_mode_matches_oracle_probabilities():
     assert m.hparams['act_dtype'] == 'fp32'
     from interactive_unet.train_engine import TrainEngine
     with pytest.raises(NotImplementedError):
-        TrainEngine(m)
+        TrainEngine(m)                                   # an explicit act_dtype='fp32' module is inference-only

@@ -1,0 +1,88 @@
+"""UNet.training_step / validation_step / configure_optimizers (unet.py:71-116) on the native path: the Lightning-shaped loop
+`loss = model.training_step(batch); loss.backward(); optimizer.step()` drives the same kernels as trainer.train_model's fused step."""
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import metrics_ref, unet_ref
+
+
+def _model(seed=1, **kw):
+    from interactive_unet.unet import UNet
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        m = UNet(lr=1e-3, num_classes=2, pretrained=False, **kw)
+    m.load_named(unet_ref.init_params(dim=2, ncls=2, seed=seed))
+    return m.cuda()
+
+
+def _batch(seed=0, N=2, shape=(32, 48)):
+    rng = np.random.default_rng(seed)
+    X = torch.tensor(rng.random((N, 1) + shape, dtype=np.float32))
+    lab = X[:, 0] > 0.5
+    y = torch.stack([~lab, lab], 1).float()
+    w = torch.tensor((rng.random((N, 1) + shape) > 0.2).astype(np.float32)).expand(N, 2, *shape).contiguous()
+    return X, y * w, w
+
+
+def test_lightning_shaped_loop_matches_the_fused_step():
+    """Two steps of {training_step -> backward -> torch AdamW from configure_optimizers} leave the parameters where two fused
+    TrainEngine.train_step calls leave a twin module (same kernels for forward / backward; AdamW by torch vs the flat kernel)."""
+    from interactive_unet.train_engine import TrainEngine
+    a, b = _model(act_dtype='bf16'), _model(act_dtype='bf16')
+    opt = a.configure_optimizers()
+    assert isinstance(opt, torch.optim.AdamW) and opt.defaults['lr'] == a.lr and opt.defaults['weight_decay'] == 1e-2
+    te_b = TrainEngine(b, lr=b.lr, loss_kind='mcc_ce')
+    for step in range(2):
+        batch = _batch(step)
+        opt.zero_grad()
+        loss = a.training_step(batch)
+        assert loss.requires_grad and loss.dim() == 0
+        loss.backward()
+        gflat = torch.cat([a.tensor(n).grad.reshape(-1) for n in a.train_engine().names])
+        opt.step()
+        row = te_b.train_step(*batch)
+        assert abs(loss.item() - row['Loss']) <= 1e-6 * max(1.0, abs(row['Loss'])), (loss.item(), row)
+        gb = te_b.grad / te_b.loss_scale
+        if step == 0:
+            assert torch.equal(gflat, gb), 'same kernels on the same weights: the same gradient bits'
+        else:                                   # the two AdamW implementations left the weights an ulp apart
+            assert (gflat - gb).norm() <= 1e-2 * gb.norm()
+        for k in ('Dice', 'IoU', 'MCC'):
+            assert abs(float(a.logged_metrics[f'train/{k}']) - row[k]) < 1e-6
+    for n in a.train_engine().names:
+        pa, pb = a.tensor(n).detach(), b.tensor(n).detach()
+        assert (pa - pb).abs().max().item() <= 2e-6 * max(1.0, pb.abs().max().item()), n
+    # validation_step: eval-mode BatchNorm, same loss as the engine's eval_step, no gradient
+    vb = _batch(7)
+    v = a.validation_step(vb)
+    assert not v.requires_grad
+    assert abs(v.item() - a.train_engine().eval_step(*vb)['Loss']) < 1e-6
+    assert 'val/Loss' in a.logged_metrics and 'val/MCC' in a.logged_metrics
+
+
+def test_default_module_trains_16_bit_and_predicts_in_split_precision():
+    """UNet() as the reference builds it: training_step runs (fp16 activations, dynamic loss scale), the loss tracks the oracle's
+    forward in the same rounding, and forward() afterwards answers from the fp16x2 engine with the UPDATED weights."""
+    from interactive_unet.engine_x2 import EngineX2
+    m = _model(seed=2)
+    opt = m.configure_optimizers()
+    batch = _batch(3)
+    p0 = {k: v.detach().cpu().clone() for k, v in m.named_tensors().items()}
+    loss = m.training_step(batch)
+    want = metrics_ref.loss('mcc_ce', unet_ref.forward(p0, batch[0], dim=2, training=True, act_dtype=torch.float16).detach().numpy(),
+                            batch[1].numpy(), batch[2].numpy(), axes=(0, 2, 3))
+    assert abs(loss.item() - want) < 5e-3
+    loss.backward()
+    opt.step()
+    m.eval()
+    assert isinstance(m.engine('eval'), EngineX2)
+    probs = m(batch[0].cuda()).cpu()
+    p1 = {k: v.detach().cpu() for k, v in m.named_tensors().items()}
+    assert (p1['enc0.conv1.weight'] - p0['enc0.conv1.weight']).abs().max() > 0
+    ref = unet_ref.forward(p1, batch[0], dim=2)
+    assert (probs - ref).abs().max().item() <= 1e-5
