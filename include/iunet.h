@@ -85,10 +85,6 @@ int iunet_conv3_fwd_act(int dtype, int nd, const void* x, long long x_sstride, v
 int iunet_conv3_num_tiles(int nd, int N, int D, int H, int W);
 /* rows of partial sums a conv3_fwd launch writes: one per tile (layouts 0, 1) or one per workgroup (layout 2) */
 int iunet_conv3_stats_parts(int nd, int N, int D, int H, int W, int Cout, int layout);
-/* profiling only: ablation variants of the bf16 3-D Cout = 32 conv (mask bits: 1 no weight loads, 2 no LDS reads,
- * 4 no staging, 8 no stores); results are meaningless except for mask 0. */
-int iunet_dbg_conv3_ablate(int exp, const void* x, void* y, const void* wpk, const void* bias, int N, int D, int H, int W,
-                           int Cin, int Cout, void* stream);
 /* first conv reads the caller's tensor directly: in_dtype 0 f32, 1 f16, 2 u8 (x/255,
  * predict.py:30), 3 bf16; in_strides = element strides (n, c, d, h, w).  stats (optional): partial BatchNorm
  * sums [iunet_conv3_num_tiles][Cout][2], as for iunet_conv3_fwd. */
@@ -170,6 +166,35 @@ int iunet_x2_convT_fwd(int nd, const void* x, long long x_ss, int x_lo, void* y,
 int iunet_x2_head_fwd(const void* x, long long x_ss, int x_lo, int C0, const void* w, const void* bias, float act_scale, int ncls,
                       void* logits, void* probs, void* cls, const long long* out_strides, float divisor, int accumulate, int N, int D,
                       int H, int W, void* stream);
+
+/* ---- handle level: the whole forward as one call (csrc/net.hip) ---------------------------------------------------------
+ * For a caller that is not Python: the launch graph interactive_unet/engine.py / engine_x2.py sequence (unet.py:65-69 over the
+ * canonical network) sequenced in C++.  The handle is host memory; every device buffer is the caller's.
+ *   iunet_net* net; iunet_net_create(2, 4, 32, 1, 2, 2, 0.f, &net);             // 2-D, 4 levels, base 32, 1 -> 2 classes, fp16x2
+ *   flat = device floats [iunet_net_num_params(net)] filled tensor by tensor (iunet_net_param gives name / offset / count)
+ *   packed = device bytes [iunet_net_packed_bytes(net)];  iunet_net_load(net, flat, packed, stream);
+ *   ws = device bytes [iunet_net_workspace_bytes(net, N, 1, H, W)];  iunet_net_forward_argmax(net, x_u8, cls_u8, N, 1, H, W, ws, stream);
+ * mode: 0 fp16, 1 bf16 (16-bit activations), 2 fp16x2 (split precision: logits within 1e-3 of the fp32 predict); act_scale: a
+ * power of two, mode 2 only (0 = default 64). */
+typedef struct iunet_net iunet_net;
+int iunet_net_create(int dim, int levels, int base, int cin, int ncls, int mode, float act_scale, iunet_net** out);
+void iunet_net_destroy(iunet_net* net);
+/* the flat fp32 parameter vector: trainable tensors and BatchNorm running statistics in the canonical order (the state_dict keys of
+ * interactive_unet/unet.py: enc{l}.conv{j}.weight [Cout][Cin][3^d], enc{l}.bn{j}.{weight,bias,running_mean,running_var},
+ * dec{l}.up.weight [Cin][Cout][2^d], dec{l}.up.bias, ..., head.weight [ncls][base], head.bias) */
+long long iunet_net_num_params(const iunet_net* net);
+int iunet_net_num_tensors(const iunet_net* net);
+int iunet_net_param(const iunet_net* net, int index, char* name, int name_cap, long long* offset, long long* numel);
+long long iunet_net_packed_bytes(const iunet_net* net);
+/* fold eval-mode BatchNorm, scale / split (mode 2), reorder: flat_params -> packed; both stay the caller's and must outlive the forwards */
+int iunet_net_load(iunet_net* net, const void* flat_params, void* packed, void* stream);
+long long iunet_net_workspace_bytes(const iunet_net* net, int N, int D, int H, int W);      /* 0 = bad shape */
+/* x: the caller's tensor (in_dtype 0 f32, 1 f16, 2 u8 / 255, 3 bf16; element strides n, c, d, h, w) -> logits / probs (fp32, element
+ * strides out_strides; probs = ((accumulate ? probs : 0) + p) / divisor, predict.py:101-110) and / or cls uint8 [N][D*H*W] */
+int iunet_net_forward(iunet_net* net, const void* x, int in_dtype, const long long* in_strides, int N, int D, int H, int W, void* workspace,
+                      void* logits, void* probs, void* cls, const long long* out_strides, float divisor, int accumulate, void* stream);
+/* predict.py:30-38: uint8 [N][cin][D][H][W] -> class map uint8 [N][D*H*W] */
+int iunet_net_forward_argmax(iunet_net* net, const void* x_u8, void* cls_u8, int N, int D, int H, int W, void* workspace, void* stream);
 
 /* ---- fp8 matrix cores: BASELINE config C5 ("fp8 weights / bf16 activations on CDNA4 fp8 MFMA") ------------------------
  * The stage convolutions of the forward pass (unet.py:65-69 over the canonical network) with the operator stored as OCP

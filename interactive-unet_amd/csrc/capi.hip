@@ -25,8 +25,6 @@ int iunet_conv3_v4_stats_parts(int nd, int Cout);
 int iunet_conv3_v4_pairs(int nd, int N, int D, int H, int W, int Cin, int Cout, int bw);
 int iunet_conv3_tiles(int nd, int N, int D, int H, int W);
 long long iunet_pack_conv3_size(int Cout, int Cin, int taps, int mode);
-int iunet_conv3_exp_launch(int exp, const void* x, void* y, const void* wpk, const float* bias, int N, int D, int H, int W,
-                           int Cin, int Cout, hipStream_t stream);
 int iunet_pack_conv3_launch(int dtype, const float* w, const float* scale, void* dst, int Cout, int Cin, int taps,
                             int mode, hipStream_t stream);
 int iunet_first_conv_launch(int dtype, int nd, const void* x, int in_dtype, long long sN, long long sC, long long sD,
@@ -165,12 +163,6 @@ int iunet_conv3_dgrad_bnstats(int dtype, int nd, const void* dy, long long dy_ss
   const float* par[4] = {(const float*)mean, (const float*)invstd, (const float*)scale, (const float*)shift};
   return iunet_conv3_launch(dtype, nd, dy, dy_sstride, dz, dz_sstride, wpk, nullptr, (float*)stats, N, D, H, W, Cin, Cout, 0, 2,
                             (hipStream_t)stream, nullptr, nullptr, yp, yp_sstride, par);
-}
-
-/* profiling only: ablation builds of the 3-D Cout=32 bf16 conv (not part of the product path) */
-int iunet_dbg_conv3_ablate(int exp, const void* x, void* y, const void* wpk, const void* bias, int N, int D, int H, int W,
-                           int Cin, int Cout, void* stream) {
-  return iunet_conv3_exp_launch(exp, x, y, wpk, (const float*)bias, N, D, H, W, Cin, Cout, (hipStream_t)stream);
 }
 
 int iunet_first_conv_fwd(int dtype, int nd, const void* x, int in_dtype, const long long* in_strides, void* y,

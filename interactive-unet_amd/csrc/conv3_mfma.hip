@@ -387,24 +387,6 @@ int iunet_conv3_launch(int dtype, int nd, const void* x, long long x_sstride, vo
 #undef IUNET_DISPATCH
 }
 
-// profiling-only entry: bf16, 3-D, Cout = 32 tile with ablation switches (see EXP above)
-int iunet_conv3_exp_launch(int exp, const void* x, void* y, const void* wpk, const float* bias, int N, int D, int H, int W,
-                           int Cin, int Cout, hipStream_t stream) {
-  Conv3Params p;
-  p.x = x; p.x_sstride = (long long)Cin * D * H * W; p.y = y; p.y_sstride = (long long)Cout * D * H * W; p.wpk = wpk;
-  p.bias = bias; p.stats = nullptr; p.N = N; p.D = D; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.epi = 2;
-  p.tilesZ = (D + 3) / 4; p.tilesY = (H + 7) / 8; p.tilesX = (W + 15) / 16;
-  constexpr int LDS = 4 * 17408;
-  dim3 grid(p.tilesZ * p.tilesY * p.tilesX * N, Cout / 32);
-#define IUNET_EXP_CASE(E) case E: { IUNET_SET_MAX_LDS((conv3_mfma_kernel<bf16, 3, 2, E>), LDS); \
-    hipLaunchKernelGGL((conv3_mfma_kernel<bf16, 3, 2, E>), grid, dim3(256), LDS, stream, p); } break;
-  switch (exp) { IUNET_EXP_CASE(0) IUNET_EXP_CASE(1) IUNET_EXP_CASE(2) IUNET_EXP_CASE(4) IUNET_EXP_CASE(8) IUNET_EXP_CASE(3) IUNET_EXP_CASE(7) IUNET_EXP_CASE(15)
-    default: iunet_set_error("conv3_exp: unsupported ablation mask %d", exp); return IUNET_ERR_ARG; }
-#undef IUNET_EXP_CASE
-  IUNET_CHECK_HIP(hipGetLastError());
-  return IUNET_OK;
-}
-
 int iunet_conv3_tiles(int nd, int N, int D, int H, int W) {
   const int TZ = nd == 3 ? 4 : 1, TY = nd == 3 ? 8 : 16, TX = nd == 3 ? 16 : 32;
   return N * ((D + TZ - 1) / TZ) * ((H + TY - 1) / TY) * ((W + TX - 1) / TX);

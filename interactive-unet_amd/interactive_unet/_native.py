@@ -21,7 +21,6 @@ _SIGS = {
     'iunet_abi_version': [],
     'iunet_conv3_num_tiles': [c_int] * 5,
     'iunet_conv3_stats_parts': [c_int] * 7,
-    'iunet_dbg_conv3_ablate': [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     'iunet_pack_conv3': [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     'iunet_pack_first_conv': [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     'iunet_pack_convT': [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
@@ -58,6 +57,14 @@ _SIGS = {
                            c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     'iunet_x2_head_fwd': [c_void_p, c_ll, c_int, c_int, c_void_p, c_void_p, c_float, c_int, c_void_p, c_void_p, c_void_p,
                           ctypes.POINTER(c_ll), c_float, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    # ---- handle level (csrc/net.hip): the whole forward sequenced in C++
+    'iunet_net_create': [c_int, c_int, c_int, c_int, c_int, c_int, c_float, ctypes.POINTER(c_void_p)],
+    'iunet_net_num_tensors': [c_void_p],
+    'iunet_net_param': [c_void_p, c_int, ctypes.c_char_p, c_int, ctypes.POINTER(c_ll), ctypes.POINTER(c_ll)],
+    'iunet_net_load': [c_void_p, c_void_p, c_void_p, c_void_p],
+    'iunet_net_forward': [c_void_p, c_void_p, c_int, ctypes.POINTER(c_ll), c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                          c_void_p, ctypes.POINTER(c_ll), c_float, c_int, c_void_p],
+    'iunet_net_forward_argmax': [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     # ---- fp8 matrix cores (config C5)
     'iunet_f8_pack_conv3': [c_void_p] * 5 + [c_float, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     'iunet_conv3_f8_fwd': [c_int, c_int, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_void_p, c_void_p,
@@ -135,7 +142,8 @@ _SIGS = {
 _INT_RETURN = ['iunet_pack_desc_bytes', 'iunet_augment_desc_bytes']
 _INT_RETURN_ARGS = {'iunet_zoom_nearest_len': [c_int, ctypes.c_double], 'iunet_x2_convT_kc': [c_int]}
 _LL_RETURN = {'iunet_conv3_wgrad_slab_floats': [c_int] * 7, 'iunet_f32_pack_conv_elems': [c_int] * 3, 'iunet_f8_pack_conv3_bytes': [c_int] * 3, 'iunet_conv3_f8_workspace_elems': [c_int] * 7, 'iunet_pack_conv3_elems': [c_int] * 4,
-              'iunet_pack_first_conv_elems': [c_int] * 3, 'iunet_slice_scatter_workspace_bytes': [c_int]}
+              'iunet_pack_first_conv_elems': [c_int] * 3, 'iunet_slice_scatter_workspace_bytes': [c_int],
+              'iunet_net_num_params': [c_void_p], 'iunet_net_packed_bytes': [c_void_p], 'iunet_net_workspace_bytes': [c_void_p] + [c_int] * 4}
 
 
 class NativeError(RuntimeError):
@@ -166,12 +174,13 @@ def lib():
             fn = getattr(l, name)
             fn.argtypes = args
             fn.restype = c_ll
+        l.iunet_net_destroy.argtypes, l.iunet_net_destroy.restype = [c_void_p], None
         _lib = l
     return _lib
 
 
 def exported_symbols():
-    return ['iunet_last_error'] + list(_SIGS) + list(_LL_RETURN) + list(_INT_RETURN) + list(_INT_RETURN_ARGS)
+    return ['iunet_last_error', 'iunet_net_destroy'] + list(_SIGS) + list(_LL_RETURN) + list(_INT_RETURN) + list(_INT_RETURN_ARGS)
 
 
 def check(status):
