@@ -9,14 +9,17 @@ Here:
 * compute          the flat (i, j, k) block list is cut into W contiguous runs (balanced to one block; a split by
                     block planes would cap 8 GPUs at 5.5x for an 11^3 grid); a rank runs the network on its blocks
                     and keeps their probabilities [S,S,S,C] in HBM;
-* input exchange   all-gather of the uint8 slabs (RCCL; 1 GiB total for 1024^3 -- a block run touches neighbouring
-                    slabs through overlap and reflect padding);
+* input exchange   every rank receives exactly the planes its block run touches (its z footprint: the clipped blocks'
+                    extent -- reflect padding mirrors inside a block's own range), point to point from their owners
+                    into one preallocated window: <= 3 of 11 block planes per rank at 1024^3 / 8 ranks instead of the
+                    whole volume;
 * output exchange  a block's probabilities are cut along z at the slab boundaries into PIECES (contiguous memory);
                     the pieces that fall in another rank's slab go to that owner point to point (xGMI is point to
                     point: each peer has its own link), in `rounds` grouped exchanges issued while the next blocks
-                    compute, so only the last round is exposed;
+                    compute, into slices of one preallocated pool;
 * blending         every owner blends the pieces of its slab -- its own and the received ones -- in FLAT BLOCK
-                    ORDER with the same kernel as the single-process path (pred += P * win, weight += win, each
+                    ORDER, as far as they have arrived after every round (a rank computes the tail of its run first:
+                    those pieces head the next owner's list), with the same kernel as the single-process path (pred += P * win, weight += win, each
                     operation separately rounded).  Every voxel therefore sees exactly the additions of the
                     one-process loop in exactly its order: the N-rank result is byte-identical to the 1-rank
                     result (tests/test_shard_cpu.py), which fp32 partial sums per rank cannot give.
@@ -105,8 +108,19 @@ class NativeOps:
             self._store = torch.empty((max(n, 1), S, S, S, C), dtype=torch.float32, device=self.device)
         return self._store
 
-    def new_piece(self, nz):
-        return torch.empty((nz, self.S, self.S, self.C), dtype=torch.float32, device=self.device)
+    def new_window(self, shape):
+        """uint8 planes of this rank's footprint (filled by the input exchange); cached."""
+        w = getattr(self, '_window', None)
+        if w is None or tuple(w.shape) != tuple(shape):
+            w = self._window = torch.empty(tuple(shape), dtype=torch.uint8, device=self.device)
+        return w
+
+    def recv_pool(self, nplanes):
+        """ONE fp32 buffer [nplanes, S, S, C] for every probability piece this rank receives (no allocation per piece); cached."""
+        p = getattr(self, '_pool', None)
+        if p is None or p.shape[0] < nplanes:
+            p = self._pool = torch.empty((max(nplanes, 1), self.S, self.S, self.C), dtype=torch.float32, device=self.device)
+        return p
 
     def forward_blocks(self, volume, padded, store, j0):
         """Probabilities of the blocks with padded coordinates `padded` into store[j0 : j0 + len(padded)]."""
@@ -168,12 +182,32 @@ class DistComm:
         return dist.batch_isend_irecv(ops) if ops else []
 
 
+def compute_order(run, pieces, rank):
+    """The order in which rank `rank` runs the blocks of its contiguous run [lo, hi): first the blocks with a piece in a HIGHER
+    rank's slab (the tail of the run: those pieces head that owner's flat-order blend list, so they must arrive first), then the
+    rest, each group ascending.  Forward results do not depend on the order; the BLEND order stays the flat one."""
+    lo, hi = run
+    tail = [b for b in range(lo, hi) if any(q > rank for q, _, _, _ in pieces[b])]
+    ts = set(tail)
+    return tail + [b for b in range(lo, hi) if b not in ts]
+
+
 def predict_volume_sharded(ops, my_slab, volume_shape, input_size, overlap=0.25, group=None, rounds=8, comm=None):
     """Whole-volume prediction across the ranks of `group` (or of `comm`, an object with DistComm's interface).
 
     my_slab: this rank's uint8 z-slab [h_r, Y, X] of the input (device of `ops`).
     Returns (uint8 [h_r, Y, X, C] result for the same slab, stats dict).  The result is byte-identical to the slab
-    of the single-process result whatever the number of ranks."""
+    of the single-process result whatever the number of ranks.
+
+    Multi-rank schedule (every rank derives the whole of it from the shapes alone):
+    * input: a rank needs the planes its block run touches (its z footprint: <= 3 block planes of 11 at 1024^3 / 8 ranks; reflect
+      padding mirrors inside a block's own clipped range) -- the owners send exactly those sub-slabs point to point into one
+      preallocated window [f1 - f0, Y, X]; the blocks are gathered from the window with z shifted by f0;
+    * rounds: `rounds` grouped exchanges of probability pieces, each issued behind the forwards that produce its pieces and in
+      flight while the next round computes; receive buffers are slices of ONE preallocated pool;
+    * blend: the owner walks its flat-order piece list as far as it has arrived after every round (own pieces: as soon as
+      their forward is enqueued; received ones: one round later, after that round's handles are waited for on the stream), so
+      what is left behind the last round is that round's pieces only."""
     comm = comm or DistComm(group)
     world, rank = comm.world, comm.rank
     V = tuple(int(v) for v in volume_shape)
@@ -189,48 +223,91 @@ def predict_volume_sharded(ops, my_slab, volume_shape, input_size, overlap=0.25,
         ops.predict_run(acc, my_slab, bc, pbc, lbc, lo, hi)
         return ops.finalize(acc), {'blocks': hi - lo, 'bytes_sent': 0, 'slab': (z0, z1), 'pieces_blended': hi - lo,
                                    'rounds': 0}
-    # ---- input exchange: all-gather the (padded) uint8 slabs ----
-    padded = torch.zeros((h,) + V[1:], dtype=torch.uint8, device=dev)
-    padded[:my_slab.shape[0]] = my_slab
-    parts = comm.all_gather(padded)
-    volume = torch.cat(parts, 0)[:V[0]].contiguous()
-    del parts
-    # ---- schedule (identical on every rank): local block t of every run belongs to round t // per_round ----
+    # ---- input exchange: every rank gets the planes of its footprint, nothing more ----
+    foot = [footprint(bc, a, b) for a, b in runs]
+    f0, f1 = foot[rank]
+    window = ops.new_window((max(f1 - f0, 1),) + V[1:])
+    sends, recvs, halo_recv = [], [], 0
+    for q in range(world):
+        a, b = max(z0, foot[q][0]), min(z1, foot[q][1])              # my planes that rank q needs
+        if b > a and q != rank:
+            sends.append((my_slab[a - z0:b - z0], q))
+        a, b = max(bounds[q][0], f0), min(bounds[q][1], f1)          # rank q's planes that I need
+        if b > a:
+            if q == rank:
+                window[a - f0:b - f0].copy_(my_slab[a - z0:b - z0])
+            else:
+                recvs.append((window[a - f0:b - f0], q))
+                halo_recv += (b - a) * V[1] * V[2]
+    for work in comm.exchange(sends, recvs):
+        work.wait()
+    shifted = pbc.copy()
+    shifted[:, 0] -= f0
+    shifted[:, 3] -= f0
+    # ---- schedule (identical on every rank) ----
+    pieces = [block_pieces(bc[b], lbc[b], bounds) for b in range(len(pbc))]
+    orders = [compute_order(runs[r], pieces, r) for r in range(world)]
     longest = max(b - a for a, b in runs)
     rounds = max(1, min(int(rounds), longest))
     per_round = -(-longest // rounds)
-    pieces = [block_pieces(bc[b], lbc[b], bounds) for b in range(len(pbc))]
+    round_of, slot_of = {}, {}
+    for r, order in enumerate(orders):
+        for pos, b in enumerate(order):
+            round_of[b] = pos // per_round
+            if r == rank:
+                slot_of[b] = pos
+    # everything that lands in my slab, in flat block order: (block, source rank, pa, za, zb)
+    mine = sorted((b, src, pa, za, zb) for src, order in enumerate(orders) for b in order
+                  for q, za, zb, pa in pieces[b] if q == rank)
+    pool = ops.recv_pool(sum(zb - za for b, src, pa, za, zb in mine if src != rank))
+    buf_of, used = {}, 0
+    for b, src, pa, za, zb in mine:
+        if src != rank:
+            buf_of[(b, za)] = pool[used:used + (zb - za)]
+            used += zb - za
     store = ops.new_store(hi - lo)
-    mine = []                    # (flat block index, piece tensor, pa, za, zb): everything that lands in my slab
-    pending, sent = [], 0
-    for t in range(rounds):
-        a, b = min(lo + t * per_round, hi), min(lo + (t + 1) * per_round, hi)
-        if b > a:
-            ops.forward_blocks(volume, pbc[a:b], store, a - lo)
-        sends, recvs = [], []
-        for src, (rl, rh) in enumerate(runs):
-            for blk in range(min(rl + t * per_round, rh), min(rl + (t + 1) * per_round, rh)):
-                for q, za, zb, pa in pieces[blk]:
-                    if src == rank:
-                        piece = store[blk - lo, pa:pa + (zb - za)]
-                        if q == rank:
-                            mine.append((blk, piece, pa, za, zb))
-                        else:
-                            sends.append((piece, q))
-                            sent += piece.numel() * 4
-                    elif q == rank:
-                        buf = ops.new_piece(zb - za)
-                        recvs.append((buf, src))
-                        mine.append((blk, buf, pa, za, zb))
-        pending += comm.exchange(sends, recvs)             # in flight while the next round's blocks compute
-    for work in pending:
-        work.wait()
-    # ---- blend my slab's pieces in flat block order, normalise + quantise ----
     acc = ops.make_slab_accumulator(z1 - z0, V[1], V[2])
-    for blk, piece, pa, za, zb in sorted(mine, key=lambda m: m[0]):
-        c, l = bc[blk], lbc[blk]
-        block = (za - z0, int(c[1]), int(c[2]), zb - z0, int(c[4]), int(c[5]))
-        local = (pa, int(l[1]), int(l[2]), pa + (zb - za), int(l[4]), int(l[5]))
-        ops.blend_piece(acc, piece, pa, block, local)
+    nxt, sent, early = 0, 0, 0
+
+    def blend_ready(done_round_remote, done_round_own):
+        nonlocal nxt
+        while nxt < len(mine):
+            b, src, pa, za, zb = mine[nxt]
+            if round_of[b] > (done_round_own if src == rank else done_round_remote):
+                break
+            piece = store[slot_of[b], pa:pa + (zb - za)] if src == rank else buf_of[(b, za)]
+            c, l = bc[b], lbc[b]
+            block = (za - z0, int(c[1]), int(c[2]), zb - z0, int(c[4]), int(c[5]))
+            local = (pa, int(l[1]), int(l[2]), pa + (zb - za), int(l[4]), int(l[5]))
+            ops.blend_piece(acc, piece, pa, block, local)
+            nxt += 1
+
+    handles = []
+    for t in range(rounds):
+        blocks_t = orders[rank][t * per_round:(t + 1) * per_round]
+        if blocks_t:
+            ops.forward_blocks(window, shifted[blocks_t], store, t * per_round)
+        sends, recvs = [], []
+        for src, order in enumerate(orders):
+            for b in order[t * per_round:(t + 1) * per_round]:
+                for q, za, zb, pa in pieces[b]:
+                    if src == rank and q != rank:
+                        piece = store[slot_of[b], pa:pa + (zb - za)]
+                        sends.append((piece, q))
+                        sent += piece.numel() * 4
+                    elif src != rank and q == rank:
+                        recvs.append((buf_of[(b, za)], src))
+        handles.append(comm.exchange(sends, recvs))         # in flight while the next round's blocks compute
+        if t > 0:
+            for work in handles[t - 1]:                       # round t - 1 has had a whole round of compute to land
+                work.wait()
+        blend_ready(t - 1, t)
+        if t == rounds - 2:
+            early = nxt
+    for work in handles[-1]:
+        work.wait()
+    blend_ready(rounds, rounds)
+    assert nxt == len(mine)
     out = ops.finalize(acc)
-    return out, {'blocks': hi - lo, 'bytes_sent': sent, 'slab': (z0, z1), 'pieces_blended': len(mine), 'rounds': rounds}
+    return out, {'blocks': hi - lo, 'bytes_sent': sent, 'slab': (z0, z1), 'pieces_blended': len(mine), 'rounds': rounds,
+                 'halo_bytes_received': halo_recv, 'footprint': (f0, f1), 'pieces_blended_before_last_round': early}

@@ -132,3 +132,77 @@ def test_c4_subvolume_throughput_mode_vs_parity_mode():
           f'class map compared on {sure.mean():.3f} of the voxels')
     assert d.max() <= 2
     assert np.array_equal(outs['fp16'].argmax(-1)[sure], outs['fp32'].argmax(-1)[sure])
+
+
+def test_c4_eight_virtual_ranks_at_full_size():
+    """The 8-GPU geometry of C4 (1024^3, 1 331 blocks: 166 / 167 per rank, z-slabs of 128 planes) on ONE GPU: eight virtual ranks
+    (threads, real device ops, the in-process communicator of test_gpu_shard.py) run shard.predict_volume_sharded in the bench's
+    dtype (bf16).  Asserted: every rank's slab is byte-identical to the 1-rank result; the halo exchange delivers at most the
+    rank's footprint (<= 3 block planes + overlap) instead of the whole volume; the probability pieces a rank sends stay within
+    SURVEY 8e's estimate (<= 2 GB); most pieces are blended before the last round.  Reported: the summed 8-rank device time against
+    the 1-rank time (no RCCL here: what it measures is the extra work of the sharded path -- halo copies, piece copies, cut
+    blends, eight slab finalisations)."""
+    import threading
+    import time
+    from interactive_unet import predict, shard
+    from interactive_unet.unet import UNet
+    from tests.test_gpu_shard import ThreadComm, _Shared
+    S, C, V, world = 128, 2, (1024, 1024, 1024), 8
+    p = unet_ref.init_params(dim=3, ncls=C, seed=5, randomize_bn=True)
+
+    def model():
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            m = UNet(num_classes=C, dim=3, act_dtype='bf16', pretrained=False)
+        m.load_named(p)
+        return m.cuda().eval()
+    g = torch.Generator(device='cuda').manual_seed(2)
+    vol = torch.randint(0, 256, V, dtype=torch.uint8, device='cuda', generator=g)
+    ops1 = shard.NativeOps(model(), C, S)
+    times = []
+    for _ in range(2):                                          # second run: caches warm
+        torch.cuda.synchronize(); t0 = time.time()
+        want, _ = shard.predict_volume_sharded(ops1, vol, V, S, 0.25)
+        torch.cuda.synchronize(); times.append(time.time() - t0)
+    t1 = times[-1]
+    want = want.clone()
+    del ops1
+    torch.cuda.empty_cache()
+    bounds, _ = shard.slab_bounds(V[0], world)
+    shared = _Shared(world)
+    opss = [shard.NativeOps(model(), C, S) for _ in range(world)]
+    slabs = [vol[a:b].contiguous() for a, b in bounds]
+    res, errs = [None] * world, []
+
+    def run(r):
+        try:
+            res[r] = shard.predict_volume_sharded(opss[r], slabs[r], V, S, 0.25, comm=ThreadComm(shared, r))
+        except Exception as e:                                   # pragma: no cover
+            errs.append(e)
+            shared.barrier.abort()
+    t8 = None
+    for _ in range(2):
+        th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+        torch.cuda.synchronize(); t0 = time.time()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(timeout=600)
+        torch.cuda.synchronize(); t8 = time.time() - t0
+        assert not errs, errs
+    nb = [r[1]['blocks'] for r in res]
+    assert sum(nb) == 1331 and max(nb) - min(nb) <= 1
+    for r, (a, b) in enumerate(bounds):
+        out, st = res[r]
+        assert torch.equal(out, want[a:b]), f'rank {r}: slab differs from the 1-rank result'
+        f0, f1 = st['footprint']
+        assert f1 - f0 <= 3 * 96 + 32 + 32 and st['halo_bytes_received'] <= (f1 - f0) * V[1] * V[2]
+        assert st['bytes_sent'] <= 2.0e9, st
+        assert st['pieces_blended_before_last_round'] >= 0.7 * st['pieces_blended'], st
+    sent = [r[1]['bytes_sent'] / 1e9 for r in res]
+    halo = [r[1]['halo_bytes_received'] / 2 ** 20 for r in res]
+    print(f'C4 on 8 virtual ranks (one GPU, bf16): blocks per rank {nb}; pieces sent per rank {min(sent):.2f}-{max(sent):.2f} GB; halo planes '
+          f'received per rank {min(halo):.0f}-{max(halo):.0f} MiB (a whole-slab all-gather: 896 MiB); pieces blended before the last round '
+          f'{min(r[1]["pieces_blended_before_last_round"] / r[1]["pieces_blended"] for r in res):.2f}+; summed 8-rank time {t8:.3f} s vs 1 rank '
+          f'{t1:.3f} s: overhead {100 * (t8 / t1 - 1):.1f} %')
+    assert t8 <= 1.25 * t1

@@ -68,8 +68,11 @@ class NumpyOps:
     def new_store(self, n):
         return torch.zeros((max(n, 1),) + (self.S,) * 3 + (self.C,), dtype=torch.float32)
 
-    def new_piece(self, nz):
-        return torch.zeros((nz, self.S, self.S, self.C), dtype=torch.float32)
+    def new_window(self, shape):
+        return torch.zeros(tuple(shape), dtype=torch.uint8)
+
+    def recv_pool(self, nplanes):
+        return torch.zeros((max(nplanes, 1), self.S, self.S, self.C), dtype=torch.float32)
 
     def forward_blocks(self, volume, padded, store, j0):
         for i, pb in enumerate(padded):
