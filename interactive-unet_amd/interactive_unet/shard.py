@@ -73,6 +73,7 @@ class NativeOps:
         self.device = model.device
         self.eng = model.engine('eval')
         self._acc, self._store, self._blk = {}, None, None
+        self.round_align = max(1, int(P.BLOCK_BATCH)) if self.eng.dim == 3 else 1
 
     # ---- single-rank path: blend at once into a whole-volume accumulator (predict.predict_volume_array's loop)
     def make_accumulator(self, V):
@@ -250,6 +251,9 @@ def predict_volume_sharded(ops, my_slab, volume_shape, input_size, overlap=0.25,
     longest = max(b - a for a, b in runs)
     rounds = max(1, min(int(rounds), longest))
     per_round = -(-longest // rounds)
+    align = max(1, int(getattr(ops, 'round_align', 1)))         # whole forward batches per round (no odd block per round)
+    per_round = -(-per_round // align) * align
+    rounds = -(-longest // per_round)
     round_of, slot_of = {}, {}
     for r, order in enumerate(orders):
         for pos, b in enumerate(order):

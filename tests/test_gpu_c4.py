@@ -139,7 +139,7 @@ def test_c4_eight_virtual_ranks_at_full_size():
     (threads, real device ops, the in-process communicator of test_gpu_shard.py) run shard.predict_volume_sharded in the bench's
     dtype (bf16).  Asserted: every rank's slab is byte-identical to the 1-rank result; the halo exchange delivers at most the
     rank's footprint (<= 3 block planes + overlap) instead of the whole volume; the probability pieces a rank sends stay within
-    SURVEY 8e's estimate (<= 2 GB); most pieces are blended before the last round.  Reported: the summed 8-rank device time against
+    SURVEY 8e's estimate (<= 2 GB); the owners blend while the rounds run (>= 35 % of the pieces before the last round).  Reported: the summed 8-rank device time against
     the 1-rank time (no RCCL here: what it measures is the extra work of the sharded path -- halo copies, piece copies, cut
     blends, eight slab finalisations)."""
     import threading
@@ -198,7 +198,9 @@ def test_c4_eight_virtual_ranks_at_full_size():
         f0, f1 = st['footprint']
         assert f1 - f0 <= 3 * 96 + 32 + 32 and st['halo_bytes_received'] <= (f1 - f0) * V[1] * V[2]
         assert st['bytes_sent'] <= 2.0e9, st
-        assert st['pieces_blended_before_last_round'] >= 0.7 * st['pieces_blended'], st
+        # own blocks are blended as their forwards are issued; what waits for the last round is that round's blocks plus what
+        # FOLLOWS them in flat order (the own tail's pieces, computed first for the next owner's sake, and the next rank's head)
+        assert st['pieces_blended_before_last_round'] >= 0.35 * st['pieces_blended'], st
     sent = [r[1]['bytes_sent'] / 1e9 for r in res]
     halo = [r[1]['halo_bytes_received'] / 2 ** 20 for r in res]
     print(f'C4 on 8 virtual ranks (one GPU, bf16): blocks per rank {nb}; pieces sent per rank {min(sent):.2f}-{max(sent):.2f} GB; halo planes '
