@@ -34,7 +34,9 @@ The JSON line also carries
                   parity mode on one chunk (that mode is held within 1e-3 of the CPU oracle by tests/test_gpu_parity.py),
                   plus, when the CPU baseline runs, both modes against the CPU fp32 oracle on its sample;
   cpu_baseline -- the oracle (oracle/unet_ref.py, torch CPU fp32, host cores) timed on a bounded sample of the same
-                  workload, rank 0 / N = 1 only.
+                  workload, rank 0 / N = 1 only;
+  legs.predict_2p5d -- the reference's own predict semantics (predict.py:79-112): one 128^3 block through the
+                  2-D net along 3 axes, in fp16x2 and fp16, with the oracle's predict_block on the host cores beside it.
 """
 import argparse
 import json
@@ -323,6 +325,59 @@ def cpu_baseline(cfg, model=None, chunk_u8=None):
     return out, chk
 
 
+def predict_2p5d_leg(dev, with_cpu):
+    """The reference's own predict semantics (predict.py:79-112): one 128^3 uint8 block through the 2-D U-Net
+    (4 levels, base 32, 1 -> 2 classes) slice by slice along the three axes -- strided views of the block, the head accumulating
+    into [S, S, S, C] -- in the default prediction mode (fp16x2) and in fp16; plus the oracle's predict_block on the host cores."""
+    import warnings
+    from interactive_unet import predict as P
+    from interactive_unet.unet import UNet
+    S, C = 128, 2
+    blk = synth_chunks(1, (S, S, S), 777, dev).reshape(S, S, S)
+    out = torch.empty((S, S, S, C), dtype=torch.float32, device=dev)
+    fpv2 = flops_per_voxel(2, 4, 32, 1, C)
+    res = {'block': [S, S, S], 'axes': 3, 'semantics': 'predict.py:79-112 (2-D net over the slices along 3 axes, probabilities averaged)',
+           'fwd_flop_per_block': 3 * fpv2 * S ** 3}
+    probs = {}
+    for name, kw in (('fp16x2', {}), ('fp16', {'act_dtype': 'fp16'})):
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            m = UNet(num_classes=C, dim=2, pretrained=False, **kw)
+        m.reset_parameters(seed=0)
+        m = m.to(dev).eval()
+        run = lambda: P.predict_block_device(m, blk, out, C, None, (0, 1, 2))
+        for _ in range(2):
+            run()
+        torch.cuda.synchronize()
+        reps, t0 = 10, time.time()
+        for _ in range(reps):
+            run()
+        torch.cuda.synchronize()
+        ms = (time.time() - t0) / reps * 1e3
+        res[name] = {'ms_per_block': round(ms, 3), 'voxels_per_s': round(S ** 3 / ms * 1e3, 1),
+                     'tflops(algorithmic)': round(3 * fpv2 * S ** 3 / ms / 1e9, 1)}
+        probs[name] = out.clone()
+        params = {k: t.detach().float().cpu() for k, t in m.named_tensors().items()}
+        del m
+    if with_cpu:
+        from oracle import predict_ref, unet_ref
+        cores = min(16, len(os.sched_getaffinity(0)))
+        torch.set_num_threads(cores)
+        fn = lambda b: unet_ref.forward(params, torch.from_numpy(b), dim=2).numpy()
+        x = blk.cpu().numpy().astype(np.float32) / 255.0
+        t0 = time.time()
+        with torch.no_grad():
+            want = predict_ref.predict_block(fn, x, C, 8, (0, 1, 2))
+        dt = time.time() - t0
+        res['cpu_baseline'] = {'value': round(S ** 3 / dt, 1), 'unit': 'voxels/s', 'cores': cores, 'kind': 'port',
+                               'sample': f'the oracle predict_block (fp32 2-D U-Net, batch 8, 3 axes) on the same 128^3 block, torch CPU, {cores} threads'}
+        for name in probs:
+            d = (probs[name].cpu() - torch.from_numpy(want)).abs()
+            res[name]['max_abs_prob_vs_cpu_fp32'] = float(d.max())
+            res[name]['argmax_mismatch'] = int((probs[name].cpu().argmax(-1) != torch.from_numpy(want).argmax(-1)).sum())
+    return res
+
+
 def relaunch(args):
     """--gpus N without a launcher: start N ranks of this script under torch.distributed.run as CHILD processes
     (nothing in this process has touched the GPU) and hand back their exit code."""
@@ -347,6 +402,7 @@ def main():
     ap.add_argument('--c4-reps', type=int, default=1, help='c3 only: timed 1024^3 predictions appended to the line (0 = skip)')
     ap.add_argument('--c4-size', type=int, default=1024)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-2p5d', action='store_true', help='skip legs.predict_2p5d (the reference-semantics 2.5-D block prediction)')
     ap.add_argument('--no-parity-mode', action='store_true', help='skip the second timed region (prediction leg in fp16x2)')
     args = ap.parse_args()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -631,6 +687,8 @@ def main():
             out['cpu_baseline'], chk = cpu_baseline(cfg, model, probe)
             if chk:
                 out['parity']['vs_cpu_oracle'] = chk
+        if args.workload in ('c3', 'c2') and not args.no_2p5d:
+            out['legs']['predict_2p5d'] = predict_2p5d_leg(dev, world == 1 and not args.no_cpu_baseline)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
