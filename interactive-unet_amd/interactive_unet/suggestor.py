@@ -36,9 +36,10 @@ class Suggestor(unet.UNet):
                              pretrained=False, dim=2)
 
 
-def make_suggestions(image_features, mask, lr=0.0001, steps=30, model=None, generator=None):
+def make_suggestions(image_features, mask, lr=0.0001, steps=30, model=None, generator=None, trace=None):
     """suggestor.py:43-116.  image_features float [1, ch, S, S] in [0, 1] (app.py:311: image / 255), mask uint8 [S, S, 3] palette
-    colours (black = unlabelled) -> (suggestions uint8 [S, S, 3], model)."""
+    colours (black = unlabelled) -> (suggestions uint8 [S, S, 3], model).  `trace` (a list, tests only): receives one (x, y, w, loss)
+    tuple of host tensors per step -- the augmented batch the step trained on and its loss -- so that an oracle can replay the run."""
     image_size = mask.shape[0]
     unique_colors = get_unique_colors(mask)[1:]
     num_classes = len(unique_colors)
@@ -65,6 +66,8 @@ def make_suggestions(image_features, mask, lr=0.0001, steps=30, model=None, gene
         angle = torch.empty(1).uniform_(-360.0, 360.0, generator=generator).item()
         xt, yt, wt = ds.batch([0], params=[(hflip, vflip, angle, (0, 0, H, W))])
         row = engine.train_step(xt, yt, wt)
+        if trace is not None:
+            trace.append((xt.float().cpu(), yt.float().cpu(), wt.float().cpu(), row['Loss']))
         if not np.isfinite(row['Loss']):              # suggestor.py:93-96: start over with a fresh model
             model = Suggestor(ch, num_classes).to(device)
             model.train()

@@ -433,3 +433,51 @@ def test_suggestor_contract_and_learning():
     mask3[60:70, 56:72] = loader.COLORS[4]
     sug3, model3 = suggestor.make_suggestions(feats, mask3, steps=2, model=model, generator=gen)
     assert model3 is not model and model3.num_classes == 3 and sug3.shape == (S, S, 3)
+
+
+def test_suggestor_trajectory_against_the_oracle_train_loop():
+    """SURVEY 8f rank 4 (suggestor.py:78-103): the per-brush-stroke fine-tune is 30 steps of {augment, forward, MCC + CE with the
+    annotation mask as weight, backward, AdamW}.  The network behind it is unpinned (smp mobilenet absent), so what CAN be pinned
+    is the loop: the native run records the augmented batch and the loss of every step; the oracle (oracle/unet_ref.py forward in
+    training mode with the HIP path's fp16 rounding points + the host metrics' mcc_ce_loss + torch autograd + the restated AdamW)
+    replays the same batches from the same initial weights.  The two loss trajectories must track each other step by step."""
+    from interactive_unet import suggestor, loader, metrics as host_metrics
+    rng = np.random.default_rng(21)
+    S, steps, lr = 64, 30, 1e-4
+    truth = np.zeros((S, S), int)
+    truth[S // 2:, :] = 1
+    img = np.clip(np.where(truth == 1, 190, 70) + rng.normal(0, 15, (S, S)), 1, 255).astype(np.uint8)
+    feats = (img / 255).astype('float32')[None, None]
+    mask = np.zeros((S, S, 3), np.uint8)
+    mask[8:12, 6:40] = loader.COLORS[1]
+    mask[50:54, 20:60] = loader.COLORS[2]
+    model = suggestor.Suggestor(1, 2)
+    model.reset_parameters(seed=4)
+    p0 = {k: v.detach().clone() for k, v in model.named_tensors().items()}
+    trace = []
+    sug, model = suggestor.make_suggestions(feats, mask, lr=lr, steps=steps, model=model.cuda(), generator=torch.Generator().manual_seed(9),
+                                            trace=trace)
+    assert len(trace) == steps and sug.shape == (S, S, 3)
+    pr = {k: v.clone().requires_grad_(not unet_ref.is_buffer(k)) for k, v in p0.items()}
+    m = {k: torch.zeros_like(v) for k, v in pr.items()}
+    v = {k: torch.zeros_like(t) for k, t in pr.items()}
+    names = [k for k, t in pr.items() if t.requires_grad]
+    worst = 0.0
+    for it, (x, y, w, loss_native) in enumerate(trace):
+        probs = unet_ref.forward(pr, x, dim=2, training=True, act_dtype=torch.float16)
+        loss = host_metrics.mcc_ce_loss(probs, y, w, axes=[0, 2, 3])
+        grads = torch.autograd.grad(loss, [pr[k] for k in names])
+        with torch.no_grad():
+            unet_ref.adamw_step({k: t.data for k, t in pr.items()}, dict(zip(names, grads)), m, v, it + 1, lr)
+        d = abs(loss.item() - loss_native)
+        worst = max(worst, d)
+        assert d <= (5e-3 if it == 0 else 2e-2), (it, loss.item(), loss_native)
+    first, last = trace[0][3], trace[-1][3]
+    print(f'suggestor trajectory: native loss {first:.4f} -> {last:.4f} over {steps} steps; max |native - oracle| per step = {worst:.2e}')
+    # after the replay the two runs have moved the weights the same way (AdamW normalises the gradient, so an entry whose tiny
+    # gradient differs in the fp16 noise can move the other way: compare directions, not entries)
+    nat = {k: t.detach().cpu() for k, t in model.named_tensors().items()}
+    for k in ('enc0.conv1.weight', 'dec0.conv2.weight', 'head.weight'):
+        a, b = (nat[k] - p0[k]).reshape(-1).double(), (pr[k].detach() - p0[k]).reshape(-1).double()
+        cos = float(a @ b / (a.norm() * b.norm()))
+        assert cos >= 0.7, (k, cos)

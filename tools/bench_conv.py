@@ -25,6 +25,7 @@ def main():
     ap.add_argument('--base', type=int, default=32, help='channels at level 0 (64: the C5 network)')
     ap.add_argument('--levels', type=int, default=4)
     ap.add_argument('--f8', type=int, default=0, help='1: also time the fp8 matrix-core kernel (conv3_f8.hip) on each shape')
+    ap.add_argument('--x2', type=int, default=0, help='1: also time the split-precision conv (fp16x2: conv3_v4.hip SPL) on each shape; 2: only it')
     a = ap.parse_args()
     T = torch.bfloat16 if a.dtype == 'bf16' else torch.float16
     dt = nv.DTYPE_CODE[T]; nd = a.dim; taps = 3 ** nd
@@ -56,7 +57,7 @@ def main():
         nv.call('iunet_pack_conv3', dt, nv.ptr(w), None, nv.ptr(wpk), cout, cin, taps, pm, nv.stream())
         f = lambda: nv.call('iunet_conv3_fwd', dt, nd, nv.ptr(x), cin * vox, nv.ptr(y), cout * vox, nv.ptr(wpk), nv.ptr(bias), None,
                             a.n, D, S, S, cin, cout, 2, lay, nv.stream())
-        ms = timeit(f, iters=a.iters)
+        ms = timeit(f, iters=a.iters) if a.x2 != 2 else float('nan')
         fl = 2.0 * taps * cin * cout * vox * a.n
         line = f'L{lvl} {cin:3d}->{cout:3d} @{S}^{nd} N={a.n} layout {lay}: fwd {ms*1e3:8.1f} us {fl/ms/1e9:7.1f} TF/s'
         tot_f += fl; tot_t += ms
@@ -78,6 +79,19 @@ def main():
                                 nv.ptr(bias), a.n, D, S, S, cin, cout, 2, nv.ptr(wk), nv.stream())
             ms3 = timeit(h, iters=a.iters)
             line += f' | fp8 {ms3*1e3:8.1f} us {fl/ms3/1e9:7.1f} TF/s ({ms/ms3:.2f}x){" split-K" if need else ""}'
+        if a.x2:
+            wv = torch.empty(3 * cin * cout * taps, device='cuda')
+            osc, b2 = torch.empty(cout, device='cuda'), torch.empty(cout, device='cuda')
+            nv.call('iunet_x2_prep', nv.ptr(w), nv.ptr(wv), nv.ptr(osc), nv.ptr(b2), None, None, None, None, nv.ptr(bias), 1e-5, 64.0, 64.0,
+                    cout, cin, taps, 0, 16 if nd == 3 else 32, nv.stream())
+            wx = torch.empty(nv.pack_conv3_elems(cout, 3 * cin, taps, 2), dtype=torch.float16, device='cuda')
+            nv.call('iunet_pack_conv3', 0, nv.ptr(wv), None, nv.ptr(wx), cout, 3 * cin, taps, 2, nv.stream())
+            xs = (torch.randn(a.n * 2 * cin * vox, device='cuda') * 8).to(torch.float16)      # hi planes | lo planes (random words: timing only)
+            ys = torch.empty(a.n * 2 * cout * vox, dtype=torch.float16, device='cuda')
+            k = lambda: nv.call('iunet_x2_conv3_fwd', nd, nv.ptr(xs), 2 * cin * vox, cin // 8, nv.ptr(ys), 2 * cout * vox, cout // 8, nv.ptr(wx),
+                                nv.ptr(osc), nv.ptr(b2), a.n, D, S, S, cin, cout, 2, nv.stream())
+            ms4 = timeit(k, iters=a.iters)
+            line += f' | fp16x2 {ms4*1e3:8.1f} us {fl/ms4/1e9:7.1f} TF/s algorithmic = {3*fl/ms4/1e9:7.1f} TF/s of MFMA work ({ms4/ms:.2f}x the 16-bit time)'
         print(line, flush=True)
     print(f'sum fwd: {tot_t*1e3:.1f} us, {tot_f/tot_t/1e9:.1f} TF/s')
 
