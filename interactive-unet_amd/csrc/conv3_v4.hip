@@ -135,9 +135,15 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + v4_loader_threads(ND
   // bricks than XCDs the brick range of a workgroup is rotated by its Cout tile, so the launch still spreads over all XCDs;
   // larger grids keep the Cout tiles of one brick on one XCD (they read the same input: the second one hits in L2)
   const int nbricks = p.N * p.nbz * p.nby * p.nbx;
-  const int xcd = (blockIdx.x + (nbricks < 8 ? blockIdx.y : 0)) & 7, slot = blockIdx.x >> 3;
+  // A brick clamped to a small tile grid has fewer slots than the XCD has workgroups for this Cout tile (2-D slices of 128^2 at the
+  // deep levels: 2 of 8): the launch then holds `ngrp` groups of slots per XCD, each walking its own share of the XCD's bricks --
+  // a batch of many small images (the 2.5-D block prediction: 128 slices per launch) fills the chip instead of a quarter of it.
+  const int bslots = p.bx * p.by * p.bz, ngrp = (int)gridDim.x / (8 * bslots);
+  const int xcd = (blockIdx.x + (nbricks < 8 ? blockIdx.y : 0)) & 7, slot_all = blockIdx.x >> 3;
+  const int grp = slot_all / bslots, slot = slot_all - grp * bslots;
   const int sx = slot % p.bx, sy = (slot / p.bx) % p.by, sz = slot / (p.bx * p.by);
-  const int b_begin = (int)((long long)xcd * nbricks / 8), b_end = (int)((long long)(xcd + 1) * nbricks / 8);
+  const int xb0 = (int)((long long)xcd * nbricks / 8), xb1 = (int)((long long)(xcd + 1) * nbricks / 8);
+  const int b_begin = xb0 + (int)((long long)(xb1 - xb0) * grp / ngrp), b_end = xb0 + (int)((long long)(xb1 - xb0) * (grp + 1) / ngrp);
   const int nchunk = p.Cin / (16 * S16);               // steps per tile
   const int nsteps = (b_end - b_begin) * nchunk;
   // step -> (tile of this workgroup, 16-channel chunk).  PAIR: tile = 2 * pair + (s & 1), chunk advances every second step
@@ -744,7 +750,15 @@ int launch_v4(ConvV4Params p, hipStream_t stream) {
   // one workgroup per CU: 8 XCDs x (bz x by x bx) brick slots per Cout tile
   iunet_brick_shape(ND, ncob, p.tilesZ, p.tilesY, p.tilesX, &p.bz, &p.by, &p.bx);
   p.nbz = (p.tilesZ + p.bz - 1) / p.bz; p.nby = (p.tilesY + p.by - 1) / p.by; p.nbx = (p.tilesX + p.bx - 1) / p.bx;
-  const int gx = 8 * p.bz * p.by * p.bx;
+  // slot groups: the brick table's slot count over this (possibly clamped) brick's, while every group still gets a brick per XCD
+  int groups = 1;
+  if (!PAIR) {
+    const long long nbricks = (long long)p.N * p.nbz * p.nby * p.nbx;
+    groups = iunet_conv3_v4_stats_parts(ND, p.Cout) / 8 / (p.bz * p.by * p.bx);
+    while (groups > 1 && nbricks / 8 < groups) groups >>= 1;
+    if (groups < 1) groups = 1;
+  }
+  const int gx = 8 * p.bz * p.by * p.bx * groups;
   if (p.stats != nullptr) {
     // the caller reduces iunet_conv3_v4_stats_parts rows (the brick table's slot count); a brick clamped to a small tile grid
     // launches fewer workgroups: the rows nobody writes are zeroed

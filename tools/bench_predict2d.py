@@ -8,7 +8,7 @@ from interactive_unet.unet import UNet
 from interactive_unet import predict
 with warnings.catch_warnings():
     warnings.simplefilter('ignore')
-    m = UNet(num_classes=2, dim=2, act_dtype='fp16', pretrained=False).cuda().eval()
+    m = UNet(num_classes=2, dim=2, act_dtype=(sys.argv[1] if len(sys.argv) > 1 else 'fp16'), pretrained=False).cuda().eval()      # fp16 | bf16 | fp16x2 | fp32
 rng = np.random.default_rng(0)
 img = rng.integers(1, 255, (512, 512), dtype=np.uint8)
 def t(fn, n=20):
