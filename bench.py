@@ -109,7 +109,8 @@ def pmc_traffic(workload, tiles=1):
     """HBM bytes per launch of the roofline kernel from the committed PMC profile (rocprofv3 cannot run inside the timed
     process): FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate passes, scaled to the tiles of the launch.  None where
     no profile is committed."""
-    for name in (f'r02_pmc_{workload}_dec0conv1.json', 'r02_pmc_c3_dec0conv1.json' if workload == 'c4' else ''):
+    for name in (f'r03_pmc_{workload}_dec0conv1.json', 'r03_pmc_c3_dec0conv1.json' if workload == 'c4' else '',
+                 f'r02_pmc_{workload}_dec0conv1.json', 'r02_pmc_c3_dec0conv1.json' if workload == 'c4' else ''):
         try:
             with open(os.path.join(ROOT, 'profiles', name)) as f:
                 d = json.load(f)

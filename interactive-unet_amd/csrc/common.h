@@ -9,6 +9,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstdio>
+#include <cstdlib>
 
 typedef _Float16 f16;
 typedef __bf16 bf16;
@@ -144,6 +146,11 @@ inline void iunet_brick_shape(int nd, int ncob, int tilesZ, int tilesY, int tile
     else if (ncob == 2) { y = 4; x = 4; }
     else if (ncob <= 4) { y = 2; x = 4; }
     else                { y = 2; x = 2; }
+  }
+  if (nd == 3 && ncob == 1) {                    // A/B switch (IUNET_BRICK3="z y x", product 32): brick shape of the one-Cout-tile 3-D launches
+    static const char* e = getenv("IUNET_BRICK3");
+    int ez, ey, ex;
+    if (e && sscanf(e, "%d %d %d", &ez, &ey, &ex) == 3 && ez * ey * ex == 32) { z = ez; y = ey; x = ex; }
   }
   const int want = z * y * x;
   const int mz = nd == 3 ? p2(tilesZ) : 1, my = p2(tilesY), mx = p2(tilesX);

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collect the round's profile artefacts on the GPU box (run from the repo root through gpurun); the summaries land in
-# gpurun_out/profiles_$RND/ and are copied into profiles/ (tracked) afterwards.   bash tools/collect_profiles.sh [r02]
-RND=${1:-r02}
+# gpurun_out/profiles_$RND/ and are copied into profiles/ (tracked) afterwards.   bash tools/collect_profiles.sh [r03]
+RND=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/profiles_$RND
 mkdir -p $OUT
@@ -33,7 +33,7 @@ stats bench_c3 python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --c4-r
 stats bench_c5 python3 $R/bench.py --workload c5 --steps 3 --warmup 1 --no-cpu-baseline
 stats bench_c2 python3 $R/bench.py --workload c2 --steps 5 --warmup 2 --no-cpu-baseline
 # the launches of the roofline layer (dec0.conv1 forward) inside the profiled steps: what bench.py's in-situ `roofline` times
-python3 $R/tools/roofline_launches.py $OUT/bench_c3_kernel_trace.csv conv3_v4_kernel 300 420 262144 1 > $OUT/${RND}_bench_c3_roofline_launches.txt      # 256 workgroups x 1024 threads: the compact-operator variant (8 loader waves)
+python3 $R/tools/roofline_launches.py $OUT/bench_c3_kernel_trace.csv 'conv3_v4_kernelIDF16bLi3ELb0ELb0ELb0ELb0ELb1ELb0E' 300 460 262144 1 > $OUT/${RND}_bench_c3_roofline_launches.txt      # 256 workgroups x 1024 threads: the bf16 compact-operator variant (8 loader waves)
 python3 $R/tools/roofline_launches.py $OUT/bench_c5_kernel_trace.csv conv3_f8_kernel 400 1000 98304 2 > $OUT/${RND}_bench_c5_roofline_launches.txt
 python3 $R/tools/roofline_launches.py $OUT/bench_c2_kernel_trace.csv conv3_v4_kernel 85 140 196608 1 > $OUT/${RND}_bench_c2_roofline_launches.txt
 # 3. the roofline kernels alone: 3 warm-up + 50 launches, the sequence bench.py times
@@ -41,10 +41,20 @@ stats roofline_c3 python3 $R/tools/bench_conv.py --only 0:64:32 --wgrad 0 --iter
 stats roofline_c3_1tile python3 $R/tools/bench_conv.py --only 0:64:32 --wgrad 0 --iters 50
 stats roofline_c5 python3 $R/tools/bench_conv.py --only 0:128:64 --base 64 --levels 5 --wgrad 0 --f8 1 --iters 50
 stats roofline_c2 python3 $R/tools/bench_conv.py --only 0:64:32 --dim 2 --size 512 --n 8 --dtype f16 --wgrad 0 --iters 50
+# the split-precision (fp16x2) conv of the same layer alone, and one whole split-precision forward per configuration
+stats roofline_x2 python3 $R/tools/bench_conv.py --only 0:64:32 --wgrad 0 --iters 50 --n 2 --x2 2
+stats forward_x2 python3 $R/tools/bench_x2.py x2
+python3 $R/tools/bench_conv.py --wgrad 0 --iters 30 --n 1 --x2 1 > $OUT/${RND}_conv_layers_x2_3d.txt 2>/dev/null
+python3 $R/tools/bench_conv.py --dim 2 --size 512 --n 8 --dtype f16 --wgrad 0 --iters 30 --x2 1 > $OUT/${RND}_conv_layers_x2_2d.txt 2>/dev/null
 # 4. HBM traffic of the roofline kernels (separate passes, as the guide prescribes)
 for c in FETCH_SIZE WRITE_SIZE; do
   pmc c3 $c python3 $R/tools/bench_conv.py --only 0:64:32 --wgrad 0 --iters 2
   pmc c5 $c python3 $R/tools/bench_conv.py --only 0:128:64 --base 64 --levels 5 --wgrad 0 --f8 1 --iters 2
   pmc c2 $c python3 $R/tools/bench_conv.py --only 0:64:32 --dim 2 --size 512 --n 8 --dtype f16 --wgrad 0 --iters 2
+  pmc x2 $c python3 $R/tools/bench_conv.py --only 0:64:32 --wgrad 0 --iters 2 --x2 2
 done
+python3 $R/tools/pmc_json.py $OUT $RND c3 conv3_v4_kernel 'dec0.conv1 64->32 @ 1 x 128^3 bf16' 402653184 1
+python3 $R/tools/pmc_json.py $OUT $RND c5 conv3_f8_kernel 'dec0.conv1 128->64 @ 1 x 128^3 bf16 in / fp8 MFMA' 805306368 1
+python3 $R/tools/pmc_json.py $OUT $RND c2 conv3_v4_kernel 'dec0.conv1 64->32 @ 8 x 512^2 f16' 402653184 8
+python3 $R/tools/pmc_json.py $OUT $RND x2 conv3_v4_kernel 'dec0.conv1 64->32 @ 1 x 128^3 fp16x2 (hi + lo planes in and out)' 805306368 1
 ls -la $OUT
