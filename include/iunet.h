@@ -109,15 +109,15 @@ int iunet_head_fwd(int dtype, const void* x, long long x_ss, int C0, const void*
  * entry points run the same forward graph (unet.py:65-69 over the canonical network) with fp32 activations, fp32 weights
  * and the f32-input matrix instruction (exact fp32 products and sums), 1/16 of the bf16 rate.  Layout of THIS mode: planar
  * fp32, C planes of [D][H][W]; `*_ss` = elements between consecutive samples. */
-/* operator packing: conv w fp32 [Cout][Cin][taps] (taps 9 / 27) or, transposed != 0, ConvTranspose k2 s2 w fp32
+/* operator packing: conv w fp32 [Cout][Cin][taps] (taps 9 / 27; 1 = pointwise) or, transposed != 0, ConvTranspose k2 s2 w fp32
  * [Cin][Cout][taps] (taps 4 / 8); a non-NULL gamma folds an eval-mode BatchNorm (w * gamma / sqrt(var + eps); bias_out =
  * beta - mean * that scale; every operation separately rounded, as the CPU oracle's fold).  dst:
  * iunet_f32_pack_conv_elems floats. */
 long long iunet_f32_pack_conv_elems(int Cout, int Cin, int taps);
 int iunet_f32_pack_conv(const void* w, void* dst, void* bias_out, const void* gamma, const void* beta, const void* mean,
                         const void* var, float eps, int Cout, int Cin, int taps, int transposed, void* stream);
-/* 3^d conv pad 1 (transposed == 0) or ConvTranspose k2 s2 (transposed != 0; D, H, W = input grid, output 2x) + bias + optional
- * ReLU.  The input is read through element strides in_strides (n, c, d, h, w) and in_dtype (0 f32, 1 f16, 2 u8 / 255, 3
+/* 3^d conv pad 1 (transposed == 0), ConvTranspose k2 s2 (transposed == 1; D, H, W = input grid, output 2x) or 1x1 conv
+ * (transposed == 2; operator packed with taps == 1) + bias + optional ReLU.  The input is read through element strides in_strides (n, c, d, h, w) and in_dtype (0 f32, 1 f16, 2 u8 / 255, 3
  * bf16), so the first conv takes the caller's tensor or a 2.5-D view of a block directly; y: planar fp32. */
 int iunet_f32_conv_fwd(int nd, const void* x, int in_dtype, const long long* in_strides, void* y, long long y_ss,
                        const void* wpk, const void* bias, int N, int D, int H, int W, int Cin, int Cout, int relu,
@@ -128,6 +128,42 @@ int iunet_f32_maxpool_fwd(int nd, const void* x, long long x_ss, void* y, long l
 int iunet_f32_head_fwd(const void* x, long long x_ss, int C0, const void* w, const void* bias, int ncls, void* logits,
                        void* probs, void* cls, const long long* out_strides, float divisor, int accumulate, int N, int D, int H,
                        int W, void* stream);
+
+/* ---- fp32 parity form of the TRAINING step (csrc/train_f32.hip; interactive_unet/train_engine_f32.py sequences it) -------------
+ * unet.py:88-102 + autograd + AdamW with planar fp32 tensors and fp32 arithmetic throughout: convolutions, transposed convolutions
+ * and every data gradient run on iunet_f32_conv_fwd (a conv's data gradient is the conv with the flipped, transposed operator; a
+ * transposed conv's is the 1x1 conv -- transposed == 2, operator packed with taps == 1 -- over the space-to-depth view of dy); the
+ * entry points below are the rest of the step.  A whole step differs from CPU autograd only by the order of the sums. */
+/* BatchNorm batch statistics of y [N][C][vox]: mean, std = sqrt(biased var + eps) (two passes, double accumulation); run_mean /
+ * run_var (or NULL both): running statistics updated with `momentum` and the unbiased variance */
+int iunet_f32_bn_stats(const void* y, long long y_ss, int C, int N, long long vox, float eps, float momentum, void* mean, void* stdv,
+                       void* run_mean, void* run_var, void* stream);
+/* z = relu(((y - mean) / std) * gamma + beta) */
+int iunet_f32_bn_relu_fwd(const void* y, long long y_ss, void* z, long long z_ss, const void* mean, const void* stdv, const void* gamma,
+                          const void* beta, int C, int N, long long vox, void* stream);
+/* backward of the pair: dz -> dy (through the ReLU mask and the batch-statistics BatchNorm), dgamma [C], dbeta [C] */
+int iunet_f32_bn_relu_bwd(const void* dz, long long dz_ss, const void* y, long long y_ss, void* dy, long long dy_ss, const void* mean,
+                          const void* stdv, const void* gamma, const void* beta, void* dgamma, void* dbeta, int C, int N, long long vox,
+                          void* stream);
+/* dz (+)= dpool at the first maximum of every 2^d window of z (Do, Ho, Wo = pooled grid) */
+int iunet_f32_maxpool_bwd(int nd, const void* z, long long z_ss, const void* dpool, long long dp_ss, void* dz, long long dz_ss, int C,
+                          int N, int Do, int Ho, int Wo, int accumulate, void* stream);
+/* weight gradient on the f32-input MFMA: slab [iunet_f32_wgrad_splits][Cout][Cin][taps] partial sums of dy (x) tap-shifted x (taps 3^nd,
+ * or 1: pointwise -- transposed-conv and head weight gradients); iunet_reduce_slab sums the rows in a fixed order */
+int iunet_f32_wgrad_splits(int nd, int N, int D, int H, int W, int Cin, int Cout);
+int iunet_f32_wgrad(int nd, const void* x, long long x_ss, const void* dy, long long dy_ss, void* slab, int N, int D, int H, int W,
+                    int Cin, int Cout, int taps, void* stream);
+/* iunet_head_loss_fwd / _bwd on planar fp32 features: out4 = [loss, dice, iou, mcc (rounded tensors, unet.py:75-86)], coef [ncls][3];
+ * backward: dlogits [N][dl_ss / vox planes][vox] (the first ncls written; the head's dW = iunet_f32_wgrad taps 1, db =
+ * iunet_f32_channel_sum) and dx [N][C0][vox] */
+int iunet_f32_head_loss_num_parts(int N, long long vox);
+int iunet_f32_head_loss_fwd(const void* x, long long x_ss, int C0, const void* w, const void* bias, int ncls, const void* target,
+                            const void* weight, int tdtype, int kind, void* slab, void* out4, void* coef, int N, long long vox,
+                            void* stream);
+int iunet_f32_head_loss_bwd(const void* x, long long x_ss, int C0, const void* w, const void* bias, int ncls, const void* target,
+                            const void* weight, int tdtype, const void* coef, void* dlogits, long long dl_ss, void* dx, long long dx_ss,
+                            int N, long long vox, void* stream);
+int iunet_f32_channel_sum(const void* t, long long t_ss, void* out, int C, int N, long long vox, void* stream);
 
 /* ---- fp16x2 split precision: the tolerance-meeting forward on the 16-bit matrix cores ------------------------------------
  * BASELINE.json north_star's 1e-3 on logits / integer-exact class map against the fp32 reference predict (predict.py:30-35,

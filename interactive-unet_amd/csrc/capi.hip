@@ -214,8 +214,8 @@ int iunet_f32_pack_conv(const void* w, void* dst, void* bias_out, const void* ga
                         const void* var, float eps, int Cout, int Cin, int taps, int transposed, void* stream) {
   IUNET_REQUIRE(w && dst, "f32_pack_conv: null pointer");
   IUNET_REQUIRE(Cout > 0 && Cout % 32 == 0 && Cin > 0, "f32_pack_conv: Cout must be a positive multiple of 32, Cin > 0 (got %d, %d)", Cout, Cin);
-  IUNET_REQUIRE(transposed ? (taps == 4 || taps == 8) : (taps == 9 || taps == 27),
-                "f32_pack_conv: taps must be 9 / 27 (conv) or 4 / 8 (transposed), got %d", taps);
+  IUNET_REQUIRE(transposed ? (taps == 4 || taps == 8) : (taps == 9 || taps == 27 || taps == 1),
+                "f32_pack_conv: taps must be 9 / 27 (conv), 1 (pointwise) or 4 / 8 (transposed), got %d", taps);
   IUNET_REQUIRE(!gamma || (beta && mean && var && bias_out), "f32_pack_conv: a BatchNorm fold needs gamma, beta, mean, var and bias_out");
   return iunet_f32_pack_launch((const float*)w, (float*)dst, (float*)bias_out, (const float*)gamma, (const float*)beta,
                                (const float*)mean, (const float*)var, eps, Cout, Cin, taps, transposed, (hipStream_t)stream);

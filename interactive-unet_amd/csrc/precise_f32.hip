@@ -32,6 +32,8 @@ struct F32ConvParams {
   const float* w;                      // packed operator (f32_pack_conv_kernel)
   const float* bias;                   // [Cout] or null
   int N, D, H, W, Cin, Cout, relu;     // D, H, W: input grid (the output grid of a transposed conv is 2x)
+  int dense;                           // CT instantiation only: 1 = plain 1x1 conv (output voxel = input voxel, one position): the
+                                       // pointwise GEMMs of the fp32 training mode (transposed-conv data gradient)
 };
 
 __device__ __forceinline__ float f32_load_in(const void* p, long long off, int dt) {
@@ -155,7 +157,8 @@ __global__ __launch_bounds__(256) void f32_conv_kernel(F32ConvParams p) {
   }
 
   // epilogue: D[cout = 16 ct + 4 (lane >> 4) + j][voxel x = lane & 15]
-  const int Do = CT ? (ND == 3 ? 2 * p.D : 1) : p.D, Ho = CT ? 2 * p.H : p.H, Wo = CT ? 2 * p.W : p.W;
+  const bool up = CT && !p.dense;
+  const int Do = up ? (ND == 3 ? 2 * p.D : 1) : p.D, Ho = up ? 2 * p.H : p.H, Wo = up ? 2 * p.W : p.W;
   const long long ovox = (long long)Do * Ho * Wo;
   const int pa = ND == 3 ? (pos >> 2) & 1 : 0, pb = (pos >> 1) & 1, pc = pos & 1;
   float* yout = p.y + n * p.y_ss;
@@ -164,7 +167,7 @@ __global__ __launch_bounds__(256) void f32_conv_kernel(F32ConvParams p) {
     const int r = 4 * wave + i, tz = r / TY, ty = r % TY;
     const int gz = z0 + tz, gy = y0 + ty, gx = x0 + l15;
     if (gz >= p.D || gy >= p.H || gx >= p.W) continue;
-    const int oz = CT ? (ND == 3 ? 2 * gz + pa : 0) : gz, oy = CT ? 2 * gy + pb : gy, ox = CT ? 2 * gx + pc : gx;
+    const int oz = up ? (ND == 3 ? 2 * gz + pa : 0) : gz, oy = up ? 2 * gy + pb : gy, ox = up ? 2 * gx + pc : gx;
     const long long o = ((long long)oz * Ho + oy) * Wo + ox;
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
@@ -317,14 +320,16 @@ int iunet_f32_pack_launch(const float* w, float* dst, float* bias_out, const flo
 int iunet_f32_conv_launch(int nd, const void* x, int in_dtype, const long long* st, float* y, long long y_ss, const float* wpk,
                           const float* bias, int N, int D, int H, int W, int Cin, int Cout, int relu, int transposed,
                           hipStream_t stream) {
+  // transposed: 0 = 3^d conv, 1 = ConvTranspose k2 s2, 2 = 1x1 conv (dense pointwise GEMM; operator packed with taps = 1)
   F32ConvParams p;
+  p.dense = transposed == 2;
   p.x = x; p.sN = st[0]; p.sC = st[1]; p.sD = st[2]; p.sH = st[3]; p.sW = st[4]; p.in_dtype = in_dtype;
   p.y = y; p.y_ss = y_ss; p.w = wpk; p.bias = bias;
   p.N = N; p.D = D; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.relu = relu;
   const int TZ = nd == 3 ? 4 : 1, TY = nd == 3 ? 4 : 16;
   const long long tiles = (long long)N * ((D + TZ - 1) / TZ) * ((H + TY - 1) / TY) * ((W + 15) / 16);
   IUNET_REQUIRE(tiles < (1ll << 31), "f32 conv: too many tiles");
-  dim3 grid((unsigned)tiles, Cout / 32, transposed ? (nd == 3 ? 8 : 4) : 1);
+  dim3 grid((unsigned)tiles, Cout / 32, transposed == 1 ? (nd == 3 ? 8 : 4) : 1);
   if (nd == 3) {
     if (transposed) hipLaunchKernelGGL((f32_conv_kernel<3, true>), grid, dim3(256), 0, stream, p);
     else hipLaunchKernelGGL((f32_conv_kernel<3, false>), grid, dim3(256), 0, stream, p);

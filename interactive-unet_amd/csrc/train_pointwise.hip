@@ -966,6 +966,14 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     else hipLaunchKernelGGL((kern<bf16>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); \
   } while (0)
 
+// (train_f32.hip: the fp32 parity form of the head + loss forward shares the finalize pass)
+int iunet_loss_finalize_launch(const float* slab, int nparts, int ncls, int kind, int has_weight, double nvox_total, float* out4,
+                               float* coef, hipStream_t stream) {
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, stream, slab, nparts, ncls, kind, has_weight, nvox_total, out4, coef);
+  IUNET_CHECK_HIP(hipGetLastError());
+  return IUNET_OK;
+}
+
 extern "C" {
 
 int iunet_bn_finalize(const void* slab, int nparts, int C, double count, const void* gamma, const void* beta,

@@ -46,6 +46,20 @@ _SIGS = {
     'iunet_f32_maxpool_fwd': [c_int, c_void_p, c_ll, c_void_p, c_ll, c_int, c_int, c_int, c_int, c_int, c_void_p],
     'iunet_f32_head_fwd': [c_void_p, c_ll, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                            ctypes.POINTER(c_ll), c_float, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    # ---- fp32 parity form of the training step (csrc/train_f32.hip)
+    'iunet_f32_bn_stats': [c_void_p, c_ll, c_int, c_int, c_ll, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    'iunet_f32_bn_relu_fwd': [c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_ll, c_void_p],
+    'iunet_f32_bn_relu_bwd': [c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                              c_int, c_int, c_ll, c_void_p],
+    'iunet_f32_maxpool_bwd': [c_int, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_ll, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    'iunet_f32_wgrad_splits': [c_int] * 7,
+    'iunet_f32_wgrad': [c_int, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    'iunet_f32_head_loss_num_parts': [c_int, c_ll],
+    'iunet_f32_head_loss_fwd': [c_void_p, c_ll, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
+                                c_void_p, c_int, c_ll, c_void_p],
+    'iunet_f32_head_loss_bwd': [c_void_p, c_ll, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_ll,
+                                c_void_p, c_ll, c_int, c_ll, c_void_p],
+    'iunet_f32_channel_sum': [c_void_p, c_ll, c_void_p, c_int, c_int, c_ll, c_void_p],
     # ---- fp16x2 split precision (the tolerance-meeting mode on the 16-bit matrix cores)
     'iunet_x2_prep': [c_void_p] * 9 + [c_float, c_float, c_float, c_int, c_int, c_int, c_int, c_int, c_void_p],
     'iunet_x2_first_conv_fwd': [c_int, c_void_p, c_int, ctypes.POINTER(c_ll), c_void_p, c_ll, c_int, c_void_p, c_void_p, c_void_p,

@@ -16,7 +16,7 @@ import warnings
 import torch
 
 from . import metrics, unet
-from .train_engine import TrainEngine
+from .train_engine_f32 import make_train_engine
 
 METRICS = ('Loss', 'Dice', 'IoU', 'MCC')
 
@@ -65,7 +65,7 @@ def train_model(lr=0.0001, batch_size=1, epochs=10, num_channels=1, num_classes=
     if rank0:
         os.makedirs(log_dir, exist_ok=True)
     fields = ['epoch', 'step'] + [f'train/{m}' for m in METRICS] + [f'val/{m}' for m in METRICS]
-    engine = TrainEngine(model, lr=lr, loss_kind=loss_function.native_kind, process_group=process_group)
+    engine = make_train_engine(model, lr=lr, loss_kind=loss_function.native_kind, process_group=process_group)
     model.train()
     best, step = float('inf'), 0
     for epoch in range(epochs):

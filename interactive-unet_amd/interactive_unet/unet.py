@@ -12,8 +12,9 @@ Numeric modes.  The reference TRAINS under `precision='16-mixed'` (trainer.py:59
 The default module (act_dtype=None) does the same: native training with fp16 activations, `forward()` / prediction in the
 split-precision mode 'fp16x2' (engine_x2.py: every value two fp16 words, three 16-bit MFMAs per product; logits within
 1e-3 of the CPU fp32 path, class map exact).  An explicit act_dtype selects one mode for both: 'fp16' / 'bf16' = 16-bit
-activations on the matrix cores (the throughput path: logits off the fp32 path by 4e-3 / 3e-2); 'fp16x2' and 'fp32' (the
-f32-input matrix instruction, engine_f32.py, 1/16 of the 16-bit rate) are inference-only.  `infer_dtype` overrides the
+activations on the matrix cores (the throughput path: logits off the fp32 path by 4e-3 / 3e-2); 'fp32' = the f32-input matrix
+instruction for prediction (engine_f32.py) AND training (train_engine_f32.py: the parity form of the step, gradients within 1e-4 of
+CPU autograd), 1/16 of the 16-bit rate; 'fp16x2' is inference-only.  `infer_dtype` overrides the
 mode of `forward()` alone.
 """
 import math
@@ -239,11 +240,11 @@ class UNet(nn.Module):
         """The native training engine bound to this module (created on first use: it re-homes the parameters in one flat tensor)."""
         te = getattr(self, '_train_engine', None)
         if te is None or te.dev != self.device:
-            from .train_engine import TrainEngine
+            from .train_engine_f32 import make_train_engine
             lk = getattr(self.loss_function, 'native_kind', None)
             if lk is None:
                 raise NotImplementedError(f'loss_function {self.loss_function!r} has no native kernel: use one of metrics.py\'s seven')
-            te = TrainEngine(self, lr=self.lr, loss_kind=lk)
+            te = make_train_engine(self, lr=self.lr, loss_kind=lk)       # act_dtype='fp32': the fp32 parity form of the step
             object.__setattr__(self, '_train_engine', te)
         return te
 
