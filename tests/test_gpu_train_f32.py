@@ -238,7 +238,10 @@ def test_whole_step_against_cpu_autograd(dim, shape, ncls, loss_name, weighted):
     new = {k: t.detach().clone() for k, t in pr.items()}
     mm = {k: torch.zeros_like(v) for k, v in new.items()}
     vv = {k: torch.zeros_like(t) for k, t in new.items()}
-    unet_ref.adamw_step(new, want, mm, vv, 1, lr)
+    # (AdamW's first step moves every entry by ~lr whatever the gradient's size, so it is applied to the DEVICE's gradients here: an
+    #  entry with |g| ~ 1e-8 would turn the 1e-5 gradient noise into a different step; the kernel itself is what is under test)
+    dev_g = {n: flat[te.offsets[n][0]:te.offsets[n][0] + te.offsets[n][1]].cpu().reshape(want[n].shape) for n in te.names}
+    unet_ref.adamw_step(new, dev_g, mm, vv, 1, lr)
     cnt = X.numel() / X.shape[1]
     te.optimizer_step()
     torch.cuda.synchronize()
@@ -252,9 +255,7 @@ def test_whole_step_against_cpu_autograd(dim, shape, ncls, loss_name, weighted):
         else:
             ref = new[name]
         d = (t.detach().cpu() - ref).abs().max().item()
-        # AdamW's first step moves every entry by ~lr whatever the gradient's size: entries with |g| ~ 1e-8 amplify the 1e-5 relative
-        # gradient noise, so the parameters are held to a fraction of the step, the statistics tightly
-        assert d <= (2e-6 if unet_ref.is_buffer(name) else 0.05 * lr) * max(1.0, ref.abs().max().item()), (name, d)
+        assert d <= 2e-6 * max(1.0, ref.abs().max().item()), (name, d)
     # the Lightning-shaped API rides on the same engine
     loss2 = m.training_step((X, y, w))
     loss2.backward()
