@@ -262,3 +262,44 @@ def test_whole_step_against_cpu_autograd(dim, shape, ncls, loss_name, weighted):
     assert m.tensor('head.weight').grad is not None
     ev = te.eval_step(X, y, w)
     assert np.isfinite(ev['Loss'])
+
+
+@pytest.mark.parametrize('dim,shape,dtype', [(3, (32, 64, 64), 'bf16'), (2, (256, 256), 'fp16')])
+def test_16_bit_step_against_the_fp32_form_on_the_device(dim, shape, dtype):
+    """The fp32 form as the device-side checker of the 16-bit training path at a size where CPU autograd takes minutes: same weights,
+    same batch, one step each.  With 10^5 .. 10^6 elements per channel the mask flips of the 16-bit storage noise average out, so
+    the two gradients must point the same way tensor by tensor (the 32 x 48-pixel CPU comparison of test_gpu_train.py can only ask
+    for cos > 0.85 on the deep tensors)."""
+    from interactive_unet.unet import UNet
+    from interactive_unet.train_engine import TrainEngine
+    N, ncls = 2, 2
+    p = unet_ref.init_params(dim=dim, ncls=ncls, seed=5)
+    g = torch.Generator(device='cuda').manual_seed(0)
+    X = torch.rand((N, 1) + tuple(s // 4 for s in shape), generator=g, device='cuda')
+    X = F.interpolate(X, size=shape, mode='trilinear' if dim == 3 else 'bilinear', align_corners=False)
+    lab = X[:, 0] > X.mean()
+    y = torch.stack([~lab, lab], 1).float()
+    w = (torch.rand((N, 1) + shape, generator=g, device='cuda') > 0.2).float().expand(N, ncls, *shape).contiguous()
+    y = y * w
+    grads = {}
+    for name in ('fp32', dtype):
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            m = UNet(lr=1e-3, num_classes=ncls, dim=dim, act_dtype=name, pretrained=False)
+        m.load_named(p)
+        m = m.cuda()
+        te = m.train_engine()
+        out4, state = te.step_forward(X, y, w)
+        flat, _ = te.step_backward(state)
+        torch.cuda.synchronize()
+        grads[name] = (out4[0].item(), flat.clone(), dict(te.offsets), list(te.names))
+        del te, m
+    l32, g32, offs, names = grads['fp32']
+    l16, g16, _, _ = grads[dtype]
+    assert abs(l32 - l16) <= (2e-3 if dtype == 'fp16' else 1e-2), (l32, l16)
+    cos = lambda a, b: torch.nn.functional.cosine_similarity(a, b, dim=0).item()
+    worst = min(((n, cos(g32[offs[n][0]:offs[n][0] + offs[n][1]], g16[offs[n][0]:offs[n][0] + offs[n][1]])) for n in names), key=lambda t: t[1])
+    total = cos(g32, g16)
+    print(f'[{dtype} vs fp32 form, {dim}-D {N} x {shape}] loss {l16:.5f} vs {l32:.5f}; cos(whole gradient) = {total:.5f}; worst tensor {worst[0]}: {worst[1]:.4f}')
+    assert total >= (0.999 if dtype == 'fp16' else 0.99), total
+    assert worst[1] >= (0.98 if dtype == 'fp16' else 0.9), worst
