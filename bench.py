@@ -283,13 +283,13 @@ def cpu_baseline(cfg, model=None, chunk_u8=None):
     for it in range(reps + 1):
         if it == 1:
             t0 = time.time()                                   # first iteration warms the thread pool
-        probs = unet_ref.forward(pr, x, dim=dim, levels=levels, training=True)
+        probs = unet_ref.forward(pr, x, dim=dim, levels=levels, training=True, norm=cfg.get('norm', 'batch'))
         loss = host_metrics.mcc_ce_loss(probs, y, None, axes=axes)
         grads = torch.autograd.grad(loss, [t for k, t in pr.items() if t.requires_grad])
         with torch.no_grad():
             g = dict(zip([k for k, t in pr.items() if t.requires_grad], grads))
             unet_ref.adamw_step({k: t.data for k, t in pr.items()}, g, m, v, it + 1, 1e-4)
-            unet_ref.forward(pr, x, dim=dim, levels=levels)
+            unet_ref.forward(pr, x, dim=dim, levels=levels, norm=cfg.get('norm', 'batch'))
     dt = time.time() - t0
     nvox = int(np.prod(shp))
     out = {'value': round(reps * 2 * nvox / dt, 1), 'unit': 'voxels/s', 'cores': cores, 'kind': 'port',
@@ -403,6 +403,8 @@ def main():
     ap.add_argument('--c4-reps', type=int, default=1, help='c3 only: timed 1024^3 predictions appended to the line (0 = skip)')
     ap.add_argument('--c4-size', type=int, default=1024)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--norm', default='batch', choices=['batch', 'group'], help="'group': GroupNorm(8) instead of BatchNorm after every stage conv "
+                    "(north_star 'GroupNorm/BN'); statistics per (sample, group) at training and inference, nothing folds")
     ap.add_argument('--no-2p5d', action='store_true', help='skip legs.predict_2p5d (the reference-semantics 2.5-D block prediction)')
     ap.add_argument('--no-parity-mode', action='store_true', help='skip the second timed region (prediction leg in fp16x2)')
     args = ap.parse_args()
@@ -447,7 +449,8 @@ def main():
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
         model = UNet(lr=1e-4, num_classes=ncls, dim=dim, levels=levels, base=base, act_dtype=cfg['dtype'], pretrained=False,
-                     weight_dtype=cfg['wq'])
+                     weight_dtype=cfg['wq'], norm=args.norm)
+    cfg['norm'] = args.norm
     model.reset_parameters(seed=0)                                      # random-init weights of the canonical architecture
     model = model.to(dev)
     fpv = flops_per_voxel(dim, levels, base, 1, ncls)
@@ -590,7 +593,7 @@ def main():
     # by default; the reference trains under '16-mixed' and predicts in fp32, trainer.py:59 / predict.py:30-35).  Timed exactly as
     # `value` is: warm-up, barrier, K steps, barrier, max over ranks.
     pm = None
-    if not cfg['wq'] and not args.no_parity_mode:
+    if not cfg['wq'] and not args.no_parity_mode and args.norm == 'batch':      # (the split-precision mode folds BatchNorm into its operators)
         model.infer_dtype, model._engines, model._packed_sig = 'fp16x2', {}, None
         if dim == 3:
             ops = shard.NativeOps(model, ncls, S)                 # (step / predict_leg look `ops` up at call time)
@@ -631,10 +634,14 @@ def main():
     if rank == 0:
         # `roofline` top level = the layer alone, back to back (the figure `rocprofv3 --kernel-trace --stats` of tools/bench_conv.py
         # reproduces: profiles/r03_roofline_*); the launches inside real steps are the `in_situ` sub-object
-        in_situ = conv_roofline_in_situ(nv, cfg, args.workload, dtype, probe_events[:400])
-        roof = conv_roofline_back_to_back(nv, cfg, args.workload, dtype, in_situ['tiles_per_launch'])
-        roof['traffic'] = in_situ.pop('traffic')
-        roof['in_situ'] = in_situ
+        if probe_events:
+            in_situ = conv_roofline_in_situ(nv, cfg, args.workload, dtype, probe_events[:400])
+            roof = conv_roofline_back_to_back(nv, cfg, args.workload, dtype, in_situ['tiles_per_launch'])
+            roof['traffic'] = in_situ.pop('traffic')
+            roof['in_situ'] = in_situ
+        else:                                     # (GroupNorm: the engines' timing hook sits in the BatchNorm launch path)
+            roof = conv_roofline_back_to_back(nv, cfg, args.workload, dtype, max(1, B if dim == 3 else B))
+            roof['traffic'] = pmc_traffic(args.workload, roof['tiles_per_launch'])
         if dim == 3 and roof['tiles_per_launch'] != 1:
             roof['back_to_back_1_tile'] = conv_roofline_back_to_back(nv, cfg, args.workload, dtype, 1)
         tile_s = 'x'.join(str(s) for s in tile)
@@ -645,7 +652,7 @@ def main():
                     f'softmax, point-to-point exchange of the probability pieces in 8 rounds overlapped with the forwards, blend in '
                     f'flat block order by the slab owners, normalise/quantise; wall time includes every exchange')
         else:
-            desc = (f'{args.workload.upper()}: {dim}-D U-Net {levels}-level base {base}, 1->{ncls} classes, {cfg["dtype"]}'
+            desc = (f'{args.workload.upper()}: {dim}-D U-Net {levels}-level base {base}{", GroupNorm(8)" if args.norm == "group" else ""}, 1->{ncls} classes, {cfg["dtype"]}'
                     f'{", inference weights e4m3" if cfg["wq"] else ""}; {B} x {tile_s} uint8 tiles per GPU per step; step = 1 training '
                     f'step (forward with BatchNorm batch stats, MCC+CE loss, backward, AdamW, weight re-pack; gradients all-reduced '
                     f'over RCCL for N > 1) on the {B} tiles + ' +
@@ -683,9 +690,13 @@ def main():
             probe = my_slab[:S, :S, :S].contiguous()
         else:
             probe = chunks[0]
-        out['parity'], _ = native_parity(model, cfg, probe)
+        if args.norm == 'batch':
+            out['parity'], _ = native_parity(model, cfg, probe)
+        else:
+            out['parity'] = {'skipped': 'the fp32 and fp16x2 modes fold BatchNorm; the GroupNorm network is checked against the oracle '
+                                        'in tests/test_gpu_groupnorm.py'}
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'], chk = cpu_baseline(cfg, model, probe)
+            out['cpu_baseline'], chk = cpu_baseline(cfg, model if args.norm == 'batch' else None, probe)
             if chk:
                 out['parity']['vs_cpu_oracle'] = chk
         if args.workload in ('c3', 'c2') and not args.no_2p5d:

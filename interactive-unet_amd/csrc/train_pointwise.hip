@@ -298,7 +298,10 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
 }
 
 // pass 2: dy = a * (dyh - c1 - xhat * c2); plane = grid dimension (wave-uniform constants), two items per thread
-template <typename T>
+// GN (GroupNorm form): coef = (gamma invstd, invstd m1, invstd m2) and dy = a dz' - b1 - xhat b2 -- the statistics of a GROUP depend on
+// every channel of it, so a channel with gamma = 0 still has the gradient -invstd (m1 + xhat m2), which the BatchNorm factorisation
+// a (dz' - c1 - xhat c2) (a = gamma invstd) cannot express.
+template <typename T, bool GN = false>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dz, long long dz_ss, const T* __restrict__ z,
                                                            long long z_ss, const T* __restrict__ y, long long y_ss,
                                                            T* __restrict__ dy, long long dy_ss, const float* __restrict__ mean,
@@ -336,7 +339,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
       const float zv = z ? to_f32<T>(zz[u][j]) : to_f32<T>(from_f32<T>(fmaf(sc[j], yv, sh[j])));
       const float d = zv > 0.f ? to_f32<T>(g[u][j]) : 0.f;
       const float xh = (yv - mu[j]) * is[j];
-      o[j] = from_f32<T>(ca[j] * (d - c1[j] - xh * c2[j]));
+      o[j] = from_f32<T>(GN ? ca[j] * d - c1[j] - xh * c2[j] : ca[j] * (d - c1[j] - xh * c2[j]));
     }
     *(V8T<T>*)(dy + n * dy_ss + base + v * 8) = o;
   }
@@ -407,7 +410,7 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict
 // mean / invstd: s1 = sum dz', s2 = sum dz' * xhat (dz' = dz where relu passed).  One block of C threads (C <= 1024):
 //   dgamma[c] = sum_n s2, dbeta[c] = sum_n s1;
 //   per (n, group): m1 = sum_c gamma_c s1 / M, m2 = sum_c gamma_c s2 / M, M = channels per group x voxels;
-//   dy = invstd_g (gamma_c dz' - m1 - xhat m2) = a (dz' - c1 - xhat c2) with coef[n][c] = (gamma_c invstd, m1 / gamma_c, m2 / gamma_c)
+//   dy = invstd_g (gamma_c dz' - m1 - xhat m2) = a dz' - b1 - xhat b2 with coef[n][c] = (gamma_c invstd, invstd m1, invstd m2)
 __global__ __launch_bounds__(1024) void gn_bwd_finalize_kernel(const float* __restrict__ slab, int chunks, int C, int groups, int N,
                                                               double vox, const float* __restrict__ gamma,
                                                               const float* __restrict__ invstd, float* dgamma, float* dbeta,
@@ -432,10 +435,10 @@ __global__ __launch_bounds__(1024) void gn_bwd_finalize_kernel(const float* __re
       double m1 = 0.0, m2 = 0.0;
       for (int k = 0; k < cpg; ++k) { m1 += gs[0][g0 + k]; m2 += gs[1][g0 + k]; }
       const double M = vox * cpg;
-      const float gsafe = gam != 0.f ? gam : 1e-20f;            // gamma = 0: the channel's own term vanishes with a = 0
-      coef[((long long)n * C + c) * 3 + 0] = gam * invstd[n * C + c];
-      coef[((long long)n * C + c) * 3 + 1] = (float)(m1 / M) / gsafe;
-      coef[((long long)n * C + c) * 3 + 2] = (float)(m2 / M) / gsafe;
+      const float is = invstd[n * C + c];
+      coef[((long long)n * C + c) * 3 + 0] = gam * is;
+      coef[((long long)n * C + c) * 3 + 1] = is * (float)(m1 / M);
+      coef[((long long)n * C + c) * 3 + 2] = is * (float)(m2 / M);
     }
   }
   if (c < C) { dgamma[c] = (float)dg; dbeta[c] = (float)db; }
@@ -1125,8 +1128,8 @@ int iunet_gn_relu_bwd(int dtype, const void* dz, long long dz_ss, const void* y,
     const float *mu = (const float*)mean + (long long)n * C, *is = (const float*)invstd + (long long)n * C;
     const float *sc = (const float*)scale + (long long)n * C, *sh = (const float*)shift + (long long)n * C;
     const float* cf = (const float*)coef + (long long)n * C * 3;
-    if (dtype == 0) hipLaunchKernelGGL(bn_bwd_apply_kernel<f16>, g2, dim3(256), 0, (hipStream_t)stream, (const f16*)dzn, dz_ss, (const f16*)nullptr, 0LL, (const f16*)yn, y_ss, (f16*)dyn, dy_ss, mu, is, cf, sc, sh, C / 8, vox);
-    else hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16>, g2, dim3(256), 0, (hipStream_t)stream, (const bf16*)dzn, dz_ss, (const bf16*)nullptr, 0LL, (const bf16*)yn, y_ss, (bf16*)dyn, dy_ss, mu, is, cf, sc, sh, C / 8, vox);
+    if (dtype == 0) hipLaunchKernelGGL((bn_bwd_apply_kernel<f16, true>), g2, dim3(256), 0, (hipStream_t)stream, (const f16*)dzn, dz_ss, (const f16*)nullptr, 0LL, (const f16*)yn, y_ss, (f16*)dyn, dy_ss, mu, is, cf, sc, sh, C / 8, vox);
+    else hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16, true>), g2, dim3(256), 0, (hipStream_t)stream, (const bf16*)dzn, dz_ss, (const bf16*)nullptr, 0LL, (const bf16*)yn, y_ss, (bf16*)dyn, dy_ss, mu, is, cf, sc, sh, C / 8, vox);
   }
   IUNET_CHECK_HIP(hipGetLastError());
   return IUNET_OK;

@@ -22,6 +22,7 @@ def test_gn_relu_fwd_bwd_vs_torch(nv, dtype, N, C, groups, sp):
     y[:, 3] *= 4.0                                                   # channels of one group with different ranges
     dz = (torch.randn((N, C) + sp, generator=g)).to(dtype).float()
     gamma = 0.5 + torch.rand(C, generator=g)
+    gamma[1] = 0.0                                                   # a channel with gamma = 0 still gets -invstd (m1 + xhat m2) through the group statistics
     beta = 0.3 * torch.randn(C, generator=g)
     yr = y.clone().requires_grad_(True)
     gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)

@@ -203,3 +203,24 @@ def test_reference_layout_128_chunks_in_256_shards(tmp_path):
     back = zarr3.open(str(tmp_path / 'p.zarr'))['0']
     assert back.chunks == (128, 128, 128, 2) and back.shards == (256, 256, 256, 2)
     assert torch.equal(back.to_device('cpu'), vol)
+
+
+def test_round_trip_with_zarr_python_when_available(tmp_path):
+    """The reference app reads the stores this writer produces with zarr-python 3 (pyproject.toml:23).  The package is absent from the
+    build image (the writer is pinned against spec-derived shard files above), so this runs wherever it IS installed: write with
+    zarr3.py / read with zarr-python, and the reverse, chunk layout of predict.py:173-180."""
+    zarr = pytest.importorskip('zarr', minversion='3.0')
+    import numpy as np
+    from interactive_unet import zarr3
+    rng = np.random.default_rng(0)
+    data = rng.integers(0, 256, (40, 36, 33, 2), dtype=np.uint8)
+    path = str(tmp_path / 'ours.zarr')
+    arr = zarr3.open(path, mode='w').create_array(name='0', shape=list(data.shape), dtype='uint8', overwrite=True,
+                                                  chunks=(16, 16, 16, 2), shards=(32, 32, 32, 2))
+    arr[...] = data
+    assert np.array_equal(zarr.open(path, mode='r')['0'][...], data)
+    path2 = str(tmp_path / 'theirs.zarr')
+    root = zarr.open(path2, mode='w')
+    a2 = root.create_array(name='0', shape=data.shape, dtype='uint8', chunks=(16, 16, 16, 2), shards=(32, 32, 32, 2))
+    a2[...] = data
+    assert np.array_equal(zarr3.open(path2, mode='r')['0'][...], data)
