@@ -1,18 +1,24 @@
 """Merge gpurun_out/levels_<tag>/* (tools/level_report.sh) into profiles/<round>_conv_levels_<tag>.md.
-    python tools/level_report.py [tag=3d] [round=r02]"""
+    python tools/level_report.py [tag=3d] [round=r03]        (a tag beginning with x2: the split-precision conv, tools/level_report.sh ... "--x2 2")"""
 import csv, glob, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag_ = sys.argv[1] if len(sys.argv) > 1 else '3d'
-rnd = sys.argv[2] if len(sys.argv) > 2 else 'r02'
+rnd = sys.argv[2] if len(sys.argv) > 2 else 'r03'
+x2 = tag_.startswith('x2')
 L = os.path.join(ROOT, 'gpurun_out', f'levels_{tag_}')
 rows, head = [], None
 for f in sorted(glob.glob(os.path.join(L, 'time_*.txt'))):
     tag = os.path.basename(f)[5:-4]
     line = open(f).readline()
-    m = re.search(r'L(\d)\s+(\d+)->\s*(\d+) @(\d+)\^(\d) N=(\d+) layout (\d): fwd\s+([\d.]+) us\s+([\d.]+) TF/s', line)
+    if x2:      # "... | fp16x2 553.7 us 418.9 TF/s algorithmic = 1256.6 TF/s of MFMA work ..."
+        m = re.search(r'L(\d)\s+(\d+)->\s*(\d+) @(\d+)\^(\d) N=(\d+) layout (\d):.*fp16x2\s+([\d.]+) us\s+[\d.]+ TF/s algorithmic =\s+([\d.]+) TF/s', line)
+    else:
+        m = re.search(r'L(\d)\s+(\d+)->\s*(\d+) @(\d+)\^(\d) N=(\d+) layout (\d): fwd\s+([\d.]+) us\s+([\d.]+) TF/s', line)
     if not m:
         continue
     lvl, cin, cout, S, nd, n, lay, us, tf = m.groups()
+    if x2:
+        lay = 'split (3 x K16)'
     def ctr(kind, name):
         g = glob.glob(os.path.join(L, f'{kind}_{tag}', '**', '*_counter_collection.csv'), recursive=True)
         if not g:
@@ -26,13 +32,15 @@ for f in sorted(glob.glob(os.path.join(L, 'time_*.txt'))):
     nd, n = int(nd), int(n)
     vox = int(S) ** nd * n
     alg = (int(cin) + int(cout)) * 2 * vox + int(cin) * int(cout) * 3 ** nd * 2      # activations once in, once out + the filter once
+    if x2:
+        alg *= 2                                                                        # hi + lo words of everything
     traffic = (2 * fetch + write) * 1024 if fetch is not None and write is not None else None
     head = (nd, n)
     rows.append((lvl, cin, cout, S, lay, float(us), float(tf), util, alg, traffic, nd))
 out = os.path.join(ROOT, 'profiles', f'{rnd}_conv_levels_{tag_}.md')
 with open(out, 'w') as o:
     nd, n = head
-    o.write(f'# 3^{nd} conv forward per resolution level ({n} x level-0 tile per launch) -- rocprofv3 PMC, MI355X\n\n')
+    o.write(f'# 3^{nd} conv forward per resolution level ({n} x level-0 tile per launch){" -- SPLIT PRECISION (fp16x2: TFLOP/s = MFMA work, 3 MFMAs per product; algorithmic = a third)" if x2 else ""} -- rocprofv3 PMC, MI355X\n\n')
     o.write('time / TFLOP/s: HIP events over 30 back-to-back launches (tools/bench_conv.py); MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / '
             '(GRBM_GUI_ACTIVE / 8 x 1024 SIMDs); HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE (gfx950 FETCH_SIZE correction), separate '
             'passes; algorithmic MB = activations once in + once out + the filter once; % of peak vs 2.5 PFLOP/s dense 16-bit MFMA and 8 TB/s.  '
