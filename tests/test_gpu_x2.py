@@ -216,3 +216,41 @@ def test_network_small_shapes(dim, shape, cin, ncls, in_dtype):
     r = _compare(f'fp16x2 {dim}-D {shape} cin={cin}', *_forward(e, xd, dim, ncls), ref, _labels(img, ncls))
     _assert_fp32_mode(r)
     assert r['err'] <= 1e-4 * max(1.0, r['scale'])
+
+
+def test_c5_geometry_in_split_precision():
+    """5 levels, base 64, 4 classes (the network of BASELINE.json configs[4]) in fp16x2: 1 024 real = 3 072 virtual input channels at the
+    widest decoder conv.  Against the fp32 oracle on a small block."""
+    from tests.test_gpu_parity import _smooth, _forward, _compare, _assert_fp32_mode, _labels
+    from interactive_unet.engine_x2 import EngineX2
+    dim, shape, ncls = 3, (16, 16, 32), 4
+    p = unet_ref.init_params(dim=dim, levels=5, base=64, ncls=ncls, seed=4, randomize_bn=True)
+    img = np.stack([_smooth(shape, 3 + i) for i in range(1)])[:, None]
+    x = torch.tensor(img)
+    ref = unet_ref.forward_logits(p, x.float() / 255.0, dim=dim, levels=5)
+    e = EngineX2(dim=dim, levels=5, base=64, ncls=ncls)
+    e.load_eval({k: v.cuda() for k, v in p.items()})
+    r = _compare('fp16x2 3-D 5 levels base 64', *_forward(e, x.cuda(), dim, ncls), ref, _labels(img, ncls))
+    _assert_fp32_mode(r)
+
+
+def test_activations_beyond_the_fp16_range_saturate_finite():
+    """act_scale x |activation| above 65504 clamps (split16): the result stays finite, and with a smaller act_scale the same network is
+    exact again -- the documented range of the mode (|activation| <= 65504 / act_scale = 1 023 at the default 2^6)."""
+    from interactive_unet.engine_x2 import EngineX2
+    dim, shape = 2, (32, 32)
+    p = unet_ref.init_params(dim=dim, ncls=2, seed=2, randomize_bn=True)
+    p['enc0.bn1.weight'] = p['enc0.bn1.weight'] * 4000.0                 # activations of the first layer in the thousands
+    x = torch.rand((1, 1) + shape)
+    ref = unet_ref.forward_logits(p, x, dim=dim)
+    assert torch.isfinite(ref).all()
+    out = {}
+    for scale in (64.0, 1.0):
+        e = EngineX2(dim=dim, act_scale=scale)
+        e.load_eval({k: v.cuda() for k, v in p.items()})
+        lg = torch.empty((1, 2) + shape, device='cuda')
+        e.infer(x.cuda(), (1024, 1024, 1024, 32, 1), 1, 1, 32, 32, logits=lg)
+        torch.cuda.synchronize()
+        out[scale] = lg.cpu()
+        assert torch.isfinite(out[scale]).all()
+    assert (out[1.0] - ref).abs().max().item() <= 1e-3 * max(1.0, ref.abs().max().item())
