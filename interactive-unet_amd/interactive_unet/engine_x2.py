@@ -202,6 +202,21 @@ class EngineX2:
                 self.act_scale, self.ncls, nv.ptr(logits), nv.ptr(probs), nv.ptr(cls), nv.ll_array(out_strides),
                 float(divisor), int(bool(accumulate)), N, D, H, W, s)
 
+    # ------------------------------------------------------------------ range check
+    def max_stored(self):
+        """Largest |stored hi word| of the last forward's activations (a host-synchronising diagnostic, never on the hot path).  The
+        mode keeps act_scale x activation in fp16: a value of 65504 means an activation saturated (|activation| >= 65504 / act_scale
+        = 1 023 at the default 2^6) and the result is no longer within tolerance -- lower act_scale for such a model."""
+        m = 0.0
+        for ws in self._ws_cache.values():
+            for k, t in ws.items():
+                if k != 'dims':
+                    m = max(m, float(t.abs().max()))
+        return m
+
+    def saturated(self):
+        return self.max_stored() >= 65504.0
+
     # ------------------------------------------------------------------ layout helpers (tests)
     def to_split(self, t):
         """fp32 [N, C, *spatial] -> flat split tensor [N][C/8 hi planes | C/8 lo planes][*spatial][8] of act_scale * t."""

@@ -306,6 +306,10 @@ def predict_volumes(input_size=256, num_channels=1, num_classes=2, overlap=0.25,
         start = time.time()
         volume = zarr3.open(f, mode='r')['0'].to_device(device)
         final = predict_volume_array(model, volume, input_size, num_classes, overlap, batch_size, axes)
+        eng = model.engine('eval')
+        if getattr(eng, 'saturated', None) is not None and eng.saturated():      # split precision keeps act_scale x activation in fp16
+            print(f'WARNING: activations of this model exceed the fp16x2 range (stored {eng.max_stored():.0f}): predict with '
+                  f"UNet(infer_dtype='fp32') or a smaller act_scale")
         save_path = f.replace('image_volumes', 'predicted_volumes')
         root = zarr3.open(save_path, mode='w')
         arr = root.create_array(name='0', shape=list(final.shape), dtype='uint8', overwrite=True,

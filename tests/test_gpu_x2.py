@@ -253,4 +253,5 @@ def test_activations_beyond_the_fp16_range_saturate_finite():
         torch.cuda.synchronize()
         out[scale] = lg.cpu()
         assert torch.isfinite(out[scale]).all()
+        assert e.saturated() == (scale == 64.0), (scale, e.max_stored())          # the diagnostic sees the clamp
     assert (out[1.0] - ref).abs().max().item() <= 1e-3 * max(1.0, ref.abs().max().item())
