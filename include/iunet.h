@@ -239,6 +239,11 @@ int iunet_net_forward_argmax(iunet_net* net, const void* x_u8, void* cls_u8, int
 /* w fp32 [Cout][Cin][taps] (x an optional eval-mode BatchNorm fold, as iunet_f32_pack_conv) -> dst: iunet_f8_pack_conv3_bytes
  * bytes (K16 fragment order of iunet_conv3_pick_layout's layouts 1 / 2, one byte per element), wscale fp32 [Cout]: the
  * power-of-two scale 2^k, k minimal with max |w'| / 2^k <= 448, each weight = e4m3(w' / scale); bias_out fp32 [Cout]. */
+/* Operator order of a layer's e4m3 bytes: 0 = K16 ([cob32][chunk16][column pair][dy][2][64 lanes][8 B], v_mfma_f32_16x16x32_fp8_fp8),
+ * 1 = K128 (3-D layers with Cin % 32 == 0: per (32 Cout, 32 Cin) block [group 2][dy 3][m 2][half 2][64 lanes][16 B] +
+ * [dy 3][m 2][64][8 B] for the ninth filter column, 27 648 B; v_mfma_f32_16x16x128_f8f6f4, csrc/conv3_f8k.hip).  A function of the
+ * layer only; both pack entry points and iunet_conv3_f8_fwd follow it. */
+int iunet_f8_pack_order(int taps, int Cin);
 long long iunet_f8_pack_conv3_bytes(int Cout, int Cin, int taps);
 int iunet_f8_pack_conv3(const void* w, const void* gamma, const void* beta, const void* mean, const void* var, float eps,
                         void* dst, void* wscale, void* bias_out, int Cout, int Cin, int taps, void* stream);
@@ -250,6 +255,22 @@ long long iunet_conv3_f8_workspace_elems(int nd, int N, int D, int H, int W, int
 int iunet_conv3_f8_fwd(int dtype, int nd, const void* x, long long x_sstride, void* y, long long y_sstride, const void* wpk,
                        const void* wscale, const void* bias, int N, int D, int H, int W, int Cin, int Cout, int epi,
                        void* workspace, void* stream);
+/* e4m3 ACTIVATION PLANES between the layers of the fp8 network (format 1: C / 16 planes of [D][H][W][16 bytes]; sample strides in
+ * BYTES; format 0 = the 16-bit NHWC8c planes of every other entry point).  The K = 128 convolution (iunet_f8_pack_order == 1) reads
+ * them by LDS-DMA: half the bytes of the 16-bit tensor cross the L2 -> CU fabric, no conversion work in the loader waves.  Every
+ * producer rounds its 16-bit result once more to e4m3 -- the rounding the consumer conv's loader applies to a 16-bit tensor -- so the
+ * network's values do not depend on the format of the tensors in between (tests/test_gpu_f8.py).  Formats other than 0 are refused
+ * (IUNET_ERR_UNSUPPORTED) for layers on the K16 path.  max-pool: rounding is monotonic, the pooled bytes are the rounded maximum. */
+int iunet_conv3_f8_fwd_q(int dtype, int nd, const void* x, long long x_sstride, int x_fmt, void* y, long long y_sstride, int y_fmt,
+                         const void* wpk, const void* wscale, const void* bias, int N, int D, int H, int W, int Cin, int Cout, int epi,
+                         void* workspace, void* stream);
+int iunet_first_conv_fwd_q(int dtype, int nd, const void* x, int in_dtype, const long long* in_strides, void* y,
+                           long long y_sstride_bytes, const void* w, const void* bias, int N, int D, int H, int W,
+                           int Cin, int Cout, int relu, void* stream);
+int iunet_maxpool_q_fwd(int nd, const void* x, long long x_ss_bytes, void* y, long long y_ss_bytes, int C, int N, int Do, int Ho, int Wo,
+                        void* stream);
+int iunet_convT_fwd_q(int dtype, int nd, const void* x, long long x_ss, void* y, long long y_ss_bytes, const void* wpk,
+                      const void* bias, int N, int D, int H, int W, int Cin, int Cout, void* stream);
 
 /* ---- whole-volume prediction (predict.py:201-256) -------------------------------------- */
 /* get_padded_block (predict.py:291-316): reflect-padded S^3 uint8 block of a device volume. */

@@ -30,13 +30,18 @@ int iunet_pack_conv3_launch(int dtype, const float* w, const float* scale, void*
 int iunet_first_conv_launch(int dtype, int nd, const void* x, int in_dtype, long long sN, long long sC, long long sD,
                             long long sH, long long sW, void* y, long long y_sstride, const void* w,
                             const float* bias, float* stats, int N, int D, int H, int W, int Cin, int Cout, int relu,
-                            hipStream_t stream);
+                            hipStream_t stream, int out8 = 0);
 int iunet_pack_first_conv_launch(int dtype, const float* w, const float* scale, void* dst, int Cout, int Cin, int taps,
                                  hipStream_t stream);
 int iunet_maxpool_launch(int dtype, int nd, const void* x, long long x_ss, void* y, long long y_ss, int planes, int N,
                          int Do, int Ho, int Wo, hipStream_t stream);
 int iunet_convT_launch(int dtype, int nd, const void* x, long long x_ss, void* y, long long y_ss, const void* wpk,
-                       const float* bias, int N, int D, int H, int W, int Cin, int Cout, hipStream_t stream);
+                       const float* bias, int N, int D, int H, int W, int Cin, int Cout, hipStream_t stream, int out8 = 0);
+int iunet_maxpool_q_launch(int nd, const void* x, long long x_ss, void* y, long long y_ss, int planes16, int N, int Do, int Ho, int Wo,
+                           hipStream_t stream);
+int iunet_conv3_f8_launch_q(int dtype, int nd, const void* x, long long x_sstride, int x_fmt, void* y, long long y_sstride, int y_fmt,
+                            const void* wpk, const float* wscale, const float* bias, int N, int D, int H, int W, int Cin, int Cout,
+                            int epi, float* workspace, hipStream_t stream);
 int iunet_pack_convT_launch(int dtype, const float* w, void* dst, int Cin, int Cout, int npos, hipStream_t stream);
 int iunet_head_launch(int dtype, const void* x, long long x_ss, int C0, const float* w, const float* bias, int ncls,
                       float* logits, float* probs, unsigned char* cls, long long oN, long long oC, long long oD,
@@ -252,6 +257,8 @@ int iunet_f32_head_fwd(const void* x, long long x_ss, int C0, const void* w, con
 }
 
 /* ---- fp8 matrix cores (conv3_f8.hip): BASELINE config C5 ---------------------------------------------------- */
+int iunet_f8_pack_order(int taps, int Cin) { return iunet_f8_k128(taps, Cin); }
+
 long long iunet_f8_pack_conv3_bytes(int Cout, int Cin, int taps) {
   if (Cout <= 0 || Cout % 32 || Cin <= 0 || Cin % 32 || (taps != 9 && taps != 27)) return 0;
   return iunet_f8_pack_bytes(Cout, Cin, taps);
@@ -285,6 +292,57 @@ int iunet_conv3_f8_fwd(int dtype, int nd, const void* x, long long x_sstride, vo
   IUNET_REQUIRE(epi == 0 || bias != nullptr, "conv3_f8: epilogue %d needs a bias", epi);
   return iunet_conv3_f8_launch(dtype, nd, x, x_sstride, y, y_sstride, wpk, (const float*)wscale, (const float*)bias, N, D, H, W,
                                Cin, Cout, epi, (float*)workspace, (hipStream_t)stream);
+}
+
+/* e4m3 activation planes (format 1: C / 16 planes of [D][H][W][16 bytes], sample strides in BYTES) between the layers of the fp8
+ * network: what the K = 128 convolution reads by LDS-DMA.  Producers round their 16-bit result once more to e4m3 -- the rounding
+ * the consumer conv's loader would have applied -- so the network's values do not depend on the format of the tensors in between. */
+int iunet_conv3_f8_fwd_q(int dtype, int nd, const void* x, long long x_sstride, int x_fmt, void* y, long long y_sstride, int y_fmt,
+                         const void* wpk, const void* wscale, const void* bias, int N, int D, int H, int W, int Cin, int Cout, int epi,
+                         void* workspace, void* stream) {
+  DT_OK(dtype);
+  IUNET_REQUIRE(x && y && wpk && wscale, "conv3_f8_q: null pointer");
+  IUNET_REQUIRE(nd == 2 || nd == 3, "conv3_f8_q: nd must be 2 or 3");
+  IUNET_REQUIRE((x_fmt == 0 || x_fmt == 1) && (y_fmt == 0 || y_fmt == 1), "conv3_f8_q: formats are 0 (16-bit) or 1 (e4m3 planes)");
+  IUNET_REQUIRE_GRID("conv3_f8_q", N, D, H, W);
+  IUNET_REQUIRE(nd == 3 || D == 1, "conv3_f8_q: 2-D needs D == 1");
+  IUNET_REQUIRE(Cin >= 32 && Cout >= 32 && Cin % 32 == 0 && Cout % 32 == 0, "conv3_f8_q: channels must be positive multiples of 32 (%d, %d)", Cin, Cout);
+  IUNET_REQUIRE(epi >= 0 && epi <= 2, "conv3_f8_q: bad epilogue %d", epi);
+  IUNET_REQUIRE(epi == 0 || bias != nullptr, "conv3_f8_q: epilogue %d needs a bias", epi);
+  return iunet_conv3_f8_launch_q(dtype, nd, x, x_sstride, x_fmt, y, y_sstride, y_fmt, wpk, (const float*)wscale, (const float*)bias,
+                                 N, D, H, W, Cin, Cout, epi, (float*)workspace, (hipStream_t)stream);
+}
+
+int iunet_first_conv_fwd_q(int dtype, int nd, const void* x, int in_dtype, const long long* in_strides, void* y,
+                           long long y_sstride_bytes, const void* w, const void* bias, int N, int D, int H, int W,
+                           int Cin, int Cout, int relu, void* stream) {
+  DT_OK(dtype);
+  IUNET_REQUIRE(x && y && w && in_strides, "first_conv_q: null pointer");
+  IUNET_REQUIRE(in_dtype >= 0 && in_dtype <= 3, "first_conv_q: bad input dtype %d", in_dtype);
+  IUNET_REQUIRE(nd == 2 || nd == 3, "first_conv_q: nd must be 2 or 3");
+  IUNET_REQUIRE(nd == 3 || D == 1, "first_conv_q: 2-D needs D == 1");
+  IUNET_REQUIRE_GRID("first_conv_q", N, D, H, W);
+  return iunet_first_conv_launch(dtype, nd, x, in_dtype, in_strides[0], in_strides[1], in_strides[2], in_strides[3],
+                                 in_strides[4], y, y_sstride_bytes, w, (const float*)bias, nullptr, N, D, H, W, Cin, Cout, relu,
+                                 (hipStream_t)stream, 1);
+}
+
+int iunet_maxpool_q_fwd(int nd, const void* x, long long x_ss_bytes, void* y, long long y_ss_bytes, int C, int N, int Do, int Ho, int Wo,
+                        void* stream) {
+  IUNET_REQUIRE(x && y, "maxpool_q: null pointer");
+  IUNET_REQUIRE(nd == 2 || nd == 3, "maxpool_q: nd must be 2 or 3");
+  IUNET_REQUIRE(C > 0 && C % 16 == 0, "maxpool_q: C must be a positive multiple of 16 (got %d)", C);
+  IUNET_REQUIRE_GRID("maxpool_q", N, Do, Ho, Wo);
+  return iunet_maxpool_q_launch(nd, x, x_ss_bytes, y, y_ss_bytes, C / 16, N, Do, Ho, Wo, (hipStream_t)stream);
+}
+
+int iunet_convT_fwd_q(int dtype, int nd, const void* x, long long x_ss, void* y, long long y_ss_bytes, const void* wpk,
+                      const void* bias, int N, int D, int H, int W, int Cin, int Cout, void* stream) {
+  DT_OK(dtype);
+  IUNET_REQUIRE(x && y && wpk, "convT_q: null pointer");
+  IUNET_REQUIRE(nd == 2 || nd == 3, "convT_q: nd must be 2 or 3");
+  IUNET_REQUIRE_GRID("convT_q", N, D, H, W);
+  return iunet_convT_launch(dtype, nd, x, x_ss, y, y_ss_bytes, wpk, (const float*)bias, N, D, H, W, Cin, Cout, (hipStream_t)stream, 1);
 }
 
 }  // extern "C"

@@ -163,3 +163,46 @@ inline void iunet_brick_shape(int nd, int ncob, int tilesZ, int tilesY, int tile
   }
   *bz = z; *by = y; *bx = x;
 }
+
+// ---- e4m3 activation planes ("NHWC16c" bytes: C / 16 planes of [D][H][W][16 B]) -- what the K = 128 fp8 convolution reads by LDS-DMA.
+// 8 values of type T -> 8 OCP e4m3 bytes (round to nearest even, saturating at +-448): the conversion of the fp8 convs' loader waves
+template <typename T>
+__device__ __forceinline__ void e4m3_pack8(const u32x4 v, unsigned& lo, unsigned& hi) {
+  const typename Vec8<T>::type in = __builtin_bit_cast(typename Vec8<T>::type, v);
+  float f[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f[j] = __builtin_amdgcn_fmed3f(to_f32<T>(in[j]), -448.0f, 448.0f);
+  int a = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], 0, false);
+  a = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], a, true);
+  int b = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], 0, false);
+  b = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], b, true);
+  lo = (unsigned)a; hi = (unsigned)b;
+}
+// the 8 channels of 16-bit plane `pl8` at voxel `vox` of a tensor with `nvox` voxels per plane -> their half of an e4m3 granule
+// (y = the sample's base, bytes)
+template <typename T>
+__device__ __forceinline__ void e4m3_store8(unsigned char* y, int pl8, long long vox, long long nvox, const u32x4 v) {
+  unsigned lo, hi;
+  e4m3_pack8<T>(v, lo, hi);
+  typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+  *(u32x2_t*)(y + ((long long)(pl8 >> 1) * nvox + vox) * 16 + (pl8 & 1) * 8) = u32x2_t{lo, hi};
+}
+
+// ---- K = 128 operator order of the fp8 convolution (conv3_f8k.hip; written by pack_batch.hip kind 5 and conv3_f8.hip: pack_f8_kernel)
+// filter column (dz * 3 + dx) of K = 128 group g, lane group q: {0, 3, 1, 4 | 2, 5, 6, 7} -- the lane groups 0 / 1 and 2 / 3 of one
+// LDS pass differ in dz only; column 8 goes to the K = 32 instruction
+__host__ __device__ constexpr int f8k_col(int g, int q) {
+  return g == 0 ? (q == 0 ? 0 : q == 1 ? 3 : q == 2 ? 1 : 4) : (q == 0 ? 2 : q == 1 ? 5 : q == 2 ? 6 : 7);
+}
+constexpr int F8K_WSTEP = 2 * 3 * 2 * 2 * 1024 + 3 * 2 * 512;      // bytes of one (32 Cout, 32 Cin) block: 27 648
+// Byte offset, inside that block, of the 8 input channels 16 e + 8 o .. + 7 of filter column col, row shift dy, Cout half m,
+// operator row `row` (conv3_f8.hip's Cout map: co = 8 (row >> 2) + 4 m + (row & 3))
+__host__ __device__ inline int f8k_offset(int col, int dy, int m, int e, int o, int row) {
+  if (col == 8) return 2 * 3 * 2 * 2 * 1024 + ((dy * 2 + m) * 64 + (2 * e + o) * 16 + row) * 8;
+  int g = 0, q = 0;
+  for (int gg = 0; gg < 2; ++gg)
+    for (int qq = 0; qq < 4; ++qq)
+      if (f8k_col(gg, qq) == col) { g = gg; q = qq; }
+  return ((((g * 3 + dy) * 2 + m) * 2 + e) * 64 + q * 16 + row) * 16 + 8 * o;
+}
+int iunet_f8_k128(int taps, int Cin);        // conv3_f8k.hip: 1 = the K = 128 order (3-D, Cin % 32 == 0), 0 = the K16 order

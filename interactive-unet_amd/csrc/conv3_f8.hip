@@ -21,6 +21,10 @@
 #include <cstdlib>
 #include <type_traits>
 
+int iunet_conv3_f8k_launch(int dtype, const void* x, long long x_sstride, void* y, long long y_sstride, const void* wpk,
+                           const float* wscale, const float* bias, int N, int D, int H, int W, int Cin, int Cout, int epi,
+                           int ksplit, float* partial, int small, int in8, int out8, hipStream_t stream);
+
 namespace {
 
 typedef long i64;
@@ -388,7 +392,7 @@ __global__ __launch_bounds__(256) void pack_f8_kernel(const float* __restrict__ 
                                                       const float* __restrict__ beta, const float* __restrict__ mean,
                                                       const float* __restrict__ var, float eps, unsigned char* __restrict__ dst,
                                                       float* __restrict__ wscale, float* __restrict__ bias_out, int Cout, int Cin,
-                                                      int taps) {
+                                                      int taps, int k128) {
 #pragma clang fp contract(off)
   const int co = blockIdx.x;
   const float fs = gamma ? gamma[co] / sqrtf(var[co] + eps) : 1.0f;
@@ -426,7 +430,11 @@ __global__ __launch_bounds__(256) void pack_f8_kernel(const float* __restrict__ 
         pk |= (unsigned long long)f8_encode_e4m3(f8_round_e4m3((wc[(ci0 + j) * taps + tap] * fs) / sc)) << (8 * j);
     }
     const int lane = qq * 16 + row;
-    const long long o = ((((((long long)cob * nchunk + chunk) * ncmb + c) * 3 + dy) * 2 + mt) * 64 + lane) * 8;
+    long long o = ((((((long long)cob * nchunk + chunk) * ncmb + c) * 3 + dy) * 2 + mt) * 64 + lane) * 8;
+    if (k128) {                                      // conv3_f8k.hip's order: blocks of 32 input channels, no padded column
+      if (col >= ncol) continue;
+      o = ((long long)cob * (nchunk >> 1) + (chunk >> 1)) * F8K_WSTEP + f8k_offset(col, dy, mt, chunk & 1, qq & 1, row);
+    }
     *(unsigned long long*)(dst + o) = pk;
   }
 }
@@ -437,7 +445,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void f8_splitk_reduce_kernel(const float* __restrict__ partial, int ksplit, T* __restrict__ y,
                                                                long long y_ss, const float* __restrict__ wscale,
                                                                const float* __restrict__ bias, int N, int planes, long long vox,
-                                                               int epi) {
+                                                               int epi, int out8) {
   using V8 = typename Vec8<T>::type;
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= vox) return;
@@ -458,7 +466,12 @@ __global__ __launch_bounds__(256) void f8_splitk_reduce_kernel(const float* __re
     if (epi == 2) r = fmaxf(r, 0.f);
     o[j] = from_f32<T>(r);
   }
-  *(V8*)(y + n * y_ss + ((long long)pl * vox + i) * 8) = o;
+  if (!out8) { *(V8*)(y + n * y_ss + ((long long)pl * vox + i) * 8) = o; return; }
+  // e4m3 planes [Cout / 16][voxels][16 B], y_ss in bytes: the 16-bit result rounded once more (conv3_f8k.hip's epilogue)
+  unsigned o0, o1;
+  cvt8_e4m3<T>(__builtin_bit_cast(u32x4, o), o0, o1);
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  *(u32x2*)((unsigned char*)y + n * y_ss + ((long long)(pl >> 1) * vox + i) * 16 + (pl & 1) * 8) = u32x2{o0, o1};
 }
 
 }  // namespace
@@ -474,7 +487,7 @@ int iunet_conv3_f8_ksplit(int nd, int N, int D, int H, int W, int Cin, int Cout)
   const long long tiles = nd == 3 ? (long long)((D + 3) / 4) * ((H + 7) / 8) * ((W + 15) / 16)
                                   : (long long)((H + 15) / 16) * ((W + 31) / 32);
   const long long tasks = tiles * (Cout / 32);                   // (tile, Cout tile) pairs of one sample: one workgroup each
-  const int nchunk = Cin / (nd == 3 ? 16 : 32);
+  const int nchunk = Cin / ((nd == 3 && !iunet_f8_k128(27, Cin)) ? 16 : 32);      // steps of the Cin loop
   // measured on C5's 16^3 level (tools/bench_conv.py --f8 1, IUNET_F8_KSPLIT sweep): two shares win from Cin = 512 on
   // (512 -> 512: 69 -> 56 us, 1024 -> 512: 130 -> 88 us); four are slower again (more partial sums than they save), and
   // shorter loops (Cin <= 256) lose to the reduction pass
@@ -495,14 +508,21 @@ long long iunet_f8_pack_bytes(int Cout, int Cin, int taps) {
 int iunet_f8_pack_launch(const float* w, const float* gamma, const float* beta, const float* mean, const float* var, float eps,
                          void* dst, float* wscale, float* bias_out, int Cout, int Cin, int taps, hipStream_t stream) {
   hipLaunchKernelGGL(pack_f8_kernel, dim3(Cout), dim3(256), 0, stream, w, gamma, beta, mean, var, eps, (unsigned char*)dst, wscale,
-                     bias_out, Cout, Cin, taps);
+                     bias_out, Cout, Cin, taps, iunet_f8_k128(taps, Cin));
   IUNET_CHECK_HIP(hipGetLastError());
   return IUNET_OK;
 }
 
-int iunet_conv3_f8_launch(int dtype, int nd, const void* x, long long x_sstride, void* y, long long y_sstride, const void* wpk,
-                          const float* wscale, const float* bias, int N, int D, int H, int W, int Cin, int Cout, int epi,
-                          float* workspace, hipStream_t stream) {
+// x_fmt / y_fmt: 0 = 16-bit NHWC8c planes (strides in elements), 1 = e4m3 planes [C / 16][D][H][W][16 B] (strides in bytes; the K = 128
+// path only: 3-D, iunet_f8_k128).  An e4m3 output is the 16-bit result rounded once more -- bit for bit what a consumer conv's loader
+// makes of the 16-bit tensor -- so a chain of convs keeps its values whichever format the tensors between them have.
+int iunet_conv3_f8_launch_q(int dtype, int nd, const void* x, long long x_sstride, int x_fmt, void* y, long long y_sstride, int y_fmt,
+                            const void* wpk, const float* wscale, const float* bias, int N, int D, int H, int W, int Cin, int Cout,
+                            int epi, float* workspace, hipStream_t stream) {
+  if ((x_fmt || y_fmt) && !(nd == 3 && iunet_f8_k128(27, Cin))) {
+    iunet_set_error("conv3_f8: e4m3 activation planes need the K = 128 path (3-D, Cin %% 32 == 0; got nd %d, Cin %d)", nd, Cin);
+    return IUNET_ERR_UNSUPPORTED;
+  }
   ConvF8Params p;
   p.ksplit = workspace ? iunet_conv3_f8_ksplit(nd, N, D, H, W, Cin, Cout) : 1;
   p.partial = workspace;
@@ -522,6 +542,18 @@ int iunet_conv3_f8_launch(int dtype, int nd, const void* x, long long x_sstride,
   const bool fits = nd == 3 ? cin_wg <= 128 : cin_wg <= 256;
   const bool ws = fits && big_tiles >= 2 * slots;
   const bool small = nd == 3 && !ws && big_tiles * (Cout / 32) * p.ksplit < 128;
+  if (nd == 3 && iunet_f8_k128(27, Cin)) {            // the K = 128 matrix instruction (conv3_f8k.hip): weights always stream
+    const bool small_k = big_tiles * (Cout / 32) * p.ksplit < 128;
+    const int rc = iunet_conv3_f8k_launch(dtype, x, x_sstride, y, y_sstride, wpk, wscale, bias, N, D, H, W, Cin, Cout, epi, p.ksplit,
+                                          workspace, small_k ? 1 : 0, x_fmt, p.ksplit > 1 ? 0 : y_fmt, stream);
+    if (rc != IUNET_OK || p.ksplit == 1) return rc;
+    const long long voxk = (long long)D * H * W;
+    dim3 gridk((unsigned)((voxk + 255) / 256), Cout / 8, N);
+    if (dtype == 0) hipLaunchKernelGGL(f8_splitk_reduce_kernel<f16>, gridk, dim3(256), 0, stream, workspace, p.ksplit, (f16*)y, y_sstride, wscale, bias, N, Cout / 8, voxk, epi, y_fmt);
+    else hipLaunchKernelGGL(f8_splitk_reduce_kernel<bf16>, gridk, dim3(256), 0, stream, workspace, p.ksplit, (bf16*)y, y_sstride, wscale, bias, N, Cout / 8, voxk, epi, y_fmt);
+    IUNET_CHECK_HIP(hipGetLastError());
+    return IUNET_OK;
+  }
 #define F8_GO(TT) (nd == 3 ? (ws ? launch_f8<TT, 3, true, false>(p, stream)                                          \
                                  : (small ? launch_f8<TT, 3, false, true>(p, stream) : launch_f8<TT, 3, false, false>(p, stream))) \
                            : (ws ? launch_f8<TT, 2, true, false>(p, stream) : launch_f8<TT, 2, false, false>(p, stream)))
@@ -530,8 +562,14 @@ int iunet_conv3_f8_launch(int dtype, int nd, const void* x, long long x_sstride,
   if (rc != IUNET_OK || p.ksplit == 1) return rc;
   const long long vox = (long long)D * H * W;
   dim3 grid((unsigned)((vox + 255) / 256), Cout / 8, N);
-  if (dtype == 0) hipLaunchKernelGGL(f8_splitk_reduce_kernel<f16>, grid, dim3(256), 0, stream, workspace, p.ksplit, (f16*)y, y_sstride, wscale, bias, N, Cout / 8, vox, epi);
-  else hipLaunchKernelGGL(f8_splitk_reduce_kernel<bf16>, grid, dim3(256), 0, stream, workspace, p.ksplit, (bf16*)y, y_sstride, wscale, bias, N, Cout / 8, vox, epi);
+  if (dtype == 0) hipLaunchKernelGGL(f8_splitk_reduce_kernel<f16>, grid, dim3(256), 0, stream, workspace, p.ksplit, (f16*)y, y_sstride, wscale, bias, N, Cout / 8, vox, epi, 0);
+  else hipLaunchKernelGGL(f8_splitk_reduce_kernel<bf16>, grid, dim3(256), 0, stream, workspace, p.ksplit, (bf16*)y, y_sstride, wscale, bias, N, Cout / 8, vox, epi, 0);
   IUNET_CHECK_HIP(hipGetLastError());
   return IUNET_OK;
+}
+
+int iunet_conv3_f8_launch(int dtype, int nd, const void* x, long long x_sstride, void* y, long long y_sstride, const void* wpk,
+                          const float* wscale, const float* bias, int N, int D, int H, int W, int Cin, int Cout, int epi,
+                          float* workspace, hipStream_t stream) {
+  return iunet_conv3_f8_launch_q(dtype, nd, x, x_sstride, 0, y, y_sstride, 0, wpk, wscale, bias, N, D, H, W, Cin, Cout, epi, workspace, stream);
 }

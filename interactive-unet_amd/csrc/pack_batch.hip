@@ -208,7 +208,7 @@ __device__ __forceinline__ bool granule(const PackDesc& d, int r, const float*& 
 // 16 x taps floats (forward: w[co][chunk]), 16 rows of 32 x taps floats (data gradient: w[chunk][co tile]) -- and writes the
 // block's 30 KB (3-D) of packed operator from there.  The direct gather of pack_batch_kernel's other kinds touches a 128-byte line
 // for 4 useful bytes at a time: on C5's 90 M parameters that was ~1 ms per step.
-__device__ __forceinline__ void pack_k16_block(const PackDesc& d, int blk, float* tile) {
+__device__ __forceinline__ void pack_k16_block(const PackDesc& d, int blk, float* tile, bool k128) {
   const int CoutP = d.dgrad ? d.Cin : d.Cout, CinP = d.dgrad ? d.Cout : d.Cin;
   const int taps = d.taps, ncol = taps / 3, ncmb = (ncol + 1) / 2, nchunk = CinP >> 4;
   const int chunk = blk % nchunk, cob = blk / nchunk;
@@ -267,7 +267,10 @@ __device__ __forceinline__ void pack_k16_block(const PackDesc& d, int blk, float
 #pragma unroll
         for (int j = 0; j < 8; ++j) pk |= (unsigned long long)encode_e4m3(round_e4m3(v[j] / sc)) << (8 * j);
       }
-      *(unsigned long long*)((unsigned char*)d.dst + (out0 + r0) * 8) = pk;
+      if (!k128) *(unsigned long long*)((unsigned char*)d.dst + (out0 + r0) * 8) = pk;
+      else if (col < ncol)                           // conv3_f8k.hip's order: blocks of 32 input channels, no padded column
+        *(unsigned long long*)((unsigned char*)d.dst + ((long long)cob * (nchunk >> 1) + (chunk >> 1)) * F8K_WSTEP +
+                               f8k_offset(col, dy, m, chunk & 1, qq & 1, row)) = pk;
       continue;
     }
     if (d.qscale) {
@@ -359,13 +362,14 @@ __device__ __forceinline__ void pack_k16c_block(const PackDesc& d, int blk, floa
   __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void pack_batch_kernel(const PackDesc* __restrict__ descs) {
+__global__ __launch_bounds__(256) void pack_batch_kernel(const PackDesc* __restrict__ descs, int f8_k128) {
   const PackDesc d = descs[blockIdx.y];
   __shared__ __attribute__((aligned(16))) float tile[32 * 16 * 27];               // one K16 block of source weights (54 KB)
   if (d.kind == 1 || d.kind == 5 || d.kind == 6) {
     const int CoutP = d.dgrad ? d.Cin : d.Cout, CinP = d.dgrad ? d.Cout : d.Cin;
     const int nblocks = (CoutP >> 5) * (CinP >> 4);
-    for (int blk = blockIdx.x; blk < nblocks; blk += gridDim.x) { if (d.kind == 6) pack_k16c_block(d, blk, tile); else pack_k16_block(d, blk, tile); }
+    const bool k128 = f8_k128 && d.kind == 5 && d.taps == 27 && d.Cin % 32 == 0;      // iunet_f8_k128(taps, Cin)
+    for (int blk = blockIdx.x; blk < nblocks; blk += gridDim.x) { if (d.kind == 6) pack_k16c_block(d, blk, tile); else pack_k16_block(d, blk, tile, k128); }
     if (d.bias_out && blockIdx.x == 0) {
       for (int co = threadIdx.x; co < d.Cout; co += 256) d.bias_out[co] = fold_bias(d, co);
     }
@@ -450,7 +454,8 @@ int iunet_pack_batch(const void* descs, int n, int quant_max_cout, void* stream)
     hipLaunchKernelGGL(pack_qscale_kernel, dim3(quant_max_cout, n), dim3(256), 0, (hipStream_t)stream, (const PackDesc*)descs);
   // 1024 workgroups per layer (grid-stride; the small layers' surplus exits at once): the largest operators (28 M elements in C5) need
   // more than one workgroup per CU to hide their gather latency
-  hipLaunchKernelGGL(pack_batch_kernel, dim3(1024, n), dim3(256), 0, (hipStream_t)stream, (const PackDesc*)descs);
+  hipLaunchKernelGGL(pack_batch_kernel, dim3(1024, n), dim3(256), 0, (hipStream_t)stream, (const PackDesc*)descs,
+                     iunet_f8_k128(27, 32));
   IUNET_CHECK_HIP(hipGetLastError());
   return IUNET_OK;
 }

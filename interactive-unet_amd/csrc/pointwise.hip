@@ -17,6 +17,7 @@ struct FirstConvParams {
   const float* bias;   // [Cout] or null
   float* stats;        // [ntiles][Cout][2] or null (ntiles = iunet_conv3_num_tiles)
   int N, D, H, W, Cin, Cout, nd, relu;
+  int out8;            // 1: y = e4m3 planes [Cout / 16][D][H][W][16 B], y_sstride in bytes (the 16-bit result rounded once more)
 };
 
 __device__ __forceinline__ float load_in(const void* p, long long off, int dt) {
@@ -113,7 +114,11 @@ __global__ __launch_bounds__(256) void first_conv_kernel(FirstConvParams p) {
       if (p.relu) r = fmaxf(r, 0.f);
       o[j] = from_f32<T>(r);
     }
-    if (ok) *(V8*)(yout + (long long)(cob * 4 + q) * plane_stride + (((long long)gz * p.H + gy) * p.W + gx) * 8) = o;
+    if (ok) {
+      if (!p.out8) *(V8*)(yout + (long long)(cob * 4 + q) * plane_stride + (((long long)gz * p.H + gy) * p.W + gx) * 8) = o;
+      else e4m3_store8<T>((unsigned char*)p.y + (long long)n * p.y_sstride, cob * 4 + q, ((long long)gz * p.H + gy) * p.W + gx,
+                          (long long)p.D * p.H * p.W, __builtin_bit_cast(u32x4, o));
+    }
   }
   if (p.stats) {
 #pragma unroll
@@ -191,6 +196,50 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const T* __restrict__ x, l
   *(V8*)(y + n * y_ss + (long long)pl * ovox * 8 + r * 8) = o;
 }
 
+// max-pool of e4m3 planes (16 channels = 16 B per voxel and plane): rounding to e4m3 is monotonic, so the maximum of the rounded
+// values IS the rounded maximum -- the pooled tensor holds the bytes the 16-bit pool + the consumer's loader rounding would give
+template <int ND>
+__global__ __launch_bounds__(256) void maxpool_q_kernel(const unsigned char* __restrict__ x, long long x_ss, unsigned char* __restrict__ y,
+                                                        long long y_ss, int planes16, int Do, int Ho, int Wo) {
+  const long long ovox = (long long)Do * Ho * Wo;
+  const long long total = ovox * planes16;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int n = blockIdx.y;
+  const int pl = (int)(i / ovox);
+  const long long r = i - (long long)pl * ovox;
+  const int ox = (int)(r % Wo), oy = (int)((r / Wo) % Ho), oz = (int)(r / ((long long)Wo * Ho));
+  const int Di = ND == 3 ? Do * 2 : 1, Hi = Ho * 2, Wi = Wo * 2;
+  const unsigned char* xp = x + n * x_ss + (long long)pl * Di * Hi * Wi * 16;
+  float m[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) m[j] = -INFINITY;
+#pragma unroll
+  for (int a = 0; a < (ND == 3 ? 2 : 1); ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int z = ND == 3 ? oz * 2 + a : 0;
+        const u32x4 v = *(const u32x4*)(xp + (((long long)z * Hi + oy * 2 + b) * Wi + ox * 2 + c) * 16);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          m[4 * d + 0] = fmaxf(m[4 * d + 0], __builtin_amdgcn_cvt_f32_fp8((int)v[d], 0));
+          m[4 * d + 1] = fmaxf(m[4 * d + 1], __builtin_amdgcn_cvt_f32_fp8((int)v[d], 1));
+          m[4 * d + 2] = fmaxf(m[4 * d + 2], __builtin_amdgcn_cvt_f32_fp8((int)v[d], 2));
+          m[4 * d + 3] = fmaxf(m[4 * d + 3], __builtin_amdgcn_cvt_f32_fp8((int)v[d], 3));
+        }
+      }
+  u32x4 o;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    int w = __builtin_amdgcn_cvt_pk_fp8_f32(m[4 * d], m[4 * d + 1], 0, false);      // exact: the inputs are e4m3 values
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(m[4 * d + 2], m[4 * d + 3], w, true);
+    o[d] = (unsigned)w;
+  }
+  *(u32x4*)(y + n * y_ss + ((long long)pl * ovox + r) * 16) = o;
+}
+
 // ------------------------------------------------------------------ transposed conv k2 s2
 // One wave = 16 consecutive input x voxels x 32 output channels x all 2^d output
 // positions.  A = packed weights [cob32][kstep][pos][t][64][8], B = activations.
@@ -199,6 +248,7 @@ struct ConvTParams {
   void* y; long long y_sstride;
   const void* wpk; const float* bias;
   int N, D, H, W, Cin, Cout;   // input grid
+  int out8;                    // 1: y = e4m3 planes [Cout / 16][2D][2H][2W][16 B], y_sstride in bytes
 };
 
 template <typename T, int ND>
@@ -277,7 +327,11 @@ __global__ __launch_bounds__(256) void convT_kernel(ConvTParams p) {
         v[d] = odd ? t1 : t0;
       }
       const int xo = 2 * x0 + 16 * h + l15;                    // output x of this lane in instruction h
-      if (xo < Wo) *(i32x4*)(row + (16 * h + l15) * 8) = v;
+      if (xo < Wo) {
+        if (!p.out8) *(i32x4*)(row + (16 * h + l15) * 8) = v;
+        else e4m3_store8<T>((unsigned char*)p.y + (long long)n * p.y_sstride, cob * 4 + q, ((long long)oz * Ho + y * 2 + b) * Wo + xo,
+                            (long long)Do * Ho * Wo, __builtin_bit_cast(u32x4, v));
+      }
     }
   }
 }
@@ -375,7 +429,12 @@ __global__ __launch_bounds__(256) void convT_lds_kernel(ConvTParams p) {
             const int t1 = __builtin_amdgcn_ds_bpermute(src, oc[1][d]);
             v[d] = odd ? t1 : t0;
           }
-          if (2 * x0 + 16 * h + l15 < Wo) *(i32x4*)(row + (16 * h + l15) * 8) = v;
+          if (2 * x0 + 16 * h + l15 < Wo) {
+            if (!p.out8) *(i32x4*)(row + (16 * h + l15) * 8) = v;
+            else e4m3_store8<T>((unsigned char*)p.y + (long long)n_[g] * p.y_sstride, cob * 4 + q,
+                                ((long long)oz * Ho + y_[g] * 2 + bb) * Wo + 2 * x0 + 16 * h + l15, (long long)Do * Ho * Wo,
+                                __builtin_bit_cast(u32x4, v));
+          }
         }
       }
     }
@@ -511,7 +570,12 @@ __global__ __launch_bounds__(256) void convT_chunk_kernel(ConvTParams p) {
             const int t1 = __builtin_amdgcn_ds_bpermute(src, oc[1][d]);
             v[d] = odd ? t1 : t0;
           }
-          if (2 * x0 + 16 * h + l15 < Wo) *(i32x4*)(row + (16 * h + l15) * 8) = v;
+          if (2 * x0 + 16 * h + l15 < Wo) {
+            if (!p.out8) *(i32x4*)(row + (16 * h + l15) * 8) = v;
+            else e4m3_store8<T>((unsigned char*)p.y + (long long)n_[g] * p.y_sstride, cob * 4 + q,
+                                ((long long)oz * Ho + y_[g] * 2 + bb) * Wo + 2 * x0 + 16 * h + l15, (long long)Do * Ho * Wo,
+                                __builtin_bit_cast(u32x4, v));
+          }
         }
       }
     }
@@ -608,13 +672,13 @@ __global__ __launch_bounds__(256) void head_kernel(HeadParams p) {
 int iunet_first_conv_launch(int dtype, int nd, const void* x, int in_dtype, long long sN, long long sC, long long sD,
                             long long sH, long long sW, void* y, long long y_sstride, const void* w,
                             const float* bias, float* stats, int N, int D, int H, int W, int Cin, int Cout, int relu,
-                            hipStream_t stream) {
+                            hipStream_t stream, int out8) {
   IUNET_REQUIRE(Cin >= 1 && Cin <= 4, "first_conv: Cin must be 1..4 (got %d)", Cin);
   IUNET_REQUIRE(Cout % 32 == 0, "first_conv: Cout must be a multiple of 32 (got %d)", Cout);
   FirstConvParams p;
   p.x = x; p.sN = sN; p.sC = sC; p.sD = sD; p.sH = sH; p.sW = sW; p.in_dtype = in_dtype;
   p.y = y; p.y_sstride = y_sstride; p.w = w; p.bias = bias; p.stats = stats;
-  p.N = N; p.D = D; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.nd = nd; p.relu = relu;
+  p.N = N; p.D = D; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.nd = nd; p.relu = relu; p.out8 = out8;
   const int TZ = nd == 3 ? 4 : 1, TY = nd == 3 ? 8 : 16, TX = nd == 3 ? 16 : 32;
   dim3 grid(N * ((D + TZ - 1) / TZ) * ((H + TY - 1) / TY) * ((W + TX - 1) / TX), Cout / 32);
 #define IUNET_FC(TT, NDV, CI) hipLaunchKernelGGL((first_conv_kernel<TT, NDV, CI>), grid, dim3(256), 0, stream, p)
@@ -653,12 +717,22 @@ int iunet_maxpool_launch(int dtype, int nd, const void* x, long long x_ss, void*
   return IUNET_OK;
 }
 
+int iunet_maxpool_q_launch(int nd, const void* x, long long x_ss, void* y, long long y_ss, int planes16, int N, int Do, int Ho, int Wo,
+                           hipStream_t stream) {
+  const long long total = (long long)Do * Ho * Wo * planes16;
+  dim3 grid((unsigned)((total + 255) / 256), N);
+  if (nd == 3) hipLaunchKernelGGL((maxpool_q_kernel<3>), grid, dim3(256), 0, stream, (const unsigned char*)x, x_ss, (unsigned char*)y, y_ss, planes16, Do, Ho, Wo);
+  else hipLaunchKernelGGL((maxpool_q_kernel<2>), grid, dim3(256), 0, stream, (const unsigned char*)x, x_ss, (unsigned char*)y, y_ss, planes16, Do, Ho, Wo);
+  IUNET_CHECK_HIP(hipGetLastError());
+  return IUNET_OK;
+}
+
 int iunet_convT_launch(int dtype, int nd, const void* x, long long x_ss, void* y, long long y_ss, const void* wpk,
-                       const float* bias, int N, int D, int H, int W, int Cin, int Cout, hipStream_t stream) {
+                       const float* bias, int N, int D, int H, int W, int Cin, int Cout, hipStream_t stream, int out8) {
   IUNET_REQUIRE(Cin % 32 == 0 && Cout % 32 == 0, "convT: Cin (%d) and Cout (%d) must be multiples of 32", Cin, Cout);
   ConvTParams p;
   p.x = x; p.x_sstride = x_ss; p.y = y; p.y_sstride = y_ss; p.wpk = wpk; p.bias = bias;
-  p.N = N; p.D = D; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
+  p.N = N; p.D = D; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.out8 = out8;
   const long long waves = (long long)N * D * H * ((W + 15) / 16);
   const int nk = Cin / 32;
   if (nk <= 4 && waves >= 256) {

@@ -12,6 +12,7 @@ read / write them directly.
 """
 import ctypes
 import math
+import os
 
 import torch
 
@@ -169,6 +170,14 @@ class Engine:
         self._eval_table.run()
 
     # ------------------------------------------------------------------ workspace
+    def q_planes(self):
+        """True when the activations between fp8 convolutions travel as e4m3 planes: config C5 in 3-D with every stage conv on the
+        K = 128 operator order (IUNET_F8_Q=0: 16-bit tensors everywhere -- the A/B switch; the results are the same bits)."""
+        if getattr(self, '_qp', None) is None:            # decided once per engine (its workspaces depend on it)
+            self._qp = bool(self.weight_dtype and self.act_quant and self.dim == 3 and self.norm != 'group'
+                            and os.environ.get('IUNET_F8_Q', '1') != '0' and nv.lib().iunet_f8_pack_order(27, self.ch[0]) == 1)
+        return self._qp
+
     def level_dims(self, D, H, W):
         out = []
         for l in range(self.levels):
@@ -188,15 +197,18 @@ class Engine:
             self.check_shape(D, H, W)
             dims = self.level_dims(D, H, W)
             mk = lambda c, v: torch.empty(N * c * v, dtype=self.act_dtype, device=self.device)
+            # fp8 network on the K = 128 path: every tensor that only fp8 convolutions read is stored as e4m3 planes (one byte per
+            # element: include/iunet.h, format 1); what a transposed conv or the head reads (b) stays 16-bit
+            mq = (lambda c, v: torch.empty(N * c * v, dtype=torch.uint8, device=self.device)) if self.q_planes() else mk
             ws = {'dims': dims}
             for l in range(self.levels):
                 v = _vox(dims[l])
-                ws[f'a{l}'] = mk(self.ch[l], v)
+                ws[f'a{l}'] = mq(self.ch[l], v)
                 ws[f'b{l}'] = mk(self.ch[l], v)
                 if l < self.levels - 1:
-                    ws[f'cat{l}'] = mk(2 * self.ch[l], v)
+                    ws[f'cat{l}'] = mq(2 * self.ch[l], v)
                 if l > 0:
-                    ws[f'pin{l}'] = mk(self.ch[l - 1], v)
+                    ws[f'pin{l}'] = mq(self.ch[l - 1], v)
             if self.norm == 'group':
                 f32 = lambda n: torch.empty(n, dtype=torch.float32, device=self.device)
                 ws['raw'] = mk(max(self.ch[l] * _vox(dims[l]) for l in range(self.levels)), 1)
@@ -216,7 +228,7 @@ class Engine:
         nv.call('iunet_gn_relu_fwd', self.dt, nv.ptr(ws['raw']), co * v, y_ptr, y_ss, nv.ptr(gamma), nv.ptr(beta), self.groups,
                 BN_EPS, nv.ptr(ws['gnslab']), nv.ptr(sc), nv.ptr(sh), nv.ptr(mu), nv.ptr(ist), co, N, v, s)
 
-    def _conv3(self, x_ptr, x_ss, y_ptr, y_ss, name, N, dims, ci, co, s, ws=None):
+    def _conv3(self, x_ptr, x_ss, y_ptr, y_ss, name, N, dims, ci, co, s, ws=None, xf=0, yf=0):
         pk, bias = self.packed[name][0], self.packed[name][1]
         if self.norm == 'group':
             lay, wpk = pk.pick(self.dim, N, dims[0], dims[1], dims[2])
@@ -228,22 +240,23 @@ class Engine:
         if probe is not None:                       # bench.py: HIP events around THIS layer's launch inside the real step
             e0 = torch.cuda.Event(enable_timing=True)
             e0.record()
-            self._conv3_launch(x_ptr, x_ss, y_ptr, y_ss, name, N, dims, ci, co, s, ws)
+            self._conv3_launch(x_ptr, x_ss, y_ptr, y_ss, name, N, dims, ci, co, s, ws, xf, yf)
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
             probe['events'].append((e0, e1, N))
             return
-        self._conv3_launch(x_ptr, x_ss, y_ptr, y_ss, name, N, dims, ci, co, s, ws)
+        self._conv3_launch(x_ptr, x_ss, y_ptr, y_ss, name, N, dims, ci, co, s, ws, xf, yf)
 
-    def _conv3_launch(self, x_ptr, x_ss, y_ptr, y_ss, name, N, dims, ci, co, s, ws=None):
+    def _conv3_launch(self, x_ptr, x_ss, y_ptr, y_ss, name, N, dims, ci, co, s, ws=None, xf=0, yf=0):
         pk, bias = self.packed[name][0], self.packed[name][1]
         if isinstance(pk, F8Conv):
             need = nv.lib().iunet_conv3_f8_workspace_elems(self.dim, N, dims[0], dims[1], dims[2], ci, co)      # split-K scratch
             if need > (self._f8_ws.numel() if self._f8_ws is not None else 0):
                 self._f8_ws = torch.empty(need, dtype=torch.float32, device=self.device)
-            nv.call('iunet_conv3_f8_fwd', self.dt, self.dim, x_ptr, x_ss, y_ptr, y_ss, nv.ptr(pk.bytes), nv.ptr(pk.scale),
+            nv.call('iunet_conv3_f8_fwd_q', self.dt, self.dim, x_ptr, x_ss, xf, y_ptr, y_ss, yf, nv.ptr(pk.bytes), nv.ptr(pk.scale),
                     nv.ptr(bias), N, dims[0], dims[1], dims[2], ci, co, 2, nv.ptr(self._f8_ws) if need else None, s)
             return
+        assert not (xf or yf)
         lay, wpk = pk.pick(self.dim, N, dims[0], dims[1], dims[2])
         nv.call('iunet_conv3_fwd', self.dt, self.dim, x_ptr, x_ss, y_ptr, y_ss, nv.ptr(wpk), nv.ptr(bias), None,
                 N, dims[0], dims[1], dims[2], ci, co, 2, lay, s)
@@ -261,39 +274,49 @@ class Engine:
         es = torch.tensor([], dtype=self.act_dtype).element_size()
         s = nv.stream()
         L, ch = self.levels, self.ch
-        P = lambda t, off_elems=0: ctypes.c_void_p(t.data_ptr() + off_elems * es)
+        P = lambda t, off_elems=0: ctypes.c_void_p(t.data_ptr() + off_elems * t.element_size())
+        q = 1 if self.q_planes() else 0            # a / cat / pin are e4m3 planes (one byte per element: the offsets below hold as they are)
         for l in range(L):
             v = _vox(dims[l])
             if l == 0:
                 w, b = self.packed['enc0.conv1'][0], self.packed['enc0.conv1'][1]
                 gn = self.norm == 'group'
-                nv.call('iunet_first_conv_fwd', self.dt, self.dim, nv.ptr(x), nv.IN_DTYPE_CODE[x.dtype],
-                        nv.ll_array(x_strides), P(ws['raw']) if gn else P(ws['a0']), ch[0] * v, nv.ptr(w), nv.ptr(b), None,
-                        N, dims[0][0], dims[0][1], dims[0][2], self.cin, ch[0], 0 if gn else 1, s)
+                if q:
+                    nv.call('iunet_first_conv_fwd_q', self.dt, self.dim, nv.ptr(x), nv.IN_DTYPE_CODE[x.dtype],
+                            nv.ll_array(x_strides), P(ws['a0']), ch[0] * v, nv.ptr(w), nv.ptr(b),
+                            N, dims[0][0], dims[0][1], dims[0][2], self.cin, ch[0], 1, s)
+                else:
+                    nv.call('iunet_first_conv_fwd', self.dt, self.dim, nv.ptr(x), nv.IN_DTYPE_CODE[x.dtype],
+                            nv.ll_array(x_strides), P(ws['raw']) if gn else P(ws['a0']), ch[0] * v, nv.ptr(w), nv.ptr(b), None,
+                            N, dims[0][0], dims[0][1], dims[0][2], self.cin, ch[0], 0 if gn else 1, s)
                 if gn:
                     self._group_norm('enc0.conv1', ws, P(ws['a0']), ch[0] * v, N, dims[0], ch[0], s)
             else:
                 self._conv3(P(ws[f'pin{l}']), ch[l - 1] * v, P(ws[f'a{l}']), ch[l] * v, f'enc{l}.conv1', N, dims[l],
-                            ch[l - 1], ch[l], s, ws)
+                            ch[l - 1], ch[l], s, ws, q, q)
             if l < L - 1:
                 self._conv3(P(ws[f'a{l}']), ch[l] * v, P(ws[f'cat{l}']), 2 * ch[l] * v, f'enc{l}.conv2', N, dims[l],
-                            ch[l], ch[l], s, ws)
+                            ch[l], ch[l], s, ws, q, q)
                 vo = _vox(dims[l + 1])
-                nv.call('iunet_maxpool_fwd', self.dt, self.dim, P(ws[f'cat{l}']), 2 * ch[l] * v, P(ws[f'pin{l + 1}']),
-                        ch[l] * vo, ch[l], N, dims[l + 1][0], dims[l + 1][1], dims[l + 1][2], s)
+                if q:
+                    nv.call('iunet_maxpool_q_fwd', self.dim, P(ws[f'cat{l}']), 2 * ch[l] * v, P(ws[f'pin{l + 1}']),
+                            ch[l] * vo, ch[l], N, dims[l + 1][0], dims[l + 1][1], dims[l + 1][2], s)
+                else:
+                    nv.call('iunet_maxpool_fwd', self.dt, self.dim, P(ws[f'cat{l}']), 2 * ch[l] * v, P(ws[f'pin{l + 1}']),
+                            ch[l] * vo, ch[l], N, dims[l + 1][0], dims[l + 1][1], dims[l + 1][2], s)
             else:
                 self._conv3(P(ws[f'a{l}']), ch[l] * v, P(ws[f'b{l}']), ch[l] * v, f'enc{l}.conv2', N, dims[l],
-                            ch[l], ch[l], s, ws)
+                            ch[l], ch[l], s, ws, q, 0)
         for l in range(L - 2, -1, -1):
             v, vi = _vox(dims[l]), _vox(dims[l + 1])
             wpk, bias = self.packed[f'dec{l}.up']
-            nv.call('iunet_convT_fwd', self.dt, self.dim, P(ws[f'b{l + 1}']), ch[l + 1] * vi,
+            nv.call('iunet_convT_fwd_q' if q else 'iunet_convT_fwd', self.dt, self.dim, P(ws[f'b{l + 1}']), ch[l + 1] * vi,
                     P(ws[f'cat{l}'], ch[l] * v), 2 * ch[l] * v, nv.ptr(wpk), nv.ptr(bias),
                     N, dims[l + 1][0], dims[l + 1][1], dims[l + 1][2], ch[l + 1], ch[l], s)
             self._conv3(P(ws[f'cat{l}']), 2 * ch[l] * v, P(ws[f'a{l}']), ch[l] * v, f'dec{l}.conv1', N, dims[l],
-                        2 * ch[l], ch[l], s, ws)
+                        2 * ch[l], ch[l], s, ws, q, q)
             self._conv3(P(ws[f'a{l}']), ch[l] * v, P(ws[f'b{l}']), ch[l] * v, f'dec{l}.conv2', N, dims[l],
-                        ch[l], ch[l], s, ws)
+                        ch[l], ch[l], s, ws, q, 0)
         if features_only:
             return ws['b0']                       # input of the head, NHWC8c
         hw, hb = self.packed['head']

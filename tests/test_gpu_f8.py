@@ -51,8 +51,40 @@ def run_conv_f8(nv, x, w, dtype, nd, bn=None, epi=0, bias=None, splitk=True):
     return unblocked(y.float().cpu(), N, Cout, sp), dst.cpu(), sc.cpu(), (None if bd is None else bd.cpu())
 
 
+F8K_COL = ((0, 3, 1, 4), (2, 5, 6, 7))       # filter column (dz * 3 + dx) of K = 128 group g, lane group q; column 8: the K = 32 part
+
+
+def unpack_k128(bytes_u8, cout, cin):
+    """Inverse of the K128 order (include/iunet.h: iunet_f8_pack_order; csrc/conv3_f8k.hip) -> float32 [Cout][Cin][27]."""
+    vals = bytes_u8.view(torch.float8_e4m3fn).float().numpy()
+    nblk = (cout // 32) * (cin // 32)
+    v = vals[:nblk * 27648].reshape(cout // 32, cin // 32, 27648)
+    big = v[:, :, :24576].reshape(cout // 32, cin // 32, 2, 3, 2, 2, 64, 16)      # [g][dy][m][half e][lane][16 channels]
+    small = v[:, :, 24576:].reshape(cout // 32, cin // 32, 3, 2, 64, 8)          # [dy][m][lane][8 channels]
+    out = np.zeros((cout, cin, 27), np.float32)
+    for lane in range(64):
+        row, q = lane & 15, lane >> 4
+        for m in range(2):
+            co_in = 8 * (row >> 2) + 4 * m + (row & 3)
+            for dy in range(3):
+                for g in range(2):
+                    col = F8K_COL[g][q]
+                    tap = ((col // 3) * 3 + dy) * 3 + col % 3
+                    for e in range(2):
+                        for j in range(16):
+                            out[co_in::32, 16 * e + j::32, tap] = big[:, :, g, dy, m, e, lane, j]
+                tap = (2 * 3 + dy) * 3 + 2                                       # column 8 = (dz 2, dx 2)
+                for j in range(8):
+                    out[co_in::32, 8 * q + j::32, tap] = small[:, :, dy, m, lane, j]
+    return out
+
+
 def unpack_k16(bytes_u8, cout, cin, taps):
-    """Inverse of the K16 order [cob32][chunk16][column pair][dy][2][64][8] -> float32 [Cout][Cin][taps] (e4m3 values)."""
+    """Inverse of the layer's operator order -> float32 [Cout][Cin][taps] (e4m3 values): the K16 order
+    [cob32][chunk16][column pair][dy][2][64][8], or the K128 order where iunet_f8_pack_order says so."""
+    from interactive_unet import _native
+    if _native.lib().iunet_f8_pack_order(taps, cin):
+        return unpack_k128(bytes_u8, cout, cin)
     vals = bytes_u8.view(torch.float8_e4m3fn).float().numpy()
     ncol = taps // 3
     ncmb, nchunk = (ncol + 1) // 2, cin // 16
@@ -121,6 +153,140 @@ def test_pack_table_kind5_equals_the_per_layer_entry(nv, nd, cout, cin, fold):
         assert torch.equal(got, ref), (off, int((got != ref).sum()))
         if fold:
             assert torch.equal(b_got, b_ref)
+
+
+def blocked_q(t):
+    """[N, C, *spatial] float tensor of e4m3-representable values -> flat uint8 e4m3 planes [N][C / 16][*spatial][16] (format 1)."""
+    N, C = t.shape[:2]
+    sp = t.shape[2:]
+    t = t.reshape(N, C // 16, 16, *sp)
+    perm = [0, 1] + list(range(3, 3 + len(sp))) + [2]
+    return t.permute(*perm).contiguous().to(torch.float8_e4m3fn).view(torch.uint8).reshape(-1)
+
+
+def unblocked_q(flat_u8, N, C, sp):
+    t = flat_u8.view(torch.float8_e4m3fn).float().reshape(N, C // 16, *sp, 16)
+    perm = [0, 1, 2 + len(sp)] + list(range(2, 2 + len(sp)))
+    return t.permute(*perm).reshape(N, C, *sp)
+
+
+@pytest.mark.parametrize('xf,yf', [(1, 1), (1, 0), (0, 1)])
+@pytest.mark.parametrize('shape,cin,cout', [((4, 8, 16), 32, 32), ((9, 7, 17), 128, 64), ((16, 16, 16), 256, 256), ((8, 8, 8), 512, 128)])
+def test_conv3_f8_e4m3_planes_exact_integers(nv, shape, cin, cout, xf, yf):
+    """The K = 128 conv reading and / or writing e4m3 activation planes (include/iunet.h format 1): small integers, every product and
+    sum exact -> bit equality with torch's conv; the e4m3 output is the 16-bit result rounded once more (values chosen inside the
+    exactly representable range of both roundings: |y| <= 448 saturates, so the reference is clamped the same way)."""
+    if not nv.lib().iunet_f8_pack_order(27, cin):
+        pytest.skip('K16 operator order selected (IUNET_F8_K128=0)')
+    g = torch.Generator().manual_seed(3)
+    N, dtype, dev = 2, torch.bfloat16, 'cuda'
+    D, H, W = shape
+    vox = D * H * W
+    x = torch.randint(-2, 3, (N, cin) + shape, generator=g).float()
+    w = torch.randint(-1, 2, (cout, cin) + (3,) * 3, generator=g).float()
+    w[torch.rand(w.shape, generator=g) < 0.9] = 0                                  # sparse: sums stay small
+    w[:, 0, 1, 1, 1] = 1                                                           # (no all-zero output channel: the scale is defined)
+    bias = torch.randint(-2, 3, (cout,), generator=g).float()
+    want = torch.relu(F.conv3d(x, w, bias=bias, padding=1)).to(dtype).float()
+    wd = w.contiguous().to(dev)
+    dst = torch.zeros(nv.lib().iunet_f8_pack_conv3_bytes(cout, cin, 27), dtype=torch.uint8, device=dev)
+    sc = torch.empty(cout, device=dev)
+    nv.call('iunet_f8_pack_conv3', nv.ptr(wd), None, None, None, None, 1e-5, nv.ptr(dst), nv.ptr(sc), None, cout, cin, 27, nv.stream())
+    xb = (blocked_q(x) if xf else blocked(x, dtype)).to(dev)
+    y = torch.full((N * cout * vox,), 0x7f, dtype=torch.uint8, device=dev) if yf else torch.full((N * cout * vox,), float('nan'), dtype=dtype, device=dev)
+    need = nv.lib().iunet_conv3_f8_workspace_elems(3, N, D, H, W, cin, cout)
+    ws = torch.full((need,), float('nan'), device=dev) if need else None
+    nv.call('iunet_conv3_f8_fwd_q', nv.DTYPE_CODE[dtype], 3, nv.ptr(xb), cin * vox, xf, nv.ptr(y), cout * vox, yf, nv.ptr(dst), nv.ptr(sc),
+            nv.ptr(bias.to(dev)), N, D, H, W, cin, cout, 2, nv.ptr(ws), nv.stream())
+    torch.cuda.synchronize()
+    if yf:
+        got = unblocked_q(y.cpu(), N, cout, shape)
+        want = want.clamp(-448, 448).to(torch.float8_e4m3fn).float()
+    else:
+        got = unblocked(y.float().cpu(), N, cout, shape)
+    assert torch.isfinite(got).all()
+    assert torch.equal(got, want), f'{(got != want).sum().item()} of {got.numel()} differ'
+
+
+def test_e4m3_plane_producers_round_like_the_conv_loader(nv):
+    """first conv, max-pool and transposed conv writing e4m3 planes: the bytes are the 16-bit kernels' results rounded to e4m3
+    (round to nearest even, saturating), which is what the fp8 conv's loader makes of the 16-bit tensor."""
+    g = torch.Generator().manual_seed(11)
+    dev, dtype, dt = 'cuda', torch.bfloat16, nv.DTYPE_CODE[torch.bfloat16]
+    N, D, H, W = 2, 4, 8, 16
+    vox = D * H * W
+    # ---- first conv (1 -> 64)
+    x = torch.randint(0, 256, (N, 1, D, H, W), generator=g, dtype=torch.uint8).to(dev)
+    w = (torch.randn((64, 1, 3, 3, 3), generator=g) * 3).to(dev)
+    b = torch.randn(64, generator=g).to(dev)
+    wp = torch.empty(nv.lib().iunet_pack_first_conv_elems(64, 1, 27), dtype=dtype, device=dev)
+    nv.call('iunet_pack_first_conv', dt, nv.ptr(w), None, nv.ptr(wp), 64, 1, 27, nv.stream())
+    y16 = torch.empty(N * 64 * vox, dtype=dtype, device=dev)
+    y8 = torch.empty(N * 64 * vox, dtype=torch.uint8, device=dev)
+    strides = nv.ll_array((vox, vox, H * W, W, 1))
+    nv.call('iunet_first_conv_fwd', dt, 3, nv.ptr(x), nv.IN_DTYPE_CODE[x.dtype], strides, nv.ptr(y16), 64 * vox, nv.ptr(wp), nv.ptr(b), None,
+            N, D, H, W, 1, 64, 1, nv.stream())
+    nv.call('iunet_first_conv_fwd_q', dt, 3, nv.ptr(x), nv.IN_DTYPE_CODE[x.dtype], strides, nv.ptr(y8), 64 * vox, nv.ptr(wp), nv.ptr(b),
+            N, D, H, W, 1, 64, 1, nv.stream())
+    torch.cuda.synchronize()
+    ref = unblocked(y16.float().cpu(), N, 64, (D, H, W)).clamp(-448, 448).to(torch.float8_e4m3fn).float()
+    assert torch.equal(unblocked_q(y8.cpu(), N, 64, (D, H, W)), ref)
+    # ---- max-pool of e4m3 planes = rounded max-pool
+    t = (torch.randn((N, 32, D, H, W), generator=g) * 20).to(dtype).float()
+    tq = blocked_q(t.clamp(-448, 448).to(torch.float8_e4m3fn).float()).to(dev)
+    pq = torch.empty(N * 32 * vox // 8, dtype=torch.uint8, device=dev)
+    nv.call('iunet_maxpool_q_fwd', 3, nv.ptr(tq), 32 * vox, nv.ptr(pq), 32 * vox // 8, 32, N, D // 2, H // 2, W // 2, nv.stream())
+    torch.cuda.synchronize()
+    ref = F.max_pool3d(t, 2).clamp(-448, 448).to(torch.float8_e4m3fn).float()
+    assert torch.equal(unblocked_q(pq.cpu(), N, 32, (D // 2, H // 2, W // 2)), ref)
+    # ---- transposed conv (three kernels: direct, resident weights, chunked weights), output into the second half of a concat buffer
+    for cin, cout, sp in ((64, 32, (2, 4, 16)), (64, 32, (4, 8, 16)), (256, 64, (4, 8, 16)), (32, 32, (1, 2, 3))):
+        Di, Hi, Wi = sp
+        vi, vo = Di * Hi * Wi, 8 * Di * Hi * Wi
+        xi = (torch.randn((N, cin) + sp, generator=g)).to(dtype).float()
+        wt = (torch.randn((cin, cout, 2, 2, 2), generator=g) * 0.5).to(dev)
+        bt = torch.randn(cout, generator=g).to(dev)
+        wpk = torch.empty(wt.numel(), dtype=dtype, device=dev)
+        nv.call('iunet_pack_convT', dt, nv.ptr(wt), nv.ptr(wpk), cin, cout, 8, nv.stream())
+        xb = blocked(xi, dtype).to(dev)
+        o16 = torch.zeros(N * 2 * cout * vo, dtype=dtype, device=dev)
+        o8 = torch.zeros(N * 2 * cout * vo, dtype=torch.uint8, device=dev)
+        import ctypes
+        nv.call('iunet_convT_fwd', dt, 3, nv.ptr(xb), cin * vi, ctypes.c_void_p(o16.data_ptr() + cout * vo * 2), 2 * cout * vo, nv.ptr(wpk),
+                nv.ptr(bt), N, Di, Hi, Wi, cin, cout, nv.stream())
+        nv.call('iunet_convT_fwd_q', dt, 3, nv.ptr(xb), cin * vi, ctypes.c_void_p(o8.data_ptr() + cout * vo), 2 * cout * vo, nv.ptr(wpk),
+                nv.ptr(bt), N, Di, Hi, Wi, cin, cout, nv.stream())
+        torch.cuda.synchronize()
+        osp = (2 * Di, 2 * Hi, 2 * Wi)
+        ref = unblocked(o16.float().cpu(), N, 2 * cout, osp).clamp(-448, 448).to(torch.float8_e4m3fn).float()
+        got = unblocked_q(o8.cpu(), N, 2 * cout, osp)
+        assert torch.equal(got[:, cout:], ref[:, cout:]), (cin, cout, sp)
+        assert not got[:, :cout].any()                                             # the skip half of the buffer is untouched
+
+
+def test_fp8_network_bits_do_not_depend_on_the_activation_format():
+    """Engine with e4m3 planes between the fp8 convs (default) against the same engine with 16-bit tensors everywhere (IUNET_F8_Q=0):
+    every producer rounds exactly as the consumer's loader would have -> identical logits, bit for bit."""
+    import os, warnings
+    from interactive_unet.unet import UNet
+    p = unet_ref.init_params(dim=3, levels=3, base=32, ncls=3, seed=9, randomize_bn=True)
+    x = torch.randint(0, 256, (2, 1, 16, 32, 32), dtype=torch.uint8, generator=torch.Generator().manual_seed(2)).cuda()
+    outs = []
+    for q in ('1', '0'):
+        os.environ['IUNET_F8_Q'] = q
+        try:
+            with warnings.catch_warnings():
+                warnings.simplefilter('ignore')
+                m = UNet(num_classes=3, dim=3, levels=3, base=32, act_dtype='bf16', pretrained=False, weight_dtype='fp8_e4m3')
+            m.load_named(p)
+            m = m.cuda().eval()
+            eng = m.engine('eval')
+            probs = m(x)
+            assert eng.q_planes() == (q == '1')
+            outs.append(probs.cpu())
+        finally:
+            os.environ.pop('IUNET_F8_Q', None)
+    assert torch.equal(outs[0], outs[1])
 
 
 @pytest.mark.parametrize('dtype', ['bf16', 'f16'])

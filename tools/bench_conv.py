@@ -24,7 +24,7 @@ def main():
     ap.add_argument('--layout', type=int, default=-1, help='-1 = library policy, 0 / 1 / 2 / 3 = force a kernel structure (3: compact operator, padding-free step)')
     ap.add_argument('--base', type=int, default=32, help='channels at level 0 (64: the C5 network)')
     ap.add_argument('--levels', type=int, default=4)
-    ap.add_argument('--f8', type=int, default=0, help='1: also time the fp8 matrix-core kernel (conv3_f8.hip) on each shape')
+    ap.add_argument('--f8', type=int, default=0, help='1: also time the fp8 matrix-core kernel (conv3_f8.hip / conv3_f8k.hip) on each shape; 2: with e4m3 activation planes in and out (3-D, the engine\'s format between fp8 convs)')
     ap.add_argument('--x2', type=int, default=0, help='1: also time the split-precision conv (fp16x2: conv3_v4.hip SPL) on each shape; 2: only it')
     a = ap.parse_args()
     T = torch.bfloat16 if a.dtype == 'bf16' else torch.float16
@@ -75,10 +75,14 @@ def main():
             nv.call('iunet_f8_pack_conv3', nv.ptr(w), None, None, None, None, 1e-5, nv.ptr(wb), nv.ptr(sc), None, cout, cin, taps, nv.stream())
             need = nv.lib().iunet_conv3_f8_workspace_elems(nd, a.n, D, S, S, cin, cout)
             wk = torch.empty(need, device='cuda') if need else None
-            h = lambda: nv.call('iunet_conv3_f8_fwd', dt, nd, nv.ptr(x), cin * vox, nv.ptr(y), cout * vox, nv.ptr(wb), nv.ptr(sc),
-                                nv.ptr(bias), a.n, D, S, S, cin, cout, 2, nv.ptr(wk), nv.stream())
+            qf = 1 if (a.f8 == 2 and nd == 3 and nv.lib().iunet_f8_pack_order(taps, cin)) else 0
+            if qf:       # e4m3 planes: one byte per element (random e4m3 values of moderate size: timing only)
+                xq = (torch.randn(a.n * cin * vox, device='cuda') * 2).to(torch.float8_e4m3fn).view(torch.uint8)
+                yq = torch.empty(a.n * cout * vox, dtype=torch.uint8, device='cuda')
+            h = lambda: nv.call('iunet_conv3_f8_fwd_q', dt, nd, nv.ptr(xq if qf else x), cin * vox, qf, nv.ptr(yq if qf else y), cout * vox, qf,
+                                nv.ptr(wb), nv.ptr(sc), nv.ptr(bias), a.n, D, S, S, cin, cout, 2, nv.ptr(wk), nv.stream())
             ms3 = timeit(h, iters=a.iters)
-            line += f' | fp8 {ms3*1e3:8.1f} us {fl/ms3/1e9:7.1f} TF/s ({ms/ms3:.2f}x){" split-K" if need else ""}'
+            line += f' | fp8{" (e4m3 planes)" if qf else ""} {ms3*1e3:8.1f} us {fl/ms3/1e9:7.1f} TF/s ({ms/ms3:.2f}x){" split-K" if need else ""}'
         if a.x2:
             wv = torch.empty(3 * cin * cout * taps, device='cuda')
             osc, b2 = torch.empty(cout, device='cuda'), torch.empty(cout, device='cuda')
