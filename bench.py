@@ -120,9 +120,12 @@ def pmc_traffic(workload, tiles=1):
     return None
 
 
-def _roof_fields(flops, alg_bytes, ms, burst=None, settled=None):
+FP8_PEAK_TFLOPS = 5000.0        # dense e4m3 peak of the K = 128 matrix instructions (MI355X_MICROARCH.md, "Matrix cores")
+
+
+def _roof_fields(flops, alg_bytes, ms, burst=None, settled=None, MFMA_PEAK_TFLOPS=MFMA_PEAK_TFLOPS):
     """Roofline numbers of one launch shape: bound by arithmetic intensity (activations once in, once out) against the ridge
-    of the two peaks; `ms` = average launch duration."""
+    of the two peaks; `ms` = average launch duration.  MFMA_PEAK_TFLOPS: the dense peak of the instruction the kernel issues."""
     tf = lambda t: flops / (t * 1e-3) / 1e12
     gbs = lambda t: alg_bytes / (t * 1e-3) / 1e9
     hbm_bound = flops / alg_bytes < MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
@@ -150,9 +153,17 @@ def _roof_kernel_name(nv, cfg, dtype, N):
     lay = nv.lib().iunet_conv3_pick_layout(dim, N, D, H, W, 2 * base, base)
     if nv.lib().iunet_conv3_compact_ok(dim, N, D, H, W, 2 * base, base, 0, 0):
         lay = 3                                    # what the engines launch (PackedConv.pick): the compact operator, padding-free step
-    kname = 'conv3_f8_kernel' if cfg['wq'] else {0: 'conv3_mfma_kernel', 1: 'conv3_v2_kernel', 2: 'conv3_v4_kernel', 3: 'conv3_v4_kernel'}[lay]
+    k128 = bool(cfg['wq']) and dim == 3 and nv.lib().iunet_f8_pack_order(27, 2 * base) == 1
+    kname = 'conv3_f8k_kernel' if k128 else 'conv3_f8_kernel' if cfg['wq'] else {0: 'conv3_mfma_kernel', 1: 'conv3_v2_kernel', 2: 'conv3_v4_kernel', 3: 'conv3_v4_kernel'}[lay]
     tname = 'bf16' if dtype == torch.bfloat16 else 'f16'
+    if k128:
+        return (f'{kname}<{tname}> (dec0.conv1 {2 * base}->{base} @ {N} x {"x".join(str(s) for s in shape)}, v_mfma_f32_16x16x128_f8f6f4, '
+                f'e4m3 activation planes in and out)'), lay
     return f'{kname}<{tname},{dim}> (dec0.conv1 {2 * base}->{base} @ {N} x {"x".join(str(s) for s in shape)})', lay
+
+
+def _f8_k128(nv, cfg):
+    return bool(cfg['wq']) and cfg['dim'] == 3 and nv.lib().iunet_f8_pack_order(27, 2 * cfg['base']) == 1
 
 
 def conv_roofline_in_situ(nv, cfg, workload, dtype, events):
@@ -169,7 +180,8 @@ def conv_roofline_in_situ(nv, cfg, workload, dtype, events):
     N = max(n for _, n in per)
     ms = ms_tot / len(per) * (N * len(per) / n_tot)             # average duration of a launch of N tiles
     flops = 2.0 * taps * cin * cout * vox * N
-    out = _roof_fields(flops, (cin + cout) * 2.0 * vox * N, ms)
+    k128 = _f8_k128(nv, cfg)            # e4m3 planes in and out: one byte per element; priced against the fp8 dense peak
+    out = _roof_fields(flops, (cin + cout) * (1.0 if k128 else 2.0) * vox * N, ms, MFMA_PEAK_TFLOPS=FP8_PEAK_TFLOPS if k128 else MFMA_PEAK_TFLOPS)
     name, _ = _roof_kernel_name(nv, cfg, dtype, N)
     out = {'bound': out.pop('bound'), 'kernel': name, **out}
     out.update({'launches': len(per), 'tiles_per_launch': N, 'measured': 'in situ: HIP events around the forward launches of this layer '
@@ -207,6 +219,11 @@ def conv_roofline_back_to_back(nv, cfg, workload, dtype, N, iters=50):
         nv.call('iunet_f8_pack_conv3', nv.ptr(w), None, None, None, None, 1e-5, nv.ptr(wb), nv.ptr(wsc), None, cout, cin, taps, nv.stream())
         run = lambda: nv.call('iunet_conv3_f8_fwd', dt, dim, nv.ptr(x), cin * vox, nv.ptr(y), cout * vox, nv.ptr(wb), nv.ptr(wsc),
                               nv.ptr(bias), N, D, H, W, cin, cout, 2, None, nv.stream())
+        if _f8_k128(nv, cfg):    # as the engine launches it: e4m3 activation planes in and out (one byte per element)
+            xq = (torch.randn(N * cin * vox, device=dev) * 2).to(torch.float8_e4m3fn).view(torch.uint8)
+            yq = torch.empty(N * cout * vox, dtype=torch.uint8, device=dev)
+            run = lambda: nv.call('iunet_conv3_f8_fwd_q', dt, dim, nv.ptr(xq), cin * vox, 1, nv.ptr(yq), cout * vox, 1, nv.ptr(wb), nv.ptr(wsc),
+                                  nv.ptr(bias), N, D, H, W, cin, cout, 2, None, nv.stream())
     for _ in range(3):
         run()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(iters + 1)]
@@ -217,7 +234,9 @@ def conv_roofline_back_to_back(nv, cfg, workload, dtype, N, iters=50):
     torch.cuda.synchronize()
     per = [ev[i].elapsed_time(ev[i + 1]) for i in range(iters)]
     ms = ev[0].elapsed_time(ev[iters]) / iters
-    out = _roof_fields(2.0 * taps * cin * cout * vox * N, (cin + cout) * 2.0 * vox * N, ms, sum(per[:8]) / 8, sum(per[-20:]) / 20)
+    k128 = _f8_k128(nv, cfg)
+    out = _roof_fields(2.0 * taps * cin * cout * vox * N, (cin + cout) * (1.0 if k128 else 2.0) * vox * N, ms, sum(per[:8]) / 8, sum(per[-20:]) / 20,
+                       MFMA_PEAK_TFLOPS=FP8_PEAK_TFLOPS if k128 else MFMA_PEAK_TFLOPS)
     out = {'bound': out.pop('bound'), 'kernel': name, **out}
     out.update({'launches': iters, 'tiles_per_launch': N, 'measured': f'3 warm-up + {iters} back-to-back launches of the layer alone'})
     return out

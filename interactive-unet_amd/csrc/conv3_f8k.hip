@@ -283,7 +283,7 @@ __global__ __launch_bounds__((F8KTile<SMALL>::NCW * 64 + f8k_loader_threads(IN8)
   // operand registers: K = 128 row fragments of the two groups, K = 128 operator fragments of the running and the next (group, dy),
   // and the K = 32 group's 8-byte fragments
   i32x8 R[2][NR + 2], A[2][2];
-  i64 R8[NR + 2], A8[2][2];
+  i64 R8[NR + 2], A8[3][2];
 
   auto rd128 = [&](const unsigned char* ptr, int second) -> i32x8 {          // two 16-byte halves `second` bytes apart
     const u32x4 lo = *(const u32x4*)ptr, hi = *(const u32x4*)(ptr + second);
@@ -298,12 +298,16 @@ __global__ __launch_bounds__((F8KTile<SMALL>::NCW * 64 + f8k_loader_threads(IN8)
       constexpr int r0 = dy == 0 ? 0 : NR - 1 + dy, r1 = dy == 0 ? NR : NR + dy;          // new rows: 0 .. 3, then 4, then 5
 #pragma unroll
       for (int r = r0; r < r1; ++r) R[g][r] = rd128(ab + rbase + coff[g] + r * PX * 16, PLANE);
-    } else {
+    } else if constexpr (dy == 0) {
+      // the ninth column's operands are 8 bytes per lane: ALL of them (6 operator + 6 row fragments, 24 registers) are read behind the
+      // last K = 128 sub-group, so the step's barrier can sit in front of its 24 K = 32 instructions -- the loaders get the buffer
+      // 384 matrix cycles earlier, and the next step's first 12 reads have those cycles to land
 #pragma unroll
-      for (int m = 0; m < 2; ++m) A8[dy & 1][m] = *(const i64*)(wl + W128 + (dy * 2 + m) * 512 + lane * 8);
-      constexpr int r0 = dy == 0 ? 0 : NR - 1 + dy, r1 = dy == 0 ? NR : NR + dy;
+      for (int d = 0; d < 3; ++d)
 #pragma unroll
-      for (int r = r0; r < r1; ++r) R8[r] = *(const i64*)(ab + rbase + coff8 + r * PX * 16);
+        for (int m = 0; m < 2; ++m) A8[d][m] = *(const i64*)(wl + W128 + (d * 2 + m) * 512 + lane * 8);
+#pragma unroll
+      for (int r = 0; r < NR + 2; ++r) R8[r] = *(const i64*)(ab + rbase + coff8 + r * PX * 16);
     }
   };
   auto mfma_sub = [&](auto SG, auto NREADS) {
@@ -314,22 +318,29 @@ __global__ __launch_bounds__((F8KTile<SMALL>::NCW * 64 + f8k_loader_threads(IN8)
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
         if constexpr (g < 2) acc[m][n] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A[sg & 1][m], R[g][n + dy], acc[m][n], 0, 0, 0, 0, 0, 0);
-        else acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(A8[dy & 1][m], R8[n + dy], acc[m][n], 0, 0, 0);
+        else acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(A8[dy][m], R8[n + dy], acc[m][n], 0, 0, 0);
       }
 #else
     if constexpr (g < 2) { asm volatile("" :: "v"(A[sg & 1][0]), "v"(A[sg & 1][1]), "v"(R[g][dy]), "v"(R[g][dy + 1]), "v"(R[g][dy + 2]), "v"(R[g][dy + 3])); }
-    else { asm volatile("" :: "v"(A8[dy & 1][0]), "v"(A8[dy & 1][1]), "v"(R8[dy]), "v"(R8[dy + 1]), "v"(R8[dy + 2]), "v"(R8[dy + 3])); }
+    else { asm volatile("" :: "v"(A8[dy][0]), "v"(A8[dy][1]), "v"(R8[dy]), "v"(R8[dy + 1]), "v"(R8[dy + 2]), "v"(R8[dy + 3])); }
 #endif
     // spread the next sub-group's LDS reads between this sub-group's 8 MFMAs
-    if constexpr (nreads > 0) {
+    if constexpr (nreads >= 8) {
       constexpr int RPM = (nreads + 7) / 8;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);         // one MFMA
         __builtin_amdgcn_sched_group_barrier(0x100, RPM, 0);       // RPM LDS reads
       }
+    } else if constexpr (nreads > 0) {
+      constexpr int MPR = 8 / nreads;
+#pragma unroll
+      for (int i = 0; i < nreads; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, MPR, 0);       // MPR MFMAs
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);         // one LDS read
+      }
     }
-    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (sg < 6 || sg == 8) __builtin_amdgcn_sched_barrier(0);      // (the three K = 32 sub-groups are one scheduling region)
   };
   auto tile_epilogue = [&](int s) {
     const int chunk = s - (s / nchunk) * nchunk;
@@ -404,12 +415,10 @@ __global__ __launch_bounds__((F8KTile<SMALL>::NCW * 64 + f8k_loader_threads(IN8)
     load_sub(ab, wl, I3{}); mfma_sub(I2{}, N12{});
     load_sub(ab, wl, I4{}); mfma_sub(I3{}, N6{});
     load_sub(ab, wl, I5{}); mfma_sub(I4{}, N6{});
-    load_sub(ab, wl, I6{}); mfma_sub(I5{}, N6{});
-    load_sub(ab, wl, I7{}); mfma_sub(I6{}, N3{});
-    load_sub(ab, wl, I8{}); mfma_sub(I7{}, N3{});
+    load_sub(ab, wl, I6{}); mfma_sub(I5{}, N12{});
     lds_barrier();                                           // step s + 1 is published; every read of step s has landed
-    load_sub(abn, wln, I0{});
-    mfma_sub(I8{}, N12{});
+    load_sub(abn, wln, I0{});                                // 12 reads spread over the 24 K = 32 instructions
+    mfma_sub(I6{}, N4{}); mfma_sub(I7{}, N4{}); mfma_sub(I8{}, N4{});
     tile_epilogue(s);
   }
 }

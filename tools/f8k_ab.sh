@@ -1,10 +1,12 @@
-B="python3 tools/bench_conv.py --only 0:128:64 --base 64 --levels 5 --f8 1 --wgrad 0 --iters 30"
+# A/B and ablation runs of the K = 128 fp8 conv on one layer (e4m3 planes in and out).  bash tools/f8k_ab.sh [L:Cin:Cout]
+# needs: tools/ab_build.sh conv3_f8k.hip -DF8K_NLT8=512 -> lib/libiunet_ab512.so, -DF8K_NOMFMA -> lib/libiunet_abnomfma.so
+LAYER=${1:-0:128:64}
+B="python3 tools/bench_conv.py --only $LAYER --base 64 --levels 5 --f8 2 --wgrad 0 --iters 30"
 L=interactive-unet_amd/lib
 run() { echo "== $1"; shift; env "$@" timeout -k 10 120 $B 2>&1 | grep "fp8"; }
-run main512 A=1
-run nlt256 IUNET_LIB=$L/libiunet_ab256.so
+run main A=1
+run loaders512 IUNET_LIB=$L/libiunet_ab512.so
 run nomfma IUNET_LIB=$L/libiunet_abnomfma.so
-run noconv IUNET_F8K_DBG=1
 run noactload IUNET_F8K_DBG=2
 run noweights IUNET_F8K_DBG=8
 run noact_noweights IUNET_F8K_DBG=10
