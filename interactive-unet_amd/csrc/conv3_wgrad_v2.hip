@@ -12,6 +12,7 @@
 //   (and reads half as many slabs: one workgroup per CU instead of two).
 #include "common.h"
 #include <cstdlib>
+#include <type_traits>
 
 #ifdef IUNET_STAMPS
 // Diagnostic build only (build.sh never defines IUNET_STAMPS): cycles and real time around the consumers' tile loop, to
@@ -46,7 +47,12 @@ __device__ __forceinline__ typename Vec8<T>::type tr_frag_v2(unsigned addr) {
   return __builtin_bit_cast(typename Vec8<T>::type, v);
 }
 
-template <typename T>
+// DYR ("dy reuse"): the consumers' second form.  A k-step is the 16 x voxels of row y in BOTH z slices of the tile (instead of two
+// consecutive rows of one slice), so the x fragment of halo row h serves the three taps dy = 0, 1, 2 (output rows h, h - 1, h - 2):
+// 10 x fragments per (dz, dx, ci half) and tile instead of 24, 43 % fewer LDS fragment reads in all (the first form reads 1 KB of
+// fragments per 1.6 MFMAs: 164 B/clk of the LDS's 256 beside the loaders' stores -- what held its matrix pipe at 65 %).  Work items =
+// (dz, dx, ci half, co half): 36, five for waves 0-3 and four for waves 4-7 (waves w and w + 4 share a SIMD: nine items each).
+template <typename T, bool DYR>
 __global__ __launch_bounds__(768, 1) void conv3_wgrad_v2_kernel(WgradV2Params p) {
   constexpr int TZ = 2, TY = 8, TX = 16, TAPS = 27;
   constexpr int PY = TY + 2, PX = TX + 2;
@@ -202,6 +208,98 @@ __global__ __launch_bounds__(768, 1) void conv3_wgrad_v2_kernel(WgradV2Params p)
   }
 
   // ==================================================================== consumer waves
+  if constexpr (DYR) {
+    using V8 = typename Vec8<T>::type;
+    const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3;
+    const int gh = g >> 1, gl = g & 1;
+    // lane part of the tr-read addresses (bytes): k-group gh = z slice (dy image: 128 voxels further; x image: the next ring slot),
+    // voxel (gl * 8 + q) of the row, channels 4 pp .. 4 pp + 3
+    const unsigned laneY = lds0 + OFF_Y + (pp >> 1) * PLANE_Y + (pp & 1) * 8 + (gh * (TY * TX) + gl * 8 + q) * 16;
+    const unsigned laneXb = lds0 + (pp >> 1) * PLANE_X + (pp & 1) * 8 + (gl * 8 + q) * 16;
+    // units (filter column c = dz * 3 + dx, ci half): 2 w and 2 w + 1 with both co halves; waves 0-3 also one co half of unit 16 + (w >> 1)
+    unsigned ustat[3];
+    int udz[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int u = k < 2 ? 2 * wave + k : 16 + ((wave & 3) >> 1);
+      const int c = u >> 1, cih = u & 1;
+      ustat[k] = (unsigned)__builtin_amdgcn_readfirstlane((c % 3) * 16 + cih * 2 * PLANE_X);
+      udz[k] = __builtin_amdgcn_readfirstlane(c / 3);
+    }
+    const int xco = wave & 1;                                       // co half of the fifth item (waves 0-3)
+    f32x4 acc[5][3];
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+      for (int d = 0; d < 3; ++d) acc[i][d] = f32x4{0, 0, 0, 0};
+    int base = 0;
+    lds_barrier();                                                 // tile 0 is in LDS
+    // one tile: halo rows h = 0 .. 9; row h multiplies the dy-gradient rows h (dy 0), h - 1 (dy 1), h - 2 (dy 2)
+    auto tile_body = [&](int k, auto NITEMS) {
+      constexpr int NIT = decltype(NITEMS)::value, NUN = NIT == 5 ? 3 : 2;
+      unsigned xoff[NUN];
+#pragma unroll
+      for (int u = 0; u < NUN; ++u) {
+        const unsigned s0 = (unsigned)(((base + udz[u]) % NSLOT) * ZPIX * 16), s1 = (unsigned)(((base + udz[u] + 1) % NSLOT) * ZPIX * 16);
+        xoff[u] = laneXb + ustat[u] + (gh ? s1 : s0);
+      }
+      const unsigned baseY = laneY + (unsigned)((k & 1) * YBUF);
+      auto rdA = [&](int y, int coh) { return tr_frag_v2<T>(baseY + (unsigned)(y * 16 * 16 + coh * 2 * PLANE_Y)); };
+      auto rdB = [&](int u, int h) { return tr_frag_v2<T>(xoff[u] + (unsigned)(h * PX * 16)); };
+      V8 Ar[4][2], Bq[2][NUN];
+      Ar[0][0] = rdA(0, 0); Ar[0][1] = rdA(0, 1);
+#pragma unroll
+      for (int u = 0; u < NUN; ++u) Bq[0][u] = rdB(u, 0);
+#pragma unroll
+      for (int h = 0; h < TY + 2; ++h) {
+        if (h + 1 < TY) { Ar[(h + 1) & 3][0] = rdA(h + 1, 0); Ar[(h + 1) & 3][1] = rdA(h + 1, 1); }
+        if (h + 1 < TY + 2) {
+#pragma unroll
+          for (int u = 0; u < NUN; ++u) Bq[(h + 1) & 1][u] = rdB(u, h + 1);
+        }
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          const int y = h - d;
+          if (y >= 0 && y < TY) {
+#pragma unroll
+            for (int i = 0; i < NIT; ++i) {
+              const int u = i >> 1;
+              const V8 a = i < 4 ? Ar[y & 3][i & 1] : (xco ? Ar[y & 3][1] : Ar[y & 3][0]);
+              acc[i][d] = mfma16<T>(a, Bq[h & 1][u], acc[i][d]);
+            }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    for (int k = 0; k < nt; ++k) {
+      if (!(p.dbg & 2)) {
+        if (wave < 4) tile_body(k, std::integral_constant<int, 5>{}); else tile_body(k, std::integral_constant<int, 4>{});
+      }
+      lds_barrier();
+      if (k + 1 < nt && fresh(k + 1)) {
+        lds_barrier();                                             // the loaders complete the new column's first tile
+        base = (base + 4) % NSLOT;
+      } else {
+        base = (base + 2) % NSLOT;
+      }
+    }
+    // ---- store the slab: rows = co (coh * 16 + 4 g + j), cols = ci ----
+    float* slab = p.slab + ((((long long)blockIdx.x * gridDim.y + cob) * gridDim.z + cib) * TAPS) * 1024;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      if (i == 4 && wave >= 4) break;
+      const int u = i < 4 ? 2 * wave + (i >> 1) : 16 + ((wave & 3) >> 1);
+      const int c = u >> 1, cih = u & 1, coh = i < 4 ? (i & 1) : xco;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        const int tap = ((c / 3) * 3 + d) * 3 + (c % 3);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) slab[tap * 1024 + (coh * 16 + 4 * g + j) * 32 + cih * 16 + i16] = acc[i][d][j];
+      }
+    }
+    return;
+  }
   // Unit wave uw owns units u = uw + 8 i (unit = tap x ci half: a 32 co x 16 ci block of dW) and walks ALL eight k-steps of
   // a tile, so its 7 x 2 accumulators are complete sums: no reduction between waves, and 56 accumulator registers leave
   // room for a deep fragment pipeline.  (Splitting the voxels over two wave groups instead halved the dy fragment reads
@@ -329,16 +427,17 @@ int iunet_conv3_wgrad_v2_launch(int dtype, const void* x, long long x_ss, const 
   p.tilesZ = (D + 1) / 2; p.tilesY = (H + 7) / 8; p.tilesX = (W + 15) / 16;
   static const int dbg = getenv("IUNET_WG2_DBG") ? atoi(getenv("IUNET_WG2_DBG")) : 0;
   p.dbg = dbg;
+  static const int dyr = getenv("IUNET_WG2_DYR") ? atoi(getenv("IUNET_WG2_DYR")) : 1;      // A/B switch: 0 = the first consumer form
   constexpr int PLANE_X = 6 * 180 * 16 + 192, PLANE_Y = 256 * 16 + 64;
   constexpr int LDS = 4 * PLANE_X + 2 * 4 * PLANE_Y;      // 103 168 B: x z-plane ring + two dy buffers
   const int nb = iunet_conv3_wgrad_v2_blocks(N, D, H, W, Cin, Cout);
   dim3 grid(nb, Cout / 32, Cin / 32);
   if (dtype == 0) {
-    IUNET_SET_MAX_LDS(conv3_wgrad_v2_kernel<f16>, LDS);
-    hipLaunchKernelGGL(conv3_wgrad_v2_kernel<f16>, grid, dim3(768), LDS, stream, p);
+    if (dyr) { IUNET_SET_MAX_LDS((conv3_wgrad_v2_kernel<f16, true>), LDS); hipLaunchKernelGGL((conv3_wgrad_v2_kernel<f16, true>), grid, dim3(768), LDS, stream, p); }
+    else { IUNET_SET_MAX_LDS((conv3_wgrad_v2_kernel<f16, false>), LDS); hipLaunchKernelGGL((conv3_wgrad_v2_kernel<f16, false>), grid, dim3(768), LDS, stream, p); }
   } else {
-    IUNET_SET_MAX_LDS(conv3_wgrad_v2_kernel<bf16>, LDS);
-    hipLaunchKernelGGL(conv3_wgrad_v2_kernel<bf16>, grid, dim3(768), LDS, stream, p);
+    if (dyr) { IUNET_SET_MAX_LDS((conv3_wgrad_v2_kernel<bf16, true>), LDS); hipLaunchKernelGGL((conv3_wgrad_v2_kernel<bf16, true>), grid, dim3(768), LDS, stream, p); }
+    else { IUNET_SET_MAX_LDS((conv3_wgrad_v2_kernel<bf16, false>), LDS); hipLaunchKernelGGL((conv3_wgrad_v2_kernel<bf16, false>), grid, dim3(768), LDS, stream, p); }
   }
   IUNET_CHECK_HIP(hipGetLastError());
   return IUNET_OK;
