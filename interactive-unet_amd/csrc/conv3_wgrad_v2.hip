@@ -22,6 +22,9 @@ extern "C" int iunet_wg2_stamps_read(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wg2_stamps), sizeof(unsigned long long) * 4 * 512);
 }
 #endif
+// 16 zero bytes: the source of the voxels outside the image when a tile goes global -> LDS without registers
+__device__ __attribute__((aligned(16))) unsigned int g_wg2_zero16[4] = {0u, 0u, 0u, 0u};
+
 namespace {
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -36,7 +39,7 @@ struct WgradV2Params {
   float* slab;                        // [gridDim.x][Cout/32][Cin/32][27][32][32]
   int N, D, H, W, Cin, Cout;
   int tilesZ, tilesY, tilesX;
-  int dbg;                            // profiling only (IUNET_WG2_DBG): 1 no refill after tile 0, 2 no MFMA phase
+  int dbg;                            // profiling only (IUNET_WG2_DBG): 1 no refill after tile 0, 2 no MFMA phase, 4 register-staged loads always
 };
 
 template <typename T>
@@ -98,6 +101,86 @@ __global__ __launch_bounds__(768, 1) void conv3_wgrad_v2_kernel(WgradV2Params p)
   if (wave >= NCW) {
     // ================================================================== loader waves
     const int lt = tid - NCW * 64;
+    if (p.x_scale == nullptr && !(p.dbg & 4)) {
+      // ---- everything by LDS-DMA (launches whose input needs no arithmetic on the way; IUNET_WG2_DBG=4: the register path always).
+      // Loader wave w copies channel plane w of x (3 wave instructions per halo z-plane: 180 voxels) and plane w of dy (4 instructions:
+      // 256 voxels) global -> LDS without registers; voxels outside the image read 16 zero bytes.  Tile k + 1 is copied while the
+      // consumers work on tile k -- into the ring slots / dy buffer they are not reading --, waited for and published by the tile's barrier.
+      const int lw = __builtin_amdgcn_readfirstlane(lt >> 6), ll = lt & 63;
+      int xcd[3], ycd[4];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int pix = j * 64 + ll;
+        xcd[j] = pix < ZPIX ? ((pix / PX) << 8) | (pix % PX) : -1;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int pix = j * 64 + ll;
+        ycd[j] = (pix % TX) | (((pix / TX) % TY) << 8) | ((pix / (TX * TY)) << 16);
+      }
+      auto dma16 = [&](const void* gsrc, unsigned dst) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+      };
+      // halo planes pz in [pz_lo, pz_hi) of tile k -> ring slots (slot0 + pz - pz_lo ... ) given by slot_of(pz)
+      auto dma_x = [&](int k, int pz_lo, int pz_hi, int slot_first) {
+        int n_img, z0, y0, x0;
+        tile_origin(k, n_img, z0, y0, x0);
+        const T* xin = (const T*)p.x + (long long)n_img * p.x_ss + (long long)(cib * 4 + lw) * plane_stride;
+        for (int pz = pz_lo; pz < pz_hi; ++pz) {
+          const int slot = (slot_first + pz - pz_lo) % NSLOT;
+          const int gz = z0 + pz - 1;
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            if (xcd[j] >= 0) {
+              const int gy = y0 + (xcd[j] >> 8) - 1, gx = x0 + (xcd[j] & 255) - 1;
+              const bool ok = (unsigned)gz < (unsigned)p.D && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+              const void* gsrc = ok ? (const void*)(xin + (((long long)gz * p.H + gy) * p.W + gx) * 8) : (const void*)g_wg2_zero16;
+              dma16(gsrc, __builtin_amdgcn_readfirstlane(lds0 + lw * PLANE_X + slot * (ZPIX * 16) + j * 1024));
+            }
+          }
+        }
+      };
+      auto dma_y = [&](int k) {
+        int n_img, z0, y0, x0;
+        tile_origin(k, n_img, z0, y0, x0);
+        const T* dyin = (const T*)p.dy + (long long)n_img * p.dy_ss + (long long)(cob * 4 + lw) * plane_stride;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int gz = z0 + (ycd[j] >> 16), gy = y0 + ((ycd[j] >> 8) & 255), gx = x0 + (ycd[j] & 255);
+          const bool ok = gz < p.D && gy < p.H && gx < p.W;
+          const void* gsrc = ok ? (const void*)(dyin + (((long long)gz * p.H + gy) * p.W + gx) * 8) : (const void*)g_wg2_zero16;
+          dma16(gsrc, __builtin_amdgcn_readfirstlane(lds0 + OFF_Y + (k & 1) * YBUF + lw * PLANE_Y + j * 1024));
+        }
+      };
+      auto landed = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+      const bool refill = !(p.dbg & 1);
+      int base = 0;
+      if (nt > 0) { dma_x(0, 0, 4, 0); dma_y(0); }
+      landed();
+      lds_barrier();
+      for (int k = 0; k < nt; ++k) {
+        const bool more = k + 1 < nt && refill;
+        const bool fr = more && fresh(k + 1);
+        if (more) {
+          // incoming planes go to the two free slots base + 4, base + 5: pz 2, 3 of a continuing column, pz 0, 1 of a new one
+          if (fr) dma_x(k + 1, 0, 2, base + 4); else dma_x(k + 1, 2, 4, base + 4);
+          dma_y(k + 1);
+        }
+        landed();
+        lds_barrier();                              // tile k is consumed
+        if (k + 1 < nt && fresh(k + 1)) {             // (same condition as the consumers': the barrier count must match)
+          if (fr) dma_x(k + 1, 2, 4, base + 6);       // pz 2, 3 of the new column into the slots tile k just released (base, base + 1)
+          landed();
+          lds_barrier();
+          base = (base + 4) % NSLOT;
+        } else {
+          base = (base + 2) % NSLOT;
+        }
+      }
+      return;
+    }
     struct Staged { u32x4 x[XIT]; u32x4 y[YIT]; unsigned okx, oky; };
     // per-thread item tables, computed once: the loaders' integer arithmetic per tile is what their rate depends on
     // x: loader wave w owns channel plane w (its BatchNorm constants are then wave-uniform); item = (zi, voxel of the
