@@ -372,6 +372,12 @@ int iunet_gn_num_parts(int N, long long vox);
 int iunet_gn_relu_fwd(int dtype, const void* y, long long y_ss, void* z, long long z_ss, const void* gamma, const void* beta,
                       int groups, float eps, void* slab, void* scale, void* shift, void* mean, void* invstd, int C, int N,
                       long long vox, void* stream);
+/* GroupNorm statistics of ONE sample from the statistics epilogue of the convolutions (stats = [nparts][C][2] partial (sum, sum of
+ * squares) of a launch with N = 1: iunet_conv3_fwd / iunet_first_conv_fwd, nparts = iunet_conv3_stats_parts / iunet_conv3_num_tiles)
+ * -> scale / shift / mean / invstd [C] of that sample, applied by iunet_conv3_fwd_act (in the next conv's loader waves) or by
+ * iunet_bn_relu_fwd / iunet_bn_relu_pool_fwd: the fused form of the inference GroupNorm (no statistics pass over the tensor). */
+int iunet_gn_finalize(const void* stats, int nparts, int C, int groups, long long vox, const void* gamma, const void* beta, float eps,
+                      void* scale, void* shift, void* mean, void* invstd, void* stream);
 int iunet_gn_relu_bwd(int dtype, const void* dz, long long dz_ss, const void* y, long long y_ss, void* dy, long long dy_ss,
                       const void* gamma, int groups, const void* scale, const void* shift, const void* mean, const void* invstd,
                       void* dgamma, void* dbeta, void* slab, void* coef, int C, int N, long long vox, void* stream);

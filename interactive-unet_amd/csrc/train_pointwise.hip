@@ -1098,6 +1098,21 @@ int iunet_gn_relu_fwd(int dtype, const void* y, long long y_ss, void* z, long lo
   return IUNET_OK;
 }
 
+// GroupNorm statistics of ONE sample from the BatchNorm-statistics epilogue of the convolutions (stats = [nparts][C][2] partial sums
+// (sum, sum of squares) of a launch with N = 1: iunet_conv3_fwd / iunet_first_conv_fwd) -> scale / shift / mean / invstd [C] of that
+// sample: what iunet_conv3_fwd_act (the next conv's loader waves) and iunet_bn_relu_fwd / _pool_fwd apply.  The statistics pass of
+// iunet_gn_relu_fwd over the tensor goes away.
+int iunet_gn_finalize(const void* stats, int nparts, int C, int groups, long long vox, const void* gamma, const void* beta, float eps,
+                      void* scale, void* shift, void* mean, void* invstd, void* stream) {
+  IUNET_REQUIRE(stats && gamma && beta && scale && shift && mean && invstd, "gn_finalize: null pointer");
+  IUNET_REQUIRE(nparts > 0 && C > 0 && groups > 0 && C % groups == 0 && vox > 0, "gn_finalize: %d parts, %d channels in %d groups, %lld voxels",
+                nparts, C, groups, vox);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, 1), dim3(64), 0, (hipStream_t)stream, (const float*)stats, nparts, C, groups,
+                     (double)vox, (const float*)gamma, (const float*)beta, eps, (float*)scale, (float*)shift, (float*)mean, (float*)invstd);
+  IUNET_CHECK_HIP(hipGetLastError());
+  return IUNET_OK;
+}
+
 // backward of z = relu(group_norm(y)): dy, dgamma, dbeta from dz and y; scale / shift / mean / invstd [N][C] from the forward;
 // slab as above, coef: N * C * 3 floats of scratch.  C <= 1024.
 int iunet_gn_relu_bwd(int dtype, const void* dz, long long dz_ss, const void* y, long long y_ss, void* dy, long long dy_ss,

@@ -116,6 +116,7 @@ _SIGS = {
     'iunet_bn_relu_bwd_apply': [c_int, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                 c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_ll, c_void_p],
     'iunet_gn_num_parts': [c_int, c_ll],
+    'iunet_gn_finalize': [c_void_p, c_int, c_int, c_int, c_ll, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     'iunet_gn_relu_fwd': [c_int, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p,
                           c_void_p, c_void_p, c_int, c_int, c_ll, c_void_p],
     'iunet_gn_relu_bwd': [c_int, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_int, c_void_p, c_void_p, c_void_p,

@@ -212,6 +212,16 @@ class Engine:
             if self.norm == 'group':
                 f32 = lambda n: torch.empty(n, dtype=torch.float32, device=self.device)
                 ws['raw'] = mk(max(self.ch[l] * _vox(dims[l]) for l in range(self.levels)), 1)
+                # fused form (one sample at a time): raw outputs of a stage's two convs, the convs' statistics rows, two
+                # (scale, shift, mean, invstd) sets
+                one = max(self.ch[l] * _vox(dims[l]) for l in range(self.levels))
+                ws['rawA'] = torch.empty(one, dtype=self.act_dtype, device=self.device)
+                ws['rawB'] = torch.empty(one, dtype=self.act_dtype, device=self.device)
+                parts = max(max(nv.lib().iunet_conv3_num_tiles(self.dim, 1, *dims[l]),
+                                nv.lib().iunet_conv3_stats_parts(self.dim, 1, *dims[l], self.ch[l], 2)) * self.ch[l] for l in range(self.levels))
+                ws['gstats'] = f32(2 * parts)
+                ws['gnA'] = [f32(max(self.ch)) for _ in range(4)]
+                ws['gnB'] = [f32(max(self.ch)) for _ in range(4)]
                 ws['gn'] = [f32(N * max(self.ch)) for _ in range(4)]
                 ws['gnslab'] = f32(max(nv.lib().iunet_gn_num_parts(N, _vox(dims[l])) * self.ch[l] * 2 for l in range(self.levels)))
             if len(self._ws_cache) > 4:
@@ -227,6 +237,82 @@ class Engine:
         v = _vox(dims)
         nv.call('iunet_gn_relu_fwd', self.dt, nv.ptr(ws['raw']), co * v, y_ptr, y_ss, nv.ptr(gamma), nv.ptr(beta), self.groups,
                 BN_EPS, nv.ptr(ws['gnslab']), nv.ptr(sc), nv.ptr(sh), nv.ptr(mu), nv.ptr(ist), co, N, v, s)
+
+    def _gn_stage(self, ws, stage, x_ptr, ci, co, d, z_ptr, s, first=None, pool=None):
+        """One stage (two convs, GroupNorm + ReLU after each) of ONE sample, fused as the BatchNorm training forward is: the convs'
+        epilogues deliver the per-channel sums (iunet_gn_finalize turns them into the sample's scale / shift), conv1's activation
+        is applied by conv2's loader waves and never written, conv2's is written once (with the max-pool of an encoder stage in the
+        same pass).  x_ptr: this sample's input planes (first: (x tensor, strides, sample) for the network's first conv);
+        z_ptr: this sample's output planes; pool = (pooled output pointer, pooled dims)."""
+        L = nv.lib()
+        v = _vox(d)
+        st = ws['gstats']
+        for j, (a, b, src) in enumerate(((ci, co, x_ptr), (co, co, None)), 1):
+            name = f'{stage}.conv{j}'
+            pk, _, gamma, beta = self.packed[name]
+            y = ws['rawA'] if j == 1 else ws['rawB']
+            sc, sh, mu, ist = ws['gnA'] if j == 1 else ws['gnB']
+            if first is not None and j == 1:
+                x, xs, n = first
+                nparts = L.iunet_conv3_num_tiles(self.dim, 1, *d)
+                nv.call('iunet_first_conv_fwd', self.dt, self.dim, ctypes.c_void_p(x.data_ptr() + n * xs[0] * x.element_size()),
+                        nv.IN_DTYPE_CODE[x.dtype], nv.ll_array(xs), nv.ptr(y), b * v, nv.ptr(pk), None, nv.ptr(st),
+                        1, d[0], d[1], d[2], a, b, 0, s)
+            elif j == 1:
+                lay, wpk = pk.pick(self.dim, 1, *d)
+                nparts = L.iunet_conv3_stats_parts(self.dim, 1, *d, b, lay)
+                nv.call('iunet_conv3_fwd', self.dt, self.dim, src, a * v, nv.ptr(y), b * v, nv.ptr(wpk), None, nv.ptr(st),
+                        1, d[0], d[1], d[2], a, b, 0, lay, s)
+            else:
+                scA, shA = ws['gnA'][0], ws['gnA'][1]
+                lay, wpk = pk.pick(self.dim, 1, *d, act=True)
+                if lay in (2, 3):            # conv1's GroupNorm + ReLU in this conv's loader waves
+                    nparts = L.iunet_conv3_stats_parts(self.dim, 1, *d, b, lay)
+                    nv.call('iunet_conv3_fwd_act', self.dt, self.dim, nv.ptr(ws['rawA']), a * v, nv.ptr(y), b * v, nv.ptr(wpk), None,
+                            nv.ptr(st), nv.ptr(scA), nv.ptr(shA), 1, d[0], d[1], d[2], a, b, 0, lay, s)
+                else:                        # layouts without the fused input activation: materialise it (in place of the raw output)
+                    nv.call('iunet_bn_relu_fwd', self.dt, nv.ptr(ws['rawA']), a * v, nv.ptr(ws['rawA']), a * v, nv.ptr(scA), nv.ptr(shA),
+                            a, 1, v, s)
+                    lay, wpk = pk.pick(self.dim, 1, *d)
+                    nparts = L.iunet_conv3_stats_parts(self.dim, 1, *d, b, lay)
+                    nv.call('iunet_conv3_fwd', self.dt, self.dim, nv.ptr(ws['rawA']), a * v, nv.ptr(y), b * v, nv.ptr(wpk), None,
+                            nv.ptr(st), 1, d[0], d[1], d[2], a, b, 0, lay, s)
+            nv.call('iunet_gn_finalize', nv.ptr(st), nparts, b, self.groups, v, nv.ptr(gamma), nv.ptr(beta), BN_EPS,
+                    nv.ptr(sc), nv.ptr(sh), nv.ptr(mu), nv.ptr(ist), s)
+        scB, shB = ws['gnB'][0], ws['gnB'][1]
+        if pool is not None:
+            p_ptr, do = pool
+            nv.call('iunet_bn_relu_pool_fwd', self.dt, self.dim, nv.ptr(ws['rawB']), co * v, z_ptr, co * v, p_ptr, co * _vox(do),
+                    nv.ptr(scB), nv.ptr(shB), co, 1, do[0], do[1], do[2], s)
+        else:
+            nv.call('iunet_bn_relu_fwd', self.dt, nv.ptr(ws['rawB']), co * v, z_ptr, co * v, nv.ptr(scB), nv.ptr(shB), co, 1, v, s)
+
+    def _infer_gn_features(self, ws, x, x_strides, N, s):
+        """The GroupNorm network up to the head's input (ws['b0']), one sample at a time through _gn_stage (GroupNorm statistics are
+        per sample: a launch of one sample delivers them in the conv epilogue's rows)."""
+        dims, L, ch = ws['dims'], self.levels, self.ch
+        P = lambda t, off_elems=0: ctypes.c_void_p(t.data_ptr() + off_elems * t.element_size())
+        for l in range(L):
+            v = _vox(dims[l])
+            for n in range(N):
+                ci = self.cin if l == 0 else ch[l - 1]
+                src = None if l == 0 else P(ws[f'pin{l}'], n * ci * v)
+                first = (x, x_strides, n) if l == 0 else None
+                if l < L - 1:
+                    vo = _vox(dims[l + 1])
+                    self._gn_stage(ws, f'enc{l}', src, ci, ch[l], dims[l], P(ws[f'cat{l}'], n * 2 * ch[l] * v), s, first=first,
+                                   pool=(P(ws[f'pin{l + 1}'], n * ch[l] * vo), dims[l + 1]))
+                else:
+                    self._gn_stage(ws, f'enc{l}', src, ci, ch[l], dims[l], P(ws[f'b{l}'], n * ch[l] * v), s, first=first)
+        for l in range(L - 2, -1, -1):
+            v, vi = _vox(dims[l]), _vox(dims[l + 1])
+            wpk, bias = self.packed[f'dec{l}.up']
+            nv.call('iunet_convT_fwd', self.dt, self.dim, P(ws[f'b{l + 1}']), ch[l + 1] * vi,
+                    P(ws[f'cat{l}'], ch[l] * v), 2 * ch[l] * v, nv.ptr(wpk), nv.ptr(bias),
+                    N, dims[l + 1][0], dims[l + 1][1], dims[l + 1][2], ch[l + 1], ch[l], s)
+            for n in range(N):
+                self._gn_stage(ws, f'dec{l}', P(ws[f'cat{l}'], n * 2 * ch[l] * v), 2 * ch[l], ch[l], dims[l],
+                               P(ws[f'b{l}'], n * ch[l] * v), s)
 
     def _conv3(self, x_ptr, x_ss, y_ptr, y_ss, name, N, dims, ci, co, s, ws=None, xf=0, yf=0):
         pk, bias = self.packed[name][0], self.packed[name][1]
@@ -276,7 +362,10 @@ class Engine:
         L, ch = self.levels, self.ch
         P = lambda t, off_elems=0: ctypes.c_void_p(t.data_ptr() + off_elems * t.element_size())
         q = 1 if self.q_planes() else 0            # a / cat / pin are e4m3 planes (one byte per element: the offsets below hold as they are)
-        for l in range(L):
+        gn_fused = self.norm == 'group' and os.environ.get('IUNET_GN_FUSED', '1') != '0'      # (0: the two-pass form, A/B switch)
+        if gn_fused:
+            self._infer_gn_features(ws, x, x_strides, N, s)
+        for l in range(L if not gn_fused else 0):
             v = _vox(dims[l])
             if l == 0:
                 w, b = self.packed['enc0.conv1'][0], self.packed['enc0.conv1'][1]
@@ -307,7 +396,7 @@ class Engine:
             else:
                 self._conv3(P(ws[f'a{l}']), ch[l] * v, P(ws[f'b{l}']), ch[l] * v, f'enc{l}.conv2', N, dims[l],
                             ch[l], ch[l], s, ws, q, 0)
-        for l in range(L - 2, -1, -1):
+        for l in range(L - 2, -1, -1) if not gn_fused else ():
             v, vi = _vox(dims[l]), _vox(dims[l + 1])
             wpk, bias = self.packed[f'dec{l}.up']
             nv.call('iunet_convT_fwd_q' if q else 'iunet_convT_fwd', self.dt, self.dim, P(ws[f'b{l + 1}']), ch[l + 1] * vi,

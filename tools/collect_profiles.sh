@@ -34,27 +34,35 @@ stats bench_c5 python3 $R/bench.py --workload c5 --steps 3 --warmup 1 --no-cpu-b
 stats bench_c2 python3 $R/bench.py --workload c2 --steps 5 --warmup 2 --no-cpu-baseline
 # the launches of the roofline layer (dec0.conv1 forward) inside the profiled steps: what bench.py's in-situ `roofline` times
 python3 $R/tools/roofline_launches.py $OUT/bench_c3_kernel_trace.csv 'conv3_v4_kernelIDF16bLi3ELb0ELb0ELb0ELb0ELb1ELb0E' 300 460 262144 1 > $OUT/${RND}_bench_c3_roofline_launches.txt      # 256 workgroups x 1024 threads: the bf16 compact-operator variant (8 loader waves)
-python3 $R/tools/roofline_launches.py $OUT/bench_c5_kernel_trace.csv conv3_f8_kernel 400 1000 98304 2 > $OUT/${RND}_bench_c5_roofline_launches.txt
+python3 $R/tools/roofline_launches.py $OUT/bench_c5_kernel_trace.csv conv3_f8k_kernel 250 600 98304 2 > $OUT/${RND}_bench_c5_roofline_launches.txt      # 2 x 128 workgroups x 768 threads: the K = 128 kernel on e4m3 planes
 python3 $R/tools/roofline_launches.py $OUT/bench_c2_kernel_trace.csv conv3_v4_kernel 85 140 196608 1 > $OUT/${RND}_bench_c2_roofline_launches.txt
 # 3. the roofline kernels alone: 3 warm-up + 50 launches, the sequence bench.py times
 stats roofline_c3 python3 $R/tools/bench_conv.py --only 0:64:32 --wgrad 0 --iters 50 --n 2
 stats roofline_c3_1tile python3 $R/tools/bench_conv.py --only 0:64:32 --wgrad 0 --iters 50
-stats roofline_c5 python3 $R/tools/bench_conv.py --only 0:128:64 --base 64 --levels 5 --wgrad 0 --f8 1 --iters 50
+stats roofline_c5 python3 $R/tools/bench_conv.py --only 0:128:64 --base 64 --levels 5 --wgrad 0 --f8 2 --iters 50      # e4m3 planes in and out, as the engine launches it
 stats roofline_c2 python3 $R/tools/bench_conv.py --only 0:64:32 --dim 2 --size 512 --n 8 --dtype f16 --wgrad 0 --iters 50
 # the split-precision (fp16x2) conv of the same layer alone, and one whole split-precision forward per configuration
 stats roofline_x2 python3 $R/tools/bench_conv.py --only 0:64:32 --wgrad 0 --iters 50 --n 2 --x2 2
 stats forward_x2 python3 $R/tools/bench_x2.py x2
 python3 $R/tools/bench_conv.py --wgrad 0 --iters 30 --n 1 --x2 1 > $OUT/${RND}_conv_layers_x2_3d.txt 2>/dev/null
 python3 $R/tools/bench_conv.py --dim 2 --size 512 --n 8 --dtype f16 --wgrad 0 --iters 30 --x2 1 > $OUT/${RND}_conv_layers_x2_2d.txt 2>/dev/null
+# every C5 stage-conv shape: 16-bit kernel and the K = 128 fp8 kernel on e4m3 planes side by side
+python3 $R/tools/bench_conv.py --base 64 --levels 5 --f8 2 --wgrad 0 --iters 30 > $OUT/${RND}_conv_layers_c5_f8.txt 2>/dev/null
+# the training step and the C5 prediction forward by kernel
+rm -rf $OUT/tmp_tr; rocprofv3 --kernel-trace --output-format csv -d $OUT/tmp_tr -o tr -- python3 $R/tools/bench_train3d.py 10 > $OUT/train3d.log 2>&1
+python3 $R/tools/step_profile.py $OUT/tmp_tr/tr_kernel_trace.csv 13 40 > $OUT/${RND}_train_step_by_kernel.txt; rm -rf $OUT/tmp_tr
+rm -rf $OUT/tmp_c5; rocprofv3 --kernel-trace --output-format csv -d $OUT/tmp_c5 -o c5 -- python3 $R/tools/bench_c5_predict.py 10 > $OUT/c5_predict.log 2>&1
+python3 $R/tools/step_profile.py $OUT/tmp_c5/c5_kernel_trace.csv 13 20 > $OUT/${RND}_c5_forward_by_kernel.txt; rm -rf $OUT/tmp_c5
+echo "done layer tables and step profiles"
 # 4. HBM traffic of the roofline kernels (separate passes, as the guide prescribes)
 for c in FETCH_SIZE WRITE_SIZE; do
   pmc c3 $c python3 $R/tools/bench_conv.py --only 0:64:32 --wgrad 0 --iters 2
-  pmc c5 $c python3 $R/tools/bench_conv.py --only 0:128:64 --base 64 --levels 5 --wgrad 0 --f8 1 --iters 2
+  pmc c5 $c python3 $R/tools/bench_conv.py --only 0:128:64 --base 64 --levels 5 --wgrad 0 --f8 2 --iters 2
   pmc c2 $c python3 $R/tools/bench_conv.py --only 0:64:32 --dim 2 --size 512 --n 8 --dtype f16 --wgrad 0 --iters 2
   pmc x2 $c python3 $R/tools/bench_conv.py --only 0:64:32 --wgrad 0 --iters 2 --x2 2
 done
 python3 $R/tools/pmc_json.py $OUT $RND c3 conv3_v4_kernel 'dec0.conv1 64->32 @ 1 x 128^3 bf16' 402653184 1
-python3 $R/tools/pmc_json.py $OUT $RND c5 conv3_f8_kernel 'dec0.conv1 128->64 @ 1 x 128^3 bf16 in / fp8 MFMA' 805306368 1
+python3 $R/tools/pmc_json.py $OUT $RND c5 conv3_f8k_kernel 'dec0.conv1 128->64 @ 1 x 128^3, e4m3 planes in and out, K = 128 fp8 MFMA' 402653184 1
 python3 $R/tools/pmc_json.py $OUT $RND c2 conv3_v4_kernel 'dec0.conv1 64->32 @ 8 x 512^2 f16' 402653184 8
 python3 $R/tools/pmc_json.py $OUT $RND x2 conv3_v4_kernel 'dec0.conv1 64->32 @ 1 x 128^3 fp16x2 (hi + lo planes in and out)' 805306368 1
 ls -la $OUT
