@@ -714,12 +714,14 @@ def main():
         else:
             out['parity'] = {'skipped': 'the fp32 and fp16x2 modes fold BatchNorm; the GroupNorm network is checked against the oracle '
                                         'in tests/test_gpu_groupnorm.py'}
+        # (the 2.5-D leg's device timings come BEFORE the host baseline: its ~90 launches per block are sensitive to the host cores, and the
+        #  baseline's 16 torch threads keep spinning for a while after their last operator -- one run read 6.8 ms instead of 3.0 that way)
+        if args.workload in ('c3', 'c2') and not args.no_2p5d:
+            out['legs']['predict_2p5d'] = predict_2p5d_leg(dev, world == 1 and not args.no_cpu_baseline)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'], chk = cpu_baseline(cfg, model if args.norm == 'batch' else None, probe)
             if chk:
                 out['parity']['vs_cpu_oracle'] = chk
-        if args.workload in ('c3', 'c2') and not args.no_2p5d:
-            out['legs']['predict_2p5d'] = predict_2p5d_leg(dev, world == 1 and not args.no_cpu_baseline)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -251,7 +251,7 @@ struct ConvTParams {
   int out8;                    // 1: y = e4m3 planes [Cout / 16][2D][2H][2W][16 B], y_sstride in bytes
 };
 
-template <typename T, int ND>
+template <typename T, int ND, bool O8 = false>      // O8: e4m3 planes out (a template flag: its store code costs the 16-bit forms registers)
 __global__ __launch_bounds__(256) void convT_kernel(ConvTParams p) {
   using V8 = typename Vec8<T>::type;
   constexpr int NPOS = ND == 3 ? 8 : 4;
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(256) void convT_kernel(ConvTParams p) {
       }
       const int xo = 2 * x0 + 16 * h + l15;                    // output x of this lane in instruction h
       if (xo < Wo) {
-        if (!p.out8) *(i32x4*)(row + (16 * h + l15) * 8) = v;
+        if constexpr (!O8) *(i32x4*)(row + (16 * h + l15) * 8) = v;
         else e4m3_store8<T>((unsigned char*)p.y + (long long)n * p.y_sstride, cob * 4 + q, ((long long)oz * Ho + y * 2 + b) * Wo + xo,
                             (long long)Do * Ho * Wo, __builtin_bit_cast(u32x4, v));
       }
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256) void convT_kernel(ConvTParams p) {
 // wave and step: the kernel above fetches 16 KB of weight fragments per k-step and wave through the vector cache to
 // move 10 KB of activations -- 4x more cache traffic for the weights than for the tensor, 3.0 TB/s.  Here the only
 // global traffic is the tensor itself.
-template <typename T, int ND, int NK>
+template <typename T, int ND, int NK, bool O8 = false>
 __global__ __launch_bounds__(256) void convT_lds_kernel(ConvTParams p) {
   using V8 = typename Vec8<T>::type;
   constexpr int NPOS = ND == 3 ? 8 : 4;
@@ -430,7 +430,7 @@ __global__ __launch_bounds__(256) void convT_lds_kernel(ConvTParams p) {
             v[d] = odd ? t1 : t0;
           }
           if (2 * x0 + 16 * h + l15 < Wo) {
-            if (!p.out8) *(i32x4*)(row + (16 * h + l15) * 8) = v;
+            if constexpr (!O8) *(i32x4*)(row + (16 * h + l15) * 8) = v;
             else e4m3_store8<T>((unsigned char*)p.y + (long long)n_[g] * p.y_sstride, cob * 4 + q,
                                 ((long long)oz * Ho + y_[g] * 2 + bb) * Wo + 2 * x0 + 16 * h + l15, (long long)Do * Ho * Wo,
                                 __builtin_bit_cast(u32x4, v));
@@ -445,7 +445,7 @@ __global__ __launch_bounds__(256) void convT_lds_kernel(ConvTParams p) {
 // the top fetches them per wave and k-step through the vector cache (1 KB of weight fragments per voxel and k-step: C5's
 // 256 / 512 / 1024-channel levels ran 60-115 us on a few MB of tensor).  Here they pass through LDS in chunks of NK = 4 k-steps
 // shared by the workgroup's 4 waves x 2 voxel groups; the accumulators live across the chunks.
-template <typename T, int ND>
+template <typename T, int ND, bool O8 = false>
 __global__ __launch_bounds__(256) void convT_chunk_kernel(ConvTParams p) {
   constexpr int NK = 4;
   using V8 = typename Vec8<T>::type;
@@ -571,7 +571,7 @@ __global__ __launch_bounds__(256) void convT_chunk_kernel(ConvTParams p) {
             v[d] = odd ? t1 : t0;
           }
           if (2 * x0 + 16 * h + l15 < Wo) {
-            if (!p.out8) *(i32x4*)(row + (16 * h + l15) * 8) = v;
+            if constexpr (!O8) *(i32x4*)(row + (16 * h + l15) * 8) = v;
             else e4m3_store8<T>((unsigned char*)p.y + (long long)n_[g] * p.y_sstride, cob * 4 + q,
                                 ((long long)oz * Ho + y_[g] * 2 + bb) * Wo + 2 * x0 + 16 * h + l15, (long long)Do * Ho * Wo,
                                 __builtin_bit_cast(u32x4, v));
@@ -730,6 +730,7 @@ int iunet_maxpool_q_launch(int nd, const void* x, long long x_ss, void* y, long 
 int iunet_convT_launch(int dtype, int nd, const void* x, long long x_ss, void* y, long long y_ss, const void* wpk,
                        const float* bias, int N, int D, int H, int W, int Cin, int Cout, hipStream_t stream, int out8) {
   IUNET_REQUIRE(Cin % 32 == 0 && Cout % 32 == 0, "convT: Cin (%d) and Cout (%d) must be multiples of 32", Cin, Cout);
+  IUNET_REQUIRE(!out8 || nd == 3, "convT: e4m3 planes out exist in 3-D only (the K = 128 fp8 convolution's format)");
   ConvTParams p;
   p.x = x; p.x_sstride = x_ss; p.y = y; p.y_sstride = y_ss; p.wpk = wpk; p.bias = bias;
   p.N = N; p.D = D; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.out8 = out8;
@@ -743,8 +744,9 @@ int iunet_convT_launch(int dtype, int nd, const void* x, long long x_ss, void* y
     const int cap = 1024 / (Cout / 32);                // ~4 workgroups per CU in total
     if (gx > cap) gx = cap;
     dim3 g2(gx, Cout / 32);
-#define CTL(TT, NDV, NKV) do { IUNET_SET_MAX_LDS((convT_lds_kernel<TT, NDV, NKV>), lds); \
-    hipLaunchKernelGGL((convT_lds_kernel<TT, NDV, NKV>), g2, dim3(256), lds, stream, p); } while (0)
+#define CTL(TT, NDV, NKV) do { if (out8 && NDV == 3) { IUNET_SET_MAX_LDS((convT_lds_kernel<TT, 3, NKV, true>), lds); \
+    hipLaunchKernelGGL((convT_lds_kernel<TT, 3, NKV, true>), g2, dim3(256), lds, stream, p); } else { IUNET_SET_MAX_LDS((convT_lds_kernel<TT, NDV, NKV>), lds); \
+    hipLaunchKernelGGL((convT_lds_kernel<TT, NDV, NKV>), g2, dim3(256), lds, stream, p); } } while (0)
 #define CTL_NK(TT, NDV) switch (nk) { case 1: CTL(TT, NDV, 1); break; case 2: CTL(TT, NDV, 2); break; case 3: CTL(TT, NDV, 3); break; default: CTL(TT, NDV, 4); break; }
     if (dtype == 0) { if (nd == 3) { CTL_NK(f16, 3) } else { CTL_NK(f16, 2) } }
     else            { if (nd == 3) { CTL_NK(bf16, 3) } else { CTL_NK(bf16, 2) } }
@@ -761,8 +763,9 @@ int iunet_convT_launch(int dtype, int nd, const void* x, long long x_ss, void* y
     const int cap = 512 / (Cout / 32) > 1 ? 512 / (Cout / 32) : 1;
     if (gx > cap) gx = cap;
     dim3 g2(gx, Cout / 32);
-#define CTC(TT, NDV) do { IUNET_SET_MAX_LDS((convT_chunk_kernel<TT, NDV>), lds); \
-    hipLaunchKernelGGL((convT_chunk_kernel<TT, NDV>), g2, dim3(256), lds, stream, p); } while (0)
+#define CTC(TT, NDV) do { if (out8 && NDV == 3) { IUNET_SET_MAX_LDS((convT_chunk_kernel<TT, 3, true>), lds); \
+    hipLaunchKernelGGL((convT_chunk_kernel<TT, 3, true>), g2, dim3(256), lds, stream, p); } else { IUNET_SET_MAX_LDS((convT_chunk_kernel<TT, NDV>), lds); \
+    hipLaunchKernelGGL((convT_chunk_kernel<TT, NDV>), g2, dim3(256), lds, stream, p); } } while (0)
     if (dtype == 0) { if (nd == 3) CTC(f16, 3); else CTC(f16, 2); } else { if (nd == 3) CTC(bf16, 3); else CTC(bf16, 2); }
 #undef CTC
     IUNET_CHECK_HIP(hipGetLastError());
@@ -770,10 +773,12 @@ int iunet_convT_launch(int dtype, int nd, const void* x, long long x_ss, void* y
   }
   dim3 grid((unsigned)((waves + 3) / 4), Cout / 32);
   if (dtype == 0) {
-    if (nd == 3) hipLaunchKernelGGL((convT_kernel<f16, 3>), grid, dim3(256), 0, stream, p);
+    if (nd == 3 && out8) hipLaunchKernelGGL((convT_kernel<f16, 3, true>), grid, dim3(256), 0, stream, p);
+    else if (nd == 3) hipLaunchKernelGGL((convT_kernel<f16, 3>), grid, dim3(256), 0, stream, p);
     else hipLaunchKernelGGL((convT_kernel<f16, 2>), grid, dim3(256), 0, stream, p);
   } else {
-    if (nd == 3) hipLaunchKernelGGL((convT_kernel<bf16, 3>), grid, dim3(256), 0, stream, p);
+    if (nd == 3 && out8) hipLaunchKernelGGL((convT_kernel<bf16, 3, true>), grid, dim3(256), 0, stream, p);
+    else if (nd == 3) hipLaunchKernelGGL((convT_kernel<bf16, 3>), grid, dim3(256), 0, stream, p);
     else hipLaunchKernelGGL((convT_kernel<bf16, 2>), grid, dim3(256), 0, stream, p);
   }
   IUNET_CHECK_HIP(hipGetLastError());
