@@ -20,6 +20,7 @@ def nv():
 
 @pytest.mark.parametrize('nd,shape,cin,cout', [(2, (16, 32), 32, 32), (2, (40, 72), 64, 32), (2, (16, 32), 32, 96),
                                                (3, (2, 8, 16), 32, 32), (3, (6, 12, 20), 64, 64),
+                                               (3, (5, 9, 17), 32, 32), (3, (3, 5, 7), 64, 32), (3, (8, 24, 48), 32, 64),      # odd extents: tiles cut on every side; many tiles per workgroup run (z-plane ring, new columns)
                                                (3, (4, 8, 16), 256, 512), (2, (16, 32), 512, 256)])      # >= 128 filter blocks: LDS-transposing slab reduce
 def test_conv3_wgrad_exact_integers(nv, nd, shape, cin, cout):
     """dW = sum dy (x) shifted x through the transposing LDS reads; small integers make every
