@@ -180,12 +180,16 @@ __global__ __launch_bounds__((F8KTile<SMALL>::NCW * 64 + f8k_loader_threads(IN8)
           }
         }
       };
+      // two steps per tile (64 input channels per workgroup): the two operator buffers hold the two steps' operators for the whole
+      // launch -- copied once, 27 KB of every step's 64 KB less across the L2 -> CU fabric
+      const bool wres = nchunk == 2;
       dma_weights(0, 0);
+      if (wres && nsteps > 1) dma_weights(1, 1);
       dma_acts(0);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       lds_barrier();
       for (int s = 0; s < nsteps; ++s) {
-        if (s + 1 < nsteps) { dma_weights(s + 1, (s + 1) & 1); dma_acts(s + 1); }
+        if (s + 1 < nsteps) { if (!wres) dma_weights(s + 1, (s + 1) & 1); dma_acts(s + 1); }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         lds_barrier();
       }
@@ -242,7 +246,9 @@ __global__ __launch_bounds__((F8KTile<SMALL>::NCW * 64 + f8k_loader_threads(IN8)
     };
     const int last = nsteps - 1;
     Staged r;
+    const bool wres = nchunk == 2;                                 // (see the e4m3 path above)
     dma_weights(0, 0);
+    if (wres && nsteps > 1) dma_weights(1, 1);
     load(0, r);
     commit(0, r);
     load(min(1, last), r);
@@ -252,7 +258,7 @@ __global__ __launch_bounds__((F8KTile<SMALL>::NCW * 64 + f8k_loader_threads(IN8)
     // loaded during step s - 1 -- are converted and written, and the loads of step s + 2 are issued into the same registers: they
     // stay in flight over the barrier and the consumers' whole next step
     for (int s = 0; s < nsteps; ++s) {
-      if (s + 1 < nsteps) dma_weights(s + 1, (s + 1) & 1);
+      if (s + 1 < nsteps && !wres) dma_weights(s + 1, (s + 1) & 1);
       commit(s + 1, r);                                          // (buffer (s + 1) & 1: garbage after the last step, unread)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the operator copy has landed before the barrier publishes it
       load(min(s + 2, last), r);
