@@ -736,7 +736,10 @@ int iunet_convT_launch(int dtype, int nd, const void* x, long long x_ss, void* y
   p.N = N; p.D = D; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.out8 = out8;
   const long long waves = (long long)N * D * H * ((W + 15) / 16);
   const int nk = Cin / 32;
-  if (nk <= 4 && waves >= 256) {
+  // Cin = 128 (4 k-steps) goes through the chunked-weights kernel too: the resident-weights form needs all 512 registers there (one
+  // wave per SIMD, 36-52 B of scratch) and measured 112 / 44 us against 109 / 32 us (128 -> 64 @ 64^3 / 2 x 32^3); IUNET_CONVT_CHUNK4=0: A/B
+  static const int chunk4 = getenv("IUNET_CONVT_CHUNK4") ? atoi(getenv("IUNET_CONVT_CHUNK4")) : 1;
+  if (nk <= 4 && waves >= 256 && !(chunk4 && nk == 4)) {
     // weights of the Cout tile in LDS, grid-stride walk over the voxel groups
     const int npos = nd == 3 ? 8 : 4;
     const int lds = nk * npos * 2 * 1024;
@@ -755,7 +758,7 @@ int iunet_convT_launch(int dtype, int nd, const void* x, long long x_ss, void* y
     IUNET_CHECK_HIP(hipGetLastError());
     return IUNET_OK;
   }
-  if (nk > 4 && nk % 4 == 0 && waves >= 64) {
+  if (nk >= 4 && nk % 4 == 0 && waves >= 64) {
     // weights through LDS in chunks of 4 k-steps (convT_chunk_kernel): few workgroups, each walking many voxel groups per weight pass
     const int npos = nd == 3 ? 8 : 4;
     const int lds = 2 * 4 * npos * 2 * 1024;           // two chunk buffers
