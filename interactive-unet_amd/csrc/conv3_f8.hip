@@ -49,21 +49,6 @@ struct ConvF8Params {
   float* partial;                             // [ksplit][N][Cout / 8][voxels][8] fp32 (split-K only)
 };
 
-// 8 activations of type T -> 8 e4m3 bytes (round to nearest even, saturating at +-448)
-template <typename T>
-__device__ __forceinline__ void cvt8_e4m3(const u32x4 v, unsigned& lo, unsigned& hi) {
-  using V8 = typename Vec8<T>::type;
-  const V8 in = __builtin_bit_cast(V8, v);
-  float f[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) f[j] = __builtin_amdgcn_fmed3f(to_f32<T>(in[j]), -448.0f, 448.0f);
-  int a = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], 0, false);
-  a = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], a, true);
-  int b = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], 0, false);
-  b = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], b, true);
-  lo = (unsigned)a; hi = (unsigned)b;
-}
-
 template <typename T, int ND, bool WS, bool SMALL>
 __global__ __launch_bounds__((F8Tile<ND, SMALL>::NCW * 64 + (WS ? 256 : 512)), 1) void conv3_f8_kernel(ConvF8Params p) {
   using V8 = typename Vec8<T>::type;
@@ -181,8 +166,8 @@ __global__ __launch_bounds__((F8Tile<ND, SMALL>::NCW * 64 + (WS ? 256 : 512)), 1
           if (pix < NPIX) {
             const bool ok = (r.ok >> it) & 1u;
             unsigned o0, o1, o2, o3;
-            cvt8_e4m3<T>(v0, o0, o1);
-            cvt8_e4m3<T>(v1, o2, o3);
+            e4m3_pack8<T>(v0, o0, o1);
+            e4m3_pack8<T>(v1, o2, o3);
             *(u32x4*)(ab + h * PLANE + pix * 16) = ok ? u32x4{o0, o1, o2, o3} : u32x4{0u, 0u, 0u, 0u};
           }
         }
@@ -469,7 +454,7 @@ __global__ __launch_bounds__(256) void f8_splitk_reduce_kernel(const float* __re
   if (!out8) { *(V8*)(y + n * y_ss + ((long long)pl * vox + i) * 8) = o; return; }
   // e4m3 planes [Cout / 16][voxels][16 B], y_ss in bytes: the 16-bit result rounded once more (conv3_f8k.hip's epilogue)
   unsigned o0, o1;
-  cvt8_e4m3<T>(__builtin_bit_cast(u32x4, o), o0, o1);
+  e4m3_pack8<T>(__builtin_bit_cast(u32x4, o), o0, o1);
   typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
   *(u32x2*)((unsigned char*)y + n * y_ss + ((long long)(pl >> 1) * vox + i) * 16 + (pl & 1) * 8) = u32x2{o0, o1};
 }

@@ -43,21 +43,6 @@ struct ConvF8KParams {
   int dbg;                                    // profiling only (IUNET_F8K_DBG): 1 no e4m3 conversion, 2 no activation loads, 8 no operator copies
 };
 
-// 8 activations of type T -> 8 e4m3 bytes (round to nearest even, saturating at +-448): conv3_f8.hip's conversion
-template <typename T>
-__device__ __forceinline__ void k_cvt8_e4m3(const u32x4 v, unsigned& lo, unsigned& hi) {
-  using V8 = typename Vec8<T>::type;
-  const V8 in = __builtin_bit_cast(V8, v);
-  float f[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) f[j] = __builtin_amdgcn_fmed3f(to_f32<T>(in[j]), -448.0f, 448.0f);
-  int a = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], 0, false);
-  a = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], a, true);
-  int b = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], 0, false);
-  b = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], b, true);
-  lo = (unsigned)a; hi = (unsigned)b;
-}
-
 // loader threads: 8 waves when the 16-bit input is rounded on the way into LDS (tools/f8k_ab.sh: 529 us against 574 with 4 on
 // 128 -> 64 @ 128^3), 4 when the input is e4m3 already and everything moves by LDS-DMA
 #ifndef F8K_NLT
@@ -235,10 +220,10 @@ __global__ __launch_bounds__((F8KTile<SMALL>::NCW * 64 + f8k_loader_threads(IN8)
           const bool ok = (r.ok >> it) & 1u;
           unsigned o0, o1, o2, o3, o4, o5, o6, o7;
           if (p.dbg & 1) { *(u32x4*)(ab + plds[it]) = v0; *(u32x4*)(ab + PLANE + plds[it]) = v2; continue; }
-          k_cvt8_e4m3<T>(v0, o0, o1);
-          k_cvt8_e4m3<T>(v1, o2, o3);
-          k_cvt8_e4m3<T>(v2, o4, o5);
-          k_cvt8_e4m3<T>(v3, o6, o7);
+          e4m3_pack8<T>(v0, o0, o1);
+          e4m3_pack8<T>(v1, o2, o3);
+          e4m3_pack8<T>(v2, o4, o5);
+          e4m3_pack8<T>(v3, o6, o7);
           *(u32x4*)(ab + plds[it]) = ok ? u32x4{o0, o1, o2, o3} : u32x4{0u, 0u, 0u, 0u};
           *(u32x4*)(ab + PLANE + plds[it]) = ok ? u32x4{o4, o5, o6, o7} : u32x4{0u, 0u, 0u, 0u};
         }
@@ -384,7 +369,7 @@ __global__ __launch_bounds__((F8KTile<SMALL>::NCW * 64 + f8k_loader_threads(IN8)
           if (!p.out8) { if (ok) *(V8*)(yout + (long long)(cob * 4 + q) * plane_stride + vo) = o; }
           else {                     // e4m3 planes: this lane group's 8 channels are half of a 16-byte granule
             unsigned o0, o1;
-            k_cvt8_e4m3<T>(__builtin_bit_cast(u32x4, o), o0, o1);
+            e4m3_pack8<T>(__builtin_bit_cast(u32x4, o), o0, o1);
             typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
             if (ok) *(u32x2*)((unsigned char*)p.y + (long long)n_img * p.y_sstride + (long long)(cob * 2 + (q >> 1)) * plane_stride * 2 + vo * 2 + (q & 1) * 8) = u32x2{o0, o1};
           }
