@@ -118,7 +118,13 @@ def multiscale_levels(volume, chunk_shape, shard_shape, scale=0.5):
     resize_volume(previous, scale, block_size=shard_shape[0])."""
     levels, z0 = [], volume
     for _ in range(num_multiscale_steps(tuple(volume.shape), chunk_shape, scale)):
-        z1 = torch.empty(tuple(int(x * scale) for x in z0.shape), dtype=z0.dtype, device=z0.device)
+        shape1 = tuple(int(x * scale) for x in z0.shape)
+        if 0 in shape1:
+            # utils.py:64 scales EVERY axis, the class axis of a prediction too: 2 classes -> 1 -> 0.  The reference's zoom of an
+            # empty array raises (volumes of >= 8 chunks per axis, i.e. 1024^3 at 128^3 chunks); here the pyramid ends at the last
+            # level that exists, after level 0 and the levels before it have been written
+            break
+        z1 = torch.empty(shape1, dtype=z0.dtype, device=z0.device)
         resize_volume(z0, z1, scale=scale, block_size=int(shard_shape[0]), order=0)
         levels.append(z1)
         z0 = z1

@@ -299,22 +299,35 @@ def predict_volumes(input_size=256, num_channels=1, num_classes=2, overlap=0.25,
     multiscale pyramid (predict.py:261).  The store is read and written by zarr3.py shard by shard through pinned staging;
     everything between -- block grid, reflect-padded blocks, block prediction, Gaussian blend, normalise + quantise, the
     pyramid levels -- stays in HBM (the reference keeps float32 accumulators in temporary Zarr arrays on disk)."""
+    from concurrent.futures import ThreadPoolExecutor
     from . import zarr3
     device = torch.device('cuda')
     model = _load_model(num_channels, num_classes, device)
-    for f in np.sort(glob.glob('data/image_volumes/*.zarr')):
-        start = time.time()
-        volume = zarr3.open(f, mode='r')['0'].to_device(device)
-        final = predict_volume_array(model, volume, input_size, num_classes, overlap, batch_size, axes)
-        eng = model.engine('eval')
-        if getattr(eng, 'saturated', None) is not None and eng.saturated():      # split precision keeps act_scale x activation in fp16
-            print(f'WARNING: activations of this model exceed the fp16x2 range (stored {eng.max_stored():.0f}): predict with '
-                  f"UNet(infer_dtype='fp32') or a smaller act_scale")
-        save_path = f.replace('image_volumes', 'predicted_volumes')
+
+    def store(final, save_path, name, shape, start):
+        # encoding and writing the [Z, Y, X, C] result (zstd on the host cores, ~1 GB/s) takes about as long as predicting it: it runs
+        # behind the next volume's read + prediction (one result in flight; its device tensor is this call's own)
         root = zarr3.open(save_path, mode='w')
         arr = root.create_array(name='0', shape=list(final.shape), dtype='uint8', overwrite=True,
                                 chunks=(chunk_size,) * 3 + (num_classes,), shards=(shard_size,) * 3 + (num_classes,))
         arr.from_device(final)
         multiscale.add_multiscales(save_path, scale=0.5, level0=final)     # predict.py:261 (levels zoomed on the device)
-        print(f'Completed volume {os.path.basename(f)} {tuple(volume.shape)} in {time.time() - start}.')
+        print(f'Completed volume {name} {shape} in {time.time() - start}.')
+
+    pending = None
+    with ThreadPoolExecutor(max_workers=1) as writer:
+        for f in np.sort(glob.glob('data/image_volumes/*.zarr')):
+            start = time.time()
+            volume = zarr3.open(f, mode='r')['0'].to_device(device)
+            final = predict_volume_array(model, volume, input_size, num_classes, overlap, batch_size, axes)
+            eng = model.engine('eval')
+            if getattr(eng, 'saturated', None) is not None and eng.saturated():      # split precision keeps act_scale x activation in fp16
+                print(f'WARNING: activations of this model exceed the fp16x2 range (stored {eng.max_stored():.0f}): predict with '
+                      f"UNet(infer_dtype='fp32') or a smaller act_scale")
+            if pending is not None:
+                pending.result()                                           # (raises what the writer raised)
+            pending = writer.submit(store, final, f.replace('image_volumes', 'predicted_volumes'), os.path.basename(f),
+                                    tuple(volume.shape), start)
+        if pending is not None:
+            pending.result()
     print('\nAll volumes segmented.\n')

@@ -236,9 +236,10 @@ class Array:
             out[box] = tmp
         return out
 
-    def write_shard(self, sidx, block):
+    def write_shard(self, sidx, block, pool=None):
         """Store the shard-shaped array `block` as shard `sidx`.  Inner chunks that lie entirely beyond the array's
-        bounds are not stored (index entry 2^64-1), the others are stored whole; an all-fill shard still gets a file."""
+        bounds are not stored (index entry 2^64-1), the others are stored whole; an all-fill shard still gets a file.
+        pool: an executor that encodes the inner chunks side by side (libzstd releases the interpreter lock)."""
         if self.readonly:
             raise PermissionError('zarr3: array opened read-only')
         f = self._shard_file(sidx)
@@ -251,12 +252,14 @@ class Array:
             parts, pos = [], 0
             isz = 16 * n + (4 if self._index_crc else 0)
             base = 0 if self._index_end else isz
+            todo = []
             for ci, cidx in enumerate(np.ndindex(*self._cps)):
                 start = [s * o + i * c for s, o, i, c in zip(sidx, self._outer, cidx, self.chunks)]
                 if any(st >= sh for st, sh in zip(start, self.shape)):
                     continue
-                box = tuple(slice(i * c, (i + 1) * c) for i, c in zip(cidx, self.chunks))
-                enc = self._encode_chunk(np.ascontiguousarray(block[box]))
+                todo.append((ci, tuple(slice(i * c, (i + 1) * c) for i, c in zip(cidx, self.chunks))))
+            encode = lambda item: self._encode_chunk(np.ascontiguousarray(block[item[1]]))
+            for (ci, _), enc in zip(todo, pool.map(encode, todo) if pool is not None else map(encode, todo)):
                 index[ci] = (base + pos, len(enc))
                 parts.append(enc)
                 pos += len(enc)
@@ -358,9 +361,11 @@ class Array:
             torch.cuda.current_stream().synchronize()
         return out
 
-    def from_device(self, tensor, workers=8, ring=4):
+    def from_device(self, tensor, workers=8, ring=4, encoders=None):
         """Store a device (or host) tensor of the array's shape: one asynchronous device-to-host copy per shard into a
-        ring of pinned buffers, worker threads encode the inner chunks and write the shard files."""
+        ring of pinned buffers, worker threads write the shard files; the inner chunks of the shards in flight are encoded
+        side by side by `encoders` more threads (default: the host cores of this process, at most 16) -- a 256^3 x 2 shard
+        is 8 chunks of 4 MB, and zstd at ~0.3 GB/s per core was what a whole prediction waited for."""
         import torch
         if tuple(tensor.shape) != self.shape:
             raise ValueError(f'zarr3: tensor {tuple(tensor.shape)} does not match array {self.shape}')
@@ -369,11 +374,17 @@ class Array:
         busy = [None] * ring
         grid = list(np.ndindex(*self.nshards))
 
+        if encoders is None:
+            try:
+                encoders = min(16, len(os.sched_getaffinity(0)))
+            except AttributeError:
+                encoders = min(16, os.cpu_count() or 1)
+
         def store(i, ev):
             if ev is not None:
                 ev.synchronize()
-            self.write_shard(grid[i], bufs[i % ring].numpy())
-        with ThreadPoolExecutor(max_workers=min(workers, ring)) as ex:
+            self.write_shard(grid[i], bufs[i % ring].numpy(), pool=enc)
+        with ThreadPoolExecutor(max_workers=max(1, encoders)) as enc, ThreadPoolExecutor(max_workers=min(workers, ring)) as ex:
             for i, sidx in enumerate(grid):
                 slot = i % ring
                 if busy[slot] is not None:

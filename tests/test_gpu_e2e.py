@@ -131,17 +131,22 @@ def test_predict_volumes_zarr_end_to_end(tmp_path, monkeypatch):
     src = zarr3.open(os.path.join('data', 'image_volumes', 'a.zarr'))
     assert np.array_equal(src['0'][...], vol) and src['0'].chunks == (16, 16, 16) and src['0'].shards == (32, 32, 32)
     assert src.array_keys() == ['0', '1', '2']                               # 72 -> 36 -> 18 (fits a 16^3 chunk at 2 steps)
-    want = predict.predict_volume_array(model, vol, input_size=S, num_classes=C).cpu().numpy()
+    # a second volume of another shape: its read + prediction overlap the first one's encode + write (predict_volumes' write-behind)
+    vol_b = _volume((40, 64, 48), 43)
+    multiscale.create_multiscale_zarr(vol_b, os.path.join('data', 'image_volumes', 'b.zarr'), chunk_size=16, shard_size=32)
+    wants = {'a': predict.predict_volume_array(model, vol, input_size=S, num_classes=C).cpu().numpy(),
+             'b': predict.predict_volume_array(model, vol_b, input_size=S, num_classes=C).cpu().numpy()}
     predict.predict_volumes(input_size=S, num_classes=C, chunk_size=16, shard_size=32)
-    out = zarr3.open(os.path.join('data', 'predicted_volumes', 'a.zarr'))
-    a0 = out['0']
-    assert a0.shape == V + (C,) and a0.chunks == (16, 16, 16, C) and a0.shards == (32, 32, 32, C)
-    assert np.array_equal(a0[...], want)
-    levels = multiscale.multiscale_levels(torch.tensor(want).cuda(), a0.chunks, a0.shards)
-    assert out.array_keys() == [str(i) for i in range(len(levels) + 1)]
-    for i, lv in enumerate(levels):
-        assert np.array_equal(out[str(i + 1)][...], lv.cpu().numpy())
-    assert multiscale.read_volume(os.path.join('data', 'predicted_volumes', 'a.zarr'), level=1).shape == tuple(levels[0].shape)
+    for name, want in wants.items():
+        out = zarr3.open(os.path.join('data', 'predicted_volumes', f'{name}.zarr'))
+        a0 = out['0']
+        assert a0.shape == want.shape and a0.chunks == (16, 16, 16, C) and a0.shards == (32, 32, 32, C)
+        assert np.array_equal(a0[...], want)
+        levels = multiscale.multiscale_levels(torch.tensor(want).cuda(), a0.chunks, a0.shards)
+        assert out.array_keys() == [str(i) for i in range(len(levels) + 1)]
+        for i, lv in enumerate(levels):
+            assert np.array_equal(out[str(i + 1)][...], lv.cpu().numpy())
+        assert multiscale.read_volume(os.path.join('data', 'predicted_volumes', f'{name}.zarr'), level=1).shape == tuple(levels[0].shape)
 
 
 def test_train_model_files_and_learning(tmp_path, monkeypatch):
