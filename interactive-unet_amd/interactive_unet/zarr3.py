@@ -200,8 +200,9 @@ class Array:
         return arr.tobytes() if raw is None else raw
 
     # ---- one shard <-> one outer-chunk-shaped numpy array
-    def read_shard(self, sidx, out=None):
-        """The shard with grid index `sidx` as a full shard-shaped array (fill value where nothing is stored)."""
+    def read_shard(self, sidx, out=None, pool=None):
+        """The shard with grid index `sidx` as a full shard-shaped array (fill value where nothing is stored).  pool: an executor
+        that decodes the inner chunks side by side."""
         if out is None:
             out = np.empty(self._outer, dtype=self.dtype)
         f = self._shard_file(sidx)
@@ -221,7 +222,7 @@ class Array:
         if self._index_crc and struct.unpack('<I', ibytes[-4:])[0] != crc32c(ibytes[:-4]):
             raise ValueError(f'zarr3: shard index crc32c mismatch in {f}')
         index = np.frombuffer(ibytes[:16 * n], dtype='<u8').reshape(n, 2)
-        tmp = None
+        todo = []
         for ci, cidx in enumerate(np.ndindex(*self._cps)):
             off, nb = int(index[ci, 0]), int(index[ci, 1])
             box = tuple(slice(i * c, (i + 1) * c) for i, c in zip(cidx, self.chunks))
@@ -230,10 +231,15 @@ class Array:
                 continue
             if off + nb > len(data):
                 raise ValueError(f'zarr3: chunk {cidx} of {f} points outside the file')
-            if tmp is None:
-                tmp = np.empty(self.chunks, dtype=self.dtype)
+            todo.append((box, off, nb))
+
+        def decode(item):
+            box, off, nb = item
+            tmp = np.empty(self.chunks, dtype=self.dtype)
             self._decode_chunk(data[off:off + nb], tmp)
-            out[box] = tmp
+            out[box] = tmp                                    # (the chunks of a shard are disjoint boxes of `out`)
+        for _ in (pool.map(decode, todo) if pool is not None else map(decode, todo)):
+            pass
         return out
 
     def write_shard(self, sidx, block, pool=None):
@@ -323,9 +329,10 @@ class Array:
             self.write_shard(sidx, buf)
 
     # ---- whole volume <-> HBM, shard by shard through pinned staging
-    def to_device(self, device, out=None, workers=8, ring=4):
-        """The whole array as a tensor on `device`: worker threads read + decode shards into a ring of pinned
-        shard buffers, this thread issues one asynchronous host-to-device copy per shard."""
+    def to_device(self, device, out=None, workers=8, ring=4, decoders=None):
+        """The whole array as a tensor on `device`: worker threads read shards into a ring of pinned shard buffers (their inner
+        chunks decoded side by side by `decoders` more threads: the host cores of this process, at most 16), this thread issues one
+        asynchronous host-to-device copy per shard."""
         import torch
         tdt = {np.dtype('uint8'): torch.uint8, np.dtype('int8'): torch.int8, np.dtype('bool'): torch.bool}[self.dtype]
         dev = torch.device(device)
@@ -336,13 +343,19 @@ class Array:
         events = [None] * ring
         grid = list(np.ndindex(*self.nshards))
 
+        if decoders is None:
+            try:
+                decoders = min(16, len(os.sched_getaffinity(0)))
+            except AttributeError:
+                decoders = min(16, os.cpu_count() or 1)
+
         def load(i):
             slot = i % ring
             if events[slot] is not None:
                 events[slot].synchronize()                    # the copy that last used this buffer has finished
-            self.read_shard(grid[i], bufs[slot].numpy())
+            self.read_shard(grid[i], bufs[slot].numpy(), pool=dec)
             return i
-        with ThreadPoolExecutor(max_workers=min(workers, ring)) as ex:
+        with ThreadPoolExecutor(max_workers=max(1, decoders)) as dec, ThreadPoolExecutor(max_workers=min(workers, ring)) as ex:
             futs = {}
             nxt = 0
             for i in range(len(grid)):
