@@ -605,7 +605,7 @@ class TrainEngine:
                 g.zero_()
         return g, ok
 
-    def eval_step(self, X, y, w=None):
+    def eval_step(self, X, y, w=None, sync=True):
         """validation_step (unet.py:104-116): eval-mode BatchNorm (running statistics)."""
         self.sync_weights()
         X, y, w, N, D, H, W, vox, xs = self._prep(X, y, w)
@@ -613,5 +613,7 @@ class TrainEngine:
         feat = eng.infer(X, xs, N, D, H, W, features_only=True)
         ws = self.workspace(N, D, H, W)
         self.loss_forward(ws, feat, y, w, N, vox)
+        if not sync:
+            return ws['out4']                 # device tensor [loss, dice, iou, mcc], overwritten by the next step: clone to keep
         o = ws['out4'].tolist()
         return {'Loss': o[0], 'Dice': o[1], 'IoU': o[2], 'MCC': o[3]}

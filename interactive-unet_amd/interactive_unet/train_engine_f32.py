@@ -364,7 +364,7 @@ class TrainEngineF32:
             return {'Loss': o[0], 'Dice': o[1], 'IoU': o[2], 'MCC': o[3]}
         return out4
 
-    def eval_step(self, X, y, w=None):
+    def eval_step(self, X, y, w=None, sync=True):
         """validation_step (unet.py:104-116): eval-mode BatchNorm (running statistics), fp32 forward (engine_f32.EngineF32)"""
         self.sync_weights()
         X, y, w, N, D, H, W, vox = self._prep(X, y, w)
@@ -377,6 +377,8 @@ class TrainEngineF32:
         feat = self._eval_eng.infer(X, (self.cin * vox, vox, H * W, W, 1), N, D, H, W, features_only=True)
         ws = self.workspace(N, D, H, W)
         self.loss_forward(ws, feat, y, w, N, vox)
+        if not sync:
+            return ws['out4']                 # device tensor [loss, dice, iou, mcc], overwritten by the next step: clone to keep
         o = ws['out4'].tolist()
         return {'Loss': o[0], 'Dice': o[1], 'IoU': o[2], 'MCC': o[3]}
 
