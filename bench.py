@@ -315,6 +315,16 @@ def cpu_baseline(cfg, model=None, chunk_u8=None):
            'sample': f'{reps} x (1 training step + 1 prediction forward) of the fp32 oracle ({dim}-D U-Net, {levels} levels, '
                      f'base {base}) on one {"x".join(map(str, shp))} tile ({frac:.3g} of a bench tile), torch CPU, '
                      f'{cores} threads; voxels counted once per leg'}
+    if dim == 3 and base == 32 and tuple(cfg['tile']) == (128, 128, 128):
+        # the prediction forward on ONE full 128^3 chunk (it fits the host: ~7 s on 16 threads)
+        x128 = torch.rand((1, 1, 128, 128, 128))
+        with torch.no_grad():
+            t1 = time.time()
+            unet_ref.forward(pr, x128, dim=dim, levels=levels, norm=cfg.get('norm', 'batch'))
+            d128 = time.time() - t1
+        out['forward_128'] = {'seconds': round(d128, 2), 'voxels_per_s': round(128 ** 3 / d128, 1),
+                              'sample': 'one prediction forward of the fp32 oracle on a full 128x128x128 chunk (BASELINE.md B3)'}
+        del x128
     chk = None
     if model is not None and chunk_u8 is not None:
         # checker: oracle logits of a crop of the bench tile with the MODEL's current weights vs both native modes
