@@ -14,7 +14,11 @@
 //     are chosen to differ in dz only, so the pass sees 16 distinct 16-byte slots (conflict-free);
 //   * operator in HBM and LDS per (32 Cout, 32 Cin): [group 2][dy 3][m 2][half 2][64 lanes][16 B] + [dy 3][m 2][64][8 B] for
 //     the ninth column (27 648 B; pack_batch.hip kind 5 / pack_f8_kernel write this order when iunet_f8_k128 says so);
-//   * the weights always stream by LDS-DMA (two step buffers), the 16-bit activations are rounded to e4m3 by the 4 loader waves.
+//   * the operator streams by LDS-DMA into two step buffers (64 input channels per workgroup = two steps: both stay resident);
+//   * activations (template flag IN8): e4m3 planes [C / 16][D][H][W][16 B] -- the format the fp8 layers hand each other (engine.py:
+//     q_planes), the HBM tensor IS the LDS image, 4 loader waves copy it by LDS-DMA -- or 16-bit NHWC8c planes rounded to e4m3 by 8
+//     loader waves (the stand-alone entry point; that form was bound by its loaders: 453 us with the MFMAs compiled out against 529 us
+//     in all on 128 -> 64 @ 128^3, which is why the planes exist).  The epilogue writes 16-bit planes or e4m3 planes (out8).
 #include "common.h"
 #include <cstdlib>
 #include <type_traits>
