@@ -8,7 +8,8 @@ OUT=$R/gpurun_out/levels_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 ARGS="--dim $DIM --n $N --size $SIZE --dtype $DT --wgrad 0 $EXTRA"
-for shape in 0:32:32 0:64:32 1:32:64 1:64:64 1:128:64 2:64:128 2:128:128 2:256:128 3:128:256 3:256:256; do
+SHAPES=${SHAPES:-"0:32:32 0:64:32 1:32:64 1:64:64 1:128:64 2:64:128 2:128:128 2:256:128 3:128:256 3:256:256"}      # C5 (tag f8_3d): SHAPES="0:64:64 0:128:64 1:64:128 ..." with EXTRA "--base 64 --levels 5 --f8 2"
+for shape in $SHAPES; do
   tag=$(echo $shape | tr : _)
   python3 $R/tools/bench_conv.py --only $shape $ARGS --iters 30 2>/dev/null > $OUT/time_$tag.txt
   rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --output-format csv -d $OUT/mfma_$tag -- python3 $R/tools/bench_conv.py --only $shape $ARGS --iters 2 > /dev/null 2>&1
