@@ -106,6 +106,11 @@ class TrainEngine:
         # the data-parallel all-reduce
         first_dec = f'dec{self.levels - 2}.up.weight'
         self._dec_start = self.offsets[first_dec][0] if first_dec in self.offsets else 0
+        # the bottom encoder level's parameters (its two convs hold almost half of the net): a bucket of their own, reduced while
+        # the upper encoder levels still run their backward -- only if they are one run that ends where the decoder starts
+        bottom = [self.offsets[n] for n in names if n.startswith(f'enc{self.levels - 1}.')]
+        lo = min((o for o, _ in bottom), default=0)
+        self._bottom_start = lo if bottom and lo + sum(s for _, s in bottom) == self._dec_start else None
 
     def p(self, name):
         return self.model.tensor(name)
@@ -493,6 +498,8 @@ class TrainEngine:
                 self._stage_conv_bwd(ws, f'enc{l}.conv1', self._P(dz1), ch[l] * v, self._P(z1), ch[l] * v,
                                      self._P(ws[f'pin{l}']), ch[l - 1] * v, ch[l - 1], ch[l], l,
                                      self._P(ws[f'dpin{l}']), ch[l - 1] * v, N)
+            if l == L - 1 and L > 1 and self.pg is not None and self._bottom_start is not None:
+                self.buckets.start(self._bottom_start, self._dec_start)
 
     # ------------------------------------------------------------------ optimiser
     def optimizer_step(self):

@@ -160,8 +160,13 @@ def _dp_worker(rank, world, port, q):
         local = torch.randn(n, generator=g)
         grad[split:] = local[split:]                           # decoder + head gradients are ready first ...
         buckets.start_tail()                                   # ... and go out while the encoder part is "computed"
-        grad[:split] = local[:split]
-        w = buckets.finish()
+        if step == 0:                                          # the bottom encoder level is next: a bucket of its own
+            grad[300:split] = local[300:split]                 # (step 1 goes without it: the two-bucket form of a net whose
+            buckets.start(300, split)                          #  bottom level is not one run of the flat tensor)
+            grad[:300] = local[:300]
+        else:
+            grad[:split] = local[:split]
+        w = buckets.finish()                                   # reduces what is left ([0, 300)) and waits for all three
         flat -= 0.1 * grad / w
         q.put(('grad', rank, step, local.numpy().copy(), grad.numpy().copy()))
     q.put(('flat', rank, start.numpy(), flat.numpy().copy(), [b.numpy().copy() for b in bufs]))
