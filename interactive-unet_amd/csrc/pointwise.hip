@@ -336,12 +336,20 @@ __global__ __launch_bounds__(256) void convT_kernel(ConvTParams p) {
   }
 }
 
-// Same operator with the weights of the Cout tile resident in LDS (Cin <= 128: 32 / 64 KB) and two 16-voxel groups per
-// wave and step: the kernel above fetches 16 KB of weight fragments per k-step and wave through the vector cache to
+// Same operator with the weights of the Cout tile resident in LDS (Cin <= 128: 16 KB per 32 input channels in 3-D) and two 16-voxel
+// groups per wave and step: the kernel above fetches 16 KB of weight fragments per k-step and wave through the vector cache to
 // move 10 KB of activations -- 4x more cache traffic for the weights than for the tensor, 3.0 TB/s.  Here the only
 // global traffic is the tensor itself.
-template <typename T, int ND, int NK, bool O8 = false>
-__global__ __launch_bounds__(256) void convT_lds_kernel(ConvTParams p) {
+// [r3] Two workgroups per CU (256 registers per lane) and a software pipeline across the iterations: the first form let the
+// compiler hoist the loop-invariant weight fragments out of the voxel loop into registers (64 x NK of them: 360 registers at NK = 2,
+// 512 + 52 B of scratch at NK = 4 -- one wave per SIMD, every load's latency in the open; 128 -> 64 @ 64^3 ran at 0.3 PF and
+// 1.6 TB/s).  Now the fragments stay in LDS (their offset is opaque per iteration) and the activation fragments of the NEXT
+// iteration are fetched into the registers of k-step ks as soon as its MFMAs are issued.
+// NT = threads per workgroup: 256 (two workgroups per CU) while the weights take at most 64 KB, 512 (one workgroup, 8 waves on one
+// copy of the weights) for the 128 KB of Cin = 256 in 3-D.
+template <typename T, int ND, int NK, bool O8 = false, int NT = 256>
+__global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void convT_lds_kernel(ConvTParams p) {
+  constexpr int NW = NT / 64;                                    // waves per workgroup
   using V8 = typename Vec8<T>::type;
   constexpr int NPOS = ND == 3 ? 8 : 4;
   constexpr int G = 2;                                           // voxel groups per wave and step
@@ -351,7 +359,8 @@ __global__ __launch_bounds__(256) void convT_lds_kernel(ConvTParams p) {
   const int cob = blockIdx.y;
   {
     const u32x4* wsrc = (const u32x4*)p.wpk + (long long)cob * NK * NPOS * 2 * 64;
-    for (int i = threadIdx.x; i < NK * NPOS * 2 * 64; i += 256) *(u32x4*)(smem + i * 16) = wsrc[i];
+    for (int i = threadIdx.x; i < NK * NPOS * 2 * 64; i += NT) *(u32x4*)(smem + i * 16) = wsrc[i];
+    if (threadIdx.x < 32) ((float*)(smem + NK * NPOS * 2 * 1024))[threadIdx.x] = p.bias ? p.bias[cob * 32 + threadIdx.x] : 0.f;      // read per epilogue: 8 registers less
   }
   __syncthreads();
   const int xg = (p.W + 15) / 16;
@@ -359,85 +368,128 @@ __global__ __launch_bounds__(256) void convT_lds_kernel(ConvTParams p) {
   const long long in_plane = (long long)p.D * p.H * p.W * 8;
   const int Do = ND == 3 ? p.D * 2 : 1, Ho = p.H * 2, Wo = p.W * 2;
   const long long out_plane = (long long)Do * Ho * Wo * 8;
-  float bias[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) bias[j] = p.bias ? p.bias[cob * 32 + q * 8 + j] : 0.f;
   const int src_lo = ((lane & 48) | (l15 >> 1)) * 4, src_hi = src_lo + 8 * 4;
   const bool odd = l15 & 1;
-  const V8* wl = (const V8*)smem + lane;
 
-  for (long long g0 = ((long long)blockIdx.x * 4 + wave) * G; g0 < ngroups; g0 += (long long)gridDim.x * 4 * G) {
-    int n_[G], z_[G], y_[G], xb_[G];
-    V8 b[G][NK];
+  struct Where { int n, z, y, xb; const T* xin; };
+  auto locate = [&](long long wid) -> Where {                      // voxel group wid (clamped: a missing group re-reads the last one, never stored)
+    wid = wid < ngroups ? wid : ngroups - 1;
+    Where w;
+    w.n = (int)(wid / rows);
+    const long long r = wid - w.n * rows;
+    w.xb = (int)(r % xg); w.y = (int)((r / xg) % p.H); w.z = (int)(r / ((long long)xg * p.H));
+    const int xc = min(w.xb * 16 + l15, p.W - 1);
+    w.xin = (const T*)p.x + w.n * p.x_sstride + (((long long)w.z * p.H + w.y) * p.W + xc) * 8 + (long long)q * in_plane;
+    return w;
+  };
+  const long long stride = (long long)gridDim.x * NW * G;
+  long long g0 = ((long long)blockIdx.x * NW + wave) * G;
+  if (g0 >= ngroups) return;
+  Where cur[G];
+  V8 b[G][NK];
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-      const long long wid = g0 + g < ngroups ? g0 + g : ngroups - 1;      // a missing partner recomputes the last group (never stored)
-      n_[g] = (int)(wid / rows);
-      const long long r = wid - n_[g] * rows;
-      xb_[g] = (int)(r % xg); y_[g] = (int)((r / xg) % p.H); z_[g] = (int)(r / ((long long)xg * p.H));
-      const int xc = min(xb_[g] * 16 + l15, p.W - 1);
-      const T* xin = (const T*)p.x + n_[g] * p.x_sstride + (((long long)z_[g] * p.H + y_[g]) * p.W + xc) * 8;
+  for (int g = 0; g < G; ++g) {
+    cur[g] = locate(g0 + g);
 #pragma unroll
-      for (int ks = 0; ks < NK; ++ks) b[g][ks] = *(const V8*)(xin + (long long)(ks * 4 + q) * in_plane);
-    }
-    f32x4 acc[G][NPOS][2];
+    for (int ks = 0; ks < NK; ++ks) b[g][ks] = *(const V8*)(cur[g].xin + (long long)(ks * 4) * in_plane);
+  }
+  for (; g0 < ngroups; g0 += stride) {
+    Where nxt[G];
 #pragma unroll
-    for (int g = 0; g < G; ++g)
+    for (int g = 0; g < G; ++g) nxt[g] = locate(g0 + stride + g);
+    unsigned woff = lane * 16;
+    asm volatile("" : "+v"(woff));                               // the weight fragments are read from LDS every iteration (see the header)
+    const V8* wl = (const V8*)(smem + woff);
+    // the output positions in two halves (z' = 0, 1 in 3-D; y' in 2-D): 64 accumulator registers instead of 128, so that two
+    // workgroups fit on a CU without scratch; the activation fragments serve both halves and are replaced during the second
 #pragma unroll
-      for (int s = 0; s < NPOS; ++s) { acc[g][s][0] = f32x4{0, 0, 0, 0}; acc[g][s][1] = f32x4{0, 0, 0, 0}; }
+    for (int hf = 0; hf < 2; ++hf) {
+      constexpr int HP = NPOS / 2;
+      f32x4 acc[G][HP][2];
 #pragma unroll
-    for (int ks = 0; ks < NK; ++ks)
+      for (int g = 0; g < G; ++g)
 #pragma unroll
-      for (int s = 0; s < NPOS; ++s) {
-        const V8 a0 = wl[((ks * NPOS + s) * 2 + 0) * 64];
-        const V8 a1 = wl[((ks * NPOS + s) * 2 + 1) * 64];
+        for (int s = 0; s < HP; ++s) { acc[g][s][0] = f32x4{0, 0, 0, 0}; acc[g][s][1] = f32x4{0, 0, 0, 0}; }
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-          acc[g][s][0] = mfma16<T>(a0, b[g][ks], acc[g][s][0]);
-          acc[g][s][1] = mfma16<T>(a1, b[g][ks], acc[g][s][1]);
+      for (int ks = 0; ks < NK; ++ks) {
+#pragma unroll
+        for (int s = 0; s < HP; ++s) {
+          const V8 a0 = wl[((ks * NPOS + hf * HP + s) * 2 + 0) * 64];
+          const V8 a1 = wl[((ks * NPOS + hf * HP + s) * 2 + 1) * 64];
+#pragma unroll
+          for (int g = 0; g < G; ++g) {
+            acc[g][s][0] = mfma16<T>(a0, b[g][ks], acc[g][s][0]);
+            acc[g][s][1] = mfma16<T>(a1, b[g][ks], acc[g][s][1]);
+          }
+        }
+        if (hf == 1) {
+#pragma unroll
+          for (int g = 0; g < G; ++g) b[g][ks] = *(const V8*)(nxt[g].xin + (long long)(ks * 4) * in_plane);      // the next iteration's, in place
         }
       }
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-      if (g0 + g >= ngroups) break;
-      T* yout = (T*)p.y + n_[g] * p.y_sstride + (long long)(cob * 4 + q) * out_plane;
-      const int x0 = xb_[g] * 16;
+      for (int g = 0; g < G; ++g) {
+        if (g0 + g >= ngroups) break;
+        T* yout = (T*)p.y + cur[g].n * p.y_sstride + (long long)(cob * 4 + q) * out_plane;
+        const int x0 = cur[g].xb * 16;
 #pragma unroll
-      for (int sp = 0; sp < NPOS / 2; ++sp) {
-        const int a = ND == 3 ? (sp >> 1) : 0, bb = sp & 1;
-        typedef int i32x4 __attribute__((ext_vector_type(4)));
-        i32x4 oc[2];
+        for (int s2 = 0; s2 < HP / 2; ++s2) {
+          const int sp = hf * (HP / 2) + s2;
+          const int a = ND == 3 ? (sp >> 1) : 0, bb = sp & 1;
+          typedef int i32x4 __attribute__((ext_vector_type(4)));
+          i32x4 oc[2];
+          const f32x4 bias0 = ((const f32x4*)(smem + NK * NPOS * 2 * 1024))[2 * q], bias1 = ((const f32x4*)(smem + NK * NPOS * 2 * 1024))[2 * q + 1];
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          V8 o;
+          for (int c = 0; c < 2; ++c) {
+            V8 o;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            o[j] = from_f32<T>(acc[g][sp * 2 + c][0][j] + bias[j]);
-            o[4 + j] = from_f32<T>(acc[g][sp * 2 + c][1][j] + bias[4 + j]);
+            for (int j = 0; j < 4; ++j) {
+              o[j] = from_f32<T>(acc[g][s2 * 2 + c][0][j] + bias0[j]);
+              o[4 + j] = from_f32<T>(acc[g][s2 * 2 + c][1][j] + bias1[j]);
+            }
+            oc[c] = __builtin_bit_cast(i32x4, o);
           }
-          oc[c] = __builtin_bit_cast(i32x4, o);
-        }
-        const int oz = ND == 3 ? z_[g] * 2 + a : 0;
-        T* row = yout + (((long long)oz * Ho + y_[g] * 2 + bb) * Wo + 2 * x0) * 8;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int src = h ? src_hi : src_lo;
-          i32x4 v;
-#pragma unroll
-          for (int d = 0; d < 4; ++d) {
-            const int t0 = __builtin_amdgcn_ds_bpermute(src, oc[0][d]);
-            const int t1 = __builtin_amdgcn_ds_bpermute(src, oc[1][d]);
-            v[d] = odd ? t1 : t0;
+          const int oz = ND == 3 ? cur[g].z * 2 + a : 0;
+          if constexpr (O8) {
+            // e4m3 planes: a 16-byte granule = 16 channels of one output voxel = the 8 bytes of this lane and of its partner 16 lanes
+            // on (q ^ 1).  Even q assembles the granule of voxel 2x, odd q of voxel 2x + 1: each sends the partner the half it does
+            // not store (2 exchanges instead of 16), and one instruction writes 2 planes x 32 consecutive voxels x 16 B.
+            unsigned E[2][2];
+            e4m3_pack8<T>(__builtin_bit_cast(u32x4, oc[0]), E[0][0], E[0][1]);
+            e4m3_pack8<T>(__builtin_bit_cast(u32x4, oc[1]), E[1][0], E[1][1]);
+            const bool oq = q & 1;
+            const int partner = (lane ^ 16) * 4;
+            const unsigned r0 = (unsigned)__builtin_amdgcn_ds_bpermute(partner, (int)(oq ? E[0][0] : E[1][0]));
+            const unsigned r1 = (unsigned)__builtin_amdgcn_ds_bpermute(partner, (int)(oq ? E[0][1] : E[1][1]));
+            const u32x4 gran = oq ? u32x4{r0, r1, E[1][0], E[1][1]} : u32x4{E[0][0], E[0][1], r0, r1};
+            if (x0 + l15 < p.W)
+              *(u32x4*)((unsigned char*)p.y + (long long)cur[g].n * p.y_sstride +
+                        ((long long)((cob * 4 + q) >> 1) * ((long long)Do * Ho * Wo) + ((long long)oz * Ho + cur[g].y * 2 + bb) * Wo + 2 * (x0 + l15) + (oq ? 1 : 0)) * 16) = gran;
+            continue;
           }
-          if (2 * x0 + 16 * h + l15 < Wo) {
-            if constexpr (!O8) *(i32x4*)(row + (16 * h + l15) * 8) = v;
-            else e4m3_store8<T>((unsigned char*)p.y + (long long)n_[g] * p.y_sstride, cob * 4 + q,
-                                ((long long)oz * Ho + y_[g] * 2 + bb) * Wo + 2 * x0 + 16 * h + l15, (long long)Do * Ho * Wo,
-                                __builtin_bit_cast(u32x4, v));
+          T* row = yout + (((long long)oz * Ho + cur[g].y * 2 + bb) * Wo + 2 * x0) * 8;
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int src = h ? src_hi : src_lo;
+            i32x4 v;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+              const int t0 = __builtin_amdgcn_ds_bpermute(src, oc[0][d]);
+              const int t1 = __builtin_amdgcn_ds_bpermute(src, oc[1][d]);
+              v[d] = odd ? t1 : t0;
+            }
+            if (2 * x0 + 16 * h + l15 < Wo) {
+              if constexpr (!O8) *(i32x4*)(row + (16 * h + l15) * 8) = v;
+              else e4m3_store8<T>((unsigned char*)p.y + (long long)cur[g].n * p.y_sstride, cob * 4 + q,
+                                  ((long long)oz * Ho + cur[g].y * 2 + bb) * Wo + 2 * x0 + 16 * h + l15, (long long)Do * Ho * Wo,
+                                  __builtin_bit_cast(u32x4, v));
+            }
           }
         }
       }
     }
+#pragma unroll
+    for (int g = 0; g < G; ++g) cur[g] = nxt[g];
   }
 }
 
@@ -736,21 +788,30 @@ int iunet_convT_launch(int dtype, int nd, const void* x, long long x_ss, void* y
   p.N = N; p.D = D; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.out8 = out8;
   const long long waves = (long long)N * D * H * ((W + 15) / 16);
   const int nk = Cin / 32;
-  // Cin = 128 (4 k-steps) goes through the chunked-weights kernel too: the resident-weights form needs all 512 registers there (one
-  // wave per SIMD, 36-52 B of scratch) and measured 112 / 44 us against 109 / 32 us (128 -> 64 @ 64^3 / 2 x 32^3); IUNET_CONVT_CHUNK4=0: A/B
-  static const int chunk4 = getenv("IUNET_CONVT_CHUNK4") ? atoi(getenv("IUNET_CONVT_CHUNK4")) : 1;
-  if (nk <= 4 && waves >= 256 && !(chunk4 && nk == 4)) {
+  // Cin = 128 (4 k-steps): the resident-weights form again since its pipelined rewrite (128 -> 64 @ 64^3 -> e4m3 planes 122 -> 81 us,
+  // @ 2 x 32^3 40 -> 31 us against the chunked-weights kernel); IUNET_CONVT_CHUNK4=1: A/B
+  static const int chunk4 = getenv("IUNET_CONVT_CHUNK4") ? atoi(getenv("IUNET_CONVT_CHUNK4")) : 0;
+  // Cin = 256 in 3-D (128 KB of weights per Cout tile, one workgroup of 8 waves per CU): resident when every workgroup walks several
+  // sweeps (256 -> 128 @ 32^3: 47 -> 34 us; at 2 x 16^3 the 128 KB per workgroup cost more than they save: 14.5 -> 17.5 us, so the
+  // chunked-weights kernel keeps the small grids -- both kernels sum in the same order, the bits do not depend on the choice).
+  // IUNET_CONVT_RES8=0: A/B
+  static const int res8 = getenv("IUNET_CONVT_RES8") ? atoi(getenv("IUNET_CONVT_RES8")) : 1;
+  if ((nk <= 4 || (nk == 8 && res8 && nd == 3 && waves >= 2048)) && waves >= 256 && !(chunk4 && nk == 4)) {
     // weights of the Cout tile in LDS, grid-stride walk over the voxel groups
     const int npos = nd == 3 ? 8 : 4;
-    const int lds = nk * npos * 2 * 1024;
-    int gx = (int)((waves + 7) / 8);
-    const int cap = 1024 / (Cout / 32);                // ~4 workgroups per CU in total
+    const int lds = nk * npos * 2 * 1024 + 128;        // + the Cout tile's bias
+    const bool big = lds > 65 * 1024;                  // 8 waves on one copy of the weights, one workgroup per CU
+    const int per_wg = big ? 16 : 8;                   // voxel groups per workgroup and sweep
+    int gx = (int)((waves + per_wg - 1) / per_wg);
+    static const int cap_all = getenv("IUNET_CONVT_CAP") ? atoi(getenv("IUNET_CONVT_CAP")) : 512;      // workgroups per launch: two per CU, each walking its share of the groups
+    const int cap = (big ? cap_all / 2 : cap_all) / (Cout / 32) > 8 ? (big ? cap_all / 2 : cap_all) / (Cout / 32) : 8;
     if (gx > cap) gx = cap;
     dim3 g2(gx, Cout / 32);
-#define CTL(TT, NDV, NKV) do { if (out8 && NDV == 3) { IUNET_SET_MAX_LDS((convT_lds_kernel<TT, 3, NKV, true>), lds); \
-    hipLaunchKernelGGL((convT_lds_kernel<TT, 3, NKV, true>), g2, dim3(256), lds, stream, p); } else { IUNET_SET_MAX_LDS((convT_lds_kernel<TT, NDV, NKV>), lds); \
-    hipLaunchKernelGGL((convT_lds_kernel<TT, NDV, NKV>), g2, dim3(256), lds, stream, p); } } while (0)
-#define CTL_NK(TT, NDV) switch (nk) { case 1: CTL(TT, NDV, 1); break; case 2: CTL(TT, NDV, 2); break; case 3: CTL(TT, NDV, 3); break; default: CTL(TT, NDV, 4); break; }
+#define CTL(TT, NDV, NKV, NTV) do { if (out8 && NDV == 3) { IUNET_SET_MAX_LDS((convT_lds_kernel<TT, 3, NKV, true, NTV>), lds); \
+    hipLaunchKernelGGL((convT_lds_kernel<TT, 3, NKV, true, NTV>), g2, dim3(NTV), lds, stream, p); } else { IUNET_SET_MAX_LDS((convT_lds_kernel<TT, NDV, NKV, false, NTV>), lds); \
+    hipLaunchKernelGGL((convT_lds_kernel<TT, NDV, NKV, false, NTV>), g2, dim3(NTV), lds, stream, p); } } while (0)
+#define CTL_NK(TT, NDV) switch (nk) { case 1: CTL(TT, NDV, 1, 256); break; case 2: CTL(TT, NDV, 2, 256); break; case 3: CTL(TT, NDV, 3, 256); break; \
+    case 4: CTL(TT, NDV, 4, 256); break; default: CTL(TT, NDV, 8, (NDV == 3 ? 512 : 256)); break; }
     if (dtype == 0) { if (nd == 3) { CTL_NK(f16, 3) } else { CTL_NK(f16, 2) } }
     else            { if (nd == 3) { CTL_NK(bf16, 3) } else { CTL_NK(bf16, 2) } }
 #undef CTL_NK

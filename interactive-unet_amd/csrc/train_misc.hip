@@ -67,8 +67,11 @@ __global__ __launch_bounds__(256) void convT_dgrad_kernel(ConvTDgradParams p) {
 // fetches through the vector cache were 2x the tensor traffic.
 // NCI: input-channel blocks (of 32) per workgroup.  Every ci block needs the whole gradient tensor dy; with one block per
 // workgroup the level-0 launch (Cin = 64) read its 268 MB twice and ran at the HBM rate of the doubled traffic.
+// [r3] The operator fragments are loop-invariant: left alone, the compiler hoists them out of the voxel loop into registers (NCI x NK x
+// 2^d x 2 of them: 352 registers at NK = 2, 512 + 464 B of scratch at NK = 4 -- one wave per SIMD).  Their LDS offset is made opaque
+// per iteration, and the operator sizes that leave room for two workgroups per CU (<= 64 KB) are compiled for 256 registers.
 template <typename T, int ND, int NK, int NCI>
-__global__ __launch_bounds__(256) void convT_dgrad_lds_kernel(ConvTDgradParams p) {
+__global__ __launch_bounds__(256, (NCI * NK * (ND == 3 ? 16 : 8) <= 64) ? 2 : 1) void convT_dgrad_lds_kernel(ConvTDgradParams p) {
   using V8 = V8T<T>;
   constexpr int NPOS = ND == 3 ? 8 : 4, G = 2;
   constexpr int WCI = NPOS * NK * 2 * 64;                        // 16-byte granules of one ci block's operator
@@ -85,8 +88,10 @@ __global__ __launch_bounds__(256) void convT_dgrad_lds_kernel(ConvTDgradParams p
   const long long rows = (long long)p.D * p.H * xg, ngroups = rows * p.N;
   const int Do = ND == 3 ? p.D * 2 : 1, Ho = p.H * 2, Wo = p.W * 2;
   const long long out_plane = (long long)Do * Ho * Wo * 8, in_plane = (long long)p.D * p.H * p.W * 8;
-  const V8* wl = (const V8*)smem + lane;
   for (long long g0 = ((long long)blockIdx.x * 4 + wave) * G; g0 < ngroups; g0 += (long long)gridDim.x * 4 * G) {
+    unsigned woff = lane * 16;
+    asm volatile("" : "+v"(woff));
+    const V8* wl = (const V8*)(smem + woff);
     f32x4 acc[NCI][G][2];
     const T* dyb[G];
     long long xoff[G];

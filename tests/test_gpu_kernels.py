@@ -243,6 +243,8 @@ def test_maxpool(nv, nd, dt):
 @pytest.mark.parametrize('nd,shape,cin,cout', [(2, (8, 16), 64, 32), (2, (6, 20), 256, 128), (3, (4, 4, 16), 64, 32),
                                                (3, (8, 16, 24), 64, 32), (2, (40, 72), 128, 64), (3, (6, 10, 40), 96, 64),
                                                (3, (2, 3, 8), 128, 64),
+                                               (3, (16, 32, 80), 64, 32), (3, (16, 16, 72), 128, 64), (2, (96, 200), 96, 32),      # resident weights, several iterations per wave, ragged x
+                                               (3, (16, 16, 72), 256, 64), (2, (64, 72), 256, 64),      # Cin = 256 resident (3-D, >= 2048 voxel groups: 8 waves on one copy)
                                                (3, (8, 8, 16), 256, 128), (3, (5, 9, 20), 512, 64), (2, (24, 40), 256, 32)])     # Cin > 128: weights chunked through LDS
 def test_convT_exact_integers(nv, nd, shape, cin, cout):
     g = torch.Generator().manual_seed(6)
