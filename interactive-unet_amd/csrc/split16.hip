@@ -258,8 +258,10 @@ struct X2ConvTParams {
 // cache (the virtual [hi | hi | lo] operator) spent 12 % of the 128^3 forward on 1.7 % of its FLOPs.  One chunk (Cin <= 64): loaded once per workgroup, which then
 // walks its voxel groups; more: double-buffered by LDS-DMA through every pass (the structure of pointwise.hip's convT_chunk_kernel).
 // Per (k-step, position, cout half): 2 fragment reads feed 3 MFMAs per voxel group: x_hi w_hi + x_lo w_hi + x_hi w_lo.
-template <int ND, int KC>
-__global__ __launch_bounds__(256) void x2_convT_lds_kernel(X2ConvTParams p) {
+// RES (one chunk, resident): the output positions go in two halves -- 64 accumulator registers instead of 128, the kernel then fits
+// 256 registers and two workgroups share a CU (the first form held 418: one wave per SIMD, its loads and its heavy epilogue in the open).
+template <int ND, int KC, bool RES = false>
+__global__ __launch_bounds__(256, RES ? 2 : 1) void x2_convT_lds_kernel(X2ConvTParams p) {
   constexpr int NPOS = ND == 3 ? 8 : 4;
   constexpr int G = 2;
   constexpr int CHB = 2 * KC * NPOS * 2 * 1024;                 // bytes of one chunk
@@ -274,9 +276,13 @@ __global__ __launch_bounds__(256) void x2_convT_lds_kernel(X2ConvTParams p) {
   const long long in_plane = (long long)p.D * p.H * p.W * 8;
   const int Do = ND == 3 ? p.D * 2 : 1, Ho = p.H * 2, Wo = p.W * 2;
   const long long out_plane = (long long)Do * Ho * Wo * 8;
-  float bias[8], osc[8];
+  float bias[RES ? 1 : 8], osc[RES ? 1 : 8];
+  if constexpr (!RES) {
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { bias[j] = p.bias[cob * 32 + q * 8 + j]; osc[j] = p.oscale[cob * 32 + q * 8 + j]; }
+    for (int j = 0; j < 8; ++j) { bias[j] = p.bias[cob * 32 + q * 8 + j]; osc[j] = p.oscale[cob * 32 + q * 8 + j]; }
+  } else if (threadIdx.x < 64) {      // RES: [oscale 32 | bias 32] behind the chunk, read per epilogue (16 registers less); published by the first pass's barrier
+    ((float*)(smem + CHB))[threadIdx.x] = threadIdx.x < 32 ? p.oscale[cob * 32 + threadIdx.x] : p.bias[cob * 32 + threadIdx.x - 32];
+  }
   const int src_lo = ((lane & 48) | (l15 >> 1)) * 4, src_hi = src_lo + 8 * 4;
   const bool odd = l15 & 1;
   const f16x8* wl = (const f16x8*)smem + lane;
@@ -307,11 +313,6 @@ __global__ __launch_bounds__(256) void x2_convT_lds_kernel(X2ConvTParams p) {
       const int xc = min(xb_[g] * 16 + l15, p.W - 1);
       xin_[g] = (const f16*)p.x + n_[g] * p.x_sstride + (((long long)z_[g] * p.H + y_[g]) * p.W + xc) * 8;
     }
-    f32x4 acc[G][NPOS][2];
-#pragma unroll
-    for (int g = 0; g < G; ++g)
-#pragma unroll
-      for (int s = 0; s < NPOS; ++s) { acc[g][s][0] = f32x4{0, 0, 0, 0}; acc[g][s][1] = f32x4{0, 0, 0, 0}; }
     auto load_b = [&](int ch, f16x8 (&bb)[G][2][KC]) {
 #pragma unroll
       for (int g = 0; g < G; ++g)
@@ -322,7 +323,34 @@ __global__ __launch_bounds__(256) void x2_convT_lds_kernel(X2ConvTParams p) {
           bb[g][1][j] = *(const f16x8*)(xin_[g] + (pl + p.x_lo) * in_plane);
         }
     };
+    constexpr int NH = RES ? 2 : 1, HP = NPOS / NH;                // passes over the output positions, positions per pass
+    f32x4 acc[G][HP][2];
+    auto zero_acc = [&]() {
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int s = 0; s < HP; ++s) { acc[g][s][0] = f32x4{0, 0, 0, 0}; acc[g][s][1] = f32x4{0, 0, 0, 0}; }
+    };
     f16x8 bcur[G][2][KC], bnext[G][2][KC];
+    auto mfmas = [&](int ch, int hf) {                             // chunk ch on positions hf * HP ..
+      const f16x8* wb = wl + (ch & 1) * (CHB / 16);
+#pragma unroll
+      for (int j = 0; j < KC; ++j)
+#pragma unroll
+        for (int s = 0; s < HP; ++s)
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const f16x8 ah = wb[(((0 * KC + j) * NPOS + hf * HP + s) * 2 + t) * 64];
+            const f16x8 al = wb[(((1 * KC + j) * NPOS + hf * HP + s) * 2 + t) * 64];
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+              acc[g][s][t] = mfma16<f16>(ah, bcur[g][0][j], acc[g][s][t]);
+              acc[g][s][t] = mfma16<f16>(ah, bcur[g][1][j], acc[g][s][t]);
+              acc[g][s][t] = mfma16<f16>(al, bcur[g][0][j], acc[g][s][t]);
+            }
+          }
+    };
+    zero_acc();
     if (!resident) {
       __syncthreads();                                             // the previous pass's last chunk is read
       dma_chunk(0);
@@ -332,22 +360,7 @@ __global__ __launch_bounds__(256) void x2_convT_lds_kernel(X2ConvTParams p) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this chunk's weights and fragments have landed
       __syncthreads();
       if (ch + 1 < nchunks) { dma_chunk(ch + 1); load_b(ch + 1, bnext); }
-      const f16x8* wb = wl + (ch & 1) * (CHB / 16);
-#pragma unroll
-      for (int j = 0; j < KC; ++j)
-#pragma unroll
-        for (int s = 0; s < NPOS; ++s)
-#pragma unroll
-          for (int t = 0; t < 2; ++t) {
-            const f16x8 ah = wb[(((0 * KC + j) * NPOS + s) * 2 + t) * 64];
-            const f16x8 al = wb[(((1 * KC + j) * NPOS + s) * 2 + t) * 64];
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-              acc[g][s][t] = mfma16<f16>(ah, bcur[g][0][j], acc[g][s][t]);
-              acc[g][s][t] = mfma16<f16>(ah, bcur[g][1][j], acc[g][s][t]);
-              acc[g][s][t] = mfma16<f16>(al, bcur[g][0][j], acc[g][s][t]);
-            }
-          }
+      mfmas(ch, 0);
       if (ch + 1 < nchunks) {
 #pragma unroll
         for (int g = 0; g < G; ++g)
@@ -359,20 +372,31 @@ __global__ __launch_bounds__(256) void x2_convT_lds_kernel(X2ConvTParams p) {
     }
     resident = nchunks == 1;
 #pragma unroll
+    for (int hf = 0; hf < NH; ++hf) {
+    if (hf > 0) { zero_acc(); mfmas(0, hf); }                        // RES: the second half of the positions on the same fragments
+#pragma unroll
     for (int g = 0; g < G; ++g) {
       if (g0 + g >= ngroups) break;
       f16* yout = (f16*)p.y + n_[g] * p.y_sstride + (long long)(cob * 4 + q) * out_plane;
       const int x0 = xb_[g] * 16;
 #pragma unroll
-      for (int sp = 0; sp < NPOS / 2; ++sp) {
+      for (int s2 = 0; s2 < HP / 2; ++s2) {
+        const int sp = hf * (HP / 2) + s2;
         const int a = ND == 3 ? (sp >> 1) : 0, b = sp & 1;
         i32x4 oc[2][2];                                  // [x position][hi | lo]
+        [[maybe_unused]] f32x4 cs[4];                    // RES: this lane's 8 channels of [oscale | bias]
+        if constexpr (RES) {
+          const f32x4* sp4 = (const f32x4*)(smem + CHB);
+          cs[0] = sp4[2 * q]; cs[1] = sp4[2 * q + 1]; cs[2] = sp4[8 + 2 * q]; cs[3] = sp4[8 + 2 * q + 1];
+        }
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
           f16x8 o, ol;
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
-            const float rr = fmaf(j < 4 ? acc[g][sp * 2 + c][0][j & 3] : acc[g][sp * 2 + c][1][j & 3], osc[j], bias[j]);
+            float rr;
+            if constexpr (RES) rr = fmaf(j < 4 ? acc[g][s2 * 2 + c][0][j & 3] : acc[g][s2 * 2 + c][1][j & 3], cs[j >> 2][j & 3], cs[2 + (j >> 2)][j & 3]);
+            else rr = fmaf(j < 4 ? acc[g][s2 * 2 + c][0][j & 3] : acc[g][s2 * 2 + c][1][j & 3], osc[j], bias[j]);
             f16 hi, lo;
             split16<f16>(rr, hi, lo);
             o[j] = hi; ol[j] = lo;
@@ -397,6 +421,7 @@ __global__ __launch_bounds__(256) void x2_convT_lds_kernel(X2ConvTParams p) {
             if (2 * x0 + 16 * h + l15 < Wo) *(i32x4*)(row + (w ? (long long)p.y_lo * out_plane : 0) + (16 * h + l15) * 8) = v;
           }
       }
+    }
     }
   }
 }
@@ -563,14 +588,16 @@ int iunet_x2_convT_fwd(int nd, const void* x, long long x_ss, int x_lo, void* y,
   p.oscale = (const float*)oscale; p.bias = (const float*)bias; p.N = N; p.D = D; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
   const long long waves = (long long)N * D * H * ((W + 15) / 16);
   const int kc = iunet_x2_convT_kc(Cin), nchunks = Cin / 32 / kc, npos = nd == 3 ? 8 : 4;
-  const int chb = 2 * kc * npos * 2 * 1024, lds = (nchunks == 1 ? 1 : 2) * chb;
+  const int chb = 2 * kc * npos * 2 * 1024, lds = nchunks == 1 ? chb + 256 : 2 * chb;      // (resident form: + its [oscale | bias])
   int gx = (int)((waves + 7) / 8);
   const int per_cu = lds <= 80 * 1024 ? 2 : 1;
   const int cap = per_cu * 256 / (Cout / 32) > 1 ? per_cu * 256 / (Cout / 32) : 1;
   if (gx > cap) gx = cap;
   dim3 grid(gx, Cout / 32);
-#define X2CT(NDV, KCV) do { IUNET_SET_MAX_LDS((x2_convT_lds_kernel<NDV, KCV>), lds); \
-    hipLaunchKernelGGL((x2_convT_lds_kernel<NDV, KCV>), grid, dim3(256), lds, (hipStream_t)stream, p); } while (0)
+  static const int res_on = getenv("IUNET_X2CT_RES") ? atoi(getenv("IUNET_X2CT_RES")) : 1;      // A/B: the two-half resident form
+#define X2CT(NDV, KCV) do { if (nchunks == 1 && res_on) { IUNET_SET_MAX_LDS((x2_convT_lds_kernel<NDV, KCV, true>), lds); \
+    hipLaunchKernelGGL((x2_convT_lds_kernel<NDV, KCV, true>), grid, dim3(256), lds, (hipStream_t)stream, p); } else { IUNET_SET_MAX_LDS((x2_convT_lds_kernel<NDV, KCV>), lds); \
+    hipLaunchKernelGGL((x2_convT_lds_kernel<NDV, KCV>), grid, dim3(256), lds, (hipStream_t)stream, p); } } while (0)
   if (nd == 3) { if (kc == 2) X2CT(3, 2); else X2CT(3, 1); } else { if (kc == 2) X2CT(2, 2); else X2CT(2, 1); }
 #undef X2CT
   IUNET_CHECK_HIP(hipGetLastError());

@@ -48,6 +48,8 @@ python3 $R/tools/bench_conv.py --wgrad 0 --iters 30 --n 1 --x2 1 > $OUT/${RND}_c
 python3 $R/tools/bench_conv.py --dim 2 --size 512 --n 8 --dtype f16 --wgrad 0 --iters 30 --x2 1 > $OUT/${RND}_conv_layers_x2_2d.txt 2>/dev/null
 # every C5 stage-conv shape: 16-bit kernel and the K = 128 fp8 kernel on e4m3 planes side by side
 python3 $R/tools/bench_conv.py --base 64 --levels 5 --f8 2 --wgrad 0 --iters 30 > $OUT/${RND}_conv_layers_c5_f8.txt 2>/dev/null
+# every transposed-conv shape of C3 / C5 / C2 alone
+python3 $R/tools/bench_convT.py 30 > $OUT/${RND}_convT_layers.txt 2>/dev/null
 # the training step and the C5 prediction forward by kernel
 rm -rf $OUT/tmp_tr; rocprofv3 --kernel-trace --output-format csv -d $OUT/tmp_tr -o tr -- python3 $R/tools/bench_train3d.py 10 > $OUT/train3d.log 2>&1
 python3 $R/tools/step_profile.py $OUT/tmp_tr/tr_kernel_trace.csv 13 40 > $OUT/${RND}_train_step_by_kernel.txt; rm -rf $OUT/tmp_tr
