@@ -220,9 +220,24 @@ __device__ __forceinline__ void pack_k16_block(const PackDesc& d, int blk, float
     return d.dgrad ? ((long long)(chunk * 16 + row) * d.Cin + cob * 32) * taps : ((long long)(cob * 32 + row) * d.Cin + chunk * 16) * taps;
   };
   if (((size_t)d.w & 15) == 0) {                       // every row starts on a 16-byte boundary when the tensor does
-    for (int i = threadIdx.x; i < nrows * rl4; i += 256) {
-      const int row = i / rl4, o4 = i - row * rl4;
-      *(f32x4*)(tile + row * rowlen + o4 * 4) = *(const f32x4*)(d.w + row_base(row) + o4 * 4);
+    // seven loads in flight per thread (two rounds per 3-D block) (a rolled load -> LDS-store loop waited for every one of its 14 loads in turn: 27 us per block,
+    // 700 us per step on C5's 13 000 blocks)
+    for (int i0 = threadIdx.x; i0 < nrows * rl4; i0 += 7 * 256) {
+      f32x4 v[7];
+#pragma unroll
+      for (int u = 0; u < 7; ++u) {
+        const int i = min(i0 + u * 256, nrows * rl4 - 1);
+        const int row = i / rl4, o4 = i - row * rl4;
+        v[u] = *(const f32x4*)(d.w + row_base(row) + o4 * 4);
+      }
+#pragma unroll
+      for (int u = 0; u < 7; ++u) {
+        const int i = i0 + u * 256;
+        if (i < nrows * rl4) {
+          const int row = i / rl4, o4 = i - row * rl4;
+          *(f32x4*)(tile + row * rowlen + o4 * 4) = v[u];
+        }
+      }
     }
   } else {                                             // a parameter at an odd offset of the flat vector
     for (int i = threadIdx.x; i < nrows * rowlen; i += 256) {
@@ -305,9 +320,22 @@ __device__ __forceinline__ void pack_k16c_block(const PackDesc& d, int blk, floa
     return d.dgrad ? ((long long)(chunk * 16 + row) * d.Cin + cob * 32) * taps : ((long long)(cob * 32 + row) * d.Cin + chunk * 16) * taps;
   };
   if (((size_t)d.w & 15) == 0) {
-    for (int i = threadIdx.x; i < nrows * rl4; i += 256) {
-      const int row = i / rl4, o4 = i - row * rl4;
-      *(f32x4*)(tile + row * rowlen + o4 * 4) = *(const f32x4*)(d.w + row_base(row) + o4 * 4);
+    for (int i0 = threadIdx.x; i0 < nrows * rl4; i0 += 7 * 256) {      // seven loads in flight per thread (two rounds per 3-D block), as in pack_k16_block
+      f32x4 v[7];
+#pragma unroll
+      for (int u = 0; u < 7; ++u) {
+        const int i = min(i0 + u * 256, nrows * rl4 - 1);
+        const int row = i / rl4, o4 = i - row * rl4;
+        v[u] = *(const f32x4*)(d.w + row_base(row) + o4 * 4);
+      }
+#pragma unroll
+      for (int u = 0; u < 7; ++u) {
+        const int i = i0 + u * 256;
+        if (i < nrows * rl4) {
+          const int row = i / rl4, o4 = i - row * rl4;
+          *(f32x4*)(tile + row * rowlen + o4 * 4) = v[u];
+        }
+      }
     }
   } else {
     for (int i = threadIdx.x; i < nrows * rowlen; i += 256) {
@@ -362,60 +390,92 @@ __device__ __forceinline__ void pack_k16c_block(const PackDesc& d, int blk, floa
   __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void pack_batch_kernel(const PackDesc* __restrict__ descs, int f8_k128) {
-  const PackDesc d = descs[blockIdx.y];
+// Tasks of one layer: a K16 block each for the 3^d convs, 1 024 granules (of 8 elements) each for the other kinds.
+__device__ __forceinline__ int pack_tasks(const PackDesc& d) {
+  if (d.kind == 1 || d.kind == 5 || d.kind == 6) return ((d.dgrad ? d.Cin : d.Cout) >> 5) * ((d.dgrad ? d.Cout : d.Cin) >> 4);
+  const long long gran = (d.total + 7) / 8;
+  return (int)((gran + 1023) / 1024);
+}
+constexpr int PACK_MAX_LAYERS = 512;
+
+// The layers' tasks form ONE list walked grid-stride by the launch's workgroups (each rebuilds the prefix of the task counts in
+// LDS: n <= 512 descriptors).  The first form launched 1 024 workgroups per layer and let the surplus exit: 40 000 workgroups with
+// 54 KB of LDS each for the 800 blocks of the C3 net -- 70 us per step of workgroup dispatch (573 us on C5's 13 000 blocks).
+__global__ __launch_bounds__(256) void pack_batch_kernel(const PackDesc* __restrict__ descs, int n, int f8_k128) {
   __shared__ __attribute__((aligned(16))) float tile[32 * 16 * 27];               // one K16 block of source weights (54 KB)
-  if (d.kind == 1 || d.kind == 5 || d.kind == 6) {
-    const int CoutP = d.dgrad ? d.Cin : d.Cout, CinP = d.dgrad ? d.Cout : d.Cin;
-    const int nblocks = (CoutP >> 5) * (CinP >> 4);
-    const bool k128 = f8_k128 && d.kind == 5 && d.taps == 27 && d.Cin % 32 == 0;      // iunet_f8_k128(taps, Cin)
-    for (int blk = blockIdx.x; blk < nblocks; blk += gridDim.x) { if (d.kind == 6) pack_k16c_block(d, blk, tile); else pack_k16_block(d, blk, tile, k128); }
-    if (d.bias_out && blockIdx.x == 0) {
-      for (int co = threadIdx.x; co < d.Cout; co += 256) d.bias_out[co] = fold_bias(d, co);
+  __shared__ int first[PACK_MAX_LAYERS + 1];
+  for (int i = threadIdx.x; i < n; i += 256) first[i + 1] = pack_tasks(descs[i]);
+  if (threadIdx.x == 0) first[0] = 0;
+  __syncthreads();
+  if (threadIdx.x < 64) {                     // inclusive scan by one wave, 64 entries at a time
+    int carry = 0;
+    for (int base = 0; base < n; base += 64) {
+      const int i = base + threadIdx.x;
+      int v = i < n ? first[i + 1] : 0;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(v, o); if ((int)threadIdx.x >= o) v += t; }
+      if (i < n) first[i + 1] = v + carry;
+      carry += __shfl(v, 63);
     }
-    return;
   }
-  const bool fold = d.gamma != nullptr && !d.dgrad && d.kind <= 1;     // the kinds whose elem() multiplies by the folded scale
-  for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g * 8 < d.total; g += (long long)gridDim.x * 256) {
-    float v[8];
-    int oc = 0;
-    if (d.kind == 2) {
+  __syncthreads();
+  const int ntask = first[n];
+  for (int task = blockIdx.x; task < ntask; task += gridDim.x) {
+    int lo = 0, hi = n - 1;                   // the layer of this task: last i with first[i] <= task (uniform over the workgroup)
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (first[mid] <= task) lo = mid; else hi = mid - 1; }
+    lo = __builtin_amdgcn_readfirstlane(lo);            // uniform by construction: the descriptor then loads into scalar registers
+    const PackDesc d = descs[lo];                        // (left in vector registers, every index computation below ran on the vector ALU)
+    const int local = __builtin_amdgcn_readfirstlane(task - first[lo]);
+    if (d.bias_out && local == 0) {
+      for (int co = threadIdx.x; co < d.Cout; co += 256) d.bias_out[co] = fold_bias(d, co);      // separately rounded, as the host formula beta - mean * scale
+    }
+    if (d.kind == 1 || d.kind == 5 || d.kind == 6) {
+      const bool k128 = f8_k128 && d.kind == 5 && d.taps == 27 && d.Cin % 32 == 0;      // iunet_f8_k128(taps, Cin)
+      if (d.kind == 6) pack_k16c_block(d, local, tile); else pack_k16_block(d, local, tile, k128);
+      __syncthreads();                        // the tile is read to the end before the next task overwrites it
+      continue;
+    }
+    const bool fold = d.gamma != nullptr && !d.dgrad && d.kind <= 1;     // the kinds whose elem() multiplies by the folded scale
+#pragma unroll 1
+    for (int k = 0; k < 4; ++k) {
+      const long long g = (long long)local * 1024 + k * 256 + threadIdx.x;
+      if (g * 8 >= d.total) break;
+      float v[8];
+      int oc = 0;
+      if (d.kind == 2) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = elem(d, g * 8 + j, oc);
-    } else {
-      const float* src; long long stride; float fs;
-      if (granule(d, (int)g, src, stride, fs, oc)) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = src[j * stride];
-        if (fold) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = mul_rn(v[j], fs);
-        }
+        for (int j = 0; j < 8; ++j) v[j] = elem(d, g * 8 + j, oc);
       } else {
+        const float* src; long long stride; float fs;
+        if (granule(d, (int)g, src, stride, fs, oc)) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = 0.f;
+          for (int j = 0; j < 8; ++j) v[j] = src[j * stride];
+          if (fold) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = mul_rn(v[j], fs);
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = 0.f;
+        }
+      }
+      if (d.qscale) {
+        const float sc = d.qscale[oc];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = sc * round_e4m3(v[j] / sc);
+      }
+      if (d.dtype == 0) {
+        typename Vec8<f16>::type o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = from_f32<f16>(v[j]);
+        *(typename Vec8<f16>::type*)((f16*)d.dst + g * 8) = o;
+      } else {
+        typename Vec8<bf16>::type o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = from_f32<bf16>(v[j]);
+        *(typename Vec8<bf16>::type*)((bf16*)d.dst + g * 8) = o;
       }
     }
-    if (d.qscale) {
-      const float sc = d.qscale[oc];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = sc * round_e4m3(v[j] / sc);
-    }
-    if (d.dtype == 0) {
-      typename Vec8<f16>::type o;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) o[j] = from_f32<f16>(v[j]);
-      *(typename Vec8<f16>::type*)((f16*)d.dst + g * 8) = o;
-    } else {
-      typename Vec8<bf16>::type o;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) o[j] = from_f32<bf16>(v[j]);
-      *(typename Vec8<bf16>::type*)((bf16*)d.dst + g * 8) = o;
-    }
-  }
-  if (d.bias_out && blockIdx.x == 0) {
-    for (int co = threadIdx.x; co < d.Cout; co += 256)      // separately rounded, as the host formula beta - mean * scale
-      d.bias_out[co] = fold_bias(d, co);
   }
 }
 
@@ -452,9 +512,10 @@ int iunet_pack_batch(const void* descs, int n, int quant_max_cout, void* stream)
   IUNET_REQUIRE(descs && n > 0, "pack_batch: empty descriptor table");
   if (quant_max_cout > 0)
     hipLaunchKernelGGL(pack_qscale_kernel, dim3(quant_max_cout, n), dim3(256), 0, (hipStream_t)stream, (const PackDesc*)descs);
-  // 1024 workgroups per layer (grid-stride; the small layers' surplus exits at once): the largest operators (28 M elements in C5) need
-  // more than one workgroup per CU to hide their gather latency
-  hipLaunchKernelGGL(pack_batch_kernel, dim3(1024, n), dim3(256), 0, (hipStream_t)stream, (const PackDesc*)descs,
+  IUNET_REQUIRE(n <= PACK_MAX_LAYERS, "pack_batch: %d descriptors (at most %d per launch)", n, PACK_MAX_LAYERS);
+  // one task list over all layers, 2 048 workgroups walking it (two resident per CU by their LDS, four rounds of them: the largest
+  // operators -- 28 M elements in C5 -- need that many to hide their gather latency; a small net's surplus exits after the prefix)
+  hipLaunchKernelGGL(pack_batch_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, (const PackDesc*)descs, n,
                      iunet_f8_k128(27, 32));
   IUNET_CHECK_HIP(hipGetLastError());
   return IUNET_OK;
