@@ -164,6 +164,20 @@ inline void iunet_brick_shape(int nd, int ncob, int tilesZ, int tilesY, int tile
   *bz = z; *by = y; *bx = x;
 }
 
+// Global -> LDS copy of `nitems` 16-byte items by `nthreads` threads with up to 8 loads in flight per thread.  A rolled
+// `for (i = tid; i < n; i += nthreads) lds[i] = src[i]` waits for each load before it issues the next (the LDS store needs the value):
+// a 64 KB operator staged by 256 threads took 16 memory latencies that way.  The caller publishes the copy with its own barrier.
+__device__ __forceinline__ void stage_to_lds(unsigned char* lds, const u32x4* __restrict__ src, int nitems, int tid, int nthreads) {
+  for (int i0 = tid; i0 < nitems; i0 += 8 * nthreads) {
+    u32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = src[min(i0 + u * nthreads, nitems - 1)];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (i0 + u * nthreads < nitems) *(u32x4*)(lds + (long long)(i0 + u * nthreads) * 16) = v[u];
+  }
+}
+
 // ---- e4m3 activation planes ("NHWC16c" bytes: C / 16 planes of [D][H][W][16 B]) -- what the K = 128 fp8 convolution reads by LDS-DMA.
 // 8 values of type T -> 8 OCP e4m3 bytes (round to nearest even, saturating at +-448): the conversion of the fp8 convs' loader waves
 template <typename T>

@@ -198,7 +198,7 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + v4_loader_threads(ND
   }
   if (WS) {     // all weights of this Cout tile: global -> LDS once, by everybody
     const int nitems = nchunk * (WSTEP / 16);
-    for (int i = tid; i < nitems; i += NCW * 64 + NLT) *(u32x4*)(smem + OFF_W + i * 16) = wsrc[i];
+    stage_to_lds(smem + OFF_W, wsrc, nitems, tid, NCW * 64 + NLT);
   }
 
   if (p.in_scale != nullptr) {

@@ -359,7 +359,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void convT_lds_kernel(ConvTP
   const int cob = blockIdx.y;
   {
     const u32x4* wsrc = (const u32x4*)p.wpk + (long long)cob * NK * NPOS * 2 * 64;
-    for (int i = threadIdx.x; i < NK * NPOS * 2 * 64; i += NT) *(u32x4*)(smem + i * 16) = wsrc[i];
+    stage_to_lds(smem, wsrc, NK * NPOS * 2 * 64, threadIdx.x, NT);
     if (threadIdx.x < 32) ((float*)(smem + NK * NPOS * 2 * 1024))[threadIdx.x] = p.bias ? p.bias[cob * 32 + threadIdx.x] : 0.f;      // read per epilogue: 8 registers less
   }
   __syncthreads();

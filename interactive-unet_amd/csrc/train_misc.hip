@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256, (NCI * NK * (ND == 3 ? 16 : 8) <= 64) ? 2 : 1)
   const int cib0 = blockIdx.y * NCI;
   {
     const u32x4* wsrc = (const u32x4*)p.wpk + (long long)cib0 * WCI;
-    for (int i = threadIdx.x; i < NCI * WCI; i += 256) *(u32x4*)(smem + i * 16) = wsrc[i];
+    stage_to_lds(smem, wsrc, NCI * WCI, threadIdx.x, 256);
   }
   __syncthreads();
   const int xg = (p.W + 15) / 16;
