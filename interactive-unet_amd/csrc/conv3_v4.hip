@@ -198,7 +198,9 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + v4_loader_threads(ND
   }
   if (WS) {     // all weights of this Cout tile: global -> LDS once, by everybody
     const int nitems = nchunk * (WSTEP / 16);
-    stage_to_lds(smem + OFF_W, wsrc, nitems, tid, NCW * 64 + NLT);
+    // (a rolled loop on purpose: staged through stage_to_lds -- 8 loads in flight per thread -- these launches measured 13 % SLOWER,
+    //  272 against 240 us at 32 -> 32 @ 2 x 128^3)
+    for (int i = tid; i < nitems; i += NCW * 64 + NLT) *(u32x4*)(smem + OFF_W + i * 16) = wsrc[i];
   }
 
   if (p.in_scale != nullptr) {
