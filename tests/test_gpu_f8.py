@@ -240,7 +240,8 @@ def test_e4m3_plane_producers_round_like_the_conv_loader(nv):
     ref = F.max_pool3d(t, 2).clamp(-448, 448).to(torch.float8_e4m3fn).float()
     assert torch.equal(unblocked_q(pq.cpu(), N, 32, (D // 2, H // 2, W // 2)), ref)
     # ---- transposed conv (three kernels: direct, resident weights, chunked weights), output into the second half of a concat buffer
-    for cin, cout, sp in ((64, 32, (2, 4, 16)), (64, 32, (4, 8, 16)), (256, 64, (4, 8, 16)), (32, 32, (1, 2, 3))):
+    for cin, cout, sp in ((64, 32, (2, 4, 16)), (64, 32, (4, 8, 16)), (256, 64, (4, 8, 16)), (32, 32, (1, 2, 3)),
+                          (128, 64, (8, 16, 32)), (96, 32, (4, 16, 40)), (256, 64, (16, 16, 64))):      # resident weights: whole-granule epilogue (4 and 3 k-steps, ragged x; 8 k-steps on 8 waves)
         Di, Hi, Wi = sp
         vi, vo = Di * Hi * Wi, 8 * Di * Hi * Wi
         xi = (torch.randn((N, cin) + sp, generator=g)).to(dtype).float()
