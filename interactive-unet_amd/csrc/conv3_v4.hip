@@ -51,9 +51,12 @@ template <bool SMALL> struct V4Tile<2, SMALL> { static constexpr int TZ = 1, TY 
 // loader threads: 4 loader waves when only activations stream (resident weights), when tiles go in pairs, and for the 2-D split
 // launches (their consumers need more than the 128 registers that 16 waves per CU leave: 52 B of scratch per lane otherwise, and the
 // operand-sharing schedule moves a third fewer bytes); 8 when the weights stream too
-// (the fused-BatchNorm-backward data gradient on 4 loader waves -- 168 registers, no scratch instead of 56 B per lane -- measured the same
-// step time, 7.59 vs 7.62 ms: its scratch traffic is not what the training leg waits for)
-constexpr int v4_loader_threads(int nd, bool ws, bool pair, bool spl) { return (ws || pair || (spl && nd == 2)) ? 256 : 512; }
+// ([r3] the fused-BatchNorm-backward data gradient runs on 4 loader waves too: 153-165 registers and no scratch instead of 128 + 56 B
+// (3-D) / 144 B (2-D) per lane; A/B on one box: C3 training step 6.90-6.92 against 6.97-7.00 ms, 2-D step 13.61-13.66 against 13.75 ms)
+#ifndef V4_BW_LT
+#define V4_BW_LT 256            // (A/B: -DV4_BW_LT=512)
+#endif
+constexpr int v4_loader_threads(int nd, bool ws, bool pair, bool spl, bool bwv = false) { return (ws || pair || (spl && nd == 2)) ? 256 : bwv ? V4_BW_LT : 512; }
 
 struct ConvV4Params {
   const void* x;  long long x_sstride;
@@ -95,7 +98,7 @@ struct ConvV4Params {
 // previous chunk (read from the previous step's halo buffer, which a ring of THREE buffers keeps alive) and column 8 of its own.
 // 27 taps in 27 K-slots: -10 % MFMAs, fragment reads and weight bytes.  LDS: 3 x 34 816 + 24 576 + 30 720 + scratch = 162 304 B.
 template <typename T, int ND, bool WS, bool SMALL, bool BW = false, bool PAIR = false, bool NP = false, bool SPL = false>
-__global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + v4_loader_threads(ND, WS, PAIR, SPL)), 1) void conv3_v4_kernel(ConvV4Params p) {
+__global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + v4_loader_threads(ND, WS, PAIR, SPL, BW)), 1) void conv3_v4_kernel(ConvV4Params p) {
   static_assert(!SPL || (!WS && !BW && !PAIR && !NP), "split precision: streamed weights (Cin' = 3 Cin >= 96), forward only, padded operator");
   static_assert(!PAIR || (!WS && !BW && ND == 3), "tile pairs: the streamed-weight 3-D forward / data-gradient variant only");
   static_assert(!NP || (!WS && !BW && !PAIR && ND == 3), "padding-free step: the streamed-weight 3-D variants without fused BatchNorm-backward sums (so far)");
@@ -103,7 +106,7 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + v4_loader_threads(ND
   using TL = V4Tile<ND, SMALL>;
   // consumer waves; loader threads: 4 loader waves when only activations stream, 8 when the weights stream too (twice the
   // bytes per step: the extra waves double the loads in flight, -6...-11 % on those layers)
-  constexpr int NCW = TL::NCW, NLT = v4_loader_threads(ND, WS, PAIR, SPL);
+  constexpr int NCW = TL::NCW, NLT = v4_loader_threads(ND, WS, PAIR, SPL, BW);
   constexpr int TZ = TL::TZ, TY = TL::TY, TX = TL::TX, PADZ = TL::PADZ, NCOL = TL::NCOL, S16 = TL::S16;
   constexpr int FX = TX / 16, NI = TZ * TY * FX / NCW, NR = NI / FX;    // x halves; fragments per consumer wave; tile rows per wave
   constexpr int PZ = TZ + 2 * PADZ, PY = TY + 2, PX = TX + 2;
@@ -770,7 +773,7 @@ int launch_v4(ConvV4Params p, hipStream_t stream) {
     if (gx < rows)
       IUNET_CHECK_HIP(hipMemsetAsync(p.stats + (long long)gx * p.Cout * 2, 0, (size_t)(rows - gx) * p.Cout * 2 * sizeof(float), stream));
   }
-  hipLaunchKernelGGL((conv3_v4_kernel<T, ND, WS, SMALL, BW, PAIR, NP, SPL>), dim3(gx, ncob), dim3(TL::NCW * 64 + v4_loader_threads(ND, WS, PAIR, SPL)), lds, stream, p);
+  hipLaunchKernelGGL((conv3_v4_kernel<T, ND, WS, SMALL, BW, PAIR, NP, SPL>), dim3(gx, ncob), dim3(TL::NCW * 64 + v4_loader_threads(ND, WS, PAIR, SPL, BW)), lds, stream, p);
   IUNET_CHECK_HIP(hipGetLastError());
   return IUNET_OK;
 }
