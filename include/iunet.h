@@ -34,7 +34,7 @@ int iunet_abi_version(void);
 /* ---- weight packing (host fp32 master weights -> MFMA fragment order) ---------------- */
 /* conv weights fp32 [Cout][Cin][taps] (torch Conv{2,3}d layout); optional per-cout scale
  * folds an eval-mode BatchNorm.  mode bit 0: data-gradient operator (channels transposed, taps
- * mirrored); mode bit 1: K16 fragment order for weight layout 1 (see iunet_conv3_pick_layout); mode bit 2: the compact K16 order of layout 3 (taps = 27 only).  dst: iunet_pack_conv3_elems(...) elements of `dtype`. */
+ * mirrored); mode bit 1: K16 fragment order for weight layout 1 (see iunet_conv3_pick_layout); mode bit 2: the compact K16 order (no padded filter column: layout 3 for taps = 27; for taps = 9 the cross-pair step of the 2-D split-precision conv).  dst: iunet_pack_conv3_elems(...) elements of `dtype`. */
 long long iunet_pack_conv3_elems(int Cout, int Cin, int taps, int mode);
 int iunet_pack_conv3(int dtype, const void* w, const void* scale, void* dst, int Cout, int Cin, int taps, int mode,
                      void* stream);
@@ -176,7 +176,7 @@ int iunet_f32_channel_sum(const void* t, long long t_ss, void* out, int C, int N
  * (transposed != 0; taps 4 / 8), optional eval-mode BatchNorm fold (gamma..var, as iunet_f32_pack_conv) or the layer's own
  * bias_in -> wv: transposed 0: the VIRTUAL fp32 operator over 3 Cin input channels, [w_hi | w_hi | w_lo] per chunk of `chunk`
  * channels -- the step of the kernel that consumes it: 16 (3-D stage conv), 32 (2-D), Cin (first conv) -- (3 Cout Cin taps
- * floats; feed it to iunet_pack_conv3 mode 2 / iunet_pack_first_conv with "Cin" = 3 Cin, dtype 0); transposed 2 (what
+ * floats; feed it to iunet_pack_conv3 mode iunet_x2_pack_mode(nd) / iunet_pack_first_conv with "Cin" = 3 Cin, dtype 0); transposed 2 (what
  * iunet_x2_convT_fwd takes; Cin % 32 == 0): both words once over 2 Cin channels, in chunks of iunet_x2_convT_kc(Cin) k-steps of 32
  * channels [chunk][hi | lo][k-step][32] (feed it to iunet_pack_convT with "Cin" = 2 Cin); oscale [Cout] = the power of two the
  * accumulator is multiplied by (act_out / (act_in * row scale)), bias_out [Cout] = act_out * bias. */
@@ -189,7 +189,10 @@ int iunet_x2_prep(const void* w, void* wv, void* oscale, void* bias_out, const v
 int iunet_x2_first_conv_fwd(int nd, const void* x, int in_dtype, const long long* in_strides, void* y, long long y_sstride, int y_lo,
                             const void* w, const void* oscale, const void* bias, float act_scale, int N, int D, int H, int W, int Cin,
                             int Cout, int relu, void* stream);
-/* stage conv 3^d pad 1 (epi as iunet_conv3_fwd); Cin = real input channels */
+/* iunet_pack_conv3 mode of the stage convs' virtual operator: 2 (padded K16 order) in 3-D; 6 (compact order) in 2-D, where the third
+ * filter column of the two 16-channel halves of a 32-channel step shares one k-group (9 taps in 9 k-slots instead of 12) */
+int iunet_x2_pack_mode(int nd);
+/* stage conv 3^d pad 1 (epi as iunet_conv3_fwd); Cin = real input channels; wpk packed with mode iunet_x2_pack_mode(nd) */
 int iunet_x2_conv3_fwd(int nd, const void* x, long long x_sstride, int x_lo, void* y, long long y_sstride, int y_lo, const void* wpk,
                        const void* oscale, const void* bias, int N, int D, int H, int W, int Cin, int Cout, int epi, void* stream);
 /* 2^d max-pool on hi + lo sums (the winner's word pair is copied: no rounding) */

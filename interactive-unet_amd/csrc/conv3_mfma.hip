@@ -303,14 +303,18 @@ __global__ void pack_conv3_k16_kernel(const float* __restrict__ w, const float* 
   }
 }
 
-// Compact K16 order of the 3^3 filter (mode bit 2; conv3_v4.hip's padding-free step): the ninth (dz, dx) column of two consecutive
-// 16-channel chunks shares one k-step instead of being padded to a pair with zeros.  Per Cout tile and chunk PAIR (32 channels):
-//   [even chunk: column pairs 0..3][dy][2][64][8]  (24 KB)  |  [odd chunk: the same]  (24 KB)  |  [cross: dy][2][64][8]  (6 KB),
-// cross lanes q >> 1 = 0: column 8 of the even chunk, q >> 1 = 1: column 8 of the odd chunk.  Cout x Cin x 27 elements: no padding.
+// Compact K16 order (mode bit 2; conv3_v4.hip's padding-free step): the last filter column -- (dz, dx) column 8 of the 3^3 filter, dx
+// column 2 of the 3^2 filter -- of two consecutive 16-channel chunks shares one k-step instead of being padded to a pair with zeros.
+// Per Cout tile and chunk PAIR (32 channels), NR = 4 (3-D) / 1 (2-D) regular column pairs:
+//   [even chunk: column pairs 0..NR-1][dy][2][64][8]  (24 / 6 KB)  |  [odd chunk: the same]  |  [cross: dy][2][64][8]  (6 KB),
+// cross lanes q >> 1 = 0: the last column of the even chunk, q >> 1 = 1: of the odd chunk.  Cout x Cin x taps elements: no padding.
+// 2-D: the pair block IS one 32-channel step of conv3_v4.hip -- three k-groups instead of four (-25 % MFMAs and fragment reads).
 template <typename T>
 __global__ void pack_conv3_k16c_kernel(const float* __restrict__ w, const float* __restrict__ scale, T* __restrict__ dst,
-                                       int CoutP, int CinP, int dgrad, int CinO) {
-  constexpr int taps = 27, FR = 512, EVEN = 4 * 3 * 2 * FR, PAIR = 2 * EVEN + 3 * 2 * FR;      // elements
+                                       int CoutP, int CinP, int taps, int dgrad, int CinO) {
+  constexpr int FR = 512;                                           // elements of one fragment (64 lanes x 8)
+  const int ncol = taps / 3, nreg = ncol / 2;                       // 9 columns: 4 regular pairs; 3 columns: 1
+  const int EVEN = nreg * 3 * 2 * FR, PAIR = 2 * EVEN + 3 * 2 * FR, NF = nreg * 6;      // elements; fragments of a chunk's regular part
   const int npair = CinP >> 5;
   const long long total = (long long)(CoutP / 32) * npair * PAIR;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -320,8 +324,8 @@ __global__ void pack_conv3_k16c_kernel(const float* __restrict__ w, const float*
     const int j = e & 7, lane = (e >> 3) & 63;
     const int row = lane & 15, qq = lane >> 4;
     int frag = e >> 9, chunk, col;                                  // fragment index within the pair block
-    if (frag < 48) { chunk = 2 * pr + frag / 24; frag %= 24; col = 2 * (frag / 6) + (qq >> 1); frag %= 6; }
-    else { frag -= 48; chunk = 2 * pr + (qq >> 1); col = 8; }
+    if (frag < 2 * NF) { chunk = 2 * pr + frag / NF; frag %= NF; col = 2 * (frag / 6) + (qq >> 1); frag %= 6; }
+    else { frag -= 2 * NF; chunk = 2 * pr + (qq >> 1); col = ncol - 1; }
     const int dy = frag >> 1, m = frag & 1;
     const int co = cob * 32 + 8 * (row >> 2) + 4 * m + (row & 3);
     const int ci = chunk * 16 + 8 * (qq & 1) + j;
@@ -418,7 +422,7 @@ int iunet_conv3_pick(int nd, int N, int D, int H, int W, int Cin, int Cout) {
 
 // elements of the packed operator (the K16 order pads the tap count to an even number)
 long long iunet_pack_conv3_size(int Cout, int Cin, int taps, int mode) {
-  if ((mode & 4) && taps == 27) return (long long)Cout * Cin * taps;   // compact K16 (3-D): no padding
+  if (mode & 4) return (long long)Cout * Cin * taps;                   // compact K16: no padding
   const int t = (mode & 2) ? ((taps / 3 + 1) / 2) * 6 : taps;      // K16 order pads the filter columns to pairs
   return (long long)Cout * Cin * t;
 }
@@ -430,12 +434,11 @@ int iunet_pack_conv3_launch(int dtype, const float* w, const float* scale, void*
   const int CoutP = dg == 0 ? Cout : Cin, CinP = dg == 0 ? Cin : Cout;
   IUNET_REQUIRE(CoutP % 32 == 0 && CinP % 32 == 0, "pack_conv3: channel counts must be multiples of 32 (%d, %d)", CoutP, CinP);
   const int MI = iunet_conv3_mi(CoutP);
-  if (mode & 4) {     // compact K16 (conv3_v4.hip layout 3: 3-D only)
-    IUNET_REQUIRE(taps == 27, "pack_conv3: the compact K16 order exists for the 3^3 filter only");
-    const long long tot = (long long)CoutP * CinP * 27;
+  if (mode & 4) {     // compact K16 (conv3_v4.hip: layout 3 in 3-D, the cross-pair step of the 2-D split-precision conv)
+    const long long tot = (long long)CoutP * CinP * taps;
     const int nb = (int)((tot + 255) / 256 < 4096 ? (tot + 255) / 256 : 4096);
-    if (dtype == 0) hipLaunchKernelGGL(pack_conv3_k16c_kernel<f16>, dim3(nb), dim3(256), 0, stream, w, scale, (f16*)dst, CoutP, CinP, dg, Cin);
-    else hipLaunchKernelGGL(pack_conv3_k16c_kernel<bf16>, dim3(nb), dim3(256), 0, stream, w, scale, (bf16*)dst, CoutP, CinP, dg, Cin);
+    if (dtype == 0) hipLaunchKernelGGL(pack_conv3_k16c_kernel<f16>, dim3(nb), dim3(256), 0, stream, w, scale, (f16*)dst, CoutP, CinP, taps, dg, Cin);
+    else hipLaunchKernelGGL(pack_conv3_k16c_kernel<bf16>, dim3(nb), dim3(256), 0, stream, w, scale, (bf16*)dst, CoutP, CinP, taps, dg, Cin);
     IUNET_CHECK_HIP(hipGetLastError());
     return IUNET_OK;
   }

@@ -37,6 +37,7 @@ extern "C" int iunet_v4_stamps_read(unsigned long long* out) {
 __device__ __attribute__((aligned(16))) unsigned int g_v4_zero16[4] = {0u, 0u, 0u, 0u};
 int iunet_conv3_v4_stats_parts(int nd, int Cout);
 int iunet_conv3_v4_pairs(int nd, int N, int D, int H, int W, int Cin, int Cout, int bw);
+int iunet_conv3_v4_x2_pack_mode(int nd);
 
 namespace {
 
@@ -99,9 +100,14 @@ struct ConvV4Params {
 // 27 taps in 27 K-slots: -10 % MFMAs, fragment reads and weight bytes.  LDS: 3 x 34 816 + 24 576 + 30 720 + scratch = 162 304 B.
 template <typename T, int ND, bool WS, bool SMALL, bool BW = false, bool PAIR = false, bool NP = false, bool SPL = false>
 __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + v4_loader_threads(ND, WS, PAIR, SPL, BW)), 1) void conv3_v4_kernel(ConvV4Params p) {
-  static_assert(!SPL || (!WS && !BW && !PAIR && !NP), "split precision: streamed weights (Cin' = 3 Cin >= 96), forward only, padded operator");
+  static_assert(!SPL || (!WS && !BW && !PAIR && !(NP && ND == 3)), "split precision: streamed weights (Cin' = 3 Cin >= 96), forward only, padded operator in 3-D");
   static_assert(!PAIR || (!WS && !BW && ND == 3), "tile pairs: the streamed-weight 3-D forward / data-gradient variant only");
-  static_assert(!NP || (!WS && !BW && !PAIR && ND == 3), "padding-free step: the streamed-weight 3-D variants without fused BatchNorm-backward sums (so far)");
+  static_assert(!NP || (!BW && !PAIR && (ND == 2 || !WS)), "padding-free step: the streamed-weight 3-D variants and the 2-D ones, without fused BatchNorm-backward sums (so far)");
+  // NP in 3-D: the ninth column of two consecutive 16-channel STEPS shares a k-slot (ring of three halo buffers, below).  NP in 2-D
+  // (NP2): a step already holds two 16-channel sub-chunks, so the third filter column of both shares one k-group inside the step --
+  // groups (sub-chunk 0: columns 0, 1), (sub-chunk 1: columns 0, 1), (cross: column 2 of both) = 9 taps in 9 k-slots instead of 12:
+  // -25 % MFMAs, fragment reads and weight bytes; nothing else of the step changes (two halo buffers, one weight stride).
+  constexpr bool NP3 = NP && ND == 3, NP2 = NP && ND == 2;
   using V8 = typename Vec8<T>::type;
   using TL = V4Tile<ND, SMALL>;
   // consumer waves; loader threads: 4 loader waves when only activations stream, 8 when the weights stream too (twice the
@@ -116,13 +122,13 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + v4_loader_threads(ND
   constexpr int ABUF = CP * PLANE;                     // one step of the halo tile
   constexpr int NCMB = (NCOL + 1) / 2, KS = NCMB * 3;
   constexpr int WBYTES = KS * 2 * 1024;                // one 16-channel chunk of packed weights
-  constexpr int WSTEP = S16 * WBYTES;                  // the weights of one step
-  constexpr int NBUF = NP ? 3 : 2;                     // halo buffers
+  constexpr int WSTEP = NP2 ? 3 * 3 * 2 * 1024 : S16 * WBYTES;      // the weights of one step (NP2: three k-groups of 6 KB)
+  constexpr int NBUF = NP3 ? 3 : 2;                    // halo buffers
   constexpr int OFF_W = NBUF * ABUF;
   constexpr int WE = 4 * 3 * 2 * 1024, WO = WE + 3 * 2 * 1024;      // NP: bytes of an even step's weights (4 column pairs) / an odd step's (+ the cross pair)
   constexpr int AIT = (NPIX + NLT - 1) / NLT;          // halo pixels per loader thread (5 / 3)
-  constexpr int WIT = ((NP ? WO : WSTEP) / 16 + NLT - 1) / NLT;    // 16-byte weight items per loader thread (8 / 6)
-  constexpr int NGRP = S16 * NCMB;                     // (16-channel sub-chunk, column pair) groups per step
+  constexpr int WIT = ((NP3 ? WO : WSTEP) / 16 + NLT - 1) / NLT;    // 16-byte weight items per loader thread (8 / 6)
+  constexpr int NGRP = NP2 ? 3 : S16 * NCMB;           // (16-channel sub-chunk, column pair) groups per step
   constexpr int NRD = FX * (NR + 2) + 6;               // LDS fragment reads per group
   static_assert(NCW * NI == TZ * TY * FX, "consumer waves x fragments must cover the tile");
 
@@ -159,15 +165,15 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + v4_loader_threads(ND
     return;
   }
   const long long plane_stride = (long long)p.D * p.H * p.W * 8;
-  const int off_red = OFF_W + (NP ? WE + WO : (WS ? nchunk : 2) * WSTEP);    // 2 KB of scratch for the BatchNorm partial sums
+  const int off_red = OFF_W + (NP3 ? WE + WO : (WS ? nchunk : 2) * WSTEP);    // 2 KB of scratch for the BatchNorm partial sums
   const int off_act = off_red + 2048;                       // the fused input activation: [Cin / 8][scale 8 | shift 8] floats
-  const int off_bw = off_act + (p.in_scale != nullptr || !NP ? p.Cin * 8 : 0);                   // bw_y: [mean | invstd | scale | shift][32] floats of this Cout tile
+  const int off_bw = off_act + (p.in_scale != nullptr || !NP3 ? p.Cin * 8 : 0);                   // bw_y: [mean | invstd | scale | shift][32] floats of this Cout tile
   constexpr bool bw = BW;
   if (bw && tid < 128) {
     const float* src = (tid >> 5) == 0 ? p.bw_mean : (tid >> 5) == 1 ? p.bw_invstd : (tid >> 5) == 2 ? p.bw_scale : p.bw_shift;
     ((float*)(smem + off_bw))[tid] = src[cob * 32 + (tid & 31)];       // read in tile epilogues, many barriers later
   }
-  const u32x4* wsrc = (const u32x4*)p.wpk + (long long)cob * (NP ? (nchunk / 2) * ((WE + WO) / 16) : nchunk * (WSTEP / 16));
+  const u32x4* wsrc = (const u32x4*)p.wpk + (long long)cob * (NP3 ? (nchunk / 2) * ((WE + WO) / 16) : nchunk * (WSTEP / 16));
   // SPL: virtual chunk = 3 * c + part for channel chunk c; part 0 = x_lo w_hi, 1 = x_hi w_hi, 2 = x_hi w_lo.  Consecutive parts share an
   // operand -- 0 -> 1 the weights, 1 -> 2 the halo tile -- so the buffers are named by what they hold instead of by step parity (halo:
   // 0 = lo, 1 = hi; weights: 0 = w_hi, 1 = w_lo) and the loaders skip what is resident: 2 halo tiles + 2 weight chunks per channel
@@ -175,7 +181,7 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + v4_loader_threads(ND
   auto part_of = [&](int s) -> int { const int c = chunk_of(s); return c - 3 * (c / 3); };
   auto abuf_of = [&](int s) -> int {                                                               // halo buffer of step s
     if constexpr (SPL) return part_of(s) == 0 ? 0 : ABUF;
-    return NP ? (s - 3 * (s / 3)) * ABUF : (s & 1) * ABUF;
+    return NP3 ? (s - 3 * (s / 3)) * ABUF : (s & 1) * ABUF;
   };
   // first source plane of a chunk
   auto src_plane = [&](int chunk) -> long long {
@@ -235,9 +241,9 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + v4_loader_threads(ND
       const int chunk = chunk_of(s);
       // NP: the pair block of the chunk's pair is [even 24 KB | odd 24 KB | cross 6 KB]; an even step takes the first part into the
       // "even" region, an odd step the rest into the "odd" region (each region is free again after the next step of the other parity)
-      const u32x4* ws = NP ? wsrc + (long long)(chunk >> 1) * ((WE + WO) / 16) + ((chunk & 1) ? WE / 16 : 0) : wsrc + (long long)chunk * (WSTEP / 16);
-      const int nitem = NP ? ((chunk & 1) ? WO / 16 : WE / 16) : WSTEP / 16;
-      const int woff = NP ? ((chunk & 1) ? WE : 0) : buf * WSTEP;
+      const u32x4* ws = NP3 ? wsrc + (long long)(chunk >> 1) * ((WE + WO) / 16) + ((chunk & 1) ? WE / 16 : 0) : wsrc + (long long)chunk * (WSTEP / 16);
+      const int nitem = NP3 ? ((chunk & 1) ? WO / 16 : WE / 16) : WSTEP / 16;
+      const int woff = NP3 ? ((chunk & 1) ? WE : 0) : buf * WSTEP;
 #pragma unroll
       for (int it = 0; it < WIT; ++it) {
         if (it < it0 || it >= it1) continue;
@@ -442,7 +448,7 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + v4_loader_threads(ND
           load(min(s + 2, last), r2);
           commit(s + 1, r, ACT);
           lds_barrier();
-          if (!NP || s + 2 <= last) dma_weights(min(s + 2, last), 0);     // (NP: a clamped copy would land in the region being read)
+          if (!NP3 || s + 2 <= last) dma_weights(min(s + 2, last), 0);     // (NP: a clamped copy would land in the region being read)
           load(min(s + 3, last), r);
           commit(s + 2, r2, ACT);
           lds_barrier();
@@ -512,7 +518,7 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + v4_loader_threads(ND
   auto step_ptrs = [&](int s, const unsigned char*& ab, const unsigned char*& wl) {
     const int chunk = chunk_of(s);
     ab = smem + abuf_of(s) + rbase;
-    wl = smem + OFF_W + (NP ? ((chunk & 1) ? WE : 0) : (WS ? chunk : PAIR ? (chunk & 1) : SPL ? (chunk - 3 * (chunk / 3) == 2) : (s & 1)) * WSTEP) + lane * 16;
+    wl = smem + OFF_W + (NP3 ? ((chunk & 1) ? WE : 0) : (WS ? chunk : PAIR ? (chunk & 1) : SPL ? (chunk - 3 * (chunk / 3) == 2) : (s & 1)) * WSTEP) + lane * 16;
   };
   // NP, odd steps: the cross group.  Lanes q >> 1 = 0 read column 8 of the PREVIOUS step's halo buffer, q >> 1 = 1 of this step's;
   // the weights follow the four regular pairs in the odd region.
@@ -531,6 +537,20 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + v4_loader_threads(ND
   };
   auto load_group = [&](const unsigned char* ab, const unsigned char* wl, int g, auto BUF) {
     constexpr int b = decltype(BUF)::value;
+    if constexpr (NP2) {
+      // groups 0, 1: columns 0 / 1 (lanes q >> 1) of sub-chunk g; group 2, the cross group: column 2 of sub-chunk q >> 1
+      const int hoff = g == 2 ? (q >> 1) * 2 * PLANE + col_off[NCMB - 1] : g * 2 * PLANE + col_off[0];
+#pragma unroll
+      for (int xh = 0; xh < FX; ++xh)
+#pragma unroll
+        for (int r = 0; r < NR + 2; ++r) R[b][xh][r] = *(const V8*)(ab + hoff + (r * PX + xh * 16) * 16);
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+        A[b][dy][0] = *(const V8*)(wl + ((g * 3 + dy) * 2 + 0) * 1024);
+        A[b][dy][1] = *(const V8*)(wl + ((g * 3 + dy) * 2 + 1) * 1024);
+      }
+      return;
+    }
     const int h = g / NCMB, c = g - h * NCMB;
 #pragma unroll
     for (int xh = 0; xh < FX; ++xh)
@@ -690,15 +710,15 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + v4_loader_threads(ND
       using B1 = std::integral_constant<int, 1>;
       auto one_step = [&](int s, auto TSET, auto ODD) {
         // NP: an even step has the four regular column pairs, an odd step those plus the cross pair (ODD: compile-time parity)
-        constexpr int NG = NP ? (decltype(ODD)::value ? NCMB : NCMB - 1) : NGRP;
+        constexpr int NG = NP3 ? (decltype(ODD)::value ? NCMB : NCMB - 1) : NGRP;
         const unsigned char *ab, *wl, *abp = nullptr;
         step_ptrs(s, ab, wl);
-        if constexpr (NP) abp = smem + abuf_of(s - 1) + rbase;
+        if constexpr (NP3) abp = smem + abuf_of(s - 1) + rbase;
         bw_prefetch(s);
         load_group(ab, wl, 0, B0{});
         __builtin_amdgcn_sched_barrier(0);
         auto fetch = [&](int g, auto BUF) {
-          if (NP && g == NCMB - 1) load_cross(ab, abp, wl, BUF); else load_group(ab, wl, g, BUF);
+          if (NP3 && g == NCMB - 1) load_cross(ab, abp, wl, BUF); else load_group(ab, wl, g, BUF);
         };
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
@@ -712,7 +732,7 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + v4_loader_threads(ND
       using ODDS = std::integral_constant<int, 1>;
       if constexpr (PAIR) {
         for (int s = 0; s + 1 < nsteps; s += 2) { one_step(s, TS0{}, EVEN{}); one_step(s + 1, TS1{}, EVEN{}); }     // tile A, tile B of the same chunk
-      } else if constexpr (NP) {
+      } else if constexpr (NP3) {
         for (int s = 0; s + 1 < nsteps; s += 2) { one_step(s, TS0{}, EVEN{}); one_step(s + 1, TS0{}, ODDS{}); }     // chunk parity = step parity (nchunk is even)
       } else {
         for (int s = 0; s < nsteps; ++s) one_step(s, TS0{}, EVEN{});
@@ -747,8 +767,8 @@ int launch_v4(ConvV4Params p, hipStream_t stream) {
   using TL = V4Tile<ND, SMALL>;
   constexpr int NPIX = (TL::TZ + 2 * TL::PADZ) * (TL::TY + 2) * (TL::TX + 2);
   constexpr int PLANE = ((NPIX * 16 + 255) / 256) * 256;
-  constexpr int WSTEP = TL::S16 * ((TL::NCOL + 1) / 2) * 3 * 2 * 1024;
-  const int lds = NP ? 3 * 2 * PLANE + (24576 + 30720) + 2048 + (p.in_scale != nullptr ? p.Cin * 8 : 0) + 512
+  constexpr int WSTEP = (NP && ND == 2) ? 3 * 3 * 2 * 1024 : TL::S16 * ((TL::NCOL + 1) / 2) * 3 * 2 * 1024;
+  const int lds = (NP && ND == 3) ? 3 * 2 * PLANE + (24576 + 30720) + 2048 + (p.in_scale != nullptr ? p.Cin * 8 : 0) + 512
                      : 2 * 2 * TL::S16 * PLANE + (WS ? p.Cin / (16 * TL::S16) : 2) * WSTEP + 2048 + (SPL ? 0 : p.Cin * 8) + 512;      // (SPL: no fused input activation, and Cin is the 3x virtual count)
   IUNET_REQUIRE(lds <= 160 * 1024, "conv3 layout 3: %d bytes of LDS (a fused input activation fits up to 192 input channels)", lds);
   IUNET_SET_MAX_LDS((conv3_v4_kernel<T, ND, WS, SMALL, BW, PAIR, NP, SPL>), lds);
@@ -841,8 +861,15 @@ int iunet_conv3_v4_launch(int dtype, int nd, const void* x, long long x_sstride,
 #undef V4_GO
 }
 
+// pack mode (iunet_pack_conv3) of the split conv's virtual operator: 2 = the padded K16 order, 6 = the compact order -- 2-D launches
+// run the cross-pair step on it (three k-groups per 32-channel step instead of four).  IUNET_X2_NP2=0: A/B switch back to the padded order.
+int iunet_conv3_v4_x2_pack_mode(int nd) {
+  static const int np2 = getenv("IUNET_X2_NP2") ? atoi(getenv("IUNET_X2_NP2")) : 1;
+  return nd == 2 && np2 ? 6 : 2;
+}
+
 // fp16x2 split-precision forward (split16.hip): Cin real input channels; x / y are views of Cin / 8 (Cout / 8) hi planes with the lo
-// planes x_lo / y_lo planes further on; wpk = the K16 order (layout 1 / 2) of the VIRTUAL operator
+// planes x_lo / y_lo planes further on; wpk = the K16 order (iunet_conv3_v4_x2_pack_mode: padded in 3-D, compact in 2-D) of the VIRTUAL operator
 // [Cout][3 Cin][taps] = [w_hi | w_hi | w_lo]; y = split(relu?(acc * oscale + bias)).
 int iunet_conv3_v4_x2_launch(int nd, const void* x, long long x_sstride, int x_lo, void* y, long long y_sstride, int y_lo, const void* wpk,
                              const float* oscale, const float* bias, int N, int D, int H, int W, int Cin, int Cout, int epi,
@@ -857,7 +884,11 @@ int iunet_conv3_v4_x2_launch(int nd, const void* x, long long x_sstride, int x_l
   p.bz = p.by = p.bx = p.nbz = p.nby = p.nbx = 0;
   p.dbg = 0;
   p.split_nc = Cin / (nd == 3 ? 16 : 32); p.x_lo = x_lo; p.y_lo = y_lo; p.oscale = oscale;
-  if (nd == 2) return launch_v4<f16, 2, false, false, false, false, false, true>(p, stream);
+  if (nd == 2) {
+    // the cross-pair step (NP2, the compact operator of pack mode 6) for every 2-D launch: one summation order per layer whatever the grid
+    if (iunet_conv3_v4_x2_pack_mode(2) == 6) return launch_v4<f16, 2, false, false, false, false, true, true>(p, stream);
+    return launch_v4<f16, 2, false, false, false, false, false, true>(p, stream);
+  }
   // the tile size follows the grid as in the 16-bit launch (the operator order -- the padded K16 one -- does not: a layer keeps one
   // summation order whatever the grid).  The compact order's split instantiation spills its fragment arrays (640 B per lane) and is not built.
   const long long big_tiles = (long long)N * ((D + 3) / 4) * ((H + 7) / 8) * ((W + 15) / 16);

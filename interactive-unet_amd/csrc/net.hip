@@ -29,6 +29,7 @@ int iunet_pack_convT(int, const void*, void*, int, int, int, void*);
 long long iunet_pack_conv3_elems(int, int, int, int);
 long long iunet_pack_first_conv_elems(int, int, int);
 int iunet_conv3_pick_layout(int, int, int, int, int, int, int);
+int iunet_x2_pack_mode(int);
 int iunet_conv3_compact_ok(int, int, int, int, int, int, int, int, int);
 int iunet_first_conv_fwd(int, int, const void*, int, const long long*, void*, long long, const void*, const void*, void*, int, int, int,
                          int, int, int, int, void*);
@@ -142,7 +143,7 @@ int iunet_net_create(int dim, int levels, int base, int cin, int ncls, int mode,
       const int vci = mode == 2 ? 3 * op.ci : op.ci;
       if (op.first) op.pk[1] = pk_take(iunet_pack_first_conv_elems(co, vci, n->taps) * 2);
       else {
-        op.pk[1] = pk_take(iunet_pack_conv3_elems(co, vci, n->taps, 2) * 2);
+        op.pk[1] = pk_take(iunet_pack_conv3_elems(co, vci, n->taps, mode == 2 ? iunet_x2_pack_mode(dim) : 2) * 2);
         if (mode != 2) {          // the layouts a 16-bit launch may pick (interactive_unet/_native.py: PackedConv)
           if (co % 64 == 0 && n->taps == 9 && op.ci > 64) op.pk[0] = pk_take(iunet_pack_conv3_elems(co, op.ci, n->taps, 0) * 2);
           if (n->taps == 27 && op.ci > 32) op.pk[3] = pk_take(iunet_pack_conv3_elems(co, op.ci, n->taps, 6) * 2);
@@ -215,7 +216,7 @@ int iunet_net_load(iunet_net* n, const void* flat_params, void* packed, void* st
                          op.first ? op.ci : (n->dim == 3 ? 16 : 32), stream);
       if (rc) return rc;
       rc = op.first ? iunet_pack_first_conv(0, wv, nullptr, K + op.pk[1], op.co, 3 * op.ci, n->taps, stream)
-                    : iunet_pack_conv3(0, wv, nullptr, K + op.pk[1], op.co, 3 * op.ci, n->taps, 2, stream);
+                    : iunet_pack_conv3(0, wv, nullptr, K + op.pk[1], op.co, 3 * op.ci, n->taps, iunet_x2_pack_mode(n->dim), stream);
       if (rc) return rc;
     } else {
       hipLaunchKernelGGL(net_fold_bn_kernel, dim3((op.co + 255) / 256), dim3(256), 0, (hipStream_t)stream, g, be, mu, va, eps, aux,

@@ -24,6 +24,7 @@
 int iunet_conv3_v4_x2_launch(int nd, const void* x, long long x_sstride, int x_lo, void* y, long long y_sstride, int y_lo, const void* wpk,
                              const float* oscale, const float* bias, int N, int D, int H, int W, int Cin, int Cout, int epi,
                              hipStream_t stream);
+int iunet_conv3_v4_x2_pack_mode(int nd);
 
 namespace {
 
@@ -548,8 +549,12 @@ int iunet_x2_first_conv_fwd(int nd, const void* x, int in_dtype, const long long
   return IUNET_OK;
 }
 
+/* pack mode of the stage convs' virtual operator (iunet_pack_conv3 on iunet_x2_prep's output): 2 (padded K16 order) in 3-D, 6 (compact
+ * order: the third filter column of the two 16-channel halves of a step shares one k-group -- 9 taps in 9 k-slots) in 2-D */
+int iunet_x2_pack_mode(int nd) { return iunet_conv3_v4_x2_pack_mode(nd); }
+
 /* stage conv 3^d of the split-precision forward: x / y = Cin / 8 (Cout / 8) hi planes, the lo planes x_lo / y_lo planes further on;
- * wpk = iunet_pack_conv3 (K16 order, mode 2) of the virtual operator [Cout][3 Cin][taps]; epi as iunet_conv3_fwd */
+ * wpk = iunet_pack_conv3 (mode iunet_x2_pack_mode(nd)) of the virtual operator [Cout][3 Cin][taps]; epi as iunet_conv3_fwd */
 int iunet_x2_conv3_fwd(int nd, const void* x, long long x_sstride, int x_lo, void* y, long long y_sstride, int y_lo, const void* wpk,
                        const void* oscale, const void* bias, int N, int D, int H, int W, int Cin, int Cout, int epi, void* stream) {
   IUNET_REQUIRE(x && y && wpk && oscale, "x2_conv3: null pointer");

@@ -86,14 +86,15 @@ class EngineX2:
                 first = prefix == 'enc0' and j == 1
                 w = self._source(params, f'{name}.weight')
                 bn = [self._source(params, f'{prefix}.bn{j}.{k}') for k in ('weight', 'bias', 'running_mean', 'running_var')]
-                npk = lib.iunet_pack_first_conv_elems(b, 3 * a, self.taps) if first else nv.pack_conv3_elems(b, 3 * a, self.taps, 2)
+                pmode = lib.iunet_x2_pack_mode(self.dim)      # 2: padded K16 order (3-D); 6: compact order (2-D: the cross-pair step)
+                npk = lib.iunet_pack_first_conv_elems(b, 3 * a, self.taps) if first else nv.pack_conv3_elems(b, 3 * a, self.taps, pmode)
                 wv, dst, osc, bias = bufs(name, b * 3 * a * self.taps, npk, b)
                 nv.call('iunet_x2_prep', nv.ptr(w), nv.ptr(wv), nv.ptr(osc), nv.ptr(bias), nv.ptr(bn[0]), nv.ptr(bn[1]),
                         nv.ptr(bn[2]), nv.ptr(bn[3]), None, BN_EPS, A, A, b, a, self.taps, 0, a if first else (16 if self.dim == 3 else 32), s)
                 if first:
                     nv.call('iunet_pack_first_conv', 0, nv.ptr(wv), None, nv.ptr(dst), b, 3 * a, self.taps, s)
                 else:
-                    nv.call('iunet_pack_conv3', 0, nv.ptr(wv), None, nv.ptr(dst), b, 3 * a, self.taps, 2, s)
+                    nv.call('iunet_pack_conv3', 0, nv.ptr(wv), None, nv.ptr(dst), b, 3 * a, self.taps, pmode, s)
                 P[name] = (dst, osc, bias)
         for l in range(self.levels - 2, -1, -1):
             name = f'dec{l}.up'

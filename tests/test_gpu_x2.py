@@ -53,8 +53,9 @@ def _prep_conv(nv, w, bn=None, bias=None, transposed=False):
         dst = torch.empty(nv.lib().iunet_pack_first_conv_elems(co, 3 * ci, taps), dtype=torch.float16, device=dev)
         nv.call('iunet_pack_first_conv', 0, nv.ptr(wv), None, nv.ptr(dst), co, 3 * ci, taps, nv.stream())
     else:
-        dst = torch.empty(nv.pack_conv3_elems(co, 3 * ci, taps, 2), dtype=torch.float16, device=dev)
-        nv.call('iunet_pack_conv3', 0, nv.ptr(wv), None, nv.ptr(dst), co, 3 * ci, taps, 2, nv.stream())
+        pm = nv.lib().iunet_x2_pack_mode(3 if taps == 27 else 2)       # padded K16 order in 3-D, compact (cross-pair step) in 2-D
+        dst = torch.empty(nv.pack_conv3_elems(co, 3 * ci, taps, pm), dtype=torch.float16, device=dev)
+        nv.call('iunet_pack_conv3', 0, nv.ptr(wv), None, nv.ptr(dst), co, 3 * ci, taps, pm, nv.stream())
     torch.cuda.synchronize()
     return dst, osc, b
 
@@ -70,6 +71,8 @@ def _conv_ref(x, w, dim, bias=None, relu=False):
     (3, (4, 8, 16), 96, 64, 1),         # small-tile variant, two Cout tiles
     (2, (32, 64), 32, 32, 2),
     (2, (24, 40), 64, 64, 1),
+    (2, (16, 32), 128, 32, 1),          # 12 virtual steps on the cross-pair order
+    (2, (40, 72), 96, 64, 3),           # ragged tiles, several tiles per workgroup
 ])
 def test_conv3_x2(dim, shape, ci, co, N):
     nv, e = _nv(), _engine(dim)

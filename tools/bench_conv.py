@@ -88,8 +88,9 @@ def main():
             osc, b2 = torch.empty(cout, device='cuda'), torch.empty(cout, device='cuda')
             nv.call('iunet_x2_prep', nv.ptr(w), nv.ptr(wv), nv.ptr(osc), nv.ptr(b2), None, None, None, None, nv.ptr(bias), 1e-5, 64.0, 64.0,
                     cout, cin, taps, 0, 16 if nd == 3 else 32, nv.stream())
-            wx = torch.empty(nv.pack_conv3_elems(cout, 3 * cin, taps, 2), dtype=torch.float16, device='cuda')
-            nv.call('iunet_pack_conv3', 0, nv.ptr(wv), None, nv.ptr(wx), cout, 3 * cin, taps, 2, nv.stream())
+            xpm = nv.lib().iunet_x2_pack_mode(nd)        # padded K16 order in 3-D, compact order (cross-pair step) in 2-D
+            wx = torch.empty(nv.pack_conv3_elems(cout, 3 * cin, taps, xpm), dtype=torch.float16, device='cuda')
+            nv.call('iunet_pack_conv3', 0, nv.ptr(wv), None, nv.ptr(wx), cout, 3 * cin, taps, xpm, nv.stream())
             xs = (torch.randn(a.n * 2 * cin * vox, device='cuda') * 8).to(torch.float16)      # hi planes | lo planes (random words: timing only)
             ys = torch.empty(a.n * 2 * cout * vox, dtype=torch.float16, device='cuda')
             k = lambda: nv.call('iunet_x2_conv3_fwd', nd, nv.ptr(xs), 2 * cin * vox, cin // 8, nv.ptr(ys), 2 * cout * vox, cout // 8, nv.ptr(wx),
