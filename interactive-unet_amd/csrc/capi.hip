@@ -117,10 +117,15 @@ int iunet_conv3_pick_layout(int nd, int N, int D, int H, int W, int Cin, int Cou
   return iunet_conv3_pick(nd, N, D, H, W, Cin, Cout);
 }
 
-// can this launch run on layout 3 (compact operator, padding-free step: conv3_v4.hip NP)?  3-D, streamed weights (Cin > 32), no fused
-// BatchNorm-backward sums, a fused input activation up to 192 input channels (LDS)
+// can this launch run on layout 3 (compact operator, padding-free step: conv3_v4.hip NP)?  No fused BatchNorm-backward sums.  3-D:
+// streamed weights (Cin > 32), a fused input activation up to 192 input channels (LDS).  2-D (the cross-pair step): every channel
+// count, a fused input activation on the resident-weights variant only (Cin <= 64: the layers the training forward fuses).
+// IUNET_NO_COMPACT2D=1: A/B switch back to layouts 0 / 1 / 2 in 2-D.
 int iunet_conv3_compact_ok(int nd, int N, int D, int H, int W, int Cin, int Cout, int act, int bw) {
-  if (nd != 3 || N < 1 || D < 1 || H < 1 || W < 1 || Cin <= 32 || Cout < 32 || Cin % 32 || Cout % 32 || bw) return 0;
+  static const bool off2d = getenv("IUNET_NO_COMPACT2D") != nullptr;
+  if ((nd != 2 && nd != 3) || N < 1 || D < 1 || H < 1 || W < 1 || Cin < 32 || Cout < 32 || Cin % 32 || Cout % 32 || bw) return 0;
+  if (nd == 2) return !off2d && D == 1 && !(act && Cin > 64);
+  if (Cin <= 32) return 0;
   return !(act && Cin > 192);        // independent of the grid: a layer keeps one summation order whatever the launch size
 }
 

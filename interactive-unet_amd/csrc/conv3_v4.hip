@@ -57,7 +57,7 @@ template <bool SMALL> struct V4Tile<2, SMALL> { static constexpr int TZ = 1, TY 
 #ifndef V4_BW_LT
 #define V4_BW_LT 256            // (A/B: -DV4_BW_LT=512)
 #endif
-constexpr int v4_loader_threads(int nd, bool ws, bool pair, bool spl, bool bwv = false) { return (ws || pair || (spl && nd == 2)) ? 256 : bwv ? V4_BW_LT : 512; }
+constexpr int v4_loader_threads(int nd, bool ws, bool pair, bool spl, bool bwv = false, bool np = false) { return (ws || pair || ((spl || np) && nd == 2)) ? 256 : bwv ? V4_BW_LT : 512; }
 
 struct ConvV4Params {
   const void* x;  long long x_sstride;
@@ -99,7 +99,7 @@ struct ConvV4Params {
 // previous chunk (read from the previous step's halo buffer, which a ring of THREE buffers keeps alive) and column 8 of its own.
 // 27 taps in 27 K-slots: -10 % MFMAs, fragment reads and weight bytes.  LDS: 3 x 34 816 + 24 576 + 30 720 + scratch = 162 304 B.
 template <typename T, int ND, bool WS, bool SMALL, bool BW = false, bool PAIR = false, bool NP = false, bool SPL = false>
-__global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + v4_loader_threads(ND, WS, PAIR, SPL, BW)), 1) void conv3_v4_kernel(ConvV4Params p) {
+__global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + v4_loader_threads(ND, WS, PAIR, SPL, BW, NP)), 1) void conv3_v4_kernel(ConvV4Params p) {
   static_assert(!SPL || (!WS && !BW && !PAIR && !(NP && ND == 3)), "split precision: streamed weights (Cin' = 3 Cin >= 96), forward only, padded operator in 3-D");
   static_assert(!PAIR || (!WS && !BW && ND == 3), "tile pairs: the streamed-weight 3-D forward / data-gradient variant only");
   static_assert(!NP || (!BW && !PAIR && (ND == 2 || !WS)), "padding-free step: the streamed-weight 3-D variants and the 2-D ones, without fused BatchNorm-backward sums (so far)");
@@ -112,7 +112,7 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + v4_loader_threads(ND
   using TL = V4Tile<ND, SMALL>;
   // consumer waves; loader threads: 4 loader waves when only activations stream, 8 when the weights stream too (twice the
   // bytes per step: the extra waves double the loads in flight, -6...-11 % on those layers)
-  constexpr int NCW = TL::NCW, NLT = v4_loader_threads(ND, WS, PAIR, SPL, BW);
+  constexpr int NCW = TL::NCW, NLT = v4_loader_threads(ND, WS, PAIR, SPL, BW, NP);
   constexpr int TZ = TL::TZ, TY = TL::TY, TX = TL::TX, PADZ = TL::PADZ, NCOL = TL::NCOL, S16 = TL::S16;
   constexpr int FX = TX / 16, NI = TZ * TY * FX / NCW, NR = NI / FX;    // x halves; fragments per consumer wave; tile rows per wave
   constexpr int PZ = TZ + 2 * PADZ, PY = TY + 2, PX = TX + 2;
@@ -360,7 +360,7 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + v4_loader_threads(ND
 #endif
       // 3-D only: the 2-D level-0 layers are HBM-bound and need the register path's loads in flight across the barrier (measured:
       // C2's dec0.conv1 at 45 % of the HBM peak by LDS-DMA against 49 % through registers)
-      if ((ND == 3 || SPL) && !decltype(ACT)::value && !(p.dbg & 64)) {      // (IUNET_V4_DBG=64: the register path for every launch -- A/B switch)
+      if ((ND == 3 || SPL || (NP2 && !WS)) && !decltype(ACT)::value && !(p.dbg & 64)) {      // (IUNET_V4_DBG=64: the register path for every launch -- A/B switch)
         // ---- everything by LDS-DMA: in iteration s (consumers on step s) the buffers of step s + 1 are filled ----
         if (!WS) dma_weights(0, 0);
         dma_acts(0);
@@ -666,7 +666,9 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + v4_loader_threads(ND
     __builtin_amdgcn_sched_barrier(0);                           // nothing moves across the group boundary
   };
   // The groups of one step of the cross-step pipeline; PAR = fragment set of its first group.
-  constexpr bool XSTEP = WS && !BW;       // cross-step pipeline: the variants with resident weights (168-register cap); BW keeps its yp fragments instead
+  // cross-step pipeline: the variants with resident weights (168-register cap); BW keeps its yp fragments instead; the 2-D cross-pair
+  // step has an odd group count (both parities of the pipeline instantiated: 76 B of scratch per lane) and restarts every step too
+  constexpr bool XSTEP = WS && !BW && !NP2;
   using TS0 = std::integral_constant<int, 0>;
   using TS1 = std::integral_constant<int, PAIR ? 1 : 0>;
   auto step_groups = [&](int s, auto PAR) {
@@ -793,7 +795,7 @@ int launch_v4(ConvV4Params p, hipStream_t stream) {
     if (gx < rows)
       IUNET_CHECK_HIP(hipMemsetAsync(p.stats + (long long)gx * p.Cout * 2, 0, (size_t)(rows - gx) * p.Cout * 2 * sizeof(float), stream));
   }
-  hipLaunchKernelGGL((conv3_v4_kernel<T, ND, WS, SMALL, BW, PAIR, NP, SPL>), dim3(gx, ncob), dim3(TL::NCW * 64 + v4_loader_threads(ND, WS, PAIR, SPL, BW)), lds, stream, p);
+  hipLaunchKernelGGL((conv3_v4_kernel<T, ND, WS, SMALL, BW, PAIR, NP, SPL>), dim3(gx, ncob), dim3(TL::NCW * 64 + v4_loader_threads(ND, WS, PAIR, SPL, BW, NP)), lds, stream, p);
   IUNET_CHECK_HIP(hipGetLastError());
   return IUNET_OK;
 }
@@ -847,7 +849,11 @@ int iunet_conv3_v4_launch(int dtype, int nd, const void* x, long long x_sstride,
   if (compact) {      // layout 3: the compact operator, padding-free step (streamed weights, big tiles, no fused BatchNorm-backward sums so far)
     // (every grid size: a layer must not change its summation order with the number of blocks in a launch -- the sharded prediction
     //  is byte-identical across world sizes)
-    IUNET_REQUIRE(nd == 3 && !ws && bw_y == nullptr, "conv3 layout 3: 3-D, Cin > 32, no fused BatchNorm-backward sums");
+    IUNET_REQUIRE(bw_y == nullptr && (nd == 2 || !ws), "conv3 layout 3: no fused BatchNorm-backward sums; 3-D: Cin > 32");
+    if (nd == 2) {    // the cross-pair step: resident weights up to 64 input channels, streamed beyond
+      if (ws) return dtype == 0 ? launch_v4<f16, 2, true, false, false, false, true>(p, stream) : launch_v4<bf16, 2, true, false, false, false, true>(p, stream);
+      return dtype == 0 ? launch_v4<f16, 2, false, false, false, false, true>(p, stream) : launch_v4<bf16, 2, false, false, false, false, true>(p, stream);
+    }
     if (small) return dtype == 0 ? launch_v4<f16, 3, false, true, false, false, true>(p, stream) : launch_v4<bf16, 3, false, true, false, false, true>(p, stream);
     return dtype == 0 ? launch_v4<f16, 3, false, false, false, false, true>(p, stream) : launch_v4<bf16, 3, false, false, false, false, true>(p, stream);
   }

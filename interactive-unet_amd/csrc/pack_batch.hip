@@ -308,12 +308,14 @@ __device__ __forceinline__ void pack_k16_block(const PackDesc& d, int blk, float
   __syncthreads();                                     // the tile is reused by this workgroup's next block
 }
 
-// kind 6: the compact K16 order (per Cout tile and chunk PAIR: [even chunk 24 KB | odd chunk 24 KB | cross pair 6 KB]).  One
-// workgroup per (Cout tile, 16-channel chunk) as above: the chunk's four regular column pairs, and its half of the cross fragments
-// (the lanes q >> 1 = chunk parity: column 8 of this chunk).
+// kind 6: the compact K16 order (per Cout tile and chunk PAIR: [even chunk 24 KB | odd chunk 24 KB | cross pair 6 KB]; 3^2 filters:
+// [6 KB | 6 KB | 6 KB] -- one regular column pair per chunk and the third column in the cross pair).  One
+// workgroup per (Cout tile, 16-channel chunk) as above: the chunk's regular column pairs, and its half of the cross fragments
+// (the lanes q >> 1 = chunk parity: the last column of this chunk).
 __device__ __forceinline__ void pack_k16c_block(const PackDesc& d, int blk, float* tile) {
   const int CinP = d.dgrad ? d.Cout : d.Cin;
-  constexpr int taps = 27;
+  const int taps = d.taps, ncol = taps / 3;
+  const int NREG = (ncol / 2) * 384;                   // granules of a chunk's regular pairs: 4 x (3 dy x 2 m x 64 lanes) / 1 x
   const int nchunk = CinP >> 4, chunk = blk % nchunk, cob = blk / nchunk;
   const int nrows = d.dgrad ? 16 : 32, rowlen = (d.dgrad ? 32 : 16) * taps, rl4 = rowlen >> 2;
   auto row_base = [&](int row) -> long long {
@@ -345,14 +347,14 @@ __device__ __forceinline__ void pack_k16c_block(const PackDesc& d, int blk, floa
   }
   __syncthreads();
   const int par = chunk & 1;
-  const long long pair_base = ((long long)cob * (nchunk >> 1) + (chunk >> 1)) * 3456;      // granules (16 B)
-  for (int t = threadIdx.x; t < 1536 + 192; t += 256) {
+  const long long pair_base = ((long long)cob * (nchunk >> 1) + (chunk >> 1)) * (2 * NREG + 384);      // granules (16 B)
+  for (int t = threadIdx.x; t < NREG + 192; t += 256) {
     int frag, lane, col;
     long long og;
-    if (t < 1536) { frag = t >> 6; lane = t & 63; col = 2 * (frag / 6) + (lane >> 5); frag %= 6; og = pair_base + par * 1536 + t; }
+    if (t < NREG) { frag = t >> 6; lane = t & 63; col = 2 * (frag / 6) + (lane >> 5); frag %= 6; og = pair_base + par * NREG + t; }
     else {
-      const int u = t - 1536, l32 = u & 31;
-      frag = u >> 5; lane = (par * 2 + (l32 >> 4)) * 16 + (l32 & 15); col = 8; og = pair_base + 3072 + frag * 64 + lane;
+      const int u = t - NREG, l32 = u & 31;
+      frag = u >> 5; lane = (par * 2 + (l32 >> 4)) * 16 + (l32 & 15); col = ncol - 1; og = pair_base + 2 * NREG + frag * 64 + lane;
     }
     const int dy = frag >> 1, m = frag & 1;
     const int row = lane & 15, qq = lane >> 4;

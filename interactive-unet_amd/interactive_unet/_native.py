@@ -266,11 +266,12 @@ class PackedConv:
         # layout 0 is only ever picked for 2-D launches with more than 64 input channels (iunet_conv3_pick_layout: every 3-D conv
         # and the narrow 2-D ones run on the K16 operator): packing it for the others was half of the per-step pack work
         in_ch = cout if dgrad else cin
-        if self.out_ch % 64 == 0 and taps == 9 and in_ch > 64:
+        # layout 3: the compact K16 order (the padding-free step of conv3_v4.hip: 3^3 filters with streamed weights, every 3^2 filter)
+        # beside the padded one, which the launches that do not qualify keep using (fused BatchNorm-backward sums)
+        compact2d = taps == 9 and not os.environ.get('IUNET_NO_COMPACT2D')
+        if self.out_ch % 64 == 0 and taps == 9 and in_ch > 64 and not compact2d:
             self.buf[0] = torch.empty(pack_conv3_elems(cout, cin, taps, self.dg), dtype=dtype, device=device)
-        # layout 3: the compact K16 order (3^3 filters with streamed weights: the padding-free step of conv3_v4.hip) beside the padded one,
-        # which the launches that do not qualify keep using (small grids, fused BatchNorm-backward sums)
-        if taps == 27 and in_ch > 32 and not os.environ.get('IUNET_NO_COMPACT'):
+        if ((taps == 27 and in_ch > 32) or compact2d) and not os.environ.get('IUNET_NO_COMPACT'):
             self.buf[3] = torch.empty(pack_conv3_elems(cout, cin, taps, 6 | self.dg), dtype=dtype, device=device)
 
     def pack(self, w, scale=None):

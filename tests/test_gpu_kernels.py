@@ -135,6 +135,45 @@ def test_conv3_compact_operator_exact_integers(nv, shape, cin, cout):
         assert torch.equal(got[ok], want[ok])
 
 
+@pytest.mark.parametrize('shape,cin,cout', [((16, 32), 32, 32), ((48, 40), 64, 64), ((20, 70), 128, 64), ((33, 65), 256, 32),
+                                            ((70, 130), 64, 128)])
+def test_conv2_cross_pair_exact_integers(nv, shape, cin, cout):
+    """Layout 3 in 2-D: the compact order of the 3^2 filter and the cross-pair step (the third filter column of a step's two 16-channel
+    halves in one k-group; resident weights up to 64 input channels, streamed by LDS-DMA beyond): forward with statistics, bias +
+    ReLU epilogue and the data gradient, bit for bit; the batched packer (descriptor kind 6) writes the per-layer kernel's bytes."""
+    g = torch.Generator().manual_seed(23)
+    N = 3
+    assert nv.lib().iunet_conv3_compact_ok(2, N, 1, *shape, cin, cout, 0, 0) == 1
+    x = torch.randint(-2, 3, (N, cin) + shape, generator=g).float()
+    w = torch.randint(-1, 2, (cout, cin, 3, 3), generator=g).float()
+    bias = torch.randint(-3, 4, (cout,), generator=g).float()
+    ref = F.conv2d(x, w, padding=1)
+    for dt in (torch.float16, torch.bfloat16):
+        got, st = run_conv3(nv, x, w, dt, 2, layout=3, stats=True)
+        ok = ref.abs() <= (2048 if dt == torch.float16 else 256)
+        assert torch.equal(got[ok], ref[ok]), (dt, (got - ref)[ok].abs().max())
+        assert torch.equal(st[:, 0], ref.sum((0, 2, 3)))
+    refb = F.relu(ref + bias.view(1, -1, 1, 1))
+    got = run_conv3(nv, x, w, torch.float16, 2, layout=3, bias=bias, epi=2)
+    ok = refb.abs() <= 2048
+    assert torch.equal(got[ok], refb[ok])
+    dy = torch.randint(-2, 3, (N, cout) + shape, generator=g).float()
+    want = F.conv_transpose2d(dy, w, padding=1)
+    got = run_conv3(nv, dy, w, torch.float16, 2, layout=3, mode=1)
+    ok = want.abs() <= 2048
+    assert torch.equal(got[ok], want[ok])
+    # descriptor kind 6 of iunet_pack_batch == iunet_pack_conv3 mode 6 (forward and data-gradient operators)
+    wd = (torch.randn(cout, cin, 3, 3, generator=g) * 0.1).cuda()
+    for dg in (0, 1):
+        n = nv.pack_conv3_elems(cout, cin, 9, 6 | dg)
+        a = torch.zeros(n, dtype=torch.float16, device='cuda')
+        b = torch.ones(n, dtype=torch.float16, device='cuda')
+        nv.call('iunet_pack_conv3', 0, nv.ptr(wd), None, nv.ptr(a), cout, cin, 9, 6 | dg, nv.stream())
+        nv.PackTable([nv.make_desc(wd, b, cout, cin, 9, 6, torch.float16, dg)], 'cuda', sources=[wd]).run()
+        torch.cuda.synchronize()
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16)), dg
+
+
 @pytest.mark.parametrize('nd', [2, 3])
 def test_conv3_random_bias_relu_stats(nv, nd):
     g = torch.Generator().manual_seed(2)

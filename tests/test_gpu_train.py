@@ -398,8 +398,9 @@ def test_full_train_step_vs_autograd(dim, shape, dtype):
     assert np.isfinite(ev['Loss'])
 
 
-@pytest.mark.parametrize('nd,cin,big', [(3, 32, False), (3, 64, False), (2, 32, False), (2, 64, False), (3, 64, True)])
-def test_conv3_fwd_and_wgrad_with_fused_input_activation(nv, nd, cin, big):
+@pytest.mark.parametrize('nd,cin,big,lay', [(3, 32, False, 2), (3, 64, False, 2), (2, 32, False, 2), (2, 64, False, 2), (3, 64, True, 2),
+                                            (2, 32, False, 3), (2, 64, False, 3)])       # layout 3 in 2-D: the cross-pair step
+def test_conv3_fwd_and_wgrad_with_fused_input_activation(nv, nd, cin, big, lay):
     """iunet_conv3_fwd_act / iunet_conv3_wgrad_act (input = relu(scale * y + shift) applied while staging) equal
     the unfused sequence bn_relu_fwd -> conv3_fwd / conv3_wgrad bit for bit (same rounding of the activation).
     big: a grid walked in tile pairs -- the fused launch stages its halo tiles through registers, the plain one by LDS-DMA."""
@@ -419,19 +420,21 @@ def test_conv3_fwd_and_wgrad_with_fused_input_activation(nv, nd, cin, big):
     s = nv.stream()
     z = torch.empty_like(yb)
     nv.call('iunet_bn_relu_fwd', dt, nv.ptr(yb), cin * vox, nv.ptr(z), cin * vox, nv.ptr(scale), nv.ptr(shift), cin, N, vox, s)
-    wpk = torch.empty(nv.pack_conv3_elems(cout, cin, taps, 2), dtype=T, device='cuda')
-    nv.call('iunet_pack_conv3', dt, nv.ptr(w), None, nv.ptr(wpk), cout, cin, taps, 2, s)
-    nt = nv.lib().iunet_conv3_stats_parts(nd, N, D, H, W, cout, 2)
+    pm = 6 if lay == 3 else 2
+    assert lay == 2 or nv.lib().iunet_conv3_compact_ok(nd, N, D, H, W, cin, cout, 1, 0) == 1
+    wpk = torch.empty(nv.pack_conv3_elems(cout, cin, taps, pm), dtype=T, device='cuda')
+    nv.call('iunet_pack_conv3', dt, nv.ptr(w), None, nv.ptr(wpk), cout, cin, taps, pm, s)
+    nt = nv.lib().iunet_conv3_stats_parts(nd, N, D, H, W, cout, lay)
     outs, stats = [], []
     for fused in (False, True):
         out = torch.full((N * cout * vox,), float('nan'), dtype=T, device='cuda')
         st = torch.zeros(nt * cout * 2, device='cuda')
         if fused:
             nv.call('iunet_conv3_fwd_act', dt, nd, nv.ptr(yb), cin * vox, nv.ptr(out), cout * vox, nv.ptr(wpk), None,
-                    nv.ptr(st), nv.ptr(scale), nv.ptr(shift), N, D, H, W, cin, cout, 0, 2, s)
+                    nv.ptr(st), nv.ptr(scale), nv.ptr(shift), N, D, H, W, cin, cout, 0, lay, s)
         else:
             nv.call('iunet_conv3_fwd', dt, nd, nv.ptr(z), cin * vox, nv.ptr(out), cout * vox, nv.ptr(wpk), None,
-                    nv.ptr(st), N, D, H, W, cin, cout, 0, 2, s)
+                    nv.ptr(st), N, D, H, W, cin, cout, 0, lay, s)
         outs.append(out); stats.append(st)
     torch.cuda.synchronize()
     assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
