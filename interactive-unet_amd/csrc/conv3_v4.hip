@@ -57,7 +57,10 @@ template <bool SMALL> struct V4Tile<2, SMALL> { static constexpr int TZ = 1, TY 
 #ifndef V4_BW_LT
 #define V4_BW_LT 256            // (A/B: -DV4_BW_LT=512)
 #endif
-constexpr int v4_loader_threads(int nd, bool ws, bool pair, bool spl, bool bwv = false, bool np = false) { return (ws || pair || ((spl || np) && nd == 2)) ? 256 : bwv ? V4_BW_LT : 512; }
+#ifndef V4_X2_LT3D
+#define V4_X2_LT3D 512          // loader threads of the 3-D split conv (A/B: -DV4_X2_LT3D=256)
+#endif
+constexpr int v4_loader_threads(int nd, bool ws, bool pair, bool spl, bool bwv = false, bool np = false) { return (ws || pair || ((spl || np) && nd == 2)) ? 256 : bwv ? V4_BW_LT : (spl && nd == 3) ? V4_X2_LT3D : 512; }
 
 struct ConvV4Params {
   const void* x;  long long x_sstride;
@@ -851,6 +854,10 @@ int iunet_conv3_v4_launch(int dtype, int nd, const void* x, long long x_sstride,
     //  is byte-identical across world sizes)
     IUNET_REQUIRE(bw_y == nullptr && (nd == 2 || !ws), "conv3 layout 3: no fused BatchNorm-backward sums; 3-D: Cin > 32");
     if (nd == 2) {    // the cross-pair step: resident weights up to 64 input channels, streamed beyond
+      // (the two variants read the same operator and add in the same order: which one runs is a speed choice.  IUNET_V4_WS2D = the
+      //  largest Cin that keeps its weights resident when the input needs no arithmetic -- A/B switch)
+      static const int ws2d = getenv("IUNET_V4_WS2D") ? atoi(getenv("IUNET_V4_WS2D")) : 64;
+      const bool ws = in_scale != nullptr ? Cin <= 64 : Cin <= ws2d;
       if (ws) return dtype == 0 ? launch_v4<f16, 2, true, false, false, false, true>(p, stream) : launch_v4<bf16, 2, true, false, false, false, true>(p, stream);
       return dtype == 0 ? launch_v4<f16, 2, false, false, false, false, true>(p, stream) : launch_v4<bf16, 2, false, false, false, false, true>(p, stream);
     }

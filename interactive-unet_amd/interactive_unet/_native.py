@@ -291,9 +291,12 @@ class PackedConv:
         """(layout, buffer) for a launch on this grid.  act: the launch applies a fused input activation (iunet_conv3_fwd_act);
         bw: it accumulates the BatchNorm-backward sums (iunet_conv3_dgrad_bnstats)."""
         in_ch = self.cout if self.dg else self.cin
-        if 3 in self.buf and lib().iunet_conv3_compact_ok(nd, N, D, H, W, in_ch, self.out_ch, int(bool(act)), int(bool(bw))):
-            return 3, self.buf[3]
         lay = lib().iunet_conv3_pick_layout(nd, N, D, H, W, in_ch, self.out_ch)
+        # the fused sums exist in layout 2 only: a launch that asks for them elsewhere (2-D, more than 64 input channels) runs plain,
+        # so it may as well run on the compact operator
+        bw = bool(bw) and lay == 2
+        if 3 in self.buf and lib().iunet_conv3_compact_ok(nd, N, D, H, W, in_ch, self.out_ch, int(bool(act)), int(bw)):
+            return 3, self.buf[3]
         if lay == 0 and 0 not in self.buf:
             lay = 1
         return lay, self.buf[1 if lay == 2 else lay]      # layout 2 runs on the K16 operator of layout 1

@@ -37,6 +37,11 @@ def test_lightning_shaped_loop_matches_the_fused_step():
     opt = a.configure_optimizers()
     assert isinstance(opt, torch.optim.AdamW) and opt.defaults['lr'] == a.lr and opt.defaults['weight_decay'] == 1e-2
     te_b = TrainEngine(b, lr=b.lr, loss_kind='mcc_ce')
+    def params_agree():              # the two AdamW implementations: an ulp apart at most
+        for n in a.train_engine().names:
+            pa, pb = a.tensor(n).detach(), b.tensor(n).detach()
+            assert (pa - pb).abs().max().item() <= 2e-6 * max(1.0, pb.abs().max().item()), n
+
     for step in range(2):
         batch = _batch(step)
         opt.zero_grad()
@@ -46,17 +51,18 @@ def test_lightning_shaped_loop_matches_the_fused_step():
         gflat = torch.cat([a.tensor(n).grad.reshape(-1) for n in a.train_engine().names])
         opt.step()
         row = te_b.train_step(*batch)
-        assert abs(loss.item() - row['Loss']) <= 1e-6 * max(1.0, abs(row['Loss'])), (loss.item(), row)
-        gb = te_b.grad / te_b.loss_scale
-        if step == 0:
-            assert torch.equal(gflat, gb), 'same kernels on the same weights: the same gradient bits'
-        else:                                   # the two AdamW implementations left the weights an ulp apart
-            assert (gflat - gb).norm() <= 1e-2 * gb.norm()
+        # the same weights through the same kernels (step 1: after a's re-pack behind torch's optimiser): the same bits
+        assert abs(loss.item() - row['Loss']) <= 1e-6 * max(1.0, abs(row['Loss'])), (step, loss.item(), row)
+        assert torch.equal(gflat, te_b.grad / te_b.loss_scale), (step, 'same kernels on the same weights: the same gradient bits')
         for k in ('Dice', 'IoU', 'MCC'):
-            assert abs(float(a.logged_metrics[f'train/{k}']) - row[k]) < 1e-6
-    for n in a.train_engine().names:
-        pa, pb = a.tensor(n).detach(), b.tensor(n).detach()
-        assert (pa - pb).abs().max().item() <= 2e-6 * max(1.0, pb.abs().max().item()), n
+            assert abs(float(a.logged_metrics[f'train/{k}']) - row[k]) < 1e-6, (step, k)
+        params_agree()
+        if step == 0:
+            # Weights an ulp apart round to different bf16 operands in a handful of places, and a 16-bit network with batch statistics
+            # over 48 values at its bottom level turns one such flip into percent-level gradient differences (measured: 12 %): step 1
+            # compares the KERNELS, so it starts from the same weights again (the optimiser moments stay each engine's own).
+            te_b.flat.copy_(a.train_engine().flat)
+            te_b.repack()
     # validation_step: eval-mode BatchNorm, same loss as the engine's eval_step, no gradient
     vb = _batch(7)
     v = a.validation_step(vb)
