@@ -379,13 +379,20 @@ def predict_2p5d_leg(dev, with_cpu):
         for _ in range(2):
             run()
         torch.cuda.synchronize()
-        reps, t0 = 10, time.time()
-        for _ in range(reps):
-            run()
-        torch.cuda.synchronize()
-        ms = (time.time() - t0) / reps * 1e3
-        res[name] = {'ms_per_block': round(ms, 3), 'voxels_per_s': round(S ** 3 / ms * 1e3, 1),
-                     'tflops(algorithmic)': round(3 * fpv2 * S ** 3 / ms / 1e9, 1)}
+        # three groups of 10 blocks, every group reported, the fastest one quoted: a block is ~90 dependent launches of 10-100 us, and
+        # a host thread that loses its core for a scheduler period (the box's CPU share is spent in bursts by the phases around this
+        # leg: 16-thread torch CPU operators, numpy generators) stalls one group by tens of milliseconds -- seen as 7-10 ms per block
+        # in one group where the others read 2.7
+        reps, groups = 10, []
+        for _ in range(3):
+            t0 = time.time()
+            for _ in range(reps):
+                run()
+            torch.cuda.synchronize()
+            groups.append((time.time() - t0) / reps * 1e3)
+        ms = min(groups)
+        res[name] = {'ms_per_block': round(ms, 3), 'ms_per_block_groups_of_10': [round(g, 3) for g in groups],
+                     'voxels_per_s': round(S ** 3 / ms * 1e3, 1), 'tflops(algorithmic)': round(3 * fpv2 * S ** 3 / ms / 1e9, 1)}
         probs[name] = out.clone()
         params = {k: t.detach().float().cpu() for k, t in m.named_tensors().items()}
         del m

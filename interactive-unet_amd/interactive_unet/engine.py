@@ -74,7 +74,27 @@ class Engine:
         self._ws_cache = {}
         self._f8_ws = None
         self.probe = None          # {'name': layer, 'events': []}: timing hook of one layer's launches (bench.py roofline)
+        self.use_graph = True      # False: every forward sequenced from Python (tests compare the two)
+        self._g, self._gparams, self._g_dirty, self._g_fwd = None, None, False, 0      # the C++-sequenced forward (_graph)
         nv.lib()   # fail loudly now if the HIP library is missing
+
+    def _graph(self):
+        """The C++-sequenced forward (net_graph.NetGraph) on this engine's current parameters, or None where the handle level does not
+        apply (GroupNorm, fp8 operators, IUNET_PY_GRAPH=1).  The handle packs its own copy of the operators (one copy of the parameters
+        + ~40 launches), so it is loaded at the SECOND forward on the same parameters: a training loop that predicts once per optimiser
+        step, or a validation pass that only asks for features, never pays for it; a slice / block / volume prediction does once."""
+        from . import net_graph
+        self._g_fwd += 1
+        if self._g_fwd < 2:
+            return None
+        if not net_graph.ENABLED or not self.use_graph or self.norm != 'batch' or self.weight_dtype or not (2 <= self.levels <= 6) or self._gparams is None:
+            return None
+        if self._g is None:
+            self._g = net_graph.NetGraph(self.dim, self.levels, self.base, self.cin, self.ncls, self.dt, self.device)
+        if self._g_dirty:
+            self._g.set_params(self._gparams)
+            self._g_dirty = False
+        return self._g
 
     # ------------------------------------------------------------------ weights
     def stage_names(self):
@@ -107,6 +127,7 @@ class Engine:
         moves.  `params`: {name: fp32 tensor}."""
         if not hasattr(self, '_stage'):
             self._stage, self._eval_sig, self._eval_table = {}, None, None
+        self._gparams, self._g_dirty, self._g_fwd = params, True, 0
         src = {}
         for prefix in self.stage_names():
             for j in (1, 2):
@@ -355,6 +376,11 @@ class Engine:
         cls uint8 [N, D*H*W]."""
         if self.packed is None:
             raise RuntimeError('Engine.load_eval() has not been called')
+        g = self._graph()
+        if g is not None and not features_only and self.probe is None:
+            # the whole forward as one C call (csrc/net.hip: the same launches on the same operators, sequenced in C++)
+            self.check_shape(D, H, W)
+            return g.infer(x, x_strides, N, D, H, W, logits, probs, cls, out_strides, divisor, accumulate)
         ws = self.workspace(N, D, H, W)
         dims = ws['dims']
         es = torch.tensor([], dtype=self.act_dtype).element_size()

@@ -41,7 +41,27 @@ class EngineX2:
         self.packed = None
         self._ws_cache = {}
         self.probe = None          # {'name': layer, 'events': []}: timing hook of one layer's launches (bench.py)
+        self.use_graph = True      # False: every forward sequenced from Python (tests compare the two)
+        self._g, self._gparams, self._g_dirty, self._g_last, self._g_fwd = None, None, False, None, 0      # the C++-sequenced forward (_graph)
         nv.lib()
+
+    def _graph(self):
+        """The C++-sequenced forward (net_graph.NetGraph) on this engine's current parameters, or None where the handle level does not
+        apply (GroupNorm, fp8 operators, IUNET_PY_GRAPH=1).  The handle packs its own copy of the operators (one copy of the parameters
+        + ~40 launches), so it is loaded at the SECOND forward on the same parameters: a training loop that predicts once per optimiser
+        step, or a validation pass that only asks for features, never pays for it; a slice / block / volume prediction does once."""
+        from . import net_graph
+        self._g_fwd += 1
+        if self._g_fwd < 2:
+            return None
+        if not net_graph.ENABLED or not self.use_graph or self.norm != 'batch' or self.weight_dtype or not (2 <= self.levels <= 6) or self._gparams is None:
+            return None
+        if self._g is None:
+            self._g = net_graph.NetGraph(self.dim, self.levels, self.base, self.cin, self.ncls, 2, self.device, act_scale=self.act_scale)
+        if self._g_dirty:
+            self._g.set_params(self._gparams)
+            self._g_dirty = False
+        return self._g
 
     def stage_names(self):
         return [f'enc{l}' for l in range(self.levels)] + [f'dec{l}' for l in range(self.levels - 2, -1, -1)]
@@ -69,6 +89,7 @@ class EngineX2:
         allocated once: a re-pack after an optimiser step is launches only (no allocation, no synchronisation)."""
         if not hasattr(self, '_stage'):
             self._stage, self._bufs = {}, {}
+        self._gparams, self._g_dirty, self._g_fwd = params, True, 0
         dev = self.device
         lib, s, P, A = nv.lib(), nv.stream(), {}, self.act_scale
 
@@ -157,6 +178,13 @@ class EngineX2:
         """engine.Engine.infer in split precision (same arguments and output contract)."""
         if self.packed is None:
             raise RuntimeError('EngineX2.load_eval() has not been called')
+        g = self._graph()
+        if g is not None and not features_only and self.probe is None:
+            # the whole forward as one C call (csrc/net.hip: the same launches on the same operators, sequenced in C++)
+            self.check_shape(D, H, W)
+            self._g_last = (x, x_strides, N, D, H, W)
+            return g.infer(x, x_strides, N, D, H, W, logits, probs, cls, out_strides, divisor, accumulate)
+        self._g_last = None
         ws = self.workspace(N, D, H, W)
         dims, L, ch, s = ws['dims'], self.levels, self.ch, nv.stream()
         Pt = lambda t, planes=0, v=0: ctypes.c_void_p(t.data_ptr() + 2 * planes * v * 8)      # view starting `planes` planes in
@@ -208,6 +236,8 @@ class EngineX2:
         """Largest |stored hi word| of the last forward's activations (a host-synchronising diagnostic, never on the hot path).  The
         mode keeps act_scale x activation in fp16: a value of 65504 means an activation saturated (|activation| >= 65504 / act_scale
         = 1 023 at the default 2^6) and the result is no longer within tolerance -- lower act_scale for such a model."""
+        if self._g_last is not None:          # the last forward ran inside the C++ graph: replay it here so that its activations can be read
+            self.infer(*self._g_last, features_only=True)
         m = 0.0
         for ws in self._ws_cache.values():
             for k, t in ws.items():

@@ -101,9 +101,20 @@ def test_c_graph_matches_the_python_engines_and_the_oracle(dim, shape, mode):
     e = EngineX2(dim=dim, ncls=ncls) if mode == 2 else Engine(dim=dim, ncls=ncls, act_dtype=(torch.float16, torch.bfloat16)[mode])
     e.load_eval({k: v.cuda() for k, v in p.items()})
     lg2, cl2 = torch.empty_like(logits), torch.empty_like(cls)
+    e.use_graph = False                                   # the engine's own launch sequence
     e.infer(x, (vox, vox, H * W, W, 1), N, D, H, W, logits=lg2, cls=cl2)
     torch.cuda.synchronize()
     assert torch.equal(logits, lg2) and torch.equal(cls, cl2), 'the C++ graph and the Python-sequenced engine launch the same kernels'
+    # ... and the engine's default route IS that graph (net_graph.NetGraph behind Engine.infer): strided 2.5-D style output included
+    e.use_graph = True
+    e._g_fwd = 1                                          # (the handle is loaded at the second forward on the same parameters)
+    lg3, pr3, pr2 = torch.empty_like(logits), torch.full_like(probs, 0.25), torch.full_like(probs, 0.25)
+    e.infer(x, (vox, vox, H * W, W, 1), N, D, H, W, logits=lg3, probs=pr3, accumulate=True, divisor=3.0)
+    assert e._g is not None and e._g.loaded
+    e.use_graph = False
+    e.infer(x, (vox, vox, H * W, W, 1), N, D, H, W, probs=pr2, accumulate=True, divisor=3.0)
+    torch.cuda.synchronize()
+    assert torch.equal(lg3, lg2) and torch.equal(pr3, pr2)
     ref = unet_ref.forward_logits(p, x.cpu().float() / 255.0, dim=dim)
     err = (logits.cpu() - ref).abs().max().item()
     print(f'[net handle {dim}-D mode {mode}] max |logit - CPU fp32 oracle| = {err:.2e}')
