@@ -60,7 +60,10 @@ template <bool SMALL> struct V4Tile<2, SMALL> { static constexpr int TZ = 1, TY 
 #ifndef V4_X2_LT3D
 #define V4_X2_LT3D 512          // loader threads of the 3-D split conv (A/B: -DV4_X2_LT3D=256)
 #endif
-constexpr int v4_loader_threads(int nd, bool ws, bool pair, bool spl, bool bwv = false, bool np = false) { return (ws || pair || ((spl || np) && nd == 2)) ? 256 : bwv ? V4_BW_LT : (spl && nd == 3) ? V4_X2_LT3D : 512; }
+#ifndef V4_NP3_LT
+#define V4_NP3_LT 512           // loader threads of the 3-D compact-operator conv (A/B: -DV4_NP3_LT=256)
+#endif
+constexpr int v4_loader_threads(int nd, bool ws, bool pair, bool spl, bool bwv = false, bool np = false) { return (ws || pair || ((spl || np) && nd == 2)) ? 256 : bwv ? V4_BW_LT : (spl && nd == 3) ? V4_X2_LT3D : (np && nd == 3) ? V4_NP3_LT : 512; }
 
 struct ConvV4Params {
   const void* x;  long long x_sstride;
