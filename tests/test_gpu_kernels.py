@@ -141,6 +141,8 @@ def test_conv2_cross_pair_exact_integers(nv, shape, cin, cout):
     """Layout 3 in 2-D: the compact order of the 3^2 filter and the cross-pair step (the third filter column of a step's two 16-channel
     halves in one k-group; resident weights up to 64 input channels, streamed by LDS-DMA beyond): forward with statistics, bias +
     ReLU epilogue and the data gradient, bit for bit; the batched packer (descriptor kind 6) writes the per-layer kernel's bytes."""
+    if os.environ.get('IUNET_NO_COMPACT2D'):
+        pytest.skip('A/B switch IUNET_NO_COMPACT2D: no layout 3 in 2-D')
     g = torch.Generator().manual_seed(23)
     N = 3
     assert nv.lib().iunet_conv3_compact_ok(2, N, 1, *shape, cin, cout, 0, 0) == 1

@@ -110,7 +110,8 @@ def test_c_graph_matches_the_python_engines_and_the_oracle(dim, shape, mode):
     e._g_fwd = 1                                          # (the handle is loaded at the second forward on the same parameters)
     lg3, pr3, pr2 = torch.empty_like(logits), torch.full_like(probs, 0.25), torch.full_like(probs, 0.25)
     e.infer(x, (vox, vox, H * W, W, 1), N, D, H, W, logits=lg3, probs=pr3, accumulate=True, divisor=3.0)
-    assert e._g is not None and e._g.loaded
+    from interactive_unet import net_graph
+    assert not net_graph.ENABLED or (e._g is not None and e._g.loaded)       # (IUNET_PY_GRAPH=1 keeps the Python sequence)
     e.use_graph = False
     e.infer(x, (vox, vox, H * W, W, 1), N, D, H, W, probs=pr2, accumulate=True, divisor=3.0)
     torch.cuda.synchronize()
