@@ -468,6 +468,10 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + v4_loader_threads(ND
   }
 
   // ==================================================================== consumer waves
+#ifdef V4_PRIO      // A/B (never defined by build.sh): static issue priority of the MFMA waves over the loader waves (1), and of the
+                    // younger consumer half over the older one (2)   [MI355X_MICROARCH.md, two waves per SIMD, item 4]
+  if (V4_PRIO >= 2 && wave >= NCW / 2) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1);
+#endif
   const int l15 = lane & 15, q = lane >> 4;
   int col_off[NCMB];
 #pragma unroll
