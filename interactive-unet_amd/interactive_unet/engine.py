@@ -94,6 +94,7 @@ class Engine:
         if self._g_dirty:
             self._g.set_params(self._gparams)
             self._g_dirty = False
+            self._ws_cache.clear()         # the handle has its own workspace: the Python sequence's buffers go back to the allocator
         return self._g
 
     # ------------------------------------------------------------------ weights

@@ -61,6 +61,7 @@ class EngineX2:
         if self._g_dirty:
             self._g.set_params(self._gparams)
             self._g_dirty = False
+            self._ws_cache.clear()         # the handle has its own workspace: the Python sequence's buffers go back to the allocator
         return self._g
 
     def stage_names(self):
