@@ -246,7 +246,9 @@ def predict_slice(image_slice, num_channels=1, num_classes=2, return_probabiliti
     eng = model.engine('eval')
     H, W = image_slice.shape[:2]
     x = torch.as_tensor(np.ascontiguousarray(image_slice)).to(device)
-    probs = torch.empty((1, eng.ncls, H, W), dtype=torch.float32, device=device)
+    # the probabilities are written only for the callers that read them (the coloured class map needs the argmax alone)
+    need_probs = return_probabilities or num_classes < eng.ncls
+    probs = torch.empty((1, eng.ncls, H, W), dtype=torch.float32, device=device) if need_probs else None
     cls = torch.empty((1, H * W), dtype=torch.uint8, device=device)
     if x.dtype != torch.uint8:
         x = (x.to(torch.float32) / 255).contiguous()

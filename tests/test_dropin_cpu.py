@@ -89,6 +89,17 @@ def test_overlay_install_resolves_every_caller_attribute(tmp_path):
     assert set(install_overlay.REPLACED) <= set(done)
     assert (pkg / 'utils.py').read_text() == textwrap.dedent(STUB_UTILS)    # the caller's utils.py is untouched
     assert (pkg / 'predict.py.reference').exists()
+    # every module a native module imports from its own package -- at import time or lazily inside a function -- was installed with it
+    import re
+    for f in pkg.glob('*.py'):
+        if f.name in ('utils.py', 'volumedata.py', 'annotator.py', 'app.py', '__init__.py'):
+            continue
+        text = f.read_text()
+        needed = set(re.findall(r'from \.(\w+) import', text))
+        for grp in re.findall(r'from \. import ([\w, ]+)', text):
+            needed |= {n.split(' as ')[0].strip() for n in grp.split(',')}
+        for mod in needed - {'utils'}:
+            assert (pkg / f'{mod}.py').exists(), f'{f.name} imports .{mod}, which the overlay does not install'
     env = dict(os.environ, PYTHONPATH=str(tmp_path / 'checkout'))
     r = subprocess.run([sys.executable, '-c', 'import interactive_unet.app'], env=env, cwd=str(tmp_path), capture_output=True,
                        text=True, timeout=300)
