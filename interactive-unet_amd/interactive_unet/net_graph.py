@@ -1,8 +1,8 @@
 """The prediction forward as ONE C call: the handle level of the C ABI (csrc/net.hip, include/iunet.h "handle level") behind the
 engines' `infer`.  The launch graph of a forward -- ~30 dependent launches -- is sequenced in C++ instead of ~30 ctypes calls from
-Python: the same kernels on the same operators (bit-identical, tests/test_net_handle.py), a fifth of the host time per forward, and
-no Python between the launches for a busy host to delay (the 2.5-D block prediction of the reference, predict.py:79-112, is ~90
-launches per block: with the host cores busy it read 7-10 ms per block instead of 2.7 through the Python-sequenced engine).
+Python: the same kernels on the same operators (bit-identical, tests/test_net_handle.py) and no Python between the launches (the
+Python sequence costs ~0.15 ms of host time per 2-D forward; the 2.5-D block prediction of the reference, predict.py:79-112, is three
+forwards = ~90 launches per block).
 
 `IUNET_PY_GRAPH=1` keeps every forward on the Python-sequenced engines (A/B switch).  Engines fall back to their own sequence for
 what the handle does not cover: GroupNorm, fp8 operators, `features_only`, and launches with a timing probe attached."""
