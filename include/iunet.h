@@ -206,6 +206,25 @@ int iunet_x2_head_fwd(const void* x, long long x_ss, int x_lo, int C0, const voi
                       void* logits, void* probs, void* cls, const long long* out_strides, float divisor, int accumulate, int N, int D,
                       int H, int W, void* stream);
 
+/* ---- fp16x2 with the cross terms on the fp8 matrix cores ("x2m", 3-D stage convs; csrc/conv3_x2m.hip) ------------------------
+ * The two cross terms of a split product (x_lo w_hi, x_hi w_lo) are 2^-11 of it: they run as one K = 128 step of
+ * v_mfma_f32_16x16x128_f8f6f4 over the virtual channels [x_lo8 | x_hi8] x [w_hi8 | w_lo8] (e4m3) into the accumulator of the main
+ * term x_hi w_hi -- two matrix-step units per 16 input channels instead of three.  Beside its hi (and optional lo) planes a tensor
+ * carries "m8" planes: 2 C / 16 planes [D][H][W][16 B] of e4m3, plane 2c = e4m3((v - hi) * 2^4), plane 2c + 1 = e4m3(hi * 2^-8) of
+ * the 16-channel chunk c (v = act_scale * activation).  Same graph, same reference semantics (unet.py:65-69, predict.py:30-35). */
+long long iunet_x2m_w8_bytes(int Cout, int Cin);
+/* w fp32 [Cout][Cin][27] (+ optional BatchNorm fold) -> whi fp32 [Cout][Cin][27] = w_hi (feed it to iunet_pack_conv3, dtype 0, mode 2),
+ * w8 = iunet_x2m_w8_bytes bytes (K128 order of [e4m3(w_hi 2^-4) | e4m3(w_lo 2^8)] per 16-channel chunk), oscale / bias_out as iunet_x2_prep */
+int iunet_x2m_prep(const void* w, void* whi, void* w8, void* oscale, void* bias_out, const void* gamma, const void* beta, const void* mean,
+                   const void* var, float eps, float act_in, float act_out, int Cout, int Cin, void* stream);
+/* m8 planes (x8_ss bytes per sample) of a split tensor that another kernel wrote as hi + lo words (x_ss fp16 elements per sample) */
+int iunet_x2m_make8(const void* x, long long x_ss, int x_lo, void* x8, long long x8_ss, int C, int N, int D, int H, int W, void* stream);
+/* the stage conv: x = Cin / 8 hi planes + x8 = its m8 planes; y = Cout / 8 hi planes (+ lo planes y_lo planes further on unless
+ * y_lo < 0) + y8 = its m8 planes (or null); sat: optional device int raised to the bit pattern of a saturated (|v| >= 65504) hi word */
+int iunet_x2m_conv3_fwd(const void* x, long long x_ss, const void* x8, long long x8_ss, void* y, long long y_ss, int y_lo, void* y8,
+                        long long y8_ss, const void* w16, const void* w8, const void* oscale, const void* bias, int N, int D, int H, int W,
+                        int Cin, int Cout, int epi, void* sat, void* stream);
+
 /* ---- handle level: the whole forward as one call (csrc/net.hip) ---------------------------------------------------------
  * For a caller that is not Python: the launch graph interactive_unet/engine.py / engine_x2.py sequence (unet.py:65-69 over the
  * canonical network) sequenced in C++.  The handle is host memory; every device buffer is the caller's.

@@ -1,0 +1,602 @@
+// 3x3x3 convolution of the split-precision forward with the CROSS TERMS ON THE fp8 MATRIX CORES ("x2m", 3-D only).
+//
+// fp16x2 (split16.hip, conv3_v4.hip flag SPL) evaluates (x_hi + x_lo)(w_hi + w_lo) as x_hi w_hi + x_lo w_hi + x_hi w_lo: three
+// v_mfma_f32_16x16x32_f16 per product.  The two cross terms are 2^-11 of the product, so their operands need ~4 significant bits, not
+// 11: here they run as ONE step of the K = 128 fp8 instruction (v_mfma_f32_16x16x128_f8f6f4, twice the multiply-adds per clock,
+// conv3_f8k.hip) over 32 VIRTUAL channels per 16-channel chunk -- [x_lo8 | x_hi8] against [w_hi8 | w_lo8], all e4m3 -- into the SAME
+// fp32 accumulators as the main term.  Per 16 input channels: one 16-bit step (120 K = 32 instructions) + one fp8 step (48 K = 128 +
+// 24 K = 32 fp8 instructions) = 2 x 1 920 matrix cycles per wave instead of 3 x 1 920.  An e4m3 operand carries a relative rounding
+// error of 2^-4 on a term that is 2^-12 (rms) of the product: 2^-16 per operand, four operands -- the logits land ~20x closer to the
+// fp32 path than the fp16 mode's (tools/x2m_numerics.py: the same arithmetic on the CPU; tests/test_gpu_x2m.py on the device).
+//
+// Tensors.  An activation tensor of C channels (values v = act_scale * activation, fp32 in the producer's epilogue):
+//   hi planes   C / 8  x [D][H][W][8] fp16         hi = f16(v)                         (the NHWC8c planes of every 16-bit kernel)
+//   lo planes   C / 8  x [D][H][W][8] fp16         lo = f16(v - hi)                    (what the pool / transposed conv / head read; optional)
+//   m8 planes   2C / 16 x [D][H][W][16 B] e4m3     plane 2c: lo8 = e4m3((v - hi) * 2^4), plane 2c + 1: hi8 = e4m3(hi * 2^-8)  of chunk c
+// and the operator of a (32 Cout, 16 Cin) block twice: w_hi in the padded K16 order of the 16-bit kernels (30 720 B, pack mode 2) and
+// [w_hi8 = e4m3(w_hi * 2^-4) | w_lo8 = e4m3(w_lo * 2^8)] in the K128 order of conv3_f8k.hip (27 648 B).  The powers of two pair up
+// (2^4 x 2^-4, 2^-8 x 2^8), so every term carries the scale of the main term and one accumulator scale per output channel undoes it.
+// Ranges: |lo| <= 2^-11 |hi| <= 16 -> lo8 <= 256; hi <= 65504 -> hi8 <= 256; w_hi in [2^9, 2^10) per row -> w_hi8 < 64; w_lo8 <= 64.
+//
+// Structure: conv3_v4.hip's / conv3_f8k.hip's (one persistent workgroup per CU: 8 consumer waves read LDS and issue MFMAs, 4 loader
+// waves move everything by LDS-DMA, one barrier per step, per-XCD bricks).  The two kinds of step alternate, so ONE set of buffers per
+// kind is a double buffer: while the consumers work on the 16-bit step of chunk c the loaders fill the fp8 buffers of chunk c, and
+// vice versa.  LDS: 34 816 (16-bit halo) + 30 720 (K16 operator) + 36 864 (e4m3 halo, z stride 192) + 27 648 (K128 operator) + 256.
+#include "common.h"
+#include <cstdlib>
+#include <type_traits>
+
+namespace {
+
+typedef long i64;
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+template <bool SMALL> struct XMTile { static constexpr int TZ = SMALL ? 2 : 4, TY = 8, TX = 16, NCW = SMALL ? 4 : 8; };
+constexpr int XM_NLT = 256;                                    // loader threads (everything moves by LDS-DMA)
+
+__device__ __attribute__((aligned(16))) unsigned int g_xm_zero16[4] = {0u, 0u, 0u, 0u};
+
+struct ConvX2MParams {
+  const void* x;  long long x_sstride;        // hi planes, elements
+  const void* x8; long long x8_sstride;       // m8 planes, bytes
+  void* y;        long long y_sstride; int y_lo;      // hi planes (elements); lo planes y_lo planes further on, y_lo < 0: not written
+  void* y8;       long long y8_sstride;       // m8 planes of the output (bytes) or null
+  const void* w16;                            // [cob][chunk16][column pair 5][dy][2][64][8] f16 (pack mode 2 of w_hi)
+  const void* w8;                             // [cob][chunk16][F8K_WSTEP] e4m3 (K128 order of [w_hi8 | w_lo8])
+  const float* oscale; const float* bias;
+  int N, D, H, W, Cin, Cout;
+  int tilesZ, tilesY, tilesX;
+  int bz, by, bx;
+  int nbz, nby, nbx;
+  int epi;
+  int* sat;                                   // optional: the largest |hi| bit pattern stored by this launch (atomicMax; range check)
+};
+
+// this lane's 8 values r[j] (fp32, scaled) -> hi words, lo words, and the two half-granules of the m8 planes
+__device__ __forceinline__ void xm_split8(const float (&r)[8], f16x8& hi, f16x8& lo, u32x2& lo8, u32x2& hi8) {
+  float l4[8], h8[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float v = fminf(fmaxf(r[j], -65504.f), 65504.f);
+    const f16 h = (f16)v;
+    const float res = v - (float)h;                            // exact in fp32
+    hi[j] = h; lo[j] = (f16)res;
+    l4[j] = __builtin_amdgcn_fmed3f(res * 16.0f, -448.0f, 448.0f);
+    h8[j] = __builtin_amdgcn_fmed3f((float)h * 0.00390625f, -448.0f, 448.0f);
+  }
+  int a = __builtin_amdgcn_cvt_pk_fp8_f32(l4[0], l4[1], 0, false);
+  a = __builtin_amdgcn_cvt_pk_fp8_f32(l4[2], l4[3], a, true);
+  int b = __builtin_amdgcn_cvt_pk_fp8_f32(l4[4], l4[5], 0, false);
+  b = __builtin_amdgcn_cvt_pk_fp8_f32(l4[6], l4[7], b, true);
+  lo8 = u32x2{(unsigned)a, (unsigned)b};
+  a = __builtin_amdgcn_cvt_pk_fp8_f32(h8[0], h8[1], 0, false);
+  a = __builtin_amdgcn_cvt_pk_fp8_f32(h8[2], h8[3], a, true);
+  b = __builtin_amdgcn_cvt_pk_fp8_f32(h8[4], h8[5], 0, false);
+  b = __builtin_amdgcn_cvt_pk_fp8_f32(h8[6], h8[7], b, true);
+  hi8 = u32x2{(unsigned)a, (unsigned)b};
+}
+
+template <bool SMALL>
+__global__ __launch_bounds__((XMTile<SMALL>::NCW * 64 + XM_NLT), 1) void conv3_x2m_kernel(ConvX2MParams p) {
+  using TL = XMTile<SMALL>;
+  constexpr int NCW = TL::NCW, NLT = XM_NLT, NLW = NLT / 64;
+  constexpr int TZ = TL::TZ, TY = TL::TY, TX = TL::TX;
+  constexpr int NI = TZ * TY / NCW, NR = NI;                   // 4 tile rows (16 voxels each) per consumer wave
+  constexpr int PZ = TZ + 2, PY = TY + 2, PX = TX + 2;
+  constexpr int NPIX = PZ * PY * PX;                           // 1080 / 720
+  // 16-bit halo image: two 8-channel planes [pixel][16 B], pixels dense
+  constexpr int PLANE16 = ((NPIX * 16 + 255) / 256) * 256;
+  constexpr int A16 = 2 * PLANE16;
+  constexpr int NCMB = 5, W16 = NCMB * 3 * 2 * 1024;           // 30 720
+  // e4m3 halo image: two 16-channel planes [voxel][16 B], z-plane stride padded 180 -> 192 voxels (conv3_f8k.hip)
+  constexpr int ZS = 192;
+  constexpr int PLANE8 = PZ * ZS * 16;
+  constexpr int A8 = 2 * PLANE8;
+  constexpr int W128 = 2 * 3 * 2 * 2 * 1024, W32 = 3 * 2 * 512, W8 = W128 + W32;      // 27 648
+  constexpr int OFF_A16 = 0, OFF_W16 = A16, OFF_A8 = OFF_W16 + W16, OFF_W8 = OFF_A8 + A8, OFF_E = OFF_W8 + W8;
+  static_assert(NI == 4 && NCW * NI == TZ * TY, "a consumer wave owns 4 rows of one z slice");
+
+  extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cob = blockIdx.y;
+  const int nbricks = p.N * p.nbz * p.nby * p.nbx;
+  const int xcd = (blockIdx.x + (nbricks < 8 ? blockIdx.y : 0)) & 7, slot = blockIdx.x >> 3;
+  const int sx = slot % p.bx, sy = (slot / p.bx) % p.by, sz = slot / (p.bx * p.by);
+  const int b_begin = (int)((long long)xcd * nbricks / 8), b_end = (int)((long long)(xcd + 1) * nbricks / 8);
+  const int nchunk = p.Cin / 16;
+  const int npairs = (b_end - b_begin) * nchunk;               // (16-bit step, fp8 step) pairs of this workgroup
+  if (npairs <= 0) return;
+  const long long plane_stride = (long long)p.D * p.H * p.W * 8;      // elements of a 16-bit plane = half the bytes of an m8 plane
+  const long long plane16b = (long long)p.D * p.H * p.W * 16;         // bytes of either plane
+
+  auto tile_origin = [&](int k, int& n_img, int& z0, int& y0, int& x0) -> bool {
+    int b = b_begin + k;
+    const int Bx = b % p.nbx; b /= p.nbx;
+    const int By = b % p.nby; b /= p.nby;
+    const int Bz = b % p.nbz; n_img = b / p.nbz;
+    const int tz = Bz * p.bz + sz, ty = By * p.by + sy, tx = Bx * p.bx + sx;
+    z0 = tz * TZ; y0 = ty * TY; x0 = tx * TX;
+    return tz < p.tilesZ && ty < p.tilesY && tx < p.tilesX;
+  };
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  if (tid < 64) ((float*)(smem + OFF_E))[tid] = tid < 32 ? p.oscale[cob * 32 + tid] : (p.epi != 0 ? p.bias[cob * 32 + tid - 32] : 0.f);
+
+  if (wave >= NCW) {
+    // ================================================================== loader waves: everything global -> LDS without registers
+    const int lt = tid - NCW * 64;
+    const int lw = __builtin_amdgcn_readfirstlane(lt >> 6);
+    auto dma_piece = [&](const unsigned char* gsrc, unsigned dst) {      // one wave instruction: 64 x 16 B to LDS dst + lane * 16
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+    };
+    auto dma_weights = [&](const unsigned char* ws, int off, int bytes) {      // lane-linear copy of a step's operator
+      const int npiece = bytes / 1024;
+      for (int piece = lw; piece < npiece; piece += NLW)
+        dma_piece(ws + piece * 1024 + (lt & 63) * 16, __builtin_amdgcn_readfirstlane(lds0 + off + piece * 1024));
+    };
+    // 16-bit halo tile: 64 consecutive halo pixels per wave instruction (conv3_v4.hip: dma_acts)
+    constexpr int AIT = (PLANE16 / 16 + NLT - 1) / NLT;
+    int pcoord[AIT];
+#pragma unroll
+    for (int it = 0; it < AIT; ++it) {
+      const int pix = min(lt + it * NLT, NPIX - 1);
+      const int px = pix % PX, t2 = pix / PX;
+      pcoord[it] = px | ((t2 % PY) << 8) | ((t2 / PY) << 16);
+    }
+    // e4m3 halo tile: 64 consecutive 16-byte slots of a plane per wave instruction (conv3_f8k.hip: dma_acts)
+    constexpr int NSLOT = PZ * ZS;
+    constexpr int DIT = (NSLOT + NLT - 1) / NLT;
+    static_assert(NSLOT % 64 == 0, "an e4m3 plane is whole wave instructions");
+    int dcoord[DIT];
+#pragma unroll
+    for (int it = 0; it < DIT; ++it) {
+      const int s = lt + it * NLT;
+      const int pz = s / ZS, rem = s - pz * ZS, py = rem / PX, px = rem - py * PX;
+      dcoord[it] = (s < NSLOT && rem < PY * PX) ? (px | (py << 8) | (pz << 16)) : -1;
+    }
+    auto dma16 = [&](int k) {                                  // pair k: hi halo tile + K16 operator of its chunk
+      const int tile = k / nchunk, chunk = k - tile * nchunk;
+      int n_img, z0, y0, x0;
+      tile_origin(tile, n_img, z0, y0, x0);
+      dma_weights((const unsigned char*)p.w16 + ((long long)cob * nchunk + chunk) * W16, OFF_W16, W16);
+      const f16* xc = (const f16*)p.x + (long long)n_img * p.x_sstride + (long long)chunk * 2 * plane_stride;
+#pragma unroll
+      for (int it = 0; it < AIT; ++it) {
+        const int base = it * NLT + lw * 64;
+        if (base < PLANE16 / 16) {
+          const int pix = lt + it * NLT;
+          const int px = pcoord[it] & 255, py = (pcoord[it] >> 8) & 255, pz = pcoord[it] >> 16;
+          const int gz = z0 + pz - 1, gy = y0 + py - 1, gx = x0 + px - 1;
+          const bool ok = pix < NPIX && (unsigned)gz < (unsigned)p.D && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+          const long long goff = (((long long)gz * p.H + gy) * p.W + gx) * 8;
+          if (pix < PLANE16 / 16) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+              dma_piece(ok ? (const unsigned char*)(xc + e * plane_stride + goff) : (const unsigned char*)g_xm_zero16,
+                        __builtin_amdgcn_readfirstlane(lds0 + OFF_A16 + e * PLANE16 + base * 16));
+          }
+        }
+      }
+    };
+    auto dma8 = [&](int k) {                                   // pair k: [lo8 | hi8] halo tile + K128 operator of its chunk
+      const int tile = k / nchunk, chunk = k - tile * nchunk;
+      int n_img, z0, y0, x0;
+      tile_origin(tile, n_img, z0, y0, x0);
+      dma_weights((const unsigned char*)p.w8 + ((long long)cob * nchunk + chunk) * W8, OFF_W8, W8);
+      const unsigned char* xc = (const unsigned char*)p.x8 + (long long)n_img * p.x8_sstride + (long long)chunk * 2 * plane16b;
+#pragma unroll
+      for (int it = 0; it < DIT; ++it) {
+        const int base = it * NLT + lw * 64;
+        if (base < NSLOT) {
+          const int c = dcoord[it];
+          const int gz = z0 + (c >> 16) - 1, gy = y0 + ((c >> 8) & 255) - 1, gx = x0 + (c & 255) - 1;
+          const bool ok = c >= 0 && (unsigned)gz < (unsigned)p.D && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+          const long long goff = (((long long)gz * p.H + gy) * p.W + gx) * 16;
+#pragma unroll
+          for (int e = 0; e < 2; ++e)
+            dma_piece(ok ? xc + e * plane16b + goff : (const unsigned char*)g_xm_zero16,
+                      __builtin_amdgcn_readfirstlane(lds0 + OFF_A8 + e * PLANE8 + base * 16));
+        }
+      }
+    };
+    auto landed = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+    dma16(0);
+    landed();
+    lds_barrier();
+    for (int k = 0; k < npairs; ++k) {
+      dma8(k);                                                 // consumers: 16-bit step of pair k
+      landed();
+      lds_barrier();
+      if (k + 1 < npairs) dma16(k + 1);                        // consumers: fp8 step of pair k
+      landed();
+      lds_barrier();
+    }
+    return;
+  }
+
+  // ==================================================================== consumer waves
+  const int l15 = lane & 15, q = lane >> 4;
+  const int row_first = wave * NI;                             // first tile row (z * TY + y) of this wave
+  // ---- 16-bit step: lanes q & 1 take the 8-channel half, q >> 1 the column of a pair (conv3_v4.hip)
+  int col_off[NCMB];
+#pragma unroll
+  for (int c = 0; c < NCMB; ++c) {
+    const int col = min(2 * c + (q >> 1), 8);                  // the missing partner re-reads a valid column (zero weights)
+    col_off[c] = ((col / 3) * PY * PX + (col % 3)) * 16;
+  }
+  const int rbase16 = (q & 1) * PLANE16 + ((((row_first / TY) * PY + (row_first % TY)) * PX) + l15) * 16;
+  // ---- fp8 step: a lane group takes one filter column of a K = 128 group (conv3_f8k.hip)
+  int coff[2];
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const int col = q == 0 ? f8k_col(g, 0) : q == 1 ? f8k_col(g, 1) : q == 2 ? f8k_col(g, 2) : f8k_col(g, 3);
+    coff[g] = ((col / 3) * ZS + (col % 3)) * 16;
+  }
+  const int coff8 = (2 * ZS + 2) * 16 + (q >> 1) * PLANE8 + (q & 1) * 8;
+  const int rbase8 = (((row_first / TY) * ZS + (row_first % TY) * PX) + l15) * 16;
+
+  f32x4 acc[2][NI];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < NI; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+  using I3 = std::integral_constant<int, 3>; using I4 = std::integral_constant<int, 4>; using I5 = std::integral_constant<int, 5>;
+  using I6 = std::integral_constant<int, 6>; using I7 = std::integral_constant<int, 7>; using I8 = std::integral_constant<int, 8>;
+
+  // -------------------------------------------------------------- the 16-bit step: x_hi w_hi, 5 column pairs x 3 dy x 4 rows x 2 halves
+  auto step16 = [&]() {
+    f16x8 R[2][NR + 2], A[2][3][2];
+    const unsigned char* ab = smem + OFF_A16 + rbase16;
+    const unsigned char* wl = smem + OFF_W16 + lane * 16;
+    auto load_group = [&](int c, auto BUF) {
+      constexpr int b = decltype(BUF)::value;
+#pragma unroll
+      for (int r = 0; r < NR + 2; ++r) R[b][r] = *(const f16x8*)(ab + r * PX * 16 + col_off[c]);
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+        A[b][dy][0] = *(const f16x8*)(wl + ((c * 3 + dy) * 2 + 0) * 1024);
+        A[b][dy][1] = *(const f16x8*)(wl + ((c * 3 + dy) * 2 + 1) * 1024);
+      }
+    };
+    auto group_mfmas = [&](auto BUF, bool reads_pending) {
+      constexpr int b = decltype(BUF)::value;
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int n = 0; n < NI; ++n) {
+          acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[b][dy][0], R[b][n + dy], acc[0][n], 0, 0, 0);
+          acc[1][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[b][dy][1], R[b][n + dy], acc[1][n], 0, 0, 0);
+        }
+      if (reads_pending) {
+        constexpr int NRD = NR + 2 + 6, MPR = (3 * NI * 2) / NRD;      // 12 LDS reads spread over 24 MFMAs
+#pragma unroll
+        for (int i = 0; i < NRD; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, MPR, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    load_group(0, I0{});
+    __builtin_amdgcn_sched_barrier(0);
+    load_group(1, I1{}); group_mfmas(I0{}, true);
+    load_group(2, I0{}); group_mfmas(I1{}, true);
+    load_group(3, I1{}); group_mfmas(I0{}, true);
+    load_group(4, I0{}); group_mfmas(I1{}, true);
+    group_mfmas(I0{}, false);
+  };
+
+  // -------------------------------------------------------------- the fp8 step: [x_lo8 | x_hi8] [w_hi8 | w_lo8], 2 K = 128 groups + the ninth column
+  auto step8 = [&]() {
+    i32x8 R[2][NR + 2], A[2][2];
+    i64 R8[NR + 2], A8[3][2];
+    const unsigned char* ab = smem + OFF_A8;
+    const unsigned char* wl = smem + OFF_W8;
+    auto rd128 = [&](const unsigned char* ptr, int second) -> i32x8 {
+      const u32x4 lo = *(const u32x4*)ptr, hi = *(const u32x4*)(ptr + second);
+      return i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+    };
+    auto load_sub = [&](auto SG) {
+      constexpr int sg = decltype(SG)::value, g = sg / 3, dy = sg % 3;
+      if constexpr (g < 2) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) A[sg & 1][m] = rd128(wl + ((g * 3 + dy) * 2 + m) * 2048 + lane * 16, 1024);
+        constexpr int r0 = dy == 0 ? 0 : NR - 1 + dy, r1 = dy == 0 ? NR : NR + dy;
+#pragma unroll
+        for (int r = r0; r < r1; ++r) R[g][r] = rd128(ab + rbase8 + coff[g] + r * PX * 16, PLANE8);
+      } else if constexpr (dy == 0) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+#pragma unroll
+          for (int m = 0; m < 2; ++m) A8[d][m] = *(const i64*)(wl + W128 + (d * 2 + m) * 512 + lane * 8);
+#pragma unroll
+        for (int r = 0; r < NR + 2; ++r) R8[r] = *(const i64*)(ab + rbase8 + coff8 + r * PX * 16);
+      }
+    };
+    auto mfma_sub = [&](auto SG, auto NREADS) {
+      constexpr int sg = decltype(SG)::value, g = sg / 3, dy = sg % 3, nreads = decltype(NREADS)::value;
+#pragma unroll
+      for (int n = 0; n < NI; ++n)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          if constexpr (g < 2) acc[m][n] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A[sg & 1][m], R[g][n + dy], acc[m][n], 0, 0, 0, 0, 0, 0);
+          else acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(A8[dy][m], R8[n + dy], acc[m][n], 0, 0, 0);
+        }
+      if constexpr (nreads >= 8) {
+        constexpr int RPM = (nreads + 7) / 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, RPM, 0);
+        }
+      } else if constexpr (nreads > 0) {
+        constexpr int MPR = 8 / nreads;
+#pragma unroll
+        for (int i = 0; i < nreads; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, MPR, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+      }
+      if constexpr (sg < 6 || sg == 8) __builtin_amdgcn_sched_barrier(0);
+    };
+    using N0 = std::integral_constant<int, 0>; using N6 = std::integral_constant<int, 6>; using N12 = std::integral_constant<int, 12>;
+    load_sub(I0{});
+    __builtin_amdgcn_sched_barrier(0);
+    load_sub(I1{}); mfma_sub(I0{}, N6{});
+    load_sub(I2{}); mfma_sub(I1{}, N6{});
+    load_sub(I3{}); mfma_sub(I2{}, N12{});
+    load_sub(I4{}); mfma_sub(I3{}, N6{});
+    load_sub(I5{}); mfma_sub(I4{}, N6{});
+    load_sub(I6{}); mfma_sub(I5{}, N12{});
+    mfma_sub(I6{}, N0{}); mfma_sub(I7{}, N0{}); mfma_sub(I8{}, N0{});
+  };
+
+  auto tile_epilogue = [&](int tile) {
+    int n_img, z0, y0, x0;
+    tile_origin(tile, n_img, z0, y0, x0);
+    f16* yout = (f16*)p.y + (long long)n_img * p.y_sstride;
+    float bias_r[8], os_r[8];
+    {
+      const f32x4* ep = (const f32x4*)(smem + OFF_E) + 2 * q;
+      const f32x4 w0 = ep[0], w1 = ep[1], b0 = ep[8], b1 = ep[9];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { os_r[j] = w0[j]; os_r[4 + j] = w1[j]; bias_r[j] = b0[j]; bias_r[4 + j] = b1[j]; }
+    }
+    unsigned short hmax = 0;
+#pragma unroll
+    for (int n = 0; n < NI; ++n) {
+      const int row = row_first + n;
+      const int gz = z0 + row / TY, gy = y0 + row % TY, gx = x0 + l15;
+      const bool ok = gz < p.D && gy < p.H && gx < p.W;
+      const long long vo = ((long long)gz * p.H + gy) * p.W + gx;
+      float r[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        r[j] = fmaf(j < 4 ? acc[0][n][j] : acc[1][n][j - 4], os_r[j], bias_r[j]);
+        if (p.epi == 2) r[j] = fmaxf(r[j], 0.f);
+      }
+      f16x8 hi, lo;
+      u32x2 lo8, hi8;
+      xm_split8(r, hi, lo, lo8, hi8);
+      if (ok) {
+        *(f16x8*)(yout + (long long)(cob * 4 + q) * plane_stride + vo * 8) = hi;
+        if (p.y_lo >= 0) *(f16x8*)(yout + (long long)(p.y_lo + cob * 4 + q) * plane_stride + vo * 8) = lo;
+        if (p.y8 != nullptr) {
+          unsigned char* y8 = (unsigned char*)p.y8 + (long long)n_img * p.y8_sstride + (long long)(2 * (cob * 2 + (q >> 1))) * plane16b + vo * 16 + (q & 1) * 8;
+          *(u32x2*)y8 = lo8;
+          *(u32x2*)(y8 + plane16b) = hi8;
+        }
+        if (p.sat != nullptr) {
+          const u32x4 hb = __builtin_bit_cast(u32x4, hi);
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {
+            const unsigned short a = hb[d] & 0x7fffu, b = (hb[d] >> 16) & 0x7fffu;
+            hmax = hmax > a ? hmax : a; hmax = hmax > b ? hmax : b;
+          }
+        }
+      }
+      acc[0][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+      acc[1][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (p.sat != nullptr && hmax >= 0x7bffu) atomicMax(p.sat, (int)hmax);      // only a saturated word ever touches memory
+  };
+
+  lds_barrier();                                               // the first 16-bit step is in LDS
+  for (int k = 0; k < npairs; ++k) {
+    step16();
+    lds_barrier();                                             // the fp8 buffers of pair k are filled; the 16-bit buffers are free
+    step8();
+    const int tile = k / nchunk;
+    if (k - tile * nchunk == nchunk - 1) tile_epilogue(tile);
+    lds_barrier();                                             // the 16-bit buffers of pair k + 1 are filled; the fp8 buffers are free
+  }
+}
+
+template <bool SMALL>
+int launch_x2m(ConvX2MParams p, hipStream_t stream) {
+  using TL = XMTile<SMALL>;
+  constexpr int PZ = TL::TZ + 2, NPIX = PZ * 10 * 18;
+  constexpr int PLANE16 = ((NPIX * 16 + 255) / 256) * 256, PLANE8 = PZ * 192 * 16;
+  const int lds = 2 * PLANE16 + 30720 + 2 * PLANE8 + F8K_WSTEP + 256;
+  IUNET_SET_MAX_LDS((conv3_x2m_kernel<SMALL>), lds);
+  p.tilesZ = (p.D + TL::TZ - 1) / TL::TZ; p.tilesY = (p.H + TL::TY - 1) / TL::TY; p.tilesX = (p.W + TL::TX - 1) / TL::TX;
+  const int ncob = p.Cout / 32;
+  iunet_brick_shape(3, ncob, p.tilesZ, p.tilesY, p.tilesX, &p.bz, &p.by, &p.bx);
+  p.nbz = (p.tilesZ + p.bz - 1) / p.bz; p.nby = (p.tilesY + p.by - 1) / p.by; p.nbx = (p.tilesX + p.bx - 1) / p.bx;
+  const int gx = 8 * p.bz * p.by * p.bx;
+  hipLaunchKernelGGL((conv3_x2m_kernel<SMALL>), dim3(gx, ncob), dim3(TL::NCW * 64 + XM_NLT), lds, stream, p);
+  IUNET_CHECK_HIP(hipGetLastError());
+  return IUNET_OK;
+}
+
+// ------------------------------------------------------------------ operator preparation
+// One workgroup per output channel: BatchNorm fold (the oracle's fp32 operation order, as x2_prep_kernel), row scale s = 2^k with
+// max |w'| s in [2^9, 2^10), hi = f16(w' s), res = w' s - hi (exact).  Writes w_hi as fp32 [Cout][Cin][27] (iunet_pack_conv3 mode 2 makes
+// the K16 operator of it) and the K128 operator of the virtual channels [w_hi8 = e4m3(hi / 16) | w_lo8 = e4m3(res * 256)] per 16-channel chunk.
+__device__ __forceinline__ unsigned xm_e4m3(float v) {
+  const int a = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(v, -448.0f, 448.0f), 0.f, 0, false);
+  return (unsigned)a & 0xffu;
+}
+__global__ __launch_bounds__(256) void x2m_prep_kernel(const float* __restrict__ w, float* __restrict__ whi, unsigned char* __restrict__ w8,
+                                                      float* __restrict__ oscale, float* __restrict__ bias_out,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      const float* __restrict__ mean, const float* __restrict__ var, float eps,
+                                                      float act_in, float act_out, int Cout, int Cin) {
+#pragma clang fp contract(off)
+  constexpr int taps = 27;
+  __shared__ float red[256];
+  const int co = blockIdx.x, tid = threadIdx.x;
+  float a = 1.0f;
+  if (gamma) { const float s = var[co] + eps; a = gamma[co] / sqrtf(s); }
+  const int n = Cin * taps;
+  const float* wc = w + (long long)co * n;
+  float m = 0.f;
+  for (int i = tid; i < n; i += 256) m = fmaxf(m, fabsf(gamma ? wc[i] * a : wc[i]));
+  red[tid] = m;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] = fmaxf(red[tid], red[tid + o]); __syncthreads(); }
+  m = red[0];
+  float s = 1.0f;
+  if (m > 0.f && m < INFINITY) {
+    int e;
+    (void)frexpf(m, &e);
+    int k = 10 - e;
+    k = k < -40 ? -40 : k > 40 ? 40 : k;
+    s = ldexpf(1.0f, k);
+  }
+  const int cob = co >> 5, r32 = co & 31;
+  const int mt = (r32 >> 2) & 1, row = (r32 >> 3) * 4 + (r32 & 3);       // co = cob * 32 + 8 (row >> 2) + 4 m + (row & 3)
+  const int nchunk = Cin >> 4;
+  // one thread = the 8 consecutive input channels of one tap: 8 fp32 words of w_hi + two 8-byte pieces of the K128 block
+  for (int i = tid; i < (Cin >> 3) * taps; i += 256) {
+    const int g8 = i / taps, tap = i - g8 * taps;
+    const int chunk = g8 >> 1, o = g8 & 1;
+    const int dz = tap / 9, dy = (tap / 3) % 3, dx = tap % 3, col = dz * 3 + dx;
+    unsigned long long ph = 0, pl = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int ci = g8 * 8 + j;
+      const float v0 = wc[(long long)ci * taps + tap];
+      float v = (gamma ? v0 * a : v0) * s;
+      v = fminf(fmaxf(v, -65504.f), 65504.f);
+      const f16 h = (f16)v;
+      const float res = v - (float)h;
+      whi[(long long)co * n + (long long)ci * taps + tap] = (float)h;
+      ph |= (unsigned long long)xm_e4m3((float)h * 0.0625f) << (8 * j);
+      pl |= (unsigned long long)xm_e4m3(res * 256.0f) << (8 * j);
+    }
+    unsigned char* blk = w8 + ((long long)cob * nchunk + chunk) * F8K_WSTEP;
+    *(unsigned long long*)(blk + f8k_offset(col, dy, mt, 0, o, row)) = ph;      // virtual channels 0..15: against x_lo8
+    *(unsigned long long*)(blk + f8k_offset(col, dy, mt, 1, o, row)) = pl;      // virtual channels 16..31: against x_hi8
+  }
+  if (tid == 0) {
+    oscale[co] = act_out / (act_in * s);
+    float b = 0.f;
+    if (gamma) { const float t = mean[co] * a; b = beta[co] - t; }
+    bias_out[co] = b * act_out;
+  }
+}
+
+// ------------------------------------------------------------------ m8 planes of a tensor that some other kernel wrote as hi + lo words
+// (first conv, max-pool, transposed conv): one thread = one voxel of one 16-channel chunk
+__global__ __launch_bounds__(256) void x2m_make8_kernel(const f16* __restrict__ x, long long x_ss, int x_lo, unsigned char* __restrict__ y8,
+                                                       long long y8_ss, int chunks, long long vox) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= vox) return;
+  const int c = blockIdx.y, n = blockIdx.z;
+  const f16* xh = x + n * x_ss + ((long long)(2 * c) * vox + i) * 8;
+  u32x4 o_lo, o_hi;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const f16x8 vh = *(const f16x8*)(xh + (long long)h * vox * 8), vl = *(const f16x8*)(xh + ((long long)h + x_lo) * vox * 8);
+    float l4[8], h8[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      l4[j] = __builtin_amdgcn_fmed3f((float)vl[j] * 16.0f, -448.0f, 448.0f);
+      h8[j] = __builtin_amdgcn_fmed3f((float)vh[j] * 0.00390625f, -448.0f, 448.0f);
+    }
+    int a = __builtin_amdgcn_cvt_pk_fp8_f32(l4[0], l4[1], 0, false);
+    a = __builtin_amdgcn_cvt_pk_fp8_f32(l4[2], l4[3], a, true);
+    int b = __builtin_amdgcn_cvt_pk_fp8_f32(l4[4], l4[5], 0, false);
+    b = __builtin_amdgcn_cvt_pk_fp8_f32(l4[6], l4[7], b, true);
+    o_lo[2 * h] = (unsigned)a; o_lo[2 * h + 1] = (unsigned)b;
+    a = __builtin_amdgcn_cvt_pk_fp8_f32(h8[0], h8[1], 0, false);
+    a = __builtin_amdgcn_cvt_pk_fp8_f32(h8[2], h8[3], a, true);
+    b = __builtin_amdgcn_cvt_pk_fp8_f32(h8[4], h8[5], 0, false);
+    b = __builtin_amdgcn_cvt_pk_fp8_f32(h8[6], h8[7], b, true);
+    o_hi[2 * h] = (unsigned)a; o_hi[2 * h + 1] = (unsigned)b;
+  }
+  unsigned char* yo = y8 + n * y8_ss + ((long long)(2 * c) * vox + i) * 16;
+  *(u32x4*)yo = o_lo;
+  *(u32x4*)(yo + vox * 16) = o_hi;
+  (void)chunks;
+}
+
+}  // namespace
+
+extern "C" {
+
+/* bytes of the K128 operator of a 3x3x3 split conv with the cross terms on the fp8 matrix cores (iunet_x2m_prep) */
+long long iunet_x2m_w8_bytes(int Cout, int Cin) { return (long long)(Cout / 32) * (Cin / 16) * F8K_WSTEP; }
+
+/* operator of a 3x3x3 stage conv in the x2m form: whi = fp32 [Cout][Cin][27] holding w_hi (feed it to iunet_pack_conv3, dtype 0, mode 2),
+ * w8 = iunet_x2m_w8_bytes bytes (the K128 operator of [w_hi8 | w_lo8]); oscale / bias_out as iunet_x2_prep */
+int iunet_x2m_prep(const void* w, void* whi, void* w8, void* oscale, void* bias_out, const void* gamma, const void* beta, const void* mean,
+                   const void* var, float eps, float act_in, float act_out, int Cout, int Cin, void* stream) {
+  IUNET_REQUIRE(w && whi && w8 && oscale && bias_out, "x2m_prep: null pointer");
+  IUNET_REQUIRE(Cout > 0 && Cout % 32 == 0 && Cin > 0 && Cin % 32 == 0, "x2m_prep: channels must be positive multiples of 32 (%d, %d)", Cout, Cin);
+  IUNET_REQUIRE(!gamma || (beta && mean && var), "x2m_prep: a BatchNorm fold needs gamma, beta, mean and var");
+  int e1, e2;
+  IUNET_REQUIRE(act_in > 0.f && act_out > 0.f && frexpf(act_in, &e1) == 0.5f && frexpf(act_out, &e2) == 0.5f,
+                "x2m_prep: the activation scales must be powers of two (got %g, %g)", act_in, act_out);
+  hipLaunchKernelGGL(x2m_prep_kernel, dim3(Cout), dim3(256), 0, (hipStream_t)stream, (const float*)w, (float*)whi, (unsigned char*)w8,
+                     (float*)oscale, (float*)bias_out, (const float*)gamma, (const float*)beta, (const float*)mean, (const float*)var,
+                     eps, act_in, act_out, Cout, Cin);
+  IUNET_CHECK_HIP(hipGetLastError());
+  return IUNET_OK;
+}
+
+/* m8 planes (x8: [2 C / 16][D][H][W][16 B] per sample, x8_ss bytes apart) of a split tensor of C channels (hi planes at x, lo planes
+ * x_lo planes further on; x_ss elements) */
+int iunet_x2m_make8(const void* x, long long x_ss, int x_lo, void* x8, long long x8_ss, int C, int N, int D, int H, int W, void* stream) {
+  IUNET_REQUIRE(x && x8, "x2m_make8: null pointer");
+  IUNET_REQUIRE(C > 0 && C % 16 == 0, "x2m_make8: C must be a multiple of 16 (got %d)", C);
+  IUNET_REQUIRE_GRID("x2m_make8", N, D, H, W);
+  const long long vox = (long long)D * H * W;
+  dim3 grid((unsigned)((vox + 255) / 256), C / 16, N);
+  hipLaunchKernelGGL(x2m_make8_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const f16*)x, x_ss, x_lo, (unsigned char*)x8, x8_ss, C / 16, vox);
+  IUNET_CHECK_HIP(hipGetLastError());
+  return IUNET_OK;
+}
+
+/* 3x3x3 stage conv of the split-precision forward, cross terms on the fp8 matrix cores.  x: Cin / 8 hi planes (x_ss elements per sample),
+ * x8: the m8 planes of the same tensor (x8_ss bytes per sample); y: Cout / 8 hi planes, the lo planes y_lo planes further on (y_lo < 0: no
+ * lo planes -- a tensor only 3x3x3 convs read), y8: its m8 planes or null; w16 / w8 / oscale / bias from iunet_x2m_prep (+ iunet_pack_conv3);
+ * epi as iunet_conv3_fwd; sat: optional device int, raised (atomicMax) to the bit pattern of a saturated hi word */
+int iunet_x2m_conv3_fwd(const void* x, long long x_ss, const void* x8, long long x8_ss, void* y, long long y_ss, int y_lo, void* y8,
+                        long long y8_ss, const void* w16, const void* w8, const void* oscale, const void* bias, int N, int D, int H, int W,
+                        int Cin, int Cout, int epi, void* sat, void* stream) {
+  IUNET_REQUIRE(x && x8 && y && w16 && w8 && oscale, "x2m_conv3: null pointer");
+  IUNET_REQUIRE_GRID("x2m_conv3", N, D, H, W);
+  IUNET_REQUIRE(Cin >= 32 && Cout >= 32 && Cin % 32 == 0 && Cout % 32 == 0, "x2m_conv3: channels must be positive multiples of 32 (%d -> %d)", Cin, Cout);
+  IUNET_REQUIRE(epi >= 0 && epi <= 2, "x2m_conv3: bad epilogue %d", epi);
+  IUNET_REQUIRE(epi == 0 || bias != nullptr, "x2m_conv3: epilogue %d needs a bias", epi);
+  ConvX2MParams p;
+  p.x = x; p.x_sstride = x_ss; p.x8 = x8; p.x8_sstride = x8_ss; p.y = y; p.y_sstride = y_ss; p.y_lo = y_lo; p.y8 = y8; p.y8_sstride = y8_ss;
+  p.w16 = w16; p.w8 = w8; p.oscale = (const float*)oscale; p.bias = (const float*)bias;
+  p.N = N; p.D = D; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.epi = epi; p.sat = (int*)sat;
+  p.tilesZ = p.tilesY = p.tilesX = 0;
+  p.bz = p.by = p.bx = p.nbz = p.nby = p.nbx = 0;
+  // the tile size follows the grid as in the 16-bit launch; the summation order of a voxel does not depend on it
+  const long long big_tiles = (long long)N * ((D + 3) / 4) * ((H + 7) / 8) * ((W + 15) / 16);
+  const bool small = big_tiles * (Cout / 32) < 128;
+  return small ? launch_x2m<true>(p, (hipStream_t)stream) : launch_x2m<false>(p, (hipStream_t)stream);
+}
+
+}  // extern "C"
