@@ -219,6 +219,16 @@ int iunet_x2m_prep(const void* w, void* whi, void* w8, void* oscale, void* bias_
                    const void* var, float eps, float act_in, float act_out, int Cout, int Cin, void* stream);
 /* m8 planes (x8_ss bytes per sample) of a split tensor that another kernel wrote as hi + lo words (x_ss fp16 elements per sample) */
 int iunet_x2m_make8(const void* x, long long x_ss, int x_lo, void* x8, long long x8_ss, int C, int N, int D, int H, int W, void* stream);
+/* producers of the x2m form: iunet_x2_first_conv_fwd / iunet_x2_convT_fwd writing, beside the hi planes, the m8 planes of their output
+ * (y8, bytes per sample; null: none) and the lo planes only when y_lo >= 0; the max-pool on (hi, m8): the larger hi + lo8 / 16 wins, its hi
+ * word and m8 bytes are copied (Do, Ho, Wo = output grid) */
+int iunet_x2m_first_conv_fwd(int nd, const void* x, int in_dtype, const long long* in_strides, void* y, long long y_sstride, int y_lo,
+                             void* y8, long long y8_sstride, const void* w, const void* oscale, const void* bias, float act_scale, int N,
+                             int D, int H, int W, int Cin, int Cout, int relu, void* stream);
+int iunet_x2m_convT_fwd(int nd, const void* x, long long x_ss, int x_lo, void* y, long long y_ss, int y_lo, void* y8, long long y8_ss,
+                        const void* wpk, const void* oscale, const void* bias, int N, int D, int H, int W, int Cin, int Cout, void* stream);
+int iunet_x2m_maxpool_fwd(int nd, const void* x, long long x_ss, const void* x8, long long x8_ss, void* y, long long y_ss, void* y8,
+                          long long y8_ss, int C, int N, int Do, int Ho, int Wo, void* stream);
 /* the stage conv: x = Cin / 8 hi planes + x8 = its m8 planes; y = Cout / 8 hi planes (+ lo planes y_lo planes further on unless
  * y_lo < 0) + y8 = its m8 planes (or null); sat: optional device int raised to the bit pattern of a saturated (|v| >= 65504) hi word */
 int iunet_x2m_conv3_fwd(const void* x, long long x_ss, const void* x8, long long x8_ss, void* y, long long y_ss, int y_lo, void* y8,
@@ -232,8 +242,10 @@ int iunet_x2m_conv3_fwd(const void* x, long long x_ss, const void* x8, long long
  *   flat = device floats [iunet_net_num_params(net)] filled tensor by tensor (iunet_net_param gives name / offset / count)
  *   packed = device bytes [iunet_net_packed_bytes(net)];  iunet_net_load(net, flat, packed, stream);
  *   ws = device bytes [iunet_net_workspace_bytes(net, N, 1, H, W)];  iunet_net_forward_argmax(net, x_u8, cls_u8, N, 1, H, W, ws, stream);
- * mode: 0 fp16, 1 bf16 (16-bit activations), 2 fp16x2 (split precision: logits within 1e-3 of the fp32 predict); act_scale: a
- * power of two, mode 2 only (0 = default 64). */
+ * mode: 0 fp16, 1 bf16 (16-bit activations), 2 fp16x2 (split precision: logits within 1e-3 of the fp32 predict), 3 (3-D only) fp16x2 with
+ * the cross terms of the stage convs on the fp8 matrix cores (the x2m entry points above: two matrix-step units per 16 input channels
+ * instead of three; the first 4 bytes of its workspace are an int the stage convs raise to 0x7bff when a stored activation word saturates
+ * at 65504 -- zero it once, read it when convenient); act_scale: a power of two, modes 2 / 3 only (0 = default 64). */
 typedef struct iunet_net iunet_net;
 int iunet_net_create(int dim, int levels, int base, int cin, int ncls, int mode, float act_scale, iunet_net** out);
 void iunet_net_destroy(iunet_net* net);

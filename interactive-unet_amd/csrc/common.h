@@ -202,6 +202,41 @@ __device__ __forceinline__ void e4m3_store8(unsigned char* y, int pl8, long long
   *(u32x2_t*)(y + ((long long)(pl8 >> 1) * nvox + vox) * 16 + (pl8 & 1) * 8) = u32x2_t{lo, hi};
 }
 
+// ---- "m8" planes of the split-precision forward with its cross terms on the fp8 matrix cores (conv3_x2m.hip): beside its fp16 hi
+// planes a tensor carries 2 C / 16 e4m3 planes [D][H][W][16 B], plane 2c = e4m3((v - hi) * 2^4), plane 2c + 1 = e4m3(hi * 2^-8) of the
+// 16-channel chunk c.  8 fp32 values -> 8 e4m3 bytes (round to nearest even, saturating at +-448)
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u32x2_t x2m_pack8(const float (&f)[8]) {
+  float c[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) c[j] = __builtin_amdgcn_fmed3f(f[j], -448.0f, 448.0f);
+  int a = __builtin_amdgcn_cvt_pk_fp8_f32(c[0], c[1], 0, false);
+  a = __builtin_amdgcn_cvt_pk_fp8_f32(c[2], c[3], a, true);
+  int b = __builtin_amdgcn_cvt_pk_fp8_f32(c[4], c[5], 0, false);
+  b = __builtin_amdgcn_cvt_pk_fp8_f32(c[6], c[7], b, true);
+  return u32x2_t{(unsigned)a, (unsigned)b};
+}
+// this lane's 8 values r[j] (fp32, scaled by act_scale) -> hi words, lo words and its two half-granules of the m8 planes
+__device__ __forceinline__ void x2m_split8(const float (&r)[8], f16x8& hi, f16x8& lo, u32x2_t& lo8, u32x2_t& hi8) {
+  float l4[8], h8[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float v = fminf(fmaxf(r[j], -65504.f), 65504.f);
+    const f16 h = (f16)v;
+    const float res = v - (float)h;                            // exact in fp32
+    hi[j] = h; lo[j] = (f16)res;
+    l4[j] = res * 16.0f;
+    h8[j] = (float)h * 0.00390625f;
+  }
+  lo8 = x2m_pack8(l4);
+  hi8 = x2m_pack8(h8);
+}
+// byte offset, inside the m8 planes of one sample, of the half-granule that holds the 8 channels of 8-channel plane `pl8` at voxel
+// `vox` (lo8; the hi8 half-granule is one plane = nvox * 16 bytes further on)
+__device__ __forceinline__ long long x2m_off(int pl8, long long vox, long long nvox) {
+  return ((long long)(2 * (pl8 >> 1)) * nvox + vox) * 16 + (pl8 & 1) * 8;
+}
+
 // ---- K = 128 operator order of the fp8 convolution (conv3_f8k.hip; written by pack_batch.hip kind 5 and conv3_f8.hip: pack_f8_kernel)
 // filter column (dz * 3 + dx) of K = 128 group g, lane group q: {0, 3, 1, 4 | 2, 5, 6, 7} -- the lane groups 0 / 1 and 2 / 3 of one
 // LDS pass differ in dz only; column 8 goes to the K = 32 instruction

@@ -30,7 +30,7 @@ namespace {
 
 typedef long i64;
 typedef int i32x8 __attribute__((ext_vector_type(8)));
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef u32x2_t u32x2;
 
 template <bool SMALL> struct XMTile { static constexpr int TZ = SMALL ? 2 : 4, TY = 8, TX = 16, NCW = SMALL ? 4 : 8; };
 constexpr int XM_NLT = 256;                                    // loader threads (everything moves by LDS-DMA)
@@ -52,30 +52,6 @@ struct ConvX2MParams {
   int epi;
   int* sat;                                   // optional: the largest |hi| bit pattern stored by this launch (atomicMax; range check)
 };
-
-// this lane's 8 values r[j] (fp32, scaled) -> hi words, lo words, and the two half-granules of the m8 planes
-__device__ __forceinline__ void xm_split8(const float (&r)[8], f16x8& hi, f16x8& lo, u32x2& lo8, u32x2& hi8) {
-  float l4[8], h8[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const float v = fminf(fmaxf(r[j], -65504.f), 65504.f);
-    const f16 h = (f16)v;
-    const float res = v - (float)h;                            // exact in fp32
-    hi[j] = h; lo[j] = (f16)res;
-    l4[j] = __builtin_amdgcn_fmed3f(res * 16.0f, -448.0f, 448.0f);
-    h8[j] = __builtin_amdgcn_fmed3f((float)h * 0.00390625f, -448.0f, 448.0f);
-  }
-  int a = __builtin_amdgcn_cvt_pk_fp8_f32(l4[0], l4[1], 0, false);
-  a = __builtin_amdgcn_cvt_pk_fp8_f32(l4[2], l4[3], a, true);
-  int b = __builtin_amdgcn_cvt_pk_fp8_f32(l4[4], l4[5], 0, false);
-  b = __builtin_amdgcn_cvt_pk_fp8_f32(l4[6], l4[7], b, true);
-  lo8 = u32x2{(unsigned)a, (unsigned)b};
-  a = __builtin_amdgcn_cvt_pk_fp8_f32(h8[0], h8[1], 0, false);
-  a = __builtin_amdgcn_cvt_pk_fp8_f32(h8[2], h8[3], a, true);
-  b = __builtin_amdgcn_cvt_pk_fp8_f32(h8[4], h8[5], 0, false);
-  b = __builtin_amdgcn_cvt_pk_fp8_f32(h8[6], h8[7], b, true);
-  hi8 = u32x2{(unsigned)a, (unsigned)b};
-}
 
 template <bool SMALL>
 __global__ __launch_bounds__((XMTile<SMALL>::NCW * 64 + XM_NLT), 1) void conv3_x2m_kernel(ConvX2MParams p) {
@@ -383,12 +359,12 @@ __global__ __launch_bounds__((XMTile<SMALL>::NCW * 64 + XM_NLT), 1) void conv3_x
       }
       f16x8 hi, lo;
       u32x2 lo8, hi8;
-      xm_split8(r, hi, lo, lo8, hi8);
+      x2m_split8(r, hi, lo, lo8, hi8);
       if (ok) {
         *(f16x8*)(yout + (long long)(cob * 4 + q) * plane_stride + vo * 8) = hi;
         if (p.y_lo >= 0) *(f16x8*)(yout + (long long)(p.y_lo + cob * 4 + q) * plane_stride + vo * 8) = lo;
         if (p.y8 != nullptr) {
-          unsigned char* y8 = (unsigned char*)p.y8 + (long long)n_img * p.y8_sstride + (long long)(2 * (cob * 2 + (q >> 1))) * plane16b + vo * 16 + (q & 1) * 8;
+          unsigned char* y8 = (unsigned char*)p.y8 + (long long)n_img * p.y8_sstride + x2m_off(cob * 4 + q, vo, plane16b / 16);
           *(u32x2*)y8 = lo8;
           *(u32x2*)(y8 + plane16b) = hi8;
         }
@@ -538,6 +514,61 @@ __global__ __launch_bounds__(256) void x2m_make8_kernel(const f16* __restrict__ 
   (void)chunks;
 }
 
+// ------------------------------------------------------------------ max-pool 2^d on (hi, m8): the larger hi + lo8 / 16 wins and its hi word
+// and m8 bytes are copied -- the pooled tensor holds exactly the values its source holds for a 3x3x3 consumer.  One thread = one output
+// voxel of one 8-channel plane.
+template <int ND>
+__global__ __launch_bounds__(256) void x2m_maxpool_kernel(const f16* __restrict__ x, long long x_ss, const unsigned char* __restrict__ x8,
+                                                         long long x8_ss, f16* __restrict__ y, long long y_ss, unsigned char* __restrict__ y8,
+                                                         long long y8_ss, int planes, int Do, int Ho, int Wo) {
+  const long long ovox = (long long)Do * Ho * Wo;
+  const long long total = ovox * planes;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int n = blockIdx.y;
+  const int pl = (int)(i / ovox);
+  const long long r = i - (long long)pl * ovox;
+  const int ox = (int)(r % Wo), oy = (int)((r / Wo) % Ho), oz = (int)(r / ((long long)Wo * Ho));
+  const int Di = ND == 3 ? Do * 2 : 1, Hi = Ho * 2, Wi = Wo * 2;
+  const long long ivox = (long long)Di * Hi * Wi;
+  const f16* xh = x + n * x_ss + (long long)pl * ivox * 8;
+  const unsigned char* xm = x8 + n * x8_ss;
+  float m[8];
+  f16x8 oh;
+  unsigned char b_lo[8], b_hi[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { m[j] = -INFINITY; b_lo[j] = 0; b_hi[j] = 0; oh[j] = (f16)0.f; }
+#pragma unroll
+  for (int a = 0; a < (ND == 3 ? 2 : 1); ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int z = ND == 3 ? oz * 2 + a : 0;
+        const long long vi = ((long long)z * Hi + oy * 2 + b) * Wi + ox * 2 + c;
+        const f16x8 vh = *(const f16x8*)(xh + vi * 8);
+        const unsigned char* g = xm + x2m_off(pl, vi, ivox);
+        const u32x2 l8 = *(const u32x2*)g, h8 = *(const u32x2*)(g + ivox * 16);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const unsigned wl = j < 4 ? l8[0] : l8[1], wh = j < 4 ? h8[0] : h8[1];
+          const float lo = (j & 3) == 0 ? __builtin_amdgcn_cvt_f32_fp8((int)wl, 0) : (j & 3) == 1 ? __builtin_amdgcn_cvt_f32_fp8((int)wl, 1)
+                         : (j & 3) == 2 ? __builtin_amdgcn_cvt_f32_fp8((int)wl, 2) : __builtin_amdgcn_cvt_f32_fp8((int)wl, 3);
+          const float v = (float)vh[j] + lo * 0.0625f;
+          if (v > m[j]) { m[j] = v; oh[j] = vh[j]; b_lo[j] = (unsigned char)(wl >> (8 * (j & 3))); b_hi[j] = (unsigned char)(wh >> (8 * (j & 3))); }
+        }
+      }
+  *(f16x8*)(y + n * y_ss + (long long)pl * ovox * 8 + r * 8) = oh;
+  u32x2 ol, ohh;
+  ol[0] = b_lo[0] | (b_lo[1] << 8) | (b_lo[2] << 16) | ((unsigned)b_lo[3] << 24);
+  ol[1] = b_lo[4] | (b_lo[5] << 8) | (b_lo[6] << 16) | ((unsigned)b_lo[7] << 24);
+  ohh[0] = b_hi[0] | (b_hi[1] << 8) | (b_hi[2] << 16) | ((unsigned)b_hi[3] << 24);
+  ohh[1] = b_hi[4] | (b_hi[5] << 8) | (b_hi[6] << 16) | ((unsigned)b_hi[7] << 24);
+  unsigned char* yo = y8 + n * y8_ss + x2m_off(pl, r, ovox);
+  *(u32x2*)yo = ol;
+  *(u32x2*)(yo + ovox * 16) = ohh;
+}
+
 }  // namespace
 
 extern "C" {
@@ -571,6 +602,23 @@ int iunet_x2m_make8(const void* x, long long x_ss, int x_lo, void* x8, long long
   const long long vox = (long long)D * H * W;
   dim3 grid((unsigned)((vox + 255) / 256), C / 16, N);
   hipLaunchKernelGGL(x2m_make8_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const f16*)x, x_ss, x_lo, (unsigned char*)x8, x8_ss, C / 16, vox);
+  IUNET_CHECK_HIP(hipGetLastError());
+  return IUNET_OK;
+}
+
+/* 2^d max-pool of a tensor in the x2m form: hi planes + m8 planes in (x_ss elements / x8_ss bytes per sample), the same out; Do, Ho, Wo =
+ * output grid.  The winner is the larger hi + lo8 / 16 (what a 3x3x3 consumer would read); its hi word and m8 bytes are copied. */
+int iunet_x2m_maxpool_fwd(int nd, const void* x, long long x_ss, const void* x8, long long x8_ss, void* y, long long y_ss, void* y8,
+                          long long y8_ss, int C, int N, int Do, int Ho, int Wo, void* stream) {
+  IUNET_REQUIRE(x && x8 && y && y8, "x2m_maxpool: null pointer");
+  IUNET_REQUIRE(nd == 2 || nd == 3, "x2m_maxpool: nd must be 2 or 3");
+  IUNET_REQUIRE(C > 0 && C % 16 == 0 && N > 0 && Do > 0 && Ho > 0 && Wo > 0, "x2m_maxpool: bad shape");
+  const long long total = (long long)Do * Ho * Wo * (C / 8);
+  dim3 grid((unsigned)((total + 255) / 256), N);
+  if (nd == 3) hipLaunchKernelGGL((x2m_maxpool_kernel<3>), grid, dim3(256), 0, (hipStream_t)stream, (const f16*)x, x_ss, (const unsigned char*)x8, x8_ss,
+                                  (f16*)y, y_ss, (unsigned char*)y8, y8_ss, C / 8, Do, Ho, Wo);
+  else hipLaunchKernelGGL((x2m_maxpool_kernel<2>), grid, dim3(256), 0, (hipStream_t)stream, (const f16*)x, x_ss, (const unsigned char*)x8, x8_ss,
+                          (f16*)y, y_ss, (unsigned char*)y8, y8_ss, C / 8, Do, Ho, Wo);
   IUNET_CHECK_HIP(hipGetLastError());
   return IUNET_OK;
 }

@@ -3,7 +3,8 @@
 // iunet_net_param), let it fold / scale / pack them into a caller-owned device buffer, then run forwards on a caller-owned workspace.
 // The launch graph that interactive_unet/engine.py and engine_x2.py sequence from Python is sequenced here in C++ from the same entry
 // points.  Modes: 2 = fp16x2 split precision (the tolerance-meeting default: logits within 1e-3 of the fp32 reference predict,
-// predict.py:30-35), 0 / 1 = fp16 / bf16 activations (the throughput path).  No device allocation, no synchronisation: the handle is
+// predict.py:30-35), 3 = the same with the cross terms of the 3-D stage convs on the fp8 matrix cores (conv3_x2m.hip: what the 3-D
+// prediction runs), 0 / 1 = fp16 / bf16 activations (the throughput path).  No device allocation, no synchronisation: the handle is
 // host memory only.
 #include "common.h"
 #include <cstdio>
@@ -23,6 +24,15 @@ int iunet_x2_convT_fwd(int, const void*, long long, int, void*, long long, int, 
                        int, int, void*);
 int iunet_x2_head_fwd(const void*, long long, int, int, const void*, const void*, float, int, void*, void*, void*, const long long*, float,
                       int, int, int, int, int, void*);
+int iunet_x2m_prep(const void*, void*, void*, void*, void*, const void*, const void*, const void*, const void*, float, float, float, int, int, void*);
+int iunet_x2m_first_conv_fwd(int, const void*, int, const long long*, void*, long long, int, void*, long long, const void*, const void*, const void*,
+                             float, int, int, int, int, int, int, int, void*);
+int iunet_x2m_convT_fwd(int, const void*, long long, int, void*, long long, int, void*, long long, const void*, const void*, const void*, int, int,
+                        int, int, int, int, void*);
+int iunet_x2m_maxpool_fwd(int, const void*, long long, const void*, long long, void*, long long, void*, long long, int, int, int, int, int, void*);
+int iunet_x2m_conv3_fwd(const void*, long long, const void*, long long, void*, long long, int, void*, long long, const void*, const void*,
+                        const void*, const void*, int, int, int, int, int, int, int, void*, void*);
+long long iunet_x2m_w8_bytes(int, int);
 int iunet_pack_conv3(int, const void*, const void*, void*, int, int, int, int, void*);
 int iunet_pack_first_conv(int, const void*, const void*, void*, int, int, int, void*);
 int iunet_pack_convT(int, const void*, void*, int, int, int, void*);
@@ -64,7 +74,7 @@ struct Param { std::string name; long long off, numel; };
 struct ConvOp {                       // one stage conv (or the first conv): where its parameters and packed operators live
   int ci, co, first;
   long long w, bn;                    // flat-parameter offsets: weight; gamma (beta, mean, var follow, co each)
-  long long pk[4];                    // packed-buffer byte offsets by layout (0, 1 = K16, 3 = compact; -1 = absent); x2: pk[1]
+  long long pk[4];                    // packed-buffer byte offsets by layout (0, 1 = K16, 3 = compact; -1 = absent); x2: pk[1]; x2m: pk[1] = w_hi (K16), pk[0] = K128 bytes
   long long aux;                      // x2: [oscale co | bias co] floats; 16-bit: [scale co | bias co]
 };
 struct UpOp { int ci, co; long long w, b, pk, aux; };
@@ -90,15 +100,29 @@ namespace {
 
 int stage_index(const iunet_net* n, bool dec, int l) { return dec ? n->levels + (n->levels - 2 - l) : l; }
 
-struct WsLayout { std::vector<long long> a, b, cat, pin; long long bytes; };
+struct WsLayout { std::vector<long long> a, b, cat, pin, am, catm, pinm; long long bytes; };
 
-// activation buffers of one forward (elements of 2 bytes; x2 holds hi + lo planes: twice the channels)
+// activation buffers of one forward (elements of 2 bytes; x2 holds hi + lo planes: twice the channels).  x2m (mode 3): the first 256
+// bytes hold the range flag (an int the stage convs raise to 0x7bff when a stored hi word saturates; the caller zeroes it once), a / cat /
+// pin are hi planes + m8 planes (2 bytes per element), b hi + lo planes
 WsLayout ws_layout(const iunet_net* n, int N, int D, int H, int W) {
   WsLayout L;
   const int lv = n->levels, mul = n->mode == 2 ? 2 : 1;
-  long long off = 0;
+  long long off = n->mode == 3 ? 256 : 0;
   auto take = [&](long long elems) { const long long o = off; off = align256(off + elems * 2); return o; };
   L.a.resize(lv); L.b.resize(lv); L.cat.resize(lv, -1); L.pin.resize(lv, -1);
+  L.am.resize(lv, -1); L.catm.resize(lv, -1); L.pinm.resize(lv, -1);
+  if (n->mode == 3) {
+    for (int l = 0; l < lv; ++l) {
+      const long long v = (long long)(D >> l) * (H >> l) * (W >> l);
+      L.a[l] = take((long long)N * n->ch[l] * v); L.am[l] = take((long long)N * n->ch[l] * v);
+      L.b[l] = take((long long)N * 2 * n->ch[l] * v);
+      if (l < lv - 1) { L.cat[l] = take((long long)N * 2 * n->ch[l] * v); L.catm[l] = take((long long)N * 2 * n->ch[l] * v); }
+      if (l > 0) { L.pin[l] = take((long long)N * n->ch[l - 1] * v); L.pinm[l] = take((long long)N * n->ch[l - 1] * v); }
+    }
+    L.bytes = off;
+    return L;
+  }
   for (int l = 0; l < lv; ++l) {
     const long long v = (long long)(n->dim == 3 ? D >> l : 1) * (H >> l) * (W >> l);
     L.a[l] = take((long long)N * mul * n->ch[l] * v);
@@ -114,7 +138,8 @@ WsLayout ws_layout(const iunet_net* n, int N, int D, int H, int W) {
 
 extern "C" {
 
-/* mode: 0 fp16, 1 bf16, 2 fp16x2 (split precision); act_scale: power of two (mode 2 only; 0 = the default 64) */
+/* mode: 0 fp16, 1 bf16, 2 fp16x2 (split precision), 3 fp16x2 with the cross terms of the stage convs on the fp8 matrix cores (3-D only);
+ * act_scale: power of two (modes 2, 3; 0 = the default 64) */
 int iunet_net_create(int dim, int levels, int base, int cin, int ncls, int mode, float act_scale, iunet_net** out) {
   IUNET_REQUIRE(out != nullptr, "net_create: null handle pointer");
   IUNET_REQUIRE(dim == 2 || dim == 3, "net_create: dim must be 2 or 3 (got %d)", dim);
@@ -122,7 +147,8 @@ int iunet_net_create(int dim, int levels, int base, int cin, int ncls, int mode,
   IUNET_REQUIRE(base > 0 && base % 32 == 0, "net_create: base channels must be a positive multiple of 32 (got %d)", base);
   IUNET_REQUIRE(cin >= 1 && cin <= 4, "net_create: 1..4 input channels (got %d)", cin);
   IUNET_REQUIRE(ncls >= 2 && ncls <= 10, "net_create: 2..10 classes (app.py:162; got %d)", ncls);
-  IUNET_REQUIRE(mode >= 0 && mode <= 2, "net_create: mode must be 0 (fp16), 1 (bf16) or 2 (fp16x2), got %d", mode);
+  IUNET_REQUIRE(mode >= 0 && mode <= 3, "net_create: mode must be 0 (fp16), 1 (bf16), 2 (fp16x2) or 3 (fp16x2, cross terms on fp8), got %d", mode);
+  IUNET_REQUIRE(mode != 3 || dim == 3, "net_create: mode 3 (cross terms on the K = 128 fp8 instruction) is 3-D only");
   iunet_net* n = new iunet_net();
   n->dim = dim; n->levels = levels; n->base = base; n->cin = cin; n->ncls = ncls; n->mode = mode;
   n->act_scale = act_scale > 0.f ? act_scale : 64.0f;
@@ -140,9 +166,12 @@ int iunet_net_create(int dim, int levels, int base, int cin, int ncls, int mode,
       op.w = add(c + ".weight", (long long)co * op.ci * n->taps);
       op.bn = add(b + ".weight", co); add(b + ".bias", co); add(b + ".running_mean", co); add(b + ".running_var", co);
       for (int k = 0; k < 4; ++k) op.pk[k] = -1;
-      const int vci = mode == 2 ? 3 * op.ci : op.ci;
+      const int vci = (mode == 2 || (mode == 3 && op.first)) ? 3 * op.ci : op.ci;
       if (op.first) op.pk[1] = pk_take(iunet_pack_first_conv_elems(co, vci, n->taps) * 2);
-      else {
+      else if (mode == 3) {
+        op.pk[1] = pk_take(iunet_pack_conv3_elems(co, op.ci, n->taps, 2) * 2);
+        op.pk[0] = pk_take(iunet_x2m_w8_bytes(co, op.ci));
+      } else {
         op.pk[1] = pk_take(iunet_pack_conv3_elems(co, vci, n->taps, mode == 2 ? iunet_x2_pack_mode(dim) : 2) * 2);
         if (mode != 2) {          // the layouts a 16-bit launch may pick (interactive_unet/_native.py: PackedConv)
           const bool compact2d = n->taps == 9 && iunet_conv3_compact_ok(2, 1, 1, 16, 32, op.ci, co, 0, 0);      // (off: IUNET_NO_COMPACT2D)
@@ -151,7 +180,7 @@ int iunet_net_create(int dim, int levels, int base, int cin, int ncls, int mode,
         }
       }
       op.aux = pk_take(2ll * co * 4);
-      if (mode == 2 && 3ll * co * op.ci * n->taps > max_virtual) max_virtual = 3ll * co * op.ci * n->taps;
+      if (mode >= 2 && 3ll * co * op.ci * n->taps > max_virtual) max_virtual = 3ll * co * op.ci * n->taps;
       n->conv.push_back(op);
     }
   };
@@ -162,9 +191,9 @@ int iunet_net_create(int dim, int levels, int base, int cin, int ncls, int mode,
     const std::string p = "dec" + std::to_string(l);
     u.w = add(p + ".up.weight", (long long)u.ci * u.co * n->npos);
     u.b = add(p + ".up.bias", u.co);
-    u.pk = pk_take((long long)(mode == 2 ? 2 : 1) * u.ci * u.co * n->npos * 2);
+    u.pk = pk_take((long long)(mode >= 2 ? 2 : 1) * u.ci * u.co * n->npos * 2);
     u.aux = pk_take(2ll * u.co * 4);
-    if (mode == 2 && 2ll * u.ci * u.co * n->npos > max_virtual) max_virtual = 2ll * u.ci * u.co * n->npos;
+    if (mode >= 2 && 2ll * u.ci * u.co * n->npos > max_virtual) max_virtual = 2ll * u.ci * u.co * n->npos;
     n->up.push_back(u);
     stage(p, 2 * n->ch[l], n->ch[l]);
   }
@@ -211,7 +240,14 @@ int iunet_net_load(iunet_net* n, const void* flat_params, void* packed, void* st
     const float *g = P + op.bn, *be = g + op.co, *mu = be + op.co, *va = mu + op.co;
     float* aux = (float*)(K + op.aux);
     int rc;
-    if (n->mode == 2) {
+    if (n->mode == 3 && !op.first) {
+      float* whi = (float*)(K + n->scratch_off);
+      IUNET_CHECK_HIP(hipMemsetAsync(K + op.pk[0], 0, (size_t)iunet_x2m_w8_bytes(op.co, op.ci), (hipStream_t)stream));
+      rc = iunet_x2m_prep(w, whi, K + op.pk[0], aux, aux + op.co, g, be, mu, va, eps, A, A, op.co, op.ci, stream);
+      if (rc) return rc;
+      rc = iunet_pack_conv3(0, whi, nullptr, K + op.pk[1], op.co, op.ci, n->taps, 2, stream);
+      if (rc) return rc;
+    } else if (n->mode >= 2) {
       float* wv = (float*)(K + n->scratch_off);
       rc = iunet_x2_prep(w, wv, aux, aux + op.co, g, be, mu, va, nullptr, eps, A, A, op.co, op.ci, n->taps, 0,
                          op.first ? op.ci : (n->dim == 3 ? 16 : 32), stream);
@@ -235,7 +271,7 @@ int iunet_net_load(iunet_net* n, const void* flat_params, void* packed, void* st
   for (const UpOp& u : n->up) {
     float* aux = (float*)(K + u.aux);
     int rc;
-    if (n->mode == 2) {
+    if (n->mode >= 2) {
       float* wv = (float*)(K + n->scratch_off);
       rc = iunet_x2_prep(P + u.w, wv, aux, aux + u.co, nullptr, nullptr, nullptr, nullptr, P + u.b, eps, A, A, u.co, u.ci, n->npos, 2, 0, stream);
       if (!rc) rc = iunet_pack_convT(0, wv, K + u.pk, 2 * u.ci, u.co, n->npos, stream);
@@ -271,6 +307,74 @@ int iunet_net_forward(iunet_net* n, const void* x, int in_dtype, const long long
   unsigned char* WS = (unsigned char*)workspace;
   unsigned char* K = n->packed;
   const int lv = n->levels, dim = n->dim, mode = n->mode;
+  if (mode == 3) {
+    // ---- x2m: a / cat / pin = (hi planes, m8 planes), b = (hi planes, lo planes); engine_x2.EngineX2._infer_mixed sequences the same launches
+    const float A = n->act_scale;
+    void* sat = WS;
+    auto dims3 = [&](int l, int& d, int& h, int& w) { d = D >> l; h = H >> l; w = W >> l; };
+    auto vox3 = [&](int l) { return (long long)(D >> l) * (H >> l) * (W >> l); };
+    auto convm = [&](const ConvOp& op, long long xo, long long x_ss, long long x8o, long long x8_ss, long long yo, long long y_ss, int y_lo,
+                     long long y8o, long long y8_ss, int l) -> int {
+      int d, h, w;
+      dims3(l, d, h, w);
+      const float* aux = (const float*)(K + op.aux);
+      return iunet_x2m_conv3_fwd(WS + xo, x_ss, WS + x8o, x8_ss, WS + yo, y_ss, y_lo, y8o >= 0 ? WS + y8o : nullptr, y8_ss, K + op.pk[1], K + op.pk[0],
+                                 aux, aux + op.co, N, d, h, w, op.ci, op.co, 2, sat, stream);
+    };
+    int rc = 0;
+    for (int l = 0; l < lv; ++l) {
+      int d, h, w;
+      dims3(l, d, h, w);
+      const long long v = vox3(l);
+      const int c = n->ch[l];
+      const ConvOp& c1 = n->conv[2 * stage_index(n, false, l)];
+      const ConvOp& c2 = n->conv[2 * stage_index(n, false, l) + 1];
+      if (l == 0) {
+        const float* aux = (const float*)(K + c1.aux);
+        rc = iunet_x2m_first_conv_fwd(dim, x, in_dtype, in_strides, WS + L.a[0], (long long)c * v, -1, WS + L.am[0], 2ll * c * v, K + c1.pk[1], aux,
+                                      aux + c, A, N, d, h, w, n->cin, c, 1, stream);
+      } else {
+        const int cp = n->ch[l - 1];
+        rc = convm(c1, L.pin[l], (long long)cp * v, L.pinm[l], 2ll * cp * v, L.a[l], (long long)c * v, -1, L.am[l], 2ll * c * v, l);
+      }
+      if (rc) return rc;
+      if (l < lv - 1) {
+        rc = convm(c2, L.a[l], (long long)c * v, L.am[l], 2ll * c * v, L.cat[l], 2ll * c * v, -1, L.catm[l], 4ll * c * v, l);
+        if (rc) return rc;
+        int dn, hn, wn;
+        dims3(l + 1, dn, hn, wn);
+        rc = iunet_x2m_maxpool_fwd(dim, WS + L.cat[l], 2ll * c * v, WS + L.catm[l], 4ll * c * v, WS + L.pin[l + 1], (long long)c * vox3(l + 1),
+                                   WS + L.pinm[l + 1], 2ll * c * vox3(l + 1), c, N, dn, hn, wn, stream);
+      } else {
+        rc = convm(c2, L.a[l], (long long)c * v, L.am[l], 2ll * c * v, L.b[l], 2ll * c * v, c / 8, -1, 0, l);
+      }
+      if (rc) return rc;
+    }
+    for (int l = lv - 2; l >= 0; --l) {
+      int di, hi, wi;
+      dims3(l + 1, di, hi, wi);
+      const long long v = vox3(l), vi = vox3(l + 1);
+      const int c = n->ch[l], cn = n->ch[l + 1];
+      const UpOp& u = n->up[lv - 2 - l];
+      const float* aux = (const float*)(K + u.aux);
+      // up half of the concat buffer: hi planes [c / 8, 2 c / 8), m8 planes [2 c / 16, 4 c / 16)
+      rc = iunet_x2m_convT_fwd(dim, WS + L.b[l + 1], 2ll * cn * vi, cn / 8, WS + L.cat[l] + (long long)(c / 8) * v * 16, 2ll * c * v, -1,
+                               WS + L.catm[l] + (long long)(2 * c / 16) * v * 16, 4ll * c * v, K + u.pk, aux, aux + c, N, di, hi, wi, cn, c, stream);
+      if (rc) return rc;
+      const ConvOp& c1 = n->conv[2 * stage_index(n, true, l)];
+      const ConvOp& c2 = n->conv[2 * stage_index(n, true, l) + 1];
+      rc = convm(c1, L.cat[l], 2ll * c * v, L.catm[l], 4ll * c * v, L.a[l], (long long)c * v, -1, L.am[l], 2ll * c * v, l);
+      if (rc) return rc;
+      rc = convm(c2, L.a[l], (long long)c * v, L.am[l], 2ll * c * v, L.b[l], 2ll * c * v, c / 8, -1, 0, l);
+      if (rc) return rc;
+    }
+    if (!logits && !probs && !cls) return IUNET_OK;
+    const long long v0 = vox3(0);
+    const long long dflt[5] = {n->ncls * v0, v0, (long long)H * W, W, 1};
+    const int c0 = n->ch[0];
+    return iunet_x2_head_fwd(WS + L.b[0], 2ll * c0 * v0, c0 / 8, c0, n->flat + n->head_w, n->flat + n->head_b, A, n->ncls, logits, probs, cls,
+                             out_strides ? out_strides : dflt, divisor, accumulate, N, D, H, W, stream);
+  }
   const bool x2 = mode == 2;
   const int mul = x2 ? 2 : 1;
   auto dims = [&](int l, int& d, int& h, int& w) { d = dim == 3 ? D >> l : 1; h = H >> l; w = W >> l; };

@@ -103,7 +103,8 @@ __global__ __launch_bounds__(256) void x2_prep_kernel(const float* __restrict__ 
 // ------------------------------------------------------------------ first conv
 struct X2FirstParams {
   const void* x; long long sN, sC, sD, sH, sW; int in_dtype;       // caller's tensor, generic element strides; 0 f32, 1 f16, 2 u8 (/ 255), 3 bf16
-  void* y; long long y_sstride; int y_lo;
+  void* y; long long y_sstride; int y_lo;             // y_lo < 0: no lo planes (x2m: a tensor only 3x3x3 convs read)
+  void* y8; long long y8_sstride;                      // x2m: the m8 planes of the output (conv3_x2m.hip; bytes) or null
   const void* w;                        // virtual operator [Cout][3 Cin][taps] in the first conv's fragment order (pack_first_conv, "Cin" = 3 Cin)
   const float* oscale; const float* bias;
   float act_scale;
@@ -186,18 +187,23 @@ __global__ __launch_bounds__(256) void x2_first_conv_kernel(X2FirstParams p) {
     const int gz = z0 + fz, gy = y0 + fy, gx = x0 + xh * 16 + l15;
     const bool ok = gz < p.D && gy < p.H && gx < p.W;
     f16x8 o, ol;
+    float rr[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      float r = fmaf(j < 4 ? acc0[j & 3] : acc1[j & 3], osc[j], bias[j]);
-      if (p.relu) r = fmaxf(r, 0.f);
-      f16 hi, lo;
-      split16<f16>(r, hi, lo);
-      o[j] = hi; ol[j] = lo;
+      rr[j] = fmaf(j < 4 ? acc0[j & 3] : acc1[j & 3], osc[j], bias[j]);
+      if (p.relu) rr[j] = fmaxf(rr[j], 0.f);
     }
+    u32x2_t l8, h8;
+    x2m_split8(rr, o, ol, l8, h8);                     // (hi, lo: split16's words)
     if (ok) {
       const long long off = (((long long)gz * p.H + gy) * p.W + gx) * 8;
       *(f16x8*)(yout + (long long)(cob * 4 + q) * plane_stride + off) = o;
-      *(f16x8*)(yout + (long long)(p.y_lo + cob * 4 + q) * plane_stride + off) = ol;
+      if (p.y_lo >= 0) *(f16x8*)(yout + (long long)(p.y_lo + cob * 4 + q) * plane_stride + off) = ol;
+      if (p.y8 != nullptr) {
+        unsigned char* y8 = (unsigned char*)p.y8 + (long long)n * p.y8_sstride + x2m_off(cob * 4 + q, off / 8, plane_stride / 8);
+        *(u32x2_t*)y8 = l8;
+        *(u32x2_t*)(y8 + plane_stride * 2) = h8;
+      }
     }
   }
 }
@@ -249,7 +255,8 @@ __global__ __launch_bounds__(256) void x2_maxpool_kernel(const f16* __restrict__
 // global, stride-2 interleave of the two x positions for full-line stores).
 struct X2ConvTParams {
   const void* x; long long x_sstride; int x_lo;
-  void* y; long long y_sstride; int y_lo;
+  void* y; long long y_sstride; int y_lo;             // y_lo < 0: no lo planes
+  void* y8; long long y8_sstride;                      // x2m: the m8 planes of the output (bytes) or null
   const void* wpk; const float* oscale; const float* bias;
   int N, D, H, W, Cin, Cout;            // input grid; Cin = real input channels
 };
@@ -393,14 +400,30 @@ __global__ __launch_bounds__(256, RES ? 2 : 1) void x2_convT_lds_kernel(X2ConvTP
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
           f16x8 o, ol;
+          float rr[8];
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
-            float rr;
-            if constexpr (RES) rr = fmaf(j < 4 ? acc[g][s2 * 2 + c][0][j & 3] : acc[g][s2 * 2 + c][1][j & 3], cs[j >> 2][j & 3], cs[2 + (j >> 2)][j & 3]);
-            else rr = fmaf(j < 4 ? acc[g][s2 * 2 + c][0][j & 3] : acc[g][s2 * 2 + c][1][j & 3], osc[j], bias[j]);
-            f16 hi, lo;
-            split16<f16>(rr, hi, lo);
-            o[j] = hi; ol[j] = lo;
+            if constexpr (RES) rr[j] = fmaf(j < 4 ? acc[g][s2 * 2 + c][0][j & 3] : acc[g][s2 * 2 + c][1][j & 3], cs[j >> 2][j & 3], cs[2 + (j >> 2)][j & 3]);
+            else rr[j] = fmaf(j < 4 ? acc[g][s2 * 2 + c][0][j & 3] : acc[g][s2 * 2 + c][1][j & 3], osc[j], bias[j]);
+          }
+          if (p.y8 == nullptr) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              f16 hi, lo;
+              split16<f16>(rr[j], hi, lo);
+              o[j] = hi; ol[j] = lo;
+            }
+          } else {
+            // x2m: this lane's half-granules of the m8 planes go straight out (output voxel 2 x + c of row (oz, oy): 8-byte stores)
+            u32x2_t l8, h8;
+            x2m_split8(rr, o, ol, l8, h8);
+            if (x0 + l15 < p.W) {
+              const long long ovox = (long long)Do * Ho * Wo;
+              const long long vo = ((long long)(ND == 3 ? z_[g] * 2 + a : 0) * Ho + y_[g] * 2 + b) * Wo + 2 * (x0 + l15) + c;
+              unsigned char* y8 = (unsigned char*)p.y8 + n_[g] * p.y8_sstride + x2m_off(cob * 4 + q, vo, ovox);
+              *(u32x2_t*)y8 = l8;
+              *(u32x2_t*)(y8 + ovox * 16) = h8;
+            }
           }
           oc[c][0] = __builtin_bit_cast(i32x4, o);
           oc[c][1] = __builtin_bit_cast(i32x4, ol);
@@ -408,7 +431,8 @@ __global__ __launch_bounds__(256, RES ? 2 : 1) void x2_convT_lds_kernel(X2ConvTP
         const int oz = ND == 3 ? z_[g] * 2 + a : 0;
         f16* row = yout + (((long long)oz * Ho + y_[g] * 2 + b) * Wo + 2 * x0) * 8;
 #pragma unroll
-        for (int w = 0; w < 2; ++w)
+        for (int w = 0; w < 2; ++w) {
+          if (w == 1 && p.y_lo < 0) continue;              // (x2m: the lo planes of a tensor only 3x3x3 convs read are not written)
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
             const int src = h ? src_hi : src_lo;
@@ -421,6 +445,7 @@ __global__ __launch_bounds__(256, RES ? 2 : 1) void x2_convT_lds_kernel(X2ConvTP
             }
             if (2 * x0 + 16 * h + l15 < Wo) *(i32x4*)(row + (w ? (long long)p.y_lo * out_plane : 0) + (16 * h + l15) * 8) = v;
           }
+        }
       }
     }
     }
@@ -523,9 +548,22 @@ int iunet_x2_prep(const void* w, void* wv, void* oscale, void* bias_out, const v
 
 /* unet.py:65-69 first conv of the split-precision forward: the caller's tensor (strides, dtype as iunet_first_conv_fwd) ->
  * split(relu?(conv * oscale + bias)); w = iunet_pack_first_conv of the virtual operator with "Cin" = 3 Cin */
+int iunet_x2m_first_conv_fwd(int nd, const void* x, int in_dtype, const long long* in_strides, void* y, long long y_sstride, int y_lo,
+                             void* y8, long long y8_sstride, const void* w, const void* oscale, const void* bias, float act_scale, int N,
+                             int D, int H, int W, int Cin, int Cout, int relu, void* stream);
 int iunet_x2_first_conv_fwd(int nd, const void* x, int in_dtype, const long long* in_strides, void* y, long long y_sstride, int y_lo,
                             const void* w, const void* oscale, const void* bias, float act_scale, int N, int D, int H, int W, int Cin,
                             int Cout, int relu, void* stream) {
+  IUNET_REQUIRE(y_lo >= 0, "x2_first_conv: y_lo must not be negative");
+  return iunet_x2m_first_conv_fwd(nd, x, in_dtype, in_strides, y, y_sstride, y_lo, nullptr, 0, w, oscale, bias, act_scale, N, D, H, W, Cin, Cout,
+                                  relu, stream);
+}
+
+/* the same first conv writing, beside the hi planes, the m8 planes of its output (y8, y8_sstride bytes per sample; null: none) and the
+ * lo planes only when y_lo >= 0 */
+int iunet_x2m_first_conv_fwd(int nd, const void* x, int in_dtype, const long long* in_strides, void* y, long long y_sstride, int y_lo,
+                             void* y8, long long y8_sstride, const void* w, const void* oscale, const void* bias, float act_scale, int N,
+                             int D, int H, int W, int Cin, int Cout, int relu, void* stream) {
   IUNET_REQUIRE(x && y && w && oscale && bias && in_strides, "x2_first_conv: null pointer");
   IUNET_REQUIRE(nd == 2 || nd == 3, "x2_first_conv: nd must be 2 or 3");
   IUNET_REQUIRE_GRID("x2_first_conv", N, D, H, W);
@@ -536,7 +574,7 @@ int iunet_x2_first_conv_fwd(int nd, const void* x, int in_dtype, const long long
   IUNET_REQUIRE(pow2(act_scale), "x2_first_conv: the activation scale must be a power of two (got %g)", act_scale);
   X2FirstParams p;
   p.x = x; p.sN = in_strides[0]; p.sC = in_strides[1]; p.sD = in_strides[2]; p.sH = in_strides[3]; p.sW = in_strides[4];
-  p.in_dtype = in_dtype; p.y = y; p.y_sstride = y_sstride; p.y_lo = y_lo; p.w = w; p.oscale = (const float*)oscale;
+  p.in_dtype = in_dtype; p.y = y; p.y_sstride = y_sstride; p.y_lo = y_lo; p.y8 = y8; p.y8_sstride = y8_sstride; p.w = w; p.oscale = (const float*)oscale;
   p.bias = (const float*)bias; p.act_scale = act_scale; p.N = N; p.D = D; p.H = H; p.W = W; p.Cout = Cout; p.relu = relu;
   const int TZ = nd == 3 ? 4 : 1, TY = nd == 3 ? 8 : 16, TX = nd == 3 ? 16 : 32;
   dim3 grid(N * ((D + TZ - 1) / TZ) * ((H + TY - 1) / TY) * ((W + TX - 1) / TX), Cout / 32);
@@ -582,14 +620,24 @@ int iunet_x2_maxpool_fwd(int nd, const void* x, long long x_ss, int x_lo, void* 
 }
 
 /* transposed conv k2 s2; wpk = iunet_pack_convT ("Cin" = 2 Cin) of iunet_x2_prep's transposed = 2 operator [2 Cin][Cout][npos] */
+int iunet_x2m_convT_fwd(int nd, const void* x, long long x_ss, int x_lo, void* y, long long y_ss, int y_lo, void* y8, long long y8_ss,
+                        const void* wpk, const void* oscale, const void* bias, int N, int D, int H, int W, int Cin, int Cout, void* stream);
 int iunet_x2_convT_fwd(int nd, const void* x, long long x_ss, int x_lo, void* y, long long y_ss, int y_lo, const void* wpk,
                        const void* oscale, const void* bias, int N, int D, int H, int W, int Cin, int Cout, void* stream) {
+  IUNET_REQUIRE(y_lo >= 0, "x2_convT: y_lo must not be negative");
+  return iunet_x2m_convT_fwd(nd, x, x_ss, x_lo, y, y_ss, y_lo, nullptr, 0, wpk, oscale, bias, N, D, H, W, Cin, Cout, stream);
+}
+
+/* the same transposed conv writing, beside the hi planes, the m8 planes of its output (y8, y8_ss bytes per sample; null: none) and the lo
+ * planes only when y_lo >= 0 */
+int iunet_x2m_convT_fwd(int nd, const void* x, long long x_ss, int x_lo, void* y, long long y_ss, int y_lo, void* y8, long long y8_ss,
+                        const void* wpk, const void* oscale, const void* bias, int N, int D, int H, int W, int Cin, int Cout, void* stream) {
   IUNET_REQUIRE(x && y && wpk && oscale && bias, "x2_convT: null pointer");
   IUNET_REQUIRE(nd == 2 || nd == 3, "x2_convT: nd must be 2 or 3");
   IUNET_REQUIRE_GRID("x2_convT", N, D, H, W);
   IUNET_REQUIRE(Cin >= 32 && Cout >= 32 && Cin % 32 == 0 && Cout % 32 == 0, "x2_convT: channels must be positive multiples of 32 (%d, %d)", Cin, Cout);
   X2ConvTParams p;
-  p.x = x; p.x_sstride = x_ss; p.x_lo = x_lo; p.y = y; p.y_sstride = y_ss; p.y_lo = y_lo; p.wpk = wpk;
+  p.x = x; p.x_sstride = x_ss; p.x_lo = x_lo; p.y = y; p.y_sstride = y_ss; p.y_lo = y_lo; p.y8 = y8; p.y8_sstride = y8_ss; p.wpk = wpk;
   p.oscale = (const float*)oscale; p.bias = (const float*)bias; p.N = N; p.D = D; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
   const long long waves = (long long)N * D * H * ((W + 15) / 16);
   const int kc = iunet_x2_convT_kc(Cin), nchunks = Cin / 32 / kc, npos = nd == 3 ? 8 : 4;

@@ -74,6 +74,11 @@ _SIGS = {
     # ---- fp16x2 with the cross terms on the fp8 matrix cores (csrc/conv3_x2m.hip)
     'iunet_x2m_prep': [c_void_p] * 9 + [c_float, c_float, c_float, c_int, c_int, c_void_p],
     'iunet_x2m_make8': [c_void_p, c_ll, c_int, c_void_p, c_ll, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    'iunet_x2m_first_conv_fwd': [c_int, c_void_p, c_int, ctypes.POINTER(c_ll), c_void_p, c_ll, c_int, c_void_p, c_ll, c_void_p, c_void_p, c_void_p,
+                                 c_float, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    'iunet_x2m_convT_fwd': [c_int, c_void_p, c_ll, c_int, c_void_p, c_ll, c_int, c_void_p, c_ll, c_void_p, c_void_p, c_void_p,
+                            c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    'iunet_x2m_maxpool_fwd': [c_int, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_ll, c_int, c_int, c_int, c_int, c_int, c_void_p],
     'iunet_x2m_conv3_fwd': [c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_ll, c_int, c_void_p, c_ll, c_void_p, c_void_p, c_void_p, c_void_p,
                             c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     # ---- handle level (csrc/net.hip): the whole forward sequenced in C++

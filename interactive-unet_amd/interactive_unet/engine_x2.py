@@ -10,8 +10,14 @@ default prediction path run.
 Tensors: C channels = C/8 hi planes + C/8 lo planes of [D][H][W][8] fp16; the two halves of a skip-concat buffer stay views
 ([skip_hi | up_hi | skip_lo | up_lo]); activations are kept multiplied by `act_scale` (a power of two, undone exactly by the
 next operator's accumulator scale).
+
+`mixed` (3-D, the default there; IUNET_X2M=0 switches it off): the 3x3x3 stage convs evaluate the two cross terms of a split product
+(x_lo w_hi, x_hi w_lo: 2^-11 of it) on the K = 128 fp8 matrix instruction -- two matrix-step units per 16 input channels instead of
+three (csrc/conv3_x2m.hip).  A tensor a 3x3x3 conv reads then carries hi planes + "m8" planes (e4m3 of the residual and of the hi
+word, 2 bytes per element); the lo planes exist only where a transposed conv or the head reads (the last conv of a stage).
 """
 import ctypes
+import os
 
 import torch
 
@@ -24,7 +30,7 @@ class EngineX2:
     weight_dtype = None
     norm = 'batch'
 
-    def __init__(self, dim=2, levels=4, base=32, cin=1, ncls=2, device='cuda', act_scale=64.0):
+    def __init__(self, dim=2, levels=4, base=32, cin=1, ncls=2, device='cuda', act_scale=64.0, mixed=None):
         if dim not in (2, 3):
             raise ValueError('dim must be 2 or 3')
         if base % 32 != 0:
@@ -35,6 +41,8 @@ class EngineX2:
             raise NotImplementedError('native U-Net supports 2..10 classes (app.py:162)')
         self.dim, self.levels, self.base, self.cin, self.ncls = dim, levels, base, cin, ncls
         self.act_scale = float(act_scale)
+        # cross terms on the fp8 matrix cores: the 3-D stage convs (the K = 128 instruction holds 4 filter columns x 32 channels; 2-D stays fp16x2)
+        self.mixed = (os.environ.get('IUNET_X2M', '1') != '0' if mixed is None else bool(mixed)) and dim == 3
         self.device = torch.device(device)
         self.ch = [base * 2 ** l for l in range(levels)]
         self.taps, self.npos = 3 ** dim, 2 ** dim
@@ -44,6 +52,8 @@ class EngineX2:
         self.use_graph = True      # False: every forward sequenced from Python (tests compare the two)
         self._g, self._gparams, self._g_dirty, self._g_last, self._g_fwd = None, None, False, None, 0      # the C++-sequenced forward (_graph)
         nv.lib()
+        # range flag of the x2m convs: raised (atomicMax, no synchronisation) to 0x7bff when a stored hi word saturated at 65504
+        self._sat = torch.zeros(1, dtype=torch.int32, device=self.device) if self.mixed else None
 
     def _graph(self):
         """The C++-sequenced forward (net_graph.NetGraph) on this engine's current parameters, or None where the handle level does not
@@ -57,7 +67,7 @@ class EngineX2:
         if not net_graph.ENABLED or not self.use_graph or self.norm != 'batch' or self.weight_dtype or not (2 <= self.levels <= 6) or self._gparams is None:
             return None
         if self._g is None:
-            self._g = net_graph.NetGraph(self.dim, self.levels, self.base, self.cin, self.ncls, 2, self.device, act_scale=self.act_scale)
+            self._g = net_graph.NetGraph(self.dim, self.levels, self.base, self.cin, self.ncls, 3 if self.mixed else 2, self.device, act_scale=self.act_scale)
         if self._g_dirty:
             self._g.set_params(self._gparams)
             self._g_dirty = False
@@ -108,6 +118,21 @@ class EngineX2:
                 first = prefix == 'enc0' and j == 1
                 w = self._source(params, f'{name}.weight')
                 bn = [self._source(params, f'{prefix}.bn{j}.{k}') for k in ('weight', 'bias', 'running_mean', 'running_var')]
+                if self.mixed and not first:
+                    # x2m: w_hi in the padded K16 order + [w_hi8 | w_lo8] in the K128 order of the fp8 step
+                    key = name + '#m'
+                    bm = self._bufs.get(key)
+                    if bm is None:
+                        bm = self._bufs[key] = (torch.empty(b * a * self.taps, dtype=torch.float32, device=dev),
+                                                torch.empty(nv.pack_conv3_elems(b, a, self.taps, 2), dtype=torch.float16, device=dev),
+                                                torch.zeros(lib.iunet_x2m_w8_bytes(b, a), dtype=torch.uint8, device=dev),
+                                                torch.empty(b, dtype=torch.float32, device=dev), torch.empty(b, dtype=torch.float32, device=dev))
+                    whi, w16, w8, osc, bias = bm
+                    nv.call('iunet_x2m_prep', nv.ptr(w), nv.ptr(whi), nv.ptr(w8), nv.ptr(osc), nv.ptr(bias), nv.ptr(bn[0]), nv.ptr(bn[1]),
+                            nv.ptr(bn[2]), nv.ptr(bn[3]), BN_EPS, A, A, b, a, s)
+                    nv.call('iunet_pack_conv3', 0, nv.ptr(whi), None, nv.ptr(w16), b, a, self.taps, 2, s)
+                    P[name] = (w16, osc, bias, w8)
+                    continue
                 pmode = lib.iunet_x2_pack_mode(self.dim)      # 2: padded K16 order (3-D); 6: compact order (2-D: the cross-pair step)
                 npk = lib.iunet_pack_first_conv_elems(b, 3 * a, self.taps) if first else nv.pack_conv3_elems(b, 3 * a, self.taps, pmode)
                 wv, dst, osc, bias = bufs(name, b * 3 * a * self.taps, npk, b)
@@ -146,9 +171,19 @@ class EngineX2:
             self.check_shape(D, H, W)
             dims = self.level_dims(D, H, W)
             mk = lambda c, v: torch.empty(N * 2 * c * v, dtype=torch.float16, device=self.device)     # hi + lo planes
+            mk8 = lambda c, v: torch.empty(N * 2 * c * v, dtype=torch.uint8, device=self.device)      # m8 planes: 2 bytes per element
+            mkh = lambda c, v: torch.empty(N * c * v, dtype=torch.float16, device=self.device)        # hi planes only
             ws = {'dims': dims}
             for l in range(self.levels):
                 v = _vox(dims[l])
+                if self.mixed:       # a, cat, pin: read by 3x3x3 convs only (hi + m8); b: by a transposed conv or the head (hi + lo)
+                    ws[f'a{l}'], ws[f'a{l}m'] = mkh(self.ch[l], v), mk8(self.ch[l], v)
+                    ws[f'b{l}'] = mk(self.ch[l], v)
+                    if l < self.levels - 1:
+                        ws[f'cat{l}'], ws[f'cat{l}m'] = mkh(2 * self.ch[l], v), mk8(2 * self.ch[l], v)
+                    if l > 0:
+                        ws[f'pin{l}'], ws[f'pin{l}m'] = mkh(self.ch[l - 1], v), mk8(self.ch[l - 1], v)
+                    continue
                 ws[f'a{l}'] = mk(self.ch[l], v)
                 ws[f'b{l}'] = mk(self.ch[l], v)
                 if l < self.levels - 1:
@@ -189,6 +224,11 @@ class EngineX2:
         ws = self.workspace(N, D, H, W)
         dims, L, ch, s = ws['dims'], self.levels, self.ch, nv.stream()
         Pt = lambda t, planes=0, v=0: ctypes.c_void_p(t.data_ptr() + 2 * planes * v * 8)      # view starting `planes` planes in
+        if self.mixed:
+            self._infer_mixed(ws, x, x_strides, N, D, H, W, s)
+            if features_only:
+                return ws['b0']
+            return self._head(ws, N, D, H, W, logits, probs, cls, out_strides, divisor, accumulate, s)
         for l in range(L):
             d, v = dims[l], _vox(dims[l])
             c8 = ch[l] // 8
@@ -224,13 +264,70 @@ class EngineX2:
                         N, d, ch[l], ch[l], s)
         if features_only:
             return ws['b0']                       # input of the head: [N][hi planes | lo planes], scaled by act_scale
+        self._head(ws, N, D, H, W, logits, probs, cls, out_strides, divisor, accumulate, s)
+
+    def _head(self, ws, N, D, H, W, logits, probs, cls, out_strides, divisor, accumulate, s):
+        dims, ch = ws['dims'], self.ch
         hw, hb = self.packed['head']
         if out_strides is None:
             v = _vox(dims[0])
             out_strides = (self.ncls * v, v, H * W, W, 1)
-        nv.call('iunet_x2_head_fwd', Pt(ws['b0']), 2 * ch[0] * _vox(dims[0]), ch[0] // 8, ch[0], nv.ptr(hw), nv.ptr(hb),
+        nv.call('iunet_x2_head_fwd', nv.ptr(ws['b0']), 2 * ch[0] * _vox(dims[0]), ch[0] // 8, ch[0], nv.ptr(hw), nv.ptr(hb),
                 self.act_scale, self.ncls, nv.ptr(logits), nv.ptr(probs), nv.ptr(cls), nv.ll_array(out_strides),
                 float(divisor), int(bool(accumulate)), N, D, H, W, s)
+
+    def _conv3m(self, name, xp, x_ss, x8p, x8_ss, yp, y_ss, y_lo, y8p, y8_ss, N, d, ci, co, s):
+        """3x3x3 stage conv, cross terms on the fp8 matrix cores: (hi planes, m8 planes) -> hi planes (+ lo planes if y_lo >= 0, + m8 planes)."""
+        w16, osc, b, w8 = self.packed[name]
+        probe = self.probe if (self.probe is not None and self.probe['name'] == name) else None
+        if probe is not None:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+        nv.call('iunet_x2m_conv3_fwd', xp, x_ss, x8p, x8_ss, yp, y_ss, y_lo, y8p, y8_ss, nv.ptr(w16), nv.ptr(w8), nv.ptr(osc), nv.ptr(b),
+                N, d[0], d[1], d[2], ci, co, 2, nv.ptr(self._sat), s)
+        if probe is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            probe['events'].append((e0, e1, N))
+
+    def _infer_mixed(self, ws, x, x_strides, N, D, H, W, s):
+        """The 3-D forward in the x2m form (everything but the head): a / cat / pin tensors are (hi planes, m8 planes), b tensors (hi, lo)."""
+        dims, L, ch = ws['dims'], self.levels, self.ch
+        P8 = lambda t, planes16=0, v=0: ctypes.c_void_p(t.data_ptr() + planes16 * v * 16)     # m8 view starting `planes16` 16-byte planes in
+        Ph = lambda t, planes=0, v=0: ctypes.c_void_p(t.data_ptr() + planes * v * 16)         # hi view starting `planes` 8-channel planes in
+        for l in range(L):
+            d, v = dims[l], _vox(dims[l])
+            c = ch[l]
+            if l == 0:
+                w, osc, b = self.packed['enc0.conv1']
+                nv.call('iunet_x2m_first_conv_fwd', self.dim, nv.ptr(x), nv.IN_DTYPE_CODE[x.dtype], nv.ll_array(x_strides),
+                        Ph(ws['a0']), c * v, -1, P8(ws['a0m']), 2 * c * v, nv.ptr(w), nv.ptr(osc), nv.ptr(b), self.act_scale,
+                        N, d[0], d[1], d[2], self.cin, c, 1, s)
+            else:
+                cp = ch[l - 1]
+                self._conv3m(f'enc{l}.conv1', Ph(ws[f'pin{l}']), cp * v, P8(ws[f'pin{l}m']), 2 * cp * v, Ph(ws[f'a{l}']), c * v, -1,
+                             P8(ws[f'a{l}m']), 2 * c * v, N, d, cp, c, s)
+            if l < L - 1:
+                # skip half of the concat buffer: hi planes [0, c / 8), m8 planes [0, 2 c / 16)
+                self._conv3m(f'enc{l}.conv2', Ph(ws[f'a{l}']), c * v, P8(ws[f'a{l}m']), 2 * c * v, Ph(ws[f'cat{l}']), 2 * c * v, -1,
+                             P8(ws[f'cat{l}m']), 4 * c * v, N, d, c, c, s)
+                do = dims[l + 1]
+                nv.call('iunet_x2m_maxpool_fwd', self.dim, Ph(ws[f'cat{l}']), 2 * c * v, P8(ws[f'cat{l}m']), 4 * c * v,
+                        Ph(ws[f'pin{l + 1}']), c * _vox(do), P8(ws[f'pin{l + 1}m']), 2 * c * _vox(do), c, N, do[0], do[1], do[2], s)
+            else:
+                self._conv3m(f'enc{l}.conv2', Ph(ws[f'a{l}']), c * v, P8(ws[f'a{l}m']), 2 * c * v, nv.ptr(ws[f'b{l}']), 2 * c * v, c // 8,
+                             None, 0, N, d, c, c, s)
+        for l in range(L - 2, -1, -1):
+            d, v, di, vi = dims[l], _vox(dims[l]), dims[l + 1], _vox(dims[l + 1])
+            c, cn = ch[l], ch[l + 1]
+            w, osc, b = self.packed[f'dec{l}.up']
+            # up half of the concat buffer: hi planes [c / 8, 2 c / 8), m8 planes [2 c / 16, 4 c / 16)
+            nv.call('iunet_x2m_convT_fwd', self.dim, nv.ptr(ws[f'b{l + 1}']), 2 * cn * vi, cn // 8, Ph(ws[f'cat{l}'], c // 8, v), 2 * c * v, -1,
+                    P8(ws[f'cat{l}m'], 2 * c // 16, v), 4 * c * v, nv.ptr(w), nv.ptr(osc), nv.ptr(b), N, di[0], di[1], di[2], cn, c, s)
+            self._conv3m(f'dec{l}.conv1', Ph(ws[f'cat{l}']), 2 * c * v, P8(ws[f'cat{l}m']), 4 * c * v, Ph(ws[f'a{l}']), c * v, -1,
+                         P8(ws[f'a{l}m']), 2 * c * v, N, d, 2 * c, c, s)
+            self._conv3m(f'dec{l}.conv2', Ph(ws[f'a{l}']), c * v, P8(ws[f'a{l}m']), 2 * c * v, nv.ptr(ws[f'b{l}']), 2 * c * v, c // 8,
+                         None, 0, N, d, c, c, s)
 
     # ------------------------------------------------------------------ range check
     def max_stored(self):
@@ -242,11 +339,16 @@ class EngineX2:
         m = 0.0
         for ws in self._ws_cache.values():
             for k, t in ws.items():
-                if k != 'dims':
+                if k != 'dims' and t.dtype == torch.float16:
                     m = max(m, float(t.abs().max()))
         return m
 
     def saturated(self):
+        """Did an activation saturate (a host-synchronising diagnostic)?  mixed (3-D): EVERY forward since the engine was made raises
+        an on-device flag in the stage convs' epilogues (no synchronisation on the hot path): the answer covers all of them, whichever
+        sequence -- Python or the C++ graph -- ran them.  Otherwise: the last forward's activations are scanned."""
+        if self.mixed:
+            return int(self._sat.item()) >= 0x7bff or (self._g is not None and self._g.saturated())
         return self.max_stored() >= 65504.0
 
     # ------------------------------------------------------------------ layout helpers (tests)

@@ -23,7 +23,7 @@ class NetGraph:
         self.lib = nv.lib()
         self.h = ctypes.c_void_p()
         nv.call('iunet_net_create', dim, levels, base, cin, ncls, mode, float(act_scale), ctypes.byref(self.h))
-        self.device, self.ncls, self.cin = device, ncls, cin
+        self.device, self.ncls, self.cin, self.mode = device, ncls, cin, mode
         self.layout = []
         for i in range(self.lib.iunet_net_num_tensors(self.h)):
             name = ctypes.create_string_buffer(96)
@@ -65,7 +65,14 @@ class NetGraph:
             if len(self._ws) > 4:
                 self._ws.clear()
             ws = self._ws[key] = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            if self.mode == 3:
+                ws[:256].zero_()           # the range flag of the x2m stage convs (csrc/net.hip: ws_layout)
         return ws
+
+    def saturated(self):
+        """mode 3: did any forward on any of this handle's workspaces store a saturated (|act_scale x activation| >= 65504) hi word?
+        One small device-to-host read per workspace; the flags are cumulative since the workspace was made."""
+        return self.mode == 3 and any(int(ws[:4].view(torch.int32).item()) >= 0x7bff for ws in self._ws.values())
 
     def infer(self, x, x_strides, N, D, H, W, logits=None, probs=None, cls=None, out_strides=None, divisor=1.0, accumulate=False):
         if not self.filled:

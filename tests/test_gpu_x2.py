@@ -27,7 +27,7 @@ def _nv():
 
 def _engine(dim, **kw):
     from interactive_unet.engine_x2 import EngineX2
-    return EngineX2(dim=dim, **kw)
+    return EngineX2(dim=dim, mixed=False, **kw)          # (the 3-D default, cross terms on the fp8 matrix cores: tests/test_gpu_x2m.py)
 
 
 def _prep_conv(nv, w, bn=None, bias=None, transposed=False):
@@ -231,7 +231,7 @@ def test_c5_geometry_in_split_precision():
     img = np.stack([_smooth(shape, 3 + i) for i in range(1)])[:, None]
     x = torch.tensor(img)
     ref = unet_ref.forward_logits(p, x.float() / 255.0, dim=dim, levels=5)
-    e = EngineX2(dim=dim, levels=5, base=64, ncls=ncls)
+    e = EngineX2(dim=dim, levels=5, base=64, ncls=ncls, mixed=False)
     e.load_eval({k: v.cuda() for k, v in p.items()})
     r = _compare('fp16x2 3-D 5 levels base 64', *_forward(e, x.cuda(), dim, ncls), ref, _labels(img, ncls))
     _assert_fp32_mode(r)

@@ -159,3 +159,125 @@ def test_conv3_x2m_without_lo_planes_and_saturation_flag():
     hi, lo, _, sat = _run(nv, xs, x8, w16, w8, osc, bias, N, shape, ci, co, 0, y_lo=False)
     assert torch.equal(lo, torch.zeros_like(lo))                             # y_lo < 0: no lo planes written
     assert hi.abs().max().item() == 65504.0 and sat == 0x7bff                # the clamp, and its flag
+
+
+# ---------------------------------------------------------------------------------------------------------------- producers and network
+def test_producers_write_the_m8_planes_of_their_hi_and_lo_words():
+    """first conv, transposed conv and max-pool in the x2m form against the fp16x2 kernels' hi / lo words (+ iunet_x2m_make8 of them)."""
+    from tests.test_gpu_x2 import _prep_conv
+    nv = _nv()
+    g = torch.Generator().manual_seed(21)
+    N, co, shape = 2, 32, (6, 10, 20)
+    vox = int(np.prod(shape))
+    # ---- first conv
+    xu = torch.randint(0, 256, (N, 1) + shape, generator=g, dtype=torch.uint8).cuda()
+    w = torch.randn((co, 1, 3, 3, 3), generator=g) * (2.0 / 27) ** 0.5
+    wpk, osc, b = _prep_conv(nv, w)
+    st = nv.ll_array((vox, vox, shape[1] * shape[2], shape[2], 1))
+    y = torch.zeros(N * 2 * co * vox, dtype=torch.float16, device='cuda')
+    nv.call('iunet_x2_first_conv_fwd', 3, nv.ptr(xu), 2, st, nv.ptr(y), 2 * co * vox, co // 8, nv.ptr(wpk), nv.ptr(osc), nv.ptr(b), A, N, *shape, 1, co, 1, nv.stream())
+    want8 = torch.empty(N * 2 * co * vox, dtype=torch.uint8, device='cuda')
+    nv.call('iunet_x2m_make8', nv.ptr(y), 2 * co * vox, co // 8, nv.ptr(want8), 2 * co * vox, co, N, *shape, nv.stream())
+    yh = torch.zeros(N * co * vox, dtype=torch.float16, device='cuda')
+    y8 = torch.zeros(N * 2 * co * vox, dtype=torch.uint8, device='cuda')
+    nv.call('iunet_x2m_first_conv_fwd', 3, nv.ptr(xu), 2, st, nv.ptr(yh), co * vox, -1, nv.ptr(y8), 2 * co * vox, nv.ptr(wpk), nv.ptr(osc), nv.ptr(b), A, N, *shape,
+            1, co, 1, nv.stream())
+    torch.cuda.synchronize()
+    assert torch.equal(yh.view(N, co * vox), y.view(N, 2 * co * vox)[:, :co * vox])
+    # (the producer rounds the exact fp32 residual, make8 the fp16 lo word of it: equal unless the lo word itself was rounded -- never at these sizes)
+    lo_a, hi_a = _m8_unpack(y8.cpu(), N, co, shape)
+    lo_b, hi_b = _m8_unpack(want8.cpu(), N, co, shape)
+    assert torch.equal(hi_a, hi_b) and (lo_a != lo_b).float().mean().item() < 2e-3
+    # ---- max-pool on (hi, m8): the winner's words are copied
+    do = tuple(s // 2 for s in shape)
+    ovox = int(np.prod(do))
+    ph = torch.zeros(N * co * ovox, dtype=torch.float16, device='cuda')
+    p8 = torch.zeros(N * 2 * co * ovox, dtype=torch.uint8, device='cuda')
+    nv.call('iunet_x2m_maxpool_fwd', 3, nv.ptr(yh), co * vox, nv.ptr(y8), 2 * co * vox, nv.ptr(ph), co * ovox, nv.ptr(p8), 2 * co * ovox, co, N, *do, nv.stream())
+    torch.cuda.synchronize()
+    un = lambda t, sp: t.cpu().reshape(N, co // 8, *sp, 8).permute(0, 1, 5, 2, 3, 4).reshape(N, co, *sp).float()
+    hi_full = un(yh, shape)
+    val = hi_full + lo_a / 16.0
+    want_val = F.max_pool3d(val, 2)
+    got_lo, got_hi8 = _m8_unpack(p8.cpu(), N, co, do)
+    assert torch.equal(un(ph, do) + got_lo / 16.0, want_val)
+    assert torch.equal(got_hi8, _e4m3(un(ph, do) / 256.0))
+    # ---- transposed conv
+    ci = 64
+    xin = torch.rand((N, ci) + do, generator=g) * 2
+    wt = torch.randn((ci, co, 2, 2, 2), generator=g) * (1.0 / ci) ** 0.5
+    bt = torch.randn(co, generator=g) * 0.1
+    wpk, osc, b = _prep_conv(nv, wt, bias=bt, transposed=True)
+    from interactive_unet.engine_x2 import EngineX2
+    xs = EngineX2(dim=3, mixed=False).to_split(xin).cuda()
+    y = torch.zeros(N * 2 * co * ovox * 8, dtype=torch.float16, device='cuda')
+    nv.call('iunet_x2_convT_fwd', 3, nv.ptr(xs), 2 * ci * ovox, ci // 8, nv.ptr(y), 2 * co * ovox * 8, co // 8, nv.ptr(wpk), nv.ptr(osc), nv.ptr(b), N, *do, ci, co, nv.stream())
+    up = tuple(2 * s for s in do)
+    uvox = ovox * 8
+    nv.call('iunet_x2m_make8', nv.ptr(y), 2 * co * uvox, co // 8, nv.ptr(want8[:N * 2 * co * uvox]), 2 * co * uvox, co, N, *up, nv.stream())
+    yh = torch.zeros(N * co * uvox, dtype=torch.float16, device='cuda')
+    y8 = torch.zeros(N * 2 * co * uvox, dtype=torch.uint8, device='cuda')
+    nv.call('iunet_x2m_convT_fwd', 3, nv.ptr(xs), 2 * ci * ovox, ci // 8, nv.ptr(yh), co * uvox, -1, nv.ptr(y8), 2 * co * uvox, nv.ptr(wpk), nv.ptr(osc), nv.ptr(b),
+            N, *do, ci, co, nv.stream())
+    torch.cuda.synchronize()
+    assert torch.equal(yh.view(N, co * uvox), y.view(N, 2 * co * uvox)[:, :co * uvox])
+    lo_a, hi_a = _m8_unpack(y8.cpu(), N, co, up)
+    lo_b, hi_b = _m8_unpack(want8[:N * 2 * co * uvox].cpu(), N, co, up)
+    assert torch.equal(hi_a, hi_b) and (lo_a != lo_b).float().mean().item() < 2e-3
+
+
+@pytest.mark.parametrize('shape,cin,ncls,in_dtype', [((16, 32, 48), 1, 3, torch.uint8), ((8, 24, 40), 2, 4, torch.float16)])
+def test_network_x2m_small_shapes(shape, cin, ncls, in_dtype):
+    """The 3-D network in the x2m form against the fp32 oracle (the headline size is in test_gpu_parity.py), the C++-sequenced forward
+    bit-identical to the Python-sequenced one, the range flag quiet."""
+    from tests.test_gpu_parity import _smooth, _forward, _compare, _assert_fp32_mode, _labels
+    from interactive_unet.engine_x2 import EngineX2
+    dim = 3
+    p = unet_ref.init_params(dim=dim, cin=cin, ncls=ncls, seed=3, randomize_bn=True)
+    N = 2
+    img = np.stack([np.stack([_smooth(shape, 10 * i + c) for c in range(cin)]) for i in range(N)])
+    x = torch.tensor(img)
+    if in_dtype == torch.uint8:
+        xd, xf = x.cuda(), x.float() / 255.0
+    else:
+        xf = (x.float() / 255.0).to(in_dtype).float()
+        xd = xf.to(in_dtype).cuda()
+    ref = unet_ref.forward_logits(p, xf, dim=dim)
+    e = EngineX2(dim=dim, cin=cin, ncls=ncls)
+    assert e.mixed                                        # the 3-D default
+    e.load_eval({k: v.cuda() for k, v in p.items()})
+    e.use_graph = False
+    lg, pr, cl = _forward(e, xd, dim, ncls)
+    r = _compare(f'x2m 3-D {shape} cin={cin}', lg, pr, cl, ref, _labels(img, ncls))
+    _assert_fp32_mode(r)
+    assert r['err'] <= 3e-4 * max(1.0, r['scale'])        # ~6e-5 of the logit scale measured; fp16: 1.5e-3
+    e.use_graph = True
+    e._g_fwd = 1
+    lg2, pr2, cl2 = _forward(e, xd, dim, ncls)
+    from interactive_unet import net_graph
+    assert not net_graph.ENABLED or (e._g is not None and e._g.loaded)
+    assert torch.equal(lg, lg2) and torch.equal(pr, pr2) and torch.equal(cl, cl2)
+    assert not e.saturated()
+
+
+def test_network_x2m_c5_geometry_and_range_flag():
+    """5 levels, base 64, 4 classes in the x2m form (split-K free: 64 chunk pairs at the widest conv); then the same network with a
+    BatchNorm gain that drives activations beyond 65504 / act_scale: finite result, the on-device flag raised."""
+    from tests.test_gpu_parity import _smooth, _forward, _compare, _assert_fp32_mode, _labels
+    from interactive_unet.engine_x2 import EngineX2
+    dim, shape, ncls = 3, (16, 16, 32), 4
+    p = unet_ref.init_params(dim=dim, levels=5, base=64, ncls=ncls, seed=4, randomize_bn=True)
+    img = np.stack([_smooth(shape, 3 + i) for i in range(1)])[:, None]
+    x = torch.tensor(img)
+    ref = unet_ref.forward_logits(p, x.float() / 255.0, dim=dim, levels=5)
+    e = EngineX2(dim=dim, levels=5, base=64, ncls=ncls)
+    e.load_eval({k: v.cuda() for k, v in p.items()})
+    r = _compare('x2m 3-D 5 levels base 64', *_forward(e, x.cuda(), dim, ncls), ref, _labels(img, ncls))
+    _assert_fp32_mode(r)
+    assert not e.saturated()
+    p2 = dict(p)
+    p2['enc0.bn2.weight'] = p['enc0.bn2.weight'] * 4000.0
+    e2 = EngineX2(dim=dim, levels=5, base=64, ncls=ncls)
+    e2.load_eval({k: v.cuda() for k, v in p2.items()})
+    lg, _, _ = _forward(e2, x.cuda(), dim, ncls)
+    assert torch.isfinite(lg).all() and e2.saturated()
