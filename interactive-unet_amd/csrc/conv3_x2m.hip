@@ -225,113 +225,98 @@ __global__ __launch_bounds__((XMTile<SMALL>::NCW * 64 + XM_NLT), 1) void conv3_x
   using I3 = std::integral_constant<int, 3>; using I4 = std::integral_constant<int, 4>; using I5 = std::integral_constant<int, 5>;
   using I6 = std::integral_constant<int, 6>; using I7 = std::integral_constant<int, 7>; using I8 = std::integral_constant<int, 8>;
 
+  // Operand registers of the two kinds of step.  The software pipeline runs ACROSS the steps: a step's one barrier sits in front of its
+  // LAST group of matrix instructions -- every LDS read of the step has landed by then (its last group's operands are in registers), so
+  // the loaders may overwrite its buffers, and the other kind's buffers are published -- and the first group of the NEXT step is read
+  // behind that barrier, between the last group's matrix instructions (conv3_v4.hip's resident-weight variants, conv3_f8k.hip).
+  f16x8 R16[2][NR + 2], A16f[2][3][2];                         // 16-bit step: row / operator fragments of the running and the next column pair
+  i32x8 R8f[2][NR + 2], A8f[2][2];                             // fp8 step: K = 128 row fragments of the two groups, operator of the running / next (group, dy)
+  i64 R8n[NR + 2], A8n[3][2];                                  // the ninth column's K = 32 operands
+
   // -------------------------------------------------------------- the 16-bit step: x_hi w_hi, 5 column pairs x 3 dy x 4 rows x 2 halves
-  auto step16 = [&]() {
-    f16x8 R[2][NR + 2], A[2][3][2];
+  auto load_group = [&](int c, auto BUF) {
+    constexpr int b = decltype(BUF)::value;
     const unsigned char* ab = smem + OFF_A16 + rbase16;
     const unsigned char* wl = smem + OFF_W16 + lane * 16;
-    auto load_group = [&](int c, auto BUF) {
-      constexpr int b = decltype(BUF)::value;
 #pragma unroll
-      for (int r = 0; r < NR + 2; ++r) R[b][r] = *(const f16x8*)(ab + r * PX * 16 + col_off[c]);
+    for (int r = 0; r < NR + 2; ++r) R16[b][r] = *(const f16x8*)(ab + r * PX * 16 + col_off[c]);
 #pragma unroll
-      for (int dy = 0; dy < 3; ++dy) {
-        A[b][dy][0] = *(const f16x8*)(wl + ((c * 3 + dy) * 2 + 0) * 1024);
-        A[b][dy][1] = *(const f16x8*)(wl + ((c * 3 + dy) * 2 + 1) * 1024);
+    for (int dy = 0; dy < 3; ++dy) {
+      A16f[b][dy][0] = *(const f16x8*)(wl + ((c * 3 + dy) * 2 + 0) * 1024);
+      A16f[b][dy][1] = *(const f16x8*)(wl + ((c * 3 + dy) * 2 + 1) * 1024);
+    }
+  };
+  auto group_mfmas = [&](auto BUF, bool reads_pending) {
+    constexpr int b = decltype(BUF)::value;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int n = 0; n < NI; ++n) {
+        acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A16f[b][dy][0], R16[b][n + dy], acc[0][n], 0, 0, 0);
+        acc[1][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A16f[b][dy][1], R16[b][n + dy], acc[1][n], 0, 0, 0);
       }
-    };
-    auto group_mfmas = [&](auto BUF, bool reads_pending) {
-      constexpr int b = decltype(BUF)::value;
+    if (reads_pending) {
+      constexpr int NRD = NR + 2 + 6, MPR = (3 * NI * 2) / NRD;      // 12 LDS reads spread over 24 MFMAs
 #pragma unroll
-      for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-        for (int n = 0; n < NI; ++n) {
-          acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[b][dy][0], R[b][n + dy], acc[0][n], 0, 0, 0);
-          acc[1][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[b][dy][1], R[b][n + dy], acc[1][n], 0, 0, 0);
-        }
-      if (reads_pending) {
-        constexpr int NRD = NR + 2 + 6, MPR = (3 * NI * 2) / NRD;      // 12 LDS reads spread over 24 MFMAs
-#pragma unroll
-        for (int i = 0; i < NRD; ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, MPR, 0);
-        }
+      for (int i = 0; i < NRD; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, MPR, 0);
       }
-      __builtin_amdgcn_sched_barrier(0);
-    };
-    load_group(0, I0{});
+    }
     __builtin_amdgcn_sched_barrier(0);
-    load_group(1, I1{}); group_mfmas(I0{}, true);
-    load_group(2, I0{}); group_mfmas(I1{}, true);
-    load_group(3, I1{}); group_mfmas(I0{}, true);
-    load_group(4, I0{}); group_mfmas(I1{}, true);
-    group_mfmas(I0{}, false);
   };
 
   // -------------------------------------------------------------- the fp8 step: [x_lo8 | x_hi8] [w_hi8 | w_lo8], 2 K = 128 groups + the ninth column
-  auto step8 = [&]() {
-    i32x8 R[2][NR + 2], A[2][2];
-    i64 R8[NR + 2], A8[3][2];
+  auto rd128 = [&](const unsigned char* ptr, int second) -> i32x8 {
+    const u32x4 lo = *(const u32x4*)ptr, hi = *(const u32x4*)(ptr + second);
+    return i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+  };
+  auto load_sub = [&](auto SG) {                               // sub-group sg = 0 .. 8: (group 0, dy 0..2), (group 1, dy 0..2), (ninth column, dy 0..2)
+    constexpr int sg = decltype(SG)::value, g = sg / 3, dy = sg % 3;
     const unsigned char* ab = smem + OFF_A8;
     const unsigned char* wl = smem + OFF_W8;
-    auto rd128 = [&](const unsigned char* ptr, int second) -> i32x8 {
-      const u32x4 lo = *(const u32x4*)ptr, hi = *(const u32x4*)(ptr + second);
-      return i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
-    };
-    auto load_sub = [&](auto SG) {
-      constexpr int sg = decltype(SG)::value, g = sg / 3, dy = sg % 3;
-      if constexpr (g < 2) {
+    if constexpr (g < 2) {
 #pragma unroll
-        for (int m = 0; m < 2; ++m) A[sg & 1][m] = rd128(wl + ((g * 3 + dy) * 2 + m) * 2048 + lane * 16, 1024);
-        constexpr int r0 = dy == 0 ? 0 : NR - 1 + dy, r1 = dy == 0 ? NR : NR + dy;
+      for (int m = 0; m < 2; ++m) A8f[sg & 1][m] = rd128(wl + ((g * 3 + dy) * 2 + m) * 2048 + lane * 16, 1024);
+      constexpr int r0 = dy == 0 ? 0 : NR - 1 + dy, r1 = dy == 0 ? NR : NR + dy;
 #pragma unroll
-        for (int r = r0; r < r1; ++r) R[g][r] = rd128(ab + rbase8 + coff[g] + r * PX * 16, PLANE8);
-      } else if constexpr (dy == 0) {
+      for (int r = r0; r < r1; ++r) R8f[g][r] = rd128(ab + rbase8 + coff[g] + r * PX * 16, PLANE8);
+    } else if constexpr (dy == 0) {
 #pragma unroll
-        for (int d = 0; d < 3; ++d)
+      for (int d = 0; d < 3; ++d)
 #pragma unroll
-          for (int m = 0; m < 2; ++m) A8[d][m] = *(const i64*)(wl + W128 + (d * 2 + m) * 512 + lane * 8);
+        for (int m = 0; m < 2; ++m) A8n[d][m] = *(const i64*)(wl + W128 + (d * 2 + m) * 512 + lane * 8);
 #pragma unroll
-        for (int r = 0; r < NR + 2; ++r) R8[r] = *(const i64*)(ab + rbase8 + coff8 + r * PX * 16);
-      }
-    };
-    auto mfma_sub = [&](auto SG, auto NREADS) {
-      constexpr int sg = decltype(SG)::value, g = sg / 3, dy = sg % 3, nreads = decltype(NREADS)::value;
-#pragma unroll
-      for (int n = 0; n < NI; ++n)
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-          if constexpr (g < 2) acc[m][n] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A[sg & 1][m], R[g][n + dy], acc[m][n], 0, 0, 0, 0, 0, 0);
-          else acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(A8[dy][m], R8[n + dy], acc[m][n], 0, 0, 0);
-        }
-      if constexpr (nreads >= 8) {
-        constexpr int RPM = (nreads + 7) / 8;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x100, RPM, 0);
-        }
-      } else if constexpr (nreads > 0) {
-        constexpr int MPR = 8 / nreads;
-#pragma unroll
-        for (int i = 0; i < nreads; ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x008, MPR, 0);
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-      }
-      if constexpr (sg < 6 || sg == 8) __builtin_amdgcn_sched_barrier(0);
-    };
-    using N0 = std::integral_constant<int, 0>; using N6 = std::integral_constant<int, 6>; using N12 = std::integral_constant<int, 12>;
-    load_sub(I0{});
-    __builtin_amdgcn_sched_barrier(0);
-    load_sub(I1{}); mfma_sub(I0{}, N6{});
-    load_sub(I2{}); mfma_sub(I1{}, N6{});
-    load_sub(I3{}); mfma_sub(I2{}, N12{});
-    load_sub(I4{}); mfma_sub(I3{}, N6{});
-    load_sub(I5{}); mfma_sub(I4{}, N6{});
-    load_sub(I6{}); mfma_sub(I5{}, N12{});
-    mfma_sub(I6{}, N0{}); mfma_sub(I7{}, N0{}); mfma_sub(I8{}, N0{});
+      for (int r = 0; r < NR + 2; ++r) R8n[r] = *(const i64*)(ab + rbase8 + coff8 + r * PX * 16);
+    }
   };
+  auto mfma_sub = [&](auto SG, auto NREADS) {
+    constexpr int sg = decltype(SG)::value, g = sg / 3, dy = sg % 3, nreads = decltype(NREADS)::value;
+#pragma unroll
+    for (int n = 0; n < NI; ++n)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        if constexpr (g < 2) acc[m][n] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A8f[sg & 1][m], R8f[g][n + dy], acc[m][n], 0, 0, 0, 0, 0, 0);
+        else acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(A8n[dy][m], R8n[n + dy], acc[m][n], 0, 0, 0);
+      }
+    if constexpr (nreads >= 8) {
+      constexpr int RPM = (nreads + 7) / 8;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, RPM, 0);
+      }
+    } else if constexpr (nreads > 0) {
+      constexpr int MPR = 8 / nreads;
+#pragma unroll
+      for (int i = 0; i < nreads; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, MPR, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+    }
+    if constexpr (sg < 6 || sg == 8) __builtin_amdgcn_sched_barrier(0);      // (the three K = 32 sub-groups are one scheduling region)
+  };
+  using N4 = std::integral_constant<int, 4>; using N6 = std::integral_constant<int, 6>; using N12 = std::integral_constant<int, 12>;
 
   auto tile_epilogue = [&](int tile) {
     int n_img, z0, y0, x0;
@@ -384,13 +369,29 @@ __global__ __launch_bounds__((XMTile<SMALL>::NCW * 64 + XM_NLT), 1) void conv3_x
   };
 
   lds_barrier();                                               // the first 16-bit step is in LDS
+  load_group(0, I0{});
+  __builtin_amdgcn_sched_barrier(0);
   for (int k = 0; k < npairs; ++k) {
-    step16();
-    lds_barrier();                                             // the fp8 buffers of pair k are filled; the 16-bit buffers are free
-    step8();
+    // ---- 16-bit step of pair k (its first column pair is in fragment set 0 already)
+    load_group(1, I1{}); group_mfmas(I0{}, true);
+    load_group(2, I0{}); group_mfmas(I1{}, true);
+    load_group(3, I1{}); group_mfmas(I0{}, true);
+    load_group(4, I0{}); group_mfmas(I1{}, true);
+    lds_barrier();                                             // the 16-bit buffers are read; the fp8 buffers of pair k are filled
+    load_sub(I0{});                                            // 12 reads between the last column pair's 24 MFMAs
+    group_mfmas(I0{}, true);
+    // ---- fp8 step of pair k
+    load_sub(I1{}); mfma_sub(I0{}, N6{});
+    load_sub(I2{}); mfma_sub(I1{}, N6{});
+    load_sub(I3{}); mfma_sub(I2{}, N12{});
+    load_sub(I4{}); mfma_sub(I3{}, N6{});
+    load_sub(I5{}); mfma_sub(I4{}, N6{});
+    load_sub(I6{}); mfma_sub(I5{}, N12{});
+    lds_barrier();                                             // the fp8 buffers are read; the 16-bit buffers of pair k + 1 are filled
+    load_group(0, I0{});                                       // (after the last pair: a harmless re-read) 12 reads between the 24 K = 32 instructions
+    mfma_sub(I6{}, N4{}); mfma_sub(I7{}, N4{}); mfma_sub(I8{}, N4{});
     const int tile = k / nchunk;
     if (k - tile * nchunk == nchunk - 1) tile_epilogue(tile);
-    lds_barrier();                                             // the 16-bit buffers of pair k + 1 are filled; the fp8 buffers are free
   }
 }
 
