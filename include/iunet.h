@@ -195,6 +195,11 @@ int iunet_x2_pack_mode(int nd);
 /* stage conv 3^d pad 1 (epi as iunet_conv3_fwd); Cin = real input channels; wpk packed with mode iunet_x2_pack_mode(nd) */
 int iunet_x2_conv3_fwd(int nd, const void* x, long long x_sstride, int x_lo, void* y, long long y_sstride, int y_lo, const void* wpk,
                        const void* oscale, const void* bias, int N, int D, int H, int W, int Cin, int Cout, int epi, void* stream);
+/* the same stage conv with a range flag: sat = optional device int that a launch raises (atomicMax, no synchronisation) to 0x7bff when a
+ * stored hi word saturated at +-65504 -- act_scale x |activation| left the fp16 range and the result is no longer within tolerance;
+ * iunet_x2m_first_conv_fwd / iunet_x2m_convT_fwd take the same flag */
+int iunet_x2_conv3_fwd_flag(int nd, const void* x, long long x_sstride, int x_lo, void* y, long long y_sstride, int y_lo, const void* wpk,
+                            const void* oscale, const void* bias, int N, int D, int H, int W, int Cin, int Cout, int epi, void* sat, void* stream);
 /* 2^d max-pool on hi + lo sums (the winner's word pair is copied: no rounding) */
 int iunet_x2_maxpool_fwd(int nd, const void* x, long long x_ss, int x_lo, void* y, long long y_ss, int y_lo, int C, int N, int Do,
                          int Ho, int Wo, void* stream);
@@ -224,9 +229,9 @@ int iunet_x2m_make8(const void* x, long long x_ss, int x_lo, void* x8, long long
  * word and m8 bytes are copied (Do, Ho, Wo = output grid) */
 int iunet_x2m_first_conv_fwd(int nd, const void* x, int in_dtype, const long long* in_strides, void* y, long long y_sstride, int y_lo,
                              void* y8, long long y8_sstride, const void* w, const void* oscale, const void* bias, float act_scale, int N,
-                             int D, int H, int W, int Cin, int Cout, int relu, void* stream);
+                             int D, int H, int W, int Cin, int Cout, int relu, void* sat, void* stream);
 int iunet_x2m_convT_fwd(int nd, const void* x, long long x_ss, int x_lo, void* y, long long y_ss, int y_lo, void* y8, long long y8_ss,
-                        const void* wpk, const void* oscale, const void* bias, int N, int D, int H, int W, int Cin, int Cout, void* stream);
+                        const void* wpk, const void* oscale, const void* bias, int N, int D, int H, int W, int Cin, int Cout, void* sat, void* stream);
 int iunet_x2m_maxpool_fwd(int nd, const void* x, long long x_ss, const void* x8, long long x8_ss, void* y, long long y_ss, void* y8,
                           long long y8_ss, int C, int N, int Do, int Ho, int Wo, void* stream);
 /* the stage conv: x = Cin / 8 hi planes + x8 = its m8 planes; y = Cout / 8 hi planes (+ lo planes y_lo planes further on unless
@@ -244,8 +249,8 @@ int iunet_x2m_conv3_fwd(const void* x, long long x_ss, const void* x8, long long
  *   ws = device bytes [iunet_net_workspace_bytes(net, N, 1, H, W)];  iunet_net_forward_argmax(net, x_u8, cls_u8, N, 1, H, W, ws, stream);
  * mode: 0 fp16, 1 bf16 (16-bit activations), 2 fp16x2 (split precision: logits within 1e-3 of the fp32 predict), 3 (3-D only) fp16x2 with
  * the cross terms of the stage convs on the fp8 matrix cores (the x2m entry points above: two matrix-step units per 16 input channels
- * instead of three; the first 4 bytes of its workspace are an int the stage convs raise to 0x7bff when a stored activation word saturates
- * at 65504 -- zero it once, read it when convenient); act_scale: a power of two, modes 2 / 3 only (0 = default 64). */
+ * instead of three); modes 2 / 3: the first 4 bytes of the workspace are an int the forward raises to 0x7bff when a stored activation word
+ * saturates at 65504 -- zero it once, read it when convenient; act_scale: a power of two, modes 2 / 3 only (0 = default 64). */
 typedef struct iunet_net iunet_net;
 int iunet_net_create(int dim, int levels, int base, int cin, int ncls, int mode, float act_scale, iunet_net** out);
 void iunet_net_destroy(iunet_net* net);

@@ -231,6 +231,18 @@ __device__ __forceinline__ void x2m_split8(const float (&r)[8], f16x8& hi, f16x8
   lo8 = x2m_pack8(l4);
   hi8 = x2m_pack8(h8);
 }
+// range flag of the split-precision modes: a stored hi word of +-65504 means act_scale x activation saturated (split16's clamp).  Only a
+// saturated word ever touches memory (atomicMax of its bit pattern 0x7bff into the caller's int): no traffic, no synchronisation.
+__device__ __forceinline__ void x2_note_saturation(int* sat, const f16x8 hi) {
+  const u32x4 hb = __builtin_bit_cast(u32x4, hi);
+  unsigned m = 0;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    const unsigned a = hb[d] & 0x7fffu, b = (hb[d] >> 16) & 0x7fffu;
+    m = m > a ? m : a; m = m > b ? m : b;
+  }
+  if (m >= 0x7bffu) atomicMax(sat, (int)m);
+}
 // byte offset, inside the m8 planes of one sample, of the half-granule that holds the 8 channels of 8-channel plane `pl8` at voxel
 // `vox` (lo8; the hi8 half-granule is one plane = nvox * 16 bytes further on)
 __device__ __forceinline__ long long x2m_off(int pl8, long long vox, long long nvox) {

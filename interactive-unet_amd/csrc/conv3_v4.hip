@@ -91,6 +91,7 @@ struct ConvV4Params {
   // plane of a chunk, the buffer naming and the epilogue differ.  split_nc = channel chunks, x_lo / y_lo = plane offset of the lo planes.
   int split_nc, x_lo, y_lo;
   const float* oscale;                        // [Cout]: power-of-two factor on the accumulator (operator and activation scales)
+  int* sat;                                   // SPL: optional range flag (common.h: x2_note_saturation)
 };
 
 // BW: the data-gradient variant that also accumulates the BatchNorm-backward sums of the layer its output flows into (bw_y); a
@@ -631,8 +632,10 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + v4_loader_threads(ND
           }
         }
         if (ok && !(p.dbg & 4)) *(V8*)(yout + (long long)(cob * 4 + q) * plane_stride + (((long long)gz * p.H + gy) * p.W + gx) * 8) = o;
-        if constexpr (SPL)
+        if constexpr (SPL) {
           if (ok && !(p.dbg & 4)) *(V8*)(yout + (long long)(p.y_lo + cob * 4 + q) * plane_stride + (((long long)gz * p.H + gy) * p.W + gx) * 8) = o_lo;
+          if (ok && p.sat != nullptr) x2_note_saturation(p.sat, o);
+        }
         acc[ts][0][n] = f32x4{0.f, 0.f, 0.f, 0.f};
         acc[ts][1][n] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
@@ -847,7 +850,7 @@ int iunet_conv3_v4_launch(int dtype, int nd, const void* x, long long x_sstride,
   IUNET_REQUIRE(bw_y == nullptr || stats != nullptr, "conv3 layout 2: the fused BatchNorm-backward sums need a statistics buffer");
   p.tilesZ = p.tilesY = p.tilesX = 0;
   p.bz = p.by = p.bx = p.nbz = p.nby = p.nbx = 0;
-  p.split_nc = 0; p.x_lo = p.y_lo = 0; p.oscale = nullptr;
+  p.split_nc = 0; p.x_lo = p.y_lo = 0; p.oscale = nullptr; p.sat = nullptr;
   static const int dbg = getenv("IUNET_V4_DBG") ? atoi(getenv("IUNET_V4_DBG")) : 0;
   p.dbg = dbg;
   // weights resident in LDS for the whole launch when they fit beside the two activation buffers
@@ -893,7 +896,7 @@ int iunet_conv3_v4_x2_pack_mode(int nd) {
 // [Cout][3 Cin][taps] = [w_hi | w_hi | w_lo]; y = split(relu?(acc * oscale + bias)).
 int iunet_conv3_v4_x2_launch(int nd, const void* x, long long x_sstride, int x_lo, void* y, long long y_sstride, int y_lo, const void* wpk,
                              const float* oscale, const float* bias, int N, int D, int H, int W, int Cin, int Cout, int epi,
-                             hipStream_t stream) {
+                             int* sat, hipStream_t stream) {
   IUNET_REQUIRE(Cin % 32 == 0 && Cout % 32 == 0, "conv3 x2: Cin %% 32, Cout %% 32 (got %d -> %d)", Cin, Cout);
   ConvV4Params p;
   p.x = x; p.x_sstride = x_sstride; p.y = y; p.y_sstride = y_sstride; p.wpk = wpk; p.bias = bias; p.stats = nullptr;
@@ -903,7 +906,7 @@ int iunet_conv3_v4_x2_launch(int nd, const void* x, long long x_sstride, int x_l
   p.tilesZ = p.tilesY = p.tilesX = 0;
   p.bz = p.by = p.bx = p.nbz = p.nby = p.nbx = 0;
   p.dbg = 0;
-  p.split_nc = Cin / (nd == 3 ? 16 : 32); p.x_lo = x_lo; p.y_lo = y_lo; p.oscale = oscale;
+  p.split_nc = Cin / (nd == 3 ? 16 : 32); p.x_lo = x_lo; p.y_lo = y_lo; p.oscale = oscale; p.sat = sat;
   if (nd == 2) {
     // the cross-pair step (NP2, the compact operator of pack mode 6) for every 2-D launch: one summation order per layer whatever the grid
     if (iunet_conv3_v4_x2_pack_mode(2) == 6) return launch_v4<f16, 2, false, false, false, false, true, true>(p, stream);

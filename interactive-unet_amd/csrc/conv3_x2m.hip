@@ -329,7 +329,6 @@ __global__ __launch_bounds__((XMTile<SMALL>::NCW * 64 + XM_NLT), 1) void conv3_x
 #pragma unroll
       for (int j = 0; j < 4; ++j) { os_r[j] = w0[j]; os_r[4 + j] = w1[j]; bias_r[j] = b0[j]; bias_r[4 + j] = b1[j]; }
     }
-    unsigned short hmax = 0;
 #pragma unroll
     for (int n = 0; n < NI; ++n) {
       const int row = row_first + n;
@@ -353,19 +352,11 @@ __global__ __launch_bounds__((XMTile<SMALL>::NCW * 64 + XM_NLT), 1) void conv3_x
           *(u32x2*)y8 = lo8;
           *(u32x2*)(y8 + plane16b) = hi8;
         }
-        if (p.sat != nullptr) {
-          const u32x4 hb = __builtin_bit_cast(u32x4, hi);
-#pragma unroll
-          for (int d = 0; d < 4; ++d) {
-            const unsigned short a = hb[d] & 0x7fffu, b = (hb[d] >> 16) & 0x7fffu;
-            hmax = hmax > a ? hmax : a; hmax = hmax > b ? hmax : b;
-          }
-        }
+        if (p.sat != nullptr) x2_note_saturation(p.sat, hi);
       }
       acc[0][n] = f32x4{0.f, 0.f, 0.f, 0.f};
       acc[1][n] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    if (p.sat != nullptr && hmax >= 0x7bffu) atomicMax(p.sat, (int)hmax);      // only a saturated word ever touches memory
   };
 
   lds_barrier();                                               // the first 16-bit step is in LDS

@@ -26,9 +26,11 @@ int iunet_x2_head_fwd(const void*, long long, int, int, const void*, const void*
                       int, int, int, int, int, void*);
 int iunet_x2m_prep(const void*, void*, void*, void*, void*, const void*, const void*, const void*, const void*, float, float, float, int, int, void*);
 int iunet_x2m_first_conv_fwd(int, const void*, int, const long long*, void*, long long, int, void*, long long, const void*, const void*, const void*,
-                             float, int, int, int, int, int, int, int, void*);
+                             float, int, int, int, int, int, int, int, void*, void*);
 int iunet_x2m_convT_fwd(int, const void*, long long, int, void*, long long, int, void*, long long, const void*, const void*, const void*, int, int,
-                        int, int, int, int, void*);
+                        int, int, int, int, void*, void*);
+int iunet_x2_conv3_fwd_flag(int, const void*, long long, int, void*, long long, int, const void*, const void*, const void*, int, int, int, int,
+                            int, int, int, void*, void*);
 int iunet_x2m_maxpool_fwd(int, const void*, long long, const void*, long long, void*, long long, void*, long long, int, int, int, int, int, void*);
 int iunet_x2m_conv3_fwd(const void*, long long, const void*, long long, void*, long long, int, void*, long long, const void*, const void*,
                         const void*, const void*, int, int, int, int, int, int, int, void*, void*);
@@ -102,13 +104,13 @@ int stage_index(const iunet_net* n, bool dec, int l) { return dec ? n->levels + 
 
 struct WsLayout { std::vector<long long> a, b, cat, pin, am, catm, pinm; long long bytes; };
 
-// activation buffers of one forward (elements of 2 bytes; x2 holds hi + lo planes: twice the channels).  x2m (mode 3): the first 256
-// bytes hold the range flag (an int the stage convs raise to 0x7bff when a stored hi word saturates; the caller zeroes it once), a / cat /
-// pin are hi planes + m8 planes (2 bytes per element), b hi + lo planes
+// activation buffers of one forward (elements of 2 bytes; x2 holds hi + lo planes: twice the channels).  Modes 2 and 3: the first 256
+// bytes hold the range flag (an int the forward raises to 0x7bff when a stored hi word saturates; the caller zeroes it once).  x2m (mode 3):
+// a / cat / pin are hi planes + m8 planes (2 bytes per element), b hi + lo planes
 WsLayout ws_layout(const iunet_net* n, int N, int D, int H, int W) {
   WsLayout L;
   const int lv = n->levels, mul = n->mode == 2 ? 2 : 1;
-  long long off = n->mode == 3 ? 256 : 0;
+  long long off = n->mode >= 2 ? 256 : 0;
   auto take = [&](long long elems) { const long long o = off; off = align256(off + elems * 2); return o; };
   L.a.resize(lv); L.b.resize(lv); L.cat.resize(lv, -1); L.pin.resize(lv, -1);
   L.am.resize(lv, -1); L.catm.resize(lv, -1); L.pinm.resize(lv, -1);
@@ -332,7 +334,7 @@ int iunet_net_forward(iunet_net* n, const void* x, int in_dtype, const long long
       if (l == 0) {
         const float* aux = (const float*)(K + c1.aux);
         rc = iunet_x2m_first_conv_fwd(dim, x, in_dtype, in_strides, WS + L.a[0], (long long)c * v, -1, WS + L.am[0], 2ll * c * v, K + c1.pk[1], aux,
-                                      aux + c, A, N, d, h, w, n->cin, c, 1, stream);
+                                      aux + c, A, N, d, h, w, n->cin, c, 1, sat, stream);
       } else {
         const int cp = n->ch[l - 1];
         rc = convm(c1, L.pin[l], (long long)cp * v, L.pinm[l], 2ll * cp * v, L.a[l], (long long)c * v, -1, L.am[l], 2ll * c * v, l);
@@ -359,7 +361,7 @@ int iunet_net_forward(iunet_net* n, const void* x, int in_dtype, const long long
       const float* aux = (const float*)(K + u.aux);
       // up half of the concat buffer: hi planes [c / 8, 2 c / 8), m8 planes [2 c / 16, 4 c / 16)
       rc = iunet_x2m_convT_fwd(dim, WS + L.b[l + 1], 2ll * cn * vi, cn / 8, WS + L.cat[l] + (long long)(c / 8) * v * 16, 2ll * c * v, -1,
-                               WS + L.catm[l] + (long long)(2 * c / 16) * v * 16, 4ll * c * v, K + u.pk, aux, aux + c, N, di, hi, wi, cn, c, stream);
+                               WS + L.catm[l] + (long long)(2 * c / 16) * v * 16, 4ll * c * v, K + u.pk, aux, aux + c, N, di, hi, wi, cn, c, sat, stream);
       if (rc) return rc;
       const ConvOp& c1 = n->conv[2 * stage_index(n, true, l)];
       const ConvOp& c2 = n->conv[2 * stage_index(n, true, l) + 1];
@@ -386,7 +388,7 @@ int iunet_net_forward(iunet_net* n, const void* x, int in_dtype, const long long
     int d, h, w;
     dims(l, d, h, w);
     const float* aux = (const float*)(K + op.aux);
-    if (x2) return iunet_x2_conv3_fwd(dim, xp, x_ss, x_lo, yp, y_ss, y_lo, K + op.pk[1], aux, aux + op.co, N, d, h, w, op.ci, op.co, 2, stream);
+    if (x2) return iunet_x2_conv3_fwd_flag(dim, xp, x_ss, x_lo, yp, y_ss, y_lo, K + op.pk[1], aux, aux + op.co, N, d, h, w, op.ci, op.co, 2, WS, stream);
     int lay = 1;
     if (op.pk[3] >= 0 && iunet_conv3_compact_ok(dim, N, d, h, w, op.ci, op.co, 0, 0)) lay = 3;
     else {
@@ -404,8 +406,8 @@ int iunet_net_forward(iunet_net* n, const void* x, int in_dtype, const long long
     const ConvOp& c2 = n->conv[2 * stage_index(n, false, l) + 1];
     if (l == 0) {
       const float* aux = (const float*)(K + c1.aux);
-      rc = x2 ? iunet_x2_first_conv_fwd(dim, x, in_dtype, in_strides, WS + L.a[0], 2ll * c * v, c8, K + c1.pk[1], aux, aux + c, n->act_scale,
-                                        N, d, h, w, n->cin, c, 1, stream)
+      rc = x2 ? iunet_x2m_first_conv_fwd(dim, x, in_dtype, in_strides, WS + L.a[0], 2ll * c * v, c8, nullptr, 0, K + c1.pk[1], aux, aux + c, n->act_scale,
+                                         N, d, h, w, n->cin, c, 1, WS, stream)
               : iunet_first_conv_fwd(mode, dim, x, in_dtype, in_strides, WS + L.a[0], (long long)c * v, K + c1.pk[1], aux + c, nullptr,
                                      N, d, h, w, n->cin, c, 1, stream);
     } else {
@@ -435,8 +437,8 @@ int iunet_net_forward(iunet_net* n, const void* x, int in_dtype, const long long
     const UpOp& u = n->up[lv - 2 - l];
     const float* aux = (const float*)(K + u.aux);
     // up half of the concat buffer: hi planes [c8, 2 c8) (x2: lo planes [3 c8, 4 c8))
-    rc = x2 ? iunet_x2_convT_fwd(dim, WS + L.b[l + 1], 2ll * cn * vi, cn / 8, plane(L.cat[l], c8, l), 4ll * c * v, 2 * c8, K + u.pk, aux, aux + c,
-                                 N, di, hi, wi, cn, c, stream)
+    rc = x2 ? iunet_x2m_convT_fwd(dim, WS + L.b[l + 1], 2ll * cn * vi, cn / 8, plane(L.cat[l], c8, l), 4ll * c * v, 2 * c8, nullptr, 0, K + u.pk, aux, aux + c,
+                                  N, di, hi, wi, cn, c, WS, stream)
             : iunet_convT_fwd(mode, dim, WS + L.b[l + 1], (long long)cn * vi, plane(L.cat[l], c8, l), 2ll * c * v, K + u.pk, n->flat + u.b,
                               N, di, hi, wi, cn, c, stream);
     if (rc) return rc;

@@ -23,7 +23,7 @@
 
 int iunet_conv3_v4_x2_launch(int nd, const void* x, long long x_sstride, int x_lo, void* y, long long y_sstride, int y_lo, const void* wpk,
                              const float* oscale, const float* bias, int N, int D, int H, int W, int Cin, int Cout, int epi,
-                             hipStream_t stream);
+                             int* sat, hipStream_t stream);
 int iunet_conv3_v4_x2_pack_mode(int nd);
 
 namespace {
@@ -105,6 +105,7 @@ struct X2FirstParams {
   const void* x; long long sN, sC, sD, sH, sW; int in_dtype;       // caller's tensor, generic element strides; 0 f32, 1 f16, 2 u8 (/ 255), 3 bf16
   void* y; long long y_sstride; int y_lo;             // y_lo < 0: no lo planes (x2m: a tensor only 3x3x3 convs read)
   void* y8; long long y8_sstride;                      // x2m: the m8 planes of the output (conv3_x2m.hip; bytes) or null
+  int* sat;                                            // optional range flag (common.h: x2_note_saturation)
   const void* w;                        // virtual operator [Cout][3 Cin][taps] in the first conv's fragment order (pack_first_conv, "Cin" = 3 Cin)
   const float* oscale; const float* bias;
   float act_scale;
@@ -199,6 +200,7 @@ __global__ __launch_bounds__(256) void x2_first_conv_kernel(X2FirstParams p) {
       const long long off = (((long long)gz * p.H + gy) * p.W + gx) * 8;
       *(f16x8*)(yout + (long long)(cob * 4 + q) * plane_stride + off) = o;
       if (p.y_lo >= 0) *(f16x8*)(yout + (long long)(p.y_lo + cob * 4 + q) * plane_stride + off) = ol;
+      if (p.sat != nullptr) x2_note_saturation(p.sat, o);
       if (p.y8 != nullptr) {
         unsigned char* y8 = (unsigned char*)p.y8 + (long long)n * p.y8_sstride + x2m_off(cob * 4 + q, off / 8, plane_stride / 8);
         *(u32x2_t*)y8 = l8;
@@ -257,6 +259,7 @@ struct X2ConvTParams {
   const void* x; long long x_sstride; int x_lo;
   void* y; long long y_sstride; int y_lo;             // y_lo < 0: no lo planes
   void* y8; long long y8_sstride;                      // x2m: the m8 planes of the output (bytes) or null
+  int* sat;                                            // optional range flag
   const void* wpk; const float* oscale; const float* bias;
   int N, D, H, W, Cin, Cout;            // input grid; Cin = real input channels
 };
@@ -425,6 +428,7 @@ __global__ __launch_bounds__(256, RES ? 2 : 1) void x2_convT_lds_kernel(X2ConvTP
               *(u32x2_t*)(y8 + ovox * 16) = h8;
             }
           }
+          if (p.sat != nullptr && x0 + l15 < p.W) x2_note_saturation(p.sat, o);
           oc[c][0] = __builtin_bit_cast(i32x4, o);
           oc[c][1] = __builtin_bit_cast(i32x4, ol);
         }
@@ -550,20 +554,20 @@ int iunet_x2_prep(const void* w, void* wv, void* oscale, void* bias_out, const v
  * split(relu?(conv * oscale + bias)); w = iunet_pack_first_conv of the virtual operator with "Cin" = 3 Cin */
 int iunet_x2m_first_conv_fwd(int nd, const void* x, int in_dtype, const long long* in_strides, void* y, long long y_sstride, int y_lo,
                              void* y8, long long y8_sstride, const void* w, const void* oscale, const void* bias, float act_scale, int N,
-                             int D, int H, int W, int Cin, int Cout, int relu, void* stream);
+                             int D, int H, int W, int Cin, int Cout, int relu, void* sat, void* stream);
 int iunet_x2_first_conv_fwd(int nd, const void* x, int in_dtype, const long long* in_strides, void* y, long long y_sstride, int y_lo,
                             const void* w, const void* oscale, const void* bias, float act_scale, int N, int D, int H, int W, int Cin,
                             int Cout, int relu, void* stream) {
   IUNET_REQUIRE(y_lo >= 0, "x2_first_conv: y_lo must not be negative");
   return iunet_x2m_first_conv_fwd(nd, x, in_dtype, in_strides, y, y_sstride, y_lo, nullptr, 0, w, oscale, bias, act_scale, N, D, H, W, Cin, Cout,
-                                  relu, stream);
+                                  relu, nullptr, stream);
 }
 
 /* the same first conv writing, beside the hi planes, the m8 planes of its output (y8, y8_sstride bytes per sample; null: none) and the
- * lo planes only when y_lo >= 0 */
+ * lo planes only when y_lo >= 0; sat: optional device int raised to 0x7bff when a stored hi word saturated */
 int iunet_x2m_first_conv_fwd(int nd, const void* x, int in_dtype, const long long* in_strides, void* y, long long y_sstride, int y_lo,
                              void* y8, long long y8_sstride, const void* w, const void* oscale, const void* bias, float act_scale, int N,
-                             int D, int H, int W, int Cin, int Cout, int relu, void* stream) {
+                             int D, int H, int W, int Cin, int Cout, int relu, void* sat, void* stream) {
   IUNET_REQUIRE(x && y && w && oscale && bias && in_strides, "x2_first_conv: null pointer");
   IUNET_REQUIRE(nd == 2 || nd == 3, "x2_first_conv: nd must be 2 or 3");
   IUNET_REQUIRE_GRID("x2_first_conv", N, D, H, W);
@@ -574,7 +578,7 @@ int iunet_x2m_first_conv_fwd(int nd, const void* x, int in_dtype, const long lon
   IUNET_REQUIRE(pow2(act_scale), "x2_first_conv: the activation scale must be a power of two (got %g)", act_scale);
   X2FirstParams p;
   p.x = x; p.sN = in_strides[0]; p.sC = in_strides[1]; p.sD = in_strides[2]; p.sH = in_strides[3]; p.sW = in_strides[4];
-  p.in_dtype = in_dtype; p.y = y; p.y_sstride = y_sstride; p.y_lo = y_lo; p.y8 = y8; p.y8_sstride = y8_sstride; p.w = w; p.oscale = (const float*)oscale;
+  p.in_dtype = in_dtype; p.y = y; p.y_sstride = y_sstride; p.y_lo = y_lo; p.y8 = y8; p.y8_sstride = y8_sstride; p.sat = (int*)sat; p.w = w; p.oscale = (const float*)oscale;
   p.bias = (const float*)bias; p.act_scale = act_scale; p.N = N; p.D = D; p.H = H; p.W = W; p.Cout = Cout; p.relu = relu;
   const int TZ = nd == 3 ? 4 : 1, TY = nd == 3 ? 8 : 16, TX = nd == 3 ? 16 : 32;
   dim3 grid(N * ((D + TZ - 1) / TZ) * ((H + TY - 1) / TY) * ((W + TX - 1) / TX), Cout / 32);
@@ -593,8 +597,8 @@ int iunet_x2_pack_mode(int nd) { return iunet_conv3_v4_x2_pack_mode(nd); }
 
 /* stage conv 3^d of the split-precision forward: x / y = Cin / 8 (Cout / 8) hi planes, the lo planes x_lo / y_lo planes further on;
  * wpk = iunet_pack_conv3 (mode iunet_x2_pack_mode(nd)) of the virtual operator [Cout][3 Cin][taps]; epi as iunet_conv3_fwd */
-int iunet_x2_conv3_fwd(int nd, const void* x, long long x_sstride, int x_lo, void* y, long long y_sstride, int y_lo, const void* wpk,
-                       const void* oscale, const void* bias, int N, int D, int H, int W, int Cin, int Cout, int epi, void* stream) {
+int iunet_x2_conv3_fwd_flag(int nd, const void* x, long long x_sstride, int x_lo, void* y, long long y_sstride, int y_lo, const void* wpk,
+                            const void* oscale, const void* bias, int N, int D, int H, int W, int Cin, int Cout, int epi, void* sat, void* stream) {
   IUNET_REQUIRE(x && y && wpk && oscale, "x2_conv3: null pointer");
   IUNET_REQUIRE(nd == 2 || nd == 3, "x2_conv3: nd must be 2 or 3");
   IUNET_REQUIRE_GRID("x2_conv3", N, D, H, W);
@@ -603,7 +607,12 @@ int iunet_x2_conv3_fwd(int nd, const void* x, long long x_sstride, int x_lo, voi
   IUNET_REQUIRE(epi >= 0 && epi <= 2, "x2_conv3: bad epilogue %d", epi);
   IUNET_REQUIRE(epi == 0 || bias != nullptr, "x2_conv3: epilogue %d needs a bias", epi);
   return iunet_conv3_v4_x2_launch(nd, x, x_sstride, x_lo, y, y_sstride, y_lo, wpk, (const float*)oscale, (const float*)bias, N, D, H, W,
-                                  Cin, Cout, epi, (hipStream_t)stream);
+                                  Cin, Cout, epi, (int*)sat, (hipStream_t)stream);
+}
+
+int iunet_x2_conv3_fwd(int nd, const void* x, long long x_sstride, int x_lo, void* y, long long y_sstride, int y_lo, const void* wpk,
+                       const void* oscale, const void* bias, int N, int D, int H, int W, int Cin, int Cout, int epi, void* stream) {
+  return iunet_x2_conv3_fwd_flag(nd, x, x_sstride, x_lo, y, y_sstride, y_lo, wpk, oscale, bias, N, D, H, W, Cin, Cout, epi, nullptr, stream);
 }
 
 int iunet_x2_maxpool_fwd(int nd, const void* x, long long x_ss, int x_lo, void* y, long long y_ss, int y_lo, int C, int N, int Do,
@@ -621,23 +630,23 @@ int iunet_x2_maxpool_fwd(int nd, const void* x, long long x_ss, int x_lo, void* 
 
 /* transposed conv k2 s2; wpk = iunet_pack_convT ("Cin" = 2 Cin) of iunet_x2_prep's transposed = 2 operator [2 Cin][Cout][npos] */
 int iunet_x2m_convT_fwd(int nd, const void* x, long long x_ss, int x_lo, void* y, long long y_ss, int y_lo, void* y8, long long y8_ss,
-                        const void* wpk, const void* oscale, const void* bias, int N, int D, int H, int W, int Cin, int Cout, void* stream);
+                        const void* wpk, const void* oscale, const void* bias, int N, int D, int H, int W, int Cin, int Cout, void* sat, void* stream);
 int iunet_x2_convT_fwd(int nd, const void* x, long long x_ss, int x_lo, void* y, long long y_ss, int y_lo, const void* wpk,
                        const void* oscale, const void* bias, int N, int D, int H, int W, int Cin, int Cout, void* stream) {
   IUNET_REQUIRE(y_lo >= 0, "x2_convT: y_lo must not be negative");
-  return iunet_x2m_convT_fwd(nd, x, x_ss, x_lo, y, y_ss, y_lo, nullptr, 0, wpk, oscale, bias, N, D, H, W, Cin, Cout, stream);
+  return iunet_x2m_convT_fwd(nd, x, x_ss, x_lo, y, y_ss, y_lo, nullptr, 0, wpk, oscale, bias, N, D, H, W, Cin, Cout, nullptr, stream);
 }
 
 /* the same transposed conv writing, beside the hi planes, the m8 planes of its output (y8, y8_ss bytes per sample; null: none) and the lo
- * planes only when y_lo >= 0 */
+ * planes only when y_lo >= 0; sat: optional range flag */
 int iunet_x2m_convT_fwd(int nd, const void* x, long long x_ss, int x_lo, void* y, long long y_ss, int y_lo, void* y8, long long y8_ss,
-                        const void* wpk, const void* oscale, const void* bias, int N, int D, int H, int W, int Cin, int Cout, void* stream) {
+                        const void* wpk, const void* oscale, const void* bias, int N, int D, int H, int W, int Cin, int Cout, void* sat, void* stream) {
   IUNET_REQUIRE(x && y && wpk && oscale && bias, "x2_convT: null pointer");
   IUNET_REQUIRE(nd == 2 || nd == 3, "x2_convT: nd must be 2 or 3");
   IUNET_REQUIRE_GRID("x2_convT", N, D, H, W);
   IUNET_REQUIRE(Cin >= 32 && Cout >= 32 && Cin % 32 == 0 && Cout % 32 == 0, "x2_convT: channels must be positive multiples of 32 (%d, %d)", Cin, Cout);
   X2ConvTParams p;
-  p.x = x; p.x_sstride = x_ss; p.x_lo = x_lo; p.y = y; p.y_sstride = y_ss; p.y_lo = y_lo; p.y8 = y8; p.y8_sstride = y8_ss; p.wpk = wpk;
+  p.x = x; p.x_sstride = x_ss; p.x_lo = x_lo; p.y = y; p.y_sstride = y_ss; p.y_lo = y_lo; p.y8 = y8; p.y8_sstride = y8_ss; p.sat = (int*)sat; p.wpk = wpk;
   p.oscale = (const float*)oscale; p.bias = (const float*)bias; p.N = N; p.D = D; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
   const long long waves = (long long)N * D * H * ((W + 15) / 16);
   const int kc = iunet_x2_convT_kc(Cin), nchunks = Cin / 32 / kc, npos = nd == 3 ? 8 : 4;

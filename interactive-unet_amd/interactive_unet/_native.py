@@ -75,9 +75,11 @@ _SIGS = {
     'iunet_x2m_prep': [c_void_p] * 9 + [c_float, c_float, c_float, c_int, c_int, c_void_p],
     'iunet_x2m_make8': [c_void_p, c_ll, c_int, c_void_p, c_ll, c_int, c_int, c_int, c_int, c_int, c_void_p],
     'iunet_x2m_first_conv_fwd': [c_int, c_void_p, c_int, ctypes.POINTER(c_ll), c_void_p, c_ll, c_int, c_void_p, c_ll, c_void_p, c_void_p, c_void_p,
-                                 c_float, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+                                 c_float, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     'iunet_x2m_convT_fwd': [c_int, c_void_p, c_ll, c_int, c_void_p, c_ll, c_int, c_void_p, c_ll, c_void_p, c_void_p, c_void_p,
-                            c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+                            c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
+    'iunet_x2_conv3_fwd_flag': [c_int, c_void_p, c_ll, c_int, c_void_p, c_ll, c_int, c_void_p, c_void_p, c_void_p,
+                                c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     'iunet_x2m_maxpool_fwd': [c_int, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_ll, c_int, c_int, c_int, c_int, c_int, c_void_p],
     'iunet_x2m_conv3_fwd': [c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_ll, c_int, c_void_p, c_ll, c_void_p, c_void_p, c_void_p, c_void_p,
                             c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],

@@ -52,8 +52,8 @@ class EngineX2:
         self.use_graph = True      # False: every forward sequenced from Python (tests compare the two)
         self._g, self._gparams, self._g_dirty, self._g_last, self._g_fwd = None, None, False, None, 0      # the C++-sequenced forward (_graph)
         nv.lib()
-        # range flag of the x2m convs: raised (atomicMax, no synchronisation) to 0x7bff when a stored hi word saturated at 65504
-        self._sat = torch.zeros(1, dtype=torch.int32, device=self.device) if self.mixed else None
+        # range flag: every producer of the forward raises it (atomicMax, no synchronisation) to 0x7bff when a stored hi word saturated at 65504
+        self._sat = torch.zeros(1, dtype=torch.int32, device=self.device)
 
     def _graph(self):
         """The C++-sequenced forward (net_graph.NetGraph) on this engine's current parameters, or None where the handle level does not
@@ -202,8 +202,8 @@ class EngineX2:
         if probe is not None:
             e0 = torch.cuda.Event(enable_timing=True)
             e0.record()
-        nv.call('iunet_x2_conv3_fwd', self.dim, xp, x_ss, x_lo, yp, y_ss, y_lo, nv.ptr(w), nv.ptr(osc), nv.ptr(b),
-                N, d[0], d[1], d[2], ci, co, 2, s)
+        nv.call('iunet_x2_conv3_fwd_flag', self.dim, xp, x_ss, x_lo, yp, y_ss, y_lo, nv.ptr(w), nv.ptr(osc), nv.ptr(b),
+                N, d[0], d[1], d[2], ci, co, 2, nv.ptr(self._sat), s)
         if probe is not None:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
@@ -234,9 +234,9 @@ class EngineX2:
             c8 = ch[l] // 8
             if l == 0:
                 w, osc, b = self.packed['enc0.conv1']
-                nv.call('iunet_x2_first_conv_fwd', self.dim, nv.ptr(x), nv.IN_DTYPE_CODE[x.dtype], nv.ll_array(x_strides),
-                        Pt(ws['a0']), 2 * ch[0] * v, c8, nv.ptr(w), nv.ptr(osc), nv.ptr(b), self.act_scale,
-                        N, d[0], d[1], d[2], self.cin, ch[0], 1, s)
+                nv.call('iunet_x2m_first_conv_fwd', self.dim, nv.ptr(x), nv.IN_DTYPE_CODE[x.dtype], nv.ll_array(x_strides),
+                        Pt(ws['a0']), 2 * ch[0] * v, c8, None, 0, nv.ptr(w), nv.ptr(osc), nv.ptr(b), self.act_scale,
+                        N, d[0], d[1], d[2], self.cin, ch[0], 1, nv.ptr(self._sat), s)
             else:
                 self._conv3(f'enc{l}.conv1', Pt(ws[f'pin{l}']), 2 * ch[l - 1] * v, ch[l - 1] // 8, Pt(ws[f'a{l}']), 2 * ch[l] * v, c8,
                             N, d, ch[l - 1], ch[l], s)
@@ -255,9 +255,9 @@ class EngineX2:
             c8 = ch[l] // 8
             w, osc, b = self.packed[f'dec{l}.up']
             # up half of the concat buffer: hi planes [c8, 2 c8), lo planes [3 c8, 4 c8)
-            nv.call('iunet_x2_convT_fwd', self.dim, Pt(ws[f'b{l + 1}']), 2 * ch[l + 1] * vi, ch[l + 1] // 8,
-                    Pt(ws[f'cat{l}'], c8, v), 4 * ch[l] * v, 2 * c8, nv.ptr(w), nv.ptr(osc), nv.ptr(b),
-                    N, di[0], di[1], di[2], ch[l + 1], ch[l], s)
+            nv.call('iunet_x2m_convT_fwd', self.dim, Pt(ws[f'b{l + 1}']), 2 * ch[l + 1] * vi, ch[l + 1] // 8,
+                    Pt(ws[f'cat{l}'], c8, v), 4 * ch[l] * v, 2 * c8, None, 0, nv.ptr(w), nv.ptr(osc), nv.ptr(b),
+                    N, di[0], di[1], di[2], ch[l + 1], ch[l], nv.ptr(self._sat), s)
             self._conv3(f'dec{l}.conv1', Pt(ws[f'cat{l}']), 4 * ch[l] * v, 2 * c8, Pt(ws[f'a{l}']), 2 * ch[l] * v, c8,
                         N, d, 2 * ch[l], ch[l], s)
             self._conv3(f'dec{l}.conv2', Pt(ws[f'a{l}']), 2 * ch[l] * v, c8, Pt(ws[f'b{l}']), 2 * ch[l] * v, c8,
@@ -302,7 +302,7 @@ class EngineX2:
                 w, osc, b = self.packed['enc0.conv1']
                 nv.call('iunet_x2m_first_conv_fwd', self.dim, nv.ptr(x), nv.IN_DTYPE_CODE[x.dtype], nv.ll_array(x_strides),
                         Ph(ws['a0']), c * v, -1, P8(ws['a0m']), 2 * c * v, nv.ptr(w), nv.ptr(osc), nv.ptr(b), self.act_scale,
-                        N, d[0], d[1], d[2], self.cin, c, 1, s)
+                        N, d[0], d[1], d[2], self.cin, c, 1, nv.ptr(self._sat), s)
             else:
                 cp = ch[l - 1]
                 self._conv3m(f'enc{l}.conv1', Ph(ws[f'pin{l}']), cp * v, P8(ws[f'pin{l}m']), 2 * cp * v, Ph(ws[f'a{l}']), c * v, -1,
@@ -323,7 +323,7 @@ class EngineX2:
             w, osc, b = self.packed[f'dec{l}.up']
             # up half of the concat buffer: hi planes [c / 8, 2 c / 8), m8 planes [2 c / 16, 4 c / 16)
             nv.call('iunet_x2m_convT_fwd', self.dim, nv.ptr(ws[f'b{l + 1}']), 2 * cn * vi, cn // 8, Ph(ws[f'cat{l}'], c // 8, v), 2 * c * v, -1,
-                    P8(ws[f'cat{l}m'], 2 * c // 16, v), 4 * c * v, nv.ptr(w), nv.ptr(osc), nv.ptr(b), N, di[0], di[1], di[2], cn, c, s)
+                    P8(ws[f'cat{l}m'], 2 * c // 16, v), 4 * c * v, nv.ptr(w), nv.ptr(osc), nv.ptr(b), N, di[0], di[1], di[2], cn, c, nv.ptr(self._sat), s)
             self._conv3m(f'dec{l}.conv1', Ph(ws[f'cat{l}']), 2 * c * v, P8(ws[f'cat{l}m']), 4 * c * v, Ph(ws[f'a{l}']), c * v, -1,
                          P8(ws[f'a{l}m']), 2 * c * v, N, d, 2 * c, c, s)
             self._conv3m(f'dec{l}.conv2', Ph(ws[f'a{l}']), c * v, P8(ws[f'a{l}m']), 2 * c * v, nv.ptr(ws[f'b{l}']), 2 * c * v, c // 8,
@@ -344,12 +344,11 @@ class EngineX2:
         return m
 
     def saturated(self):
-        """Did an activation saturate (a host-synchronising diagnostic)?  mixed (3-D): EVERY forward since the engine was made raises
-        an on-device flag in the stage convs' epilogues (no synchronisation on the hot path): the answer covers all of them, whichever
-        sequence -- Python or the C++ graph -- ran them.  Otherwise: the last forward's activations are scanned."""
-        if self.mixed:
-            return int(self._sat.item()) >= 0x7bff or (self._g is not None and self._g.saturated())
-        return self.max_stored() >= 65504.0
+        """Did an activation saturate (a host-synchronising diagnostic, one 4-byte read)?  EVERY forward since the engine was made raises
+        an on-device flag in its producers' epilogues (first conv, stage convs, transposed convs; atomicMax of the saturated word's bit
+        pattern, nothing on the hot path), whichever sequence -- Python or the C++ graph -- ran it: the answer covers every block of a
+        volume, not the last one.  `max_stored()` still scans the last forward's tensors for the value itself."""
+        return int(self._sat.item()) >= 0x7bff or (self._g is not None and self._g.saturated())
 
     # ------------------------------------------------------------------ layout helpers (tests)
     def to_split(self, t):

@@ -65,14 +65,14 @@ class NetGraph:
             if len(self._ws) > 4:
                 self._ws.clear()
             ws = self._ws[key] = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-            if self.mode == 3:
-                ws[:256].zero_()           # the range flag of the x2m stage convs (csrc/net.hip: ws_layout)
+            if self.mode >= 2:
+                ws[:256].zero_()           # the range flag of the split-precision forward (csrc/net.hip: ws_layout)
         return ws
 
     def saturated(self):
-        """mode 3: did any forward on any of this handle's workspaces store a saturated (|act_scale x activation| >= 65504) hi word?
+        """modes 2 / 3: did any forward on any of this handle's workspaces store a saturated (|act_scale x activation| >= 65504) hi word?
         One small device-to-host read per workspace; the flags are cumulative since the workspace was made."""
-        return self.mode == 3 and any(int(ws[:4].view(torch.int32).item()) >= 0x7bff for ws in self._ws.values())
+        return self.mode >= 2 and any(int(ws[:4].view(torch.int32).item()) >= 0x7bff for ws in self._ws.values())
 
     def infer(self, x, x_strides, N, D, H, W, logits=None, probs=None, cls=None, out_strides=None, divisor=1.0, accumulate=False):
         if not self.filled:

@@ -306,14 +306,22 @@ def predict_volumes(input_size=256, num_channels=1, num_classes=2, overlap=0.25,
     device = torch.device('cuda')
     model = _load_model(num_channels, num_classes, device)
 
-    def store(final, save_path, name, shape, start):
+    def store(final, done, save_path, name, shape, start):
         # encoding and writing the [Z, Y, X, C] result (zstd on the host cores, ~1 GB/s) takes about as long as predicting it: it runs
-        # behind the next volume's read + prediction (one result in flight; its device tensor is this call's own)
-        root = zarr3.open(save_path, mode='w')
-        arr = root.create_array(name='0', shape=list(final.shape), dtype='uint8', overwrite=True,
-                                chunks=(chunk_size,) * 3 + (num_classes,), shards=(shard_size,) * 3 + (num_classes,))
-        arr.from_device(final)
-        multiscale.add_multiscales(save_path, scale=0.5, level0=final)     # predict.py:261 (levels zoomed on the device)
+        # behind the next volume's read + prediction (one result in flight; its device tensor is this call's own).
+        # The current device and stream are per THREAD: this worker starts on device 0 / the default stream whatever the caller had set.
+        # It takes the result's device, runs its launches (the device-to-host copies, the pyramid's zoom kernels) on a stream of its
+        # own, and makes that stream wait for the event the caller recorded behind the prediction.
+        with torch.cuda.device(final.device):
+            side = torch.cuda.Stream(device=final.device)
+            side.wait_event(done)
+            with torch.cuda.stream(side):
+                root = zarr3.open(save_path, mode='w')
+                arr = root.create_array(name='0', shape=list(final.shape), dtype='uint8', overwrite=True,
+                                        chunks=(chunk_size,) * 3 + (num_classes,), shards=(shard_size,) * 3 + (num_classes,))
+                arr.from_device(final)
+                multiscale.add_multiscales(save_path, scale=0.5, level0=final)     # predict.py:261 (levels zoomed on the device)
+                side.synchronize()                                               # `final` is released when this returns
         print(f'Completed volume {name} {shape} in {time.time() - start}.')
 
     pending = None
@@ -328,7 +336,9 @@ def predict_volumes(input_size=256, num_channels=1, num_classes=2, overlap=0.25,
                       f"UNet(infer_dtype='fp32') or a smaller act_scale")
             if pending is not None:
                 pending.result()                                           # (raises what the writer raised)
-            pending = writer.submit(store, final, f.replace('image_volumes', 'predicted_volumes'), os.path.basename(f),
+            done = torch.cuda.Event()
+            done.record()                                                  # on the caller's current stream, behind the prediction
+            pending = writer.submit(store, final, done, f.replace('image_volumes', 'predicted_volumes'), os.path.basename(f),
                                     tuple(volume.shape), start)
         if pending is not None:
             pending.result()

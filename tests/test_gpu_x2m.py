@@ -181,7 +181,7 @@ def test_producers_write_the_m8_planes_of_their_hi_and_lo_words():
     yh = torch.zeros(N * co * vox, dtype=torch.float16, device='cuda')
     y8 = torch.zeros(N * 2 * co * vox, dtype=torch.uint8, device='cuda')
     nv.call('iunet_x2m_first_conv_fwd', 3, nv.ptr(xu), 2, st, nv.ptr(yh), co * vox, -1, nv.ptr(y8), 2 * co * vox, nv.ptr(wpk), nv.ptr(osc), nv.ptr(b), A, N, *shape,
-            1, co, 1, nv.stream())
+            1, co, 1, None, nv.stream())
     torch.cuda.synchronize()
     assert torch.equal(yh.view(N, co * vox), y.view(N, 2 * co * vox)[:, :co * vox])
     # (the producer rounds the exact fp32 residual, make8 the fp16 lo word of it: equal unless the lo word itself was rounded -- never at these sizes)
@@ -218,7 +218,7 @@ def test_producers_write_the_m8_planes_of_their_hi_and_lo_words():
     yh = torch.zeros(N * co * uvox, dtype=torch.float16, device='cuda')
     y8 = torch.zeros(N * 2 * co * uvox, dtype=torch.uint8, device='cuda')
     nv.call('iunet_x2m_convT_fwd', 3, nv.ptr(xs), 2 * ci * ovox, ci // 8, nv.ptr(yh), co * uvox, -1, nv.ptr(y8), 2 * co * uvox, nv.ptr(wpk), nv.ptr(osc), nv.ptr(b),
-            N, *do, ci, co, nv.stream())
+            N, *do, ci, co, None, nv.stream())
     torch.cuda.synchronize()
     assert torch.equal(yh.view(N, co * uvox), y.view(N, 2 * co * uvox)[:, :co * uvox])
     lo_a, hi_a = _m8_unpack(y8.cpu(), N, co, up)
