@@ -494,6 +494,54 @@ int iunet_check_finite(const void* g, long long n, void* flag, void* stream);
 int iunet_adamw_step(void* p, const void* g, void* m, void* v, long long n, float lr, float b1, float b2, float eps,
                      float wd, int step, float grad_scale_inv, const void* skip_flag, void* stream);
 
+/* ---- training state on the device (csrc/train_pointwise.hip): 8 x 4 bytes -- [0] float loss scale, [1] int completed optimiser steps,
+ * [2] int good steps since the scale last changed, [3] int overflow flag of the last step, [4..6] the step's AdamW coefficients, [7] int
+ * dynamic scaling.  The reference trains under precision='16-mixed' (trainer.py:59): GradScaler's semantics -- an overflowing fp16 step is
+ * skipped, halves the scale and is not counted; 2000 good steps double it -- without a host read per step. */
+int iunet_train_state_init(void* state, float loss_scale, int dynamic, void* stream);
+/* iunet_head_loss_bwd / _bwd_act (in_scale / in_shift non-null) with the loss scale read from state[0] */
+int iunet_head_loss_bwd_dev(int dtype, const void* x, long long x_ss, int C0, const void* w, const void* bias, int ncls,
+                            const void* target, const void* weight, int tdtype, const void* coef, const void* state, void* dx,
+                            long long dx_ss, void* dwslab, const void* in_scale, const void* in_shift, int N, long long vox,
+                            void* stream);
+/* dW [ncls][C0], db [ncls] of the head from the reduced row of iunet_head_loss_bwd's slab ([C0 / 8][ncls][8] weight sums, then [ncls]) */
+int iunet_head_grad_scatter(const void* row, void* dw, void* db, int ncls, int C0, void* stream);
+/* the optimiser step on the device state: overflow check of the flat gradient (check != 0: fp16), AdamW (unet.py:71-73; skipped on
+ * overflow) with its bias corrections from state[1] + 1, then the scale / step-count update; world = ranks the gradient was summed over */
+int iunet_adamw_step_dev(void* p, const void* g, void* m, void* v, long long n, float lr, float b1, float b2, float eps, float wd,
+                         void* state, int check, float world, void* stream);
+
+/* ---- handle level: the TRAINING step as one call (csrc/train_net.hip) -----------------------------------------------------------
+ * unet.py:88-102 (forward with BatchNorm batch statistics, the reference's loss on the softmax probabilities, metrics.py) + backward +
+ * AdamW (unet.py:71-73) + the re-pack of the updated operators, sequenced in C++ -- the launches interactive_unet/train_engine.py
+ * sequences from Python, bit for bit.  Every device buffer is the caller's:
+ *   iunet_train* t; iunet_train_create(2, 4, 32, 1, 2, 0, 6, &t);          // 2-D, 4 levels, base 32, 1 -> 2 classes, fp16, mcc_ce
+ *   flat, grad, m, v = device floats [iunet_train_num_params(t)] (iunet_train_param: name / offset / count; grad, m, v zeroed)
+ *   running[2 * iunet_train_num_bn(t)] = device pointers: running_mean, running_var ([Cout] floats) of every BatchNorm, canonical order
+ *   state = 32 device bytes, iunet_train_state_init(state, 1024.f, 1, stream);   packed = device bytes [iunet_train_packed_bytes(t)]
+ *   iunet_train_bind(t, flat, grad, m, v, running, packed, state, stream);
+ *   ws = device bytes [iunet_train_workspace_bytes(t, N, 1, H, W)];
+ *   iunet_train_step(t, x, 2, x_strides, target, weight, 1, N, 1, H, W, ws, 1e-4f, 0.9f, 0.999f, 1e-8f, 1e-2f, out4, stream);
+ * dtype: 0 fp16 (dynamic loss scale), 1 bf16; loss_kind: 0 ce, 1 dice, 2 iou, 3 mcc, 4 dice_ce, 5 iou_ce, 6 mcc_ce (utils.py:458-475).
+ * Data parallel callers run iunet_train_forward_backward, all-reduce `grad`, then iunet_train_update(world = ranks). */
+typedef struct iunet_train iunet_train;
+int iunet_train_create(int dim, int levels, int base, int cin, int ncls, int dtype, int loss_kind, iunet_train** out);
+void iunet_train_destroy(iunet_train* t);
+long long iunet_train_num_params(const iunet_train* t);
+int iunet_train_num_tensors(const iunet_train* t);
+int iunet_train_param(const iunet_train* t, int index, char* name, int name_cap, long long* offset, long long* numel);
+int iunet_train_num_bn(const iunet_train* t);
+long long iunet_train_packed_bytes(const iunet_train* t);
+long long iunet_train_workspace_bytes(const iunet_train* t, int N, int D, int H, int W);
+int iunet_train_bind(iunet_train* t, void* flat, void* grad, void* m, void* v, void* const* running, void* packed, void* state, void* stream);
+int iunet_train_repack(iunet_train* t, void* stream);
+int iunet_train_forward_backward(iunet_train* t, const void* x, int in_dtype, const long long* in_strides, const void* target,
+                                 const void* weight, int tdtype, int N, int D, int H, int W, void* workspace, void* out4, void* stream);
+int iunet_train_update(iunet_train* t, float lr, float b1, float b2, float eps, float wd, float world, void* stream);
+int iunet_train_step(iunet_train* t, const void* x, int in_dtype, const long long* in_strides, const void* target, const void* weight,
+                     int tdtype, int N, int D, int H, int W, void* workspace, float lr, float b1, float b2, float eps, float wd, void* out4,
+                     void* stream);
+
 #ifdef __cplusplus
 }
 #endif

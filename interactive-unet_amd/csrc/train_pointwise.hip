@@ -505,6 +505,7 @@ struct HeadLossParams {
   void* dx; long long dx_ss;   // bwd: gradient wrt head input (T, blocked)
   float* dwslab;        // bwd: [nblocks][ncls*(C0+1)]
   float loss_scale;
+  const float* loss_scale_dev;   // non-null: the loss scale lives on the device (the training handle's state), read here
   int N; long long vox;
   // optional [C0] pair: the head input is relu(in_scale * x + in_shift) rounded to T -- the BatchNorm + ReLU of the last stage conv,
   // applied while loading (training: that activation is read only by the head, so it is never written; bit-identical to reading
@@ -664,6 +665,7 @@ __global__ __launch_bounds__(256) void head_loss_bwd_kernel(HeadLossParams p) {
   constexpr int ITER = (PL * NCLS <= 16) ? HeadBwdIter<NCLS>::value : 1;
   constexpr int C0 = PL * 8;
   const int n = blockIdx.y;
+  const float lscale = p.loss_scale_dev ? *p.loss_scale_dev : p.loss_scale;
   float accw[PL][NCLS][8], accb[NCLS];
 #pragma unroll
   for (int pl = 0; pl < PL; ++pl)
@@ -719,7 +721,7 @@ __global__ __launch_bounds__(256) void head_loss_bwd_kernel(HeadLossParams p) {
       dot += g[c] * pr;
     }
 #pragma unroll
-    for (int c = 0; c < NCLS; ++c) { dl[c] = e[c] * (g[c] - dot) * p.loss_scale; accb[c] += dl[c]; }   // softmax backward
+    for (int c = 0; c < NCLS; ++c) { dl[c] = e[c] * (g[c] - dot) * lscale; accb[c] += dl[c]; }   // softmax backward
     T* dxo = (T*)p.dx + n * p.dx_ss + v * 8;
 #pragma unroll
     for (int pl = 0; pl < PL; ++pl) {
@@ -763,6 +765,7 @@ __global__ __launch_bounds__(256) void head_loss_bwd_wide_kernel(HeadLossParams 
  
   constexpr int C0 = PL * 8, SUBS = 256 / PL;
   const int n = blockIdx.y, t = threadIdx.x;
+  const float lscale = p.loss_scale_dev ? *p.loss_scale_dev : p.loss_scale;
   __shared__ V8T<T> xs[PL][256];
   __shared__ float dls[256][NCLS];
   __shared__ float red[4 * NCLS];
@@ -839,7 +842,7 @@ __global__ __launch_bounds__(256) void head_loss_bwd_wide_kernel(HeadLossParams 
         dot += g[c] * pr;
       }
 #pragma unroll
-      for (int c = 0; c < NCLS; ++c) { dl[c] = e[c] * (g[c] - dot) * p.loss_scale; accb[c] += dl[c]; }   // softmax backward
+      for (int c = 0; c < NCLS; ++c) { dl[c] = e[c] * (g[c] - dot) * lscale; accb[c] += dl[c]; }   // softmax backward
       T* dxo = (T*)p.dx + n * p.dx_ss + v * 8;
 #pragma unroll 1
       for (int pl = 0; pl < PL; ++pl) {
@@ -958,6 +961,56 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
   const float denom = sqrtf(vn) / bc2_sqrt + eps;
   pv -= (lr / bc1) * (mn / denom);
   p[i] = pv;
+}
+
+// ---- the training state on the device (csrc/train_net.hip; interactive_unet/train_engine.py): no host read per step
+// state[0] float loss scale, [1] int completed optimiser steps, [2] int good steps since the last scale change, [3] int overflow flag of
+// the step in flight, [4] float bc1 = 1 - b1^step, [5] float sqrt(1 - b2^step), [6] float 1 / (loss scale x world), [7] int dynamic scale
+__global__ void train_state_coef_kernel(float* __restrict__ st, float b1, float b2, float world) {
+  int* si = (int*)st;
+  const float step = (float)(si[1] + 1);
+  st[4] = 1.f - powf(b1, step);
+  st[5] = sqrtf(1.f - powf(b2, step));
+  st[6] = 1.0f / (st[0] * world);
+}
+// GradScaler semantics (the reference trains under precision='16-mixed', trainer.py:59): an overflowing step is skipped, halves the
+// scale and is not counted; 2000 good steps in a row double it.  A fixed scale counts every step (the Python form did).
+__global__ void train_state_update_kernel(float* __restrict__ st) {
+  int* si = (int*)st;
+  const bool dyn = si[7] != 0, bad = si[3] != 0;
+  if (!dyn) { si[1] += 1; return; }
+  if (bad) { st[0] = fmaxf(st[0] * 0.5f, 1.0f); si[2] = 0; }
+  else {
+    si[1] += 1;
+    si[2] += 1;
+    if (si[2] >= 2000) { st[0] *= 2.0f; si[2] = 0; }
+  }
+}
+__global__ __launch_bounds__(256) void adamw_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                        float* __restrict__ v, long long n, float lr, float b1, float b2,
+                                                        float eps, float wd, const float* __restrict__ st) {
+  if (((const int*)st)[3]) return;                       // the gradient overflowed: the step is skipped
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float bc1 = st[4], bc2_sqrt = st[5], ginv = st[6];
+  const float gr = g[i] * ginv;
+  float pv = p[i] * (1.f - lr * wd);
+  const float mn = b1 * m[i] + (1.f - b1) * gr;
+  const float vn = b2 * v[i] + (1.f - b2) * gr * gr;
+  m[i] = mn; v[i] = vn;
+  const float denom = sqrtf(vn) / bc2_sqrt + eps;
+  pv -= (lr / bc1) * (mn / denom);
+  p[i] = pv;
+}
+// head gradient from the reduced slab row: [C0 / 8][ncls][8] weight sums, then [ncls] bias sums -> dW [ncls][C0], db [ncls]
+__global__ void head_grad_scatter_kernel(const float* __restrict__ t, float* __restrict__ dw, float* __restrict__ db, int ncls, int C0) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < ncls * C0) {
+    const int c = i / C0, ch = i - c * C0;
+    dw[i] = t[((ch >> 3) * ncls + c) * 8 + (ch & 7)];
+  } else if (i < ncls * C0 + ncls) {
+    db[i - ncls * C0] = t[i];
+  }
 }
 
 }  // namespace
@@ -1253,13 +1306,13 @@ int iunet_head_loss_fwd_act(int dtype, const void* x, long long x_ss, int C0, co
 static int head_loss_bwd_impl(int dtype, const void* x, long long x_ss, int C0, const void* w, const void* bias, int ncls,
                               const void* target, const void* weight, int tdtype, const void* coef, float loss_scale, void* dx,
                               long long dx_ss, void* dwslab, int N, long long vox, const void* in_scale, const void* in_shift,
-                              void* stream) {
+                              void* stream, const void* loss_scale_dev = nullptr) {
   DT_OK(dtype);
   IUNET_REQUIRE(x && w && bias && target && coef && dx && dwslab, "head_loss_bwd: null pointer");
   IUNET_REQUIRE(ncls >= 2 && ncls <= 10, "head_loss: num_classes must be 2..10");
   HeadLossParams p{};
   p.x = x; p.x_ss = x_ss; p.planes = C0 / 8; p.w = (const float*)w; p.bias = (const float*)bias;
-  p.target = target; p.weight = weight; p.tdtype = tdtype; p.coef = (const float*)coef; p.loss_scale = loss_scale;
+  p.target = target; p.weight = weight; p.tdtype = tdtype; p.coef = (const float*)coef; p.loss_scale = loss_scale; p.loss_scale_dev = (const float*)loss_scale_dev;
   p.dx = dx; p.dx_ss = dx_ss; p.dwslab = (float*)dwslab; p.N = N; p.vox = vox;
   p.in_scale = (const float*)in_scale; p.in_shift = (const float*)in_shift;
   IUNET_REQUIRE(C0 == 32 || C0 == 64, "head_loss_bwd: head input must have 32 or 64 channels (got %d)", C0);
@@ -1329,6 +1382,49 @@ int iunet_adamw_step(void* p, const void* g, void* m, void* v, long long n, floa
   hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (float*)p,
                      (const float*)g, (float*)m, (float*)v, n, lr, b1, b2, eps, wd, bc1, bc2s, grad_scale_inv,
                      (const int*)skip_flag);
+  IUNET_CHECK_HIP(hipGetLastError());
+  return IUNET_OK;
+}
+
+/* ---- training state on the device: loss scale, step count and the overflow back-off without a host read per step ------------- */
+int iunet_train_state_init(void* state, float loss_scale, int dynamic, void* stream) {
+  IUNET_REQUIRE(state && loss_scale > 0.f, "train_state_init: bad arguments");
+  float h[8] = {loss_scale, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  ((int*)h)[7] = dynamic ? 1 : 0;
+  IUNET_CHECK_HIP(hipMemcpyAsync(state, h, sizeof(h), hipMemcpyHostToDevice, (hipStream_t)stream));
+  IUNET_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));          // (h is a stack buffer; initialisation is not on the hot path)
+  return IUNET_OK;
+}
+/* head + loss backward with the loss scale read from state[0] (in_scale / in_shift null: the head input is the stored activation) */
+int iunet_head_loss_bwd_dev(int dtype, const void* x, long long x_ss, int C0, const void* w, const void* bias, int ncls,
+                            const void* target, const void* weight, int tdtype, const void* coef, const void* state, void* dx,
+                            long long dx_ss, void* dwslab, const void* in_scale, const void* in_shift, int N, long long vox,
+                            void* stream) {
+  IUNET_REQUIRE(state != nullptr, "head_loss_bwd_dev: null state");
+  IUNET_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "head_loss_bwd_dev: in_scale and in_shift come together");
+  return head_loss_bwd_impl(dtype, x, x_ss, C0, w, bias, ncls, target, weight, tdtype, coef, 0.f, dx, dx_ss, dwslab, N, vox,
+                            in_scale, in_shift, stream, state);
+}
+/* dW [ncls][C0], db [ncls] of the head from the reduced slab row of iunet_head_loss_bwd */
+int iunet_head_grad_scatter(const void* row, void* dw, void* db, int ncls, int C0, void* stream) {
+  IUNET_REQUIRE(row && dw && db && ncls > 0 && C0 % 8 == 0, "head_grad_scatter: bad arguments");
+  const int n = ncls * C0 + ncls;
+  hipLaunchKernelGGL(head_grad_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)row, (float*)dw, (float*)db, ncls, C0);
+  IUNET_CHECK_HIP(hipGetLastError());
+  return IUNET_OK;
+}
+/* the optimiser step on the device state: overflow check of the flat gradient (fp16 training: check != 0), the step's coefficients,
+ * AdamW (skipped on overflow), then the scale / step-count update.  world: ranks the gradient was summed over. */
+int iunet_adamw_step_dev(void* p, const void* g, void* m, void* v, long long n, float lr, float b1, float b2, float eps, float wd,
+                         void* state, int check, float world, void* stream) {
+  IUNET_REQUIRE(p && g && m && v && state && n > 0 && world >= 1.f, "adamw_dev: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  IUNET_CHECK_HIP(hipMemsetAsync((int*)state + 3, 0, sizeof(int), s));
+  if (check) hipLaunchKernelGGL(check_finite_kernel, dim3(1024), dim3(256), 0, s, (const float*)g, n, (int*)state + 3);
+  hipLaunchKernelGGL(train_state_coef_kernel, dim3(1), dim3(1), 0, s, (float*)state, b1, b2, world);
+  hipLaunchKernelGGL(adamw_dev_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (float*)p, (const float*)g, (float*)m, (float*)v,
+                     n, lr, b1, b2, eps, wd, (const float*)state);
+  hipLaunchKernelGGL(train_state_update_kernel, dim3(1), dim3(1), 0, s, (float*)state);
   IUNET_CHECK_HIP(hipGetLastError());
   return IUNET_OK;
 }

@@ -91,6 +91,23 @@ _SIGS = {
     'iunet_net_forward': [c_void_p, c_void_p, c_int, ctypes.POINTER(c_ll), c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                           c_void_p, ctypes.POINTER(c_ll), c_float, c_int, c_void_p],
     'iunet_net_forward_argmax': [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
+    # ---- training state on the device + the training step as one C call (csrc/train_net.hip)
+    'iunet_train_state_init': [c_void_p, c_float, c_int, c_void_p],
+    'iunet_head_loss_bwd_dev': [c_int, c_void_p, c_ll, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                c_void_p, c_ll, c_void_p, c_void_p, c_void_p, c_int, c_ll, c_void_p],
+    'iunet_head_grad_scatter': [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
+    'iunet_adamw_step_dev': [c_void_p, c_void_p, c_void_p, c_void_p, c_ll, c_float, c_float, c_float, c_float, c_float, c_void_p, c_int, c_float, c_void_p],
+    'iunet_train_create': [c_int, c_int, c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_void_p)],
+    'iunet_train_num_tensors': [c_void_p],
+    'iunet_train_param': [c_void_p, c_int, ctypes.c_char_p, c_int, ctypes.POINTER(c_ll), ctypes.POINTER(c_ll)],
+    'iunet_train_num_bn': [c_void_p],
+    'iunet_train_bind': [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_void_p), c_void_p, c_void_p, c_void_p],
+    'iunet_train_repack': [c_void_p, c_void_p],
+    'iunet_train_forward_backward': [c_void_p, c_void_p, c_int, ctypes.POINTER(c_ll), c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                     c_void_p, c_void_p, c_void_p],
+    'iunet_train_update': [c_void_p, c_float, c_float, c_float, c_float, c_float, c_float, c_void_p],
+    'iunet_train_step': [c_void_p, c_void_p, c_int, ctypes.POINTER(c_ll), c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                         c_float, c_float, c_float, c_float, c_float, c_void_p, c_void_p],
     # ---- fp8 matrix cores (config C5)
     'iunet_f8_pack_conv3': [c_void_p] * 5 + [c_float, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     'iunet_conv3_f8_fwd': [c_int, c_int, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_void_p, c_void_p,
@@ -175,7 +192,7 @@ _SIGS = {
 # functions that return a size / count instead of a status
 _INT_RETURN = ['iunet_pack_desc_bytes', 'iunet_augment_desc_bytes']
 _INT_RETURN_ARGS = {'iunet_zoom_nearest_len': [c_int, ctypes.c_double], 'iunet_x2_convT_kc': [c_int], 'iunet_x2_pack_mode': [c_int], 'iunet_f8_pack_order': [c_int, c_int]}
-_LL_RETURN = {'iunet_x2m_w8_bytes': [c_int] * 2, 'iunet_conv3_wgrad_slab_floats': [c_int] * 7, 'iunet_f32_pack_conv_elems': [c_int] * 3, 'iunet_f8_pack_conv3_bytes': [c_int] * 3, 'iunet_conv3_f8_workspace_elems': [c_int] * 7, 'iunet_pack_conv3_elems': [c_int] * 4,
+_LL_RETURN = {'iunet_x2m_w8_bytes': [c_int] * 2, 'iunet_train_num_params': [c_void_p], 'iunet_train_packed_bytes': [c_void_p], 'iunet_train_workspace_bytes': [c_void_p, c_int, c_int, c_int, c_int], 'iunet_conv3_wgrad_slab_floats': [c_int] * 7, 'iunet_f32_pack_conv_elems': [c_int] * 3, 'iunet_f8_pack_conv3_bytes': [c_int] * 3, 'iunet_conv3_f8_workspace_elems': [c_int] * 7, 'iunet_pack_conv3_elems': [c_int] * 4,
               'iunet_pack_first_conv_elems': [c_int] * 3, 'iunet_slice_scatter_workspace_bytes': [c_int],
               'iunet_net_num_params': [c_void_p], 'iunet_net_packed_bytes': [c_void_p], 'iunet_net_workspace_bytes': [c_void_p] + [c_int] * 4}
 
@@ -209,12 +226,13 @@ def lib():
             fn.argtypes = args
             fn.restype = c_ll
         l.iunet_net_destroy.argtypes, l.iunet_net_destroy.restype = [c_void_p], None
+        l.iunet_train_destroy.argtypes, l.iunet_train_destroy.restype = [c_void_p], None
         _lib = l
     return _lib
 
 
 def exported_symbols():
-    return ['iunet_last_error', 'iunet_net_destroy'] + list(_SIGS) + list(_LL_RETURN) + list(_INT_RETURN) + list(_INT_RETURN_ARGS)
+    return ['iunet_last_error', 'iunet_net_destroy', 'iunet_train_destroy'] + list(_SIGS) + list(_LL_RETURN) + list(_INT_RETURN) + list(_INT_RETURN_ARGS)
 
 
 def check(status):

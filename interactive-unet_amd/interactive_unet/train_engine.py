@@ -44,10 +44,13 @@ class TrainEngine:
         self.lr = model.lr if lr is None else lr
         self.kind = LOSS_KINDS[loss_kind] if isinstance(loss_kind, str) else int(loss_kind)
         self.betas, self.eps, self.wd = betas, eps, weight_decay
-        self.loss_scale = float(loss_scale) if loss_scale is not None else (1024.0 if self.T == torch.float16 else 1.0)
+        # loss scale, step count and the overflow back-off live ON THE DEVICE (csrc/train_pointwise.hip: training state): the head's
+        # backward reads the scale there, the optimiser step checks the gradient, skips / halves / counts there -- no host read per step
+        # (the fp16 step used to read its overflow flag on the host every step)
         self.dynamic_scale = self.T == torch.float16 and loss_scale is None
-        self.good_steps = 0
-        self.step_count = 0
+        self.state = torch.zeros(8, dtype=torch.float32, device=self.dev)
+        nv.call('iunet_train_state_init', nv.ptr(self.state), float(loss_scale) if loss_scale is not None else (1024.0 if self.T == torch.float16 else 1.0),
+                int(self.dynamic_scale), nv.stream())
         self.pg = process_group
         # the BatchNorm + ReLU between the two convs of a stage is applied by the consumers while they stage their input
         # wherever the second conv runs on layout 2 (3-D: always; 2-D: up to 64 channels) -- see _conv2_input
@@ -76,8 +79,31 @@ class TrainEngine:
         self._alloc_packed()
         self._ws = {}
         self.probe = None          # timing hook of one layer's forward launches (bench.py roofline), see engine.Engine.probe
+        self.use_handle = True     # False: every step sequenced from Python (tests compare the two)
         self.repack()
         model._packed_sig = None
+
+    # ------------------------------------------------------------------ training state (device-resident; reading it synchronises)
+    @property
+    def loss_scale(self):
+        return float(self.state[0].item())
+
+    @loss_scale.setter
+    def loss_scale(self, value):
+        self.state[0:1].fill_(float(value))
+
+    @property
+    def step_count(self):
+        return int(self.state.view(torch.int32)[1].item())
+
+    @property
+    def good_steps(self):
+        return int(self.state.view(torch.int32)[2].item())
+
+    @property
+    def last_step_ok(self):
+        """False when the last optimiser step was skipped because the fp16 gradient overflowed (a host read)."""
+        return int(self.state.view(torch.int32)[3].item()) == 0
 
     # ------------------------------------------------------------------ parameters
     def _flatten(self):
@@ -100,7 +126,6 @@ class TrainEngine:
         self.grad = torch.zeros_like(flat)
         self.m = torch.zeros_like(flat)
         self.v = torch.zeros_like(flat)
-        self.flag = torch.zeros(1, dtype=torch.int32, device=self.dev)
         self.names = names
         # first element of the decoder + head parameters (they follow the encoder in the flat order): bucket boundary of
         # the data-parallel all-reduce
@@ -435,21 +460,18 @@ class TrainEngine:
         v0 = _vox(dims[0])
         dfeat = ws['dz.dec0.conv2']
         nparts = nv.lib().iunet_head_loss_bwd_num_parts(N, v0, self.ncls, ch[0])
-        if self.head_act:
-            nv.call('iunet_head_loss_bwd_act', self.dt, self._P(ws['y.dec0.conv2']), ch[0] * v0, ch[0], nv.ptr(self.p('head.weight')),
+        if self.head_act:       # (the loss scale is read from the device state)
+            nv.call('iunet_head_loss_bwd_dev', self.dt, self._P(ws['y.dec0.conv2']), ch[0] * v0, ch[0], nv.ptr(self.p('head.weight')),
                     nv.ptr(self.p('head.bias')), self.ncls, nv.ptr(y), nv.ptr(w), tdt, nv.ptr(ws['coef']),
-                    self.loss_scale, self._P(dfeat), ch[0] * v0, nv.ptr(ws['hslab']), nv.ptr(ws['scale.dec0.conv2']),
+                    nv.ptr(self.state), self._P(dfeat), ch[0] * v0, nv.ptr(ws['hslab']), nv.ptr(ws['scale.dec0.conv2']),
                     nv.ptr(ws['shift.dec0.conv2']), N, v0, s)
         else:
-            nv.call('iunet_head_loss_bwd', self.dt, self._P(ws['z.dec0.conv2']), ch[0] * v0, ch[0], nv.ptr(self.p('head.weight')),
+            nv.call('iunet_head_loss_bwd_dev', self.dt, self._P(ws['z.dec0.conv2']), ch[0] * v0, ch[0], nv.ptr(self.p('head.weight')),
                     nv.ptr(self.p('head.bias')), self.ncls, nv.ptr(y), nv.ptr(w), tdt, nv.ptr(ws['coef']),
-                    self.loss_scale, self._P(dfeat), ch[0] * v0, nv.ptr(ws['hslab']), N, v0, s)
+                    nv.ptr(self.state), self._P(dfeat), ch[0] * v0, nv.ptr(ws['hslab']), None, None, N, v0, s)
         nv.call('iunet_reduce_slab', nv.ptr(ws['hslab']), nparts, self.ncls * (ch[0] + 1), nv.ptr(ws['htmp']), 1.0, 0, s)
         # slab layout: [planes][ncls][8] weight partials, then [ncls] bias partials
-        nw = self.ncls * ch[0]
-        hw = ws['htmp'][:nw].view(ch[0] // 8, self.ncls, 8).permute(1, 0, 2).reshape(self.ncls, ch[0])
-        self.g('head.weight').view(self.ncls, ch[0]).copy_(hw)
-        self.g('head.bias').copy_(ws['htmp'][nw:nw + self.ncls])
+        nv.call('iunet_head_grad_scatter', nv.ptr(ws['htmp']), nv.ptr(self.g('head.weight')), nv.ptr(self.g('head.bias')), self.ncls, ch[0], s)
         # decoder, level 0 upwards
         for l in range(0, L - 1):
             v, vi, di = _vox(dims[l]), _vox(dims[l + 1]), dims[l + 1]
@@ -506,25 +528,11 @@ class TrainEngine:
         s = nv.stream()
         n = self.flat.numel()
         world = self.buckets.finish() if self.pg is not None else 1
-        flag = None
-        if self.T == torch.float16:
-            self.flag.zero_()
-            nv.call('iunet_check_finite', nv.ptr(self.grad), n, nv.ptr(self.flag), s)
-            flag = self.flag
-        self.step_count += 1
-        nv.call('iunet_adamw_step', nv.ptr(self.flat), nv.ptr(self.grad), nv.ptr(self.m), nv.ptr(self.v), n,
-                float(self.lr), self.betas[0], self.betas[1], self.eps, self.wd, self.step_count,
-                1.0 / (self.loss_scale * world), nv.ptr(flag), s)
-        if self.dynamic_scale:
-            if int(self.flag.item()):                  # GradScaler semantics: back off, skip, undo the step count
-                self.loss_scale = max(self.loss_scale * 0.5, 1.0)
-                self.step_count -= 1
-                self.good_steps = 0
-            else:
-                self.good_steps += 1
-                if self.good_steps >= 2000:
-                    self.loss_scale *= 2.0
-                    self.good_steps = 0
+        # overflow check (fp16), this step's coefficients, AdamW (skipped on overflow), GradScaler's back-off / growth and the step
+        # count: all on the device state -- nothing is read back
+        nv.call('iunet_adamw_step_dev', nv.ptr(self.flat), nv.ptr(self.grad), nv.ptr(self.m), nv.ptr(self.v), n,
+                float(self.lr), self.betas[0], self.betas[1], self.eps, self.wd, nv.ptr(self.state),
+                int(self.T == torch.float16), float(world), s)
         self.repack()
         self.model._packed_sig = None          # weights changed behind torch's version counters
 
@@ -548,17 +556,43 @@ class TrainEngine:
         [N,ncls,*sp] (fp16 or fp32, the loader's contract loader.py:142-154)."""
         self.sync_weights()
         X, y, w, N, D, H, W, vox, xs = self._prep(X, y, w)
-        ws = self.forward_train(X, xs, N, D, H, W)
-        if self.head_act:
-            tdt, w = self.loss_forward(ws, ws['y.dec0.conv2'], y, w, N, vox, act='dec0.conv2')
+        h = self._handle()
+        if h is not None:
+            # the whole step as ONE C call (csrc/train_net.hip: the same launches in the same order, sequenced in C++)
+            out4 = h.step(X, xs, y, w, N, D, H, W, float(self.lr), self.betas, self.eps, self.wd)
+            self._py_stale = True                  # the Python sequence's packed operators are behind the weights now
+            self.model._packed_sig = None
         else:
-            tdt, w = self.loss_forward(ws, ws['z.dec0.conv2'], y, w, N, vox)
-        self.backward(ws, X, xs, y, w, tdt, N)
-        self.optimizer_step()
+            self._refresh()
+            ws = self.forward_train(X, xs, N, D, H, W)
+            if self.head_act:
+                tdt, w = self.loss_forward(ws, ws['y.dec0.conv2'], y, w, N, vox, act='dec0.conv2')
+            else:
+                tdt, w = self.loss_forward(ws, ws['z.dec0.conv2'], y, w, N, vox)
+            self.backward(ws, X, xs, y, w, tdt, N)
+            self.optimizer_step()
+            out4 = ws['out4']
         if sync:
-            o = ws['out4'].tolist()
+            o = out4.tolist()
             return {'Loss': o[0], 'Dice': o[1], 'IoU': o[2], 'MCC': o[3]}
-        return ws['out4']
+        return out4
+
+    def _handle(self):
+        """The C++-sequenced step (TrainHandle over iunet_train_*), or None where it does not apply: data parallel (the gradient buckets
+        start their all-reduce between the backward's launches), GroupNorm, a timing probe attached, IUNET_PY_TRAIN=1 (A/B switch), and the
+        FIRST step (a model that trains one step -- a smoke test -- never pays for the handle's own copy of the packed operators)."""
+        self._steps_seen = getattr(self, '_steps_seen', 0) + 1
+        if self.pg is not None or self.gn or self.probe is not None or os.environ.get('IUNET_PY_TRAIN') or not self.use_handle or self._steps_seen < 2:
+            return None
+        if getattr(self, '_h', None) is None:
+            self._h = TrainHandle(self)
+        return self._h
+
+    def _refresh(self):
+        """Before a Python-sequenced forward: re-pack this sequence's operators if C++-sequenced steps moved the weights since."""
+        if getattr(self, '_py_stale', False):
+            self.repack()
+            self._py_stale = False
 
     def _eval_engine(self):
         """The folded-BatchNorm forward in the TRAINING dtype (its features feed the fused head + loss kernel): the module's own
@@ -580,6 +614,8 @@ class TrainEngine:
         if ver != getattr(self, '_seen_version', None):
             if getattr(self, '_seen_version', None) is not None:
                 self.repack()
+                if getattr(self, '_h', None) is not None:
+                    self._h.repack()
                 self.model._packed_sig = None
             self._seen_version = ver
 
@@ -587,6 +623,7 @@ class TrainEngine:
         """Forward half of a training step (unet.py:88-102): -> (out4 = [Loss, Dice, IoU, MCC] device tensor, state for
         step_backward).  UNet.training_step wraps the pair in an autograd function."""
         self.sync_weights()
+        self._refresh()
         X, y, w, N, D, H, W, vox, xs = self._prep(X, y, w)
         ws = self.forward_train(X, xs, N, D, H, W)
         if self.head_act:
@@ -624,3 +661,77 @@ class TrainEngine:
             return ws['out4']                 # device tensor [loss, dice, iou, mcc], overwritten by the next step: clone to keep
         o = ws['out4'].tolist()
         return {'Loss': o[0], 'Dice': o[1], 'IoU': o[2], 'MCC': o[3]}
+
+
+class TrainHandle:
+    """iunet_train_* handle (csrc/train_net.hip) over a TrainEngine's own device vectors: the flat parameters / gradient / AdamW moments,
+    the module's BatchNorm running statistics and the device training state are SHARED with the Python-sequenced path (either may run the
+    next step); the packed operators and the step workspace are the handle's own."""
+
+    def __init__(self, te):
+        self.te = te
+        self.lib = nv.lib()
+        self.h = ctypes.c_void_p()
+        m = te.model
+        nv.call('iunet_train_create', te.dim, te.levels, m.base, te.cin, te.ncls, te.dt, te.kind, ctypes.byref(self.h))
+        n = self.lib.iunet_train_num_params(self.h)
+        if n != te.flat.numel():
+            raise RuntimeError(f'iunet_train: {n} parameters, the engine holds {te.flat.numel()}')
+        for i in range(self.lib.iunet_train_num_tensors(self.h)):        # the two flat layouts are the same order
+            name = ctypes.create_string_buffer(96)
+            off, cnt = ctypes.c_longlong(), ctypes.c_longlong()
+            nv.call('iunet_train_param', self.h, i, name, 96, ctypes.byref(off), ctypes.byref(cnt))
+            if te.offsets[name.value.decode()] != (off.value, cnt.value):
+                raise RuntimeError(f'iunet_train: flat layout mismatch at {name.value.decode()}')
+        bns = []
+        for prefix in te.stage_names():
+            for j in (1, 2):
+                bns += [te.p(f'{prefix}.bn{j}.running_mean'), te.p(f'{prefix}.bn{j}.running_var')]
+        assert len(bns) == 2 * self.lib.iunet_train_num_bn(self.h)
+        self._running = bns
+        arr = (ctypes.c_void_p * len(bns))(*[t.data_ptr() for t in bns])
+        self.packed = torch.empty(self.lib.iunet_train_packed_bytes(self.h), dtype=torch.uint8, device=te.dev)
+        nv.call('iunet_train_bind', self.h, nv.ptr(te.flat), nv.ptr(te.grad), nv.ptr(te.m), nv.ptr(te.v), arr, nv.ptr(self.packed),
+                nv.ptr(te.state), nv.stream())
+        self._ws = {}
+        self.out4 = torch.empty(4, dtype=torch.float32, device=te.dev)
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.lib.iunet_train_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def repack(self):
+        nv.call('iunet_train_repack', self.h, nv.stream())
+
+    def workspace(self, N, D, H, W):
+        key = (N, D, H, W)
+        ws = self._ws.get(key)
+        if ws is None:
+            nbytes = self.lib.iunet_train_workspace_bytes(self.h, N, D, H, W)
+            if nbytes <= 0:
+                raise ValueError(f'spatial size {(D, H, W)} must be divisible by {2 ** (self.te.levels - 1)}')
+            self._ws = {key: torch.empty(nbytes, dtype=torch.uint8, device=self.te.dev)}
+            ws = self._ws[key]
+        return ws
+
+    def _targets(self, y, w):
+        tdt = {torch.float32: 0, torch.float16: 1}[y.dtype]
+        if w is not None and w.dtype != y.dtype:
+            w = w.to(y.dtype)
+        return tdt, w
+
+    def forward_backward(self, X, xs, y, w, N, D, H, W):
+        tdt, w = self._targets(y, w)
+        nv.call('iunet_train_forward_backward', self.h, nv.ptr(X), nv.IN_DTYPE_CODE[X.dtype], nv.ll_array(xs), nv.ptr(y), nv.ptr(w), tdt,
+                N, D, H, W, nv.ptr(self.workspace(N, D, H, W)), nv.ptr(self.out4), nv.stream())
+        return self.out4
+
+    def step(self, X, xs, y, w, N, D, H, W, lr, betas, eps, wd):
+        tdt, w = self._targets(y, w)
+        nv.call('iunet_train_step', self.h, nv.ptr(X), nv.IN_DTYPE_CODE[X.dtype], nv.ll_array(xs), nv.ptr(y), nv.ptr(w), tdt,
+                N, D, H, W, nv.ptr(self.workspace(N, D, H, W)), lr, betas[0], betas[1], eps, wd, nv.ptr(self.out4), nv.stream())
+        return self.out4
