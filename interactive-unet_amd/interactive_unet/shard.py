@@ -123,6 +123,21 @@ class NativeOps:
             p = self._pool = torch.empty((max(nplanes, 1), self.S, self.S, self.C), dtype=torch.float32, device=self.device)
         return p
 
+    def hbm_bytes(self, acc=None):
+        """Device bytes this rank's prediction holds: the footprint window, the block-probability store, the receive pool, the slab
+        accumulators and the engine's activation workspaces + packed operators (whichever sequence -- Python or the C++ graph -- ran)."""
+        nb = lambda t: 0 if t is None else t.numel() * t.element_size()
+        total = nb(getattr(self, '_window', None)) + nb(self._store) + nb(getattr(self, '_pool', None))
+        if acc is not None:
+            total += sum(nb(getattr(acc, k, None)) for k in ('pred', 'weight', 'final', 'window', 'block_probs'))
+        eng = self.eng
+        for ws in getattr(eng, '_ws_cache', {}).values():
+            total += sum(nb(t) for k, t in ws.items() if torch.is_tensor(t))
+        g = getattr(eng, '_g', None)
+        if g is not None:
+            total += sum(nb(t) for t in g._ws.values()) + nb(g.packed) + nb(g.flat)
+        return total
+
     def forward_blocks(self, volume, padded, store, j0):
         """Probabilities of the blocks with padded coordinates `padded` into store[j0 : j0 + len(padded)]."""
         S, C, nb = self.S, self.C, len(padded)
@@ -314,4 +329,5 @@ def predict_volume_sharded(ops, my_slab, volume_shape, input_size, overlap=0.25,
     assert nxt == len(mine)
     out = ops.finalize(acc)
     return out, {'blocks': hi - lo, 'bytes_sent': sent, 'slab': (z0, z1), 'pieces_blended': len(mine), 'rounds': rounds,
-                 'halo_bytes_received': halo_recv, 'footprint': (f0, f1), 'pieces_blended_before_last_round': early}
+                 'halo_bytes_received': halo_recv, 'footprint': (f0, f1), 'pieces_blended_before_last_round': early,
+                 'hbm_bytes': ops.hbm_bytes(acc) if hasattr(ops, 'hbm_bytes') else None}

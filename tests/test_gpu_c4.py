@@ -134,8 +134,11 @@ def test_c4_subvolume_throughput_mode_vs_parity_mode():
     assert np.array_equal(outs['fp16'].argmax(-1)[sure], outs['fp32'].argmax(-1)[sure])
 
 
-def test_c4_eight_virtual_ranks_at_full_size():
-    """The 8-GPU geometry of C4 (1024^3, 1 331 blocks: 166 / 167 per rank, z-slabs of 128 planes) on ONE GPU: eight virtual ranks
+@pytest.mark.parametrize('mode', ['bf16', 'compliant'])
+def test_c4_eight_virtual_ranks_at_full_size(mode):
+    """(mode 'compliant': the default prediction mode -- split precision with the cross terms on the fp8 matrix cores -- whose activations
+    are 4 bytes per element instead of 2: the per-rank HBM footprint it reports is asserted)
+    The 8-GPU geometry of C4 (1024^3, 1 331 blocks: 166 / 167 per rank, z-slabs of 128 planes) on ONE GPU: eight virtual ranks
     (threads, real device ops, the in-process communicator of test_gpu_shard.py) run shard.predict_volume_sharded in the bench's
     dtype (bf16).  Asserted: every rank's slab is byte-identical to the 1-rank result; the halo exchange delivers at most the
     rank's footprint (<= 3 block planes + overlap) instead of the whole volume; the probability pieces a rank sends stay within
@@ -153,12 +156,13 @@ def test_c4_eight_virtual_ranks_at_full_size():
     def model():
         with warnings.catch_warnings():
             warnings.simplefilter('ignore')
-            m = UNet(num_classes=C, dim=3, act_dtype='bf16', pretrained=False)
+            m = UNet(num_classes=C, dim=3, act_dtype='bf16', infer_dtype=('bf16' if mode == 'bf16' else 'fp16x2'), pretrained=False)
         m.load_named(p)
         return m.cuda().eval()
     g = torch.Generator(device='cuda').manual_seed(2)
     vol = torch.randint(0, 256, V, dtype=torch.uint8, device='cuda', generator=g)
     ops1 = shard.NativeOps(model(), C, S)
+    assert getattr(ops1.eng, 'mixed', False) == (mode == 'compliant')
     times = []
     for _ in range(2):                                          # second run: caches warm
         torch.cuda.synchronize(); t0 = time.time()
@@ -203,7 +207,12 @@ def test_c4_eight_virtual_ranks_at_full_size():
         assert st['pieces_blended_before_last_round'] >= 0.35 * st['pieces_blended'], st
     sent = [r[1]['bytes_sent'] / 1e9 for r in res]
     halo = [r[1]['halo_bytes_received'] / 2 ** 20 for r in res]
-    print(f'C4 on 8 virtual ranks (one GPU, bf16): blocks per rank {nb}; pieces sent per rank {min(sent):.2f}-{max(sent):.2f} GB; halo planes '
+    hbm = [r[1]['hbm_bytes'] / 2 ** 30 for r in res]
+    # per-rank HBM: slab accumulators 128 x 1024^2 x (8 + 4 + 2) B = 1.75 GiB, <= 167 block probabilities x 16 MiB = 2.6 GiB, the receive
+    # pool, the footprint window, and the engine's workspace for a batch of blocks (the compliant mode's is about twice the 16-bit one's)
+    print(f'    per-rank HBM footprint ({mode}): {min(hbm):.2f}-{max(hbm):.2f} GiB of 288')
+    assert max(hbm) <= (10.0 if mode == 'bf16' else 12.0), hbm
+    print(f'C4 on 8 virtual ranks (one GPU, {mode}): blocks per rank {nb}; pieces sent per rank {min(sent):.2f}-{max(sent):.2f} GB; halo planes '
           f'received per rank {min(halo):.0f}-{max(halo):.0f} MiB (a whole-slab all-gather: 896 MiB); pieces blended before the last round '
           f'{min(r[1]["pieces_blended_before_last_round"] / r[1]["pieces_blended"] for r in res):.2f}+; summed 8-rank time {t8:.3f} s vs 1 rank '
           f'{t1:.3f} s: overhead {100 * (t8 / t1 - 1):.1f} %')

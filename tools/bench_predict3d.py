@@ -11,7 +11,7 @@ reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 mode = sys.argv[2] if len(sys.argv) > 2 else 'bf16'
 with warnings.catch_warnings():
     warnings.simplefilter('ignore')
-    m = UNet(num_classes=2, dim=3, act_dtype='bf16', infer_dtype=None if mode == 'fp16x2' else 'bf16', pretrained=False).cuda().eval()
+    m = UNet(num_classes=2, dim=3, act_dtype='bf16', infer_dtype='fp16x2' if mode == 'fp16x2' else 'bf16', pretrained=False).cuda().eval()
 m.reset_parameters(seed=0)
 S, V = 128, (416, 128, 128)
 vol = torch.randint(0, 256, V, dtype=torch.uint8, device='cuda')
