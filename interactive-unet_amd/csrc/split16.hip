@@ -478,14 +478,25 @@ __global__ __launch_bounds__(256) void x2_head_kernel(X2HeadParams p) {
   float l[NCLS];
 #pragma unroll
   for (int c = 0; c < NCLS; ++c) l[c] = 0.f;
-  for (int pl = 0; pl < p.planes; ++pl) {
-    const f16x8 xh = *(const f16x8*)(xin + (long long)pl * vox * 8);
-    const f16x8 xl = *(const f16x8*)(xin + (long long)(p.x_lo + pl) * vox * 8);
+  // (the loads of four planes are issued before the first is consumed: left rolled, a thread waited out 2 x planes memory latencies)
+  for (int pl0 = 0; pl0 < p.planes; pl0 += 4) {
+    f16x8 xh[4], xl[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float a = ((float)xh[j] + (float)xl[j]) * p.inv_act;
+    for (int u = 0; u < 4; ++u) {
+      const int pl = min(pl0 + u, p.planes - 1);
+      xh[u] = *(const f16x8*)(xin + (long long)pl * vox * 8);
+      xl[u] = *(const f16x8*)(xin + (long long)(p.x_lo + pl) * vox * 8);
+    }
 #pragma unroll
-      for (int c = 0; c < NCLS; ++c) l[c] = fmaf(a, p.w[c * p.planes * 8 + pl * 8 + j], l[c]);
+    for (int u = 0; u < 4; ++u) {
+      const int pl = pl0 + u;
+      if (pl >= p.planes) break;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float a = ((float)xh[u][j] + (float)xl[u][j]) * p.inv_act;
+#pragma unroll
+        for (int c = 0; c < NCLS; ++c) l[c] = fmaf(a, p.w[c * p.planes * 8 + pl * 8 + j], l[c]);
+      }
     }
   }
 #pragma unroll
