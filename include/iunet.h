@@ -211,7 +211,7 @@ int iunet_x2_head_fwd(const void* x, long long x_ss, int x_lo, int C0, const voi
                       void* logits, void* probs, void* cls, const long long* out_strides, float divisor, int accumulate, int N, int D,
                       int H, int W, void* stream);
 
-/* ---- fp16x2 with the cross terms on the fp8 matrix cores ("x2m", 3-D stage convs; csrc/conv3_x2m.hip) ------------------------
+/* ---- fp16x2 with the cross terms on the fp8 matrix cores ("x2m", the stage convs; csrc/conv3_x2m.hip) ---------------------------
  * The two cross terms of a split product (x_lo w_hi, x_hi w_lo) are 2^-11 of it: they run as one K = 128 step of
  * v_mfma_f32_16x16x128_f8f6f4 over the virtual channels [x_lo8 | x_hi8] x [w_hi8 | w_lo8] (e4m3) into the accumulator of the main
  * term x_hi w_hi -- two matrix-step units per 16 input channels instead of three.  Beside its hi (and optional lo) planes a tensor
@@ -222,6 +222,14 @@ long long iunet_x2m_w8_bytes(int Cout, int Cin);
  * w8 = iunet_x2m_w8_bytes bytes (K128 order of [e4m3(w_hi 2^-4) | e4m3(w_lo 2^8)] per 16-channel chunk), oscale / bias_out as iunet_x2_prep */
 int iunet_x2m_prep(const void* w, void* whi, void* w8, void* oscale, void* bias_out, const void* gamma, const void* beta, const void* mean,
                    const void* var, float eps, float act_in, float act_out, int Cout, int Cin, void* stream);
+/* nd-generic forms (nd = 2: 3 x 3 filters on 16 x 32-pixel tiles, a step = 32 channels = two virtual blocks, four taps per K = 128
+ * instruction + tap 8 on the K = 32 fp8 instruction; whi goes to iunet_pack_conv3 mode 6, the cross-pair order; nd = 3: as above) */
+long long iunet_x2m_w8_bytes_nd(int nd, int Cout, int Cin);
+int iunet_x2m_prep_nd(int nd, const void* w, void* whi, void* w8, void* oscale, void* bias_out, const void* gamma, const void* beta,
+                      const void* mean, const void* var, float eps, float act_in, float act_out, int Cout, int Cin, void* stream);
+int iunet_x2m_conv_fwd(int nd, const void* x, long long x_ss, const void* x8, long long x8_ss, void* y, long long y_ss, int y_lo, void* y8,
+                       long long y8_ss, const void* w16, const void* w8, const void* oscale, const void* bias, int N, int D, int H, int W,
+                       int Cin, int Cout, int epi, void* sat, void* stream);
 /* m8 planes (x8_ss bytes per sample) of a split tensor that another kernel wrote as hi + lo words (x_ss fp16 elements per sample) */
 int iunet_x2m_make8(const void* x, long long x_ss, int x_lo, void* x8, long long x8_ss, int C, int N, int D, int H, int W, void* stream);
 /* producers of the x2m form: iunet_x2_first_conv_fwd / iunet_x2_convT_fwd writing, beside the hi planes, the m8 planes of their output
@@ -247,7 +255,7 @@ int iunet_x2m_conv3_fwd(const void* x, long long x_ss, const void* x8, long long
  *   flat = device floats [iunet_net_num_params(net)] filled tensor by tensor (iunet_net_param gives name / offset / count)
  *   packed = device bytes [iunet_net_packed_bytes(net)];  iunet_net_load(net, flat, packed, stream);
  *   ws = device bytes [iunet_net_workspace_bytes(net, N, 1, H, W)];  iunet_net_forward_argmax(net, x_u8, cls_u8, N, 1, H, W, ws, stream);
- * mode: 0 fp16, 1 bf16 (16-bit activations), 2 fp16x2 (split precision: logits within 1e-3 of the fp32 predict), 3 (3-D only) fp16x2 with
+ * mode: 0 fp16, 1 bf16 (16-bit activations), 2 fp16x2 (split precision: logits within 1e-3 of the fp32 predict), 3 fp16x2 with
  * the cross terms of the stage convs on the fp8 matrix cores (the x2m entry points above: two matrix-step units per 16 input channels
  * instead of three); modes 2 / 3: the first 4 bytes of the workspace are an int the forward raises to 0x7bff when a stored activation word
  * saturates at 65504 -- zero it once, read it when convenient; act_scale: a power of two, modes 2 / 3 only (0 = default 64). */

@@ -386,6 +386,319 @@ __global__ __launch_bounds__((XMTile<SMALL>::NCW * 64 + XM_NLT), 1) void conv3_x
   }
 }
 
+
+// ==================================================================================================================== 2-D (3 x 3 filters)
+// The same two kinds of step on conv3_v4.hip's 2-D geometry: tile 16 x 32 pixels, 8 consumer waves (2 rows x 2 x-halves each), a step =
+// 32 input channels.  16-bit step: the cross-pair order (pack mode 6: sub-chunk 0 columns 0 / 1, sub-chunk 1 columns 0 / 1, column 2 of
+// both: 9 taps in 9 k-slots, 72 K = 32 instructions).  fp8 step: the 32 channels are two virtual blocks b = [lo8 | hi8] of 16 channels; a
+// lane of the K = 128 instruction holds one block at ONE tap, the four lane groups take four taps -- groups (b0: taps 0..3), (b0: 4..7),
+// (b1: 0..3), (b1: 4..7) -- and tap 8 of both blocks goes to two K = 32 fp8 instructions: 32 K = 128 + 16 K = 32 instructions = 1 280
+// matrix cycles per wave beside the 1 152 of the 16-bit step (2 432 against the 3 456 of fp16x2's three 16-bit steps).  Operator of a
+// (32 Cout, 32 Cin) block: [group 4][m 2][half 2][64 lanes][16 B] + [block 2][m 2][64 lanes][8 B] = 18 432 B.  Small images (the deep
+// levels of 128^2 slices) run several slot groups per XCD, as conv3_v4.hip does, so a batch of slices fills the chip.
+constexpr int X2M2_W8 = 4 * 2 * 2 * 1024 + 2 * 2 * 512;         // 18 432
+__host__ __device__ inline int x2m2_w8_offset(int tap, int m, int b, int e, int o, int row) {      // 8 channels 8 o.. of half e of block b at `tap`
+  if (tap == 8) return 4 * 2 * 2 * 1024 + ((b * 2 + m) * 64 + (2 * e + o) * 16 + row) * 8;
+  const int G = b * 2 + (tap >> 2), q = tap & 3;
+  return (((G * 2 + m) * 2 + e) * 64 + q * 16 + row) * 16 + 8 * o;
+}
+
+__global__ __launch_bounds__(8 * 64 + XM_NLT, 1) void conv2_x2m_kernel(ConvX2MParams p) {
+  constexpr int NCW = 8, NLT = XM_NLT, NLW = NLT / 64;
+  constexpr int TY = 16, TX = 32, FX = 2, NI = 4, NR = 2;
+  constexpr int PY = TY + 2, PX = TX + 2, NPIX = PY * PX;                     // 612
+  constexpr int PLANE = ((NPIX * 16 + 255) / 256) * 256;                       // 9 984: one plane of either halo image
+  constexpr int A16 = 4 * PLANE, W16 = 3 * 3 * 2 * 1024;                       // 32 channels = four 8-channel planes; 18 432
+  constexpr int A8 = 4 * PLANE, W128 = 4 * 2 * 2 * 1024, W8 = X2M2_W8;          // [lo8 b0 | hi8 b0 | lo8 b1 | hi8 b1]
+  constexpr int OFF_A16 = 0, OFF_W16 = A16, OFF_A8 = OFF_W16 + W16, OFF_W8 = OFF_A8 + A8, OFF_E = OFF_W8 + W8;
+
+  extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cob = blockIdx.y;
+  const int nbricks = p.N * p.nby * p.nbx;
+  const int bslots = p.bx * p.by, ngrp = (int)gridDim.x / (8 * bslots);
+  const int xcd = (blockIdx.x + (nbricks < 8 ? blockIdx.y : 0)) & 7, slot_all = blockIdx.x >> 3;
+  const int grp = slot_all / bslots, slot = slot_all - grp * bslots;
+  const int sx = slot % p.bx, sy = slot / p.bx;
+  const int xb0 = (int)((long long)xcd * nbricks / 8), xb1 = (int)((long long)(xcd + 1) * nbricks / 8);
+  const int b_begin = xb0 + (int)((long long)(xb1 - xb0) * grp / ngrp), b_end = xb0 + (int)((long long)(xb1 - xb0) * (grp + 1) / ngrp);
+  const int nchunk = p.Cin / 32;
+  const int npairs = (b_end - b_begin) * nchunk;
+  if (npairs <= 0) return;
+  const long long nvox = (long long)p.H * p.W;
+  const long long plane_stride = nvox * 8;                    // elements of a 16-bit plane
+  const long long plane16b = nvox * 16;                       // bytes of either plane
+
+  auto tile_origin = [&](int k, int& n_img, int& y0, int& x0) -> bool {
+    int b = b_begin + k;
+    const int Bx = b % p.nbx; b /= p.nbx;
+    const int By = b % p.nby; n_img = b / p.nby;
+    const int ty = By * p.by + sy, tx = Bx * p.bx + sx;
+    y0 = ty * TY; x0 = tx * TX;
+    return ty < p.tilesY && tx < p.tilesX;
+  };
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  if (tid < 64) ((float*)(smem + OFF_E))[tid] = tid < 32 ? p.oscale[cob * 32 + tid] : (p.epi != 0 ? p.bias[cob * 32 + tid - 32] : 0.f);
+
+  if (wave >= NCW) {
+    // ================================================================== loader waves (LDS-DMA only)
+    const int lt = tid - NCW * 64;
+    const int lw = __builtin_amdgcn_readfirstlane(lt >> 6);
+    auto dma_piece = [&](const unsigned char* gsrc, unsigned dst) {
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+    };
+    auto dma_weights = [&](const unsigned char* ws, int off, int bytes) {
+      const int npiece = bytes / 1024;
+      for (int piece = lw; piece < npiece; piece += NLW)
+        dma_piece(ws + piece * 1024 + (lt & 63) * 16, __builtin_amdgcn_readfirstlane(lds0 + off + piece * 1024));
+    };
+    constexpr int AIT = (PLANE / 16 + NLT - 1) / NLT;          // 3
+    int pcoord[AIT];
+#pragma unroll
+    for (int it = 0; it < AIT; ++it) {
+      const int pix = min(lt + it * NLT, NPIX - 1);
+      pcoord[it] = (pix % PX) | ((pix / PX) << 8);
+    }
+    // one halo image: 4 planes of 16 bytes per pixel, `src` = the first plane (bytes), consecutive planes plane16b apart
+    auto dma_halo = [&](const unsigned char* src, int y0, int x0, int off) {
+#pragma unroll
+      for (int it = 0; it < AIT; ++it) {
+        const int base = it * NLT + lw * 64;
+        if (base < PLANE / 16) {
+          const int pix = lt + it * NLT;
+          const int px = pcoord[it] & 255, py = pcoord[it] >> 8;
+          const int gy = y0 + py - 1, gx = x0 + px - 1;
+          const bool ok = pix < NPIX && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+          const long long goff = ((long long)gy * p.W + gx) * 16;
+          if (pix < PLANE / 16) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              dma_piece(ok ? src + e * plane16b + goff : (const unsigned char*)g_xm_zero16,
+                        __builtin_amdgcn_readfirstlane(lds0 + off + e * PLANE + base * 16));
+          }
+        }
+      }
+    };
+    auto dma16 = [&](int k) {
+      const int tile = k / nchunk, chunk = k - tile * nchunk;
+      int n_img, y0, x0;
+      tile_origin(tile, n_img, y0, x0);
+      dma_weights((const unsigned char*)p.w16 + ((long long)cob * nchunk + chunk) * W16, OFF_W16, W16);
+      dma_halo((const unsigned char*)((const f16*)p.x + (long long)n_img * p.x_sstride + (long long)chunk * 4 * plane_stride), y0, x0, OFF_A16);
+    };
+    auto dma8 = [&](int k) {
+      const int tile = k / nchunk, chunk = k - tile * nchunk;
+      int n_img, y0, x0;
+      tile_origin(tile, n_img, y0, x0);
+      dma_weights((const unsigned char*)p.w8 + ((long long)cob * nchunk + chunk) * W8, OFF_W8, W8);
+      dma_halo((const unsigned char*)p.x8 + (long long)n_img * p.x8_sstride + (long long)chunk * 4 * plane16b, y0, x0, OFF_A8);
+    };
+    auto landed = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+    dma16(0);
+    landed();
+    lds_barrier();
+    for (int k = 0; k < npairs; ++k) {
+      dma8(k);
+      landed();
+      lds_barrier();
+      if (k + 1 < npairs) dma16(k + 1);
+      landed();
+      lds_barrier();
+    }
+    return;
+  }
+
+  // ==================================================================== consumer waves
+  const int l15 = lane & 15, q = lane >> 4;
+  const int row_first = wave * NR;                            // first tile row of this wave
+  // 16-bit step: q & 1 = 8-channel half, q >> 1 = column of the pair (groups 0, 1) / sub-chunk (cross group)
+  const int rbase16 = (q & 1) * PLANE + (row_first * PX + l15) * 16;
+  const int hoff16[3] = {(q >> 1) * 16, 2 * PLANE + (q >> 1) * 16, (q >> 1) * 2 * PLANE + 2 * 16};
+  // fp8 step: lane group q of K = 128 group G reads block G >> 1 at tap 4 (G & 1) + q
+  int toff[4];
+#pragma unroll
+  for (int G = 0; G < 4; ++G) {
+    const int tap = (G & 1) * 4 + q;
+    toff[G] = (G >> 1) * 2 * PLANE + ((tap / 3) * PX + (tap % 3)) * 16;
+  }
+  const int rbase8 = (row_first * PX + l15) * 16;
+  const int toff8 = (q >> 1) * PLANE + (2 * PX + 2) * 16 + (q & 1) * 8;       // tap 8 for the K = 32 instruction (+ block * 2 PLANE)
+
+  f32x4 acc[2][NI];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < NI; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+
+  f16x8 R16[2][FX][NR + 2], A16f[2][3][2];
+  i32x8 R8f[2][NI], A8f[2][2];
+  i64 R8n[2][NI], A8n[2][2];
+  auto load_group = [&](int g, auto BUF) {
+    constexpr int b = decltype(BUF)::value;
+    const unsigned char* ab = smem + OFF_A16 + rbase16 + hoff16[g];
+    const unsigned char* wl = smem + OFF_W16 + lane * 16;
+#pragma unroll
+    for (int xh = 0; xh < FX; ++xh)
+#pragma unroll
+      for (int r = 0; r < NR + 2; ++r) R16[b][xh][r] = *(const f16x8*)(ab + (r * PX + xh * 16) * 16);
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      A16f[b][dy][0] = *(const f16x8*)(wl + ((g * 3 + dy) * 2 + 0) * 1024);
+      A16f[b][dy][1] = *(const f16x8*)(wl + ((g * 3 + dy) * 2 + 1) * 1024);
+    }
+  };
+  auto group_mfmas = [&](auto BUF) {
+    constexpr int b = decltype(BUF)::value;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int n = 0; n < NI; ++n) {
+        acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A16f[b][dy][0], R16[b][n % FX][n / FX + dy], acc[0][n], 0, 0, 0);
+        acc[1][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A16f[b][dy][1], R16[b][n % FX][n / FX + dy], acc[1][n], 0, 0, 0);
+      }
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {                            // the next group's (12 .. 14) LDS reads between the 24 MFMAs
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto rd128 = [&](const unsigned char* ptr, int second) -> i32x8 {
+    const u32x4 lo = *(const u32x4*)ptr, hi = *(const u32x4*)(ptr + second);
+    return i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+  };
+  auto load_g8 = [&](int G, auto BUF) {
+    constexpr int b = decltype(BUF)::value;
+    const unsigned char* ab = smem + OFF_A8 + rbase8 + toff[G];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) A8f[b][m] = rd128(smem + OFF_W8 + (G * 2 + m) * 2048 + lane * 16, 1024);
+#pragma unroll
+    for (int n = 0; n < NI; ++n) R8f[b][n] = rd128(ab + ((n / FX) * PX + (n % FX) * 16) * 16, PLANE);
+  };
+  auto load_tap8 = [&]() {
+#pragma unroll
+    for (int bl = 0; bl < 2; ++bl) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m) A8n[bl][m] = *(const i64*)(smem + OFF_W8 + W128 + (bl * 2 + m) * 512 + lane * 8);
+#pragma unroll
+      for (int n = 0; n < NI; ++n) R8n[bl][n] = *(const i64*)(smem + OFF_A8 + rbase8 + bl * 2 * PLANE + toff8 + ((n / FX) * PX + (n % FX) * 16) * 16);
+    }
+  };
+  auto mfma_g8 = [&](auto BUF) {
+    constexpr int b = decltype(BUF)::value;
+#pragma unroll
+    for (int n = 0; n < NI; ++n)
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+        acc[m][n] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A8f[b][m], R8f[b][n], acc[m][n], 0, 0, 0, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {                             // the next group's 12 reads between the 8 K = 128 instructions
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto mfma_tap8 = [&]() {
+#pragma unroll
+    for (int bl = 0; bl < 2; ++bl)
+#pragma unroll
+      for (int n = 0; n < NI; ++n)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(A8n[bl][m], R8n[bl][n], acc[m][n], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 14; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto tile_epilogue = [&](int tile) {
+    int n_img, y0, x0;
+    tile_origin(tile, n_img, y0, x0);
+    f16* yout = (f16*)p.y + (long long)n_img * p.y_sstride;
+    float bias_r[8], os_r[8];
+    {
+      const f32x4* ep = (const f32x4*)(smem + OFF_E) + 2 * q;
+      const f32x4 w0 = ep[0], w1 = ep[1], b0 = ep[8], b1 = ep[9];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { os_r[j] = w0[j]; os_r[4 + j] = w1[j]; bias_r[j] = b0[j]; bias_r[4 + j] = b1[j]; }
+    }
+#pragma unroll
+    for (int n = 0; n < NI; ++n) {
+      const int gy = y0 + row_first + n / FX, gx = x0 + (n % FX) * 16 + l15;
+      const bool ok = gy < p.H && gx < p.W;
+      const long long vo = (long long)gy * p.W + gx;
+      float r[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        r[j] = fmaf(j < 4 ? acc[0][n][j] : acc[1][n][j - 4], os_r[j], bias_r[j]);
+        if (p.epi == 2) r[j] = fmaxf(r[j], 0.f);
+      }
+      f16x8 hi, lo;
+      u32x2 lo8, hi8;
+      x2m_split8(r, hi, lo, lo8, hi8);
+      if (ok) {
+        *(f16x8*)(yout + (long long)(cob * 4 + q) * plane_stride + vo * 8) = hi;
+        if (p.y_lo >= 0) *(f16x8*)(yout + (long long)(p.y_lo + cob * 4 + q) * plane_stride + vo * 8) = lo;
+        if (p.y8 != nullptr) {
+          unsigned char* y8 = (unsigned char*)p.y8 + (long long)n_img * p.y8_sstride + x2m_off(cob * 4 + q, vo, nvox);
+          *(u32x2*)y8 = lo8;
+          *(u32x2*)(y8 + plane16b) = hi8;
+        }
+        if (p.sat != nullptr) x2_note_saturation(p.sat, hi);
+      }
+      acc[0][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+      acc[1][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+
+  lds_barrier();                                               // the first 16-bit step is in LDS
+  load_group(0, I0{});
+  __builtin_amdgcn_sched_barrier(0);
+  for (int k = 0; k < npairs; ++k) {
+    // ---- 16-bit step (its first group is in fragment set 0)
+    load_group(1, I1{}); group_mfmas(I0{});
+    load_group(2, I0{}); group_mfmas(I1{});
+    lds_barrier();                                             // the 16-bit buffers are read; the fp8 buffers of pair k are filled
+    load_g8(0, I0{});
+    group_mfmas(I0{});
+    // ---- fp8 step
+    load_g8(1, I1{}); mfma_g8(I0{});
+    load_g8(2, I0{}); mfma_g8(I1{});
+    load_g8(3, I1{}); mfma_g8(I0{});
+    load_tap8(); mfma_g8(I1{});
+    lds_barrier();                                             // the fp8 buffers are read; the 16-bit buffers of pair k + 1 are filled
+    load_group(0, I0{});                                       // (after the last pair: a harmless re-read)
+    mfma_tap8();
+    const int tile = k / nchunk;
+    if (k - tile * nchunk == nchunk - 1) tile_epilogue(tile);
+  }
+}
+
+int launch_x2m_2d(ConvX2MParams p, hipStream_t stream) {
+  constexpr int PLANE = ((18 * 34 * 16 + 255) / 256) * 256;
+  const int lds = 8 * PLANE + 18432 + X2M2_W8 + 256;
+  IUNET_SET_MAX_LDS(conv2_x2m_kernel, lds);
+  p.tilesZ = 1; p.tilesY = (p.H + 15) / 16; p.tilesX = (p.W + 31) / 32;
+  const int ncob = p.Cout / 32;
+  iunet_brick_shape(2, ncob, 1, p.tilesY, p.tilesX, &p.bz, &p.by, &p.bx);
+  p.nbz = 1; p.nby = (p.tilesY + p.by - 1) / p.by; p.nbx = (p.tilesX + p.bx - 1) / p.bx;
+  // slot groups: a brick clamped to a small tile grid holds fewer slots than the XCD has workgroups for this Cout tile
+  const long long nbricks = (long long)p.N * p.nby * p.nbx;
+  const int table = 8 * (ncob == 1 ? 32 : ncob == 2 ? 16 : ncob <= 4 ? 8 : 4);      // (conv3_v4.hip: iunet_conv3_v4_stats_parts)
+  int groups = table / 8 / (p.by * p.bx);
+  while (groups > 1 && nbricks / 8 < groups) groups >>= 1;
+  if (groups < 1) groups = 1;
+  const int gx = 8 * p.by * p.bx * groups;
+  hipLaunchKernelGGL(conv2_x2m_kernel, dim3(gx, ncob), dim3(8 * 64 + XM_NLT), lds, stream, p);
+  IUNET_CHECK_HIP(hipGetLastError());
+  return IUNET_OK;
+}
+
 template <bool SMALL>
 int launch_x2m(ConvX2MParams p, hipStream_t stream) {
   using TL = XMTile<SMALL>;
@@ -415,9 +728,8 @@ __global__ __launch_bounds__(256) void x2m_prep_kernel(const float* __restrict__
                                                       float* __restrict__ oscale, float* __restrict__ bias_out,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       const float* __restrict__ mean, const float* __restrict__ var, float eps,
-                                                      float act_in, float act_out, int Cout, int Cin) {
+                                                      float act_in, float act_out, int Cout, int Cin, int taps) {
 #pragma clang fp contract(off)
-  constexpr int taps = 27;
   __shared__ float red[256];
   const int co = blockIdx.x, tid = threadIdx.x;
   float a = 1.0f;
@@ -458,6 +770,12 @@ __global__ __launch_bounds__(256) void x2m_prep_kernel(const float* __restrict__
       whi[(long long)co * n + (long long)ci * taps + tap] = (float)h;
       ph |= (unsigned long long)xm_e4m3((float)h * 0.0625f) << (8 * j);
       pl |= (unsigned long long)xm_e4m3(res * 256.0f) << (8 * j);
+    }
+    if (taps == 9) {          // 2-D: blocks of 32 input channels = two virtual blocks (conv2_x2m_kernel)
+      unsigned char* blk = w8 + ((long long)cob * (nchunk >> 1) + (chunk >> 1)) * X2M2_W8;
+      *(unsigned long long*)(blk + x2m2_w8_offset(tap, mt, chunk & 1, 0, o, row)) = ph;
+      *(unsigned long long*)(blk + x2m2_w8_offset(tap, mt, chunk & 1, 1, o, row)) = pl;
+      continue;
     }
     unsigned char* blk = w8 + ((long long)cob * nchunk + chunk) * F8K_WSTEP;
     *(unsigned long long*)(blk + f8k_offset(col, dy, mt, 0, o, row)) = ph;      // virtual channels 0..15: against x_lo8
@@ -574,11 +892,23 @@ extern "C" {
 
 /* bytes of the K128 operator of a 3x3x3 split conv with the cross terms on the fp8 matrix cores (iunet_x2m_prep) */
 long long iunet_x2m_w8_bytes(int Cout, int Cin) { return (long long)(Cout / 32) * (Cin / 16) * F8K_WSTEP; }
+/* the same for nd = 2 (3 x 3 filters: 18 432 bytes per 32 x 32 block) or 3 */
+long long iunet_x2m_w8_bytes_nd(int nd, int Cout, int Cin) {
+  return nd == 2 ? (long long)(Cout / 32) * (Cin / 32) * X2M2_W8 : iunet_x2m_w8_bytes(Cout, Cin);
+}
 
 /* operator of a 3x3x3 stage conv in the x2m form: whi = fp32 [Cout][Cin][27] holding w_hi (feed it to iunet_pack_conv3, dtype 0, mode 2),
  * w8 = iunet_x2m_w8_bytes bytes (the K128 operator of [w_hi8 | w_lo8]); oscale / bias_out as iunet_x2_prep */
+int iunet_x2m_prep_nd(int nd, const void* w, void* whi, void* w8, void* oscale, void* bias_out, const void* gamma, const void* beta,
+                      const void* mean, const void* var, float eps, float act_in, float act_out, int Cout, int Cin, void* stream);
 int iunet_x2m_prep(const void* w, void* whi, void* w8, void* oscale, void* bias_out, const void* gamma, const void* beta, const void* mean,
                    const void* var, float eps, float act_in, float act_out, int Cout, int Cin, void* stream) {
+  return iunet_x2m_prep_nd(3, w, whi, w8, oscale, bias_out, gamma, beta, mean, var, eps, act_in, act_out, Cout, Cin, stream);
+}
+/* nd = 2: w fp32 [Cout][Cin][9] -> whi (feed it to iunet_pack_conv3, dtype 0, mode 6: the cross-pair order) + the 2-D K128 operator */
+int iunet_x2m_prep_nd(int nd, const void* w, void* whi, void* w8, void* oscale, void* bias_out, const void* gamma, const void* beta,
+                      const void* mean, const void* var, float eps, float act_in, float act_out, int Cout, int Cin, void* stream) {
+  IUNET_REQUIRE(nd == 2 || nd == 3, "x2m_prep: nd must be 2 or 3");
   IUNET_REQUIRE(w && whi && w8 && oscale && bias_out, "x2m_prep: null pointer");
   IUNET_REQUIRE(Cout > 0 && Cout % 32 == 0 && Cin > 0 && Cin % 32 == 0, "x2m_prep: channels must be positive multiples of 32 (%d, %d)", Cout, Cin);
   IUNET_REQUIRE(!gamma || (beta && mean && var), "x2m_prep: a BatchNorm fold needs gamma, beta, mean and var");
@@ -587,7 +917,7 @@ int iunet_x2m_prep(const void* w, void* whi, void* w8, void* oscale, void* bias_
                 "x2m_prep: the activation scales must be powers of two (got %g, %g)", act_in, act_out);
   hipLaunchKernelGGL(x2m_prep_kernel, dim3(Cout), dim3(256), 0, (hipStream_t)stream, (const float*)w, (float*)whi, (unsigned char*)w8,
                      (float*)oscale, (float*)bias_out, (const float*)gamma, (const float*)beta, (const float*)mean, (const float*)var,
-                     eps, act_in, act_out, Cout, Cin);
+                     eps, act_in, act_out, Cout, Cin, nd == 3 ? 27 : 9);
   IUNET_CHECK_HIP(hipGetLastError());
   return IUNET_OK;
 }
@@ -626,9 +956,20 @@ int iunet_x2m_maxpool_fwd(int nd, const void* x, long long x_ss, const void* x8,
  * x8: the m8 planes of the same tensor (x8_ss bytes per sample); y: Cout / 8 hi planes, the lo planes y_lo planes further on (y_lo < 0: no
  * lo planes -- a tensor only 3x3x3 convs read), y8: its m8 planes or null; w16 / w8 / oscale / bias from iunet_x2m_prep (+ iunet_pack_conv3);
  * epi as iunet_conv3_fwd; sat: optional device int, raised (atomicMax) to the bit pattern of a saturated hi word */
+int iunet_x2m_conv_fwd(int nd, const void* x, long long x_ss, const void* x8, long long x8_ss, void* y, long long y_ss, int y_lo, void* y8,
+                       long long y8_ss, const void* w16, const void* w8, const void* oscale, const void* bias, int N, int D, int H, int W,
+                       int Cin, int Cout, int epi, void* sat, void* stream);
 int iunet_x2m_conv3_fwd(const void* x, long long x_ss, const void* x8, long long x8_ss, void* y, long long y_ss, int y_lo, void* y8,
                         long long y8_ss, const void* w16, const void* w8, const void* oscale, const void* bias, int N, int D, int H, int W,
                         int Cin, int Cout, int epi, void* sat, void* stream) {
+  return iunet_x2m_conv_fwd(3, x, x_ss, x8, x8_ss, y, y_ss, y_lo, y8, y8_ss, w16, w8, oscale, bias, N, D, H, W, Cin, Cout, epi, sat, stream);
+}
+/* the same for nd = 2 (3 x 3 filters, D == 1; operators from iunet_x2m_prep_nd(2, ..) + iunet_pack_conv3 mode 6) or 3 */
+int iunet_x2m_conv_fwd(int nd, const void* x, long long x_ss, const void* x8, long long x8_ss, void* y, long long y_ss, int y_lo, void* y8,
+                       long long y8_ss, const void* w16, const void* w8, const void* oscale, const void* bias, int N, int D, int H, int W,
+                       int Cin, int Cout, int epi, void* sat, void* stream) {
+  IUNET_REQUIRE(nd == 2 || nd == 3, "x2m_conv3: nd must be 2 or 3");
+  IUNET_REQUIRE(nd == 3 || D == 1, "x2m_conv3: 2-D needs D == 1");
   IUNET_REQUIRE(x && x8 && y && w16 && w8 && oscale, "x2m_conv3: null pointer");
   IUNET_REQUIRE_GRID("x2m_conv3", N, D, H, W);
   IUNET_REQUIRE(Cin >= 32 && Cout >= 32 && Cin % 32 == 0 && Cout % 32 == 0, "x2m_conv3: channels must be positive multiples of 32 (%d -> %d)", Cin, Cout);
@@ -640,6 +981,7 @@ int iunet_x2m_conv3_fwd(const void* x, long long x_ss, const void* x8, long long
   p.N = N; p.D = D; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.epi = epi; p.sat = (int*)sat;
   p.tilesZ = p.tilesY = p.tilesX = 0;
   p.bz = p.by = p.bx = p.nbz = p.nby = p.nbx = 0;
+  if (nd == 2) return launch_x2m_2d(p, (hipStream_t)stream);
   // the tile size follows the grid as in the 16-bit launch; the summation order of a voxel does not depend on it
   const long long big_tiles = (long long)N * ((D + 3) / 4) * ((H + 7) / 8) * ((W + 15) / 16);
   const bool small = big_tiles * (Cout / 32) < 128;

@@ -24,7 +24,10 @@ int iunet_x2_convT_fwd(int, const void*, long long, int, void*, long long, int, 
                        int, int, void*);
 int iunet_x2_head_fwd(const void*, long long, int, int, const void*, const void*, float, int, void*, void*, void*, const long long*, float,
                       int, int, int, int, int, void*);
-int iunet_x2m_prep(const void*, void*, void*, void*, void*, const void*, const void*, const void*, const void*, float, float, float, int, int, void*);
+int iunet_x2m_prep_nd(int, const void*, void*, void*, void*, void*, const void*, const void*, const void*, const void*, float, float, float, int, int, void*);
+int iunet_x2m_conv_fwd(int, const void*, long long, const void*, long long, void*, long long, int, void*, long long, const void*, const void*,
+                       const void*, const void*, int, int, int, int, int, int, int, void*, void*);
+long long iunet_x2m_w8_bytes_nd(int, int, int);
 int iunet_x2m_first_conv_fwd(int, const void*, int, const long long*, void*, long long, int, void*, long long, const void*, const void*, const void*,
                              float, int, int, int, int, int, int, int, void*, void*);
 int iunet_x2m_convT_fwd(int, const void*, long long, int, void*, long long, int, void*, long long, const void*, const void*, const void*, int, int,
@@ -116,7 +119,7 @@ WsLayout ws_layout(const iunet_net* n, int N, int D, int H, int W) {
   L.am.resize(lv, -1); L.catm.resize(lv, -1); L.pinm.resize(lv, -1);
   if (n->mode == 3) {
     for (int l = 0; l < lv; ++l) {
-      const long long v = (long long)(D >> l) * (H >> l) * (W >> l);
+      const long long v = (long long)(n->dim == 3 ? D >> l : 1) * (H >> l) * (W >> l);
       L.a[l] = take((long long)N * n->ch[l] * v); L.am[l] = take((long long)N * n->ch[l] * v);
       L.b[l] = take((long long)N * 2 * n->ch[l] * v);
       if (l < lv - 1) { L.cat[l] = take((long long)N * 2 * n->ch[l] * v); L.catm[l] = take((long long)N * 2 * n->ch[l] * v); }
@@ -150,7 +153,6 @@ int iunet_net_create(int dim, int levels, int base, int cin, int ncls, int mode,
   IUNET_REQUIRE(cin >= 1 && cin <= 4, "net_create: 1..4 input channels (got %d)", cin);
   IUNET_REQUIRE(ncls >= 2 && ncls <= 10, "net_create: 2..10 classes (app.py:162; got %d)", ncls);
   IUNET_REQUIRE(mode >= 0 && mode <= 3, "net_create: mode must be 0 (fp16), 1 (bf16), 2 (fp16x2) or 3 (fp16x2, cross terms on fp8), got %d", mode);
-  IUNET_REQUIRE(mode != 3 || dim == 3, "net_create: mode 3 (cross terms on the K = 128 fp8 instruction) is 3-D only");
   iunet_net* n = new iunet_net();
   n->dim = dim; n->levels = levels; n->base = base; n->cin = cin; n->ncls = ncls; n->mode = mode;
   n->act_scale = act_scale > 0.f ? act_scale : 64.0f;
@@ -171,8 +173,8 @@ int iunet_net_create(int dim, int levels, int base, int cin, int ncls, int mode,
       const int vci = (mode == 2 || (mode == 3 && op.first)) ? 3 * op.ci : op.ci;
       if (op.first) op.pk[1] = pk_take(iunet_pack_first_conv_elems(co, vci, n->taps) * 2);
       else if (mode == 3) {
-        op.pk[1] = pk_take(iunet_pack_conv3_elems(co, op.ci, n->taps, 2) * 2);
-        op.pk[0] = pk_take(iunet_x2m_w8_bytes(co, op.ci));
+        op.pk[1] = pk_take(iunet_pack_conv3_elems(co, op.ci, n->taps, dim == 3 ? 2 : 6) * 2);
+        op.pk[0] = pk_take(iunet_x2m_w8_bytes_nd(dim, co, op.ci));
       } else {
         op.pk[1] = pk_take(iunet_pack_conv3_elems(co, vci, n->taps, mode == 2 ? iunet_x2_pack_mode(dim) : 2) * 2);
         if (mode != 2) {          // the layouts a 16-bit launch may pick (interactive_unet/_native.py: PackedConv)
@@ -244,10 +246,10 @@ int iunet_net_load(iunet_net* n, const void* flat_params, void* packed, void* st
     int rc;
     if (n->mode == 3 && !op.first) {
       float* whi = (float*)(K + n->scratch_off);
-      IUNET_CHECK_HIP(hipMemsetAsync(K + op.pk[0], 0, (size_t)iunet_x2m_w8_bytes(op.co, op.ci), (hipStream_t)stream));
-      rc = iunet_x2m_prep(w, whi, K + op.pk[0], aux, aux + op.co, g, be, mu, va, eps, A, A, op.co, op.ci, stream);
+      IUNET_CHECK_HIP(hipMemsetAsync(K + op.pk[0], 0, (size_t)iunet_x2m_w8_bytes_nd(n->dim, op.co, op.ci), (hipStream_t)stream));
+      rc = iunet_x2m_prep_nd(n->dim, w, whi, K + op.pk[0], aux, aux + op.co, g, be, mu, va, eps, A, A, op.co, op.ci, stream);
       if (rc) return rc;
-      rc = iunet_pack_conv3(0, whi, nullptr, K + op.pk[1], op.co, op.ci, n->taps, 2, stream);
+      rc = iunet_pack_conv3(0, whi, nullptr, K + op.pk[1], op.co, op.ci, n->taps, n->dim == 3 ? 2 : 6, stream);
       if (rc) return rc;
     } else if (n->mode >= 2) {
       float* wv = (float*)(K + n->scratch_off);
@@ -313,15 +315,15 @@ int iunet_net_forward(iunet_net* n, const void* x, int in_dtype, const long long
     // ---- x2m: a / cat / pin = (hi planes, m8 planes), b = (hi planes, lo planes); engine_x2.EngineX2._infer_mixed sequences the same launches
     const float A = n->act_scale;
     void* sat = WS;
-    auto dims3 = [&](int l, int& d, int& h, int& w) { d = D >> l; h = H >> l; w = W >> l; };
-    auto vox3 = [&](int l) { return (long long)(D >> l) * (H >> l) * (W >> l); };
+    auto dims3 = [&](int l, int& d, int& h, int& w) { d = dim == 3 ? D >> l : 1; h = H >> l; w = W >> l; };
+    auto vox3 = [&](int l) { return (long long)(dim == 3 ? D >> l : 1) * (H >> l) * (W >> l); };
     auto convm = [&](const ConvOp& op, long long xo, long long x_ss, long long x8o, long long x8_ss, long long yo, long long y_ss, int y_lo,
                      long long y8o, long long y8_ss, int l) -> int {
       int d, h, w;
       dims3(l, d, h, w);
       const float* aux = (const float*)(K + op.aux);
-      return iunet_x2m_conv3_fwd(WS + xo, x_ss, WS + x8o, x8_ss, WS + yo, y_ss, y_lo, y8o >= 0 ? WS + y8o : nullptr, y8_ss, K + op.pk[1], K + op.pk[0],
-                                 aux, aux + op.co, N, d, h, w, op.ci, op.co, 2, sat, stream);
+      return iunet_x2m_conv_fwd(dim, WS + xo, x_ss, WS + x8o, x8_ss, WS + yo, y_ss, y_lo, y8o >= 0 ? WS + y8o : nullptr, y8_ss, K + op.pk[1], K + op.pk[0],
+                                aux, aux + op.co, N, d, h, w, op.ci, op.co, 2, sat, stream);
     };
     int rc = 0;
     for (int l = 0; l < lv; ++l) {

@@ -11,7 +11,7 @@ Tensors: C channels = C/8 hi planes + C/8 lo planes of [D][H][W][8] fp16; the tw
 ([skip_hi | up_hi | skip_lo | up_lo]); activations are kept multiplied by `act_scale` (a power of two, undone exactly by the
 next operator's accumulator scale).
 
-`mixed` (3-D, the default there; IUNET_X2M=0 switches it off): the 3x3x3 stage convs evaluate the two cross terms of a split product
+`mixed` (the default; IUNET_X2M=0 switches it off): the stage convs evaluate the two cross terms of a split product
 (x_lo w_hi, x_hi w_lo: 2^-11 of it) on the K = 128 fp8 matrix instruction -- two matrix-step units per 16 input channels instead of
 three (csrc/conv3_x2m.hip).  A tensor a 3x3x3 conv reads then carries hi planes + "m8" planes (e4m3 of the residual and of the hi
 word, 2 bytes per element); the lo planes exist only where a transposed conv or the head reads (the last conv of a stage).
@@ -41,8 +41,9 @@ class EngineX2:
             raise NotImplementedError('native U-Net supports 2..10 classes (app.py:162)')
         self.dim, self.levels, self.base, self.cin, self.ncls = dim, levels, base, cin, ncls
         self.act_scale = float(act_scale)
-        # cross terms on the fp8 matrix cores: the 3-D stage convs (the K = 128 instruction holds 4 filter columns x 32 channels; 2-D stays fp16x2)
-        self.mixed = (os.environ.get('IUNET_X2M', '1') != '0' if mixed is None else bool(mixed)) and dim == 3
+        # cross terms of the stage convs on the fp8 matrix cores (csrc/conv3_x2m.hip; 3-D: 4 filter columns x 32 virtual channels per
+        # K = 128 instruction, 2-D: 4 taps x 32)
+        self.mixed = os.environ.get('IUNET_X2M', '1') != '0' if mixed is None else bool(mixed)
         self.device = torch.device(device)
         self.ch = [base * 2 ** l for l in range(levels)]
         self.taps, self.npos = 3 ** dim, 2 ** dim
@@ -124,13 +125,14 @@ class EngineX2:
                     bm = self._bufs.get(key)
                     if bm is None:
                         bm = self._bufs[key] = (torch.empty(b * a * self.taps, dtype=torch.float32, device=dev),
-                                                torch.empty(nv.pack_conv3_elems(b, a, self.taps, 2), dtype=torch.float16, device=dev),
-                                                torch.zeros(lib.iunet_x2m_w8_bytes(b, a), dtype=torch.uint8, device=dev),
+                                                torch.empty(nv.pack_conv3_elems(b, a, self.taps, 2 if self.dim == 3 else 6), dtype=torch.float16, device=dev),
+                                                torch.zeros(lib.iunet_x2m_w8_bytes_nd(self.dim, b, a), dtype=torch.uint8, device=dev),
                                                 torch.empty(b, dtype=torch.float32, device=dev), torch.empty(b, dtype=torch.float32, device=dev))
                     whi, w16, w8, osc, bias = bm
-                    nv.call('iunet_x2m_prep', nv.ptr(w), nv.ptr(whi), nv.ptr(w8), nv.ptr(osc), nv.ptr(bias), nv.ptr(bn[0]), nv.ptr(bn[1]),
+                    nv.call('iunet_x2m_prep_nd', self.dim, nv.ptr(w), nv.ptr(whi), nv.ptr(w8), nv.ptr(osc), nv.ptr(bias), nv.ptr(bn[0]), nv.ptr(bn[1]),
                             nv.ptr(bn[2]), nv.ptr(bn[3]), BN_EPS, A, A, b, a, s)
-                    nv.call('iunet_pack_conv3', 0, nv.ptr(whi), None, nv.ptr(w16), b, a, self.taps, 2, s)
+                    # w_hi: the padded K16 order in 3-D, the cross-pair order (three k-groups per 32-channel step) in 2-D
+                    nv.call('iunet_pack_conv3', 0, nv.ptr(whi), None, nv.ptr(w16), b, a, self.taps, 2 if self.dim == 3 else 6, s)
                     P[name] = (w16, osc, bias, w8)
                     continue
                 pmode = lib.iunet_x2_pack_mode(self.dim)      # 2: padded K16 order (3-D); 6: compact order (2-D: the cross-pair step)
@@ -283,7 +285,7 @@ class EngineX2:
         if probe is not None:
             e0 = torch.cuda.Event(enable_timing=True)
             e0.record()
-        nv.call('iunet_x2m_conv3_fwd', xp, x_ss, x8p, x8_ss, yp, y_ss, y_lo, y8p, y8_ss, nv.ptr(w16), nv.ptr(w8), nv.ptr(osc), nv.ptr(b),
+        nv.call('iunet_x2m_conv_fwd', self.dim, xp, x_ss, x8p, x8_ss, yp, y_ss, y_lo, y8p, y8_ss, nv.ptr(w16), nv.ptr(w8), nv.ptr(osc), nv.ptr(b),
                 N, d[0], d[1], d[2], ci, co, 2, nv.ptr(self._sat), s)
         if probe is not None:
             e1 = torch.cuda.Event(enable_timing=True)
@@ -291,7 +293,7 @@ class EngineX2:
             probe['events'].append((e0, e1, N))
 
     def _infer_mixed(self, ws, x, x_strides, N, D, H, W, s):
-        """The 3-D forward in the x2m form (everything but the head): a / cat / pin tensors are (hi planes, m8 planes), b tensors (hi, lo)."""
+        """The forward in the x2m form (everything but the head): a / cat / pin tensors are (hi planes, m8 planes), b tensors (hi, lo)."""
         dims, L, ch = ws['dims'], self.levels, self.ch
         P8 = lambda t, planes16=0, v=0: ctypes.c_void_p(t.data_ptr() + planes16 * v * 16)     # m8 view starting `planes16` 16-byte planes in
         Ph = lambda t, planes=0, v=0: ctypes.c_void_p(t.data_ptr() + planes * v * 16)         # hi view starting `planes` 8-channel planes in

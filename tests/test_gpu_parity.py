@@ -40,10 +40,10 @@ def _smooth(shape, seed, sigma=3):
 
 def _native_engine(p, dim, cin, ncls, dtype):
     if dtype in ('fp16x2', 'x2m'):
-        # 'x2m' (3-D): the cross terms of the stage convs on the fp8 matrix cores -- what EngineX2 / UNet() run by default in 3-D
+        # 'x2m': the cross terms of the stage convs on the fp8 matrix cores -- what EngineX2 / UNet() run by default
         from interactive_unet.engine_x2 import EngineX2
         e = EngineX2(dim=dim, cin=cin, ncls=ncls, mixed=(dtype == 'x2m'))
-        assert e.mixed == (dtype == 'x2m' and dim == 3)
+        assert e.mixed == (dtype == 'x2m')
     elif dtype == torch.float32:
         from interactive_unet.engine_f32 import EngineF32
         e = EngineF32(dim=dim, cin=cin, ncls=ncls)
@@ -153,15 +153,14 @@ def _headline(dim, shape, N, seed):
     print(f'[parity] fp32 oracle forward of {N} x {shape}: {time.time() - t0:.1f} s on {torch.get_num_threads()} threads')
     y_true = _labels(img, ncls)
     res = {}
-    for dtype in (('x2m',) if dim == 3 else ()) + ('fp16x2', torch.float32, torch.float16, torch.bfloat16):
+    for dtype in ('x2m', 'fp16x2', torch.float32, torch.float16, torch.bfloat16):
         e = _native_engine(p, dim, 1, ncls, dtype)
         res[dtype] = _compare(f'{str(dtype).split(".")[-1]} {dim}-D {N} x {shape}', *_forward(e, x.cuda(), dim, ncls), ref, y_true)
         del e
         torch.cuda.empty_cache()
     _assert_fp32_mode(res['fp16x2'])
     _assert_fp32_mode(res[torch.float32])
-    if dim == 3:
-        _assert_fp32_mode(res['x2m'])                    # the default 3-D prediction mode: within 1e-3, class map equal outside its tie band
+    _assert_fp32_mode(res['x2m'])                        # the default prediction mode: within 1e-3, class map equal outside its tie band
     for dtype in (torch.float16, torch.bfloat16):
         r = res[dtype]
         assert r['err'] <= REL_BOUND_16[dtype] * max(1.0, r['scale']), (dtype, r)
@@ -197,7 +196,7 @@ def test_unet_module_default_predicts_in_split_precision():
     x = torch.tensor(_smooth((96, 64), 3))[None, None]
     got = m(x.cuda()).cpu()
     want = unet_ref.forward(p, x.float() / 255.0, dim=2)
-    assert (got - want).abs().max().item() <= 1e-5
+    assert (got - want).abs().max().item() <= 2e-4        # probabilities; the logits are held to 1e-3 above (x2m: ~1e-4 measured)
     # an explicit 16-bit act_dtype keeps the throughput mode for both
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')

@@ -50,27 +50,32 @@ def _m8_unpack(b, N, C, sp):
 
 
 def _prep(nv, w, bn=None, act_out=A):
+    """operators of one stage conv in the x2m form; w [Cout][Cin][3][3][3] (3-D) or [Cout][Cin][3][3] (2-D)"""
     co, ci = w.shape[:2]
+    nd = w.dim() - 2
+    taps = 3 ** nd
     dev = 'cuda'
     w = w.to(dev, torch.float32).contiguous()
-    whi = torch.empty(co * ci * 27, device=dev)
-    w8 = torch.zeros(nv.lib().iunet_x2m_w8_bytes(co, ci), dtype=torch.uint8, device=dev)
+    whi = torch.empty(co * ci * taps, device=dev)
+    w8 = torch.zeros(nv.lib().iunet_x2m_w8_bytes_nd(nd, co, ci), dtype=torch.uint8, device=dev)
     osc, b = torch.empty(co, device=dev), torch.empty(co, device=dev)
     bnp = [None] * 4 if bn is None else [t.to(dev, torch.float32).contiguous() for t in bn]
-    nv.call('iunet_x2m_prep', nv.ptr(w), nv.ptr(whi), nv.ptr(w8), nv.ptr(osc), nv.ptr(b), *[nv.ptr(t) for t in bnp], 1e-5, A, act_out, co, ci, nv.stream())
-    w16 = torch.empty(nv.pack_conv3_elems(co, ci, 27, 2), dtype=torch.float16, device=dev)
-    nv.call('iunet_pack_conv3', 0, nv.ptr(whi), None, nv.ptr(w16), co, ci, 27, 2, nv.stream())
+    nv.call('iunet_x2m_prep_nd', nd, nv.ptr(w), nv.ptr(whi), nv.ptr(w8), nv.ptr(osc), nv.ptr(b), *[nv.ptr(t) for t in bnp], 1e-5, A, act_out, co, ci, nv.stream())
+    pm = 2 if nd == 3 else 6                              # padded K16 order / the cross-pair order
+    w16 = torch.empty(nv.pack_conv3_elems(co, ci, taps, pm), dtype=torch.float16, device=dev)
+    nv.call('iunet_pack_conv3', 0, nv.ptr(whi), None, nv.ptr(w16), co, ci, taps, pm, nv.stream())
     torch.cuda.synchronize()
-    return w16, w8, osc, b, whi.reshape(co, ci, 3, 3, 3).cpu()
+    return w16, w8, osc, b, whi.reshape(w.shape).cpu()
 
 
-def _run(nv, xhi, x8, w16, w8, osc, bias, N, shape, ci, co, epi, y_lo=True, x_ss=None):
+def _run(nv, xhi, x8, w16, w8, osc, bias, N, shape, ci, co, epi, y_lo=True, x_ss=None, nd=3):
+    """shape: (D, H, W); nd = 2 needs D == 1"""
     vox = int(np.prod(shape))
     x_ss = ci * vox if x_ss is None else x_ss
     y = torch.zeros(N * 2 * co * vox, dtype=torch.float16, device='cuda')
     y8 = torch.zeros(N * 2 * co * vox, dtype=torch.uint8, device='cuda')
     sat = torch.zeros(1, dtype=torch.int32, device='cuda')
-    nv.call('iunet_x2m_conv3_fwd', nv.ptr(xhi), x_ss, nv.ptr(x8), 2 * ci * vox, nv.ptr(y), 2 * co * vox, co // 8 if y_lo else -1,
+    nv.call('iunet_x2m_conv_fwd', nd, nv.ptr(xhi), x_ss, nv.ptr(x8), 2 * ci * vox, nv.ptr(y), 2 * co * vox, co // 8 if y_lo else -1,
             nv.ptr(y8), 2 * co * vox, nv.ptr(w16), nv.ptr(w8), nv.ptr(osc), nv.ptr(bias), N, shape[0], shape[1], shape[2], ci, co, epi,
             nv.ptr(sat), nv.stream())
     torch.cuda.synchronize()
@@ -113,6 +118,67 @@ def test_conv3_x2m_exact_integers(shape, ci, co, N):
     assert torch.equal(hi, h)
     assert torch.equal(lo8, _e4m3((v - h) * 16.0)) and torch.equal(hi8, _e4m3(h / 256.0))
     assert sat == 0
+
+
+@pytest.mark.parametrize('shape,ci,co,N', [
+    ((32, 64), 32, 32, 2),
+    ((24, 40), 64, 64, 1),            # ragged tiles, two Cout tiles, two chunk pairs
+    ((16, 16), 128, 32, 5),           # images smaller than a tile (slot groups), four chunk pairs
+    ((40, 72), 96, 64, 3),            # ragged, several tiles per workgroup
+])
+def test_conv2_x2m_exact_integers(shape, ci, co, N):
+    """The 2-D form (3 x 3 filters, 16 x 32 tiles, a step = 32 channels: cross-pair order for the 16-bit step, four taps per K = 128
+    instruction + tap 8 on the K = 32 instruction for the fp8 step) on data that makes every operand of both steps an exact integer."""
+    nv = _nv()
+    g = torch.Generator().manual_seed(31)
+    a = (torch.randint(8, 16, (co, ci, 3, 3), generator=g) * 4).float() * (torch.randint(0, 2, (co, ci, 3, 3), generator=g) * 2 - 1).float()
+    b = torch.randint(-15, 16, (co, ci, 3, 3), generator=g).float()
+    w = 16.0 * a + b / 256.0
+    w16, w8, osc, bias, whi = _prep(nv, w, act_out=1.0)
+    assert torch.equal(whi, 16.0 * a) and torch.equal(osc.cpu(), torch.full((co,), 1.0 / 64))
+    X = torch.randint(-3, 4, (N, ci) + shape, generator=g).float()
+    L8 = torch.randint(-4, 5, (N, ci) + shape, generator=g).float()
+    H8 = torch.randint(-4, 5, (N, ci) + shape, generator=g).float()
+    sp = (1,) + shape
+    xhi = _blocked(X.reshape(N, ci, *sp), 8).to(torch.float16).cuda()
+    x8 = _m8_planes(L8.reshape(N, ci, *sp), H8.reshape(N, ci, *sp)).cuda()
+    hi, lo, y8, sat = _run(nv, xhi, x8, w16, w8, osc, bias, N, sp, ci, co, 0, nd=2)
+    want = (F.conv2d(X.double(), (16.0 * a).double(), padding=1) + F.conv2d(L8.double(), a.double(), padding=1)
+            + F.conv2d(H8.double(), b.double(), padding=1)).reshape(N, co, *sp)
+    assert want.abs().max() < 2 ** 22
+    got = (hi.double() + lo.double()) * 64.0
+    assert torch.equal(got, want), (got - want).abs().max()
+    v = (want / 64.0).float()
+    h = v.to(torch.float16).float()
+    lo8, hi8 = _m8_unpack(y8, N, co, sp)
+    assert torch.equal(hi, h) and torch.equal(lo8, _e4m3((v - h) * 16.0)) and torch.equal(hi8, _e4m3(h / 256.0)) and sat == 0
+
+
+@pytest.mark.parametrize('shape,ci,co,N', [((32, 64), 32, 32, 2), ((24, 40), 64, 64, 1), ((16, 32), 256, 32, 1)])
+def test_conv2_x2m_random(shape, ci, co, N):
+    nv = _nv()
+    g = torch.Generator().manual_seed(32)
+    x = torch.rand((N, ci) + shape, generator=g) * 2
+    w = torch.randn((co, ci, 3, 3), generator=g) * (2.0 / (ci * 9)) ** 0.5
+    bn = [0.75 + 0.5 * torch.rand(co, generator=g), 0.1 * torch.randn(co, generator=g), 0.2 * torch.randn(co, generator=g),
+          0.5 + torch.rand(co, generator=g)]
+    w16, w8, osc, bias, _ = _prep(nv, w, bn)
+    sp = (1,) + shape
+    v = (x * A).reshape(N, ci, *sp)
+    xh = v.to(torch.float16)
+    xl = (v - xh.float()).to(torch.float16)
+    vox = int(np.prod(shape))
+    xs = torch.cat([_blocked(xh, 8), _blocked(xl, 8)], 1).contiguous().cuda()
+    x8 = torch.empty(N * 2 * ci * vox, dtype=torch.uint8, device='cuda')
+    nv.call('iunet_x2m_make8', nv.ptr(xs), 2 * ci * vox, ci // 8, nv.ptr(x8), 2 * ci * vox, ci, N, 1, shape[0], shape[1], nv.stream())
+    hi, lo, y8, sat = _run(nv, xs, x8, w16, w8, osc, bias, N, sp, ci, co, 2, x_ss=2 * ci * vox, nd=2)
+    wf, bf = unet_ref.fold_bn(w, *bn)
+    xq = ((xh.double() + xl.double()) / A).reshape(N, ci, *shape)
+    want = torch.relu(F.conv2d(xq, wf.double(), bf.double(), padding=1)).reshape(N, co, *sp)
+    got = (hi.double() + lo.double()) / A
+    err = (got - want).abs().max().item() / want.abs().max().item()
+    print(f'[x2m conv 2-D {ci}->{co} {shape}] max rel err {err:.2e}')
+    assert err < 6e-5 and sat == 0, err
 
 
 @pytest.mark.parametrize('shape,ci,co,N', [((8, 16, 32), 32, 32, 1), ((6, 10, 20), 64, 32, 2), ((4, 8, 16), 96, 64, 1)])
@@ -226,13 +292,14 @@ def test_producers_write_the_m8_planes_of_their_hi_and_lo_words():
     assert torch.equal(hi_a, hi_b) and (lo_a != lo_b).float().mean().item() < 2e-3
 
 
-@pytest.mark.parametrize('shape,cin,ncls,in_dtype', [((16, 32, 48), 1, 3, torch.uint8), ((8, 24, 40), 2, 4, torch.float16)])
+@pytest.mark.parametrize('shape,cin,ncls,in_dtype', [((16, 32, 48), 1, 3, torch.uint8), ((8, 24, 40), 2, 4, torch.float16),
+                                                      ((64, 96), 1, 3, torch.uint8), ((40, 72), 3, 2, torch.float32)])
 def test_network_x2m_small_shapes(shape, cin, ncls, in_dtype):
     """The 3-D network in the x2m form against the fp32 oracle (the headline size is in test_gpu_parity.py), the C++-sequenced forward
     bit-identical to the Python-sequenced one, the range flag quiet."""
     from tests.test_gpu_parity import _smooth, _forward, _compare, _assert_fp32_mode, _labels
     from interactive_unet.engine_x2 import EngineX2
-    dim = 3
+    dim = len(shape)
     p = unet_ref.init_params(dim=dim, cin=cin, ncls=ncls, seed=3, randomize_bn=True)
     N = 2
     img = np.stack([np.stack([_smooth(shape, 10 * i + c) for c in range(cin)]) for i in range(N)])
@@ -244,11 +311,11 @@ def test_network_x2m_small_shapes(shape, cin, ncls, in_dtype):
         xd = xf.to(in_dtype).cuda()
     ref = unet_ref.forward_logits(p, xf, dim=dim)
     e = EngineX2(dim=dim, cin=cin, ncls=ncls)
-    assert e.mixed                                        # the 3-D default
+    assert e.mixed                                        # the default
     e.load_eval({k: v.cuda() for k, v in p.items()})
     e.use_graph = False
     lg, pr, cl = _forward(e, xd, dim, ncls)
-    r = _compare(f'x2m 3-D {shape} cin={cin}', lg, pr, cl, ref, _labels(img, ncls))
+    r = _compare(f'x2m {dim}-D {shape} cin={cin}', lg, pr, cl, ref, _labels(img, ncls))
     _assert_fp32_mode(r)
     assert r['err'] <= 3e-4 * max(1.0, r['scale'])        # ~6e-5 of the logit scale measured; fp16: 1.5e-3
     e.use_graph = True

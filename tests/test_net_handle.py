@@ -61,7 +61,7 @@ def test_refusals():
     l = nv.lib()
     assert l.iunet_net_create(4, 4, 32, 1, 2, 2, 0.0, ctypes.byref(h)) < 0 and b'dim' in l.iunet_last_error()
     assert l.iunet_net_create(2, 4, 48, 1, 2, 2, 0.0, ctypes.byref(h)) < 0 and b'base' in l.iunet_last_error()
-    assert l.iunet_net_create(2, 4, 32, 1, 2, 3, 0.0, ctypes.byref(h)) < 0 and b'mode' in l.iunet_last_error()
+    assert l.iunet_net_create(2, 4, 32, 1, 2, 4, 0.0, ctypes.byref(h)) < 0 and b'mode' in l.iunet_last_error()
     h = _create(nv, 2, 4, 32, 1, 2, 2)
     st = nv.ll_array((1, 1, 1, 1, 1))
     assert l.iunet_net_forward(h, ctypes.c_void_p(8), 2, st, 1, 1, 64, 64, ctypes.c_void_p(8), None, None, ctypes.c_void_p(8), None, 1.0, 0, None) < 0
@@ -70,7 +70,7 @@ def test_refusals():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('dim,shape,mode', [(2, (64, 96), 2), (3, (16, 32, 48), 2), (3, (16, 32, 48), 3), (2, (64, 96), 0), (3, (16, 32, 48), 1)])
+@pytest.mark.parametrize('dim,shape,mode', [(2, (64, 96), 2), (2, (64, 96), 3), (3, (16, 32, 48), 2), (3, (16, 32, 48), 3), (2, (64, 96), 0), (3, (16, 32, 48), 1)])
 def test_c_graph_matches_the_python_engines_and_the_oracle(dim, shape, mode):
     from interactive_unet.engine import Engine
     from interactive_unet.engine_x2 import EngineX2

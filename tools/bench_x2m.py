@@ -14,6 +14,8 @@ from interactive_unet import _native as nv
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 128
+DIM = int(sys.argv[3]) if len(sys.argv) > 3 else 3          # 2: the 2-D stage convs (`python tools/bench_x2m.py 8 512 2`)
+TAPS = 3 ** DIM
 A = 64.0
 LAYERS = [(0, 32, 32), (0, 64, 32), (1, 32, 64), (1, 64, 64), (1, 128, 64), (2, 64, 128), (2, 128, 128), (2, 256, 128), (3, 128, 256), (3, 256, 256)]
 
@@ -32,34 +34,36 @@ def timeit(run, iters=20):
 
 for lvl, ci, co in LAYERS:
     d = S >> lvl
-    vox = d ** 3
+    vox = d ** DIM
+    dd = (d, d, d) if DIM == 3 else (1, d, d)
     dev = 'cuda'
-    w = (torch.randn((co, ci, 3, 3, 3), device=dev) * (2.0 / (ci * 27)) ** 0.5).contiguous()
+    w = (torch.randn((co, ci) + (3,) * DIM, device=dev) * (2.0 / (ci * TAPS)) ** 0.5).contiguous()
     s = nv.stream()
     # fp16x2
-    wv = torch.empty(3 * ci * co * 27, device=dev)
+    wv = torch.empty(3 * ci * co * TAPS, device=dev)
     osc, b = torch.empty(co, device=dev), torch.empty(co, device=dev)
-    nv.call('iunet_x2_prep', nv.ptr(w), nv.ptr(wv), nv.ptr(osc), nv.ptr(b), None, None, None, None, None, 1e-5, A, A, co, ci, 27, 0, 16, s)
-    pm = nv.lib().iunet_x2_pack_mode(3)
-    wpk = torch.empty(nv.pack_conv3_elems(co, 3 * ci, 27, pm), dtype=torch.float16, device=dev)
-    nv.call('iunet_pack_conv3', 0, nv.ptr(wv), None, nv.ptr(wpk), co, 3 * ci, 27, pm, s)
+    nv.call('iunet_x2_prep', nv.ptr(w), nv.ptr(wv), nv.ptr(osc), nv.ptr(b), None, None, None, None, None, 1e-5, A, A, co, ci, TAPS, 0, 16 if DIM == 3 else 32, s)
+    pm = nv.lib().iunet_x2_pack_mode(DIM)
+    wpk = torch.empty(nv.pack_conv3_elems(co, 3 * ci, TAPS, pm), dtype=torch.float16, device=dev)
+    nv.call('iunet_pack_conv3', 0, nv.ptr(wv), None, nv.ptr(wpk), co, 3 * ci, TAPS, pm, s)
     xs = (torch.rand(N * 2 * ci * vox, device=dev) * 100).to(torch.float16)
     y = torch.empty(N * 2 * co * vox, dtype=torch.float16, device=dev)
-    t_x2 = timeit(lambda: nv.call('iunet_x2_conv3_fwd', 3, nv.ptr(xs), 2 * ci * vox, ci // 8, nv.ptr(y), 2 * co * vox, co // 8, nv.ptr(wpk),
-                                  nv.ptr(osc), nv.ptr(b), N, d, d, d, ci, co, 2, s))
+    t_x2 = timeit(lambda: nv.call('iunet_x2_conv3_fwd', DIM, nv.ptr(xs), 2 * ci * vox, ci // 8, nv.ptr(y), 2 * co * vox, co // 8, nv.ptr(wpk),
+                                  nv.ptr(osc), nv.ptr(b), N, *dd, ci, co, 2, s))
     # x2m
-    whi = torch.empty(co * ci * 27, device=dev)
-    w8 = torch.zeros(nv.lib().iunet_x2m_w8_bytes(co, ci), dtype=torch.uint8, device=dev)
-    nv.call('iunet_x2m_prep', nv.ptr(w), nv.ptr(whi), nv.ptr(w8), nv.ptr(osc), nv.ptr(b), None, None, None, None, 1e-5, A, A, co, ci, s)
-    w16 = torch.empty(nv.pack_conv3_elems(co, ci, 27, 2), dtype=torch.float16, device=dev)
-    nv.call('iunet_pack_conv3', 0, nv.ptr(whi), None, nv.ptr(w16), co, ci, 27, 2, s)
+    whi = torch.empty(co * ci * TAPS, device=dev)
+    w8 = torch.zeros(nv.lib().iunet_x2m_w8_bytes_nd(DIM, co, ci), dtype=torch.uint8, device=dev)
+    nv.call('iunet_x2m_prep_nd', DIM, nv.ptr(w), nv.ptr(whi), nv.ptr(w8), nv.ptr(osc), nv.ptr(b), None, None, None, None, 1e-5, A, A, co, ci, s)
+    pm16 = 2 if DIM == 3 else 6
+    w16 = torch.empty(nv.pack_conv3_elems(co, ci, TAPS, pm16), dtype=torch.float16, device=dev)
+    nv.call('iunet_pack_conv3', 0, nv.ptr(whi), None, nv.ptr(w16), co, ci, TAPS, pm16, s)
     x8 = torch.empty(N * 2 * ci * vox, dtype=torch.uint8, device=dev)
-    nv.call('iunet_x2m_make8', nv.ptr(xs), 2 * ci * vox, ci // 8, nv.ptr(x8), 2 * ci * vox, ci, N, d, d, d, s)
+    nv.call('iunet_x2m_make8', nv.ptr(xs), 2 * ci * vox, ci // 8, nv.ptr(x8), 2 * ci * vox, ci, N, *dd, s)
     y8 = torch.empty(N * 2 * co * vox, dtype=torch.uint8, device=dev)
     res = {}
     for name, ylo, yy8 in (('hi+lo+m8', co // 8, y8), ('hi+m8', -1, y8), ('hi+lo', co // 8, None)):
-        res[name] = timeit(lambda: nv.call('iunet_x2m_conv3_fwd', nv.ptr(xs), 2 * ci * vox, nv.ptr(x8), 2 * ci * vox, nv.ptr(y), 2 * co * vox, ylo,
-                                           nv.ptr(yy8), 2 * co * vox, nv.ptr(w16), nv.ptr(w8), nv.ptr(osc), nv.ptr(b), N, d, d, d, ci, co, 2, None, s))
-    fl = 2.0 * 27 * ci * co * vox * N
-    print(f'L{lvl} {ci:3d}->{co:3d} @ {N} x {d}^3: fp16x2 {t_x2:8.1f} us ({fl / t_x2 / 1e6:6.1f} TF/s alg) | x2m ' +
+        res[name] = timeit(lambda: nv.call('iunet_x2m_conv_fwd', DIM, nv.ptr(xs), 2 * ci * vox, nv.ptr(x8), 2 * ci * vox, nv.ptr(y), 2 * co * vox, ylo,
+                                           nv.ptr(yy8), 2 * co * vox, nv.ptr(w16), nv.ptr(w8), nv.ptr(osc), nv.ptr(b), N, *dd, ci, co, 2, None, s))
+    fl = 2.0 * TAPS * ci * co * vox * N
+    print(f'L{lvl} {ci:3d}->{co:3d} @ {N} x {d}^{DIM}: fp16x2 {t_x2:8.1f} us ({fl / t_x2 / 1e6:6.1f} TF/s alg) | x2m ' +
           ' '.join(f'{k} {v:8.1f} us' for k, v in res.items()) + f' | x2m/fp16x2 = {res["hi+lo+m8"] / t_x2:.3f} ({fl / res["hi+m8"] / 1e6:6.1f} TF/s alg)', flush=True)
