@@ -109,8 +109,8 @@ def pmc_traffic(workload, tiles=1):
     """HBM bytes per launch of the roofline kernel from the committed PMC profile (rocprofv3 cannot run inside the timed
     process): FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate passes, scaled to the tiles of the launch.  None where
     no profile is committed."""
-    for name in (f'r03_pmc_{workload}_dec0conv1.json', 'r03_pmc_c3_dec0conv1.json' if workload == 'c4' else '',
-                 f'r02_pmc_{workload}_dec0conv1.json', 'r02_pmc_c3_dec0conv1.json' if workload == 'c4' else ''):
+    for name in (f'r04_pmc_{workload}_dec0conv1.json', 'r04_pmc_c3_dec0conv1.json' if workload == 'c4' else '',
+                 f'r03_pmc_{workload}_dec0conv1.json', 'r03_pmc_c3_dec0conv1.json' if workload == 'c4' else ''):
         try:
             with open(os.path.join(ROOT, 'profiles', name)) as f:
                 d = json.load(f)
@@ -257,7 +257,7 @@ def native_parity(model, cfg, chunk_u8):
     engs = [model.engine('eval'), e32]
     names = []
     if not cfg['wq']:
-        for nm, mixed in (('fp16x2', False),) + ((('x2m', True),) if dim == 3 else ()):
+        for nm, mixed in (('fp16x2', False), ('x2m', True)):
             ex2 = EngineX2(dim, cfg['levels'], cfg['base'], 1, ncls, model.device, mixed=mixed)
             ex2.load_eval(model.named_tensors())
             engs.append(ex2)
@@ -344,7 +344,7 @@ def cpu_baseline(cfg, model=None, chunk_u8=None):
         modes = [(cfg['dtype'], model.engine('eval')), ('fp32_mode', e32)]
         if not cfg['wq']:
             from interactive_unet.engine_x2 import EngineX2
-            for nm, mixed in (('fp16x2', False),) + ((('x2m', True),) if dim == 3 else ()):
+            for nm, mixed in (('fp16x2', False), ('x2m', True)):
                 ex2 = EngineX2(dim, levels, base, 1, ncls, model.device, mixed=mixed)
                 ex2.load_eval(model.named_tensors())
                 modes.append((nm, ex2))
@@ -764,7 +764,7 @@ def run(args, workload, rank, world, dev, dist, group):
         out['legs'] = leg_fields(head)
         if c4 is not None:
             out['c4'] = c4
-        x2m_on = compliant and dim == 3 and os.environ.get('IUNET_X2M', '1') != '0'      # (EngineX2's 3-D default)
+        x2m_on = compliant and os.environ.get('IUNET_X2M', '1') != '0'      # (EngineX2's default)
         x2_name = ('fp16x2 with the cross terms on the fp8 matrix cores (x2m: x_hi w_hi on v_mfma_f32_16x16x32_f16 + [x_lo8 | x_hi8][w_hi8 | w_lo8] on '
                    'v_mfma_f32_16x16x128_f8f6f4, fp32 accumulate)') if x2m_on else 'fp16x2 (split precision: fp16 hi + lo words, fp32 accumulate)'
         if compliant:
@@ -774,7 +774,11 @@ def run(args, workload, rank, world, dev, dist, group):
             if predict_events:
                 ps = conv_roofline_in_situ(nv, cfg, workload, torch.float16, predict_events[:400])
                 ps.pop('traffic', None)
-                ps['kernel'] = ('conv3_x2m_kernel' if x2m_on else 'split-precision conv (conv3_v4_kernel<f16,...,SPL>)') + ', ' + ps['kernel'].split('(', 1)[1].rstrip(')')
+                if dim == 3:
+                    ps['traffic'] = pmc_traffic('x2m' if x2m_on else 'x2', ps['tiles_per_launch'])
+                    ps['algorithmic_bytes_per_launch'] *= 2          # 4 bytes per element in and out (hi words + lo words / m8 bytes)
+                    ps['hbm_gbs_algorithmic'] = round(2 * ps['hbm_gbs_algorithmic'], 1)
+                ps['kernel'] = (('conv3_x2m_kernel' if dim == 3 else 'conv2_x2m_kernel') if x2m_on else 'split-precision conv (conv3_v4_kernel<f16,...,SPL>)') + ', ' + ps['kernel'].split('(', 1)[1].rstrip(')')
                 # matrix work per multiply-add: fp16x2 three 16-bit products; x2m one 16-bit product + two fp8 products at twice the rate =
                 # the time of two 16-bit products at peak
                 units = 2 if x2m_on else 3

@@ -8,6 +8,7 @@
 // host memory only.
 #include "common.h"
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -180,7 +181,8 @@ int iunet_net_create(int dim, int levels, int base, int cin, int ncls, int mode,
         if (mode != 2) {          // the layouts a 16-bit launch may pick (interactive_unet/_native.py: PackedConv)
           const bool compact2d = n->taps == 9 && iunet_conv3_compact_ok(2, 1, 1, 16, 32, op.ci, co, 0, 0);      // (off: IUNET_NO_COMPACT2D)
           if (co % 64 == 0 && n->taps == 9 && op.ci > 64 && !compact2d) op.pk[0] = pk_take(iunet_pack_conv3_elems(co, op.ci, n->taps, 0) * 2);
-          if ((n->taps == 27 && op.ci > 32) || compact2d) op.pk[3] = pk_take(iunet_pack_conv3_elems(co, op.ci, n->taps, 6) * 2);
+          const char* nc = getenv("IUNET_NO_COMPACT");                                  // (the switch _native.PackedConv honours: ADVICE r3)
+          if (((n->taps == 27 && op.ci > 32) || compact2d) && !(nc && nc[0])) op.pk[3] = pk_take(iunet_pack_conv3_elems(co, op.ci, n->taps, 6) * 2);
         }
       }
       op.aux = pk_take(2ll * co * 4);

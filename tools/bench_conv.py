@@ -26,6 +26,8 @@ def main():
     ap.add_argument('--levels', type=int, default=4)
     ap.add_argument('--f8', type=int, default=0, help='1: also time the fp8 matrix-core kernel (conv3_f8.hip / conv3_f8k.hip) on each shape; 2: with e4m3 activation planes in and out (3-D, the engine\'s format between fp8 convs)')
     ap.add_argument('--x2', type=int, default=0, help='1: also time the split-precision conv (fp16x2: conv3_v4.hip SPL) on each shape; 2: only it')
+    ap.add_argument('--x2m', type=int, default=0, help='1: also time the split-precision conv with its cross terms on the fp8 matrix cores (conv3_x2m.hip; '
+                    'hi + m8 planes in and out) on each shape; 2: only it')
     a = ap.parse_args()
     T = torch.bfloat16 if a.dtype == 'bf16' else torch.float16
     dt = nv.DTYPE_CODE[T]; nd = a.dim; taps = 3 ** nd
@@ -57,7 +59,7 @@ def main():
         nv.call('iunet_pack_conv3', dt, nv.ptr(w), None, nv.ptr(wpk), cout, cin, taps, pm, nv.stream())
         f = lambda: nv.call('iunet_conv3_fwd', dt, nd, nv.ptr(x), cin * vox, nv.ptr(y), cout * vox, nv.ptr(wpk), nv.ptr(bias), None,
                             a.n, D, S, S, cin, cout, 2, lay, nv.stream())
-        ms = timeit(f, iters=a.iters) if a.x2 != 2 else float('nan')
+        ms = timeit(f, iters=a.iters) if (a.x2 != 2 and a.x2m != 2) else float('nan')
         fl = 2.0 * taps * cin * cout * vox * a.n
         line = f'L{lvl} {cin:3d}->{cout:3d} @{S}^{nd} N={a.n} layout {lay}: fwd {ms*1e3:8.1f} us {fl/ms/1e9:7.1f} TF/s'
         tot_f += fl; tot_t += ms
@@ -97,6 +99,23 @@ def main():
                                 nv.ptr(osc), nv.ptr(b2), a.n, D, S, S, cin, cout, 2, nv.stream())
             ms4 = timeit(k, iters=a.iters)
             line += f' | fp16x2 {ms4*1e3:8.1f} us {fl/ms4/1e9:7.1f} TF/s algorithmic = {3*fl/ms4/1e9:7.1f} TF/s of MFMA work ({ms4/ms:.2f}x the 16-bit time)'
+        if a.x2m:
+            whi = torch.empty(cin * cout * taps, device='cuda')
+            w8 = torch.zeros(nv.lib().iunet_x2m_w8_bytes_nd(nd, cout, cin), dtype=torch.uint8, device='cuda')
+            osc, b2 = torch.empty(cout, device='cuda'), torch.empty(cout, device='cuda')
+            nv.call('iunet_x2m_prep_nd', nd, nv.ptr(w), nv.ptr(whi), nv.ptr(w8), nv.ptr(osc), nv.ptr(b2), None, None, None, None, 1e-5, 64.0, 64.0, cout, cin, nv.stream())
+            pm16 = 2 if nd == 3 else 6
+            w16 = torch.empty(nv.pack_conv3_elems(cout, cin, taps, pm16), dtype=torch.float16, device='cuda')
+            nv.call('iunet_pack_conv3', 0, nv.ptr(whi), None, nv.ptr(w16), cout, cin, taps, pm16, nv.stream())
+            xh = (torch.randn(a.n * cin * vox, device='cuda') * 8).to(torch.float16)                  # hi planes
+            x8 = (torch.randn(a.n * 2 * cin * vox, device='cuda') * 2).to(torch.float8_e4m3fn).view(torch.uint8)      # m8 planes (random e4m3 bytes: timing only)
+            yh = torch.empty(a.n * cout * vox, dtype=torch.float16, device='cuda')
+            y8 = torch.empty(a.n * 2 * cout * vox, dtype=torch.uint8, device='cuda')
+            km = lambda: nv.call('iunet_x2m_conv_fwd', nd, nv.ptr(xh), cin * vox, nv.ptr(x8), 2 * cin * vox, nv.ptr(yh), cout * vox, -1, nv.ptr(y8), 2 * cout * vox,
+                                 nv.ptr(w16), nv.ptr(w8), nv.ptr(osc), nv.ptr(b2), a.n, D, S, S, cin, cout, 2, None, nv.stream())
+            ms5 = timeit(km, iters=a.iters)
+            line += (f' | x2m {ms5*1e3:8.1f} us {fl/ms5/1e9:7.1f} TF/s algorithmic = {2*fl/ms5/1e9:7.1f} TF/s of matrix work in 16-bit equivalents '
+                     f'(1 x 16-bit + 2 x fp8 at twice the rate; {ms5/ms:.2f}x the 16-bit time)')
         print(line, flush=True)
     print(f'sum fwd: {tot_t*1e3:.1f} us, {tot_f/tot_t/1e9:.1f} TF/s')
 

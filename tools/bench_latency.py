@@ -32,7 +32,7 @@ for mode in ('fp16', 'fp16x2'):
         gr = t(g.replay)
         # C++-sequenced handle
         h = ctypes.c_void_p()
-        nv.call('iunet_net_create', 2, 4, 32, 1, 2, 2 if mode == 'fp16x2' else 0, 0.0, ctypes.byref(h))
+        nv.call('iunet_net_create', 2, 4, 32, 1, 2, (3 if getattr(m.engine('eval'), 'mixed', False) else 2) if mode == 'fp16x2' else 0, 0.0, ctypes.byref(h))      # (fp16x2: the engine's own form -- mode 3, cross terms on the fp8 matrix cores, by default)
         flat = torch.empty(nv.lib().iunet_net_num_params(h), device='cuda')
         off = 0
         for name, tns in m.named_tensors().items():

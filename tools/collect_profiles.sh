@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collect the round's profile artefacts on the GPU box (run from the repo root through gpurun); the summaries land in
-# gpurun_out/profiles_$RND/ and are copied into profiles/ (tracked) afterwards.   bash tools/collect_profiles.sh [r03]
-RND=${1:-r03}
+# gpurun_out/profiles_$RND/ and are copied into profiles/ (tracked) afterwards.   bash tools/collect_profiles.sh [r04]
+RND=${1:-r04}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/profiles_$RND
 mkdir -p $OUT
@@ -43,9 +43,10 @@ stats roofline_c5 python3 $R/tools/bench_conv.py --only 0:128:64 --base 64 --lev
 stats roofline_c2 python3 $R/tools/bench_conv.py --only 0:64:32 --dim 2 --size 512 --n 8 --dtype f16 --wgrad 0 --iters 50
 # the split-precision (fp16x2) conv of the same layer alone, and one whole split-precision forward per configuration
 stats roofline_x2 python3 $R/tools/bench_conv.py --only 0:64:32 --wgrad 0 --iters 50 --n 2 --x2 2
+stats roofline_x2m python3 $R/tools/bench_conv.py --only 0:64:32 --wgrad 0 --iters 50 --n 2 --x2m 2      # the predict leg's kernel: cross terms on the fp8 matrix cores
 stats forward_x2 python3 $R/tools/bench_x2.py x2
-python3 $R/tools/bench_conv.py --wgrad 0 --iters 30 --n 1 --x2 1 > $OUT/${RND}_conv_layers_x2_3d.txt 2>/dev/null
-python3 $R/tools/bench_conv.py --dim 2 --size 512 --n 8 --dtype f16 --wgrad 0 --iters 30 --x2 1 > $OUT/${RND}_conv_layers_x2_2d.txt 2>/dev/null
+python3 $R/tools/bench_conv.py --wgrad 0 --iters 30 --n 1 --x2 1 --x2m 1 > $OUT/${RND}_conv_layers_x2_3d.txt 2>/dev/null
+python3 $R/tools/bench_conv.py --dim 2 --size 512 --n 8 --dtype f16 --wgrad 0 --iters 30 --x2 1 --x2m 1 > $OUT/${RND}_conv_layers_x2_2d.txt 2>/dev/null
 # every C5 stage-conv shape: 16-bit kernel and the K = 128 fp8 kernel on e4m3 planes side by side
 python3 $R/tools/bench_conv.py --base 64 --levels 5 --f8 2 --wgrad 0 --iters 30 > $OUT/${RND}_conv_layers_c5_f8.txt 2>/dev/null
 # every transposed-conv shape of C3 / C5 / C2 alone
@@ -55,6 +56,12 @@ rm -rf $OUT/tmp_tr; rocprofv3 --kernel-trace --output-format csv -d $OUT/tmp_tr 
 python3 $R/tools/step_profile.py $OUT/tmp_tr/tr_kernel_trace.csv 13 40 > $OUT/${RND}_train_step_by_kernel.txt; rm -rf $OUT/tmp_tr
 rm -rf $OUT/tmp_c5; rocprofv3 --kernel-trace --output-format csv -d $OUT/tmp_c5 -o c5 -- python3 $R/tools/bench_c5_predict.py 10 > $OUT/c5_predict.log 2>&1
 python3 $R/tools/step_profile.py $OUT/tmp_c5/c5_kernel_trace.csv 13 20 > $OUT/${RND}_c5_forward_by_kernel.txt; rm -rf $OUT/tmp_c5
+rm -rf $OUT/tmp_t2; rocprofv3 --kernel-trace --output-format csv -d $OUT/tmp_t2 -o t2 -- python3 $R/tools/bench_train2d.py 8 > $OUT/train2d.log 2>&1
+python3 $R/tools/step_profile.py $OUT/tmp_t2/t2_kernel_trace.csv 128 40 > $OUT/${RND}_train2d_step_by_kernel.txt; rm -rf $OUT/tmp_t2      # 2 modes x (4 + 30 + 30) steps
+rm -rf $OUT/tmp_pp; rocprofv3 --kernel-trace --output-format csv -d $OUT/tmp_pp -o pp -- python3 $R/tools/bench_predict3d.py 10 fp16x2 > $OUT/predict3d.log 2>&1
+python3 $R/tools/step_profile.py $OUT/tmp_pp/pp_kernel_trace.csv 26 30 > $OUT/${RND}_predict_x2m_by_kernel.txt; rm -rf $OUT/tmp_pp      # 13 volumes of 4 blocks = 26 two-block forwards
+python3 $R/tools/bench_train2d.py 1 8 2>/dev/null | grep -v amdgpu > $OUT/${RND}_train2d_latency.txt
+python3 $R/tools/bench_latency.py 2>/dev/null | grep -v amdgpu > $OUT/${RND}_slice_latency.txt
 echo "done layer tables and step profiles"
 # 4. HBM traffic of the roofline kernels (separate passes, as the guide prescribes)
 for c in FETCH_SIZE WRITE_SIZE; do
@@ -62,9 +69,20 @@ for c in FETCH_SIZE WRITE_SIZE; do
   pmc c5 $c python3 $R/tools/bench_conv.py --only 0:128:64 --base 64 --levels 5 --wgrad 0 --f8 2 --iters 2
   pmc c2 $c python3 $R/tools/bench_conv.py --only 0:64:32 --dim 2 --size 512 --n 8 --dtype f16 --wgrad 0 --iters 2
   pmc x2 $c python3 $R/tools/bench_conv.py --only 0:64:32 --wgrad 0 --iters 2 --x2 2
+  pmc x2m $c python3 $R/tools/bench_conv.py --only 0:64:32 --wgrad 0 --iters 2 --x2m 2
 done
 python3 $R/tools/pmc_json.py $OUT $RND c3 conv3_v4_kernel 'dec0.conv1 64->32 @ 1 x 128^3 bf16' 402653184 1
 python3 $R/tools/pmc_json.py $OUT $RND c5 conv3_f8k_kernel 'dec0.conv1 128->64 @ 1 x 128^3, e4m3 planes in and out, K = 128 fp8 MFMA' 402653184 1
 python3 $R/tools/pmc_json.py $OUT $RND c2 conv3_v4_kernel 'dec0.conv1 64->32 @ 8 x 512^2 f16' 402653184 8
 python3 $R/tools/pmc_json.py $OUT $RND x2 conv3_v4_kernel 'dec0.conv1 64->32 @ 1 x 128^3 fp16x2 (hi + lo planes in and out)' 805306368 1
+python3 $R/tools/pmc_json.py $OUT $RND x2m conv3_x2m_kernel 'dec0.conv1 64->32 @ 1 x 128^3 x2m (hi + m8 planes in and out)' 805306368 1
+# 5. per-level MFMA pipe busy + HBM bytes of the stage convs (north_star: "for the 3x3 conv at each resolution level"): the 16-bit kernels and
+#    the split-precision kernel with its cross terms on the fp8 matrix cores, 3-D and 2-D
+cd $R
+bash tools/level_report.sh 3 1 128 bf16 3d > /dev/null 2>&1;               python3 tools/level_report.py 3d $RND
+bash tools/level_report.sh 3 1 128 bf16 x2m_3d "--x2m 2" > /dev/null 2>&1; python3 tools/level_report.py x2m_3d $RND
+bash tools/level_report.sh 2 8 512 f16 2d > /dev/null 2>&1;                python3 tools/level_report.py 2d $RND
+bash tools/level_report.sh 2 8 512 f16 x2m_2d "--x2m 2" > /dev/null 2>&1;  python3 tools/level_report.py x2m_2d $RND
+cp profiles/${RND}_conv_levels_*.md $OUT/ 2>/dev/null
+for f in conv3_v4 conv3_x2m conv3_f8k conv3_wgrad_v2 conv3_wgrad pointwise split16 train_misc; do python3 tools/regreport.py interactive-unet_amd/csrc/$f.hip; done > $OUT/${RND}_register_report.txt 2>&1
 ls -la $OUT
