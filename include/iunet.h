@@ -230,6 +230,14 @@ int iunet_x2m_prep_nd(int nd, const void* w, void* whi, void* w8, void* oscale, 
 int iunet_x2m_conv_fwd(int nd, const void* x, long long x_ss, const void* x8, long long x8_ss, void* y, long long y_ss, int y_lo, void* y8,
                        long long y8_ss, const void* w16, const void* w8, const void* oscale, const void* bias, int N, int D, int H, int W,
                        int Cin, int Cout, int epi, void* sat, void* stream);
+/* the LAST stage conv of the network with the 1x1 head + softmax + class map (unet.py:63-69, predict.py:38) in its epilogue: its 32 output
+ * channels are never written; logits / probs / cls are iunet_x2m_conv_fwd + iunet_x2_head_fwd bit for bit (the head's fmaf chain is walked
+ * through the lane groups in channel order).  iunet_x2m_head_fusable: 1 for the heads it takes (2 or 3 classes on 32 channels). */
+int iunet_x2m_head_fusable(int ncls, int C0);
+int iunet_x2m_conv_head_fwd(int nd, const void* x, long long x_ss, const void* x8, long long x8_ss, const void* w16, const void* w8,
+                            const void* oscale, const void* bias, const void* head_w, const void* head_b, float act_scale, int ncls,
+                            void* logits, void* probs, void* cls, const long long* out_strides, float divisor, int accumulate, int N, int D,
+                            int H, int W, int Cin, void* sat, void* stream);
 /* m8 planes (x8_ss bytes per sample) of a split tensor that another kernel wrote as hi + lo words (x_ss fp16 elements per sample) */
 int iunet_x2m_make8(const void* x, long long x_ss, int x_lo, void* x8, long long x8_ss, int C, int N, int D, int H, int W, void* stream);
 /* producers of the x2m form: iunet_x2_first_conv_fwd / iunet_x2_convT_fwd writing, beside the hi planes, the m8 planes of their output

@@ -51,9 +51,78 @@ struct ConvX2MParams {
   int nbz, nby, nbx;
   int epi;
   int* sat;                                   // optional: the largest |hi| bit pattern stored by this launch (atomicMax; range check)
+  // fused 1x1 head (template HEAD = classes; the launch's 32 output channels are the head's input, never written): unet.py:63-69 +
+  // predict.py:38 on the split words this conv would have stored -- the arithmetic of split16.hip's x2_head_kernel, bit for bit
+  const float* head_w; const float* head_b;   // fp32 [ncls][32], [ncls]
+  float inv_act;
+  float* logits; float* probs; unsigned char* cls;
+  long long oN, oC, oD, oH, oW;               // element strides of logits / probs
+  float divisor; int accumulate;
 };
 
-template <bool SMALL>
+// The head in the epilogue, in two parts.  (1) x2m_head_logits, per fragment: lane (q, l15) holds the 8 channels 8 q .. 8 q + 7 of voxel
+// l15 (fp32 epilogue values r, scaled by act_scale).  Summation order of split16.hip's x2_head_kernel: one fmaf chain per 8-channel plane
+// (= lane group), then (p0 + p1) + (p2 + p3) -- two butterfly exchanges between the lane groups; IEEE addition commutes, so all four
+// groups end with the same bits -- + bias: the unfused kernel's logits, bit for bit, in every lane group.  (2) x2m_head_store, once per
+// tile: a consumer wave owns FOUR fragments of 16 voxels and has four lane groups, so group q takes fragment q -- softmax, class map and
+// stores run once per VOXEL per lane (computed per fragment they ran four times over: +70 us on the 2 x 128^3 launch).
+// hw: LDS copy [NCLS][32] of the head weights + [NCLS] biases behind it.
+template <int NCLS>
+__device__ __forceinline__ void x2m_head_logits(const ConvX2MParams& p, const float* hw, const float (&r)[8], int q, bool ok, float (&l)[NCLS]) {
+  f16x8 hi;
+#pragma unroll
+  for (int c = 0; c < NCLS; ++c) l[c] = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float v = fminf(fmaxf(r[j], -65504.f), 65504.f);
+    const f16 h = (f16)v;
+    const f16 lw = (f16)(v - (float)h);
+    hi[j] = h;
+    const float a = ((float)h + (float)lw) * p.inv_act;        // what the head would have read back: (hi + lo) / act_scale
+#pragma unroll
+    for (int c = 0; c < NCLS; ++c) l[c] = fmaf(a, hw[c * 32 + q * 8 + j], l[c]);
+  }
+  if (ok && p.sat != nullptr) x2_note_saturation(p.sat, hi);
+#pragma unroll
+  for (int c = 0; c < NCLS; ++c) {
+    l[c] = __fadd_rn(l[c], __shfl_xor(l[c], 16));              // q0, q1: p0 + p1;  q2, q3: p2 + p3
+    l[c] = __fadd_rn(l[c], __shfl_xor(l[c], 32));              // (p0 + p1) + (p2 + p3) in every group
+    l[c] = __fadd_rn(l[c], hw[NCLS * 32 + c]);
+  }
+}
+template <int NCLS>
+__device__ __forceinline__ void x2m_head_store(const ConvX2MParams& p, const float (&l)[NCLS], bool ok, int n_img, long long nvox, long long vo,
+                                               int gz, int gy, int gx) {
+  if (!ok) return;
+  const long long obase = n_img * p.oN + gz * p.oD + gy * p.oH + gx * p.oW;
+  float mx = l[0];
+#pragma unroll
+  for (int c = 1; c < NCLS; ++c) mx = fmaxf(mx, l[c]);
+  if (p.logits) {
+#pragma unroll
+    for (int c = 0; c < NCLS; ++c) p.logits[obase + c * p.oC] = l[c];
+  }
+  float e[NCLS], sum = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCLS; ++c) { e[c] = expf(l[c] - mx); sum += e[c]; }
+  float pr[NCLS];
+  pr[0] = __fdiv_rn(e[0], sum);
+  float pm = pr[0]; int am = 0;
+#pragma unroll
+  for (int c = 1; c < NCLS; ++c) { pr[c] = __fdiv_rn(e[c], sum); if (pr[c] > pm) { pm = pr[c]; am = c; } }
+  if (p.cls) p.cls[n_img * nvox + vo] = (unsigned char)am;
+  if (p.probs) {
+#pragma unroll
+    for (int c = 0; c < NCLS; ++c) {
+      float* o = p.probs + obase + c * p.oC;
+      float rr = p.accumulate ? __fadd_rn(*o, pr[c]) : pr[c];
+      if (p.divisor != 1.0f) rr = __fdiv_rn(rr, p.divisor);
+      *o = rr;
+    }
+  }
+}
+
+template <bool SMALL, int HEAD = 0>
 __global__ __launch_bounds__((XMTile<SMALL>::NCW * 64 + XM_NLT), 1) void conv3_x2m_kernel(ConvX2MParams p) {
   using TL = XMTile<SMALL>;
   constexpr int NCW = TL::NCW, NLT = XM_NLT, NLW = NLT / 64;
@@ -99,6 +168,9 @@ __global__ __launch_bounds__((XMTile<SMALL>::NCW * 64 + XM_NLT), 1) void conv3_x
   };
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
   if (tid < 64) ((float*)(smem + OFF_E))[tid] = tid < 32 ? p.oscale[cob * 32 + tid] : (p.epi != 0 ? p.bias[cob * 32 + tid - 32] : 0.f);
+  if constexpr (HEAD > 0) {      // head weights [HEAD][32] + biases behind the [oscale | bias] block; published by the first barrier
+    for (int i = tid; i < HEAD * 33; i += (int)blockDim.x) ((float*)(smem + OFF_E + 256))[i] = i < HEAD * 32 ? p.head_w[i] : p.head_b[i - HEAD * 32];
+  }
 
   if (wave >= NCW) {
     // ================================================================== loader waves: everything global -> LDS without registers
@@ -329,6 +401,7 @@ __global__ __launch_bounds__((XMTile<SMALL>::NCW * 64 + XM_NLT), 1) void conv3_x
 #pragma unroll
       for (int j = 0; j < 4; ++j) { os_r[j] = w0[j]; os_r[4 + j] = w1[j]; bias_r[j] = b0[j]; bias_r[4 + j] = b1[j]; }
     }
+    [[maybe_unused]] float hl[HEAD > 0 ? HEAD : 1];
 #pragma unroll
     for (int n = 0; n < NI; ++n) {
       const int row = row_first + n;
@@ -341,6 +414,12 @@ __global__ __launch_bounds__((XMTile<SMALL>::NCW * 64 + XM_NLT), 1) void conv3_x
         r[j] = fmaf(j < 4 ? acc[0][n][j] : acc[1][n][j - 4], os_r[j], bias_r[j]);
         if (p.epi == 2) r[j] = fmaxf(r[j], 0.f);
       }
+      if constexpr (HEAD > 0) {
+        float lf[HEAD];
+        x2m_head_logits<HEAD>(p, (const float*)(smem + OFF_E + 256), r, q, ok, lf);
+#pragma unroll
+        for (int c = 0; c < HEAD; ++c) hl[c] = q == n ? lf[c] : hl[c];          // lane group q keeps fragment q's voxels
+      } else {
       f16x8 hi, lo;
       u32x2 lo8, hi8;
       x2m_split8(r, hi, lo, lo8, hi8);
@@ -354,8 +433,14 @@ __global__ __launch_bounds__((XMTile<SMALL>::NCW * 64 + XM_NLT), 1) void conv3_x
         }
         if (p.sat != nullptr) x2_note_saturation(p.sat, hi);
       }
+      }
       acc[0][n] = f32x4{0.f, 0.f, 0.f, 0.f};
       acc[1][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if constexpr (HEAD > 0) {
+      const int row = row_first + q;                                            // this lane group's fragment
+      const int gz = z0 + row / TY, gy = y0 + row % TY, gx = x0 + l15;
+      x2m_head_store<HEAD>(p, hl, gz < p.D && gy < p.H && gx < p.W, n_img, plane16b / 16, ((long long)gz * p.H + gy) * p.W + gx, gz, gy, gx);
     }
   };
 
@@ -403,6 +488,7 @@ __host__ __device__ inline int x2m2_w8_offset(int tap, int m, int b, int e, int 
   return (((G * 2 + m) * 2 + e) * 64 + q * 16 + row) * 16 + 8 * o;
 }
 
+template <int HEAD = 0>
 __global__ __launch_bounds__(8 * 64 + XM_NLT, 1) void conv2_x2m_kernel(ConvX2MParams p) {
   constexpr int NCW = 8, NLT = XM_NLT, NLW = NLT / 64;
   constexpr int TY = 16, TX = 32, FX = 2, NI = 4, NR = 2;
@@ -440,6 +526,9 @@ __global__ __launch_bounds__(8 * 64 + XM_NLT, 1) void conv2_x2m_kernel(ConvX2MPa
   };
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
   if (tid < 64) ((float*)(smem + OFF_E))[tid] = tid < 32 ? p.oscale[cob * 32 + tid] : (p.epi != 0 ? p.bias[cob * 32 + tid - 32] : 0.f);
+  if constexpr (HEAD > 0) {      // head weights [HEAD][32] + biases behind the [oscale | bias] block; published by the first barrier
+    for (int i = tid; i < HEAD * 33; i += (int)blockDim.x) ((float*)(smem + OFF_E + 256))[i] = i < HEAD * 32 ? p.head_w[i] : p.head_b[i - HEAD * 32];
+  }
 
   if (wave >= NCW) {
     // ================================================================== loader waves (LDS-DMA only)
@@ -627,6 +716,7 @@ __global__ __launch_bounds__(8 * 64 + XM_NLT, 1) void conv2_x2m_kernel(ConvX2MPa
 #pragma unroll
       for (int j = 0; j < 4; ++j) { os_r[j] = w0[j]; os_r[4 + j] = w1[j]; bias_r[j] = b0[j]; bias_r[4 + j] = b1[j]; }
     }
+    [[maybe_unused]] float hl[HEAD > 0 ? HEAD : 1];
 #pragma unroll
     for (int n = 0; n < NI; ++n) {
       const int gy = y0 + row_first + n / FX, gx = x0 + (n % FX) * 16 + l15;
@@ -638,6 +728,12 @@ __global__ __launch_bounds__(8 * 64 + XM_NLT, 1) void conv2_x2m_kernel(ConvX2MPa
         r[j] = fmaf(j < 4 ? acc[0][n][j] : acc[1][n][j - 4], os_r[j], bias_r[j]);
         if (p.epi == 2) r[j] = fmaxf(r[j], 0.f);
       }
+      if constexpr (HEAD > 0) {
+        float lf[HEAD];
+        x2m_head_logits<HEAD>(p, (const float*)(smem + OFF_E + 256), r, q, ok, lf);
+#pragma unroll
+        for (int c = 0; c < HEAD; ++c) hl[c] = q == n ? lf[c] : hl[c];
+      } else {
       f16x8 hi, lo;
       u32x2 lo8, hi8;
       x2m_split8(r, hi, lo, lo8, hi8);
@@ -651,8 +747,13 @@ __global__ __launch_bounds__(8 * 64 + XM_NLT, 1) void conv2_x2m_kernel(ConvX2MPa
         }
         if (p.sat != nullptr) x2_note_saturation(p.sat, hi);
       }
+      }
       acc[0][n] = f32x4{0.f, 0.f, 0.f, 0.f};
       acc[1][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if constexpr (HEAD > 0) {
+      const int gy = y0 + row_first + q / FX, gx = x0 + (q % FX) * 16 + l15;     // this lane group's fragment
+      x2m_head_store<HEAD>(p, hl, gy < p.H && gx < p.W, n_img, nvox, (long long)gy * p.W + gx, 0, gy, gx);
     }
   };
 
@@ -679,10 +780,11 @@ __global__ __launch_bounds__(8 * 64 + XM_NLT, 1) void conv2_x2m_kernel(ConvX2MPa
   }
 }
 
+template <int HEAD>
 int launch_x2m_2d(ConvX2MParams p, hipStream_t stream) {
   constexpr int PLANE = ((18 * 34 * 16 + 255) / 256) * 256;
-  const int lds = 8 * PLANE + 18432 + X2M2_W8 + 256;
-  IUNET_SET_MAX_LDS(conv2_x2m_kernel, lds);
+  const int lds = 8 * PLANE + 18432 + X2M2_W8 + 256 + (HEAD > 0 ? 2048 : 0);
+  IUNET_SET_MAX_LDS(conv2_x2m_kernel<HEAD>, lds);
   p.tilesZ = 1; p.tilesY = (p.H + 15) / 16; p.tilesX = (p.W + 31) / 32;
   const int ncob = p.Cout / 32;
   iunet_brick_shape(2, ncob, 1, p.tilesY, p.tilesX, &p.bz, &p.by, &p.bx);
@@ -694,24 +796,24 @@ int launch_x2m_2d(ConvX2MParams p, hipStream_t stream) {
   while (groups > 1 && nbricks / 8 < groups) groups >>= 1;
   if (groups < 1) groups = 1;
   const int gx = 8 * p.by * p.bx * groups;
-  hipLaunchKernelGGL(conv2_x2m_kernel, dim3(gx, ncob), dim3(8 * 64 + XM_NLT), lds, stream, p);
+  hipLaunchKernelGGL(conv2_x2m_kernel<HEAD>, dim3(gx, ncob), dim3(8 * 64 + XM_NLT), lds, stream, p);
   IUNET_CHECK_HIP(hipGetLastError());
   return IUNET_OK;
 }
 
-template <bool SMALL>
+template <bool SMALL, int HEAD = 0>
 int launch_x2m(ConvX2MParams p, hipStream_t stream) {
   using TL = XMTile<SMALL>;
   constexpr int PZ = TL::TZ + 2, NPIX = PZ * 10 * 18;
   constexpr int PLANE16 = ((NPIX * 16 + 255) / 256) * 256, PLANE8 = PZ * 192 * 16;
-  const int lds = 2 * PLANE16 + 30720 + 2 * PLANE8 + F8K_WSTEP + 256;
-  IUNET_SET_MAX_LDS((conv3_x2m_kernel<SMALL>), lds);
+  const int lds = 2 * PLANE16 + 30720 + 2 * PLANE8 + F8K_WSTEP + 256 + (HEAD > 0 ? 2048 : 0);
+  IUNET_SET_MAX_LDS((conv3_x2m_kernel<SMALL, HEAD>), lds);
   p.tilesZ = (p.D + TL::TZ - 1) / TL::TZ; p.tilesY = (p.H + TL::TY - 1) / TL::TY; p.tilesX = (p.W + TL::TX - 1) / TL::TX;
   const int ncob = p.Cout / 32;
   iunet_brick_shape(3, ncob, p.tilesZ, p.tilesY, p.tilesX, &p.bz, &p.by, &p.bx);
   p.nbz = (p.tilesZ + p.bz - 1) / p.bz; p.nby = (p.tilesY + p.by - 1) / p.by; p.nbx = (p.tilesX + p.bx - 1) / p.bx;
   const int gx = 8 * p.bz * p.by * p.bx;
-  hipLaunchKernelGGL((conv3_x2m_kernel<SMALL>), dim3(gx, ncob), dim3(TL::NCW * 64 + XM_NLT), lds, stream, p);
+  hipLaunchKernelGGL((conv3_x2m_kernel<SMALL, HEAD>), dim3(gx, ncob), dim3(TL::NCW * 64 + XM_NLT), lds, stream, p);
   IUNET_CHECK_HIP(hipGetLastError());
   return IUNET_OK;
 }
@@ -981,11 +1083,55 @@ int iunet_x2m_conv_fwd(int nd, const void* x, long long x_ss, const void* x8, lo
   p.N = N; p.D = D; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.epi = epi; p.sat = (int*)sat;
   p.tilesZ = p.tilesY = p.tilesX = 0;
   p.bz = p.by = p.bx = p.nbz = p.nby = p.nbx = 0;
-  if (nd == 2) return launch_x2m_2d(p, (hipStream_t)stream);
+  p.head_w = p.head_b = nullptr; p.inv_act = 0.f; p.logits = p.probs = nullptr; p.cls = nullptr;
+  p.oN = p.oC = p.oD = p.oH = p.oW = 0; p.divisor = 1.f; p.accumulate = 0;
+  if (nd == 2) return launch_x2m_2d<0>(p, (hipStream_t)stream);
   // the tile size follows the grid as in the 16-bit launch; the summation order of a voxel does not depend on it
   const long long big_tiles = (long long)N * ((D + 3) / 4) * ((H + 7) / 8) * ((W + 15) / 16);
   const bool small = big_tiles * (Cout / 32) < 128;
   return small ? launch_x2m<true>(p, (hipStream_t)stream) : launch_x2m<false>(p, (hipStream_t)stream);
+}
+
+/* 1 if iunet_x2m_conv_head_fwd takes this head (2 or 3 classes on 32 feature channels), else 0: the caller then runs the conv into hi + lo
+ * planes and iunet_x2_head_fwd on them */
+int iunet_x2m_head_fusable(int ncls, int C0) {
+  static const int off = getenv("IUNET_X2M_HEAD") ? (atoi(getenv("IUNET_X2M_HEAD")) == 0) : 0;      // A/B switch: IUNET_X2M_HEAD=0 keeps the head its own launch
+  return !off && ncls >= 2 && ncls <= 3 && C0 == 32;      // (4 classes: the epilogue's registers spill beside the step loop's)
+}
+
+/* The LAST stage conv of the network with the 1x1 head + softmax + class map in its epilogue (unet.py:63-69, predict.py:38): the conv's
+ * 32 output channels are never written -- the head works on the split words the conv would have stored, in the unfused head's own fmaf
+ * chain, so logits / probs / cls are iunet_x2m_conv_fwd + iunet_x2_head_fwd bit for bit.  Output contract of iunet_head_fwd
+ * (out_strides n, c, d, h, w in elements; probs = ((accumulate ? probs : 0) + p) / divisor; cls uint8 [N][D*H*W]). */
+int iunet_x2m_conv_head_fwd(int nd, const void* x, long long x_ss, const void* x8, long long x8_ss, const void* w16, const void* w8,
+                            const void* oscale, const void* bias, const void* head_w, const void* head_b, float act_scale, int ncls,
+                            void* logits, void* probs, void* cls, const long long* out_strides, float divisor, int accumulate, int N, int D,
+                            int H, int W, int Cin, void* sat, void* stream) {
+  IUNET_REQUIRE(nd == 2 || nd == 3, "x2m_conv_head: nd must be 2 or 3");
+  IUNET_REQUIRE(nd == 3 || D == 1, "x2m_conv_head: 2-D needs D == 1");
+  IUNET_REQUIRE(x && x8 && w16 && w8 && oscale && bias && head_w && head_b && out_strides, "x2m_conv_head: null pointer");
+  IUNET_REQUIRE_GRID("x2m_conv_head", N, D, H, W);
+  IUNET_REQUIRE(Cin >= 32 && Cin % 32 == 0, "x2m_conv_head: Cin must be a positive multiple of 32 (got %d)", Cin);
+  IUNET_REQUIRE(ncls == 2 || ncls == 3, "x2m_conv_head: 2 or 3 classes (got %d)", ncls);
+  int e1;
+  IUNET_REQUIRE(act_scale > 0.f && frexpf(act_scale, &e1) == 0.5f, "x2m_conv_head: the activation scale must be a power of two (got %g)", act_scale);
+  ConvX2MParams p;
+  p.x = x; p.x_sstride = x_ss; p.x8 = x8; p.x8_sstride = x8_ss; p.y = nullptr; p.y_sstride = 0; p.y_lo = -1; p.y8 = nullptr; p.y8_sstride = 0;
+  p.w16 = w16; p.w8 = w8; p.oscale = (const float*)oscale; p.bias = (const float*)bias;
+  p.N = N; p.D = D; p.H = H; p.W = W; p.Cin = Cin; p.Cout = 32; p.epi = 2; p.sat = (int*)sat;
+  p.tilesZ = p.tilesY = p.tilesX = 0;
+  p.bz = p.by = p.bx = p.nbz = p.nby = p.nbx = 0;
+  p.head_w = (const float*)head_w; p.head_b = (const float*)head_b; p.inv_act = 1.0f / act_scale;
+  p.logits = (float*)logits; p.probs = (float*)probs; p.cls = (unsigned char*)cls;
+  p.oN = out_strides[0]; p.oC = out_strides[1]; p.oD = out_strides[2]; p.oH = out_strides[3]; p.oW = out_strides[4];
+  p.divisor = divisor; p.accumulate = accumulate;
+  hipStream_t s = (hipStream_t)stream;
+  if (nd == 2) return ncls == 2 ? launch_x2m_2d<2>(p, s) : launch_x2m_2d<3>(p, s);
+  // (the tile size follows the grid as in iunet_x2m_conv_fwd: one summation order per voxel either way)
+  const long long big_tiles = (long long)N * ((D + 3) / 4) * ((H + 7) / 8) * ((W + 15) / 16);
+  if (big_tiles < 128)
+    return ncls == 2 ? launch_x2m<true, 2>(p, s) : launch_x2m<true, 3>(p, s);
+  return ncls == 2 ? launch_x2m<false, 2>(p, s) : launch_x2m<false, 3>(p, s);
 }
 
 }  // extern "C"

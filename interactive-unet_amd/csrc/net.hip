@@ -29,6 +29,9 @@ int iunet_x2m_prep_nd(int, const void*, void*, void*, void*, void*, const void*,
 int iunet_x2m_conv_fwd(int, const void*, long long, const void*, long long, void*, long long, int, void*, long long, const void*, const void*,
                        const void*, const void*, int, int, int, int, int, int, int, void*, void*);
 long long iunet_x2m_w8_bytes_nd(int, int, int);
+int iunet_x2m_head_fusable(int, int);
+int iunet_x2m_conv_head_fwd(int, const void*, long long, const void*, long long, const void*, const void*, const void*, const void*, const void*,
+                            const void*, float, int, void*, void*, void*, const long long*, float, int, int, int, int, int, int, void*, void*);
 int iunet_x2m_first_conv_fwd(int, const void*, int, const long long*, void*, long long, int, void*, long long, const void*, const void*, const void*,
                              float, int, int, int, int, int, int, int, void*, void*);
 int iunet_x2m_convT_fwd(int, const void*, long long, int, void*, long long, int, void*, long long, const void*, const void*, const void*, int, int,
@@ -371,6 +374,14 @@ int iunet_net_forward(iunet_net* n, const void* x, int in_dtype, const long long
       const ConvOp& c2 = n->conv[2 * stage_index(n, true, l) + 1];
       rc = convm(c1, L.cat[l], 2ll * c * v, L.catm[l], 4ll * c * v, L.a[l], (long long)c * v, -1, L.am[l], 2ll * c * v, l);
       if (rc) return rc;
+      if (l == 0 && (logits || probs || cls) && iunet_x2m_head_fusable(n->ncls, c)) {
+        // the head in the last conv's epilogue: the last activation is never written (the same bits as conv + head)
+        const long long dflt0[5] = {n->ncls * v, v, (long long)H * W, W, 1};
+        const float* aux2 = (const float*)(K + c2.aux);
+        return iunet_x2m_conv_head_fwd(dim, WS + L.a[0], (long long)c * v, WS + L.am[0], 2ll * c * v, K + c2.pk[1], K + c2.pk[0], aux2, aux2 + c,
+                                       n->flat + n->head_w, n->flat + n->head_b, A, n->ncls, logits, probs, cls, out_strides ? out_strides : dflt0,
+                                       divisor, accumulate, N, dim == 3 ? D : 1, H, W, c, sat, stream);
+      }
       rc = convm(c2, L.a[l], (long long)c * v, L.am[l], 2ll * c * v, L.b[l], 2ll * c * v, c / 8, -1, 0, l);
       if (rc) return rc;
     }

@@ -478,7 +478,10 @@ __global__ __launch_bounds__(256) void x2_head_kernel(X2HeadParams p) {
   float l[NCLS];
 #pragma unroll
   for (int c = 0; c < NCLS; ++c) l[c] = 0.f;
-  // (the loads of four planes are issued before the first is consumed: left rolled, a thread waited out 2 x planes memory latencies)
+  // Summation order (shared with the head fused into the last x2m conv's epilogue, conv3_x2m.hip: x2m_head): one fmaf chain per
+  // 8-channel plane, the planes of a group of four added as (p0 + p1) + (p2 + p3) -- what two butterfly exchanges between the four lane
+  // groups of an MFMA fragment give --, the groups (base 64: two) added in order.  The loads of a group are issued before the first is
+  // consumed.
   for (int pl0 = 0; pl0 < p.planes; pl0 += 4) {
     f16x8 xh[4], xl[4];
 #pragma unroll
@@ -487,16 +490,25 @@ __global__ __launch_bounds__(256) void x2_head_kernel(X2HeadParams p) {
       xh[u] = *(const f16x8*)(xin + (long long)pl * vox * 8);
       xl[u] = *(const f16x8*)(xin + (long long)(p.x_lo + pl) * vox * 8);
     }
+    float part[4][NCLS];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int pl = pl0 + u;
-      if (pl >= p.planes) break;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float a = ((float)xh[u][j] + (float)xl[u][j]) * p.inv_act;
+      for (int c = 0; c < NCLS; ++c) part[u][c] = 0.f;
+      if (pl < p.planes) {
 #pragma unroll
-        for (int c = 0; c < NCLS; ++c) l[c] = fmaf(a, p.w[c * p.planes * 8 + pl * 8 + j], l[c]);
+        for (int j = 0; j < 8; ++j) {
+          const float a = ((float)xh[u][j] + (float)xl[u][j]) * p.inv_act;
+#pragma unroll
+          for (int c = 0; c < NCLS; ++c) part[u][c] = fmaf(a, p.w[c * p.planes * 8 + pl * 8 + j], part[u][c]);
+        }
       }
+    }
+#pragma unroll
+    for (int c = 0; c < NCLS; ++c) {
+      const float g = __fadd_rn(__fadd_rn(part[0][c], part[1][c]), __fadd_rn(part[2][c], part[3][c]));
+      l[c] = pl0 == 0 ? g : __fadd_rn(l[c], g);
     }
   }
 #pragma unroll

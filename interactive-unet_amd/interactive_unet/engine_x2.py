@@ -227,9 +227,15 @@ class EngineX2:
         dims, L, ch, s = ws['dims'], self.levels, self.ch, nv.stream()
         Pt = lambda t, planes=0, v=0: ctypes.c_void_p(t.data_ptr() + 2 * planes * v * 8)      # view starting `planes` planes in
         if self.mixed:
-            self._infer_mixed(ws, x, x_strides, N, D, H, W, s)
+            # the last stage conv carries the head in its epilogue where the library has that form (2 or 3 classes on 32 channels): the
+            # last activation is never written.  Same bits as conv + head (tests/test_gpu_x2m.py)
+            fuse = not features_only and self.probe is None and bool(nv.lib().iunet_x2m_head_fusable(self.ncls, self.ch[0]))
+            head = (logits, probs, cls, out_strides, divisor, accumulate) if fuse else None
+            self._infer_mixed(ws, x, x_strides, N, D, H, W, s, head=head)
             if features_only:
                 return ws['b0']
+            if fuse:
+                return None
             return self._head(ws, N, D, H, W, logits, probs, cls, out_strides, divisor, accumulate, s)
         for l in range(L):
             d, v = dims[l], _vox(dims[l])
@@ -292,7 +298,7 @@ class EngineX2:
             e1.record()
             probe['events'].append((e0, e1, N))
 
-    def _infer_mixed(self, ws, x, x_strides, N, D, H, W, s):
+    def _infer_mixed(self, ws, x, x_strides, N, D, H, W, s, head=None):
         """The forward in the x2m form (everything but the head): a / cat / pin tensors are (hi planes, m8 planes), b tensors (hi, lo)."""
         dims, L, ch = ws['dims'], self.levels, self.ch
         P8 = lambda t, planes16=0, v=0: ctypes.c_void_p(t.data_ptr() + planes16 * v * 16)     # m8 view starting `planes16` 16-byte planes in
@@ -328,6 +334,16 @@ class EngineX2:
                     P8(ws[f'cat{l}m'], 2 * c // 16, v), 4 * c * v, nv.ptr(w), nv.ptr(osc), nv.ptr(b), N, di[0], di[1], di[2], cn, c, nv.ptr(self._sat), s)
             self._conv3m(f'dec{l}.conv1', Ph(ws[f'cat{l}']), 2 * c * v, P8(ws[f'cat{l}m']), 4 * c * v, Ph(ws[f'a{l}']), c * v, -1,
                          P8(ws[f'a{l}m']), 2 * c * v, N, d, 2 * c, c, s)
+            if l == 0 and head is not None:
+                logits, probs, cls, out_strides, divisor, accumulate = head
+                if out_strides is None:
+                    out_strides = (self.ncls * v, v, H * W, W, 1)
+                w16, osc, b, w8 = self.packed['dec0.conv2']
+                hw, hb = self.packed['head']
+                nv.call('iunet_x2m_conv_head_fwd', self.dim, Ph(ws['a0']), c * v, P8(ws['a0m']), 2 * c * v, nv.ptr(w16), nv.ptr(w8), nv.ptr(osc),
+                        nv.ptr(b), nv.ptr(hw), nv.ptr(hb), self.act_scale, self.ncls, nv.ptr(logits), nv.ptr(probs), nv.ptr(cls),
+                        nv.ll_array(out_strides), float(divisor), int(bool(accumulate)), N, d[0], d[1], d[2], c, nv.ptr(self._sat), s)
+                continue
             self._conv3m(f'dec{l}.conv2', Ph(ws[f'a{l}']), c * v, P8(ws[f'a{l}m']), 2 * c * v, nv.ptr(ws[f'b{l}']), 2 * c * v, c // 8,
                          None, 0, N, d, c, c, s)
 

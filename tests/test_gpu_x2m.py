@@ -348,3 +348,50 @@ def test_network_x2m_c5_geometry_and_range_flag():
     e2.load_eval({k: v.cuda() for k, v in p2.items()})
     lg, _, _ = _forward(e2, x.cuda(), dim, ncls)
     assert torch.isfinite(lg).all() and e2.saturated()
+
+
+@pytest.mark.parametrize('dim,shape,ncls', [(3, (16, 32, 48), 2), (3, (8, 24, 40), 3), (2, (64, 96), 2), (2, (40, 72), 3)])
+def test_head_in_the_last_conv_epilogue_is_conv_plus_head_bit_for_bit(dim, shape, ncls, monkeypatch):
+    """iunet_x2m_conv_head_fwd (the last stage conv with the 1x1 head + softmax + class map in its epilogue, the last activation never
+    written) against iunet_x2m_conv_fwd into hi + lo planes followed by iunet_x2_head_fwd: logits, probabilities (accumulating into a
+    channels-last buffer with a divisor, the 2.5-D / block-store contract) and class map must be the same bits."""
+    nv = _nv()
+    assert nv.lib().iunet_x2m_head_fusable(ncls, 32) == 1 and nv.lib().iunet_x2m_head_fusable(5, 32) == 0
+    g = torch.Generator().manual_seed(41)
+    N, ci, co = 2, 32, 32
+    sp = shape if dim == 3 else (1,) + shape
+    vox = int(np.prod(shape))
+    x = torch.rand((N, ci) + sp, generator=g) * 2
+    w = torch.randn((co, ci) + (3,) * dim, generator=g) * (2.0 / (ci * 3 ** dim)) ** 0.5
+    bn = [0.75 + 0.5 * torch.rand(co, generator=g), 0.1 * torch.randn(co, generator=g), 0.2 * torch.randn(co, generator=g), 0.5 + torch.rand(co, generator=g)]
+    w16, w8, osc, bias, _ = _prep(nv, w, bn)
+    v = x * A
+    xh = v.to(torch.float16)
+    xs = _blocked(xh, 8).cuda()
+    x8 = _m8_planes(_e4m3((v - xh.float()) * 16.0), _e4m3(xh.float() / 256.0)).cuda()
+    hw = (torch.randn((ncls, co), generator=g) * 0.3).cuda()
+    hb = (torch.randn(ncls, generator=g) * 0.1).cuda()
+    # unfused: conv -> hi + lo planes -> head
+    y = torch.zeros(N * 2 * co * vox, dtype=torch.float16, device='cuda')
+    nv.call('iunet_x2m_conv_fwd', dim, nv.ptr(xs), ci * vox, nv.ptr(x8), 2 * ci * vox, nv.ptr(y), 2 * co * vox, co // 8, None, 0, nv.ptr(w16), nv.ptr(w8),
+            nv.ptr(osc), nv.ptr(bias), N, *sp, ci, co, 2, None, nv.stream())
+    outs = []
+    for fused in (False, True):
+        lg = torch.zeros((N, ncls) + sp, device='cuda')
+        pr = torch.full((N,) + sp + (ncls,), 0.125, device='cuda')                 # channels-last, accumulated into
+        cl = torch.zeros((N, vox), dtype=torch.uint8, device='cuda')
+        st_l = nv.ll_array((ncls * vox, vox, sp[1] * sp[2], sp[2], 1))
+        st_p = nv.ll_array((ncls * vox, 1, sp[1] * sp[2] * ncls, sp[2] * ncls, ncls))
+        for out, st in ((('lg',), st_l), (('pr',), st_p)):
+            args = (nv.ptr(lg) if out[0] == 'lg' else None, nv.ptr(pr) if out[0] == 'pr' else None, nv.ptr(cl), st, 3.0 if out[0] == 'pr' else 1.0,
+                    1 if out[0] == 'pr' else 0)
+            if fused:
+                nv.call('iunet_x2m_conv_head_fwd', dim, nv.ptr(xs), ci * vox, nv.ptr(x8), 2 * ci * vox, nv.ptr(w16), nv.ptr(w8), nv.ptr(osc), nv.ptr(bias),
+                        nv.ptr(hw), nv.ptr(hb), A, ncls, *args, N, *sp, ci, None, nv.stream())
+            else:
+                nv.call('iunet_x2_head_fwd', nv.ptr(y), 2 * co * vox, co // 8, co, nv.ptr(hw), nv.ptr(hb), A, ncls, *args, N, *sp, nv.stream())
+        torch.cuda.synchronize()
+        outs.append((lg.cpu(), pr.cpu(), cl.cpu()))
+    (lg0, pr0, cl0), (lg1, pr1, cl1) = outs
+    assert torch.equal(lg0, lg1) and torch.equal(pr0, pr1) and torch.equal(cl0, cl1)
+    assert lg0.abs().max() > 0.1 and (pr0 != 0.125 / 3.0).any()
