@@ -453,7 +453,11 @@ int iunet_conv3_f8k_launch(int dtype, const void* x, long long x_sstride, void* 
   p.N = N; p.D = D; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.epi = epi;
   p.tilesZ = p.tilesY = p.tilesX = 0;
   p.bz = p.by = p.bx = p.nbz = p.nby = p.nbx = 0;
+#ifdef IUNET_ABLATE      // result-destroying profiling switches exist in diagnostic builds only (tools/ab_build.sh <file> -DIUNET_ABLATE): ADVICE r3
   static const int dbg = getenv("IUNET_F8K_DBG") ? atoi(getenv("IUNET_F8K_DBG")) : 0;
+#else
+  static const int dbg = 0;
+#endif
   p.dbg = dbg;
   p.out8 = out8;
 #define F8K_GO(TT) (in8 ? (small ? launch_f8k<TT, true, true>(p, stream) : launch_f8k<TT, false, true>(p, stream)) \

@@ -851,7 +851,11 @@ int iunet_conv3_v4_launch(int dtype, int nd, const void* x, long long x_sstride,
   p.tilesZ = p.tilesY = p.tilesX = 0;
   p.bz = p.by = p.bx = p.nbz = p.nby = p.nbx = 0;
   p.split_nc = 0; p.x_lo = p.y_lo = 0; p.oscale = nullptr; p.sat = nullptr;
+#ifdef IUNET_ABLATE      // result-destroying profiling switches exist in diagnostic builds only (tools/ab_build.sh <file> -DIUNET_ABLATE): ADVICE r3
   static const int dbg = getenv("IUNET_V4_DBG") ? atoi(getenv("IUNET_V4_DBG")) : 0;
+#else
+  static const int dbg = 0;
+#endif
   p.dbg = dbg;
   // weights resident in LDS for the whole launch when they fit beside the two activation buffers
   const bool ws = nd == 3 ? Cin <= 32 : Cin <= 64;

@@ -508,7 +508,11 @@ int iunet_conv3_wgrad_v2_launch(int dtype, const void* x, long long x_ss, const 
   p.x = x; p.x_ss = x_ss; p.dy = dy; p.dy_ss = dy_ss; p.slab = slab; p.x_scale = x_scale; p.x_shift = x_shift;
   p.N = N; p.D = D; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
   p.tilesZ = (D + 1) / 2; p.tilesY = (H + 7) / 8; p.tilesX = (W + 15) / 16;
+#ifdef IUNET_ABLATE      // result-destroying profiling switches exist in diagnostic builds only (tools/ab_build.sh <file> -DIUNET_ABLATE): ADVICE r3
   static const int dbg = getenv("IUNET_WG2_DBG") ? atoi(getenv("IUNET_WG2_DBG")) : 0;
+#else
+  static const int dbg = 0;
+#endif
   p.dbg = dbg;
   static const int dyr = getenv("IUNET_WG2_DYR") ? atoi(getenv("IUNET_WG2_DYR")) : 1;      // A/B switch: 0 = the first consumer form
   constexpr int PLANE_X = 6 * 180 * 16 + 192, PLANE_Y = 256 * 16 + 64;

@@ -635,18 +635,29 @@ class TrainEngine:
     def step_backward(self, state):
         """Backward half: the flat fp32 gradient of loss_scale x loss in self.grad (all-reduced over the process group, if any).
         -> (flat gradient of the loss itself as a new tensor, finite?).  fp16: a non-finite gradient halves the loss scale
-        (GradScaler's back-off) and comes back as zeros."""
+        (GradScaler's back-off) and comes back as zeros; 2000 finite steps in a row double it (GradScaler's growth).  The caller owns the
+        optimiser here (UNet.configure_optimizers): `last_backward_ok` tells it whether to step -- torch's AdamW applied to an all-zero
+        gradient still decays the weights and moves its moments, so a loop that wants GradScaler's semantics skips
+        `optimizer.step()` when it is False."""
         ws, X, xs, y, w, tdt, N = state
         self.backward(ws, X, xs, y, w, tdt, N)
         world = self.buckets.finish() if self.pg is not None else 1
-        g = self.grad * (1.0 / (self.loss_scale * world))
+        scale = self.loss_scale
+        g = self.grad * (1.0 / (scale * world))
         ok = True
         if self.T == torch.float16:
             ok = bool(torch.isfinite(g).all().item())
             if not ok:
                 if self.dynamic_scale:
-                    self.loss_scale = max(self.loss_scale * 0.5, 1.0)
+                    self.loss_scale = max(scale * 0.5, 1.0)
+                    self._good_backwards = 0
                 g.zero_()
+            elif self.dynamic_scale:
+                self._good_backwards = getattr(self, '_good_backwards', 0) + 1
+                if self._good_backwards >= 2000:
+                    self.loss_scale = scale * 2.0
+                    self._good_backwards = 0
+        self.last_backward_ok = ok
         return g, ok
 
     def eval_step(self, X, y, w=None, sync=True):

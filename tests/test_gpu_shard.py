@@ -49,6 +49,11 @@ class ThreadComm:
             assert t.shape == buf.shape
             buf.copy_(t)
         self.sh.barrier.wait()
+        # every pair's sends were matched by exactly as many receives in this exchange (what RCCL's batch_isend_irecv needs: ADVICE r3)
+        with self.sh.lock:
+            left = {k: len(v) for k, v in self.sh.mail.items() if v and k[1] == self.rank}
+        assert not left, f'rank {self.rank}: unmatched sends {left}'
+        self.sh.barrier.wait()
         return []
 
 
@@ -72,6 +77,8 @@ def _volume(shape, seed):
 @pytest.mark.parametrize('dim,world,V,rounds,kw', [
     (3, 3, (100, 56, 72), 4, {}), (3, 4, (72, 40, 40), 8, {}), (2, 2, (56, 40, 72), 3, {}),
     (3, 2, (72, 40, 40), 4, {'act_dtype': 'fp16x2'}),                  # the default prediction mode (split precision)
+    (3, 3, (59, 40, 40), 2, {}),                                         # the last block reflects at the high z end (59 = 24 * 2 + 11)
+    (3, 4, (40, 32, 32), 2, {}),                                         # fewer block planes than ranks: some ranks own no block
     # config C5's numerics: e4m3 operators on the fp8 matrix cores, 5 levels, base 64 -- the 512- and 1024-channel layers take the
     # split-K path, whose share count must not depend on how many blocks a launch holds
     (3, 2, (72, 40, 40), 4, {'act_dtype': 'bf16', 'weight_dtype': 'fp8_e4m3', 'levels': 5, 'base': 64}),

@@ -91,4 +91,4 @@ def test_default_module_trains_16_bit_and_predicts_in_split_precision():
     p1 = {k: v.detach().cpu() for k, v in m.named_tensors().items()}
     assert (p1['enc0.conv1.weight'] - p0['enc0.conv1.weight']).abs().max() > 0
     ref = unet_ref.forward(p1, batch[0], dim=2)
-    assert (probs - ref).abs().max().item() <= 1e-5
+    assert (probs - ref).abs().max().item() <= 2e-4          # probabilities of the default mode (x2m: ~5e-5 measured; fp16: 1.5e-3)
