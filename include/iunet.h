@@ -230,6 +230,15 @@ int iunet_x2m_prep_nd(int nd, const void* w, void* whi, void* w8, void* oscale, 
 int iunet_x2m_conv_fwd(int nd, const void* x, long long x_ss, const void* x8, long long x8_ss, void* y, long long y_ss, int y_lo, void* y8,
                        long long y8_ss, const void* w16, const void* w8, const void* oscale, const void* bias, int N, int D, int H, int W,
                        int Cin, int Cout, int epi, void* sat, void* stream);
+/* an ENCODER stage's second conv (unet.py:63-69: the skip tensor) with the stage's 2^d max-pool riding in its epilogue: y / y8 as
+ * iunet_x2m_conv_fwd, and py / py8 = hi planes (py_ss elements per sample) / m8 planes (py8_ss bytes per sample) of the pooled tensor on the
+ * grid D/2 (nd = 3), H/2, W/2 -- the words iunet_x2m_maxpool_fwd makes of y / y8, bit for bit, without reading them back (2-D: pooled in the
+ * consumer waves' registers; 3-D: x and y in registers, the z pair through LDS by the loader waves).  iunet_x2m_pool_fusable: 1 where the
+ * library's own callers fuse (3-D; IUNET_X2M_POOL=0: nowhere, =2: 2-D too -- there the extra stores cost what the pool launch does). */
+int iunet_x2m_pool_fusable(int nd);
+int iunet_x2m_conv_pool_fwd(int nd, const void* x, long long x_ss, const void* x8, long long x8_ss, void* y, long long y_ss, int y_lo, void* y8,
+                            long long y8_ss, void* py, long long py_ss, void* py8, long long py8_ss, const void* w16, const void* w8,
+                            const void* oscale, const void* bias, int N, int D, int H, int W, int Cin, int Cout, int epi, void* sat, void* stream);
 /* the LAST stage conv of the network with the 1x1 head + softmax + class map (unet.py:63-69, predict.py:38) in its epilogue: its 32 output
  * channels are never written; logits / probs / cls are iunet_x2m_conv_fwd + iunet_x2_head_fwd bit for bit (the head's fmaf chain is walked
  * through the lane groups in channel order).  iunet_x2m_head_fusable: 1 for the heads it takes (2 or 3 classes on 32 channels). */

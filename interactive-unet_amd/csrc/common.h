@@ -231,6 +231,52 @@ __device__ __forceinline__ void x2m_split8(const float (&r)[8], f16x8& hi, f16x8
   lo8 = x2m_pack8(l4);
   hi8 = x2m_pack8(h8);
 }
+// ---- 2^d max-pool on the split words of the x2m form.  A candidate is the pair (hi word, lo8 byte) of one channel; the value a 3x3x3
+// consumer reads is hi + lo8 / 16.  |lo8 / 16| never exceeds half an ulp of hi (x2m_split8: lo is the fp16 rounding residual, and e4m3
+// rounding cannot carry it past the power of two that bounds it), so the order of the VALUES is the lexicographic order of (hi, lo8) --
+// they differ only where two values tie at a rounding midpoint, and there the larger hi is as good a winner.  That order is one unsigned
+// compare on a 24-bit key: [sortable hi word | sortable lo8 byte] (sign-magnitude -> offset binary: x ^ (sign ? all ones : sign bit)).
+// A total order on the words themselves: the winner does not depend on the order the candidates meet in, so the pool kernel
+// (conv3_x2m.hip: x2m_maxpool_kernel) and the conv epilogue that pools on the way out (x, y in registers, z through LDS) agree bit for bit.
+__device__ __forceinline__ void x2m_pool_keys(const f16x8 hi, const u32x2_t lo8, unsigned (&k)[8]) {
+  const u32x4 hb = __builtin_bit_cast(u32x4, hi);
+  unsigned hf[4], lf[2];
+#pragma unroll
+  for (int d = 0; d < 4; ++d) hf[d] = hb[d] ^ (((hb[d] >> 15) & 0x00010001u) * 0x7fffu + 0x80008000u);
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const unsigned t = (lo8[e] >> 7) & 0x01010101u;
+    lf[e] = lo8[e] ^ (((t << 7) - t) + 0x80808080u);
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j)           // bytes [lo8 | hi lo | hi hi | 0]
+    k[j] = __builtin_amdgcn_perm(hf[j >> 1], lf[j >> 2], 0x0c000000u | ((5u + 2u * (j & 1)) << 16) | ((4u + 2u * (j & 1)) << 8) | (unsigned)(j & 3));
+}
+// the words of 8 winning keys: hi, lo8, and hi8 = e4m3(hi * 2^-8) as x2m_split8 makes it
+__device__ __forceinline__ void x2m_pool_unkeys(const unsigned (&k)[8], f16x8& hi, u32x2_t& lo8, u32x2_t& hi8) {
+  u32x4 hb;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    const unsigned f = __builtin_amdgcn_perm(k[2 * d + 1], k[2 * d], 0x06050201u);
+    hb[d] = f ^ (0xffffffffu - ((f >> 15) & 0x00010001u) * 0x7fffu);
+  }
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const unsigned t0 = __builtin_amdgcn_perm(k[4 * e + 1], k[4 * e], 0x0c0c0400u), t1 = __builtin_amdgcn_perm(k[4 * e + 3], k[4 * e + 2], 0x0c0c0400u);
+    const unsigned f = __builtin_amdgcn_perm(t1, t0, 0x05040100u);
+    const unsigned t = (f >> 7) & 0x01010101u;
+    lo8[e] = f ^ (0xffffffffu - ((t << 7) - t));
+  }
+  hi = __builtin_bit_cast(f16x8, hb);
+  float h8[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) h8[j] = (float)hi[j] * 0.00390625f;
+  hi8 = x2m_pack8(h8);
+}
+// the value of lane ^ 1 (DPP quad_perm [1, 0, 3, 2]: no LDS traffic)
+__device__ __forceinline__ unsigned lane_xor1(unsigned v) {
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);
+}
 // range flag of the split-precision modes: a stored hi word of +-65504 means act_scale x activation saturated (split16's clamp).  Only a
 // saturated word ever touches memory (atomicMax of its bit pattern 0x7bff into the caller's int): no traffic, no synchronisation.
 __device__ __forceinline__ void x2_note_saturation(int* sat, const f16x8 hi) {

@@ -58,6 +58,10 @@ struct ConvX2MParams {
   float* logits; float* probs; unsigned char* cls;
   long long oN, oC, oD, oH, oW;               // element strides of logits / probs
   float divisor; int accumulate;
+  // 2^d max-pool on the way out (template POOL): besides y / y8 the launch writes the pooled tensor (hi + m8 planes of the half-size grid),
+  // the words of x2m_maxpool_kernel on y / y8 (common.h: x2m_pool_take)
+  void* pool_y;  long long pool_y_ss;         // hi planes, elements per sample
+  void* pool_y8; long long pool_y8_ss;        // m8 planes, bytes per sample
 };
 
 // The head in the epilogue, in two parts.  (1) x2m_head_logits, per fragment: lane (q, l15) holds the 8 channels 8 q .. 8 q + 7 of voxel
@@ -122,8 +126,13 @@ __device__ __forceinline__ void x2m_head_store(const ConvX2MParams& p, const flo
   }
 }
 
-template <bool SMALL, int HEAD = 0>
+// POOL: the 2 x 2 x 2 max-pool of the output rides along.  A consumer wave owns 4 rows of ONE z slice: it pools x (lane pairs, DPP) and y
+// (fragment pairs) in registers and leaves its 2 x 8 winners per 8-channel group in LDS (32 B each: eight 24-bit keys, common.h x2m_pool_keys; 2 KB per wave);
+// the z pair lives in the wave two further on, so the LOADER waves -- idle between their LDS-DMA issue and the step's barrier -- combine the
+// two slices after the next barrier and store the pooled hi / m8 words.  The consumers never wait for it.
+template <bool SMALL, int HEAD = 0, bool POOL = false>
 __global__ __launch_bounds__((XMTile<SMALL>::NCW * 64 + XM_NLT), 1) void conv3_x2m_kernel(ConvX2MParams p) {
+  static_assert(!(POOL && HEAD > 0), "the pooled conv is an encoder conv: no head");
   using TL = XMTile<SMALL>;
   constexpr int NCW = TL::NCW, NLT = XM_NLT, NLW = NLT / 64;
   constexpr int TZ = TL::TZ, TY = TL::TY, TX = TL::TX;
@@ -140,6 +149,7 @@ __global__ __launch_bounds__((XMTile<SMALL>::NCW * 64 + XM_NLT), 1) void conv3_x
   constexpr int A8 = 2 * PLANE8;
   constexpr int W128 = 2 * 3 * 2 * 2 * 1024, W32 = 3 * 2 * 512, W8 = W128 + W32;      // 27 648
   constexpr int OFF_A16 = 0, OFF_W16 = A16, OFF_A8 = OFF_W16 + W16, OFF_W8 = OFF_A8 + A8, OFF_E = OFF_W8 + W8;
+  constexpr int OFF_P = OFF_E + 256;                           // POOL: [wave][row pair 2][x 8][q 4] x 32 B
   static_assert(NI == 4 && NCW * NI == TZ * TY, "a consumer wave owns 4 rows of one z slice");
 
   extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
@@ -252,6 +262,40 @@ __global__ __launch_bounds__((XMTile<SMALL>::NCW * 64 + XM_NLT), 1) void conv3_x
       }
     };
     auto landed = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+    // POOL: thread = (pooled voxel of the tile, 8-channel group q): the z pair of its x-y winners sits in waves w and w + 2.  Two parts:
+    // pool_words reads and decodes while the step's LDS-DMA is in flight; pool_store issues the three stores AFTER the wait for that
+    // DMA -- a store issued before it would sit in the same vmcnt wait and hold the step's barrier until its write came back.
+    [[maybe_unused]] f16x8 pw_hi; [[maybe_unused]] u32x2 pw_lo8, pw_hi8;
+    [[maybe_unused]] f16* pw_dst = nullptr; [[maybe_unused]] unsigned char* pw_dst8 = nullptr; [[maybe_unused]] long long pw_plane = 0;
+    [[maybe_unused]] auto pool_words = [&](int tile) {
+      pw_dst = nullptr;
+      if (lt >= NCW * 32) return;
+      const int q = lt & 3, x8 = (lt >> 2) & 7, py = (lt >> 5) & 3, pz = lt >> 7;
+      const unsigned char* a = smem + OFF_P + (((((4 * pz + (py >> 1)) * 2 + (py & 1)) * 8 + x8) * 4 + q) * 32);
+      const unsigned char* b = a + 2 * (2 * 8 * 4 * 32);
+      const u32x4 a0 = *(const u32x4*)a, a1 = *(const u32x4*)(a + 16), b0 = *(const u32x4*)b, b1 = *(const u32x4*)(b + 16);
+      unsigned kk[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { kk[j] = max(a0[j], b0[j]); kk[4 + j] = max(a1[j], b1[j]); }
+      int n_img, z0, y0, x0;
+      tile_origin(tile, n_img, z0, y0, x0);
+      const int Do = p.D >> 1, Ho = p.H >> 1, Wo = p.W >> 1;
+      const int oz = (z0 >> 1) + pz, oy = (y0 >> 1) + py, ox = (x0 >> 1) + x8;
+      if (oz < Do && oy < Ho && ox < Wo) {
+        const long long onvox = (long long)Do * Ho * Wo, ovo = ((long long)oz * Ho + oy) * Wo + ox;
+        x2m_pool_unkeys(kk, pw_hi, pw_lo8, pw_hi8);
+        pw_dst = (f16*)p.pool_y + (long long)n_img * p.pool_y_ss + ((long long)(cob * 4 + q) * onvox + ovo) * 8;
+        pw_dst8 = (unsigned char*)p.pool_y8 + (long long)n_img * p.pool_y8_ss + x2m_off(cob * 4 + q, ovo, onvox);
+        pw_plane = onvox * 16;
+      }
+    };
+    [[maybe_unused]] auto pool_store = [&]() {
+      if (pw_dst != nullptr) {
+        *(f16x8*)pw_dst = pw_hi;
+        *(u32x2*)pw_dst8 = pw_lo8;
+        *(u32x2*)(pw_dst8 + pw_plane) = pw_hi8;
+      }
+    };
     dma16(0);
     landed();
     lds_barrier();
@@ -260,8 +304,16 @@ __global__ __launch_bounds__((XMTile<SMALL>::NCW * 64 + XM_NLT), 1) void conv3_x
       landed();
       lds_barrier();
       if (k + 1 < npairs) dma16(k + 1);                        // consumers: fp8 step of pair k
+      const bool pool_now = POOL && k > 0 && k % nchunk == 0;  // the tile that ended with pair k - 1 left its x-y winners before this barrier
+      if constexpr (POOL) { if (pool_now) pool_words(k / nchunk - 1); }
       landed();
+      if constexpr (POOL) { if (pool_now) pool_store(); }
       lds_barrier();
+    }
+    if constexpr (POOL) {
+      lds_barrier();                                           // the consumers' last epilogue
+      pool_words(npairs / nchunk - 1);
+      pool_store();
     }
     return;
   }
@@ -402,6 +454,7 @@ __global__ __launch_bounds__((XMTile<SMALL>::NCW * 64 + XM_NLT), 1) void conv3_x
       for (int j = 0; j < 4; ++j) { os_r[j] = w0[j]; os_r[4 + j] = w1[j]; bias_r[j] = b0[j]; bias_r[4 + j] = b1[j]; }
     }
     [[maybe_unused]] float hl[HEAD > 0 ? HEAD : 1];
+    [[maybe_unused]] unsigned pool_k[8];                       // POOL: the keys of the first fragment of a y pair (common.h: x2m_pool_keys)
 #pragma unroll
     for (int n = 0; n < NI; ++n) {
       const int row = row_first + n;
@@ -432,6 +485,25 @@ __global__ __launch_bounds__((XMTile<SMALL>::NCW * 64 + XM_NLT), 1) void conv3_x
           *(u32x2*)(y8 + plane16b) = hi8;
         }
         if (p.sat != nullptr) x2_note_saturation(p.sat, hi);
+      }
+      if constexpr (POOL) {
+        unsigned kk[8];
+        x2m_pool_keys(hi, lo8, kk);
+        if ((n & 1) == 0) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) pool_k[j] = kk[j];
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            kk[j] = max(kk[j], pool_k[j]);                     // rows n - 1, n (y pair)
+            kk[j] = max(kk[j], lane_xor1(kk[j]));              // x pair
+          }
+          if (!(l15 & 1)) {
+            unsigned char* dst = smem + OFF_P + ((((wave * 2 + (n >> 1)) * 8 + (l15 >> 1)) * 4 + q) * 32);
+            *(u32x4*)dst = u32x4{kk[0], kk[1], kk[2], kk[3]};
+            *(u32x4*)(dst + 16) = u32x4{kk[4], kk[5], kk[6], kk[7]};
+          }
+        }
       }
       }
       acc[0][n] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -469,6 +541,7 @@ __global__ __launch_bounds__((XMTile<SMALL>::NCW * 64 + XM_NLT), 1) void conv3_x
     const int tile = k / nchunk;
     if (k - tile * nchunk == nchunk - 1) tile_epilogue(tile);
   }
+  if constexpr (POOL) lds_barrier();                           // the loaders finish the last tile's pool behind this one
 }
 
 
@@ -488,8 +561,12 @@ __host__ __device__ inline int x2m2_w8_offset(int tap, int m, int b, int e, int 
   return (((G * 2 + m) * 2 + e) * 64 + q * 16 + row) * 16 + 8 * o;
 }
 
-template <int HEAD = 0>
+// POOL: the 2 x 2 max-pool of the output rides along -- a consumer wave owns two whole rows of the tile, so the pool is in registers
+// (y: fragment pairs, x: lane pairs by DPP); the winners' keys go to LDS (8 x 16 pooled pixels x 4 channel groups x 32 B) and the LOADER
+// waves decode and store them after the next barrier, as in 3-D (consumers storing the pooled words themselves measured slower).
+template <int HEAD = 0, bool POOL = false>
 __global__ __launch_bounds__(8 * 64 + XM_NLT, 1) void conv2_x2m_kernel(ConvX2MParams p) {
+  static_assert(!(POOL && HEAD > 0), "the pooled conv is an encoder conv: no head");
   constexpr int NCW = 8, NLT = XM_NLT, NLW = NLT / 64;
   constexpr int TY = 16, TX = 32, FX = 2, NI = 4, NR = 2;
   constexpr int PY = TY + 2, PX = TX + 2, NPIX = PY * PX;                     // 612
@@ -497,6 +574,7 @@ __global__ __launch_bounds__(8 * 64 + XM_NLT, 1) void conv2_x2m_kernel(ConvX2MPa
   constexpr int A16 = 4 * PLANE, W16 = 3 * 3 * 2 * 1024;                       // 32 channels = four 8-channel planes; 18 432
   constexpr int A8 = 4 * PLANE, W128 = 4 * 2 * 2 * 1024, W8 = X2M2_W8;          // [lo8 b0 | hi8 b0 | lo8 b1 | hi8 b1]
   constexpr int OFF_A16 = 0, OFF_W16 = A16, OFF_A8 = OFF_W16 + W16, OFF_W8 = OFF_A8 + A8, OFF_E = OFF_W8 + W8;
+  constexpr int OFF_P = OFF_E + 256;                           // POOL: [pooled row 8][pooled x 16][q 4] x 32 B of keys
 
   extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -586,6 +664,44 @@ __global__ __launch_bounds__(8 * 64 + XM_NLT, 1) void conv2_x2m_kernel(ConvX2MPa
       dma_halo((const unsigned char*)p.x8 + (long long)n_img * p.x8_sstride + (long long)chunk * 4 * plane16b, y0, x0, OFF_A8);
     };
     auto landed = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+    // POOL: two (pooled pixel, channel group) items per loader thread.  pool_words reads and decodes the winners' keys while the step's
+    // LDS-DMA is in flight; pool_store issues the stores AFTER the wait for that DMA (a store issued before it would sit in the same
+    // vmcnt wait and hold the step's barrier until its write came back).
+    [[maybe_unused]] f16x8 pw_hi[2]; [[maybe_unused]] u32x2 pw_lo8[2], pw_hi8[2];
+    [[maybe_unused]] f16* pw_dst[2] = {nullptr, nullptr}; [[maybe_unused]] unsigned char* pw_dst8[2] = {nullptr, nullptr};
+    [[maybe_unused]] long long pw_plane = 0;
+    [[maybe_unused]] auto pool_words = [&](int tile) {
+      int n_img, y0, x0;
+      tile_origin(tile, n_img, y0, x0);
+      const int Ho = p.H >> 1, Wo = p.W >> 1;
+      const long long onvox = (long long)Ho * Wo;
+      pw_plane = onvox * 16;
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int item = lt + it * NLT;
+        const int q = item & 3, px = (item >> 2) & 15, py = item >> 6;
+        const unsigned char* a = smem + OFF_P + item * 32;
+        const u32x4 a0 = *(const u32x4*)a, a1 = *(const u32x4*)(a + 16);
+        const unsigned kk[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+        const int oy = (y0 >> 1) + py, ox = (x0 >> 1) + px;
+        pw_dst[it] = nullptr;
+        if (oy < Ho && ox < Wo) {
+          const long long ovo = (long long)oy * Wo + ox;
+          x2m_pool_unkeys(kk, pw_hi[it], pw_lo8[it], pw_hi8[it]);
+          pw_dst[it] = (f16*)p.pool_y + (long long)n_img * p.pool_y_ss + ((long long)(cob * 4 + q) * onvox + ovo) * 8;
+          pw_dst8[it] = (unsigned char*)p.pool_y8 + (long long)n_img * p.pool_y8_ss + x2m_off(cob * 4 + q, ovo, onvox);
+        }
+      }
+    };
+    [[maybe_unused]] auto pool_store = [&]() {
+#pragma unroll
+      for (int it = 0; it < 2; ++it)
+        if (pw_dst[it] != nullptr) {
+          *(f16x8*)pw_dst[it] = pw_hi[it];
+          *(u32x2*)pw_dst8[it] = pw_lo8[it];
+          *(u32x2*)(pw_dst8[it] + pw_plane) = pw_hi8[it];
+        }
+    };
     dma16(0);
     landed();
     lds_barrier();
@@ -594,8 +710,16 @@ __global__ __launch_bounds__(8 * 64 + XM_NLT, 1) void conv2_x2m_kernel(ConvX2MPa
       landed();
       lds_barrier();
       if (k + 1 < npairs) dma16(k + 1);
+      const bool pool_now = POOL && k > 0 && k % nchunk == 0;  // the tile that ended with pair k - 1 left its keys before this barrier
+      if constexpr (POOL) { if (pool_now) pool_words(k / nchunk - 1); }
       landed();
+      if constexpr (POOL) { if (pool_now) pool_store(); }
       lds_barrier();
+    }
+    if constexpr (POOL) {
+      lds_barrier();                                           // the consumers' last epilogue
+      pool_words(npairs / nchunk - 1);
+      pool_store();
     }
     return;
   }
@@ -717,6 +841,7 @@ __global__ __launch_bounds__(8 * 64 + XM_NLT, 1) void conv2_x2m_kernel(ConvX2MPa
       for (int j = 0; j < 4; ++j) { os_r[j] = w0[j]; os_r[4 + j] = w1[j]; bias_r[j] = b0[j]; bias_r[4 + j] = b1[j]; }
     }
     [[maybe_unused]] float hl[HEAD > 0 ? HEAD : 1];
+    [[maybe_unused]] unsigned pool_k[2][8];                    // POOL: the keys of row 0's two fragments (common.h: x2m_pool_keys)
 #pragma unroll
     for (int n = 0; n < NI; ++n) {
       const int gy = y0 + row_first + n / FX, gx = x0 + (n % FX) * 16 + l15;
@@ -746,6 +871,25 @@ __global__ __launch_bounds__(8 * 64 + XM_NLT, 1) void conv2_x2m_kernel(ConvX2MPa
           *(u32x2*)(y8 + plane16b) = hi8;
         }
         if (p.sat != nullptr) x2_note_saturation(p.sat, hi);
+      }
+      if constexpr (POOL) {
+        unsigned kk[8];
+        x2m_pool_keys(hi, lo8, kk);
+        if (n < FX) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) pool_k[n % FX][j] = kk[j];
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            kk[j] = max(kk[j], pool_k[n % FX][j]);             // the wave's two rows (y pair)
+            kk[j] = max(kk[j], lane_xor1(kk[j]));              // x pair
+          }
+          if (!(l15 & 1)) {                                    // pooled pixel (row `wave`, x (n % FX) * 8 + l15 / 2) of the tile
+            unsigned char* dst = smem + OFF_P + (((wave * 16 + (n % FX) * 8 + (l15 >> 1)) * 4 + q) * 32);
+            *(u32x4*)dst = u32x4{kk[0], kk[1], kk[2], kk[3]};
+            *(u32x4*)(dst + 16) = u32x4{kk[4], kk[5], kk[6], kk[7]};
+          }
+        }
       }
       }
       acc[0][n] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -778,13 +922,14 @@ __global__ __launch_bounds__(8 * 64 + XM_NLT, 1) void conv2_x2m_kernel(ConvX2MPa
     const int tile = k / nchunk;
     if (k - tile * nchunk == nchunk - 1) tile_epilogue(tile);
   }
+  if constexpr (POOL) lds_barrier();                           // the loaders store the last tile's pool behind this one
 }
 
-template <int HEAD>
+template <int HEAD, bool POOL = false>
 int launch_x2m_2d(ConvX2MParams p, hipStream_t stream) {
   constexpr int PLANE = ((18 * 34 * 16 + 255) / 256) * 256;
-  const int lds = 8 * PLANE + 18432 + X2M2_W8 + 256 + (HEAD > 0 ? 2048 : 0);
-  IUNET_SET_MAX_LDS(conv2_x2m_kernel<HEAD>, lds);
+  const int lds = 8 * PLANE + 18432 + X2M2_W8 + 256 + (HEAD > 0 ? 2048 : 0) + (POOL ? 8 * 16 * 4 * 32 : 0);
+  IUNET_SET_MAX_LDS((conv2_x2m_kernel<HEAD, POOL>), lds);
   p.tilesZ = 1; p.tilesY = (p.H + 15) / 16; p.tilesX = (p.W + 31) / 32;
   const int ncob = p.Cout / 32;
   iunet_brick_shape(2, ncob, 1, p.tilesY, p.tilesX, &p.bz, &p.by, &p.bx);
@@ -796,24 +941,24 @@ int launch_x2m_2d(ConvX2MParams p, hipStream_t stream) {
   while (groups > 1 && nbricks / 8 < groups) groups >>= 1;
   if (groups < 1) groups = 1;
   const int gx = 8 * p.by * p.bx * groups;
-  hipLaunchKernelGGL(conv2_x2m_kernel<HEAD>, dim3(gx, ncob), dim3(8 * 64 + XM_NLT), lds, stream, p);
+  hipLaunchKernelGGL((conv2_x2m_kernel<HEAD, POOL>), dim3(gx, ncob), dim3(8 * 64 + XM_NLT), lds, stream, p);
   IUNET_CHECK_HIP(hipGetLastError());
   return IUNET_OK;
 }
 
-template <bool SMALL, int HEAD = 0>
+template <bool SMALL, int HEAD = 0, bool POOL = false>
 int launch_x2m(ConvX2MParams p, hipStream_t stream) {
   using TL = XMTile<SMALL>;
   constexpr int PZ = TL::TZ + 2, NPIX = PZ * 10 * 18;
   constexpr int PLANE16 = ((NPIX * 16 + 255) / 256) * 256, PLANE8 = PZ * 192 * 16;
-  const int lds = 2 * PLANE16 + 30720 + 2 * PLANE8 + F8K_WSTEP + 256 + (HEAD > 0 ? 2048 : 0);
-  IUNET_SET_MAX_LDS((conv3_x2m_kernel<SMALL, HEAD>), lds);
+  const int lds = 2 * PLANE16 + 30720 + 2 * PLANE8 + F8K_WSTEP + 256 + (HEAD > 0 ? 2048 : 0) + (POOL ? TL::NCW * 64 * 32 : 0);
+  IUNET_SET_MAX_LDS((conv3_x2m_kernel<SMALL, HEAD, POOL>), lds);
   p.tilesZ = (p.D + TL::TZ - 1) / TL::TZ; p.tilesY = (p.H + TL::TY - 1) / TL::TY; p.tilesX = (p.W + TL::TX - 1) / TL::TX;
   const int ncob = p.Cout / 32;
   iunet_brick_shape(3, ncob, p.tilesZ, p.tilesY, p.tilesX, &p.bz, &p.by, &p.bx);
   p.nbz = (p.tilesZ + p.bz - 1) / p.bz; p.nby = (p.tilesY + p.by - 1) / p.by; p.nbx = (p.tilesX + p.bx - 1) / p.bx;
   const int gx = 8 * p.bz * p.by * p.bx;
-  hipLaunchKernelGGL((conv3_x2m_kernel<SMALL, HEAD>), dim3(gx, ncob), dim3(TL::NCW * 64 + XM_NLT), lds, stream, p);
+  hipLaunchKernelGGL((conv3_x2m_kernel<SMALL, HEAD, POOL>), dim3(gx, ncob), dim3(TL::NCW * 64 + XM_NLT), lds, stream, p);
   IUNET_CHECK_HIP(hipGetLastError());
   return IUNET_OK;
 }
@@ -926,8 +1071,8 @@ __global__ __launch_bounds__(256) void x2m_make8_kernel(const f16* __restrict__ 
   (void)chunks;
 }
 
-// ------------------------------------------------------------------ max-pool 2^d on (hi, m8): the larger hi + lo8 / 16 wins and its hi word
-// and m8 bytes are copied -- the pooled tensor holds exactly the values its source holds for a 3x3x3 consumer.  One thread = one output
+// ------------------------------------------------------------------ max-pool 2^d on (hi, m8): the larger hi + lo8 / 16 wins -- the order
+// of common.h's x2m_pool_keys, shared with the conv epilogue that pools on the way out -- and its hi word and m8 bytes are copied -- the pooled tensor holds exactly the values its source holds for a 3x3x3 consumer.  One thread = one output
 // voxel of one 16-channel chunk: two hi planes (16 B each) and the chunk's two whole m8 granules per input voxel -- every access a full
 // 16-byte item, consecutive threads on consecutive voxels (a thread per 8-channel plane read half granules: 1.8 TB/s at 128^3).
 template <int ND>
@@ -946,11 +1091,9 @@ __global__ __launch_bounds__(256) void x2m_maxpool_kernel(const f16* __restrict_
   const long long ivox = (long long)Di * Hi * Wi;
   const f16* xh = x + n * x_ss + (long long)(2 * c) * ivox * 8;
   const unsigned char* xm = x8 + n * x8_ss + (long long)(2 * c) * ivox * 16;
-  float m[16];
-  f16 oh[16];
-  unsigned char b_lo[16], b_hi[16];
+  unsigned k0[8], k1[8];                                       // the winners so far (common.h: x2m_pool_keys), channels 0..7 / 8..15
 #pragma unroll
-  for (int j = 0; j < 16; ++j) { m[j] = -INFINITY; b_lo[j] = 0; b_hi[j] = 0; oh[j] = (f16)0.f; }
+  for (int j = 0; j < 8; ++j) { k0[j] = 0u; k1[j] = 0u; }
 #pragma unroll
   for (int a = 0; a < (ND == 3 ? 2 : 1); ++a)
 #pragma unroll
@@ -960,29 +1103,21 @@ __global__ __launch_bounds__(256) void x2m_maxpool_kernel(const f16* __restrict_
         const int z = ND == 3 ? oz * 2 + a : 0;
         const long long vi = ((long long)z * Hi + oy * 2 + b) * Wi + ox * 2 + cc;
         const f16x8 v0 = *(const f16x8*)(xh + vi * 8), v1 = *(const f16x8*)(xh + (ivox + vi) * 8);
-        const u32x4 l8 = *(const u32x4*)(xm + vi * 16), h8 = *(const u32x4*)(xm + (ivox + vi) * 16);
+        const u32x4 l8 = *(const u32x4*)(xm + vi * 16);       // (the hi8 granule is a function of the hi words: not read)
+        unsigned c0[8], c1[8];
+        x2m_pool_keys(v0, u32x2{l8[0], l8[1]}, c0);
+        x2m_pool_keys(v1, u32x2{l8[2], l8[3]}, c1);
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          const unsigned wl = l8[j >> 2], wh = h8[j >> 2];
-          const float lo = (j & 3) == 0 ? __builtin_amdgcn_cvt_f32_fp8((int)wl, 0) : (j & 3) == 1 ? __builtin_amdgcn_cvt_f32_fp8((int)wl, 1)
-                         : (j & 3) == 2 ? __builtin_amdgcn_cvt_f32_fp8((int)wl, 2) : __builtin_amdgcn_cvt_f32_fp8((int)wl, 3);
-          const f16 hv = j < 8 ? v0[j & 7] : v1[j & 7];
-          const float v = (float)hv + lo * 0.0625f;
-          if (v > m[j]) { m[j] = v; oh[j] = hv; b_lo[j] = (unsigned char)(wl >> (8 * (j & 3))); b_hi[j] = (unsigned char)(wh >> (8 * (j & 3))); }
-        }
+        for (int j = 0; j < 8; ++j) { k0[j] = max(k0[j], c0[j]); k1[j] = max(k1[j], c1[j]); }
       }
   f16x8 o0, o1;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) { o0[j] = oh[j]; o1[j] = oh[8 + j]; }
+  u32x2 l0, l1, h0, h1;
+  x2m_pool_unkeys(k0, o0, l0, h0);
+  x2m_pool_unkeys(k1, o1, l1, h1);
   f16* yo = y + n * y_ss + ((long long)(2 * c) * ovox + r) * 8;
   *(f16x8*)yo = o0;
   *(f16x8*)(yo + ovox * 8) = o1;
-  u32x4 ol, ohh;
-#pragma unroll
-  for (int d = 0; d < 4; ++d) {
-    ol[d] = b_lo[4 * d] | (b_lo[4 * d + 1] << 8) | (b_lo[4 * d + 2] << 16) | ((unsigned)b_lo[4 * d + 3] << 24);
-    ohh[d] = b_hi[4 * d] | (b_hi[4 * d + 1] << 8) | (b_hi[4 * d + 2] << 16) | ((unsigned)b_hi[4 * d + 3] << 24);
-  }
+  const u32x4 ol = u32x4{l0[0], l0[1], l1[0], l1[1]}, ohh = u32x4{h0[0], h0[1], h1[0], h1[1]};
   unsigned char* y8o = y8 + n * y8_ss + ((long long)(2 * c) * ovox + r) * 16;
   *(u32x4*)y8o = ol;
   *(u32x4*)(y8o + ovox * 16) = ohh;
@@ -1066,17 +1201,21 @@ int iunet_x2m_conv3_fwd(const void* x, long long x_ss, const void* x8, long long
                         int Cin, int Cout, int epi, void* sat, void* stream) {
   return iunet_x2m_conv_fwd(3, x, x_ss, x8, x8_ss, y, y_ss, y_lo, y8, y8_ss, w16, w8, oscale, bias, N, D, H, W, Cin, Cout, epi, sat, stream);
 }
-/* the same for nd = 2 (3 x 3 filters, D == 1; operators from iunet_x2m_prep_nd(2, ..) + iunet_pack_conv3 mode 6) or 3 */
-int iunet_x2m_conv_fwd(int nd, const void* x, long long x_ss, const void* x8, long long x8_ss, void* y, long long y_ss, int y_lo, void* y8,
-                       long long y8_ss, const void* w16, const void* w8, const void* oscale, const void* bias, int N, int D, int H, int W,
-                       int Cin, int Cout, int epi, void* sat, void* stream) {
-  IUNET_REQUIRE(nd == 2 || nd == 3, "x2m_conv3: nd must be 2 or 3");
-  IUNET_REQUIRE(nd == 3 || D == 1, "x2m_conv3: 2-D needs D == 1");
-  IUNET_REQUIRE(x && x8 && y && w16 && w8 && oscale, "x2m_conv3: null pointer");
-  IUNET_REQUIRE_GRID("x2m_conv3", N, D, H, W);
-  IUNET_REQUIRE(Cin >= 32 && Cout >= 32 && Cin % 32 == 0 && Cout % 32 == 0, "x2m_conv3: channels must be positive multiples of 32 (%d -> %d)", Cin, Cout);
-  IUNET_REQUIRE(epi >= 0 && epi <= 2, "x2m_conv3: bad epilogue %d", epi);
-  IUNET_REQUIRE(epi == 0 || bias != nullptr, "x2m_conv3: epilogue %d needs a bias", epi);
+static int x2m_conv_impl(const char* who, int nd, const void* x, long long x_ss, const void* x8, long long x8_ss, void* y, long long y_ss, int y_lo,
+                         void* y8, long long y8_ss, void* py, long long py_ss, void* py8, long long py8_ss, const void* w16, const void* w8,
+                         const void* oscale, const void* bias, int N, int D, int H, int W, int Cin, int Cout, int epi, void* sat, void* stream) {
+  IUNET_REQUIRE(nd == 2 || nd == 3, "%s: nd must be 2 or 3", who);
+  IUNET_REQUIRE(nd == 3 || D == 1, "%s: 2-D needs D == 1", who);
+  IUNET_REQUIRE(x && x8 && y && w16 && w8 && oscale, "%s: null pointer", who);
+  IUNET_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0, "%s: bad shape N %d, %d x %d x %d", who, N, D, H, W);
+  IUNET_REQUIRE(Cin >= 32 && Cout >= 32 && Cin % 32 == 0 && Cout % 32 == 0, "%s: channels must be positive multiples of 32 (%d -> %d)", who, Cin, Cout);
+  IUNET_REQUIRE(epi >= 0 && epi <= 2, "%s: bad epilogue %d", who, epi);
+  IUNET_REQUIRE(epi == 0 || bias != nullptr, "%s: epilogue %d needs a bias", who, epi);
+  const bool pool = py != nullptr;
+  if (pool) {
+    IUNET_REQUIRE(py8 != nullptr, "%s: the pooled tensor needs its m8 planes", who);
+    IUNET_REQUIRE(H % 2 == 0 && W % 2 == 0 && (nd == 2 || D % 2 == 0), "%s: the pooled grid needs even sizes (%d, %d, %d)", who, D, H, W);
+  }
   ConvX2MParams p;
   p.x = x; p.x_sstride = x_ss; p.x8 = x8; p.x8_sstride = x8_ss; p.y = y; p.y_sstride = y_ss; p.y_lo = y_lo; p.y8 = y8; p.y8_sstride = y8_ss;
   p.w16 = w16; p.w8 = w8; p.oscale = (const float*)oscale; p.bias = (const float*)bias;
@@ -1085,11 +1224,43 @@ int iunet_x2m_conv_fwd(int nd, const void* x, long long x_ss, const void* x8, lo
   p.bz = p.by = p.bx = p.nbz = p.nby = p.nbx = 0;
   p.head_w = p.head_b = nullptr; p.inv_act = 0.f; p.logits = p.probs = nullptr; p.cls = nullptr;
   p.oN = p.oC = p.oD = p.oH = p.oW = 0; p.divisor = 1.f; p.accumulate = 0;
-  if (nd == 2) return launch_x2m_2d<0>(p, (hipStream_t)stream);
+  p.pool_y = py; p.pool_y_ss = py_ss; p.pool_y8 = py8; p.pool_y8_ss = py8_ss;
+  hipStream_t s = (hipStream_t)stream;
+  if (nd == 2) return pool ? launch_x2m_2d<0, true>(p, s) : launch_x2m_2d<0>(p, s);
   // the tile size follows the grid as in the 16-bit launch; the summation order of a voxel does not depend on it
   const long long big_tiles = (long long)N * ((D + 3) / 4) * ((H + 7) / 8) * ((W + 15) / 16);
   const bool small = big_tiles * (Cout / 32) < 128;
-  return small ? launch_x2m<true>(p, (hipStream_t)stream) : launch_x2m<false>(p, (hipStream_t)stream);
+  if (pool) return small ? launch_x2m<true, 0, true>(p, s) : launch_x2m<false, 0, true>(p, s);
+  return small ? launch_x2m<true>(p, s) : launch_x2m<false>(p, s);
+}
+
+/* the same for nd = 2 (3 x 3 filters, D == 1; operators from iunet_x2m_prep_nd(2, ..) + iunet_pack_conv3 mode 6) or 3 */
+int iunet_x2m_conv_fwd(int nd, const void* x, long long x_ss, const void* x8, long long x8_ss, void* y, long long y_ss, int y_lo, void* y8,
+                       long long y8_ss, const void* w16, const void* w8, const void* oscale, const void* bias, int N, int D, int H, int W,
+                       int Cin, int Cout, int epi, void* sat, void* stream) {
+  return x2m_conv_impl("x2m_conv3", nd, x, x_ss, x8, x8_ss, y, y_ss, y_lo, y8, y8_ss, nullptr, 0, nullptr, 0, w16, w8, oscale, bias, N, D, H, W,
+                       Cin, Cout, epi, sat, stream);
+}
+
+/* 1 where the callers (net.hip, engine_x2.py) let the pool ride in the conv: in 3-D by default (2 x 128^3, one box: 32->32 @ 128^3 471 us
+ * against 460 + 97 for conv + pool, 64->64 @ 64^3 188 against 183 + 20, 128->128 @ 32^3 88.5 against 86.6 + 5.5); not in 2-D, where the
+ * three layers together gain little (8 x 512^2: 158 against 152 + 39, 69 against 65 + 13, but 64->64 @ 256^2 107-113 against 79 + 22 us:
+ * the pooled instantiation of that launch is 13 us slower with all of its pool work switched off).  IUNET_X2M_POOL=0: never, =2: in 2-D
+ * too (A/B switch). */
+int iunet_x2m_pool_fusable(int nd) {
+  static const int mode = getenv("IUNET_X2M_POOL") ? atoi(getenv("IUNET_X2M_POOL")) : 1;
+  return mode >= 2 ? (nd == 2 || nd == 3) : mode == 1 ? nd == 3 : 0;
+}
+
+/* An encoder stage's second conv (unet.py:63-69: the skip tensor) WITH the stage's 2^d max-pool riding along: y / y8 as iunet_x2m_conv_fwd,
+ * and py / py8 = the pooled tensor (hi planes, py_ss elements per sample; m8 planes, py8_ss bytes per sample) of the grid D/2 (nd = 3), H/2,
+ * W/2 -- the words iunet_x2m_maxpool_fwd makes of y / y8, bit for bit, without reading them back */
+int iunet_x2m_conv_pool_fwd(int nd, const void* x, long long x_ss, const void* x8, long long x8_ss, void* y, long long y_ss, int y_lo, void* y8,
+                            long long y8_ss, void* py, long long py_ss, void* py8, long long py8_ss, const void* w16, const void* w8,
+                            const void* oscale, const void* bias, int N, int D, int H, int W, int Cin, int Cout, int epi, void* sat, void* stream) {
+  IUNET_REQUIRE(py && py8, "x2m_conv_pool: null pooled tensor");
+  return x2m_conv_impl("x2m_conv_pool", nd, x, x_ss, x8, x8_ss, y, y_ss, y_lo, y8, y8_ss, py, py_ss, py8, py8_ss, w16, w8, oscale, bias, N, D, H, W,
+                       Cin, Cout, epi, sat, stream);
 }
 
 /* 1 if iunet_x2m_conv_head_fwd takes this head (2 or 3 classes on 32 feature channels), else 0: the caller then runs the conv into hi + lo
@@ -1125,6 +1296,7 @@ int iunet_x2m_conv_head_fwd(int nd, const void* x, long long x_ss, const void* x
   p.logits = (float*)logits; p.probs = (float*)probs; p.cls = (unsigned char*)cls;
   p.oN = out_strides[0]; p.oC = out_strides[1]; p.oD = out_strides[2]; p.oH = out_strides[3]; p.oW = out_strides[4];
   p.divisor = divisor; p.accumulate = accumulate;
+  p.pool_y = p.pool_y8 = nullptr; p.pool_y_ss = p.pool_y8_ss = 0;
   hipStream_t s = (hipStream_t)stream;
   if (nd == 2) return ncls == 2 ? launch_x2m_2d<2>(p, s) : launch_x2m_2d<3>(p, s);
   // (the tile size follows the grid as in iunet_x2m_conv_fwd: one summation order per voxel either way)

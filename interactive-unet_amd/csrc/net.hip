@@ -39,6 +39,9 @@ int iunet_x2m_convT_fwd(int, const void*, long long, int, void*, long long, int,
 int iunet_x2_conv3_fwd_flag(int, const void*, long long, int, void*, long long, int, const void*, const void*, const void*, int, int, int, int,
                             int, int, int, void*, void*);
 int iunet_x2m_maxpool_fwd(int, const void*, long long, const void*, long long, void*, long long, void*, long long, int, int, int, int, int, void*);
+int iunet_x2m_pool_fusable(int);
+int iunet_x2m_conv_pool_fwd(int, const void*, long long, const void*, long long, void*, long long, int, void*, long long, void*, long long, void*, long long,
+                            const void*, const void*, const void*, const void*, int, int, int, int, int, int, int, void*, void*);
 int iunet_x2m_conv3_fwd(const void*, long long, const void*, long long, void*, long long, int, void*, long long, const void*, const void*,
                         const void*, const void*, int, int, int, int, int, int, int, void*, void*);
 long long iunet_x2m_w8_bytes(int, int);
@@ -348,12 +351,19 @@ int iunet_net_forward(iunet_net* n, const void* x, int in_dtype, const long long
       }
       if (rc) return rc;
       if (l < lv - 1) {
-        rc = convm(c2, L.a[l], (long long)c * v, L.am[l], 2ll * c * v, L.cat[l], 2ll * c * v, -1, L.catm[l], 4ll * c * v, l);
-        if (rc) return rc;
-        int dn, hn, wn;
-        dims3(l + 1, dn, hn, wn);
-        rc = iunet_x2m_maxpool_fwd(dim, WS + L.cat[l], 2ll * c * v, WS + L.catm[l], 4ll * c * v, WS + L.pin[l + 1], (long long)c * vox3(l + 1),
-                                   WS + L.pinm[l + 1], 2ll * c * vox3(l + 1), c, N, dn, hn, wn, stream);
+        if (iunet_x2m_pool_fusable(dim)) {       // the stage's max-pool rides in the epilogue of its second conv (same words, one launch)
+          const float* aux = (const float*)(K + c2.aux);
+          rc = iunet_x2m_conv_pool_fwd(dim, WS + L.a[l], (long long)c * v, WS + L.am[l], 2ll * c * v, WS + L.cat[l], 2ll * c * v, -1, WS + L.catm[l],
+                                       4ll * c * v, WS + L.pin[l + 1], (long long)c * vox3(l + 1), WS + L.pinm[l + 1], 2ll * c * vox3(l + 1),
+                                       K + c2.pk[1], K + c2.pk[0], aux, aux + c2.co, N, d, h, w, c2.ci, c2.co, 2, sat, stream);
+        } else {
+          rc = convm(c2, L.a[l], (long long)c * v, L.am[l], 2ll * c * v, L.cat[l], 2ll * c * v, -1, L.catm[l], 4ll * c * v, l);
+          if (rc) return rc;
+          int dn, hn, wn;
+          dims3(l + 1, dn, hn, wn);
+          rc = iunet_x2m_maxpool_fwd(dim, WS + L.cat[l], 2ll * c * v, WS + L.catm[l], 4ll * c * v, WS + L.pin[l + 1], (long long)c * vox3(l + 1),
+                                     WS + L.pinm[l + 1], 2ll * c * vox3(l + 1), c, N, dn, hn, wn, stream);
+        }
       } else {
         rc = convm(c2, L.a[l], (long long)c * v, L.am[l], 2ll * c * v, L.b[l], 2ll * c * v, c / 8, -1, 0, l);
       }

@@ -284,15 +284,20 @@ class EngineX2:
                 self.act_scale, self.ncls, nv.ptr(logits), nv.ptr(probs), nv.ptr(cls), nv.ll_array(out_strides),
                 float(divisor), int(bool(accumulate)), N, D, H, W, s)
 
-    def _conv3m(self, name, xp, x_ss, x8p, x8_ss, yp, y_ss, y_lo, y8p, y8_ss, N, d, ci, co, s):
-        """3x3x3 stage conv, cross terms on the fp8 matrix cores: (hi planes, m8 planes) -> hi planes (+ lo planes if y_lo >= 0, + m8 planes)."""
+    def _conv3m(self, name, xp, x_ss, x8p, x8_ss, yp, y_ss, y_lo, y8p, y8_ss, N, d, ci, co, s, pool=None):
+        """3x3x3 stage conv, cross terms on the fp8 matrix cores: (hi planes, m8 planes) -> hi planes (+ lo planes if y_lo >= 0, + m8 planes).
+        pool = (hi planes, stride, m8 planes, stride) of the half-size grid: the stage's max-pool rides in the conv's epilogue."""
         w16, osc, b, w8 = self.packed[name]
         probe = self.probe if (self.probe is not None and self.probe['name'] == name) else None
         if probe is not None:
             e0 = torch.cuda.Event(enable_timing=True)
             e0.record()
-        nv.call('iunet_x2m_conv_fwd', self.dim, xp, x_ss, x8p, x8_ss, yp, y_ss, y_lo, y8p, y8_ss, nv.ptr(w16), nv.ptr(w8), nv.ptr(osc), nv.ptr(b),
-                N, d[0], d[1], d[2], ci, co, 2, nv.ptr(self._sat), s)
+        if pool is not None:
+            nv.call('iunet_x2m_conv_pool_fwd', self.dim, xp, x_ss, x8p, x8_ss, yp, y_ss, y_lo, y8p, y8_ss, pool[0], pool[1], pool[2], pool[3],
+                    nv.ptr(w16), nv.ptr(w8), nv.ptr(osc), nv.ptr(b), N, d[0], d[1], d[2], ci, co, 2, nv.ptr(self._sat), s)
+        else:
+            nv.call('iunet_x2m_conv_fwd', self.dim, xp, x_ss, x8p, x8_ss, yp, y_ss, y_lo, y8p, y8_ss, nv.ptr(w16), nv.ptr(w8), nv.ptr(osc), nv.ptr(b),
+                    N, d[0], d[1], d[2], ci, co, 2, nv.ptr(self._sat), s)
         if probe is not None:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
@@ -317,11 +322,14 @@ class EngineX2:
                              P8(ws[f'a{l}m']), 2 * c * v, N, d, cp, c, s)
             if l < L - 1:
                 # skip half of the concat buffer: hi planes [0, c / 8), m8 planes [0, 2 c / 16)
-                self._conv3m(f'enc{l}.conv2', Ph(ws[f'a{l}']), c * v, P8(ws[f'a{l}m']), 2 * c * v, Ph(ws[f'cat{l}']), 2 * c * v, -1,
-                             P8(ws[f'cat{l}m']), 4 * c * v, N, d, c, c, s)
                 do = dims[l + 1]
-                nv.call('iunet_x2m_maxpool_fwd', self.dim, Ph(ws[f'cat{l}']), 2 * c * v, P8(ws[f'cat{l}m']), 4 * c * v,
-                        Ph(ws[f'pin{l + 1}']), c * _vox(do), P8(ws[f'pin{l + 1}m']), 2 * c * _vox(do), c, N, do[0], do[1], do[2], s)
+                fused = bool(nv.lib().iunet_x2m_pool_fusable(self.dim))
+                pool = (Ph(ws[f'pin{l + 1}']), c * _vox(do), P8(ws[f'pin{l + 1}m']), 2 * c * _vox(do))
+                self._conv3m(f'enc{l}.conv2', Ph(ws[f'a{l}']), c * v, P8(ws[f'a{l}m']), 2 * c * v, Ph(ws[f'cat{l}']), 2 * c * v, -1,
+                             P8(ws[f'cat{l}m']), 4 * c * v, N, d, c, c, s, pool=pool if fused else None)
+                if not fused:
+                    nv.call('iunet_x2m_maxpool_fwd', self.dim, Ph(ws[f'cat{l}']), 2 * c * v, P8(ws[f'cat{l}m']), 4 * c * v,
+                            pool[0], pool[1], pool[2], pool[3], c, N, do[0], do[1], do[2], s)
             else:
                 self._conv3m(f'enc{l}.conv2', Ph(ws[f'a{l}']), c * v, P8(ws[f'a{l}m']), 2 * c * v, nv.ptr(ws[f'b{l}']), 2 * c * v, c // 8,
                              None, 0, N, d, c, c, s)

@@ -395,3 +395,57 @@ def test_head_in_the_last_conv_epilogue_is_conv_plus_head_bit_for_bit(dim, shape
     (lg0, pr0, cl0), (lg1, pr1, cl1) = outs
     assert torch.equal(lg0, lg1) and torch.equal(pr0, pr1) and torch.equal(cl0, cl1)
     assert lg0.abs().max() > 0.1 and (pr0 != 0.125 / 3.0).any()
+
+
+@pytest.mark.parametrize('nd,shape,ci,co,N', [(3, (8, 16, 32), 32, 32, 2), (3, (6, 10, 20), 64, 32, 1), (3, (16, 32, 48), 32, 64, 3), (3, (4, 8, 16), 96, 64, 1),
+                                            (2, (1, 32, 64), 32, 32, 2), (2, (1, 24, 40), 64, 64, 1), (2, (1, 70, 132), 32, 32, 3)])
+def test_max_pool_in_the_conv_epilogue_is_conv_plus_pool_bit_for_bit(nd, shape, ci, co, N):
+    """iunet_x2m_conv_pool_fwd: the encoder stages' second conv with the 2^d max-pool riding in its epilogue (2-D: in the consumer waves'
+    registers; 3-D: x, y in registers, the z pair through LDS by the loader waves; big and small tiles, ragged grids, several samples and
+    Cout tiles) writes the conv's own output unchanged and the words iunet_x2m_maxpool_fwd makes of it.  The data hold many exact ties
+    (ReLU zeros, repeated values): the winner is defined by a total order on the words, not by position."""
+    nv = _nv()
+    g = torch.Generator().manual_seed(31)
+    sp = shape[3 - nd:]
+    x = torch.rand((N, ci) + shape, generator=g) * 2
+    w = torch.randn((co, ci) + (3,) * nd, generator=g) * (2.0 / (ci * 3 ** nd)) ** 0.5
+    bn = [0.75 + 0.5 * torch.rand(co, generator=g), 0.1 * torch.randn(co, generator=g) - 0.3, 0.2 * torch.randn(co, generator=g),
+          0.5 + torch.rand(co, generator=g)]
+    w16, w8, osc, bias, _ = _prep(nv, w, bn)
+    v = x * A
+    xh = v.to(torch.float16)
+    vox = int(np.prod(shape))
+    xs = _blocked(xh, 8).cuda()
+    x8 = _m8_planes(_e4m3((v - xh.float()) * 16.0), _e4m3(xh.float() / 256.0)).cuda()
+    po = tuple(s // 2 if i >= 3 - nd else 1 for i, s in enumerate(shape))
+    pvox = int(np.prod(po))
+    sat = torch.zeros(1, dtype=torch.int32, device='cuda')
+
+    def conv(pool):
+        y = torch.zeros(N * co * vox, dtype=torch.float16, device='cuda')
+        y8 = torch.zeros(N * 2 * co * vox, dtype=torch.uint8, device='cuda')
+        py = torch.full((N * co * pvox,), 7.0, dtype=torch.float16, device='cuda')
+        py8 = torch.full((N * 2 * co * pvox,), 9, dtype=torch.uint8, device='cuda')
+        if pool:
+            nv.call('iunet_x2m_conv_pool_fwd', nd, nv.ptr(xs), ci * vox, nv.ptr(x8), 2 * ci * vox, nv.ptr(y), co * vox, -1, nv.ptr(y8), 2 * co * vox,
+                    nv.ptr(py), co * pvox, nv.ptr(py8), 2 * co * pvox, nv.ptr(w16), nv.ptr(w8), nv.ptr(osc), nv.ptr(bias),
+                    N, shape[0], shape[1], shape[2], ci, co, 2, nv.ptr(sat), nv.stream())
+        else:
+            nv.call('iunet_x2m_conv_fwd', nd, nv.ptr(xs), ci * vox, nv.ptr(x8), 2 * ci * vox, nv.ptr(y), co * vox, -1, nv.ptr(y8), 2 * co * vox,
+                    nv.ptr(w16), nv.ptr(w8), nv.ptr(osc), nv.ptr(bias), N, shape[0], shape[1], shape[2], ci, co, 2, nv.ptr(sat), nv.stream())
+            nv.call('iunet_x2m_maxpool_fwd', nd, nv.ptr(y), co * vox, nv.ptr(y8), 2 * co * vox, nv.ptr(py), co * pvox, nv.ptr(py8), 2 * co * pvox,
+                    co, N, po[0], po[1], po[2], nv.stream())
+        torch.cuda.synchronize()
+        return y, y8, py, py8
+
+    a, b = conv(False), conv(True)
+    for name, u, f in zip(('hi', 'm8', 'pooled hi', 'pooled m8'), a, b):
+        assert torch.equal(u, f), f'{name}: {int((u != f).sum())} of {u.numel()} words differ'
+    # and the pooled words are the max-pool of the values a 3x3x3 consumer reads: hi + lo8 / 16
+    lo8, _ = _m8_unpack(a[1].cpu(), N, co, shape)
+    val = a[0].cpu().float().reshape(N, co // 8, *shape, 8).permute(0, 1, 5, 2, 3, 4).reshape(N, co, *shape) + lo8 / 16.0
+    plo8, phi8 = _m8_unpack(b[3].cpu(), N, co, po)
+    ph = b[2].cpu().float().reshape(N, co // 8, *po, 8).permute(0, 1, 5, 2, 3, 4).reshape(N, co, *po)
+    want = F.max_pool3d(val, (1, 2, 2) if nd == 2 else 2)
+    assert torch.equal(ph + plo8 / 16.0, want) and torch.equal(phi8, _e4m3(ph / 256.0))
+    assert (want == 0).float().mean() > 0.02 and sat.item() == 0          # (the ReLU zeros are there: ties were exercised)

@@ -64,6 +64,18 @@ for lvl, ci, co in LAYERS:
     for name, ylo, yy8 in (('hi+lo+m8', co // 8, y8), ('hi+m8', -1, y8), ('hi+lo', co // 8, None)):
         res[name] = timeit(lambda: nv.call('iunet_x2m_conv_fwd', DIM, nv.ptr(xs), 2 * ci * vox, nv.ptr(x8), 2 * ci * vox, nv.ptr(y), 2 * co * vox, ylo,
                                            nv.ptr(yy8), 2 * co * vox, nv.ptr(w16), nv.ptr(w8), nv.ptr(osc), nv.ptr(b), N, *dd, ci, co, 2, None, s))
+    pool_txt = ''
+    if ci == co and lvl < 3:                # an encoder stage's second conv: the stage's max-pool in its epilogue against its own launch
+        pv = vox // 2 ** DIM
+        pd = tuple(max(v // 2, 1) for v in dd)
+        py = torch.empty(N * co * pv, dtype=torch.float16, device=dev)
+        py8 = torch.empty(N * 2 * co * pv, dtype=torch.uint8, device=dev)
+        t_f = timeit(lambda: nv.call('iunet_x2m_conv_pool_fwd', DIM, nv.ptr(xs), 2 * ci * vox, nv.ptr(x8), 2 * ci * vox, nv.ptr(y), 2 * co * vox, -1,
+                                     nv.ptr(y8), 2 * co * vox, nv.ptr(py), co * pv, nv.ptr(py8), 2 * co * pv, nv.ptr(w16), nv.ptr(w8), nv.ptr(osc), nv.ptr(b),
+                                     N, *dd, ci, co, 2, None, s))
+        t_p = timeit(lambda: nv.call('iunet_x2m_maxpool_fwd', DIM, nv.ptr(y), 2 * co * vox, nv.ptr(y8), 2 * co * vox, nv.ptr(py), co * pv, nv.ptr(py8),
+                                     2 * co * pv, co, N, *pd, s))
+        pool_txt = f' | conv+pool in one launch {t_f:8.1f} us against {res["hi+m8"]:.1f} + {t_p:.1f} us'
     fl = 2.0 * TAPS * ci * co * vox * N
     print(f'L{lvl} {ci:3d}->{co:3d} @ {N} x {d}^{DIM}: fp16x2 {t_x2:8.1f} us ({fl / t_x2 / 1e6:6.1f} TF/s alg) | x2m ' +
-          ' '.join(f'{k} {v:8.1f} us' for k, v in res.items()) + f' | x2m/fp16x2 = {res["hi+lo+m8"] / t_x2:.3f} ({fl / res["hi+m8"] / 1e6:6.1f} TF/s alg)', flush=True)
+          ' '.join(f'{k} {v:8.1f} us' for k, v in res.items()) + f' | x2m/fp16x2 = {res["hi+lo+m8"] / t_x2:.3f} ({fl / res["hi+m8"] / 1e6:6.1f} TF/s alg)' + pool_txt, flush=True)
