@@ -301,17 +301,26 @@ int iunet_conv3_wgrad_v2_blocks(int N, int D, int H, int W, int Cin, int Cout);
 int iunet_conv3_wgrad_v2_launch(int dtype, const void* x, long long x_ss, const void* dy, long long dy_ss, float* slab,
                                 int N, int D, int H, int W, int Cin, int Cout, const float* x_scale, const float* x_shift,
                                 hipStream_t stream);
+int iunet_conv2_wgrad_v2_blocks(int N, int H, int W, int Cin, int Cout, int* rows);
+int iunet_conv2_wgrad_v2_launch(int dtype, const void* x, long long x_ss, const void* dy, long long dy_ss, float* slab, int N, int H, int W,
+                                int Cin, int Cout, const float* x_scale, const float* x_shift, hipStream_t stream);
 static bool wgrad_use_v2(int nd) {
-  static const bool off = getenv("IUNET_WGRAD_V1") != nullptr;       // A/B runs: the two-workgroups-per-CU structure
-  return nd == 3 && !off;
+  static const bool off = getenv("IUNET_WGRAD_V1") != nullptr;       // A/B runs: the two-workgroups-per-CU structure (both 2-D and 3-D)
+  static const bool off2 = getenv("IUNET_WGRAD2D_V1") != nullptr;    // ... in 2-D only
+  return !off && !(nd == 2 && off2);
 }
 
 extern "C" {
 
-// number of voxel-walking workgroups per (co, ci) block and the slab size they need
+// number of slab rows (one or two per voxel-walking workgroup) of a (co, ci) block and the slab size they need
 int iunet_conv3_wgrad_blocks(int nd, int N, int D, int H, int W, int Cin, int Cout) {
   if (N < 1 || D < 1 || H < 1 || W < 1 || Cin < 32 || Cout < 32 || (nd != 2 && nd != 3)) return 0;
-  if (wgrad_use_v2(nd)) return iunet_conv3_wgrad_v2_blocks(N, D, H, W, Cin, Cout);
+  if (wgrad_use_v2(nd)) {
+    if (nd == 3) return iunet_conv3_wgrad_v2_blocks(N, D, H, W, Cin, Cout);
+    int rows = 0;
+    iunet_conv2_wgrad_v2_blocks(N, H, W, Cin, Cout, &rows);            // (the 32 x 32 block writes two slab rows per workgroup)
+    return rows;
+  }
   const int TZ = nd == 3 ? 2 : 1, TY = nd == 3 ? 8 : 16, TX = nd == 3 ? 16 : 32;
   const long long ntiles = (long long)N * ((D + TZ - 1) / TZ) * ((H + TY - 1) / TY) * ((W + TX - 1) / TX);
   const int pairs = (Cin / 32) * (Cout / 32);
@@ -342,7 +351,8 @@ static int wgrad_impl(int dtype, int nd, const void* x, long long x_ss, const vo
   p.tilesZ = (D + TZ - 1) / TZ; p.tilesY = (H + TY - 1) / TY; p.tilesX = (W + TX - 1) / TX;
   const int nb = iunet_conv3_wgrad_blocks(nd, N, D, H, W, Cin, Cout);
   int rc;
-  if (wgrad_use_v2(nd)) rc = iunet_conv3_wgrad_v2_launch(dtype, x, x_ss, dy, dy_ss, (float*)slab, N, D, H, W, Cin, Cout, x_scale, x_shift, (hipStream_t)stream);
+  if (wgrad_use_v2(nd) && nd == 2) rc = iunet_conv2_wgrad_v2_launch(dtype, x, x_ss, dy, dy_ss, (float*)slab, N, H, W, Cin, Cout, x_scale, x_shift, (hipStream_t)stream);
+  else if (wgrad_use_v2(nd)) rc = iunet_conv3_wgrad_v2_launch(dtype, x, x_ss, dy, dy_ss, (float*)slab, N, D, H, W, Cin, Cout, x_scale, x_shift, (hipStream_t)stream);
   else if (dtype == 0) rc = nd == 3 ? launch_wgrad<f16, 3>(p, nb, (hipStream_t)stream) : launch_wgrad<f16, 2>(p, nb, (hipStream_t)stream);
   else rc = nd == 3 ? launch_wgrad<bf16, 3>(p, nb, (hipStream_t)stream) : launch_wgrad<bf16, 2>(p, nb, (hipStream_t)stream);
   if (rc != IUNET_OK) return rc;

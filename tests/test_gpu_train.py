@@ -21,6 +21,7 @@ def nv():
 
 
 @pytest.mark.parametrize('nd,shape,cin,cout', [(2, (16, 32), 32, 32), (2, (40, 72), 64, 32), (2, (16, 32), 32, 96),
+                                               (2, (40, 72), 32, 64), (2, (70, 50), 64, 128), (2, (130, 200), 32, 32),      # 2-D dy-reuse form: 64 x 32 blocks on 8-row tiles / 32 x 32 blocks on 16-row tiles (two slab rows), ragged grids, several tiles per workgroup
                                                (3, (2, 8, 16), 32, 32), (3, (6, 12, 20), 64, 64),
                                                (3, (5, 9, 17), 32, 32), (3, (3, 5, 7), 64, 32), (3, (8, 24, 48), 32, 64),      # odd extents: tiles cut on every side; many tiles per workgroup run (z-plane ring, new columns)
                                                (3, (4, 8, 16), 256, 512), (2, (16, 32), 512, 256)])      # >= 128 filter blocks: LDS-transposing slab reduce
