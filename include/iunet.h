@@ -239,6 +239,18 @@ int iunet_x2m_pool_fusable(int nd);
 int iunet_x2m_conv_pool_fwd(int nd, const void* x, long long x_ss, const void* x8, long long x8_ss, void* y, long long y_ss, int y_lo, void* y8,
                             long long y8_ss, void* py, long long py_ss, void* py8, long long py8_ss, const void* w16, const void* w8,
                             const void* oscale, const void* bias, int N, int D, int H, int W, int Cin, int Cout, int epi, void* sat, void* stream);
+/* The FIRST ENCODER STAGE of the 2-D network as one launch (unet.py:63-69: conv 1 -> 32 + BatchNorm + ReLU, conv 32 -> 32 + BatchNorm + ReLU): the
+ * second conv (operators w16 / w8 / oscale / bias of iunet_x2m_conv_fwd) whose loader waves compute the first conv on the way in from the
+ * caller's one-channel image (x, in_dtype, in_strides; fw / f_oscale / f_bias / act_scale: what iunet_x2m_first_conv_fwd takes) -- the
+ * 32-channel tensor between the two convs never exists in HBM.  y / y8 (and, with py != NULL, the pooled py / py8 of
+ * iunet_x2m_conv_pool_fwd) hold iunet_x2m_first_conv_fwd + iunet_x2m_conv_fwd (+ pool) bit for bit.  iunet_x2m_first_stage_fusable: 1 where
+ * the library's own callers use it (2-D, one input channel, 32 channels at level 0, a batch of >= 2 048 tiles of 16 x 32 pixels: the loader
+ * waves' first conv is the longer side of a tile step and the first tile's hides behind nothing; IUNET_X2M_FIRST=0: never, =2: always). */
+int iunet_x2m_first_stage_fusable(int nd, int cin, int c0, int N, int H, int W);
+int iunet_x2m_first_stage_fwd(const void* x, int in_dtype, const long long* in_strides, const void* fw, const void* f_oscale, const void* f_bias,
+                              float act_scale, void* y, long long y_ss, int y_lo, void* y8, long long y8_ss, void* py, long long py_ss, void* py8,
+                              long long py8_ss, const void* w16, const void* w8, const void* oscale, const void* bias, int N, int H, int W,
+                              void* sat, void* stream);
 /* the LAST stage conv of the network with the 1x1 head + softmax + class map (unet.py:63-69, predict.py:38) in its epilogue: its 32 output
  * channels are never written; logits / probs / cls are iunet_x2m_conv_fwd + iunet_x2_head_fwd bit for bit (the head's fmaf chain is walked
  * through the lane groups in channel order).  iunet_x2m_head_fusable: 1 for the heads it takes (2 or 3 classes on 32 channels). */

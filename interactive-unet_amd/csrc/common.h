@@ -231,6 +231,15 @@ __device__ __forceinline__ void x2m_split8(const float (&r)[8], f16x8& hi, f16x8
   lo8 = x2m_pack8(l4);
   hi8 = x2m_pack8(h8);
 }
+// one element of the caller's input tensor (generic strides): 0 f32, 1 f16, 2 u8 (/ 255: predict.py:30, correctly rounded as torch's), 3 bf16
+__device__ __forceinline__ float x2_load_in(const void* p, long long off, int dt) {
+  switch (dt) {
+    case 0: return ((const float*)p)[off];
+    case 1: return (float)((const f16*)p)[off];
+    case 2: return __fdiv_rn((float)((const unsigned char*)p)[off], 255.0f);
+    default: return (float)((const bf16*)p)[off];
+  }
+}
 // ---- 2^d max-pool on the split words of the x2m form.  A candidate is the pair (hi word, lo8 byte) of one channel; the value a 3x3x3
 // consumer reads is hi + lo8 / 16.  |lo8 / 16| never exceeds half an ulp of hi (x2m_split8: lo is the fp16 rounding residual, and e4m3
 // rounding cannot carry it past the power of two that bounds it), so the order of the VALUES is the lexicographic order of (hi, lo8) --

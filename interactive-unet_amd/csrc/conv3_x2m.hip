@@ -62,6 +62,11 @@ struct ConvX2MParams {
   // the words of x2m_maxpool_kernel on y / y8 (common.h: x2m_pool_take)
   void* pool_y;  long long pool_y_ss;         // hi planes, elements per sample
   void* pool_y8; long long pool_y8_ss;        // m8 planes, bytes per sample
+  // the network's FIRST conv computed on the way in (2-D, template FIRST): x / x8 are not read -- the loader waves make the 32-channel halo
+  // tile from the caller's one-channel image with the first conv's own operator (split16.hip: x2_first_conv_kernel's arithmetic and words)
+  const void* f_x; long long f_sN, f_sH, f_sW; int f_dtype;      // the caller's tensor (generic element strides; dtype code of x2_load_in)
+  const void* f_w; const float* f_oscale; const float* f_bias;   // pack_first_conv order of [32][3][9], accumulator scale, folded bias
+  float f_act;
 };
 
 // The head in the epilogue, in two parts.  (1) x2m_head_logits, per fragment: lane (q, l15) holds the 8 channels 8 q .. 8 q + 7 of voxel
@@ -564,9 +569,16 @@ __host__ __device__ inline int x2m2_w8_offset(int tap, int m, int b, int e, int 
 // POOL: the 2 x 2 max-pool of the output rides along -- a consumer wave owns two whole rows of the tile, so the pool is in registers
 // (y: fragment pairs, x: lane pairs by DPP); the winners' keys go to LDS (8 x 16 pooled pixels x 4 channel groups x 32 B) and the LOADER
 // waves decode and store them after the next barrier, as in 3-D (consumers storing the pooled words themselves measured slower).
-template <int HEAD = 0, bool POOL = false>
+// FIRST: the launch is the SECOND conv of the first encoder stage and computes the first conv (one input channel -> 32, BatchNorm folded,
+// ReLU) itself: its 32-channel input tensor never exists in HBM.  Each loader wave owns a band of the 18 halo rows: it stages the band's
+// raw pixels (+ 1 ring) as split words [lo | hi | hi] in a private LDS patch, gathers the im2col operand per lane and runs
+// x2_first_conv_kernel's two MFMAs per 16 halo pixels (K = 27 of 32), scales, splits (x2m_split8: the words that kernel would have
+// stored) and writes the hi words into the 16-bit halo image during the consumers' fp8 step; the e4m3 words wait in registers for the
+// barrier that frees the fp8 halo image.  Halo pixels outside the image are the second conv's zero padding, not conv values.
+template <int HEAD = 0, bool POOL = false, bool FIRST = false>
 __global__ __launch_bounds__(8 * 64 + XM_NLT, 1) void conv2_x2m_kernel(ConvX2MParams p) {
   static_assert(!(POOL && HEAD > 0), "the pooled conv is an encoder conv: no head");
+  static_assert(!(FIRST && HEAD > 0), "the first stage's second conv has no head");
   constexpr int NCW = 8, NLT = XM_NLT, NLW = NLT / 64;
   constexpr int TY = 16, TX = 32, FX = 2, NI = 4, NR = 2;
   constexpr int PY = TY + 2, PX = TX + 2, NPIX = PY * PX;                     // 612
@@ -575,6 +587,8 @@ __global__ __launch_bounds__(8 * 64 + XM_NLT, 1) void conv2_x2m_kernel(ConvX2MPa
   constexpr int A8 = 4 * PLANE, W128 = 4 * 2 * 2 * 1024, W8 = X2M2_W8;          // [lo8 b0 | hi8 b0 | lo8 b1 | hi8 b1]
   constexpr int OFF_A16 = 0, OFF_W16 = A16, OFF_A8 = OFF_W16 + W16, OFF_W8 = OFF_A8 + A8, OFF_E = OFF_W8 + W8;
   constexpr int OFF_P = OFF_E + 256;                           // POOL: [pooled row 8][pooled x 16][q 4] x 32 B of keys
+  constexpr int FPX = PX + 2, FPIX = 7 * FPX, FPATCH = 3 * FPIX * 2;      // FIRST: a wave's patch: 7 rows x 36 pixels x [lo | hi | hi] f16 (1 512 B)
+  constexpr int OFF_F = OFF_P + (POOL ? 8 * 16 * 4 * 32 : 0);
 
   extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -702,6 +716,115 @@ __global__ __launch_bounds__(8 * 64 + XM_NLT, 1) void conv2_x2m_kernel(ConvX2MPa
           *(u32x2*)(pw_dst8[it] + pw_plane) = pw_hi8[it];
         }
     };
+    if constexpr (FIRST) {
+      // ---- the first conv on the way in (nchunk == 1: a pair is a tile; the operators of the one chunk stay resident)
+      const int ll = lt & 63, l15 = ll & 15, q = ll >> 4;
+      const int hr0 = lw == 0 ? 0 : lw == 1 ? 5 : lw == 2 ? 10 : 14, nrow = lw < 2 ? 5 : 4;      // this wave's halo rows [hr0, hr0 + nrow)
+      const int npx = nrow * PX, nfr = (npx + 15) / 16;                   // 170 / 136 pixels: 11 / 9 fragments
+      constexpr int MAXF = 11;
+      f16* xs = (f16*)(smem + OFF_F + lw * FPATCH);
+      const f16x8 wa0 = ((const f16x8*)p.f_w)[ll], wa1 = ((const f16x8*)p.f_w)[64 + ll];
+      float fos[8], fbi[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { fos[j] = p.f_oscale[8 * q + j]; fbi[j] = p.f_bias[8 * q + j]; }
+      int koff[8];                                                       // k = 8 q + j = tap * 3 + part (pack_first_conv_kernel); k >= 27: zero weight
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = 8 * q + j, kc = k < 27 ? k : 0, tap = kc / 3, part = kc % 3;
+        koff[j] = part * FPIX + (tap / 3) * FPX + (tap % 3);
+      }
+      float raw[4];
+      auto patch_load = [&](int tile) {                                  // raw pixels of the band's patch: image rows y0 + hr0 - 2 .., columns x0 - 2 ..
+        int n_img, y0, x0;
+        tile_origin(tile, n_img, y0, x0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int idx = ll + 64 * i, pr = idx / FPX, pc = idx - pr * FPX;
+          const int gy = y0 + hr0 - 2 + pr, gx = x0 - 2 + pc;
+          raw[i] = 0.f;
+          if (idx < (nrow + 2) * FPX && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W)
+            raw[i] = x2_load_in(p.f_x, n_img * p.f_sN + gy * p.f_sH + gx * p.f_sW, p.f_dtype);
+        }
+      };
+      auto patch_commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int idx = ll + 64 * i;
+          if (idx < (nrow + 2) * FPX) {
+            f16 hi, lo;
+            split16<f16>(raw[i] * p.f_act, hi, lo);
+            xs[idx] = lo; xs[FPIX + idx] = hi; xs[2 * FPIX + idx] = hi;
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // (the patch is this wave's own: no barrier)
+      };
+      u32x2 m_lo[MAXF], m_hi[MAXF];
+      auto first_conv = [&](int tile) {                                  // hi words -> the 16-bit halo image; e4m3 words -> m_lo / m_hi
+        int n_img, y0, x0;
+        tile_origin(tile, n_img, y0, x0);
+#pragma unroll
+        for (int f = 0; f < MAXF; ++f) {
+          if (f < nfr) {
+            const int lp = min(16 * f + l15, npx - 1);                   // the band's pixel of this lane (the last fragment is partial)
+            const int pr = lp / PX, pc = lp - pr * PX;
+            const int base = pr * FPX + pc;
+            f16x8 b;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) b[j] = xs[base + koff[j]];
+            const f32x4 a0 = mfma16<f16>(wa0, b, f32x4{0.f, 0.f, 0.f, 0.f}), a1 = mfma16<f16>(wa1, b, f32x4{0.f, 0.f, 0.f, 0.f});
+            float rr[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) rr[j] = fmaxf(fmaf(j < 4 ? a0[j & 3] : a1[j & 3], fos[j], fbi[j]), 0.f);
+            f16x8 hi, lo;
+            u32x2 l8, h8;
+            x2m_split8(rr, hi, lo, l8, h8);
+            const int gy = y0 + hr0 + pr - 1, gx = x0 + pc - 1;
+            const bool in = (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+            if (!in) { hi = f16x8{0, 0, 0, 0, 0, 0, 0, 0}; l8 = u32x2{0u, 0u}; h8 = u32x2{0u, 0u}; }      // the second conv's zero padding
+            else if (p.sat != nullptr) x2_note_saturation(p.sat, hi);
+            m_lo[f] = l8; m_hi[f] = h8;
+            if (16 * f + l15 < npx) *(f16x8*)(smem + OFF_A16 + q * PLANE + (hr0 * PX + lp) * 16) = hi;
+          }
+        }
+      };
+      auto m8_commit = [&]() {
+#pragma unroll
+        for (int f = 0; f < MAXF; ++f) {
+          if (f < nfr && 16 * f + l15 < npx) {
+            unsigned char* d = smem + OFF_A8 + (2 * (q >> 1)) * PLANE + (hr0 * PX + 16 * f + l15) * 16 + (q & 1) * 8;
+            *(u32x2*)d = m_lo[f];
+            *(u32x2*)(d + PLANE) = m_hi[f];
+          }
+        }
+      };
+      // (A/B, 8 x 512^2: the fragments kept apart by scheduling barriers 197 us, left to the compiler 179 us, spread over both step windows
+      // with the first five fragments' hi words held back 201 us -- 400 B of scratch per lane; the two launches 54 + 140-147 us)
+      patch_load(0);
+      patch_commit();
+      first_conv(0);
+      dma_weights((const unsigned char*)p.w16 + (long long)cob * W16, OFF_W16, W16);
+      dma_weights((const unsigned char*)p.w8 + (long long)cob * W8, OFF_W8, W8);
+      landed();
+      lds_barrier();
+      for (int k = 0; k < npairs; ++k) {
+        m8_commit();                                                     // consumers: 16-bit step of tile k
+        if (k + 1 < npairs) patch_load(k + 1);
+        landed();
+        lds_barrier();
+        const bool pool_now = POOL && k > 0;
+        if (k + 1 < npairs) { patch_commit(); first_conv(k + 1); }       // consumers: fp8 step of tile k
+        if constexpr (POOL) { if (pool_now) pool_words(k - 1); }
+        landed();
+        if constexpr (POOL) { if (pool_now) pool_store(); }
+        lds_barrier();
+      }
+      if constexpr (POOL) {
+        lds_barrier();
+        pool_words(npairs - 1);
+        pool_store();
+      }
+      return;
+    }
     dma16(0);
     landed();
     lds_barrier();
@@ -925,11 +1048,11 @@ __global__ __launch_bounds__(8 * 64 + XM_NLT, 1) void conv2_x2m_kernel(ConvX2MPa
   if constexpr (POOL) lds_barrier();                           // the loaders store the last tile's pool behind this one
 }
 
-template <int HEAD, bool POOL = false>
+template <int HEAD, bool POOL = false, bool FIRST = false>
 int launch_x2m_2d(ConvX2MParams p, hipStream_t stream) {
   constexpr int PLANE = ((18 * 34 * 16 + 255) / 256) * 256;
-  const int lds = 8 * PLANE + 18432 + X2M2_W8 + 256 + (HEAD > 0 ? 2048 : 0) + (POOL ? 8 * 16 * 4 * 32 : 0);
-  IUNET_SET_MAX_LDS((conv2_x2m_kernel<HEAD, POOL>), lds);
+  const int lds = 8 * PLANE + 18432 + X2M2_W8 + 256 + (HEAD > 0 ? 2048 : 0) + (POOL ? 8 * 16 * 4 * 32 : 0) + (FIRST ? 4 * 3 * 7 * 36 * 2 : 0);
+  IUNET_SET_MAX_LDS((conv2_x2m_kernel<HEAD, POOL, FIRST>), lds);
   p.tilesZ = 1; p.tilesY = (p.H + 15) / 16; p.tilesX = (p.W + 31) / 32;
   const int ncob = p.Cout / 32;
   iunet_brick_shape(2, ncob, 1, p.tilesY, p.tilesX, &p.bz, &p.by, &p.bx);
@@ -941,7 +1064,7 @@ int launch_x2m_2d(ConvX2MParams p, hipStream_t stream) {
   while (groups > 1 && nbricks / 8 < groups) groups >>= 1;
   if (groups < 1) groups = 1;
   const int gx = 8 * p.by * p.bx * groups;
-  hipLaunchKernelGGL((conv2_x2m_kernel<HEAD, POOL>), dim3(gx, ncob), dim3(8 * 64 + XM_NLT), lds, stream, p);
+  hipLaunchKernelGGL((conv2_x2m_kernel<HEAD, POOL, FIRST>), dim3(gx, ncob), dim3(8 * 64 + XM_NLT), lds, stream, p);
   IUNET_CHECK_HIP(hipGetLastError());
   return IUNET_OK;
 }
@@ -1225,6 +1348,7 @@ static int x2m_conv_impl(const char* who, int nd, const void* x, long long x_ss,
   p.head_w = p.head_b = nullptr; p.inv_act = 0.f; p.logits = p.probs = nullptr; p.cls = nullptr;
   p.oN = p.oC = p.oD = p.oH = p.oW = 0; p.divisor = 1.f; p.accumulate = 0;
   p.pool_y = py; p.pool_y_ss = py_ss; p.pool_y8 = py8; p.pool_y8_ss = py8_ss;
+  p.f_x = p.f_w = nullptr; p.f_oscale = p.f_bias = nullptr; p.f_sN = p.f_sH = p.f_sW = 0; p.f_dtype = 0; p.f_act = 0.f;
   hipStream_t s = (hipStream_t)stream;
   if (nd == 2) return pool ? launch_x2m_2d<0, true>(p, s) : launch_x2m_2d<0>(p, s);
   // the tile size follows the grid as in the 16-bit launch; the summation order of a voxel does not depend on it
@@ -1263,6 +1387,48 @@ int iunet_x2m_conv_pool_fwd(int nd, const void* x, long long x_ss, const void* x
                        Cin, Cout, epi, sat, stream);
 }
 
+/* 1 where the callers (net.hip, engine_x2.py) run the first encoder stage as ONE launch: 2-D, one input channel, 32 channels at level 0, and a
+ * batch of at least 2 048 tiles of 16 x 32 pixels (8 per CU).  The loader waves' first conv is the longer side of every tile step (11 us per
+ * tile against 8.7 for the second conv alone), and the first tile's has nothing to hide behind: 8 x 512^2 (16 tiles per CU) 179 us against
+ * 54 + 140 for the two launches, 48 x 128^2 (6 per CU) 71 against 24 + 41-43.  IUNET_X2M_FIRST=0: never, =2: whatever the batch (A/B switch) */
+int iunet_x2m_first_stage_fusable(int nd, int cin, int c0, int N, int H, int W) {
+  static const int mode = getenv("IUNET_X2M_FIRST") ? atoi(getenv("IUNET_X2M_FIRST")) : 1;
+  if (mode == 0 || nd != 2 || cin != 1 || c0 != 32 || N < 1 || H < 1 || W < 1) return 0;
+  return mode >= 2 || (long long)N * ((H + 15) / 16) * ((W + 31) / 32) >= 2048;
+}
+
+/* The FIRST ENCODER STAGE of the 2-D network as one launch (unet.py:63-69: conv 1 -> 32 + BatchNorm + ReLU, conv 32 -> 32 + BatchNorm + ReLU):
+ * the second conv (iunet_x2m_conv_fwd's operators w16 / w8 / oscale / bias, epilogue 2) whose loader waves compute the first conv on the way
+ * in, from the caller's one-channel image (x, in_dtype / in_strides as iunet_x2m_first_conv_fwd) with that conv's own operator (fw / f_oscale
+ * / f_bias / act_scale: what iunet_x2m_first_conv_fwd takes) -- the 32-channel tensor between the two convs is never written.  y / y8 (and,
+ * with py != NULL, the 2 x 2 max-pool py / py8 as iunet_x2m_conv_pool_fwd) hold iunet_x2m_first_conv_fwd + iunet_x2m_conv_fwd (+ pool) bit
+ * for bit. */
+int iunet_x2m_first_stage_fwd(const void* x, int in_dtype, const long long* in_strides, const void* fw, const void* f_oscale, const void* f_bias,
+                              float act_scale, void* y, long long y_ss, int y_lo, void* y8, long long y8_ss, void* py, long long py_ss, void* py8,
+                              long long py8_ss, const void* w16, const void* w8, const void* oscale, const void* bias, int N, int H, int W,
+                              void* sat, void* stream) {
+  IUNET_REQUIRE(x && in_strides && fw && f_oscale && f_bias && y && w16 && w8 && oscale && bias, "x2m_first_stage: null pointer");
+  IUNET_REQUIRE(in_dtype >= 0 && in_dtype <= 3, "x2m_first_stage: bad input dtype %d", in_dtype);
+  IUNET_REQUIRE(N > 0 && H > 0 && W > 0, "x2m_first_stage: bad shape N %d, %d x %d", N, H, W);
+  IUNET_REQUIRE((py == nullptr) == (py8 == nullptr), "x2m_first_stage: the pooled tensor is hi planes AND m8 planes");
+  IUNET_REQUIRE(py == nullptr || (H % 2 == 0 && W % 2 == 0), "x2m_first_stage: the pooled grid needs even sizes (%d, %d)", H, W);
+  int e1;
+  IUNET_REQUIRE(act_scale > 0.f && frexpf(act_scale, &e1) == 0.5f, "x2m_first_stage: the activation scale must be a power of two (got %g)", act_scale);
+  ConvX2MParams p;
+  p.x = nullptr; p.x_sstride = 0; p.x8 = nullptr; p.x8_sstride = 0; p.y = y; p.y_sstride = y_ss; p.y_lo = y_lo; p.y8 = y8; p.y8_sstride = y8_ss;
+  p.w16 = w16; p.w8 = w8; p.oscale = (const float*)oscale; p.bias = (const float*)bias;
+  p.N = N; p.D = 1; p.H = H; p.W = W; p.Cin = 32; p.Cout = 32; p.epi = 2; p.sat = (int*)sat;
+  p.tilesZ = p.tilesY = p.tilesX = 0;
+  p.bz = p.by = p.bx = p.nbz = p.nby = p.nbx = 0;
+  p.head_w = p.head_b = nullptr; p.inv_act = 0.f; p.logits = p.probs = nullptr; p.cls = nullptr;
+  p.oN = p.oC = p.oD = p.oH = p.oW = 0; p.divisor = 1.f; p.accumulate = 0;
+  p.pool_y = py; p.pool_y_ss = py_ss; p.pool_y8 = py8; p.pool_y8_ss = py8_ss;
+  p.f_x = x; p.f_sN = in_strides[0]; p.f_sH = in_strides[3]; p.f_sW = in_strides[4]; p.f_dtype = in_dtype;
+  p.f_w = fw; p.f_oscale = (const float*)f_oscale; p.f_bias = (const float*)f_bias; p.f_act = act_scale;
+  hipStream_t s = (hipStream_t)stream;
+  return py != nullptr ? launch_x2m_2d<0, true, true>(p, s) : launch_x2m_2d<0, false, true>(p, s);
+}
+
 /* 1 if iunet_x2m_conv_head_fwd takes this head (2 or 3 classes on 32 feature channels), else 0: the caller then runs the conv into hi + lo
  * planes and iunet_x2_head_fwd on them */
 int iunet_x2m_head_fusable(int ncls, int C0) {
@@ -1297,6 +1463,7 @@ int iunet_x2m_conv_head_fwd(int nd, const void* x, long long x_ss, const void* x
   p.oN = out_strides[0]; p.oC = out_strides[1]; p.oD = out_strides[2]; p.oH = out_strides[3]; p.oW = out_strides[4];
   p.divisor = divisor; p.accumulate = accumulate;
   p.pool_y = p.pool_y8 = nullptr; p.pool_y_ss = p.pool_y8_ss = 0;
+  p.f_x = p.f_w = nullptr; p.f_oscale = p.f_bias = nullptr; p.f_sN = p.f_sH = p.f_sW = 0; p.f_dtype = 0; p.f_act = 0.f;
   hipStream_t s = (hipStream_t)stream;
   if (nd == 2) return ncls == 2 ? launch_x2m_2d<2>(p, s) : launch_x2m_2d<3>(p, s);
   // (the tile size follows the grid as in iunet_x2m_conv_fwd: one summation order per voxel either way)

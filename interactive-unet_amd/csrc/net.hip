@@ -40,6 +40,9 @@ int iunet_x2_conv3_fwd_flag(int, const void*, long long, int, void*, long long, 
                             int, int, int, void*, void*);
 int iunet_x2m_maxpool_fwd(int, const void*, long long, const void*, long long, void*, long long, void*, long long, int, int, int, int, int, void*);
 int iunet_x2m_pool_fusable(int);
+int iunet_x2m_first_stage_fusable(int, int, int, int, int, int);
+int iunet_x2m_first_stage_fwd(const void*, int, const long long*, const void*, const void*, const void*, float, void*, long long, int, void*, long long, void*,
+                              long long, void*, long long, const void*, const void*, const void*, const void*, int, int, int, void*, void*);
 int iunet_x2m_conv_pool_fwd(int, const void*, long long, const void*, long long, void*, long long, int, void*, long long, void*, long long, void*, long long,
                             const void*, const void*, const void*, const void*, int, int, int, int, int, int, int, void*, void*);
 int iunet_x2m_conv3_fwd(const void*, long long, const void*, long long, void*, long long, int, void*, long long, const void*, const void*,
@@ -341,6 +344,24 @@ int iunet_net_forward(iunet_net* n, const void* x, int in_dtype, const long long
       const int c = n->ch[l];
       const ConvOp& c1 = n->conv[2 * stage_index(n, false, l)];
       const ConvOp& c2 = n->conv[2 * stage_index(n, false, l) + 1];
+      if (l == 0 && lv > 1 && iunet_x2m_first_stage_fusable(dim, n->cin, c, N, h, w)) {
+        // 2-D, one input channel: the first encoder stage is ONE launch (the first conv is computed by the second conv's loader waves)
+        const float* aux1 = (const float*)(K + c1.aux);
+        const float* aux2 = (const float*)(K + c2.aux);
+        const bool pooled = iunet_x2m_pool_fusable(dim) != 0;
+        rc = iunet_x2m_first_stage_fwd(x, in_dtype, in_strides, K + c1.pk[1], aux1, aux1 + c, A, WS + L.cat[0], 2ll * c * v, -1, WS + L.catm[0], 4ll * c * v,
+                                       pooled ? WS + L.pin[1] : nullptr, (long long)c * vox3(1), pooled ? WS + L.pinm[1] : nullptr, 2ll * c * vox3(1),
+                                       K + c2.pk[1], K + c2.pk[0], aux2, aux2 + c2.co, N, h, w, sat, stream);
+        if (rc) return rc;
+        if (!pooled) {
+          int dn, hn, wn;
+          dims3(1, dn, hn, wn);
+          rc = iunet_x2m_maxpool_fwd(dim, WS + L.cat[0], 2ll * c * v, WS + L.catm[0], 4ll * c * v, WS + L.pin[1], (long long)c * vox3(1), WS + L.pinm[1],
+                                     2ll * c * vox3(1), c, N, dn, hn, wn, stream);
+          if (rc) return rc;
+        }
+        continue;
+      }
       if (l == 0) {
         const float* aux = (const float*)(K + c1.aux);
         rc = iunet_x2m_first_conv_fwd(dim, x, in_dtype, in_strides, WS + L.a[0], (long long)c * v, -1, WS + L.am[0], 2ll * c * v, K + c1.pk[1], aux,

@@ -112,15 +112,6 @@ struct X2FirstParams {
   int N, D, H, W, Cout, relu;
 };
 
-__device__ __forceinline__ float x2_load_in(const void* p, long long off, int dt) {
-  switch (dt) {
-    case 0: return ((const float*)p)[off];
-    case 1: return (float)((const f16*)p)[off];
-    case 2: return __fdiv_rn((float)((const unsigned char*)p)[off], 255.0f);      // predict.py:30, correctly rounded as torch's
-    default: return (float)((const bf16*)p)[off];
-  }
-}
-
 // The structure of pointwise.hip's first_conv_kernel (K = taps x channels padded to 32, im2col operand gathered per lane from an
 // LDS image of the halo tile) over the 3 CIN virtual channels [lo | hi | hi] of act_scale * x (operator rows [w_hi | w_hi | w_lo]).
 template <int ND, int CIN>

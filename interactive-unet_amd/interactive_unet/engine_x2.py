@@ -308,9 +308,24 @@ class EngineX2:
         dims, L, ch = ws['dims'], self.levels, self.ch
         P8 = lambda t, planes16=0, v=0: ctypes.c_void_p(t.data_ptr() + planes16 * v * 16)     # m8 view starting `planes16` 16-byte planes in
         Ph = lambda t, planes=0, v=0: ctypes.c_void_p(t.data_ptr() + planes * v * 16)         # hi view starting `planes` 8-channel planes in
+        # 2-D, one input channel: the first encoder stage is ONE launch (the first conv is computed by the second conv's loader waves)
+        stage0 = L > 1 and bool(nv.lib().iunet_x2m_first_stage_fusable(self.dim, self.cin, ch[0], N, H, W)) and self.probe is None
         for l in range(L):
             d, v = dims[l], _vox(dims[l])
             c = ch[l]
+            if l == 0 and stage0:
+                fw, fosc, fb = self.packed['enc0.conv1']
+                w16, osc, b, w8 = self.packed['enc0.conv2']
+                do = dims[1]
+                pooled = bool(nv.lib().iunet_x2m_pool_fusable(self.dim))
+                pool = (Ph(ws['pin1']), c * _vox(do), P8(ws['pin1m']), 2 * c * _vox(do))
+                nv.call('iunet_x2m_first_stage_fwd', nv.ptr(x), nv.IN_DTYPE_CODE[x.dtype], nv.ll_array(x_strides), nv.ptr(fw), nv.ptr(fosc), nv.ptr(fb),
+                        self.act_scale, Ph(ws['cat0']), 2 * c * v, -1, P8(ws['cat0m']), 4 * c * v, *(pool if pooled else (None, 0, None, 0)),
+                        nv.ptr(w16), nv.ptr(w8), nv.ptr(osc), nv.ptr(b), N, d[1], d[2], nv.ptr(self._sat), s)
+                if not pooled:
+                    nv.call('iunet_x2m_maxpool_fwd', self.dim, Ph(ws['cat0']), 2 * c * v, P8(ws['cat0m']), 4 * c * v,
+                            pool[0], pool[1], pool[2], pool[3], c, N, do[0], do[1], do[2], s)
+                continue
             if l == 0:
                 w, osc, b = self.packed['enc0.conv1']
                 nv.call('iunet_x2m_first_conv_fwd', self.dim, nv.ptr(x), nv.IN_DTYPE_CODE[x.dtype], nv.ll_array(x_strides),

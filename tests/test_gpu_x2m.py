@@ -449,3 +449,89 @@ def test_max_pool_in_the_conv_epilogue_is_conv_plus_pool_bit_for_bit(nd, shape, 
     want = F.max_pool3d(val, (1, 2, 2) if nd == 2 else 2)
     assert torch.equal(ph + plo8 / 16.0, want) and torch.equal(phi8, _e4m3(ph / 256.0))
     assert (want == 0).float().mean() > 0.02 and sat.item() == 0          # (the ReLU zeros are there: ties were exercised)
+
+
+@pytest.mark.parametrize('shape,N,in_dtype,pool', [((64, 96), 2, torch.uint8, True), ((70, 132), 3, torch.float32, True), ((18, 34), 1, torch.float16, False),
+                                                   ((256, 256), 2, torch.uint8, True)])
+def test_first_encoder_stage_in_one_launch_is_first_conv_plus_conv_bit_for_bit(shape, N, in_dtype, pool):
+    """iunet_x2m_first_stage_fwd (2-D): the second conv of the first encoder stage whose loader waves compute the first conv (1 -> 32 channels)
+    on the way in -- the tensor between the two convs never exists -- against iunet_x2m_first_conv_fwd + iunet_x2m_conv_fwd (+ pool): the skip
+    tensor and the pooled tensor, every word.  Strided input views of three dtypes, ragged tile grids (halo rows and columns outside the image
+    are the second conv's zero padding, not conv values), several tiles per workgroup."""
+    from tests.test_gpu_x2 import _prep_conv
+    nv = _nv()
+    g = torch.Generator().manual_seed(51)
+    H, W = shape
+    vox, c = H * W, 32
+    if in_dtype == torch.uint8:
+        base = torch.randint(0, 256, (N, H + 3, W + 5), generator=g, dtype=torch.uint8).cuda()
+    else:
+        base = torch.rand((N, H + 3, W + 5), generator=g).to(in_dtype).cuda()
+    x = base[:, 1:H + 1, 2:W + 2]                                   # a strided view: the kernels read the caller's tensor as it lies
+    st = nv.ll_array((x.stride(0), x.stride(0), x.stride(0), x.stride(1), x.stride(2)))
+    w1 = torch.randn((c, 1, 3, 3), generator=g) * (2.0 / 9) ** 0.5
+    bn1 = [0.75 + 0.5 * torch.rand(c, generator=g), 0.1 * torch.randn(c, generator=g), 0.2 * torch.randn(c, generator=g), 0.5 + torch.rand(c, generator=g)]
+    fw, fosc, fb = _prep_conv(nv, w1, bn1)
+    w2 = torch.randn((c, c, 3, 3), generator=g) * (2.0 / (c * 9)) ** 0.5
+    bn2 = [0.75 + 0.5 * torch.rand(c, generator=g), 0.1 * torch.randn(c, generator=g) - 0.2, 0.2 * torch.randn(c, generator=g), 0.5 + torch.rand(c, generator=g)]
+    w16, w8, osc, bias, _ = _prep(nv, w2, bn2)
+    f = nv.lib().iunet_x2m_first_stage_fusable
+    assert f(2, 1, 32, 8, 512, 512) == 1 and f(2, 1, 32, 1, 128, 128) == 0 and f(3, 1, 32, 8, 512, 512) == 0 and f(2, 2, 32, 8, 512, 512) == 0
+    pv = (H // 2) * (W // 2)
+    code = nv.IN_DTYPE_CODE[x.dtype]
+
+    def run(fused):
+        y = torch.zeros(N * c * vox, dtype=torch.float16, device='cuda')
+        y8 = torch.zeros(N * 2 * c * vox, dtype=torch.uint8, device='cuda')
+        py = torch.full((N * c * pv,), 7.0, dtype=torch.float16, device='cuda')
+        py8 = torch.full((N * 2 * c * pv,), 9, dtype=torch.uint8, device='cuda')
+        sat = torch.zeros(1, dtype=torch.int32, device='cuda')
+        pargs = (nv.ptr(py), c * pv, nv.ptr(py8), 2 * c * pv) if pool else (None, 0, None, 0)
+        if fused:
+            nv.call('iunet_x2m_first_stage_fwd', nv.ptr(x), code, st, nv.ptr(fw), nv.ptr(fosc), nv.ptr(fb), A, nv.ptr(y), c * vox, -1, nv.ptr(y8), 2 * c * vox,
+                    *pargs, nv.ptr(w16), nv.ptr(w8), nv.ptr(osc), nv.ptr(bias), N, H, W, nv.ptr(sat), nv.stream())
+        else:
+            a = torch.zeros(N * c * vox, dtype=torch.float16, device='cuda')
+            a8 = torch.zeros(N * 2 * c * vox, dtype=torch.uint8, device='cuda')
+            nv.call('iunet_x2m_first_conv_fwd', 2, nv.ptr(x), code, st, nv.ptr(a), c * vox, -1, nv.ptr(a8), 2 * c * vox, nv.ptr(fw), nv.ptr(fosc), nv.ptr(fb), A,
+                    N, 1, H, W, 1, c, 1, nv.ptr(sat), nv.stream())
+            if pool:
+                nv.call('iunet_x2m_conv_pool_fwd', 2, nv.ptr(a), c * vox, nv.ptr(a8), 2 * c * vox, nv.ptr(y), c * vox, -1, nv.ptr(y8), 2 * c * vox, *pargs,
+                        nv.ptr(w16), nv.ptr(w8), nv.ptr(osc), nv.ptr(bias), N, 1, H, W, c, c, 2, nv.ptr(sat), nv.stream())
+            else:
+                nv.call('iunet_x2m_conv_fwd', 2, nv.ptr(a), c * vox, nv.ptr(a8), 2 * c * vox, nv.ptr(y), c * vox, -1, nv.ptr(y8), 2 * c * vox,
+                        nv.ptr(w16), nv.ptr(w8), nv.ptr(osc), nv.ptr(bias), N, 1, H, W, c, c, 2, nv.ptr(sat), nv.stream())
+        torch.cuda.synchronize()
+        return y, y8, py, py8, sat
+
+    a, b = run(False), run(True)
+    for name, u, f in zip(('hi', 'm8', 'pooled hi', 'pooled m8', 'range flag'), a, b):
+        assert torch.equal(u, f), f'{name}: {int((u != f).sum())} of {u.numel()} words differ'
+    assert a[0].float().abs().max().item() > 0 and (a[0] == 0).float().mean().item() < 0.9
+
+
+def test_network_2d_with_the_first_stage_in_one_launch_equals_the_per_slice_forward():
+    """8 x 512^2 (4 096 tiles: iunet_x2m_first_stage_fusable says yes) runs the first encoder stage as one launch; each slice alone (512 tiles) runs
+    first conv and second conv as two.  Same logits, bit for bit -- through the Python-sequenced forward and the C++-sequenced one."""
+    from interactive_unet.engine_x2 import EngineX2
+    nv = _nv()
+    f = nv.lib().iunet_x2m_first_stage_fusable
+    if not (f(2, 1, 32, 8, 512, 512) == 1 and f(2, 1, 32, 1, 512, 512) == 0):
+        pytest.skip('IUNET_X2M_FIRST overrides the policy')
+    p = unet_ref.init_params(dim=2, seed=3, randomize_bn=True)
+    e = EngineX2(dim=2)
+    e.load_eval({k: v.cuda() for k, v in p.items()})
+    g = torch.Generator().manual_seed(5)
+    x = torch.randint(0, 256, (8, 1, 512, 512), generator=g, dtype=torch.uint8).cuda()
+    vox = 512 * 512
+    outs = []
+    for rep in range(2):                                   # second call: the C++-sequenced forward (net_graph)
+        lg = torch.empty((8, 2, 512, 512), device='cuda')
+        e.infer(x, (vox, vox, vox, 512, 1), 8, 1, 512, 512, logits=lg)
+        outs.append(lg)
+    one = torch.empty((1, 2, 512, 512), device='cuda')
+    for i in (0, 5):
+        e.infer(x[i:i + 1], (vox, vox, vox, 512, 1), 1, 1, 512, 512, logits=one)
+        torch.cuda.synchronize()
+        assert torch.equal(one[0], outs[0][i]) and torch.equal(one[0], outs[1][i])
+    assert not e.saturated()
