@@ -47,6 +47,14 @@ stats roofline_x2m python3 $R/tools/bench_conv.py --only 0:64:32 --wgrad 0 --ite
 stats forward_x2 python3 $R/tools/bench_x2.py x2
 python3 $R/tools/bench_conv.py --wgrad 0 --iters 30 --n 1 --x2 1 --x2m 1 > $OUT/${RND}_conv_layers_x2_3d.txt 2>/dev/null
 python3 $R/tools/bench_conv.py --dim 2 --size 512 --n 8 --dtype f16 --wgrad 0 --iters 30 --x2 1 --x2m 1 > $OUT/${RND}_conv_layers_x2_2d.txt 2>/dev/null
+# x2m stage convs layer by layer incl. the pooled encoder convs (conv + pool in one launch against two), the 2-D first stage in one launch
+python3 $R/tools/bench_x2m.py 2 128 3 > $OUT/${RND}_x2m_layers_3d.txt 2>/dev/null
+python3 $R/tools/bench_x2m.py 8 512 2 > $OUT/${RND}_x2m_layers_2d.txt 2>/dev/null
+{ python3 $R/tools/bench_first_stage.py; python3 $R/tools/bench_first_stage.py 48 128; } > $OUT/${RND}_first_stage_2d.txt 2>/dev/null
+# forward and weight gradient per stage shape: 2-D (the dy-reuse form against the first form) and 3-D at the C3 step's batch of 2
+python3 $R/tools/bench_conv.py --dim 2 --size 512 --n 8 --dtype fp16 --iters 20 > $OUT/${RND}_conv_wgrad_layers_2d.txt 2>/dev/null
+IUNET_WGRAD2D_V1=1 python3 $R/tools/bench_conv.py --dim 2 --size 512 --n 8 --dtype fp16 --iters 20 > $OUT/${RND}_conv_wgrad_layers_2d_first_form.txt 2>/dev/null
+python3 $R/tools/bench_conv.py --dim 3 --size 128 --n 2 --dtype bf16 --iters 10 > $OUT/${RND}_conv_wgrad_layers_3d_n2.txt 2>/dev/null
 # every C5 stage-conv shape: 16-bit kernel and the K = 128 fp8 kernel on e4m3 planes side by side
 python3 $R/tools/bench_conv.py --base 64 --levels 5 --f8 2 --wgrad 0 --iters 30 > $OUT/${RND}_conv_layers_c5_f8.txt 2>/dev/null
 # every transposed-conv shape of C3 / C5 / C2 alone
@@ -84,5 +92,5 @@ bash tools/level_report.sh 3 1 128 bf16 x2m_3d "--x2m 2" > /dev/null 2>&1; pytho
 bash tools/level_report.sh 2 8 512 f16 2d > /dev/null 2>&1;                python3 tools/level_report.py 2d $RND
 bash tools/level_report.sh 2 8 512 f16 x2m_2d "--x2m 2" > /dev/null 2>&1;  python3 tools/level_report.py x2m_2d $RND
 cp profiles/${RND}_conv_levels_*.md $OUT/ 2>/dev/null
-for f in conv3_v4 conv3_x2m conv3_f8k conv3_wgrad_v2 conv3_wgrad pointwise split16 train_misc; do python3 tools/regreport.py interactive-unet_amd/csrc/$f.hip; done > $OUT/${RND}_register_report.txt 2>&1
+for f in conv3_v4 conv3_x2m conv3_f8k conv3_wgrad_v2 conv2_wgrad_v2 conv3_wgrad pointwise split16 train_misc; do python3 tools/regreport.py interactive-unet_amd/csrc/$f.hip; done > $OUT/${RND}_register_report.txt 2>&1
 ls -la $OUT
