@@ -1366,14 +1366,16 @@ int iunet_x2m_conv_fwd(int nd, const void* x, long long x_ss, const void* x8, lo
                        Cin, Cout, epi, sat, stream);
 }
 
-/* 1 where the callers (net.hip, engine_x2.py) let the pool ride in the conv: in 3-D by default (2 x 128^3, one box: 32->32 @ 128^3 471 us
- * against 460 + 97 for conv + pool, 64->64 @ 64^3 188 against 183 + 20, 128->128 @ 32^3 88.5 against 86.6 + 5.5); not in 2-D, where the
- * three layers together gain little (8 x 512^2: 158 against 152 + 39, 69 against 65 + 13, but 64->64 @ 256^2 107-113 against 79 + 22 us:
- * the pooled instantiation of that launch is 13 us slower with all of its pool work switched off).  IUNET_X2M_POOL=0: never, =2: in 2-D
- * too (A/B switch). */
-int iunet_x2m_pool_fusable(int nd) {
+/* 1 where the callers (net.hip, engine_x2.py) let the pool ride in the conv with C channels: always in 3-D (2 x 128^3, one box: 32->32 @
+ * 128^3 470 us against 458 + 95 for conv + pool, 64->64 @ 64^3 189 against 180 + 21, 128->128 @ 32^3 89 against 87 + 5); in 2-D except at
+ * C = 64 (8 x 512^2: 162 against 152 + 39, 72 against 67 + 13, but 64->64 @ 256^2 107-113 against 79 + 22 us: the pooled instantiation of that
+ * launch -- two Cout tiles on two steps per tile -- is 13 us slower with all of its pool work switched off).  IUNET_X2M_POOL=0: never, =2:
+ * everywhere, =3: 3-D only (A/B switch). */
+int iunet_x2m_pool_fusable(int nd, int C) {
   static const int mode = getenv("IUNET_X2M_POOL") ? atoi(getenv("IUNET_X2M_POOL")) : 1;
-  return mode >= 2 ? (nd == 2 || nd == 3) : mode == 1 ? nd == 3 : 0;
+  if (mode == 0 || (nd != 2 && nd != 3)) return 0;
+  if (nd == 3 || mode == 2) return 1;
+  return mode == 1 && C != 64;
 }
 
 /* An encoder stage's second conv (unet.py:63-69: the skip tensor) WITH the stage's 2^d max-pool riding along: y / y8 as iunet_x2m_conv_fwd,

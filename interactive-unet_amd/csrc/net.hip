@@ -39,7 +39,7 @@ int iunet_x2m_convT_fwd(int, const void*, long long, int, void*, long long, int,
 int iunet_x2_conv3_fwd_flag(int, const void*, long long, int, void*, long long, int, const void*, const void*, const void*, int, int, int, int,
                             int, int, int, void*, void*);
 int iunet_x2m_maxpool_fwd(int, const void*, long long, const void*, long long, void*, long long, void*, long long, int, int, int, int, int, void*);
-int iunet_x2m_pool_fusable(int);
+int iunet_x2m_pool_fusable(int, int);
 int iunet_x2m_first_stage_fusable(int, int, int, int, int, int);
 int iunet_x2m_first_stage_fwd(const void*, int, const long long*, const void*, const void*, const void*, float, void*, long long, int, void*, long long, void*,
                               long long, void*, long long, const void*, const void*, const void*, const void*, int, int, int, void*, void*);
@@ -348,7 +348,7 @@ int iunet_net_forward(iunet_net* n, const void* x, int in_dtype, const long long
         // 2-D, one input channel: the first encoder stage is ONE launch (the first conv is computed by the second conv's loader waves)
         const float* aux1 = (const float*)(K + c1.aux);
         const float* aux2 = (const float*)(K + c2.aux);
-        const bool pooled = iunet_x2m_pool_fusable(dim) != 0;
+        const bool pooled = iunet_x2m_pool_fusable(dim, c) != 0;
         rc = iunet_x2m_first_stage_fwd(x, in_dtype, in_strides, K + c1.pk[1], aux1, aux1 + c, A, WS + L.cat[0], 2ll * c * v, -1, WS + L.catm[0], 4ll * c * v,
                                        pooled ? WS + L.pin[1] : nullptr, (long long)c * vox3(1), pooled ? WS + L.pinm[1] : nullptr, 2ll * c * vox3(1),
                                        K + c2.pk[1], K + c2.pk[0], aux2, aux2 + c2.co, N, h, w, sat, stream);
@@ -372,7 +372,7 @@ int iunet_net_forward(iunet_net* n, const void* x, int in_dtype, const long long
       }
       if (rc) return rc;
       if (l < lv - 1) {
-        if (iunet_x2m_pool_fusable(dim)) {       // the stage's max-pool rides in the epilogue of its second conv (same words, one launch)
+        if (iunet_x2m_pool_fusable(dim, c)) {       // the stage's max-pool rides in the epilogue of its second conv (same words, one launch)
           const float* aux = (const float*)(K + c2.aux);
           rc = iunet_x2m_conv_pool_fwd(dim, WS + L.a[l], (long long)c * v, WS + L.am[l], 2ll * c * v, WS + L.cat[l], 2ll * c * v, -1, WS + L.catm[l],
                                        4ll * c * v, WS + L.pin[l + 1], (long long)c * vox3(l + 1), WS + L.pinm[l + 1], 2ll * c * vox3(l + 1),

@@ -317,7 +317,7 @@ class EngineX2:
                 fw, fosc, fb = self.packed['enc0.conv1']
                 w16, osc, b, w8 = self.packed['enc0.conv2']
                 do = dims[1]
-                pooled = bool(nv.lib().iunet_x2m_pool_fusable(self.dim))
+                pooled = bool(nv.lib().iunet_x2m_pool_fusable(self.dim, c))
                 pool = (Ph(ws['pin1']), c * _vox(do), P8(ws['pin1m']), 2 * c * _vox(do))
                 nv.call('iunet_x2m_first_stage_fwd', nv.ptr(x), nv.IN_DTYPE_CODE[x.dtype], nv.ll_array(x_strides), nv.ptr(fw), nv.ptr(fosc), nv.ptr(fb),
                         self.act_scale, Ph(ws['cat0']), 2 * c * v, -1, P8(ws['cat0m']), 4 * c * v, *(pool if pooled else (None, 0, None, 0)),
@@ -338,7 +338,7 @@ class EngineX2:
             if l < L - 1:
                 # skip half of the concat buffer: hi planes [0, c / 8), m8 planes [0, 2 c / 16)
                 do = dims[l + 1]
-                fused = bool(nv.lib().iunet_x2m_pool_fusable(self.dim))
+                fused = bool(nv.lib().iunet_x2m_pool_fusable(self.dim, c))
                 pool = (Ph(ws[f'pin{l + 1}']), c * _vox(do), P8(ws[f'pin{l + 1}m']), 2 * c * _vox(do))
                 self._conv3m(f'enc{l}.conv2', Ph(ws[f'a{l}']), c * v, P8(ws[f'a{l}m']), 2 * c * v, Ph(ws[f'cat{l}']), 2 * c * v, -1,
                              P8(ws[f'cat{l}m']), 4 * c * v, N, d, c, c, s, pool=pool if fused else None)
