@@ -458,6 +458,15 @@ int iunet_gn_finalize(const void* stats, int nparts, int C, int groups, long lon
 int iunet_gn_relu_bwd(int dtype, const void* dz, long long dz_ss, const void* y, long long y_ss, void* dy, long long dy_ss,
                       const void* gamma, int groups, const void* scale, const void* shift, const void* mean, const void* invstd,
                       void* dgamma, void* dbeta, void* slab, void* coef, int C, int N, long long vox, void* stream);
+/* the same with the 2^d max-pool of an encoder stage folded in: the forward's normalise pass writes z AND its max-pool; the backward forms
+ * dz = dskip + route(dpool) on the fly in both of its passes (the GroupNorm forms of iunet_bn_relu_pool_fwd / _bwd) */
+int iunet_gn_relu_pool_fwd(int dtype, int nd, const void* y, long long y_ss, void* z, long long z_ss, void* pooled, long long p_ss,
+                           const void* gamma, const void* beta, int groups, float eps, void* slab, void* scale, void* shift, void* mean,
+                           void* invstd, int C, int N, int Do, int Ho, int Wo, void* stream);
+int iunet_gn_relu_pool_bwd(int dtype, int nd, const void* dskip, long long ds_ss, const void* dpool, long long dp_ss, const void* y,
+                           long long y_ss, void* dy, long long dy_ss, const void* gamma, int groups, const void* scale, const void* shift,
+                           const void* mean, const void* invstd, void* dgamma, void* dbeta, void* slab, void* coef, int C, int N, int Do,
+                           int Ho, int Wo, void* stream);
 /* iunet_maxpool_bwd (add_skip) + iunet_bn_relu_bwd of an encoder stage's second conv without materialising the gradient of
  * the stage output: dz = dskip + route(dpool), routed to the first maximum of each 2^d window of relu(bn(y)) (recomputed).
  * (Do, Ho, Wo) = pooled grid; dskip, y, dy on the 2x grid; slab as for iunet_bn_relu_bwd on the 2x grid. */

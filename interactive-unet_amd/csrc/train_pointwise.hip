@@ -77,12 +77,13 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
 template <typename T>
 __global__ __launch_bounds__(256) void bn_relu_fwd_kernel(const T* __restrict__ y, long long y_ss, T* __restrict__ z,
                                                           long long z_ss, const float* __restrict__ scale,
-                                                          const float* __restrict__ shift, int planes, long long vox) {
+                                                          const float* __restrict__ shift, int planes, long long vox,
+                                                          int pss = 0 /* per-sample stride of scale / shift (GroupNorm: C; BatchNorm: 0) */) {
   const int pl = blockIdx.y, n = blockIdx.z;
   const long long v0 = (long long)blockIdx.x * 512 + threadIdx.x;
   float sc[8], sh[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { sc[j] = scale[pl * 8 + j]; sh[j] = shift[pl * 8 + j]; }
+  for (int j = 0; j < 8; ++j) { sc[j] = scale[n * pss + pl * 8 + j]; sh[j] = shift[n * pss + pl * 8 + j]; }
   const long long base = (long long)pl * vox * 8;
   V8T<T> in[2];
 #pragma unroll
@@ -107,14 +108,14 @@ template <typename T, int ND>
 __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const T* __restrict__ y, long long y_ss, T* __restrict__ z,
                                                                long long z_ss, T* __restrict__ pooled, long long p_ss,
                                                                const float* __restrict__ scale, const float* __restrict__ shift,
-                                                               int Do, int Ho, int Wo) {
+                                                               int Do, int Ho, int Wo, int pss = 0 /* per-sample stride of scale / shift (GroupNorm: C) */) {
   const long long ovox = (long long)Do * Ho * Wo;
   const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
   if (r >= ovox) return;
   const int pl = blockIdx.y, n = blockIdx.z;
   float sc[8], sh[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { sc[j] = scale[pl * 8 + j]; sh[j] = shift[pl * 8 + j]; }
+  for (int j = 0; j < 8; ++j) { sc[j] = scale[n * pss + pl * 8 + j]; sh[j] = shift[n * pss + pl * 8 + j]; }
   const int ox = (int)(r % Wo), oy = (int)((r / Wo) % Ho), oz = (int)(r / ((long long)Wo * Ho));
   const int Di = ND == 3 ? Do * 2 : 1, Hi = Ho * 2, Wi = Wo * 2;
   const long long ipl = (long long)pl * Di * Hi * Wi * 8;
@@ -155,7 +156,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
                                                             const T* __restrict__ y, long long y_ss,
                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
                                                             const float* __restrict__ scale, const float* __restrict__ shift,
-                                                            int C, long long vox, int per_block, float* __restrict__ slab) {
+                                                            int C, long long vox, int per_block, float* __restrict__ slab,
+                                                            int pss = 0 /* per-sample stride of mean / invstd / scale / shift (GroupNorm: C) */) {
   const int pl = blockIdx.y, n = blockIdx.z;
   const long long v0 = (long long)blockIdx.x * per_block;
   const long long v1 = min(v0 + per_block, vox);
@@ -163,8 +165,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
   float s1[8], s2[8], mu[8], is[8], sc[8], sh[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    s1[j] = 0.f; s2[j] = 0.f; mu[j] = mean[pl * 8 + j]; is[j] = invstd[pl * 8 + j];
-    sc[j] = scale[pl * 8 + j]; sh[j] = shift[pl * 8 + j];
+    const int c = n * pss + pl * 8 + j;
+    s1[j] = 0.f; s2[j] = 0.f; mu[j] = mean[c]; is[j] = invstd[c];
+    sc[j] = scale[c]; sh[j] = shift[c];
   }
   const long long po = (long long)pl * vox * 8;
 #pragma unroll 4
@@ -197,14 +200,15 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
 // maximum of each 2^d window of z = relu(bn(y)), recomputed from y) and is never written.  One thread per pooled voxel
 // and channel plane.  PASS 1: per-channel sums (as bn_bwd_reduce_kernel), PASS 2: dy (as bn_bwd_apply_kernel).
 // Every value is rounded where the three-kernel sequence maxpool_bwd -> reduce -> apply rounds it.
-template <typename T, int ND, int PASS>
+template <typename T, int ND, int PASS, bool GN = false>
 __global__ __launch_bounds__(256) void bn_pool_bwd_kernel(const T* __restrict__ dskip, long long ds_ss,
                                                           const T* __restrict__ dpool, long long dp_ss,
                                                           const T* __restrict__ y, long long y_ss, T* __restrict__ dy,
                                                           long long dy_ss, const float* __restrict__ mean,
                                                           const float* __restrict__ invstd, const float* __restrict__ coef,
                                                           const float* __restrict__ scale, const float* __restrict__ shift,
-                                                          int C, int Do, int Ho, int Wo, int per_block, float* __restrict__ slab) {
+                                                          int C, int Do, int Ho, int Wo, int per_block, float* __restrict__ slab,
+                                                          int pss = 0 /* per-sample stride of the per-channel parameters (GroupNorm: C) */) {
   constexpr int NW = ND == 3 ? 8 : 4;
   const int pl = blockIdx.y, n = blockIdx.z;
   const long long ovox = (long long)Do * Ho * Wo;
@@ -213,7 +217,7 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_kernel(const T* __restrict__ 
   float mu[8], is[8], sc[8], sh[8], ca[8], c1[8], c2[8], s1[8], s2[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    const int c = pl * 8 + j;
+    const int c = n * pss + pl * 8 + j;
     mu[j] = mean[c]; is[j] = invstd[c]; sc[j] = scale[c]; sh[j] = shift[c]; s1[j] = 0.f; s2[j] = 0.f;
     if (PASS == 2) { ca[j] = coef[c * 3]; c1[j] = coef[c * 3 + 1]; c2[j] = coef[c * 3 + 2]; }
   }
@@ -252,7 +256,7 @@ __global__ __launch_bounds__(256) void bn_pool_bwd_kernel(const T* __restrict__ 
         const float d = zv[s][j] > 0.f ? dz : 0.f;
         const float xh = (to_f32<T>(yy[s][j]) - mu[j]) * is[j];
         if (PASS == 1) { s1[j] += d; s2[j] += d * xh; }
-        else o[j] = from_f32<T>(ca[j] * (d - c1[j] - xh * c2[j]));
+        else o[j] = from_f32<T>(GN ? ca[j] * d - c1[j] - xh * c2[j] : ca[j] * (d - c1[j] - xh * c2[j]));      // (GN: bn_bwd_apply_kernel's GroupNorm form)
       }
       if (PASS == 2) *(V8T<T>*)(dy + n * dy_ss + off[s]) = o;
     }
@@ -307,13 +311,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            T* __restrict__ dy, long long dy_ss, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ coef,
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
-                                                           int planes, long long vox) {
+                                                           int planes, long long vox,
+                                                           int pss = 0 /* per-sample stride of the per-channel parameters (GroupNorm: C) */) {
   const int pl = blockIdx.y, n = blockIdx.z;
   const long long v0 = (long long)blockIdx.x * 512 + threadIdx.x;
   float mu[8], is[8], ca[8], c1[8], c2[8], sc[8], sh[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    const int c = pl * 8 + j;
+    const int c = n * pss + pl * 8 + j;
     mu[j] = mean[c]; is[j] = invstd[c]; ca[j] = coef[c * 3]; c1[j] = coef[c * 3 + 1]; c2[j] = coef[c * 3 + 2];
     sc[j] = scale[c]; sh[j] = shift[c];
   }
@@ -375,28 +380,31 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ y, 
 
 // one block per (group, sample): mean / biased variance over the group's channels x voxels (double, fixed order) ->
 // per-(sample, channel) scale = gamma * invstd, shift = beta - mean * scale, mean, invstd  ([N][C] each)
-__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ slab, int chunks, int C, int groups, double vox,
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ slab, int chunks, int C, int groups, double vox,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                          float* scale, float* shift, float* mean_o, float* invstd_o) {
   const int g = blockIdx.x, n = blockIdx.y, cpg = C / groups;
   double s = 0.0, s2 = 0.0;
-  for (int i = threadIdx.x; i < chunks * cpg; i += 64) {
+  for (int i = threadIdx.x; i < chunks * cpg; i += 256) {
     const int ch = i / cpg, c = g * cpg + i % cpg;
     const float* p = slab + (((long long)n * chunks + ch) * C + c) * 2;
     s += (double)p[0]; s2 += (double)p[1];
   }
-  __shared__ double red[2][64];
-  red[0][threadIdx.x] = s; red[1][threadIdx.x] = s2;
+  __shared__ double red[2][4];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); s2 += __shfl_xor(s2, o); }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = s2; }
   __syncthreads();
-  for (int o = 32; o > 0; o >>= 1) {
-    if (threadIdx.x < o) { red[0][threadIdx.x] += red[0][threadIdx.x + o]; red[1][threadIdx.x] += red[1][threadIdx.x + o]; }
-    __syncthreads();
+  if (threadIdx.x == 0) {
+    red[0][0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    red[1][0] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
   }
+  __syncthreads();
   const double cnt = vox * cpg, mean = red[0][0] / cnt;
   double var = red[1][0] / cnt - mean * mean;
   if (var < 0.0) var = 0.0;
   const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-  for (int k = threadIdx.x; k < cpg; k += 64) {
+  for (int k = threadIdx.x; k < cpg; k += 256) {
     const int c = g * cpg + k;
     const float sc = gamma[c] * invstd;
     scale[n * C + c] = sc;
@@ -1146,18 +1154,11 @@ int iunet_gn_relu_fwd(int dtype, const void* y, long long y_ss, void* z, long lo
   dim3 g1(chunks, C / 8, N);
   if (dtype == 0) hipLaunchKernelGGL(gn_stats_kernel<f16>, g1, dim3(256), 0, (hipStream_t)stream, (const f16*)y, y_ss, C, vox, per_block, (float*)slab);
   else hipLaunchKernelGGL(gn_stats_kernel<bf16>, g1, dim3(256), 0, (hipStream_t)stream, (const bf16*)y, y_ss, C, vox, per_block, (float*)slab);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, N), dim3(64), 0, (hipStream_t)stream, (const float*)slab, chunks, C, groups,
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, N), dim3(256), 0, (hipStream_t)stream, (const float*)slab, chunks, C, groups,
                      (double)vox, (const float*)gamma, (const float*)beta, eps, (float*)scale, (float*)shift, (float*)mean, (float*)invstd);
-  const int es = 2;
-  dim3 g2((unsigned)((vox + 511) / 512), C / 8, 1);
-  for (int n = 0; n < N; ++n) {
-    const char* yn = (const char*)y + (long long)n * y_ss * es;
-    char* zn = (char*)z + (long long)n * z_ss * es;
-    const float* sc = (const float*)scale + (long long)n * C;
-    const float* sh = (const float*)shift + (long long)n * C;
-    if (dtype == 0) hipLaunchKernelGGL(bn_relu_fwd_kernel<f16>, g2, dim3(256), 0, (hipStream_t)stream, (const f16*)yn, y_ss, (f16*)zn, z_ss, sc, sh, C / 8, vox);
-    else hipLaunchKernelGGL(bn_relu_fwd_kernel<bf16>, g2, dim3(256), 0, (hipStream_t)stream, (const bf16*)yn, y_ss, (bf16*)zn, z_ss, sc, sh, C / 8, vox);
-  }
+  dim3 g2((unsigned)((vox + 511) / 512), C / 8, N);        // one launch over the samples: sample n reads its row of scale / shift
+  if (dtype == 0) hipLaunchKernelGGL(bn_relu_fwd_kernel<f16>, g2, dim3(256), 0, (hipStream_t)stream, (const f16*)y, y_ss, (f16*)z, z_ss, (const float*)scale, (const float*)shift, C / 8, vox, C);
+  else hipLaunchKernelGGL(bn_relu_fwd_kernel<bf16>, g2, dim3(256), 0, (hipStream_t)stream, (const bf16*)y, y_ss, (bf16*)z, z_ss, (const float*)scale, (const float*)shift, C / 8, vox, C);
   IUNET_CHECK_HIP(hipGetLastError());
   return IUNET_OK;
 }
@@ -1171,7 +1172,7 @@ int iunet_gn_finalize(const void* stats, int nparts, int C, int groups, long lon
   IUNET_REQUIRE(stats && gamma && beta && scale && shift && mean && invstd, "gn_finalize: null pointer");
   IUNET_REQUIRE(nparts > 0 && C > 0 && groups > 0 && C % groups == 0 && vox > 0, "gn_finalize: %d parts, %d channels in %d groups, %lld voxels",
                 nparts, C, groups, vox);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, 1), dim3(64), 0, (hipStream_t)stream, (const float*)stats, nparts, C, groups,
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, 1), dim3(256), 0, (hipStream_t)stream, (const float*)stats, nparts, C, groups,
                      (double)vox, (const float*)gamma, (const float*)beta, eps, (float*)scale, (float*)shift, (float*)mean, (float*)invstd);
   IUNET_CHECK_HIP(hipGetLastError());
   return IUNET_OK;
@@ -1186,30 +1187,73 @@ int iunet_gn_relu_bwd(int dtype, const void* dz, long long dz_ss, const void* y,
   IUNET_REQUIRE(dz && y && dy && gamma && scale && shift && mean && invstd && dgamma && dbeta && slab && coef, "gn_relu_bwd: null pointer");
   IUNET_REQUIRE(C > 0 && C % 8 == 0 && C <= 1024 && N > 0 && vox > 0, "gn_relu_bwd: C %d (multiple of 8, <= 1024), N %d, %lld voxels", C, N, vox);
   IUNET_REQUIRE(groups > 0 && C % groups == 0, "gn_relu_bwd: %d channels do not split into %d groups", C, groups);
-  const int per_block = BN_BWD_PER_BLOCK, es = 2;
+  const int per_block = BN_BWD_PER_BLOCK;
   const int chunks = (int)((vox + per_block - 1) / per_block);
-  dim3 g1(chunks, C / 8, 1), g2((unsigned)((vox + 511) / 512), C / 8, 1);
-  for (int n = 0; n < N; ++n) {
-    const char* dzn = (const char*)dz + (long long)n * dz_ss * es;
-    const char* yn = (const char*)y + (long long)n * y_ss * es;
-    const float *mu = (const float*)mean + (long long)n * C, *is = (const float*)invstd + (long long)n * C;
-    const float *sc = (const float*)scale + (long long)n * C, *sh = (const float*)shift + (long long)n * C;
-    float* sl = (float*)slab + (long long)n * chunks * C * 2;
-    if (dtype == 0) hipLaunchKernelGGL(bn_bwd_reduce_kernel<f16>, g1, dim3(256), 0, (hipStream_t)stream, (const f16*)dzn, dz_ss, (const f16*)nullptr, 0LL, (const f16*)yn, y_ss, mu, is, sc, sh, C, vox, per_block, sl);
-    else hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16>, g1, dim3(256), 0, (hipStream_t)stream, (const bf16*)dzn, dz_ss, (const bf16*)nullptr, 0LL, (const bf16*)yn, y_ss, mu, is, sc, sh, C, vox, per_block, sl);
-  }
+  dim3 g1(chunks, C / 8, N), g2((unsigned)((vox + 511) / 512), C / 8, N);      // one launch over the samples: sample n reads its rows of the parameters
+  const float *mu = (const float*)mean, *is = (const float*)invstd, *sc = (const float*)scale, *sh = (const float*)shift;
+  if (dtype == 0) hipLaunchKernelGGL(bn_bwd_reduce_kernel<f16>, g1, dim3(256), 0, (hipStream_t)stream, (const f16*)dz, dz_ss, (const f16*)nullptr, 0LL, (const f16*)y, y_ss, mu, is, sc, sh, C, vox, per_block, (float*)slab, C);
+  else hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16>, g1, dim3(256), 0, (hipStream_t)stream, (const bf16*)dz, dz_ss, (const bf16*)nullptr, 0LL, (const bf16*)y, y_ss, mu, is, sc, sh, C, vox, per_block, (float*)slab, C);
   hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(groups), dim3(256), 0, (hipStream_t)stream, (const float*)slab, chunks, C, groups, N,
                      (double)vox, (const float*)gamma, (const float*)invstd, (float*)dgamma, (float*)dbeta, (float*)coef);
-  for (int n = 0; n < N; ++n) {
-    const char* dzn = (const char*)dz + (long long)n * dz_ss * es;
-    const char* yn = (const char*)y + (long long)n * y_ss * es;
-    char* dyn = (char*)dy + (long long)n * dy_ss * es;
-    const float *mu = (const float*)mean + (long long)n * C, *is = (const float*)invstd + (long long)n * C;
-    const float *sc = (const float*)scale + (long long)n * C, *sh = (const float*)shift + (long long)n * C;
-    const float* cf = (const float*)coef + (long long)n * C * 3;
-    if (dtype == 0) hipLaunchKernelGGL((bn_bwd_apply_kernel<f16, true>), g2, dim3(256), 0, (hipStream_t)stream, (const f16*)dzn, dz_ss, (const f16*)nullptr, 0LL, (const f16*)yn, y_ss, (f16*)dyn, dy_ss, mu, is, cf, sc, sh, C / 8, vox);
-    else hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16, true>), g2, dim3(256), 0, (hipStream_t)stream, (const bf16*)dzn, dz_ss, (const bf16*)nullptr, 0LL, (const bf16*)yn, y_ss, (bf16*)dyn, dy_ss, mu, is, cf, sc, sh, C / 8, vox);
-  }
+  const float* cf = (const float*)coef;
+  if (dtype == 0) hipLaunchKernelGGL((bn_bwd_apply_kernel<f16, true>), g2, dim3(256), 0, (hipStream_t)stream, (const f16*)dz, dz_ss, (const f16*)nullptr, 0LL, (const f16*)y, y_ss, (f16*)dy, dy_ss, mu, is, cf, sc, sh, C / 8, vox, C);
+  else hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16, true>), g2, dim3(256), 0, (hipStream_t)stream, (const bf16*)dz, dz_ss, (const bf16*)nullptr, 0LL, (const bf16*)y, y_ss, (bf16*)dy, dy_ss, mu, is, cf, sc, sh, C / 8, vox, C);
+  IUNET_CHECK_HIP(hipGetLastError());
+  return IUNET_OK;
+}
+
+// iunet_gn_relu_fwd whose normalise pass also writes the 2^d max-pool of z (encoder stages: the pool would re-read z right away):
+// statistics pass + finalize + ONE pass that writes z and the pooled tensor ((Do, Ho, Wo) grid, p_ss elements per sample).
+int iunet_gn_relu_pool_fwd(int dtype, int nd, const void* y, long long y_ss, void* z, long long z_ss, void* pooled, long long p_ss,
+                           const void* gamma, const void* beta, int groups, float eps, void* slab, void* scale, void* shift, void* mean,
+                           void* invstd, int C, int N, int Do, int Ho, int Wo, void* stream) {
+  DT_OK(dtype);
+  IUNET_REQUIRE(y && z && pooled && gamma && beta && slab && scale && shift && mean && invstd, "gn_relu_pool_fwd: null pointer");
+  IUNET_REQUIRE(nd == 2 || nd == 3, "gn_relu_pool_fwd: nd must be 2 or 3");
+  IUNET_REQUIRE(C > 0 && C % 8 == 0 && N > 0 && Do > 0 && Ho > 0 && Wo > 0, "gn_relu_pool_fwd: bad shape");
+  IUNET_REQUIRE(groups > 0 && C % groups == 0, "gn_relu_pool_fwd: %d channels do not split into %d groups", C, groups);
+  const long long ovox = (long long)Do * Ho * Wo, vox = ovox * (nd == 3 ? 8 : 4);
+  const int per_block = BN_BWD_PER_BLOCK;
+  const int chunks = (int)((vox + per_block - 1) / per_block);
+  dim3 g1(chunks, C / 8, N);
+  if (dtype == 0) hipLaunchKernelGGL(gn_stats_kernel<f16>, g1, dim3(256), 0, (hipStream_t)stream, (const f16*)y, y_ss, C, vox, per_block, (float*)slab);
+  else hipLaunchKernelGGL(gn_stats_kernel<bf16>, g1, dim3(256), 0, (hipStream_t)stream, (const bf16*)y, y_ss, C, vox, per_block, (float*)slab);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, N), dim3(256), 0, (hipStream_t)stream, (const float*)slab, chunks, C, groups,
+                     (double)vox, (const float*)gamma, (const float*)beta, eps, (float*)scale, (float*)shift, (float*)mean, (float*)invstd);
+  dim3 grid((unsigned)((ovox + 255) / 256), C / 8, N);
+#define GRP(TT, NDV) hipLaunchKernelGGL((bn_relu_pool_fwd_kernel<TT, NDV>), grid, dim3(256), 0, (hipStream_t)stream, (const TT*)y, y_ss, (TT*)z, z_ss, (TT*)pooled, p_ss, (const float*)scale, (const float*)shift, Do, Ho, Wo, C)
+  if (dtype == 0) { if (nd == 3) GRP(f16, 3); else GRP(f16, 2); } else { if (nd == 3) GRP(bf16, 3); else GRP(bf16, 2); }
+#undef GRP
+  IUNET_CHECK_HIP(hipGetLastError());
+  return IUNET_OK;
+}
+
+// iunet_maxpool_bwd (add_skip) + iunet_gn_relu_bwd of an encoder stage's second conv in two passes instead of three (the GroupNorm form of
+// iunet_bn_relu_pool_bwd): dz = dskip + route(dpool) is formed on the fly in both passes and never written.  slab / coef as iunet_gn_relu_bwd.
+int iunet_gn_relu_pool_bwd(int dtype, int nd, const void* dskip, long long ds_ss, const void* dpool, long long dp_ss, const void* y,
+                           long long y_ss, void* dy, long long dy_ss, const void* gamma, int groups, const void* scale, const void* shift,
+                           const void* mean, const void* invstd, void* dgamma, void* dbeta, void* slab, void* coef, int C, int N, int Do,
+                           int Ho, int Wo, void* stream) {
+  DT_OK(dtype);
+  IUNET_REQUIRE(dskip && dpool && y && dy && gamma && scale && shift && mean && invstd && dgamma && dbeta && slab && coef, "gn_relu_pool_bwd: null pointer");
+  IUNET_REQUIRE(nd == 2 || nd == 3, "gn_relu_pool_bwd: nd must be 2 or 3");
+  IUNET_REQUIRE(C > 0 && C % 8 == 0 && C <= 1024 && N > 0 && Do > 0 && Ho > 0 && Wo > 0, "gn_relu_pool_bwd: bad shape");
+  IUNET_REQUIRE(groups > 0 && C % groups == 0, "gn_relu_pool_bwd: %d channels do not split into %d groups", C, groups);
+  const long long ovox = (long long)Do * Ho * Wo, vox = ovox * (nd == 3 ? 8 : 4);
+  const int per_block = BN_POOL_PER_BLOCK / (nd == 3 ? 8 : 4);
+  const int chunks = (int)((ovox + per_block - 1) / per_block);
+  IUNET_REQUIRE(chunks * N <= iunet_bn_bwd_num_parts(N, vox), "gn_relu_pool_bwd: slab part count");
+  dim3 g1(chunks, C / 8, N), g2((unsigned)((ovox + 255) / 256), C / 8, N);
+#define GPB(TT, NDV, PASSV, GRID, PB) hipLaunchKernelGGL((bn_pool_bwd_kernel<TT, NDV, PASSV, true>), GRID, dim3(256), 0, (hipStream_t)stream, \
+    (const TT*)dskip, ds_ss, (const TT*)dpool, dp_ss, (const TT*)y, y_ss, (TT*)dy, dy_ss, (const float*)mean, (const float*)invstd, \
+    (const float*)coef, (const float*)scale, (const float*)shift, C, Do, Ho, Wo, PB, (float*)slab, C)
+  if (dtype == 0) { if (nd == 3) GPB(f16, 3, 1, g1, per_block); else GPB(f16, 2, 1, g1, per_block); }
+  else { if (nd == 3) GPB(bf16, 3, 1, g1, per_block); else GPB(bf16, 2, 1, g1, per_block); }
+  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(groups), dim3(256), 0, (hipStream_t)stream, (const float*)slab, chunks, C, groups, N,
+                     (double)vox, (const float*)gamma, (const float*)invstd, (float*)dgamma, (float*)dbeta, (float*)coef);
+  if (dtype == 0) { if (nd == 3) GPB(f16, 3, 2, g2, 256); else GPB(f16, 2, 2, g2, 256); }
+  else { if (nd == 3) GPB(bf16, 3, 2, g2, 256); else GPB(bf16, 2, 2, g2, 256); }
+#undef GPB
   IUNET_CHECK_HIP(hipGetLastError());
   return IUNET_OK;
 }

@@ -295,12 +295,15 @@ class TrainEngine:
                 probe['events'].append((e0, e1, N))
         bn = name.replace('conv', 'bn')
         if self.gn:
-            nv.call('iunet_gn_relu_fwd', self.dt, self._P(y), co * v, z_ptr, z_ss, nv.ptr(self.p(bn + '.weight')),
-                    nv.ptr(self.p(bn + '.bias')), self.groups, BN_EPS, nv.ptr(ws['bnslab']), nv.ptr(ws['scale.' + name]),
-                    nv.ptr(ws['shift.' + name]), nv.ptr(ws['mean.' + name]), nv.ptr(ws['invstd.' + name]), co, N, v, s)
-            if pool is not None:
+            if pool is not None:                # encoder stage: the normalise pass writes the activation and its max-pool
                 p_ptr, p_ss, do = pool
-                nv.call('iunet_maxpool_fwd', self.dt, self.dim, z_ptr, z_ss, p_ptr, p_ss, co, N, do[0], do[1], do[2], s)
+                nv.call('iunet_gn_relu_pool_fwd', self.dt, self.dim, self._P(y), co * v, z_ptr, z_ss, p_ptr, p_ss, nv.ptr(self.p(bn + '.weight')),
+                        nv.ptr(self.p(bn + '.bias')), self.groups, BN_EPS, nv.ptr(ws['bnslab']), nv.ptr(ws['scale.' + name]),
+                        nv.ptr(ws['shift.' + name]), nv.ptr(ws['mean.' + name]), nv.ptr(ws['invstd.' + name]), co, N, do[0], do[1], do[2], s)
+            else:
+                nv.call('iunet_gn_relu_fwd', self.dt, self._P(y), co * v, z_ptr, z_ss, nv.ptr(self.p(bn + '.weight')),
+                        nv.ptr(self.p(bn + '.bias')), self.groups, BN_EPS, nv.ptr(ws['bnslab']), nv.ptr(ws['scale.' + name]),
+                        nv.ptr(ws['shift.' + name]), nv.ptr(ws['mean.' + name]), nv.ptr(ws['invstd.' + name]), co, N, v, s)
             return
         nv.call('iunet_bn_finalize', nv.ptr(stats), nparts, co, float(N) * v,
                 nv.ptr(self.p(bn + '.weight')), nv.ptr(self.p(bn + '.bias')),
@@ -391,10 +394,14 @@ class TrainEngine:
         bn = name.replace('conv', 'bn')
         dy = ws['dy']
         first = name == 'enc0.conv1'
-        if self.gn:
-            if pool_bwd is not None:         # encoder stage: dz = skip gradient + max-pool backward of dpool (in place on the skip gradient)
-                dp_ptr, dp_ss, do = pool_bwd
-                nv.call('iunet_maxpool_bwd', self.dt, self.dim, z_ptr, z_ss, dp_ptr, dp_ss, dz_ptr, dz_ss, 1, co, N, do[0], do[1], do[2], s)
+        if self.gn and pool_bwd is not None:
+            # encoder stage: dz = skip gradient + max-pool backward of dpool, formed on the fly in both passes (never written)
+            dp_ptr, dp_ss, do = pool_bwd
+            nv.call('iunet_gn_relu_pool_bwd', self.dt, self.dim, dz_ptr, dz_ss, dp_ptr, dp_ss, self._P(ws['y.' + name]), co * v, self._P(dy), co * v,
+                    nv.ptr(self.p(bn + '.weight')), self.groups, nv.ptr(ws['scale.' + name]), nv.ptr(ws['shift.' + name]),
+                    nv.ptr(ws['mean.' + name]), nv.ptr(ws['invstd.' + name]), nv.ptr(self.g(bn + '.weight')),
+                    nv.ptr(self.g(bn + '.bias')), nv.ptr(ws['bnslab']), nv.ptr(ws['bncoef']), co, N, do[0], do[1], do[2], s)
+        elif self.gn:
             nv.call('iunet_gn_relu_bwd', self.dt, dz_ptr, dz_ss, self._P(ws['y.' + name]), co * v, self._P(dy), co * v,
                     nv.ptr(self.p(bn + '.weight')), self.groups, nv.ptr(ws['scale.' + name]), nv.ptr(ws['shift.' + name]),
                     nv.ptr(ws['mean.' + name]), nv.ptr(ws['invstd.' + name]), nv.ptr(self.g(bn + '.weight')),

@@ -137,3 +137,58 @@ def test_groupnorm_train_step_vs_autograd(dim, shape, dtype):
     print(f'GroupNorm train step {dim}-D {dtype}: loss {out["Loss"]:.5f} vs oracle {lv:.5f}; worst gradient cosine {worst:.4f}')
     losses = [te.train_step(torch.tensor(img), torch.tensor(y), torch.tensor(wt))['Loss'] for _ in range(6)]
     assert losses[-1] < out['Loss']
+
+
+@pytest.mark.parametrize('dtype,nd,N,C,groups,do', [(torch.bfloat16, 3, 2, 32, 8, (3, 5, 6)), (torch.float16, 2, 3, 64, 8, (1, 20, 17)), (torch.bfloat16, 3, 1, 128, 8, (2, 2, 4))])
+def test_gn_pooled_forward_and_backward_equal_the_unfused_sequences(nv, dtype, nd, N, C, groups, do):
+    """iunet_gn_relu_pool_fwd = iunet_gn_relu_fwd + iunet_maxpool_fwd and iunet_gn_relu_pool_bwd = iunet_maxpool_bwd (add_skip) +
+    iunet_gn_relu_bwd, bit for bit: every value is rounded where the unfused sequence rounds it; the gradient of the stage output is never
+    written.  The skip gradient sits in the first half of a wider buffer (the concat gradient), as in the network."""
+    g = torch.Generator().manual_seed(3)
+    sp = tuple(2 * d for d in do) if nd == 3 else (1, 2 * do[1], 2 * do[2])
+    vox, ovox = int(np.prod(sp)), int(np.prod(do))
+    dev = 'cuda'
+    y = (torch.randn((N, C) + sp, generator=g) * 1.5 + 0.3).to(dtype).float()
+    y[:, :, ..., ::2] = y[:, :, ..., 1::2]                          # ties inside every window: the FIRST maximum takes the pooled gradient
+    gamma, beta = (0.5 + torch.rand(C, generator=g)).to(dev), (0.3 * torch.randn(C, generator=g)).to(dev)
+    dskip = torch.randn((N, 2 * C) + sp, generator=g).to(dtype).float()
+    dpool = torch.randn((N, C) + do, generator=g).to(dtype).float()
+    yb, dcat, dpb = blocked(y, dtype).to(dev), blocked(dskip, dtype).to(dev), blocked(dpool, dtype).to(dev)
+    dt = nv.DTYPE_CODE[dtype]
+    parts = nv.lib().iunet_gn_num_parts(N, vox)
+    res = []
+    for fused in (False, True):
+        slab = torch.zeros(parts * C * 2, device=dev)
+        st = [torch.zeros(N * C, device=dev) for _ in range(4)]
+        coef = torch.zeros(N * C * 3, device=dev)
+        dg, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+        z, pooled = torch.zeros_like(yb), torch.zeros(N * C * ovox, dtype=dtype, device=dev)
+        dy = torch.zeros_like(yb)
+        dc = dcat.clone()
+        if fused:
+            nv.call('iunet_gn_relu_pool_fwd', dt, nd, nv.ptr(yb), C * vox, nv.ptr(z), C * vox, nv.ptr(pooled), C * ovox, nv.ptr(gamma), nv.ptr(beta), groups, 1e-5,
+                    nv.ptr(slab), *[nv.ptr(t) for t in st], C, N, do[0], do[1], do[2], nv.stream())
+            nv.call('iunet_gn_relu_pool_bwd', dt, nd, nv.ptr(dc), 2 * C * vox, nv.ptr(dpb), C * ovox, nv.ptr(yb), C * vox, nv.ptr(dy), C * vox, nv.ptr(gamma), groups,
+                    *[nv.ptr(t) for t in st], nv.ptr(dg), nv.ptr(db), nv.ptr(slab), nv.ptr(coef), C, N, do[0], do[1], do[2], nv.stream())
+        else:
+            nv.call('iunet_gn_relu_fwd', dt, nv.ptr(yb), C * vox, nv.ptr(z), C * vox, nv.ptr(gamma), nv.ptr(beta), groups, 1e-5, nv.ptr(slab),
+                    *[nv.ptr(t) for t in st], C, N, vox, nv.stream())
+            nv.call('iunet_maxpool_fwd', dt, nd, nv.ptr(z), C * vox, nv.ptr(pooled), C * ovox, C, N, do[0], do[1], do[2], nv.stream())
+            nv.call('iunet_maxpool_bwd', dt, nd, nv.ptr(z), C * vox, nv.ptr(dpb), C * ovox, nv.ptr(dc), 2 * C * vox, 1, C, N, do[0], do[1], do[2], nv.stream())
+            nv.call('iunet_gn_relu_bwd', dt, nv.ptr(dc), 2 * C * vox, nv.ptr(yb), C * vox, nv.ptr(dy), C * vox, nv.ptr(gamma), groups, *[nv.ptr(t) for t in st],
+                    nv.ptr(dg), nv.ptr(db), nv.ptr(slab), nv.ptr(coef), C, N, vox, nv.stream())
+        torch.cuda.synchronize()
+        res.append((z, pooled, dy, *st))
+        grads = (dg, db)
+        res[-1] += grads
+    names = ('z', 'pooled', 'dy', 'scale', 'shift', 'mean', 'invstd', 'dgamma', 'dbeta')
+    for name, a, b in zip(names, *res):
+        if name in ('dgamma', 'dbeta'):      # (the pooled first pass walks the voxels window by window: another summation order of the same terms)
+            assert torch.allclose(a, b, rtol=2e-5, atol=2e-5 * a.abs().max().item()), name
+        elif name == 'dy':
+            d = (a.float() - b.float()).abs().max().item()
+            assert d <= 2.0 ** (-7 if dtype == torch.bfloat16 else -10) * a.float().abs().max().item(), (name, d)
+            assert (a != b).float().mean().item() < 0.01
+        else:
+            assert torch.equal(a, b), name
+    assert res[0][2].float().abs().max().item() > 0
