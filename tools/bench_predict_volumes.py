@@ -21,7 +21,7 @@ try:
     os.makedirs('model'); os.makedirs('data/image_volumes'); os.makedirs('data/predicted_volumes')
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
-        m = UNet(num_classes=2, dim=3, act_dtype='bf16', infer_dtype=None if mode == 'fp16x2' else 'bf16', pretrained=False)
+        m = UNet(num_classes=2, dim=3, act_dtype='bf16', infer_dtype='fp16x2' if mode == 'fp16x2' else 'bf16', pretrained=False)
     m.reset_parameters(seed=0)
     m.save_checkpoint('model/model.ckpt')
     for i in range(n):
