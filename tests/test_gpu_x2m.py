@@ -6,6 +6,8 @@ form 16 a + b / 256 so that w_hi8 = a and w_lo8 = b exactly -- must give the bit
 orders, the pairing of the powers of two, halos, ragged tiles); (b) on random fp32 data the result is within ~2^-14 of the exact conv
 of the split input (the fp16 mode leaves 2^-11; a dropped cross term 2^-12).  Network level: logits against the fp32 oracle.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -476,7 +478,9 @@ def test_first_encoder_stage_in_one_launch_is_first_conv_plus_conv_bit_for_bit(s
     bn2 = [0.75 + 0.5 * torch.rand(c, generator=g), 0.1 * torch.randn(c, generator=g) - 0.2, 0.2 * torch.randn(c, generator=g), 0.5 + torch.rand(c, generator=g)]
     w16, w8, osc, bias, _ = _prep(nv, w2, bn2)
     f = nv.lib().iunet_x2m_first_stage_fusable
-    assert f(2, 1, 32, 8, 512, 512) == 1 and f(2, 1, 32, 1, 128, 128) == 0 and f(3, 1, 32, 8, 512, 512) == 0 and f(2, 2, 32, 8, 512, 512) == 0
+    assert f(3, 1, 32, 8, 512, 512) == 0 and f(2, 2, 32, 8, 512, 512) == 0
+    if 'IUNET_X2M_FIRST' not in os.environ:          # the library's own policy: batches of >= 2 048 tiles
+        assert f(2, 1, 32, 8, 512, 512) == 1 and f(2, 1, 32, 1, 128, 128) == 0
     pv = (H // 2) * (W // 2)
     code = nv.IN_DTYPE_CODE[x.dtype]
 
