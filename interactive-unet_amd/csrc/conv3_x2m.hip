@@ -667,14 +667,16 @@ __global__ __launch_bounds__(8 * 64 + XM_NLT, 1) void conv2_x2m_kernel(ConvX2MPa
       const int tile = k / nchunk, chunk = k - tile * nchunk;
       int n_img, y0, x0;
       tile_origin(tile, n_img, y0, x0);
-      dma_weights((const unsigned char*)p.w16 + ((long long)cob * nchunk + chunk) * W16, OFF_W16, W16);
+      if (nchunk > 1 || k == 0)                                // (a 32-channel input: the one chunk's operators stay resident)
+        dma_weights((const unsigned char*)p.w16 + ((long long)cob * nchunk + chunk) * W16, OFF_W16, W16);
       dma_halo((const unsigned char*)((const f16*)p.x + (long long)n_img * p.x_sstride + (long long)chunk * 4 * plane_stride), y0, x0, OFF_A16);
     };
     auto dma8 = [&](int k) {
       const int tile = k / nchunk, chunk = k - tile * nchunk;
       int n_img, y0, x0;
       tile_origin(tile, n_img, y0, x0);
-      dma_weights((const unsigned char*)p.w8 + ((long long)cob * nchunk + chunk) * W8, OFF_W8, W8);
+      if (nchunk > 1 || k == 0)
+        dma_weights((const unsigned char*)p.w8 + ((long long)cob * nchunk + chunk) * W8, OFF_W8, W8);
       dma_halo((const unsigned char*)p.x8 + (long long)n_img * p.x8_sstride + (long long)chunk * 4 * plane16b, y0, x0, OFF_A8);
     };
     auto landed = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };

@@ -69,6 +69,8 @@ python3 $R/tools/step_profile.py $OUT/tmp_t2/t2_kernel_trace.csv 128 40 > $OUT/$
 rm -rf $OUT/tmp_pp; rocprofv3 --kernel-trace --output-format csv -d $OUT/tmp_pp -o pp -- python3 $R/tools/bench_predict3d.py 10 fp16x2 > $OUT/predict3d.log 2>&1
 python3 $R/tools/step_profile.py $OUT/tmp_pp/pp_kernel_trace.csv 26 30 > $OUT/${RND}_predict_x2m_by_kernel.txt; rm -rf $OUT/tmp_pp      # 13 volumes of 4 blocks = 26 two-block forwards
 python3 $R/tools/bench_train2d.py 1 8 2>/dev/null | grep -v amdgpu > $OUT/${RND}_train2d_latency.txt
+{ python3 $R/tools/bench_train3d.py 10; python3 $R/tools/bench_train3d.py 10 gn; } 2>/dev/null | grep -v amdgpu > $OUT/${RND}_train3d_batchnorm_groupnorm.txt      # the C3 training step with BatchNorm and with GroupNorm(8)
+python3 $R/tools/bench_predict_volumes.py 3 512 2>/dev/null | tail -1 > $OUT/${RND}_predict_volumes.txt; python3 $R/tools/bench_predict_volumes.py 2 1024 2>/dev/null | tail -1 >> $OUT/${RND}_predict_volumes.txt
 python3 $R/tools/bench_latency.py 2>/dev/null | grep -v amdgpu > $OUT/${RND}_slice_latency.txt
 echo "done layer tables and step profiles"
 # 4. HBM traffic of the roofline kernels (separate passes, as the guide prescribes)
