@@ -726,9 +726,10 @@ __global__ __launch_bounds__(8 * 64 + XM_NLT, 1) void conv2_x2m_kernel(ConvX2MPa
       constexpr int MAXF = 11;
       f16* xs = (f16*)(smem + OFF_F + lw * FPATCH);
       const f16x8 wa0 = ((const f16x8*)p.f_w)[ll], wa1 = ((const f16x8*)p.f_w)[64 + ll];
-      float fos[8], fbi[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { fos[j] = p.f_oscale[8 * q + j]; fbi[j] = p.f_bias[8 * q + j]; }
+      // the first conv's accumulator scales and biases: a copy per wave behind its patch (read per fragment: 16 registers less to hold)
+      float* fsb = (float*)(smem + OFF_F + 4 * FPATCH + lw * 256);
+      fsb[ll] = ll < 32 ? p.f_oscale[ll] : p.f_bias[ll - 32];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       int koff[8];                                                       // k = 8 q + j = tap * 3 + part (pack_first_conv_kernel); k >= 27: zero weight
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -760,7 +761,7 @@ __global__ __launch_bounds__(8 * 64 + XM_NLT, 1) void conv2_x2m_kernel(ConvX2MPa
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // (the patch is this wave's own: no barrier)
       };
-      u32x2 m_lo[MAXF], m_hi[MAXF];
+      u32x2 m_lo[MAXF];                                                  // (the hi8 words are a function of the hi words: m8_commit reads those back from the 16-bit image)
       auto first_conv = [&](int tile) {                                  // hi words -> the 16-bit halo image; e4m3 words -> m_lo / m_hi
         int n_img, y0, x0;
         tile_origin(tile, n_img, y0, x0);
@@ -775,8 +776,12 @@ __global__ __launch_bounds__(8 * 64 + XM_NLT, 1) void conv2_x2m_kernel(ConvX2MPa
             for (int j = 0; j < 8; ++j) b[j] = xs[base + koff[j]];
             const f32x4 a0 = mfma16<f16>(wa0, b, f32x4{0.f, 0.f, 0.f, 0.f}), a1 = mfma16<f16>(wa1, b, f32x4{0.f, 0.f, 0.f, 0.f});
             float rr[8];
+            {
+              const f32x4 s0 = *(const f32x4*)(fsb + 8 * q), s1 = *(const f32x4*)(fsb + 8 * q + 4);
+              const f32x4 b0 = *(const f32x4*)(fsb + 32 + 8 * q), b1 = *(const f32x4*)(fsb + 32 + 8 * q + 4);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) rr[j] = fmaxf(fmaf(j < 4 ? a0[j & 3] : a1[j & 3], fos[j], fbi[j]), 0.f);
+              for (int j = 0; j < 4; ++j) { rr[j] = fmaxf(fmaf(a0[j], s0[j], b0[j]), 0.f); rr[4 + j] = fmaxf(fmaf(a1[j], s1[j], b1[j]), 0.f); }
+            }
             f16x8 hi, lo;
             u32x2 l8, h8;
             x2m_split8(rr, hi, lo, l8, h8);
@@ -784,7 +789,7 @@ __global__ __launch_bounds__(8 * 64 + XM_NLT, 1) void conv2_x2m_kernel(ConvX2MPa
             const bool in = (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
             if (!in) { hi = f16x8{0, 0, 0, 0, 0, 0, 0, 0}; l8 = u32x2{0u, 0u}; h8 = u32x2{0u, 0u}; }      // the second conv's zero padding
             else if (p.sat != nullptr) x2_note_saturation(p.sat, hi);
-            m_lo[f] = l8; m_hi[f] = h8;
+            m_lo[f] = l8;
             if (16 * f + l15 < npx) *(f16x8*)(smem + OFF_A16 + q * PLANE + (hr0 * PX + lp) * 16) = hi;
           }
         }
@@ -793,9 +798,14 @@ __global__ __launch_bounds__(8 * 64 + XM_NLT, 1) void conv2_x2m_kernel(ConvX2MPa
 #pragma unroll
         for (int f = 0; f < MAXF; ++f) {
           if (f < nfr && 16 * f + l15 < npx) {
-            unsigned char* d = smem + OFF_A8 + (2 * (q >> 1)) * PLANE + (hr0 * PX + 16 * f + l15) * 16 + (q & 1) * 8;
+            const int pix = hr0 * PX + 16 * f + l15;
+            const f16x8 hi = *(const f16x8*)(smem + OFF_A16 + q * PLANE + pix * 16);
+            float h8[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) h8[j] = (float)hi[j] * 0.00390625f;       // hi8 = e4m3(hi * 2^-8), as x2m_split8
+            unsigned char* d = smem + OFF_A8 + (2 * (q >> 1)) * PLANE + pix * 16 + (q & 1) * 8;
             *(u32x2*)d = m_lo[f];
-            *(u32x2*)(d + PLANE) = m_hi[f];
+            *(u32x2*)(d + PLANE) = x2m_pack8(h8);
           }
         }
       };
@@ -1053,7 +1063,7 @@ __global__ __launch_bounds__(8 * 64 + XM_NLT, 1) void conv2_x2m_kernel(ConvX2MPa
 template <int HEAD, bool POOL = false, bool FIRST = false>
 int launch_x2m_2d(ConvX2MParams p, hipStream_t stream) {
   constexpr int PLANE = ((18 * 34 * 16 + 255) / 256) * 256;
-  const int lds = 8 * PLANE + 18432 + X2M2_W8 + 256 + (HEAD > 0 ? 2048 : 0) + (POOL ? 8 * 16 * 4 * 32 : 0) + (FIRST ? 4 * 3 * 7 * 36 * 2 : 0);
+  const int lds = 8 * PLANE + 18432 + X2M2_W8 + 256 + (HEAD > 0 ? 2048 : 0) + (POOL ? 8 * 16 * 4 * 32 : 0) + (FIRST ? 4 * 3 * 7 * 36 * 2 + 4 * 256 : 0);
   IUNET_SET_MAX_LDS((conv2_x2m_kernel<HEAD, POOL, FIRST>), lds);
   p.tilesZ = 1; p.tilesY = (p.H + 15) / 16; p.tilesX = (p.W + 31) / 32;
   const int ncob = p.Cout / 32;
