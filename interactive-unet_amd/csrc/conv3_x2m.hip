@@ -809,8 +809,9 @@ __global__ __launch_bounds__(8 * 64 + XM_NLT, 1) void conv2_x2m_kernel(ConvX2MPa
           }
         }
       };
-      // (A/B, 8 x 512^2: the fragments kept apart by scheduling barriers 197 us, left to the compiler 179 us, spread over both step windows
-      // with the first five fragments' hi words held back 201 us -- 400 B of scratch per lane; the two launches 54 + 140-147 us)
+      // (A/B, 8 x 512^2, with the hi8 words and the scales still held in registers: the fragments kept apart by scheduling barriers 197 us, left
+      // to the compiler 179 us, spread over both step windows with the first five fragments' hi words held back 201 us -- 400 B of scratch
+      // per lane; as it is now 171-181 us; the two launches 53 + 140-154 us)
       patch_load(0);
       patch_commit();
       first_conv(0);
@@ -1402,9 +1403,9 @@ int iunet_x2m_conv_pool_fwd(int nd, const void* x, long long x_ss, const void* x
 }
 
 /* 1 where the callers (net.hip, engine_x2.py) run the first encoder stage as ONE launch: 2-D, one input channel, 32 channels at level 0, and a
- * batch of at least 2 048 tiles of 16 x 32 pixels (8 per CU).  The loader waves' first conv is the longer side of every tile step (11 us per
- * tile against 8.7 for the second conv alone), and the first tile's has nothing to hide behind: 8 x 512^2 (16 tiles per CU) 179 us against
- * 54 + 140 for the two launches, 48 x 128^2 (6 per CU) 71 against 24 + 41-43.  IUNET_X2M_FIRST=0: never, =2: whatever the batch (A/B switch) */
+ * batch of at least 2 048 tiles of 16 x 32 pixels (8 per CU).  The loader waves' first conv is the longer side of a tile step,
+ * and the first tile's has nothing to hide behind: 8 x 512^2 (16 tiles per CU) 171-181 us against 53 + 147-154 for the two launches, 128 x
+ * 128^2 172-175 against 54 + 130-138, 48 x 128^2 (6 per CU) 67 against 24 + 41.  IUNET_X2M_FIRST=0: never, =2: whatever the batch (A/B switch) */
 int iunet_x2m_first_stage_fusable(int nd, int cin, int c0, int N, int H, int W) {
   static const int mode = getenv("IUNET_X2M_FIRST") ? atoi(getenv("IUNET_X2M_FIRST")) : 1;
   if (mode == 0 || nd != 2 || cin != 1 || c0 != 32 || N < 1 || H < 1 || W < 1) return 0;
