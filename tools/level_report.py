@@ -7,6 +7,7 @@ rnd = sys.argv[2] if len(sys.argv) > 2 else 'r03'
 x2m = tag_.startswith('x2m')      # the split conv with its cross terms on the fp8 matrix cores (tools/level_report.sh ... "--x2m 2")
 x2 = tag_.startswith('x2') and not x2m
 f8 = tag_.startswith('f8')          # C5: the K = 128 fp8 kernel on e4m3 planes (tools/level_report.sh ... "--base 64 --levels 5 --f8 2")
+wg = tag_.startswith('wgrad')       # the weight gradient (WGRAD=1 bash tools/level_report.sh ... wgrad_3d)
 L = os.path.join(ROOT, 'gpurun_out', f'levels_{tag_}')
 rows, head = [], None
 for f in sorted(glob.glob(os.path.join(L, 'time_*.txt'))):
@@ -18,6 +19,8 @@ for f in sorted(glob.glob(os.path.join(L, 'time_*.txt'))):
         m = re.search(r'L(\d)\s+(\d+)->\s*(\d+) @(\d+)\^(\d) N=(\d+) layout (\d):.*fp16x2\s+([\d.]+) us\s+[\d.]+ TF/s algorithmic =\s+([\d.]+) TF/s', line)
     elif f8:    # "... | fp8 (e4m3 planes) 358.0 us 2591.3 TF/s (1.91x)"
         m = re.search(r'L(\d)\s+(\d+)->\s*(\d+) @(\d+)\^(\d) N=(\d+) layout (\d):.*fp8[^|]*?\s([\d.]+) us\s+([\d.]+) TF/s', line)
+    elif wg:    # "... | wgrad 229.2 us 1011.9 TF/s"
+        m = re.search(r'L(\d)\s+(\d+)->\s*(\d+) @(\d+)\^(\d) N=(\d+) layout (\d):.*wgrad\s+([\d.]+) us\s+([\d.]+) TF/s', line)
     else:
         m = re.search(r'L(\d)\s+(\d+)->\s*(\d+) @(\d+)\^(\d) N=(\d+) layout (\d): fwd\s+([\d.]+) us\s+([\d.]+) TF/s', line)
     if not m:
@@ -29,19 +32,22 @@ for f in sorted(glob.glob(os.path.join(L, 'time_*.txt'))):
         lay = 'x2m (K16 + K128 fp8)'
     if f8:
         lay = 'K128 fp8' + (', split-K' if 'split-K' in line else '')
+    if wg:
+        lay = 'dy-reuse form'
     def ctr(kind, name):
         g = glob.glob(os.path.join(L, f'{kind}_{tag}', '**', '*_counter_collection.csv'), recursive=True)
         if not g:
             return None
         vals = [float(r['Counter_Value']) for r in csv.DictReader(open(g[0]))
-                if r['Counter_Name'] == name and ('conv3_f8k' if f8 else '_x2m_kernel' if x2m else 'conv3') in r['Kernel_Name'] and 'pack' not in r['Kernel_Name']]
+                if r['Counter_Name'] == name and ('wgrad_v2_kernel' if wg else 'conv3_f8k' if f8 else '_x2m_kernel' if x2m else 'conv3') in r['Kernel_Name']
+                and 'pack' not in r['Kernel_Name'] and (wg or 'wgrad' not in r['Kernel_Name'])]
         return sum(vals) / len(vals) if vals else None
     busy, gui = ctr('mfma', 'SQ_VALU_MFMA_BUSY_CYCLES'), ctr('mfma', 'GRBM_GUI_ACTIVE')
     fetch, write = ctr('fetch', 'FETCH_SIZE'), ctr('write', 'WRITE_SIZE')
     util = busy / (gui / 8 * 1024) if busy and gui else None       # 1024 SIMDs, GUI_ACTIVE summed over 8 XCDs
     nd, n = int(nd), int(n)
     vox = int(S) ** nd * n
-    alg = (int(cin) + int(cout)) * 2 * vox + int(cin) * int(cout) * 3 ** nd * 2      # activations once in, once out + the filter once
+    alg = (int(cin) + int(cout)) * 2 * vox + int(cin) * int(cout) * 3 ** nd * (4 if wg else 2)      # activations once in, once out + the filter once (weight gradient: input + output gradient once in, dW fp32 once out)
     if x2 or x2m:
         alg *= 2                                                                        # hi + lo words (x2m: hi words + m8 bytes) of everything
     if f8:
@@ -52,7 +58,7 @@ for f in sorted(glob.glob(os.path.join(L, 'time_*.txt'))):
 out = os.path.join(ROOT, 'profiles', f'{rnd}_conv_levels_{tag_}.md')
 with open(out, 'w') as o:
     nd, n = head
-    o.write(f'# 3^{nd} conv forward per resolution level ({n} x level-0 tile per launch){" -- SPLIT PRECISION (fp16x2: TFLOP/s = MFMA work, 3 MFMAs per product; algorithmic = a third)" if x2 else " -- SPLIT PRECISION WITH THE CROSS TERMS ON THE fp8 MATRIX CORES (x2m: TFLOP/s = matrix work in 16-bit equivalents, one 16-bit + two double-rate fp8 products per multiply-add; algorithmic = half; MFMA pipe busy counts both instruction kinds)" if x2m else " -- C5 on the K = 128 fp8 instruction, e4m3 planes in and out (MFMA pipe busy counts both instruction forms)" if f8 else ""} -- rocprofv3 PMC, MI355X\n\n')
+    o.write(f'# 3^{nd} conv {"WEIGHT GRADIENT" if wg else "forward"} per resolution level ({n} x level-0 tile per launch){" -- SPLIT PRECISION (fp16x2: TFLOP/s = MFMA work, 3 MFMAs per product; algorithmic = a third)" if x2 else " -- SPLIT PRECISION WITH THE CROSS TERMS ON THE fp8 MATRIX CORES (x2m: TFLOP/s = matrix work in 16-bit equivalents, one 16-bit + two double-rate fp8 products per multiply-add; algorithmic = half; MFMA pipe busy counts both instruction kinds)" if x2m else " -- C5 on the K = 128 fp8 instruction, e4m3 planes in and out (MFMA pipe busy counts both instruction forms)" if f8 else ""} -- rocprofv3 PMC, MI355X\n\n')
     o.write('time / TFLOP/s: HIP events over 30 back-to-back launches (tools/bench_conv.py); MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / '
             '(GRBM_GUI_ACTIVE / 8 x 1024 SIMDs); HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE (gfx950 FETCH_SIZE correction), separate '
             'passes; algorithmic MB = activations once in + once out + the filter once; % of peak vs ' + ('5 PFLOP/s dense fp8' if f8 else '2.5 PFLOP/s dense 16-bit') + ' MFMA and 8 TB/s.  '
