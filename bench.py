@@ -776,8 +776,9 @@ def run(args, workload, rank, world, dev, dist, group):
                 ps.pop('traffic', None)
                 if dim == 3:
                     ps['traffic'] = pmc_traffic('x2m' if x2m_on else 'x2', ps['tiles_per_launch'])
-                    ps['algorithmic_bytes_per_launch'] *= 2          # 4 bytes per element in and out (hi words + lo words / m8 bytes)
-                    ps['hbm_gbs_algorithmic'] = round(2 * ps['hbm_gbs_algorithmic'], 1)
+                    bpe = 1.5 if x2m_on else 2.0                      # bytes per element against the 16-bit kernel's 2: x2m 3 (hi word + lo8 byte), fp16x2 4 (hi + lo words)
+                    ps['algorithmic_bytes_per_launch'] = int(ps['algorithmic_bytes_per_launch'] * bpe)
+                    ps['hbm_gbs_algorithmic'] = round(bpe * ps['hbm_gbs_algorithmic'], 1)
                 ps['kernel'] = (('conv3_x2m_kernel' if dim == 3 else 'conv2_x2m_kernel') if x2m_on else 'split-precision conv (conv3_v4_kernel<f16,...,SPL>)') + ', ' + ps['kernel'].split('(', 1)[1].rstrip(')')
                 # matrix work per multiply-add: fp16x2 three 16-bit products; x2m one 16-bit product + two fp8 products at twice the rate =
                 # the time of two 16-bit products at peak

@@ -215,8 +215,9 @@ int iunet_x2_head_fwd(const void* x, long long x_ss, int x_lo, int C0, const voi
  * The two cross terms of a split product (x_lo w_hi, x_hi w_lo) are 2^-11 of it: they run as one K = 128 step of
  * v_mfma_f32_16x16x128_f8f6f4 over the virtual channels [x_lo8 | x_hi8] x [w_hi8 | w_lo8] (e4m3) into the accumulator of the main
  * term x_hi w_hi -- two matrix-step units per 16 input channels instead of three.  Beside its hi (and optional lo) planes a tensor
- * carries "m8" planes: 2 C / 16 planes [D][H][W][16 B] of e4m3, plane 2c = e4m3((v - hi) * 2^4), plane 2c + 1 = e4m3(hi * 2^-8) of
- * the 16-channel chunk c (v = act_scale * activation).  Same graph, same reference semantics (unet.py:65-69, predict.py:30-35). */
+ * carries lo8 planes (the "m8" / x8 / y8 arguments): C / 16 planes [D][H][W][16 B] of e4m3((v - hi) * 2^4) per 16-channel chunk (v =
+ * act_scale * activation): 3 bytes per element in HBM.  The other half of the fp8 step's operand, e4m3(hi * 2^-8), is a function of the hi
+ * words: the conv's loader waves make it in LDS.  Same graph, same reference semantics (unet.py:65-69, predict.py:30-35). */
 long long iunet_x2m_w8_bytes(int Cout, int Cin);
 /* w fp32 [Cout][Cin][27] (+ optional BatchNorm fold) -> whi fp32 [Cout][Cin][27] = w_hi (feed it to iunet_pack_conv3, dtype 0, mode 2),
  * w8 = iunet_x2m_w8_bytes bytes (K128 order of [e4m3(w_hi 2^-4) | e4m3(w_lo 2^8)] per 16-channel chunk), oscale / bias_out as iunet_x2_prep */
@@ -231,7 +232,7 @@ int iunet_x2m_conv_fwd(int nd, const void* x, long long x_ss, const void* x8, lo
                        long long y8_ss, const void* w16, const void* w8, const void* oscale, const void* bias, int N, int D, int H, int W,
                        int Cin, int Cout, int epi, void* sat, void* stream);
 /* an ENCODER stage's second conv (unet.py:63-69: the skip tensor) with the stage's 2^d max-pool riding in its epilogue: y / y8 as
- * iunet_x2m_conv_fwd, and py / py8 = hi planes (py_ss elements per sample) / m8 planes (py8_ss bytes per sample) of the pooled tensor on the
+ * iunet_x2m_conv_fwd, and py / py8 = hi planes (py_ss elements per sample) / lo8 planes (py8_ss bytes per sample) of the pooled tensor on the
  * grid D/2 (nd = 3), H/2, W/2 -- the words iunet_x2m_maxpool_fwd makes of y / y8, bit for bit, without reading them back (2-D: pooled in the
  * consumer waves' registers; 3-D: x and y in registers, the z pair through LDS by the loader waves).  iunet_x2m_pool_fusable: 1 where the
  * library's own callers fuse a conv of C channels (3-D; 2-D except C = 64, where the pooled launch measured slower than conv + pool;
@@ -260,11 +261,11 @@ int iunet_x2m_conv_head_fwd(int nd, const void* x, long long x_ss, const void* x
                             const void* oscale, const void* bias, const void* head_w, const void* head_b, float act_scale, int ncls,
                             void* logits, void* probs, void* cls, const long long* out_strides, float divisor, int accumulate, int N, int D,
                             int H, int W, int Cin, void* sat, void* stream);
-/* m8 planes (x8_ss bytes per sample) of a split tensor that another kernel wrote as hi + lo words (x_ss fp16 elements per sample) */
+/* lo8 planes (x8_ss bytes per sample) of a split tensor that another kernel wrote as hi + lo words (x_ss fp16 elements per sample) */
 int iunet_x2m_make8(const void* x, long long x_ss, int x_lo, void* x8, long long x8_ss, int C, int N, int D, int H, int W, void* stream);
-/* producers of the x2m form: iunet_x2_first_conv_fwd / iunet_x2_convT_fwd writing, beside the hi planes, the m8 planes of their output
- * (y8, bytes per sample; null: none) and the lo planes only when y_lo >= 0; the max-pool on (hi, m8): the larger hi + lo8 / 16 wins, its hi
- * word and m8 bytes are copied (Do, Ho, Wo = output grid) */
+/* producers of the x2m form: iunet_x2_first_conv_fwd / iunet_x2_convT_fwd writing, beside the hi planes, the lo8 planes of their output
+ * (y8, bytes per sample; null: none) and the lo planes only when y_lo >= 0; the max-pool on (hi, lo8): the larger hi + lo8 / 16 wins, its hi
+ * word and lo8 byte are copied (Do, Ho, Wo = output grid) */
 int iunet_x2m_first_conv_fwd(int nd, const void* x, int in_dtype, const long long* in_strides, void* y, long long y_sstride, int y_lo,
                              void* y8, long long y8_sstride, const void* w, const void* oscale, const void* bias, float act_scale, int N,
                              int D, int H, int W, int Cin, int Cout, int relu, void* sat, void* stream);
@@ -272,8 +273,8 @@ int iunet_x2m_convT_fwd(int nd, const void* x, long long x_ss, int x_lo, void* y
                         const void* wpk, const void* oscale, const void* bias, int N, int D, int H, int W, int Cin, int Cout, void* sat, void* stream);
 int iunet_x2m_maxpool_fwd(int nd, const void* x, long long x_ss, const void* x8, long long x8_ss, void* y, long long y_ss, void* y8,
                           long long y8_ss, int C, int N, int Do, int Ho, int Wo, void* stream);
-/* the stage conv: x = Cin / 8 hi planes + x8 = its m8 planes; y = Cout / 8 hi planes (+ lo planes y_lo planes further on unless
- * y_lo < 0) + y8 = its m8 planes (or null); sat: optional device int raised to the bit pattern of a saturated (|v| >= 65504) hi word */
+/* the stage conv: x = Cin / 8 hi planes + x8 = its lo8 planes; y = Cout / 8 hi planes (+ lo planes y_lo planes further on unless
+ * y_lo < 0) + y8 = its lo8 planes (or null); sat: optional device int raised to the bit pattern of a saturated (|v| >= 65504) hi word */
 int iunet_x2m_conv3_fwd(const void* x, long long x_ss, const void* x8, long long x8_ss, void* y, long long y_ss, int y_lo, void* y8,
                         long long y8_ss, const void* w16, const void* w8, const void* oscale, const void* bias, int N, int D, int H, int W,
                         int Cin, int Cout, int epi, void* sat, void* stream);

@@ -261,8 +261,8 @@ __device__ __forceinline__ void x2m_pool_keys(const f16x8 hi, const u32x2_t lo8,
   for (int j = 0; j < 8; ++j)           // bytes [lo8 | hi lo | hi hi | 0]
     k[j] = __builtin_amdgcn_perm(hf[j >> 1], lf[j >> 2], 0x0c000000u | ((5u + 2u * (j & 1)) << 16) | ((4u + 2u * (j & 1)) << 8) | (unsigned)(j & 3));
 }
-// the words of 8 winning keys: hi, lo8, and hi8 = e4m3(hi * 2^-8) as x2m_split8 makes it
-__device__ __forceinline__ void x2m_pool_unkeys(const unsigned (&k)[8], f16x8& hi, u32x2_t& lo8, u32x2_t& hi8) {
+// the words of 8 winning keys: hi, lo8
+__device__ __forceinline__ void x2m_pool_unkeys(const unsigned (&k)[8], f16x8& hi, u32x2_t& lo8) {
   u32x4 hb;
 #pragma unroll
   for (int d = 0; d < 4; ++d) {
@@ -277,10 +277,6 @@ __device__ __forceinline__ void x2m_pool_unkeys(const unsigned (&k)[8], f16x8& h
     lo8[e] = f ^ (0xffffffffu - ((t << 7) - t));
   }
   hi = __builtin_bit_cast(f16x8, hb);
-  float h8[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) h8[j] = (float)hi[j] * 0.00390625f;
-  hi8 = x2m_pack8(h8);
 }
 // the value of lane ^ 1 (DPP quad_perm [1, 0, 3, 2]: no LDS traffic)
 __device__ __forceinline__ unsigned lane_xor1(unsigned v) {
@@ -298,10 +294,18 @@ __device__ __forceinline__ void x2_note_saturation(int* sat, const f16x8 hi) {
   }
   if (m >= 0x7bffu) atomicMax(sat, (int)m);
 }
-// byte offset, inside the m8 planes of one sample, of the half-granule that holds the 8 channels of 8-channel plane `pl8` at voxel
-// `vox` (lo8; the hi8 half-granule is one plane = nvox * 16 bytes further on)
+// byte offset, inside the lo8 planes of one sample ([C / 16][voxels][16 B]: the e4m3 words e4m3((v - hi) * 2^4) of a 16-channel chunk per
+// voxel), of the half-granule that holds the 8 channels of 8-channel plane `pl8` at voxel `vox`.  (The other half of the fp8 step's
+// operand, hi8 = e4m3(hi * 2^-8), is a function of the hi words: the conv loaders make it in LDS from the 16-bit halo image.)
 __device__ __forceinline__ long long x2m_off(int pl8, long long vox, long long nvox) {
-  return ((long long)(2 * (pl8 >> 1)) * nvox + vox) * 16 + (pl8 & 1) * 8;
+  return ((long long)(pl8 >> 1) * nvox + vox) * 16 + (pl8 & 1) * 8;
+}
+// hi8 of 8 hi words
+__device__ __forceinline__ u32x2_t x2m_hi8(const f16x8 hi) {
+  float h8[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) h8[j] = (float)hi[j] * 0.00390625f;
+  return x2m_pack8(h8);
 }
 
 // ---- K = 128 operator order of the fp8 convolution (conv3_f8k.hip; written by pack_batch.hip kind 5 and conv3_f8.hip: pack_f8_kernel)

@@ -12,7 +12,9 @@
 // Tensors.  An activation tensor of C channels (values v = act_scale * activation, fp32 in the producer's epilogue):
 //   hi planes   C / 8  x [D][H][W][8] fp16         hi = f16(v)                         (the NHWC8c planes of every 16-bit kernel)
 //   lo planes   C / 8  x [D][H][W][8] fp16         lo = f16(v - hi)                    (what the pool / transposed conv / head read; optional)
-//   m8 planes   2C / 16 x [D][H][W][16 B] e4m3     plane 2c: lo8 = e4m3((v - hi) * 2^4), plane 2c + 1: hi8 = e4m3(hi * 2^-8)  of chunk c
+//   lo8 planes  C / 16 x [D][H][W][16 B] e4m3      lo8 = e4m3((v - hi) * 2^4) of the 16-channel chunk (parameter names x8 / y8 / "m8")
+//   hi8 = e4m3(hi * 2^-8), the other half of the fp8 step's operand, is a function of the hi words: the loader waves make it in LDS from
+//   the 16-bit halo image of the same pair while the consumers run its 16-bit step -- an activation costs 3 bytes in HBM, not 4
 // and the operator of a (32 Cout, 16 Cin) block twice: w_hi in the padded K16 order of the 16-bit kernels (30 720 B, pack mode 2) and
 // [w_hi8 = e4m3(w_hi * 2^-4) | w_lo8 = e4m3(w_lo * 2^8)] in the K128 order of conv3_f8k.hip (27 648 B).  The powers of two pair up
 // (2^4 x 2^-4, 2^-8 x 2^8), so every term carries the scale of the main term and one accumulator scale per output channel undoes it.
@@ -39,9 +41,9 @@ __device__ __attribute__((aligned(16))) unsigned int g_xm_zero16[4] = {0u, 0u, 0
 
 struct ConvX2MParams {
   const void* x;  long long x_sstride;        // hi planes, elements
-  const void* x8; long long x8_sstride;       // m8 planes, bytes
+  const void* x8; long long x8_sstride;       // lo8 planes, bytes
   void* y;        long long y_sstride; int y_lo;      // hi planes (elements); lo planes y_lo planes further on, y_lo < 0: not written
-  void* y8;       long long y8_sstride;       // m8 planes of the output (bytes) or null
+  void* y8;       long long y8_sstride;       // lo8 planes of the output (bytes) or null
   const void* w16;                            // [cob][chunk16][column pair 5][dy][2][64][8] f16 (pack mode 2 of w_hi)
   const void* w8;                             // [cob][chunk16][F8K_WSTEP] e4m3 (K128 order of [w_hi8 | w_lo8])
   const float* oscale; const float* bias;
@@ -61,7 +63,7 @@ struct ConvX2MParams {
   // 2^d max-pool on the way out (template POOL): besides y / y8 the launch writes the pooled tensor (hi + m8 planes of the half-size grid),
   // the words of x2m_maxpool_kernel on y / y8 (common.h: x2m_pool_take)
   void* pool_y;  long long pool_y_ss;         // hi planes, elements per sample
-  void* pool_y8; long long pool_y8_ss;        // m8 planes, bytes per sample
+  void* pool_y8; long long pool_y8_ss;        // lo8 planes, bytes per sample
   // the network's FIRST conv computed on the way in (2-D, template FIRST): x / x8 are not read -- the loader waves make the 32-channel halo
   // tile from the caller's one-channel image with the first conv's own operator (split16.hip: x2_first_conv_kernel's arithmetic and words)
   const void* f_x; long long f_sN, f_sH, f_sW; int f_dtype;      // the caller's tensor (generic element strides; dtype code of x2_load_in)
@@ -245,12 +247,12 @@ __global__ __launch_bounds__((XMTile<SMALL>::NCW * 64 + XM_NLT), 1) void conv3_x
         }
       }
     };
-    auto dma8 = [&](int k) {                                   // pair k: [lo8 | hi8] halo tile + K128 operator of its chunk
+    auto dma8 = [&](int k) {                                   // pair k: lo8 halo tile + K128 operator of its chunk
       const int tile = k / nchunk, chunk = k - tile * nchunk;
       int n_img, z0, y0, x0;
       tile_origin(tile, n_img, z0, y0, x0);
       dma_weights((const unsigned char*)p.w8 + ((long long)cob * nchunk + chunk) * W8, OFF_W8, W8);
-      const unsigned char* xc = (const unsigned char*)p.x8 + (long long)n_img * p.x8_sstride + (long long)chunk * 2 * plane16b;
+      const unsigned char* xc = (const unsigned char*)p.x8 + (long long)n_img * p.x8_sstride + (long long)chunk * plane16b;
 #pragma unroll
       for (int it = 0; it < DIT; ++it) {
         const int base = it * NLT + lw * 64;
@@ -259,10 +261,25 @@ __global__ __launch_bounds__((XMTile<SMALL>::NCW * 64 + XM_NLT), 1) void conv3_x
           const int gz = z0 + (c >> 16) - 1, gy = y0 + ((c >> 8) & 255) - 1, gx = x0 + (c & 255) - 1;
           const bool ok = c >= 0 && (unsigned)gz < (unsigned)p.D && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
           const long long goff = (((long long)gz * p.H + gy) * p.W + gx) * 16;
+          dma_piece(ok ? xc + goff : (const unsigned char*)g_xm_zero16, __builtin_amdgcn_readfirstlane(lds0 + OFF_A8 + base * 16));
+        }
+      }
+    };
+    // the other half of the fp8 step's operand, hi8 = e4m3(hi * 2^-8): made here from the 16-bit halo image of the SAME pair (in LDS since
+    // the last barrier, read by the consumers' 16-bit step at the same time) -- it is a function of the hi words, so it never travels
+    auto make_hi8 = [&]() {
 #pragma unroll
-          for (int e = 0; e < 2; ++e)
-            dma_piece(ok ? xc + e * plane16b + goff : (const unsigned char*)g_xm_zero16,
-                      __builtin_amdgcn_readfirstlane(lds0 + OFF_A8 + e * PLANE8 + base * 16));
+      for (int it = 0; it < DIT; ++it) {
+        const int s = lt + it * NLT;
+        if (s < NSLOT) {
+          const int c = dcoord[it];
+          u32x4 o = u32x4{0u, 0u, 0u, 0u};
+          if (c >= 0) {
+            const int pix = ((c >> 16) * PY + ((c >> 8) & 255)) * PX + (c & 255);
+            const u32x2 a = x2m_hi8(*(const f16x8*)(smem + OFF_A16 + pix * 16)), b = x2m_hi8(*(const f16x8*)(smem + OFF_A16 + PLANE16 + pix * 16));
+            o = u32x4{a[0], a[1], b[0], b[1]};
+          }
+          *(u32x4*)(smem + OFF_A8 + PLANE8 + s * 16) = o;
         }
       }
     };
@@ -270,7 +287,7 @@ __global__ __launch_bounds__((XMTile<SMALL>::NCW * 64 + XM_NLT), 1) void conv3_x
     // POOL: thread = (pooled voxel of the tile, 8-channel group q): the z pair of its x-y winners sits in waves w and w + 2.  Two parts:
     // pool_words reads and decodes while the step's LDS-DMA is in flight; pool_store issues the three stores AFTER the wait for that
     // DMA -- a store issued before it would sit in the same vmcnt wait and hold the step's barrier until its write came back.
-    [[maybe_unused]] f16x8 pw_hi; [[maybe_unused]] u32x2 pw_lo8, pw_hi8;
+    [[maybe_unused]] f16x8 pw_hi; [[maybe_unused]] u32x2 pw_lo8;
     [[maybe_unused]] f16* pw_dst = nullptr; [[maybe_unused]] unsigned char* pw_dst8 = nullptr; [[maybe_unused]] long long pw_plane = 0;
     [[maybe_unused]] auto pool_words = [&](int tile) {
       pw_dst = nullptr;
@@ -288,7 +305,7 @@ __global__ __launch_bounds__((XMTile<SMALL>::NCW * 64 + XM_NLT), 1) void conv3_x
       const int oz = (z0 >> 1) + pz, oy = (y0 >> 1) + py, ox = (x0 >> 1) + x8;
       if (oz < Do && oy < Ho && ox < Wo) {
         const long long onvox = (long long)Do * Ho * Wo, ovo = ((long long)oz * Ho + oy) * Wo + ox;
-        x2m_pool_unkeys(kk, pw_hi, pw_lo8, pw_hi8);
+        x2m_pool_unkeys(kk, pw_hi, pw_lo8);
         pw_dst = (f16*)p.pool_y + (long long)n_img * p.pool_y_ss + ((long long)(cob * 4 + q) * onvox + ovo) * 8;
         pw_dst8 = (unsigned char*)p.pool_y8 + (long long)n_img * p.pool_y8_ss + x2m_off(cob * 4 + q, ovo, onvox);
         pw_plane = onvox * 16;
@@ -298,7 +315,6 @@ __global__ __launch_bounds__((XMTile<SMALL>::NCW * 64 + XM_NLT), 1) void conv3_x
       if (pw_dst != nullptr) {
         *(f16x8*)pw_dst = pw_hi;
         *(u32x2*)pw_dst8 = pw_lo8;
-        *(u32x2*)(pw_dst8 + pw_plane) = pw_hi8;
       }
     };
     dma16(0);
@@ -306,6 +322,7 @@ __global__ __launch_bounds__((XMTile<SMALL>::NCW * 64 + XM_NLT), 1) void conv3_x
     lds_barrier();
     for (int k = 0; k < npairs; ++k) {
       dma8(k);                                                 // consumers: 16-bit step of pair k
+      make_hi8();
       landed();
       lds_barrier();
       if (k + 1 < npairs) dma16(k + 1);                        // consumers: fp8 step of pair k
@@ -487,7 +504,6 @@ __global__ __launch_bounds__((XMTile<SMALL>::NCW * 64 + XM_NLT), 1) void conv3_x
         if (p.y8 != nullptr) {
           unsigned char* y8 = (unsigned char*)p.y8 + (long long)n_img * p.y8_sstride + x2m_off(cob * 4 + q, vo, plane16b / 16);
           *(u32x2*)y8 = lo8;
-          *(u32x2*)(y8 + plane16b) = hi8;
         }
         if (p.sat != nullptr) x2_note_saturation(p.sat, hi);
       }
@@ -643,8 +659,9 @@ __global__ __launch_bounds__(8 * 64 + XM_NLT, 1) void conv2_x2m_kernel(ConvX2MPa
       const int pix = min(lt + it * NLT, NPIX - 1);
       pcoord[it] = (pix % PX) | ((pix / PX) << 8);
     }
-    // one halo image: 4 planes of 16 bytes per pixel, `src` = the first plane (bytes), consecutive planes plane16b apart
-    auto dma_halo = [&](const unsigned char* src, int y0, int x0, int off) {
+    // one halo image: NPL source planes of 16 bytes per pixel (`src` = the first, consecutive ones plane16b apart) -> LDS planes off + e * STEP * PLANE
+    auto dma_halo = [&](const unsigned char* src, int y0, int x0, int off, auto NPLc, auto STEPc) {
+      constexpr int NPL = decltype(NPLc)::value, STEP = decltype(STEPc)::value;
 #pragma unroll
       for (int it = 0; it < AIT; ++it) {
         const int base = it * NLT + lw * 64;
@@ -656,9 +673,9 @@ __global__ __launch_bounds__(8 * 64 + XM_NLT, 1) void conv2_x2m_kernel(ConvX2MPa
           const long long goff = ((long long)gy * p.W + gx) * 16;
           if (pix < PLANE / 16) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+            for (int e = 0; e < NPL; ++e)
               dma_piece(ok ? src + e * plane16b + goff : (const unsigned char*)g_xm_zero16,
-                        __builtin_amdgcn_readfirstlane(lds0 + off + e * PLANE + base * 16));
+                        __builtin_amdgcn_readfirstlane(lds0 + off + e * STEP * PLANE + base * 16));
           }
         }
       }
@@ -669,7 +686,8 @@ __global__ __launch_bounds__(8 * 64 + XM_NLT, 1) void conv2_x2m_kernel(ConvX2MPa
       tile_origin(tile, n_img, y0, x0);
       if (nchunk > 1 || k == 0)                                // (a 32-channel input: the one chunk's operators stay resident)
         dma_weights((const unsigned char*)p.w16 + ((long long)cob * nchunk + chunk) * W16, OFF_W16, W16);
-      dma_halo((const unsigned char*)((const f16*)p.x + (long long)n_img * p.x_sstride + (long long)chunk * 4 * plane_stride), y0, x0, OFF_A16);
+      dma_halo((const unsigned char*)((const f16*)p.x + (long long)n_img * p.x_sstride + (long long)chunk * 4 * plane_stride), y0, x0, OFF_A16,
+               std::integral_constant<int, 4>{}, std::integral_constant<int, 1>{});
     };
     auto dma8 = [&](int k) {
       const int tile = k / nchunk, chunk = k - tile * nchunk;
@@ -677,13 +695,28 @@ __global__ __launch_bounds__(8 * 64 + XM_NLT, 1) void conv2_x2m_kernel(ConvX2MPa
       tile_origin(tile, n_img, y0, x0);
       if (nchunk > 1 || k == 0)
         dma_weights((const unsigned char*)p.w8 + ((long long)cob * nchunk + chunk) * W8, OFF_W8, W8);
-      dma_halo((const unsigned char*)p.x8 + (long long)n_img * p.x8_sstride + (long long)chunk * 4 * plane16b, y0, x0, OFF_A8);
+      dma_halo((const unsigned char*)p.x8 + (long long)n_img * p.x8_sstride + (long long)chunk * 2 * plane16b, y0, x0, OFF_A8,
+               std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{});      // the lo8 planes of the two 16-channel blocks -> LDS planes 0, 2
+    };
+    // hi8 planes (LDS planes 1, 3) of the fp8 halo image from the 16-bit halo image of the same pair (see conv3_x2m_kernel)
+    auto make_hi8 = [&]() {
+#pragma unroll
+      for (int it = 0; it < AIT; ++it) {
+        const int pix = lt + it * NLT;
+        if (pix < PLANE / 16) {
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            const u32x2 a0 = x2m_hi8(*(const f16x8*)(smem + OFF_A16 + (2 * b) * PLANE + pix * 16)), a1 = x2m_hi8(*(const f16x8*)(smem + OFF_A16 + (2 * b + 1) * PLANE + pix * 16));
+            *(u32x4*)(smem + OFF_A8 + (2 * b + 1) * PLANE + pix * 16) = u32x4{a0[0], a0[1], a1[0], a1[1]};
+          }
+        }
+      }
     };
     auto landed = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
     // POOL: two (pooled pixel, channel group) items per loader thread.  pool_words reads and decodes the winners' keys while the step's
     // LDS-DMA is in flight; pool_store issues the stores AFTER the wait for that DMA (a store issued before it would sit in the same
     // vmcnt wait and hold the step's barrier until its write came back).
-    [[maybe_unused]] f16x8 pw_hi[2]; [[maybe_unused]] u32x2 pw_lo8[2], pw_hi8[2];
+    [[maybe_unused]] f16x8 pw_hi[2]; [[maybe_unused]] u32x2 pw_lo8[2];
     [[maybe_unused]] f16* pw_dst[2] = {nullptr, nullptr}; [[maybe_unused]] unsigned char* pw_dst8[2] = {nullptr, nullptr};
     [[maybe_unused]] long long pw_plane = 0;
     [[maybe_unused]] auto pool_words = [&](int tile) {
@@ -703,7 +736,7 @@ __global__ __launch_bounds__(8 * 64 + XM_NLT, 1) void conv2_x2m_kernel(ConvX2MPa
         pw_dst[it] = nullptr;
         if (oy < Ho && ox < Wo) {
           const long long ovo = (long long)oy * Wo + ox;
-          x2m_pool_unkeys(kk, pw_hi[it], pw_lo8[it], pw_hi8[it]);
+          x2m_pool_unkeys(kk, pw_hi[it], pw_lo8[it]);
           pw_dst[it] = (f16*)p.pool_y + (long long)n_img * p.pool_y_ss + ((long long)(cob * 4 + q) * onvox + ovo) * 8;
           pw_dst8[it] = (unsigned char*)p.pool_y8 + (long long)n_img * p.pool_y8_ss + x2m_off(cob * 4 + q, ovo, onvox);
         }
@@ -715,7 +748,6 @@ __global__ __launch_bounds__(8 * 64 + XM_NLT, 1) void conv2_x2m_kernel(ConvX2MPa
         if (pw_dst[it] != nullptr) {
           *(f16x8*)pw_dst[it] = pw_hi[it];
           *(u32x2*)pw_dst8[it] = pw_lo8[it];
-          *(u32x2*)(pw_dst8[it] + pw_plane) = pw_hi8[it];
         }
     };
     if constexpr (FIRST) {
@@ -800,12 +832,9 @@ __global__ __launch_bounds__(8 * 64 + XM_NLT, 1) void conv2_x2m_kernel(ConvX2MPa
           if (f < nfr && 16 * f + l15 < npx) {
             const int pix = hr0 * PX + 16 * f + l15;
             const f16x8 hi = *(const f16x8*)(smem + OFF_A16 + q * PLANE + pix * 16);
-            float h8[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) h8[j] = (float)hi[j] * 0.00390625f;       // hi8 = e4m3(hi * 2^-8), as x2m_split8
             unsigned char* d = smem + OFF_A8 + (2 * (q >> 1)) * PLANE + pix * 16 + (q & 1) * 8;
             *(u32x2*)d = m_lo[f];
-            *(u32x2*)(d + PLANE) = x2m_pack8(h8);
+            *(u32x2*)(d + PLANE) = x2m_hi8(hi);
           }
         }
       };
@@ -843,6 +872,7 @@ __global__ __launch_bounds__(8 * 64 + XM_NLT, 1) void conv2_x2m_kernel(ConvX2MPa
     lds_barrier();
     for (int k = 0; k < npairs; ++k) {
       dma8(k);
+      make_hi8();
       landed();
       lds_barrier();
       if (k + 1 < npairs) dma16(k + 1);
@@ -1004,7 +1034,6 @@ __global__ __launch_bounds__(8 * 64 + XM_NLT, 1) void conv2_x2m_kernel(ConvX2MPa
         if (p.y8 != nullptr) {
           unsigned char* y8 = (unsigned char*)p.y8 + (long long)n_img * p.y8_sstride + x2m_off(cob * 4 + q, vo, nvox);
           *(u32x2*)y8 = lo8;
-          *(u32x2*)(y8 + plane16b) = hi8;
         }
         if (p.sat != nullptr) x2_note_saturation(p.sat, hi);
       }
@@ -1172,45 +1201,33 @@ __global__ __launch_bounds__(256) void x2m_prep_kernel(const float* __restrict__
   }
 }
 
-// ------------------------------------------------------------------ m8 planes of a tensor that some other kernel wrote as hi + lo words
+// ------------------------------------------------------------------ lo8 planes of a tensor that some other kernel wrote as hi + lo words
 // (first conv, max-pool, transposed conv): one thread = one voxel of one 16-channel chunk
 __global__ __launch_bounds__(256) void x2m_make8_kernel(const f16* __restrict__ x, long long x_ss, int x_lo, unsigned char* __restrict__ y8,
                                                        long long y8_ss, int chunks, long long vox) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= vox) return;
   const int c = blockIdx.y, n = blockIdx.z;
-  const f16* xh = x + n * x_ss + ((long long)(2 * c) * vox + i) * 8;
-  u32x4 o_lo, o_hi;
+  const f16* xl = x + n * x_ss + ((long long)(2 * c + x_lo) * vox + i) * 8;
+  u32x4 o_lo;
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
-    const f16x8 vh = *(const f16x8*)(xh + (long long)h * vox * 8), vl = *(const f16x8*)(xh + ((long long)h + x_lo) * vox * 8);
-    float l4[8], h8[8];
+    const f16x8 vl = *(const f16x8*)(xl + (long long)h * vox * 8);
+    float l4[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      l4[j] = __builtin_amdgcn_fmed3f((float)vl[j] * 16.0f, -448.0f, 448.0f);
-      h8[j] = __builtin_amdgcn_fmed3f((float)vh[j] * 0.00390625f, -448.0f, 448.0f);
-    }
-    int a = __builtin_amdgcn_cvt_pk_fp8_f32(l4[0], l4[1], 0, false);
-    a = __builtin_amdgcn_cvt_pk_fp8_f32(l4[2], l4[3], a, true);
-    int b = __builtin_amdgcn_cvt_pk_fp8_f32(l4[4], l4[5], 0, false);
-    b = __builtin_amdgcn_cvt_pk_fp8_f32(l4[6], l4[7], b, true);
-    o_lo[2 * h] = (unsigned)a; o_lo[2 * h + 1] = (unsigned)b;
-    a = __builtin_amdgcn_cvt_pk_fp8_f32(h8[0], h8[1], 0, false);
-    a = __builtin_amdgcn_cvt_pk_fp8_f32(h8[2], h8[3], a, true);
-    b = __builtin_amdgcn_cvt_pk_fp8_f32(h8[4], h8[5], 0, false);
-    b = __builtin_amdgcn_cvt_pk_fp8_f32(h8[6], h8[7], b, true);
-    o_hi[2 * h] = (unsigned)a; o_hi[2 * h + 1] = (unsigned)b;
+    for (int j = 0; j < 8; ++j) l4[j] = (float)vl[j] * 16.0f;
+    const u32x2 w = x2m_pack8(l4);
+    o_lo[2 * h] = w[0]; o_lo[2 * h + 1] = w[1];
   }
-  unsigned char* yo = y8 + n * y8_ss + ((long long)(2 * c) * vox + i) * 16;
-  *(u32x4*)yo = o_lo;
-  *(u32x4*)(yo + vox * 16) = o_hi;
+  *(u32x4*)(y8 + n * y8_ss + ((long long)c * vox + i) * 16) = o_lo;
   (void)chunks;
 }
 
-// ------------------------------------------------------------------ max-pool 2^d on (hi, m8): the larger hi + lo8 / 16 wins -- the order
-// of common.h's x2m_pool_keys, shared with the conv epilogue that pools on the way out -- and its hi word and m8 bytes are copied -- the pooled tensor holds exactly the values its source holds for a 3x3x3 consumer.  One thread = one output
-// voxel of one 16-channel chunk: two hi planes (16 B each) and the chunk's two whole m8 granules per input voxel -- every access a full
-// 16-byte item, consecutive threads on consecutive voxels (a thread per 8-channel plane read half granules: 1.8 TB/s at 128^3).
+// ------------------------------------------------------------------ max-pool 2^d on (hi, lo8): the larger hi + lo8 / 16 wins -- the order
+// of common.h's x2m_pool_keys, shared with the conv epilogue that pools on the way out -- and its hi word and lo8 byte are copied: the
+// pooled tensor holds exactly the values its source holds for a 3x3x3 consumer.  One thread = one output voxel of one 16-channel chunk: two
+// hi planes (16 B each) and the chunk's whole lo8 granule per input voxel -- every access a full 16-byte item, consecutive threads on
+// consecutive voxels (a thread per 8-channel plane read half granules: 1.8 TB/s at 128^3).
 template <int ND>
 __global__ __launch_bounds__(256) void x2m_maxpool_kernel(const f16* __restrict__ x, long long x_ss, const unsigned char* __restrict__ x8,
                                                          long long x8_ss, f16* __restrict__ y, long long y_ss, unsigned char* __restrict__ y8,
@@ -1226,7 +1243,7 @@ __global__ __launch_bounds__(256) void x2m_maxpool_kernel(const f16* __restrict_
   const int Di = ND == 3 ? Do * 2 : 1, Hi = Ho * 2, Wi = Wo * 2;
   const long long ivox = (long long)Di * Hi * Wi;
   const f16* xh = x + n * x_ss + (long long)(2 * c) * ivox * 8;
-  const unsigned char* xm = x8 + n * x8_ss + (long long)(2 * c) * ivox * 16;
+  const unsigned char* xm = x8 + n * x8_ss + (long long)c * ivox * 16;
   unsigned k0[8], k1[8];                                       // the winners so far (common.h: x2m_pool_keys), channels 0..7 / 8..15
 #pragma unroll
   for (int j = 0; j < 8; ++j) { k0[j] = 0u; k1[j] = 0u; }
@@ -1247,16 +1264,13 @@ __global__ __launch_bounds__(256) void x2m_maxpool_kernel(const f16* __restrict_
         for (int j = 0; j < 8; ++j) { k0[j] = max(k0[j], c0[j]); k1[j] = max(k1[j], c1[j]); }
       }
   f16x8 o0, o1;
-  u32x2 l0, l1, h0, h1;
-  x2m_pool_unkeys(k0, o0, l0, h0);
-  x2m_pool_unkeys(k1, o1, l1, h1);
+  u32x2 l0, l1;
+  x2m_pool_unkeys(k0, o0, l0);
+  x2m_pool_unkeys(k1, o1, l1);
   f16* yo = y + n * y_ss + ((long long)(2 * c) * ovox + r) * 8;
   *(f16x8*)yo = o0;
   *(f16x8*)(yo + ovox * 8) = o1;
-  const u32x4 ol = u32x4{l0[0], l0[1], l1[0], l1[1]}, ohh = u32x4{h0[0], h0[1], h1[0], h1[1]};
-  unsigned char* y8o = y8 + n * y8_ss + ((long long)(2 * c) * ovox + r) * 16;
-  *(u32x4*)y8o = ol;
-  *(u32x4*)(y8o + ovox * 16) = ohh;
+  *(u32x4*)(y8 + n * y8_ss + ((long long)c * ovox + r) * 16) = u32x4{l0[0], l0[1], l1[0], l1[1]};
 }
 
 }  // namespace

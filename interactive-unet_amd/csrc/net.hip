@@ -119,7 +119,7 @@ struct WsLayout { std::vector<long long> a, b, cat, pin, am, catm, pinm; long lo
 
 // activation buffers of one forward (elements of 2 bytes; x2 holds hi + lo planes: twice the channels).  Modes 2 and 3: the first 256
 // bytes hold the range flag (an int the forward raises to 0x7bff when a stored hi word saturates; the caller zeroes it once).  x2m (mode 3):
-// a / cat / pin are hi planes + m8 planes (2 bytes per element), b hi + lo planes
+// a / cat / pin are hi planes + lo8 planes (2 + 1 bytes per element), b hi + lo planes
 WsLayout ws_layout(const iunet_net* n, int N, int D, int H, int W) {
   WsLayout L;
   const int lv = n->levels, mul = n->mode == 2 ? 2 : 1;
@@ -130,10 +130,10 @@ WsLayout ws_layout(const iunet_net* n, int N, int D, int H, int W) {
   if (n->mode == 3) {
     for (int l = 0; l < lv; ++l) {
       const long long v = (long long)(n->dim == 3 ? D >> l : 1) * (H >> l) * (W >> l);
-      L.a[l] = take((long long)N * n->ch[l] * v); L.am[l] = take((long long)N * n->ch[l] * v);
+      L.a[l] = take((long long)N * n->ch[l] * v); L.am[l] = take((long long)N * n->ch[l] * v / 2);
       L.b[l] = take((long long)N * 2 * n->ch[l] * v);
-      if (l < lv - 1) { L.cat[l] = take((long long)N * 2 * n->ch[l] * v); L.catm[l] = take((long long)N * 2 * n->ch[l] * v); }
-      if (l > 0) { L.pin[l] = take((long long)N * n->ch[l - 1] * v); L.pinm[l] = take((long long)N * n->ch[l - 1] * v); }
+      if (l < lv - 1) { L.cat[l] = take((long long)N * 2 * n->ch[l] * v); L.catm[l] = take((long long)N * n->ch[l] * v); }
+      if (l > 0) { L.pin[l] = take((long long)N * n->ch[l - 1] * v); L.pinm[l] = take((long long)N * n->ch[l - 1] * v / 2); }
     }
     L.bytes = off;
     return L;
@@ -323,7 +323,7 @@ int iunet_net_forward(iunet_net* n, const void* x, int in_dtype, const long long
   unsigned char* K = n->packed;
   const int lv = n->levels, dim = n->dim, mode = n->mode;
   if (mode == 3) {
-    // ---- x2m: a / cat / pin = (hi planes, m8 planes), b = (hi planes, lo planes); engine_x2.EngineX2._infer_mixed sequences the same launches
+    // ---- x2m: a / cat / pin = (hi planes, lo8 planes), b = (hi planes, lo planes); engine_x2.EngineX2._infer_mixed sequences the same launches
     const float A = n->act_scale;
     void* sat = WS;
     auto dims3 = [&](int l, int& d, int& h, int& w) { d = dim == 3 ? D >> l : 1; h = H >> l; w = W >> l; };
@@ -349,44 +349,44 @@ int iunet_net_forward(iunet_net* n, const void* x, int in_dtype, const long long
         const float* aux1 = (const float*)(K + c1.aux);
         const float* aux2 = (const float*)(K + c2.aux);
         const bool pooled = iunet_x2m_pool_fusable(dim, c) != 0;
-        rc = iunet_x2m_first_stage_fwd(x, in_dtype, in_strides, K + c1.pk[1], aux1, aux1 + c, A, WS + L.cat[0], 2ll * c * v, -1, WS + L.catm[0], 4ll * c * v,
-                                       pooled ? WS + L.pin[1] : nullptr, (long long)c * vox3(1), pooled ? WS + L.pinm[1] : nullptr, 2ll * c * vox3(1),
+        rc = iunet_x2m_first_stage_fwd(x, in_dtype, in_strides, K + c1.pk[1], aux1, aux1 + c, A, WS + L.cat[0], 2ll * c * v, -1, WS + L.catm[0], 2ll * c * v,
+                                       pooled ? WS + L.pin[1] : nullptr, (long long)c * vox3(1), pooled ? WS + L.pinm[1] : nullptr, (long long)c * vox3(1),
                                        K + c2.pk[1], K + c2.pk[0], aux2, aux2 + c2.co, N, h, w, sat, stream);
         if (rc) return rc;
         if (!pooled) {
           int dn, hn, wn;
           dims3(1, dn, hn, wn);
-          rc = iunet_x2m_maxpool_fwd(dim, WS + L.cat[0], 2ll * c * v, WS + L.catm[0], 4ll * c * v, WS + L.pin[1], (long long)c * vox3(1), WS + L.pinm[1],
-                                     2ll * c * vox3(1), c, N, dn, hn, wn, stream);
+          rc = iunet_x2m_maxpool_fwd(dim, WS + L.cat[0], 2ll * c * v, WS + L.catm[0], 2ll * c * v, WS + L.pin[1], (long long)c * vox3(1), WS + L.pinm[1],
+                                     (long long)c * vox3(1), c, N, dn, hn, wn, stream);
           if (rc) return rc;
         }
         continue;
       }
       if (l == 0) {
         const float* aux = (const float*)(K + c1.aux);
-        rc = iunet_x2m_first_conv_fwd(dim, x, in_dtype, in_strides, WS + L.a[0], (long long)c * v, -1, WS + L.am[0], 2ll * c * v, K + c1.pk[1], aux,
+        rc = iunet_x2m_first_conv_fwd(dim, x, in_dtype, in_strides, WS + L.a[0], (long long)c * v, -1, WS + L.am[0], (long long)c * v, K + c1.pk[1], aux,
                                       aux + c, A, N, d, h, w, n->cin, c, 1, sat, stream);
       } else {
         const int cp = n->ch[l - 1];
-        rc = convm(c1, L.pin[l], (long long)cp * v, L.pinm[l], 2ll * cp * v, L.a[l], (long long)c * v, -1, L.am[l], 2ll * c * v, l);
+        rc = convm(c1, L.pin[l], (long long)cp * v, L.pinm[l], (long long)cp * v, L.a[l], (long long)c * v, -1, L.am[l], (long long)c * v, l);
       }
       if (rc) return rc;
       if (l < lv - 1) {
         if (iunet_x2m_pool_fusable(dim, c)) {       // the stage's max-pool rides in the epilogue of its second conv (same words, one launch)
           const float* aux = (const float*)(K + c2.aux);
-          rc = iunet_x2m_conv_pool_fwd(dim, WS + L.a[l], (long long)c * v, WS + L.am[l], 2ll * c * v, WS + L.cat[l], 2ll * c * v, -1, WS + L.catm[l],
-                                       4ll * c * v, WS + L.pin[l + 1], (long long)c * vox3(l + 1), WS + L.pinm[l + 1], 2ll * c * vox3(l + 1),
+          rc = iunet_x2m_conv_pool_fwd(dim, WS + L.a[l], (long long)c * v, WS + L.am[l], (long long)c * v, WS + L.cat[l], 2ll * c * v, -1, WS + L.catm[l],
+                                       2ll * c * v, WS + L.pin[l + 1], (long long)c * vox3(l + 1), WS + L.pinm[l + 1], (long long)c * vox3(l + 1),
                                        K + c2.pk[1], K + c2.pk[0], aux, aux + c2.co, N, d, h, w, c2.ci, c2.co, 2, sat, stream);
         } else {
-          rc = convm(c2, L.a[l], (long long)c * v, L.am[l], 2ll * c * v, L.cat[l], 2ll * c * v, -1, L.catm[l], 4ll * c * v, l);
+          rc = convm(c2, L.a[l], (long long)c * v, L.am[l], (long long)c * v, L.cat[l], 2ll * c * v, -1, L.catm[l], 2ll * c * v, l);
           if (rc) return rc;
           int dn, hn, wn;
           dims3(l + 1, dn, hn, wn);
-          rc = iunet_x2m_maxpool_fwd(dim, WS + L.cat[l], 2ll * c * v, WS + L.catm[l], 4ll * c * v, WS + L.pin[l + 1], (long long)c * vox3(l + 1),
-                                     WS + L.pinm[l + 1], 2ll * c * vox3(l + 1), c, N, dn, hn, wn, stream);
+          rc = iunet_x2m_maxpool_fwd(dim, WS + L.cat[l], 2ll * c * v, WS + L.catm[l], 2ll * c * v, WS + L.pin[l + 1], (long long)c * vox3(l + 1),
+                                     WS + L.pinm[l + 1], (long long)c * vox3(l + 1), c, N, dn, hn, wn, stream);
         }
       } else {
-        rc = convm(c2, L.a[l], (long long)c * v, L.am[l], 2ll * c * v, L.b[l], 2ll * c * v, c / 8, -1, 0, l);
+        rc = convm(c2, L.a[l], (long long)c * v, L.am[l], (long long)c * v, L.b[l], 2ll * c * v, c / 8, -1, 0, l);
       }
       if (rc) return rc;
     }
@@ -397,23 +397,23 @@ int iunet_net_forward(iunet_net* n, const void* x, int in_dtype, const long long
       const int c = n->ch[l], cn = n->ch[l + 1];
       const UpOp& u = n->up[lv - 2 - l];
       const float* aux = (const float*)(K + u.aux);
-      // up half of the concat buffer: hi planes [c / 8, 2 c / 8), m8 planes [2 c / 16, 4 c / 16)
+      // up half of the concat buffer: hi planes [c / 8, 2 c / 8), lo8 planes [c / 16, 2 c / 16)
       rc = iunet_x2m_convT_fwd(dim, WS + L.b[l + 1], 2ll * cn * vi, cn / 8, WS + L.cat[l] + (long long)(c / 8) * v * 16, 2ll * c * v, -1,
-                               WS + L.catm[l] + (long long)(2 * c / 16) * v * 16, 4ll * c * v, K + u.pk, aux, aux + c, N, di, hi, wi, cn, c, sat, stream);
+                               WS + L.catm[l] + (long long)(c / 16) * v * 16, 2ll * c * v, K + u.pk, aux, aux + c, N, di, hi, wi, cn, c, sat, stream);
       if (rc) return rc;
       const ConvOp& c1 = n->conv[2 * stage_index(n, true, l)];
       const ConvOp& c2 = n->conv[2 * stage_index(n, true, l) + 1];
-      rc = convm(c1, L.cat[l], 2ll * c * v, L.catm[l], 4ll * c * v, L.a[l], (long long)c * v, -1, L.am[l], 2ll * c * v, l);
+      rc = convm(c1, L.cat[l], 2ll * c * v, L.catm[l], 2ll * c * v, L.a[l], (long long)c * v, -1, L.am[l], (long long)c * v, l);
       if (rc) return rc;
       if (l == 0 && (logits || probs || cls) && iunet_x2m_head_fusable(n->ncls, c)) {
         // the head in the last conv's epilogue: the last activation is never written (the same bits as conv + head)
         const long long dflt0[5] = {n->ncls * v, v, (long long)H * W, W, 1};
         const float* aux2 = (const float*)(K + c2.aux);
-        return iunet_x2m_conv_head_fwd(dim, WS + L.a[0], (long long)c * v, WS + L.am[0], 2ll * c * v, K + c2.pk[1], K + c2.pk[0], aux2, aux2 + c,
+        return iunet_x2m_conv_head_fwd(dim, WS + L.a[0], (long long)c * v, WS + L.am[0], (long long)c * v, K + c2.pk[1], K + c2.pk[0], aux2, aux2 + c,
                                        n->flat + n->head_w, n->flat + n->head_b, A, n->ncls, logits, probs, cls, out_strides ? out_strides : dflt0,
                                        divisor, accumulate, N, dim == 3 ? D : 1, H, W, c, sat, stream);
       }
-      rc = convm(c2, L.a[l], (long long)c * v, L.am[l], 2ll * c * v, L.b[l], 2ll * c * v, c / 8, -1, 0, l);
+      rc = convm(c2, L.a[l], (long long)c * v, L.am[l], (long long)c * v, L.b[l], 2ll * c * v, c / 8, -1, 0, l);
       if (rc) return rc;
     }
     if (!logits && !probs && !cls) return IUNET_OK;

@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void x2_prep_kernel(const float* __restrict__ 
 struct X2FirstParams {
   const void* x; long long sN, sC, sD, sH, sW; int in_dtype;       // caller's tensor, generic element strides; 0 f32, 1 f16, 2 u8 (/ 255), 3 bf16
   void* y; long long y_sstride; int y_lo;             // y_lo < 0: no lo planes (x2m: a tensor only 3x3x3 convs read)
-  void* y8; long long y8_sstride;                      // x2m: the m8 planes of the output (conv3_x2m.hip; bytes) or null
+  void* y8; long long y8_sstride;                      // x2m: the lo8 planes of the output (conv3_x2m.hip; bytes) or null
   int* sat;                                            // optional range flag (common.h: x2_note_saturation)
   const void* w;                        // virtual operator [Cout][3 Cin][taps] in the first conv's fragment order (pack_first_conv, "Cin" = 3 Cin)
   const float* oscale; const float* bias;
@@ -195,7 +195,6 @@ __global__ __launch_bounds__(256) void x2_first_conv_kernel(X2FirstParams p) {
       if (p.y8 != nullptr) {
         unsigned char* y8 = (unsigned char*)p.y8 + (long long)n * p.y8_sstride + x2m_off(cob * 4 + q, off / 8, plane_stride / 8);
         *(u32x2_t*)y8 = l8;
-        *(u32x2_t*)(y8 + plane_stride * 2) = h8;
       }
     }
   }
@@ -249,7 +248,7 @@ __global__ __launch_bounds__(256) void x2_maxpool_kernel(const f16* __restrict__
 struct X2ConvTParams {
   const void* x; long long x_sstride; int x_lo;
   void* y; long long y_sstride; int y_lo;             // y_lo < 0: no lo planes
-  void* y8; long long y8_sstride;                      // x2m: the m8 planes of the output (bytes) or null
+  void* y8; long long y8_sstride;                      // x2m: the lo8 planes of the output (bytes) or null
   int* sat;                                            // optional range flag
   const void* wpk; const float* oscale; const float* bias;
   int N, D, H, W, Cin, Cout;            // input grid; Cin = real input channels
@@ -408,7 +407,7 @@ __global__ __launch_bounds__(256, RES ? 2 : 1) void x2_convT_lds_kernel(X2ConvTP
               o[j] = hi; ol[j] = lo;
             }
           } else {
-            // x2m: this lane's half-granules of the m8 planes go straight out (output voxel 2 x + c of row (oz, oy): 8-byte stores)
+            // x2m: this lane's half-granules of the lo8 planes go straight out (output voxel 2 x + c of row (oz, oy): 8-byte stores)
             u32x2_t l8, h8;
             x2m_split8(rr, o, ol, l8, h8);
             if (x0 + l15 < p.W) {
@@ -416,7 +415,6 @@ __global__ __launch_bounds__(256, RES ? 2 : 1) void x2_convT_lds_kernel(X2ConvTP
               const long long vo = ((long long)(ND == 3 ? z_[g] * 2 + a : 0) * Ho + y_[g] * 2 + b) * Wo + 2 * (x0 + l15) + c;
               unsigned char* y8 = (unsigned char*)p.y8 + n_[g] * p.y8_sstride + x2m_off(cob * 4 + q, vo, ovox);
               *(u32x2_t*)y8 = l8;
-              *(u32x2_t*)(y8 + ovox * 16) = h8;
             }
           }
           if (p.sat != nullptr && x0 + l15 < p.W) x2_note_saturation(p.sat, o);
@@ -577,7 +575,7 @@ int iunet_x2_first_conv_fwd(int nd, const void* x, int in_dtype, const long long
                                   relu, nullptr, stream);
 }
 
-/* the same first conv writing, beside the hi planes, the m8 planes of its output (y8, y8_sstride bytes per sample; null: none) and the
+/* the same first conv writing, beside the hi planes, the lo8 planes of its output (y8, y8_sstride bytes per sample; null: none) and the
  * lo planes only when y_lo >= 0; sat: optional device int raised to 0x7bff when a stored hi word saturated */
 int iunet_x2m_first_conv_fwd(int nd, const void* x, int in_dtype, const long long* in_strides, void* y, long long y_sstride, int y_lo,
                              void* y8, long long y8_sstride, const void* w, const void* oscale, const void* bias, float act_scale, int N,
@@ -651,7 +649,7 @@ int iunet_x2_convT_fwd(int nd, const void* x, long long x_ss, int x_lo, void* y,
   return iunet_x2m_convT_fwd(nd, x, x_ss, x_lo, y, y_ss, y_lo, nullptr, 0, wpk, oscale, bias, N, D, H, W, Cin, Cout, nullptr, stream);
 }
 
-/* the same transposed conv writing, beside the hi planes, the m8 planes of its output (y8, y8_ss bytes per sample; null: none) and the lo
+/* the same transposed conv writing, beside the hi planes, the lo8 planes of its output (y8, y8_ss bytes per sample; null: none) and the lo
  * planes only when y_lo >= 0; sat: optional range flag */
 int iunet_x2m_convT_fwd(int nd, const void* x, long long x_ss, int x_lo, void* y, long long y_ss, int y_lo, void* y8, long long y8_ss,
                         const void* wpk, const void* oscale, const void* bias, int N, int D, int H, int W, int Cin, int Cout, void* sat, void* stream) {

@@ -173,12 +173,12 @@ class EngineX2:
             self.check_shape(D, H, W)
             dims = self.level_dims(D, H, W)
             mk = lambda c, v: torch.empty(N * 2 * c * v, dtype=torch.float16, device=self.device)     # hi + lo planes
-            mk8 = lambda c, v: torch.empty(N * 2 * c * v, dtype=torch.uint8, device=self.device)      # m8 planes: 2 bytes per element
+            mk8 = lambda c, v: torch.empty(N * c * v, dtype=torch.uint8, device=self.device)          # lo8 planes: 1 byte per element (hi8 is made in LDS from the hi words)
             mkh = lambda c, v: torch.empty(N * c * v, dtype=torch.float16, device=self.device)        # hi planes only
             ws = {'dims': dims}
             for l in range(self.levels):
                 v = _vox(dims[l])
-                if self.mixed:       # a, cat, pin: read by 3x3x3 convs only (hi + m8); b: by a transposed conv or the head (hi + lo)
+                if self.mixed:       # a, cat, pin: read by 3x3x3 convs only (hi + lo8); b: by a transposed conv or the head (hi + lo)
                     ws[f'a{l}'], ws[f'a{l}m'] = mkh(self.ch[l], v), mk8(self.ch[l], v)
                     ws[f'b{l}'] = mk(self.ch[l], v)
                     if l < self.levels - 1:
@@ -285,8 +285,8 @@ class EngineX2:
                 float(divisor), int(bool(accumulate)), N, D, H, W, s)
 
     def _conv3m(self, name, xp, x_ss, x8p, x8_ss, yp, y_ss, y_lo, y8p, y8_ss, N, d, ci, co, s, pool=None):
-        """3x3x3 stage conv, cross terms on the fp8 matrix cores: (hi planes, m8 planes) -> hi planes (+ lo planes if y_lo >= 0, + m8 planes).
-        pool = (hi planes, stride, m8 planes, stride) of the half-size grid: the stage's max-pool rides in the conv's epilogue."""
+        """3x3x3 stage conv, cross terms on the fp8 matrix cores: (hi planes, lo8 planes) -> hi planes (+ lo planes if y_lo >= 0, + m8 planes).
+        pool = (hi planes, stride, lo8 planes, stride) of the half-size grid: the stage's max-pool rides in the conv's epilogue."""
         w16, osc, b, w8 = self.packed[name]
         probe = self.probe if (self.probe is not None and self.probe['name'] == name) else None
         if probe is not None:
@@ -304,7 +304,7 @@ class EngineX2:
             probe['events'].append((e0, e1, N))
 
     def _infer_mixed(self, ws, x, x_strides, N, D, H, W, s, head=None):
-        """The forward in the x2m form (everything but the head): a / cat / pin tensors are (hi planes, m8 planes), b tensors (hi, lo)."""
+        """The forward in the x2m form (everything but the head): a / cat / pin tensors are (hi planes, lo8 planes), b tensors (hi, lo)."""
         dims, L, ch = ws['dims'], self.levels, self.ch
         P8 = lambda t, planes16=0, v=0: ctypes.c_void_p(t.data_ptr() + planes16 * v * 16)     # m8 view starting `planes16` 16-byte planes in
         Ph = lambda t, planes=0, v=0: ctypes.c_void_p(t.data_ptr() + planes * v * 16)         # hi view starting `planes` 8-channel planes in
@@ -318,56 +318,56 @@ class EngineX2:
                 w16, osc, b, w8 = self.packed['enc0.conv2']
                 do = dims[1]
                 pooled = bool(nv.lib().iunet_x2m_pool_fusable(self.dim, c))
-                pool = (Ph(ws['pin1']), c * _vox(do), P8(ws['pin1m']), 2 * c * _vox(do))
+                pool = (Ph(ws['pin1']), c * _vox(do), P8(ws['pin1m']), c * _vox(do))
                 nv.call('iunet_x2m_first_stage_fwd', nv.ptr(x), nv.IN_DTYPE_CODE[x.dtype], nv.ll_array(x_strides), nv.ptr(fw), nv.ptr(fosc), nv.ptr(fb),
-                        self.act_scale, Ph(ws['cat0']), 2 * c * v, -1, P8(ws['cat0m']), 4 * c * v, *(pool if pooled else (None, 0, None, 0)),
+                        self.act_scale, Ph(ws['cat0']), 2 * c * v, -1, P8(ws['cat0m']), 2 * c * v, *(pool if pooled else (None, 0, None, 0)),
                         nv.ptr(w16), nv.ptr(w8), nv.ptr(osc), nv.ptr(b), N, d[1], d[2], nv.ptr(self._sat), s)
                 if not pooled:
-                    nv.call('iunet_x2m_maxpool_fwd', self.dim, Ph(ws['cat0']), 2 * c * v, P8(ws['cat0m']), 4 * c * v,
+                    nv.call('iunet_x2m_maxpool_fwd', self.dim, Ph(ws['cat0']), 2 * c * v, P8(ws['cat0m']), 2 * c * v,
                             pool[0], pool[1], pool[2], pool[3], c, N, do[0], do[1], do[2], s)
                 continue
             if l == 0:
                 w, osc, b = self.packed['enc0.conv1']
                 nv.call('iunet_x2m_first_conv_fwd', self.dim, nv.ptr(x), nv.IN_DTYPE_CODE[x.dtype], nv.ll_array(x_strides),
-                        Ph(ws['a0']), c * v, -1, P8(ws['a0m']), 2 * c * v, nv.ptr(w), nv.ptr(osc), nv.ptr(b), self.act_scale,
+                        Ph(ws['a0']), c * v, -1, P8(ws['a0m']), c * v, nv.ptr(w), nv.ptr(osc), nv.ptr(b), self.act_scale,
                         N, d[0], d[1], d[2], self.cin, c, 1, nv.ptr(self._sat), s)
             else:
                 cp = ch[l - 1]
-                self._conv3m(f'enc{l}.conv1', Ph(ws[f'pin{l}']), cp * v, P8(ws[f'pin{l}m']), 2 * cp * v, Ph(ws[f'a{l}']), c * v, -1,
-                             P8(ws[f'a{l}m']), 2 * c * v, N, d, cp, c, s)
+                self._conv3m(f'enc{l}.conv1', Ph(ws[f'pin{l}']), cp * v, P8(ws[f'pin{l}m']), cp * v, Ph(ws[f'a{l}']), c * v, -1,
+                             P8(ws[f'a{l}m']), c * v, N, d, cp, c, s)
             if l < L - 1:
-                # skip half of the concat buffer: hi planes [0, c / 8), m8 planes [0, 2 c / 16)
+                # skip half of the concat buffer: hi planes [0, c / 8), lo8 planes [0, c / 16)
                 do = dims[l + 1]
                 fused = bool(nv.lib().iunet_x2m_pool_fusable(self.dim, c))
-                pool = (Ph(ws[f'pin{l + 1}']), c * _vox(do), P8(ws[f'pin{l + 1}m']), 2 * c * _vox(do))
-                self._conv3m(f'enc{l}.conv2', Ph(ws[f'a{l}']), c * v, P8(ws[f'a{l}m']), 2 * c * v, Ph(ws[f'cat{l}']), 2 * c * v, -1,
-                             P8(ws[f'cat{l}m']), 4 * c * v, N, d, c, c, s, pool=pool if fused else None)
+                pool = (Ph(ws[f'pin{l + 1}']), c * _vox(do), P8(ws[f'pin{l + 1}m']), c * _vox(do))
+                self._conv3m(f'enc{l}.conv2', Ph(ws[f'a{l}']), c * v, P8(ws[f'a{l}m']), c * v, Ph(ws[f'cat{l}']), 2 * c * v, -1,
+                             P8(ws[f'cat{l}m']), 2 * c * v, N, d, c, c, s, pool=pool if fused else None)
                 if not fused:
-                    nv.call('iunet_x2m_maxpool_fwd', self.dim, Ph(ws[f'cat{l}']), 2 * c * v, P8(ws[f'cat{l}m']), 4 * c * v,
+                    nv.call('iunet_x2m_maxpool_fwd', self.dim, Ph(ws[f'cat{l}']), 2 * c * v, P8(ws[f'cat{l}m']), 2 * c * v,
                             pool[0], pool[1], pool[2], pool[3], c, N, do[0], do[1], do[2], s)
             else:
-                self._conv3m(f'enc{l}.conv2', Ph(ws[f'a{l}']), c * v, P8(ws[f'a{l}m']), 2 * c * v, nv.ptr(ws[f'b{l}']), 2 * c * v, c // 8,
+                self._conv3m(f'enc{l}.conv2', Ph(ws[f'a{l}']), c * v, P8(ws[f'a{l}m']), c * v, nv.ptr(ws[f'b{l}']), 2 * c * v, c // 8,
                              None, 0, N, d, c, c, s)
         for l in range(L - 2, -1, -1):
             d, v, di, vi = dims[l], _vox(dims[l]), dims[l + 1], _vox(dims[l + 1])
             c, cn = ch[l], ch[l + 1]
             w, osc, b = self.packed[f'dec{l}.up']
-            # up half of the concat buffer: hi planes [c / 8, 2 c / 8), m8 planes [2 c / 16, 4 c / 16)
+            # up half of the concat buffer: hi planes [c / 8, 2 c / 8), lo8 planes [c / 16, 2 c / 16)
             nv.call('iunet_x2m_convT_fwd', self.dim, nv.ptr(ws[f'b{l + 1}']), 2 * cn * vi, cn // 8, Ph(ws[f'cat{l}'], c // 8, v), 2 * c * v, -1,
-                    P8(ws[f'cat{l}m'], 2 * c // 16, v), 4 * c * v, nv.ptr(w), nv.ptr(osc), nv.ptr(b), N, di[0], di[1], di[2], cn, c, nv.ptr(self._sat), s)
-            self._conv3m(f'dec{l}.conv1', Ph(ws[f'cat{l}']), 2 * c * v, P8(ws[f'cat{l}m']), 4 * c * v, Ph(ws[f'a{l}']), c * v, -1,
-                         P8(ws[f'a{l}m']), 2 * c * v, N, d, 2 * c, c, s)
+                    P8(ws[f'cat{l}m'], c // 16, v), 2 * c * v, nv.ptr(w), nv.ptr(osc), nv.ptr(b), N, di[0], di[1], di[2], cn, c, nv.ptr(self._sat), s)
+            self._conv3m(f'dec{l}.conv1', Ph(ws[f'cat{l}']), 2 * c * v, P8(ws[f'cat{l}m']), 2 * c * v, Ph(ws[f'a{l}']), c * v, -1,
+                         P8(ws[f'a{l}m']), c * v, N, d, 2 * c, c, s)
             if l == 0 and head is not None:
                 logits, probs, cls, out_strides, divisor, accumulate = head
                 if out_strides is None:
                     out_strides = (self.ncls * v, v, H * W, W, 1)
                 w16, osc, b, w8 = self.packed['dec0.conv2']
                 hw, hb = self.packed['head']
-                nv.call('iunet_x2m_conv_head_fwd', self.dim, Ph(ws['a0']), c * v, P8(ws['a0m']), 2 * c * v, nv.ptr(w16), nv.ptr(w8), nv.ptr(osc),
+                nv.call('iunet_x2m_conv_head_fwd', self.dim, Ph(ws['a0']), c * v, P8(ws['a0m']), c * v, nv.ptr(w16), nv.ptr(w8), nv.ptr(osc),
                         nv.ptr(b), nv.ptr(hw), nv.ptr(hb), self.act_scale, self.ncls, nv.ptr(logits), nv.ptr(probs), nv.ptr(cls),
                         nv.ll_array(out_strides), float(divisor), int(bool(accumulate)), N, d[0], d[1], d[2], c, nv.ptr(self._sat), s)
                 continue
-            self._conv3m(f'dec{l}.conv2', Ph(ws[f'a{l}']), c * v, P8(ws[f'a{l}m']), 2 * c * v, nv.ptr(ws[f'b{l}']), 2 * c * v, c // 8,
+            self._conv3m(f'dec{l}.conv2', Ph(ws[f'a{l}']), c * v, P8(ws[f'a{l}m']), c * v, nv.ptr(ws[f'b{l}']), 2 * c * v, c // 8,
                          None, 0, N, d, c, c, s)
 
     # ------------------------------------------------------------------ range check

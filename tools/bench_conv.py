@@ -27,7 +27,7 @@ def main():
     ap.add_argument('--f8', type=int, default=0, help='1: also time the fp8 matrix-core kernel (conv3_f8.hip / conv3_f8k.hip) on each shape; 2: with e4m3 activation planes in and out (3-D, the engine\'s format between fp8 convs)')
     ap.add_argument('--x2', type=int, default=0, help='1: also time the split-precision conv (fp16x2: conv3_v4.hip SPL) on each shape; 2: only it')
     ap.add_argument('--x2m', type=int, default=0, help='1: also time the split-precision conv with its cross terms on the fp8 matrix cores (conv3_x2m.hip; '
-                    'hi + m8 planes in and out) on each shape; 2: only it')
+                    'hi + lo8 planes in and out) on each shape; 2: only it')
     a = ap.parse_args()
     T = torch.bfloat16 if a.dtype == 'bf16' else torch.float16
     dt = nv.DTYPE_CODE[T]; nd = a.dim; taps = 3 ** nd
@@ -108,7 +108,7 @@ def main():
             w16 = torch.empty(nv.pack_conv3_elems(cout, cin, taps, pm16), dtype=torch.float16, device='cuda')
             nv.call('iunet_pack_conv3', 0, nv.ptr(whi), None, nv.ptr(w16), cout, cin, taps, pm16, nv.stream())
             xh = (torch.randn(a.n * cin * vox, device='cuda') * 8).to(torch.float16)                  # hi planes
-            x8 = (torch.randn(a.n * 2 * cin * vox, device='cuda') * 2).to(torch.float8_e4m3fn).view(torch.uint8)      # m8 planes (random e4m3 bytes: timing only)
+            x8 = (torch.randn(a.n * 2 * cin * vox, device='cuda') * 2).to(torch.float8_e4m3fn).view(torch.uint8)      # lo8 planes (random e4m3 bytes: timing only)
             yh = torch.empty(a.n * cout * vox, dtype=torch.float16, device='cuda')
             y8 = torch.empty(a.n * 2 * cout * vox, dtype=torch.uint8, device='cuda')
             km = lambda: nv.call('iunet_x2m_conv_fwd', nd, nv.ptr(xh), cin * vox, nv.ptr(x8), 2 * cin * vox, nv.ptr(yh), cout * vox, -1, nv.ptr(y8), 2 * cout * vox,

@@ -85,7 +85,7 @@ python3 $R/tools/pmc_json.py $OUT $RND c3 conv3_v4_kernel 'dec0.conv1 64->32 @ 1
 python3 $R/tools/pmc_json.py $OUT $RND c5 conv3_f8k_kernel 'dec0.conv1 128->64 @ 1 x 128^3, e4m3 planes in and out, K = 128 fp8 MFMA' 402653184 1
 python3 $R/tools/pmc_json.py $OUT $RND c2 conv3_v4_kernel 'dec0.conv1 64->32 @ 8 x 512^2 f16' 402653184 8
 python3 $R/tools/pmc_json.py $OUT $RND x2 conv3_v4_kernel 'dec0.conv1 64->32 @ 1 x 128^3 fp16x2 (hi + lo planes in and out)' 805306368 1
-python3 $R/tools/pmc_json.py $OUT $RND x2m conv3_x2m_kernel 'dec0.conv1 64->32 @ 1 x 128^3 x2m (hi + m8 planes in and out)' 805306368 1
+python3 $R/tools/pmc_json.py $OUT $RND x2m conv3_x2m_kernel 'dec0.conv1 64->32 @ 1 x 128^3 x2m (hi + lo8 planes in and out: 3 bytes per element)' 603979776 1
 # 5. per-level MFMA pipe busy + HBM bytes of the stage convs (north_star: "for the 3x3 conv at each resolution level"): the 16-bit kernels and
 #    the split-precision kernel with its cross terms on the fp8 matrix cores, 3-D and 2-D
 cd $R

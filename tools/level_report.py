@@ -48,8 +48,10 @@ for f in sorted(glob.glob(os.path.join(L, 'time_*.txt'))):
     nd, n = int(nd), int(n)
     vox = int(S) ** nd * n
     alg = (int(cin) + int(cout)) * 2 * vox + int(cin) * int(cout) * 3 ** nd * (4 if wg else 2)      # activations once in, once out + the filter once (weight gradient: input + output gradient once in, dW fp32 once out)
-    if x2 or x2m:
-        alg *= 2                                                                        # hi + lo words (x2m: hi words + m8 bytes) of everything
+    if x2:
+        alg *= 2                                                                        # hi + lo words of everything
+    if x2m:
+        alg = alg * 3 // 2                                                              # hi words + lo8 bytes: 3 bytes per element
     if f8:
         alg //= 2                                                                       # one byte per activation and per weight
     traffic = (2 * fetch + write) * 1024 if fetch is not None and write is not None else None
