@@ -247,7 +247,9 @@ int iunet_x2m_conv_pool_fwd(int nd, const void* x, long long x_ss, const void* x
  * 32-channel tensor between the two convs never exists in HBM.  y / y8 (and, with py != NULL, the pooled py / py8 of
  * iunet_x2m_conv_pool_fwd) hold iunet_x2m_first_conv_fwd + iunet_x2m_conv_fwd (+ pool) bit for bit.  iunet_x2m_first_stage_fusable: 1 where
  * the library's own callers use it (2-D, one input channel, 32 channels at level 0, a batch of >= 2 048 tiles of 16 x 32 pixels: the loader
- * waves' first conv is the longer side of a tile step and the first tile's hides behind nothing; IUNET_X2M_FIRST=0: never, =2: always). */
+ * waves' first conv is the longer side of a tile step and the first tile's hides behind nothing -- and a stage whose pool does NOT ride in
+ * the second conv, iunet_x2m_pool_fusable: with first conv AND pool on the loader waves the launch measured slower than first conv + pooled
+ * conv; IUNET_X2M_FIRST=0: never, =2: always). */
 int iunet_x2m_first_stage_fusable(int nd, int cin, int c0, int N, int H, int W);
 int iunet_x2m_first_stage_fwd(const void* x, int in_dtype, const long long* in_strides, const void* fw, const void* f_oscale, const void* f_bias,
                               float act_scale, void* y, long long y_ss, int y_lo, void* y8, long long y8_ss, void* py, long long py_ss, void* py8,

@@ -1416,14 +1416,17 @@ int iunet_x2m_conv_pool_fwd(int nd, const void* x, long long x_ss, const void* x
                        Cin, Cout, epi, sat, stream);
 }
 
-/* 1 where the callers (net.hip, engine_x2.py) run the first encoder stage as ONE launch: 2-D, one input channel, 32 channels at level 0, and a
- * batch of at least 2 048 tiles of 16 x 32 pixels (8 per CU).  The loader waves' first conv is the longer side of a tile step,
- * and the first tile's has nothing to hide behind: 8 x 512^2 (16 tiles per CU) 171-181 us against 53 + 147-154 for the two launches, 128 x
- * 128^2 172-175 against 54 + 130-138, 48 x 128^2 (6 per CU) 67 against 24 + 41.  IUNET_X2M_FIRST=0: never, =2: whatever the batch (A/B switch) */
+/* 1 where the callers (net.hip, engine_x2.py) run the first encoder stage as ONE launch: 2-D, one input channel, 32 channels at level 0, a
+ * batch of at least 2 048 tiles of 16 x 32 pixels (8 per CU) -- the loader waves' first conv is the longer side of a tile step, and the
+ * first tile's has nothing to hide behind -- AND a stage whose max-pool does not ride in the second conv (iunet_x2m_pool_fusable): the
+ * callers' stage 0 always feeds a pool, and at 3 bytes per element the launch with first conv AND pool on the loader waves loses to first
+ * conv + pooled conv (8 x 512^2: 218 us against 47 + 140; 128 x 128^2: 219 against 49 + 119; without the pool in the launch 161 + 38 against
+ * 47 + 128 + 38: tools/bench_first_stage.py).  IUNET_X2M_FIRST=0: never, =2: whatever the batch and the pool (A/B and test switch) */
 int iunet_x2m_first_stage_fusable(int nd, int cin, int c0, int N, int H, int W) {
   static const int mode = getenv("IUNET_X2M_FIRST") ? atoi(getenv("IUNET_X2M_FIRST")) : 1;
   if (mode == 0 || nd != 2 || cin != 1 || c0 != 32 || N < 1 || H < 1 || W < 1) return 0;
-  return mode >= 2 || (long long)N * ((H + 15) / 16) * ((W + 31) / 32) >= 2048;
+  if (mode >= 2) return 1;
+  return !iunet_x2m_pool_fusable(nd, c0) && (long long)N * ((H + 15) / 16) * ((W + 31) / 32) >= 2048;
 }
 
 /* The FIRST ENCODER STAGE of the 2-D network as one launch (unet.py:63-69: conv 1 -> 32 + BatchNorm + ReLU, conv 32 -> 32 + BatchNorm + ReLU):

@@ -481,8 +481,8 @@ def test_first_encoder_stage_in_one_launch_is_first_conv_plus_conv_bit_for_bit(s
     w16, w8, osc, bias, _ = _prep(nv, w2, bn2)
     f = nv.lib().iunet_x2m_first_stage_fusable
     assert f(3, 1, 32, 8, 512, 512) == 0 and f(2, 2, 32, 8, 512, 512) == 0
-    if 'IUNET_X2M_FIRST' not in os.environ:          # the library's own policy: batches of >= 2 048 tiles
-        assert f(2, 1, 32, 8, 512, 512) == 1 and f(2, 1, 32, 1, 128, 128) == 0
+    if 'IUNET_X2M_FIRST' not in os.environ:          # the library's own policy: batches of >= 2 048 tiles whose pool does not ride in the second conv
+        assert f(2, 1, 32, 8, 512, 512) == (0 if nv.lib().iunet_x2m_pool_fusable(2, 32) else 1) and f(2, 1, 32, 1, 128, 128) == 0
     pv = (H // 2) * (W // 2)
     code = nv.IN_DTYPE_CODE[x.dtype]
 
@@ -516,14 +516,37 @@ def test_first_encoder_stage_in_one_launch_is_first_conv_plus_conv_bit_for_bit(s
     assert a[0].float().abs().max().item() > 0 and (a[0] == 0).float().mean().item() < 0.9
 
 
-def test_network_2d_with_the_first_stage_in_one_launch_equals_the_per_slice_forward():
-    """8 x 512^2 (4 096 tiles: iunet_x2m_first_stage_fusable says yes) runs the first encoder stage as one launch; each slice alone (512 tiles) runs
-    first conv and second conv as two.  Same logits, bit for bit -- through the Python-sequenced forward and the C++-sequenced one."""
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_FIRST_STAGE_CHILD = r'''
+import sys, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + '/interactive-unet_amd')
+from interactive_unet.engine_x2 import EngineX2
+from interactive_unet import _native as nv
+from oracle import unet_ref
+assert nv.lib().iunet_x2m_first_stage_fusable(2, 1, 32, 8, 512, 512) == 1
+p = unet_ref.init_params(dim=2, seed=3, randomize_bn=True)
+e = EngineX2(dim=2)
+e.load_eval({k: v.cuda() for k, v in p.items()})
+x = torch.randint(0, 256, (8, 1, 512, 512), generator=torch.Generator().manual_seed(5), dtype=torch.uint8).cuda()
+vox = 512 * 512
+outs = []
+for rep in range(2):                                   # second call: the C++-sequenced forward (net_graph)
+    lg = torch.empty((8, 2, 512, 512), device='cuda')
+    e.infer(x, (vox, vox, vox, 512, 1), 8, 1, 512, 512, logits=lg)
+    outs.append(lg.cpu())
+assert not e.saturated()
+torch.save(outs, sys.argv[2])
+'''
+
+
+def test_network_2d_with_the_first_stage_in_one_launch_equals_the_library_policy(tmp_path):
+    """The library's own policy runs encoder stage 0 as first conv + pooled conv (iunet_x2m_first_stage_fusable: at 3 bytes per element
+    that is the faster sequence wherever the pool rides in the conv); IUNET_X2M_FIRST=2 -- read once per process, hence the child -- runs the
+    stage as ONE launch.  Same logits, bit for bit, through the Python-sequenced forward and the C++-sequenced one; a slice alone equals its
+    row of the batch."""
+    import subprocess, sys
     from interactive_unet.engine_x2 import EngineX2
     nv = _nv()
-    f = nv.lib().iunet_x2m_first_stage_fusable
-    if not (f(2, 1, 32, 8, 512, 512) == 1 and f(2, 1, 32, 1, 512, 512) == 0):
-        pytest.skip('IUNET_X2M_FIRST overrides the policy')
     p = unet_ref.init_params(dim=2, seed=3, randomize_bn=True)
     e = EngineX2(dim=2)
     e.load_eval({k: v.cuda() for k, v in p.items()})
@@ -541,3 +564,12 @@ def test_network_2d_with_the_first_stage_in_one_launch_equals_the_per_slice_forw
         torch.cuda.synchronize()
         assert torch.equal(one[0], outs[0][i]) and torch.equal(one[0], outs[1][i])
     assert not e.saturated()
+    if os.environ.get('IUNET_X2M_FIRST') == '2':
+        return                                             # this process already ran the one-launch stage
+    out = tmp_path / 'first_stage_logits.pt'
+    env = dict(os.environ, IUNET_X2M_FIRST='2')
+    r = subprocess.run([sys.executable, '-c', _FIRST_STAGE_CHILD, ROOT, str(out)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    child = torch.load(out)
+    for k in range(2):
+        assert torch.equal(child[k], outs[k].cpu()), f'forward {k}: {int((child[k] != outs[k].cpu()).sum())} logits differ'

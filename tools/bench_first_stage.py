@@ -38,3 +38,15 @@ conv = lambda: nv.call('iunet_x2m_conv_fwd', 2, nv.ptr(a), c * vox, nv.ptr(a8), 
                        nv.ptr(w16), nv.ptr(w8), nv.ptr(osc), nv.ptr(bias), N, 1, S, S, c, c, 2, None, s)
 tf, t1, t2 = timeit(fused), timeit(first), timeit(conv)
 print(f'{N} x {S}^2: first stage in one launch {tf:.1f} us against {t1:.1f} (first conv) + {t2:.1f} (second conv) = {t1 + t2:.1f} us')
+# ... and with the stage's max-pool: what the network's encoder stage 0 runs
+pv = vox // 4
+p = torch.zeros(N * c * pv, dtype=torch.float16, device='cuda'); p8 = torch.zeros(N * 2 * c * pv, dtype=torch.uint8, device='cuda')
+fused_pool = lambda: nv.call('iunet_x2m_first_stage_fwd', nv.ptr(x), 2, st, nv.ptr(fw), nv.ptr(fosc), nv.ptr(fb), A, nv.ptr(y), c * vox, -1, nv.ptr(y8),
+                             2 * c * vox, nv.ptr(p), c * pv, nv.ptr(p8), 2 * c * pv, nv.ptr(w16), nv.ptr(w8), nv.ptr(osc), nv.ptr(bias), N, S, S, None, s)
+conv_pool = lambda: nv.call('iunet_x2m_conv_pool_fwd', 2, nv.ptr(a), c * vox, nv.ptr(a8), 2 * c * vox, nv.ptr(y), c * vox, -1, nv.ptr(y8), 2 * c * vox,
+                            nv.ptr(p), c * pv, nv.ptr(p8), 2 * c * pv, nv.ptr(w16), nv.ptr(w8), nv.ptr(osc), nv.ptr(bias), N, 1, S, S, c, c, 2, None, s)
+pool = lambda: nv.call('iunet_x2m_maxpool_fwd', 2, nv.ptr(y), c * vox, nv.ptr(y8), 2 * c * vox, nv.ptr(p), c * pv, nv.ptr(p8), 2 * c * pv, c, N, 1, S // 2,
+                       S // 2, s)
+tfp, tcp, tp = timeit(fused_pool), timeit(conv_pool), timeit(pool)
+print(f'{N} x {S}^2 with the pool: all in one launch {tfp:.1f} us; first stage + pool launch {tf:.1f} + {tp:.1f} = {tf + tp:.1f} us; '
+      f'first conv + pooled conv {t1:.1f} + {tcp:.1f} = {t1 + tcp:.1f} us; three launches {t1 + t2 + tp:.1f} us')

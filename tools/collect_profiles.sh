@@ -50,7 +50,7 @@ python3 $R/tools/bench_conv.py --dim 2 --size 512 --n 8 --dtype f16 --wgrad 0 --
 # x2m stage convs layer by layer incl. the pooled encoder convs (conv + pool in one launch against two), the 2-D first stage in one launch
 python3 $R/tools/bench_x2m.py 2 128 3 > $OUT/${RND}_x2m_layers_3d.txt 2>/dev/null
 python3 $R/tools/bench_x2m.py 8 512 2 > $OUT/${RND}_x2m_layers_2d.txt 2>/dev/null
-{ python3 $R/tools/bench_first_stage.py; python3 $R/tools/bench_first_stage.py 48 128; } > $OUT/${RND}_first_stage_2d.txt 2>/dev/null
+{ python3 $R/tools/bench_first_stage.py; python3 $R/tools/bench_first_stage.py 128 128; python3 $R/tools/bench_first_stage.py 48 128; } 2>/dev/null | grep -v amdgpu > $OUT/${RND}_first_stage_2d_with_pool.txt      # (r04_first_stage_2d.txt: the same tool before it timed the pooled combinations)
 # forward and weight gradient per stage shape: 2-D (the dy-reuse form against the first form) and 3-D at the C3 step's batch of 2
 python3 $R/tools/bench_conv.py --dim 2 --size 512 --n 8 --dtype fp16 --iters 20 > $OUT/${RND}_conv_wgrad_layers_2d.txt 2>/dev/null
 IUNET_WGRAD2D_V1=1 python3 $R/tools/bench_conv.py --dim 2 --size 512 --n 8 --dtype fp16 --iters 20 > $OUT/${RND}_conv_wgrad_layers_2d_first_form.txt 2>/dev/null
