@@ -235,8 +235,8 @@ int iunet_x2m_conv_fwd(int nd, const void* x, long long x_ss, const void* x8, lo
  * iunet_x2m_conv_fwd, and py / py8 = hi planes (py_ss elements per sample) / lo8 planes (py8_ss bytes per sample) of the pooled tensor on the
  * grid D/2 (nd = 3), H/2, W/2 -- the words iunet_x2m_maxpool_fwd makes of y / y8, bit for bit, without reading them back (2-D: pooled in the
  * consumer waves' registers; 3-D: x and y in registers, the z pair through LDS by the loader waves).  iunet_x2m_pool_fusable: 1 where the
- * library's own callers fuse a conv of C channels (3-D; 2-D except C = 64, where the pooled launch measured slower than conv + pool;
- * IUNET_X2M_POOL=0: nowhere, =2: everywhere, =3: 3-D only). */
+ * library's own callers fuse a conv of C channels (3-D and 2-D; IUNET_X2M_POOL=0: nowhere, =3: 3-D only, =4: 2-D without the 64-channel
+ * stage, the policy of the 4-byte format). */
 int iunet_x2m_pool_fusable(int nd, int C);
 int iunet_x2m_conv_pool_fwd(int nd, const void* x, long long x_ss, const void* x8, long long x8_ss, void* y, long long y_ss, int y_lo, void* y8,
                             long long y8_ss, void* py, long long py_ss, void* py8, long long py8_ss, const void* w16, const void* w8,

@@ -1393,16 +1393,17 @@ int iunet_x2m_conv_fwd(int nd, const void* x, long long x_ss, const void* x8, lo
                        Cin, Cout, epi, sat, stream);
 }
 
-/* 1 where the callers (net.hip, engine_x2.py) let the pool ride in the conv with C channels: always in 3-D (2 x 128^3, one box: 32->32 @
- * 128^3 470 us against 458 + 95 for conv + pool, 64->64 @ 64^3 189 against 180 + 21, 128->128 @ 32^3 89 against 87 + 5); in 2-D except at
- * C = 64 (8 x 512^2: 162 against 152 + 39, 72 against 67 + 13, but 64->64 @ 256^2 107-113 against 79 + 22 us: the pooled instantiation of that
- * launch -- two Cout tiles on two steps per tile -- is 13 us slower with all of its pool work switched off).  IUNET_X2M_POOL=0: never, =2:
- * everywhere, =3: 3-D only (A/B switch). */
+/* 1 where the callers (net.hip, engine_x2.py) let the pool ride in the conv with C channels: in 3-D (2 x 128^3, one box, 3 bytes per
+ * element: 32->32 @ 128^3 441 us against 441 + 92 for conv + pool, 64->64 @ 64^3 190 against 184 + 19, 128->128 @ 32^3 91 against 89 + 5) and
+ * in 2-D (8 x 512^2: 132 against 130 + 39, 64->64 @ 256^2 90 against 80 + 20, 79 against 77 + 14; at 4 bytes per element the 64-channel launch
+ * -- two Cout tiles on two steps per tile -- read 107-113 against 79 + 22 and was excluded; the whole forward with it: 1.55-1.57 against
+ * 1.56-1.57 ms at 8 x 512^2, 1.60-1.61 against 1.60-1.63 at 128 x 128^2).  IUNET_X2M_POOL=0: never, =3: 3-D only, =4: 2-D without the
+ * 64-channel stage (A/B switches; =2, the former "everywhere", is the default now). */
 int iunet_x2m_pool_fusable(int nd, int C) {
   static const int mode = getenv("IUNET_X2M_POOL") ? atoi(getenv("IUNET_X2M_POOL")) : 1;
   if (mode == 0 || (nd != 2 && nd != 3)) return 0;
-  if (nd == 3 || mode == 2) return 1;
-  return mode == 1 && C != 64;
+  if (nd == 3) return 1;
+  return mode == 3 ? 0 : mode == 4 ? C != 64 : 1;
 }
 
 /* An encoder stage's second conv (unet.py:63-69: the skip tensor) WITH the stage's 2^d max-pool riding along: y / y8 as iunet_x2m_conv_fwd,
