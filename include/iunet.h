@@ -184,6 +184,14 @@ int iunet_x2_convT_kc(int Cin);
 int iunet_x2_prep(const void* w, void* wv, void* oscale, void* bias_out, const void* gamma, const void* beta, const void* mean,
                   const void* var, const void* bias_in, float eps, float act_in, float act_out, int Cout, int Cin, int taps,
                   int transposed, int chunk, void* stream);
+/* The same preparation for EVERY operator of a network in one launch per kernel (a prediction engine that follows a training loop re-prepares
+ * ~17 operators per optimiser step: predict.py:30-35 behind trainer.py:56-63): `table` = n rows of X2PrepDesc in device memory
+ * (csrc/x2_prep_desc.h: the arguments above per row + `row0`, the running sum of Cout), `rows` = the sum of Cout.  iunet_x2_prep_batch takes
+ * the rows of iunet_x2_prep (kind = transposed, kc = chunk or iunet_x2_convT_kc), iunet_x2m_prep_batch those of iunet_x2m_prep_nd (kind 3,
+ * taps 27 / 9); feed the `out` operators to iunet_pack_batch.  Same bits as the per-layer calls. */
+int iunet_x2_prep_desc_bytes(void);
+int iunet_x2_prep_batch(const void* table, int n, int rows, void* stream);
+int iunet_x2m_prep_batch(const void* table, int n, int rows, void* stream);
 /* first conv: the caller's tensor (strides / dtype as iunet_first_conv_fwd; u8 is x / 255 correctly rounded, predict.py:30),
  * multiplied by act_scale and split -> y = split(relu?(acc * oscale + bias)) */
 int iunet_x2_first_conv_fwd(int nd, const void* x, int in_dtype, const long long* in_strides, void* y, long long y_sstride, int y_lo,

@@ -25,6 +25,7 @@
 // kind is a double buffer: while the consumers work on the 16-bit step of chunk c the loaders fill the fp8 buffers of chunk c, and
 // vice versa.  LDS: 34 816 (16-bit halo) + 30 720 (K16 operator) + 36 864 (e4m3 halo, z stride 192) + 27 648 (K128 operator) + 256.
 #include "common.h"
+#include "x2_prep_desc.h"
 #include <cstdlib>
 #include <type_traits>
 
@@ -1136,14 +1137,13 @@ __device__ __forceinline__ unsigned xm_e4m3(float v) {
   const int a = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(v, -448.0f, 448.0f), 0.f, 0, false);
   return (unsigned)a & 0xffu;
 }
-__global__ __launch_bounds__(256) void x2m_prep_kernel(const float* __restrict__ w, float* __restrict__ whi, unsigned char* __restrict__ w8,
-                                                      float* __restrict__ oscale, float* __restrict__ bias_out,
-                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                      const float* __restrict__ mean, const float* __restrict__ var, float eps,
-                                                      float act_in, float act_out, int Cout, int Cin, int taps) {
+__device__ __forceinline__ void x2m_prep_row(const float* __restrict__ w, float* __restrict__ whi, unsigned char* __restrict__ w8,
+                                             float* __restrict__ oscale, float* __restrict__ bias_out,
+                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                             const float* __restrict__ mean, const float* __restrict__ var, float eps,
+                                             float act_in, float act_out, int Cout, int Cin, int taps, int co, float* red) {
 #pragma clang fp contract(off)
-  __shared__ float red[256];
-  const int co = blockIdx.x, tid = threadIdx.x;
+  const int tid = threadIdx.x;
   float a = 1.0f;
   if (gamma) { const float s = var[co] + eps; a = gamma[co] / sqrtf(s); }
   const int n = Cin * taps;
@@ -1199,6 +1199,24 @@ __global__ __launch_bounds__(256) void x2m_prep_kernel(const float* __restrict__
     if (gamma) { const float t = mean[co] * a; b = beta[co] - t; }
     bias_out[co] = b * act_out;
   }
+}
+__global__ __launch_bounds__(256) void x2m_prep_kernel(const float* __restrict__ w, float* __restrict__ whi, unsigned char* __restrict__ w8,
+                                                      float* __restrict__ oscale, float* __restrict__ bias_out,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      const float* __restrict__ mean, const float* __restrict__ var, float eps,
+                                                      float act_in, float act_out, int Cout, int Cin, int taps) {
+  __shared__ float red[256];
+  x2m_prep_row(w, whi, w8, oscale, bias_out, gamma, beta, mean, var, eps, act_in, act_out, Cout, Cin, taps, blockIdx.x, red);
+}
+// every x2m stage conv of a table (x2_prep_desc.h, kind 3) in one launch: workgroup -> (operator, output channel)
+__global__ __launch_bounds__(256) void x2m_prep_batch_kernel(const X2PrepDesc* __restrict__ table, int n) {
+  __shared__ float red[256];
+  int i = 0;
+  while (i + 1 < n && (int)blockIdx.x >= table[i + 1].row0) ++i;
+  const X2PrepDesc d = table[i];
+  const int co = (int)blockIdx.x - d.row0;
+  if (co >= d.Cout) return;
+  x2m_prep_row(d.w, d.out, d.w8, d.oscale, d.bias_out, d.gamma, d.beta, d.mean, d.var, d.eps, d.act_in, d.act_out, d.Cout, d.Cin, d.taps, co, red);
 }
 
 // ------------------------------------------------------------------ lo8 planes of a tensor that some other kernel wrote as hi + lo words
@@ -1305,6 +1323,15 @@ int iunet_x2m_prep_nd(int nd, const void* w, void* whi, void* w8, void* oscale, 
   hipLaunchKernelGGL(x2m_prep_kernel, dim3(Cout), dim3(256), 0, (hipStream_t)stream, (const float*)w, (float*)whi, (unsigned char*)w8,
                      (float*)oscale, (float*)bias_out, (const float*)gamma, (const float*)beta, (const float*)mean, (const float*)var,
                      eps, act_in, act_out, Cout, Cin, nd == 3 ? 27 : 9);
+  IUNET_CHECK_HIP(hipGetLastError());
+  return IUNET_OK;
+}
+
+/* iunet_x2m_prep_nd for every stage conv of a device-resident table of n X2PrepDesc rows (kind 3; taps = 27 or 9) in ONE launch of `rows`
+ * workgroups (the table's running sum of Cout): the same kernel body per row, the same bits */
+int iunet_x2m_prep_batch(const void* table, int n, int rows, void* stream) {
+  IUNET_REQUIRE(table != nullptr && n > 0 && rows > 0, "x2m_prep_batch: empty table");
+  hipLaunchKernelGGL(x2m_prep_batch_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, (const X2PrepDesc*)table, n);
   IUNET_CHECK_HIP(hipGetLastError());
   return IUNET_OK;
 }

@@ -20,6 +20,7 @@
 // (BatchNorm fold in the oracle's fp32 operation order, scaling, split into the virtual fp32 operator that the ordinary pack
 // kernels then reorder), the first convolution, the max-pool, the transposed convolution and the head.
 #include "common.h"
+#include "x2_prep_desc.h"
 
 int iunet_conv3_v4_x2_launch(int nd, const void* x, long long x_sstride, int x_lo, void* y, long long y_sstride, int y_lo, const void* wpk,
                              const float* oscale, const float* bias, int N, int D, int H, int W, int Cin, int Cout, int epi,
@@ -39,14 +40,13 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 // a = gamma / sqrt(var + eps), w' = w * a, bias' = beta - mean * a (each operation rounded on its own, oracle/unet_ref.py fold_bn),
 // s = 2^k with max |w'| * s in [2^9, 2^10), w'' = w' * s (exact), hi = f16(w''), lo = f16(w'' - hi);
 // oscale = act_out / (act_in * s), bias_out = bias' * act_out (powers of two: exact).
-__global__ __launch_bounds__(256) void x2_prep_kernel(const float* __restrict__ w, float* __restrict__ wv, float* __restrict__ oscale,
-                                                     float* __restrict__ bias_out, const float* __restrict__ gamma,
-                                                     const float* __restrict__ beta, const float* __restrict__ mean,
-                                                     const float* __restrict__ var, const float* __restrict__ bias_in, float eps,
-                                                     float act_in, float act_out, int Cout, int Cin, int taps, int kind, int kc) {
+__device__ __forceinline__ void x2_prep_row(const float* __restrict__ w, float* __restrict__ wv, float* __restrict__ oscale,
+                                            float* __restrict__ bias_out, const float* __restrict__ gamma,
+                                            const float* __restrict__ beta, const float* __restrict__ mean,
+                                            const float* __restrict__ var, const float* __restrict__ bias_in, float eps,
+                                            float act_in, float act_out, int Cout, int Cin, int taps, int kind, int kc, int co, float* red) {
 #pragma clang fp contract(off)
-  __shared__ float red[256];
-  const int co = blockIdx.x, tid = threadIdx.x;
+  const int tid = threadIdx.x;
   float a = 1.0f;
   if (gamma) { const float s = var[co] + eps; a = gamma[co] / sqrtf(s); }
   const int n = Cin * taps;
@@ -98,6 +98,25 @@ __global__ __launch_bounds__(256) void x2_prep_kernel(const float* __restrict__ 
     else if (bias_in) b = bias_in[co];
     bias_out[co] = b * act_out;
   }
+}
+__global__ __launch_bounds__(256) void x2_prep_kernel(const float* __restrict__ w, float* __restrict__ wv, float* __restrict__ oscale,
+                                                     float* __restrict__ bias_out, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, const float* __restrict__ mean,
+                                                     const float* __restrict__ var, const float* __restrict__ bias_in, float eps,
+                                                     float act_in, float act_out, int Cout, int Cin, int taps, int kind, int kc) {
+  __shared__ float red[256];
+  x2_prep_row(w, wv, oscale, bias_out, gamma, beta, mean, var, bias_in, eps, act_in, act_out, Cout, Cin, taps, kind, kc, blockIdx.x, red);
+}
+// every operator of a table in one launch: workgroup -> (operator, output channel) by the table's running row count
+__global__ __launch_bounds__(256) void x2_prep_batch_kernel(const X2PrepDesc* __restrict__ table, int n) {
+  __shared__ float red[256];
+  int i = 0;
+  while (i + 1 < n && (int)blockIdx.x >= table[i + 1].row0) ++i;
+  const X2PrepDesc d = table[i];
+  const int co = (int)blockIdx.x - d.row0;
+  if (co >= d.Cout) return;
+  x2_prep_row(d.w, d.out, d.oscale, d.bias_out, d.gamma, d.beta, d.mean, d.var, d.bias_in, d.eps, d.act_in, d.act_out, d.Cout, d.Cin, d.taps,
+              d.kind, d.kc, co, red);
 }
 
 // ------------------------------------------------------------------ first conv
@@ -558,6 +577,17 @@ int iunet_x2_prep(const void* w, void* wv, void* oscale, void* bias_out, const v
                      (float*)bias_out, (const float*)gamma, (const float*)beta, (const float*)mean, (const float*)var,
                      (const float*)bias_in, eps, act_in, act_out, Cout, Cin, taps, transposed,
                      transposed ? iunet_x2_convT_kc(Cin) : chunk);
+  IUNET_CHECK_HIP(hipGetLastError());
+  return IUNET_OK;
+}
+
+/* iunet_x2_prep for every operator of a device-resident table of n X2PrepDesc rows (kinds 0..2; x2_prep_desc.h) in ONE launch of `rows`
+ * workgroups (= the table's running sum of Cout); the caller validated each row as iunet_x2_prep would (engine_x2.py builds the rows from the
+ * arguments it used to pass layer by layer).  Same kernel body per row: the same bits. */
+int iunet_x2_prep_desc_bytes(void) { return (int)sizeof(X2PrepDesc); }
+int iunet_x2_prep_batch(const void* table, int n, int rows, void* stream) {
+  IUNET_REQUIRE(table != nullptr && n > 0 && rows > 0, "x2_prep_batch: empty table");
+  hipLaunchKernelGGL(x2_prep_batch_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, (const X2PrepDesc*)table, n);
   IUNET_CHECK_HIP(hipGetLastError());
   return IUNET_OK;
 }

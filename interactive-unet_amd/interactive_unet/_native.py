@@ -74,6 +74,8 @@ _SIGS = {
     # ---- fp16x2 with the cross terms on the fp8 matrix cores (csrc/conv3_x2m.hip)
     'iunet_x2m_prep': [c_void_p] * 9 + [c_float, c_float, c_float, c_int, c_int, c_void_p],
     'iunet_x2m_prep_nd': [c_int] + [c_void_p] * 9 + [c_float, c_float, c_float, c_int, c_int, c_void_p],
+    'iunet_x2_prep_batch': [c_void_p, c_int, c_int, c_void_p],
+    'iunet_x2m_prep_batch': [c_void_p, c_int, c_int, c_void_p],
     'iunet_x2m_conv_fwd': [c_int, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_ll, c_int, c_void_p, c_ll, c_void_p, c_void_p, c_void_p, c_void_p,
                            c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     'iunet_x2m_conv_pool_fwd': [c_int, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_ll, c_int, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_ll,
@@ -203,7 +205,7 @@ _SIGS = {
                                c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
 }
 # functions that return a size / count instead of a status
-_INT_RETURN = ['iunet_pack_desc_bytes', 'iunet_augment_desc_bytes']
+_INT_RETURN = ['iunet_pack_desc_bytes', 'iunet_augment_desc_bytes', 'iunet_x2_prep_desc_bytes']
 _INT_RETURN_ARGS = {'iunet_zoom_nearest_len': [c_int, ctypes.c_double], 'iunet_x2_convT_kc': [c_int], 'iunet_x2m_head_fusable': [c_int, c_int], 'iunet_x2m_pool_fusable': [c_int, c_int], 'iunet_x2m_first_stage_fusable': [c_int] * 6, 'iunet_x2_pack_mode': [c_int], 'iunet_f8_pack_order': [c_int, c_int]}
 _LL_RETURN = {'iunet_x2m_w8_bytes': [c_int] * 2, 'iunet_x2m_w8_bytes_nd': [c_int] * 3, 'iunet_train_num_params': [c_void_p], 'iunet_train_packed_bytes': [c_void_p], 'iunet_train_workspace_bytes': [c_void_p, c_int, c_int, c_int, c_int], 'iunet_conv3_wgrad_slab_floats': [c_int] * 7, 'iunet_f32_pack_conv_elems': [c_int] * 3, 'iunet_f8_pack_conv3_bytes': [c_int] * 3, 'iunet_conv3_f8_workspace_elems': [c_int] * 7, 'iunet_pack_conv3_elems': [c_int] * 4,
               'iunet_pack_first_conv_elems': [c_int] * 3, 'iunet_slice_scatter_workspace_bytes': [c_int],
@@ -294,6 +296,43 @@ class PackTable:
 
     def run(self):
         call('iunet_pack_batch', ptr(self.dev), self.n, self.quant_max_cout, stream())
+
+
+class X2PrepDesc(ctypes.Structure):
+    """One operator of iunet_x2_prep_batch / iunet_x2m_prep_batch (mirror of csrc/x2_prep_desc.h)."""
+    _fields_ = [('w', c_void_p), ('out', c_void_p), ('w8', c_void_p), ('oscale', c_void_p), ('bias_out', c_void_p), ('gamma', c_void_p),
+                ('beta', c_void_p), ('mean', c_void_p), ('var', c_void_p), ('bias_in', c_void_p), ('eps', c_float), ('act_in', c_float),
+                ('act_out', c_float), ('Cout', c_int), ('Cin', c_int), ('taps', c_int), ('kind', c_int), ('kc', c_int), ('row0', c_int)]
+
+
+def make_x2_prep_desc(w, out, oscale, bias_out, cout, cin, taps, kind, kc, act_in, act_out, bn=None, bias_in=None, w8=None, eps=1e-5):
+    d = X2PrepDesc()
+    d.w, d.out, d.oscale, d.bias_out = w.data_ptr(), out.data_ptr(), oscale.data_ptr(), bias_out.data_ptr()
+    d.w8 = None if w8 is None else w8.data_ptr()
+    if bn is not None:
+        d.gamma, d.beta, d.mean, d.var = [t.data_ptr() for t in bn]
+    d.bias_in = None if bias_in is None else bias_in.data_ptr()
+    d.eps, d.act_in, d.act_out = eps, act_in, act_out
+    d.Cout, d.Cin, d.taps, d.kind, d.kc = cout, cin, taps, kind, kc
+    return d
+
+
+class X2PrepTable:
+    """Descriptor table of iunet_x2_prep_batch (x2m=False) / iunet_x2m_prep_batch (x2m=True) in device memory."""
+
+    def __init__(self, descs, device, x2m):
+        assert lib().iunet_x2_prep_desc_bytes() == ctypes.sizeof(X2PrepDesc), 'X2PrepDesc layout mismatch with libiunet'
+        rows = 0
+        for d in descs:
+            d.row0 = rows
+            rows += d.Cout
+        arr = (X2PrepDesc * len(descs))(*descs)
+        self.dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
+        self.n, self.rows = len(descs), rows
+        self.fn = 'iunet_x2m_prep_batch' if x2m else 'iunet_x2_prep_batch'
+
+    def run(self):
+        call(self.fn, ptr(self.dev), self.n, self.rows, stream())
 
 
 class PackedConv:

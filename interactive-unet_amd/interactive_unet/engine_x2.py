@@ -97,65 +97,100 @@ class EngineX2:
         return st
 
     def load_eval(self, params):
-        """Fold eval-mode BatchNorm (fp32, the oracle's operation order), scale, split and pack every operator.  Every buffer is
-        allocated once: a re-pack after an optimiser step is launches only (no allocation, no synchronisation)."""
+        """Fold eval-mode BatchNorm (fp32, the oracle's operation order), scale, split and pack every operator: THREE launches over
+        device-resident descriptor tables (iunet_x2_prep_batch: first conv, transposed convs and -- fp16x2 -- the stage convs;
+        iunet_x2m_prep_batch: the x2m stage convs; iunet_pack_batch: the fragment orders), rebuilt only when a source tensor moves.  Every
+        buffer is allocated once: a re-pack after an optimiser step is launches only (no allocation, no synchronisation).
+        IUNET_X2_PREP_PER_LAYER=1: the per-layer calls the tables replace (two launches per operator; same bits: tests/test_gpu_x2m.py)."""
         if not hasattr(self, '_stage'):
-            self._stage, self._bufs = {}, {}
+            self._stage, self._bufs, self._eval_sig, self._eval_tables = {}, {}, None, None
         self._gparams, self._g_dirty, self._g_fwd = params, True, 0
         dev = self.device
-        lib, s, P, A = nv.lib(), nv.stream(), {}, self.act_scale
-
-        def bufs(name, n_virtual, n_packed, co):
-            b = self._bufs.get(name)
-            if b is None:
-                b = self._bufs[name] = (torch.empty(n_virtual, dtype=torch.float32, device=dev),
-                                        torch.empty(n_packed, dtype=torch.float16, device=dev),
-                                        torch.empty(co, dtype=torch.float32, device=dev), torch.empty(co, dtype=torch.float32, device=dev))
-            return b
+        lib, A = nv.lib(), self.act_scale
+        src = {}
         for prefix in self.stage_names():
-            ci, co = self.stage_io(prefix)
-            for j, (a, b) in enumerate(((ci, co), (co, co)), 1):
-                name = f'{prefix}.conv{j}'
-                first = prefix == 'enc0' and j == 1
-                w = self._source(params, f'{name}.weight')
-                bn = [self._source(params, f'{prefix}.bn{j}.{k}') for k in ('weight', 'bias', 'running_mean', 'running_var')]
-                if self.mixed and not first:
-                    # x2m: w_hi in the padded K16 order + [w_hi8 | w_lo8] in the K128 order of the fp8 step
-                    key = name + '#m'
-                    bm = self._bufs.get(key)
-                    if bm is None:
-                        bm = self._bufs[key] = (torch.empty(b * a * self.taps, dtype=torch.float32, device=dev),
-                                                torch.empty(nv.pack_conv3_elems(b, a, self.taps, 2 if self.dim == 3 else 6), dtype=torch.float16, device=dev),
-                                                torch.zeros(lib.iunet_x2m_w8_bytes_nd(self.dim, b, a), dtype=torch.uint8, device=dev),
-                                                torch.empty(b, dtype=torch.float32, device=dev), torch.empty(b, dtype=torch.float32, device=dev))
-                    whi, w16, w8, osc, bias = bm
-                    nv.call('iunet_x2m_prep_nd', self.dim, nv.ptr(w), nv.ptr(whi), nv.ptr(w8), nv.ptr(osc), nv.ptr(bias), nv.ptr(bn[0]), nv.ptr(bn[1]),
-                            nv.ptr(bn[2]), nv.ptr(bn[3]), BN_EPS, A, A, b, a, s)
-                    # w_hi: the padded K16 order in 3-D, the cross-pair order (three k-groups per 32-channel step) in 2-D
-                    nv.call('iunet_pack_conv3', 0, nv.ptr(whi), None, nv.ptr(w16), b, a, self.taps, 2 if self.dim == 3 else 6, s)
-                    P[name] = (w16, osc, bias, w8)
-                    continue
-                pmode = lib.iunet_x2_pack_mode(self.dim)      # 2: padded K16 order (3-D); 6: compact order (2-D: the cross-pair step)
-                npk = lib.iunet_pack_first_conv_elems(b, 3 * a, self.taps) if first else nv.pack_conv3_elems(b, 3 * a, self.taps, pmode)
-                wv, dst, osc, bias = bufs(name, b * 3 * a * self.taps, npk, b)
-                nv.call('iunet_x2_prep', nv.ptr(w), nv.ptr(wv), nv.ptr(osc), nv.ptr(bias), nv.ptr(bn[0]), nv.ptr(bn[1]),
-                        nv.ptr(bn[2]), nv.ptr(bn[3]), None, BN_EPS, A, A, b, a, self.taps, 0, a if first else (16 if self.dim == 3 else 32), s)
-                if first:
-                    nv.call('iunet_pack_first_conv', 0, nv.ptr(wv), None, nv.ptr(dst), b, 3 * a, self.taps, s)
-                else:
-                    nv.call('iunet_pack_conv3', 0, nv.ptr(wv), None, nv.ptr(dst), b, 3 * a, self.taps, pmode, s)
+            for j in (1, 2):
+                src[f'{prefix}.conv{j}.weight'] = self._source(params, f'{prefix}.conv{j}.weight')
+                for k in ('weight', 'bias', 'running_mean', 'running_var'):
+                    src[f'{prefix}.bn{j}.{k}'] = self._source(params, f'{prefix}.bn{j}.{k}')
+        for l in range(self.levels - 1):
+            src[f'dec{l}.up.weight'] = self._source(params, f'dec{l}.up.weight')
+            src[f'dec{l}.up.bias'] = self._source(params, f'dec{l}.up.bias')
+        src['head.weight'] = self._source(params, 'head.weight')
+        src['head.bias'] = self._source(params, 'head.bias')
+        sig = tuple(t.data_ptr() for t in src.values())
+        if sig != self._eval_sig:
+            P, d_x2, d_x2m, d_pack, per_layer = {}, [], [], [], []
+
+            def bufs(name, n_virtual, n_packed, co):
+                b = self._bufs.get(name)
+                if b is None:
+                    b = self._bufs[name] = (torch.empty(n_virtual, dtype=torch.float32, device=dev),
+                                            torch.empty(n_packed, dtype=torch.float16, device=dev),
+                                            torch.empty(co, dtype=torch.float32, device=dev), torch.empty(co, dtype=torch.float32, device=dev))
+                return b
+            for prefix in self.stage_names():
+                ci, co = self.stage_io(prefix)
+                for j, (a, b) in enumerate(((ci, co), (co, co)), 1):
+                    name = f'{prefix}.conv{j}'
+                    first = prefix == 'enc0' and j == 1
+                    w = src[f'{name}.weight']
+                    bn = [src[f'{prefix}.bn{j}.{k}'] for k in ('weight', 'bias', 'running_mean', 'running_var')]
+                    if self.mixed and not first:
+                        # x2m: w_hi in the padded K16 order (3-D) / the cross-pair order (2-D: three k-groups per 32-channel step)
+                        # + [w_hi8 | w_lo8] in the K128 order of the fp8 step
+                        key = name + '#m'
+                        bm = self._bufs.get(key)
+                        pmode = 2 if self.dim == 3 else 6
+                        if bm is None:
+                            bm = self._bufs[key] = (torch.empty(b * a * self.taps, dtype=torch.float32, device=dev),
+                                                    torch.empty(nv.pack_conv3_elems(b, a, self.taps, pmode), dtype=torch.float16, device=dev),
+                                                    torch.zeros(lib.iunet_x2m_w8_bytes_nd(self.dim, b, a), dtype=torch.uint8, device=dev),
+                                                    torch.empty(b, dtype=torch.float32, device=dev), torch.empty(b, dtype=torch.float32, device=dev))
+                        whi, w16, w8, osc, bias = bm
+                        d_x2m.append(nv.make_x2_prep_desc(w, whi, osc, bias, b, a, self.taps, 3, 0, A, A, bn=bn, w8=w8, eps=BN_EPS))
+                        d_pack.append(nv.make_desc(whi, w16, b, a, self.taps, 1 if pmode == 2 else 6, torch.float16))
+                        per_layer.append(('iunet_x2m_prep_nd', (self.dim, nv.ptr(w), nv.ptr(whi), nv.ptr(w8), nv.ptr(osc), nv.ptr(bias), nv.ptr(bn[0]),
+                                                                nv.ptr(bn[1]), nv.ptr(bn[2]), nv.ptr(bn[3]), BN_EPS, A, A, b, a)))
+                        per_layer.append(('iunet_pack_conv3', (0, nv.ptr(whi), None, nv.ptr(w16), b, a, self.taps, pmode)))
+                        P[name] = (w16, osc, bias, w8)
+                        continue
+                    pmode = lib.iunet_x2_pack_mode(self.dim)      # 2: padded K16 order (3-D); 6: compact order (2-D: the cross-pair step)
+                    npk = lib.iunet_pack_first_conv_elems(b, 3 * a, self.taps) if first else nv.pack_conv3_elems(b, 3 * a, self.taps, pmode)
+                    wv, dst, osc, bias = bufs(name, b * 3 * a * self.taps, npk, b)
+                    kc = a if first else (16 if self.dim == 3 else 32)
+                    d_x2.append(nv.make_x2_prep_desc(w, wv, osc, bias, b, a, self.taps, 0, kc, A, A, bn=bn, eps=BN_EPS))
+                    d_pack.append(nv.make_desc(wv, dst, b, 3 * a, self.taps, 2 if first else (1 if pmode == 2 else 6), torch.float16))
+                    per_layer.append(('iunet_x2_prep', (nv.ptr(w), nv.ptr(wv), nv.ptr(osc), nv.ptr(bias), nv.ptr(bn[0]), nv.ptr(bn[1]), nv.ptr(bn[2]),
+                                                        nv.ptr(bn[3]), None, BN_EPS, A, A, b, a, self.taps, 0, kc)))
+                    if first:
+                        per_layer.append(('iunet_pack_first_conv', (0, nv.ptr(wv), None, nv.ptr(dst), b, 3 * a, self.taps)))
+                    else:
+                        per_layer.append(('iunet_pack_conv3', (0, nv.ptr(wv), None, nv.ptr(dst), b, 3 * a, self.taps, pmode)))
+                    P[name] = (dst, osc, bias)
+            for l in range(self.levels - 2, -1, -1):
+                name = f'dec{l}.up'
+                w, b0 = src[f'{name}.weight'], src[f'{name}.bias']
+                ci, co = self.ch[l + 1], self.ch[l]
+                wv, dst, osc, bias = bufs(name, 2 * ci * co * self.npos, 2 * ci * co * self.npos, co)
+                # both words once, chunked for the LDS-resident kernel
+                d_x2.append(nv.make_x2_prep_desc(w, wv, osc, bias, co, ci, self.npos, 2, lib.iunet_x2_convT_kc(ci), A, A, bias_in=b0, eps=BN_EPS))
+                d_pack.append(nv.make_desc(wv, dst, co, 2 * ci, self.npos, 3, torch.float16))
+                per_layer.append(('iunet_x2_prep', (nv.ptr(w), nv.ptr(wv), nv.ptr(osc), nv.ptr(bias), None, None, None, None, nv.ptr(b0), BN_EPS, A, A,
+                                                    co, ci, self.npos, 2, 0)))
+                per_layer.append(('iunet_pack_convT', (0, nv.ptr(wv), nv.ptr(dst), 2 * ci, co, self.npos)))
                 P[name] = (dst, osc, bias)
-        for l in range(self.levels - 2, -1, -1):
-            name = f'dec{l}.up'
-            w, b0 = self._source(params, f'{name}.weight'), self._source(params, f'{name}.bias')
-            ci, co = self.ch[l + 1], self.ch[l]
-            wv, dst, osc, bias = bufs(name, 2 * ci * co * self.npos, 2 * ci * co * self.npos, co)
-            nv.call('iunet_x2_prep', nv.ptr(w), nv.ptr(wv), nv.ptr(osc), nv.ptr(bias), None, None, None, None, nv.ptr(b0),
-                    BN_EPS, A, A, co, ci, self.npos, 2, 0, s)         # both words once, chunked for the LDS-resident kernel
-            nv.call('iunet_pack_convT', 0, nv.ptr(wv), nv.ptr(dst), 2 * ci, co, self.npos, s)
-            P[name] = (dst, osc, bias)
-        P['head'] = (self._source(params, 'head.weight').reshape(self.ncls, self.ch[0]), self._source(params, 'head.bias'))
-        self.packed = P
+            P['head'] = (src['head.weight'].reshape(self.ncls, self.ch[0]), src['head.bias'])
+            tabs = [nv.X2PrepTable(d_x2, dev, False)] + ([nv.X2PrepTable(d_x2m, dev, True)] if d_x2m else [])
+            tabs.append(nv.PackTable(d_pack, dev, sources=list(src.values())))
+            self._eval_tables, self._per_layer, self._eval_sig, self.packed = tabs, per_layer, sig, P
+        if os.environ.get('IUNET_X2_PREP_PER_LAYER'):
+            s = nv.stream()
+            for fn, args in self._per_layer:
+                nv.call(fn, *args, s)
+            return
+        for t in self._eval_tables:
+            t.run()
 
     # ------------------------------------------------------------------ workspace
     def level_dims(self, D, H, W):

@@ -573,3 +573,53 @@ def test_network_2d_with_the_first_stage_in_one_launch_equals_the_library_policy
     child = torch.load(out)
     for k in range(2):
         assert torch.equal(child[k], outs[k].cpu()), f'forward {k}: {int((child[k] != outs[k].cpu()).sum())} logits differ'
+
+
+@pytest.mark.parametrize('dim,mixed', [(3, True), (2, True), (3, False), (2, False)])
+def test_batched_operator_preparation_equals_the_per_layer_calls(dim, mixed, monkeypatch):
+    """EngineX2.load_eval re-prepares every operator of the network in three launches over descriptor tables (iunet_x2_prep_batch,
+    iunet_x2m_prep_batch, iunet_pack_batch); IUNET_X2_PREP_PER_LAYER=1 makes the two calls per operator they replace.  Same packed operators,
+    scales and biases, bit for bit -- and the tables follow the parameters in place (an optimiser step moves values, not addresses)."""
+    from interactive_unet.engine_x2 import EngineX2
+    p = {k: v.cuda() for k, v in unet_ref.init_params(dim=dim, seed=11, randomize_bn=True).items()}
+    e = EngineX2(dim=dim, mixed=mixed)
+
+    def snapshot():
+        torch.cuda.synchronize()
+        return {k: [t.clone() for t in v] for k, v in e.packed.items() if k != 'head'}
+    monkeypatch.delenv('IUNET_X2_PREP_PER_LAYER', raising=False)
+    e.load_eval(p)
+    assert len(e._eval_tables) == (3 if mixed else 2)
+    a = snapshot()
+    for k, v in e.packed.items():                   # the second pass must rewrite everything
+        if k != 'head':
+            for t in v:
+                t.zero_() if t.dtype == torch.uint8 else t.fill_(3)          # (the K = 128 operator's padding bytes stay zero)
+    monkeypatch.setenv('IUNET_X2_PREP_PER_LAYER', '1')
+    e.load_eval(p)
+    b = snapshot()
+    assert a.keys() == b.keys() and len(a) == 4 * (e.levels - 1) + 2 + (e.levels - 1)
+    for k in a:
+        for i, (u, v) in enumerate(zip(a[k], b[k])):
+            assert torch.equal(u, v), f'{k}[{i}]: {int((u != v).sum())} of {u.numel()} words differ'
+    # new values at the same addresses: the cached tables see them
+    with torch.no_grad():
+        for k, v in p.items():
+            if k.endswith('weight') and v.dim() > 1:
+                v.mul_(1.25).add_(0.01)
+    monkeypatch.delenv('IUNET_X2_PREP_PER_LAYER')
+    tabs = e._eval_tables
+    e.load_eval(p)
+    assert e._eval_tables is tabs
+    c = snapshot()
+    monkeypatch.setenv('IUNET_X2_PREP_PER_LAYER', '1')
+    for k, v in e.packed.items():
+        if k != 'head':
+            for t in v:
+                t.zero_() if t.dtype == torch.uint8 else t.fill_(5)
+    e.load_eval(p)
+    d = snapshot()
+    assert any(not torch.equal(a[k][0], c[k][0]) for k in a)
+    for k in c:
+        for i, (u, v) in enumerate(zip(c[k], d[k])):
+            assert torch.equal(u, v), f'after the update, {k}[{i}]: {int((u != v).sum())} of {u.numel()} words differ'
