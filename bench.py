@@ -541,6 +541,7 @@ def run(args, workload, rank, world, dev, dist, group):
     model = model.to(dev)
     fpv = flops_per_voxel(dim, levels, base, 1, ncls)
     legs = {'train': 0.0, 'predict': 0.0}
+    leg_events = []
     info = {}
     ops = None
 
@@ -601,14 +602,19 @@ def run(args, workload, rank, world, dev, dist, group):
         scaling = 'weak'
 
         def step(timed=False):
-            t0 = time.time()
+            # timed: the two legs by HIP events on the launch stream, no sync between them -- a sync would add the host's wake-up and
+            # enqueue latency (~0.3 ms) to the leg behind it, which the K timed steps (the host runs ahead of the GPU) never pay
+            if timed:
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+                ev[0].record()
             trainer.train_step(X, y, w, sync=False)
             if timed:
-                torch.cuda.synchronize(); t1 = time.time(); legs['train'] += t1 - t0
+                ev[1].record()
             model.engine('eval')                                            # re-packs the updated weights (BN folded)
             predict_leg()
             if timed:
-                torch.cuda.synchronize(); legs['predict'] += time.time() - t1
+                ev[2].record()
+                leg_events.append(ev)
 
     def barrier():
         if dist is not None:
@@ -643,8 +649,13 @@ def run(args, workload, rank, world, dev, dist, group):
         barrier()
         dt = max_over_ranks(time.time() - t0)
         nleg = 4 if workload != 'c4' else 1          # (2 steps read the prediction leg anywhere in 2.08-2.43 ms on one box)
+        leg_events.clear()
         for _ in range(nleg):
             step(timed=True)
+        torch.cuda.synchronize()
+        for ev in leg_events:
+            legs['train'] += ev[0].elapsed_time(ev[1]) * 1e-3
+            legs['predict'] += ev[1].elapsed_time(ev[2]) * 1e-3
         res = {'dt': dt, 'train': legs['train'] / nleg, 'predict': legs['predict'] / nleg, 'c4': None}
         if workload == 'c3' and c4_reps > 0:
             Vs = args.c4_size
