@@ -268,19 +268,21 @@ __global__ __launch_bounds__((XMTile<SMALL>::NCW * 64 + XM_NLT), 1) void conv3_x
     };
     // the other half of the fp8 step's operand, hi8 = e4m3(hi * 2^-8): made here from the 16-bit halo image of the SAME pair (in LDS since
     // the last barrier, read by the consumers' 16-bit step at the same time) -- it is a function of the hi words, so it never travels
-    auto make_hi8 = [&]() {
+    auto make_hi8 = [&]() {                                    // every read first (one LDS round trip, not one per slot), then convert + write
+      f16x8 va[DIT], vb[DIT];
+#pragma unroll
+      for (int it = 0; it < DIT; ++it) {
+        const int c = dcoord[it];
+        const int pix = c >= 0 ? ((c >> 16) * PY + ((c >> 8) & 255)) * PX + (c & 255) : 0;
+        va[it] = *(const f16x8*)(smem + OFF_A16 + pix * 16);
+        vb[it] = *(const f16x8*)(smem + OFF_A16 + PLANE16 + pix * 16);
+      }
 #pragma unroll
       for (int it = 0; it < DIT; ++it) {
         const int s = lt + it * NLT;
         if (s < NSLOT) {
-          const int c = dcoord[it];
-          u32x4 o = u32x4{0u, 0u, 0u, 0u};
-          if (c >= 0) {
-            const int pix = ((c >> 16) * PY + ((c >> 8) & 255)) * PX + (c & 255);
-            const u32x2 a = x2m_hi8(*(const f16x8*)(smem + OFF_A16 + pix * 16)), b = x2m_hi8(*(const f16x8*)(smem + OFF_A16 + PLANE16 + pix * 16));
-            o = u32x4{a[0], a[1], b[0], b[1]};
-          }
-          *(u32x4*)(smem + OFF_A8 + PLANE8 + s * 16) = o;
+          const u32x2 a = x2m_hi8(va[it]), b = x2m_hi8(vb[it]);
+          *(u32x4*)(smem + OFF_A8 + PLANE8 + s * 16) = dcoord[it] >= 0 ? u32x4{a[0], a[1], b[0], b[1]} : u32x4{0u, 0u, 0u, 0u};
         }
       }
     };
@@ -323,7 +325,9 @@ __global__ __launch_bounds__((XMTile<SMALL>::NCW * 64 + XM_NLT), 1) void conv3_x
     lds_barrier();
     for (int k = 0; k < npairs; ++k) {
       dma8(k);                                                 // consumers: 16-bit step of pair k
+#ifndef X2M_ABLATE_NO_HI8      // (tools/ab_build.sh -DX2M_ABLATE_NO_HI8: timing only, the fp8 operand's hi8 half stays stale)
       make_hi8();
+#endif
       landed();
       lds_barrier();
       if (k + 1 < npairs) dma16(k + 1);                        // consumers: fp8 step of pair k
@@ -700,14 +704,21 @@ __global__ __launch_bounds__(8 * 64 + XM_NLT, 1) void conv2_x2m_kernel(ConvX2MPa
                std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{});      // the lo8 planes of the two 16-channel blocks -> LDS planes 0, 2
     };
     // hi8 planes (LDS planes 1, 3) of the fp8 halo image from the 16-bit halo image of the same pair (see conv3_x2m_kernel)
-    auto make_hi8 = [&]() {
+    auto make_hi8 = [&]() {                                    // every read first (one LDS round trip, not one per pixel), then convert + write
+      f16x8 v[AIT][4];
+#pragma unroll
+      for (int it = 0; it < AIT; ++it) {
+        const int pix = min(lt + it * NLT, PLANE / 16 - 1);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[it][e] = *(const f16x8*)(smem + OFF_A16 + e * PLANE + pix * 16);
+      }
 #pragma unroll
       for (int it = 0; it < AIT; ++it) {
         const int pix = lt + it * NLT;
         if (pix < PLANE / 16) {
 #pragma unroll
           for (int b = 0; b < 2; ++b) {
-            const u32x2 a0 = x2m_hi8(*(const f16x8*)(smem + OFF_A16 + (2 * b) * PLANE + pix * 16)), a1 = x2m_hi8(*(const f16x8*)(smem + OFF_A16 + (2 * b + 1) * PLANE + pix * 16));
+            const u32x2 a0 = x2m_hi8(v[it][2 * b]), a1 = x2m_hi8(v[it][2 * b + 1]);
             *(u32x4*)(smem + OFF_A8 + (2 * b + 1) * PLANE + pix * 16) = u32x4{a0[0], a0[1], a1[0], a1[1]};
           }
         }
@@ -873,7 +884,9 @@ __global__ __launch_bounds__(8 * 64 + XM_NLT, 1) void conv2_x2m_kernel(ConvX2MPa
     lds_barrier();
     for (int k = 0; k < npairs; ++k) {
       dma8(k);
+#ifndef X2M_ABLATE_NO_HI8      // (tools/ab_build.sh -DX2M_ABLATE_NO_HI8: timing only, the fp8 operand's hi8 half stays stale)
       make_hi8();
+#endif
       landed();
       lds_barrier();
       if (k + 1 < npairs) dma16(k + 1);
