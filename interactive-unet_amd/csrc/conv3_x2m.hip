@@ -26,6 +26,22 @@
 // vice versa.  LDS: 34 816 (16-bit halo) + 30 720 (K16 operator) + 36 864 (e4m3 halo, z stride 192) + 27 648 (K128 operator) + 256.
 #include "common.h"
 #include "x2_prep_desc.h"
+// tools/ab_build.sh conv3_x2m.hip -DX2M_ABLATE_NO_MFMA: timing only -- every matrix instruction becomes one multiply-add on the first words of its
+// operands (the LDS reads and the loaders stay): what the kernel takes without its matrix work (what bounds the x2m kernel)
+#ifdef X2M_ABLATE_NO_MFMA
+template <typename A, typename B> __device__ __forceinline__ f32x4 x2m_ablate(const A a, const B b, f32x4 c) {
+  c[0] = fmaf(__builtin_bit_cast(float, (unsigned)__builtin_bit_cast(unsigned long long, *(const unsigned long long*)&a)),
+              __builtin_bit_cast(float, (unsigned)__builtin_bit_cast(unsigned long long, *(const unsigned long long*)&b)), c[0]);
+  return c;
+}
+#define X2M_MFMA16(a, b, c) x2m_ablate(a, b, c)
+#define X2M_MFMA128(a, b, c) x2m_ablate(a, b, c)
+#define X2M_MFMA32F8(a, b, c) x2m_ablate(a, b, c)
+#else
+#define X2M_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
+#define X2M_MFMA128(a, b, c) __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, 0, 0, 0)
+#define X2M_MFMA32F8(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a, b, c, 0, 0, 0)
+#endif
 #include <cstdlib>
 #include <type_traits>
 
@@ -286,7 +302,11 @@ __global__ __launch_bounds__((XMTile<SMALL>::NCW * 64 + XM_NLT), 1) void conv3_x
         }
       }
     };
+#ifdef X2M_ABLATE_NO_WAIT      // (timing only: the step barriers do not wait for the copies to land)
+    auto landed = [&]() {};
+#else
     auto landed = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+#endif
     // POOL: thread = (pooled voxel of the tile, 8-channel group q): the z pair of its x-y winners sits in waves w and w + 2.  Two parts:
     // pool_words reads and decodes while the step's LDS-DMA is in flight; pool_store issues the three stores AFTER the wait for that
     // DMA -- a store issued before it would sit in the same vmcnt wait and hold the step's barrier until its write came back.
@@ -324,13 +344,17 @@ __global__ __launch_bounds__((XMTile<SMALL>::NCW * 64 + XM_NLT), 1) void conv3_x
     landed();
     lds_barrier();
     for (int k = 0; k < npairs; ++k) {
+#ifndef X2M_ABLATE_NO_COPIES   // (timing only: the loader waves keep their barriers and nothing else -- the consumers alone)
       dma8(k);                                                 // consumers: 16-bit step of pair k
-#ifndef X2M_ABLATE_NO_HI8      // (tools/ab_build.sh -DX2M_ABLATE_NO_HI8: timing only, the fp8 operand's hi8 half stays stale)
+#endif
+#if !defined(X2M_ABLATE_NO_HI8) && !defined(X2M_ABLATE_NO_COPIES)      // (tools/ab_build.sh -DX2M_ABLATE_NO_HI8: timing only, the fp8 operand's hi8 half stays stale)
       make_hi8();
 #endif
       landed();
       lds_barrier();
+#ifndef X2M_ABLATE_NO_COPIES
       if (k + 1 < npairs) dma16(k + 1);                        // consumers: fp8 step of pair k
+#endif
       const bool pool_now = POOL && k > 0 && k % nchunk == 0;  // the tile that ended with pair k - 1 left its x-y winners before this barrier
       if constexpr (POOL) { if (pool_now) pool_words(k / nchunk - 1); }
       landed();
@@ -403,8 +427,8 @@ __global__ __launch_bounds__((XMTile<SMALL>::NCW * 64 + XM_NLT), 1) void conv3_x
     for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
       for (int n = 0; n < NI; ++n) {
-        acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A16f[b][dy][0], R16[b][n + dy], acc[0][n], 0, 0, 0);
-        acc[1][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A16f[b][dy][1], R16[b][n + dy], acc[1][n], 0, 0, 0);
+        acc[0][n] = X2M_MFMA16(A16f[b][dy][0], R16[b][n + dy], acc[0][n]);
+        acc[1][n] = X2M_MFMA16(A16f[b][dy][1], R16[b][n + dy], acc[1][n]);
       }
     if (reads_pending) {
       constexpr int NRD = NR + 2 + 6, MPR = (3 * NI * 2) / NRD;      // 12 LDS reads spread over 24 MFMAs
@@ -447,8 +471,8 @@ __global__ __launch_bounds__((XMTile<SMALL>::NCW * 64 + XM_NLT), 1) void conv3_x
     for (int n = 0; n < NI; ++n)
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
-        if constexpr (g < 2) acc[m][n] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A8f[sg & 1][m], R8f[g][n + dy], acc[m][n], 0, 0, 0, 0, 0, 0);
-        else acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(A8n[dy][m], R8n[n + dy], acc[m][n], 0, 0, 0);
+        if constexpr (g < 2) acc[m][n] = X2M_MFMA128(A8f[sg & 1][m], R8f[g][n + dy], acc[m][n]);
+        else acc[m][n] = X2M_MFMA32F8(A8n[dy][m], R8n[n + dy], acc[m][n]);
       }
     if constexpr (nreads >= 8) {
       constexpr int RPM = (nreads + 7) / 8;
@@ -724,7 +748,11 @@ __global__ __launch_bounds__(8 * 64 + XM_NLT, 1) void conv2_x2m_kernel(ConvX2MPa
         }
       }
     };
+#ifdef X2M_ABLATE_NO_WAIT      // (timing only: the step barriers do not wait for the copies to land)
+    auto landed = [&]() {};
+#else
     auto landed = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+#endif
     // POOL: two (pooled pixel, channel group) items per loader thread.  pool_words reads and decodes the winners' keys while the step's
     // LDS-DMA is in flight; pool_store issues the stores AFTER the wait for that DMA (a store issued before it would sit in the same
     // vmcnt wait and hold the step's barrier until its write came back).
@@ -883,13 +911,17 @@ __global__ __launch_bounds__(8 * 64 + XM_NLT, 1) void conv2_x2m_kernel(ConvX2MPa
     landed();
     lds_barrier();
     for (int k = 0; k < npairs; ++k) {
+#ifndef X2M_ABLATE_NO_COPIES
       dma8(k);
-#ifndef X2M_ABLATE_NO_HI8      // (tools/ab_build.sh -DX2M_ABLATE_NO_HI8: timing only, the fp8 operand's hi8 half stays stale)
+#endif
+#if !defined(X2M_ABLATE_NO_HI8) && !defined(X2M_ABLATE_NO_COPIES)      // (tools/ab_build.sh -DX2M_ABLATE_NO_HI8: timing only, the fp8 operand's hi8 half stays stale)
       make_hi8();
 #endif
       landed();
       lds_barrier();
+#ifndef X2M_ABLATE_NO_COPIES
       if (k + 1 < npairs) dma16(k + 1);
+#endif
       const bool pool_now = POOL && k > 0 && k % nchunk == 0;  // the tile that ended with pair k - 1 left its keys before this barrier
       if constexpr (POOL) { if (pool_now) pool_words(k / nchunk - 1); }
       landed();
@@ -950,8 +982,8 @@ __global__ __launch_bounds__(8 * 64 + XM_NLT, 1) void conv2_x2m_kernel(ConvX2MPa
     for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
       for (int n = 0; n < NI; ++n) {
-        acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A16f[b][dy][0], R16[b][n % FX][n / FX + dy], acc[0][n], 0, 0, 0);
-        acc[1][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A16f[b][dy][1], R16[b][n % FX][n / FX + dy], acc[1][n], 0, 0, 0);
+        acc[0][n] = X2M_MFMA16(A16f[b][dy][0], R16[b][n % FX][n / FX + dy], acc[0][n]);
+        acc[1][n] = X2M_MFMA16(A16f[b][dy][1], R16[b][n % FX][n / FX + dy], acc[1][n]);
       }
 #pragma unroll
     for (int i = 0; i < 12; ++i) {                            // the next group's (12 .. 14) LDS reads between the 24 MFMAs
@@ -987,7 +1019,7 @@ __global__ __launch_bounds__(8 * 64 + XM_NLT, 1) void conv2_x2m_kernel(ConvX2MPa
     for (int n = 0; n < NI; ++n)
 #pragma unroll
       for (int m = 0; m < 2; ++m)
-        acc[m][n] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A8f[b][m], R8f[b][n], acc[m][n], 0, 0, 0, 0, 0, 0);
+        acc[m][n] = X2M_MFMA128(A8f[b][m], R8f[b][n], acc[m][n]);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {                             // the next group's 12 reads between the 8 K = 128 instructions
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -1001,7 +1033,7 @@ __global__ __launch_bounds__(8 * 64 + XM_NLT, 1) void conv2_x2m_kernel(ConvX2MPa
 #pragma unroll
       for (int n = 0; n < NI; ++n)
 #pragma unroll
-        for (int m = 0; m < 2; ++m) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(A8n[bl][m], R8n[bl][n], acc[m][n], 0, 0, 0);
+        for (int m = 0; m < 2; ++m) acc[m][n] = X2M_MFMA32F8(A8n[bl][m], R8n[bl][n], acc[m][n]);
 #pragma unroll
     for (int i = 0; i < 14; ++i) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
