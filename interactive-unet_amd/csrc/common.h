@@ -217,19 +217,27 @@ __device__ __forceinline__ u32x2_t x2m_pack8(const float (&f)[8]) {
   return u32x2_t{(unsigned)a, (unsigned)b};
 }
 // this lane's 8 values r[j] (fp32, scaled by act_scale) -> hi words, lo words and its two half-granules of the m8 planes
+// (lo8 = e4m3(res * 16) by v_cvt_scalef32_pk_fp8_f32 with scale 2^-4, one instruction per pair: bit for bit res * 16 -> clamp ->
+// v_cvt_pk_fp8_f32 on every f32 pattern with |res| <= 28 -- tools/micro/cvt_scale_fp8_f32.hip walks all 2^32 -- and |res| <= 16 here, half
+// an ulp of the largest hi word.  hi8 (a function of the hi words: x2m_hi8 below) is kept for the callers that still take it.)
+__device__ __forceinline__ u32x2_t x2m_hi8(const f16x8 hi);
 __device__ __forceinline__ void x2m_split8(const float (&r)[8], f16x8& hi, f16x8& lo, u32x2_t& lo8, u32x2_t& hi8) {
-  float l4[8], h8[8];
+  typedef short s16x2 __attribute__((ext_vector_type(2)));
+  float res[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const float v = fminf(fmaxf(r[j], -65504.f), 65504.f);
     const f16 h = (f16)v;
-    const float res = v - (float)h;                            // exact in fp32
-    hi[j] = h; lo[j] = (f16)res;
-    l4[j] = res * 16.0f;
-    h8[j] = (float)h * 0.00390625f;
+    res[j] = v - (float)h;                                     // exact in fp32
+    hi[j] = h; lo[j] = (f16)res[j];
   }
-  lo8 = x2m_pack8(l4);
-  hi8 = x2m_pack8(h8);
+  s16x2 a = s16x2{0, 0}, b = s16x2{0, 0};
+  a = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(a, res[0], res[1], 0.0625f, false);
+  a = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(a, res[2], res[3], 0.0625f, true);
+  b = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(b, res[4], res[5], 0.0625f, false);
+  b = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(b, res[6], res[7], 0.0625f, true);
+  lo8 = u32x2_t{__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b)};
+  hi8 = x2m_hi8(hi);
 }
 // one element of the caller's input tensor (generic strides): 0 f32, 1 f16, 2 u8 (/ 255: predict.py:30, correctly rounded as torch's), 3 bf16
 __device__ __forceinline__ float x2_load_in(const void* p, long long off, int dt) {
