@@ -202,6 +202,13 @@ __device__ __forceinline__ void e4m3_store8(unsigned char* y, int pl8, long long
   *(u32x2_t*)(y + ((long long)(pl8 >> 1) * nvox + vox) * 16 + (pl8 & 1) * 8) = u32x2_t{lo, hi};
 }
 
+// The address of a __device__ object, taken ONCE per kernel: left to itself the compiler re-materialises a global's address at every use --
+// s_getpc + s_load from the GOT + s_waitcnt lgkmcnt(0) in front of EVERY LDS-DMA piece of the loaders' loops (the zero page of the
+// out-of-image halo) -- because a symbol address is "free" to recompute.  The empty asm makes the value opaque: it stays in two SGPRs.
+template <typename T> __device__ __forceinline__ const T* iunet_opaque_ptr(const T* p) {
+  asm volatile("" : "+s"(p));
+  return p;
+}
 // ---- "m8" planes of the split-precision forward with its cross terms on the fp8 matrix cores (conv3_x2m.hip): beside its fp16 hi
 // planes a tensor carries 2 C / 16 e4m3 planes [D][H][W][16 B], plane 2c = e4m3((v - hi) * 2^4), plane 2c + 1 = e4m3(hi * 2^-8) of the
 // 16-channel chunk c.  8 fp32 values -> 8 e4m3 bytes (round to nearest even, saturating at +-448)

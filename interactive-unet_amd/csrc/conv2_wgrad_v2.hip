@@ -91,6 +91,7 @@ __global__ __launch_bounds__(768, 1) void conv2_wgrad_v2_kernel(Wgrad2Params p) 
   };
 
   if (wave >= NCW) {
+    const unsigned* zero16 = iunet_opaque_ptr((const unsigned*)g_wg2d_zero16);      // (common.h: one address computation per kernel, not one per DMA piece)
     // ================================================================== loader waves: wave w owns channel plane w of x and YPW planes of the gradient
     const int lt = tid - NCW * 64;
     const int lw = __builtin_amdgcn_readfirstlane(lt >> 6), ll = lt & 63;
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(768, 1) void conv2_wgrad_v2_kernel(Wgrad2Params p) 
           if (xc[it] >= 0) {                                              // (the last instruction of a plane is partial: lanes past the halo skip)
             const int gy = y0 + (xc[it] >> 8) - 1, gx = x0 + (xc[it] & 255) - 1;
             const bool ok = (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
-            const void* gsrc = ok ? (const void*)(xin + ((long long)gy * p.W + gx) * 8) : (const void*)g_wg2d_zero16;
+            const void* gsrc = ok ? (const void*)(xin + ((long long)gy * p.W + gx) * 8) : (const void*)zero16;
             dma16(gsrc, __builtin_amdgcn_readfirstlane(buf + lw * PLANE_X + it * 1024));
           }
         }
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(768, 1) void conv2_wgrad_v2_kernel(Wgrad2Params p) 
           const int gy = y0 + pix / TX, gx = x0 + pix % TX;
           const bool ok = gy < p.H && gx < p.W;
           const T* dyin = (const T*)p.dy + (long long)n_img * p.dy_ss + (long long)(cobk * NPY + pl) * plane_stride;
-          const void* gsrc = ok ? (const void*)(dyin + ((long long)gy * p.W + gx) * 8) : (const void*)g_wg2d_zero16;
+          const void* gsrc = ok ? (const void*)(dyin + ((long long)gy * p.W + gx) * 8) : (const void*)zero16;
           dma16(gsrc, __builtin_amdgcn_readfirstlane(buf + OFF_Y + pl * PLANE_Y + (it % (NVOX / 64)) * 1024));
         }
       };

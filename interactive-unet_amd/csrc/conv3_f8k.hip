@@ -109,6 +109,7 @@ __global__ __launch_bounds__((F8KTile<SMALL>::NCW * 64 + f8k_loader_threads(IN8)
   if (tid < 64) ((float*)(smem + OFF_E))[tid] = tid < 32 ? p.wscale[cob * 32 + tid] : (p.epi != 0 ? p.bias[cob * 32 + tid - 32] : 0.f);
 
   if (wave >= NCW) {
+    const unsigned* zero16 = iunet_opaque_ptr((const unsigned*)g_f8k_zero16);      // (common.h: one address computation per kernel, not one per DMA piece)
     // ================================================================== loader waves
     const int lt = tid - NCW * 64;
     const int lw = __builtin_amdgcn_readfirstlane(lt >> 6);
@@ -160,7 +161,7 @@ __global__ __launch_bounds__((F8KTile<SMALL>::NCW * 64 + f8k_loader_threads(IN8)
             const long long goff = (((long long)gz * p.H + gy) * p.W + gx) * 16;
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-              const unsigned char* gsrc = ok ? xc + e * plane16 + goff : (const unsigned char*)g_f8k_zero16;
+              const unsigned char* gsrc = ok ? xc + e * plane16 + goff : (const unsigned char*)zero16;
               const unsigned dst = __builtin_amdgcn_readfirstlane(abuf + e * PLANE + base * 16);
               unsigned keep;
               asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"

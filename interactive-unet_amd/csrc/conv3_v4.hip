@@ -229,6 +229,7 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + v4_loader_threads(ND
   }
 
   if (wave >= NCW) {
+    const unsigned* zero16 = iunet_opaque_ptr((const unsigned*)g_v4_zero16);      // (common.h: one address computation per kernel, not one per DMA piece)
     // ================================================================== loader waves
     const int lt = tid - NCW * 64;
     int pcoord[AIT];
@@ -308,7 +309,7 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + v4_loader_threads(ND
           if (pix < PLANE / 16) {                                             // (2-D: the last instruction would run past the plane)
 #pragma unroll
             for (int k = 0; k < CP; ++k) {
-              const u32x4* gsrc = ok ? (const u32x4*)(xc + k * plane_stride + goff) : (const u32x4*)g_v4_zero16;
+              const u32x4* gsrc = ok ? (const u32x4*)(xc + k * plane_stride + goff) : (const u32x4*)zero16;
               const unsigned dst = __builtin_amdgcn_readfirstlane(abuf + k * PLANE + base * 16);
               unsigned keep;
               asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"

@@ -99,6 +99,7 @@ __global__ __launch_bounds__(768, 1) void conv3_wgrad_v2_kernel(WgradV2Params p)
   auto fresh = [&](int k) { return k == 0 || (t_begin + k) % p.tilesZ == 0; };      // first tile of a z column (or of the run)
 
   if (wave >= NCW) {
+    const unsigned* zero16 = iunet_opaque_ptr((const unsigned*)g_wg2_zero16);      // (common.h: one address computation per kernel, not one per DMA piece)
     // ================================================================== loader waves
     const int lt = tid - NCW * 64;
     if (p.x_scale == nullptr && !(p.dbg & 4)) {
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(768, 1) void conv3_wgrad_v2_kernel(WgradV2Params p)
             if (xcd[j] >= 0) {
               const int gy = y0 + (xcd[j] >> 8) - 1, gx = x0 + (xcd[j] & 255) - 1;
               const bool ok = (unsigned)gz < (unsigned)p.D && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
-              const void* gsrc = ok ? (const void*)(xin + (((long long)gz * p.H + gy) * p.W + gx) * 8) : (const void*)g_wg2_zero16;
+              const void* gsrc = ok ? (const void*)(xin + (((long long)gz * p.H + gy) * p.W + gx) * 8) : (const void*)zero16;
               dma16(gsrc, __builtin_amdgcn_readfirstlane(lds0 + lw * PLANE_X + slot * (ZPIX * 16) + j * 1024));
             }
           }
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(768, 1) void conv3_wgrad_v2_kernel(WgradV2Params p)
         for (int j = 0; j < 4; ++j) {
           const int gz = z0 + (ycd[j] >> 16), gy = y0 + ((ycd[j] >> 8) & 255), gx = x0 + (ycd[j] & 255);
           const bool ok = gz < p.D && gy < p.H && gx < p.W;
-          const void* gsrc = ok ? (const void*)(dyin + (((long long)gz * p.H + gy) * p.W + gx) * 8) : (const void*)g_wg2_zero16;
+          const void* gsrc = ok ? (const void*)(dyin + (((long long)gz * p.H + gy) * p.W + gx) * 8) : (const void*)zero16;
           dma16(gsrc, __builtin_amdgcn_readfirstlane(lds0 + OFF_Y + (k & 1) * YBUF + lw * PLANE_Y + j * 1024));
         }
       };

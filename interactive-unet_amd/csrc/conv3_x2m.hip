@@ -207,6 +207,7 @@ __global__ __launch_bounds__((XMTile<SMALL>::NCW * 64 + XM_NLT), 1) void conv3_x
   }
 
   if (wave >= NCW) {
+    const unsigned* zero16 = iunet_opaque_ptr((const unsigned*)g_xm_zero16);      // (common.h: one address computation per kernel, not one per DMA piece)
     // ================================================================== loader waves: everything global -> LDS without registers
     const int lt = tid - NCW * 64;
     const int lw = __builtin_amdgcn_readfirstlane(lt >> 6);
@@ -258,7 +259,7 @@ __global__ __launch_bounds__((XMTile<SMALL>::NCW * 64 + XM_NLT), 1) void conv3_x
           if (pix < PLANE16 / 16) {
 #pragma unroll
             for (int e = 0; e < 2; ++e)
-              dma_piece(ok ? (const unsigned char*)(xc + e * plane_stride + goff) : (const unsigned char*)g_xm_zero16,
+              dma_piece(ok ? (const unsigned char*)(xc + e * plane_stride + goff) : (const unsigned char*)zero16,
                         __builtin_amdgcn_readfirstlane(lds0 + OFF_A16 + e * PLANE16 + base * 16));
           }
         }
@@ -278,7 +279,7 @@ __global__ __launch_bounds__((XMTile<SMALL>::NCW * 64 + XM_NLT), 1) void conv3_x
           const int gz = z0 + (c >> 16) - 1, gy = y0 + ((c >> 8) & 255) - 1, gx = x0 + (c & 255) - 1;
           const bool ok = c >= 0 && (unsigned)gz < (unsigned)p.D && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
           const long long goff = (((long long)gz * p.H + gy) * p.W + gx) * 16;
-          dma_piece(ok ? xc + goff : (const unsigned char*)g_xm_zero16, __builtin_amdgcn_readfirstlane(lds0 + OFF_A8 + base * 16));
+          dma_piece(ok ? xc + goff : (const unsigned char*)zero16, __builtin_amdgcn_readfirstlane(lds0 + OFF_A8 + base * 16));
         }
       }
     };
@@ -668,6 +669,7 @@ __global__ __launch_bounds__(8 * 64 + XM_NLT, 1) void conv2_x2m_kernel(ConvX2MPa
   }
 
   if (wave >= NCW) {
+    const unsigned* zero16 = iunet_opaque_ptr((const unsigned*)g_xm_zero16);      // (common.h: one address computation per kernel, not one per DMA piece)
     // ================================================================== loader waves (LDS-DMA only)
     const int lt = tid - NCW * 64;
     const int lw = __builtin_amdgcn_readfirstlane(lt >> 6);
@@ -703,7 +705,7 @@ __global__ __launch_bounds__(8 * 64 + XM_NLT, 1) void conv2_x2m_kernel(ConvX2MPa
           if (pix < PLANE / 16) {
 #pragma unroll
             for (int e = 0; e < NPL; ++e)
-              dma_piece(ok ? src + e * plane16b + goff : (const unsigned char*)g_xm_zero16,
+              dma_piece(ok ? src + e * plane16b + goff : (const unsigned char*)zero16,
                         __builtin_amdgcn_readfirstlane(lds0 + off + e * STEP * PLANE + base * 16));
           }
         }
