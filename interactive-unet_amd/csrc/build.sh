@@ -10,7 +10,12 @@ FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-result -Wno-int-to
 pids=()
 for f in "$HERE"/*.hip; do
   o="$HERE/obj/$(basename "${f%.hip}").o"
-  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ "$HERE/common.h" -nt "$o" ]; then
+  stale=0
+  if [ ! -f "$o" ] || [ "$f" -nt "$o" ]; then stale=1; fi
+  for h in "$HERE"/*.h; do                      # any shared header (common.h, pack_desc.h, x2_prep_desc.h ...) newer than the object
+    if [ "$h" -nt "$o" ]; then stale=1; fi
+  done
+  if [ "$stale" = 1 ]; then
     hipcc $FLAGS -c "$f" -o "$o" &
     pids+=($!)
   fi
