@@ -109,7 +109,8 @@ def pmc_traffic(workload, tiles=1):
     """HBM bytes per launch of the roofline kernel from the committed PMC profile (rocprofv3 cannot run inside the timed
     process): FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate passes, scaled to the tiles of the launch.  None where
     no profile is committed."""
-    for name in (f'r04_pmc_{workload}_dec0conv1.json', 'r04_pmc_c3_dec0conv1.json' if workload == 'c4' else '',
+    for name in (f'r05_pmc_{workload}_dec0conv1.json', 'r05_pmc_c3_dec0conv1.json' if workload == 'c4' else '',
+                 f'r04_pmc_{workload}_dec0conv1.json', 'r04_pmc_c3_dec0conv1.json' if workload == 'c4' else '',
                  f'r03_pmc_{workload}_dec0conv1.json', 'r03_pmc_c3_dec0conv1.json' if workload == 'c4' else ''):
         try:
             with open(os.path.join(ROOT, 'profiles', name)) as f:
@@ -270,12 +271,22 @@ def native_parity(model, cfg, chunk_u8):
         outs.append((lg, cl))
     torch.cuda.synchronize()
     (lg, cl), (lg32, cl32) = outs[:2]
+    top2 = torch.topk(lg32, 2, dim=1).values
+    margin = (top2[:, 0] - top2[:, 1]).reshape(1, vox)                 # top-2 margin of the fp32 mode: a mismatch inside 2 x err is a tie
+
+    def band(err, mism):
+        """(voxels whose fp32 margin is <= 2 err: the tie band, mismatches outside it: must be 0)"""
+        return int((margin <= 2 * err).sum()), int((mism & (margin > 2 * err)).sum())
+    err = float((lg - lg32).abs().max())
     res = {'tile': list(shape), 'dtype_vs': 'native fp32 parity mode (engine_f32, f32-input MFMA)',
-           'max_abs_logit_vs_fp32': float((lg - lg32).abs().max()), 'logit_scale': float(lg32.abs().max()),
+           'max_abs_logit_vs_fp32': err, 'logit_scale': float(lg32.abs().max()),
            'argmax_mismatch': int((cl != cl32).sum()), 'voxels': vox}
+    res['tie_band_voxels'], res['argmax_mismatch_outside_tie_band'] = band(err, cl != cl32)
     for nm, (lgx, clx) in zip(names, outs[2:]):
-        res[f'{nm}_max_abs_logit_vs_fp32'] = float((lgx - lg32).abs().max())
+        e = float((lgx - lg32).abs().max())
+        res[f'{nm}_max_abs_logit_vs_fp32'] = e
         res[f'{nm}_argmax_mismatch'] = int((clx != cl32).sum())
+        res[f'{nm}_tie_band_voxels'], res[f'{nm}_argmax_mismatch_outside_tie_band'] = band(e, clx != cl32)
     del engs
     return res, lg32
 
@@ -343,7 +354,11 @@ def cpu_baseline(cfg, model=None, chunk_u8=None):
         chk = {'sample': f'{"x".join(map(str, shp))} crop of a bench tile, current weights'}
         modes = [(cfg['dtype'], model.engine('eval')), ('fp32_mode', e32)]
         if not cfg['wq']:
+            from interactive_unet.engine_auto import EngineAuto
             from interactive_unet.engine_x2 import EngineX2
+            ea = EngineAuto(dim, levels, base, 1, ncls, model.device)        # what UNet() predicts in: the calibrated choice
+            ea.load_eval(model.named_tensors())
+            modes.append(('default_mode', ea))
             for nm, mixed in (('fp16x2', False), ('x2m', True)):
                 ex2 = EngineX2(dim, levels, base, 1, ncls, model.device, mixed=mixed)
                 ex2.load_eval(model.named_tensors())
@@ -356,10 +371,17 @@ def cpu_baseline(cfg, model=None, chunk_u8=None):
             err = float((lg.cpu() - ref).abs().max())
             mism = cl.cpu().long().reshape(-1) != ref.argmax(1).reshape(-1)
             chk[f'{name}_max_abs_logit_vs_cpu_fp32'] = err
+            if name == 'default_mode':
+                chk['default_mode_selection'] = e.describe()
             chk[f'{name}_argmax_mismatch'] = int(mism.sum())
-            if mism.any():       # are the mismatches ties of the oracle (its own top-2 margin within twice the measured error)?
-                top2 = torch.topk(ref, 2, dim=1).values
-                chk[f'{name}_largest_oracle_margin_at_a_mismatch'] = float((top2[:, 0] - top2[:, 1]).reshape(-1)[mism].max())
+            # the tie band of the oracle (voxels whose own top-2 margin is within twice the measured error) next to the mismatch count
+            # (VERDICT r4 item 1d): a mismatch inside it is a tie, one outside it would be a wrong class
+            top2 = torch.topk(ref, 2, dim=1).values
+            mg = (top2[:, 0] - top2[:, 1]).reshape(-1)
+            chk[f'{name}_tie_band_voxels'] = int((mg <= 2 * err).sum())
+            chk[f'{name}_argmax_mismatch_outside_tie_band'] = int((mism & (mg > 2 * err)).sum())
+            if mism.any():
+                chk[f'{name}_largest_oracle_margin_at_a_mismatch'] = float(mg[mism].max())
         chk['voxels'] = nvox
     return out, chk
 
@@ -470,16 +492,31 @@ def main():
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
+        import datetime
         import torch.distributed as dist
+        # a mismatched exchange schedule must end the run with a non-zero exit, not hang it: every collective / point-to-point wait of
+        # the job fails after IUNET_BENCH_TIMEOUT_S seconds (default 300)
+        tmo = datetime.timedelta(seconds=float(os.environ.get('IUNET_BENCH_TIMEOUT_S', '300')))
         if backend == 'nccl':
-            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+            os.environ.setdefault('TORCH_NCCL_ASYNC_ERROR_HANDLING', '1')
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local), timeout=tmo)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=tmo)
     group = dist.group.WORLD if dist else None
     dev = torch.device('cuda', local)
+    ranks_seen = 1
+    if dist is not None:
+        # proof that the communicator carries `world` ranks: an all-reduce of ones, reported as `rccl_ranks`
+        one = torch.ones(1, device=dev)
+        dist.all_reduce(one)
+        ranks_seen = int(one.item())
+        if ranks_seen != world:
+            sys.exit(f'bench.py: the all-reduce of ones over the process group returned {ranks_seen}, expected {world}')
 
     out = run(args, args.workload, rank, world, dev, dist, group)
     if out is not None and rank == 0:
+        out['rccl_ranks'] = ranks_seen if (dist is not None and backend == 'nccl') else None
+        out['process_group'] = {'backend': backend if dist is not None else None, 'ranks_seen_by_all_reduce': ranks_seen}
         if world == 1 and args.workload == 'c3' and not args.no_extras:
             # the other single-GPU configurations of BASELINE.json in the SAME driver-run line, as compact sub-objects
             # (10 steps each; the full lines of those workloads are `--workload c2 / c5`)
@@ -705,6 +742,7 @@ def run(args, workload, rank, world, dev, dist, group):
     if compliant:
         set_predict_mode('fp16x2')
     head = timed_region(args.c4_reps)
+    selection = model.engine('eval').describe() if compliant and hasattr(model.engine('eval'), 'describe') else None
     dt = head['dt']
     value = (train_vox + unique_vox) * args.steps / dt
     c4 = head['c4']
@@ -775,13 +813,15 @@ def run(args, workload, rank, world, dev, dist, group):
         out['legs'] = leg_fields(head)
         if c4 is not None:
             out['c4'] = c4
-        x2m_on = compliant and os.environ.get('IUNET_X2M', '1') != '0'      # (EngineX2's default)
+        x2m_on = compliant and selection is not None and selection['form'] == 'x2m'      # the form engine_auto.EngineAuto selected
         x2_name = ('fp16x2 with the cross terms on the fp8 matrix cores (x2m: x_hi w_hi on v_mfma_f32_16x16x32_f16 + [x_lo8 | x_hi8][w_hi8 | w_lo8] on '
                    'v_mfma_f32_16x16x128_f8f6f4, fp32 accumulate)') if x2m_on else 'fp16x2 (split precision: fp16 hi + lo words, fp32 accumulate)'
         if compliant:
             out['headline_mode'] = (f'compliant pairing: training {cfg["dtype"]} (trainer.py:59 trains under 16-mixed) + prediction {x2_name}: logits within '
                                     f'1e-3 of the CPU fp32 path (predict.py:30-35 predicts in fp32); the all-16-bit step is `throughput_mode`')
-            out['config']['predict_dtype'] = 'fp16x2 (x2m)' if x2m_on else 'fp16x2'
+            # the form the default engine SELECTED for this model (x2m against fp16x2 on a calibration tile; engine_auto.py) and the figure behind it
+            out['config']['predict_dtype'] = f"fp16x2 ({selection['form']})" if selection else 'fp16x2'
+            out['config']['predict_mode_selection'] = selection
             if predict_events:
                 ps = conv_roofline_in_situ(nv, cfg, workload, torch.float16, predict_events[:400])
                 ps.pop('traffic', None)

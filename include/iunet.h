@@ -373,6 +373,11 @@ int iunet_div_f32(void* p, long long n, float d, void* stream);
 /* class map -> colours (predict.py:41-45 + utils.py:351-357): out_rgb uint8 [n][3] = palette[cls[i]], palette uint8
  * [ncls][3] on the device, classes >= ncls black. */
 int iunet_colorize(const void* cls, long long n, const void* palette, int ncls, void* out_rgb, void* stream);
+/* Calibration of the default prediction mode (the reference predicts in fp32, predict.py:30-35; north star: logits within 1e-3):
+ * out2[0] = max |a - b|, out2[1] = max |a| of two fp32 logit tensors of n elements (device floats, overwritten; NaN if either
+ * holds one).  interactive_unet/engine_auto.py runs one tile through the x2m and the fp16x2 forward and keeps x2m iff
+ * out2[0] <= its threshold (4e-4). */
+int iunet_logit_diff(const void* a, const void* b, long long n, void* out2, void* stream);
 
 /* ---- oblique slices (slicer.py:94-115, :196-228; SURVEY 8f "Slicer on device") ----------- */
 /* out[i][j] (uint8 [sw][sw]) = map_coordinates(vol[lo : lo + len], origin + a * r_i + b * r_j - lo, order, mode

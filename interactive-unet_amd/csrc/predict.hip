@@ -2,6 +2,7 @@
 // float32 accumulators `pred` / `weight` live in HBM instead of in temporary Zarr
 // arrays on disk.  All kernels are HBM-bound byte / float32 streaming work.
 #include "common.h"
+#include <algorithm>
 
 namespace {
 
@@ -79,9 +80,47 @@ __global__ __launch_bounds__(256) void colorize_kernel(const unsigned char* __re
   out[i * 3] = r; out[i * 3 + 1] = g; out[i * 3 + 2] = b;
 }
 
+// Calibration figure of the default prediction mode (engine_auto.py): out[0] = max |a - b|, out[1] = max |a| over two fp32 logit
+// tensors of one shape.  Non-negative floats order like their bit patterns, so the reduction is an integer atomicMax (exact,
+// order-independent); NaN patterns sort above every finite value and therefore surface as a NaN result.
+__global__ __launch_bounds__(256) void logit_diff_kernel(const float* __restrict__ a, const float* __restrict__ b, long long n,
+                                                        unsigned int* __restrict__ out) {
+  float d = 0.f, m = 0.f;
+  unsigned int dn = 0u, mn = 0u;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float x = a[i], y = b[i];
+    const float e = fabsf(x - y), s = fabsf(x);
+    if (e != e) dn = 0x7fc00000u;
+    if (s != s) mn = 0x7fc00000u;
+    d = fmaxf(d, e);
+    m = fmaxf(m, s);
+  }
+  unsigned int du = max(__float_as_uint(d), dn), mu = max(__float_as_uint(m), mn);
+  for (int o = 32; o > 0; o >>= 1) {
+    du = max(du, (unsigned int)__shfl_xor((int)du, o));
+    mu = max(mu, (unsigned int)__shfl_xor((int)mu, o));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMax(out, du);
+    atomicMax(out + 1, mu);
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+// max |a - b| and max |a| of two fp32 tensors of n elements -> out[0], out[1] (device floats, overwritten).  The selection rule of the
+// default prediction mode compares the logits of the x2m and the fp16x2 forward of one calibration tile with it.
+int iunet_logit_diff(const void* a, const void* b, long long n, void* out2, void* stream) {
+  IUNET_REQUIRE(a && b && out2 && n > 0, "logit_diff: null pointer or empty tensor");
+  IUNET_CHECK_HIP(hipMemsetAsync(out2, 0, 8, (hipStream_t)stream));
+  const unsigned grid = (unsigned)std::min<long long>((n + 255) / 256, 2048);
+  hipLaunchKernelGGL(logit_diff_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)a, (const float*)b, n,
+                     (unsigned int*)out2);
+  IUNET_CHECK_HIP(hipGetLastError());
+  return IUNET_OK;
+}
 
 // predict.get_padded_block (predict.py:291-316) on a device-resident uint8 volume.
 int iunet_gather_block(const void* vol, int Vz, int Vy, int Vx, int i0, int j0, int k0, int S, void* out, void* stream) {

@@ -95,6 +95,7 @@ _SIGS = {
     'iunet_x2m_conv3_fwd': [c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_ll, c_int, c_void_p, c_ll, c_void_p, c_void_p, c_void_p, c_void_p,
                             c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     # ---- handle level (csrc/net.hip): the whole forward sequenced in C++
+    'iunet_logit_diff': [c_void_p, c_void_p, c_ll, c_void_p, c_void_p],
     'iunet_net_create': [c_int, c_int, c_int, c_int, c_int, c_int, c_float, ctypes.POINTER(c_void_p)],
     'iunet_net_num_tensors': [c_void_p],
     'iunet_net_param': [c_void_p, c_int, ctypes.c_char_p, c_int, ctypes.POINTER(c_ll), ctypes.POINTER(c_ll)],

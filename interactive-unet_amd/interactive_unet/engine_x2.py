@@ -13,8 +13,11 @@ next operator's accumulator scale).
 
 `mixed` (the default; IUNET_X2M=0 switches it off): the stage convs evaluate the two cross terms of a split product
 (x_lo w_hi, x_hi w_lo: 2^-11 of it) on the K = 128 fp8 matrix instruction -- two matrix-step units per 16 input channels instead of
-three (csrc/conv3_x2m.hip).  A tensor a 3x3x3 conv reads then carries hi planes + "m8" planes (e4m3 of the residual and of the hi
-word, 2 bytes per element); the lo planes exist only where a transposed conv or the head reads (the last conv of a stage).
+three (csrc/conv3_x2m.hip).  A tensor a 3x3x3 conv reads then carries hi planes + lo8 planes (e4m3 of the residual: 1 byte per element, 3 in
+all; the e4m3 image of the hi word is made in LDS by the conv's loader waves and never stored); the lo planes exist only where a
+transposed conv or the head reads (the last conv of a stage).
+
+Which of the two forms a model predicts in is decided by engine_auto.EngineAuto (a calibration of x2m against fp16x2 on one tile).
 """
 import ctypes
 import os
@@ -105,6 +108,7 @@ class EngineX2:
         if not hasattr(self, '_stage'):
             self._stage, self._bufs, self._eval_sig, self._eval_tables = {}, {}, None, None
         self._gparams, self._g_dirty, self._g_fwd = params, True, 0
+        self.reset_saturation()
         dev = self.device
         lib, A = nv.lib(), self.act_scale
         src = {}
@@ -207,9 +211,11 @@ class EngineX2:
         if ws is None:
             self.check_shape(D, H, W)
             dims = self.level_dims(D, H, W)
-            mk = lambda c, v: torch.empty(N * 2 * c * v, dtype=torch.float16, device=self.device)     # hi + lo planes
-            mk8 = lambda c, v: torch.empty(N * c * v, dtype=torch.uint8, device=self.device)          # lo8 planes: 1 byte per element (hi8 is made in LDS from the hi words)
-            mkh = lambda c, v: torch.empty(N * c * v, dtype=torch.float16, device=self.device)        # hi planes only
+            # (zero-filled once: buffers the current launch sequence skips -- b0 behind the fused head, a0 behind the one-launch first
+            #  stage -- must not show up as garbage in max_stored(); the workspaces are cached, the fill is not on the hot path)
+            mk = lambda c, v: torch.zeros(N * 2 * c * v, dtype=torch.float16, device=self.device)     # hi + lo planes
+            mk8 = lambda c, v: torch.zeros(N * c * v, dtype=torch.uint8, device=self.device)          # lo8 planes: 1 byte per element (hi8 is made in LDS from the hi words)
+            mkh = lambda c, v: torch.zeros(N * c * v, dtype=torch.float16, device=self.device)        # hi planes only
             ws = {'dims': dims}
             for l in range(self.levels):
                 v = _vox(dims[l])
@@ -419,8 +425,15 @@ class EngineX2:
                     m = max(m, float(t.abs().max()))
         return m
 
+    def reset_saturation(self):
+        """Lower the range flags (this engine's and the C++ graph's workspaces'): `saturated()` then answers for the forwards that follow.
+        load_eval calls it (new weights: what an earlier network did says nothing), predict_volumes per volume."""
+        self._sat.zero_()
+        if self._g is not None:
+            self._g.reset_saturation()
+
     def saturated(self):
-        """Did an activation saturate (a host-synchronising diagnostic, one 4-byte read)?  EVERY forward since the engine was made raises
+        """Did an activation saturate (a host-synchronising diagnostic, one 4-byte read)?  EVERY forward since reset_saturation() raises
         an on-device flag in its producers' epilogues (first conv, stage convs, transposed convs; atomicMax of the saturated word's bit
         pattern, nothing on the hot path), whichever sequence -- Python or the C++ graph -- ran it: the answer covers every block of a
         volume, not the last one.  `max_stored()` still scans the last forward's tensors for the value itself."""

@@ -69,9 +69,14 @@ class NetGraph:
                 ws[:256].zero_()           # the range flag of the split-precision forward (csrc/net.hip: ws_layout)
         return ws
 
+    def reset_saturation(self):
+        for ws in self._ws.values():
+            if self.mode >= 2:
+                ws[:4].zero_()
+
     def saturated(self):
         """modes 2 / 3: did any forward on any of this handle's workspaces store a saturated (|act_scale x activation| >= 65504) hi word?
-        One small device-to-host read per workspace; the flags are cumulative since the workspace was made."""
+        One small device-to-host read per workspace; the flags are cumulative since the workspace was made / reset_saturation()."""
         return self.mode >= 2 and any(int(ws[:4].view(torch.int32).item()) >= 0x7bff for ws in self._ws.values())
 
     def infer(self, x, x_strides, N, D, H, W, logits=None, probs=None, cls=None, out_strides=None, divisor=1.0, accumulate=False):

@@ -194,7 +194,12 @@ def predict_block(model, block, num_classes=2, batch_size=8, axes=[0, 1, 2]):
     blk = block.to(dev, torch.float32).contiguous()
     S = blk.shape[0]
     out = torch.empty((S, S, S, num_classes), dtype=torch.float32, device=dev)
-    predict_block_device(model, blk, out, num_classes, batch_size, axes)
+    eng = model.engine('eval')
+    run = lambda: predict_block_device(model, blk, out, num_classes, batch_size, axes)
+    if hasattr(eng, 'run_checked'):
+        eng.run_checked(run)
+    else:
+        run()
     return out.cpu().numpy()
 
 
@@ -252,7 +257,11 @@ def predict_slice(image_slice, num_channels=1, num_classes=2, return_probabiliti
     cls = torch.empty((1, H * W), dtype=torch.uint8, device=device)
     if x.dtype != torch.uint8:
         x = (x.to(torch.float32) / 255).contiguous()
-    eng.infer(x, (H * W, H * W, H * W, W, 1), 1, 1, H, W, probs=probs, cls=cls)
+    run = lambda: eng.infer(x, (H * W, H * W, H * W, W, 1), 1, 1, H, W, probs=probs, cls=cls)
+    if hasattr(eng, 'run_checked'):
+        eng.run_checked(run)            # default mode: a forward whose activations left the fp16 range is re-run in a wider form
+    else:
+        run()
     if return_probabilities:
         return np.moveaxis(probs.cpu().numpy(), 1, -1)
     if num_classes < eng.ncls:                         # argmax over the first num_classes only (rare: host path)
@@ -329,11 +338,11 @@ def predict_volumes(input_size=256, num_channels=1, num_classes=2, overlap=0.25,
         for f in np.sort(glob.glob('data/image_volumes/*.zarr')):
             start = time.time()
             volume = zarr3.open(f, mode='r')['0'].to_device(device)
-            final = predict_volume_array(model, volume, input_size, num_classes, overlap, batch_size, axes)
             eng = model.engine('eval')
-            if getattr(eng, 'saturated', None) is not None and eng.saturated():      # split precision keeps act_scale x activation in fp16
-                print(f'WARNING: activations of this model exceed the fp16x2 range (stored {eng.max_stored():.0f}): predict with '
-                      f"UNet(infer_dtype='fp32') or a smaller act_scale")
+            run = lambda: predict_volume_array(model, volume, input_size, num_classes, overlap, batch_size, axes)
+            # split precision keeps act_scale x activation in fp16: the range flag covers every block of the volume; a volume whose
+            # activations left that range is predicted again in a wider form (engine_auto.EngineAuto.run_checked) -- never a warning
+            final = eng.run_checked(run) if hasattr(eng, 'run_checked') else run()
             if pending is not None:
                 pending.result()                                           # (raises what the writer raised)
             done = torch.cuda.Event()

@@ -75,6 +75,25 @@ class NativeOps:
         self._acc, self._store, self._blk = {}, None, None
         self.round_align = max(1, int(P.BLOCK_BATCH)) if self.eng.dim == 3 else 1
 
+    def agree_form(self, comm, volume, padded_first):
+        """Ranks in SEPARATE processes take one decision about the prediction form (engine_auto.EngineAuto: x2m or fp16x2): each runs
+        the calibration on its own first block (none: contributes 0) and the figure is all-reduced (MAX) -- entered by every rank at the
+        same weight-load counts whatever its local state, at most once per `recal_every` weight loads; blocking (one 8-byte read).
+        In-process communicators (the virtual-rank tests) share one engine and need no agreement."""
+        eng = self.eng
+        if not isinstance(comm, DistComm) or comm.world <= 1 or not hasattr(eng, 'collective_due') or not eng.collective_due():
+            return
+        S = self.S
+        x, xs, dims = None, None, (S, S, S)
+        if padded_first is not None:
+            if eng.dim == 3:
+                x = P.gather_block(volume, padded_first, S)
+                xs = (S ** 3, S ** 3, S * S, S, 1)
+            else:
+                x = P.gather_block(volume, padded_first, S)
+                xs, dims = (S * S, 0, 0, S, 1), (1, S, S)          # the block's slices along axis 0 (predict.py:87-98)
+        eng.calibrate(x, xs, dims[0], dims[1], dims[2], blocking=True, group=comm.group if comm.group is not None else True)
+
     # ---- single-rank path: blend at once into a whole-volume accumulator (predict.predict_volume_array's loop)
     def make_accumulator(self, V):
         """Accumulators are cached per shape (the Gaussian window and 12 B/voxel of HBM are not re-created for every
@@ -130,12 +149,13 @@ class NativeOps:
         total = nb(getattr(self, '_window', None)) + nb(self._store) + nb(getattr(self, '_pool', None))
         if acc is not None:
             total += sum(nb(getattr(acc, k, None)) for k in ('pred', 'weight', 'final', 'window', 'block_probs'))
-        eng = self.eng
-        for ws in getattr(eng, '_ws_cache', {}).values():
-            total += sum(nb(t) for k, t in ws.items() if torch.is_tensor(t))
-        g = getattr(eng, '_g', None)
-        if g is not None:
-            total += sum(nb(t) for t in g._ws.values()) + nb(g.packed) + nb(g.flat)
+        # (engine_auto.EngineAuto holds one engine per prediction form it has used: the calibration's second form counts too)
+        for eng in (getattr(self.eng, '_engines', None) or {'': self.eng}).values():
+            for ws in getattr(eng, '_ws_cache', {}).values():
+                total += sum(nb(t) for k, t in ws.items() if torch.is_tensor(t))
+            g = getattr(eng, '_g', None)
+            if g is not None:
+                total += sum(nb(t) for t in g._ws.values()) + nb(g.packed) + nb(g.flat)
         return total
 
     def forward_blocks(self, volume, padded, store, j0):
@@ -260,6 +280,8 @@ def predict_volume_sharded(ops, my_slab, volume_shape, input_size, overlap=0.25,
     shifted = pbc.copy()
     shifted[:, 0] -= f0
     shifted[:, 3] -= f0
+    if hasattr(ops, 'agree_form'):
+        ops.agree_form(comm, window, shifted[lo] if hi > lo else None)
     # ---- schedule (identical on every rank) ----
     pieces = [block_pieces(bc[b], lbc[b], bounds) for b in range(len(pbc))]
     orders = [compute_order(runs[r], pieces, r) for r in range(world)]

@@ -10,8 +10,11 @@ base, act_dtype, infer_dtype) select the 3-D / wider variants of BASELINE.json's
 
 Numeric modes.  The reference TRAINS under `precision='16-mixed'` (trainer.py:59) and PREDICTS in fp32 (predict.py:30-35).
 The default module (act_dtype=None) does the same: native training with fp16 activations, `forward()` / prediction in the
-split-precision mode 'fp16x2' (engine_x2.py: every value two fp16 words, three 16-bit MFMAs per product; logits within
-1e-3 of the CPU fp32 path, class map exact).  An explicit act_dtype selects one mode for both: 'fp16' / 'bf16' = 16-bit
+split-precision mode 'fp16x2' (logits within 1e-3 of the CPU fp32 path) -- engine_auto.EngineAuto picks, by a calibration on
+the model's own weights and input, the faster x2m form (cross terms on the fp8 matrix cores) where it holds the tolerance with
+margin and the full fp16x2 form (engine_x2.py: every value two fp16 words, three 16-bit MFMAs per product) where it does not,
+and re-runs a prediction whose activations left the fp16 range in a wider form (`infer_policy` = 'x2m' / 'fp16x2' pins one
+form).  An explicit act_dtype selects one mode for both: 'fp16' / 'bf16' = 16-bit
 activations on the matrix cores (the throughput path: logits off the fp32 path by 4e-3 / 3e-2); 'fp32' = the f32-input matrix
 instruction for prediction (engine_f32.py) AND training (train_engine_f32.py: the parity form of the step, gradients within 1e-4 of
 CPU autograd), 1/16 of the 16-bit rate; 'fp16x2' is inference-only.  `infer_dtype` overrides the
@@ -89,7 +92,7 @@ class UNet(nn.Module):
     def __init__(self, lr=0.0001, num_channels=1, num_classes=2, loss_function=metrics.mcc_ce_loss,
                  architecture='U-Net', encoder_name='mit_b0', pretrained=True,
                  dim=2, levels=4, base=32, act_dtype=None, weight_dtype=None, norm='batch', groups=8, infer_dtype=None,
-                 act_quant=None):
+                 act_quant=None, infer_policy=None):
         super().__init__()
         if architecture != 'U-Net':
             raise NotImplementedError(f"architecture {architecture!r}: only 'U-Net' has a native MI355X "
@@ -102,7 +105,8 @@ class UNet(nn.Module):
                             dim=dim, levels=levels, base=base,
                             act_dtype=None if act_dtype is None else _ACT_NAME[_ACT[act_dtype]],
                             weight_dtype=weight_dtype, norm=norm, groups=groups,
-                            infer_dtype=None if infer_dtype is None else _ACT_NAME[_ACT[infer_dtype]], act_quant=act_quant)
+                            infer_dtype=None if infer_dtype is None else _ACT_NAME[_ACT[infer_dtype]], act_quant=act_quant,
+                            infer_policy=infer_policy)
         self.lr = lr
         self.loss_function = loss_function
         self.dim, self.levels, self.base = dim, levels, base
@@ -121,6 +125,8 @@ class UNet(nn.Module):
         # True = W8A8): the stage convs run on the fp8 matrix cores, which also rounds their ACTIVATIONS to e4m3; False = W8A16,
         # e4m3-valued operators on the 16-bit matrix cores with unquantised activations (engine.Engine has the numbers)
         self.weight_dtype, self.act_quant = weight_dtype, act_quant
+        # form of the split-precision prediction: None / 'auto' = calibrated choice (engine_auto.py), 'x2m' / 'fp16x2' = pinned
+        self.infer_policy = infer_policy
         # norm='group': GroupNorm(groups) instead of BatchNorm after every stage conv (north_star "GroupNorm/BN"); the
         # bn{j}.weight / .bias parameters are its affine pair, the running statistics are unused
         if norm not in ('batch', 'group'):
@@ -196,8 +202,9 @@ class UNet(nn.Module):
                 if self.weight_dtype is not None or self.norm != 'batch':
                     raise ValueError(f"{_ACT_NAME[self.infer_dtype]!r} is a parity mode: BatchNorm network, no weight_dtype")
                 if self.infer_dtype == X2:
-                    from .engine_x2 import EngineX2
-                    eng = EngineX2(self.dim, self.levels, self.base, self.num_channels, self.num_classes, dev)
+                    from .engine_auto import EngineAuto
+                    eng = EngineAuto(self.dim, self.levels, self.base, self.num_channels, self.num_classes, dev,
+                                     policy=getattr(self, 'infer_policy', None))
                 else:
                     from .engine_f32 import EngineF32
                     eng = EngineF32(self.dim, self.levels, self.base, self.num_channels, self.num_classes, dev)
@@ -225,7 +232,11 @@ class UNet(nn.Module):
         D, H, W = sp if self.dim == 3 else (1,) + sp
         vox = D * H * W
         probs = torch.empty((N, self.num_classes) + sp, dtype=torch.float32, device=self.device)
-        eng.infer(x, (self.num_channels * vox, vox, H * W, W, 1), N, D, H, W, probs=probs)
+        run = lambda: eng.infer(x, (self.num_channels * vox, vox, H * W, W, 1), N, D, H, W, probs=probs)
+        if hasattr(eng, 'run_checked'):
+            eng.run_checked(run)          # split precision: one 4-byte read of the range flag; a saturated forward is re-run wider
+        else:
+            run()
         return probs
 
     # ---- optimiser / steps (unet.py:71-116) -------------------------------------------------

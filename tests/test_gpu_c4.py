@@ -134,6 +134,44 @@ def test_c4_subvolume_throughput_mode_vs_parity_mode():
     assert np.array_equal(outs['fp16'].argmax(-1)[sure], outs['fp32'].argmax(-1)[sure])
 
 
+def test_c4_subvolume_default_mode_vs_parity_mode():
+    """The same 256^3 pipeline in the DEFAULT prediction mode -- what UNet() selects (engine_auto.EngineAuto: x2m here) -- against the
+    fp32 parity mode: the probabilities differ by <= 3e-4, so the truncated uint8 outputs differ by at most 1 LSB
+    (a value on either side of an integer), and the class map is equal wherever the fp32 mode's two classes are more than 1 LSB apart;
+    plus the accumulators before quantisation: |pred / weight| within 1e-3 everywhere (blend of probabilities each within tolerance)."""
+    from interactive_unet import predict
+    from interactive_unet.unet import UNet
+    S, C, V = 128, 2, (256, 256, 256)
+    p = unet_ref.init_params(dim=3, ncls=C, seed=5, randomize_bn=True)
+    g = torch.Generator(device='cuda').manual_seed(2)
+    vol = torch.randint(0, 256, V, dtype=torch.uint8, device='cuda', generator=g)
+    outs, probs, form = {}, {}, None
+    for dt in (None, 'fp32'):
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            model = UNet(num_classes=C, dim=3, act_dtype=dt, pretrained=False)
+        model.load_named(p)
+        model = model.cuda().eval()
+        acc = predict.predict_volume_array(model, vol, input_size=S, num_classes=C, overlap=0.25, finalize=False)
+        probs[dt] = (acc.pred / acc.weight.clamp_min(1e-3)[..., None]).cpu()
+        outs[dt] = acc.finalize().cpu().numpy().astype(int)
+        if dt is None:
+            eng = model.engine('eval')
+            form = eng.describe()
+            assert eng.form in ('x2m', 'fp16x2') and not eng.saturated()
+        del model, acc
+        torch.cuda.empty_cache()
+    dp = (probs[None] - probs['fp32']).abs().max().item()
+    d = np.abs(outs[None] - outs['fp32'])
+    sure = np.abs(outs['fp32'][..., 0] - outs['fp32'][..., 1]) > 1
+    print(f'C4 sub-volume 256^3 (27 blocks) in the default mode ({form["form"]}, calibration {form["calibration_max_abs_logit_diff_x2m_vs_fp16x2"]:.2e}): '
+          f'max |blended probability diff| vs the fp32 mode = {dp:.2e}; max |uint8 diff| = {d.max()}, differing = {(d > 0).mean():.5f}; '
+          f'class map compared on {sure.mean():.4f} of the voxels')
+    assert dp <= 1e-3
+    assert d.max() <= 1
+    assert np.array_equal(outs[None].argmax(-1)[sure], outs['fp32'].argmax(-1)[sure])
+
+
 @pytest.mark.parametrize('mode', ['bf16', 'compliant'])
 def test_c4_eight_virtual_ranks_at_full_size(mode):
     """(mode 'compliant': the default prediction mode -- split precision with the cross terms on the fp8 matrix cores -- whose activations

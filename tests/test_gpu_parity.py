@@ -185,18 +185,20 @@ def test_unet_module_default_predicts_in_split_precision():
     fp16x2 engine, while the training dtype stays 16-bit (trainer.py:59 '16-mixed')."""
     import warnings
     from interactive_unet.unet import UNet
-    from interactive_unet.engine_x2 import EngineX2
+    from interactive_unet.engine_auto import EngineAuto
     p = unet_ref.init_params(dim=2, ncls=2, seed=9, randomize_bn=True)
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
         m = UNet()
     m.load_named(p)
     m = m.cuda().eval()
-    assert isinstance(m.engine('eval'), EngineX2) and m.act_dtype == torch.float16
+    assert isinstance(m.engine('eval'), EngineAuto) and m.act_dtype == torch.float16
     x = torch.tensor(_smooth((96, 64), 3))[None, None]
     got = m(x.cuda()).cpu()
     want = unet_ref.forward(p, x.float() / 255.0, dim=2)
     assert (got - want).abs().max().item() <= 2e-4        # probabilities; the logits are held to 1e-3 above (x2m: ~1e-4 measured)
+    eng = m.engine('eval')                                # the calibrated choice between x2m and fp16x2 (engine_auto.py)
+    assert eng.form in ('x2m', 'fp16x2') and eng.calibrations == 1 and eng.calibration['diff'] <= 1e-3
     # an explicit 16-bit act_dtype keeps the throughput mode for both
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')

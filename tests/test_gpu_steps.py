@@ -74,7 +74,7 @@ def test_lightning_shaped_loop_matches_the_fused_step():
 def test_default_module_trains_16_bit_and_predicts_in_split_precision():
     """UNet() as the reference builds it: training_step runs (fp16 activations, dynamic loss scale), the loss tracks the oracle's
     forward in the same rounding, and forward() afterwards answers from the fp16x2 engine with the UPDATED weights."""
-    from interactive_unet.engine_x2 import EngineX2
+    from interactive_unet.engine_auto import EngineAuto
     m = _model(seed=2)
     opt = m.configure_optimizers()
     batch = _batch(3)
@@ -86,7 +86,7 @@ def test_default_module_trains_16_bit_and_predicts_in_split_precision():
     loss.backward()
     opt.step()
     m.eval()
-    assert isinstance(m.engine('eval'), EngineX2)
+    assert isinstance(m.engine('eval'), EngineAuto)
     probs = m(batch[0].cuda()).cpu()
     p1 = {k: v.detach().cpu() for k, v in m.named_tensors().items()}
     assert (p1['enc0.conv1.weight'] - p0['enc0.conv1.weight']).abs().max() > 0

@@ -37,6 +37,8 @@ def main():
     ap.add_argument('--target', type=float, default=20.0)
     ap.add_argument('--eval-every', type=int, default=50)
     ap.add_argument('--eval-size', type=int, default=None)
+    ap.add_argument('--loss', default='mcc_ce')
+    ap.add_argument('--wd', type=float, default=1e-2)
     args = ap.parse_args()
     from interactive_unet.unet import UNet
     from interactive_unet.train_engine import TrainEngine
@@ -54,7 +56,7 @@ def main():
         model = UNet(lr=args.lr, dim=dim, act_dtype='fp16', pretrained=False)
     model.reset_parameters(seed=0)
     model = model.to(dev)
-    te = TrainEngine(model, lr=args.lr, loss_kind='mcc_ce')
+    te = TrainEngine(model, lr=args.lr, loss_kind=args.loss, weight_decay=args.wd)
     imgs = np.stack([smooth(tshape, 100 + i) for i in range(4 * B)])[:, None]
     X = torch.tensor(imgs).to(dev)
     lab = (X > 127)
