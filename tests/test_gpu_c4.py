@@ -137,7 +137,8 @@ def test_c4_subvolume_throughput_mode_vs_parity_mode():
 def test_c4_subvolume_default_mode_vs_parity_mode():
     """The same 256^3 pipeline in the DEFAULT prediction mode -- what UNet() selects (engine_auto.EngineAuto: x2m here) -- against the
     fp32 parity mode: the probabilities differ by <= 3e-4, so the truncated uint8 outputs differ by at most 1 LSB
-    (a value on either side of an integer), and the class map is equal wherever the fp32 mode's two classes are more than 1 LSB apart;
+    (a value on either side of an integer), and the class map of the uint8 result is equal wherever the fp32 mode's two classes are more
+    than 2 LSB apart (each class may move by one: (126, 128) against (127, 127) is a tie made by the truncation, not a class change);
     plus the accumulators before quantisation: |pred / weight| within 1e-3 everywhere (blend of probabilities each within tolerance)."""
     from interactive_unet import predict
     from interactive_unet.unet import UNet
@@ -163,7 +164,7 @@ def test_c4_subvolume_default_mode_vs_parity_mode():
         torch.cuda.empty_cache()
     dp = (probs[None] - probs['fp32']).abs().max().item()
     d = np.abs(outs[None] - outs['fp32'])
-    sure = np.abs(outs['fp32'][..., 0] - outs['fp32'][..., 1]) > 1
+    sure = np.abs(outs['fp32'][..., 0] - outs['fp32'][..., 1]) > 2
     print(f'C4 sub-volume 256^3 (27 blocks) in the default mode ({form["form"]}, calibration {form["calibration_max_abs_logit_diff_x2m_vs_fp16x2"]:.2e}): '
           f'max |blended probability diff| vs the fp32 mode = {dp:.2e}; max |uint8 diff| = {d.max()}, differing = {(d > 0).mean():.5f}; '
           f'class map compared on {sure.mean():.4f} of the voxels')
