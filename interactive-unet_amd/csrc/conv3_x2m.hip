@@ -1472,7 +1472,7 @@ int iunet_x2m_conv_fwd(int nd, const void* x, long long x_ss, const void* x8, lo
  * in 2-D (8 x 512^2: 132 against 130 + 39, 64->64 @ 256^2 90 against 80 + 20, 79 against 77 + 14; at 4 bytes per element the 64-channel launch
  * -- two Cout tiles on two steps per tile -- read 107-113 against 79 + 22 and was excluded; the whole forward with it: 1.55-1.57 against
  * 1.56-1.57 ms at 8 x 512^2, 1.60-1.61 against 1.60-1.63 at 128 x 128^2).  IUNET_X2M_POOL=0: never, =3: 3-D only, =4: 2-D without the
- * 64-channel stage (A/B switches; =2, the former "everywhere", is the default now). */
+ * 64-channel stage (A/B switches; unset or any other value: everywhere, the default). */
 int iunet_x2m_pool_fusable(int nd, int C) {
   static const int mode = getenv("IUNET_X2M_POOL") ? atoi(getenv("IUNET_X2M_POOL")) : 1;
   if (mode == 0 || (nd != 2 && nd != 3)) return 0;

@@ -987,17 +987,20 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 // the step in flight, [4] float bc1 = 1 - b1^step, [5] float sqrt(1 - b2^step), [6] float 1 / (loss scale x world), [7] int dynamic scale
 __global__ void train_state_coef_kernel(float* __restrict__ st, float b1, float b2, float world) {
   int* si = (int*)st;
-  const float step = (float)(si[1] + 1);
-  st[4] = 1.f - powf(b1, step);
-  st[5] = sqrtf(1.f - powf(b2, step));
+  // in double, as torch.optim.AdamW's host arithmetic: 1 - 0.999^step in fp32 loses 1.3e-5 of its value to cancellation at step 1
+  // (ADVICE r4); one thread, once per step
+  const double step = (double)(si[1] + 1);
+  st[4] = (float)(1.0 - pow((double)b1, step));
+  st[5] = (float)sqrt(1.0 - pow((double)b2, step));
   st[6] = 1.0f / (st[0] * world);
 }
 // GradScaler semantics (the reference trains under precision='16-mixed', trainer.py:59): an overflowing step is skipped, halves the
-// scale and is not counted; 2000 good steps in a row double it.  A fixed scale counts every step (the Python form did).
+// scale and is not counted; 2000 good steps in a row double it.  A fixed scale counts the APPLIED steps too: a step skipped for a
+// non-finite fp16 gradient must not advance the bias corrections.
 __global__ void train_state_update_kernel(float* __restrict__ st) {
   int* si = (int*)st;
   const bool dyn = si[7] != 0, bad = si[3] != 0;
-  if (!dyn) { si[1] += 1; return; }
+  if (!dyn) { if (!bad) si[1] += 1; return; }
   if (bad) { st[0] = fmaxf(st[0] * 0.5f, 1.0f); si[2] = 0; }
   else {
     si[1] += 1;

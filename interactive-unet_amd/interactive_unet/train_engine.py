@@ -91,6 +91,7 @@ class TrainEngine:
     @loss_scale.setter
     def loss_scale(self, value):
         self.state[0:1].fill_(float(value))
+        self._fixed_scale = None
 
     @property
     def step_count(self):
@@ -649,7 +650,10 @@ class TrainEngine:
         ws, X, xs, y, w, tdt, N = state
         self.backward(ws, X, xs, y, w, tdt, N)
         world = self.buckets.finish() if self.pg is not None else 1
-        scale = self.loss_scale
+        # the scale lives on the device: bf16 trains at a fixed 1.0 and must not pay a host read per step for it
+        scale = self.loss_scale if self.T == torch.float16 else getattr(self, '_fixed_scale', None)
+        if scale is None:
+            scale = self._fixed_scale = self.loss_scale
         g = self.grad * (1.0 / (scale * world))
         ok = True
         if self.T == torch.float16:

@@ -5,7 +5,7 @@
 The reference's app.py does `from . import utils, trainer, predict, suggestor` (app.py:19-21): its modules resolve
 inside ITS package directory, so a directory on PYTHONPATH is never consulted.  The drop-in is therefore file-level:
 the hot-path modules of the reference (unet, trainer, predict, metrics, slicer, loader, suggestor) are replaced by the
-native ones of the same names, the native-only modules (engine, engine_f32, engine_x2, net_graph, train_engine, train_engine_f32, shard, dp, multiscale, zarr3,
+native ones of the same names, the native-only modules (engine, engine_f32, engine_x2, engine_auto, net_graph, train_engine, train_engine_f32, shard, dp, multiscale, zarr3,
 _native) are added beside them, and libiunet.so goes to <package>/../lib/ where _native.py looks for it.  The reference's
 app.py, annotator.py, volumedata.py and -- deliberately -- utils.py are NOT touched: app.py:33-788 calls ~15 project /
 TIFF / plotting helpers of utils.py that are outside the hot path.  The replaced files are kept as <name>.py.reference.
@@ -18,7 +18,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.join(os.path.dirname(HERE), 'interactive-unet_amd')
 REPLACED = ['unet', 'trainer', 'predict', 'metrics', 'slicer', 'loader', 'suggestor']
-ADDED = ['_native', 'engine', 'engine_f32', 'engine_x2', 'net_graph', 'train_engine', 'train_engine_f32', 'shard', 'dp', 'multiscale', 'zarr3']
+ADDED = ['_native', 'engine', 'engine_f32', 'engine_x2', 'engine_auto', 'net_graph', 'train_engine', 'train_engine_f32', 'shard', 'dp', 'multiscale', 'zarr3']
 NOT_INSTALLED = ['utils', '__init__']          # the reference's own stay
 
 
