@@ -360,6 +360,20 @@ int iunet_maxpool_q_fwd(int nd, const void* x, long long x_ss_bytes, void* y, lo
 int iunet_convT_fwd_q(int dtype, int nd, const void* x, long long x_ss, void* y, long long y_ss_bytes, const void* wpk,
                       const void* bias, int N, int D, int H, int W, int Cin, int Cout, void* stream);
 
+/* ---- GroupNorm(groups) + ReLU of the tolerance-meeting prediction modes (csrc/gn_precise.hip; north star "GroupNorm/BN": the reference's
+ * normalisation layers live in smp behind unet.py:33-61).  Statistics per (sample, group) in double, nothing folds into the operators: a
+ * stage conv writes its raw output, then y = relu((x - mean) * rstd * gamma + beta).  slab: iunet_gn_precise_slab_bytes(N, C, vox) bytes
+ * of scratch; scale / shift: fp32 [N][C] scratch (receive the per-sample affine pair). */
+long long iunet_gn_precise_slab_bytes(int N, int C, long long vox);
+/* fp32 mode: planar fp32 [N][C][vox], sample strides in elements (y may be a half of a concat buffer). */
+int iunet_f32_gn_relu_fwd(const void* x, long long x_ss, void* y, long long y_ss, const void* gamma, const void* beta, int groups, float eps,
+                          void* slab, void* scale, void* shift, int C, int N, long long vox, void* stream);
+/* split precision (fp16x2): C / 8 hi planes + lo planes x_lo / y_lo planes further on, values act_scale x activation; sat: optional
+ * range flag (an int raised to 0x7bff when a stored word saturates). */
+int iunet_x2_gn_relu_fwd(const void* x, long long x_ss, int x_lo, void* y, long long y_ss, int y_lo, const void* gamma, const void* beta,
+                         int groups, float eps, float act_scale, void* slab, void* scale, void* shift, int C, int N, long long vox,
+                         void* sat, void* stream);
+
 /* ---- whole-volume prediction (predict.py:201-256) -------------------------------------- */
 /* get_padded_block (predict.py:291-316): reflect-padded S^3 uint8 block of a device volume. */
 int iunet_gather_block(const void* vol, int Vz, int Vy, int Vx, int i0, int j0, int k0, int S, void* out, void* stream);

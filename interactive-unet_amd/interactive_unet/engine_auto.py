@@ -36,13 +36,20 @@ CAL_TILE = {2: 256, 3: 64}
 class EngineAuto:
     act_dtype = 'fp16x2'
     weight_dtype = None
-    norm = 'batch'
 
-    def __init__(self, dim=2, levels=4, base=32, cin=1, ncls=2, device='cuda', policy=None, threshold=THRESHOLD, recal_every=RECAL_EVERY):
+    def __init__(self, dim=2, levels=4, base=32, cin=1, ncls=2, device='cuda', policy=None, threshold=THRESHOLD, recal_every=RECAL_EVERY,
+                 norm='batch', groups=8):
         if policy is None:
             policy = {'0': 'fp16x2', '1': 'x2m'}.get(os.environ.get('IUNET_X2M', ''), 'auto')
         if policy not in ('auto', 'x2m', 'fp16x2'):
             raise ValueError("policy must be 'auto', 'x2m' or 'fp16x2'")
+        # GroupNorm networks (north_star "GroupNorm/BN") predict in the full fp16x2 form: the x2m form's producers carry the folded-
+        # BatchNorm epilogue only, so there is nothing to calibrate against; the range steps work as for BatchNorm
+        self.norm, self.groups = norm, groups
+        if norm == 'group':
+            if policy == 'x2m':
+                raise NotImplementedError("GroupNorm networks predict in the full fp16x2 form (policy 'auto' or 'fp16x2')")
+            policy = 'fp16x2'
         self.dim, self.levels, self.base, self.cin, self.ncls = dim, levels, base, cin, ncls
         self.device = torch.device(device)
         self.policy, self.threshold, self.recal_every = policy, float(threshold), int(recal_every)
@@ -64,10 +71,10 @@ class EngineAuto:
         if e is None:
             if name == 'fp32':
                 from .engine_f32 import EngineF32
-                e = EngineF32(self.dim, self.levels, self.base, self.cin, self.ncls, self.device)
+                e = EngineF32(self.dim, self.levels, self.base, self.cin, self.ncls, self.device, norm=self.norm, groups=self.groups)
             else:
                 e = EngineX2(self.dim, self.levels, self.base, self.cin, self.ncls, self.device, mixed=(name == 'x2m'),
-                             act_scale=1.0 if name == 'fp16x2_wide' else 64.0)
+                             act_scale=1.0 if name == 'fp16x2_wide' else 64.0, norm=self.norm, groups=self.groups)
             self._engines[name] = e
         return e
 

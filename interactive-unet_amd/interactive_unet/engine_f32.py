@@ -4,6 +4,9 @@ activations (planar: C planes of [D][H][W]) and fp32 operators on the f32-input 
 (csrc/precise_f32.hip) -- 1/16 of the bf16 MFMA rate, so this is the checking mode, not the throughput path: it is
 what `UNet(act_dtype='fp32')` runs, what the parity tests hold against oracle/unet_ref.forward_logits, and the
 device-side stand-in for that oracle at sizes the CPU cannot finish (C4).
+
+norm='group': GroupNorm(groups) + ReLU after every stage conv instead of the folded BatchNorm (north_star "GroupNorm/BN").  Nothing
+folds: the conv writes its raw output, csrc/gn_precise.hip takes the per-(sample, group) statistics in double and normalises.
 """
 import ctypes
 
@@ -17,7 +20,12 @@ class EngineF32:
     act_dtype = torch.float32
     weight_dtype = None
 
-    def __init__(self, dim=2, levels=4, base=32, cin=1, ncls=2, device='cuda'):
+    def __init__(self, dim=2, levels=4, base=32, cin=1, ncls=2, device='cuda', norm='batch', groups=8):
+        if norm not in ('batch', 'group'):
+            raise ValueError("norm must be 'batch' or 'group'")
+        if norm == 'group' and base % groups:
+            raise ValueError(f'{groups} groups do not divide {base} channels')
+        self.norm, self.groups = norm, groups
         if dim not in (2, 3):
             raise ValueError('dim must be 2 or 3')
         if base % 32 != 0:
@@ -51,6 +59,10 @@ class EngineF32:
                 w = src(f'{prefix}.conv{j}.weight')
                 bn = [src(f'{prefix}.bn{j}.{k}') for k in ('weight', 'bias', 'running_mean', 'running_var')]
                 dst, bias = f32(lib.iunet_f32_pack_conv_elems(b, a, self.taps)), f32(b)
+                if self.norm == 'group':          # raw operator; gamma / beta go to the normalisation pass
+                    nv.call('iunet_f32_pack_conv', nv.ptr(w), nv.ptr(dst), None, None, None, None, None, BN_EPS, b, a, self.taps, 0, s)
+                    P[f'{prefix}.conv{j}'] = (dst, None, bn[0], bn[1])
+                    continue
                 nv.call('iunet_f32_pack_conv', nv.ptr(w), nv.ptr(dst), nv.ptr(bias), nv.ptr(bn[0]), nv.ptr(bn[1]),
                         nv.ptr(bn[2]), nv.ptr(bn[3]), BN_EPS, b, a, self.taps, 0, s)
                 P[f'{prefix}.conv{j}'] = (dst, bias)
@@ -85,6 +97,11 @@ class EngineF32:
                 ws[f'b{l}'] = mk(self.ch[l], v)
                 if l > 0:
                     ws[f'pin{l}'] = mk(self.ch[l - 1], v)
+            if self.norm == 'group':
+                ws['raw'] = mk(max(self.ch[l] * _vox(dims[l]) for l in range(self.levels)), 1)
+                ws['gnslab'] = torch.empty(max(nv.lib().iunet_gn_precise_slab_bytes(N, self.ch[l], _vox(dims[l])) for l in range(self.levels)),
+                                           dtype=torch.uint8, device=self.device)
+                ws['gnsc'], ws['gnsh'] = mk(N * max(self.ch), 1), mk(N * max(self.ch), 1)
             self._ws_cache = {key: ws}
         return ws
 
@@ -98,7 +115,16 @@ class EngineF32:
         Pt = lambda t, off=0: ctypes.c_void_p(t.data_ptr() + 4 * off)
 
         def conv(name, xp, in_dt, strides, yp, y_ss, d, ci, co, transposed=0, relu=1):
-            w, b = self.packed[name]
+            w, b = self.packed[name][0], self.packed[name][1]
+            if self.norm == 'group' and not transposed:
+                # raw conv output (no bias, no ReLU) -> statistics per (sample, group) in double -> relu(normalised) into the consumer's view
+                gamma, beta = self.packed[name][2], self.packed[name][3]
+                v = _vox(d)
+                nv.call('iunet_f32_conv_fwd', self.dim, xp, in_dt, nv.ll_array(strides), nv.ptr(ws['raw']), co * v, nv.ptr(w), None,
+                        N, d[0], d[1], d[2], ci, co, 0, 0, s)
+                nv.call('iunet_f32_gn_relu_fwd', nv.ptr(ws['raw']), co * v, yp, y_ss, nv.ptr(gamma), nv.ptr(beta), self.groups, BN_EPS,
+                        nv.ptr(ws['gnslab']), nv.ptr(ws['gnsc']), nv.ptr(ws['gnsh']), co, N, v, s)
+                return
             nv.call('iunet_f32_conv_fwd', self.dim, xp, in_dt, nv.ll_array(strides), yp, y_ss, nv.ptr(w), nv.ptr(b),
                     N, d[0], d[1], d[2], ci, co, relu, transposed, s)
 

@@ -31,9 +31,20 @@ from .engine import BN_EPS, _vox
 class EngineX2:
     act_dtype = 'fp16x2'
     weight_dtype = None
-    norm = 'batch'
 
-    def __init__(self, dim=2, levels=4, base=32, cin=1, ncls=2, device='cuda', act_scale=64.0, mixed=None):
+    def __init__(self, dim=2, levels=4, base=32, cin=1, ncls=2, device='cuda', act_scale=64.0, mixed=None, norm='batch', groups=8):
+        if norm not in ('batch', 'group'):
+            raise ValueError("norm must be 'batch' or 'group'")
+        if norm == 'group' and base % groups:
+            raise ValueError(f'{groups} groups do not divide {base} channels')
+        # norm='group': GroupNorm(groups) + ReLU after every stage conv (north_star "GroupNorm/BN").  Nothing folds: the stage convs write
+        # their raw output as split words (epilogue without bias / ReLU) and csrc/gn_precise.hip normalises it with per-(sample, group)
+        # statistics taken in double; the full fp16x2 form only (mixed is off)
+        self.norm, self.groups = norm, groups
+        if norm == 'group':
+            if mixed:
+                raise NotImplementedError("GroupNorm runs in the full fp16x2 form (mixed=False)")
+            mixed = False
         if dim not in (2, 3):
             raise ValueError('dim must be 2 or 3')
         if base % 32 != 0:
@@ -140,6 +151,7 @@ class EngineX2:
                     first = prefix == 'enc0' and j == 1
                     w = src[f'{name}.weight']
                     bn = [src[f'{prefix}.bn{j}.{k}'] for k in ('weight', 'bias', 'running_mean', 'running_var')]
+                    gn = self.norm == 'group'
                     if self.mixed and not first:
                         # x2m: w_hi in the padded K16 order (3-D) / the cross-pair order (2-D: three k-groups per 32-channel step)
                         # + [w_hi8 | w_lo8] in the K128 order of the fp8 step
@@ -163,15 +175,16 @@ class EngineX2:
                     npk = lib.iunet_pack_first_conv_elems(b, 3 * a, self.taps) if first else nv.pack_conv3_elems(b, 3 * a, self.taps, pmode)
                     wv, dst, osc, bias = bufs(name, b * 3 * a * self.taps, npk, b)
                     kc = a if first else (16 if self.dim == 3 else 32)
-                    d_x2.append(nv.make_x2_prep_desc(w, wv, osc, bias, b, a, self.taps, 0, kc, A, A, bn=bn, eps=BN_EPS))
+                    d_x2.append(nv.make_x2_prep_desc(w, wv, osc, bias, b, a, self.taps, 0, kc, A, A, bn=None if gn else bn, eps=BN_EPS))
                     d_pack.append(nv.make_desc(wv, dst, b, 3 * a, self.taps, 2 if first else (1 if pmode == 2 else 6), torch.float16))
-                    per_layer.append(('iunet_x2_prep', (nv.ptr(w), nv.ptr(wv), nv.ptr(osc), nv.ptr(bias), nv.ptr(bn[0]), nv.ptr(bn[1]), nv.ptr(bn[2]),
-                                                        nv.ptr(bn[3]), None, BN_EPS, A, A, b, a, self.taps, 0, kc)))
+                    bnp = [None] * 4 if gn else [nv.ptr(t) for t in bn]
+                    per_layer.append(('iunet_x2_prep', (nv.ptr(w), nv.ptr(wv), nv.ptr(osc), nv.ptr(bias), bnp[0], bnp[1], bnp[2],
+                                                        bnp[3], None, BN_EPS, A, A, b, a, self.taps, 0, kc)))
                     if first:
                         per_layer.append(('iunet_pack_first_conv', (0, nv.ptr(wv), None, nv.ptr(dst), b, 3 * a, self.taps)))
                     else:
                         per_layer.append(('iunet_pack_conv3', (0, nv.ptr(wv), None, nv.ptr(dst), b, 3 * a, self.taps, pmode)))
-                    P[name] = (dst, osc, bias)
+                    P[name] = (dst, osc, bias, bn[0], bn[1]) if gn else (dst, osc, bias)
             for l in range(self.levels - 2, -1, -1):
                 name = f'dec{l}.up'
                 w, b0 = src[f'{name}.weight'], src[f'{name}.bias']
@@ -233,14 +246,32 @@ class EngineX2:
                     ws[f'cat{l}'] = mk(2 * self.ch[l], v)
                 if l > 0:
                     ws[f'pin{l}'] = mk(self.ch[l - 1], v)
+            if self.norm == 'group':
+                ws['raw'] = torch.zeros(N * 2 * max(self.ch[l] * _vox(dims[l]) for l in range(self.levels)), dtype=torch.float16, device=self.device)
+                ws['gnslab'] = torch.empty(max(nv.lib().iunet_gn_precise_slab_bytes(N, self.ch[l], _vox(dims[l])) for l in range(self.levels)),
+                                           dtype=torch.uint8, device=self.device)
+                ws['gnsc'] = torch.empty(N * max(self.ch), dtype=torch.float32, device=self.device)
+                ws['gnsh'] = torch.empty(N * max(self.ch), dtype=torch.float32, device=self.device)
             if len(self._ws_cache) > 4:
                 self._ws_cache.clear()
             self._ws_cache[key] = ws
         return ws
 
     # ------------------------------------------------------------------ forward (inference)
-    def _conv3(self, name, xp, x_ss, x_lo, yp, y_ss, y_lo, N, d, ci, co, s):
-        w, osc, b = self.packed[name]
+    def _gn(self, name, ws, yp, y_ss, y_lo, N, d, co, s):
+        """relu(group_norm(raw conv output in ws['raw'])) -> the split tensor at yp (csrc/gn_precise.hip: statistics in double)."""
+        v = _vox(d)
+        gamma, beta = self.packed[name][3], self.packed[name][4]
+        nv.call('iunet_x2_gn_relu_fwd', nv.ptr(ws['raw']), 2 * co * v, co // 8, yp, y_ss, y_lo, nv.ptr(gamma), nv.ptr(beta), self.groups, BN_EPS,
+                self.act_scale, nv.ptr(ws['gnslab']), nv.ptr(ws['gnsc']), nv.ptr(ws['gnsh']), co, N, v, nv.ptr(self._sat), s)
+
+    def _conv3(self, name, xp, x_ss, x_lo, yp, y_ss, y_lo, N, d, ci, co, s, ws=None):
+        w, osc, b = self.packed[name][:3]
+        if self.norm == 'group':
+            # raw output (accumulator x row scale: no bias, no ReLU) as split words, then the normalisation passes
+            nv.call('iunet_x2_conv3_fwd_flag', self.dim, xp, x_ss, x_lo, nv.ptr(ws['raw']), 2 * co * _vox(d), co // 8, nv.ptr(w), nv.ptr(osc), nv.ptr(b),
+                    N, d[0], d[1], d[2], ci, co, 0, nv.ptr(self._sat), s)
+            return self._gn(name, ws, yp, y_ss, y_lo, N, d, co, s)
         probe = self.probe if (self.probe is not None and self.probe['name'] == name) else None
         if probe is not None:
             e0 = torch.cuda.Event(enable_timing=True)
@@ -282,23 +313,26 @@ class EngineX2:
             d, v = dims[l], _vox(dims[l])
             c8 = ch[l] // 8
             if l == 0:
-                w, osc, b = self.packed['enc0.conv1']
+                w, osc, b = self.packed['enc0.conv1'][:3]
+                gn = self.norm == 'group'
                 nv.call('iunet_x2m_first_conv_fwd', self.dim, nv.ptr(x), nv.IN_DTYPE_CODE[x.dtype], nv.ll_array(x_strides),
-                        Pt(ws['a0']), 2 * ch[0] * v, c8, None, 0, nv.ptr(w), nv.ptr(osc), nv.ptr(b), self.act_scale,
-                        N, d[0], d[1], d[2], self.cin, ch[0], 1, nv.ptr(self._sat), s)
+                        Pt(ws['raw'] if gn else ws['a0']), 2 * ch[0] * v, c8, None, 0, nv.ptr(w), nv.ptr(osc), nv.ptr(b), self.act_scale,
+                        N, d[0], d[1], d[2], self.cin, ch[0], 0 if gn else 1, nv.ptr(self._sat), s)
+                if gn:
+                    self._gn('enc0.conv1', ws, Pt(ws['a0']), 2 * ch[0] * v, c8, N, d, ch[0], s)
             else:
                 self._conv3(f'enc{l}.conv1', Pt(ws[f'pin{l}']), 2 * ch[l - 1] * v, ch[l - 1] // 8, Pt(ws[f'a{l}']), 2 * ch[l] * v, c8,
-                            N, d, ch[l - 1], ch[l], s)
+                            N, d, ch[l - 1], ch[l], s, ws)
             if l < L - 1:
                 # skip half of the concat buffer: hi planes [0, c8), lo planes [2 c8, 3 c8)
                 self._conv3(f'enc{l}.conv2', Pt(ws[f'a{l}']), 2 * ch[l] * v, c8, Pt(ws[f'cat{l}']), 4 * ch[l] * v, 2 * c8,
-                            N, d, ch[l], ch[l], s)
+                            N, d, ch[l], ch[l], s, ws)
                 do = dims[l + 1]
                 nv.call('iunet_x2_maxpool_fwd', self.dim, Pt(ws[f'cat{l}']), 4 * ch[l] * v, 2 * c8, Pt(ws[f'pin{l + 1}']),
                         2 * ch[l] * _vox(do), c8, ch[l], N, do[0], do[1], do[2], s)
             else:
                 self._conv3(f'enc{l}.conv2', Pt(ws[f'a{l}']), 2 * ch[l] * v, c8, Pt(ws[f'b{l}']), 2 * ch[l] * v, c8,
-                            N, d, ch[l], ch[l], s)
+                            N, d, ch[l], ch[l], s, ws)
         for l in range(L - 2, -1, -1):
             d, v, di, vi = dims[l], _vox(dims[l]), dims[l + 1], _vox(dims[l + 1])
             c8 = ch[l] // 8
@@ -308,9 +342,9 @@ class EngineX2:
                     Pt(ws[f'cat{l}'], c8, v), 4 * ch[l] * v, 2 * c8, None, 0, nv.ptr(w), nv.ptr(osc), nv.ptr(b),
                     N, di[0], di[1], di[2], ch[l + 1], ch[l], nv.ptr(self._sat), s)
             self._conv3(f'dec{l}.conv1', Pt(ws[f'cat{l}']), 4 * ch[l] * v, 2 * c8, Pt(ws[f'a{l}']), 2 * ch[l] * v, c8,
-                        N, d, 2 * ch[l], ch[l], s)
+                        N, d, 2 * ch[l], ch[l], s, ws)
             self._conv3(f'dec{l}.conv2', Pt(ws[f'a{l}']), 2 * ch[l] * v, c8, Pt(ws[f'b{l}']), 2 * ch[l] * v, c8,
-                        N, d, ch[l], ch[l], s)
+                        N, d, ch[l], ch[l], s, ws)
         if features_only:
             return ws['b0']                       # input of the head: [N][hi planes | lo planes], scaled by act_scale
         self._head(ws, N, D, H, W, logits, probs, cls, out_strides, divisor, accumulate, s)

@@ -112,12 +112,12 @@ class UNet(nn.Module):
         self.dim, self.levels, self.base = dim, levels, base
         self.num_channels, self.num_classes = num_channels, num_classes
         # act_dtype None = the reference's pair: 16-bit training (trainer.py:59) + tolerance-meeting prediction (predict.py:30-35);
-        # the split mode folds BatchNorm into its operators, so GroupNorm / fp8-weight networks predict in their 16-bit mode
+        # fp8-weight networks predict in their own mode
         self.act_dtype = torch.float16 if act_dtype is None else _ACT[act_dtype]
         if infer_dtype is not None:
             self.infer_dtype = _ACT[infer_dtype]
-        elif act_dtype is None and weight_dtype is None and norm == 'batch':
-            self.infer_dtype = X2
+        elif act_dtype is None and weight_dtype is None:
+            self.infer_dtype = X2              # (GroupNorm networks too: engine_auto runs them in the full fp16x2 form)
         else:
             self.infer_dtype = self.act_dtype
         # 'fp8_e4m3' (BASELINE config C5): inference runs on weights quantised to OCP e4m3 with per-output-channel
@@ -199,15 +199,16 @@ class UNet(nn.Module):
         eng = self._engines.get(dev)
         if eng is None:
             if self.infer_dtype in (torch.float32, X2):
-                if self.weight_dtype is not None or self.norm != 'batch':
-                    raise ValueError(f"{_ACT_NAME[self.infer_dtype]!r} is a parity mode: BatchNorm network, no weight_dtype")
+                if self.weight_dtype is not None:
+                    raise ValueError(f"{_ACT_NAME[self.infer_dtype]!r} is a parity mode: no weight_dtype")
                 if self.infer_dtype == X2:
                     from .engine_auto import EngineAuto
                     eng = EngineAuto(self.dim, self.levels, self.base, self.num_channels, self.num_classes, dev,
-                                     policy=getattr(self, 'infer_policy', None))
+                                     policy=getattr(self, 'infer_policy', None), norm=self.norm, groups=self.groups)
                 else:
                     from .engine_f32 import EngineF32
-                    eng = EngineF32(self.dim, self.levels, self.base, self.num_channels, self.num_classes, dev)
+                    eng = EngineF32(self.dim, self.levels, self.base, self.num_channels, self.num_classes, dev, norm=self.norm,
+                                    groups=self.groups)
             else:
                 eng = Engine(self.dim, self.levels, self.base, self.num_channels, self.num_classes, self.infer_dtype, dev,
                              weight_dtype=self.weight_dtype, norm=self.norm, groups=self.groups, act_quant=self.act_quant)

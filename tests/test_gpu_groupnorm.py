@@ -192,3 +192,70 @@ def test_gn_pooled_forward_and_backward_equal_the_unfused_sequences(nv, dtype, n
         else:
             assert torch.equal(a, b), name
     assert res[0][2].float().abs().max().item() > 0
+
+
+# ---------------------------------------------------------------------------- tolerance-meeting prediction modes
+def _gn_parity(dim, shape, N, seed, modes):
+    """GroupNorm network in the fp32 mode and in split precision against the fp32 CPU oracle: the gate of tests/test_gpu_parity.py
+    (logits <= 1e-3 absolute, class map equal outside the tie band, IoU on rounded probabilities)."""
+    from tests.test_gpu_parity import _assert_fp32_mode, _compare, _forward, _labels, _smooth
+    from interactive_unet.engine_auto import EngineAuto
+    from interactive_unet.engine_f32 import EngineF32
+    from interactive_unet.engine_x2 import EngineX2
+    ncls = 2
+    p = unet_ref.init_params(dim=dim, ncls=ncls, seed=seed, randomize_bn=True)
+    img = np.stack([_smooth(shape, seed * 100 + i, sigma=6) for i in range(N)])[:, None]
+    x = torch.tensor(img)
+    ref = unet_ref.forward_logits(p, x.float() / 255.0, dim=dim, norm='group', groups=8)
+    y_true = _labels(img, ncls)
+    pc = {k: v.cuda() for k, v in p.items()}
+    res = {}
+    for mode in modes:
+        if mode == 'fp32':
+            e = EngineF32(dim=dim, ncls=ncls, norm='group', groups=8)
+        elif mode == 'fp16x2':
+            e = EngineX2(dim=dim, ncls=ncls, norm='group', groups=8)
+            assert not e.mixed
+        else:
+            e = EngineAuto(dim=dim, ncls=ncls, norm='group', groups=8)
+            assert e.policy == 'fp16x2'
+        e.load_eval(pc)
+        res[mode] = _compare(f'GroupNorm {mode} {dim}-D {N} x {shape}', *_forward(e, x.cuda(), dim, ncls), ref, y_true)
+        _assert_fp32_mode(res[mode])
+        if hasattr(e, 'saturated'):
+            assert not e.saturated()
+        del e
+        torch.cuda.empty_cache()
+    return res
+
+
+@pytest.mark.parametrize('dim,shape', [(2, (64, 96)), (2, (40, 72)), (3, (16, 32, 48)), (3, (8, 24, 40))])
+def test_groupnorm_tolerance_modes_small_shapes(dim, shape):
+    r = _gn_parity(dim, shape, 2, seed=3, modes=('fp32', 'fp16x2'))
+    assert r['fp32']['err'] <= 1e-4 and r['fp16x2']['err'] <= 1e-4
+
+
+def test_groupnorm_headline_2d_512_squared():
+    """BASELINE.json configs[1] shape with GroupNorm(8): 2 x 512^2 within 1e-3 of oracle/unet_ref.forward_logits(norm='group')."""
+    _gn_parity(2, (512, 512), 2, seed=6, modes=('fp32', 'fp16x2', 'default'))
+
+
+def test_groupnorm_headline_3d_128_cubed():
+    """BASELINE.json configs[2] shape with GroupNorm(8): one 128^3 chunk within 1e-3 of the oracle."""
+    _gn_parity(3, (128, 128, 128), 1, seed=5, modes=('fp32', 'fp16x2'))
+
+
+def test_groupnorm_unet_module_default_predicts_within_tolerance():
+    """UNet(norm='group') as a user builds it: trains in fp16, `forward()` answers from the split-precision engine (fp16x2 form)."""
+    from interactive_unet.engine_auto import EngineAuto
+    from tests.test_gpu_parity import _smooth
+    m, p = _model(2, 2, None)
+    m.eval()
+    assert isinstance(m.engine('eval'), EngineAuto) and m.engine('eval').form == 'fp16x2'
+    x = torch.tensor(_smooth((96, 64), 3))[None, None]
+    got = m(x.cuda()).cpu()
+    want = unet_ref.forward(p, x.float() / 255.0, dim=2, norm='group', groups=8)
+    assert (got - want).abs().max().item() <= 1e-4
+    m32, _ = _model(2, 2, 'fp32')
+    m32.eval()
+    assert (m32(x.cuda()).cpu() - want).abs().max().item() <= 1e-5
