@@ -253,13 +253,16 @@ def native_parity(model, cfg, chunk_u8):
     shape = tuple(chunk_u8.shape)
     D, H, W = shape if dim == 3 else (1,) + shape
     vox = D * H * W
-    e32 = EngineF32(dim, cfg['levels'], cfg['base'], 1, ncls, model.device)
+    norm = cfg.get('norm', 'batch')
+    e32 = EngineF32(dim, cfg['levels'], cfg['base'], 1, ncls, model.device, norm=norm)
     e32.load_eval(model.named_tensors())
     engs = [model.engine('eval'), e32]
     names = []
     if not cfg['wq']:
         for nm, mixed in (('fp16x2', False), ('x2m', True)):
-            ex2 = EngineX2(dim, cfg['levels'], cfg['base'], 1, ncls, model.device, mixed=mixed)
+            if mixed and norm == 'group':
+                continue                        # (GroupNorm networks have the full fp16x2 form only)
+            ex2 = EngineX2(dim, cfg['levels'], cfg['base'], 1, ncls, model.device, mixed=mixed, norm=norm)
             ex2.load_eval(model.named_tensors())
             engs.append(ex2)
             names.append(nm)
@@ -347,20 +350,23 @@ def cpu_baseline(cfg, model=None, chunk_u8=None):
         crop = chunk_u8[sl].contiguous()
         params = {k: t.detach().float().cpu() for k, t in model.named_tensors().items()}
         with torch.no_grad():
-            ref = unet_ref.forward_logits(params, crop.cpu().float()[None, None] / 255.0, dim=dim, levels=levels)
+            ref = unet_ref.forward_logits(params, crop.cpu().float()[None, None] / 255.0, dim=dim, levels=levels, norm=cfg.get('norm', 'batch'))
         D, H, W = shp if dim == 3 else (1,) + shp
-        e32 = EngineF32(dim, levels, base, 1, ncls, model.device)
+        norm = cfg.get('norm', 'batch')
+        e32 = EngineF32(dim, levels, base, 1, ncls, model.device, norm=norm)
         e32.load_eval(model.named_tensors())
         chk = {'sample': f'{"x".join(map(str, shp))} crop of a bench tile, current weights'}
         modes = [(cfg['dtype'], model.engine('eval')), ('fp32_mode', e32)]
         if not cfg['wq']:
             from interactive_unet.engine_auto import EngineAuto
             from interactive_unet.engine_x2 import EngineX2
-            ea = EngineAuto(dim, levels, base, 1, ncls, model.device)        # what UNet() predicts in: the calibrated choice
+            ea = EngineAuto(dim, levels, base, 1, ncls, model.device, norm=norm)        # what UNet() predicts in: the calibrated choice
             ea.load_eval(model.named_tensors())
             modes.append(('default_mode', ea))
             for nm, mixed in (('fp16x2', False), ('x2m', True)):
-                ex2 = EngineX2(dim, levels, base, 1, ncls, model.device, mixed=mixed)
+                if mixed and norm == 'group':
+                    continue
+                ex2 = EngineX2(dim, levels, base, 1, ncls, model.device, mixed=mixed, norm=norm)
                 ex2.load_eval(model.named_tensors())
                 modes.append((nm, ex2))
         for name, e in modes:
@@ -738,7 +744,7 @@ def run(args, workload, rank, world, dev, dist, group):
     # under '16-mixed', trainer.py:59) + prediction in the tolerance-meeting split-precision mode (fp16x2: logits within 1e-3 of the CPU
     # fp32 path, what UNet() predicts in by default; the reference predicts in fp32, predict.py:30-35).  The all-16-bit step is timed
     # afterwards, exactly the same way, as `throughput_mode`.
-    compliant = not cfg['wq'] and args.norm == 'batch' and not args.no_parity_mode
+    compliant = not cfg['wq'] and not args.no_parity_mode
     if compliant:
         set_predict_mode('fp16x2')
     head = timed_region(args.c4_reps)
@@ -849,17 +855,13 @@ def run(args, workload, rank, world, dev, dist, group):
             probe = my_slab[:S, :S, :S].contiguous()
         else:
             probe = chunks[0]
-        if args.norm == 'batch':
-            out['parity'], _ = native_parity(model, cfg, probe)
-        else:
-            out['parity'] = {'skipped': 'the fp32 and fp16x2 modes fold BatchNorm; the GroupNorm network is checked against the oracle '
-                                        'in tests/test_gpu_groupnorm.py'}
+        out['parity'], _ = native_parity(model, cfg, probe)
         # (the 2.5-D leg's device timings come BEFORE the host baseline: its ~90 launches per block are sensitive to the host cores, and the
         #  baseline's 16 torch threads keep spinning for a while after their last operator -- one run read 6.8 ms instead of 3.0 that way)
         if workload in ('c3', 'c2') and not args.no_2p5d:
             out['legs']['predict_2p5d'] = predict_2p5d_leg(dev, world == 1 and not args.no_cpu_baseline)
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'], chk = cpu_baseline(cfg, model if args.norm == 'batch' else None, probe)
+            out['cpu_baseline'], chk = cpu_baseline(cfg, model, probe)
             if chk:
                 out['parity']['vs_cpu_oracle'] = chk
     return out

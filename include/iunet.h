@@ -319,6 +319,13 @@ int iunet_net_forward(iunet_net* net, const void* x, int in_dtype, const long lo
                       void* logits, void* probs, void* cls, const long long* out_strides, float divisor, int accumulate, void* stream);
 /* predict.py:30-38: uint8 [N][cin][D][H][W] -> class map uint8 [N][D*H*W] */
 int iunet_net_forward_argmax(iunet_net* net, const void* x_u8, void* cls_u8, int N, int D, int H, int W, void* workspace, void* stream);
+/* validation_step (unet.py:104-116) as one call, 16-bit modes (0 / 1): eval-mode forward (running statistics folded by iunet_net_load) +
+ * fused head + softmax + loss / metrics on target / weight [N][ncls][D*H*W] (tdtype 0 f32, 1 f16; weight may be NULL; loss_kind 0 ce, 1
+ * dice, 2 iou, 3 mcc, 4 dice_ce, 5 iou_ce, 6 mcc_ce) -> out4 = [Loss, Dice, IoU, MCC] (4 device floats).  scratch:
+ * iunet_net_eval_scratch_bytes device bytes. */
+long long iunet_net_eval_scratch_bytes(const iunet_net* net, int N, int D, int H, int W);
+int iunet_net_eval_step(iunet_net* net, const void* x, int in_dtype, const long long* in_strides, const void* target, const void* weight,
+                        int tdtype, int loss_kind, int N, int D, int H, int W, void* workspace, void* scratch, void* out4, void* stream);
 
 /* ---- fp8 matrix cores: BASELINE config C5 ("fp8 weights / bf16 activations on CDNA4 fp8 MFMA") ------------------------
  * The stage convolutions of the forward pass (unet.py:65-69 over the canonical network) with the operator stored as OCP
@@ -614,6 +621,14 @@ int iunet_train_bind(iunet_train* t, void* flat, void* grad, void* m, void* v, v
 int iunet_train_repack(iunet_train* t, void* stream);
 int iunet_train_forward_backward(iunet_train* t, const void* x, int in_dtype, const long long* in_strides, const void* target,
                                  const void* weight, int tdtype, int N, int D, int H, int W, void* workspace, void* out4, void* stream);
+/* Data parallelism with the all-reduce overlapped (trainer.py:56-63 on N GPUs, one process per GPU): the same call with a HOST callback
+ * between the backward's launches -- hook(ctx, 0) once every launch writing the decoder + head gradients (the tail of `grad`, from the
+ * first decoder parameter on) is enqueued, hook(ctx, 1) once the bottom encoder level's are; the caller starts that bucket's all-reduce
+ * there, behind an event on `stream` (interactive_unet/dp.py: GradBuckets).  hook may be NULL. */
+typedef void (*iunet_train_hook)(void* ctx, int stage);
+int iunet_train_forward_backward_hooks(iunet_train* t, const void* x, int in_dtype, const long long* in_strides, const void* target,
+                                       const void* weight, int tdtype, int N, int D, int H, int W, void* workspace, void* out4,
+                                       iunet_train_hook hook, void* hook_ctx, void* stream);
 int iunet_train_update(iunet_train* t, float lr, float b1, float b2, float eps, float wd, float world, void* stream);
 int iunet_train_step(iunet_train* t, const void* x, int in_dtype, const long long* in_strides, const void* target, const void* weight,
                      int tdtype, int N, int D, int H, int W, void* workspace, float lr, float b1, float b2, float eps, float wd, void* out4,

@@ -62,6 +62,9 @@ int iunet_conv3_fwd(int, int, const void*, long long, void*, long long, const vo
                     int, int, void*);
 int iunet_maxpool_fwd(int, int, const void*, long long, void*, long long, int, int, int, int, int, void*);
 int iunet_convT_fwd(int, int, const void*, long long, void*, long long, const void*, const void*, int, int, int, int, int, int, void*);
+int iunet_head_loss_num_parts(int, long long);
+int iunet_head_loss_fwd(int, const void*, long long, int, const void*, const void*, int, const void*, const void*, int, int, void*, void*,
+                        void*, int, long long, void*);
 int iunet_head_fwd(int, const void*, long long, int, const void*, const void*, int, void*, void*, void*, const long long*, float, int, int,
                    int, int, int, void*);
 }
@@ -504,6 +507,32 @@ int iunet_net_forward(iunet_net* n, const void* x, int in_dtype, const long long
                                 probs, cls, os, divisor, accumulate, N, D, H, W, stream)
             : iunet_head_fwd(mode, WS + L.b[0], (long long)c0 * v0, c0, n->flat + n->head_w, n->flat + n->head_b, n->ncls, logits, probs, cls, os,
                              divisor, accumulate, N, D, H, W, stream);
+}
+
+/* validation_step (unet.py:104-116) in one call, 16-bit modes (0 / 1): the eval-mode forward (BatchNorm running statistics folded into the
+ * operators by iunet_net_load) up to the head's input, then the fused head + softmax + loss of iunet_head_loss_fwd on target / weight
+ * [N][ncls][D*H*W] (tdtype 0 f32, 1 f16; weight may be null; kind: metrics.py's seven losses) -> out4 = [Loss, Dice, IoU, MCC] (fp32,
+ * device).  scratch: iunet_net_eval_scratch_bytes. */
+long long iunet_net_eval_scratch_bytes(const iunet_net* n, int N, int D, int H, int W) {
+  if (!n || iunet_net_workspace_bytes(n, N, D, H, W) <= 0) return 0;
+  const long long v0 = (long long)D * H * W;
+  return align256((long long)iunet_head_loss_num_parts(N, v0) * n->ncls * 8 * 4) + align256((long long)n->ncls * 3 * 4);
+}
+int iunet_net_eval_step(iunet_net* n, const void* x, int in_dtype, const long long* in_strides, const void* target, const void* weight, int tdtype,
+                        int loss_kind, int N, int D, int H, int W, void* workspace, void* scratch, void* out4, void* stream) {
+  IUNET_REQUIRE(n && target && scratch && out4, "net_eval_step: null pointer");
+  IUNET_REQUIRE(n->mode == 0 || n->mode == 1, "net_eval_step: the validation step runs in the 16-bit training dtype (mode 0 / 1, got %d)", n->mode);
+  IUNET_REQUIRE(tdtype == 0 || tdtype == 1, "net_eval_step: target dtype must be 0 (f32) or 1 (f16)");
+  IUNET_REQUIRE(loss_kind >= 0 && loss_kind <= 6, "net_eval_step: loss kind %d", loss_kind);
+  int rc = iunet_net_forward(n, x, in_dtype, in_strides, N, D, H, W, workspace, nullptr, nullptr, nullptr, nullptr, 1.0f, 0, stream);
+  if (rc) return rc;
+  const WsLayout L = ws_layout(n, N, D, H, W);
+  const long long v0 = (long long)D * H * W;
+  const int c0 = n->ch[0];
+  unsigned char* S = (unsigned char*)scratch;
+  void* coef = S + align256((long long)iunet_head_loss_num_parts(N, v0) * n->ncls * 8 * 4);
+  return iunet_head_loss_fwd(n->mode, (unsigned char*)workspace + L.b[0], (long long)c0 * v0, c0, n->flat + n->head_w, n->flat + n->head_b, n->ncls,
+                             target, weight, tdtype, loss_kind, S, out4, coef, N, v0, stream);
 }
 
 /* predict.py:30-38 in one call: uint8 [N][cin][D][H][W] (contiguous) -> class map uint8 [N][D*H*W] */

@@ -352,8 +352,23 @@ int iunet_train_repack(iunet_train* n, void* stream) {
  * c, d, h, w), target / weight = [N][ncls][D*H*W] of tdtype (0 f32, 1 f16; weight may be null -- loader.py:142-154's batch contract).
  * Leaves loss_scale x dLoss/dparameter in the bound gradient vector, out4 = [Loss, Dice, IoU, MCC] (fp32 device pointer, optional),
  * the BatchNorm running statistics updated (momentum 0.1).  workspace: iunet_train_workspace_bytes. */
+typedef void (*iunet_train_hook)(void* ctx, int stage);
+int iunet_train_forward_backward_hooks(iunet_train* n, const void* x, int in_dtype, const long long* in_strides, const void* target,
+                                       const void* weight, int tdtype, int N, int D, int H, int W, void* workspace, void* out4,
+                                       iunet_train_hook hook, void* hook_ctx, void* stream);
 int iunet_train_forward_backward(iunet_train* n, const void* x, int in_dtype, const long long* in_strides, const void* target,
                                  const void* weight, int tdtype, int N, int D, int H, int W, void* workspace, void* out4, void* stream) {
+  return iunet_train_forward_backward_hooks(n, x, in_dtype, in_strides, target, weight, tdtype, N, D, H, W, workspace, out4, nullptr, nullptr, stream);
+}
+
+/* The same with a HOST callback between the backward's launches, for data parallelism (trainer.py:56-63 on N GPUs; one process per GPU):
+ * hook(ctx, 0) is called when every launch that writes the DECODER + HEAD gradients (the tail of the flat vector, from the first
+ * decoder parameter on) has been enqueued, hook(ctx, 1) when the BOTTOM encoder level's are -- the caller starts the all-reduce of that
+ * bucket there (behind an event on `stream`), so that it travels over xGMI while the rest of the backward computes; the remaining head
+ * of the vector is complete when the call returns.  hook may be null. */
+int iunet_train_forward_backward_hooks(iunet_train* n, const void* x, int in_dtype, const long long* in_strides, const void* target,
+                                       const void* weight, int tdtype, int N, int D, int H, int W, void* workspace, void* out4,
+                                       iunet_train_hook hook, void* hook_ctx, void* stream) {
   IUNET_REQUIRE(n && x && in_strides && target && workspace, "train_forward_backward: null pointer");
   IUNET_REQUIRE(n->packed != nullptr, "train_forward_backward: iunet_train_bind has not been called");
   IUNET_REQUIRE(iunet_train_workspace_bytes(n, N, D, H, W) > 0, "train_forward_backward: spatial size %d x %d x %d must be divisible by %d (D == 1 in 2-D)",
@@ -538,6 +553,7 @@ int iunet_train_forward_backward(iunet_train* n, const void* x, int in_dtype, co
     rc = iunet_convT_dgrad(dt, dim, dup, 2ll * c * v, WS + L.dz[ksrc], (long long)cn * vi, K + u.dgr, N, di, hi, wi, cn, c, stream);
     if (rc) return rc;
   }
+  if (hook) hook(hook_ctx, 0);                  // decoder + head gradients enqueued
   // encoder, bottom level upwards
   for (int l = lv - 1; l >= 0; --l) {
     const long long v = vox(l);
@@ -557,6 +573,7 @@ int iunet_train_forward_backward(iunet_train* n, const void* x, int in_dtype, co
       rc = conv_bwd(k1, WS + L.dz[k1], (long long)c * v, WS + L.pin[l], (long long)cp * v, WS + L.dpin[l], (long long)cp * v, -1, nullptr, 0, -1);
     }
     if (rc) return rc;
+    if (hook && l == lv - 1 && lv > 1) hook(hook_ctx, 1);      // the bottom encoder level's gradients enqueued
   }
   return IUNET_OK;
 }

@@ -105,6 +105,8 @@ _SIGS = {
     'iunet_net_load': [c_void_p, c_void_p, c_void_p, c_void_p],
     'iunet_net_forward': [c_void_p, c_void_p, c_int, ctypes.POINTER(c_ll), c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                           c_void_p, ctypes.POINTER(c_ll), c_float, c_int, c_void_p],
+    'iunet_net_eval_step': [c_void_p, c_void_p, c_int, ctypes.POINTER(c_ll), c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                            c_void_p, c_void_p, c_void_p],
     'iunet_net_forward_argmax': [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     # ---- training state on the device + the training step as one C call (csrc/train_net.hip)
     'iunet_train_state_init': [c_void_p, c_float, c_int, c_void_p],
@@ -120,6 +122,8 @@ _SIGS = {
     'iunet_train_repack': [c_void_p, c_void_p],
     'iunet_train_forward_backward': [c_void_p, c_void_p, c_int, ctypes.POINTER(c_ll), c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                      c_void_p, c_void_p, c_void_p],
+    'iunet_train_forward_backward_hooks': [c_void_p, c_void_p, c_int, ctypes.POINTER(c_ll), c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     'iunet_train_update': [c_void_p, c_float, c_float, c_float, c_float, c_float, c_float, c_void_p],
     'iunet_train_step': [c_void_p, c_void_p, c_int, ctypes.POINTER(c_ll), c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p,
                          c_float, c_float, c_float, c_float, c_float, c_void_p, c_void_p],
@@ -211,7 +215,7 @@ _SIGS = {
 # functions that return a size / count instead of a status
 _INT_RETURN = ['iunet_pack_desc_bytes', 'iunet_augment_desc_bytes', 'iunet_x2_prep_desc_bytes']
 _INT_RETURN_ARGS = {'iunet_zoom_nearest_len': [c_int, ctypes.c_double], 'iunet_x2_convT_kc': [c_int], 'iunet_x2m_head_fusable': [c_int, c_int], 'iunet_x2m_pool_fusable': [c_int, c_int], 'iunet_x2m_first_stage_fusable': [c_int] * 6, 'iunet_x2_pack_mode': [c_int], 'iunet_f8_pack_order': [c_int, c_int]}
-_LL_RETURN = {'iunet_gn_precise_slab_bytes': [c_int, c_int, c_ll], 'iunet_x2m_w8_bytes': [c_int] * 2, 'iunet_x2m_w8_bytes_nd': [c_int] * 3, 'iunet_train_num_params': [c_void_p], 'iunet_train_packed_bytes': [c_void_p], 'iunet_train_workspace_bytes': [c_void_p, c_int, c_int, c_int, c_int], 'iunet_conv3_wgrad_slab_floats': [c_int] * 7, 'iunet_f32_pack_conv_elems': [c_int] * 3, 'iunet_f8_pack_conv3_bytes': [c_int] * 3, 'iunet_conv3_f8_workspace_elems': [c_int] * 7, 'iunet_pack_conv3_elems': [c_int] * 4,
+_LL_RETURN = {'iunet_gn_precise_slab_bytes': [c_int, c_int, c_ll], 'iunet_net_eval_scratch_bytes': [c_void_p, c_int, c_int, c_int, c_int], 'iunet_x2m_w8_bytes': [c_int] * 2, 'iunet_x2m_w8_bytes_nd': [c_int] * 3, 'iunet_train_num_params': [c_void_p], 'iunet_train_packed_bytes': [c_void_p], 'iunet_train_workspace_bytes': [c_void_p, c_int, c_int, c_int, c_int], 'iunet_conv3_wgrad_slab_floats': [c_int] * 7, 'iunet_f32_pack_conv_elems': [c_int] * 3, 'iunet_f8_pack_conv3_bytes': [c_int] * 3, 'iunet_conv3_f8_workspace_elems': [c_int] * 7, 'iunet_pack_conv3_elems': [c_int] * 4,
               'iunet_pack_first_conv_elems': [c_int] * 3, 'iunet_slice_scatter_workspace_bytes': [c_int],
               'iunet_net_num_params': [c_void_p], 'iunet_net_packed_bytes': [c_void_p], 'iunet_net_workspace_bytes': [c_void_p] + [c_int] * 4}
 

@@ -79,6 +79,28 @@ class NetGraph:
         One small device-to-host read per workspace; the flags are cumulative since the workspace was made / reset_saturation()."""
         return self.mode >= 2 and any(int(ws[:4].view(torch.int32).item()) >= 0x7bff for ws in self._ws.values())
 
+    def eval_step(self, x, x_strides, N, D, H, W, y, w, tdt, kind):
+        """validation_step (unet.py:104-116) as one C call: -> device tensor [Loss, Dice, IoU, MCC] (overwritten by the next call)."""
+        if not self.filled:
+            raise RuntimeError('NetGraph.set_params() has not been called')
+        s = nv.stream()
+        if not self.loaded:
+            nv.call('iunet_net_load', self.h, nv.ptr(self.flat), nv.ptr(self.packed), s)
+            self.loaded = True
+        ws = self.workspace(N, D, H, W)
+        key = (N, D, H, W)
+        if not hasattr(self, '_scratch'):
+            self._scratch = {}
+        sc = self._scratch.get(key)
+        if sc is None:
+            if len(self._scratch) > 4:
+                self._scratch.clear()
+            sc = self._scratch[key] = torch.empty(self.lib.iunet_net_eval_scratch_bytes(self.h, N, D, H, W) + 16, dtype=torch.uint8, device=self.device)
+        out4 = sc[-16:].view(torch.float32)
+        nv.call('iunet_net_eval_step', self.h, nv.ptr(x), nv.IN_DTYPE_CODE[x.dtype], nv.ll_array(x_strides), nv.ptr(y), nv.ptr(w), tdt, kind,
+                N, D, H, W, nv.ptr(ws), nv.ptr(sc), nv.ptr(out4), s)
+        return out4
+
     def infer(self, x, x_strides, N, D, H, W, logits=None, probs=None, cls=None, out_strides=None, divisor=1.0, accumulate=False):
         if not self.filled:
             raise RuntimeError('NetGraph.set_params() has not been called')

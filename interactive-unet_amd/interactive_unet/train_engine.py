@@ -565,7 +565,16 @@ class TrainEngine:
         self.sync_weights()
         X, y, w, N, D, H, W, vox, xs = self._prep(X, y, w)
         h = self._handle()
-        if h is not None:
+        if h is not None and self.pg is not None:
+            # data parallel, C-sequenced: forward + backward as one call whose host callback starts the gradient buckets' all-reduce
+            # between the backward's launches (decoder + head first, then the bottom encoder level: dp.GradBuckets), the rest of the
+            # vector behind the call, then the update with the summed gradient
+            out4 = h.forward_backward(X, xs, y, w, N, D, H, W, buckets=self.buckets, bottom=(self._bottom_start, self._dec_start))
+            world = self.buckets.finish()
+            h.update(float(self.lr), self.betas, self.eps, self.wd, float(world))
+            self._py_stale = True
+            self.model._packed_sig = None
+        elif h is not None:
             # the whole step as ONE C call (csrc/train_net.hip: the same launches in the same order, sequenced in C++)
             out4 = h.step(X, xs, y, w, N, D, H, W, float(self.lr), self.betas, self.eps, self.wd)
             self._py_stale = True                  # the Python sequence's packed operators are behind the weights now
@@ -586,11 +595,13 @@ class TrainEngine:
         return out4
 
     def _handle(self):
-        """The C++-sequenced step (TrainHandle over iunet_train_*), or None where it does not apply: data parallel (the gradient buckets
-        start their all-reduce between the backward's launches), GroupNorm, a timing probe attached, IUNET_PY_TRAIN=1 (A/B switch), and the
-        FIRST step (a model that trains one step -- a smoke test -- never pays for the handle's own copy of the packed operators)."""
+        """The C++-sequenced step (TrainHandle over iunet_train_*), or None where it does not apply: GroupNorm, a timing probe attached,
+        IUNET_PY_TRAIN=1 (A/B switch), and the FIRST step (a model that trains one step -- a smoke test -- never pays for the handle's own
+        copy of the packed operators).  Data parallel runs through it too (iunet_train_forward_backward_hooks: the gradient buckets start
+        their all-reduce from a host callback between the backward's launches); IUNET_PY_DP=1 keeps that path on the Python sequence."""
         self._steps_seen = getattr(self, '_steps_seen', 0) + 1
-        if self.pg is not None or self.gn or self.probe is not None or os.environ.get('IUNET_PY_TRAIN') or not self.use_handle or self._steps_seen < 2:
+        if (self.pg is not None and os.environ.get('IUNET_PY_DP')) or self.gn or self.probe is not None or os.environ.get('IUNET_PY_TRAIN') \
+                or not self.use_handle or self._steps_seen < 2:
             return None
         if getattr(self, '_h', None) is None:
             self._h = TrainHandle(self)
@@ -612,7 +623,10 @@ class TrainEngine:
             from .engine import Engine
             self._eval_eng = Engine(self.dim, self.levels, m.base, self.cin, self.ncls, self.T, self.dev, norm=self.norm,
                                     groups=self.groups)
-        self._eval_eng.load_eval(m.named_tensors())              # one launch over a cached descriptor table
+        sig = (m._signature(), getattr(self, '_steps_seen', 0))
+        if sig != getattr(self, '_eval_sig', None):              # re-pack only when a step (or anyone else) moved the weights: a validation
+            self._eval_eng.load_eval(m.named_tensors())          # pass over many batches folds once (one launch over a cached table) and
+            self._eval_sig = sig                                 # runs from its second batch as one C call per batch (net_graph)
         return self._eval_eng
 
     def sync_weights(self):
@@ -676,6 +690,18 @@ class TrainEngine:
         self.sync_weights()
         X, y, w, N, D, H, W, vox, xs = self._prep(X, y, w)
         eng = self._eval_engine()
+        g = eng._graph() if hasattr(eng, '_graph') else None
+        if g is not None and eng.probe is None and not os.environ.get('IUNET_PY_EVAL'):
+            # the validation step as ONE C call (iunet_net_eval_step: the handle's eval-mode forward + the fused head / loss kernel); from
+            # the second batch on the same weights, as every use of the prediction handle
+            tdt = {torch.float32: 0, torch.float16: 1}[y.dtype]
+            if w is not None and w.dtype != y.dtype:
+                w = w.to(y.dtype)
+            out4 = g.eval_step(X, xs, N, D, H, W, y, w, tdt, self.kind)
+            if not sync:
+                return out4
+            o = out4.tolist()
+            return {'Loss': o[0], 'Dice': o[1], 'IoU': o[2], 'MCC': o[3]}
         feat = eng.infer(X, xs, N, D, H, W, features_only=True)
         ws = self.workspace(N, D, H, W)
         self.loss_forward(ws, feat, y, w, N, vox)
@@ -683,6 +709,9 @@ class TrainEngine:
             return ws['out4']                 # device tensor [loss, dice, iou, mcc], overwritten by the next step: clone to keep
         o = ws['out4'].tolist()
         return {'Loss': o[0], 'Dice': o[1], 'IoU': o[2], 'MCC': o[3]}
+
+
+_HOOK = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_int)       # iunet_train_hook
 
 
 class TrainHandle:
@@ -746,11 +775,33 @@ class TrainHandle:
             w = w.to(y.dtype)
         return tdt, w
 
-    def forward_backward(self, X, xs, y, w, N, D, H, W):
+    def forward_backward(self, X, xs, y, w, N, D, H, W, buckets=None, bottom=None):
+        """buckets (dp.GradBuckets): the C call's host callback starts the all-reduce of the decoder + head gradients (stage 0) and of the
+        bottom encoder level's (stage 1, bottom = (lo, hi) of that run in the flat vector or (None, ...)) between the backward's launches."""
         tdt, w = self._targets(y, w)
-        nv.call('iunet_train_forward_backward', self.h, nv.ptr(X), nv.IN_DTYPE_CODE[X.dtype], nv.ll_array(xs), nv.ptr(y), nv.ptr(w), tdt,
-                N, D, H, W, nv.ptr(self.workspace(N, D, H, W)), nv.ptr(self.out4), nv.stream())
+        if buckets is None:
+            nv.call('iunet_train_forward_backward', self.h, nv.ptr(X), nv.IN_DTYPE_CODE[X.dtype], nv.ll_array(xs), nv.ptr(y), nv.ptr(w), tdt,
+                    N, D, H, W, nv.ptr(self.workspace(N, D, H, W)), nv.ptr(self.out4), nv.stream())
+            return self.out4
+        err = []
+
+        def hook(_ctx, stage):
+            try:                                    # (an exception must not unwind through the C frame)
+                if stage == 0:
+                    buckets.start_tail()
+                elif bottom is not None and bottom[0] is not None:
+                    buckets.start(bottom[0], bottom[1])
+            except BaseException as e:              # noqa: BLE001
+                err.append(e)
+        cb = _HOOK(hook)
+        nv.call('iunet_train_forward_backward_hooks', self.h, nv.ptr(X), nv.IN_DTYPE_CODE[X.dtype], nv.ll_array(xs), nv.ptr(y), nv.ptr(w), tdt,
+                N, D, H, W, nv.ptr(self.workspace(N, D, H, W)), nv.ptr(self.out4), ctypes.cast(cb, ctypes.c_void_p), None, nv.stream())
+        if err:
+            raise err[0]
         return self.out4
+
+    def update(self, lr, betas, eps, wd, world=1.0):
+        nv.call('iunet_train_update', self.h, lr, betas[0], betas[1], eps, wd, world, nv.stream())
 
     def step(self, X, xs, y, w, N, D, H, W, lr, betas, eps, wd):
         tdt, w = self._targets(y, w)

@@ -238,7 +238,10 @@ def test_data_parallel_step_over_rccl_single_rank():
         for pg in (None, dist.group.WORLD):
             model, _ = _model(3, 2, seed=7, dtype='bf16')
             te = TrainEngine(model.train(), lr=1e-3, loss_kind='mcc_ce', process_group=pg)
-            losses.append([te.train_step(X, y, None)['Loss'] for _ in range(3)])
+            losses.append([te.train_step(X, y, None)['Loss'] for _ in range(4)])
+            # from the second step both run the C-sequenced step; the data-parallel one through iunet_train_forward_backward_hooks, whose
+            # host callback starts the gradient buckets between the backward's launches
+            assert getattr(te, '_h', None) is not None
         assert np.allclose(losses[0], losses[1], rtol=0, atol=1e-6), losses
         assert losses[0][2] < losses[0][0]
     finally:

@@ -159,3 +159,29 @@ def test_training_step_through_the_bare_c_abi():
     for b, (rm, rv) in zip(bn_names, zip(running[0::2], running[1::2])):
         assert torch.equal(rm, twin.tensor(b + '.running_mean')) and torch.equal(rv, twin.tensor(b + '.running_var'))
     l.iunet_train_destroy(h)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dim,shape,N,dtype', [(2, (64, 96), 2, 'fp16'), (3, (16, 32, 32), 2, 'bf16')])
+def test_c_sequenced_validation_step_is_the_python_sequenced_one(dim, shape, N, dtype, monkeypatch):
+    """validation_step (unet.py:104-116) as ONE C call (iunet_net_eval_step: the prediction handle's eval-mode forward + the fused head /
+    loss kernel) against the Python sequence (engine forward to the head's input + iunet_head_loss_fwd): the same four numbers, bit for bit."""
+    from interactive_unet.train_engine import TrainEngine
+    m = _model(dim, dtype)
+    te = TrainEngine(m, lr=1e-3, loss_kind='mcc_ce')
+    for step in range(2):
+        te.train_step(*_batch(step, N, shape))
+    batch = _batch(7, N, shape)
+    monkeypatch.setenv('IUNET_PY_EVAL', '1')
+    want = te.eval_step(*batch)
+    monkeypatch.delenv('IUNET_PY_EVAL')
+    first = te.eval_step(*batch)            # first forward on these weights: still the Python sequence
+    got = te.eval_step(*batch)              # second: the handle
+    eng = te._eval_engine()
+    from interactive_unet import net_graph
+    assert not net_graph.ENABLED or (eng._g is not None and eng._g.loaded)
+    assert want == first == got, (want, first, got)
+    assert 0.0 < got['Loss'] < 10.0 and 0.0 <= got['Dice'] <= 1.0
+    # the device-tensor form (trainer.train_model collects these per validation batch)
+    t = te.eval_step(*batch, sync=False)
+    assert t.tolist() == [got[k] for k in ('Loss', 'Dice', 'IoU', 'MCC')]
