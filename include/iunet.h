@@ -302,6 +302,11 @@ int iunet_x2m_conv3_fwd(const void* x, long long x_ss, const void* x8, long long
  * saturates at 65504 -- zero it once, read it when convenient; act_scale: a power of two, modes 2 / 3 only (0 = default 64). */
 typedef struct iunet_net iunet_net;
 int iunet_net_create(int dim, int levels, int base, int cin, int ncls, int mode, float act_scale, iunet_net** out);
+/* the same with the normalisation named: norm 0 = BatchNorm (eval-mode statistics folded into the operators), 1 = GroupNorm(groups) + ReLU
+ * after every stage conv (north star "GroupNorm/BN") -- mode 2 only, the split-precision form GroupNorm networks predict in (nothing
+ * folds: a stage conv writes its raw output, iunet_x2_gn_relu_fwd normalises it with per-(sample, group) statistics taken in double; the
+ * bn{j}.weight / .bias tensors of the flat vector are the affine pair, the running statistics are unused) */
+int iunet_net_create_ex(int dim, int levels, int base, int cin, int ncls, int mode, float act_scale, int norm, int groups, iunet_net** out);
 void iunet_net_destroy(iunet_net* net);
 /* the flat fp32 parameter vector: trainable tensors and BatchNorm running statistics in the canonical order (the state_dict keys of
  * interactive_unet/unet.py: enc{l}.conv{j}.weight [Cout][Cin][3^d], enc{l}.bn{j}.{weight,bias,running_mean,running_var},
@@ -610,6 +615,10 @@ int iunet_adamw_step_dev(void* p, const void* g, void* m, void* v, long long n, 
  * Data parallel callers run iunet_train_forward_backward, all-reduce `grad`, then iunet_train_update(world = ranks). */
 typedef struct iunet_train iunet_train;
 int iunet_train_create(int dim, int levels, int base, int cin, int ncls, int dtype, int loss_kind, iunet_train** out);
+/* the same with the normalisation named: norm 0 = BatchNorm, 1 = GroupNorm(groups) after every stage conv (north star "GroupNorm/BN";
+ * statistics per (sample, group), the same at training and inference: the running-statistics pointers of iunet_train_bind are accepted and
+ * left alone; train_engine.TrainEngine on a UNet(norm='group') sequences the same launches) */
+int iunet_train_create_ex(int dim, int levels, int base, int cin, int ncls, int dtype, int loss_kind, int norm, int groups, iunet_train** out);
 void iunet_train_destroy(iunet_train* t);
 long long iunet_train_num_params(const iunet_train* t);
 int iunet_train_num_tensors(const iunet_train* t);

@@ -7,6 +7,7 @@
 // prediction runs), 0 / 1 = fp16 / bf16 activations (the throughput path).  No device allocation, no synchronisation: the handle is
 // host memory only.
 #include "common.h"
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -62,6 +63,9 @@ int iunet_conv3_fwd(int, int, const void*, long long, void*, long long, const vo
                     int, int, void*);
 int iunet_maxpool_fwd(int, int, const void*, long long, void*, long long, int, int, int, int, int, void*);
 int iunet_convT_fwd(int, int, const void*, long long, void*, long long, const void*, const void*, int, int, int, int, int, int, void*);
+long long iunet_gn_precise_slab_bytes(int, int, long long);
+int iunet_x2_gn_relu_fwd(const void*, long long, int, void*, long long, int, const void*, const void*, int, float, float, void*, void*, void*, int, int,
+                         long long, void*, void*);
 int iunet_head_loss_num_parts(int, long long);
 int iunet_head_loss_fwd(int, const void*, long long, int, const void*, const void*, int, const void*, const void*, int, int, void*, void*,
                         void*, int, long long, void*);
@@ -101,6 +105,7 @@ struct UpOp { int ci, co; long long w, b, pk, aux; };
 
 struct iunet_net {
   int dim, levels, base, cin, ncls, mode;
+  int norm = 0, groups = 8;           // norm 1: GroupNorm(groups) + ReLU after every stage conv (mode 2 only): nothing folds, csrc/gn_precise.hip normalises
   float act_scale;
   int taps, npos;
   std::vector<int> ch;
@@ -118,7 +123,7 @@ namespace {
 
 int stage_index(const iunet_net* n, bool dec, int l) { return dec ? n->levels + (n->levels - 2 - l) : l; }
 
-struct WsLayout { std::vector<long long> a, b, cat, pin, am, catm, pinm; long long bytes; };
+struct WsLayout { std::vector<long long> a, b, cat, pin, am, catm, pinm; long long raw = -1, gnslab = -1, gnsc = -1, gnsh = -1; long long bytes; };
 
 // activation buffers of one forward (elements of 2 bytes; x2 holds hi + lo planes: twice the channels).  Modes 2 and 3: the first 256
 // bytes hold the range flag (an int the forward raises to 0x7bff when a stored hi word saturates; the caller zeroes it once).  x2m (mode 3):
@@ -148,6 +153,18 @@ WsLayout ws_layout(const iunet_net* n, int N, int D, int H, int W) {
     if (l < lv - 1) L.cat[l] = take((long long)N * mul * 2 * n->ch[l] * v);
     if (l > 0) L.pin[l] = take((long long)N * mul * n->ch[l - 1] * v);
   }
+  if (n->norm == 1) {        // GroupNorm: the raw output of the conv in flight, the statistics slab, the per-sample affine pairs
+    long long mx = 0, slab = 0;
+    for (int l = 0; l < lv; ++l) {
+      const long long v = (long long)(n->dim == 3 ? D >> l : 1) * (H >> l) * (W >> l);
+      mx = std::max(mx, (long long)n->ch[l] * v);
+      slab = std::max(slab, iunet_gn_precise_slab_bytes(N, n->ch[l], v));
+    }
+    L.raw = take((long long)N * 2 * mx);
+    L.gnslab = take(slab / 2 + 1);
+    L.gnsc = take(2ll * N * n->ch[lv - 1]);
+    L.gnsh = take(2ll * N * n->ch[lv - 1]);
+  }
   L.bytes = off;
   return L;
 }
@@ -158,8 +175,16 @@ extern "C" {
 
 /* mode: 0 fp16, 1 bf16, 2 fp16x2 (split precision), 3 fp16x2 with the cross terms of the stage convs on the fp8 matrix cores (3-D only);
  * act_scale: power of two (modes 2, 3; 0 = the default 64) */
+int iunet_net_create_ex(int dim, int levels, int base, int cin, int ncls, int mode, float act_scale, int norm, int groups, iunet_net** out);
 int iunet_net_create(int dim, int levels, int base, int cin, int ncls, int mode, float act_scale, iunet_net** out) {
+  return iunet_net_create_ex(dim, levels, base, cin, ncls, mode, act_scale, 0, 8, out);
+}
+/* norm: 0 BatchNorm (eval-mode statistics folded into the operators), 1 GroupNorm(groups) + ReLU after every stage conv (north star
+ * "GroupNorm/BN"; mode 2, the split-precision form GroupNorm networks predict in: engine_x2.EngineX2(norm='group')) */
+int iunet_net_create_ex(int dim, int levels, int base, int cin, int ncls, int mode, float act_scale, int norm, int groups, iunet_net** out) {
   IUNET_REQUIRE(out != nullptr, "net_create: null handle pointer");
+  IUNET_REQUIRE(norm == 0 || norm == 1, "net_create: norm must be 0 (batch) or 1 (group), got %d", norm);
+  IUNET_REQUIRE(norm == 0 || (mode == 2 && groups > 0 && base % groups == 0), "net_create: GroupNorm runs in mode 2 (fp16x2) with groups dividing base (mode %d, %d groups)", mode, groups);
   IUNET_REQUIRE(dim == 2 || dim == 3, "net_create: dim must be 2 or 3 (got %d)", dim);
   IUNET_REQUIRE(levels >= 2 && levels <= 6, "net_create: levels must be 2..6 (got %d)", levels);
   IUNET_REQUIRE(base > 0 && base % 32 == 0, "net_create: base channels must be a positive multiple of 32 (got %d)", base);
@@ -168,6 +193,7 @@ int iunet_net_create(int dim, int levels, int base, int cin, int ncls, int mode,
   IUNET_REQUIRE(mode >= 0 && mode <= 3, "net_create: mode must be 0 (fp16), 1 (bf16), 2 (fp16x2) or 3 (fp16x2, cross terms on fp8), got %d", mode);
   iunet_net* n = new iunet_net();
   n->dim = dim; n->levels = levels; n->base = base; n->cin = cin; n->ncls = ncls; n->mode = mode;
+  n->norm = norm; n->groups = groups;
   n->act_scale = act_scale > 0.f ? act_scale : 64.0f;
   n->taps = dim == 3 ? 27 : 9; n->npos = dim == 3 ? 8 : 4;
   for (int l = 0; l < levels; ++l) n->ch.push_back(base << l);
@@ -267,8 +293,9 @@ int iunet_net_load(iunet_net* n, const void* flat_params, void* packed, void* st
       if (rc) return rc;
     } else if (n->mode >= 2) {
       float* wv = (float*)(K + n->scratch_off);
-      rc = iunet_x2_prep(w, wv, aux, aux + op.co, g, be, mu, va, nullptr, eps, A, A, op.co, op.ci, n->taps, 0,
-                         op.first ? op.ci : (n->dim == 3 ? 16 : 32), stream);
+      const bool gn = n->norm == 1;         // GroupNorm: the raw operator (gamma / beta go to the normalisation pass)
+      rc = iunet_x2_prep(w, wv, aux, aux + op.co, gn ? nullptr : g, gn ? nullptr : be, gn ? nullptr : mu, gn ? nullptr : va, nullptr, eps, A, A,
+                         op.co, op.ci, n->taps, 0, op.first ? op.ci : (n->dim == 3 ? 16 : 32), stream);
       if (rc) return rc;
       rc = op.first ? iunet_pack_first_conv(0, wv, nullptr, K + op.pk[1], op.co, 3 * op.ci, n->taps, stream)
                     : iunet_pack_conv3(0, wv, nullptr, K + op.pk[1], op.co, 3 * op.ci, n->taps, iunet_x2_pack_mode(n->dim), stream);
@@ -437,6 +464,13 @@ int iunet_net_forward(iunet_net* n, const void* x, int in_dtype, const long long
     int d, h, w;
     dims(l, d, h, w);
     const float* aux = (const float*)(K + op.aux);
+    if (x2 && n->norm == 1) {        // raw output (no bias, no ReLU) as split words, then statistics + normalise + ReLU into the consumer's view
+      const long long v = (long long)d * h * w;
+      int r = iunet_x2_conv3_fwd_flag(dim, xp, x_ss, x_lo, WS + L.raw, 2ll * op.co * v, op.co / 8, K + op.pk[1], aux, aux + op.co, N, d, h, w, op.ci, op.co, 0, WS, stream);
+      if (r) return r;
+      return iunet_x2_gn_relu_fwd(WS + L.raw, 2ll * op.co * v, op.co / 8, yp, y_ss, y_lo, n->flat + op.bn, n->flat + op.bn + op.co, n->groups, 1e-5f,
+                                  n->act_scale, WS + L.gnslab, WS + L.gnsc, WS + L.gnsh, op.co, N, v, WS, stream);
+    }
     if (x2) return iunet_x2_conv3_fwd_flag(dim, xp, x_ss, x_lo, yp, y_ss, y_lo, K + op.pk[1], aux, aux + op.co, N, d, h, w, op.ci, op.co, 2, WS, stream);
     int lay = 1;
     if (op.pk[3] >= 0 && iunet_conv3_compact_ok(dim, N, d, h, w, op.ci, op.co, 0, 0)) lay = 3;
@@ -455,10 +489,14 @@ int iunet_net_forward(iunet_net* n, const void* x, int in_dtype, const long long
     const ConvOp& c2 = n->conv[2 * stage_index(n, false, l) + 1];
     if (l == 0) {
       const float* aux = (const float*)(K + c1.aux);
-      rc = x2 ? iunet_x2m_first_conv_fwd(dim, x, in_dtype, in_strides, WS + L.a[0], 2ll * c * v, c8, nullptr, 0, K + c1.pk[1], aux, aux + c, n->act_scale,
-                                         N, d, h, w, n->cin, c, 1, WS, stream)
+      const bool gn = n->norm == 1;
+      rc = x2 ? iunet_x2m_first_conv_fwd(dim, x, in_dtype, in_strides, WS + (gn ? L.raw : L.a[0]), 2ll * c * v, c8, nullptr, 0, K + c1.pk[1], aux, aux + c, n->act_scale,
+                                         N, d, h, w, n->cin, c, gn ? 0 : 1, WS, stream)
               : iunet_first_conv_fwd(mode, dim, x, in_dtype, in_strides, WS + L.a[0], (long long)c * v, K + c1.pk[1], aux + c, nullptr,
                                      N, d, h, w, n->cin, c, 1, stream);
+      if (!rc && x2 && gn)
+        rc = iunet_x2_gn_relu_fwd(WS + L.raw, 2ll * c * v, c8, WS + L.a[0], 2ll * c * v, c8, n->flat + c1.bn, n->flat + c1.bn + c, n->groups, 1e-5f, n->act_scale,
+                                  WS + L.gnslab, WS + L.gnsc, WS + L.gnsh, c, N, v, WS, stream);
     } else {
       const int cp = n->ch[l - 1];
       rc = conv(c1, WS + L.pin[l], (long long)mul * cp * v, cp / 8, WS + L.a[l], (long long)mul * c * v, c8, l);

@@ -68,6 +68,15 @@ int iunet_first_conv_wgrad_blocks(int, int, int, int, int);
 int iunet_first_conv_wgrad_bn(int, int, const void*, int, const long long*, const void*, long long, const void*, long long, const void*,
                               const void*, const void*, const void*, const void*, void*, void*, int, int, int, int, int, int, void*);
 int iunet_adamw_step_dev(void*, const void*, void*, void*, long long, float, float, float, float, float, void*, int, float, void*);
+int iunet_gn_relu_fwd(int, const void*, long long, void*, long long, const void*, const void*, int, float, void*, void*, void*, void*, void*, int, int,
+                      long long, void*);
+int iunet_gn_relu_pool_fwd(int, int, const void*, long long, void*, long long, void*, long long, const void*, const void*, int, float, void*, void*,
+                           void*, void*, void*, int, int, int, int, int, void*);
+int iunet_gn_relu_bwd(int, const void*, long long, const void*, long long, void*, long long, const void*, int, const void*, const void*, const void*,
+                      const void*, void*, void*, void*, void*, int, int, long long, void*);
+int iunet_gn_relu_pool_bwd(int, int, const void*, long long, const void*, long long, const void*, long long, void*, long long, const void*, int,
+                           const void*, const void*, const void*, const void*, void*, void*, void*, void*, int, int, int, int, int, void*);
+int iunet_first_conv_wgrad(int, int, const void*, int, const long long*, const void*, long long, void*, void*, int, int, int, int, int, int, void*);
 }
 
 namespace {
@@ -103,6 +112,7 @@ struct TWs {
 }  // namespace
 
 struct iunet_train {
+  int norm = 0, groups = 8;                      // norm 1: GroupNorm(groups) after every stage conv (statistics per (sample, group), nothing fused into the convs)
   int dim, levels, base, cin, ncls, dtype, kind;
   int taps, npos;
   bool fuse_act, fuse_bw, head_act;
@@ -166,7 +176,8 @@ TWs ws_layout(const iunet_train* n, int N, int D, int H, int W) {
     L.y[k] = act((long long)N * c.co * v);
     const bool enc = c.name[0] == 'e', skip = enc && c.name.back() == '2' && c.l < lv - 1;
     if (!skip) { L.z[k] = act((long long)N * c.co * v); L.dz[k] = act((long long)N * c.co * v); }
-    L.scale[k] = f32(c.co); L.shift[k] = f32(c.co); L.mean[k] = f32(c.co); L.invstd[k] = f32(c.co);
+    const long long rows = n->norm == 1 ? N : 1;          // GroupNorm: one (scale, shift, mean, invstd) row per sample
+    L.scale[k] = f32(rows * c.co); L.shift[k] = f32(rows * c.co); L.mean[k] = f32(rows * c.co); L.invstd[k] = f32(rows * c.co);
     if (c.first) {
       max_stats = std::max(max_stats, (long long)iunet_conv3_num_tiles(dim, N, d, h, w) * c.co * 2);
       max_wslab = std::max(max_wslab, (long long)iunet_first_conv_wgrad_blocks(dim, N, d, h, w) * c.co * 112);
@@ -195,7 +206,7 @@ TWs ws_layout(const iunet_train* n, int N, int D, int H, int W) {
   const long long v0 = vox(0);
   L.dy = act((long long)N * max_dy);
   L.stats = f32(max_stats); L.wslab = f32(max_wslab); L.bnslab = f32(max_bn);
-  L.bncoef = f32(3ll * n->ch[lv - 1]);
+  L.bncoef = f32(3ll * n->ch[lv - 1] * (n->norm == 1 ? N : 1));
   L.lslab = f32((long long)iunet_head_loss_num_parts(N, v0) * n->ncls * 8);
   L.hslab = f32((long long)iunet_head_loss_bwd_num_parts(N, v0, n->ncls, n->ch[0]) * n->ncls * (n->ch[0] + 1));
   L.htmp = f32((long long)n->ncls * (n->ch[0] + 1));
@@ -211,8 +222,15 @@ extern "C" {
 
 /* dtype: 0 fp16, 1 bf16 (the 16-bit training modes of interactive_unet.train_engine.TrainEngine); loss_kind: 0 ce, 1 dice, 2 iou, 3 mcc,
  * 4 dice_ce, 5 iou_ce, 6 mcc_ce (utils.py:458-475; the reference's default is mcc_ce, unet.py:17) */
+int iunet_train_create_ex(int dim, int levels, int base, int cin, int ncls, int dtype, int loss_kind, int norm, int groups, iunet_train** out);
 int iunet_train_create(int dim, int levels, int base, int cin, int ncls, int dtype, int loss_kind, iunet_train** out) {
+  return iunet_train_create_ex(dim, levels, base, cin, ncls, dtype, loss_kind, 0, 8, out);
+}
+/* norm: 0 BatchNorm, 1 GroupNorm(groups) after every stage conv (north star "GroupNorm/BN"; statistics per (sample, group), the same at
+ * training and inference -- the running-statistics pointers of iunet_train_bind are accepted and left alone) */
+int iunet_train_create_ex(int dim, int levels, int base, int cin, int ncls, int dtype, int loss_kind, int norm, int groups, iunet_train** out) {
   IUNET_REQUIRE(out != nullptr, "train_create: null handle pointer");
+  IUNET_REQUIRE(norm == 0 || (norm == 1 && groups > 0 && base % groups == 0), "train_create: norm must be 0 (batch) or 1 (group, groups dividing base): %d, %d groups", norm, groups);
   IUNET_REQUIRE(dim == 2 || dim == 3, "train_create: dim must be 2 or 3 (got %d)", dim);
   IUNET_REQUIRE(levels >= 2 && levels <= 6, "train_create: levels must be 2..6 (got %d)", levels);
   IUNET_REQUIRE(base > 0 && base % 32 == 0, "train_create: base channels must be a positive multiple of 32 (got %d)", base);
@@ -226,9 +244,11 @@ int iunet_train_create(int dim, int levels, int base, int cin, int ncls, int dty
   n->dim = dim; n->levels = levels; n->base = base; n->cin = cin; n->ncls = ncls; n->dtype = dtype; n->kind = loss_kind;
   n->taps = dim == 3 ? 27 : 9; n->npos = dim == 3 ? 8 : 4;
   // the A/B switches of the Python-sequenced engine (train_engine.TrainEngine.__init__): the two sequences stay the same launches
-  n->fuse_act = !env_on("IUNET_NO_ACT_FUSION");
-  n->fuse_bw = !env_on("IUNET_NO_BW_FUSION");
-  n->head_act = !env_on("IUNET_NO_HEAD_ACT");
+  n->norm = norm; n->groups = groups;
+  // (GroupNorm: per-sample statistics -- none of the per-channel fusions of the BatchNorm path applies, train_engine.TrainEngine.__init__)
+  n->fuse_act = norm == 0 && !env_on("IUNET_NO_ACT_FUSION");
+  n->fuse_bw = norm == 0 && !env_on("IUNET_NO_BW_FUSION");
+  n->head_act = norm == 0 && !env_on("IUNET_NO_HEAD_ACT");
   for (int l = 0; l < levels; ++l) n->ch.push_back(base << l);
   long long off = 0, pk = 0;
   int nbn = 0;
@@ -395,7 +415,7 @@ int iunet_train_forward_backward_hooks(iunet_train* n, const void* x, int in_dty
     dims(c.l, d, h, w);
     const long long v = vox(c.l);
     void* y = WS + L.y[k];
-    float* stats = F(L.stats);
+    float* stats = n->norm == 1 ? nullptr : F(L.stats);       // GroupNorm takes its statistics in its own pass (per sample)
     int nparts;
     if (c.first) {
       nparts = iunet_conv3_num_tiles(dim, N, d, h, w);
@@ -409,6 +429,16 @@ int iunet_train_forward_backward_hooks(iunet_train* n, const void* x, int in_dty
                                     c.ci, c.co, 0, lay, stream);
     }
     if (rc) return rc;
+    if (n->norm == 1) {
+      if (pool_p != nullptr) {
+        int dn, hn, wn;
+        dims(c.l + 1, dn, hn, wn);
+        return iunet_gn_relu_pool_fwd(dt, dim, y, c.co * v, zp, z_ss, pool_p, pool_ss, P + c.gamma, P + c.beta, n->groups, eps, F(L.bnslab), F(L.scale[k]),
+                                      F(L.shift[k]), F(L.mean[k]), F(L.invstd[k]), c.co, N, dn, hn, wn, stream);
+      }
+      return iunet_gn_relu_fwd(dt, y, c.co * v, zp, z_ss, P + c.gamma, P + c.beta, n->groups, eps, F(L.bnslab), F(L.scale[k]), F(L.shift[k]),
+                               F(L.mean[k]), F(L.invstd[k]), c.co, N, v, stream);
+    }
     rc = iunet_bn_finalize(stats, nparts, c.co, (double)N * v, P + c.gamma, P + c.beta, n->running[2 * c.bn], n->running[2 * c.bn + 1], momentum, eps,
                            F(L.scale[k]), F(L.shift[k]), F(L.mean[k]), F(L.invstd[k]), stream);
     if (rc) return rc;
@@ -497,7 +527,15 @@ int iunet_train_forward_backward_hooks(iunet_train* n, const void* x, int in_dty
     const long long v = vox(c.l);
     void* dy = WS + L.dy;
     const void* y = WS + L.y[k];
-    if (dpool != nullptr) {
+    if (n->norm == 1 && dpool != nullptr) {
+      int dn, hn, wn;
+      dims(c.l + 1, dn, hn, wn);
+      rc = iunet_gn_relu_pool_bwd(dt, dim, dzp, dz_ss, dpool, dpool_ss, y, c.co * v, dy, c.co * v, P + c.gamma, n->groups, F(L.scale[k]), F(L.shift[k]),
+                                  F(L.mean[k]), F(L.invstd[k]), G + c.gamma, G + c.beta, F(L.bnslab), F(L.bncoef), c.co, N, dn, hn, wn, stream);
+    } else if (n->norm == 1) {
+      rc = iunet_gn_relu_bwd(dt, dzp, dz_ss, y, c.co * v, dy, c.co * v, P + c.gamma, n->groups, F(L.scale[k]), F(L.shift[k]), F(L.mean[k]), F(L.invstd[k]),
+                             G + c.gamma, G + c.beta, F(L.bnslab), F(L.bncoef), c.co, N, v, stream);
+    } else if (dpool != nullptr) {
       int dn, hn, wn;
       dims(c.l + 1, dn, hn, wn);
       rc = iunet_bn_relu_pool_bwd(dt, dim, dzp, dz_ss, dpool, dpool_ss, y, c.co * v, dy, c.co * v, F(L.mean[k]), F(L.invstd[k]), P + c.gamma,
@@ -513,6 +551,8 @@ int iunet_train_forward_backward_hooks(iunet_train* n, const void* x, int in_dty
     }
     if (rc) return rc;
     float* gw = G + c.w;
+    if (c.first && n->norm == 1)
+      return iunet_first_conv_wgrad(dt, dim, x, in_dtype, in_strides, dy, c.co * v, F(L.wslab), gw, N, d, h, w, c.ci, c.co, stream);
     if (c.first)
       return iunet_first_conv_wgrad_bn(dt, dim, x, in_dtype, in_strides, dzp, dz_ss, y, c.co * v, F(L.mean[k]), F(L.invstd[k]), F(L.bncoef),
                                        F(L.scale[k]), F(L.shift[k]), F(L.wslab), gw, N, d, h, w, c.ci, c.co, stream);

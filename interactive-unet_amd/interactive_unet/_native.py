@@ -100,6 +100,7 @@ _SIGS = {
                              c_int, c_int, c_ll, c_void_p, c_void_p],
     'iunet_logit_diff': [c_void_p, c_void_p, c_ll, c_void_p, c_void_p],
     'iunet_net_create': [c_int, c_int, c_int, c_int, c_int, c_int, c_float, ctypes.POINTER(c_void_p)],
+    'iunet_net_create_ex': [c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_int, ctypes.POINTER(c_void_p)],
     'iunet_net_num_tensors': [c_void_p],
     'iunet_net_param': [c_void_p, c_int, ctypes.c_char_p, c_int, ctypes.POINTER(c_ll), ctypes.POINTER(c_ll)],
     'iunet_net_load': [c_void_p, c_void_p, c_void_p, c_void_p],
@@ -115,6 +116,7 @@ _SIGS = {
     'iunet_head_grad_scatter': [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
     'iunet_adamw_step_dev': [c_void_p, c_void_p, c_void_p, c_void_p, c_ll, c_float, c_float, c_float, c_float, c_float, c_void_p, c_int, c_float, c_void_p],
     'iunet_train_create': [c_int, c_int, c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_void_p)],
+    'iunet_train_create_ex': [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_void_p)],
     'iunet_train_num_tensors': [c_void_p],
     'iunet_train_param': [c_void_p, c_int, ctypes.c_char_p, c_int, ctypes.POINTER(c_ll), ctypes.POINTER(c_ll)],
     'iunet_train_num_bn': [c_void_p],

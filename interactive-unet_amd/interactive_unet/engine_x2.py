@@ -79,10 +79,11 @@ class EngineX2:
         self._g_fwd += 1
         if self._g_fwd < 2:
             return None
-        if not net_graph.ENABLED or not self.use_graph or self.norm != 'batch' or self.weight_dtype or not (2 <= self.levels <= 6) or self._gparams is None:
+        if not net_graph.ENABLED or not self.use_graph or self.weight_dtype or not (2 <= self.levels <= 6) or self._gparams is None:
             return None
         if self._g is None:
-            self._g = net_graph.NetGraph(self.dim, self.levels, self.base, self.cin, self.ncls, 3 if self.mixed else 2, self.device, act_scale=self.act_scale)
+            self._g = net_graph.NetGraph(self.dim, self.levels, self.base, self.cin, self.ncls, 3 if self.mixed else 2, self.device, act_scale=self.act_scale,
+                                         norm=self.norm, groups=self.groups)
         if self._g_dirty:
             self._g.set_params(self._gparams)
             self._g_dirty = False

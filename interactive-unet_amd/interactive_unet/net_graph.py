@@ -19,10 +19,10 @@ ENABLED = not os.environ.get('IUNET_PY_GRAPH')
 class NetGraph:
     """iunet_net_* handle + its device buffers (flat fp32 parameters in state_dict order, packed operators, workspaces by shape)."""
 
-    def __init__(self, dim, levels, base, cin, ncls, mode, device, act_scale=0.0):
+    def __init__(self, dim, levels, base, cin, ncls, mode, device, act_scale=0.0, norm='batch', groups=8):
         self.lib = nv.lib()
         self.h = ctypes.c_void_p()
-        nv.call('iunet_net_create', dim, levels, base, cin, ncls, mode, float(act_scale), ctypes.byref(self.h))
+        nv.call('iunet_net_create_ex', dim, levels, base, cin, ncls, mode, float(act_scale), 1 if norm == 'group' else 0, int(groups), ctypes.byref(self.h))
         self.device, self.ncls, self.cin, self.mode = device, ncls, cin, mode
         self.layout = []
         for i in range(self.lib.iunet_net_num_tensors(self.h)):

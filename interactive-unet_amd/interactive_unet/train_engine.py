@@ -595,12 +595,12 @@ class TrainEngine:
         return out4
 
     def _handle(self):
-        """The C++-sequenced step (TrainHandle over iunet_train_*), or None where it does not apply: GroupNorm, a timing probe attached,
+        """The C++-sequenced step (TrainHandle over iunet_train_*), or None where it does not apply: a timing probe attached,
         IUNET_PY_TRAIN=1 (A/B switch), and the FIRST step (a model that trains one step -- a smoke test -- never pays for the handle's own
         copy of the packed operators).  Data parallel runs through it too (iunet_train_forward_backward_hooks: the gradient buckets start
         their all-reduce from a host callback between the backward's launches); IUNET_PY_DP=1 keeps that path on the Python sequence."""
         self._steps_seen = getattr(self, '_steps_seen', 0) + 1
-        if (self.pg is not None and os.environ.get('IUNET_PY_DP')) or self.gn or self.probe is not None or os.environ.get('IUNET_PY_TRAIN') \
+        if (self.pg is not None and os.environ.get('IUNET_PY_DP')) or self.probe is not None or os.environ.get('IUNET_PY_TRAIN') \
                 or not self.use_handle or self._steps_seen < 2:
             return None
         if getattr(self, '_h', None) is None:
@@ -724,7 +724,7 @@ class TrainHandle:
         self.lib = nv.lib()
         self.h = ctypes.c_void_p()
         m = te.model
-        nv.call('iunet_train_create', te.dim, te.levels, m.base, te.cin, te.ncls, te.dt, te.kind, ctypes.byref(self.h))
+        nv.call('iunet_train_create_ex', te.dim, te.levels, m.base, te.cin, te.ncls, te.dt, te.kind, 1 if te.gn else 0, int(te.groups), ctypes.byref(self.h))
         n = self.lib.iunet_train_num_params(self.h)
         if n != te.flat.numel():
             raise RuntimeError(f'iunet_train: {n} parameters, the engine holds {te.flat.numel()}')

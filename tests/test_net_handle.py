@@ -128,3 +128,52 @@ def test_c_graph_matches_the_python_engines_and_the_oracle(dim, shape, mode):
         assert err <= 1e-3 and (not mism.any() or (top2[:, 0] - top2[:, 1])[mism].max().item() <= 2 * err)
         assert int(ws[:4].view(torch.int32).item()) == 0          # no activation saturated
     nv.lib().iunet_net_destroy(h)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dim,shape', [(2, (64, 96)), (3, (16, 32, 48))])
+def test_groupnorm_network_through_the_handle(dim, shape):
+    """iunet_net_create_ex(norm = 1): the GroupNorm(8) network in split precision (mode 2) sequenced in C++ -- the same launches as
+    engine_x2.EngineX2(norm='group') sequences from Python (torch.equal), within 1e-3 of oracle/unet_ref.forward_logits(norm='group'),
+    and the engine's own default route from its second forward on."""
+    from interactive_unet.engine_x2 import EngineX2
+    from interactive_unet import net_graph
+    nv = _nv()
+    l = nv.lib()
+    ncls, N = 3, 2
+    p = unet_ref.init_params(dim=dim, ncls=ncls, seed=12, randomize_bn=True)
+    h = ctypes.c_void_p()
+    assert l.iunet_net_create_ex(dim, 4, 32, 1, ncls, 0, 0.0, 1, 8, ctypes.byref(h)) < 0 and b'GroupNorm' in l.iunet_last_error()      # 16-bit modes: BatchNorm only
+    nv.call('iunet_net_create_ex', dim, 4, 32, 1, ncls, 2, 0.0, 1, 8, ctypes.byref(h))
+    flat = torch.empty(l.iunet_net_num_params(h), device='cuda')
+    for name, off, n in _layout(nv, h):
+        flat[off:off + n] = p[name].reshape(-1).cuda()
+    packed = torch.empty(l.iunet_net_packed_bytes(h), dtype=torch.uint8, device='cuda')
+    nv.call('iunet_net_load', h, nv.ptr(flat), nv.ptr(packed), nv.stream())
+    D, H, W = shape if dim == 3 else (1,) + shape
+    vox = D * H * W
+    ws = torch.zeros(l.iunet_net_workspace_bytes(h, N, D, H, W), dtype=torch.uint8, device='cuda')
+    rng = np.random.default_rng(5)
+    x = torch.tensor(rng.integers(0, 256, (N, 1) + shape, dtype=np.uint8)).cuda()
+    logits = torch.empty((N, ncls) + shape, device='cuda')
+    cls = torch.empty((N, vox), dtype=torch.uint8, device='cuda')
+    st = nv.ll_array((vox, vox, H * W, W, 1))
+    os_ = nv.ll_array((ncls * vox, vox, H * W, W, 1))
+    nv.call('iunet_net_forward', h, nv.ptr(x), 2, st, N, D, H, W, nv.ptr(ws), nv.ptr(logits), None, nv.ptr(cls), os_, 1.0, 0, nv.stream())
+    e = EngineX2(dim=dim, ncls=ncls, norm='group', groups=8)
+    e.load_eval({k: v.cuda() for k, v in p.items()})
+    lg2, cl2, lg3 = torch.empty_like(logits), torch.empty_like(cls), torch.empty_like(logits)
+    e.use_graph = False
+    e.infer(x, (vox, vox, H * W, W, 1), N, D, H, W, logits=lg2, cls=cl2)
+    e.use_graph = True
+    e._g_fwd = 1
+    e.infer(x, (vox, vox, H * W, W, 1), N, D, H, W, logits=lg3)
+    torch.cuda.synchronize()
+    assert torch.equal(logits, lg2) and torch.equal(cls, cl2) and torch.equal(lg3, lg2)
+    assert not net_graph.ENABLED or (e._g is not None and e._g.loaded)
+    ref = unet_ref.forward_logits(p, x.cpu().float() / 255.0, dim=dim, norm='group', groups=8)
+    err = (logits.cpu() - ref).abs().max().item()
+    print(f'[net handle {dim}-D GroupNorm, mode 2] max |logit - CPU fp32 oracle| = {err:.2e}')
+    assert err <= 1e-4
+    assert int(ws[:4].view(torch.int32).item()) == 0
+    l.iunet_net_destroy(h)

@@ -50,11 +50,11 @@ def test_train_handle_argument_checks_without_gpu():
     l.iunet_train_destroy(h)
 
 
-def _model(dim, dtype, seed=1):
+def _model(dim, dtype, seed=1, norm='batch'):
     from interactive_unet.unet import UNet
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
-        m = UNet(lr=1e-3, num_classes=2, dim=dim, pretrained=False, act_dtype=dtype)
+        m = UNet(lr=1e-3, num_classes=2, dim=dim, pretrained=False, act_dtype=dtype, norm=norm)
     m.load_named(unet_ref.init_params(dim=dim, ncls=2, seed=seed))
     return m.cuda()
 
@@ -185,3 +185,24 @@ def test_c_sequenced_validation_step_is_the_python_sequenced_one(dim, shape, N, 
     # the device-tensor form (trainer.train_model collects these per validation batch)
     t = te.eval_step(*batch, sync=False)
     assert t.tolist() == [got[k] for k in ('Loss', 'Dice', 'IoU', 'MCC')]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dim,shape,N,dtype', [(2, (64, 96), 2, 'fp16'), (3, (16, 32, 32), 2, 'bf16')])
+def test_c_sequenced_groupnorm_step_is_the_python_sequenced_step(dim, shape, N, dtype):
+    """iunet_train_create_ex(norm = 1): the GroupNorm(8) training step sequenced in C++ against train_engine.TrainEngine's Python sequence on a
+    twin module -- the same launches: losses, parameters, moments and state bit for bit over four steps."""
+    from interactive_unet.train_engine import TrainEngine
+    a, b = _model(dim, dtype, norm='group'), _model(dim, dtype, norm='group')
+    te_a = TrainEngine(a, lr=1e-3, loss_kind='mcc_ce')
+    te_b = TrainEngine(b, lr=1e-3, loss_kind='mcc_ce')
+    assert te_a.gn and te_b.gn
+    te_a.use_handle = False
+    te_b._steps_seen = 1
+    for step in range(4):
+        batch = _batch(step, N, shape)
+        ra, rb = te_a.train_step(*batch), te_b.train_step(*batch)
+        assert getattr(te_b, '_h', None) is not None and getattr(te_a, '_h', None) is None
+        assert ra == rb, (step, ra, rb)
+        _same(te_a, te_b, f'GroupNorm step {step}')
+    assert ra['Loss'] < 10.0
