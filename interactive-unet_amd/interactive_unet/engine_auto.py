@@ -206,6 +206,22 @@ class EngineAuto:
         return e.infer(x, x_strides, N, D, H, W, logits=logits, probs=probs, cls=cls, out_strides=out_strides, divisor=divisor,
                        accumulate=accumulate, features_only=features_only)
 
+    def infer_views(self, views, D, H, W, outs):
+        """Several input views of one spatial size as ONE batch (engine_x2.EngineX2.infer_views: the 2.5-D block prediction's three axes in
+        one forward); forms without that entry run the views one by one.  views = [(x, x_strides, n)], outs = [dict of infer's outputs]."""
+        if self._params is None:
+            raise RuntimeError('EngineAuto.load_eval() has not been called')
+        if self._due():
+            x, xs, _ = views[0]
+            self.calibrate(x, xs, D, H, W, blocking=self.mode is None)
+        e = self.active
+        if getattr(e, 'probe', None) is not self._probe:
+            e.probe = self._probe
+        if hasattr(e, 'infer_views'):
+            return e.infer_views(views, D, H, W, outs)
+        for (x, xs, n), o in zip(views, outs):
+            e.infer(x, xs, n, D, H, W, **o)
+
     # ------------------------------------------------------------------ range
     def saturated(self):
         e = self._engines.get(self._active_name())

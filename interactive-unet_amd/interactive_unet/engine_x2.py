@@ -284,6 +284,26 @@ class EngineX2:
             e1.record()
             probe['events'].append((e0, e1, N))
 
+    def infer_views(self, views, D, H, W, outs):
+        """ONE forward over several input views of the same spatial size: views = [(x, x_strides, n)], outs = one dict per view with
+        infer's output arguments (logits / probs / cls / out_strides / divisor / accumulate).  The first conv reads each view through
+        its own strides into its share of the batch, the network runs once at N = sum(n), and the last conv (with the head in its
+        epilogue) writes each view's output with that view's strides, in view order -- the 2.5-D block prediction (predict.py:79-112: the
+        2-D net over the slices along three axes, probabilities accumulated) as one batch of 3 S slices instead of three forwards of S:
+        a third of the launches, three times the work per launch at the deep levels.  Same bits as the views run one by one (the x2m
+        conv keeps one summation order per voxel whatever the batch).  x2m form; other forms: the views one by one."""
+        if self.packed is None:
+            raise RuntimeError('EngineX2.load_eval() has not been called')
+        fuse = self.mixed and self.probe is None and bool(nv.lib().iunet_x2m_head_fusable(self.ncls, self.ch[0]))
+        if not fuse or len(views) == 1:
+            for (x, xs, n), o in zip(views, outs):
+                self.infer(x, xs, n, D, H, W, **o)
+            return
+        self._g_last = None
+        N = sum(n for _, _, n in views)
+        ws = self.workspace(N, D, H, W)
+        self._infer_mixed(ws, None, None, N, D, H, W, nv.stream(), head=None, views=views, heads=outs)
+
     def infer(self, x, x_strides, N, D, H, W, logits=None, probs=None, cls=None, out_strides=None,
               divisor=1.0, accumulate=False, features_only=False):
         """engine.Engine.infer in split precision (same arguments and output contract)."""
@@ -379,13 +399,16 @@ class EngineX2:
             e1.record()
             probe['events'].append((e0, e1, N))
 
-    def _infer_mixed(self, ws, x, x_strides, N, D, H, W, s, head=None):
-        """The forward in the x2m form (everything but the head): a / cat / pin tensors are (hi planes, lo8 planes), b tensors (hi, lo)."""
+    def _infer_mixed(self, ws, x, x_strides, N, D, H, W, s, head=None, views=None, heads=None):
+        """The forward in the x2m form (everything but the head): a / cat / pin tensors are (hi planes, lo8 planes), b tensors (hi, lo).
+        views / heads (infer_views): several (x, strides, n) inputs filling the batch, and one fused-head output per view."""
         dims, L, ch = ws['dims'], self.levels, self.ch
+        if views is None:
+            views = [(x, x_strides, N)]
         P8 = lambda t, planes16=0, v=0: ctypes.c_void_p(t.data_ptr() + planes16 * v * 16)     # m8 view starting `planes16` 16-byte planes in
         Ph = lambda t, planes=0, v=0: ctypes.c_void_p(t.data_ptr() + planes * v * 16)         # hi view starting `planes` 8-channel planes in
         # 2-D, one input channel: the first encoder stage is ONE launch (the first conv is computed by the second conv's loader waves)
-        stage0 = L > 1 and bool(nv.lib().iunet_x2m_first_stage_fusable(self.dim, self.cin, ch[0], N, H, W)) and self.probe is None
+        stage0 = L > 1 and bool(nv.lib().iunet_x2m_first_stage_fusable(self.dim, self.cin, ch[0], N, H, W)) and self.probe is None and len(views) == 1
         for l in range(L):
             d, v = dims[l], _vox(dims[l])
             c = ch[l]
@@ -404,9 +427,13 @@ class EngineX2:
                 continue
             if l == 0:
                 w, osc, b = self.packed['enc0.conv1']
-                nv.call('iunet_x2m_first_conv_fwd', self.dim, nv.ptr(x), nv.IN_DTYPE_CODE[x.dtype], nv.ll_array(x_strides),
-                        Ph(ws['a0']), c * v, -1, P8(ws['a0m']), c * v, nv.ptr(w), nv.ptr(osc), nv.ptr(b), self.act_scale,
-                        N, d[0], d[1], d[2], self.cin, c, 1, nv.ptr(self._sat), s)
+                n0 = 0
+                for vx, vxs, vn in views:          # each view through its own strides into its share of the batch
+                    nv.call('iunet_x2m_first_conv_fwd', self.dim, nv.ptr(vx), nv.IN_DTYPE_CODE[vx.dtype], nv.ll_array(vxs),
+                            ctypes.c_void_p(ws['a0'].data_ptr() + n0 * c * v * 2), c * v, -1, ctypes.c_void_p(ws['a0m'].data_ptr() + n0 * c * v),
+                            c * v, nv.ptr(w), nv.ptr(osc), nv.ptr(b), self.act_scale,
+                            vn, d[0], d[1], d[2], self.cin, c, 1, nv.ptr(self._sat), s)
+                    n0 += vn
             else:
                 cp = ch[l - 1]
                 self._conv3m(f'enc{l}.conv1', Ph(ws[f'pin{l}']), cp * v, P8(ws[f'pin{l}m']), cp * v, Ph(ws[f'a{l}']), c * v, -1,
@@ -433,15 +460,19 @@ class EngineX2:
                     P8(ws[f'cat{l}m'], c // 16, v), 2 * c * v, nv.ptr(w), nv.ptr(osc), nv.ptr(b), N, di[0], di[1], di[2], cn, c, nv.ptr(self._sat), s)
             self._conv3m(f'dec{l}.conv1', Ph(ws[f'cat{l}']), 2 * c * v, P8(ws[f'cat{l}m']), 2 * c * v, Ph(ws[f'a{l}']), c * v, -1,
                          P8(ws[f'a{l}m']), c * v, N, d, 2 * c, c, s)
-            if l == 0 and head is not None:
-                logits, probs, cls, out_strides, divisor, accumulate = head
-                if out_strides is None:
-                    out_strides = (self.ncls * v, v, H * W, W, 1)
+            if l == 0 and (head is not None or heads is not None):
                 w16, osc, b, w8 = self.packed['dec0.conv2']
                 hw, hb = self.packed['head']
-                nv.call('iunet_x2m_conv_head_fwd', self.dim, Ph(ws['a0']), c * v, P8(ws['a0m']), c * v, nv.ptr(w16), nv.ptr(w8), nv.ptr(osc),
-                        nv.ptr(b), nv.ptr(hw), nv.ptr(hb), self.act_scale, self.ncls, nv.ptr(logits), nv.ptr(probs), nv.ptr(cls),
-                        nv.ll_array(out_strides), float(divisor), int(bool(accumulate)), N, d[0], d[1], d[2], c, nv.ptr(self._sat), s)
+                hl = [dict(zip(('logits', 'probs', 'cls', 'out_strides', 'divisor', 'accumulate'), head))] if heads is None else heads
+                n0 = 0
+                for (_, _, vn), o in zip(views, hl):          # the last conv, head in its epilogue, per view: that view's output strides
+                    out_strides = o.get('out_strides') or (self.ncls * v, v, H * W, W, 1)
+                    nv.call('iunet_x2m_conv_head_fwd', self.dim, ctypes.c_void_p(ws['a0'].data_ptr() + n0 * c * v * 2), c * v,
+                            ctypes.c_void_p(ws['a0m'].data_ptr() + n0 * c * v), c * v, nv.ptr(w16), nv.ptr(w8), nv.ptr(osc),
+                            nv.ptr(b), nv.ptr(hw), nv.ptr(hb), self.act_scale, self.ncls, nv.ptr(o.get('logits')), nv.ptr(o.get('probs')),
+                            nv.ptr(o.get('cls')), nv.ll_array(out_strides), float(o.get('divisor', 1.0)), int(bool(o.get('accumulate', False))),
+                            vn, d[0], d[1], d[2], c, nv.ptr(self._sat), s)
+                    n0 += vn
                 continue
             self._conv3m(f'dec{l}.conv2', Ph(ws[f'a{l}']), c * v, P8(ws[f'a{l}m']), c * v, nv.ptr(ws[f'b{l}']), 2 * c * v, c // 8,
                          None, 0, N, d, c, c, s)

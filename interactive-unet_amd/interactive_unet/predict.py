@@ -174,6 +174,18 @@ def predict_block_device(model, block, out, num_classes=2, batch_size=None, axes
     so = (S * S * C, S * C, C)
     rows_cols = {0: (1, 2), 1: (0, 2), 2: (0, 1)}
     axes = list(axes)
+    if bs >= S and len(axes) > 1 and hasattr(eng, 'infer_views') and not os.environ.get('IUNET_2P5D_SEQUENTIAL'):
+        # every axis' S slices as ONE batch of len(axes) * S (engine_x2.EngineX2.infer_views): each axis is a strided view of the block
+        # for the first conv and of `out` for the head; the network between them runs once.  The outputs are written in axis order
+        # (the first axis writes, the others accumulate, the last divides: predict.py:101-110) -- the same bits as the loop below.
+        views, outs = [], []
+        for ai, axis in enumerate(axes):
+            r, c = rows_cols[axis]
+            views.append((block.reshape(-1), (sb[axis], 0, 0, sb[r], sb[c]), S))
+            outs.append(dict(probs=out.reshape(-1), out_strides=(so[axis], 1, 0, so[r], so[c]), accumulate=(ai > 0),
+                             divisor=float(len(axes)) if ai == len(axes) - 1 else 1.0))
+        eng.infer_views(views, 1, S, S, outs)
+        return out
     for ai, axis in enumerate(axes):
         r, c = rows_cols[axis]
         last = ai == len(axes) - 1

@@ -186,3 +186,43 @@ def test_c5_shape_5_level_base64_4_class_forward_and_step():
     out1 = te.train_step(x, y, None)
     out2 = te.train_step(x, y, None)
     assert np.isfinite(out1['Loss']) and np.isfinite(out2['Loss']) and out2['Loss'] < out1['Loss'] + 0.05
+
+
+def test_2p5d_block_as_one_batch_of_views_equals_the_three_forwards(monkeypatch):
+    """predict.predict_block_device in the default mode: the three axes' slices as ONE batch of 3 S (EngineX2.infer_views: per-view first
+    conv and per-view fused head, the network once) against the three forwards of S slices -- the same bits, and both within tolerance
+    of the oracle's predict_block (predict.py:79-112)."""
+    import warnings
+    from interactive_unet import predict as P
+    from interactive_unet.unet import UNet
+    S, C = 64, 2
+    p = unet_ref.init_params(dim=2, ncls=C, seed=3, randomize_bn=True)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        m = UNet(num_classes=C, dim=2, pretrained=False)
+    m.load_named(p)
+    m = m.cuda().eval()
+    blk = torch.tensor(_smooth((S, S, S), 8)).cuda()
+    outs = {}
+    for mode in ('views', 'sequential'):
+        if mode == 'sequential':
+            monkeypatch.setenv('IUNET_2P5D_SEQUENTIAL', '1')
+        out = torch.full((S, S, S, C), float('nan'), device='cuda')
+        for _ in range(2):                      # (second call: the engines' C++ graph where it applies)
+            P.predict_block_device(m, blk, out, C, None, (0, 1, 2))
+        outs[mode] = out.clone()
+    assert m.engine('eval').form == 'x2m'
+    assert torch.equal(outs['views'], outs['sequential'])
+    # two axes, and a batch size below S (falls back to the loop): still the oracle's numbers
+    out2 = torch.empty((S, S, S, C), device='cuda')
+    monkeypatch.delenv('IUNET_2P5D_SEQUENTIAL')
+    P.predict_block_device(m, blk, out2, C, None, (0, 2))
+    fn = lambda b: unet_ref.forward(p, torch.tensor(b), dim=2).numpy()
+    x = blk.cpu().numpy().astype(np.float32) / 255.0
+    want3 = predict_ref.predict_block(fn, x, C, 8, (0, 1, 2))
+    want2 = predict_ref.predict_block(fn, x, C, 8, (0, 2))
+    assert np.abs(outs['views'].cpu().numpy() - want3).max() <= 2e-4
+    assert np.abs(out2.cpu().numpy() - want2).max() <= 2e-4
+    out3 = torch.empty((S, S, S, C), device='cuda')
+    P.predict_block_device(m, blk, out3, C, 16, (0, 1, 2))
+    assert torch.equal(out3, outs['views'])
