@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collect the round's profile artefacts on the GPU box (run from the repo root through gpurun); the summaries land in
-# gpurun_out/profiles_$RND/ and are copied into profiles/ (tracked) afterwards.   bash tools/collect_profiles.sh [r04]
-RND=${1:-r04}
+# gpurun_out/profiles_$RND/ and are copied into profiles/ (tracked) afterwards.   [PART=A|B] bash tools/collect_profiles.sh [r05]
+RND=${1:-r05}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/profiles_$RND
 mkdir -p $OUT
@@ -23,6 +23,8 @@ pmc() {     # pmc <name> <counter> <program args...>
   rm -rf $OUT/tmp_pmc
   echo "done pmc $name $ctr"
 }
+# PART=A: sections 1-3 (bench lines, rocprofv3 summaries, roofline kernels); PART=B: the rest; unset: everything (two calls fit gpurun's 20 minutes)
+if [ "${PART:-A}" = "A" ] || [ -z "${PART+x}" ]; then
 # 1. plain bench lines (unprofiled) of every workload
 python3 $R/bench.py --steps 20 --warmup 5 > $OUT/${RND}_bench_c3.json.log 2>/dev/null; echo "done bench c3"
 python3 $R/bench.py --workload c4 --steps 3 --warmup 1 > $OUT/${RND}_bench_c4.json.log 2>/dev/null; echo "done bench c4"
@@ -41,6 +43,8 @@ stats roofline_c3 python3 $R/tools/bench_conv.py --only 0:64:32 --wgrad 0 --iter
 stats roofline_c3_1tile python3 $R/tools/bench_conv.py --only 0:64:32 --wgrad 0 --iters 50
 stats roofline_c5 python3 $R/tools/bench_conv.py --only 0:128:64 --base 64 --levels 5 --wgrad 0 --f8 2 --iters 50      # e4m3 planes in and out, as the engine launches it
 stats roofline_c2 python3 $R/tools/bench_conv.py --only 0:64:32 --dim 2 --size 512 --n 8 --dtype f16 --wgrad 0 --iters 50
+fi
+if [ "${PART:-B}" = "B" ] || [ -z "${PART+x}" ]; then
 # the split-precision (fp16x2) conv of the same layer alone, and one whole split-precision forward per configuration
 stats roofline_x2 python3 $R/tools/bench_conv.py --only 0:64:32 --wgrad 0 --iters 50 --n 2 --x2 2
 stats roofline_x2m python3 $R/tools/bench_conv.py --only 0:64:32 --wgrad 0 --iters 50 --n 2 --x2m 2      # the predict leg's kernel: cross terms on the fp8 matrix cores
@@ -61,17 +65,20 @@ python3 $R/tools/bench_conv.py --base 64 --levels 5 --f8 2 --wgrad 0 --iters 30 
 python3 $R/tools/bench_convT.py 30 > $OUT/${RND}_convT_layers.txt 2>/dev/null
 # the training step and the C5 prediction forward by kernel
 rm -rf $OUT/tmp_tr; rocprofv3 --kernel-trace --output-format csv -d $OUT/tmp_tr -o tr -- python3 $R/tools/bench_train3d.py 10 > $OUT/train3d.log 2>&1
-python3 $R/tools/step_profile.py $OUT/tmp_tr/tr_kernel_trace.csv 13 40 > $OUT/${RND}_train_step_by_kernel.txt; rm -rf $OUT/tmp_tr
+python3 $R/tools/step_profile.py $OUT/tmp_tr/tr_kernel_trace.csv 13 40 > $OUT/${RND}_train_step_by_kernel.txt
+python3 $R/tools/step_timeline.py $OUT/tmp_tr/tr_kernel_trace.csv 135 2 > $OUT/${RND}_train3d_step_timeline.txt; rm -rf $OUT/tmp_tr      # one step in launch order (135 launches)
 rm -rf $OUT/tmp_c5; rocprofv3 --kernel-trace --output-format csv -d $OUT/tmp_c5 -o c5 -- python3 $R/tools/bench_c5_predict.py 10 > $OUT/c5_predict.log 2>&1
 python3 $R/tools/step_profile.py $OUT/tmp_c5/c5_kernel_trace.csv 13 20 > $OUT/${RND}_c5_forward_by_kernel.txt; rm -rf $OUT/tmp_c5
 rm -rf $OUT/tmp_t2; rocprofv3 --kernel-trace --output-format csv -d $OUT/tmp_t2 -o t2 -- python3 $R/tools/bench_train2d.py 8 > $OUT/train2d.log 2>&1
-python3 $R/tools/step_profile.py $OUT/tmp_t2/t2_kernel_trace.csv 128 40 > $OUT/${RND}_train2d_step_by_kernel.txt; rm -rf $OUT/tmp_t2      # 2 modes x (4 + 30 + 30) steps
+python3 $R/tools/step_profile.py $OUT/tmp_t2/t2_kernel_trace.csv 128 40 > $OUT/${RND}_train2d_step_by_kernel.txt
+python3 $R/tools/step_timeline.py $OUT/tmp_t2/t2_kernel_trace.csv 142 2 > $OUT/${RND}_train2d_step_timeline.txt; rm -rf $OUT/tmp_t2      # 2 modes x (4 + 30 + 30) steps
 rm -rf $OUT/tmp_pp; rocprofv3 --kernel-trace --output-format csv -d $OUT/tmp_pp -o pp -- python3 $R/tools/bench_predict3d.py 10 fp16x2 > $OUT/predict3d.log 2>&1
 python3 $R/tools/step_profile.py $OUT/tmp_pp/pp_kernel_trace.csv 26 30 > $OUT/${RND}_predict_x2m_by_kernel.txt; rm -rf $OUT/tmp_pp      # 13 volumes of 4 blocks = 26 two-block forwards
 python3 $R/tools/bench_train2d.py 1 8 2>/dev/null | grep -v amdgpu > $OUT/${RND}_train2d_latency.txt
 { python3 $R/tools/bench_train3d.py 10; python3 $R/tools/bench_train3d.py 10 gn; } 2>/dev/null | grep -v amdgpu > $OUT/${RND}_train3d_batchnorm_groupnorm.txt      # the C3 training step with BatchNorm and with GroupNorm(8)
 python3 $R/tools/bench_predict_volumes.py 3 512 2>/dev/null | tail -1 > $OUT/${RND}_predict_volumes.txt; python3 $R/tools/bench_predict_volumes.py 2 1024 2>/dev/null | tail -1 >> $OUT/${RND}_predict_volumes.txt
 python3 $R/tools/bench_latency.py 2>/dev/null | grep -v amdgpu > $OUT/${RND}_slice_latency.txt
+python3 $R/tools/bench_2p5d.py 2>/dev/null | grep -v amdgpu > $OUT/${RND}_predict_2p5d_views.txt      # the 2.5-D block as one batch of views against three forwards
 echo "done layer tables and step profiles"
 # 4. HBM traffic of the roofline kernels (separate passes, as the guide prescribes)
 for c in FETCH_SIZE WRITE_SIZE; do
@@ -94,5 +101,6 @@ bash tools/level_report.sh 3 1 128 bf16 x2m_3d "--x2m 2" > /dev/null 2>&1; pytho
 bash tools/level_report.sh 2 8 512 f16 2d > /dev/null 2>&1;                python3 tools/level_report.py 2d $RND
 bash tools/level_report.sh 2 8 512 f16 x2m_2d "--x2m 2" > /dev/null 2>&1;  python3 tools/level_report.py x2m_2d $RND
 cp profiles/${RND}_conv_levels_*.md $OUT/ 2>/dev/null
-for f in conv3_v4 conv3_x2m conv3_f8k conv3_wgrad_v2 conv2_wgrad_v2 conv3_wgrad pointwise split16 train_misc; do python3 tools/regreport.py interactive-unet_amd/csrc/$f.hip; done > $OUT/${RND}_register_report.txt 2>&1
+for f in conv3_v4 conv3_x2m conv3_f8k conv3_wgrad_v2 conv2_wgrad_v2 conv3_wgrad pointwise split16 train_misc gn_precise; do python3 tools/regreport.py interactive-unet_amd/csrc/$f.hip; done > $OUT/${RND}_register_report.txt 2>&1
+fi
 ls -la $OUT
