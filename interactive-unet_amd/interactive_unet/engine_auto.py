@@ -148,6 +148,22 @@ class EngineAuto:
         c = lambda n: max(f, min(n, t) // f * f)
         return (c(D) if self.dim == 3 else 1, c(H), c(W))
 
+    def _measure(self, x, x_strides, D, H, W):
+        """-> (device tensor [max |logit_x2m - logit_fp16x2|, max |logit_x2m|] of one tile of x -- zeros without data --, the tile's shape)."""
+        out2 = torch.zeros(2, dtype=torch.float32, device=self.device)
+        if x is None:
+            return out2, None
+        cD, cH, cW = tile = self._crop(D, H, W)
+        n = self.ncls * cD * cH * cW
+        lg = torch.empty(2 * n, dtype=torch.float32, device=self.device)
+        for i, name in enumerate(('x2m', 'fp16x2')):
+            e = self._ready(name)
+            keep, e.probe, fwd = e.probe, None, e._g_fwd
+            e.infer(x, x_strides, 1, cD, cH, cW, logits=lg[i * n:(i + 1) * n])
+            e.probe, e._g_fwd = keep, fwd            # (a calibration forward does not count towards loading the C++ graph)
+        nv.call('iunet_logit_diff', nv.ptr(lg), nv.ptr(lg[n:]), n, nv.ptr(out2), nv.stream())
+        return out2, tile
+
     def calibrate(self, x, x_strides, D, H, W, blocking=True, group=None):
         """Run one tile (sample 0, the crop at the origin) of `x` through x2m and fp16x2 and measure max |logit difference| on the device.
         blocking: decide now (one 8-byte device-to-host read); otherwise the figure is adopted at the next load_eval.  group: a
@@ -155,26 +171,18 @@ class EngineAuto:
         so that every rank of a sharded prediction takes the same decision (a rank without data passes x=None and contributes 0)."""
         if self._params is None:
             raise RuntimeError('EngineAuto.load_eval() has not been called')
-        out2 = torch.zeros(2, dtype=torch.float32, device=self.device)
-        tile = None
-        if x is not None:
-            cD, cH, cW = tile = self._crop(D, H, W)
-            n = self.ncls * cD * cH * cW
-            lg = torch.empty(2 * n, dtype=torch.float32, device=self.device)
-            for i, name in enumerate(('x2m', 'fp16x2')):
-                e = self._ready(name)
-                keep, e.probe, fwd = e.probe, None, e._g_fwd
-                e.infer(x, x_strides, 1, cD, cH, cW, logits=lg[i * n:(i + 1) * n])
-                e.probe, e._g_fwd = keep, fwd            # (a calibration forward does not count towards loading the C++ graph)
-            nv.call('iunet_logit_diff', nv.ptr(lg), nv.ptr(lg[n:]), n, nv.ptr(out2), nv.stream())
+        out2, tile = self._measure(x, x_strides, D, H, W)
         if group is not None:
             import torch.distributed as dist
             dist.all_reduce(out2, op=dist.ReduceOp.MAX, group=None if group is True else group)     # True: the default group
             self._last_agree = self._loads
-        host = torch.empty(2, dtype=torch.float32).pin_memory()
-        host.copy_(out2, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
+        if out2.device.type == 'cuda':
+            host = torch.empty(2, dtype=torch.float32).pin_memory()
+            host.copy_(out2, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+        else:                                   # (host tensors: the multi-process CPU tests of the agreement)
+            host, ev = out2.clone(), None
         self._pending = (host, ev, tile, self._loads, out2)
         self._last_cal = self._loads
         self.calibrations += 1
@@ -184,7 +192,8 @@ class EngineAuto:
     def _adopt(self):
         host, ev, tile, load, _keep = self._pending
         self._pending = None
-        ev.synchronize()
+        if ev is not None:
+            ev.synchronize()
         diff, scale = float(host[0]), float(host[1])
         ok = diff <= self.threshold                   # (a NaN figure compares False: fp16x2)
         self.mode = 'x2m' if ok else 'fp16x2'

@@ -201,3 +201,58 @@ def test_dp_broadcast_and_bucketed_allreduce_world2():
         assert np.array_equal(grads[(0, step)][4], total) and np.array_equal(grads[(1, step)][4], total)
         want -= (0.1 * torch.from_numpy(total) / world).numpy()
     assert np.array_equal(flats[0][3], want)
+
+
+# --------------------------------------------------------------------------- one prediction form on every rank (engine_auto.py, shard.agree_form)
+def _agree_worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from interactive_unet.engine_auto import EngineAuto
+    e = EngineAuto(dim=3, device='cpu', recal_every=4)
+
+    class _Form:                                   # stands in for the two EngineX2 forms: nothing is launched on a CPU-only rank
+        def load_eval(self, params):
+            pass
+    e._form = lambda name: _Form()
+    # what a rank's own tile measures in each agreement round: below the threshold on some ranks and above it on others
+    script = {0: [1e-4, 1e-4, 3e-4], 1: [1e-4, 9e-4, 2e-4], 2: [None, None, None]}[rank]       # rank 2 has no block (contributes 0)
+    it = iter(script)
+
+    def measure(x, xs, D, H, W):
+        v = next(it)
+        return torch.tensor([0.0 if v is None else v, 5.0]), ((64, 64, 64) if v is not None else None)
+    e._measure = measure
+    log = []
+    for load in range(1, 11):                      # ten weight loads = a data-parallel loop that predicts after every step
+        e.load_eval({})
+        if rank == 1 and load == 3:
+            e.widen()                              # a rank-local event (its activations saturated): must not desynchronise the collective
+        if e.collective_due():
+            x = None if rank == 2 else object()
+            e.calibrate(x, None, 64, 64, 64, blocking=True, group=True)
+            log.append((load, e.mode, round(e.calibration['diff'], 6)))
+    q.put((rank, log, e.form))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_prediction_form_is_agreed_over_the_process_group_world3():
+    """Ranks of a sharded prediction calibrate on their OWN data and must still select ONE form (x2m or fp16x2): the figure is all-reduced
+    (MAX), the collective is entered at the same weight-load counts by every rank whatever its local state (a widened rank, a rank without
+    blocks), and a figure above the threshold on ANY rank sends every rank to fp16x2."""
+    world = 3
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_agree_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {r: (log, form) for r, log, form in (q.get(timeout=120) for _ in range(world))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = [(1, 'x2m', 1e-4), (5, 'fp16x2', 9e-4), (9, 'x2m', 3e-4)]                 # loads 1, 5, 9 (every 4); the group maximum decides
+    for r in range(world):
+        assert [(l, m, pytest.approx(d, rel=1e-3)) for l, m, d in want] == res[r][0], (r, res[r])
+    assert res[0][1] == 'x2m' and res[2][1] == 'x2m' and res[1][1] == 'fp16x2_wide'   # rank 1 keeps its wider form, and kept taking part
