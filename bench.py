@@ -21,22 +21,29 @@ Workloads (BASELINE.json `configs`; the metric is "voxels/sec (train step + full
   c5 (configs[4])  3-D 5-level base 64, 4 classes: training step in bf16 + prediction with e4m3 weights, 1 chunk.
   c2 (configs[1])  2-D 4-level base 32, fp16: training step on 8 slices of 512^2 + prediction of the 8 slices.
 
+`value` / `ms_per_step` are the COMPLIANT pairing: training in the workload's 16-bit dtype (the reference trains under '16-mixed',
+trainer.py:59) + prediction in the default, tolerance-meeting mode (split precision; the form -- x2m or fp16x2 -- is selected by
+engine_auto.EngineAuto's calibration on the model's own weights and reported in `config.predict_dtype` /
+`config.predict_mode_selection`; the reference predicts in fp32, predict.py:30-35).
+
 The JSON line also carries
   roofline     -- the workload's bottleneck 3x3(x3) conv (dec0.conv1), timed live with HIP events on the launch
                   stream over 50 back-to-back launches (average = `achieved`: the figure the committed rocprofv3
                   summary of the same launch sequence reproduces; the first 8 and the last 20 are given as burst /
                   settled: the clock drops under sustained MFMA load), against the dense MFMA peak; `in_situ` = the
-                  same layer's launches inside real steps (events around each);
-  parity_mode  -- the same step timed a second time with the prediction leg in the tolerance-meeting mode (fp16x2
-                  split precision: logits within 1e-3 of the CPU fp32 path), value / ms_per_step computed as the
-                  headline's; the training leg stays 16-bit as the reference's ('16-mixed');
-  parity       -- max |logit| deviation and class-map mismatches of the benchmarked dtype against the native fp32
-                  parity mode on one chunk (that mode is held within 1e-3 of the CPU oracle by tests/test_gpu_parity.py),
-                  plus, when the CPU baseline runs, both modes against the CPU fp32 oracle on its sample;
+                  same layer's launches inside real steps (events around each); `predict_kernel` = the prediction leg's
+                  split-precision conv of that layer inside real steps;
+  throughput_mode -- the same step timed a second time with the prediction leg in the 16-bit dtype (its deviation from the
+                  fp32 path is in `parity`);
+  parity       -- max |logit| deviation and class-map mismatches of the benchmarked dtype, fp16x2 and x2m against the native fp32
+                  parity mode on one chunk, each with the population of its tie band (voxels whose fp32 top-2 margin is within twice
+                  the measured error) and the mismatches OUTSIDE it (must be 0); plus, when the CPU baseline runs, every mode and
+                  the default mode's own selection against the CPU fp32 oracle on its sample;
   cpu_baseline -- the oracle (oracle/unet_ref.py, torch CPU fp32, host cores) timed on a bounded sample of the same
                   workload, rank 0 / N = 1 only;
   legs.predict_2p5d -- the reference's own predict semantics (predict.py:79-112): one 128^3 block through the
-                  2-D net along 3 axes, in fp16x2 and fp16, with the oracle's predict_block on the host cores beside it.
+                  2-D net along 3 axes, in the default mode and fp16, with the oracle's predict_block on the host cores beside it;
+  rccl_ranks   -- N > 1: the result of an all-reduce of ones over the process group (must equal n_gpus).
 """
 import argparse
 import json
@@ -431,6 +438,8 @@ def predict_2p5d_leg(dev, with_cpu):
         res[name] = {'ms_per_block': round(ms, 3), 'ms_per_block_groups_of_10': [round(g, 3) for g in groups],
                      'voxels_per_s': round(S ** 3 / ms * 1e3, 1), 'tflops(algorithmic)': round(3 * fpv2 * S ** 3 / ms / 1e9, 1)}
         probs[name] = out.clone()
+        if hasattr(m.engine('eval'), 'describe'):          # ('fp16x2' = the default split-precision mode: which form the calibration selected)
+            res[name]['selected'] = m.engine('eval').describe()
         params = {k: t.detach().float().cpu() for k, t in m.named_tensors().items()}
         del m
     if with_cpu:
