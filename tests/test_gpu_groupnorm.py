@@ -259,3 +259,51 @@ def test_groupnorm_unet_module_default_predicts_within_tolerance():
     m32, _ = _model(2, 2, 'fp32')
     m32.eval()
     assert (m32(x.cuda()).cpu() - want).abs().max().item() <= 1e-5
+
+
+@pytest.mark.parametrize('N,C,groups,sp', [(2, 32, 8, (5, 7, 9)), (3, 64, 8, (40, 33)), (1, 256, 8, (4, 4, 4)), (2, 32, 4, (20001,)), (1, 64, 16, (129, 130))])
+def test_precise_groupnorm_kernels_vs_float64(nv, N, C, groups, sp):
+    """csrc/gn_precise.hip one level below the network: relu(group_norm(x)) of the fp32 mode's planar tensors and of the split-precision
+    word pairs against torch's group_norm in float64 -- segment counts that do not divide the voxels, one and several segments per plane,
+    a strided output (a half of a concat buffer), channels of one group at different scales."""
+    from interactive_unet.engine_x2 import EngineX2
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn((N, C) + sp, generator=g) * 1.5 + 0.3
+    x[:, 3] *= 40.0
+    gamma = 0.5 + torch.rand(C, generator=g)
+    beta = 0.3 * torch.randn(C, generator=g)
+    vox = int(np.prod(sp))
+    dev = 'cuda'
+    slab = torch.empty(nv.lib().iunet_gn_precise_slab_bytes(N, C, vox), dtype=torch.uint8, device=dev)
+    sc, sh = torch.empty(N * C, device=dev), torch.empty(N * C, device=dev)
+    gd, bd = gamma.to(dev), beta.to(dev)
+    # ---- fp32 planar, output into the second half of a [N][2C][vox] buffer
+    xd = x.reshape(N, C, vox).contiguous().to(dev)
+    y = torch.full((N, 2 * C, vox), float('nan'), device=dev)
+    nv.call('iunet_f32_gn_relu_fwd', nv.ptr(xd), C * vox, nv.c_void_p(y.data_ptr() + 4 * C * vox), 2 * C * vox, nv.ptr(gd), nv.ptr(bd), groups, 1e-5,
+            nv.ptr(slab), nv.ptr(sc), nv.ptr(sh), C, N, vox, nv.stream())
+    torch.cuda.synchronize()
+    want = F.relu(F.group_norm(x.double(), groups, gamma.double(), beta.double(), eps=1e-5)).reshape(N, C, vox)
+    got = y[:, C:].cpu().double()
+    assert torch.isnan(y[:, :C]).all()                                   # the other half of the buffer is untouched
+    assert (got - want).abs().max().item() <= 2e-6 * max(1.0, want.abs().max().item())
+    # the per-(sample, channel) affine pair it leaves behind: scale = rstd * gamma
+    xg = x.double().reshape(N, groups, -1)
+    rstd = 1.0 / torch.sqrt(xg.var(-1, unbiased=False) + 1e-5)
+    assert torch.allclose(sc.cpu().double().reshape(N, C), rstd.repeat_interleave(C // groups, 1) * gamma.double(), rtol=1e-6)
+    # ---- split precision: the words of act_scale x value in, act_scale x relu(gn) out
+    e = EngineX2(dim=2, mixed=False)                                     # (its layout helpers and act_scale only)
+    A = e.act_scale
+    x4 = x.reshape((N, C) + (sp if len(sp) > 1 else (1,) + sp))
+    xs = e.to_split(x4).to(dev)                                          # [N][C/8 hi | C/8 lo][vox][8]
+    ys = torch.zeros_like(xs)
+    sat = torch.zeros(1, dtype=torch.int32, device=dev)
+    nv.call('iunet_x2_gn_relu_fwd', nv.ptr(xs), 2 * C * vox, C // 8, nv.ptr(ys), 2 * C * vox, C // 8, nv.ptr(gd), nv.ptr(bd), groups, 1e-5, A,
+            nv.ptr(slab), nv.ptr(sc), nv.ptr(sh), C, N, vox, nv.ptr(sat), nv.stream())
+    torch.cuda.synchronize()
+    # reference on the values the split words actually hold (22 bits of x)
+    xin = e.from_split(xs.cpu(), N, C, x4.shape[2:]).double().reshape((N, C) + sp)
+    want2 = F.relu(F.group_norm(xin, groups, gamma.double(), beta.double(), eps=1e-5)).reshape(N, C, vox)
+    got2 = e.from_split(ys.cpu(), N, C, x4.shape[2:]).double().reshape(N, C, vox)
+    assert (got2 - want2).abs().max().item() <= 2e-6 * max(1.0, want2.abs().max().item())
+    assert int(sat.item()) == 0

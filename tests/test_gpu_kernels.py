@@ -441,3 +441,23 @@ def test_pack_batch_e4m3_quantisation_matches_oracle(nv):
     for name, got, want in expect:
         bits = torch.int16 if got.dtype != torch.float32 else torch.int32
         assert torch.equal(got.view(bits), want.view(bits)), name
+
+
+def test_logit_diff_is_exact_and_shows_nan(nv):
+    """iunet_logit_diff (the calibration figure of engine_auto.py): max |a - b| and max |a| by integer atomicMax on the float bit patterns --
+    exactly torch's maxima whatever the order; a NaN in either tensor surfaces as NaN (which the selection rule reads as "not x2m")."""
+    g = torch.Generator().manual_seed(0)
+    for n in (1, 255, 4097, 3 * 2 * 64 * 64 * 64 + 5):
+        a = (torch.randn(n, generator=g) * 7).cuda()
+        b = a + (torch.randn(n, generator=g) * 1e-4).cuda()
+        out = torch.full((2,), -1.0, device='cuda')
+        nv.call('iunet_logit_diff', nv.ptr(a), nv.ptr(b), n, nv.ptr(out), nv.stream())
+        torch.cuda.synchronize()
+        assert out[0].item() == (a - b).abs().max().item() and out[1].item() == a.abs().max().item()
+    b[17] = float('nan')
+    nv.call('iunet_logit_diff', nv.ptr(a), nv.ptr(b), n, nv.ptr(out), nv.stream())
+    assert torch.isnan(out[0]).item() and not torch.isnan(out[1]).item()
+    a[5] = float('inf')
+    nv.call('iunet_logit_diff', nv.ptr(a), nv.ptr(b), n, nv.ptr(out), nv.stream())
+    assert torch.isinf(out[1]).item()
+    assert nv.lib().iunet_logit_diff(None, None, 4, None, None) < 0
