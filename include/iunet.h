@@ -385,6 +385,11 @@ int iunet_f32_gn_relu_fwd(const void* x, long long x_ss, void* y, long long y_ss
 int iunet_x2_gn_relu_fwd(const void* x, long long x_ss, int x_lo, void* y, long long y_ss, int y_lo, const void* gamma, const void* beta,
                          int groups, float eps, float act_scale, void* slab, void* scale, void* shift, int C, int N, long long vox,
                          void* sat, void* stream);
+/* the same with the output in the x2m form (hi planes at y, lo8 planes at y8 -- y8_ss BYTES per sample --, lo planes only where y_lo >= 0):
+ * the GroupNorm network in the default prediction mode's fast form (the stage convs: iunet_x2m_conv_fwd with epilogue 0 into hi + lo planes) */
+int iunet_x2m_gn_relu_fwd(const void* x, long long x_ss, int x_lo, void* y, long long y_ss, int y_lo, void* y8, long long y8_ss, const void* gamma,
+                          const void* beta, int groups, float eps, float act_scale, void* slab, void* scale, void* shift, int C, int N, long long vox,
+                          void* sat, void* stream);
 
 /* ---- whole-volume prediction (predict.py:201-256) -------------------------------------- */
 /* get_padded_block (predict.py:291-316): reflect-padded S^3 uint8 block of a device volume. */

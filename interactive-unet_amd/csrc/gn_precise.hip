@@ -114,9 +114,12 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const double* __restric
   }
 }
 
+// FMT 1 with y8 != null: the x2m form of the output (conv3_x2m.hip) -- hi planes + lo8 planes (e4m3 of the fp16 rounding residual x 16, the
+// words x2m_split8 makes: what every x2m producer stores), and lo planes only where y_lo >= 0
 template <int FMT>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const void* __restrict__ xv, long long x_ss, int x_lo, void* __restrict__ yv,
-                                                      long long y_ss, int y_lo, const float* __restrict__ scale,
+                                                      long long y_ss, int y_lo, unsigned char* __restrict__ y8, long long y8_ss,
+                                                      const float* __restrict__ scale,
                                                       const float* __restrict__ shift, int C, long long vox, int* __restrict__ sat) {
   const int n = blockIdx.z;
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -128,16 +131,24 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const void* __restrict__ 
     const float* sc = scale + (long long)n * C + pl * 8;
     const float* sh = shift + (long long)n * C + pl * 8;
     f16x8 oh, ol;
+    float r[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float r = fmaxf(fmaf((float)h[j] + (float)l[j], sc[j], sh[j]), 0.f);
-      f16 a, b;
-      split16<f16>(r, a, b);
-      oh[j] = a; ol[j] = b;
-    }
+    for (int j = 0; j < 8; ++j) r[j] = fmaxf(fmaf((float)h[j] + (float)l[j], sc[j], sh[j]), 0.f);
     f16* yh = (f16*)yv + n * y_ss + (long long)pl * vox * 8 + i * 8;
+    if (y8 != nullptr) {
+      u32x2_t l8, h8;
+      x2m_split8(r, oh, ol, l8, h8);
+      *(u32x2_t*)(y8 + n * y8_ss + x2m_off(pl, i, vox)) = l8;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        f16 a, b;
+        split16<f16>(r[j], a, b);
+        oh[j] = a; ol[j] = b;
+      }
+    }
     *(f16x8*)yh = oh;
-    *(f16x8*)(yh + (long long)y_lo * vox * 8) = ol;
+    if (y_lo >= 0) *(f16x8*)(yh + (long long)y_lo * vox * 8) = ol;
     if (sat != nullptr) x2_note_saturation(sat, oh);
   } else {
     const int c = blockIdx.y;
@@ -148,9 +159,9 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const void* __restrict__ 
 }
 
 template <int FMT>
-int gn_launch(const char* what, const void* x, long long x_ss, int x_lo, void* y, long long y_ss, int y_lo, const void* gamma,
-              const void* beta, int groups, float eps, float act_scale, void* slab, void* scale, void* shift, int C, int N, long long vox,
-              void* sat, void* stream) {
+int gn_launch(const char* what, const void* x, long long x_ss, int x_lo, void* y, long long y_ss, int y_lo, void* y8, long long y8_ss,
+              const void* gamma, const void* beta, int groups, float eps, float act_scale, void* slab, void* scale, void* shift, int C, int N,
+              long long vox, void* sat, void* stream) {
   IUNET_REQUIRE(x && y && gamma && beta && slab && scale && shift, "%s: null pointer", what);
   IUNET_REQUIRE(N > 0 && vox > 0 && C > 0 && groups > 0 && C % groups == 0 && (FMT == 0 || C % 8 == 0),
                 "%s: %d channels in %d groups, %d samples of %lld voxels", what, C, groups, N, vox);
@@ -164,7 +175,7 @@ int gn_launch(const char* what, const void* x, long long x_ss, int x_lo, void* y
                      vox, parts, eps, act_scale, (float*)scale, (float*)shift);
   // the apply reads act_scale x value and its scale carries rstd * gamma alone: (A v) * sc + A * sh = A * (v * sc + sh)
   hipLaunchKernelGGL(gn_apply_kernel<FMT>, dim3((unsigned)((vox + 255) / 256), ny, N), dim3(256), 0, s, x, x_ss, x_lo, y, y_ss, y_lo,
-                     (const float*)scale, (const float*)shift, C, vox, (int*)sat);
+                     (unsigned char*)y8, y8_ss, (const float*)scale, (const float*)shift, C, vox, (int*)sat);
   IUNET_CHECK_HIP(hipGetLastError());
   return IUNET_OK;
 }
@@ -183,7 +194,7 @@ long long iunet_gn_precise_slab_bytes(int N, int C, long long vox) {
 // concat buffer); scale / shift: fp32 [N][C] scratch that receives the per-sample affine pair.
 int iunet_f32_gn_relu_fwd(const void* x, long long x_ss, void* y, long long y_ss, const void* gamma, const void* beta, int groups, float eps,
                           void* slab, void* scale, void* shift, int C, int N, long long vox, void* stream) {
-  return gn_launch<0>("f32_gn_relu_fwd", x, x_ss, 0, y, y_ss, 0, gamma, beta, groups, eps, 1.0f, slab, scale, shift, C, N, vox, nullptr, stream);
+  return gn_launch<0>("f32_gn_relu_fwd", x, x_ss, 0, y, y_ss, 0, nullptr, 0, gamma, beta, groups, eps, 1.0f, slab, scale, shift, C, N, vox, nullptr, stream);
 }
 
 // split precision: x / y = C / 8 hi planes + lo planes x_lo / y_lo planes further on (split16.hip's layout), values act_scale x
@@ -192,7 +203,17 @@ int iunet_x2_gn_relu_fwd(const void* x, long long x_ss, int x_lo, void* y, long 
                          int groups, float eps, float act_scale, void* slab, void* scale, void* shift, int C, int N, long long vox,
                          void* sat, void* stream) {
   IUNET_REQUIRE(x_lo > 0 && y_lo > 0, "x2_gn_relu_fwd: lo plane offsets %d / %d", x_lo, y_lo);
-  return gn_launch<1>("x2_gn_relu_fwd", x, x_ss, x_lo, y, y_ss, y_lo, gamma, beta, groups, eps, act_scale, slab, scale, shift, C, N, vox, sat, stream);
+  return gn_launch<1>("x2_gn_relu_fwd", x, x_ss, x_lo, y, y_ss, y_lo, nullptr, 0, gamma, beta, groups, eps, act_scale, slab, scale, shift, C, N, vox, sat, stream);
+}
+
+// the same with the output in the x2m form (conv3_x2m.hip): hi planes at y (y_ss elements per sample), lo8 planes at y8 (y8_ss BYTES per sample;
+// C / 16 planes of [vox][16 B]), and lo planes only where y_lo >= 0 (a tensor a transposed conv or the head reads) -- what the x2m stage convs
+// take: the GroupNorm network in the default prediction mode's fast form.  The input is the raw conv output as hi + lo planes.
+int iunet_x2m_gn_relu_fwd(const void* x, long long x_ss, int x_lo, void* y, long long y_ss, int y_lo, void* y8, long long y8_ss, const void* gamma,
+                          const void* beta, int groups, float eps, float act_scale, void* slab, void* scale, void* shift, int C, int N, long long vox,
+                          void* sat, void* stream) {
+  IUNET_REQUIRE(x_lo > 0 && y8 != nullptr && C % 16 == 0, "x2m_gn_relu_fwd: lo plane offset %d, lo8 planes %p, %d channels", x_lo, y8, C);
+  return gn_launch<1>("x2m_gn_relu_fwd", x, x_ss, x_lo, y, y_ss, y_lo, y8, y8_ss, gamma, beta, groups, eps, act_scale, slab, scale, shift, C, N, vox, sat, stream);
 }
 
 }  // extern "C"

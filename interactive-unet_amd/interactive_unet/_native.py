@@ -98,6 +98,8 @@ _SIGS = {
     'iunet_f32_gn_relu_fwd': [c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p, c_int, c_int, c_ll, c_void_p],
     'iunet_x2_gn_relu_fwd': [c_void_p, c_ll, c_int, c_void_p, c_ll, c_int, c_void_p, c_void_p, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p,
                              c_int, c_int, c_ll, c_void_p, c_void_p],
+    'iunet_x2m_gn_relu_fwd': [c_void_p, c_ll, c_int, c_void_p, c_ll, c_int, c_void_p, c_ll, c_void_p, c_void_p, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p,
+                              c_int, c_int, c_ll, c_void_p, c_void_p],
     'iunet_logit_diff': [c_void_p, c_void_p, c_ll, c_void_p, c_void_p],
     'iunet_net_create': [c_int, c_int, c_int, c_int, c_int, c_int, c_float, ctypes.POINTER(c_void_p)],
     'iunet_net_create_ex': [c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_int, ctypes.POINTER(c_void_p)],

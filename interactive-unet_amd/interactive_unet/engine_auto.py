@@ -43,13 +43,8 @@ class EngineAuto:
             policy = {'0': 'fp16x2', '1': 'x2m'}.get(os.environ.get('IUNET_X2M', ''), 'auto')
         if policy not in ('auto', 'x2m', 'fp16x2'):
             raise ValueError("policy must be 'auto', 'x2m' or 'fp16x2'")
-        # GroupNorm networks (north_star "GroupNorm/BN") predict in the full fp16x2 form: the x2m form's producers carry the folded-
-        # BatchNorm epilogue only, so there is nothing to calibrate against; the range steps work as for BatchNorm
+        # GroupNorm networks (north_star "GroupNorm/BN"): both split forms exist (csrc/gn_precise.hip writes either format), the same calibration
         self.norm, self.groups = norm, groups
-        if norm == 'group':
-            if policy == 'x2m':
-                raise NotImplementedError("GroupNorm networks predict in the full fp16x2 form (policy 'auto' or 'fp16x2')")
-            policy = 'fp16x2'
         self.dim, self.levels, self.base, self.cin, self.ncls = dim, levels, base, cin, ncls
         self.device = torch.device(device)
         self.policy, self.threshold, self.recal_every = policy, float(threshold), int(recal_every)

@@ -39,12 +39,9 @@ class EngineX2:
             raise ValueError(f'{groups} groups do not divide {base} channels')
         # norm='group': GroupNorm(groups) + ReLU after every stage conv (north_star "GroupNorm/BN").  Nothing folds: the stage convs write
         # their raw output as split words (epilogue without bias / ReLU) and csrc/gn_precise.hip normalises it with per-(sample, group)
-        # statistics taken in double; the full fp16x2 form only (mixed is off)
+        # statistics taken in double, writing the consumer's format (fp16x2: hi + lo planes; x2m: hi + lo8 planes).  What the BatchNorm
+        # network fuses into conv epilogues -- the max-pool, the head -- runs as its own launch here (the statistics come first)
         self.norm, self.groups = norm, groups
-        if norm == 'group':
-            if mixed:
-                raise NotImplementedError("GroupNorm runs in the full fp16x2 form (mixed=False)")
-            mixed = False
         if dim not in (2, 3):
             raise ValueError('dim must be 2 or 3')
         if base % 32 != 0:
@@ -81,6 +78,8 @@ class EngineX2:
             return None
         if not net_graph.ENABLED or not self.use_graph or self.weight_dtype or not (2 <= self.levels <= 6) or self._gparams is None:
             return None
+        if self.mixed and self.norm == 'group':
+            return None                    # (the handle sequences GroupNorm in the fp16x2 form only: iunet_net_create_ex, mode 2)
         if self._g is None:
             self._g = net_graph.NetGraph(self.dim, self.levels, self.base, self.cin, self.ncls, 3 if self.mixed else 2, self.device, act_scale=self.act_scale,
                                          norm=self.norm, groups=self.groups)
@@ -165,12 +164,13 @@ class EngineX2:
                                                     torch.zeros(lib.iunet_x2m_w8_bytes_nd(self.dim, b, a), dtype=torch.uint8, device=dev),
                                                     torch.empty(b, dtype=torch.float32, device=dev), torch.empty(b, dtype=torch.float32, device=dev))
                         whi, w16, w8, osc, bias = bm
-                        d_x2m.append(nv.make_x2_prep_desc(w, whi, osc, bias, b, a, self.taps, 3, 0, A, A, bn=bn, w8=w8, eps=BN_EPS))
+                        d_x2m.append(nv.make_x2_prep_desc(w, whi, osc, bias, b, a, self.taps, 3, 0, A, A, bn=None if gn else bn, w8=w8, eps=BN_EPS))
                         d_pack.append(nv.make_desc(whi, w16, b, a, self.taps, 1 if pmode == 2 else 6, torch.float16))
-                        per_layer.append(('iunet_x2m_prep_nd', (self.dim, nv.ptr(w), nv.ptr(whi), nv.ptr(w8), nv.ptr(osc), nv.ptr(bias), nv.ptr(bn[0]),
-                                                                nv.ptr(bn[1]), nv.ptr(bn[2]), nv.ptr(bn[3]), BN_EPS, A, A, b, a)))
+                        bnq = [None] * 4 if gn else [nv.ptr(t) for t in bn]
+                        per_layer.append(('iunet_x2m_prep_nd', (self.dim, nv.ptr(w), nv.ptr(whi), nv.ptr(w8), nv.ptr(osc), nv.ptr(bias), bnq[0],
+                                                                bnq[1], bnq[2], bnq[3], BN_EPS, A, A, b, a)))
                         per_layer.append(('iunet_pack_conv3', (0, nv.ptr(whi), None, nv.ptr(w16), b, a, self.taps, pmode)))
-                        P[name] = (w16, osc, bias, w8)
+                        P[name] = (w16, osc, bias, w8, bn[0], bn[1]) if gn else (w16, osc, bias, w8)
                         continue
                     pmode = lib.iunet_x2_pack_mode(self.dim)      # 2: padded K16 order (3-D); 6: compact order (2-D: the cross-pair step)
                     npk = lib.iunet_pack_first_conv_elems(b, 3 * a, self.taps) if first else nv.pack_conv3_elems(b, 3 * a, self.taps, pmode)
@@ -266,6 +266,17 @@ class EngineX2:
         nv.call('iunet_x2_gn_relu_fwd', nv.ptr(ws['raw']), 2 * co * v, co // 8, yp, y_ss, y_lo, nv.ptr(gamma), nv.ptr(beta), self.groups, BN_EPS,
                 self.act_scale, nv.ptr(ws['gnslab']), nv.ptr(ws['gnsc']), nv.ptr(ws['gnsh']), co, N, v, nv.ptr(self._sat), s)
 
+    def _gnm(self, name, ws, yp, y_ss, y_lo, y8p, y8_ss, N, d, co, s):
+        """relu(group_norm(raw conv output in ws['raw'])) -> the x2m-format tensor (hi planes at yp, lo8 planes at y8p; y8p None: a tensor a
+        transposed conv or the head reads: hi + lo planes)."""
+        v = _vox(d)
+        gamma, beta = self.packed[name][-2], self.packed[name][-1]
+        if y8p is None:
+            return nv.call('iunet_x2_gn_relu_fwd', nv.ptr(ws['raw']), 2 * co * v, co // 8, yp, y_ss, y_lo, nv.ptr(gamma), nv.ptr(beta), self.groups, BN_EPS,
+                           self.act_scale, nv.ptr(ws['gnslab']), nv.ptr(ws['gnsc']), nv.ptr(ws['gnsh']), co, N, v, nv.ptr(self._sat), s)
+        nv.call('iunet_x2m_gn_relu_fwd', nv.ptr(ws['raw']), 2 * co * v, co // 8, yp, y_ss, y_lo, y8p, y8_ss, nv.ptr(gamma), nv.ptr(beta), self.groups,
+                BN_EPS, self.act_scale, nv.ptr(ws['gnslab']), nv.ptr(ws['gnsc']), nv.ptr(ws['gnsh']), co, N, v, nv.ptr(self._sat), s)
+
     def _conv3(self, name, xp, x_ss, x_lo, yp, y_ss, y_lo, N, d, ci, co, s, ws=None):
         w, osc, b = self.packed[name][:3]
         if self.norm == 'group':
@@ -294,7 +305,7 @@ class EngineX2:
         conv keeps one summation order per voxel whatever the batch).  x2m form; other forms: the views one by one."""
         if self.packed is None:
             raise RuntimeError('EngineX2.load_eval() has not been called')
-        fuse = self.mixed and self.probe is None and bool(nv.lib().iunet_x2m_head_fusable(self.ncls, self.ch[0]))
+        fuse = self.mixed and self.probe is None and self.norm == 'batch' and bool(nv.lib().iunet_x2m_head_fusable(self.ncls, self.ch[0]))
         if not fuse or len(views) == 1:
             for (x, xs, n), o in zip(views, outs):
                 self.infer(x, xs, n, D, H, W, **o)
@@ -322,7 +333,7 @@ class EngineX2:
         if self.mixed:
             # the last stage conv carries the head in its epilogue where the library has that form (2 or 3 classes on 32 channels): the
             # last activation is never written.  Same bits as conv + head (tests/test_gpu_x2m.py)
-            fuse = not features_only and self.probe is None and bool(nv.lib().iunet_x2m_head_fusable(self.ncls, self.ch[0]))
+            fuse = not features_only and self.probe is None and self.norm == 'batch' and bool(nv.lib().iunet_x2m_head_fusable(self.ncls, self.ch[0]))
             head = (logits, probs, cls, out_strides, divisor, accumulate) if fuse else None
             self._infer_mixed(ws, x, x_strides, N, D, H, W, s, head=head)
             if features_only:
@@ -383,7 +394,14 @@ class EngineX2:
     def _conv3m(self, name, xp, x_ss, x8p, x8_ss, yp, y_ss, y_lo, y8p, y8_ss, N, d, ci, co, s, pool=None):
         """3x3x3 stage conv, cross terms on the fp8 matrix cores: (hi planes, lo8 planes) -> hi planes (+ lo planes if y_lo >= 0, + m8 planes).
         pool = (hi planes, stride, lo8 planes, stride) of the half-size grid: the stage's max-pool rides in the conv's epilogue."""
-        w16, osc, b, w8 = self.packed[name]
+        w16, osc, b, w8 = self.packed[name][:4]
+        if self.norm == 'group':
+            # raw output (accumulator x row scale: no bias, no ReLU) as hi + lo planes, then statistics + normalise + ReLU into the consumer's
+            # format: hi + lo8 planes (y8p), lo planes where y_lo >= 0
+            ws, v = self._gn_ws, _vox(d)
+            nv.call('iunet_x2m_conv_fwd', self.dim, xp, x_ss, x8p, x8_ss, nv.ptr(ws['raw']), 2 * co * v, co // 8, None, 0, nv.ptr(w16), nv.ptr(w8),
+                    nv.ptr(osc), nv.ptr(b), N, d[0], d[1], d[2], ci, co, 0, nv.ptr(self._sat), s)
+            return self._gnm(name, ws, yp, y_ss, y_lo, y8p, y8_ss, N, d, co, s)
         probe = self.probe if (self.probe is not None and self.probe['name'] == name) else None
         if probe is not None:
             e0 = torch.cuda.Event(enable_timing=True)
@@ -403,12 +421,14 @@ class EngineX2:
         """The forward in the x2m form (everything but the head): a / cat / pin tensors are (hi planes, lo8 planes), b tensors (hi, lo).
         views / heads (infer_views): several (x, strides, n) inputs filling the batch, and one fused-head output per view."""
         dims, L, ch = ws['dims'], self.levels, self.ch
+        gn = self.norm == 'group'
+        self._gn_ws = ws
         if views is None:
             views = [(x, x_strides, N)]
         P8 = lambda t, planes16=0, v=0: ctypes.c_void_p(t.data_ptr() + planes16 * v * 16)     # m8 view starting `planes16` 16-byte planes in
         Ph = lambda t, planes=0, v=0: ctypes.c_void_p(t.data_ptr() + planes * v * 16)         # hi view starting `planes` 8-channel planes in
         # 2-D, one input channel: the first encoder stage is ONE launch (the first conv is computed by the second conv's loader waves)
-        stage0 = L > 1 and bool(nv.lib().iunet_x2m_first_stage_fusable(self.dim, self.cin, ch[0], N, H, W)) and self.probe is None and len(views) == 1
+        stage0 = L > 1 and bool(nv.lib().iunet_x2m_first_stage_fusable(self.dim, self.cin, ch[0], N, H, W)) and self.probe is None and len(views) == 1 and not gn
         for l in range(L):
             d, v = dims[l], _vox(dims[l])
             c = ch[l]
@@ -426,14 +446,21 @@ class EngineX2:
                             pool[0], pool[1], pool[2], pool[3], c, N, do[0], do[1], do[2], s)
                 continue
             if l == 0:
-                w, osc, b = self.packed['enc0.conv1']
+                w, osc, b = self.packed['enc0.conv1'][:3]
                 n0 = 0
                 for vx, vxs, vn in views:          # each view through its own strides into its share of the batch
-                    nv.call('iunet_x2m_first_conv_fwd', self.dim, nv.ptr(vx), nv.IN_DTYPE_CODE[vx.dtype], nv.ll_array(vxs),
-                            ctypes.c_void_p(ws['a0'].data_ptr() + n0 * c * v * 2), c * v, -1, ctypes.c_void_p(ws['a0m'].data_ptr() + n0 * c * v),
-                            c * v, nv.ptr(w), nv.ptr(osc), nv.ptr(b), self.act_scale,
-                            vn, d[0], d[1], d[2], self.cin, c, 1, nv.ptr(self._sat), s)
+                    if gn:                         # raw output as hi + lo planes; normalised below
+                        nv.call('iunet_x2m_first_conv_fwd', self.dim, nv.ptr(vx), nv.IN_DTYPE_CODE[vx.dtype], nv.ll_array(vxs),
+                                ctypes.c_void_p(ws['raw'].data_ptr() + n0 * 2 * c * v * 2), 2 * c * v, c // 8, None, 0, nv.ptr(w), nv.ptr(osc), nv.ptr(b),
+                                self.act_scale, vn, d[0], d[1], d[2], self.cin, c, 0, nv.ptr(self._sat), s)
+                    else:
+                        nv.call('iunet_x2m_first_conv_fwd', self.dim, nv.ptr(vx), nv.IN_DTYPE_CODE[vx.dtype], nv.ll_array(vxs),
+                                ctypes.c_void_p(ws['a0'].data_ptr() + n0 * c * v * 2), c * v, -1, ctypes.c_void_p(ws['a0m'].data_ptr() + n0 * c * v),
+                                c * v, nv.ptr(w), nv.ptr(osc), nv.ptr(b), self.act_scale,
+                                vn, d[0], d[1], d[2], self.cin, c, 1, nv.ptr(self._sat), s)
                     n0 += vn
+                if gn:
+                    self._gnm('enc0.conv1', ws, Ph(ws['a0']), c * v, -1, P8(ws['a0m']), c * v, N, d, c, s)
             else:
                 cp = ch[l - 1]
                 self._conv3m(f'enc{l}.conv1', Ph(ws[f'pin{l}']), cp * v, P8(ws[f'pin{l}m']), cp * v, Ph(ws[f'a{l}']), c * v, -1,
@@ -441,7 +468,7 @@ class EngineX2:
             if l < L - 1:
                 # skip half of the concat buffer: hi planes [0, c / 8), lo8 planes [0, c / 16)
                 do = dims[l + 1]
-                fused = bool(nv.lib().iunet_x2m_pool_fusable(self.dim, c))
+                fused = not gn and bool(nv.lib().iunet_x2m_pool_fusable(self.dim, c))
                 pool = (Ph(ws[f'pin{l + 1}']), c * _vox(do), P8(ws[f'pin{l + 1}m']), c * _vox(do))
                 self._conv3m(f'enc{l}.conv2', Ph(ws[f'a{l}']), c * v, P8(ws[f'a{l}m']), c * v, Ph(ws[f'cat{l}']), 2 * c * v, -1,
                              P8(ws[f'cat{l}m']), 2 * c * v, N, d, c, c, s, pool=pool if fused else None)

@@ -160,7 +160,7 @@ def test_groupnorm_network_through_the_handle(dim, shape):
     st = nv.ll_array((vox, vox, H * W, W, 1))
     os_ = nv.ll_array((ncls * vox, vox, H * W, W, 1))
     nv.call('iunet_net_forward', h, nv.ptr(x), 2, st, N, D, H, W, nv.ptr(ws), nv.ptr(logits), None, nv.ptr(cls), os_, 1.0, 0, nv.stream())
-    e = EngineX2(dim=dim, ncls=ncls, norm='group', groups=8)
+    e = EngineX2(dim=dim, ncls=ncls, norm='group', groups=8, mixed=False)
     e.load_eval({k: v.cuda() for k, v in p.items()})
     lg2, cl2, lg3 = torch.empty_like(logits), torch.empty_like(cls), torch.empty_like(logits)
     e.use_graph = False
