@@ -267,8 +267,6 @@ def native_parity(model, cfg, chunk_u8):
     names = []
     if not cfg['wq']:
         for nm, mixed in (('fp16x2', False), ('x2m', True)):
-            if mixed and norm == 'group':
-                continue                        # (GroupNorm networks have the full fp16x2 form only)
             ex2 = EngineX2(dim, cfg['levels'], cfg['base'], 1, ncls, model.device, mixed=mixed, norm=norm)
             ex2.load_eval(model.named_tensors())
             engs.append(ex2)
@@ -371,8 +369,6 @@ def cpu_baseline(cfg, model=None, chunk_u8=None):
             ea.load_eval(model.named_tensors())
             modes.append(('default_mode', ea))
             for nm, mixed in (('fp16x2', False), ('x2m', True)):
-                if mixed and norm == 'group':
-                    continue
                 ex2 = EngineX2(dim, levels, base, 1, ncls, model.device, mixed=mixed, norm=norm)
                 ex2.load_eval(model.named_tensors())
                 modes.append((nm, ex2))
