@@ -2,9 +2,14 @@
 conv), in both split-precision forms.   python tools/bench_gn_predict.py"""
 import sys, time, torch
 sys.path.insert(0,'interactive-unet_amd'); sys.path.insert(0,'.')
-from oracle import unet_ref
+import warnings
+from interactive_unet.unet import UNet
 from interactive_unet.engine_x2 import EngineX2
-p={k:v.cuda() for k,v in unet_ref.init_params(dim=3, ncls=2, seed=1, randomize_bn=True).items()}
+with warnings.catch_warnings():
+    warnings.simplefilter('ignore')
+    m=UNet(dim=3, pretrained=False)
+m.reset_parameters(seed=1)
+p={k:v.cuda() for k,v in m.named_tensors().items()}
 x=torch.randint(1,255,(1,1,128,128,128),dtype=torch.uint8,device='cuda')
 v=128**3
 for norm in ('batch','group'):
