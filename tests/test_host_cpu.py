@@ -96,3 +96,46 @@ def test_train_model_signature_matches_reference():
     names = list(inspect.signature(trainer.train_model).parameters)[:11]
     assert names == ['lr', 'batch_size', 'epochs', 'num_channels', 'num_classes', 'loss_function_name', 'architecture',
                      'encoder_name', 'pretrained', 'reslice', 'reslice_factor']       # app.py:697-719 passes them positionally
+
+
+def test_engine_auto_host_logic(monkeypatch):
+    """engine_auto.EngineAuto's host side without a GPU: policy from the argument / IUNET_X2M, the calibration tile, the re-calibration
+    schedule over weight loads, the adoption of a figure at the next load, and the range steps."""
+    import torch
+    from interactive_unet.engine_auto import EngineAuto, THRESHOLD
+    monkeypatch.delenv('IUNET_X2M', raising=False)
+    assert EngineAuto(dim=2, device='cpu').policy == 'auto'
+    monkeypatch.setenv('IUNET_X2M', '0')
+    assert EngineAuto(dim=2, device='cpu').policy == 'fp16x2' and EngineAuto(dim=2, device='cpu', policy='x2m').policy == 'x2m'
+    monkeypatch.setenv('IUNET_X2M', '1')
+    assert EngineAuto(dim=3, device='cpu').mode == 'x2m'
+    monkeypatch.delenv('IUNET_X2M')
+    with pytest.raises(ValueError):
+        EngineAuto(dim=2, device='cpu', policy='fp8')
+    e = EngineAuto(dim=3, levels=4, device='cpu', recal_every=4)
+    assert e._crop(128, 128, 128) == (64, 64, 64) and e._crop(16, 32, 200) == (16, 32, 64) and e._crop(8, 8, 8) == (8, 8, 8)
+    e5 = EngineAuto(dim=2, levels=5, device='cpu')
+    assert e5._crop(1, 512, 48) == (1, 256, 48) and e5._crop(1, 16, 16) == (1, 16, 16)
+
+    class _Form:
+        loads = 0
+
+        def load_eval(self, params):
+            _Form.loads += 1
+    e._form = lambda name: _Form()
+    figures = iter([1e-4, 9e-4, 2e-4])
+    e._measure = lambda x, xs, D, H, W: (torch.tensor([next(figures), 3.0]), (64, 64, 64))
+    with pytest.raises(RuntimeError):
+        e.calibrate(object(), None, 64, 64, 64)
+    trace = []
+    for load in range(1, 11):
+        e.load_eval({})
+        if e._due():
+            e.calibrate(object(), None, 64, 64, 64, blocking=e.mode is None)
+        trace.append((load, e.form, e.calibrations))
+    # load 1: blocking -> x2m at once; load 5: measured 9e-4, adopted at load 6 -> fp16x2; load 9: 2e-4, adopted at load 10 -> x2m
+    assert [f for _, f, _ in trace] == ['x2m'] * 5 + ['fp16x2'] * 4 + ['x2m']
+    assert [c for _, _, c in trace] == [1, 1, 1, 1, 2, 2, 2, 2, 3, 3]
+    assert e.calibration['diff'] == pytest.approx(2e-4) and e.calibration['threshold'] == THRESHOLD and e.describe()['form'] == 'x2m'
+    assert e.widen() and e.form == 'fp16x2_wide' and not e._due()
+    assert e.widen() and e.form == 'fp32' and not e.widen()
