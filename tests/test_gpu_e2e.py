@@ -149,6 +149,42 @@ def test_predict_volumes_zarr_end_to_end(tmp_path, monkeypatch):
         assert multiscale.read_volume(os.path.join('data', 'predicted_volumes', f'{name}.zarr'), level=1).shape == tuple(levels[0].shape)
 
 
+def test_predict_volumes_reruns_a_saturated_volume_in_a_wider_form(tmp_path, monkeypatch, capsys):
+    """predict.py:114-266 with a checkpoint of the DEFAULT module (split-precision prediction) whose first activation is ~3000: beyond the
+    fp16 range of the default form.  The volume must come out as the fp32 mode predicts it (within the truncation's 1 LSB), after the
+    automatic second pass in the wider form -- never a warning beside a wrong result."""
+    from interactive_unet import predict, multiscale, zarr3
+    from interactive_unet.unet import UNet
+    monkeypatch.chdir(tmp_path)
+    S, C, V = 32, 2, (40, 56, 40)
+    gain = 3000.0
+    p = unet_ref.init_params(dim=3, ncls=C, seed=4, randomize_bn=True)
+    p['enc0.conv1.weight'] = p['enc0.conv1.weight'] * gain
+    p['enc0.bn1.bias'] = p['enc0.bn1.bias'] * gain
+    p['enc0.bn1.running_mean'] = p['enc0.bn1.running_mean'] * gain
+    p['enc0.conv2.weight'] = p['enc0.conv2.weight'] / gain
+    models = {}
+    for dt in (None, 'fp32'):
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            m = UNet(num_classes=C, dim=3, act_dtype=dt, pretrained=False)
+        m.load_named(p)
+        models[dt] = m.cuda().eval()
+    os.makedirs('model')
+    models[None].save_checkpoint(os.path.join('model', 'model.ckpt'))
+    vol = _volume(V, 47)
+    os.makedirs(os.path.join('data', 'image_volumes'))
+    os.makedirs(os.path.join('data', 'predicted_volumes'))
+    multiscale.create_multiscale_zarr(vol, os.path.join('data', 'image_volumes', 'a.zarr'), chunk_size=16, shard_size=32)
+    want = predict.predict_volume_array(models['fp32'], vol, input_size=S, num_classes=C).cpu().numpy().astype(int)
+    predict.predict_volumes(input_size=S, num_classes=C, chunk_size=16, shard_size=32)
+    out = capsys.readouterr().out
+    assert 'predicting again in fp16x2_wide' in out and 'WARNING' not in out
+    got = zarr3.open(os.path.join('data', 'predicted_volumes', 'a.zarr'))['0'][...].astype(int)
+    assert got.shape == want.shape and np.abs(got - want).max() <= 1
+    assert (got != want).mean() < 0.02
+
+
 def test_train_model_files_and_learning(tmp_path, monkeypatch):
     """trainer.train_model with injected loaders: loss goes down, model/model.ckpt and the Lightning-style
     metrics.csv appear, a second call resumes from the checkpoint (trainer.py:30-49)."""
