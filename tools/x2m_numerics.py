@@ -1,7 +1,11 @@
 """CPU emulation of the x2m arithmetic (csrc/conv3_x2m.hip) on the 3-D network: every 3x3x3 stage conv as x_hi w_hi (fp16 operands) +
 e4m3(x_lo 2^4) e4m3(w_hi 2^-4) + e4m3(x_hi 2^-8) e4m3(w_lo 2^8), fp32 accumulation, against the oracle's fp32 forward -- beside fp16x2
 (three fp16 terms) and plain fp16.  `python tools/x2m_numerics.py [size]`.  This is the experiment VERDICT r3 item 1(b) asked for, run
-before the kernel was written: x2m lands ~20x closer to fp32 than fp16, ~30x further than fp16x2."""
+before the kernel was written: x2m lands ~20x closer to fp32 than fp16, ~30x further than fp16x2.
+[r5] mode 'x2f6': the same two cross terms on e2m3 (fp6) operands with an e8m0 scale per 32 K-elements (one filter tap x the 32 virtual
+channels [lo | hi] of a 16-channel chunk: per voxel for the activations, per output channel for the operator) -- the MX form the K = 128
+instruction issues 1.7x faster (tools/micro/mfma_f6_rate.hip).  e2m3 has e4m3's three mantissa bits but TWO exponent bits: inside a block
+only the elements within 8x of the block maximum keep them."""
 import sys
 import os
 
@@ -33,6 +37,26 @@ def f16(t):
     return t.to(torch.float16).float()
 
 
+def e2m3(v):
+    """nearest e2m3 value (1 sign, 2 exponent, 3 mantissa bits: 0, 0.125 ... 0.875, 1 ... 1.875, 2 ... 3.75, 4 ... 7.5), ties to even, saturating"""
+    a = v.abs().clamp(max=7.5)
+    e = torch.floor(torch.log2(a.clamp(min=1e-30))).clamp(0, 2)
+    step = 2.0 ** (e - 3)
+    return torch.sign(v) * torch.round(a / step) * step
+
+
+def q6_blocks(parts, dims):
+    """parts: tensors that share one e8m0 scale per block; a block = the elements along `dims` (one tensor dimension list per part) --
+    -> the dequantised parts"""
+    amax = None
+    for t, d in zip(parts, dims):
+        m = t.abs().amax(dim=d, keepdim=True)
+        amax = m if amax is None else torch.maximum(amax, m)
+    k = torch.ceil(torch.log2((amax / 7.5).clamp(min=2.0 ** -126)))
+    sc = 2.0 ** k
+    return [e2m3(t / sc) * sc for t in parts]
+
+
 def run(mode):
     def split(t):
         v = (t * A).clamp(-65504, 65504)
@@ -52,6 +76,15 @@ def run(mode):
             y = y + F.conv3d(f16(lo), whi, padding=1) + F.conv3d(hi, f16(wlo), padding=1)
         elif mode == 'x2m':
             y = y + F.conv3d(q8(lo, 16.0), q8(whi, 1 / 16.0), padding=1) + F.conv3d(q8(hi, 1 / 256.0), q8(wlo, 256.0), padding=1)
+        elif mode == 'x2f6':
+            ci = t.shape[1]
+            lo6, hi6, whi6, wlo6 = torch.empty_like(lo), torch.empty_like(hi), torch.empty_like(whi), torch.empty_like(wlo)
+            for c in range(0, ci, 16):          # one block = 32 virtual channels [lo x 16 | hi / 256] of a 16-channel chunk
+                a, b = q6_blocks([lo[:, c:c + 16] * 16.0, hi[:, c:c + 16] / 256.0], [[1], [1]])               # per voxel
+                lo6[:, c:c + 16], hi6[:, c:c + 16] = a / 16.0, b * 256.0
+                a, b = q6_blocks([whi[:, c:c + 16] / 16.0, wlo[:, c:c + 16] * 256.0], [[1], [1]])             # per (output channel, tap)
+                whi6[:, c:c + 16], wlo6[:, c:c + 16] = a * 16.0, b / 256.0
+            y = y + F.conv3d(lo6, whi6, padding=1) + F.conv3d(hi6, wlo6, padding=1)
         return F.relu(y / rs.view(1, -1, 1, 1, 1) / A + bias.view(1, -1, 1, 1, 1))
 
     def keep(t):          # what a consumer reads back: 22 bits (fp16x2, and x2m's hi + lo tensors), 11 bits (fp16)
@@ -75,7 +108,7 @@ def run(mode):
     return F.conv3d(keep(t), p['head.weight'], bias=p['head.bias'])
 
 
-for mode in ('fp16', 'x2m', 'fp16x2'):
+for mode in ('fp16', 'x2m', 'x2f6', 'fp16x2'):
     lg = run(mode)
     err = (lg - ref).abs()
     mism = (lg.argmax(1) != ref.argmax(1))
