@@ -139,3 +139,37 @@ def test_engine_auto_host_logic(monkeypatch):
     assert e.calibration['diff'] == pytest.approx(2e-4) and e.calibration['threshold'] == THRESHOLD and e.describe()['form'] == 'x2m'
     assert e.widen() and e.form == 'fp16x2_wide' and not e._due()
     assert e.widen() and e.form == 'fp32' and not e.widen()
+
+
+def test_block_grid_and_padded_blocks_against_the_oracle_on_random_shapes():
+    """Beyond the reference-generated goldens: the native block grid (predict.py:362-411, truncating float -> int), reflect-padded blocks
+    (predict.py:291-316) and the sharded partition on random volume shapes / block sizes / overlaps against the oracle restatement (itself
+    pinned by the goldens), plus the invariants a prediction relies on: every voxel covered, local = clipped - padded, blocks inside the
+    padded extent."""
+    from hypothesis import given, settings, strategies as st
+    from interactive_unet import predict, shard
+    from oracle import predict_ref
+
+    @settings(max_examples=60, deadline=None)
+    @given(st.tuples(st.integers(9, 140), st.integers(9, 140), st.integers(9, 140)), st.sampled_from([8, 16, 24, 32, 64]),
+           st.sampled_from([0.0, 0.125, 0.25, 0.5]), st.integers(1, 8))
+    def check(V, S, overlap, world):
+        b, pb, lb = predict.get_block_coordinates(np.array(V), S, overlap)
+        wb, wpb, wlb = predict_ref.get_block_coordinates(V, S, overlap)
+        assert np.array_equal(b, wb) and np.array_equal(pb, wpb) and np.array_equal(lb, wlb)
+        if len(pb) == 0:          # a volume thinner than overlap * S along an axis: the reference's grid is empty there (predict.py:376), and so is ours
+            assert min(V) <= overlap * S
+            return
+        assert (pb[:, 3:] - pb[:, :3] == S).all() and np.array_equal(lb[:, :3], b[:, :3] - pb[:, :3]) and np.array_equal(lb[:, 3:], b[:, 3:] - pb[:, :3])
+        cover = np.zeros(V, dtype=np.int32)
+        for c in b:
+            cover[c[0]:c[3], c[1]:c[4], c[2]:c[5]] += 1
+        assert cover.min() >= 1
+        runs = shard.partition_blocks(len(pb), world)
+        assert runs[0][0] == 0 and runs[-1][1] == len(pb) and all(a[1] == c[0] for a, c in zip(runs, runs[1:]))
+        rng = np.random.default_rng(sum(V) + S)
+        vol = rng.integers(0, 256, size=V, dtype=np.uint8)
+        for k in rng.integers(0, len(pb), size=min(3, len(pb))):
+            if (np.array(V) >= 2).all() and (b[k][3:] - b[k][:3] >= 2).all():          # np.pad(reflect) needs two planes to mirror
+                assert np.array_equal(predict.get_padded_block(vol, *pb[k]), predict_ref.get_padded_block(vol, *[int(v) for v in pb[k]]))
+    check()
