@@ -60,6 +60,9 @@ template <bool SMALL> struct V4Tile<2, SMALL> { static constexpr int TZ = 1, TY 
 #ifndef V4_X2_LT3D
 #define V4_X2_LT3D 512          // loader threads of the 3-D split conv (A/B: -DV4_X2_LT3D=256)
 #endif
+#ifndef V4_RING2
+#define V4_RING2 1              // 2-D cross-pair step: three halo buffers, copies two steps ahead -- bit 0: resident weights (64 -> 32 @ 8 x 512^2: 116 -> 107 us), bit 1: streamed weights too (measured: no gain, 128 -> 64 75 -> 77 us; A/B: -DV4_RING2=0 / 3)
+#endif
 #ifndef V4_NP3_LT
 #define V4_NP3_LT 512           // loader threads of the 3-D compact-operator conv (A/B: -DV4_NP3_LT=256)
 #endif
@@ -130,7 +133,10 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + v4_loader_threads(ND
   constexpr int NCMB = (NCOL + 1) / 2, KS = NCMB * 3;
   constexpr int WBYTES = KS * 2 * 1024;                // one 16-channel chunk of packed weights
   constexpr int WSTEP = NP2 ? 3 * 3 * 2 * 1024 : S16 * WBYTES;      // the weights of one step (NP2: three k-groups of 6 KB)
-  constexpr int NBUF = NP3 ? 3 : 2;                    // halo buffers
+  // RING2: the 2-D cross-pair step keeps THREE halo buffers as well -- its loaders run two steps ahead by LDS-DMA (the copy of step
+  // s + 2 is issued before the wait for step s + 1: the memory pipe never drains at a step barrier); streamed weights stay one step ahead
+  constexpr bool RING2 = NP2 && !SPL && (WS ? (V4_RING2 & 1) != 0 : (V4_RING2 & 2) != 0);
+  constexpr int NBUF = (NP3 || RING2) ? 3 : 2;         // halo buffers
   constexpr int OFF_W = NBUF * ABUF;
   constexpr int WE = 4 * 3 * 2 * 1024, WO = WE + 3 * 2 * 1024;      // NP: bytes of an even step's weights (4 column pairs) / an odd step's (+ the cross pair)
   constexpr int AIT = (NPIX + NLT - 1) / NLT;          // halo pixels per loader thread (5 / 3)
@@ -174,7 +180,7 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + v4_loader_threads(ND
   const long long plane_stride = (long long)p.D * p.H * p.W * 8;
   const int off_red = OFF_W + (NP3 ? WE + WO : (WS ? nchunk : 2) * WSTEP);    // 2 KB of scratch for the BatchNorm partial sums
   const int off_act = off_red + 2048;                       // the fused input activation: [Cin / 8][scale 8 | shift 8] floats
-  const int off_bw = off_act + (p.in_scale != nullptr || !NP3 ? p.Cin * 8 : 0);                   // bw_y: [mean | invstd | scale | shift][32] floats of this Cout tile
+  const int off_bw = off_act + (p.in_scale != nullptr || !NP ? p.Cin * 8 : 0);                   // bw_y: [mean | invstd | scale | shift][32] floats of this Cout tile
   constexpr bool bw = BW;
   if (bw && tid < 128) {
     const float* src = (tid >> 5) == 0 ? p.bw_mean : (tid >> 5) == 1 ? p.bw_invstd : (tid >> 5) == 2 ? p.bw_scale : p.bw_shift;
@@ -188,7 +194,7 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + v4_loader_threads(ND
   auto part_of = [&](int s) -> int { const int c = chunk_of(s); return c - 3 * (c / 3); };
   auto abuf_of = [&](int s) -> int {                                                               // halo buffer of step s
     if constexpr (SPL) return part_of(s) == 0 ? 0 : ABUF;
-    return NP3 ? (s - 3 * (s / 3)) * ABUF : (s & 1) * ABUF;
+    return (NP3 || RING2) ? (s - 3 * (s / 3)) * ABUF : (s & 1) * ABUF;
   };
   // first source plane of a chunk
   auto src_plane = [&](int chunk) -> long long {
@@ -368,6 +374,28 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + v4_loader_threads(ND
 #endif
       // 3-D only: the 2-D level-0 layers are HBM-bound and need the register path's loads in flight across the barrier (measured:
       // C2's dec0.conv1 at 45 % of the HBM peak by LDS-DMA against 49 % through registers)
+      if constexpr (RING2) if (!decltype(ACT)::value && !(p.dbg & 64)) {
+        // ---- two steps ahead: in iteration s (consumers on step s) the copy of step s + 2 goes out -- into the buffer of step s - 1,
+        // free since the last barrier -- and only then step s + 1 is waited for: vmcnt(K), K = this wave's copy instructions per step
+        int K = 0;
+#pragma unroll
+        for (int it = 0; it < AIT; ++it) K += (it * NLT + lw * 64 < PLANE / 16) ? CP : 0;
+        auto landed_but_last = [&]() {
+          if (K == CP * AIT) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(CP * AIT) : "memory");
+          else if (K == CP * (AIT - 1)) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(CP * (AIT - 1)) : "memory");
+          else landed();
+        };
+        if (!WS) dma_weights(0, 0);
+        dma_acts(0);
+        if (last > 0) { dma_acts(1); landed_but_last(); } else landed();
+        lds_barrier();
+        for (int s = 0; s < nsteps; ++s) {
+          if (!WS && s + 1 < nsteps) dma_weights(s + 1, (s + 1) & 1);      // (in front of the halo copy: the wait below leaves only that one in flight)
+          if (s + 2 < nsteps) { dma_acts(s + 2); landed_but_last(); } else landed();
+          lds_barrier();
+        }
+        return;
+      }
       if ((ND == 3 || SPL || (NP2 && !WS)) && !decltype(ACT)::value && !(p.dbg & 64)) {      // (IUNET_V4_DBG=64: the register path for every launch -- A/B switch)
         // ---- everything by LDS-DMA: in iteration s (consumers on step s) the buffers of step s + 1 are filled ----
         if (!WS) dma_weights(0, 0);
@@ -785,7 +813,8 @@ int launch_v4(ConvV4Params p, hipStream_t stream) {
   constexpr int PLANE = ((NPIX * 16 + 255) / 256) * 256;
   constexpr int WSTEP = (NP && ND == 2) ? 3 * 3 * 2 * 1024 : TL::S16 * ((TL::NCOL + 1) / 2) * 3 * 2 * 1024;
   const int lds = (NP && ND == 3) ? 3 * 2 * PLANE + (24576 + 30720) + 2048 + (p.in_scale != nullptr ? p.Cin * 8 : 0) + 512
-                     : 2 * 2 * TL::S16 * PLANE + (WS ? p.Cin / (16 * TL::S16) : 2) * WSTEP + 2048 + (SPL ? 0 : p.Cin * 8) + 512;      // (SPL: no fused input activation, and Cin is the 3x virtual count)
+                     : ((NP && ND == 2 && !SPL && (WS ? (V4_RING2 & 1) != 0 : (V4_RING2 & 2) != 0)) ? 3 : 2) * 2 * TL::S16 * PLANE + (WS ? p.Cin / (16 * TL::S16) : 2) * WSTEP + 2048
+                           + ((SPL || (NP && ND == 2 && p.in_scale == nullptr)) ? 0 : p.Cin * 8) + 512;      // (SPL: no fused input activation, and Cin is the 3x virtual count)
   IUNET_REQUIRE(lds <= 160 * 1024, "conv3 layout 3: %d bytes of LDS (a fused input activation fits up to 192 input channels)", lds);
   IUNET_SET_MAX_LDS((conv3_v4_kernel<T, ND, WS, SMALL, BW, PAIR, NP, SPL>), lds);
   p.tilesZ = (p.D + TL::TZ - 1) / TL::TZ; p.tilesY = (p.H + TL::TY - 1) / TL::TY; p.tilesX = (p.W + TL::TX - 1) / TL::TX;
