@@ -73,8 +73,9 @@ int iunet_conv3_pick_layout(int nd, int N, int D, int H, int W, int Cin, int Cou
 int iunet_conv3_tile_pairs(int nd, int N, int D, int H, int W, int Cin, int Cout);
 /* layout 3 of iunet_conv3_fwd / _fwd_act: the layout-2 kernel on the COMPACT K16 operator (iunet_pack_conv3 mode bit 2; 3^3 filters:
  * Cout * Cin * 27 elements, the ninth filter column of two consecutive 16-channel chunks shares one k-slot) -- 10 % fewer matrix
- * instructions and weight bytes.  1 if this launch qualifies (3-D, Cin > 32, no fused BatchNorm-backward sums (bw), a fused
- * input activation (act) only up to 192 input channels), else 0: use layout 2.  The answer does not depend on the grid: layouts
+ * instructions and weight bytes.  1 if this launch qualifies (3-D: Cin > 32, no fused BatchNorm-backward sums (bw), a fused
+ * input activation (act) only up to 192 input channels; 2-D, 3^2 filters on the cross-pair step: every channel count, act or bw only
+ * up to 64 input channels), else 0: use layout 2.  The answer does not depend on the grid: layouts
  * 2 and 3 add the taps in different orders, and a layer keeps one order whatever the number of blocks in a launch. */
 int iunet_conv3_compact_ok(int nd, int N, int D, int H, int W, int Cin, int Cout, int act, int bw);
 /* iunet_conv3_fwd whose input is relu(in_scale[c] * x + in_shift[c]) (fp32 [Cin] each): in training the BatchNorm + ReLU of
@@ -484,6 +485,12 @@ int iunet_conv3_dgrad_bnstats(int dtype, int nd, const void* dy, long long dy_ss
                               const void* wpk, void* stats, const void* yp, long long yp_sstride, const void* mean,
                               const void* invstd, const void* scale, const void* shift, int N, int D, int H, int W, int Cin,
                               int Cout, void* stream);
+/* ... on a named layout: 2 (the K16 operator, as above) or 3 (the compact operator: 2-D, up to 64 input channels --
+ * iunet_conv3_compact_ok(.., act 0, bw 1) says whether a launch has it); the rows and their order are the layout-2 ones. */
+int iunet_conv3_dgrad_bnstats_lay(int dtype, int nd, const void* dy, long long dy_sstride, void* dz, long long dz_sstride,
+                                  const void* wpk, void* stats, const void* yp, long long yp_sstride, const void* mean,
+                                  const void* invstd, const void* scale, const void* shift, int N, int D, int H, int W, int Cin,
+                                  int Cout, int layout, void* stream);
 int iunet_bn_relu_bwd_apply(int dtype, const void* dz, long long dz_ss, const void* y, long long y_ss, void* dy, long long dy_ss,
                             const void* mean, const void* invstd, const void* gamma, const void* scale, const void* shift,
                             void* dgamma, void* dbeta, const void* slab, int nparts, void* coef, int C, int N, long long vox,

@@ -117,14 +117,16 @@ int iunet_conv3_pick_layout(int nd, int N, int D, int H, int W, int Cin, int Cou
   return iunet_conv3_pick(nd, N, D, H, W, Cin, Cout);
 }
 
-// can this launch run on layout 3 (compact operator, padding-free step: conv3_v4.hip NP)?  No fused BatchNorm-backward sums.  3-D:
+// can this launch run on layout 3 (compact operator, padding-free step: conv3_v4.hip NP)?  Fused BatchNorm-backward sums in 2-D on the
+// resident-weights variant only (Cin <= 64).  3-D:
 // streamed weights (Cin > 32), a fused input activation up to 192 input channels (LDS).  2-D (the cross-pair step): every channel
 // count, a fused input activation on the resident-weights variant only (Cin <= 64: the layers the training forward fuses).
 // IUNET_NO_COMPACT2D=1: A/B switch back to layouts 0 / 1 / 2 in 2-D.
 int iunet_conv3_compact_ok(int nd, int N, int D, int H, int W, int Cin, int Cout, int act, int bw) {
   static const bool off2d = getenv("IUNET_NO_COMPACT2D") != nullptr;
-  if ((nd != 2 && nd != 3) || N < 1 || D < 1 || H < 1 || W < 1 || Cin < 32 || Cout < 32 || Cin % 32 || Cout % 32 || bw) return 0;
-  if (nd == 2) return !off2d && D == 1 && !(act && Cin > 64);
+  static const bool no_bw2d = getenv("IUNET_NO_COMPACT2D_BW") != nullptr;      // A/B: the fused-sums data gradient back on layout 2
+  if ((nd != 2 && nd != 3) || N < 1 || D < 1 || H < 1 || W < 1 || Cin < 32 || Cout < 32 || Cin % 32 || Cout % 32 || (bw && nd != 2)) return 0;
+  if (nd == 2) return !off2d && D == 1 && !((act || bw) && Cin > 64) && !(bw && no_bw2d);
   if (Cin <= 32) return 0;
   return !(act && Cin > 192);        // independent of the grid: a layer keeps one summation order whatever the launch size
 }
@@ -163,16 +165,26 @@ int iunet_conv3_fwd_act(int dtype, int nd, const void* x, long long x_sstride, v
 // iunet_conv3_fwd used as the data gradient of a conv whose INPUT was z = relu(bn(yp)): besides dz (its output) it accumulates
 // the BatchNorm-backward sums of that producer layer -- sum dz', sum dz' * xhat with dz' = dz where z > 0 -- in its epilogue
 // (the reduction pass of iunet_bn_relu_bwd over dz and yp goes away); stats: [iunet_conv3_stats_parts(.., layout 2)][Cout][2].
+int iunet_conv3_dgrad_bnstats_lay(int dtype, int nd, const void* dy, long long dy_sstride, void* dz, long long dz_sstride,
+                                  const void* wpk, void* stats, const void* yp, long long yp_sstride, const void* mean,
+                                  const void* invstd, const void* scale, const void* shift, int N, int D, int H, int W, int Cin,
+                                  int Cout, int layout, void* stream) {
+  DT_OK(dtype);
+  IUNET_REQUIRE(dy && dz && wpk && stats && yp && mean && invstd && scale && shift, "conv3_dgrad_bnstats: null pointer");
+  IUNET_REQUIRE_GRID("conv3_dgrad_bnstats", N, D, H, W);
+  IUNET_REQUIRE(layout == 2 || layout == 3, "conv3_dgrad_bnstats: layout 2, or 3 (the compact operator: 2-D, Cin <= 64; iunet_conv3_compact_ok(.., bw = 1)) -- got %d", layout);
+  const float* par[4] = {(const float*)mean, (const float*)invstd, (const float*)scale, (const float*)shift};
+  return iunet_conv3_launch(dtype, nd, dy, dy_sstride, dz, dz_sstride, wpk, nullptr, (float*)stats, N, D, H, W, Cin, Cout, 0, layout,
+                            (hipStream_t)stream, nullptr, nullptr, yp, yp_sstride, par);
+}
+
+// (the layout-2 form, kept for callers of the first ABI)
 int iunet_conv3_dgrad_bnstats(int dtype, int nd, const void* dy, long long dy_sstride, void* dz, long long dz_sstride,
                               const void* wpk, void* stats, const void* yp, long long yp_sstride, const void* mean,
                               const void* invstd, const void* scale, const void* shift, int N, int D, int H, int W, int Cin,
                               int Cout, void* stream) {
-  DT_OK(dtype);
-  IUNET_REQUIRE(dy && dz && wpk && stats && yp && mean && invstd && scale && shift, "conv3_dgrad_bnstats: null pointer");
-  IUNET_REQUIRE_GRID("conv3_dgrad_bnstats", N, D, H, W);
-  const float* par[4] = {(const float*)mean, (const float*)invstd, (const float*)scale, (const float*)shift};
-  return iunet_conv3_launch(dtype, nd, dy, dy_sstride, dz, dz_sstride, wpk, nullptr, (float*)stats, N, D, H, W, Cin, Cout, 0, 2,
-                            (hipStream_t)stream, nullptr, nullptr, yp, yp_sstride, par);
+  return iunet_conv3_dgrad_bnstats_lay(dtype, nd, dy, dy_sstride, dz, dz_sstride, wpk, stats, yp, yp_sstride, mean, invstd, scale, shift,
+                                       N, D, H, W, Cin, Cout, 2, stream);
 }
 
 int iunet_first_conv_fwd(int dtype, int nd, const void* x, int in_dtype, const long long* in_strides, void* y,

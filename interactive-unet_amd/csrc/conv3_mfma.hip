@@ -377,7 +377,7 @@ int iunet_conv3_launch(int dtype, int nd, const void* x, long long x_sstride, vo
   const bool wide = (Cout % 64 == 0);
   IUNET_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv3: in_scale and in_shift come together");
   IUNET_REQUIRE(in_scale == nullptr || layout >= 2, "conv3: a fused input activation needs layout 2 or 3 (got %d)", layout);
-  IUNET_REQUIRE(bw_y == nullptr || layout == 2, "conv3: the fused BatchNorm-backward sums need layout 2 (got %d)", layout);
+  IUNET_REQUIRE(bw_y == nullptr || layout == 2 || (layout == 3 && nd == 2 && Cin <= 64), "conv3: the fused BatchNorm-backward sums need layout 2, or layout 3 in 2-D up to 64 input channels (got %d)", layout);
   if (layout >= 2) {
     return iunet_conv3_v4_launch(dtype, nd, x, x_sstride, y, y_sstride, wpk, bias, stats, N, D, H, W, Cin, Cout, epi,
                                  in_scale, in_shift, stream, bw_y, bw_y_ss, bw_par, layout == 3);

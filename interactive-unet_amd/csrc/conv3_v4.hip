@@ -112,7 +112,7 @@ template <typename T, int ND, bool WS, bool SMALL, bool BW = false, bool PAIR = 
 __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + v4_loader_threads(ND, WS, PAIR, SPL, BW, NP)), 1) void conv3_v4_kernel(ConvV4Params p) {
   static_assert(!SPL || (!WS && !BW && !PAIR && !(NP && ND == 3)), "split precision: streamed weights (Cin' = 3 Cin >= 96), forward only, padded operator in 3-D");
   static_assert(!PAIR || (!WS && !BW && ND == 3), "tile pairs: the streamed-weight 3-D forward / data-gradient variant only");
-  static_assert(!NP || (!BW && !PAIR && (ND == 2 || !WS)), "padding-free step: the streamed-weight 3-D variants and the 2-D ones, without fused BatchNorm-backward sums (so far)");
+  static_assert(!NP || (!PAIR && (ND == 2 || !WS) && (!BW || (ND == 2 && WS))), "padding-free step: the streamed-weight 3-D variants and the 2-D ones; fused BatchNorm-backward sums on the 2-D resident-weights variant only");
   // NP in 3-D: the ninth column of two consecutive 16-channel STEPS shares a k-slot (ring of three halo buffers, below).  NP in 2-D
   // (NP2): a step already holds two 16-channel sub-chunks, so the third filter column of both shares one k-group inside the step --
   // groups (sub-chunk 0: columns 0, 1), (sub-chunk 1: columns 0, 1), (cross: column 2 of both) = 9 taps in 9 k-slots instead of 12:
@@ -602,10 +602,17 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + v4_loader_threads(ND
       A[b][dy][1] = *(const V8*)(wl + h * WBYTES + ((c * 3 + dy) * 2 + 1) * 1024);
     }
   };
+  // the ReLU as ONE v_max against a wave-uniform floor, 0 or -inf (the run-time select `epi == 2 ? max(r, 0) : r` cost a v_cndmask per
+  // output value on top; two compiled epilogues cost the 128- / 168-register variants 640 B of scratch).  Without ReLU a NaN leaves as
+  // -inf: still not finite for every check downstream (with ReLU it has always left as 0)
+  // cross-step pipeline: the variants with resident weights (168-register cap); BW keeps its yp fragments instead; the 2-D cross-pair
+  // step has an odd group count (both parities of the pipeline instantiated: 76 B of scratch per lane) and restarts every step too
+  constexpr bool XSTEP = WS && !BW && !NP2;
   auto tile_epilogue = [&](int s, auto TSET) {
     constexpr int ts = decltype(TSET)::value;
     const int chunk = chunk_of(s);
     if (chunk == nchunk - 1) {
+      const float relu_floor = p.epi == 2 ? 0.f : -__builtin_inff();      // (made here from the scalar p.epi: held across the step loop it took a register)
       // ---- epilogue of this tile ----
       int n_img, z0, y0, x0;
       tile_origin(tile_of(s), n_img, z0, y0, x0);
@@ -633,7 +640,7 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + v4_loader_threads(ND
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             float r = fmaf(vals[j], j < 4 ? c0[j & 3] : c1[j & 3], j < 4 ? b0[j & 3] : b1[j & 3]);
-            if (p.epi == 2) r = fmaxf(r, 0.f);
+            if constexpr (XSTEP) { if (p.epi == 2) r = fmaxf(r, 0.f); } else r = fmaxf(r, relu_floor);      // (the cross-step pipeline's epilogue sits at its register cap: the floor form spilled 20 B there)
             T hi, lo;
             split16<T>(r, hi, lo);
             o[j] = hi; o_lo[j] = lo;
@@ -642,7 +649,7 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + v4_loader_threads(ND
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             float r = vals[j] + bias_r[j];
-            if (p.epi == 2) r = fmaxf(r, 0.f);
+            if constexpr (XSTEP) { if (p.epi == 2) r = fmaxf(r, 0.f); } else r = fmaxf(r, relu_floor);      // (the cross-step pipeline's epilogue sits at its register cap: the floor form spilled 20 B there)
             o[j] = from_f32<T>(r);
           }
         }
@@ -687,6 +694,7 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + v4_loader_threads(ND
       }
     }
   };
+
   // The MFMAs of group g on fragment set b, with the LDS reads issued just before them spread between the MFMAs.
   auto group_mfmas = [&](auto BUF, bool reads_pending, auto TSET) {
     constexpr int b = decltype(BUF)::value, ts = decltype(TSET)::value;
@@ -708,9 +716,6 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + v4_loader_threads(ND
     __builtin_amdgcn_sched_barrier(0);                           // nothing moves across the group boundary
   };
   // The groups of one step of the cross-step pipeline; PAR = fragment set of its first group.
-  // cross-step pipeline: the variants with resident weights (168-register cap); BW keeps its yp fragments instead; the 2-D cross-pair
-  // step has an odd group count (both parities of the pipeline instantiated: 76 B of scratch per lane) and restarts every step too
-  constexpr bool XSTEP = WS && !BW && !NP2;
   using TS0 = std::integral_constant<int, 0>;
   using TS1 = std::integral_constant<int, PAIR ? 1 : 0>;
   auto step_groups = [&](int s, auto PAR) {
@@ -896,12 +901,13 @@ int iunet_conv3_v4_launch(int dtype, int nd, const void* x, long long x_sstride,
   if (compact) {      // layout 3: the compact operator, padding-free step (streamed weights, big tiles, no fused BatchNorm-backward sums so far)
     // (every grid size: a layer must not change its summation order with the number of blocks in a launch -- the sharded prediction
     //  is byte-identical across world sizes)
-    IUNET_REQUIRE(bw_y == nullptr && (nd == 2 || !ws), "conv3 layout 3: no fused BatchNorm-backward sums; 3-D: Cin > 32");
+    IUNET_REQUIRE((bw_y == nullptr || (nd == 2 && Cin <= 64)) && (nd == 2 || !ws), "conv3 layout 3: fused BatchNorm-backward sums in 2-D up to 64 input channels only; 3-D: Cin > 32");
     if (nd == 2) {    // the cross-pair step: resident weights up to 64 input channels, streamed beyond
       // (the two variants read the same operator and add in the same order: which one runs is a speed choice.  IUNET_V4_WS2D = the
       //  largest Cin that keeps its weights resident when the input needs no arithmetic -- A/B switch)
       static const int ws2d = getenv("IUNET_V4_WS2D") ? atoi(getenv("IUNET_V4_WS2D")) : 64;
-      const bool ws = in_scale != nullptr ? Cin <= 64 : Cin <= ws2d;
+      const bool ws = (in_scale != nullptr || bw_y != nullptr) ? Cin <= 64 : Cin <= ws2d;
+      if (ws && bw_y != nullptr) return dtype == 0 ? launch_v4<f16, 2, true, false, true, false, true>(p, stream) : launch_v4<bf16, 2, true, false, true, false, true>(p, stream);
       if (ws) return dtype == 0 ? launch_v4<f16, 2, true, false, false, false, true>(p, stream) : launch_v4<bf16, 2, true, false, false, false, true>(p, stream);
       return dtype == 0 ? launch_v4<f16, 2, false, false, false, false, true>(p, stream) : launch_v4<bf16, 2, false, false, false, false, true>(p, stream);
     }

@@ -40,8 +40,8 @@ int iunet_bn_relu_pool_fwd(int, int, const void*, long long, void*, long long, v
 int iunet_bn_bwd_num_parts(int, long long);
 int iunet_bn_relu_bwd(int, const void*, long long, const void*, long long, const void*, long long, void*, long long, const void*,
                       const void*, const void*, const void*, const void*, void*, void*, void*, void*, int, int, long long, void*);
-int iunet_conv3_dgrad_bnstats(int, int, const void*, long long, void*, long long, const void*, void*, const void*, long long, const void*,
-                              const void*, const void*, const void*, int, int, int, int, int, int, void*);
+int iunet_conv3_dgrad_bnstats_lay(int, int, const void*, long long, void*, long long, const void*, void*, const void*, long long, const void*,
+                                  const void*, const void*, const void*, int, int, int, int, int, int, int, void*);
 int iunet_bn_relu_bwd_apply(int, const void*, long long, const void*, long long, void*, long long, const void*, const void*, const void*,
                             const void*, const void*, void*, void*, const void*, int, void*, int, int, long long, void*);
 int iunet_bn_relu_pool_bwd(int, int, const void*, long long, const void*, long long, const void*, long long, void*, long long, const void*,
@@ -562,9 +562,10 @@ int iunet_train_forward_backward_hooks(iunet_train* n, const void* x, int in_dty
     if (rc) return rc;
     long long woff;
     const int lay = pack_pick(c.dgr, dim, N, d, h, w, false, feeds >= 0 && n->fuse_bw, &woff);
-    if (feeds >= 0 && lay == 2 && n->fuse_bw) {
-      rc = iunet_conv3_dgrad_bnstats(dt, dim, dy, c.co * v, dxp, dx_ss, K + woff, F(L.stats), WS + L.y[feeds], c.ci * v, F(L.mean[feeds]),
-                                     F(L.invstd[feeds]), F(L.scale[feeds]), F(L.shift[feeds]), N, d, h, w, c.co, c.ci, stream);
+    // (pack_pick keeps the request for the fused sums only where the launch has them: layout 2, or the compact operator in 2-D up to 64 channels)
+    if (feeds >= 0 && n->fuse_bw && (lay == 2 || (lay == 3 && iunet_conv3_compact_ok(dim, N, d, h, w, c.co, c.ci, 0, 1)))) {
+      rc = iunet_conv3_dgrad_bnstats_lay(dt, dim, dy, c.co * v, dxp, dx_ss, K + woff, F(L.stats), WS + L.y[feeds], c.ci * v, F(L.mean[feeds]),
+                                         F(L.invstd[feeds]), F(L.scale[feeds]), F(L.shift[feeds]), N, d, h, w, c.co, c.ci, lay, stream);
       bw_ready[feeds] = iunet_conv3_stats_parts(dim, N, d, h, w, c.ci, 2);
     } else {
       rc = iunet_conv3_fwd(dt, dim, dy, c.co * v, dxp, dx_ss, K + woff, nullptr, nullptr, N, d, h, w, c.co, c.ci, 0, lay, stream);

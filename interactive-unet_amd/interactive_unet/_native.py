@@ -165,6 +165,8 @@ _SIGS = {
     'iunet_bn_bwd_num_parts': [c_int, c_ll],
     'iunet_conv3_dgrad_bnstats': [c_int, c_int, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_void_p, c_void_p, c_ll, c_void_p, c_void_p,
                                   c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    'iunet_conv3_dgrad_bnstats_lay': [c_int, c_int, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_void_p, c_void_p, c_ll, c_void_p, c_void_p,
+                                      c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     'iunet_bn_relu_bwd_apply': [c_int, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                 c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_ll, c_void_p],
     'iunet_gn_num_parts': [c_int, c_ll],
@@ -386,8 +388,8 @@ class PackedConv:
         bw: it accumulates the BatchNorm-backward sums (iunet_conv3_dgrad_bnstats)."""
         in_ch = self.cout if self.dg else self.cin
         lay = lib().iunet_conv3_pick_layout(nd, N, D, H, W, in_ch, self.out_ch)
-        # the fused sums exist in layout 2 only: a launch that asks for them elsewhere (2-D, more than 64 input channels) runs plain,
-        # so it may as well run on the compact operator
+        # the fused sums exist where layout 2 is the grid's choice (and, in 2-D, on the compact operator of those launches): a launch that
+        # asks for them elsewhere (2-D, more than 64 input channels) runs plain, so it may as well run on the compact operator
         bw = bool(bw) and lay == 2
         if 3 in self.buf and lib().iunet_conv3_compact_ok(nd, N, D, H, W, in_ch, self.out_ch, int(bool(act)), int(bw)):
             return 3, self.buf[3]

@@ -452,11 +452,12 @@ class TrainEngine:
                         N, d[0], d[1], d[2], ci, co, s)
             _, pkd = self.pk[name]
             lay, wd = pkd.pick(self.dim, N, *d, bw=feeds is not None and self.fuse_bw)
-            if feeds is not None and lay == 2 and self.fuse_bw:
-                nv.call('iunet_conv3_dgrad_bnstats', self.dt, self.dim, self._P(dy), co * v, dx_ptr, dx_ss, nv.ptr(wd),
+            # (pick keeps the request for the fused sums only where the launch has them: layout 2, or the compact operator in 2-D up to 64 channels)
+            if feeds is not None and self.fuse_bw and (lay == 2 or (lay == 3 and nv.lib().iunet_conv3_compact_ok(self.dim, N, d[0], d[1], d[2], co, ci, 0, 1))):
+                nv.call('iunet_conv3_dgrad_bnstats_lay', self.dt, self.dim, self._P(dy), co * v, dx_ptr, dx_ss, nv.ptr(wd),
                         nv.ptr(ws['stats']), self._P(ws['y.' + feeds]), ci * v, nv.ptr(ws['mean.' + feeds]),
                         nv.ptr(ws['invstd.' + feeds]), nv.ptr(ws['scale.' + feeds]), nv.ptr(ws['shift.' + feeds]),
-                        N, d[0], d[1], d[2], co, ci, s)
+                        N, d[0], d[1], d[2], co, ci, lay, s)
                 self._bw_ready[feeds] = nv.lib().iunet_conv3_stats_parts(self.dim, N, d[0], d[1], d[2], ci, 2)
             else:
                 nv.call('iunet_conv3_fwd', self.dt, self.dim, self._P(dy), co * v, dx_ptr, dx_ss, nv.ptr(wd), None, None,

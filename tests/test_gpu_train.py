@@ -461,6 +461,53 @@ def test_conv3_fwd_and_wgrad_with_fused_input_activation(nv, nd, cin, big, lay):
     assert torch.equal(dws[0], dws[1])
 
 
+@pytest.mark.parametrize('nd,cin,lay', [(3, 32, 2), (3, 64, 2), (2, 32, 2), (2, 64, 2), (2, 32, 3), (2, 64, 3)])
+def test_dgrad_with_fused_batchnorm_backward_sums(nv, nd, cin, lay):
+    """iunet_conv3_dgrad_bnstats_lay: the data-gradient launch whose epilogue also accumulates the BatchNorm-backward sums of the layer its
+    output flows into (sum dz', sum dz' xhat with dz' = dz where relu(bn(yp)) > 0, on the STORED dz) -- dz equals the plain launch on the
+    same layout bit for bit, the sums equal a float64 reduction of the stored tensors.  Layout 3 in 2-D = the cross-pair step with
+    resident weights (the training step's level-0 / level-1 data gradients)."""
+    g = torch.Generator().manual_seed(33)
+    T, dt = torch.bfloat16, 1
+    N, cout = 2, 32
+    shape = (6, 12, 20) if nd == 3 else (40, 72)
+    D, H, W = shape if nd == 3 else (1,) + shape
+    taps, vox = 3 ** nd, D * H * W
+    if lay == 3 and (os.environ.get('IUNET_NO_COMPACT2D') or os.environ.get('IUNET_NO_COMPACT2D_BW')):
+        pytest.skip('A/B switch: no fused sums on layout 3')
+    assert nv.lib().iunet_conv3_compact_ok(nd, N, D, H, W, cin, cout, 0, 1) == int(nd == 2)
+    assert nv.lib().iunet_conv3_compact_ok(2, N, 1, H, W, 128, cout, 0, 1) == 0          # beyond 64 channels: the plain compact launch
+    dy = torch.randn((N, cin) + shape, generator=g)
+    yp = torch.randn((N, cout) + shape, generator=g)
+    w = (torch.randn((cout, cin) + (3,) * nd, generator=g) * 0.05).cuda()
+    mean, invstd = (0.2 * torch.randn(cout, generator=g)).cuda(), (0.5 + torch.rand(cout, generator=g)).cuda()
+    scale, shift = (0.5 + torch.rand(cout, generator=g)).cuda(), (0.3 * torch.randn(cout, generator=g)).cuda()
+    dyb, ypb = blocked(dy, T).cuda(), blocked(yp, T).cuda()
+    s = nv.stream()
+    pm = 6 if lay == 3 else 2
+    wpk = torch.empty(nv.pack_conv3_elems(cout, cin, taps, pm), dtype=T, device='cuda')
+    nv.call('iunet_pack_conv3', dt, nv.ptr(w), None, nv.ptr(wpk), cout, cin, taps, pm, s)
+    nt = nv.lib().iunet_conv3_stats_parts(nd, N, D, H, W, cout, 2)
+    dz = [torch.full((N * cout * vox,), float('nan'), dtype=T, device='cuda') for _ in range(2)]
+    st = torch.full((nt * cout * 2,), float('nan'), device='cuda')
+    nv.call('iunet_conv3_fwd', dt, nd, nv.ptr(dyb), cin * vox, nv.ptr(dz[0]), cout * vox, nv.ptr(wpk), None, None, N, D, H, W, cin, cout, 0, lay, s)
+    nv.call('iunet_conv3_dgrad_bnstats_lay', dt, nd, nv.ptr(dyb), cin * vox, nv.ptr(dz[1]), cout * vox, nv.ptr(wpk), nv.ptr(st),
+            nv.ptr(ypb), cout * vox, nv.ptr(mean), nv.ptr(invstd), nv.ptr(scale), nv.ptr(shift), N, D, H, W, cin, cout, lay, s)
+    torch.cuda.synchronize()
+    assert torch.equal(dz[0].view(torch.int16), dz[1].view(torch.int16))
+    got = st.view(nt, cout, 2).double().sum(0).cpu()
+    dzf = unblocked(dz[1].cpu(), N, cout, shape).double()
+    ypf = yp.to(T).double()
+    bc = lambda v: v.cpu().double().view(1, cout, *([1] * nd))
+    zz = (bc(scale) * ypf + bc(shift)).float().to(T).float()                       # the stored activation of the producer layer
+    d = torch.where(zz > 0, dzf, torch.zeros_like(dzf))
+    red = tuple(i for i in range(nd + 2) if i != 1)
+    want = torch.stack([d.sum(red), (d * (ypf - bc(mean)) * bc(invstd)).sum(red)], 1)
+    size = torch.stack([d.abs().sum(red), (d * (ypf - bc(mean)) * bc(invstd)).abs().sum(red)], 1)
+    assert ((got - want).abs() <= 2e-5 * size + 1e-6).all(), ((got - want).abs() / size).max().item()
+    assert (zz > 0).double().mean() > 0.2 and (zz > 0).double().mean() < 0.8
+
+
 @pytest.mark.parametrize('nd', [2, 3])
 def test_bn_relu_pool_fwd_equals_two_passes(nv, nd):
     """iunet_bn_relu_pool_fwd == iunet_bn_relu_fwd followed by iunet_maxpool_fwd, bit for bit (both outputs)."""
