@@ -422,45 +422,45 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
 // The slab rows of a channel are summed by the whole block (double, fixed order: per-thread strided partials, wave shuffles, four wave
 // partials) -- [r4] the first version gave every channel ONE thread of ONE block that walked its 1 024 rows per sample alone: 209 us per
 // launch on average, 2.9 ms of the 10.8 ms C3 step with GroupNorm.
-__global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* __restrict__ slab, int chunks, int C, int groups, int N,
+__global__ __launch_bounds__(1024) void gn_bwd_finalize_kernel(const float* __restrict__ slab, int chunks, int C, int groups, int N,
                                                              double vox, const float* __restrict__ gamma,
                                                              const float* __restrict__ invstd, float* dgamma, float* dbeta,
                                                              float* coef) {
+  // [r5] one WAVE per (sample, channel) row sum -- lane-strided partials, one shuffle tree, no block barrier inside -- and a batch of
+  // the group's N x cpg sums in flight over the block's sixteen waves; one barrier before the batch's per-sample coefficients.  (The block-wide sum per
+  // (sample, channel) with two barriers each took 19.7 us per launch, 14 launches per C3 step.)
   const int g = blockIdx.x, cpg = C / groups, t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  __shared__ double sums[2][1024], acc[2][1024], wred[2][4];
-  for (int k = t; k < cpg; k += 256) { acc[0][k] = 0.0; acc[1][k] = 0.0; }
-  for (int n = 0; n < N; ++n) {
-    for (int k = 0; k < cpg; ++k) {
-      const int c = g * cpg + k;
+  __shared__ double sums[2048][2];                          // [sample of the batch][channel of the group]: NB x cpg rows at a time
+  const int NB = max(1, 2048 / cpg);                        // (cpg <= 1024: iunet_gn_relu_bwd checks C <= 1024)
+  const double M = vox * cpg;
+  double acc_a = 0.0, acc_b = 0.0;                          // dbeta / dgamma of channel t (cpg <= 1024 threads): samples added in order
+  for (int n0 = 0; n0 < N; n0 += NB) {
+    const int nb = min(NB, N - n0);
+    for (int i = wave; i < nb * cpg; i += 16) {
+      const int n = n0 + i / cpg, c = g * cpg + i % cpg;
       double a = 0.0, b = 0.0;
-      for (int ch = t; ch < chunks; ch += 256) {
-        const float* p = slab + (((long long)n * chunks + ch) * C + c) * 2;
-        a += (double)p[0]; b += (double)p[1];
+      for (int ch = lane; ch < chunks; ch += 64) {
+        const float2 v = *(const float2*)(slab + (((long long)n * chunks + ch) * C + c) * 2);
+        a += (double)v.x; b += (double)v.y;
       }
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
-      if (lane == 0) { wred[0][wave] = a; wred[1][wave] = b; }
-      __syncthreads();
-      if (t == 0) {
-        sums[0][k] = (wred[0][0] + wred[0][1]) + (wred[0][2] + wred[0][3]);
-        sums[1][k] = (wred[1][0] + wred[1][1]) + (wred[1][2] + wred[1][3]);
-      }
-      __syncthreads();
+      if (lane == 0) { sums[i][0] = a; sums[i][1] = b; }
     }
-    double m1 = 0.0, m2 = 0.0;
-    for (int k = 0; k < cpg; ++k) { const double gk = (double)gamma[g * cpg + k]; m1 += gk * sums[0][k]; m2 += gk * sums[1][k]; }
-    const double M = vox * cpg;
-    for (int k = t; k < cpg; k += 256) {
-      const int c = g * cpg + k;
-      acc[0][k] += sums[0][k]; acc[1][k] += sums[1][k];
+    __syncthreads();
+    for (int i = t; i < nb * cpg; i += 1024) {
+      const int nl = i / cpg, n = n0 + nl, c = g * cpg + i % cpg;
+      double m1 = 0.0, m2 = 0.0;
+      for (int k = 0; k < cpg; ++k) { const double gk = (double)gamma[g * cpg + k]; m1 += gk * sums[nl * cpg + k][0]; m2 += gk * sums[nl * cpg + k][1]; }
       const float is = invstd[n * C + c];
       coef[((long long)n * C + c) * 3 + 0] = gamma[c] * is;
       coef[((long long)n * C + c) * 3 + 1] = is * (float)(m1 / M);
       coef[((long long)n * C + c) * 3 + 2] = is * (float)(m2 / M);
     }
-    __syncthreads();                           // sums is rewritten for the next sample
+    if (t < cpg) for (int nl = 0; nl < nb; ++nl) { acc_a += sums[nl * cpg + t][0]; acc_b += sums[nl * cpg + t][1]; }
+    __syncthreads();                                        // sums is rewritten for the next batch of samples
   }
-  for (int k = t; k < cpg; k += 256) { dbeta[g * cpg + k] = (float)acc[0][k]; dgamma[g * cpg + k] = (float)acc[1][k]; }
+  if (t < cpg) { dbeta[g * cpg + t] = (float)acc_a; dgamma[g * cpg + t] = (float)acc_b; }
 }
 
 // ------------------------------------------------------------------ max-pool backward (+ skip gradient)
@@ -1196,7 +1196,7 @@ int iunet_gn_relu_bwd(int dtype, const void* dz, long long dz_ss, const void* y,
   const float *mu = (const float*)mean, *is = (const float*)invstd, *sc = (const float*)scale, *sh = (const float*)shift;
   if (dtype == 0) hipLaunchKernelGGL(bn_bwd_reduce_kernel<f16>, g1, dim3(256), 0, (hipStream_t)stream, (const f16*)dz, dz_ss, (const f16*)nullptr, 0LL, (const f16*)y, y_ss, mu, is, sc, sh, C, vox, per_block, (float*)slab, C);
   else hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16>, g1, dim3(256), 0, (hipStream_t)stream, (const bf16*)dz, dz_ss, (const bf16*)nullptr, 0LL, (const bf16*)y, y_ss, mu, is, sc, sh, C, vox, per_block, (float*)slab, C);
-  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(groups), dim3(256), 0, (hipStream_t)stream, (const float*)slab, chunks, C, groups, N,
+  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(groups), dim3(1024), 0, (hipStream_t)stream, (const float*)slab, chunks, C, groups, N,
                      (double)vox, (const float*)gamma, (const float*)invstd, (float*)dgamma, (float*)dbeta, (float*)coef);
   const float* cf = (const float*)coef;
   if (dtype == 0) hipLaunchKernelGGL((bn_bwd_apply_kernel<f16, true>), g2, dim3(256), 0, (hipStream_t)stream, (const f16*)dz, dz_ss, (const f16*)nullptr, 0LL, (const f16*)y, y_ss, (f16*)dy, dy_ss, mu, is, cf, sc, sh, C / 8, vox, C);
@@ -1252,7 +1252,7 @@ int iunet_gn_relu_pool_bwd(int dtype, int nd, const void* dskip, long long ds_ss
     (const float*)coef, (const float*)scale, (const float*)shift, C, Do, Ho, Wo, PB, (float*)slab, C)
   if (dtype == 0) { if (nd == 3) GPB(f16, 3, 1, g1, per_block); else GPB(f16, 2, 1, g1, per_block); }
   else { if (nd == 3) GPB(bf16, 3, 1, g1, per_block); else GPB(bf16, 2, 1, g1, per_block); }
-  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(groups), dim3(256), 0, (hipStream_t)stream, (const float*)slab, chunks, C, groups, N,
+  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(groups), dim3(1024), 0, (hipStream_t)stream, (const float*)slab, chunks, C, groups, N,
                      (double)vox, (const float*)gamma, (const float*)invstd, (float*)dgamma, (float*)dbeta, (float*)coef);
   if (dtype == 0) { if (nd == 3) GPB(f16, 3, 2, g2, 256); else GPB(f16, 2, 2, g2, 256); }
   else { if (nd == 3) GPB(bf16, 3, 2, g2, 256); else GPB(bf16, 2, 2, g2, 256); }
