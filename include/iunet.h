@@ -517,6 +517,20 @@ int iunet_gn_relu_bwd(int dtype, const void* dz, long long dz_ss, const void* y,
 int iunet_gn_relu_pool_fwd(int dtype, int nd, const void* y, long long y_ss, void* z, long long z_ss, void* pooled, long long p_ss,
                            const void* gamma, const void* beta, int groups, float eps, void* slab, void* scale, void* shift, void* mean,
                            void* invstd, int C, int N, int Do, int Ho, int Wo, void* stream);
+/* GroupNorm training without the statistics pass: the conv that produces y writes per-SAMPLE partial sums from its epilogue.
+ * iunet_conv3_sample_stats_rows: rows per sample of such a launch on this grid and layout (2 or 3), 0 = not available (layouts 0 / 1,
+ * fewer than 8 bricks per sample): run iunet_gn_relu_fwd.  iunet_conv3_fwd_sample_stats = iunet_conv3_fwd (epi 0, no bias) + stats
+ * [N][rows][Cout][2] = (sum, sum of squares) of the fp32 accumulators; its brick schedule is one sample's, walked once per sample.
+ * iunet_gn_relu_fwd_rows / _pool_fwd_rows: iunet_gn_relu_fwd / _pool_fwd on that slab (rows > 0; rows = 0: their own statistics pass). */
+int iunet_conv3_sample_stats_rows(int dtype, int nd, int N, int D, int H, int W, int Cin, int Cout, int layout);
+int iunet_conv3_fwd_sample_stats(int dtype, int nd, const void* x, long long x_sstride, void* y, long long y_sstride, const void* wpk,
+                                 void* stats, int N, int D, int H, int W, int Cin, int Cout, int layout, void* stream);
+int iunet_gn_relu_fwd_rows(int dtype, const void* y, long long y_ss, void* z, long long z_ss, const void* gamma, const void* beta,
+                           int groups, float eps, void* slab, int rows, void* scale, void* shift, void* mean, void* invstd, int C, int N,
+                           long long vox, void* stream);
+int iunet_gn_relu_pool_fwd_rows(int dtype, int nd, const void* y, long long y_ss, void* z, long long z_ss, void* pooled, long long p_ss,
+                                const void* gamma, const void* beta, int groups, float eps, void* slab, int rows, void* scale, void* shift,
+                                void* mean, void* invstd, int C, int N, int Do, int Ho, int Wo, void* stream);
 int iunet_gn_relu_pool_bwd(int dtype, int nd, const void* dskip, long long ds_ss, const void* dpool, long long dp_ss, const void* y,
                            long long y_ss, void* dy, long long dy_ss, const void* gamma, int groups, const void* scale, const void* shift,
                            const void* mean, const void* invstd, void* dgamma, void* dbeta, void* slab, void* coef, int C, int N, int Do,

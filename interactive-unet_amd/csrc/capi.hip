@@ -21,6 +21,10 @@ int iunet_conv3_launch(int dtype, int nd, const void* x, long long x_sstride, vo
                        const float* in_shift = nullptr, const void* bw_y = nullptr, long long bw_y_ss = 0,
                        const float* const* bw_par = nullptr);
 int iunet_conv3_pick(int nd, int N, int D, int H, int W, int Cin, int Cout);
+int iunet_conv3_v4_launch(int dtype, int nd, const void* x, long long x_sstride, void* y, long long y_sstride, const void* wpk,
+                          const float* bias, float* stats, int N, int D, int H, int W, int Cin, int Cout, int epi,
+                          const float* in_scale, const float* in_shift, hipStream_t stream, const void* bw_y, long long bw_y_ss,
+                          const float* const* bw_par, int compact, int per_sample, int* query_rows);
 int iunet_conv3_v4_stats_parts(int nd, int Cout);
 int iunet_conv3_v4_pairs(int nd, int N, int D, int H, int W, int Cin, int Cout, int bw);
 int iunet_conv3_tiles(int nd, int N, int D, int H, int W);
@@ -160,6 +164,33 @@ int iunet_conv3_fwd_act(int dtype, int nd, const void* x, long long x_sstride, v
   IUNET_REQUIRE(layout == 2 || layout == 3, "conv3_act: the fused input activation exists in layouts 2 and 3 only (got %d)", layout);
   return iunet_conv3_launch(dtype, nd, x, x_sstride, y, y_sstride, wpk, (const float*)bias, (float*)stats, N, D, H, W,
                             Cin, Cout, epi, layout, (hipStream_t)stream, (const float*)in_scale, (const float*)in_shift);
+}
+
+// GroupNorm: the conv's statistics epilogue per SAMPLE.  iunet_conv3_sample_stats_rows: rows per sample that
+// iunet_conv3_fwd_sample_stats writes on this grid and layout (2 or 3), or 0 when the launch has no per-sample form (layouts 0 / 1; a
+// grid with fewer than 8 bricks per sample: the caller runs its own statistics pass, iunet_gn_relu_fwd).  iunet_conv3_fwd_sample_stats =
+// iunet_conv3_fwd (epi 0, no bias) writing stats [N][rows][Cout][2] = (sum, sum of squares) of the fp32 accumulators: the slab of
+// iunet_gn_relu_fwd_rows / iunet_gn_relu_pool_fwd_rows.  The brick schedule is one sample's, walked once per sample.
+int iunet_conv3_sample_stats_rows(int dtype, int nd, int N, int D, int H, int W, int Cin, int Cout, int layout) {
+  DT_OK(dtype);
+  if (layout < 2 || (nd != 2 && nd != 3) || N < 1 || D < 1 || H < 1 || W < 1 || Cin < 32 || Cout < 32 || Cin % 32 || Cout % 32) return 0;
+  if (layout == 3 && !iunet_conv3_compact_ok(nd, N, D, H, W, Cin, Cout, 0, 0)) return 0;
+  int rows = 0;
+  if (iunet_conv3_v4_launch(dtype, nd, nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, N, D, H, W, Cin, Cout, 0, nullptr, nullptr, nullptr,
+                            nullptr, 0, nullptr, layout == 3, 1, &rows) != IUNET_OK) return 0;
+  return rows;
+}
+
+int iunet_conv3_fwd_sample_stats(int dtype, int nd, const void* x, long long x_sstride, void* y, long long y_sstride, const void* wpk,
+                                 void* stats, int N, int D, int H, int W, int Cin, int Cout, int layout, void* stream) {
+  DT_OK(dtype);
+  IUNET_REQUIRE(x && y && wpk && stats, "conv3_fwd_sample_stats: null pointer");
+  IUNET_REQUIRE_GRID("conv3_fwd_sample_stats", N, D, H, W);
+  IUNET_REQUIRE(layout == 2 || layout == 3, "conv3_fwd_sample_stats: layout 2 or 3 (got %d)", layout);
+  IUNET_REQUIRE(nd == 2 || nd == 3, "conv3: nd must be 2 or 3 (got %d)", nd);
+  IUNET_REQUIRE(nd == 3 || D == 1, "conv3: 2-D conv needs D == 1");
+  return iunet_conv3_v4_launch(dtype, nd, x, x_sstride, y, y_sstride, wpk, nullptr, (float*)stats, N, D, H, W, Cin, Cout, 0, nullptr, nullptr,
+                               (hipStream_t)stream, nullptr, 0, nullptr, layout == 3, 1, nullptr);
 }
 
 // iunet_conv3_fwd used as the data gradient of a conv whose INPUT was z = relu(bn(yp)): besides dz (its output) it accumulates

@@ -358,7 +358,8 @@ int iunet_conv3_v2_launch(int dtype, int nd, const void* x, long long x_sstride,
 int iunet_conv3_v4_launch(int dtype, int nd, const void* x, long long x_sstride, void* y, long long y_sstride, const void* wpk,
                           const float* bias, float* stats, int N, int D, int H, int W, int Cin, int Cout, int epi,
                           const float* in_scale, const float* in_shift, hipStream_t stream, const void* bw_y = nullptr,
-                          long long bw_y_ss = 0, const float* const* bw_par = nullptr, int compact = 0);
+                          long long bw_y_ss = 0, const float* const* bw_par = nullptr, int compact = 0, int per_sample = 0,
+                          int* query_rows = nullptr);
 
 // Host entry used by the net runtime and the per-kernel C ABI.
 int iunet_conv3_launch(int dtype, int nd, const void* x, long long x_sstride, void* y, long long y_sstride,

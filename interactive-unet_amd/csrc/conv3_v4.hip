@@ -95,6 +95,11 @@ struct ConvV4Params {
   int split_nc, x_lo, y_lo;
   const float* oscale;                        // [Cout]: power-of-two factor on the accumulator (operator and activation scales)
   int* sat;                                   // SPL: optional range flag (common.h: x2_note_saturation)
+  // GroupNorm: statistics per SAMPLE.  per_sample != 0 (host only): the launch is ONE sample's (N = 1 in the kernel's eyes) with the
+  // samples along gridDim.z -- workgroup (x, y, z) walks sample z and writes statistics row z * gridDim.x + x: stats [N][gridDim.x][Cout][2],
+  // the slab layout of gn_finalize_kernel.  The workgroups of sample z + 1 start as those of sample z retire (one workgroup per CU).
+  int per_sample;
+  int* query_rows;                            // host only: not null = no launch, *query_rows = rows per sample of a per_sample launch (0: not available on this grid)
 };
 
 // BW: the data-gradient variant that also accumulates the BatchNorm-backward sums of the layer its output flows into (bw_y); a
@@ -174,7 +179,7 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + v4_loader_threads(ND
   auto tile_of = [&](int s) -> int { return PAIR ? 2 * (s / (2 * nchunk)) + (s & 1) : s / nchunk; };
   auto chunk_of = [&](int s) -> int { return PAIR ? (s - (s / (2 * nchunk)) * 2 * nchunk) >> 1 : s - (s / nchunk) * nchunk; };
   if (nsteps <= 0) {                                   // no tile for this workgroup: its statistics row is zero
-    if (p.stats != nullptr && tid < 64) p.stats[((long long)blockIdx.x * p.Cout + cob * 32 + (tid >> 1)) * 2 + (tid & 1)] = 0.f;
+    if (p.stats != nullptr && tid < 64) p.stats[((long long)(blockIdx.z * gridDim.x + blockIdx.x) * p.Cout + cob * 32 + (tid >> 1)) * 2 + (tid & 1)] = 0.f;
     return;
   }
   const long long plane_stride = (long long)p.D * p.H * p.W * 8;
@@ -209,7 +214,7 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + v4_loader_threads(ND
     int b = b_begin + k;
     const int Bx = b % p.nbx; b /= p.nbx;
     const int By = b % p.nby; b /= p.nby;
-    const int Bz = b % p.nbz; n_img = b / p.nbz;
+    const int Bz = b % p.nbz; n_img = b / p.nbz + blockIdx.z;      // (gridDim.z > 1: a per-sample launch, N = 1 per z)
     const int tz = Bz * p.bz + sz, ty = By * p.by + sy, tx = Bx * p.bx + sx;
     z0 = tz * TZ; y0 = ty * TY; x0 = tx * TX;
     return tz < p.tilesZ && ty < p.tilesY && tx < p.tilesX;
@@ -806,7 +811,7 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + v4_loader_threads(ND
       float sum = 0.f;
 #pragma unroll
       for (int w = 0; w < NCW; ++w) sum += red[(w * 4 + (c >> 3)) * 16 + which * 8 + (c & 7)];
-      p.stats[((long long)blockIdx.x * p.Cout + cob * 32 + c) * 2 + which] = sum;
+      p.stats[((long long)(blockIdx.z * gridDim.x + blockIdx.x) * p.Cout + cob * 32 + c) * 2 + which] = sum;
     }
   }
 }
@@ -829,21 +834,28 @@ int launch_v4(ConvV4Params p, hipStream_t stream) {
   p.nbz = (p.tilesZ + p.bz - 1) / p.bz; p.nby = (p.tilesY + p.by - 1) / p.by; p.nbx = (p.tilesX + p.bx - 1) / p.bx;
   // slot groups: the brick table's slot count over this (possibly clamped) brick's, while every group still gets a brick per XCD
   int groups = 1;
+  const int nz = p.per_sample ? p.N : 1;                 // per-sample statistics: one sample per grid z, N = 1 inside
+  if (p.per_sample) p.N = 1;
+  const long long nbricks = (long long)p.N * p.nbz * p.nby * p.nbx;
   if (!PAIR) {
-    const long long nbricks = (long long)p.N * p.nbz * p.nby * p.nbx;
     groups = iunet_conv3_v4_stats_parts(ND, p.Cout) / 8 / (p.bz * p.by * p.bx);
     while (groups > 1 && nbricks / 8 < groups) groups >>= 1;
     if (groups < 1) groups = 1;
   }
   const int gx = 8 * p.bz * p.by * p.bx * groups;
-  if (p.stats != nullptr) {
+  if (p.query_rows != nullptr) {      // per-sample statistics need every XCD to hold a brick of every sample (else the launch would idle CUs: the caller's own pass is cheaper)
+    *p.query_rows = (!PAIR && !BW && !SPL && nbricks >= 8) ? gx : 0;
+    return IUNET_OK;
+  }
+  IUNET_REQUIRE(!p.per_sample || (!PAIR && !BW && !SPL && nbricks >= 8 && p.stats != nullptr), "conv3 layout 2 / 3: per-sample statistics are not available for this launch (iunet_conv3_sample_stats_rows says 0)");
+  if (p.stats != nullptr && !p.per_sample) {
     // the caller reduces iunet_conv3_v4_stats_parts rows (the brick table's slot count); a brick clamped to a small tile grid
     // launches fewer workgroups: the rows nobody writes are zeroed
     const int rows = iunet_conv3_v4_stats_parts(ND, p.Cout);
     if (gx < rows)
       IUNET_CHECK_HIP(hipMemsetAsync(p.stats + (long long)gx * p.Cout * 2, 0, (size_t)(rows - gx) * p.Cout * 2 * sizeof(float), stream));
   }
-  hipLaunchKernelGGL((conv3_v4_kernel<T, ND, WS, SMALL, BW, PAIR, NP, SPL>), dim3(gx, ncob), dim3(TL::NCW * 64 + v4_loader_threads(ND, WS, PAIR, SPL, BW, NP)), lds, stream, p);
+  hipLaunchKernelGGL((conv3_v4_kernel<T, ND, WS, SMALL, BW, PAIR, NP, SPL>), dim3(gx, ncob, nz), dim3(TL::NCW * 64 + v4_loader_threads(ND, WS, PAIR, SPL, BW, NP)), lds, stream, p);
   IUNET_CHECK_HIP(hipGetLastError());
   return IUNET_OK;
 }
@@ -873,7 +885,7 @@ int iunet_conv3_v4_pairs(int nd, int N, int D, int H, int W, int Cin, int Cout, 
 int iunet_conv3_v4_launch(int dtype, int nd, const void* x, long long x_sstride, void* y, long long y_sstride, const void* wpk,
                           const float* bias, float* stats, int N, int D, int H, int W, int Cin, int Cout, int epi,
                           const float* in_scale, const float* in_shift, hipStream_t stream, const void* bw_y, long long bw_y_ss,
-                          const float* const* bw_par, int compact) {
+                          const float* const* bw_par, int compact, int per_sample, int* query_rows) {
   IUNET_REQUIRE(Cin % 32 == 0 && Cout % 32 == 0, "conv3 layout 2: Cin %% 32, Cout %% 32 (got %d -> %d)", Cin, Cout);
   ConvV4Params p;
   p.x = x; p.x_sstride = x_sstride; p.y = y; p.y_sstride = y_sstride; p.wpk = wpk; p.bias = bias; p.stats = stats;
@@ -886,6 +898,7 @@ int iunet_conv3_v4_launch(int dtype, int nd, const void* x, long long x_sstride,
   p.tilesZ = p.tilesY = p.tilesX = 0;
   p.bz = p.by = p.bx = p.nbz = p.nby = p.nbx = 0;
   p.split_nc = 0; p.x_lo = p.y_lo = 0; p.oscale = nullptr; p.sat = nullptr;
+  p.per_sample = per_sample; p.query_rows = query_rows;
 #ifdef IUNET_ABLATE      // result-destroying profiling switches exist in diagnostic builds only (tools/ab_build.sh <file> -DIUNET_ABLATE): ADVICE r3
   static const int dbg = getenv("IUNET_V4_DBG") ? atoi(getenv("IUNET_V4_DBG")) : 0;
 #else
@@ -896,7 +909,7 @@ int iunet_conv3_v4_launch(int dtype, int nd, const void* x, long long x_sstride,
   const bool ws = nd == 3 ? Cin <= 32 : Cin <= 64;
   // 3-D launches whose 4 x 8 x 16 tiles would occupy fewer than half of the CUs run on the half-size tile (measured on the
   // 16^3 level: 1.4-1.6x faster there; at 128 of 256 CUs the doubled weight streaming costs more than the idle CUs)
-  const long long big_tiles = (long long)N * ((D + 3) / 4) * ((H + 7) / 8) * ((W + 15) / 16);
+  const long long big_tiles = (long long)(per_sample ? 1 : N) * ((D + 3) / 4) * ((H + 7) / 8) * ((W + 15) / 16);      // (per-sample statistics: the launch is one sample's grid, N times)
   const bool small = nd == 3 && !ws && big_tiles * (Cout / 32) < 128;
   if (compact) {      // layout 3: the compact operator, padding-free step (streamed weights, big tiles, no fused BatchNorm-backward sums so far)
     // (every grid size: a layer must not change its summation order with the number of blocks in a launch -- the sharded prediction
@@ -914,7 +927,7 @@ int iunet_conv3_v4_launch(int dtype, int nd, const void* x, long long x_sstride,
     if (small) return dtype == 0 ? launch_v4<f16, 3, false, true, false, false, true>(p, stream) : launch_v4<bf16, 3, false, true, false, false, true>(p, stream);
     return dtype == 0 ? launch_v4<f16, 3, false, false, false, false, true>(p, stream) : launch_v4<bf16, 3, false, false, false, false, true>(p, stream);
   }
-  const bool pair = iunet_conv3_v4_pairs(nd, N, D, H, W, Cin, Cout, bw_y != nullptr) != 0;
+  const bool pair = !per_sample && iunet_conv3_v4_pairs(nd, N, D, H, W, Cin, Cout, bw_y != nullptr) != 0;
   if (pair) return dtype == 0 ? launch_v4<f16, 3, false, false, false, true>(p, stream) : launch_v4<bf16, 3, false, false, false, true>(p, stream);
 #define V4_GO(TT, BWV) (nd == 3 ? (ws ? launch_v4<TT, 3, true, false, BWV>(p, stream)                                          \
                                       : (small ? launch_v4<TT, 3, false, true, BWV>(p, stream) : launch_v4<TT, 3, false, false, BWV>(p, stream))) \
@@ -947,6 +960,7 @@ int iunet_conv3_v4_x2_launch(int nd, const void* x, long long x_sstride, int x_l
   p.bz = p.by = p.bx = p.nbz = p.nby = p.nbx = 0;
   p.dbg = 0;
   p.split_nc = Cin / (nd == 3 ? 16 : 32); p.x_lo = x_lo; p.y_lo = y_lo; p.oscale = oscale; p.sat = sat;
+  p.per_sample = 0; p.query_rows = nullptr;
   if (nd == 2) {
     // the cross-pair step (NP2, the compact operator of pack mode 6) for every 2-D launch: one summation order per layer whatever the grid
     if (iunet_conv3_v4_x2_pack_mode(2) == 6) return launch_v4<f16, 2, false, false, false, false, true, true>(p, stream);

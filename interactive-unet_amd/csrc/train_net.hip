@@ -68,6 +68,12 @@ int iunet_first_conv_wgrad_blocks(int, int, int, int, int);
 int iunet_first_conv_wgrad_bn(int, int, const void*, int, const long long*, const void*, long long, const void*, long long, const void*,
                               const void*, const void*, const void*, const void*, void*, void*, int, int, int, int, int, int, void*);
 int iunet_adamw_step_dev(void*, const void*, void*, void*, long long, float, float, float, float, float, void*, int, float, void*);
+int iunet_conv3_sample_stats_rows(int, int, int, int, int, int, int, int, int);
+int iunet_conv3_fwd_sample_stats(int, int, const void*, long long, void*, long long, const void*, void*, int, int, int, int, int, int, int, void*);
+int iunet_gn_relu_fwd_rows(int, const void*, long long, void*, long long, const void*, const void*, int, float, void*, int, void*, void*, void*, void*, int, int,
+                           long long, void*);
+int iunet_gn_relu_pool_fwd_rows(int, int, const void*, long long, void*, long long, void*, long long, const void*, const void*, int, float, void*, int, void*,
+                                void*, void*, void*, int, int, int, int, int, void*);
 int iunet_gn_relu_fwd(int, const void*, long long, void*, long long, const void*, const void*, int, float, void*, void*, void*, void*, void*, int, int,
                       long long, void*);
 int iunet_gn_relu_pool_fwd(int, int, const void*, long long, void*, long long, void*, long long, const void*, const void*, int, float, void*, void*,
@@ -115,7 +121,7 @@ struct iunet_train {
   int norm = 0, groups = 8;                      // norm 1: GroupNorm(groups) after every stage conv (statistics per (sample, group), nothing fused into the convs)
   int dim, levels, base, cin, ncls, dtype, kind;
   int taps, npos;
-  bool fuse_act, fuse_bw, head_act;
+  bool fuse_act, fuse_bw, head_act, gn_conv_stats;
   std::vector<int> ch;
   std::vector<TParam> params;
   long long nparams = 0;
@@ -184,6 +190,9 @@ TWs ws_layout(const iunet_train* n, int N, int D, int H, int W) {
     } else {
       const long long p0 = iunet_conv3_stats_parts(dim, N, d, h, w, c.co, 0), p2 = iunet_conv3_stats_parts(dim, N, d, h, w, c.co, 2);
       max_stats = std::max(max_stats, std::max(p0, p2) * c.co * 2);
+      if (n->norm == 1)       // per-sample rows of the conv epilogue (layouts 2 and 3 share the grid)
+        for (int lay = 2; lay <= 3; ++lay)
+          max_stats = std::max(max_stats, (long long)N * iunet_conv3_sample_stats_rows(n->dtype, dim, N, d, h, w, c.ci, c.co, lay) * c.co * 2);
       max_wslab = std::max(max_wslab, iunet_conv3_wgrad_slab_floats(dim, N, d, h, w, c.ci, c.co));
     }
     max_bn = std::max(max_bn, (long long)iunet_bn_bwd_num_parts(N, v) * c.co * 2);
@@ -249,6 +258,7 @@ int iunet_train_create_ex(int dim, int levels, int base, int cin, int ncls, int 
   n->fuse_act = norm == 0 && !env_on("IUNET_NO_ACT_FUSION");
   n->fuse_bw = norm == 0 && !env_on("IUNET_NO_BW_FUSION");
   n->head_act = norm == 0 && !env_on("IUNET_NO_HEAD_ACT");
+  n->gn_conv_stats = norm == 1 && !env_on("IUNET_NO_GN_CONV_STATS");      // GroupNorm statistics from the conv epilogue (per sample) where the launch has that form
   for (int l = 0; l < levels; ++l) n->ch.push_back(base << l);
   long long off = 0, pk = 0;
   int nbn = 0;
@@ -415,16 +425,19 @@ int iunet_train_forward_backward_hooks(iunet_train* n, const void* x, int in_dty
     dims(c.l, d, h, w);
     const long long v = vox(c.l);
     void* y = WS + L.y[k];
-    float* stats = n->norm == 1 ? nullptr : F(L.stats);       // GroupNorm takes its statistics in its own pass (per sample)
-    int nparts;
+    float* stats = n->norm == 1 ? nullptr : F(L.stats);       // GroupNorm: per sample -- from the conv's epilogue where the launch has that form (gn_rows > 0), else in its own pass
+    int nparts, gn_rows = 0;
     if (c.first) {
       nparts = iunet_conv3_num_tiles(dim, N, d, h, w);
+      if (n->norm == 1 && n->gn_conv_stats) { stats = F(L.stats); gn_rows = nparts / N; }      // one row per tile, a sample's tiles together: per-sample rows as they are
       rc = iunet_first_conv_fwd(dt, dim, x, in_dtype, in_strides, y, c.co * v, K + c.first_pk, nullptr, stats, N, d, h, w, c.ci, c.co, 0, stream);
     } else {
       long long woff;
       const int lay = pack_pick(c.fwd, dim, N, d, h, w, x_act >= 0, false, &woff);
       nparts = iunet_conv3_stats_parts(dim, N, d, h, w, c.co, lay);
-      if (x_act < 0) rc = iunet_conv3_fwd(dt, dim, xp, x_ss, y, c.co * v, K + woff, nullptr, stats, N, d, h, w, c.ci, c.co, 0, lay, stream);
+      if (n->norm == 1 && x_act < 0 && n->gn_conv_stats) gn_rows = iunet_conv3_sample_stats_rows(dt, dim, N, d, h, w, c.ci, c.co, lay);
+      if (gn_rows > 0) rc = iunet_conv3_fwd_sample_stats(dt, dim, xp, x_ss, y, c.co * v, K + woff, F(L.stats), N, d, h, w, c.ci, c.co, lay, stream);
+      else if (x_act < 0) rc = iunet_conv3_fwd(dt, dim, xp, x_ss, y, c.co * v, K + woff, nullptr, stats, N, d, h, w, c.ci, c.co, 0, lay, stream);
       else rc = iunet_conv3_fwd_act(dt, dim, xp, x_ss, y, c.co * v, K + woff, nullptr, stats, F(L.scale[x_act]), F(L.shift[x_act]), N, d, h, w,
                                     c.ci, c.co, 0, lay, stream);
     }
@@ -433,11 +446,12 @@ int iunet_train_forward_backward_hooks(iunet_train* n, const void* x, int in_dty
       if (pool_p != nullptr) {
         int dn, hn, wn;
         dims(c.l + 1, dn, hn, wn);
-        return iunet_gn_relu_pool_fwd(dt, dim, y, c.co * v, zp, z_ss, pool_p, pool_ss, P + c.gamma, P + c.beta, n->groups, eps, F(L.bnslab), F(L.scale[k]),
-                                      F(L.shift[k]), F(L.mean[k]), F(L.invstd[k]), c.co, N, dn, hn, wn, stream);
+        return iunet_gn_relu_pool_fwd_rows(dt, dim, y, c.co * v, zp, z_ss, pool_p, pool_ss, P + c.gamma, P + c.beta, n->groups, eps,
+                                           gn_rows > 0 ? F(L.stats) : F(L.bnslab), gn_rows, F(L.scale[k]), F(L.shift[k]), F(L.mean[k]), F(L.invstd[k]), c.co, N,
+                                           dn, hn, wn, stream);
       }
-      return iunet_gn_relu_fwd(dt, y, c.co * v, zp, z_ss, P + c.gamma, P + c.beta, n->groups, eps, F(L.bnslab), F(L.scale[k]), F(L.shift[k]),
-                               F(L.mean[k]), F(L.invstd[k]), c.co, N, v, stream);
+      return iunet_gn_relu_fwd_rows(dt, y, c.co * v, zp, z_ss, P + c.gamma, P + c.beta, n->groups, eps, gn_rows > 0 ? F(L.stats) : F(L.bnslab), gn_rows,
+                                    F(L.scale[k]), F(L.shift[k]), F(L.mean[k]), F(L.invstd[k]), c.co, N, v, stream);
     }
     rc = iunet_bn_finalize(stats, nparts, c.co, (double)N * v, P + c.gamma, P + c.beta, n->running[2 * c.bn], n->running[2 * c.bn + 1], momentum, eps,
                            F(L.scale[k]), F(L.shift[k]), F(L.mean[k]), F(L.invstd[k]), stream);

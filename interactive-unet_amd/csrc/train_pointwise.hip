@@ -1145,17 +1145,20 @@ int iunet_gn_num_parts(int N, long long vox) { return iunet_bn_bwd_num_parts(N, 
 
 // z = relu(group_norm(y, groups, gamma, beta, eps)): statistics pass + finalize + one normalise pass per sample.
 // slab: iunet_gn_num_parts(N, vox) * C * 2 floats; scale / shift / mean / invstd: fp32 [N][C] outputs (the backward reads them).
-int iunet_gn_relu_fwd(int dtype, const void* y, long long y_ss, void* z, long long z_ss, const void* gamma, const void* beta,
-                      int groups, float eps, void* slab, void* scale, void* shift, void* mean, void* invstd, int C, int N,
-                      long long vox, void* stream) {
+// rows > 0: `slab` already holds the statistics, [N][rows][C][2] partial sums written by the conv that produced y
+// (iunet_conv3_fwd_sample_stats): no statistics pass.
+int iunet_gn_relu_fwd_rows(int dtype, const void* y, long long y_ss, void* z, long long z_ss, const void* gamma, const void* beta,
+                           int groups, float eps, void* slab, int rows, void* scale, void* shift, void* mean, void* invstd, int C, int N,
+                           long long vox, void* stream) {
   DT_OK(dtype);
   IUNET_REQUIRE(y && z && gamma && beta && slab && scale && shift && mean && invstd, "gn_relu_fwd: null pointer");
-  IUNET_REQUIRE(C > 0 && C % 8 == 0 && N > 0 && vox > 0, "gn_relu_fwd: C %d (multiple of 8), N %d, %lld voxels", C, N, vox);
+  IUNET_REQUIRE(C > 0 && C % 8 == 0 && N > 0 && vox > 0 && rows >= 0, "gn_relu_fwd: C %d (multiple of 8), N %d, %lld voxels, %d rows", C, N, vox, rows);
   IUNET_REQUIRE(groups > 0 && C % groups == 0, "gn_relu_fwd: %d channels do not split into %d groups", C, groups);
   const int per_block = BN_BWD_PER_BLOCK;
-  const int chunks = (int)((vox + per_block - 1) / per_block);
+  const int chunks = rows > 0 ? rows : (int)((vox + per_block - 1) / per_block);
   dim3 g1(chunks, C / 8, N);
-  if (dtype == 0) hipLaunchKernelGGL(gn_stats_kernel<f16>, g1, dim3(256), 0, (hipStream_t)stream, (const f16*)y, y_ss, C, vox, per_block, (float*)slab);
+  if (rows > 0) {}
+  else if (dtype == 0) hipLaunchKernelGGL(gn_stats_kernel<f16>, g1, dim3(256), 0, (hipStream_t)stream, (const f16*)y, y_ss, C, vox, per_block, (float*)slab);
   else hipLaunchKernelGGL(gn_stats_kernel<bf16>, g1, dim3(256), 0, (hipStream_t)stream, (const bf16*)y, y_ss, C, vox, per_block, (float*)slab);
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, N), dim3(256), 0, (hipStream_t)stream, (const float*)slab, chunks, C, groups,
                      (double)vox, (const float*)gamma, (const float*)beta, eps, (float*)scale, (float*)shift, (float*)mean, (float*)invstd);
@@ -1164,6 +1167,12 @@ int iunet_gn_relu_fwd(int dtype, const void* y, long long y_ss, void* z, long lo
   else hipLaunchKernelGGL(bn_relu_fwd_kernel<bf16>, g2, dim3(256), 0, (hipStream_t)stream, (const bf16*)y, y_ss, (bf16*)z, z_ss, (const float*)scale, (const float*)shift, C / 8, vox, C);
   IUNET_CHECK_HIP(hipGetLastError());
   return IUNET_OK;
+}
+
+int iunet_gn_relu_fwd(int dtype, const void* y, long long y_ss, void* z, long long z_ss, const void* gamma, const void* beta,
+                      int groups, float eps, void* slab, void* scale, void* shift, void* mean, void* invstd, int C, int N,
+                      long long vox, void* stream) {
+  return iunet_gn_relu_fwd_rows(dtype, y, y_ss, z, z_ss, gamma, beta, groups, eps, slab, 0, scale, shift, mean, invstd, C, N, vox, stream);
 }
 
 // GroupNorm statistics of ONE sample from the BatchNorm-statistics epilogue of the convolutions (stats = [nparts][C][2] partial sums
@@ -1207,9 +1216,19 @@ int iunet_gn_relu_bwd(int dtype, const void* dz, long long dz_ss, const void* y,
 
 // iunet_gn_relu_fwd whose normalise pass also writes the 2^d max-pool of z (encoder stages: the pool would re-read z right away):
 // statistics pass + finalize + ONE pass that writes z and the pooled tensor ((Do, Ho, Wo) grid, p_ss elements per sample).
+int iunet_gn_relu_pool_fwd_rows(int dtype, int nd, const void* y, long long y_ss, void* z, long long z_ss, void* pooled, long long p_ss,
+                                const void* gamma, const void* beta, int groups, float eps, void* slab, int rows, void* scale, void* shift,
+                                void* mean, void* invstd, int C, int N, int Do, int Ho, int Wo, void* stream);
 int iunet_gn_relu_pool_fwd(int dtype, int nd, const void* y, long long y_ss, void* z, long long z_ss, void* pooled, long long p_ss,
                            const void* gamma, const void* beta, int groups, float eps, void* slab, void* scale, void* shift, void* mean,
                            void* invstd, int C, int N, int Do, int Ho, int Wo, void* stream) {
+  return iunet_gn_relu_pool_fwd_rows(dtype, nd, y, y_ss, z, z_ss, pooled, p_ss, gamma, beta, groups, eps, slab, 0, scale, shift, mean, invstd, C, N,
+                                     Do, Ho, Wo, stream);
+}
+// (rows > 0: as iunet_gn_relu_fwd_rows)
+int iunet_gn_relu_pool_fwd_rows(int dtype, int nd, const void* y, long long y_ss, void* z, long long z_ss, void* pooled, long long p_ss,
+                                const void* gamma, const void* beta, int groups, float eps, void* slab, int rows, void* scale, void* shift,
+                                void* mean, void* invstd, int C, int N, int Do, int Ho, int Wo, void* stream) {
   DT_OK(dtype);
   IUNET_REQUIRE(y && z && pooled && gamma && beta && slab && scale && shift && mean && invstd, "gn_relu_pool_fwd: null pointer");
   IUNET_REQUIRE(nd == 2 || nd == 3, "gn_relu_pool_fwd: nd must be 2 or 3");
@@ -1217,9 +1236,10 @@ int iunet_gn_relu_pool_fwd(int dtype, int nd, const void* y, long long y_ss, voi
   IUNET_REQUIRE(groups > 0 && C % groups == 0, "gn_relu_pool_fwd: %d channels do not split into %d groups", C, groups);
   const long long ovox = (long long)Do * Ho * Wo, vox = ovox * (nd == 3 ? 8 : 4);
   const int per_block = BN_BWD_PER_BLOCK;
-  const int chunks = (int)((vox + per_block - 1) / per_block);
+  const int chunks = rows > 0 ? rows : (int)((vox + per_block - 1) / per_block);
   dim3 g1(chunks, C / 8, N);
-  if (dtype == 0) hipLaunchKernelGGL(gn_stats_kernel<f16>, g1, dim3(256), 0, (hipStream_t)stream, (const f16*)y, y_ss, C, vox, per_block, (float*)slab);
+  if (rows > 0) {}
+  else if (dtype == 0) hipLaunchKernelGGL(gn_stats_kernel<f16>, g1, dim3(256), 0, (hipStream_t)stream, (const f16*)y, y_ss, C, vox, per_block, (float*)slab);
   else hipLaunchKernelGGL(gn_stats_kernel<bf16>, g1, dim3(256), 0, (hipStream_t)stream, (const bf16*)y, y_ss, C, vox, per_block, (float*)slab);
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, N), dim3(256), 0, (hipStream_t)stream, (const float*)slab, chunks, C, groups,
                      (double)vox, (const float*)gamma, (const float*)beta, eps, (float*)scale, (float*)shift, (float*)mean, (float*)invstd);

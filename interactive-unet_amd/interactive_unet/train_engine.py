@@ -66,6 +66,7 @@ class TrainEngine:
         # the BatchNorm-backward sums of a stage's conv1 ride in the epilogue of conv2's data gradient (IUNET_NO_BW_FUSION=1: separate
         # reduction pass, for A/B runs)
         self.fuse_bw = not self.gn and not os.environ.get('IUNET_NO_BW_FUSION')
+        self.gn_conv_stats = self.gn and not os.environ.get('IUNET_NO_GN_CONV_STATS')
         self.head_act = not self.gn and not os.environ.get('IUNET_NO_HEAD_ACT')     # A/B switch: materialise the last activation
         self._bw_ready = {}
         self._flatten()
@@ -227,6 +228,8 @@ class TrainEngine:
                     max_wslab = max(max_wslab, lib.iunet_first_conv_wgrad_blocks(self.dim, N, *d) * b * 112)
                 else:
                     max_stats = max(max_stats, max(lib.iunet_conv3_stats_parts(self.dim, N, *d, b, lay) for lay in (0, 2)) * b * 2)
+                    if self.gn:          # per-sample rows of the conv epilogue
+                        max_stats = max(max_stats, max(lib.iunet_conv3_sample_stats_rows(self.dt, self.dim, N, *d, a, b, lay) for lay in (2, 3)) * N * b * 2)
                     max_wslab = max(max_wslab, lib.iunet_conv3_wgrad_slab_floats(self.dim, N, *d, a, b))
                 max_bn = max(max_bn, lib.iunet_bn_bwd_num_parts(N, v) * b * 2)
         for l in range(L):
@@ -269,12 +272,15 @@ class TrainEngine:
         s = nv.stream()
         y = ws['y.' + name]
         stats = ws['stats']
+        gn_rows = 0
         if name == 'enc0.conv1':
             x, xs = x_raw
             w, _ = self.pk[name]
             nparts = nv.lib().iunet_conv3_num_tiles(self.dim, N, *d)
+            if self.gn and self.gn_conv_stats:
+                gn_rows = nparts // N          # one row per tile, a sample's tiles together: per-sample rows as they are
             nv.call('iunet_first_conv_fwd', self.dt, self.dim, nv.ptr(x), nv.IN_DTYPE_CODE[x.dtype], nv.ll_array(xs),
-                    self._P(y), co * v, nv.ptr(w), None, None if self.gn else nv.ptr(stats), N, d[0], d[1], d[2], ci, co, 0, s)
+                    self._P(y), co * v, nv.ptr(w), None, None if (self.gn and not gn_rows) else nv.ptr(stats), N, d[0], d[1], d[2], ci, co, 0, s)
         else:
             pk, _ = self.pk[name]
             lay, w = pk.pick(self.dim, N, *d, act=x_act is not None)
@@ -283,7 +289,12 @@ class TrainEngine:
             if probe is not None:
                 e0 = torch.cuda.Event(enable_timing=True)
                 e0.record()
-            if x_act is None:
+            if self.gn and x_act is None and self.gn_conv_stats:      # GroupNorm statistics from the conv's epilogue, per sample, where the launch has that form
+                gn_rows = nv.lib().iunet_conv3_sample_stats_rows(self.dt, self.dim, N, d[0], d[1], d[2], ci, co, lay)
+            if gn_rows > 0:
+                nv.call('iunet_conv3_fwd_sample_stats', self.dt, self.dim, x_ptr, x_ss, self._P(y), co * v, nv.ptr(w), nv.ptr(stats),
+                        N, d[0], d[1], d[2], ci, co, lay, s)
+            elif x_act is None:
                 nv.call('iunet_conv3_fwd', self.dt, self.dim, x_ptr, x_ss, self._P(y), co * v, nv.ptr(w), None,
                         None if self.gn else nv.ptr(stats), N, d[0], d[1], d[2], ci, co, 0, lay, s)
             else:
@@ -298,12 +309,12 @@ class TrainEngine:
         if self.gn:
             if pool is not None:                # encoder stage: the normalise pass writes the activation and its max-pool
                 p_ptr, p_ss, do = pool
-                nv.call('iunet_gn_relu_pool_fwd', self.dt, self.dim, self._P(y), co * v, z_ptr, z_ss, p_ptr, p_ss, nv.ptr(self.p(bn + '.weight')),
-                        nv.ptr(self.p(bn + '.bias')), self.groups, BN_EPS, nv.ptr(ws['bnslab']), nv.ptr(ws['scale.' + name]),
+                nv.call('iunet_gn_relu_pool_fwd_rows', self.dt, self.dim, self._P(y), co * v, z_ptr, z_ss, p_ptr, p_ss, nv.ptr(self.p(bn + '.weight')),
+                        nv.ptr(self.p(bn + '.bias')), self.groups, BN_EPS, nv.ptr(stats if gn_rows > 0 else ws['bnslab']), gn_rows, nv.ptr(ws['scale.' + name]),
                         nv.ptr(ws['shift.' + name]), nv.ptr(ws['mean.' + name]), nv.ptr(ws['invstd.' + name]), co, N, do[0], do[1], do[2], s)
             else:
-                nv.call('iunet_gn_relu_fwd', self.dt, self._P(y), co * v, z_ptr, z_ss, nv.ptr(self.p(bn + '.weight')),
-                        nv.ptr(self.p(bn + '.bias')), self.groups, BN_EPS, nv.ptr(ws['bnslab']), nv.ptr(ws['scale.' + name]),
+                nv.call('iunet_gn_relu_fwd_rows', self.dt, self._P(y), co * v, z_ptr, z_ss, nv.ptr(self.p(bn + '.weight')),
+                        nv.ptr(self.p(bn + '.bias')), self.groups, BN_EPS, nv.ptr(stats if gn_rows > 0 else ws['bnslab']), gn_rows, nv.ptr(ws['scale.' + name]),
                         nv.ptr(ws['shift.' + name]), nv.ptr(ws['mean.' + name]), nv.ptr(ws['invstd.' + name]), co, N, v, s)
             return
         nv.call('iunet_bn_finalize', nv.ptr(stats), nparts, co, float(N) * v,

@@ -508,6 +508,55 @@ def test_dgrad_with_fused_batchnorm_backward_sums(nv, nd, cin, lay):
     assert (zz > 0).double().mean() > 0.2 and (zz > 0).double().mean() < 0.8
 
 
+@pytest.mark.parametrize('nd,cin,cout,lay,shape', [(3, 32, 32, 2, (64, 64, 64)), (3, 64, 32, 3, (64, 64, 64)), (3, 64, 64, 3, (32, 64, 64)),
+                                                    (2, 32, 32, 3, (256, 512)), (2, 128, 64, 3, (256, 256))])       # >= 8 bricks per sample
+def test_conv_with_per_sample_statistics(nv, nd, cin, cout, lay, shape):
+    """iunet_conv3_fwd_sample_stats (GroupNorm training: the conv's statistics epilogue per SAMPLE, the samples along the grid's z): the
+    output equals iunet_conv3_fwd bit for bit, the rows [N][rows][Cout][2] sum to each sample's (sum, sum of squares), and
+    iunet_gn_relu_fwd_rows on them equals iunet_gn_relu_fwd's own statistics pass within the rounding of the stored tensor."""
+    g = torch.Generator().manual_seed(35)
+    T, dt = torch.bfloat16, 1
+    N = 3
+    D, H, W = shape if nd == 3 else (1,) + shape
+    taps, vox = 3 ** nd, D * H * W
+    rows = nv.lib().iunet_conv3_sample_stats_rows(dt, nd, N, D, H, W, cin, cout, lay)
+    assert rows > 0 and nv.lib().iunet_conv3_sample_stats_rows(dt, nd, N, D, H, W, cin, cout, 1) == 0
+    tiny = (4, 8, 16) if nd == 3 else (16, 32)
+    assert nv.lib().iunet_conv3_sample_stats_rows(dt, nd, N, *((tiny if nd == 3 else (1,) + tiny)), cin, cout, lay) == 0      # one brick per sample: the caller's own pass
+    x = torch.randn((N, cin) + shape, generator=g) * torch.tensor([0.5, 1.0, 2.0]).view(N, 1, *([1] * nd)) + torch.tensor([0.0, 0.3, -0.2]).view(N, 1, *([1] * nd))
+    w = (torch.randn((cout, cin) + (3,) * nd, generator=g) * 0.05).cuda()
+    xb = blocked(x, T).cuda()
+    s = nv.stream()
+    pm = 6 if lay == 3 else 2
+    wpk = torch.empty(nv.pack_conv3_elems(cout, cin, taps, pm), dtype=T, device='cuda')
+    nv.call('iunet_pack_conv3', dt, nv.ptr(w), None, nv.ptr(wpk), cout, cin, taps, pm, s)
+    y = [torch.full((N * cout * vox,), float('nan'), dtype=T, device='cuda') for _ in range(2)]
+    st = torch.full((N * rows * cout * 2,), float('nan'), device='cuda')
+    nv.call('iunet_conv3_fwd', dt, nd, nv.ptr(xb), cin * vox, nv.ptr(y[0]), cout * vox, nv.ptr(wpk), None, None, N, D, H, W, cin, cout, 0, lay, s)
+    nv.call('iunet_conv3_fwd_sample_stats', dt, nd, nv.ptr(xb), cin * vox, nv.ptr(y[1]), cout * vox, nv.ptr(wpk), nv.ptr(st), N, D, H, W, cin, cout, lay, s)
+    torch.cuda.synchronize()
+    assert torch.equal(y[0].view(torch.int16), y[1].view(torch.int16))
+    got = st.view(N, rows, cout, 2).double().sum(1).cpu()
+    yf = unblocked(y[1].cpu(), N, cout, shape).double()
+    red = tuple(range(2, nd + 2))
+    want = torch.stack([yf.sum(red), (yf * yf).sum(red)], 2)
+    size = torch.stack([yf.abs().sum(red), (yf * yf).sum(red)], 2)
+    assert ((got - want).abs() <= 1e-3 * size).all(), ((got - want).abs() / size).max().item()
+    gamma, beta = (0.5 + torch.rand(cout, generator=g)).cuda(), (0.2 * torch.randn(cout, generator=g)).cuda()
+    outs = []
+    for r in (0, rows):
+        z = torch.empty_like(y[1])
+        par = [torch.empty(N * cout, device='cuda') for _ in range(4)]
+        slab = st if r else torch.empty(nv.lib().iunet_gn_num_parts(N, vox) * cout * 2, device='cuda')
+        nv.call('iunet_gn_relu_fwd_rows', dt, nv.ptr(y[1]), cout * vox, nv.ptr(z), cout * vox, nv.ptr(gamma), nv.ptr(beta), 8, 1e-5, nv.ptr(slab), r,
+                *[nv.ptr(t) for t in par], cout, N, vox, s)
+        outs.append((z, par))
+    torch.cuda.synchronize()
+    for a, b in zip(outs[0][1], outs[1][1]):
+        assert (a - b).abs().max().item() <= 2e-3 * max(1.0, b.abs().max().item())
+    assert (outs[0][0].float() - outs[1][0].float()).abs().max().item() <= 0.05      # a few bf16 ulps of an O(1) activation
+
+
 @pytest.mark.parametrize('nd', [2, 3])
 def test_bn_relu_pool_fwd_equals_two_passes(nv, nd):
     """iunet_bn_relu_pool_fwd == iunet_bn_relu_fwd followed by iunet_maxpool_fwd, bit for bit (both outputs)."""
