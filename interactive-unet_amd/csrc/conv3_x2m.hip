@@ -505,6 +505,7 @@ __global__ __launch_bounds__((XMTile<SMALL>::NCW * 64 + XM_NLT), 1) void conv3_x
 #pragma unroll
       for (int j = 0; j < 4; ++j) { os_r[j] = w0[j]; os_r[4 + j] = w1[j]; bias_r[j] = b0[j]; bias_r[4 + j] = b1[j]; }
     }
+    const float relu_floor = p.epi == 2 ? 0.f : -__builtin_inff();
     [[maybe_unused]] float hl[HEAD > 0 ? HEAD : 1];
     [[maybe_unused]] unsigned pool_k[8];                       // POOL: the keys of the first fragment of a y pair (common.h: x2m_pool_keys)
 #pragma unroll
@@ -517,7 +518,8 @@ __global__ __launch_bounds__((XMTile<SMALL>::NCW * 64 + XM_NLT), 1) void conv3_x
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         r[j] = fmaf(j < 4 ? acc[0][n][j] : acc[1][n][j - 4], os_r[j], bias_r[j]);
-        if (p.epi == 2) r[j] = fmaxf(r[j], 0.f);
+        if constexpr (HEAD > 0) { if (p.epi == 2) r[j] = fmaxf(r[j], 0.f); }      // (the head variants sit at their register cap)
+        else r[j] = fmaxf(r[j], relu_floor);                                      // one v_max against 0 / -inf: conv3_v4.hip's tile epilogue
       }
       if constexpr (HEAD > 0) {
         float lf[HEAD];
@@ -1054,6 +1056,7 @@ __global__ __launch_bounds__(8 * 64 + XM_NLT, 1) void conv2_x2m_kernel(ConvX2MPa
 #pragma unroll
       for (int j = 0; j < 4; ++j) { os_r[j] = w0[j]; os_r[4 + j] = w1[j]; bias_r[j] = b0[j]; bias_r[4 + j] = b1[j]; }
     }
+    const float relu_floor = p.epi == 2 ? 0.f : -__builtin_inff();
     [[maybe_unused]] float hl[HEAD > 0 ? HEAD : 1];
     [[maybe_unused]] unsigned pool_k[2][8];                    // POOL: the keys of row 0's two fragments (common.h: x2m_pool_keys)
 #pragma unroll
@@ -1065,7 +1068,8 @@ __global__ __launch_bounds__(8 * 64 + XM_NLT, 1) void conv2_x2m_kernel(ConvX2MPa
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         r[j] = fmaf(j < 4 ? acc[0][n][j] : acc[1][n][j - 4], os_r[j], bias_r[j]);
-        if (p.epi == 2) r[j] = fmaxf(r[j], 0.f);
+        if constexpr (HEAD > 0) { if (p.epi == 2) r[j] = fmaxf(r[j], 0.f); }      // (the head variants sit at their register cap)
+        else r[j] = fmaxf(r[j], relu_floor);                                      // one v_max against 0 / -inf: conv3_v4.hip's tile epilogue
       }
       if constexpr (HEAD > 0) {
         float lf[HEAD];
