@@ -18,7 +18,7 @@ CSRC = os.path.join(ROOT, 'interactive-unet_amd', 'csrc')
 
 # functions that return a size / count / version, or do pure host arithmetic: a zero call need not fail
 _NOT_STATUS = {'iunet_last_error', 'iunet_abi_version', 'iunet_pack_desc_bytes', 'iunet_augment_desc_bytes', 'iunet_x2_prep_desc_bytes',
-               'iunet_conv3_pick_layout', 'iunet_conv3_tile_pairs', 'iunet_conv3_compact_ok', 'iunet_conv3_num_tiles', 'iunet_conv3_stats_parts', 'iunet_zoom_nearest_len',
+               'iunet_conv3_pick_layout', 'iunet_conv3_tile_pairs', 'iunet_conv3_compact_ok', 'iunet_conv3_num_tiles', 'iunet_conv3_stats_parts', 'iunet_conv3_sample_stats_rows', 'iunet_zoom_nearest_len',
                'iunet_bn_bwd_num_parts', 'iunet_gn_num_parts', 'iunet_head_loss_num_parts', 'iunet_head_loss_bwd_num_parts',
                'iunet_conv3_wgrad_blocks', 'iunet_convT_wgrad_blocks', 'iunet_first_conv_wgrad_blocks', 'iunet_x2_convT_kc', 'iunet_x2_pack_mode',
                'iunet_net_num_tensors', 'iunet_f32_wgrad_splits', 'iunet_f32_head_loss_num_parts', 'iunet_f8_pack_order',
