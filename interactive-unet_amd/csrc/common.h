@@ -228,12 +228,14 @@ __device__ __forceinline__ u32x2_t x2m_pack8(const float (&f)[8]) {
 // v_cvt_pk_fp8_f32 on every f32 pattern with |res| <= 28 -- tools/micro/cvt_scale_fp8_f32.hip walks all 2^32 -- and |res| <= 16 here, half
 // an ulp of the largest hi word.  hi8 (a function of the hi words: x2m_hi8 below) is kept for the callers that still take it.)
 __device__ __forceinline__ u32x2_t x2m_hi8(const f16x8 hi);
+// (CLAMPED: the caller's values already lie in [-65504, 65504] -- the conv epilogues clamp and apply the ReLU in one v_med3)
+template <bool CLAMPED = false>
 __device__ __forceinline__ void x2m_split8(const float (&r)[8], f16x8& hi, f16x8& lo, u32x2_t& lo8, u32x2_t& hi8) {
   typedef short s16x2 __attribute__((ext_vector_type(2)));
   float res[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    const float v = fminf(fmaxf(r[j], -65504.f), 65504.f);
+    const float v = CLAMPED ? r[j] : fminf(fmaxf(r[j], -65504.f), 65504.f);
     const f16 h = (f16)v;
     res[j] = v - (float)h;                                     // exact in fp32
     hi[j] = h; lo[j] = (f16)res[j];

@@ -505,7 +505,7 @@ __global__ __launch_bounds__((XMTile<SMALL>::NCW * 64 + XM_NLT), 1) void conv3_x
 #pragma unroll
       for (int j = 0; j < 4; ++j) { os_r[j] = w0[j]; os_r[4 + j] = w1[j]; bias_r[j] = b0[j]; bias_r[4 + j] = b1[j]; }
     }
-    const float relu_floor = p.epi == 2 ? 0.f : -__builtin_inff();
+    const float relu_floor = p.epi == 2 ? 0.f : -65504.f;
     [[maybe_unused]] float hl[HEAD > 0 ? HEAD : 1];
     [[maybe_unused]] unsigned pool_k[8];                       // POOL: the keys of the first fragment of a y pair (common.h: x2m_pool_keys)
 #pragma unroll
@@ -519,7 +519,7 @@ __global__ __launch_bounds__((XMTile<SMALL>::NCW * 64 + XM_NLT), 1) void conv3_x
       for (int j = 0; j < 8; ++j) {
         r[j] = fmaf(j < 4 ? acc[0][n][j] : acc[1][n][j - 4], os_r[j], bias_r[j]);
         if constexpr (HEAD > 0) { if (p.epi == 2) r[j] = fmaxf(r[j], 0.f); }      // (the head variants sit at their register cap)
-        else r[j] = fmaxf(r[j], relu_floor);                                      // one v_max against 0 / -inf: conv3_v4.hip's tile epilogue
+        else r[j] = __builtin_amdgcn_fmed3f(r[j], relu_floor, 65504.f);           // ReLU AND the split's range clamp in one v_med3: floor = 0 or -65504 (NaN -> the floor, as fmax / fmin gave)
       }
       if constexpr (HEAD > 0) {
         float lf[HEAD];
@@ -529,7 +529,7 @@ __global__ __launch_bounds__((XMTile<SMALL>::NCW * 64 + XM_NLT), 1) void conv3_x
       } else {
       f16x8 hi, lo;
       u32x2 lo8, hi8;
-      x2m_split8(r, hi, lo, lo8, hi8);
+      x2m_split8<true>(r, hi, lo, lo8, hi8);
       if (ok) {
         *(f16x8*)(yout + (long long)(cob * 4 + q) * plane_stride + vo * 8) = hi;
         if (p.y_lo >= 0) *(f16x8*)(yout + (long long)(p.y_lo + cob * 4 + q) * plane_stride + vo * 8) = lo;
@@ -1056,7 +1056,7 @@ __global__ __launch_bounds__(8 * 64 + XM_NLT, 1) void conv2_x2m_kernel(ConvX2MPa
 #pragma unroll
       for (int j = 0; j < 4; ++j) { os_r[j] = w0[j]; os_r[4 + j] = w1[j]; bias_r[j] = b0[j]; bias_r[4 + j] = b1[j]; }
     }
-    const float relu_floor = p.epi == 2 ? 0.f : -__builtin_inff();
+    const float relu_floor = p.epi == 2 ? 0.f : -65504.f;
     [[maybe_unused]] float hl[HEAD > 0 ? HEAD : 1];
     [[maybe_unused]] unsigned pool_k[2][8];                    // POOL: the keys of row 0's two fragments (common.h: x2m_pool_keys)
 #pragma unroll
@@ -1069,7 +1069,7 @@ __global__ __launch_bounds__(8 * 64 + XM_NLT, 1) void conv2_x2m_kernel(ConvX2MPa
       for (int j = 0; j < 8; ++j) {
         r[j] = fmaf(j < 4 ? acc[0][n][j] : acc[1][n][j - 4], os_r[j], bias_r[j]);
         if constexpr (HEAD > 0) { if (p.epi == 2) r[j] = fmaxf(r[j], 0.f); }      // (the head variants sit at their register cap)
-        else r[j] = fmaxf(r[j], relu_floor);                                      // one v_max against 0 / -inf: conv3_v4.hip's tile epilogue
+        else r[j] = __builtin_amdgcn_fmed3f(r[j], relu_floor, 65504.f);           // ReLU AND the split's range clamp in one v_med3: floor = 0 or -65504 (NaN -> the floor, as fmax / fmin gave)
       }
       if constexpr (HEAD > 0) {
         float lf[HEAD];
@@ -1079,7 +1079,7 @@ __global__ __launch_bounds__(8 * 64 + XM_NLT, 1) void conv2_x2m_kernel(ConvX2MPa
       } else {
       f16x8 hi, lo;
       u32x2 lo8, hi8;
-      x2m_split8(r, hi, lo, lo8, hi8);
+      x2m_split8<true>(r, hi, lo, lo8, hi8);
       if (ok) {
         *(f16x8*)(yout + (long long)(cob * 4 + q) * plane_stride + vo * 8) = hi;
         if (p.y_lo >= 0) *(f16x8*)(yout + (long long)(p.y_lo + cob * 4 + q) * plane_stride + vo * 8) = lo;
