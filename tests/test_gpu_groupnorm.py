@@ -139,6 +139,44 @@ def test_groupnorm_train_step_vs_autograd(dim, shape, dtype):
     assert losses[-1] < out['Loss']
 
 
+@pytest.mark.parametrize('dim,shape,dtype', [(2, (256, 512), 'fp16'), (3, (64, 64, 64), 'bf16')])
+def test_groupnorm_training_with_conv_epilogue_statistics(monkeypatch, dim, shape, dtype):
+    """On grids with >= 8 bricks per sample the GroupNorm statistics of a training forward come from the conv's epilogue, per sample
+    (iunet_conv3_fwd_sample_stats; the first conv's per-tile rows) instead of a pass over the conv's output: the same training steps with
+    and without (IUNET_NO_GN_CONV_STATS=1) -- Python-sequenced first step, C handle from the second -- agree in loss and gradients to the
+    rounding of the stored 16-bit tensor (the epilogue sums the fp32 accumulators, the pass the rounded values)."""
+    from interactive_unet.train_engine import TrainEngine
+    from interactive_unet import _native as nv
+    N, ncls = 2, 2
+    D, H, W = shape if dim == 3 else (1,) + shape
+    assert nv.lib().iunet_conv3_sample_stats_rows(nv.DTYPE_CODE[torch.float16 if dtype == 'fp16' else torch.bfloat16], dim, N, D, H, W, 32, 32, 2) > 0
+    rng = np.random.default_rng(3)
+    img = rng.integers(1, 256, (N, 1) + shape, dtype=np.uint8)
+    img[1] = (img[1] // 3) + 100                                       # the two samples differ in mean and spread
+    lab = img[:, 0] > 127
+    y = np.stack([~lab, lab], 1).astype(np.float32)
+    wt = np.ones_like(y)
+    runs = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv('IUNET_NO_GN_CONV_STATS', '1')
+        else:
+            monkeypatch.delenv('IUNET_NO_GN_CONV_STATS', raising=False)
+        m, _ = _model(dim, ncls, dtype, seed=7)
+        m.train()
+        te = TrainEngine(m, lr=1e-3, loss_kind='dice_ce')
+        assert te.gn_conv_stats == (not off)
+        first = te.train_step(torch.tensor(img), torch.tensor(y), torch.tensor(wt))['Loss']
+        g1 = te.grad.clone() / te.loss_scale
+        rest = [te.train_step(torch.tensor(img), torch.tensor(y), torch.tensor(wt))['Loss'] for _ in range(3)]
+        runs.append((first, g1, rest))
+    (l0, g0, r0), (l1, g1, r1) = runs
+    cos = float((g0 * g1).sum() / (g0.norm() * g1.norm()))
+    print(f'GroupNorm {dim}-D {dtype}: first loss {l0:.6f} / {l1:.6f}, gradient cosine {cos:.6f}, later losses {r0} / {r1}')
+    assert abs(l0 - l1) <= 2e-3 and cos > 0.999 and abs(float(g0.norm() / g1.norm()) - 1) < 1e-2
+    assert all(abs(a - b) <= 5e-3 for a, b in zip(r0, r1)) and r0[-1] < l0
+
+
 @pytest.mark.parametrize('dtype,nd,N,C,groups,do', [(torch.bfloat16, 3, 2, 32, 8, (3, 5, 6)), (torch.float16, 2, 3, 64, 8, (1, 20, 17)), (torch.bfloat16, 3, 1, 128, 8, (2, 2, 4))])
 def test_gn_pooled_forward_and_backward_equal_the_unfused_sequences(nv, dtype, nd, N, C, groups, do):
     """iunet_gn_relu_pool_fwd = iunet_gn_relu_fwd + iunet_maxpool_fwd and iunet_gn_relu_pool_bwd = iunet_maxpool_bwd (add_skip) +
