@@ -619,6 +619,18 @@ int iunet_head_loss_bwd_dev(int dtype, const void* x, long long x_ss, int C0, co
                             const void* target, const void* weight, int tdtype, const void* coef, const void* state, void* dx,
                             long long dx_ss, void* dwslab, const void* in_scale, const void* in_shift, int N, long long vox,
                             void* stream);
+/* [r5] The head's backward and the BatchNorm + ReLU backward of the last stage conv (training with the head reading that conv's RAW
+ * output y: iunet_head_loss_fwd_act) in two passes over y -- the head's input gradient is never written; replaces iunet_head_loss_bwd_dev
+ * + iunet_bn_relu_bwd for that layer (y read twice and dy written once instead of y three times, dz written once and read twice).
+ * iunet_head_bn_bwd_ok: 32 head input channels, 2..4 classes.  dwslab / the reduction of its rows as iunet_head_loss_bwd; dgamma, dbeta,
+ * bncoef (3 * 32 floats of scratch) as iunet_bn_relu_bwd; bnslab: iunet_bn_bwd_num_parts(N, vox) * 64 floats; dl_scratch: N * vox * ncls
+ * floats (the logit gradients, written by the first pass and read by the second); dy: the gradient of y.
+ * Loss scale: state[0] when state is not NULL (the training handle's device state), else loss_scale. */
+int iunet_head_bn_bwd_ok(int C0, int ncls);
+int iunet_head_bn_bwd(int dtype, const void* y, long long y_ss, int C0, const void* w, const void* bias, int ncls, const void* target,
+                      const void* weight, int tdtype, const void* coef, float loss_scale, const void* state, const void* scale,
+                      const void* shift, const void* mean, const void* invstd, const void* gamma, void* dgamma, void* dbeta, void* dy,
+                      long long dy_ss, void* dwslab, void* bnslab, void* bncoef, void* dl_scratch, int N, long long vox, void* stream);
 /* dW [ncls][C0], db [ncls] of the head from the reduced row of iunet_head_loss_bwd's slab ([C0 / 8][ncls][8] weight sums, then [ncls]) */
 int iunet_head_grad_scatter(const void* row, void* dw, void* db, int ncls, int C0, void* stream);
 /* the optimiser step on the device state: overflow check of the flat gradient (check != 0: fp16), AdamW (unet.py:71-73; skipped on

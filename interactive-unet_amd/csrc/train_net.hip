@@ -55,6 +55,9 @@ int iunet_head_loss_bwd_num_parts(int, long long, int, int);
 int iunet_head_loss_bwd_dev(int, const void*, long long, int, const void*, const void*, int, const void*, const void*, int, const void*,
                             const void*, void*, long long, void*, const void*, const void*, int, long long, void*);
 int iunet_head_grad_scatter(const void*, void*, void*, int, int, void*);
+int iunet_head_bn_bwd_ok(int, int);
+int iunet_head_bn_bwd(int, const void*, long long, int, const void*, const void*, int, const void*, const void*, int, const void*, float, const void*, const void*,
+                      const void*, const void*, const void*, const void*, void*, void*, void*, long long, void*, void*, void*, void*, int, long long, void*);
 int iunet_reduce_slab(void*, int, long long, void*, float, int, void*);
 long long iunet_conv3_wgrad_slab_floats(int, int, int, int, int, int, int);
 int iunet_conv3_wgrad(int, int, const void*, long long, const void*, long long, void*, void*, float, int, int, int, int, int, int, void*);
@@ -121,7 +124,7 @@ struct iunet_train {
   int norm = 0, groups = 8;                      // norm 1: GroupNorm(groups) after every stage conv (statistics per (sample, group), nothing fused into the convs)
   int dim, levels, base, cin, ncls, dtype, kind;
   int taps, npos;
-  bool fuse_act, fuse_bw, head_act, gn_conv_stats;
+  bool fuse_act, fuse_bw, head_act, gn_conv_stats, head_bn;
   std::vector<int> ch;
   std::vector<TParam> params;
   long long nparams = 0;
@@ -258,6 +261,7 @@ int iunet_train_create_ex(int dim, int levels, int base, int cin, int ncls, int 
   n->fuse_act = norm == 0 && !env_on("IUNET_NO_ACT_FUSION");
   n->fuse_bw = norm == 0 && !env_on("IUNET_NO_BW_FUSION");
   n->head_act = norm == 0 && !env_on("IUNET_NO_HEAD_ACT");
+  n->head_bn = n->head_act && !env_on("IUNET_NO_HEAD_BN_FUSION");          // head backward + the last conv's BatchNorm backward in two passes over y (iunet_head_bn_bwd)
   n->gn_conv_stats = norm == 1 && !env_on("IUNET_NO_GN_CONV_STATS");      // GroupNorm statistics from the conv epilogue (per sample) where the launch has that form
   for (int l = 0; l < levels; ++l) n->ch.push_back(base << l);
   long long off = 0, pk = 0;
@@ -518,9 +522,17 @@ int iunet_train_forward_backward_hooks(iunet_train* n, const void* x, int in_dty
   if (out4 != nullptr) IUNET_CHECK_HIP(hipMemcpyAsync(out4, F(L.out4), 4 * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
 
   // ---- backward
+  int dy_ready = -1;          // the conv whose BatchNorm backward has already run (dy holds its output gradient)
   {
     const int nparts = iunet_head_loss_bwd_num_parts(N, v0, n->ncls, c0);
-    if (n->head_act)
+    const TConv& cl = n->conv[kl];
+    if (n->head_bn && iunet_head_bn_bwd_ok(c0, n->ncls)) {
+      rc = iunet_head_bn_bwd(dt, WS + L.y[kl], (long long)c0 * v0, c0, P + n->head_w, P + n->head_b, n->ncls, target, weight, tdtype, F(L.coef), 0.f,
+                             n->state, F(L.scale[kl]), F(L.shift[kl]), F(L.mean[kl]), F(L.invstd[kl]), P + cl.gamma, G + cl.gamma, G + cl.beta,
+                             WS + L.dy, (long long)c0 * v0, F(L.hslab), F(L.bnslab), F(L.bncoef), WS + L.dz[kl] /* unused by this path: 32 x 2 bytes per voxel */,
+                             N, v0, stream);
+      dy_ready = kl;
+    } else if (n->head_act)
       rc = iunet_head_loss_bwd_dev(dt, WS + L.y[kl], (long long)c0 * v0, c0, P + n->head_w, P + n->head_b, n->ncls, target, weight, tdtype, F(L.coef),
                                    n->state, WS + L.dz[kl], (long long)c0 * v0, F(L.hslab), F(L.scale[kl]), F(L.shift[kl]), N, v0, stream);
     else
@@ -541,7 +553,9 @@ int iunet_train_forward_backward_hooks(iunet_train* n, const void* x, int in_dty
     const long long v = vox(c.l);
     void* dy = WS + L.dy;
     const void* y = WS + L.y[k];
-    if (n->norm == 1 && dpool != nullptr) {
+    if (k == dy_ready) {
+      // (iunet_head_bn_bwd has written dy, dgamma and dbeta of this conv)
+    } else if (n->norm == 1 && dpool != nullptr) {
       int dn, hn, wn;
       dims(c.l + 1, dn, hn, wn);
       rc = iunet_gn_relu_pool_bwd(dt, dim, dzp, dz_ss, dpool, dpool_ss, y, c.co * v, dy, c.co * v, P + c.gamma, n->groups, F(L.scale[k]), F(L.shift[k]),

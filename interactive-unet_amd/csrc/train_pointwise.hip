@@ -774,6 +774,243 @@ __global__ __launch_bounds__(256) void head_loss_bwd_kernel(HeadLossParams p) {
   block_reduce_store<NCLS>(accb, red, slab + PL * NCLS * 8);
 }
 
+// [r5] The head's backward AND the BatchNorm + ReLU backward of the last stage conv in two passes over that conv's raw output y -- the
+// head's input gradient dz is never written.  The three-kernel sequence it replaces (head_loss_bwd_kernel -> bn_bwd_reduce_kernel ->
+// bn_bwd_apply_kernel, with head_act) read y three times and wrote / read dz 1 + 2 times: 1.88 GB per C3 step at level 0 against 0.8.
+// A workgroup walks 64 voxels at a time, wave pl its channel plane pl (C0 = 32: four waves; every per-channel constant is wave-uniform,
+// i.e. lives in scalar registers): z = relu(bn(y)) as bn_relu_fwd would have stored it, the plane's share of the logits -> LDS, one
+// barrier, the four shares summed in a fixed order (the same bits in all four waves), softmax and loss gradient per lane, dz = W^T dl
+// for the wave's 8 channels ROUNDED to T as head_loss_bwd_kernel stored it.  (A quad of lanes per voxel with the planes across the quad
+// kept the constants in 72 vector registers per lane: 3 waves per SIMD, 260 + 236 us for the two passes at 2 x 128^3.)
+//   PASS 1: s1 += dz', s2 += dz' xhat (bn_bwd_reduce_kernel's arithmetic), dW += dl z, db += dl -- 16 + 8 NCLS + NCLS partial sums
+//           per lane -> one BatchNorm row [C][2] and one head row [planes][NCLS][8] + [NCLS] per 2 048 voxels;
+//   PASS 2: dy = a (dz' - c1 - xhat c2) (bn_bwd_apply_kernel's arithmetic) with the coefficients of bn_bwd_finalize_kernel.
+// The logits add their 32 terms plane by plane (head_loss_fwd_kernel adds them in channel order): the gradient is that of a logit one
+// rounding away from the forward's.
+struct HeadBnBwdParams {
+  const void* y; long long y_ss;
+  const float* w; const float* bias;                 // head [NCLS][32], [NCLS]
+  const void* target; const void* weight; int tdtype;
+  const float* coef;                                 // loss coefficients [NCLS][3] (loss_finalize_kernel)
+  float loss_scale; const float* loss_scale_dev;
+  const float* scale; const float* shift; const float* mean; const float* invstd;      // the last conv's BatchNorm [32]
+  const float* bncoef;                               // PASS 2: [32][3] (bn_bwd_finalize_kernel)
+  float* bnslab; float* dwslab;                      // PASS 1 outputs: [parts][32][2], [parts][NCLS * 33]
+  void* dy; long long dy_ss;                         // PASS 2 output
+  float* dl;                                         // [N][vox][NCLS]: the logit gradients, written by PASS 1 (plane 0's wave), read by PASS 2
+  long long vox; int per_block;
+};
+
+#ifndef HBB_U
+#define HBB_U 1
+#endif
+#ifndef HBB_OCC
+#define HBB_OCC 1
+#endif
+template <typename T, int NCLS, int PASS>
+__global__ __launch_bounds__(256, HBB_OCC) void head_bn_bwd_kernel(HeadBnBwdParams p) {
+  constexpr int NV = 16 + NCLS * 8 + NCLS;           // PASS 1: partial sums per lane
+  const int n = blockIdx.y, lane = threadIdx.x & 63;
+  const int pl = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave = channel plane: every per-channel constant is wave-uniform (scalar registers)
+  const float lscale = p.loss_scale_dev ? *p.loss_scale_dev : p.loss_scale;
+  float sc[8], sh[8], mu[8], is[8], W[NCLS][8];
+  [[maybe_unused]] float ca[8], c1[8], c2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = pl * 8 + j;
+    sc[j] = p.scale[c]; sh[j] = p.shift[c]; mu[j] = p.mean[c]; is[j] = p.invstd[c];
+#pragma unroll
+    for (int k = 0; k < NCLS; ++k) W[k][j] = p.w[k * 32 + c];
+    if (PASS == 2) { ca[j] = p.bncoef[c * 3]; c1[j] = p.bncoef[c * 3 + 1]; c2[j] = p.bncoef[c * 3 + 2]; }
+  }
+  float bias[NCLS], lc[NCLS][3];
+#pragma unroll
+  for (int k = 0; k < NCLS; ++k) { bias[k] = p.bias[k]; lc[k][0] = p.coef[k * 3]; lc[k][1] = p.coef[k * 3 + 1]; lc[k][2] = p.coef[k * 3 + 2]; }
+  [[maybe_unused]] float acc[PASS == 1 ? NV : 1];
+  if (PASS == 1) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) acc[i] = 0.f;
+  }
+  constexpr int U = HBB_U;                           // voxels per lane and iteration: 64 U voxels per barrier
+  __shared__ float lp[2][4][NCLS][64 * U];           // the planes' shares of the logits, by iteration parity
+  __shared__ float tv[2][2 * NCLS][64 * U];          // targets and weights of the voxels: value 2 k + which, loaded ONCE per voxel (wave pl takes
+                                                     // values pl, pl + 4) -- every wave loading all of them cost 150-190 us of the two passes' 430
+  constexpr int NTV = (2 * NCLS + 3) / 4;            // values per wave
+  const long long v0 = (long long)blockIdx.x * p.per_block, v1 = min(v0 + p.per_block, p.vox);
+  const T* yin = (const T*)p.y + n * p.y_ss + (long long)pl * p.vox * 8;
+  const int niter = (int)((v1 - v0 + 64 * U - 1) / (64 * U));
+  auto load_y = [&](long long base, V8T<T> (&yy)[U]) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) yy[u] = *(const V8T<T>*)(yin + min(base + u * 64 + lane, v1 - 1) * 8);
+  };
+  auto load_tv = [&](long long base, float (&t)[U][NTV]) {
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int i = 0; i < NTV; ++i) {
+        const int idx = pl + 4 * i;                  // wave-uniform
+        if (idx < 2 * NCLS) {
+          const long long to = ((long long)n * NCLS + (idx >> 1)) * p.vox + min(base + u * 64 + lane, v1 - 1);
+          t[u][i] = (idx & 1) ? (p.weight ? load_t(p.weight, to, p.tdtype) : 1.f) : load_t(p.target, to, p.tdtype);
+        }
+      }
+  };
+  V8T<T> ynext[U];
+  float tnext[U][NTV];
+  load_y(v0, ynext);
+  load_tv(v0, tnext);
+  for (int it = 0; it < niter; ++it) {
+    const long long base = v0 + (long long)it * 64 * U;
+    V8T<T> yy[U];
+    float tcur[U][NTV];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      yy[u] = ynext[u];
+#pragma unroll
+      for (int i = 0; i < NTV; ++i) tcur[u][i] = tnext[u][i];
+    }
+    if (it + 1 < niter) { load_y(base + 64 * U, ynext); load_tv(base + 64 * U, tnext); }      // the next voxels are in flight over this iteration's barrier
+    const int par = it & 1;
+    float yv[U][8], zv[U][8];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float part[NCLS];
+#pragma unroll
+      for (int k = 0; k < NCLS; ++k) part[k] = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        yv[u][j] = to_f32<T>(yy[u][j]);
+        zv[u][j] = to_f32<T>(from_f32<T>(fmaxf(fmaf(sc[j], yv[u][j], sh[j]), 0.f)));      // z as bn_relu_fwd_kernel would have stored it (head_act)
+#pragma unroll
+        for (int k = 0; k < NCLS; ++k) part[k] = fmaf(zv[u][j], W[k][j], part[k]);
+      }
+#pragma unroll
+      for (int k = 0; k < NCLS; ++k) lp[par][pl][k][u * 64 + lane] = part[k];
+#pragma unroll
+      for (int i = 0; i < NTV; ++i) if (pl + 4 * i < 2 * NCLS) tv[par][pl + 4 * i][u * 64 + lane] = tcur[u][i];
+    }
+    __syncthreads();                                 // (one barrier per 64 U voxels: the other parity is being written by nobody yet -- its readers passed this barrier)
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long long v = base + u * 64 + lane;
+      const bool live = v < v1;
+      const int li = u * 64 + lane;
+      float l[NCLS], mx, yt[NCLS], wt[NCLS];
+#pragma unroll
+      for (int k = 0; k < NCLS; ++k) {
+        l[k] = ((lp[par][0][k][li] + lp[par][1][k][li]) + (lp[par][2][k][li] + lp[par][3][k][li])) + bias[k];
+        yt[k] = tv[par][2 * k][li]; wt[k] = tv[par][2 * k + 1][li];
+      }
+      mx = l[0];
+#pragma unroll
+      for (int k = 1; k < NCLS; ++k) mx = fmaxf(mx, l[k]);
+      float e[NCLS], ssum = 0.f;
+#pragma unroll
+      for (int k = 0; k < NCLS; ++k) { e[k] = __expf(l[k] - mx); ssum += e[k]; }
+      const float inv = 1.f / ssum;
+      float g[NCLS], dl[NCLS], dot = 0.f;
+#pragma unroll
+      for (int k = 0; k < NCLS; ++k) {
+        const float pr = e[k] * inv;
+        g[k] = wt[k] * (lc[k][0] + lc[k][1] * yt[k]) - lc[k][2] * wt[k] * yt[k] / (pr + 1e-12f);
+        e[k] = pr;
+        dot += g[k] * pr;
+      }
+#pragma unroll
+      for (int k = 0; k < NCLS; ++k) dl[k] = live ? e[k] * (g[k] - dot) * lscale : 0.f;      // softmax backward (head_loss_bwd_kernel); a lane past the end adds zeros
+      [[maybe_unused]] V8T<T> o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < NCLS; ++k) a = fmaf(dl[k], W[k][j], a);
+        const float dz = to_f32<T>(from_f32<T>(a));                    // the gradient head_loss_bwd_kernel stored
+        const float d = zv[u][j] > 0.f ? dz : 0.f;
+        if (PASS == 1) {
+          acc[2 * j] += d;
+          acc[2 * j + 1] += d * (yv[u][j] - mu[j]) * is[j];
+#pragma unroll
+          for (int k = 0; k < NCLS; ++k) acc[16 + k * 8 + j] = fmaf(dl[k], zv[u][j], acc[16 + k * 8 + j]);
+        } else {
+          const float xh = (yv[u][j] - mu[j]) * is[j];
+          o[j] = from_f32<T>(ca[j] * (d - c1[j] - xh * c2[j]));
+        }
+      }
+      if (PASS == 1) {
+#pragma unroll
+        for (int k = 0; k < NCLS; ++k) acc[16 + NCLS * 8 + k] += dl[k];      // (every plane's wave: plane 0's copy is the one kept)
+        if (pl == 0 && live) {
+#pragma unroll
+          for (int k = 0; k < NCLS; ++k) p.dl[((long long)n * p.vox + v) * NCLS + k] = dl[k];
+        }
+      } else if (live) {
+        *(V8T<T>*)((T*)p.dy + n * p.dy_ss + (long long)pl * p.vox * 8 + v * 8) = o;
+      }
+    }
+  }
+  if (PASS == 1) {
+    // a wave owns its plane: its 64 lanes' sums are the block's row of that plane (no cross-wave step)
+    const long long part = (long long)n * gridDim.x + blockIdx.x;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const float v = wave_sum(acc[i]);
+      if (lane == 0) {
+        if (i < 16) p.bnslab[(part * 32 + pl * 8 + (i >> 1)) * 2 + (i & 1)] = v;
+        else if (i < 16 + NCLS * 8) p.dwslab[part * (NCLS * 33) + pl * NCLS * 8 + (i - 16)] = v;      // [planes][NCLS][8]
+        else if (pl == 0) p.dwslab[part * (NCLS * 33) + 4 * NCLS * 8 + (i - 16 - NCLS * 8)] = v;     // [NCLS] bias partials
+      }
+    }
+  }
+}
+
+// PASS 2 without the head: dy = a (dz' - c1 - xhat c2) with dz = W^T dl from the logit gradients PASS 1 left (8 NCLS bytes per voxel
+// instead of the logits, the softmax and the loss terms again).  Plane = grid dimension (wave-uniform constants), two voxels per thread.
+template <typename T, int NCLS>
+__global__ __launch_bounds__(256) void head_bn_apply_kernel(HeadBnBwdParams p) {
+  const int pl = blockIdx.y, n = blockIdx.z;
+  const long long vb = (long long)blockIdx.x * 512 + threadIdx.x;
+  float sc[8], sh[8], mu[8], is[8], W[NCLS][8], ca[8], c1[8], c2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = pl * 8 + j;
+    sc[j] = p.scale[c]; sh[j] = p.shift[c]; mu[j] = p.mean[c]; is[j] = p.invstd[c];
+    ca[j] = p.bncoef[c * 3]; c1[j] = p.bncoef[c * 3 + 1]; c2[j] = p.bncoef[c * 3 + 2];
+#pragma unroll
+    for (int k = 0; k < NCLS; ++k) W[k][j] = p.w[k * 32 + c];
+  }
+  const long long po = (long long)pl * p.vox * 8;
+  V8T<T> yy[2];
+  float dl[2][NCLS];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const long long v = vb + u * 256;
+    if (v < p.vox) {
+      yy[u] = *(const V8T<T>*)((const T*)p.y + n * p.y_ss + po + v * 8);
+#pragma unroll
+      for (int k = 0; k < NCLS; ++k) dl[u][k] = p.dl[((long long)n * p.vox + v) * NCLS + k];
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const long long v = vb + u * 256;
+    if (v >= p.vox) continue;
+    V8T<T> o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float yv = to_f32<T>(yy[u][j]);
+      const float zv = to_f32<T>(from_f32<T>(fmaxf(fmaf(sc[j], yv, sh[j]), 0.f)));
+      float a = 0.f;
+#pragma unroll
+      for (int k = 0; k < NCLS; ++k) a = fmaf(dl[u][k], W[k][j], a);
+      const float dz = to_f32<T>(from_f32<T>(a));
+      const float d = zv > 0.f ? dz : 0.f;
+      const float xh = (yv - mu[j]) * is[j];
+      o[j] = from_f32<T>(ca[j] * (d - c1[j] - xh * c2[j]));
+    }
+    *(V8T<T>*)((T*)p.dy + n * p.dy_ss + po + v * 8) = o;
+  }
+}
+
 // The same backward for the shapes whose dW partials do not fit the register file (PL * NCLS > 16: base 64 with three or
 // more classes, base 32 with five or more).  Two phases per 256-voxel chunk: (1) one thread per voxel computes dl and
 // dx = W^T dl and parks its x planes and dl in LDS; (2) the workgroup re-reads them as 256 / PL voxel lanes per channel
@@ -1482,6 +1719,46 @@ int iunet_head_loss_bwd_dev(int dtype, const void* x, long long x_ss, int C0, co
   IUNET_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "head_loss_bwd_dev: in_scale and in_shift come together");
   return head_loss_bwd_impl(dtype, x, x_ss, C0, w, bias, ncls, target, weight, tdtype, coef, 0.f, dx, dx_ss, dwslab, N, vox,
                             in_scale, in_shift, stream, state);
+}
+/* [r5] head backward + the last stage conv's BatchNorm + ReLU backward in two passes over that conv's raw output y (head_bn_bwd_kernel):
+ * dwslab as iunet_head_loss_bwd ([iunet_head_loss_bwd_num_parts][ncls * 33]), dgamma / dbeta / bncoef as iunet_bn_relu_bwd, dy = the
+ * gradient of y.  bnslab: iunet_bn_bwd_num_parts(N, vox) * 64 floats; dl_scratch: N * vox * ncls floats (the logit gradients between the
+ * two passes).  loss scale: state[0] when state is given, else loss_scale. */
+int iunet_head_bn_bwd_ok(int C0, int ncls) { return C0 == 32 && ncls >= 2 && ncls <= 4; }
+int iunet_head_bn_bwd(int dtype, const void* y, long long y_ss, int C0, const void* w, const void* bias, int ncls, const void* target,
+                      const void* weight, int tdtype, const void* coef, float loss_scale, const void* state, const void* scale,
+                      const void* shift, const void* mean, const void* invstd, const void* gamma, void* dgamma, void* dbeta, void* dy,
+                      long long dy_ss, void* dwslab, void* bnslab, void* bncoef, void* dl_scratch, int N, long long vox, void* stream) {
+  DT_OK(dtype);
+  IUNET_REQUIRE(y && w && bias && target && coef && scale && shift && mean && invstd && gamma && dgamma && dbeta && dy && dwslab && bnslab && bncoef && dl_scratch,
+                "head_bn_bwd: null pointer");
+  IUNET_REQUIRE(iunet_head_bn_bwd_ok(C0, ncls), "head_bn_bwd: 32 head input channels and 2..4 classes (got %d, %d): run iunet_head_loss_bwd + iunet_bn_relu_bwd", C0, ncls);
+  IUNET_REQUIRE(N > 0 && vox > 0, "head_bn_bwd: N %d, %lld voxels", N, vox);
+  HeadBnBwdParams p{};
+  p.y = y; p.y_ss = y_ss; p.w = (const float*)w; p.bias = (const float*)bias; p.target = target; p.weight = weight; p.tdtype = tdtype;
+  p.coef = (const float*)coef; p.loss_scale = loss_scale; p.loss_scale_dev = (const float*)state;
+  p.scale = (const float*)scale; p.shift = (const float*)shift; p.mean = (const float*)mean; p.invstd = (const float*)invstd;
+  p.bncoef = (const float*)bncoef; p.bnslab = (float*)bnslab; p.dwslab = (float*)dwslab; p.dy = dy; p.dy_ss = dy_ss;
+  p.dl = (float*)dl_scratch;
+  p.vox = vox; p.per_block = BN_BWD_PER_BLOCK;
+  static_assert(BN_BWD_PER_BLOCK == 256 * 8, "head_bn_bwd: one row per block for both slabs (iunet_head_loss_bwd_num_parts = iunet_bn_bwd_num_parts)");
+  const int chunks = (int)((vox + p.per_block - 1) / p.per_block);
+  dim3 grid(chunks, N);
+#define HBB(TT, PASS) switch (ncls) { case 2: hipLaunchKernelGGL((head_bn_bwd_kernel<TT, 2, PASS>), grid, dim3(256), 0, (hipStream_t)stream, p); break; \
+    case 3: hipLaunchKernelGGL((head_bn_bwd_kernel<TT, 3, PASS>), grid, dim3(256), 0, (hipStream_t)stream, p); break; \
+    default: hipLaunchKernelGGL((head_bn_bwd_kernel<TT, 4, PASS>), grid, dim3(256), 0, (hipStream_t)stream, p); break; }
+  if (dtype == 0) { HBB(f16, 1) } else { HBB(bf16, 1) }
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(32), dim3(256), 0, (hipStream_t)stream, (const float*)bnslab, chunks * N, 32,
+                     (double)N * (double)vox, (const float*)gamma, (const float*)invstd, (float*)dgamma, (float*)dbeta, (float*)bncoef);
+#undef HBB
+  dim3 g2((unsigned)((vox + 511) / 512), 4, N);
+#define HBA(TT) switch (ncls) { case 2: hipLaunchKernelGGL((head_bn_apply_kernel<TT, 2>), g2, dim3(256), 0, (hipStream_t)stream, p); break; \
+    case 3: hipLaunchKernelGGL((head_bn_apply_kernel<TT, 3>), g2, dim3(256), 0, (hipStream_t)stream, p); break; \
+    default: hipLaunchKernelGGL((head_bn_apply_kernel<TT, 4>), g2, dim3(256), 0, (hipStream_t)stream, p); break; }
+  if (dtype == 0) { HBA(f16) } else { HBA(bf16) }
+#undef HBA
+  IUNET_CHECK_HIP(hipGetLastError());
+  return IUNET_OK;
 }
 /* dW [ncls][C0], db [ncls] of the head from the reduced slab row of iunet_head_loss_bwd */
 int iunet_head_grad_scatter(const void* row, void* dw, void* db, int ncls, int C0, void* stream) {

@@ -167,6 +167,9 @@ _SIGS = {
                                   c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     'iunet_conv3_dgrad_bnstats_lay': [c_int, c_int, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_void_p, c_void_p, c_ll, c_void_p, c_void_p,
                                       c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    'iunet_head_bn_bwd_ok': [c_int, c_int],
+    'iunet_head_bn_bwd': [c_int, c_void_p, c_ll, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_float, c_void_p, c_void_p,
+                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_ll, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_ll, c_void_p],
     'iunet_bn_relu_bwd_apply': [c_int, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_ll, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                 c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_ll, c_void_p],
     'iunet_gn_num_parts': [c_int, c_ll],

@@ -68,6 +68,9 @@ class TrainEngine:
         self.fuse_bw = not self.gn and not os.environ.get('IUNET_NO_BW_FUSION')
         self.gn_conv_stats = self.gn and not os.environ.get('IUNET_NO_GN_CONV_STATS')
         self.head_act = not self.gn and not os.environ.get('IUNET_NO_HEAD_ACT')     # A/B switch: materialise the last activation
+        # head backward + the last conv's BatchNorm backward in two passes over its raw output (iunet_head_bn_bwd; IUNET_NO_HEAD_BN_FUSION=1:
+        # the three-kernel sequence with the head's input gradient written and read back)
+        self.head_bn = self.head_act and not os.environ.get('IUNET_NO_HEAD_BN_FUSION')
         self._bw_ready = {}
         self._flatten()
         if self.pg is not None:
@@ -395,7 +398,7 @@ class TrainEngine:
 
     # ------------------------------------------------------------------ backward
     def _stage_conv_bwd(self, ws, name, dz_ptr, dz_ss, z_ptr, z_ss, x_ptr, x_ss, ci, co, l, dx_ptr, dx_ss, N,
-                        x_raw=None, x_act=None, pool_bwd=None, feeds=None):
+                        x_raw=None, x_act=None, pool_bwd=None, feeds=None, dy_ready=False):
         """Backward of one stage conv: BatchNorm + ReLU backward, weight gradient, data gradient.  `feeds`: name of the layer
         whose activation is this conv's only input (a stage's conv1 for its conv2) -- the data-gradient launch then also
         accumulates that layer's BatchNorm-backward sums in its epilogue (iunet_conv3_dgrad_bnstats), and that layer's own
@@ -406,7 +409,9 @@ class TrainEngine:
         bn = name.replace('conv', 'bn')
         dy = ws['dy']
         first = name == 'enc0.conv1'
-        if self.gn and pool_bwd is not None:
+        if dy_ready:
+            pass          # iunet_head_bn_bwd has written dy, dgamma and dbeta of this conv
+        elif self.gn and pool_bwd is not None:
             # encoder stage: dz = skip gradient + max-pool backward of dpool, formed on the fly in both passes (never written)
             dp_ptr, dp_ss, do = pool_bwd
             nv.call('iunet_gn_relu_pool_bwd', self.dt, self.dim, dz_ptr, dz_ss, dp_ptr, dp_ss, self._P(ws['y.' + name]), co * v, self._P(dy), co * v,
@@ -480,7 +485,17 @@ class TrainEngine:
         v0 = _vox(dims[0])
         dfeat = ws['dz.dec0.conv2']
         nparts = nv.lib().iunet_head_loss_bwd_num_parts(N, v0, self.ncls, ch[0])
-        if self.head_act:       # (the loss scale is read from the device state)
+        dy_ready = None
+        if self.head_bn and nv.lib().iunet_head_bn_bwd_ok(ch[0], self.ncls):
+            # head backward + BatchNorm backward of dec0.conv2 in two passes over its raw output: the head's input gradient is never written
+            bn = 'dec0.bn2'
+            nv.call('iunet_head_bn_bwd', self.dt, self._P(ws['y.dec0.conv2']), ch[0] * v0, ch[0], nv.ptr(self.p('head.weight')),
+                    nv.ptr(self.p('head.bias')), self.ncls, nv.ptr(y), nv.ptr(w), tdt, nv.ptr(ws['coef']), 0.0, nv.ptr(self.state),
+                    nv.ptr(ws['scale.dec0.conv2']), nv.ptr(ws['shift.dec0.conv2']), nv.ptr(ws['mean.dec0.conv2']), nv.ptr(ws['invstd.dec0.conv2']),
+                    nv.ptr(self.p(bn + '.weight')), nv.ptr(self.g(bn + '.weight')), nv.ptr(self.g(bn + '.bias')), self._P(ws['dy']), ch[0] * v0,
+                    nv.ptr(ws['hslab']), nv.ptr(ws['bnslab']), nv.ptr(ws['bncoef']), self._P(dfeat), N, v0, s)      # (dfeat: unused by this path, its scratch)
+            dy_ready = 'dec0.conv2'
+        elif self.head_act:       # (the loss scale is read from the device state)
             nv.call('iunet_head_loss_bwd_dev', self.dt, self._P(ws['y.dec0.conv2']), ch[0] * v0, ch[0], nv.ptr(self.p('head.weight')),
                     nv.ptr(self.p('head.bias')), self.ncls, nv.ptr(y), nv.ptr(w), tdt, nv.ptr(ws['coef']),
                     nv.ptr(self.state), self._P(dfeat), ch[0] * v0, nv.ptr(ws['hslab']), nv.ptr(ws['scale.dec0.conv2']),
@@ -499,7 +514,8 @@ class TrainEngine:
             dz1, dz2 = ws[f'dz.dec{l}.conv1'], ws[f'dz.dec{l}.conv2']
             x2, act, _ = self._conv2_input(ws, f'dec{l}', l, N)
             self._stage_conv_bwd(ws, f'dec{l}.conv2', self._P(dz2), ch[l] * v, self._P(z2), ch[l] * v, x2,
-                                 ch[l] * v, ch[l], ch[l], l, self._P(dz1), ch[l] * v, N, x_act=act, feeds=f'dec{l}.conv1')
+                                 ch[l] * v, ch[l], ch[l], l, self._P(dz1), ch[l] * v, N, x_act=act, feeds=f'dec{l}.conv1',
+                                 dy_ready=dy_ready == f'dec{l}.conv2')
             self._stage_conv_bwd(ws, f'dec{l}.conv1', self._P(dz1), ch[l] * v, self._P(z1), ch[l] * v,
                                  self._P(ws[f'cat{l}']), 2 * ch[l] * v, 2 * ch[l], ch[l], l, self._P(ws[f'dcat{l}']),
                                  2 * ch[l] * v, N)

@@ -557,6 +557,64 @@ def test_conv_with_per_sample_statistics(nv, nd, cin, cout, lay, shape):
     assert (outs[0][0].float() - outs[1][0].float()).abs().max().item() <= 0.05      # a few bf16 ulps of an O(1) activation
 
 
+@pytest.mark.parametrize('ncls,T,weighted', [(2, torch.bfloat16, True), (3, torch.float16, False), (4, torch.bfloat16, True)])
+def test_head_and_batchnorm_backward_in_two_passes(nv, ncls, T, weighted):
+    """iunet_head_bn_bwd (the head's backward + the last conv's BatchNorm + ReLU backward in two passes over that conv's raw output, the
+    head's input gradient never written) against the sequence it replaces: iunet_head_loss_bwd_act -> iunet_bn_relu_bwd.  The fused
+    kernel adds the logit's 32 terms plane by plane, so a gradient may sit one rounding of T away: dy within 2 ulp of T on (almost)
+    every element, the reduced quantities (head dW / db, dgamma, dbeta) within 1e-4 of their magnitude."""
+    g = torch.Generator().manual_seed(41)
+    dt = nv.DTYPE_CODE[T]
+    N, C0 = 2, 32
+    vox = 5000                                                        # three blocks per sample, the last one ragged
+    y = torch.randn((N, C0, vox), generator=g) * 1.2
+    yb = blocked(y, T).cuda()
+    w = (torch.randn(ncls, C0, generator=g) * 0.3).cuda()
+    b = (torch.randn(ncls, generator=g) * 0.1).cuda()
+    lab = torch.randint(0, ncls, (N, vox), generator=g)
+    tgt = torch.stack([(lab == c) for c in range(ncls)], 1).to(torch.float16).contiguous().cuda()
+    wt = (torch.rand((N, ncls, vox), generator=g) > 0.2).to(torch.float16).contiguous().cuda() if weighted else None
+    gamma = (0.5 + torch.rand(C0, generator=g)).cuda()
+    mean, invstd = (0.1 * torch.randn(C0, generator=g)).cuda(), (0.6 + torch.rand(C0, generator=g)).cuda()
+    scale = (gamma * invstd).contiguous()
+    shift = (0.2 * torch.randn(C0, generator=g)).cuda()
+    coef = torch.tensor([[-0.8e-4, 1.9e-4, 1.1e-4], [0.5e-4, -1.2e-4, 0.9e-4], [0.2e-4, 0.7e-4, 1.0e-4], [-0.3e-4, 0.4e-4, 0.6e-4]])[:ncls].contiguous().cuda()
+    lscale = 1024.0
+    s = nv.stream()
+    parts = nv.lib().iunet_head_loss_bwd_num_parts(N, vox, ncls, C0)
+    assert parts == nv.lib().iunet_bn_bwd_num_parts(N, vox) and nv.lib().iunet_head_bn_bwd_ok(C0, ncls) == 1 and nv.lib().iunet_head_bn_bwd_ok(64, ncls) == 0
+    out = []
+    for fused in (False, True):
+        dy = torch.full((N * C0 * vox,), float('nan'), dtype=T, device='cuda')
+        hslab = torch.full((parts * ncls * (C0 + 1),), float('nan'), device='cuda')
+        bnslab = torch.full((parts * C0 * 2,), float('nan'), device='cuda')
+        bncoef = torch.empty(3 * C0, device='cuda')
+        dgam, dbet = torch.empty(C0, device='cuda'), torch.empty(C0, device='cuda')
+        dlbuf = torch.full((N * vox * ncls,), float('nan'), device='cuda')
+        if fused:
+            nv.call('iunet_head_bn_bwd', dt, nv.ptr(yb), C0 * vox, C0, nv.ptr(w), nv.ptr(b), ncls, nv.ptr(tgt), nv.ptr(wt), 1, nv.ptr(coef), lscale, None,
+                    nv.ptr(scale), nv.ptr(shift), nv.ptr(mean), nv.ptr(invstd), nv.ptr(gamma), nv.ptr(dgam), nv.ptr(dbet), nv.ptr(dy), C0 * vox,
+                    nv.ptr(hslab), nv.ptr(bnslab), nv.ptr(bncoef), nv.ptr(dlbuf), N, vox, s)
+        else:
+            dz = torch.full((N * C0 * vox,), float('nan'), dtype=T, device='cuda')
+            nv.call('iunet_head_loss_bwd_act', dt, nv.ptr(yb), C0 * vox, C0, nv.ptr(w), nv.ptr(b), ncls, nv.ptr(tgt), nv.ptr(wt), 1, nv.ptr(coef), lscale,
+                    nv.ptr(dz), C0 * vox, nv.ptr(hslab), nv.ptr(scale), nv.ptr(shift), N, vox, s)
+            nv.call('iunet_bn_relu_bwd', dt, nv.ptr(dz), C0 * vox, None, 0, nv.ptr(yb), C0 * vox, nv.ptr(dy), C0 * vox, nv.ptr(mean), nv.ptr(invstd),
+                    nv.ptr(gamma), nv.ptr(scale), nv.ptr(shift), nv.ptr(dgam), nv.ptr(dbet), nv.ptr(bnslab), nv.ptr(bncoef), C0, N, vox, s)
+        hrow = torch.empty(ncls * (C0 + 1), device='cuda')
+        nv.call('iunet_reduce_slab', nv.ptr(hslab), parts, ncls * (C0 + 1), nv.ptr(hrow), 1.0, 0, s)
+        torch.cuda.synchronize()
+        out.append((dy.float().cpu(), hrow.cpu(), dgam.cpu(), dbet.cpu(), bncoef.cpu()))
+    (dy0, h0, dg0, db0, c0), (dy1, h1, dg1, db1, c1) = out
+    assert torch.isfinite(dy1).all() and dy0.abs().max() > 0
+    ulp = 2.0 ** (-7 if T == torch.bfloat16 else -10)
+    d = (dy0 - dy1).abs()
+    tol = 2 * ulp * torch.maximum(dy0.abs(), dy1.abs()) + 1e-6 * dy0.abs().max()
+    assert (d > tol).float().mean().item() < 1e-4, ((d > tol).float().mean().item(), d.max().item(), dy0.abs().max().item())
+    for a, bb in ((h0, h1), (dg0, dg1), (db0, db1), (c0, c1)):
+        assert (a - bb).abs().max().item() <= 1e-4 * a.abs().max().item() + 1e-7, ((a - bb).abs().max().item(), a.abs().max().item())
+
+
 @pytest.mark.parametrize('nd', [2, 3])
 def test_bn_relu_pool_fwd_equals_two_passes(nv, nd):
     """iunet_bn_relu_pool_fwd == iunet_bn_relu_fwd followed by iunet_maxpool_fwd, bit for bit (both outputs)."""
