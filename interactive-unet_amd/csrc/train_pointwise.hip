@@ -907,12 +907,12 @@ __global__ __launch_bounds__(256, HBB_OCC) void head_bn_bwd_kernel(HeadBnBwdPara
       float e[NCLS], ssum = 0.f;
 #pragma unroll
       for (int k = 0; k < NCLS; ++k) { e[k] = __expf(l[k] - mx); ssum += e[k]; }
-      const float inv = 1.f / ssum;
+      const float inv = __builtin_amdgcn_rcpf(ssum);      // (1 ulp: far inside the rounding of dz to T; an IEEE division is ~10 instructions)
       float g[NCLS], dl[NCLS], dot = 0.f;
 #pragma unroll
       for (int k = 0; k < NCLS; ++k) {
         const float pr = e[k] * inv;
-        g[k] = wt[k] * (lc[k][0] + lc[k][1] * yt[k]) - lc[k][2] * wt[k] * yt[k] / (pr + 1e-12f);
+        g[k] = wt[k] * (lc[k][0] + lc[k][1] * yt[k]) - lc[k][2] * wt[k] * yt[k] * __builtin_amdgcn_rcpf(pr + 1e-12f);
         e[k] = pr;
         dot += g[k] * pr;
       }
