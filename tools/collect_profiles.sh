@@ -66,12 +66,12 @@ python3 $R/tools/bench_convT.py 30 > $OUT/${RND}_convT_layers.txt 2>/dev/null
 # the training step and the C5 prediction forward by kernel
 rm -rf $OUT/tmp_tr; rocprofv3 --kernel-trace --output-format csv -d $OUT/tmp_tr -o tr -- python3 $R/tools/bench_train3d.py 10 > $OUT/train3d.log 2>&1
 python3 $R/tools/step_profile.py $OUT/tmp_tr/tr_kernel_trace.csv 13 40 > $OUT/${RND}_train_step_by_kernel.txt
-python3 $R/tools/step_timeline.py $OUT/tmp_tr/tr_kernel_trace.csv 135 2 > $OUT/${RND}_train3d_step_timeline.txt; rm -rf $OUT/tmp_tr      # one step in launch order (135 launches)
+python3 $R/tools/step_timeline.py $OUT/tmp_tr/tr_kernel_trace.csv 134 2 > $OUT/${RND}_train3d_step_timeline.txt; rm -rf $OUT/tmp_tr      # one step in launch order (134 launches)
 rm -rf $OUT/tmp_c5; rocprofv3 --kernel-trace --output-format csv -d $OUT/tmp_c5 -o c5 -- python3 $R/tools/bench_c5_predict.py 10 > $OUT/c5_predict.log 2>&1
 python3 $R/tools/step_profile.py $OUT/tmp_c5/c5_kernel_trace.csv 13 20 > $OUT/${RND}_c5_forward_by_kernel.txt; rm -rf $OUT/tmp_c5
 rm -rf $OUT/tmp_t2; rocprofv3 --kernel-trace --output-format csv -d $OUT/tmp_t2 -o t2 -- python3 $R/tools/bench_train2d.py 8 > $OUT/train2d.log 2>&1
 python3 $R/tools/step_profile.py $OUT/tmp_t2/t2_kernel_trace.csv 128 40 > $OUT/${RND}_train2d_step_by_kernel.txt
-python3 $R/tools/step_timeline.py $OUT/tmp_t2/t2_kernel_trace.csv 142 2 > $OUT/${RND}_train2d_step_timeline.txt; rm -rf $OUT/tmp_t2      # 2 modes x (4 + 30 + 30) steps
+python3 $R/tools/step_timeline.py $OUT/tmp_t2/t2_kernel_trace.csv 141 2 > $OUT/${RND}_train2d_step_timeline.txt; rm -rf $OUT/tmp_t2      # 2 modes x (4 + 30 + 30) steps
 rm -rf $OUT/tmp_pp; rocprofv3 --kernel-trace --output-format csv -d $OUT/tmp_pp -o pp -- python3 $R/tools/bench_predict3d.py 10 fp16x2 > $OUT/predict3d.log 2>&1
 python3 $R/tools/step_profile.py $OUT/tmp_pp/pp_kernel_trace.csv 26 30 > $OUT/${RND}_predict_x2m_by_kernel.txt; rm -rf $OUT/tmp_pp      # 13 volumes of 4 blocks = 26 two-block forwards
 python3 $R/tools/bench_train2d.py 1 8 2>/dev/null | grep -v amdgpu > $OUT/${RND}_train2d_latency.txt
