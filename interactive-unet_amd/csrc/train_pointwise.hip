@@ -32,31 +32,35 @@ __device__ __forceinline__ void block_reduce_store(const float (&vals)[NV], floa
 
 // ------------------------------------------------------------------ BN statistics -> scale/shift
 // slab [nparts][C][2] (sum, sumsq of the raw conv output).  One block per channel.
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ slab, int nparts, int C, double count,
-                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                          float* running_mean, float* running_var, float momentum,
-                                                          float eps, float* scale, float* shift, float* mean_o,
-                                                          float* invstd_o) {
-  const int c = blockIdx.x;
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ slab, int nparts, int C, double count,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float* running_mean, float* running_var, float momentum,
+                                                           float eps, float* scale, float* shift, float* mean_o,
+                                                           float* invstd_o) {
+  // 256 threads, or 1 024 for slabs of thousands of rows (the first conv writes one row per TILE: 8 192 at 2 x 128^3, 16 us on 256 threads)
+  const int c = blockIdx.x, nt = (int)blockDim.x, nw = nt >> 6;
   double s = 0.0, s2 = 0.0;
-  for (int p = threadIdx.x; p < nparts; p += 256) {
-    s += (double)slab[((long long)p * C + c) * 2];
-    s2 += (double)slab[((long long)p * C + c) * 2 + 1];
+  for (int p = threadIdx.x; p < nparts; p += nt) {
+    const float2 v = *(const float2*)(slab + ((long long)p * C + c) * 2);
+    s += (double)v.x; s2 += (double)v.y;
   }
-  // wave sums by lane exchange, the four waves meet in LDS: one barrier instead of the nine of a 256-wide LDS tree (these
+  // wave sums by lane exchange, the waves meet in LDS: one barrier instead of the nine of a 256-wide LDS tree (these
   // kernels are a few microseconds of pure latency between two convolutions, 28 of them per training step)
-  __shared__ double red[2][4];
+  __shared__ double red[2][16];
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); s2 += __shfl_xor(s2, o); }
   if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = s2; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    red[0][0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
-    red[1][0] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
-  }
-  if (threadIdx.x == 0) {
-    const double mean = red[0][0] / count;
-    double var = red[1][0] / count - mean * mean;
+    // (256 threads: ((w0 + w1) + (w2 + w3)), the order this kernel has always had; 1 024: the same tree over four such groups)
+    double g0[4], g1[4];
+    for (int g = 0; g < nw / 4; ++g) {
+      g0[g] = (red[0][4 * g] + red[0][4 * g + 1]) + (red[0][4 * g + 2] + red[0][4 * g + 3]);
+      g1[g] = (red[1][4 * g] + red[1][4 * g + 1]) + (red[1][4 * g + 2] + red[1][4 * g + 3]);
+    }
+    const double t0 = nw == 4 ? g0[0] : (g0[0] + g0[1]) + (g0[2] + g0[3]), t1 = nw == 4 ? g1[0] : (g1[0] + g1[1]) + (g1[2] + g1[3]);
+    const double mean = t0 / count;
+    double var = t1 / count - mean * mean;
     if (var < 0.0) var = 0.0;
     const float invstd = (float)(1.0 / sqrt(var + (double)eps));
     const float sc = gamma[c] * invstd;
@@ -1295,7 +1299,7 @@ int iunet_bn_finalize(const void* slab, int nparts, int C, double count, const v
                       void* running_mean, void* running_var, float momentum, float eps, void* scale, void* shift,
                       void* mean, void* invstd, void* stream) {
   IUNET_REQUIRE(slab && gamma && beta && scale && shift && mean && invstd, "bn_finalize: null pointer");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, (const float*)slab, nparts, C, count,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(nparts >= 2048 ? 1024 : 256), 0, (hipStream_t)stream, (const float*)slab, nparts, C, count,
                      (const float*)gamma, (const float*)beta, (float*)running_mean, (float*)running_var, momentum, eps,
                      (float*)scale, (float*)shift, (float*)mean, (float*)invstd);
   IUNET_CHECK_HIP(hipGetLastError());
