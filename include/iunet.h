@@ -622,8 +622,8 @@ int iunet_head_loss_bwd_dev(int dtype, const void* x, long long x_ss, int C0, co
 /* [r5] The head's backward and the BatchNorm + ReLU backward of the last stage conv (training with the head reading that conv's RAW
  * output y: iunet_head_loss_fwd_act) in two passes over y -- the head's input gradient is never written; replaces iunet_head_loss_bwd_dev
  * + iunet_bn_relu_bwd for that layer (y read twice and dy written once instead of y three times, dz written once and read twice).
- * iunet_head_bn_bwd_ok: 32 head input channels, 2..4 classes.  dwslab / the reduction of its rows as iunet_head_loss_bwd; dgamma, dbeta,
- * bncoef (3 * 32 floats of scratch) as iunet_bn_relu_bwd; bnslab: iunet_bn_bwd_num_parts(N, vox) * 64 floats; dl_scratch: N * vox * ncls
+ * iunet_head_bn_bwd_ok: 32 or 64 head input channels, 2..4 classes.  dwslab / the reduction of its rows as iunet_head_loss_bwd; dgamma, dbeta,
+ * bncoef (3 * C0 floats of scratch) as iunet_bn_relu_bwd; bnslab: iunet_bn_bwd_num_parts(N, vox) * 2 C0 floats; dl_scratch: N * vox * ncls
  * floats (the logit gradients, written by the first pass and read by the second); dy: the gradient of y.
  * Loss scale: state[0] when state is not NULL (the training handle's device state), else loss_scale. */
 int iunet_head_bn_bwd_ok(int C0, int ncls);

@@ -811,8 +811,9 @@ struct HeadBnBwdParams {
 #ifndef HBB_OCC
 #define HBB_OCC 1
 #endif
-template <typename T, int NCLS, int PASS>
-__global__ __launch_bounds__(256, HBB_OCC) void head_bn_bwd_kernel(HeadBnBwdParams p) {
+template <typename T, int NCLS, int PASS, int PL>      // PL: channel planes of the head input = waves per workgroup (4: base 32, 8: base 64)
+__global__ __launch_bounds__(PL * 64, HBB_OCC) void head_bn_bwd_kernel(HeadBnBwdParams p) {
+  constexpr int C0 = PL * 8;
   constexpr int NV = 16 + NCLS * 8 + NCLS;           // PASS 1: partial sums per lane
   const int n = blockIdx.y, lane = threadIdx.x & 63;
   const int pl = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave = channel plane: every per-channel constant is wave-uniform (scalar registers)
@@ -824,7 +825,7 @@ __global__ __launch_bounds__(256, HBB_OCC) void head_bn_bwd_kernel(HeadBnBwdPara
     const int c = pl * 8 + j;
     sc[j] = p.scale[c]; sh[j] = p.shift[c]; mu[j] = p.mean[c]; is[j] = p.invstd[c];
 #pragma unroll
-    for (int k = 0; k < NCLS; ++k) W[k][j] = p.w[k * 32 + c];
+    for (int k = 0; k < NCLS; ++k) W[k][j] = p.w[k * C0 + c];
     if (PASS == 2) { ca[j] = p.bncoef[c * 3]; c1[j] = p.bncoef[c * 3 + 1]; c2[j] = p.bncoef[c * 3 + 2]; }
   }
   float bias[NCLS], lc[NCLS][3];
@@ -836,10 +837,10 @@ __global__ __launch_bounds__(256, HBB_OCC) void head_bn_bwd_kernel(HeadBnBwdPara
     for (int i = 0; i < NV; ++i) acc[i] = 0.f;
   }
   constexpr int U = HBB_U;                           // voxels per lane and iteration: 64 U voxels per barrier
-  __shared__ float lp[2][4][NCLS][64 * U];           // the planes' shares of the logits, by iteration parity
+  __shared__ float lp[2][PL][NCLS][64 * U];           // the planes' shares of the logits, by iteration parity
   __shared__ float tv[2][2 * NCLS][64 * U];          // targets and weights of the voxels: value 2 k + which, loaded ONCE per voxel (wave pl takes
-                                                     // values pl, pl + 4) -- every wave loading all of them cost 150-190 us of the two passes' 430
-  constexpr int NTV = (2 * NCLS + 3) / 4;            // values per wave
+                                                     // values pl, pl + PL) -- every wave loading all of them cost 150-190 us of the two passes' 430
+  constexpr int NTV = (2 * NCLS + PL - 1) / PL;      // values per wave
   const long long v0 = (long long)blockIdx.x * p.per_block, v1 = min(v0 + p.per_block, p.vox);
   const T* yin = (const T*)p.y + n * p.y_ss + (long long)pl * p.vox * 8;
   const int niter = (int)((v1 - v0 + 64 * U - 1) / (64 * U));
@@ -852,7 +853,7 @@ __global__ __launch_bounds__(256, HBB_OCC) void head_bn_bwd_kernel(HeadBnBwdPara
     for (int u = 0; u < U; ++u)
 #pragma unroll
       for (int i = 0; i < NTV; ++i) {
-        const int idx = pl + 4 * i;                  // wave-uniform
+        const int idx = pl + PL * i;                 // wave-uniform
         if (idx < 2 * NCLS) {
           const long long to = ((long long)n * NCLS + (idx >> 1)) * p.vox + min(base + u * 64 + lane, v1 - 1);
           t[u][i] = (idx & 1) ? (p.weight ? load_t(p.weight, to, p.tdtype) : 1.f) : load_t(p.target, to, p.tdtype);
@@ -891,7 +892,7 @@ __global__ __launch_bounds__(256, HBB_OCC) void head_bn_bwd_kernel(HeadBnBwdPara
 #pragma unroll
       for (int k = 0; k < NCLS; ++k) lp[par][pl][k][u * 64 + lane] = part[k];
 #pragma unroll
-      for (int i = 0; i < NTV; ++i) if (pl + 4 * i < 2 * NCLS) tv[par][pl + 4 * i][u * 64 + lane] = tcur[u][i];
+      for (int i = 0; i < NTV; ++i) if (pl + PL * i < 2 * NCLS) tv[par][pl + PL * i][u * 64 + lane] = tcur[u][i];
     }
     __syncthreads();                                 // (one barrier per 64 U voxels: the other parity is being written by nobody yet -- its readers passed this barrier)
 #pragma unroll
@@ -902,7 +903,9 @@ __global__ __launch_bounds__(256, HBB_OCC) void head_bn_bwd_kernel(HeadBnBwdPara
       float l[NCLS], mx, yt[NCLS], wt[NCLS];
 #pragma unroll
       for (int k = 0; k < NCLS; ++k) {
-        l[k] = ((lp[par][0][k][li] + lp[par][1][k][li]) + (lp[par][2][k][li] + lp[par][3][k][li])) + bias[k];
+        float lsum = (lp[par][0][k][li] + lp[par][1][k][li]) + (lp[par][2][k][li] + lp[par][3][k][li]);
+        if (PL == 8) lsum += (lp[par][4][k][li] + lp[par][5][k][li]) + (lp[par][6][k][li] + lp[par][7][k][li]);
+        l[k] = lsum + bias[k];
         yt[k] = tv[par][2 * k][li]; wt[k] = tv[par][2 * k + 1][li];
       }
       mx = l[0];
@@ -959,9 +962,9 @@ __global__ __launch_bounds__(256, HBB_OCC) void head_bn_bwd_kernel(HeadBnBwdPara
     for (int i = 0; i < NV; ++i) {
       const float v = wave_sum(acc[i]);
       if (lane == 0) {
-        if (i < 16) p.bnslab[(part * 32 + pl * 8 + (i >> 1)) * 2 + (i & 1)] = v;
-        else if (i < 16 + NCLS * 8) p.dwslab[part * (NCLS * 33) + pl * NCLS * 8 + (i - 16)] = v;      // [planes][NCLS][8]
-        else if (pl == 0) p.dwslab[part * (NCLS * 33) + 4 * NCLS * 8 + (i - 16 - NCLS * 8)] = v;     // [NCLS] bias partials
+        if (i < 16) p.bnslab[(part * C0 + pl * 8 + (i >> 1)) * 2 + (i & 1)] = v;
+        else if (i < 16 + NCLS * 8) p.dwslab[part * (NCLS * (C0 + 1)) + pl * NCLS * 8 + (i - 16)] = v;      // [planes][NCLS][8]
+        else if (pl == 0) p.dwslab[part * (NCLS * (C0 + 1)) + PL * NCLS * 8 + (i - 16 - NCLS * 8)] = v;     // [NCLS] bias partials
       }
     }
   }
@@ -969,8 +972,9 @@ __global__ __launch_bounds__(256, HBB_OCC) void head_bn_bwd_kernel(HeadBnBwdPara
 
 // PASS 2 without the head: dy = a (dz' - c1 - xhat c2) with dz = W^T dl from the logit gradients PASS 1 left (8 NCLS bytes per voxel
 // instead of the logits, the softmax and the loss terms again).  Plane = grid dimension (wave-uniform constants), two voxels per thread.
-template <typename T, int NCLS>
+template <typename T, int NCLS, int PL>
 __global__ __launch_bounds__(256) void head_bn_apply_kernel(HeadBnBwdParams p) {
+  constexpr int C0 = PL * 8;
   const int pl = blockIdx.y, n = blockIdx.z;
   const long long vb = (long long)blockIdx.x * 512 + threadIdx.x;
   float sc[8], sh[8], mu[8], is[8], W[NCLS][8], ca[8], c1[8], c2[8];
@@ -980,7 +984,7 @@ __global__ __launch_bounds__(256) void head_bn_apply_kernel(HeadBnBwdParams p) {
     sc[j] = p.scale[c]; sh[j] = p.shift[c]; mu[j] = p.mean[c]; is[j] = p.invstd[c];
     ca[j] = p.bncoef[c * 3]; c1[j] = p.bncoef[c * 3 + 1]; c2[j] = p.bncoef[c * 3 + 2];
 #pragma unroll
-    for (int k = 0; k < NCLS; ++k) W[k][j] = p.w[k * 32 + c];
+    for (int k = 0; k < NCLS; ++k) W[k][j] = p.w[k * C0 + c];
   }
   const long long po = (long long)pl * p.vox * 8;
   V8T<T> yy[2];
@@ -1735,9 +1739,9 @@ int iunet_head_loss_bwd_dev(int dtype, const void* x, long long x_ss, int C0, co
 }
 /* [r5] head backward + the last stage conv's BatchNorm + ReLU backward in two passes over that conv's raw output y (head_bn_bwd_kernel):
  * dwslab as iunet_head_loss_bwd ([iunet_head_loss_bwd_num_parts][ncls * 33]), dgamma / dbeta / bncoef as iunet_bn_relu_bwd, dy = the
- * gradient of y.  bnslab: iunet_bn_bwd_num_parts(N, vox) * 64 floats; dl_scratch: N * vox * ncls floats (the logit gradients between the
+ * gradient of y.  bnslab: iunet_bn_bwd_num_parts(N, vox) * 2 C0 floats; dl_scratch: N * vox * ncls floats (the logit gradients between the
  * two passes).  loss scale: state[0] when state is given, else loss_scale. */
-int iunet_head_bn_bwd_ok(int C0, int ncls) { return C0 == 32 && ncls >= 2 && ncls <= 4; }
+int iunet_head_bn_bwd_ok(int C0, int ncls) { return (C0 == 32 || C0 == 64) && ncls >= 2 && ncls <= 4; }
 int iunet_head_bn_bwd(int dtype, const void* y, long long y_ss, int C0, const void* w, const void* bias, int ncls, const void* target,
                       const void* weight, int tdtype, const void* coef, float loss_scale, const void* state, const void* scale,
                       const void* shift, const void* mean, const void* invstd, const void* gamma, void* dgamma, void* dbeta, void* dy,
@@ -1745,7 +1749,7 @@ int iunet_head_bn_bwd(int dtype, const void* y, long long y_ss, int C0, const vo
   DT_OK(dtype);
   IUNET_REQUIRE(y && w && bias && target && coef && scale && shift && mean && invstd && gamma && dgamma && dbeta && dy && dwslab && bnslab && bncoef && dl_scratch,
                 "head_bn_bwd: null pointer");
-  IUNET_REQUIRE(iunet_head_bn_bwd_ok(C0, ncls), "head_bn_bwd: 32 head input channels and 2..4 classes (got %d, %d): run iunet_head_loss_bwd + iunet_bn_relu_bwd", C0, ncls);
+  IUNET_REQUIRE(iunet_head_bn_bwd_ok(C0, ncls), "head_bn_bwd: 32 or 64 head input channels and 2..4 classes (got %d, %d): run iunet_head_loss_bwd + iunet_bn_relu_bwd", C0, ncls);
   IUNET_REQUIRE(N > 0 && vox > 0, "head_bn_bwd: N %d, %lld voxels", N, vox);
   HeadBnBwdParams p{};
   p.y = y; p.y_ss = y_ss; p.w = (const float*)w; p.bias = (const float*)bias; p.target = target; p.weight = weight; p.tdtype = tdtype;
@@ -1757,18 +1761,18 @@ int iunet_head_bn_bwd(int dtype, const void* y, long long y_ss, int C0, const vo
   static_assert(BN_BWD_PER_BLOCK == 256 * 8, "head_bn_bwd: one row per block for both slabs (iunet_head_loss_bwd_num_parts = iunet_bn_bwd_num_parts)");
   const int chunks = (int)((vox + p.per_block - 1) / p.per_block);
   dim3 grid(chunks, N);
-#define HBB(TT, PASS) switch (ncls) { case 2: hipLaunchKernelGGL((head_bn_bwd_kernel<TT, 2, PASS>), grid, dim3(256), 0, (hipStream_t)stream, p); break; \
-    case 3: hipLaunchKernelGGL((head_bn_bwd_kernel<TT, 3, PASS>), grid, dim3(256), 0, (hipStream_t)stream, p); break; \
-    default: hipLaunchKernelGGL((head_bn_bwd_kernel<TT, 4, PASS>), grid, dim3(256), 0, (hipStream_t)stream, p); break; }
-  if (dtype == 0) { HBB(f16, 1) } else { HBB(bf16, 1) }
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(32), dim3(256), 0, (hipStream_t)stream, (const float*)bnslab, chunks * N, 32,
-                     (double)N * (double)vox, (const float*)gamma, (const float*)invstd, (float*)dgamma, (float*)dbeta, (float*)bncoef);
+#define HBB(TT, PLN) switch (ncls) { case 2: hipLaunchKernelGGL((head_bn_bwd_kernel<TT, 2, 1, PLN>), grid, dim3(PLN * 64), 0, (hipStream_t)stream, p); break; \
+    case 3: hipLaunchKernelGGL((head_bn_bwd_kernel<TT, 3, 1, PLN>), grid, dim3(PLN * 64), 0, (hipStream_t)stream, p); break; \
+    default: hipLaunchKernelGGL((head_bn_bwd_kernel<TT, 4, 1, PLN>), grid, dim3(PLN * 64), 0, (hipStream_t)stream, p); break; }
+  if (dtype == 0) { if (C0 == 32) { HBB(f16, 4) } else { HBB(f16, 8) } } else { if (C0 == 32) { HBB(bf16, 4) } else { HBB(bf16, 8) } }
 #undef HBB
-  dim3 g2((unsigned)((vox + 511) / 512), 4, N);
-#define HBA(TT) switch (ncls) { case 2: hipLaunchKernelGGL((head_bn_apply_kernel<TT, 2>), g2, dim3(256), 0, (hipStream_t)stream, p); break; \
-    case 3: hipLaunchKernelGGL((head_bn_apply_kernel<TT, 3>), g2, dim3(256), 0, (hipStream_t)stream, p); break; \
-    default: hipLaunchKernelGGL((head_bn_apply_kernel<TT, 4>), g2, dim3(256), 0, (hipStream_t)stream, p); break; }
-  if (dtype == 0) { HBA(f16) } else { HBA(bf16) }
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C0), dim3(256), 0, (hipStream_t)stream, (const float*)bnslab, chunks * N, C0,
+                     (double)N * (double)vox, (const float*)gamma, (const float*)invstd, (float*)dgamma, (float*)dbeta, (float*)bncoef);
+  dim3 g2((unsigned)((vox + 511) / 512), C0 / 8, N);
+#define HBA(TT, PLN) switch (ncls) { case 2: hipLaunchKernelGGL((head_bn_apply_kernel<TT, 2, PLN>), g2, dim3(256), 0, (hipStream_t)stream, p); break; \
+    case 3: hipLaunchKernelGGL((head_bn_apply_kernel<TT, 3, PLN>), g2, dim3(256), 0, (hipStream_t)stream, p); break; \
+    default: hipLaunchKernelGGL((head_bn_apply_kernel<TT, 4, PLN>), g2, dim3(256), 0, (hipStream_t)stream, p); break; }
+  if (dtype == 0) { if (C0 == 32) { HBA(f16, 4) } else { HBA(f16, 8) } } else { if (C0 == 32) { HBA(bf16, 4) } else { HBA(bf16, 8) } }
 #undef HBA
   IUNET_CHECK_HIP(hipGetLastError());
   return IUNET_OK;

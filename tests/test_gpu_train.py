@@ -557,15 +557,16 @@ def test_conv_with_per_sample_statistics(nv, nd, cin, cout, lay, shape):
     assert (outs[0][0].float() - outs[1][0].float()).abs().max().item() <= 0.05      # a few bf16 ulps of an O(1) activation
 
 
-@pytest.mark.parametrize('ncls,T,weighted', [(2, torch.bfloat16, True), (3, torch.float16, False), (4, torch.bfloat16, True)])
-def test_head_and_batchnorm_backward_in_two_passes(nv, ncls, T, weighted):
+@pytest.mark.parametrize('ncls,T,weighted,C0', [(2, torch.bfloat16, True, 32), (3, torch.float16, False, 32), (4, torch.bfloat16, True, 32),
+                                                (4, torch.bfloat16, True, 64), (2, torch.float16, False, 64)])
+def test_head_and_batchnorm_backward_in_two_passes(nv, ncls, T, weighted, C0):
     """iunet_head_bn_bwd (the head's backward + the last conv's BatchNorm + ReLU backward in two passes over that conv's raw output, the
     head's input gradient never written) against the sequence it replaces: iunet_head_loss_bwd_act -> iunet_bn_relu_bwd.  The fused
     kernel adds the logit's 32 terms plane by plane, so a gradient may sit one rounding of T away: dy within 2 ulp of T on (almost)
     every element, the reduced quantities (head dW / db, dgamma, dbeta) within 1e-4 of their magnitude."""
     g = torch.Generator().manual_seed(41)
     dt = nv.DTYPE_CODE[T]
-    N, C0 = 2, 32
+    N = 2
     vox = 5000                                                        # three blocks per sample, the last one ragged
     y = torch.randn((N, C0, vox), generator=g) * 1.2
     yb = blocked(y, T).cuda()
@@ -582,7 +583,7 @@ def test_head_and_batchnorm_backward_in_two_passes(nv, ncls, T, weighted):
     lscale = 1024.0
     s = nv.stream()
     parts = nv.lib().iunet_head_loss_bwd_num_parts(N, vox, ncls, C0)
-    assert parts == nv.lib().iunet_bn_bwd_num_parts(N, vox) and nv.lib().iunet_head_bn_bwd_ok(C0, ncls) == 1 and nv.lib().iunet_head_bn_bwd_ok(64, ncls) == 0
+    assert parts == nv.lib().iunet_bn_bwd_num_parts(N, vox) and nv.lib().iunet_head_bn_bwd_ok(C0, ncls) == 1 and nv.lib().iunet_head_bn_bwd_ok(96, ncls) == 0 and nv.lib().iunet_head_bn_bwd_ok(C0, 5) == 0
     out = []
     for fused in (False, True):
         dy = torch.full((N * C0 * vox,), float('nan'), dtype=T, device='cuda')
