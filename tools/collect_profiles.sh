@@ -101,6 +101,6 @@ bash tools/level_report.sh 3 1 128 bf16 x2m_3d "--x2m 2" > /dev/null 2>&1; pytho
 bash tools/level_report.sh 2 8 512 f16 2d > /dev/null 2>&1;                python3 tools/level_report.py 2d $RND
 bash tools/level_report.sh 2 8 512 f16 x2m_2d "--x2m 2" > /dev/null 2>&1;  python3 tools/level_report.py x2m_2d $RND
 cp profiles/${RND}_conv_levels_*.md $OUT/ 2>/dev/null
-for f in conv3_v4 conv3_x2m conv3_f8k conv3_wgrad_v2 conv2_wgrad_v2 conv3_wgrad pointwise split16 train_misc gn_precise; do python3 tools/regreport.py interactive-unet_amd/csrc/$f.hip; done > $OUT/${RND}_register_report.txt 2>&1
+for f in conv3_v4 conv3_x2m conv3_f8k conv3_wgrad_v2 conv2_wgrad_v2 conv3_wgrad pointwise split16 train_misc gn_precise train_pointwise; do python3 tools/regreport.py interactive-unet_amd/csrc/$f.hip; done > $OUT/${RND}_register_report.txt 2>&1
 fi
 ls -la $OUT
