@@ -22,7 +22,7 @@ _NOT_STATUS = {'iunet_last_error', 'iunet_abi_version', 'iunet_pack_desc_bytes',
                'iunet_bn_bwd_num_parts', 'iunet_gn_num_parts', 'iunet_head_loss_num_parts', 'iunet_head_loss_bwd_num_parts',
                'iunet_conv3_wgrad_blocks', 'iunet_convT_wgrad_blocks', 'iunet_first_conv_wgrad_blocks', 'iunet_x2_convT_kc', 'iunet_x2_pack_mode',
                'iunet_net_num_tensors', 'iunet_f32_wgrad_splits', 'iunet_f32_head_loss_num_parts', 'iunet_f8_pack_order',
-               'iunet_x2m_head_fusable', 'iunet_x2m_pool_fusable', 'iunet_x2m_first_stage_fusable', 'iunet_train_num_tensors', 'iunet_train_num_bn'}
+               'iunet_head_bn_bwd_ok', 'iunet_x2m_head_fusable', 'iunet_x2m_pool_fusable', 'iunet_x2m_first_stage_fusable', 'iunet_train_num_tensors', 'iunet_train_num_bn'}
 
 
 def _prototypes():
