@@ -531,6 +531,15 @@ int iunet_gn_relu_fwd_rows(int dtype, const void* y, long long y_ss, void* z, lo
 int iunet_gn_relu_pool_fwd_rows(int dtype, int nd, const void* y, long long y_ss, void* z, long long z_ss, void* pooled, long long p_ss,
                                 const void* gamma, const void* beta, int groups, float eps, void* slab, int rows, void* scale, void* shift,
                                 void* mean, void* invstd, int C, int N, int Do, int Ho, int Wo, void* stream);
+/* ... and the backward's first pass the same way: iunet_conv3_dgrad_sample_bnstats = iunet_conv3_dgrad_bnstats_lay with per-sample
+ * parameter rows ([N][Cout] each) and per-sample sums, stats [N][rows][Cout][2] (rows from iunet_conv3_sample_stats_rows on the launch's
+ * own Cin / Cout); iunet_gn_relu_bwd_rows = iunet_gn_relu_bwd on that slab (rows > 0: no reduction pass over dz and y). */
+int iunet_conv3_dgrad_sample_bnstats(int dtype, int nd, const void* dy, long long dy_sstride, void* dz, long long dz_sstride, const void* wpk,
+                                     void* stats, const void* yp, long long yp_sstride, const void* mean, const void* invstd, const void* scale,
+                                     const void* shift, int N, int D, int H, int W, int Cin, int Cout, int layout, void* stream);
+int iunet_gn_relu_bwd_rows(int dtype, const void* dz, long long dz_ss, const void* y, long long y_ss, void* dy, long long dy_ss,
+                           const void* gamma, int groups, const void* scale, const void* shift, const void* mean, const void* invstd,
+                           void* dgamma, void* dbeta, void* slab, int rows, void* coef, int C, int N, long long vox, void* stream);
 int iunet_gn_relu_pool_bwd(int dtype, int nd, const void* dskip, long long ds_ss, const void* dpool, long long dp_ss, const void* y,
                            long long y_ss, void* dy, long long dy_ss, const void* gamma, int groups, const void* scale, const void* shift,
                            const void* mean, const void* invstd, void* dgamma, void* dbeta, void* slab, void* coef, int C, int N, int Do,

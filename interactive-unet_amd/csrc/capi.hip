@@ -193,6 +193,23 @@ int iunet_conv3_fwd_sample_stats(int dtype, int nd, const void* x, long long x_s
                                (hipStream_t)stream, nullptr, 0, nullptr, layout == 3, 1, nullptr);
 }
 
+// iunet_conv3_dgrad_bnstats_lay per SAMPLE (GroupNorm: mean / invstd / scale / shift are [N][Cout] rows, the sums are wanted per sample):
+// stats [N][rows][Cout][2], rows = iunet_conv3_sample_stats_rows(dtype, nd, N, D, H, W, Cin, Cout, layout) > 0 -- the slab of
+// iunet_gn_relu_bwd_rows.
+int iunet_conv3_dgrad_sample_bnstats(int dtype, int nd, const void* dy, long long dy_sstride, void* dz, long long dz_sstride, const void* wpk,
+                                     void* stats, const void* yp, long long yp_sstride, const void* mean, const void* invstd, const void* scale,
+                                     const void* shift, int N, int D, int H, int W, int Cin, int Cout, int layout, void* stream) {
+  DT_OK(dtype);
+  IUNET_REQUIRE(dy && dz && wpk && stats && yp && mean && invstd && scale && shift, "conv3_dgrad_sample_bnstats: null pointer");
+  IUNET_REQUIRE_GRID("conv3_dgrad_sample_bnstats", N, D, H, W);
+  IUNET_REQUIRE(layout == 2 || (layout == 3 && nd == 2 && Cin <= 64), "conv3_dgrad_sample_bnstats: layout 2, or 3 in 2-D up to 64 input channels (got %d)", layout);
+  IUNET_REQUIRE(nd == 2 || nd == 3, "conv3: nd must be 2 or 3 (got %d)", nd);
+  IUNET_REQUIRE(nd == 3 || D == 1, "conv3: 2-D conv needs D == 1");
+  const float* par[4] = {(const float*)mean, (const float*)invstd, (const float*)scale, (const float*)shift};
+  return iunet_conv3_v4_launch(dtype, nd, dy, dy_sstride, dz, dz_sstride, wpk, nullptr, (float*)stats, N, D, H, W, Cin, Cout, 0, nullptr, nullptr,
+                               (hipStream_t)stream, yp, yp_sstride, par, layout == 3, 1, nullptr);
+}
+
 // iunet_conv3_fwd used as the data gradient of a conv whose INPUT was z = relu(bn(yp)): besides dz (its output) it accumulates
 // the BatchNorm-backward sums of that producer layer -- sum dz', sum dz' * xhat with dz' = dz where z > 0 -- in its epilogue
 // (the reduction pass of iunet_bn_relu_bwd over dz and yp goes away); stats: [iunet_conv3_stats_parts(.., layout 2)][Cout][2].

@@ -189,7 +189,7 @@ __global__ __launch_bounds__((V4Tile<ND, SMALL>::NCW * 64 + v4_loader_threads(ND
   constexpr bool bw = BW;
   if (bw && tid < 128) {
     const float* src = (tid >> 5) == 0 ? p.bw_mean : (tid >> 5) == 1 ? p.bw_invstd : (tid >> 5) == 2 ? p.bw_scale : p.bw_shift;
-    ((float*)(smem + off_bw))[tid] = src[cob * 32 + (tid & 31)];       // read in tile epilogues, many barriers later
+    ((float*)(smem + off_bw))[tid] = src[blockIdx.z * p.Cout + cob * 32 + (tid & 31)];       // read in tile epilogues, many barriers later (z > 0: a per-sample launch, the sample's rows -- GroupNorm)
   }
   const u32x4* wsrc = (const u32x4*)p.wpk + (long long)cob * (NP3 ? (nchunk / 2) * ((WE + WO) / 16) : nchunk * (WSTEP / 16));
   // SPL: virtual chunk = 3 * c + part for channel chunk c; part 0 = x_lo w_hi, 1 = x_hi w_hi, 2 = x_hi w_lo.  Consecutive parts share an
@@ -844,10 +844,10 @@ int launch_v4(ConvV4Params p, hipStream_t stream) {
   }
   const int gx = 8 * p.bz * p.by * p.bx * groups;
   if (p.query_rows != nullptr) {      // per-sample statistics need every XCD to hold a brick of every sample (else the launch would idle CUs: the caller's own pass is cheaper)
-    *p.query_rows = (!PAIR && !BW && !SPL && nbricks >= 8) ? gx : 0;
+    *p.query_rows = (!PAIR && !SPL && nbricks >= 8) ? gx : 0;
     return IUNET_OK;
   }
-  IUNET_REQUIRE(!p.per_sample || (!PAIR && !BW && !SPL && nbricks >= 8 && p.stats != nullptr), "conv3 layout 2 / 3: per-sample statistics are not available for this launch (iunet_conv3_sample_stats_rows says 0)");
+  IUNET_REQUIRE(!p.per_sample || (!PAIR && !SPL && nbricks >= 8 && p.stats != nullptr), "conv3 layout 2 / 3: per-sample statistics are not available for this launch (iunet_conv3_sample_stats_rows says 0)");
   if (p.stats != nullptr && !p.per_sample) {
     // the caller reduces iunet_conv3_v4_stats_parts rows (the brick table's slot count); a brick clamped to a small tile grid
     // launches fewer workgroups: the rows nobody writes are zeroed

@@ -73,6 +73,10 @@ int iunet_first_conv_wgrad_bn(int, int, const void*, int, const long long*, cons
 int iunet_adamw_step_dev(void*, const void*, void*, void*, long long, float, float, float, float, float, void*, int, float, void*);
 int iunet_conv3_sample_stats_rows(int, int, int, int, int, int, int, int, int);
 int iunet_conv3_fwd_sample_stats(int, int, const void*, long long, void*, long long, const void*, void*, int, int, int, int, int, int, int, void*);
+int iunet_conv3_dgrad_sample_bnstats(int, int, const void*, long long, void*, long long, const void*, void*, const void*, long long, const void*, const void*,
+                                     const void*, const void*, int, int, int, int, int, int, int, void*);
+int iunet_gn_relu_bwd_rows(int, const void*, long long, const void*, long long, void*, long long, const void*, int, const void*, const void*, const void*,
+                           const void*, void*, void*, void*, int, void*, int, int, long long, void*);
 int iunet_gn_relu_fwd_rows(int, const void*, long long, void*, long long, const void*, const void*, int, float, void*, int, void*, void*, void*, void*, int, int,
                            long long, void*);
 int iunet_gn_relu_pool_fwd_rows(int, int, const void*, long long, void*, long long, void*, long long, const void*, const void*, int, float, void*, int, void*,
@@ -124,7 +128,7 @@ struct iunet_train {
   int norm = 0, groups = 8;                      // norm 1: GroupNorm(groups) after every stage conv (statistics per (sample, group), nothing fused into the convs)
   int dim, levels, base, cin, ncls, dtype, kind;
   int taps, npos;
-  bool fuse_act, fuse_bw, head_act, gn_conv_stats, head_bn;
+  bool fuse_act, fuse_bw, head_act, gn_conv_stats, gn_bw, head_bn;
   std::vector<int> ch;
   std::vector<TParam> params;
   long long nparams = 0;
@@ -262,7 +266,8 @@ int iunet_train_create_ex(int dim, int levels, int base, int cin, int ncls, int 
   n->fuse_bw = norm == 0 && !env_on("IUNET_NO_BW_FUSION");
   n->head_act = norm == 0 && !env_on("IUNET_NO_HEAD_ACT");
   n->head_bn = n->head_act && !env_on("IUNET_NO_HEAD_BN_FUSION");          // head backward + the last conv's BatchNorm backward in two passes over y (iunet_head_bn_bwd)
-  n->gn_conv_stats = norm == 1 && !env_on("IUNET_NO_GN_CONV_STATS");      // GroupNorm statistics from the conv epilogue (per sample) where the launch has that form
+  n->gn_conv_stats = norm == 1 && !env_on("IUNET_NO_GN_CONV_STATS");
+  n->gn_bw = n->gn_conv_stats && !env_on("IUNET_NO_GN_BW_FUSION");      // ... and the backward's sums from the data gradient's epilogue, per sample      // GroupNorm statistics from the conv epilogue (per sample) where the launch has that form
   for (int l = 0; l < levels; ++l) n->ch.push_back(base << l);
   long long off = 0, pk = 0;
   int nbn = 0;
@@ -561,8 +566,11 @@ int iunet_train_forward_backward_hooks(iunet_train* n, const void* x, int in_dty
       rc = iunet_gn_relu_pool_bwd(dt, dim, dzp, dz_ss, dpool, dpool_ss, y, c.co * v, dy, c.co * v, P + c.gamma, n->groups, F(L.scale[k]), F(L.shift[k]),
                                   F(L.mean[k]), F(L.invstd[k]), G + c.gamma, G + c.beta, F(L.bnslab), F(L.bncoef), c.co, N, dn, hn, wn, stream);
     } else if (n->norm == 1) {
-      rc = iunet_gn_relu_bwd(dt, dzp, dz_ss, y, c.co * v, dy, c.co * v, P + c.gamma, n->groups, F(L.scale[k]), F(L.shift[k]), F(L.mean[k]), F(L.invstd[k]),
-                             G + c.gamma, G + c.beta, F(L.bnslab), F(L.bncoef), c.co, N, v, stream);
+      // (bw_ready: the data-gradient launch that produced dz left this layer's per-sample sums in L.stats -- no reduction pass)
+      const int rows = bw_ready[k] > 0 ? bw_ready[k] : 0;
+      bw_ready[k] = -1;
+      rc = iunet_gn_relu_bwd_rows(dt, dzp, dz_ss, y, c.co * v, dy, c.co * v, P + c.gamma, n->groups, F(L.scale[k]), F(L.shift[k]), F(L.mean[k]), F(L.invstd[k]),
+                                  G + c.gamma, G + c.beta, rows > 0 ? F(L.stats) : F(L.bnslab), rows, F(L.bncoef), c.co, N, v, stream);
     } else if (dpool != nullptr) {
       int dn, hn, wn;
       dims(c.l + 1, dn, hn, wn);
@@ -589,14 +597,24 @@ int iunet_train_forward_backward_hooks(iunet_train* n, const void* x, int in_dty
                                     c.co, stream);
     if (rc) return rc;
     long long woff;
-    const int lay = pack_pick(c.dgr, dim, N, d, h, w, false, feeds >= 0 && n->fuse_bw, &woff);
+    const int lay = pack_pick(c.dgr, dim, N, d, h, w, false, feeds >= 0 && (n->fuse_bw || n->gn_bw), &woff);      // (GroupNorm: the per-sample form of the fused sums)
     // (pack_pick keeps the request for the fused sums only where the launch has them: layout 2, or the compact operator in 2-D up to 64 channels)
     if (feeds >= 0 && n->fuse_bw && (lay == 2 || (lay == 3 && iunet_conv3_compact_ok(dim, N, d, h, w, c.co, c.ci, 0, 1)))) {
       rc = iunet_conv3_dgrad_bnstats_lay(dt, dim, dy, c.co * v, dxp, dx_ss, K + woff, F(L.stats), WS + L.y[feeds], c.ci * v, F(L.mean[feeds]),
                                          F(L.invstd[feeds]), F(L.scale[feeds]), F(L.shift[feeds]), N, d, h, w, c.co, c.ci, lay, stream);
       bw_ready[feeds] = iunet_conv3_stats_parts(dim, N, d, h, w, c.ci, 2);
     } else {
-      rc = iunet_conv3_fwd(dt, dim, dy, c.co * v, dxp, dx_ss, K + woff, nullptr, nullptr, N, d, h, w, c.co, c.ci, 0, lay, stream);
+      // GroupNorm: the same fusion per sample where the launch has that form (the parameters are [N][C] rows, the sums per sample)
+      int gn_rows = 0;
+      if (n->norm == 1 && feeds >= 0 && n->gn_bw && (lay == 2 || (lay == 3 && dim == 2 && c.co <= 64)))
+        gn_rows = iunet_conv3_sample_stats_rows(dt, dim, N, d, h, w, c.co, c.ci, lay);
+      if (gn_rows > 0) {
+        rc = iunet_conv3_dgrad_sample_bnstats(dt, dim, dy, c.co * v, dxp, dx_ss, K + woff, F(L.stats), WS + L.y[feeds], c.ci * v, F(L.mean[feeds]),
+                                              F(L.invstd[feeds]), F(L.scale[feeds]), F(L.shift[feeds]), N, d, h, w, c.co, c.ci, lay, stream);
+        bw_ready[feeds] = gn_rows;
+      } else {
+        rc = iunet_conv3_fwd(dt, dim, dy, c.co * v, dxp, dx_ss, K + woff, nullptr, nullptr, N, d, h, w, c.co, c.ci, 0, lay, stream);
+      }
     }
     return rc;
   };

@@ -1446,18 +1446,29 @@ int iunet_gn_finalize(const void* stats, int nparts, int C, int groups, long lon
 
 // backward of z = relu(group_norm(y)): dy, dgamma, dbeta from dz and y; scale / shift / mean / invstd [N][C] from the forward;
 // slab as above, coef: N * C * 3 floats of scratch.  C <= 1024.
+int iunet_gn_relu_bwd_rows(int dtype, const void* dz, long long dz_ss, const void* y, long long y_ss, void* dy, long long dy_ss,
+                           const void* gamma, int groups, const void* scale, const void* shift, const void* mean, const void* invstd,
+                           void* dgamma, void* dbeta, void* slab, int rows, void* coef, int C, int N, long long vox, void* stream);
 int iunet_gn_relu_bwd(int dtype, const void* dz, long long dz_ss, const void* y, long long y_ss, void* dy, long long dy_ss,
                       const void* gamma, int groups, const void* scale, const void* shift, const void* mean, const void* invstd,
                       void* dgamma, void* dbeta, void* slab, void* coef, int C, int N, long long vox, void* stream) {
+  return iunet_gn_relu_bwd_rows(dtype, dz, dz_ss, y, y_ss, dy, dy_ss, gamma, groups, scale, shift, mean, invstd, dgamma, dbeta, slab, 0, coef, C, N, vox, stream);
+}
+// rows > 0: `slab` already holds the first pass, [N][rows][C][2] = (sum dz', sum dz' xhat) per sample from the data-gradient launch that
+// produced dz (iunet_conv3_dgrad_sample_bnstats): no reduction pass over dz and y.
+int iunet_gn_relu_bwd_rows(int dtype, const void* dz, long long dz_ss, const void* y, long long y_ss, void* dy, long long dy_ss,
+                           const void* gamma, int groups, const void* scale, const void* shift, const void* mean, const void* invstd,
+                           void* dgamma, void* dbeta, void* slab, int rows, void* coef, int C, int N, long long vox, void* stream) {
   DT_OK(dtype);
   IUNET_REQUIRE(dz && y && dy && gamma && scale && shift && mean && invstd && dgamma && dbeta && slab && coef, "gn_relu_bwd: null pointer");
   IUNET_REQUIRE(C > 0 && C % 8 == 0 && C <= 1024 && N > 0 && vox > 0, "gn_relu_bwd: C %d (multiple of 8, <= 1024), N %d, %lld voxels", C, N, vox);
   IUNET_REQUIRE(groups > 0 && C % groups == 0, "gn_relu_bwd: %d channels do not split into %d groups", C, groups);
   const int per_block = BN_BWD_PER_BLOCK;
-  const int chunks = (int)((vox + per_block - 1) / per_block);
+  const int chunks = rows > 0 ? rows : (int)((vox + per_block - 1) / per_block);
   dim3 g1(chunks, C / 8, N), g2((unsigned)((vox + 511) / 512), C / 8, N);      // one launch over the samples: sample n reads its rows of the parameters
   const float *mu = (const float*)mean, *is = (const float*)invstd, *sc = (const float*)scale, *sh = (const float*)shift;
-  if (dtype == 0) hipLaunchKernelGGL(bn_bwd_reduce_kernel<f16>, g1, dim3(256), 0, (hipStream_t)stream, (const f16*)dz, dz_ss, (const f16*)nullptr, 0LL, (const f16*)y, y_ss, mu, is, sc, sh, C, vox, per_block, (float*)slab, C);
+  if (rows > 0) {}
+  else if (dtype == 0) hipLaunchKernelGGL(bn_bwd_reduce_kernel<f16>, g1, dim3(256), 0, (hipStream_t)stream, (const f16*)dz, dz_ss, (const f16*)nullptr, 0LL, (const f16*)y, y_ss, mu, is, sc, sh, C, vox, per_block, (float*)slab, C);
   else hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16>, g1, dim3(256), 0, (hipStream_t)stream, (const bf16*)dz, dz_ss, (const bf16*)nullptr, 0LL, (const bf16*)y, y_ss, mu, is, sc, sh, C, vox, per_block, (float*)slab, C);
   hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(groups), dim3(1024), 0, (hipStream_t)stream, (const float*)slab, chunks, C, groups, N,
                      (double)vox, (const float*)gamma, (const float*)invstd, (float*)dgamma, (float*)dbeta, (float*)coef);

@@ -67,6 +67,7 @@ class TrainEngine:
         # reduction pass, for A/B runs)
         self.fuse_bw = not self.gn and not os.environ.get('IUNET_NO_BW_FUSION')
         self.gn_conv_stats = self.gn and not os.environ.get('IUNET_NO_GN_CONV_STATS')
+        self.gn_bw = self.gn_conv_stats and not os.environ.get('IUNET_NO_GN_BW_FUSION')      # the backward's sums from the data gradient's epilogue, per sample
         self.head_act = not self.gn and not os.environ.get('IUNET_NO_HEAD_ACT')     # A/B switch: materialise the last activation
         # head backward + the last conv's BatchNorm backward in two passes over its raw output (iunet_head_bn_bwd; IUNET_NO_HEAD_BN_FUSION=1:
         # the three-kernel sequence with the head's input gradient written and read back)
@@ -419,10 +420,11 @@ class TrainEngine:
                     nv.ptr(ws['mean.' + name]), nv.ptr(ws['invstd.' + name]), nv.ptr(self.g(bn + '.weight')),
                     nv.ptr(self.g(bn + '.bias')), nv.ptr(ws['bnslab']), nv.ptr(ws['bncoef']), co, N, do[0], do[1], do[2], s)
         elif self.gn:
-            nv.call('iunet_gn_relu_bwd', self.dt, dz_ptr, dz_ss, self._P(ws['y.' + name]), co * v, self._P(dy), co * v,
+            rows = self._bw_ready.pop(name, 0)          # > 0: the data-gradient launch that produced dz left this layer's per-sample sums in ws['stats']
+            nv.call('iunet_gn_relu_bwd_rows', self.dt, dz_ptr, dz_ss, self._P(ws['y.' + name]), co * v, self._P(dy), co * v,
                     nv.ptr(self.p(bn + '.weight')), self.groups, nv.ptr(ws['scale.' + name]), nv.ptr(ws['shift.' + name]),
                     nv.ptr(ws['mean.' + name]), nv.ptr(ws['invstd.' + name]), nv.ptr(self.g(bn + '.weight')),
-                    nv.ptr(self.g(bn + '.bias')), nv.ptr(ws['bnslab']), nv.ptr(ws['bncoef']), co, N, v, s)
+                    nv.ptr(self.g(bn + '.bias')), nv.ptr(ws['stats'] if rows > 0 else ws['bnslab']), rows, nv.ptr(ws['bncoef']), co, N, v, s)
         elif pool_bwd is not None:
             # encoder stage: dz = skip gradient (dz_ptr) + max-pool backward of dpool, formed on the fly in both passes
             dp_ptr, dp_ss, do = pool_bwd
@@ -467,7 +469,10 @@ class TrainEngine:
                         nv.ptr(gw), 1.0, nv.ptr(ws['scale.' + x_act]), nv.ptr(ws['shift.' + x_act]),
                         N, d[0], d[1], d[2], ci, co, s)
             _, pkd = self.pk[name]
-            lay, wd = pkd.pick(self.dim, N, *d, bw=feeds is not None and self.fuse_bw)
+            lay, wd = pkd.pick(self.dim, N, *d, bw=feeds is not None and (self.fuse_bw or self.gn_bw))      # (GroupNorm: the per-sample form of the fused sums)
+            gn_rows = 0
+            if self.gn and feeds is not None and self.gn_bw and (lay == 2 or (lay == 3 and self.dim == 2 and co <= 64)):
+                gn_rows = nv.lib().iunet_conv3_sample_stats_rows(self.dt, self.dim, N, d[0], d[1], d[2], co, ci, lay)
             # (pick keeps the request for the fused sums only where the launch has them: layout 2, or the compact operator in 2-D up to 64 channels)
             if feeds is not None and self.fuse_bw and (lay == 2 or (lay == 3 and nv.lib().iunet_conv3_compact_ok(self.dim, N, d[0], d[1], d[2], co, ci, 0, 1))):
                 nv.call('iunet_conv3_dgrad_bnstats_lay', self.dt, self.dim, self._P(dy), co * v, dx_ptr, dx_ss, nv.ptr(wd),
@@ -475,6 +480,12 @@ class TrainEngine:
                         nv.ptr(ws['invstd.' + feeds]), nv.ptr(ws['scale.' + feeds]), nv.ptr(ws['shift.' + feeds]),
                         N, d[0], d[1], d[2], co, ci, lay, s)
                 self._bw_ready[feeds] = nv.lib().iunet_conv3_stats_parts(self.dim, N, d[0], d[1], d[2], ci, 2)
+            elif gn_rows > 0:
+                nv.call('iunet_conv3_dgrad_sample_bnstats', self.dt, self.dim, self._P(dy), co * v, dx_ptr, dx_ss, nv.ptr(wd),
+                        nv.ptr(ws['stats']), self._P(ws['y.' + feeds]), ci * v, nv.ptr(ws['mean.' + feeds]),
+                        nv.ptr(ws['invstd.' + feeds]), nv.ptr(ws['scale.' + feeds]), nv.ptr(ws['shift.' + feeds]),
+                        N, d[0], d[1], d[2], co, ci, lay, s)
+                self._bw_ready[feeds] = gn_rows
             else:
                 nv.call('iunet_conv3_fwd', self.dt, self.dim, self._P(dy), co * v, dx_ptr, dx_ss, nv.ptr(wd), None, None,
                         N, d[0], d[1], d[2], co, ci, 0, lay, s)
