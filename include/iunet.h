@@ -640,6 +640,16 @@ int iunet_head_bn_bwd(int dtype, const void* y, long long y_ss, int C0, const vo
                       const void* weight, int tdtype, const void* coef, float loss_scale, const void* state, const void* scale,
                       const void* shift, const void* mean, const void* invstd, const void* gamma, void* dgamma, void* dbeta, void* dy,
                       long long dy_ss, void* dwslab, void* bnslab, void* bncoef, void* dl_scratch, int N, long long vox, void* stream);
+/* ... for GroupNorm networks: scale / shift / mean / invstd are [N][C0] rows, bncoef N * C0 * 3 floats (as iunet_gn_relu_bwd), the head's
+ * forward reads the last conv's raw output with per-sample rows too (iunet_head_loss_fwd_act_ps, per_sample = 1; iunet_gn_relu_fwd_rows with
+ * z = NULL leaves only scale / shift / mean / invstd). */
+int iunet_head_gn_bwd(int dtype, const void* y, long long y_ss, int C0, const void* w, const void* bias, int ncls, const void* target,
+                      const void* weight, int tdtype, const void* coef, float loss_scale, const void* state, const void* scale,
+                      const void* shift, const void* mean, const void* invstd, const void* gamma, int groups, void* dgamma, void* dbeta, void* dy,
+                      long long dy_ss, void* dwslab, void* bnslab, void* bncoef, void* dl_scratch, int N, long long vox, void* stream);
+int iunet_head_loss_fwd_act_ps(int dtype, const void* x, long long x_ss, int C0, const void* w, const void* bias, int ncls,
+                               const void* target, const void* weight, int tdtype, int kind, void* slab, void* out4, void* coef,
+                               const void* in_scale, const void* in_shift, int per_sample, int N, long long vox, void* stream);
 /* dW [ncls][C0], db [ncls] of the head from the reduced row of iunet_head_loss_bwd's slab ([C0 / 8][ncls][8] weight sums, then [ncls]) */
 int iunet_head_grad_scatter(const void* row, void* dw, void* db, int ncls, int C0, void* stream);
 /* the optimiser step on the device state: overflow check of the flat gradient (check != 0: fp16), AdamW (unet.py:71-73; skipped on

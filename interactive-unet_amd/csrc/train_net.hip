@@ -56,6 +56,10 @@ int iunet_head_loss_bwd_dev(int, const void*, long long, int, const void*, const
                             const void*, void*, long long, void*, const void*, const void*, int, long long, void*);
 int iunet_head_grad_scatter(const void*, void*, void*, int, int, void*);
 int iunet_head_bn_bwd_ok(int, int);
+int iunet_head_gn_bwd(int, const void*, long long, int, const void*, const void*, int, const void*, const void*, int, const void*, float, const void*, const void*,
+                      const void*, const void*, const void*, const void*, int, void*, void*, void*, long long, void*, void*, void*, void*, int, long long, void*);
+int iunet_head_loss_fwd_act_ps(int, const void*, long long, int, const void*, const void*, int, const void*, const void*, int, int, void*, void*, void*,
+                               const void*, const void*, int, int, long long, void*);
 int iunet_head_bn_bwd(int, const void*, long long, int, const void*, const void*, int, const void*, const void*, int, const void*, float, const void*, const void*,
                       const void*, const void*, const void*, const void*, void*, void*, void*, long long, void*, void*, void*, void*, int, long long, void*);
 int iunet_reduce_slab(void*, int, long long, void*, float, int, void*);
@@ -128,7 +132,7 @@ struct iunet_train {
   int norm = 0, groups = 8;                      // norm 1: GroupNorm(groups) after every stage conv (statistics per (sample, group), nothing fused into the convs)
   int dim, levels, base, cin, ncls, dtype, kind;
   int taps, npos;
-  bool fuse_act, fuse_bw, head_act, gn_conv_stats, gn_bw, head_bn;
+  bool fuse_act, fuse_bw, head_act, gn_conv_stats, gn_bw, head_bn, gn_head;
   std::vector<int> ch;
   std::vector<TParam> params;
   long long nparams = 0;
@@ -265,6 +269,9 @@ int iunet_train_create_ex(int dim, int levels, int base, int cin, int ncls, int 
   n->fuse_act = norm == 0 && !env_on("IUNET_NO_ACT_FUSION");
   n->fuse_bw = norm == 0 && !env_on("IUNET_NO_BW_FUSION");
   n->head_act = norm == 0 && !env_on("IUNET_NO_HEAD_ACT");
+  // GroupNorm: the head reads the last conv's raw output with per-sample rows and its backward runs as iunet_head_gn_bwd (the last
+  // activation and the head's input gradient are never written) -- only in that fused form (32 / 64 head channels, 2..4 classes)
+  n->gn_head = norm == 1 && !env_on("IUNET_NO_HEAD_ACT") && !env_on("IUNET_NO_HEAD_BN_FUSION") && iunet_head_bn_bwd_ok(base, ncls);
   n->head_bn = n->head_act && !env_on("IUNET_NO_HEAD_BN_FUSION");          // head backward + the last conv's BatchNorm backward in two passes over y (iunet_head_bn_bwd)
   n->gn_conv_stats = norm == 1 && !env_on("IUNET_NO_GN_CONV_STATS");
   n->gn_bw = n->gn_conv_stats && !env_on("IUNET_NO_GN_BW_FUSION");      // ... and the backward's sums from the data gradient's epilogue, per sample      // GroupNorm statistics from the conv epilogue (per sample) where the launch has that form
@@ -509,7 +516,7 @@ int iunet_train_forward_backward_hooks(iunet_train* n, const void* x, int in_dty
     rc = conv_fwd(k1, WS + L.cat[l], 2ll * c * v, z1p, (long long)c * v, -1, nullptr, 0);
     if (rc) return rc;
     // the last stage's activation is read by the head only: with head_act the head kernels apply its BatchNorm + ReLU while loading
-    void* z2 = (l == 0 && n->head_act) ? nullptr : (void*)(WS + L.z[k2]);
+    void* z2 = (l == 0 && (n->head_act || n->gn_head)) ? nullptr : (void*)(WS + L.z[k2]);
     rc = conv_fwd(k2, x2, (long long)c * v, z2, (long long)c * v, fused ? k1 : -1, nullptr, 0);
     if (rc) return rc;
   }
@@ -517,7 +524,10 @@ int iunet_train_forward_backward_hooks(iunet_train* n, const void* x, int in_dty
   // ---- head + softmax + loss (unet.py:88-102, metrics.py)
   const long long v0 = vox(0);
   const int c0 = n->ch[0], kl = idx(true, 0, 2);
-  if (n->head_act)
+  if (n->gn_head)
+    rc = iunet_head_loss_fwd_act_ps(dt, WS + L.y[kl], (long long)c0 * v0, c0, P + n->head_w, P + n->head_b, n->ncls, target, weight, tdtype, n->kind,
+                                    F(L.lslab), F(L.out4), F(L.coef), F(L.scale[kl]), F(L.shift[kl]), 1, N, v0, stream);
+  else if (n->head_act)
     rc = iunet_head_loss_fwd_act(dt, WS + L.y[kl], (long long)c0 * v0, c0, P + n->head_w, P + n->head_b, n->ncls, target, weight, tdtype, n->kind,
                                  F(L.lslab), F(L.out4), F(L.coef), F(L.scale[kl]), F(L.shift[kl]), N, v0, stream);
   else
@@ -531,7 +541,12 @@ int iunet_train_forward_backward_hooks(iunet_train* n, const void* x, int in_dty
   {
     const int nparts = iunet_head_loss_bwd_num_parts(N, v0, n->ncls, c0);
     const TConv& cl = n->conv[kl];
-    if (n->head_bn && iunet_head_bn_bwd_ok(c0, n->ncls)) {
+    if (n->gn_head) {
+      rc = iunet_head_gn_bwd(dt, WS + L.y[kl], (long long)c0 * v0, c0, P + n->head_w, P + n->head_b, n->ncls, target, weight, tdtype, F(L.coef), 0.f,
+                             n->state, F(L.scale[kl]), F(L.shift[kl]), F(L.mean[kl]), F(L.invstd[kl]), P + cl.gamma, n->groups, G + cl.gamma, G + cl.beta,
+                             WS + L.dy, (long long)c0 * v0, F(L.hslab), F(L.bnslab), F(L.bncoef), WS + L.dz[kl], N, v0, stream);
+      dy_ready = kl;
+    } else if (n->head_bn && iunet_head_bn_bwd_ok(c0, n->ncls)) {
       rc = iunet_head_bn_bwd(dt, WS + L.y[kl], (long long)c0 * v0, c0, P + n->head_w, P + n->head_b, n->ncls, target, weight, tdtype, F(L.coef), 0.f,
                              n->state, F(L.scale[kl]), F(L.shift[kl]), F(L.mean[kl]), F(L.invstd[kl]), P + cl.gamma, G + cl.gamma, G + cl.beta,
                              WS + L.dy, (long long)c0 * v0, F(L.hslab), F(L.bnslab), F(L.bncoef), WS + L.dz[kl] /* unused by this path: 32 x 2 bytes per voxel */,

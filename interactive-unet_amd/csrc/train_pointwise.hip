@@ -534,15 +534,16 @@ struct HeadLossParams {
   // applied while loading (training: that activation is read only by the head, so it is never written; bit-identical to reading
   // the tensor bn_relu_fwd_kernel would have stored)
   const float* in_scale; const float* in_shift;
+  int pss;              // per-sample stride of in_scale / in_shift (GroupNorm: C0; BatchNorm: 0)
 };
 
 template <typename T>
-__device__ __forceinline__ V8T<T> head_act(const HeadLossParams& p, V8T<T> v, int pl) {
+__device__ __forceinline__ V8T<T> head_act(const HeadLossParams& p, V8T<T> v, int pl, int n) {
   if (p.in_scale == nullptr) return v;
   V8T<T> o;
 #pragma unroll
   for (int j = 0; j < 8; ++j)
-    o[j] = from_f32<T>(fmaxf(fmaf(p.in_scale[pl * 8 + j], to_f32<T>(v[j]), p.in_shift[pl * 8 + j]), 0.f));
+    o[j] = from_f32<T>(fmaxf(fmaf(p.in_scale[n * p.pss + pl * 8 + j], to_f32<T>(v[j]), p.in_shift[n * p.pss + pl * 8 + j]), 0.f));
   return o;
 }
 
@@ -565,7 +566,7 @@ __global__ __launch_bounds__(256) void head_loss_fwd_kernel(HeadLossParams p) {
 #pragma unroll
     for (int c = 0; c < NCLS; ++c) l[c] = p.bias[c];
     for (int pl = 0; pl < p.planes; ++pl) {
-      const V8T<T> xv = head_act<T>(p, *(const V8T<T>*)(xin + (long long)pl * p.vox * 8), pl);
+      const V8T<T> xv = head_act<T>(p, *(const V8T<T>*)(xin + (long long)pl * p.vox * 8), pl, n);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float a = to_f32<T>(xv[j]);
@@ -713,7 +714,7 @@ __global__ __launch_bounds__(256) void head_loss_bwd_kernel(HeadLossParams p) {
     const T* xin = (const T*)p.x + n * p.x_ss + v * 8;
     V8T<T> xv[PL];
 #pragma unroll
-    for (int pl = 0; pl < PL; ++pl) xv[pl] = head_act<T>(p, *(const V8T<T>*)(xin + (long long)pl * p.vox * 8), pl);
+    for (int pl = 0; pl < PL; ++pl) xv[pl] = head_act<T>(p, *(const V8T<T>*)(xin + (long long)pl * p.vox * 8), pl, n);
     float l[NCLS];
 #pragma unroll
     for (int c = 0; c < NCLS; ++c) l[c] = p.bias[c];
@@ -803,6 +804,7 @@ struct HeadBnBwdParams {
   void* dy; long long dy_ss;                         // PASS 2 output
   float* dl;                                         // [N][vox][NCLS]: the logit gradients, written by PASS 1 (plane 0's wave), read by PASS 2
   long long vox; int per_block;
+  int pss;                                           // per-sample stride of scale / shift / mean / invstd / bncoef rows (GroupNorm: C0; BatchNorm: 0)
 };
 
 #ifndef HBB_U
@@ -822,11 +824,11 @@ __global__ __launch_bounds__(PL * 64, HBB_OCC) void head_bn_bwd_kernel(HeadBnBwd
   [[maybe_unused]] float ca[8], c1[8], c2[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    const int c = pl * 8 + j;
-    sc[j] = p.scale[c]; sh[j] = p.shift[c]; mu[j] = p.mean[c]; is[j] = p.invstd[c];
+    const int c = pl * 8 + j, cs = n * p.pss + c;
+    sc[j] = p.scale[cs]; sh[j] = p.shift[cs]; mu[j] = p.mean[cs]; is[j] = p.invstd[cs];
 #pragma unroll
     for (int k = 0; k < NCLS; ++k) W[k][j] = p.w[k * C0 + c];
-    if (PASS == 2) { ca[j] = p.bncoef[c * 3]; c1[j] = p.bncoef[c * 3 + 1]; c2[j] = p.bncoef[c * 3 + 2]; }
+    if (PASS == 2) { ca[j] = p.bncoef[cs * 3]; c1[j] = p.bncoef[cs * 3 + 1]; c2[j] = p.bncoef[cs * 3 + 2]; }
   }
   float bias[NCLS], lc[NCLS][3];
 #pragma unroll
@@ -972,7 +974,7 @@ __global__ __launch_bounds__(PL * 64, HBB_OCC) void head_bn_bwd_kernel(HeadBnBwd
 
 // PASS 2 without the head: dy = a (dz' - c1 - xhat c2) with dz = W^T dl from the logit gradients PASS 1 left (8 NCLS bytes per voxel
 // instead of the logits, the softmax and the loss terms again).  Plane = grid dimension (wave-uniform constants), two voxels per thread.
-template <typename T, int NCLS, int PL>
+template <typename T, int NCLS, int PL, bool GN = false>      // GN: bn_bwd_apply_kernel's GroupNorm form (a d - c1 - xhat c2, per-sample rows)
 __global__ __launch_bounds__(256) void head_bn_apply_kernel(HeadBnBwdParams p) {
   constexpr int C0 = PL * 8;
   const int pl = blockIdx.y, n = blockIdx.z;
@@ -980,9 +982,9 @@ __global__ __launch_bounds__(256) void head_bn_apply_kernel(HeadBnBwdParams p) {
   float sc[8], sh[8], mu[8], is[8], W[NCLS][8], ca[8], c1[8], c2[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    const int c = pl * 8 + j;
-    sc[j] = p.scale[c]; sh[j] = p.shift[c]; mu[j] = p.mean[c]; is[j] = p.invstd[c];
-    ca[j] = p.bncoef[c * 3]; c1[j] = p.bncoef[c * 3 + 1]; c2[j] = p.bncoef[c * 3 + 2];
+    const int c = pl * 8 + j, cs = n * p.pss + c;
+    sc[j] = p.scale[cs]; sh[j] = p.shift[cs]; mu[j] = p.mean[cs]; is[j] = p.invstd[cs];
+    ca[j] = p.bncoef[cs * 3]; c1[j] = p.bncoef[cs * 3 + 1]; c2[j] = p.bncoef[cs * 3 + 2];
 #pragma unroll
     for (int k = 0; k < NCLS; ++k) W[k][j] = p.w[k * C0 + c];
   }
@@ -1013,7 +1015,7 @@ __global__ __launch_bounds__(256) void head_bn_apply_kernel(HeadBnBwdParams p) {
       const float dz = to_f32<T>(from_f32<T>(a));
       const float d = zv > 0.f ? dz : 0.f;
       const float xh = (yv - mu[j]) * is[j];
-      o[j] = from_f32<T>(ca[j] * (d - c1[j] - xh * c2[j]));
+      o[j] = from_f32<T>(GN ? ca[j] * d - c1[j] - xh * c2[j] : ca[j] * (d - c1[j] - xh * c2[j]));
     }
     *(V8T<T>*)((T*)p.dy + n * p.dy_ss + po + v * 8) = o;
   }
@@ -1039,7 +1041,7 @@ __global__ __launch_bounds__(256) void head_loss_bwd_wide_kernel(HeadLossParams 
   __shared__ float actp[2 * C0];
   for (int i = threadIdx.x; i < NCLS * C0; i += 256) wsm[i] = p.w[i];
   if (p.in_scale != nullptr)
-    for (int i = threadIdx.x; i < C0; i += 256) { actp[i] = p.in_scale[i]; actp[C0 + i] = p.in_shift[i]; }
+    for (int i = threadIdx.x; i < C0; i += 256) { actp[i] = p.in_scale[n * p.pss + i]; actp[C0 + i] = p.in_shift[n * p.pss + i]; }
   __syncthreads();
   float accw[NCLS][8], accb[NCLS];
 #pragma unroll
@@ -1405,7 +1407,7 @@ int iunet_gn_relu_fwd_rows(int dtype, const void* y, long long y_ss, void* z, lo
                            int groups, float eps, void* slab, int rows, void* scale, void* shift, void* mean, void* invstd, int C, int N,
                            long long vox, void* stream) {
   DT_OK(dtype);
-  IUNET_REQUIRE(y && z && gamma && beta && slab && scale && shift && mean && invstd, "gn_relu_fwd: null pointer");
+  IUNET_REQUIRE(y && gamma && beta && slab && scale && shift && mean && invstd, "gn_relu_fwd: null pointer");      // z NULL: statistics -> scale / shift only (the consumer applies them: iunet_head_loss_fwd_act_ps)
   IUNET_REQUIRE(C > 0 && C % 8 == 0 && N > 0 && vox > 0 && rows >= 0, "gn_relu_fwd: C %d (multiple of 8), N %d, %lld voxels, %d rows", C, N, vox, rows);
   IUNET_REQUIRE(groups > 0 && C % groups == 0, "gn_relu_fwd: %d channels do not split into %d groups", C, groups);
   const int per_block = BN_BWD_PER_BLOCK;
@@ -1417,7 +1419,8 @@ int iunet_gn_relu_fwd_rows(int dtype, const void* y, long long y_ss, void* z, lo
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, N), dim3(256), 0, (hipStream_t)stream, (const float*)slab, chunks, C, groups,
                      (double)vox, (const float*)gamma, (const float*)beta, eps, (float*)scale, (float*)shift, (float*)mean, (float*)invstd);
   dim3 g2((unsigned)((vox + 511) / 512), C / 8, N);        // one launch over the samples: sample n reads its row of scale / shift
-  if (dtype == 0) hipLaunchKernelGGL(bn_relu_fwd_kernel<f16>, g2, dim3(256), 0, (hipStream_t)stream, (const f16*)y, y_ss, (f16*)z, z_ss, (const float*)scale, (const float*)shift, C / 8, vox, C);
+  if (z == nullptr) {}
+  else if (dtype == 0) hipLaunchKernelGGL(bn_relu_fwd_kernel<f16>, g2, dim3(256), 0, (hipStream_t)stream, (const f16*)y, y_ss, (f16*)z, z_ss, (const float*)scale, (const float*)shift, C / 8, vox, C);
   else hipLaunchKernelGGL(bn_relu_fwd_kernel<bf16>, g2, dim3(256), 0, (hipStream_t)stream, (const bf16*)y, y_ss, (bf16*)z, z_ss, (const float*)scale, (const float*)shift, C / 8, vox, C);
   IUNET_CHECK_HIP(hipGetLastError());
   return IUNET_OK;
@@ -1611,7 +1614,7 @@ int iunet_head_loss_bwd_num_parts(int N, long long vox, int ncls, int C0) {
 // forward: head + softmax + loss sums -> loss value, rounded metrics, gradient coefficients
 static int head_loss_fwd_impl(int dtype, const void* x, long long x_ss, int C0, const void* w, const void* bias, int ncls,
                               const void* target, const void* weight, int tdtype, int kind, void* slab, void* out4, void* coef,
-                              int N, long long vox, const void* in_scale, const void* in_shift, void* stream) {
+                              int N, long long vox, const void* in_scale, const void* in_shift, void* stream, int per_sample = 0) {
   DT_OK(dtype);
   IUNET_REQUIRE(x && w && bias && target && slab && out4 && coef, "head_loss_fwd: null pointer");
   IUNET_REQUIRE(ncls >= 2 && ncls <= 10, "head_loss: num_classes must be 2..10");
@@ -1620,7 +1623,7 @@ static int head_loss_fwd_impl(int dtype, const void* x, long long x_ss, int C0, 
   HeadLossParams p{};
   p.x = x; p.x_ss = x_ss; p.planes = C0 / 8; p.w = (const float*)w; p.bias = (const float*)bias;
   p.target = target; p.weight = weight; p.tdtype = tdtype; p.slab = (float*)slab; p.N = N; p.vox = vox;
-  p.in_scale = (const float*)in_scale; p.in_shift = (const float*)in_shift;
+  p.in_scale = (const float*)in_scale; p.in_shift = (const float*)in_shift; p.pss = per_sample ? C0 : 0;
   dim3 grid((unsigned)(iunet_head_loss_num_parts(N, vox) / N), N);
   if (dtype == 0) { HEAD_SWITCH(head_loss_fwd_kernel, f16) } else { HEAD_SWITCH(head_loss_fwd_kernel, bf16) }
   hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)slab,
@@ -1643,6 +1646,14 @@ int iunet_head_loss_fwd_act(int dtype, const void* x, long long x_ss, int C0, co
                             const void* in_scale, const void* in_shift, int N, long long vox, void* stream) {
   IUNET_REQUIRE(in_scale && in_shift, "head_loss_fwd_act: null scale / shift");
   return head_loss_fwd_impl(dtype, x, x_ss, C0, w, bias, ncls, target, weight, tdtype, kind, slab, out4, coef, N, vox, in_scale, in_shift, stream);
+}
+
+// ... with per-sample rows of in_scale / in_shift ([N][C0]: GroupNorm)
+int iunet_head_loss_fwd_act_ps(int dtype, const void* x, long long x_ss, int C0, const void* w, const void* bias, int ncls,
+                               const void* target, const void* weight, int tdtype, int kind, void* slab, void* out4, void* coef,
+                               const void* in_scale, const void* in_shift, int per_sample, int N, long long vox, void* stream) {
+  IUNET_REQUIRE(in_scale && in_shift, "head_loss_fwd_act: null scale / shift");
+  return head_loss_fwd_impl(dtype, x, x_ss, C0, w, bias, ncls, target, weight, tdtype, kind, slab, out4, coef, N, vox, in_scale, in_shift, stream, per_sample);
 }
 
 // backward: dx (gradient wrt head input), dW/db slabs [num_parts][ncls*(C0+1)]
@@ -1753,10 +1764,11 @@ int iunet_head_loss_bwd_dev(int dtype, const void* x, long long x_ss, int C0, co
  * gradient of y.  bnslab: iunet_bn_bwd_num_parts(N, vox) * 2 C0 floats; dl_scratch: N * vox * ncls floats (the logit gradients between the
  * two passes).  loss scale: state[0] when state is given, else loss_scale. */
 int iunet_head_bn_bwd_ok(int C0, int ncls) { return (C0 == 32 || C0 == 64) && ncls >= 2 && ncls <= 4; }
-int iunet_head_bn_bwd(int dtype, const void* y, long long y_ss, int C0, const void* w, const void* bias, int ncls, const void* target,
-                      const void* weight, int tdtype, const void* coef, float loss_scale, const void* state, const void* scale,
-                      const void* shift, const void* mean, const void* invstd, const void* gamma, void* dgamma, void* dbeta, void* dy,
-                      long long dy_ss, void* dwslab, void* bnslab, void* bncoef, void* dl_scratch, int N, long long vox, void* stream) {
+static int head_norm_bwd_impl(int dtype, const void* y, long long y_ss, int C0, const void* w, const void* bias, int ncls, const void* target,
+                              const void* weight, int tdtype, const void* coef, float loss_scale, const void* state, const void* scale,
+                              const void* shift, const void* mean, const void* invstd, const void* gamma, void* dgamma, void* dbeta, void* dy,
+                              long long dy_ss, void* dwslab, void* bnslab, void* bncoef, void* dl_scratch, int N, long long vox, void* stream,
+                              int groups /* 0: BatchNorm ([C0] parameters); > 0: GroupNorm ([N][C0] rows) */) {
   DT_OK(dtype);
   IUNET_REQUIRE(y && w && bias && target && coef && scale && shift && mean && invstd && gamma && dgamma && dbeta && dy && dwslab && bnslab && bncoef && dl_scratch,
                 "head_bn_bwd: null pointer");
@@ -1768,7 +1780,7 @@ int iunet_head_bn_bwd(int dtype, const void* y, long long y_ss, int C0, const vo
   p.scale = (const float*)scale; p.shift = (const float*)shift; p.mean = (const float*)mean; p.invstd = (const float*)invstd;
   p.bncoef = (const float*)bncoef; p.bnslab = (float*)bnslab; p.dwslab = (float*)dwslab; p.dy = dy; p.dy_ss = dy_ss;
   p.dl = (float*)dl_scratch;
-  p.vox = vox; p.per_block = BN_BWD_PER_BLOCK;
+  p.vox = vox; p.per_block = BN_BWD_PER_BLOCK; p.pss = groups > 0 ? C0 : 0;
   static_assert(BN_BWD_PER_BLOCK == 256 * 8, "head_bn_bwd: one row per block for both slabs (iunet_head_loss_bwd_num_parts = iunet_bn_bwd_num_parts)");
   const int chunks = (int)((vox + p.per_block - 1) / p.per_block);
   dim3 grid(chunks, N);
@@ -1777,16 +1789,38 @@ int iunet_head_bn_bwd(int dtype, const void* y, long long y_ss, int C0, const vo
     default: hipLaunchKernelGGL((head_bn_bwd_kernel<TT, 4, 1, PLN>), grid, dim3(PLN * 64), 0, (hipStream_t)stream, p); break; }
   if (dtype == 0) { if (C0 == 32) { HBB(f16, 4) } else { HBB(f16, 8) } } else { if (C0 == 32) { HBB(bf16, 4) } else { HBB(bf16, 8) } }
 #undef HBB
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C0), dim3(256), 0, (hipStream_t)stream, (const float*)bnslab, chunks * N, C0,
-                     (double)N * (double)vox, (const float*)gamma, (const float*)invstd, (float*)dgamma, (float*)dbeta, (float*)bncoef);
+  if (groups > 0)      // the rows of pass 1 are [sample][chunk][C0][2]: gn_bwd_finalize_kernel's slab
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(groups), dim3(1024), 0, (hipStream_t)stream, (const float*)bnslab, chunks, C0, groups, N,
+                       (double)vox, (const float*)gamma, (const float*)invstd, (float*)dgamma, (float*)dbeta, (float*)bncoef);
+  else
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C0), dim3(256), 0, (hipStream_t)stream, (const float*)bnslab, chunks * N, C0,
+                       (double)N * (double)vox, (const float*)gamma, (const float*)invstd, (float*)dgamma, (float*)dbeta, (float*)bncoef);
   dim3 g2((unsigned)((vox + 511) / 512), C0 / 8, N);
-#define HBA(TT, PLN) switch (ncls) { case 2: hipLaunchKernelGGL((head_bn_apply_kernel<TT, 2, PLN>), g2, dim3(256), 0, (hipStream_t)stream, p); break; \
-    case 3: hipLaunchKernelGGL((head_bn_apply_kernel<TT, 3, PLN>), g2, dim3(256), 0, (hipStream_t)stream, p); break; \
-    default: hipLaunchKernelGGL((head_bn_apply_kernel<TT, 4, PLN>), g2, dim3(256), 0, (hipStream_t)stream, p); break; }
-  if (dtype == 0) { if (C0 == 32) { HBA(f16, 4) } else { HBA(f16, 8) } } else { if (C0 == 32) { HBA(bf16, 4) } else { HBA(bf16, 8) } }
+#define HBA(TT, PLN, GNV) switch (ncls) { case 2: hipLaunchKernelGGL((head_bn_apply_kernel<TT, 2, PLN, GNV>), g2, dim3(256), 0, (hipStream_t)stream, p); break; \
+    case 3: hipLaunchKernelGGL((head_bn_apply_kernel<TT, 3, PLN, GNV>), g2, dim3(256), 0, (hipStream_t)stream, p); break; \
+    default: hipLaunchKernelGGL((head_bn_apply_kernel<TT, 4, PLN, GNV>), g2, dim3(256), 0, (hipStream_t)stream, p); break; }
+#define HBA2(TT, PLN) if (groups > 0) { HBA(TT, PLN, true) } else { HBA(TT, PLN, false) }
+  if (dtype == 0) { if (C0 == 32) { HBA2(f16, 4) } else { HBA2(f16, 8) } } else { if (C0 == 32) { HBA2(bf16, 4) } else { HBA2(bf16, 8) } }
+#undef HBA2
 #undef HBA
   IUNET_CHECK_HIP(hipGetLastError());
   return IUNET_OK;
+}
+int iunet_head_bn_bwd(int dtype, const void* y, long long y_ss, int C0, const void* w, const void* bias, int ncls, const void* target,
+                      const void* weight, int tdtype, const void* coef, float loss_scale, const void* state, const void* scale,
+                      const void* shift, const void* mean, const void* invstd, const void* gamma, void* dgamma, void* dbeta, void* dy,
+                      long long dy_ss, void* dwslab, void* bnslab, void* bncoef, void* dl_scratch, int N, long long vox, void* stream) {
+  return head_norm_bwd_impl(dtype, y, y_ss, C0, w, bias, ncls, target, weight, tdtype, coef, loss_scale, state, scale, shift, mean, invstd, gamma, dgamma,
+                            dbeta, dy, dy_ss, dwslab, bnslab, bncoef, dl_scratch, N, vox, stream, 0);
+}
+/* the GroupNorm form: scale / shift / mean / invstd are [N][C0] rows, bncoef N * C0 * 3 floats (iunet_gn_relu_bwd's), C0 <= 1024 / groups as there */
+int iunet_head_gn_bwd(int dtype, const void* y, long long y_ss, int C0, const void* w, const void* bias, int ncls, const void* target,
+                      const void* weight, int tdtype, const void* coef, float loss_scale, const void* state, const void* scale,
+                      const void* shift, const void* mean, const void* invstd, const void* gamma, int groups, void* dgamma, void* dbeta, void* dy,
+                      long long dy_ss, void* dwslab, void* bnslab, void* bncoef, void* dl_scratch, int N, long long vox, void* stream) {
+  IUNET_REQUIRE(groups > 0 && C0 % groups == 0, "head_gn_bwd: %d channels do not split into %d groups", C0, groups);
+  return head_norm_bwd_impl(dtype, y, y_ss, C0, w, bias, ncls, target, weight, tdtype, coef, loss_scale, state, scale, shift, mean, invstd, gamma, dgamma,
+                            dbeta, dy, dy_ss, dwslab, bnslab, bncoef, dl_scratch, N, vox, stream, groups);
 }
 /* dW [ncls][C0], db [ncls] of the head from the reduced slab row of iunet_head_loss_bwd */
 int iunet_head_grad_scatter(const void* row, void* dw, void* db, int ncls, int C0, void* stream) {

@@ -208,6 +208,10 @@ _SIGS = {
                             c_void_p, c_float, c_void_p, c_ll, c_void_p, c_int, c_ll, c_void_p],
     'iunet_head_loss_fwd_act': [c_int, c_void_p, c_ll, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int,
                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_ll, c_void_p],
+    'iunet_head_loss_fwd_act_ps': [c_int, c_void_p, c_ll, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int,
+                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_ll, c_void_p],
+    'iunet_head_gn_bwd': [c_int, c_void_p, c_ll, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_float, c_void_p, c_void_p,
+                          c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_ll, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_ll, c_void_p],
     'iunet_head_loss_bwd_act': [c_int, c_void_p, c_ll, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int,
                                 c_void_p, c_float, c_void_p, c_ll, c_void_p, c_void_p, c_void_p, c_int, c_ll, c_void_p],
     'iunet_reduce_slab': [c_void_p, c_int, c_ll, c_void_p, c_float, c_int, c_void_p],

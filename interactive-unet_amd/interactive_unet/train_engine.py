@@ -72,6 +72,10 @@ class TrainEngine:
         # head backward + the last conv's BatchNorm backward in two passes over its raw output (iunet_head_bn_bwd; IUNET_NO_HEAD_BN_FUSION=1:
         # the three-kernel sequence with the head's input gradient written and read back)
         self.head_bn = self.head_act and not os.environ.get('IUNET_NO_HEAD_BN_FUSION')
+        # GroupNorm: the head reads the last conv's raw output with per-sample rows and its backward runs as iunet_head_gn_bwd (the last
+        # activation and the head's input gradient are never written) -- only in that fused form (32 / 64 head channels, 2..4 classes)
+        self.gn_head = (self.gn and not os.environ.get('IUNET_NO_HEAD_ACT') and not os.environ.get('IUNET_NO_HEAD_BN_FUSION')
+                        and bool(nv.lib().iunet_head_bn_bwd_ok(self.ch[0], self.ncls)))
         self._bw_ready = {}
         self._flatten()
         if self.pg is not None:
@@ -375,7 +379,7 @@ class TrainEngine:
                                  z1p, ch[l] * v, N)
             # the last stage's activation is read by the head only: with head_act the head kernels apply its BatchNorm + ReLU
             # while loading the raw conv output (iunet_head_loss_fwd_act / _bwd_act) and the tensor is never written
-            z2 = None if (l == 0 and self.head_act) else self._P(ws[f'z.dec{l}.conv2'])
+            z2 = None if (l == 0 and (self.head_act or self.gn_head)) else self._P(ws[f'z.dec{l}.conv2'])
             self._stage_conv_fwd(ws, f'dec{l}.conv2', x2, ch[l] * v, ch[l], ch[l], l, z2, ch[l] * v, N, x_act=act)
         return ws
 
@@ -390,11 +394,11 @@ class TrainEngine:
             nv.call('iunet_head_loss_fwd', self.dt, self._P(feat), self.ch[0] * vox, self.ch[0], nv.ptr(hw),
                     nv.ptr(self.p('head.bias')), self.ncls, nv.ptr(y), nv.ptr(w), tdt, self.kind, nv.ptr(ws['lslab']),
                     nv.ptr(ws['out4']), nv.ptr(ws['coef']), N, vox, nv.stream())
-        else:
-            nv.call('iunet_head_loss_fwd_act', self.dt, self._P(feat), self.ch[0] * vox, self.ch[0], nv.ptr(hw),
+        else:      # (GroupNorm: scale / shift are per-sample rows)
+            nv.call('iunet_head_loss_fwd_act_ps', self.dt, self._P(feat), self.ch[0] * vox, self.ch[0], nv.ptr(hw),
                     nv.ptr(self.p('head.bias')), self.ncls, nv.ptr(y), nv.ptr(w), tdt, self.kind, nv.ptr(ws['lslab']),
                     nv.ptr(ws['out4']), nv.ptr(ws['coef']), nv.ptr(ws['scale.' + act]), nv.ptr(ws['shift.' + act]),
-                    N, vox, nv.stream())
+                    int(self.gn), N, vox, nv.stream())
         return tdt, w
 
     # ------------------------------------------------------------------ backward
@@ -497,7 +501,15 @@ class TrainEngine:
         dfeat = ws['dz.dec0.conv2']
         nparts = nv.lib().iunet_head_loss_bwd_num_parts(N, v0, self.ncls, ch[0])
         dy_ready = None
-        if self.head_bn and nv.lib().iunet_head_bn_bwd_ok(ch[0], self.ncls):
+        if self.gn_head:
+            bn = 'dec0.bn2'
+            nv.call('iunet_head_gn_bwd', self.dt, self._P(ws['y.dec0.conv2']), ch[0] * v0, ch[0], nv.ptr(self.p('head.weight')),
+                    nv.ptr(self.p('head.bias')), self.ncls, nv.ptr(y), nv.ptr(w), tdt, nv.ptr(ws['coef']), 0.0, nv.ptr(self.state),
+                    nv.ptr(ws['scale.dec0.conv2']), nv.ptr(ws['shift.dec0.conv2']), nv.ptr(ws['mean.dec0.conv2']), nv.ptr(ws['invstd.dec0.conv2']),
+                    nv.ptr(self.p(bn + '.weight')), self.groups, nv.ptr(self.g(bn + '.weight')), nv.ptr(self.g(bn + '.bias')), self._P(ws['dy']), ch[0] * v0,
+                    nv.ptr(ws['hslab']), nv.ptr(ws['bnslab']), nv.ptr(ws['bncoef']), self._P(dfeat), N, v0, s)
+            dy_ready = 'dec0.conv2'
+        elif self.head_bn and nv.lib().iunet_head_bn_bwd_ok(ch[0], self.ncls):
             # head backward + BatchNorm backward of dec0.conv2 in two passes over its raw output: the head's input gradient is never written
             bn = 'dec0.bn2'
             nv.call('iunet_head_bn_bwd', self.dt, self._P(ws['y.dec0.conv2']), ch[0] * v0, ch[0], nv.ptr(self.p('head.weight')),
@@ -621,7 +633,7 @@ class TrainEngine:
         else:
             self._refresh()
             ws = self.forward_train(X, xs, N, D, H, W)
-            if self.head_act:
+            if self.head_act or self.gn_head:
                 tdt, w = self.loss_forward(ws, ws['y.dec0.conv2'], y, w, N, vox, act='dec0.conv2')
             else:
                 tdt, w = self.loss_forward(ws, ws['z.dec0.conv2'], y, w, N, vox)
@@ -687,7 +699,7 @@ class TrainEngine:
         self._refresh()
         X, y, w, N, D, H, W, vox, xs = self._prep(X, y, w)
         ws = self.forward_train(X, xs, N, D, H, W)
-        if self.head_act:
+        if self.head_act or self.gn_head:
             tdt, w = self.loss_forward(ws, ws['y.dec0.conv2'], y, w, N, vox, act='dec0.conv2')
         else:
             tdt, w = self.loss_forward(ws, ws['z.dec0.conv2'], y, w, N, vox)
