@@ -616,6 +616,32 @@ def test_head_and_batchnorm_backward_in_two_passes(nv, ncls, T, weighted, C0):
         assert (a - bb).abs().max().item() <= 1e-4 * a.abs().max().item() + 1e-7, ((a - bb).abs().max().item(), a.abs().max().item())
 
 
+@pytest.mark.parametrize('nparts', [1, 37, 300, 2048, 8192, 8195])
+def test_bn_finalize_over_many_rows(nv, nparts):
+    """iunet_bn_finalize on slabs of 1 .. 8 195 rows (the first conv writes one row per TILE: 8 192 at 2 x 128^3; from 2 048 rows on the
+    kernel runs on 1 024 threads) against float64: scale / shift / mean / invstd and the running statistics."""
+    g = torch.Generator().manual_seed(43)
+    C, count, eps, mom = 32, 4096.0 * nparts, 1e-5, 0.1
+    s1 = torch.randn((nparts, C), generator=g) * 10 + 3.0 * 4096
+    s2 = s1 * s1 / 4096 + 4096 * (0.5 + torch.rand((nparts, C), generator=g))          # sum of squares >= (sum)^2 / n per row
+    slab = torch.stack([s1, s2], 2).contiguous().cuda()
+    gamma, beta = (0.5 + torch.rand(C, generator=g)), 0.2 * torch.randn(C, generator=g)
+    rm, rv = torch.zeros(C).cuda(), torch.ones(C).cuda()
+    out = [torch.empty(C, device='cuda') for _ in range(4)]
+    gd, bd = gamma.cuda(), beta.cuda()                                # (kept alive over the launch)
+    nv.call('iunet_bn_finalize', nv.ptr(slab), nparts, C, count, nv.ptr(gd), nv.ptr(bd), nv.ptr(rm), nv.ptr(rv), mom, eps,
+            *[nv.ptr(t) for t in out], nv.stream())
+    torch.cuda.synchronize()
+    mean = slab[..., 0].double().sum(0).cpu() / count
+    var = (slab[..., 1].double().sum(0).cpu() / count - mean * mean).clamp(min=0)
+    invstd = 1.0 / torch.sqrt(var + eps)
+    want = [gamma.double() * invstd, beta.double() - mean * gamma.double() * invstd, mean, invstd]
+    for got, w in zip(out, want):
+        assert (got.cpu().double() - w).abs().max().item() <= 2e-6 * max(1.0, w.abs().max().item())
+    assert (rm.cpu().double() - mom * mean).abs().max().item() <= 1e-6 * max(1.0, mean.abs().max().item())
+    assert (rv.cpu().double() - ((1 - mom) + mom * var * count / (count - 1))).abs().max().item() <= 1e-5 * max(1.0, var.max().item())
+
+
 @pytest.mark.parametrize('nd', [2, 3])
 def test_bn_relu_pool_fwd_equals_two_passes(nv, nd):
     """iunet_bn_relu_pool_fwd == iunet_bn_relu_fwd followed by iunet_maxpool_fwd, bit for bit (both outputs)."""
