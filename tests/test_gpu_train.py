@@ -322,6 +322,35 @@ def test_adamw_matches_torch(nv):
     assert torch.allclose(pd.cpu(), ref.detach(), rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize('n', [10007, 4096, 3])
+def test_adamw_on_the_device_state_matches_torch(nv, n):
+    """iunet_adamw_step_dev (the training handle's optimiser step: loss scale, step count and bias corrections live in an 8-word device
+    state; four parameters per thread, a scalar tail) against torch.optim.AdamW over three steps, with n not a multiple of four too."""
+    g = torch.Generator().manual_seed(19)
+    p = torch.randn(n, generator=g)
+    ref = torch.nn.Parameter(p.clone())
+    opt = torch.optim.AdamW([ref], lr=1e-3)
+    pd = p.cuda()
+    m, v = torch.zeros(n, device='cuda'), torch.zeros(n, device='cuda')
+    state = torch.zeros(8, device='cuda')
+    state[0] = 8.0                                                     # loss scale; words 1..3, 7 are integers (zero: step 0, fixed scale)
+    for step in range(3):
+        gr = torch.randn(n, generator=g)
+        ref.grad = gr.clone()
+        opt.step()
+        gd = (gr * 8.0).cuda()
+        nv.call('iunet_adamw_step_dev', nv.ptr(pd), nv.ptr(gd), nv.ptr(m), nv.ptr(v), n, 1e-3, 0.9, 0.999, 1e-8, 1e-2, nv.ptr(state), 1, 1.0,
+                nv.stream())
+    torch.cuda.synchronize()
+    assert torch.allclose(pd.cpu(), ref.detach(), rtol=1e-5, atol=1e-6)
+    assert state.view(torch.int32)[1].item() == 3 and state.view(torch.int32)[3].item() == 0
+    gd = torch.full((n,), float('inf'), device='cuda')                 # an overflowing gradient: the step is skipped and not counted
+    before = pd.clone()
+    nv.call('iunet_adamw_step_dev', nv.ptr(pd), nv.ptr(gd), nv.ptr(m), nv.ptr(v), n, 1e-3, 0.9, 0.999, 1e-8, 1e-2, nv.ptr(state), 1, 1.0, nv.stream())
+    torch.cuda.synchronize()
+    assert torch.equal(pd, before) and state.view(torch.int32)[1].item() == 3
+
+
 @pytest.mark.parametrize('dim,shape,dtype', [(2, (64, 96), 'fp16'), (3, (16, 32, 32), 'bf16')])
 def test_full_train_step_vs_autograd(dim, shape, dtype):
     """One native optimisation step (BatchNorm batch statistics, MCC+CE loss, backward, AdamW)
