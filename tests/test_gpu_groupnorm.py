@@ -177,6 +177,60 @@ def test_groupnorm_training_with_conv_epilogue_statistics(monkeypatch, dim, shap
     assert all(abs(a - b) <= 5e-3 for a, b in zip(r0, r1)) and r0[-1] < l0
 
 
+@pytest.mark.parametrize('ncls,T,C0', [(2, torch.bfloat16, 32), (3, torch.float16, 32), (4, torch.bfloat16, 64)])
+def test_head_and_groupnorm_backward_in_two_passes(nv, ncls, T, C0):
+    """iunet_head_gn_bwd (head backward + the last conv's GroupNorm + ReLU backward in two passes over that conv's raw output, per-sample
+    parameter rows) against the sequence on materialised tensors: iunet_gn_relu_fwd -> iunet_head_loss_bwd -> iunet_gn_relu_bwd."""
+    g = torch.Generator().manual_seed(47)
+    dt = nv.DTYPE_CODE[T]
+    N, vox, groups = 3, 4500, 8
+    y = torch.randn((N, C0, vox), generator=g) * torch.tensor([0.7, 1.0, 1.6]).view(N, 1, 1) + torch.tensor([0.2, -0.1, 0.4]).view(N, 1, 1)
+    yb = blocked(y, T).cuda()
+    w = (torch.randn(ncls, C0, generator=g) * 0.3).cuda()
+    b = (torch.randn(ncls, generator=g) * 0.1).cuda()
+    lab = torch.randint(0, ncls, (N, vox), generator=g)
+    tgt = torch.stack([(lab == c) for c in range(ncls)], 1).to(torch.float16).contiguous().cuda()
+    wt = (torch.rand((N, ncls, vox), generator=g) > 0.2).to(torch.float16).contiguous().cuda()
+    gamma, beta = (0.5 + torch.rand(C0, generator=g)).cuda(), (0.2 * torch.randn(C0, generator=g)).cuda()
+    coef = torch.tensor([[-0.8e-4, 1.9e-4, 1.1e-4], [0.5e-4, -1.2e-4, 0.9e-4], [0.2e-4, 0.7e-4, 1.0e-4], [-0.3e-4, 0.4e-4, 0.6e-4]])[:ncls].contiguous().cuda()
+    s = nv.stream()
+    parts = nv.lib().iunet_head_loss_bwd_num_parts(N, vox, ncls, C0)
+    z = torch.empty_like(yb)
+    par = [torch.empty(N * C0, device='cuda') for _ in range(4)]          # scale, shift, mean, invstd rows
+    slab = torch.empty(nv.lib().iunet_gn_num_parts(N, vox) * C0 * 2, device='cuda')
+    nv.call('iunet_gn_relu_fwd', dt, nv.ptr(yb), C0 * vox, nv.ptr(z), C0 * vox, nv.ptr(gamma), nv.ptr(beta), groups, 1e-5, nv.ptr(slab),
+            *[nv.ptr(t) for t in par], C0, N, vox, s)
+    out = []
+    for fused in (False, True):
+        dy = torch.full((N * C0 * vox,), float('nan'), dtype=T, device='cuda')
+        hslab = torch.full((parts * ncls * (C0 + 1),), float('nan'), device='cuda')
+        bnslab = torch.full((parts * C0 * 2,), float('nan'), device='cuda')
+        bncoef = torch.empty(3 * C0 * N, device='cuda')
+        dgam, dbet = torch.empty(C0, device='cuda'), torch.empty(C0, device='cuda')
+        dz = torch.full((N * C0 * vox,), float('nan'), dtype=T, device='cuda')      # fused: its scratch
+        if fused:
+            nv.call('iunet_head_gn_bwd', dt, nv.ptr(yb), C0 * vox, C0, nv.ptr(w), nv.ptr(b), ncls, nv.ptr(tgt), nv.ptr(wt), 1, nv.ptr(coef), 512.0, None,
+                    *[nv.ptr(t) for t in par], nv.ptr(gamma), groups, nv.ptr(dgam), nv.ptr(dbet), nv.ptr(dy), C0 * vox, nv.ptr(hslab), nv.ptr(bnslab),
+                    nv.ptr(bncoef), nv.ptr(dz), N, vox, s)
+        else:
+            nv.call('iunet_head_loss_bwd', dt, nv.ptr(z), C0 * vox, C0, nv.ptr(w), nv.ptr(b), ncls, nv.ptr(tgt), nv.ptr(wt), 1, nv.ptr(coef), 512.0,
+                    nv.ptr(dz), C0 * vox, nv.ptr(hslab), N, vox, s)
+            nv.call('iunet_gn_relu_bwd', dt, nv.ptr(dz), C0 * vox, nv.ptr(yb), C0 * vox, nv.ptr(dy), C0 * vox, nv.ptr(gamma), groups, *[nv.ptr(t) for t in par],
+                    nv.ptr(dgam), nv.ptr(dbet), nv.ptr(bnslab), nv.ptr(bncoef), C0, N, vox, s)
+        hrow = torch.empty(ncls * (C0 + 1), device='cuda')
+        nv.call('iunet_reduce_slab', nv.ptr(hslab), parts, ncls * (C0 + 1), nv.ptr(hrow), 1.0, 0, s)
+        torch.cuda.synchronize()
+        out.append((dy.float().cpu(), hrow.cpu(), dgam.cpu(), dbet.cpu()))
+    (dy0, h0, dg0, db0), (dy1, h1, dg1, db1) = out
+    assert torch.isfinite(dy1).all() and dy0.abs().max() > 0
+    ulp = 2.0 ** (-7 if T == torch.bfloat16 else -10)
+    d = (dy0 - dy1).abs()
+    tol = 2 * ulp * torch.maximum(dy0.abs(), dy1.abs()) + 2e-3 * dy0.abs().max()       # (dy = a d - c1 - xhat c2: the terms cancel, so absolute to the tensor's scale too)
+    assert (d > tol).float().mean().item() < 1e-4, ((d > tol).float().mean().item(), d.max().item(), dy0.abs().max().item())
+    for a, bb in ((h0, h1), (dg0, dg1), (db0, db1)):
+        assert (a - bb).abs().max().item() <= 2e-4 * a.abs().max().item() + 1e-7, ((a - bb).abs().max().item(), a.abs().max().item())
+
+
 @pytest.mark.parametrize('dtype,nd,N,C,groups,do', [(torch.bfloat16, 3, 2, 32, 8, (3, 5, 6)), (torch.float16, 2, 3, 64, 8, (1, 20, 17)), (torch.bfloat16, 3, 1, 128, 8, (2, 2, 4))])
 def test_gn_pooled_forward_and_backward_equal_the_unfused_sequences(nv, dtype, nd, N, C, groups, do):
     """iunet_gn_relu_pool_fwd = iunet_gn_relu_fwd + iunet_maxpool_fwd and iunet_gn_relu_pool_bwd = iunet_maxpool_bwd (add_skip) +
