@@ -537,6 +537,48 @@ def test_dgrad_with_fused_batchnorm_backward_sums(nv, nd, cin, lay):
     assert (zz > 0).double().mean() > 0.2 and (zz > 0).double().mean() < 0.8
 
 
+@pytest.mark.parametrize('nd,ch,lay,shape', [(3, 32, 2, (64, 64, 64)), (3, 64, 2, (32, 64, 64)), (2, 32, 3, (256, 512)), (2, 64, 3, (256, 256))])
+def test_dgrad_with_per_sample_fused_sums(nv, nd, ch, lay, shape):
+    """iunet_conv3_dgrad_sample_bnstats (GroupNorm training: the data gradient whose epilogue accumulates the backward sums of the layer its
+    output flows into, with that layer's PER-SAMPLE mean / invstd / scale / shift rows, the samples along the grid's z): dz equals the plain
+    launch bit for bit, the rows [N][rows][C][2] sum to each sample's (sum dz', sum dz' xhat) of the stored tensors."""
+    g = torch.Generator().manual_seed(37)
+    T, dt = torch.bfloat16, 1
+    N = 2
+    D, H, W = shape if nd == 3 else (1,) + shape
+    taps, vox = 3 ** nd, D * H * W
+    rows = nv.lib().iunet_conv3_sample_stats_rows(dt, nd, N, D, H, W, ch, ch, lay)
+    assert rows > 0
+    dy = torch.randn((N, ch) + shape, generator=g)
+    yp = torch.randn((N, ch) + shape, generator=g) * torch.tensor([0.8, 1.5]).view(N, 1, *([1] * nd))
+    w = (torch.randn((ch, ch) + (3,) * nd, generator=g) * 0.05).cuda()
+    par = [(0.2 * torch.randn(N, ch, generator=g)).cuda(), (0.5 + torch.rand(N, ch, generator=g)).cuda(),
+           (0.5 + torch.rand(N, ch, generator=g)).cuda(), (0.3 * torch.randn(N, ch, generator=g)).cuda()]      # mean, invstd, scale, shift rows
+    dyb, ypb = blocked(dy, T).cuda(), blocked(yp, T).cuda()
+    s = nv.stream()
+    pm = 6 if lay == 3 else 2
+    wpk = torch.empty(nv.pack_conv3_elems(ch, ch, taps, pm), dtype=T, device='cuda')
+    nv.call('iunet_pack_conv3', dt, nv.ptr(w), None, nv.ptr(wpk), ch, ch, taps, pm, s)
+    dz = [torch.full((N * ch * vox,), float('nan'), dtype=T, device='cuda') for _ in range(2)]
+    st = torch.full((N * rows * ch * 2,), float('nan'), device='cuda')
+    nv.call('iunet_conv3_fwd', dt, nd, nv.ptr(dyb), ch * vox, nv.ptr(dz[0]), ch * vox, nv.ptr(wpk), None, None, N, D, H, W, ch, ch, 0, lay, s)
+    nv.call('iunet_conv3_dgrad_sample_bnstats', dt, nd, nv.ptr(dyb), ch * vox, nv.ptr(dz[1]), ch * vox, nv.ptr(wpk), nv.ptr(st), nv.ptr(ypb), ch * vox,
+            *[nv.ptr(t) for t in par], N, D, H, W, ch, ch, lay, s)
+    torch.cuda.synchronize()
+    assert torch.equal(dz[0].view(torch.int16), dz[1].view(torch.int16))
+    got = st.view(N, rows, ch, 2).double().sum(1).cpu()
+    dzf = unblocked(dz[1].cpu(), N, ch, shape).double()
+    ypf = yp.to(T).double()
+    bc = lambda v: v.cpu().double().view(N, ch, *([1] * nd))
+    mean, invstd, scale, shift = [bc(t) for t in par]
+    zz = (scale * ypf + shift).float().to(T).float()
+    d = torch.where(zz > 0, dzf, torch.zeros_like(dzf))
+    red = tuple(range(2, nd + 2))
+    want = torch.stack([d.sum(red), (d * (ypf - mean) * invstd).sum(red)], 2)
+    size = torch.stack([d.abs().sum(red), (d * (ypf - mean) * invstd).abs().sum(red)], 2)
+    assert ((got - want).abs() <= 2e-5 * size + 1e-6).all(), ((got - want).abs() / size).max().item()
+
+
 @pytest.mark.parametrize('nd,cin,cout,lay,shape', [(3, 32, 32, 2, (64, 64, 64)), (3, 64, 32, 3, (64, 64, 64)), (3, 64, 64, 3, (32, 64, 64)),
                                                     (2, 32, 32, 3, (256, 512)), (2, 128, 64, 3, (256, 256))])       # >= 8 bricks per sample
 def test_conv_with_per_sample_statistics(nv, nd, cin, cout, lay, shape):
